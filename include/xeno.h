@@ -1,0 +1,160 @@
+/* xeno.h — C-ABI of libxeno_hip.so, the MI355X batched environment-step engine.
+ *
+ * The reference (FutureAGI/Xenoverse) is pure Python and has no FFI: its boundary for this path is the
+ * duck-typed trio  env.set_task(task_dict) -> env.reset() -> env.step(action)  on one environment
+ * object per instance.  This header is the batched C form of that trio: one handle
+ * holds N environment instances of one family, `*_create` is `set_task` for the whole batch, `*_reset`
+ * and `*_step` advance all N at once on the GPU.  Each entry point cites the reference lines whose
+ * results it reproduces.  The Python classes in xenoverse_amd/ bind these symbols with ctypes and put
+ * the gymnasium VectorEnv surface on top (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *  - every symbol is extern "C"; no C++ or torch type crosses the boundary;
+ *  - return value 0 = XV_OK, negative = error; text via xv_last_error() (thread-local);
+ *  - every array argument is a CALLER-OWNED DEVICE pointer (e.g. a PyTorch-ROCm tensor's data_ptr())
+ *    that must stay alive until the handle is destroyed (task tables) or the call's work has completed
+ *    on the stream (per-step arrays).  Table pointers are borrowed, not copied: 32 GiB of transition
+ *    tables are never duplicated;
+ *  - every call is asynchronous and ordered on the engine's HIP stream; the caller synchronises
+ *    (xv_engine_sync, or its own stream/event);
+ *  - a handle is not thread-safe; distinct engines are independent (there is no global RNG state,
+ *    unlike the reference's process-wide numpy.random stream);
+ *  - device-side range errors (action out of range, stepping a terminated env with auto-reset off)
+ *    do not trap: they set bits in a sticky per-engine error word read with xv_engine_error_flags.
+ */
+#ifndef XENO_H_
+#define XENO_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XV_ABI_VERSION 1
+
+/* return codes */
+#define XV_OK 0
+#define XV_ERR_INVALID (-1)  /* bad argument (null pointer, size out of the supported range) */
+#define XV_ERR_HIP (-2)      /* a HIP runtime call failed; xv_last_error() has hipGetErrorString */
+#define XV_ERR_UNSUPPORTED (-3)
+#define XV_ERR_NOMEM (-4)
+
+/* auto-reset modes (gymnasium >= 1.1 AutoresetMode).  The reference never
+ * auto-resets, which is XV_AUTORESET_DISABLED. */
+#define XV_AUTORESET_DISABLED 0
+#define XV_AUTORESET_NEXT_STEP 1
+#define XV_AUTORESET_SAME_STEP 2
+
+/* sticky device error bits (xv_engine_error_flags) */
+#define XV_DEVERR_ACTION_RANGE 1u   /* reference: `assert action < self.na` (anymdp_env.py:97) */
+#define XV_DEVERR_STEP_TERMINAL 2u  /* reference: raise "given an terminated state" (anymdp_env.py:95-96) */
+#define XV_DEVERR_NONFINITE 4u      /* a float state left the finite range */
+
+typedef struct xv_engine xv_engine;
+typedef struct xv_anymdp xv_anymdp;
+typedef struct xv_linds xv_linds;
+typedef struct xv_cartpole xv_cartpole;
+typedef struct xv_maze xv_maze;
+
+/* ------------------------------------------------------------------------------------------------
+ * engine: one device + one stream + one Philox key
+ * ---------------------------------------------------------------------------------------------- */
+int xv_abi_version(void);
+const char* xv_last_error(void);
+
+/* `hip_stream` is a hipStream_t (NULL = the engine creates its own non-blocking stream).
+ * `seed` is the Philox4x32-10 key; `env_id_base` is added to the local env index to form the counter's
+ * env word, so that a batch sharded over ranks draws the same numbers as the unsharded batch
+ * (SURVEY.md §8(e)).  Replaces the reference's per-reset reseeding of numpy's global RandomState from
+ * OS entropy (anymdp_env.py:87, linds_env.py:114, utils/random_nn.py:9-16). */
+int xv_engine_create(int device, uint64_t seed, uint64_t env_id_base, void* hip_stream, xv_engine** out);
+int xv_engine_destroy(xv_engine* e);
+int xv_engine_sync(xv_engine* e);
+void* xv_engine_stream(xv_engine* e);
+/* reads (and with clear!=0 resets) the sticky device error word; synchronises the stream */
+int xv_engine_error_flags(xv_engine* e, int clear, uint32_t* out_flags);
+/* the launch counter that forms the Philox counter's tick word; get/set makes runs resumable */
+int xv_engine_get_tick(xv_engine* e, uint64_t* out_tick);
+int xv_engine_set_tick(xv_engine* e, uint64_t tick);
+
+/* Philox4x32-10 known-answer hook: fills out[4*n] on the device from ctr[4*n], key[2] (device ptrs). */
+int xv_philox4x32_10(xv_engine* e, const uint32_t* ctr, const uint32_t* key, uint32_t* out, int n);
+
+/* ------------------------------------------------------------------------------------------------
+ * AnyMDP — reference: xenoverse/anymdp/anymdp_env.py
+ *   set_task  :32-79   -> xv_anymdp_create   (tables prepared host-side: see xenoverse_amd/anymdp)
+ *   reset     :81-90   -> xv_anymdp_reset
+ *   step      :112-132 -> xv_anymdp_step / _step_injected   (single_step :92-110, get_observation :145-159)
+ *
+ * Table layout (all row-major, device memory, borrowed):
+ *   cdf        double [n_task][S][A][S]   inclusive CDF of transition[s,a,:], i.e. cumsum(row)/cumsum(row)[-1]
+ *                                         computed on the host in fp64 exactly as numpy.random.choice does
+ *                                         (rows of terminal states, all-zero in the reference, hold 1.0)
+ *   rs         float2 [n_task][S][A][S]   {reward[s,a,s'], reward_noise[s,a,s']} interleaved
+ *   state_map  int32  [n_task][S]         inner state -> observation id (task["state_mapping"])
+ *   term_mask  uint64 [n_task][(S+63)/64] bit s set <=> s in task["s_e"]
+ *   s0_cdf     double [n_task][s0_max]    inclusive CDF of task["s_0_prob"] (padded with 1.0)
+ *   s0_ids     int32  [n_task][s0_max]    task["s_0"] (padded by repeating the last id)
+ *   max_steps  int32  [n_task]            ceil(task["max_steps"]): `steps >= max_steps` on integer steps
+ *   env_task   int32  [n_env]             env -> task index
+ * Supported: 2 <= S <= 256, 2 <= A <= 64, 1 <= s0_max <= 256.
+ * ---------------------------------------------------------------------------------------------- */
+int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int A, int s0_max,
+                     const double* cdf, const float* rs, const int32_t* state_map,
+                     const uint64_t* term_mask, const double* s0_cdf, const int32_t* s0_ids,
+                     const int32_t* max_steps, const int32_t* env_task, xv_anymdp** out);
+int xv_anymdp_destroy(xv_anymdp* h);
+
+/* reset the envs whose mask byte is non-zero (mask == NULL: all).  obs[n_env] is written for reset
+ * envs only.  Initial state = s0_ids[upper_bound(s0_cdf, u)] (anymdp_env.py:89), u from Philox. */
+int xv_anymdp_reset(xv_anymdp* h, const uint8_t* mask, int32_t* obs);
+/* parity hook: same, with the uniform draw supplied by the caller (u[n_env], fp64 in [0,1)) */
+int xv_anymdp_reset_injected(xv_anymdp* h, const uint8_t* mask, const double* u, int32_t* obs);
+
+/* one vector step.  action[n_env] in; obs, reward, reward_gt (info["reward_gt"]), terminated,
+ * truncated out; final_obs (nullable) receives the pre-reset observation for SAME_STEP.
+ *   steps += 1; truncated = steps >= max_steps                      (anymdp_env.py:113-114)
+ *   s' = upper_bound(cdf[s,a,:], u)  == numpy.random.choice(n, p=T[s,a])   (:99-100)
+ *   r_gt = R[s,a,s'];  r = r_gt + sigma[s,a,s'] * z                  (:103-105)
+ *   terminated = s' in s_e                                           (:107-108)
+ *   obs = state_mapping[s']                                          (:146-148)
+ * u is a 53-bit uniform built from two Philox words exactly as numpy's random_sample builds it from two
+ * MT19937 words; z is a Box-Muller normal from the other two words. */
+int xv_anymdp_step(xv_anymdp* h, const int32_t* action, int32_t* obs, float* reward, float* reward_gt,
+                   uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int autoreset_mode);
+/* parity hook: the three random inputs are supplied per env: u[n_env] fp64 (transition draw),
+ * z[n_env] fp32 (standard normal), u_reset[n_env] fp64 (initial-state draw used if the env resets) */
+int xv_anymdp_step_injected(xv_anymdp* h, const int32_t* action, const double* u, const float* z,
+                            const double* u_reset, int32_t* obs, float* reward, float* reward_gt,
+                            uint8_t* terminated, uint8_t* truncated, int32_t* final_obs,
+                            int autoreset_mode);
+
+/* fused rollout: T vector steps in one launch with pre-generated actions[T][n_env] (open-loop / random
+ * policy data collection); outputs are [T][n_env].  Bit-identical to T calls of xv_anymdp_step with
+ * SAME_STEP auto-reset.  final_obs nullable. */
+int xv_anymdp_rollout(xv_anymdp* h, int T, const int32_t* actions, int32_t* obs, float* reward,
+                      float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs);
+
+/* env.inner_state / env.steps accessors (anymdp_env.py:138-143); device int32[n_env] each, nullable */
+int xv_anymdp_get_state(xv_anymdp* h, int32_t* inner_state, int32_t* steps, uint8_t* need_reset);
+int xv_anymdp_set_state(xv_anymdp* h, const int32_t* inner_state, const int32_t* steps,
+                        const uint8_t* need_reset);
+/* info["transition_gt"] = transition_obs[state, action] (anymdp_env.py:130) is a 8*S-byte row per env
+ * and is produced on request only: out[n_env][S] double, the pmf of (current inner state, action[i])
+ * scattered to observation ids. */
+int xv_anymdp_transition_gt(xv_anymdp* h, const int32_t* action, double* out);
+
+/* Synthetic task tables written directly in device memory (bench / stress configs whose tables exceed
+ * host memory: 65,536 distinct tasks of S=64, A=8 are 48 GiB).  Deterministic in (seed, task index);
+ * restated bit-for-bit by oracle/xeno_oracle.c: xo_anymdp_synth.  Band-limited rows as produced by the
+ * reference sampler's sample_transition (task_sampler_utils.py:65-175), uniform weights. */
+int xv_anymdp_synth_tasks(xv_engine* e, uint64_t seed, int64_t task_index_base, int n_task, int S, int A,
+                          int s0_max, double* cdf, float* rs, int32_t* state_map, uint64_t* term_mask,
+                          double* s0_cdf, int32_t* s0_ids, int32_t* max_steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XENO_H_ */

@@ -1,0 +1,171 @@
+"""oracle — CPU restatement of the Xenoverse env-step hot path.  TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.  The product
+(xenoverse_amd) never imports it and has no CPU fallback: without libxeno_hip.so it raises.
+
+Contents
+  xeno_oracle.c/.h   plain-C scalar restatement of each step function, citing the reference file:line
+  Makefile           builds oracle/_build/libxeno_oracle.so (gcc, -ffp-contract=off)
+  gen_golden.py      imports /root/reference (build container only) and writes tests/golden/*.npz
+  stubs/             stand-ins for numba/gymnasium/gym/pygame so that the Python reference imports here
+
+Pinning: tests/test_oracle_*.py check this restatement against every fixture under tests/golden/, which
+were produced by running the reference itself (see gen_golden.py).  There is no pure-CPU product path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libxeno_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("xeno_oracle.c", "xeno_oracle.h", "Makefile")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.xo_u53.restype = C.c_double
+        _lib.xo_upper_bound.restype = C.c_int
+        _lib.xo_max_threads.restype = C.c_int
+    return _lib
+
+
+def _p(a, t=None):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "oracle arrays must be C-contiguous"
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def philox4x32_10(ctr, key):
+    ctr = np.ascontiguousarray(ctr, dtype=np.uint32).reshape(-1, 4)
+    key = np.ascontiguousarray(key, dtype=np.uint32).reshape(2)
+    out = np.empty_like(ctr)
+    for i in range(ctr.shape[0]):
+        lib().xo_philox4x32_10(_p(ctr[i:i + 1]), _p(key), _p(out[i:i + 1]))
+    return out
+
+
+def u53(a, b):
+    return lib().xo_u53(C.c_uint32(int(a)), C.c_uint32(int(b)))
+
+
+def env_draw(seed, gid, tick, purpose):
+    out = np.empty(4, dtype=np.uint32)
+    lib().xo_env_draw(C.c_uint64(seed), C.c_uint64(gid), C.c_uint64(tick), C.c_uint32(purpose), _p(out))
+    return out
+
+
+class _AnyMDPStruct(C.Structure):
+    _fields_ = [("n_env", C.c_int), ("n_task", C.c_int), ("S", C.c_int), ("A", C.c_int),
+                ("s0_max", C.c_int),
+                ("cdf", C.c_void_p), ("rs", C.c_void_p), ("state_map", C.c_void_p),
+                ("term_mask", C.c_void_p), ("s0_cdf", C.c_void_p), ("s0_ids", C.c_void_p),
+                ("max_steps", C.c_void_p), ("env_task", C.c_void_p),
+                ("state", C.c_void_p), ("steps", C.c_void_p), ("need_reset", C.c_void_p),
+                ("err_flags", C.c_uint32)]
+
+
+class AnyMDPOracle(object):
+    """Batched CPU AnyMDP over the device table layout (include/xeno.h).  `tables` is the dict made by
+    xenoverse_amd.anymdp.tables.build_tables (numpy arrays)."""
+
+    def __init__(self, tables, env_task):
+        t = tables
+        self.S, self.A, self.s0_max = int(t["S"]), int(t["A"]), int(t["s0_max"])
+        self.n_task = int(t["cdf"].shape[0])
+        self.env_task = np.ascontiguousarray(env_task, dtype=np.int32)
+        self.n_env = int(self.env_task.shape[0])
+        self._keep = dict(
+            cdf=np.ascontiguousarray(t["cdf"], dtype=np.float64),
+            rs=np.ascontiguousarray(t["rs"], dtype=np.float32),
+            state_map=np.ascontiguousarray(t["state_map"], dtype=np.int32),
+            term_mask=np.ascontiguousarray(t["term_mask"], dtype=np.uint64),
+            s0_cdf=np.ascontiguousarray(t["s0_cdf"], dtype=np.float64),
+            s0_ids=np.ascontiguousarray(t["s0_ids"], dtype=np.int32),
+            max_steps=np.ascontiguousarray(t["max_steps"], dtype=np.int32))
+        self.state = np.zeros(self.n_env, dtype=np.int32)
+        self.steps = np.zeros(self.n_env, dtype=np.int32)
+        self.need_reset = np.ones(self.n_env, dtype=np.uint8)
+        k = self._keep
+        self._h = _AnyMDPStruct(self.n_env, self.n_task, self.S, self.A, self.s0_max,
+                                _p(k["cdf"]), _p(k["rs"]), _p(k["state_map"]), _p(k["term_mask"]),
+                                _p(k["s0_cdf"]), _p(k["s0_ids"]), _p(k["max_steps"]), _p(self.env_task),
+                                _p(self.state), _p(self.steps), _p(self.need_reset), 0)
+
+    @property
+    def err_flags(self):
+        return int(self._h.err_flags)
+
+    def _outs(self):
+        n = self.n_env
+        return (np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.float32),
+                np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.full(n, -1, np.int32))
+
+    def reset_injected(self, u, mask=None):
+        obs = np.full(self.n_env, -1, np.int32)
+        u = np.ascontiguousarray(u, np.float64)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        lib().xo_anymdp_reset_injected(C.byref(self._h), _p(m), _p(u), _p(obs))
+        return obs
+
+    def reset(self, seed, gid_base, tick, mask=None):
+        obs = np.full(self.n_env, -1, np.int32)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        lib().xo_anymdp_reset(C.byref(self._h), C.c_uint64(seed), C.c_uint64(gid_base), C.c_uint64(tick),
+                              _p(m), _p(obs))
+        return obs
+
+    def step_injected(self, action, u, z, u_reset, mode):
+        obs, rew, rgt, term, trunc, fobs = self._outs()
+        a = np.ascontiguousarray(action, np.int32)
+        u = np.ascontiguousarray(u, np.float64)
+        z = np.ascontiguousarray(z, np.float32)
+        ur = np.ascontiguousarray(u_reset, np.float64)
+        lib().xo_anymdp_step_injected(C.byref(self._h), _p(a), _p(u), _p(z), _p(ur), _p(obs), _p(rew),
+                                      _p(rgt), _p(term), _p(trunc), _p(fobs), C.c_int(mode))
+        return obs, rew, rgt, term, trunc, fobs
+
+    def step(self, seed, gid_base, tick, action, mode, n_threads=0):
+        obs, rew, rgt, term, trunc, fobs = self._outs()
+        a = np.ascontiguousarray(action, np.int32)
+        if n_threads and n_threads > 1:
+            lib().xo_anymdp_step_mt(C.byref(self._h), C.c_uint64(seed), C.c_uint64(gid_base),
+                                    C.c_uint64(tick), _p(a), _p(obs), _p(rew), _p(rgt), _p(term),
+                                    _p(trunc), _p(fobs), C.c_int(mode), C.c_int(n_threads))
+        else:
+            lib().xo_anymdp_step(C.byref(self._h), C.c_uint64(seed), C.c_uint64(gid_base),
+                                 C.c_uint64(tick), _p(a), _p(obs), _p(rew), _p(rgt), _p(term), _p(trunc),
+                                 _p(fobs), C.c_int(mode))
+        return obs, rew, rgt, term, trunc, fobs
+
+    def transition_gt(self, action):
+        a = np.ascontiguousarray(action, np.int32)
+        out = np.zeros((self.n_env, self.S), np.float64)
+        lib().xo_anymdp_transition_gt(C.byref(self._h), _p(a), _p(out))
+        return out
+
+
+def anymdp_synth(seed, task_index_base, n_task, S, A, s0_max):
+    """Synthetic task tables (same bits as the device generator xv_anymdp_synth_tasks)."""
+    words = (S + 63) // 64
+    t = dict(S=S, A=A, s0_max=s0_max,
+             cdf=np.empty((n_task, S, A, S), np.float64), rs=np.empty((n_task, S, A, S, 2), np.float32),
+             state_map=np.empty((n_task, S), np.int32), term_mask=np.empty((n_task, words), np.uint64),
+             s0_cdf=np.empty((n_task, s0_max), np.float64), s0_ids=np.empty((n_task, s0_max), np.int32),
+             max_steps=np.empty(n_task, np.int32))
+    lib().xo_anymdp_synth(C.c_uint64(seed), C.c_int64(task_index_base), C.c_int(n_task), C.c_int(S),
+                          C.c_int(A), C.c_int(s0_max), _p(t["cdf"]), _p(t["rs"]), _p(t["state_map"]),
+                          _p(t["term_mask"]), _p(t["s0_cdf"]), _p(t["s0_ids"]), _p(t["max_steps"]))
+    return t

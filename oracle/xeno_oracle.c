@@ -1,0 +1,321 @@
+/* xeno_oracle.c — CPU restatement of the Xenoverse env-step hot path.  TEST INFRASTRUCTURE.
+ *
+ * See xeno_oracle.h for who may use this.  Written from the semantics of the reference (cited per
+ * function as file:line under /root/reference/xenoverse), not from its text: the reference is one Python
+ * object per env with numpy's global RNG; this is a scalar loop over a struct-of-arrays batch with the
+ * random inputs passed in (or drawn from Philox with the device's counter convention).
+ *
+ * Build: oracle/Makefile  (-O2 -ffp-contract=off: no fused multiply-add is formed unless written as
+ * fma()/fmaf(), so float results are reproducible and match the device code, which spells out its FMAs).
+ */
+#include "xeno_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Philox4x32-10 and the draw conventions shared with the device (xenoverse_amd/csrc/philox.h)
+ * ---------------------------------------------------------------------------------------------- */
+void xo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void xo_env_draw(uint64_t seed, uint64_t gid, uint64_t tick, uint32_t purpose, uint32_t out[4]) {
+  uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)tick,
+                     (purpose & 0xFFu) | ((uint32_t)(tick >> 32) << 8)};
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  xo_philox4x32_10(ctr, key, out);
+}
+
+/* numpy legacy random_sample: (a>>5, b>>6) -> 53-bit double */
+double xo_u53(uint32_t a, uint32_t b) {
+  return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
+void xo_box_muller(uint32_t a, uint32_t b, float* z0, float* z1) {
+  double u1 = ((double)(a >> 8) + 1.0) * (1.0 / 16777216.0); /* (0,1] */
+  double u2 = (double)(b >> 8) * (1.0 / 16777216.0);         /* [0,1) */
+  double r = sqrt(-2.0 * log(u1));
+  double ang = 6.283185307179586476925286766559 * u2;
+  if (z0) *z0 = (float)(r * cos(ang));
+  if (z1) *z1 = (float)(r * sin(ang));
+}
+
+int xo_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * AnyMDP — reference: anymdp/anymdp_env.py
+ * ---------------------------------------------------------------------------------------------- */
+
+/* numpy.random.choice(n, p=row) == searchsorted(cdf, u, side='right') on cdf = cumsum(row)/cumsum(row)[-1]
+ * (anymdp_env.py:89,100; pinned by probe).  Clamp mirrors the device, which cannot
+ * index past the row; with a valid CDF (last entry 1.0 > u) the clamp is never taken. */
+int xo_upper_bound(const double* cdf, int n, double u) {
+  int j = 0;
+  while (j < n && cdf[j] <= u) ++j;
+  return j < n ? j : n - 1;
+}
+
+static inline int is_terminal(const xo_anymdp* h, int t, int s) {
+  int words = (h->S + 63) / 64;
+  return (int)((h->term_mask[(size_t)t * words + (s >> 6)] >> (s & 63)) & 1u);
+}
+
+/* reset: anymdp_env.py:81-90.  steps = 0; _state = choice(s_0, p=s_0_prob); returns observation */
+static inline void anymdp_reset_one(xo_anymdp* h, int i, double u, int32_t* obs) {
+  int t = h->env_task[i];
+  int k = xo_upper_bound(h->s0_cdf + (size_t)t * h->s0_max, h->s0_max, u);
+  int s = h->s0_ids[(size_t)t * h->s0_max + k];
+  h->state[i] = s;
+  h->steps[i] = 0;
+  h->need_reset[i] = 0;
+  if (obs) obs[i] = h->state_map[(size_t)t * h->S + s]; /* get_observation, MDP: :146-148 */
+}
+
+void xo_anymdp_reset_injected(xo_anymdp* h, const uint8_t* mask, const double* u, int32_t* obs) {
+  for (int i = 0; i < h->n_env; ++i)
+    if (!mask || mask[i]) anymdp_reset_one(h, i, u[i], obs);
+}
+
+/* step: anymdp_env.py:112-132 with single_step :92-110 inlined. */
+static inline void anymdp_step_one(xo_anymdp* h, int i, int a_in, double u, float z, double u_reset,
+                                   int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated,
+                                   uint8_t* truncated, int32_t* final_obs, int mode, uint32_t* err) {
+  const int S = h->S, A = h->A;
+  const int t = h->env_task[i];
+  int s = h->state[i];
+  if (final_obs) final_obs[i] = -1;
+  if (mode == 1 /* NEXT_STEP */ && h->need_reset[i]) {
+    /* the call after a done ignores the action and returns the reset observation (gymnasium 1.x) */
+    anymdp_reset_one(h, i, u_reset, obs);
+    reward[i] = 0.0f; reward_gt[i] = 0.0f; terminated[i] = 0; truncated[i] = 0;
+    return;
+  }
+  int a = a_in;
+  if (a < 0 || a >= A) { /* reference: assert action < self.na (:97) */
+    *err |= 1u;
+    a = a < 0 ? 0 : A - 1;
+  }
+  if (mode == 0 /* DISABLED */ && is_terminal(h, t, s)) {
+    /* reference raises "given an terminated state" (:95-96): the env is left untouched */
+    *err |= 2u;
+    obs[i] = h->state_map[(size_t)t * S + s];
+    reward[i] = 0.0f; reward_gt[i] = 0.0f; terminated[i] = 1;
+    truncated[i] = (uint8_t)(h->steps[i] >= h->max_steps[t]);
+    return;
+  }
+  int steps = h->steps[i] + 1;                              /* :113 */
+  int trunc = steps >= h->max_steps[t];                     /* :114, max_steps = ceil(task max_steps) */
+  size_t row = (((size_t)t * S + s) * A + a) * (size_t)S;
+  int s2 = xo_upper_bound(h->cdf + row, S, u);              /* :99-100 */
+  float r_gt = h->rs[(row + s2) * 2 + 0];                   /* :103 */
+  float sg = h->rs[(row + s2) * 2 + 1];                     /* :104 */
+  float r = fmaf(sg, z, r_gt);                              /* :105 normal(mu, sigma) = mu + sigma*z */
+  int term = is_terminal(h, t, s2);                         /* :107-108 */
+  h->state[i] = s2;
+  h->steps[i] = steps;
+  reward[i] = r; reward_gt[i] = r_gt;
+  terminated[i] = (uint8_t)term; truncated[i] = (uint8_t)trunc;
+  int o = h->state_map[(size_t)t * S + s2];                 /* :146-148 */
+  obs[i] = o;
+  if (term || trunc) {
+    if (mode == 2 /* SAME_STEP */) {
+      if (final_obs) final_obs[i] = o;
+      anymdp_reset_one(h, i, u_reset, obs);
+    } else if (mode == 1) {
+      h->need_reset[i] = 1;
+    }
+  }
+}
+
+void xo_anymdp_step_injected(xo_anymdp* h, const int32_t* action, const double* u, const float* z,
+                             const double* u_reset, int32_t* obs, float* reward, float* reward_gt,
+                             uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
+  for (int i = 0; i < h->n_env; ++i)
+    anymdp_step_one(h, i, action[i], u[i], z[i], u_reset[i], obs, reward, reward_gt, terminated,
+                    truncated, final_obs, mode, &h->err_flags);
+}
+
+void xo_anymdp_reset(xo_anymdp* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const uint8_t* mask,
+                     int32_t* obs) {
+  for (int i = 0; i < h->n_env; ++i) {
+    if (mask && !mask[i]) continue;
+    uint32_t w[4];
+    xo_env_draw(seed, gid_base + (uint64_t)i, tick, 1, w);
+    anymdp_reset_one(h, i, xo_u53(w[0], w[1]), obs);
+  }
+}
+
+static inline void anymdp_step_free_one(xo_anymdp* h, int i, uint64_t seed, uint64_t gid_base,
+                                        uint64_t tick, const int32_t* action, int32_t* obs,
+                                        float* reward, float* reward_gt, uint8_t* terminated,
+                                        uint8_t* truncated, int32_t* final_obs, int mode, uint32_t* err) {
+  uint32_t w[4], v[4];
+  xo_env_draw(seed, gid_base + (uint64_t)i, tick, 0, w);
+  xo_env_draw(seed, gid_base + (uint64_t)i, tick, 1, v);
+  float z;
+  xo_box_muller(w[2], w[3], &z, 0);
+  anymdp_step_one(h, i, action[i], xo_u53(w[0], w[1]), z, xo_u53(v[0], v[1]), obs, reward, reward_gt,
+                  terminated, truncated, final_obs, mode, err);
+}
+
+void xo_anymdp_step(xo_anymdp* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const int32_t* action,
+                    int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated,
+                    uint8_t* truncated, int32_t* final_obs, int mode) {
+  for (int i = 0; i < h->n_env; ++i)
+    anymdp_step_free_one(h, i, seed, gid_base, tick, action, obs, reward, reward_gt, terminated,
+                         truncated, final_obs, mode, &h->err_flags);
+}
+
+void xo_anymdp_step_mt(xo_anymdp* h, uint64_t seed, uint64_t gid_base, uint64_t tick,
+                       const int32_t* action, int32_t* obs, float* reward, float* reward_gt,
+                       uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode,
+                       int n_threads) {
+  uint32_t err_all = 0;
+  (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads) schedule(static) reduction(| : err_all)
+#endif
+  for (int i = 0; i < h->n_env; ++i) {
+    uint32_t err = 0;
+    anymdp_step_free_one(h, i, seed, gid_base, tick, action, obs, reward, reward_gt, terminated,
+                         truncated, final_obs, mode, &err);
+    err_all |= err;
+  }
+  h->err_flags |= err_all;
+}
+
+/* info["transition_gt"] = transition_obs[self.state, action] (anymdp_env.py:130; transition_obs built by
+ * map_transition_reward :12-20): the pmf row of the CURRENT inner state scattered to observation ids. */
+void xo_anymdp_transition_gt(const xo_anymdp* h, const int32_t* action, double* out) {
+  const int S = h->S, A = h->A;
+  for (int i = 0; i < h->n_env; ++i) {
+    int t = h->env_task[i], s = h->state[i], a = action[i];
+    if (a < 0) a = 0;
+    if (a >= A) a = A - 1;
+    const double* c = h->cdf + (((size_t)t * S + s) * A + a) * (size_t)S;
+    double* o = out + (size_t)i * S;
+    for (int j = 0; j < S; ++j) o[j] = 0.0;
+    if (is_terminal(h, t, s)) continue; /* all-zero row in the reference */
+    for (int j = 0; j < S; ++j)
+      o[h->state_map[(size_t)t * S + j]] = c[j] - (j ? c[j - 1] : 0.0);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Synthetic AnyMDP tasks (bench configs 2a/2b).  Integer-only construction so that the
+ * device generator (anymdp_synth.hip) is bit-identical: every weight is an integer, every partial sum is
+ * exact in uint32, and each CDF entry is one IEEE division.
+ * Shape follows the reference sampler's banded transition rows (anymdp/task_sampler_utils.py:65-175):
+ * support of row (s,a) is a band [lo,hi) around s; ~15 % of states terminal; s_0 = {0,1,2}.
+ * ---------------------------------------------------------------------------------------------- */
+static inline void synth_draw(uint64_t seed, uint64_t task, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+  uint32_t ctr[4] = {(uint32_t)task, (uint32_t)(task >> 32), c2, c3};
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  xo_philox4x32_10(ctr, key, out);
+}
+
+void xo_anymdp_synth(uint64_t seed, int64_t task_index_base, int n_task, int S, int A, int s0_max,
+                     double* cdf, float* rs, int32_t* state_map, uint64_t* term_mask, double* s0_cdf,
+                     int32_t* s0_ids, int32_t* max_steps) {
+  const int words = (S + 63) / 64;
+  for (int tl = 0; tl < n_task; ++tl) {
+    const uint64_t task = (uint64_t)(task_index_base + tl);
+    uint32_t w[4];
+    /* header */
+    synth_draw(seed, task, 0xFFFFFFFFu, 0, w);
+    max_steps[tl] = 256 + (int32_t)(w[0] % 245u);
+    int s0_len = 3;
+    if (s0_len > s0_max) s0_len = s0_max;
+    if (s0_len > S) s0_len = S;
+    uint32_t cum = 0, tot = 0;
+    for (int k = 0; k < s0_len; ++k) tot += 1u + (w[1 + k] >> 8);
+    for (int k = 0; k < s0_max; ++k) {
+      if (k < s0_len) {
+        cum += 1u + (w[1 + k] >> 8);
+        s0_cdf[(size_t)tl * s0_max + k] = (double)cum / (double)tot;
+        s0_ids[(size_t)tl * s0_max + k] = k;
+      } else {
+        s0_cdf[(size_t)tl * s0_max + k] = 1.0;
+        s0_ids[(size_t)tl * s0_max + k] = s0_len - 1;
+      }
+    }
+    /* state_map: Fisher-Yates permutation */
+    int32_t* sm = state_map + (size_t)tl * S;
+    for (int i = 0; i < S; ++i) sm[i] = i;
+    for (int i = S - 1; i >= 1; --i) {
+      synth_draw(seed, task, 0xFFFFFFFFu, 0x100u + (uint32_t)(i >> 2), w);
+      int j = (int)(w[i & 3] % (uint32_t)(i + 1));
+      int32_t tmp = sm[i]; sm[i] = sm[j]; sm[j] = tmp;
+    }
+    /* terminal states: floor(0.15 S) of the states 3..S-1 */
+    uint64_t* tm = term_mask + (size_t)tl * words;
+    for (int k = 0; k < words; ++k) tm[k] = 0;
+    int n_c = S - 3, n_term = (15 * S) / 100;
+    if (n_c < 0) n_c = 0;
+    if (n_term > n_c) n_term = n_c;
+    int cand[256];
+    for (int k = 0; k < n_c; ++k) cand[k] = 3 + k;
+    for (int k = 0; k < n_term; ++k) {
+      synth_draw(seed, task, 0xFFFFFFFFu, 0x200u + (uint32_t)(k >> 2), w);
+      int j = k + (int)(w[k & 3] % (uint32_t)(n_c - k));
+      int tmp = cand[k]; cand[k] = cand[j]; cand[j] = tmp;
+      tm[cand[k] >> 6] |= (uint64_t)1 << (cand[k] & 63);
+    }
+    /* rows */
+    for (int s = 0; s < S; ++s) {
+      int term = (int)((tm[s >> 6] >> (s & 63)) & 1u);
+      for (int a = 0; a < A; ++a) {
+        const uint32_t rowid = (uint32_t)(s * A + a);
+        size_t row = (((size_t)tl * S + s) * A + a) * (size_t)S;
+        synth_draw(seed, task, rowid, 0x1000u, w);
+        int lo_min = s - 33 > 0 ? s - 33 : 0;
+        int lo = lo_min + (int)(w[0] % (uint32_t)(s - lo_min + 1));
+        int hi_min = s + 2 < S ? s + 2 : S;
+        int hi_max = s + 17 < S ? s + 17 : S;
+        int hi = hi_min + (int)(w[1] % (uint32_t)(hi_max - hi_min + 1));
+        uint32_t wt[256];
+        uint32_t total = 0;
+        for (int j = 0; j < S; ++j) {
+          if ((j & 3) == 0) synth_draw(seed, task, rowid, (uint32_t)(j >> 2), w);
+          wt[j] = (j >= lo && j < hi) ? 104858u + (w[j & 3] >> 12) % 943718u : 0u;
+          total += wt[j];
+        }
+        uint32_t c = 0;
+        for (int j = 0; j < S; ++j) {
+          c += wt[j];
+          cdf[row + j] = term ? 1.0 : (double)c / (double)total;
+        }
+        for (int j = 0; j < S; ++j) {
+          if ((j & 1) == 0) synth_draw(seed, task, rowid, 0x100u + (uint32_t)(j >> 1), w);
+          uint32_t wa = w[(j & 1) * 2], wb = w[(j & 1) * 2 + 1];
+          rs[(row + j) * 2 + 0] = (float)((int32_t)(wa >> 8) - 8388608) * (1.0f / 4194304.0f);
+          rs[(row + j) * 2 + 1] = (wb & 1u) ? (float)(wb >> 8) * (1.0f / 67108864.0f) : 0.0f;
+        }
+      }
+    }
+  }
+}

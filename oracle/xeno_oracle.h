@@ -1,0 +1,72 @@
+/* xeno_oracle.h — CPU restatement of the Xenoverse hot path (TEST INFRASTRUCTURE, not product).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this.  The
+ * product (xenoverse_amd/, libxeno_hip.so) never does and has no CPU fallback.
+ *
+ * Every function works on the same struct-of-arrays layout as the device ABI (include/xeno.h), with host
+ * pointers, one plain scalar loop over envs, so that a parity test is "same inputs, memcmp the outputs".
+ * Pinned against the reference by tests/golden/ (made by oracle/gen_golden.py, which imports
+ * /root/reference in the build container).
+ */
+#ifndef XENO_ORACLE_H_
+#define XENO_ORACLE_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Philox4x32-10 (Salmon et al., SC'11); KATs in tests/test_oracle_philox.py */
+void xo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* counter convention shared with the device: {gid_lo, gid_hi, tick_lo, purpose | tick_hi<<8} */
+void xo_env_draw(uint64_t seed, uint64_t gid, uint64_t tick, uint32_t purpose, uint32_t out[4]);
+/* numpy random_sample construction from two 32-bit words: ((a>>5)*2^26 + (b>>6)) / 2^53 */
+double xo_u53(uint32_t a, uint32_t b);
+/* Box-Muller pair from two words (float): z0 = r cos(2 pi u2), z1 = r sin(2 pi u2) */
+void xo_box_muller(uint32_t a, uint32_t b, float* z0, float* z1);
+
+typedef struct {
+  int n_env, n_task, S, A, s0_max;
+  const double* cdf;        /* [n_task][S][A][S] */
+  const float* rs;          /* [n_task][S][A][S][2] */
+  const int32_t* state_map; /* [n_task][S] */
+  const uint64_t* term_mask;/* [n_task][(S+63)/64] */
+  const double* s0_cdf;     /* [n_task][s0_max] */
+  const int32_t* s0_ids;    /* [n_task][s0_max] */
+  const int32_t* max_steps; /* [n_task] */
+  const int32_t* env_task;  /* [n_env] */
+  /* env state */
+  int32_t* state;           /* [n_env] inner state */
+  int32_t* steps;           /* [n_env] */
+  uint8_t* need_reset;      /* [n_env] */
+  uint32_t err_flags;
+} xo_anymdp;
+
+/* first index j with cdf[j] > u (numpy.searchsorted side='right'), clamped to n-1 */
+int xo_upper_bound(const double* cdf, int n, double u);
+
+void xo_anymdp_reset_injected(xo_anymdp* h, const uint8_t* mask, const double* u, int32_t* obs);
+void xo_anymdp_step_injected(xo_anymdp* h, const int32_t* action, const double* u, const float* z,
+                             const double* u_reset, int32_t* obs, float* reward, float* reward_gt,
+                             uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode);
+/* free-running: draws u, z, u_reset with xo_env_draw(seed, gid_base+i, tick, purpose) as the device does */
+void xo_anymdp_reset(xo_anymdp* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const uint8_t* mask,
+                     int32_t* obs);
+void xo_anymdp_step(xo_anymdp* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const int32_t* action,
+                    int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated,
+                    uint8_t* truncated, int32_t* final_obs, int mode);
+/* multi-threaded twin of xo_anymdp_step used only for the cpu_baseline timing (OpenMP over envs) */
+void xo_anymdp_step_mt(xo_anymdp* h, uint64_t seed, uint64_t gid_base, uint64_t tick,
+                       const int32_t* action, int32_t* obs, float* reward, float* reward_gt,
+                       uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode,
+                       int n_threads);
+void xo_anymdp_transition_gt(const xo_anymdp* h, const int32_t* action, double* out);
+void xo_anymdp_synth(uint64_t seed, int64_t task_index_base, int n_task, int S, int A, int s0_max,
+                     double* cdf, float* rs, int32_t* state_map, uint64_t* term_mask, double* s0_cdf,
+                     int32_t* s0_ids, int32_t* max_steps);
+int xo_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,108 @@
+"""AnyMDP task dicts -> struct-of-arrays device tables (the host half of `set_task`).
+
+Reference: `AnyMDPEnv.set_task` (xenoverse/anymdp/anymdp_env.py:32-79) copies every key of the task dict
+onto the env object and validates it; `single_step` (:99-100) then calls `numpy.random.choice(n, p=row)`
+each step, which internally forms `cdf = cumsum(row); cdf /= cdf[-1]` and searches it.  Here that CDF is
+formed ONCE per task, on the host, in fp64 with numpy's own cumsum/divide so that every bit equals what
+`choice` would compute, and laid out for the device (layout: include/xeno.h, "AnyMDP").
+
+Task dict schema: ns, na, max_steps (float), state_mapping int[n], task_type,
+s_0 int[k], s_0_prob f64[k], s_e int[m], transition/reward/reward_noise f64[n,na,n].
+"""
+import math
+
+import numpy as np
+
+S_MAX = 256
+A_MAX = 64
+
+
+def validate_task(task):
+    """The checks of AnyMDPEnv.set_task (anymdp_env.py:48-76), same exception types and messages."""
+    ttype = task.get("task_type", "MDP")
+    if ttype not in ("MDP", "POMDP", "MTPOMDP"):
+        raise NotImplementedError(f"Unknown task type: {ttype}")
+    T = np.asarray(task["transition"])
+    R = np.asarray(task["reward"])
+    assert T.shape == R.shape
+    assert T.shape[0] == len(task["state_mapping"]) and T.shape[1] == task["na"]
+    assert task["ns"] > 0, "State space must be at least 1"
+    assert task["na"] > 1, "Action space must be at least 2"
+    s_e = np.asarray(task["s_e"], dtype=np.int64).reshape(-1)
+    err = (np.sum(T, axis=-1) - 1.0) ** 2
+    if len(s_e) > 0:
+        err[s_e] = 0.0
+    if (err >= 1.0e-6).any():
+        raise Exception(f"Transition Matrix Sum != 1 at {np.where(err >= 1.0e-6)}")
+    inter = np.intersect1d(np.asarray(task["s_0"]), s_e)
+    if len(inter) > 0:
+        raise Exception(f"State {inter} is {task['s_0']} and {task['s_e']}")
+
+
+def row_cdf(T):
+    """cumsum(row)/cumsum(row)[-1] along the last axis, exactly as numpy.random.choice forms it
+    (numpy/random/mtrand.pyx `choice`: `cdf = p.cumsum(); cdf /= cdf[-1]`).  All-zero rows (terminal
+    states in the reference) become 1.0: they are never sampled from."""
+    c = np.cumsum(np.asarray(T, dtype=np.float64), axis=-1)
+    last = c[..., -1:]
+    zero = last == 0.0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        c = c / np.where(zero, 1.0, last)
+    c = np.where(zero, 1.0, c)
+    return c
+
+
+def build_tables(tasks, s0_max=None, validate=True):
+    """Stack a list of reference task dicts into the device layout.  All tasks must share `na`; tasks
+    with fewer active states than the largest are padded (CDF 1.0, reward 0) — padding is unreachable
+    because the last real CDF entry is already 1.0 > u."""
+    if isinstance(tasks, dict):
+        tasks = [tasks]
+    if len(tasks) == 0:
+        raise ValueError("empty task list")
+    if validate:
+        for t in tasks:
+            validate_task(t)
+    A = int(tasks[0]["na"])
+    for t in tasks:
+        if int(t["na"]) != A:
+            raise ValueError("all tasks of one batch must share the action space size `na`")
+    n_list = [int(np.asarray(t["transition"]).shape[0]) for t in tasks]
+    S = max(n_list)
+    if not (2 <= S <= S_MAX) or not (2 <= A <= A_MAX):
+        raise ValueError(f"unsupported sizes S={S}, A={A} (need 2<=S<={S_MAX}, 2<=A<={A_MAX})")
+    k_max = max(len(np.atleast_1d(t["s_0"])) for t in tasks)
+    if s0_max is None:
+        s0_max = k_max
+    if s0_max < k_max:
+        raise ValueError("s0_max smaller than the longest s_0 list")
+    n_task = len(tasks)
+    words = (S + 63) // 64
+    cdf = np.ones((n_task, S, A, S), np.float64)
+    rs = np.zeros((n_task, S, A, S, 2), np.float32)
+    state_map = np.zeros((n_task, S), np.int32)
+    term_mask = np.zeros((n_task, words), np.uint64)
+    s0_cdf = np.ones((n_task, s0_max), np.float64)
+    s0_ids = np.zeros((n_task, s0_max), np.int32)
+    max_steps = np.zeros(n_task, np.int32)
+    obs_space = np.zeros(n_task, np.int32)
+    for i, t in enumerate(tasks):
+        n = n_list[i]
+        cdf[i, :n, :, :n] = row_cdf(t["transition"])
+        rs[i, :n, :, :n, 0] = np.asarray(t["reward"], np.float64)
+        rs[i, :n, :, :n, 1] = np.asarray(t["reward_noise"], np.float64)
+        state_map[i, :n] = np.asarray(t["state_mapping"], np.int64)
+        for s in np.asarray(t["s_e"], np.int64).reshape(-1):
+            term_mask[i, int(s) >> 6] |= np.uint64(1) << np.uint64(int(s) & 63)
+        s0 = np.atleast_1d(np.asarray(t["s_0"], np.int64))
+        p0 = np.atleast_1d(np.asarray(t["s_0_prob"], np.float64))
+        c0 = np.cumsum(p0)
+        c0 = c0 / c0[-1]
+        s0_cdf[i, :len(s0)] = c0
+        s0_ids[i, :len(s0)] = s0
+        s0_ids[i, len(s0):] = s0[-1]
+        # `truncated = steps >= max_steps` with integer steps and a real max_steps (anymdp_env.py:114)
+        max_steps[i] = int(min(math.ceil(float(t["max_steps"])), 2**31 - 1))
+        obs_space[i] = int(t["ns"])
+    return dict(S=S, A=A, s0_max=int(s0_max), cdf=cdf, rs=rs, state_map=state_map, term_mask=term_mask,
+                s0_cdf=s0_cdf, s0_ids=s0_ids, max_steps=max_steps, obs_space=obs_space)
