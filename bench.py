@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the AnyMDP hot path (BASELINE.json metric) on N MI355X GPUs of one node.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload = BASELINE.json configs[1]: anymdp |S|=64, |A|=8, 65,536 envs per GPU, synthetic tasks generated on
+the device.  Default task sharing is "distinct" (2a: one task per env, 48 GiB of
+tables per GPU, every CDF row read misses every cache); --tasks 1024 gives "shared" (2b).
+A "step" is one vector step of all envs of a rank = one launch of the step kernel; K steps are K back-to-back
+launches (xv_anymdp_step_many), auto-reset SAME_STEP, actions pre-generated on the device.
+
+One JSON line on rank 0: metric/value/unit/... as the driver's contract says, plus
+  roofline      HBM bound for the step kernel (algorithmic 562 B per env-step)
+  cpu_baseline  the C oracle (a port of the reference's step()) on the host cores, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = {8: 8 * 64 + 50}   # w*S + 50, w = 8 (fp64 CDF), S = 64  -> 562 B
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--tasks", type=int, default=0, help="tasks per GPU (0 = one per env, config 2a)")
+    ap.add_argument("--period", type=int, default=32, help="rollout-chunk ring length T")
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-allgather", action="store_true",
+                    help="N>1: skip the RCCL all-gather of rollout chunks (pure replicas)")
+    ap.add_argument("--fused", action="store_true", help="also time the fused T-step rollout kernel")
+    return ap.parse_args()
+
+
+def make_tables(eng, torch, _lib, n_task, task_base, seed, S=64, A=8, s0_max=4):
+    d = eng.device
+    words = (S + 63) // 64
+    t = dict(S=S, A=A, s0_max=s0_max,
+             cdf=torch.empty((n_task, S, A, S), dtype=torch.float64, device=d),
+             rs=torch.empty((n_task, S, A, S, 2), dtype=torch.float32, device=d),
+             state_map=torch.empty((n_task, S), dtype=torch.int32, device=d),
+             term_mask=torch.empty((n_task, words), dtype=torch.int64, device=d),
+             s0_cdf=torch.empty((n_task, s0_max), dtype=torch.float64, device=d),
+             s0_ids=torch.empty((n_task, s0_max), dtype=torch.int32, device=d),
+             max_steps=torch.empty(n_task, dtype=torch.int32, device=d))
+    _lib.check(eng.lib.xv_anymdp_synth_tasks(
+        eng.handle, seed, task_base, n_task, S, A, s0_max,
+        *[_lib.ptr(t[k]) for k in ("cdf", "rs", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")]))
+    eng.sync()
+    return t
+
+
+def cpu_baseline(seconds, seed):
+    """The CPU oracle (a C port of the reference's step(), pinned to the reference's golden vectors) on the
+    host cores: same workload shape (S=64, A=8, one synthetic task per env, random actions, SAME_STEP
+    auto-reset), on a bounded sample of envs, all host threads."""
+    import numpy as np
+    import oracle
+    n_env = 2048
+    cores = max(1, min(os.cpu_count() or 1, oracle.lib().xo_max_threads()))
+    tab = oracle.anymdp_synth(seed=seed, task_index_base=0, n_task=n_env, S=64, A=8, s0_max=4)
+    env_task = np.arange(n_env, dtype=np.int32)
+    ora = oracle.AnyMDPOracle(tab, env_task)
+    ora.reset(seed, 0, 0)
+    rng = np.random.RandomState(0)
+    acts = rng.randint(0, 8, (64, n_env)).astype(np.int32)
+    for k in range(20):
+        ora.step(seed, 0, 1 + k, acts[k % 64], 2, n_threads=cores)
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        for _ in range(50):
+            ora.step(seed, 0, 100 + k, acts[k % 64], 2, n_threads=cores)
+            k += 1
+        if time.perf_counter() - t0 >= seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n_env * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "oracle/xeno_oracle.c step (OpenMP, %d threads), %d envs x %d distinct S=64,A=8 tasks, "
+                      "%d vector steps in %.1f s" % (cores, n_env, n_env, k, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from xenoverse_amd import _lib
+    from xenoverse_amd.anymdp import AnyMDPVecEnv
+
+    n_env = args.envs
+    n_task = args.tasks if args.tasks > 0 else n_env
+    S, A = 64, 8
+    env = AnyMDPVecEnv(n_env, device="cuda:%d" % local, seed=args.seed, env_id_base=rank * n_env,
+                       autoreset_mode="same_step")
+    tab = make_tables(env.engine, torch, _lib, n_task, rank * n_task, args.seed + 1, S, A)
+    per = n_env // n_task
+    env_task = (torch.arange(n_env, device=env.device, dtype=torch.int32) // per).contiguous()
+    env.set_task(tab, env_task_index=env_task)
+    P = args.period
+    g = torch.Generator(device=env.device)
+    g.manual_seed(args.seed + 17 * rank)
+    actions = torch.randint(0, A, (P, n_env), generator=g, device=env.device, dtype=torch.int32)
+    env.reset()
+    ring = env.step_many(1, actions)   # allocates the [P, N] output ring
+
+    # optional exchange step: all-gather of the finished rollout chunk (obs/act/rew/flags, 14 B per record)
+    gather_stream = None
+    do_gather = world > 1 and not args.no_allgather
+    if do_gather:
+        rec = torch.empty((P, n_env, 14), dtype=torch.uint8, device=env.device)
+        gathered = torch.empty((world, P, n_env, 14), dtype=torch.uint8, device=env.device)
+        gather_stream = torch.cuda.Stream(device=env.device)
+
+    def pack_and_gather():
+        # pack the chunk into 14-B records and all-gather it on a side stream, overlapped with stepping
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(gather_stream):
+            gather_stream.wait_event(ev)
+            rec[..., 0:4] = ring["obs"].view(torch.uint8).view(P, n_env, 4)
+            rec[..., 4:8] = actions.view(torch.uint8).view(P, n_env, 4)
+            rec[..., 8:12] = ring["reward"].view(torch.uint8).view(P, n_env, 4)
+            rec[..., 12] = ring["terminated"]
+            rec[..., 13] = ring["truncated"]
+            dist.all_gather_into_tensor(gathered, rec)
+
+    def run(k_steps):
+        done = 0
+        while done < k_steps:
+            n = min(P, k_steps - done)
+            env.step_many(n, actions, out=ring)
+            done += n
+            if do_gather and n == P:
+                pack_and_gather()
+        if do_gather:
+            torch.cuda.current_stream().wait_stream(gather_stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    run(args.steps)
+    e1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    ev_ms = e0.elapsed_time(e1)           # HIP events on the stream the step kernels were launched on
+    if dist is not None:
+        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=env.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, ev_ms = float(tt[0]), float(tt[1])
+    errs = env.check_errors()
+
+    fused = None
+    if args.fused:
+        T = P
+        env.rollout(actions)
+        torch.cuda.synchronize()
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = max(1, args.steps // T)
+        f0.record()
+        for _ in range(reps):
+            env.rollout(actions, out=ring)
+        f1.record()
+        torch.cuda.synchronize()
+        fused = n_env * T * reps / (f0.elapsed_time(f1) * 1e-3)
+
+    if rank == 0:
+        total_steps = world * n_env * args.steps
+        kern_us = ev_ms * 1e3 / args.steps
+        algo = ALGO_BYTES_PER_ENV_STEP[8] * n_env
+        achieved = algo / (kern_us * 1e-6) / 1e9
+        out = {
+            "metric": "env-steps/sec (whole node), anymdp |S|=64 |A|=8, 65k envs/GPU",
+            "value": total_steps / wall, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "anymdp S=64 A=8, %d envs/GPU, %d tasks/GPU (%s), fp64 CDF rows, "
+                                   "SAME_STEP auto-reset, random actions"
+                                   % (n_env, n_task, "2a distinct: one task per env" if n_task == n_env
+                                      else "2b shared"),
+                       "envs_per_gpu": n_env, "tasks_per_gpu": n_task, "S": S, "A": A,
+                       "table_gib_per_gpu": round(n_task * S * A * S * 16 / 2**30, 2),
+                       "launch": "one step kernel per vector step (xv_anymdp_step_many)",
+                       "exchange": ("all_gather of %d-step rollout chunks (RCCL)" % P) if do_gather else "none",
+                       "device_error_flags": errs},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "anymdp_step_kernel<false,W64>", "avg_launch_us": kern_us,
+                         "algorithmic_bytes_per_launch": algo},
+        }
+        if fused is not None:
+            out["fused_rollout_env_steps_per_s_rank0"] = fused
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.seed)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    env.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

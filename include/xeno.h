@@ -131,6 +131,14 @@ int xv_anymdp_step_injected(xv_anymdp* h, const int32_t* action, const double* u
                             uint8_t* terminated, uint8_t* truncated, int32_t* final_obs,
                             int autoreset_mode);
 
+/* n_steps back-to-back vector steps, one kernel launch each, issued from C (a Python loop over
+ * xv_anymdp_step is host-bound at ~6 us per launch).  Step k reads actions[k % period] and writes slot
+ * k % period of the [period][n_env] output arrays — the rollout-chunk ring a learner consumes.
+ * Reference counterpart: the per-step rollout loop, anymdp/test_utils.py:42-60. */
+int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const int32_t* actions, int32_t* obs,
+                        float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated,
+                        int32_t* final_obs, int autoreset_mode);
+
 /* fused rollout: T vector steps in one launch with pre-generated actions[T][n_env] (open-loop / random
  * policy data collection); outputs are [T][n_env].  Bit-identical to T calls of xv_anymdp_step with
  * SAME_STEP auto-reset.  final_obs nullable. */

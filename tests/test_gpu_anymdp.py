@@ -1,0 +1,342 @@
+"""GPU parity: the HIP AnyMDP path (through the C-ABI) vs the reference's golden outputs and vs the CPU
+oracle on the same seeded inputs.  Integer paths (state, obs, flags, step counters) bit-exact; rewards are
+the same fp32 fmaf on both sides (bit-exact vs the oracle) and within 1e-5 rel of the fp64 reference."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from xenoverse_amd.anymdp import AnyMDPVecEnv, build_tables
+from util import close_f32, golden_files, load_anymdp_golden
+
+pytestmark = pytest.mark.gpu
+FILES = golden_files("anymdp_")
+MODES = {"disabled": 0, "next_step": 1, "same_step": 2}
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _dev_tables(tab, dev="cuda:0"):
+    out = dict(S=tab["S"], A=tab["A"], s0_max=tab["s0_max"])
+    for k in ("cdf", "rs", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps"):
+        v = np.ascontiguousarray(tab[k])
+        if v.dtype == np.uint64:
+            v = v.view(np.int64)
+        out[k] = torch.from_numpy(v).to(dev)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# golden vectors produced by the reference itself
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", FILES)
+def test_golden_single_step_tuples(path):
+    g, task = load_anymdp_golden(path)
+    n = len(g["ss_s"])
+    env = AnyMDPVecEnv(n, autoreset_mode="disabled")
+    env.set_task(task)
+    env.set_state(inner_state=g["ss_s"], steps=np.zeros(n), need_reset=np.zeros(n))
+    obs, r, term, trunc, info = env.step_injected(g["ss_a"], g["ss_u"], g["ss_z"], np.zeros(n))
+    assert np.array_equal(_np(env.inner_state), g["ss_next"])
+    assert np.array_equal(_np(obs), g["state_mapping"][g["ss_next"]])
+    assert np.array_equal(_np(term).astype(np.uint8), g["ss_term"])
+    assert np.array_equal(_np(info["reward_gt"]), g["ss_rgt"].astype(np.float32))
+    assert close_f32(_np(r), g["ss_r"])
+    assert env.check_errors() == 0
+    env.close()
+
+
+@pytest.mark.parametrize("path", FILES)
+def test_golden_reset_draws(path):
+    g, task = load_anymdp_golden(path)
+    n = len(g["reset_u"])
+    env = AnyMDPVecEnv(n, autoreset_mode="disabled")
+    env.set_task(task)
+    obs = env.reset_injected(g["reset_u"])
+    assert np.array_equal(_np(obs), g["reset_obs"])
+    assert np.array_equal(_np(env.inner_state), g["reset_state"])
+    env.close()
+
+
+@pytest.mark.parametrize("path", FILES[:2])
+def test_golden_trajectory_with_truncation_and_transition_gt(path):
+    """one env driven exactly like the reference's rollout loop (manual reset on done)"""
+    g, task = load_anymdp_golden(path)
+    env = AnyMDPVecEnv(1, autoreset_mode="disabled", with_transition_gt=True)
+    env.set_task(task)
+    o0 = env.reset_injected([float(g["init_u"])])
+    assert int(o0[0]) == int(g["init_obs"])
+    T = 600 if len(g["tr_a"]) > 600 else len(g["tr_a"])
+    T = max(T, int(np.argmax(g["tr_trunc"])) + 2)
+    for t in range(T):
+        if g["tr_set_steps"][t] >= 0:
+            env.set_state(steps=[int(g["tr_set_steps"][t])])
+        obs, r, term, trunc, info = env.step_injected([g["tr_a"][t]], [g["tr_u"][t]], [g["tr_z"][t]], [0.0])
+        assert int(obs[0]) == g["tr_obs"][t]
+        assert bool(term[0]) == bool(g["tr_term"][t]) and bool(trunc[0]) == bool(g["tr_trunc"][t])
+        assert int(info["steps"][0]) == g["tr_steps"][t]
+        assert close_f32(_np(r), g["tr_r"][t:t + 1])
+        assert np.max(np.abs(_np(info["transition_gt"])[0] - g["tr_tgt"][t])) < 1e-12
+        if term[0] or trunc[0]:
+            ro = env.reset_injected([g["tr_ur"][t]])
+            assert int(ro[0]) == g["tr_reset_obs"][t]
+    assert g["tr_trunc"][:T].sum() >= 1
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# seeded batches vs the oracle — BASELINE config 1 (S=16, A=4, 128 envs, 4 reference-sampled tasks)
+# ---------------------------------------------------------------------------------------------------
+def _config1():
+    tasks = [load_anymdp_golden(p)[1] for p in golden_files("anymdp_16x4")[:4]]
+    tab = build_tables(tasks)
+    env_task = np.repeat(np.arange(4, dtype=np.int32), 32)
+    return tasks, tab, env_task
+
+
+def _compare_step(dev_out, ora_out, exact_reward=True):
+    obs, r, term, trunc, info = dev_out
+    o_obs, o_r, o_rgt, o_term, o_trunc, o_fobs = ora_out
+    assert np.array_equal(_np(obs), o_obs)
+    assert np.array_equal(_np(term).astype(np.uint8), o_term)
+    assert np.array_equal(_np(trunc).astype(np.uint8), o_trunc)
+    assert np.array_equal(_np(info["reward_gt"]), o_rgt)
+    if exact_reward:
+        assert np.array_equal(_np(r), o_r)
+    else:
+        assert close_f32(_np(r), o_r, rel=1e-5, abs_=2e-6)
+    if "final_obs" in info:
+        assert np.array_equal(_np(info["final_obs"]), o_fobs)
+
+
+@pytest.mark.parametrize("mode", ["disabled", "next_step", "same_step"])
+def test_config1_injected_vs_oracle(mode):
+    tasks, tab, env_task = _config1()
+    n = len(env_task)
+    env = AnyMDPVecEnv(n, autoreset_mode=mode)
+    env.set_task(tasks, env_task_index=env_task)
+    ora = oracle.AnyMDPOracle(tab, env_task)
+    rng = np.random.RandomState(7)
+    u0 = rng.random_sample(n)
+    assert np.array_equal(_np(env.reset_injected(u0)), ora.reset_injected(u0))
+    ended = 0
+    for t in range(300):
+        a = rng.randint(0, tab["A"], n).astype(np.int32)
+        u, z, ur = rng.random_sample(n), rng.standard_normal(n).astype(np.float32), rng.random_sample(n)
+        d = env.step_injected(a, u, z, ur)
+        o = ora.step_injected(a, u, z, ur, MODES[mode])
+        _compare_step(d, o)
+        s, st, nr = env.get_state()
+        assert np.array_equal(_np(s), ora.state) and np.array_equal(_np(st), ora.steps)
+        assert np.array_equal(_np(nr), ora.need_reset)
+        done = (o[3] | o[4]).astype(bool)
+        ended += int(done.sum())
+        if mode == "disabled" and done.any():
+            # truncated-only envs keep stepping in the reference; terminated ones must be reset by the caller
+            m = o[3].astype(np.uint8)
+            if m.any():
+                ur2 = rng.random_sample(n)
+                assert np.array_equal(_np(env.reset_injected(ur2, mask=m))[m.astype(bool)],
+                                      ora.reset_injected(ur2, mask=m)[m.astype(bool)])
+    assert ended > 100
+    assert env.check_errors() == ora.err_flags == 0
+    env.close()
+
+
+@pytest.mark.parametrize("mode", ["next_step", "same_step"])
+def test_config1_free_running_philox_vs_oracle(mode):
+    tasks, tab, env_task = _config1()
+    n = len(env_task)
+    seed, base = 0xC0FFEE1234, 1 << 33
+    env = AnyMDPVecEnv(n, autoreset_mode=mode, seed=seed, env_id_base=base)
+    env.set_task(tasks, env_task_index=env_task)
+    ora = oracle.AnyMDPOracle(tab, env_task)
+    env.engine.tick = (1 << 32) - 3          # crosses the 32-bit tick boundary
+    tick = env.engine.tick
+    obs, _ = env.reset()
+    assert np.array_equal(_np(obs), ora.reset(seed, base, tick))
+    rng = np.random.RandomState(11)
+    for t in range(200):
+        a = rng.randint(0, tab["A"], n).astype(np.int32)
+        tick = env.engine.tick
+        d = env.step(a)
+        o = ora.step(seed, base, tick, a, MODES[mode])
+        _compare_step(d, o, exact_reward=False)
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# S = 64 wave-cooperative kernel (headline shape), synthetic tasks, ragged env count
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_env,n_task", [(2048, 32), (1000, 8), (64, 64), (37, 3)])
+def test_s64_wave_kernel_vs_oracle(n_env, n_task):
+    tab = oracle.anymdp_synth(seed=99, task_index_base=5, n_task=n_task, S=64, A=8, s0_max=4)
+    env_task = (np.arange(n_env) * n_task // n_env).astype(np.int32)
+    rng = np.random.RandomState(n_env)
+    rng.shuffle(env_task)                     # lanes of one wave mix tasks
+    seed = 4242
+    env = AnyMDPVecEnv(n_env, autoreset_mode="same_step", seed=seed)
+    env.set_task(_dev_tables(tab), env_task_index=env_task)
+    ora = oracle.AnyMDPOracle(tab, env_task)
+    tick = env.engine.tick
+    obs, _ = env.reset()
+    assert np.array_equal(_np(obs), ora.reset(seed, 0, tick))
+    for t in range(60):
+        a = rng.randint(0, 8, n_env).astype(np.int32)
+        if t % 2 == 0:
+            tick = env.engine.tick
+            d = env.step(a)
+            o = ora.step(seed, 0, tick, a, 2)
+            _compare_step(d, o, exact_reward=False)
+        else:
+            u, z, ur = rng.random_sample(n_env), rng.standard_normal(n_env).astype(np.float32), rng.random_sample(n_env)
+            # exercise exact CDF boundaries: u equal to a stored CDF entry must select the NEXT state
+            k = rng.randint(0, n_env, 8)
+            rows = tab["cdf"][env_task[k], ora.state[k], a[k]]
+            u[k] = np.minimum(rows[np.arange(8), rng.randint(0, 64, 8)], np.nextafter(1.0, 0.0))
+            d = env.step_injected(a, u, z, ur)
+            o = ora.step_injected(a, u, z, ur, 2)
+            _compare_step(d, o)
+        s, st, _ = env.get_state()
+        assert np.array_equal(_np(s), ora.state) and np.array_equal(_np(st), ora.steps)
+    assert env.check_errors() == 0
+    env.close()
+
+
+@pytest.mark.parametrize("S,A,n_task", [(16, 4, 6), (100, 5, 3), (256, 3, 2), (8, 2, 5)])
+def test_generic_kernel_other_sizes_vs_oracle(S, A, n_task):
+    tab = oracle.anymdp_synth(seed=5, task_index_base=0, n_task=n_task, S=S, A=A, s0_max=3)
+    n_env = 50 * n_task
+    env_task = np.repeat(np.arange(n_task, dtype=np.int32), 50)
+    env = AnyMDPVecEnv(n_env, autoreset_mode="same_step")
+    env.set_task(_dev_tables(tab), env_task_index=env_task)
+    ora = oracle.AnyMDPOracle(tab, env_task)
+    rng = np.random.RandomState(S)
+    u0 = rng.random_sample(n_env)
+    assert np.array_equal(_np(env.reset_injected(u0)), ora.reset_injected(u0))
+    for t in range(80):
+        a = rng.randint(0, A, n_env).astype(np.int32)
+        u, z, ur = rng.random_sample(n_env), rng.standard_normal(n_env).astype(np.float32), rng.random_sample(n_env)
+        _compare_step(env.step_injected(a, u, z, ur), ora.step_injected(a, u, z, ur, 2))
+    env.close()
+
+
+@pytest.mark.parametrize("S,A,n_task,s0_max", [(64, 8, 16, 4), (16, 4, 9, 3), (100, 5, 4, 2), (256, 3, 2, 8)])
+def test_device_synth_generator_bit_exact(S, A, n_task, s0_max):
+    import ctypes as C
+    from xenoverse_amd import Engine, _lib
+    eng = Engine("cuda:0", seed=1)
+    ref = oracle.anymdp_synth(seed=31337, task_index_base=1000, n_task=n_task, S=S, A=A, s0_max=s0_max)
+    d = "cuda:0"
+    words = (S + 63) // 64
+    t = dict(cdf=torch.empty((n_task, S, A, S), dtype=torch.float64, device=d),
+             rs=torch.empty((n_task, S, A, S, 2), dtype=torch.float32, device=d),
+             state_map=torch.empty((n_task, S), dtype=torch.int32, device=d),
+             term_mask=torch.empty((n_task, words), dtype=torch.int64, device=d),
+             s0_cdf=torch.empty((n_task, s0_max), dtype=torch.float64, device=d),
+             s0_ids=torch.empty((n_task, s0_max), dtype=torch.int32, device=d),
+             max_steps=torch.empty(n_task, dtype=torch.int32, device=d))
+    _lib.check(eng.lib.xv_anymdp_synth_tasks(eng.handle, 31337, 1000, n_task, S, A, s0_max, *[_lib.ptr(t[k]) for k in
+               ("cdf", "rs", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")]))
+    eng.sync()
+    for k in t:
+        got = _np(t[k])
+        exp = ref[k].view(np.int64) if ref[k].dtype == np.uint64 else ref[k]
+        assert np.array_equal(got, exp), k
+    # structural properties of every row: monotone CDF ending in exactly 1.0
+    c = _np(t["cdf"])
+    assert np.all(np.diff(c, axis=-1) >= 0) and np.all(c[..., -1] == 1.0)
+    eng.close()
+
+
+def test_fused_rollout_equals_stepwise():
+    tab = oracle.anymdp_synth(seed=3, task_index_base=0, n_task=16, S=64, A=8, s0_max=4)
+    n_env, T = 1024, 48
+    env_task = np.repeat(np.arange(16, dtype=np.int32), 64)
+    acts = np.random.RandomState(0).randint(0, 8, (T, n_env)).astype(np.int32)
+    outs = []
+    for fused in (False, True):
+        env = AnyMDPVecEnv(n_env, autoreset_mode="same_step", seed=77)
+        env.set_task(_dev_tables(tab), env_task_index=env_task)
+        env.reset()
+        if fused:
+            o = env.rollout(acts)
+            outs.append({k: _np(v) for k, v in o.items()})
+        else:
+            rec = {k: [] for k in ("obs", "reward", "reward_gt", "terminated", "truncated", "final_obs")}
+            for t in range(T):
+                obs, r, term, trunc, info = env.step(acts[t])
+                rec["obs"].append(_np(obs)); rec["reward"].append(_np(r)); rec["reward_gt"].append(_np(info["reward_gt"]))
+                rec["terminated"].append(_np(term).astype(np.uint8)); rec["truncated"].append(_np(trunc).astype(np.uint8))
+                rec["final_obs"].append(_np(info["final_obs"]))
+            outs.append({k: np.stack(v) for k, v in rec.items()})
+        s, st, _ = env.get_state()
+        outs[-1]["state"], outs[-1]["steps"] = _np(s), _np(st)
+        env.close()
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert outs[0]["terminated"].sum() > 1000
+
+
+def test_sharding_invariance_env_id_base():
+    """an env's trajectory depends on (seed, GLOBAL env id) only: a shard reproduces its slice of the batch"""
+    tab = oracle.anymdp_synth(seed=8, task_index_base=0, n_task=8, S=64, A=8, s0_max=4)
+    n_env, T = 512, 20
+    env_task = np.repeat(np.arange(8, dtype=np.int32), 64)
+    acts = np.random.RandomState(1).randint(0, 8, (T, n_env)).astype(np.int32)
+
+    def run(lo, hi):
+        env = AnyMDPVecEnv(hi - lo, autoreset_mode="same_step", seed=2024, env_id_base=lo)
+        env.set_task(_dev_tables(tab), env_task_index=env_task[lo:hi])
+        env.reset()
+        o = env.rollout(acts[:, lo:hi])
+        res = {k: _np(v) for k, v in o.items()}
+        env.close()
+        return res
+
+    full = run(0, n_env)
+    for lo, hi in ((0, 256), (256, 512)):
+        part = run(lo, hi)
+        for k in full:
+            assert np.array_equal(full[k][:, lo:hi], part[k]), k
+
+
+def test_error_flags_and_misuse_messages():
+    _, task = load_anymdp_golden(FILES[0])
+    env = AnyMDPVecEnv(2, autoreset_mode="disabled")
+    with pytest.raises(Exception, match="Must call \"set_task\" first"):
+        env.reset()
+    env.set_task(task)
+    with pytest.raises(Exception, match="before doing any actions"):
+        env.step([0, 0])
+    env.reset_injected([0.1, 0.1])
+    env.step_injected([0, task["na"]], [0.5, 0.5], [0.0, 0.0], [0.5, 0.5])
+    assert env.check_errors() & 1                    # action out of range
+    s_term = int(task["s_e"][0])
+    env.set_state(inner_state=[s_term, s_term])
+    obs, r, term, trunc, _ = env.step_injected([0, 0], [0.5, 0.5], [0.0, 0.0], [0.5, 0.5])
+    assert env.check_errors() & 2 and bool(term[0])   # stepping a terminated env
+    assert np.all(_np(env.inner_state) == s_term)
+    env.close()
+
+
+def test_device_philox_kat():
+    from xenoverse_amd import Engine
+    eng = Engine("cuda:0")
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+             (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, exp in kats:
+        c = torch.from_numpy(np.array(ctr, np.uint32).view(np.int32)).reshape(1, 4).cuda()
+        k = torch.from_numpy(np.array(key, np.uint32).view(np.int32)).cuda()
+        out = _np(eng.philox(c, k)).view(np.uint32)[0]
+        assert tuple(int(x) for x in out) == exp
+    rng = np.random.RandomState(0)
+    ctrs = rng.randint(0, 2**32, (1000, 4), dtype=np.uint64).astype(np.uint32)
+    key = np.array([123456789, 987654321], np.uint32)
+    out = _np(eng.philox(torch.from_numpy(ctrs.view(np.int32)).cuda(), torch.from_numpy(key.view(np.int32)).cuda()))
+    assert np.array_equal(out.view(np.uint32), oracle.philox4x32_10(ctrs, key))
+    eng.close()

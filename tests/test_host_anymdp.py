@@ -1,0 +1,61 @@
+"""Host logic of the AnyMDP boundary (CPU only): task validation as in AnyMDPEnv.set_task, table layout."""
+import numpy as np
+import pytest
+
+from xenoverse_amd.anymdp.tables import build_tables, row_cdf, validate_task
+from util import golden_files, load_anymdp_golden
+
+
+def _task():
+    return load_anymdp_golden(golden_files("anymdp_16x4")[0])[1]
+
+
+def test_tables_shapes_and_padding():
+    t0 = _task()
+    t1 = load_anymdp_golden(golden_files("anymdp_16x4")[1])[1]
+    tab = build_tables([t0, t1])
+    assert tab["cdf"].shape == (2, 16, 4, 16) and tab["rs"].shape == (2, 16, 4, 16, 2)
+    assert tab["cdf"].dtype == np.float64 and tab["rs"].dtype == np.float32
+    assert tab["max_steps"][0] == int(np.ceil(t0["max_steps"]))
+    assert np.all(tab["cdf"][..., -1] == 1.0)
+    for s in t0["s_e"]:
+        assert (int(tab["term_mask"][0, 0]) >> int(s)) & 1
+    assert bin(int(tab["term_mask"][0, 0])).count("1") == len(t0["s_e"])
+
+
+def test_row_cdf_is_numpy_choice_cdf():
+    p = np.random.RandomState(0).dirichlet(np.ones(16), size=(3, 4))
+    c = row_cdf(p)
+    ref = np.cumsum(p, -1)
+    ref /= ref[..., -1:]
+    assert np.array_equal(c, ref)
+    z = row_cdf(np.zeros((2, 5)))
+    assert np.all(z == 1.0)
+
+
+def test_validate_rejects_bad_rows_like_reference():
+    t = _task()
+    bad = dict(t)
+    T = t["transition"].copy()
+    s_ok = [s for s in range(T.shape[0]) if s not in set(t["s_e"])][0]
+    T[s_ok, 0] *= 0.5
+    bad["transition"] = T
+    with pytest.raises(Exception, match="Transition Matrix Sum != 1"):
+        validate_task(bad)
+    bad2 = dict(t)
+    bad2["s_0"] = np.array([int(t["s_e"][0])])
+    bad2["s_0_prob"] = np.array([1.0])
+    with pytest.raises(Exception):
+        validate_task(bad2)
+    bad3 = dict(t)
+    bad3["task_type"] = "FOO"
+    with pytest.raises(NotImplementedError):
+        validate_task(bad3)
+
+
+def test_mixed_action_spaces_rejected():
+    t = _task()
+    t2 = dict(t)
+    t2["na"] = 5
+    with pytest.raises(ValueError):
+        build_tables([t, t2], validate=False)

@@ -1,0 +1,78 @@
+"""ctypes binding of libxeno_hip.so (C-ABI: include/xeno.h).
+
+There is NO fallback: if the HIP library is missing or does not load, importing the engine raises.  The
+product never computes an environment step on the CPU.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxeno_hip.so")
+
+c_void_p, c_int, c_u64, c_i64, c_u32 = C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_uint32
+
+# name -> argtypes (restype is int unless listed in _RESTYPE).  Keep in sync with include/xeno.h;
+# tests/test_abi.py parses the header and checks that every declared symbol is exported and bound.
+SIGNATURES = {
+    "xv_abi_version": [],
+    "xv_last_error": [],
+    "xv_engine_create": [c_int, c_u64, c_u64, c_void_p, C.POINTER(c_void_p)],
+    "xv_engine_destroy": [c_void_p],
+    "xv_engine_sync": [c_void_p],
+    "xv_engine_stream": [c_void_p],
+    "xv_engine_error_flags": [c_void_p, c_int, C.POINTER(c_u32)],
+    "xv_engine_get_tick": [c_void_p, C.POINTER(c_u64)],
+    "xv_engine_set_tick": [c_void_p, c_u64],
+    "xv_philox4x32_10": [c_void_p, c_void_p, c_void_p, c_void_p, c_int],
+    "xv_anymdp_create": [c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 8 + [C.POINTER(c_void_p)],
+    "xv_anymdp_destroy": [c_void_p],
+    "xv_anymdp_reset": [c_void_p, c_void_p, c_void_p],
+    "xv_anymdp_reset_injected": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "xv_anymdp_step": [c_void_p] + [c_void_p] * 7 + [c_int],
+    "xv_anymdp_step_injected": [c_void_p] + [c_void_p] * 10 + [c_int],
+    "xv_anymdp_step_many": [c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int],
+    "xv_anymdp_rollout": [c_void_p, c_int] + [c_void_p] * 7,
+    "xv_anymdp_get_state": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "xv_anymdp_set_state": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "xv_anymdp_transition_gt": [c_void_p, c_void_p, c_void_p],
+    "xv_anymdp_synth_tasks": [c_void_p, c_u64, c_i64, c_int, c_int, c_int, c_int] + [c_void_p] * 7,
+}
+_RESTYPE = {"xv_last_error": C.c_char_p, "xv_engine_stream": c_void_p}
+
+_lib = None
+
+
+class XenoError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libxeno_hip.so; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise XenoError(
+            "libxeno_hip.so is not built (%s). Run `python -m xenoverse_amd.build` (needs hipcc). "
+            "xenoverse_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing: loud by design
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().xv_last_error()
+        raise XenoError("libxeno_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensors handed to the C-ABI must be contiguous"
+    return t.data_ptr()

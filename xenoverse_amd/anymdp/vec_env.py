@@ -1,0 +1,251 @@
+"""AnyMDPVecEnv — N AnyMDP environments stepped per kernel launch on one MI355X.
+
+Mirrors the reference's per-env interface (xenoverse/anymdp/anymdp_env.py: AnyMDPEnv.set_task :32-79,
+reset :81-90, step :112-132, properties :134-165) behind gymnasium's VectorEnv surface.  Same task dicts,
+same exception types/messages for misuse, same info keys (`steps`, `reward_gt`, optional `transition_gt`).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..engine import AUTORESET
+from ..spaces import Discrete
+from ..vector import VectorEnv
+from .tables import build_tables
+
+_TABLE_KEYS = ("cdf", "rs", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")
+_TABLE_DTYPES = dict(cdf=torch.float64, rs=torch.float32, state_map=torch.int32, term_mask=torch.int64,
+                     s0_cdf=torch.float64, s0_ids=torch.int32, max_steps=torch.int32)
+
+
+class AnyMDPVecEnv(VectorEnv):
+    def __init__(self, num_envs, max_steps=5000, device="cuda:0", seed=0, env_id_base=0,
+                 autoreset_mode="same_step", to_numpy=False, engine=None, with_transition_gt=False):
+        """`max_steps` is kept for signature parity with AnyMDPEnv(max_steps); as in the reference it is
+        overridden by each task's own `max_steps` at set_task (anymdp_env.py:23-34)."""
+        super().__init__(num_envs, device=device, seed=seed, env_id_base=env_id_base,
+                         autoreset_mode=autoreset_mode, to_numpy=to_numpy, engine=engine)
+        self.max_steps = max_steps
+        self.with_transition_gt = bool(with_transition_gt)
+        self._set_spaces(Discrete(1), Discrete(1))   # placeholders until set_task, as in the reference
+        self._h = None
+        self._tab = None
+
+    # ---- set_task ---------------------------------------------------------------------------------
+    def set_task(self, tasks, env_task_index=None):
+        """tasks: one reference task dict, a list of them, or a dict of prebuilt tables (numpy arrays or
+        device tensors, keys as xenoverse_amd.anymdp.tables.build_tables returns).  env_task_index[i] is
+        the task of env i (default: envs split evenly and contiguously over tasks)."""
+        if isinstance(tasks, dict) and "cdf" in tasks:
+            tab = tasks
+        else:
+            if isinstance(tasks, dict):
+                tasks = [tasks]
+            for t in tasks:
+                if t.get("task_type", "MDP") != "MDP":
+                    raise NotImplementedError(
+                        "AnyMDPVecEnv steps task_type 'MDP'; got %r" % (t.get("task_type"),))
+            tab = build_tables(tasks)
+        dev = {}
+        for k in _TABLE_KEYS:
+            v = tab[k]
+            if torch.is_tensor(v):
+                dev[k] = v.to(self.device).contiguous()
+            else:
+                v = np.ascontiguousarray(v)
+                if v.dtype == np.uint64:
+                    v = v.view(np.int64)
+                dev[k] = torch.from_numpy(v).to(self.device)
+            assert dev[k].dtype == _TABLE_DTYPES[k], (k, dev[k].dtype)
+        S, A, s0_max = int(tab["S"]), int(tab["A"]), int(tab["s0_max"])
+        n_task = int(dev["max_steps"].shape[0])
+        if env_task_index is None:
+            if self.num_envs % n_task != 0:
+                raise ValueError("num_envs (%d) is not a multiple of the task count (%d); pass "
+                                 "env_task_index" % (self.num_envs, n_task))
+            per = self.num_envs // n_task
+            env_task = torch.arange(self.num_envs, device=self.device, dtype=torch.int32) // per
+        else:
+            env_task = self._dev(env_task_index, torch.int32)
+            if env_task.shape != (self.num_envs,):
+                raise ValueError("env_task_index must have shape (num_envs,)")
+            lo, hi = int(env_task.min()), int(env_task.max())
+            if lo < 0 or hi >= n_task:
+                raise ValueError("env_task_index out of range")
+        dev["env_task"] = env_task.contiguous()
+        if self._h is not None:
+            self.lib.xv_anymdp_destroy(self._h)
+            self._h = None
+        h = C.c_void_p()
+        _lib.check(self.lib.xv_anymdp_create(
+            self.engine.handle, self.num_envs, n_task, S, A, s0_max,
+            _lib.ptr(dev["cdf"]), _lib.ptr(dev["rs"]), _lib.ptr(dev["state_map"]),
+            _lib.ptr(dev["term_mask"]), _lib.ptr(dev["s0_cdf"]), _lib.ptr(dev["s0_ids"]),
+            _lib.ptr(dev["max_steps"]), _lib.ptr(dev["env_task"]), C.byref(h)))
+        self._h = h
+        self._tab = dev       # keeps the borrowed device tables alive
+        self.S, self.A, self.s0_max, self.n_task = S, A, s0_max, n_task
+        ns = int(np.max(tab["obs_space"])) if "obs_space" in tab else S
+        self.ns, self.na = ns, A
+        self._set_spaces(Discrete(ns), Discrete(A))
+        n = self.num_envs
+        d = self.device
+        self._obs = torch.zeros(n, dtype=torch.int32, device=d)
+        self._reward = torch.zeros(n, dtype=torch.float32, device=d)
+        self._reward_gt = torch.zeros(n, dtype=torch.float32, device=d)
+        self._term = torch.zeros(n, dtype=torch.uint8, device=d)
+        self._trunc = torch.zeros(n, dtype=torch.uint8, device=d)
+        self._final_obs = torch.full((n,), -1, dtype=torch.int32, device=d)
+        self._steps = torch.zeros(n, dtype=torch.int32, device=d)
+        self._tgt = torch.zeros((n, S), dtype=torch.float64, device=d) if self.with_transition_gt else None
+        self.task_set = True
+        self.need_reset = True
+
+    # ---- reset ------------------------------------------------------------------------------------
+    def reset(self, *, seed=None, options=None):
+        """gymnasium VectorEnv.reset.  options={"reset_mask": bool[N]} resets a subset (autoreset
+        DISABLED); seed (int) re-keys this engine's Philox stream position deterministically."""
+        self._require_task()
+        if seed is not None:
+            self.engine.tick = (int(seed) & 0xFFFFFFFF) << 24
+        mask = None
+        if options is not None and options.get("reset_mask") is not None:
+            mask = self._dev(options["reset_mask"], torch.uint8)
+        _lib.check(self.lib.xv_anymdp_reset(self._h, _lib.ptr(mask), _lib.ptr(self._obs)))
+        self.need_reset = False
+        return self._out(self._obs.clone()), {"steps": self._out(self._get_steps())}
+
+    def reset_injected(self, u, mask=None):
+        """Parity hook: the initial-state uniform is supplied per env (fp64 in [0,1))."""
+        self._require_task()
+        u = self._dev(u, torch.float64)
+        m = None if mask is None else self._dev(mask, torch.uint8)
+        _lib.check(self.lib.xv_anymdp_reset_injected(self._h, _lib.ptr(m), _lib.ptr(u), _lib.ptr(self._obs)))
+        self.need_reset = False
+        return self._out(self._obs.clone())
+
+    # ---- step -------------------------------------------------------------------------------------
+    def _check_step(self):
+        if (not self.task_set) or self.need_reset:
+            # reference message, anymdp_env.py:93-94
+            raise Exception("Must \"set_task\" and \"reset\" before doing any actions")
+
+    def _infos(self, actions):
+        infos = {"steps": self._out(self._get_steps()), "reward_gt": self._out(self._reward_gt.clone())}
+        if self.autoreset_mode == "same_step":
+            infos["final_obs"] = self._out(self._final_obs.clone())
+            infos["_final_obs"] = self._out((self._term | self._trunc).bool())
+        if self.with_transition_gt:
+            _lib.check(self.lib.xv_anymdp_transition_gt(self._h, _lib.ptr(actions), _lib.ptr(self._tgt)))
+            infos["transition_gt"] = self._out(self._tgt.clone())
+        return infos
+
+    def step(self, actions):
+        self._check_step()
+        a = self._dev(actions, torch.int32)
+        if a.shape != (self.num_envs,):
+            raise AssertionError(f"Action {tuple(a.shape)} is out of range")
+        _lib.check(self.lib.xv_anymdp_step(
+            self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward), _lib.ptr(self._reward_gt),
+            _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._final_obs),
+            AUTORESET[self.autoreset_mode]))
+        return (self._out(self._obs.clone()), self._out(self._reward.clone()),
+                self._out(self._term.bool()), self._out(self._trunc.bool()), self._infos(a))
+
+    def step_injected(self, actions, u, z, u_reset):
+        """Parity hook (C-ABI xv_anymdp_step_injected): random inputs supplied per env."""
+        self._check_step()
+        a = self._dev(actions, torch.int32)
+        u = self._dev(u, torch.float64)
+        z = self._dev(z, torch.float32)
+        ur = self._dev(u_reset, torch.float64)
+        _lib.check(self.lib.xv_anymdp_step_injected(
+            self._h, _lib.ptr(a), _lib.ptr(u), _lib.ptr(z), _lib.ptr(ur), _lib.ptr(self._obs),
+            _lib.ptr(self._reward), _lib.ptr(self._reward_gt), _lib.ptr(self._term), _lib.ptr(self._trunc),
+            _lib.ptr(self._final_obs), AUTORESET[self.autoreset_mode]))
+        return (self._out(self._obs.clone()), self._out(self._reward.clone()),
+                self._out(self._term.bool()), self._out(self._trunc.bool()), self._infos(a))
+
+    def rollout(self, actions, out=None):
+        """Fused open-loop rollout: actions int32[T, N] -> dict of [T, N] device tensors, one launch.
+        Equals T calls of step() with SAME_STEP auto-reset, bit for bit."""
+        self._check_step()
+        a = self._dev(actions, torch.int32)
+        T = int(a.shape[0])
+        assert a.shape == (T, self.num_envs)
+        d = self.device
+        if out is None:
+            out = dict(obs=torch.empty((T, self.num_envs), dtype=torch.int32, device=d),
+                       reward=torch.empty((T, self.num_envs), dtype=torch.float32, device=d),
+                       reward_gt=torch.empty((T, self.num_envs), dtype=torch.float32, device=d),
+                       terminated=torch.empty((T, self.num_envs), dtype=torch.uint8, device=d),
+                       truncated=torch.empty((T, self.num_envs), dtype=torch.uint8, device=d),
+                       final_obs=torch.empty((T, self.num_envs), dtype=torch.int32, device=d))
+        _lib.check(self.lib.xv_anymdp_rollout(
+            self._h, T, _lib.ptr(a), _lib.ptr(out["obs"]), _lib.ptr(out["reward"]), _lib.ptr(out["reward_gt"]),
+            _lib.ptr(out["terminated"]), _lib.ptr(out["truncated"]), _lib.ptr(out.get("final_obs"))))
+        return out
+
+    def step_many(self, n_steps, actions, out=None):
+        """n_steps back-to-back step launches issued from C.  actions int32[P, N] is cycled with period P;
+        `out` holds [P, N] ring buffers (allocated when None) — slot k % P receives step k."""
+        self._check_step()
+        a = self._dev(actions, torch.int32)
+        P = int(a.shape[0])
+        assert a.shape == (P, self.num_envs)
+        d = self.device
+        if out is None:
+            out = dict(obs=torch.empty((P, self.num_envs), dtype=torch.int32, device=d),
+                       reward=torch.empty((P, self.num_envs), dtype=torch.float32, device=d),
+                       reward_gt=torch.empty((P, self.num_envs), dtype=torch.float32, device=d),
+                       terminated=torch.empty((P, self.num_envs), dtype=torch.uint8, device=d),
+                       truncated=torch.empty((P, self.num_envs), dtype=torch.uint8, device=d),
+                       final_obs=torch.empty((P, self.num_envs), dtype=torch.int32, device=d))
+        _lib.check(self.lib.xv_anymdp_step_many(
+            self._h, int(n_steps), P, _lib.ptr(a), _lib.ptr(out["obs"]), _lib.ptr(out["reward"]),
+            _lib.ptr(out["reward_gt"]), _lib.ptr(out["terminated"]), _lib.ptr(out["truncated"]),
+            _lib.ptr(out.get("final_obs")), AUTORESET[self.autoreset_mode]))
+        return out
+
+    # ---- accessors (anymdp_env.py:134-165) ----------------------------------------------------------
+    def _get_steps(self):
+        _lib.check(self.lib.xv_anymdp_get_state(self._h, None, _lib.ptr(self._steps), None))
+        return self._steps.clone()
+
+    @property
+    def inner_state(self):
+        s = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.xv_anymdp_get_state(self._h, _lib.ptr(s), None, None))
+        return self._out(s)
+
+    @property
+    def state(self):
+        """observation-space id of each env's state: state_mapping[_state] (anymdp_env.py:134-136)"""
+        s = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.xv_anymdp_get_state(self._h, _lib.ptr(s), None, None))
+        idx = self._tab["env_task"].long() * self.S + s.long()
+        return self._out(self._tab["state_map"].reshape(-1)[idx])
+
+    def get_state(self):
+        n, d = self.num_envs, self.device
+        s = torch.empty(n, dtype=torch.int32, device=d)
+        st = torch.empty(n, dtype=torch.int32, device=d)
+        nr = torch.empty(n, dtype=torch.uint8, device=d)
+        _lib.check(self.lib.xv_anymdp_get_state(self._h, _lib.ptr(s), _lib.ptr(st), _lib.ptr(nr)))
+        return s, st, nr
+
+    def set_state(self, inner_state=None, steps=None, need_reset=None):
+        s = None if inner_state is None else self._dev(inner_state, torch.int32)
+        st = None if steps is None else self._dev(steps, torch.int32)
+        nr = None if need_reset is None else self._dev(need_reset, torch.uint8)
+        _lib.check(self.lib.xv_anymdp_set_state(self._h, _lib.ptr(s), _lib.ptr(st), _lib.ptr(nr)))
+        self.engine.sync()   # the temporaries above must outlive the copies
+        self.need_reset = False
+
+    def close_extras(self, **kwargs):
+        if self._h is not None:
+            self.lib.xv_anymdp_destroy(self._h)
+            self._h = None
+        self._tab = None

@@ -1,0 +1,108 @@
+// engine.hip — engine handle (device + stream + Philox key + sticky device error word).
+#include "philox.h"
+#include "xv_common.h"
+
+static thread_local char g_err[512] = "";
+
+void xv_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int xv_abi_version(void) { return XV_ABI_VERSION; }
+extern "C" const char* xv_last_error(void) { return g_err; }
+
+extern "C" int xv_engine_create(int device, uint64_t seed, uint64_t env_id_base, void* hip_stream,
+                                xv_engine** out) {
+  XV_CHECK_ARG(out != nullptr);
+  *out = nullptr;
+  int n_dev = 0;
+  XV_HIP(hipGetDeviceCount(&n_dev));
+  XV_CHECK_ARG(device >= 0 && device < n_dev);
+  XV_HIP(hipSetDevice(device));
+  xv_engine* e = new (std::nothrow) xv_engine();
+  if (!e) {
+    xv_set_error("xv_engine_create: out of host memory");
+    return XV_ERR_NOMEM;
+  }
+  e->device = device;
+  e->seed = seed;
+  e->env_id_base = env_id_base;
+  e->tick = 0;
+  e->own_stream = (hip_stream == nullptr);
+  e->stream = (hipStream_t)hip_stream;
+  e->d_err = nullptr;
+  if (e->own_stream) {
+    hipError_t s = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (s != hipSuccess) {
+      xv_set_error("xv_engine_create: hipStreamCreate failed: %s", hipGetErrorString(s));
+      delete e;
+      return XV_ERR_HIP;
+    }
+  }
+  hipError_t m = hipMalloc(&e->d_err, sizeof(uint32_t));
+  if (m == hipSuccess) m = hipMemsetAsync(e->d_err, 0, sizeof(uint32_t), e->stream);
+  if (m != hipSuccess) {
+    xv_set_error("xv_engine_create: error word allocation failed: %s", hipGetErrorString(m));
+    if (e->own_stream) hipStreamDestroy(e->stream);
+    delete e;
+    return XV_ERR_HIP;
+  }
+  *out = e;
+  return XV_OK;
+}
+
+extern "C" int xv_engine_destroy(xv_engine* e) {
+  if (!e) return XV_OK;
+  hipSetDevice(e->device);
+  hipStreamSynchronize(e->stream);
+  if (e->d_err) hipFree(e->d_err);
+  if (e->own_stream) hipStreamDestroy(e->stream);
+  delete e;
+  return XV_OK;
+}
+
+extern "C" int xv_engine_sync(xv_engine* e) {
+  XV_CHECK_ARG(e != nullptr);
+  XV_HIP(hipStreamSynchronize(e->stream));
+  return XV_OK;
+}
+
+extern "C" void* xv_engine_stream(xv_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+extern "C" int xv_engine_error_flags(xv_engine* e, int clear, uint32_t* out_flags) {
+  XV_CHECK_ARG(e != nullptr && out_flags != nullptr);
+  uint32_t v = 0;
+  XV_HIP(hipMemcpyAsync(&v, e->d_err, sizeof(v), hipMemcpyDeviceToHost, e->stream));
+  XV_HIP(hipStreamSynchronize(e->stream));
+  if (clear) XV_HIP(hipMemsetAsync(e->d_err, 0, sizeof(uint32_t), e->stream));
+  *out_flags = v;
+  return XV_OK;
+}
+
+extern "C" int xv_engine_get_tick(xv_engine* e, uint64_t* out_tick) {
+  XV_CHECK_ARG(e != nullptr && out_tick != nullptr);
+  *out_tick = e->tick;
+  return XV_OK;
+}
+extern "C" int xv_engine_set_tick(xv_engine* e, uint64_t tick) {
+  XV_CHECK_ARG(e != nullptr);
+  e->tick = tick;
+  return XV_OK;
+}
+
+__global__ void xv_philox_kat_kernel(const uint32_t* ctr, const uint32_t* key, uint32_t* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const xv_u32x4 r = xv_philox4x32_10(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3], key[0], key[1]);
+  out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+}
+
+extern "C" int xv_philox4x32_10(xv_engine* e, const uint32_t* ctr, const uint32_t* key, uint32_t* out, int n) {
+  XV_CHECK_ARG(e && ctr && key && out && n > 0);
+  hipLaunchKernelGGL(xv_philox_kat_kernel, dim3(xv_div_up(n, 256)), dim3(256), 0, e->stream, ctr, key, out, n);
+  XV_LAUNCH_CHECK();
+  return XV_OK;
+}

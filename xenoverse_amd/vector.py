@@ -1,0 +1,81 @@
+"""VectorEnv base: the gymnasium >= 1.0 `VectorEnv` surface over a device
+engine.  gymnasium's class is generic over the array type; these envs return torch tensors that live on
+the GPU (`to_numpy=True` converts for NumPy consumers)."""
+import torch
+
+from . import _lib
+from .engine import AUTORESET, Engine
+from .spaces import batch_space
+
+
+class VectorEnv(object):
+    metadata = {"autoreset_mode": "same_step"}
+    render_mode = None
+    spec = None
+
+    def __init__(self, num_envs, device="cuda:0", seed=0, env_id_base=0, autoreset_mode="same_step",
+                 to_numpy=False, engine=None):
+        if autoreset_mode not in AUTORESET:
+            raise ValueError("autoreset_mode must be one of %s" % sorted(AUTORESET))
+        self.num_envs = int(num_envs)
+        self.engine = engine if engine is not None else Engine(device, seed=seed, env_id_base=env_id_base)
+        self._own_engine = engine is None
+        self.device = self.engine.device
+        self.lib = self.engine.lib
+        self.autoreset_mode = autoreset_mode
+        self.metadata = dict(type(self).metadata, autoreset_mode=autoreset_mode)
+        self.to_numpy = bool(to_numpy)
+        self.closed = False
+        self.task_set = False
+        self.single_observation_space = None
+        self.single_action_space = None
+        self.observation_space = None
+        self.action_space = None
+
+    # -- helpers ------------------------------------------------------------------------------------
+    def _set_spaces(self, single_obs, single_act):
+        self.single_observation_space = single_obs
+        self.single_action_space = single_act
+        self.observation_space = batch_space(single_obs, self.num_envs)
+        self.action_space = batch_space(single_act, self.num_envs)
+
+    def _dev(self, x, dtype):
+        """Bring `x` (tensor / ndarray / list) to a contiguous device tensor of `dtype` without copying
+        when it already is one."""
+        if torch.is_tensor(x):
+            if x.device != self.device or x.dtype != dtype:
+                x = x.to(device=self.device, dtype=dtype)
+            return x.contiguous()
+        return torch.as_tensor(x).to(device=self.device, dtype=dtype).contiguous()
+
+    def _out(self, t):
+        return t.cpu().numpy() if self.to_numpy else t
+
+    def _require_task(self):
+        if not self.task_set:
+            # reference: raise Exception("Must call \"set_task\" first") (anymdp_env.py:83, linds_env.py:110)
+            raise Exception("Must call \"set_task\" first")
+
+    def check_errors(self, clear=True):
+        """Device-side range errors are sticky bits, read on demand (one stream sync)."""
+        return self.engine.error_flags(clear)
+
+    def close(self, **kwargs):
+        if self.closed:
+            return
+        self.close_extras(**kwargs)
+        if self._own_engine:
+            self.engine.close()
+        self.closed = True
+
+    def close_extras(self, **kwargs):
+        pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+XenoError = _lib.XenoError
