@@ -52,6 +52,8 @@ extern "C" {
 #define XV_DEVERR_STEP_TERMINAL 2u  /* reference: raise "given an terminated state" (anymdp_env.py:95-96) */
 #define XV_DEVERR_NONFINITE 4u      /* a float state left the finite range */
 
+#define XV_STREAM_OWN ((void*)(intptr_t)-1)
+
 typedef struct xv_engine xv_engine;
 typedef struct xv_anymdp xv_anymdp;
 typedef struct xv_linds xv_linds;
@@ -64,7 +66,8 @@ typedef struct xv_maze xv_maze;
 int xv_abi_version(void);
 const char* xv_last_error(void);
 
-/* `hip_stream` is a hipStream_t (NULL = the engine creates its own non-blocking stream).
+/* `hip_stream` is a hipStream_t: NULL is the device's default (null) stream — what PyTorch uses unless told
+ * otherwise — and XV_STREAM_OWN makes the engine create (and own) a non-blocking stream.
  * `seed` is the Philox4x32-10 key; `env_id_base` is added to the local env index to form the counter's
  * env word, so that a batch sharded over ranks draws the same numbers as the unsharded batch
  * (SURVEY.md §8(e)).  Replaces the reference's per-reset reseeding of numpy's global RandomState from

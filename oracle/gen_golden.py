@@ -133,7 +133,7 @@ def gen_anymdp_one(name, task, n_tuples=4096, n_traj=1536, seed0=1000):
                ss_term=ss_term,
                tr_a=tr_a, tr_u=tr_u, tr_z=tr_z, tr_ur=tr_ur, tr_obs=tr_obs, tr_r=tr_r, tr_rgt=tr_rgt,
                tr_term=tr_term, tr_trunc=tr_trunc, tr_steps=tr_steps, tr_state=tr_state,
-               tr_reset_obs=tr_reset_obs, tr_tgt=tr_tgt, tr_set_steps=tr_set_steps,
+               tr_reset_obs=tr_reset_obs, tr_tgt=tr_tgt[:256], tr_set_steps=tr_set_steps,
                init_u=np.float64(init_u), init_state=np.int64(init_state), init_obs=np.int64(obs0))
     path = os.path.join(GOLD, name + ".npz")
     np.savez_compressed(path, **out)

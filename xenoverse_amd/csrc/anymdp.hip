@@ -20,7 +20,22 @@
 #include "philox.h"
 #include "xv_common.h"
 
+// One 64-byte line per task holding everything a step needs besides the CDF row and the reward pair, so that
+// it is fetched by ONE load issued together with the rows (fast path: S <= 64, s0_max <= 4).  Built once at
+// create time from the ABI arrays.  Cuts the dependent-load chain of a step from six round trips to three:
+// [per-env words] -> [header + 64 rows] -> [reward pair + obs id].
+struct __attribute__((aligned(64))) AnyMDPHdr {
+  uint64_t term_mask;    // bit s set <=> s terminal
+  int32_t max_steps;
+  uint32_t s0_ids;       // 4 x u8 inner-state ids of s_0 (padded with the last)
+  uint64_t s0_obs;       // 4 x u16 observation ids of those states: reset needs no state_map gather
+  double s0_cdf[4];      // inclusive CDF of s_0_prob padded with 1.0
+  uint64_t pad;
+};
+static_assert(sizeof(AnyMDPHdr) == 64, "header must be one 64-byte line");
+
 struct AnyMDPArgs {
+  const AnyMDPHdr* hdr;  // engine-owned, nullptr when the fast path does not apply
   // borrowed task tables
   const double* cdf;
   const float2* rs;
@@ -79,7 +94,8 @@ __device__ __forceinline__ double xv_readlane_f64(double v, int lane) {
 enum { SEARCH_GENERIC = 0, SEARCH_W64 = 1 };
 
 // T_steps == 1: one vector step.  T_steps > 1: fused rollout, io arrays are [T][n_env], mode SAME_STEP.
-template <bool INJECT, int SEARCH>
+// HDR: per-task scalars come from the packed 64-B header (S <= 64, s0_max <= 4) instead of five arrays.
+template <bool INJECT, int SEARCH, bool HDR, bool ROLLOUT>
 __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPStepIO io, int T_steps,
                                                           int mode) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,18 +104,32 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
   const int lane = threadIdx.x & 63;
   const int S = P.S, A = P.A;
 
+  // round trip 1: per-env words (coalesced)
   const int t = P.env_task[ic];
   int s = P.state[ic];
   int steps = P.steps[ic];
   int nr = P.need_reset[ic];
-  const int max_steps = P.max_steps[t];
-  const uint64_t tm0 = P.term_mask[(size_t)t * P.words];
+  int a_next = io.action[ic];
+
+  // round trip 2 (issued with the rows below): per-task scalars
+  AnyMDPHdr H;
+  int max_steps;
+  uint64_t tm0;
+  if (HDR) {
+    H = P.hdr[t];
+    max_steps = H.max_steps;
+    tm0 = H.term_mask;
+  } else {
+    max_steps = P.max_steps[t];
+    tm0 = P.term_mask[(size_t)t * P.words];
+  }
   const uint64_t gid = P.gid_base + (uint64_t)ic;
   uint32_t err = 0;
 
-  for (int ts = 0; ts < T_steps; ++ts) {
+  const int T = ROLLOUT ? T_steps : 1;   // single step: straight-line code, counted vmcnt waits
+  for (int ts = 0; ts < T; ++ts) {
     const size_t o = (size_t)ts * P.n_env + ic;
-    int a = io.action[o];
+    int a = a_next;
     if (a < 0 || a >= A) {  // reference: assert action < self.na (:97)
       if (!(mode == XV_AUTORESET_NEXT_STEP && nr)) err |= XV_DEVERR_ACTION_RANGE;
       a = a < 0 ? 0 : A - 1;
@@ -119,17 +149,21 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       // before issuing the rest (three HBM round trips instead of one)
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (ROLLOUT && ts + 1 < T) a_next = io.action[o + P.n_env];   // prefetch behind the rows
 
     // ---- random inputs ----
-    double u, u_reset = 0.0;
+    double u, u_reset;
     float z;
     if (INJECT) {
       u = io.u[o];
       z = io.z[o];
+      u_reset = io.u_reset[o];
     } else {
       const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick + (uint64_t)ts, XV_DRAW_STEP);
       u = xv_u53(w.x, w.y);
       z = xv_normal1(w.z, w.w);
+      const xv_u32x4 v = xv_env_draw(P.seed, gid, P.tick + (uint64_t)ts, XV_DRAW_RESET);
+      u_reset = xv_u53(v.x, v.y);
     }
 
     // ---- s' = upper_bound(cdf[s,a,:], u)   (:99-100, numpy.random.choice) ----
@@ -159,7 +193,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       s2 = lo < S - 1 ? lo : S - 1;
     }
 
-    // ---- dependent gathers on s' ----
+    // ---- round trip 3: dependent gathers on s' ----
     const float2 rsv = P.rs[(size_t)rowidx * S + s2];          // :103-104
     const int obs2 = P.state_map[(size_t)t * S + s2];          // :146-148
     const bool term2 = anymdp_is_term(P, t, tm0, s2);          // :107-108
@@ -195,16 +229,18 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       }
     }
     if (do_reset) {                                            // reset(): :85-90
-      if (INJECT) {
-        u_reset = io.u_reset[o];
+      if (HDR) {
+        // upper_bound over the 4 padded CDF entries; ids and obs ids come packed in the header
+        const int k = (int)(H.s0_cdf[0] <= u_reset) + (int)(H.s0_cdf[1] <= u_reset) +
+                      (int)(H.s0_cdf[2] <= u_reset);
+        s = (int)((H.s0_ids >> (8 * k)) & 0xFFu);
+        o_obs = (int)((H.s0_obs >> (16 * k)) & 0xFFFFull);
       } else {
-        const xv_u32x4 v = xv_env_draw(P.seed, gid, P.tick + (uint64_t)ts, XV_DRAW_RESET);
-        u_reset = xv_u53(v.x, v.y);
+        s = anymdp_draw_s0(P, t, u_reset);
+        o_obs = P.state_map[(size_t)t * S + s];
       }
-      s = anymdp_draw_s0(P, t, u_reset);
       steps = 0;
       nr = 0;
-      o_obs = P.state_map[(size_t)t * S + s];
     }
     if (valid) {
       io.obs[o] = o_obs;
@@ -221,6 +257,28 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
     P.need_reset[i] = (uint8_t)nr;
   }
   if (err) atomicOr(P.err, err);
+}
+
+// packs the per-task scalars into 64-byte headers (once, at create time)
+__global__ __launch_bounds__(256) void anymdp_pack_hdr_kernel(AnyMDPArgs P, AnyMDPHdr* hdr) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P.n_task) return;
+  AnyMDPHdr h;
+  h.term_mask = P.term_mask[t];
+  h.max_steps = P.max_steps[t];
+  uint32_t ids = 0;
+  uint64_t obs = 0;
+  for (int k = 0; k < 4; ++k) {
+    const int kk = k < P.s0_max ? k : P.s0_max - 1;
+    const int sid = P.s0_ids[(size_t)t * P.s0_max + kk];
+    ids |= (uint32_t)(sid & 0xFF) << (8 * k);
+    obs |= (uint64_t)(P.state_map[(size_t)t * P.S + sid] & 0xFFFF) << (16 * k);
+    h.s0_cdf[k] = k < P.s0_max ? P.s0_cdf[(size_t)t * P.s0_max + k] : 1.0;
+  }
+  h.s0_ids = ids;
+  h.s0_obs = obs;
+  h.pad = 0;
+  hdr[t] = h;
 }
 
 template <bool INJECT>
@@ -286,8 +344,12 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
   a.s0_cdf = s0_cdf; a.s0_ids = s0_ids; a.max_steps = max_steps; a.env_task = env_task;
   a.n_env = n_env; a.n_task = n_task; a.S = S; a.A = A; a.s0_max = s0_max; a.words = (S + 63) / 64;
   a.err = e->d_err;
-  a.state = nullptr; a.steps = nullptr; a.need_reset = nullptr;
+  a.state = nullptr; a.steps = nullptr; a.need_reset = nullptr; a.hdr = nullptr;
+  a.seed = e->seed; a.gid_base = e->env_id_base; a.tick = 0;
+  AnyMDPHdr* hdr = nullptr;
+  const bool use_hdr = (S <= 64 && s0_max <= 4);
   hipError_t m = hipMalloc(&a.state, sizeof(int32_t) * (size_t)n_env);
+  if (m == hipSuccess && use_hdr) m = hipMalloc(&hdr, sizeof(AnyMDPHdr) * (size_t)n_task);
   if (m == hipSuccess) m = hipMalloc(&a.steps, sizeof(int32_t) * (size_t)n_env);
   if (m == hipSuccess) m = hipMalloc(&a.need_reset, (size_t)n_env);
   if (m == hipSuccess) m = hipMemsetAsync(a.state, 0, sizeof(int32_t) * (size_t)n_env, e->stream);
@@ -298,8 +360,13 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
     if (a.state) hipFree(a.state);
     if (a.steps) hipFree(a.steps);
     if (a.need_reset) hipFree(a.need_reset);
+    if (hdr) hipFree(hdr);
     delete h;
     return XV_ERR_HIP;
+  }
+  if (use_hdr) {
+    hipLaunchKernelGGL(anymdp_pack_hdr_kernel, dim3(xv_div_up(n_task, 256)), dim3(256), 0, e->stream, a, hdr);
+    a.hdr = hdr;
   }
   *out = h;
   return XV_OK;
@@ -312,6 +379,7 @@ extern "C" int xv_anymdp_destroy(xv_anymdp* h) {
   hipFree(h->a.state);
   hipFree(h->a.steps);
   hipFree(h->a.need_reset);
+  if (h->a.hdr) hipFree((void*)h->a.hdr);
   delete h;
   return XV_OK;
 }
@@ -344,11 +412,18 @@ extern "C" int xv_anymdp_reset_injected(xv_anymdp* h, const uint8_t* mask, const
 template <bool INJECT>
 static int anymdp_launch_step(xv_anymdp* h, const AnyMDPStepIO& io, int T, int mode) {
   const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
-  if (h->a.S == 64) {
-    hipLaunchKernelGGL((anymdp_step_kernel<INJECT, SEARCH_W64>), grid, block, 0, h->eng->stream, h->a, io, T, mode);
+#define XV_LAUNCH_STEP(SEARCH, HDR, ROLL)                                                          \
+  hipLaunchKernelGGL((anymdp_step_kernel<INJECT, SEARCH, HDR, ROLL>), grid, block, 0, h->eng->stream, \
+                     h->a, io, T, mode)
+  const bool roll = T > 1;
+  if (h->a.S == 64 && h->a.hdr) {
+    if (roll) XV_LAUNCH_STEP(SEARCH_W64, true, true); else XV_LAUNCH_STEP(SEARCH_W64, true, false);
+  } else if (h->a.hdr) {
+    if (roll) XV_LAUNCH_STEP(SEARCH_GENERIC, true, true); else XV_LAUNCH_STEP(SEARCH_GENERIC, true, false);
   } else {
-    hipLaunchKernelGGL((anymdp_step_kernel<INJECT, SEARCH_GENERIC>), grid, block, 0, h->eng->stream, h->a, io, T, mode);
+    if (roll) XV_LAUNCH_STEP(SEARCH_GENERIC, false, true); else XV_LAUNCH_STEP(SEARCH_GENERIC, false, false);
   }
+#undef XV_LAUNCH_STEP
   XV_LAUNCH_CHECK();
   return XV_OK;
 }

@@ -31,8 +31,8 @@ extern "C" int xv_engine_create(int device, uint64_t seed, uint64_t env_id_base,
   e->seed = seed;
   e->env_id_base = env_id_base;
   e->tick = 0;
-  e->own_stream = (hip_stream == nullptr);
-  e->stream = (hipStream_t)hip_stream;
+  e->own_stream = (hip_stream == XV_STREAM_OWN);
+  e->stream = e->own_stream ? nullptr : (hipStream_t)hip_stream;
   e->d_err = nullptr;
   if (e->own_stream) {
     hipError_t s = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
