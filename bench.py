@@ -5,8 +5,8 @@
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Workload = BASELINE.json configs[1]: anymdp |S|=64, |A|=8, 65,536 envs per GPU, synthetic tasks generated on
-the device.  Default task sharing is "distinct" (2a: one task per env, 48 GiB of
-tables per GPU, every CDF row read misses every cache); --tasks 1024 gives "shared" (2b).
+the device.  Default task sharing is "distinct" (2a: one task per env, 32 GiB of
+tables per GPU, every table read misses every cache); --tasks 1024 gives "shared" (2b).
 A "step" is one vector step of all envs of a rank = one launch of the step kernel; K steps are K back-to-back
 launches (xv_anymdp_step_many), auto-reset SAME_STEP, actions pre-generated on the device.
 
@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-allgather", action="store_true",
                     help="N>1: skip the RCCL all-gather of rollout chunks (pure replicas)")
+    ap.add_argument("--search", default="auto", choices=["auto", "binary", "fence"])
     ap.add_argument("--fused", action="store_true", help="also time the fused T-step rollout kernel")
     return ap.parse_args()
 
@@ -47,9 +48,9 @@ def parse():
 def make_tables(eng, torch, _lib, n_task, task_base, seed, S=64, A=8, s0_max=4):
     d = eng.device
     words = (S + 63) // 64
+    NB = (S + 15) // 16
     t = dict(S=S, A=A, s0_max=s0_max,
-             cdf=torch.empty((n_task, S, A, S), dtype=torch.float64, device=d),
-             rs=torch.empty((n_task, S, A, S, 2), dtype=torch.float32, device=d),
+             rows=torch.empty((n_task, S, A, NB, 32), dtype=torch.float64, device=d),
              state_map=torch.empty((n_task, S), dtype=torch.int32, device=d),
              term_mask=torch.empty((n_task, words), dtype=torch.int64, device=d),
              s0_cdf=torch.empty((n_task, s0_max), dtype=torch.float64, device=d),
@@ -57,7 +58,7 @@ def make_tables(eng, torch, _lib, n_task, task_base, seed, S=64, A=8, s0_max=4):
              max_steps=torch.empty(n_task, dtype=torch.int32, device=d))
     _lib.check(eng.lib.xv_anymdp_synth_tasks(
         eng.handle, seed, task_base, n_task, S, A, s0_max,
-        *[_lib.ptr(t[k]) for k in ("cdf", "rs", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")]))
+        *[_lib.ptr(t[k]) for k in ("rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")]))
     eng.sync()
     return t
 
@@ -121,6 +122,8 @@ def main():
     per = n_env // n_task
     env_task = (torch.arange(n_env, device=env.device, dtype=torch.int32) // per).contiguous()
     env.set_task(tab, env_task_index=env_task)
+    env.set_search(args.search)
+    search = {"auto": "fence"}.get(args.search, args.search)
     P = args.period
     g = torch.Generator(device=env.device)
     g.manual_seed(args.seed + 17 * rank)
@@ -212,11 +215,12 @@ def main():
                        "envs_per_gpu": n_env, "tasks_per_gpu": n_task, "S": S, "A": A,
                        "table_gib_per_gpu": round(n_task * S * A * S * 16 / 2**30, 2),
                        "launch": "one step kernel per vector step (xv_anymdp_step_many)",
+                       "search": search,
                        "exchange": ("all_gather of %d-step rollout chunks (RCCL)" % P) if do_gather else "none",
                        "device_error_flags": errs},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "anymdp_step_kernel<false,W64>", "avg_launch_us": kern_us,
+                         "kernel": "anymdp_step_kernel<search=%s>" % search, "avg_launch_us": kern_us,
                          "algorithmic_bytes_per_launch": algo},
         }
         if fused is not None:

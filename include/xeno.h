@@ -91,11 +91,15 @@ int xv_philox4x32_10(xv_engine* e, const uint32_t* ctr, const uint32_t* key, uin
  *   reset     :81-90   -> xv_anymdp_reset
  *   step      :112-132 -> xv_anymdp_step / _step_injected   (single_step :92-110, get_observation :145-159)
  *
- * Table layout (all row-major, device memory, borrowed):
- *   cdf        double [n_task][S][A][S]   inclusive CDF of transition[s,a,:], i.e. cumsum(row)/cumsum(row)[-1]
- *                                         computed on the host in fp64 exactly as numpy.random.choice does
- *                                         (rows of terminal states, all-zero in the reference, hold 1.0)
- *   rs         float2 [n_task][S][A][S]   {reward[s,a,s'], reward_noise[s,a,s']} interleaved
+ * Table layout (device memory, borrowed):
+ *   rows       [n_task][S][A][NB] blocks of 256 bytes, NB = ceil(S/16).  Block b of row (t,s,a) holds
+ *                double cdf[16]   entries 16b..16b+15 of the inclusive CDF of transition[s,a,:], i.e.
+ *                                 cumsum(row)/cumsum(row)[-1] computed on the host in fp64 exactly as
+ *                                 numpy.random.choice does (entries >= S hold 2.0; rows of terminal
+ *                                 states, all-zero in the reference, hold 1.0)
+ *                float2 rs[16]    {reward[s,a,s'], reward_noise[s,a,s']} of the same 16 next states
+ *              so the one 256-B record that decides s' also carries its reward: no dependent gather.
+ *              xenoverse_amd.anymdp.tables.to_blocked builds it from the reference's task arrays.
  *   state_map  int32  [n_task][S]         inner state -> observation id (task["state_mapping"])
  *   term_mask  uint64 [n_task][(S+63)/64] bit s set <=> s in task["s_e"]
  *   s0_cdf     double [n_task][s0_max]    inclusive CDF of task["s_0_prob"] (padded with 1.0)
@@ -105,7 +109,7 @@ int xv_philox4x32_10(xv_engine* e, const uint32_t* ctr, const uint32_t* key, uin
  * Supported: 2 <= S <= 256, 2 <= A <= 64, 1 <= s0_max <= 256.
  * ---------------------------------------------------------------------------------------------- */
 int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int A, int s0_max,
-                     const double* cdf, const float* rs, const int32_t* state_map,
+                     const void* rows, const int32_t* state_map,
                      const uint64_t* term_mask, const double* s0_cdf, const int32_t* s0_ids,
                      const int32_t* max_steps, const int32_t* env_task, xv_anymdp** out);
 int xv_anymdp_destroy(xv_anymdp* h);
@@ -148,6 +152,18 @@ int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const int32_t* ac
 int xv_anymdp_rollout(xv_anymdp* h, int T, const int32_t* actions, int32_t* obs, float* reward,
                       float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs);
 
+/* How s' = upper_bound(cdf row, u) is evaluated; both modes return the same index (parity-tested).
+ *   AUTO    FENCE when available (S <= 64, s0_max <= 4, observation ids < 256), else BINARY
+ *   BINARY  per-lane binary search over the row's CDF entries in global memory (any S), then a
+ *           dependent read of the reward pair
+ *   FENCE   a 32-B fence record per row (the last CDF entry of blocks 0..2; table built at create time)
+ *           selects the ONE 256-B block that is read — by 16 lanes, coalesced — and counted with a
+ *           compare + ballot + popcount; the reward pair comes out of the same block */
+#define XV_ANYMDP_SEARCH_AUTO 0
+#define XV_ANYMDP_SEARCH_BINARY 1
+#define XV_ANYMDP_SEARCH_FENCE 3
+int xv_anymdp_set_search(xv_anymdp* h, int search);
+
 /* env.inner_state / env.steps accessors (anymdp_env.py:138-143); device int32[n_env] each, nullable */
 int xv_anymdp_get_state(xv_anymdp* h, int32_t* inner_state, int32_t* steps, uint8_t* need_reset);
 int xv_anymdp_set_state(xv_anymdp* h, const int32_t* inner_state, const int32_t* steps,
@@ -158,11 +174,11 @@ int xv_anymdp_set_state(xv_anymdp* h, const int32_t* inner_state, const int32_t*
 int xv_anymdp_transition_gt(xv_anymdp* h, const int32_t* action, double* out);
 
 /* Synthetic task tables written directly in device memory (bench / stress configs whose tables exceed
- * host memory: 65,536 distinct tasks of S=64, A=8 are 48 GiB).  Deterministic in (seed, task index);
+ * host memory: 65,536 distinct tasks of S=64, A=8 are 32 GiB).  Deterministic in (seed, task index);
  * restated bit-for-bit by oracle/xeno_oracle.c: xo_anymdp_synth.  Band-limited rows as produced by the
  * reference sampler's sample_transition (task_sampler_utils.py:65-175), uniform weights. */
 int xv_anymdp_synth_tasks(xv_engine* e, uint64_t seed, int64_t task_index_base, int n_task, int S, int A,
-                          int s0_max, double* cdf, float* rs, int32_t* state_map, uint64_t* term_mask,
+                          int s0_max, void* rows, int32_t* state_map, uint64_t* term_mask,
                           double* s0_cdf, int32_t* s0_ids, int32_t* max_steps);
 
 #ifdef __cplusplus

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import oracle
-from xenoverse_amd.anymdp import AnyMDPVecEnv, build_tables
+from xenoverse_amd.anymdp import AnyMDPVecEnv, build_tables, to_blocked
 from util import close_f32, golden_files, load_anymdp_golden
 
 pytestmark = pytest.mark.gpu
@@ -20,7 +20,8 @@ def _np(t):
 
 def _dev_tables(tab, dev="cuda:0"):
     out = dict(S=tab["S"], A=tab["A"], s0_max=tab["s0_max"])
-    for k in ("cdf", "rs", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps"):
+    tab = dict(tab, rows=to_blocked(tab["cdf"], tab["rs"]))
+    for k in ("rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps"):
         v = np.ascontiguousarray(tab[k])
         if v.dtype == np.uint64:
             v = v.view(np.int64)
@@ -171,8 +172,9 @@ def test_config1_free_running_philox_vs_oracle(mode):
 # ---------------------------------------------------------------------------------------------------
 # S = 64 wave-cooperative kernel (headline shape), synthetic tasks, ragged env count
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("search", ["fence", "binary"])
 @pytest.mark.parametrize("n_env,n_task", [(2048, 32), (1000, 8), (64, 64), (37, 3)])
-def test_s64_wave_kernel_vs_oracle(n_env, n_task):
+def test_s64_wave_kernel_vs_oracle(n_env, n_task, search):
     tab = oracle.anymdp_synth(seed=99, task_index_base=5, n_task=n_task, S=64, A=8, s0_max=4)
     env_task = (np.arange(n_env) * n_task // n_env).astype(np.int32)
     rng = np.random.RandomState(n_env)
@@ -180,6 +182,7 @@ def test_s64_wave_kernel_vs_oracle(n_env, n_task):
     seed = 4242
     env = AnyMDPVecEnv(n_env, autoreset_mode="same_step", seed=seed)
     env.set_task(_dev_tables(tab), env_task_index=env_task)
+    env.set_search(search)
     ora = oracle.AnyMDPOracle(tab, env_task)
     tick = env.engine.tick
     obs, _ = env.reset()
@@ -232,27 +235,48 @@ def test_device_synth_generator_bit_exact(S, A, n_task, s0_max):
     ref = oracle.anymdp_synth(seed=31337, task_index_base=1000, n_task=n_task, S=S, A=A, s0_max=s0_max)
     d = "cuda:0"
     words = (S + 63) // 64
-    t = dict(cdf=torch.empty((n_task, S, A, S), dtype=torch.float64, device=d),
-             rs=torch.empty((n_task, S, A, S, 2), dtype=torch.float32, device=d),
+    NB = (S + 15) // 16
+    t = dict(rows=torch.empty((n_task, S, A, NB, 32), dtype=torch.float64, device=d),
              state_map=torch.empty((n_task, S), dtype=torch.int32, device=d),
              term_mask=torch.empty((n_task, words), dtype=torch.int64, device=d),
              s0_cdf=torch.empty((n_task, s0_max), dtype=torch.float64, device=d),
              s0_ids=torch.empty((n_task, s0_max), dtype=torch.int32, device=d),
              max_steps=torch.empty(n_task, dtype=torch.int32, device=d))
     _lib.check(eng.lib.xv_anymdp_synth_tasks(eng.handle, 31337, 1000, n_task, S, A, s0_max, *[_lib.ptr(t[k]) for k in
-               ("cdf", "rs", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")]))
+               ("rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")]))
     eng.sync()
+    ref = dict(ref, rows=to_blocked(ref["cdf"], ref["rs"]))
     for k in t:
         got = _np(t[k])
         exp = ref[k].view(np.int64) if ref[k].dtype == np.uint64 else ref[k]
-        assert np.array_equal(got, exp), k
+        if k == "rows":   # bit-exact, including the float pairs viewed as 8-byte words
+            assert np.array_equal(got.view(np.int64), exp.view(np.int64)), k
+        else:
+            assert np.array_equal(got, exp), k
+    from xenoverse_amd.anymdp import from_blocked
+    c, _ = from_blocked(_np(t["rows"]), S)
     # structural properties of every row: monotone CDF ending in exactly 1.0
-    c = _np(t["cdf"])
     assert np.all(np.diff(c, axis=-1) >= 0) and np.all(c[..., -1] == 1.0)
     eng.close()
 
 
-def test_fused_rollout_equals_stepwise():
+@pytest.mark.parametrize("search", ["fence", "binary"])
+def test_golden_64x8_tuples_all_search_modes(search):
+    g, task = load_anymdp_golden([f for f in FILES if "64x8" in f][0])
+    n = len(g["ss_s"])
+    env = AnyMDPVecEnv(n, autoreset_mode="disabled")
+    env.set_task(task)
+    env.set_search(search)
+    env.set_state(inner_state=g["ss_s"], steps=np.zeros(n), need_reset=np.zeros(n))
+    obs, r, term, trunc, info = env.step_injected(g["ss_a"], g["ss_u"], g["ss_z"], np.zeros(n))
+    assert np.array_equal(_np(env.inner_state), g["ss_next"])
+    assert np.array_equal(_np(term).astype(np.uint8), g["ss_term"])
+    assert close_f32(_np(r), g["ss_r"])
+    env.close()
+
+
+@pytest.mark.parametrize("search", ["fence", "binary"])
+def test_fused_rollout_equals_stepwise(search):
     tab = oracle.anymdp_synth(seed=3, task_index_base=0, n_task=16, S=64, A=8, s0_max=4)
     n_env, T = 1024, 48
     env_task = np.repeat(np.arange(16, dtype=np.int32), 64)
@@ -261,6 +285,7 @@ def test_fused_rollout_equals_stepwise():
     for fused in (False, True):
         env = AnyMDPVecEnv(n_env, autoreset_mode="same_step", seed=77)
         env.set_task(_dev_tables(tab), env_task_index=env_task)
+        env.set_search(search)
         env.reset()
         if fused:
             o = env.rollout(acts)

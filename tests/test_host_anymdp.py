@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from xenoverse_amd.anymdp.tables import build_tables, row_cdf, validate_task
+from xenoverse_amd.anymdp.tables import build_tables, from_blocked, row_cdf, to_blocked, validate_task
 from util import golden_files, load_anymdp_golden
 
 
@@ -59,3 +59,23 @@ def test_mixed_action_spaces_rejected():
     t2["na"] = 5
     with pytest.raises(ValueError):
         build_tables([t, t2], validate=False)
+
+
+@pytest.mark.parametrize("S", [8, 16, 20, 64, 100, 256])
+def test_blocked_row_layout(S):
+    """include/xeno.h "rows": block b = 16 fp64 CDF entries then 16 {reward, noise} float pairs"""
+    rng = np.random.RandomState(S)
+    cdf = np.sort(rng.random_sample((2, 3, S)), axis=-1)
+    rs = rng.standard_normal((2, 3, S, 2)).astype(np.float32)
+    rows = to_blocked(cdf, rs)
+    NB = (S + 15) // 16
+    assert rows.shape == (2, 3, NB, 32) and rows.dtype == np.float64
+    raw = rows.reshape(2, 3, NB * 256 // 8).view(np.uint8).reshape(2, 3, NB, 256)
+    for j in sorted({0, 1, min(15, S - 1), S // 2, S - 1}):
+        b, q = divmod(j, 16)
+        assert np.array_equal(raw[..., b, 8 * q:8 * q + 8].copy().view(np.float64)[..., 0], cdf[..., j])
+        assert np.array_equal(raw[..., b, 128 + 8 * q:128 + 8 * q + 8].copy().view(np.float32), rs[..., j, :])
+    if S % 16:
+        assert np.all(rows[..., NB - 1, S % 16:16] == 2.0)      # padding never compares <= u
+    c2, r2 = from_blocked(rows, S)
+    assert np.array_equal(c2, cdf) and np.array_equal(r2, rs)

@@ -24,7 +24,7 @@ SIGNATURES = {
     "xv_engine_get_tick": [c_void_p, C.POINTER(c_u64)],
     "xv_engine_set_tick": [c_void_p, c_u64],
     "xv_philox4x32_10": [c_void_p, c_void_p, c_void_p, c_void_p, c_int],
-    "xv_anymdp_create": [c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 8 + [C.POINTER(c_void_p)],
+    "xv_anymdp_create": [c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 7 + [C.POINTER(c_void_p)],
     "xv_anymdp_destroy": [c_void_p],
     "xv_anymdp_reset": [c_void_p, c_void_p, c_void_p],
     "xv_anymdp_reset_injected": [c_void_p, c_void_p, c_void_p, c_void_p],
@@ -32,10 +32,11 @@ SIGNATURES = {
     "xv_anymdp_step_injected": [c_void_p] + [c_void_p] * 10 + [c_int],
     "xv_anymdp_step_many": [c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int],
     "xv_anymdp_rollout": [c_void_p, c_int] + [c_void_p] * 7,
+    "xv_anymdp_set_search": [c_void_p, c_int],
     "xv_anymdp_get_state": [c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_anymdp_set_state": [c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_anymdp_transition_gt": [c_void_p, c_void_p, c_void_p],
-    "xv_anymdp_synth_tasks": [c_void_p, c_u64, c_i64, c_int, c_int, c_int, c_int] + [c_void_p] * 7,
+    "xv_anymdp_synth_tasks": [c_void_p, c_u64, c_i64, c_int, c_int, c_int, c_int] + [c_void_p] * 6,
 }
 _RESTYPE = {"xv_last_error": C.c_char_p, "xv_engine_stream": c_void_p}
 

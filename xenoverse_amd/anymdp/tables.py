@@ -4,7 +4,8 @@ Reference: `AnyMDPEnv.set_task` (xenoverse/anymdp/anymdp_env.py:32-79) copies ev
 onto the env object and validates it; `single_step` (:99-100) then calls `numpy.random.choice(n, p=row)`
 each step, which internally forms `cdf = cumsum(row); cdf /= cdf[-1]` and searches it.  Here that CDF is
 formed ONCE per task, on the host, in fp64 with numpy's own cumsum/divide so that every bit equals what
-`choice` would compute, and laid out for the device (layout: include/xeno.h, "AnyMDP").
+`choice` would compute, and laid out for the device (layout: include/xeno.h, "AnyMDP": rows blocked by 16
+next states, each 256-byte block carrying its CDF entries and its {reward, noise} pairs).
 
 Task dict schema: ns, na, max_steps (float), state_mapping int[n], task_type,
 s_0 int[k], s_0_prob f64[k], s_e int[m], transition/reward/reward_noise f64[n,na,n].
@@ -50,6 +51,37 @@ def row_cdf(T):
         c = c / np.where(zero, 1.0, last)
     c = np.where(zero, 1.0, c)
     return c
+
+
+def to_blocked(cdf, rs):
+    """Flat per-row arrays -> the device's blocked row layout (include/xeno.h, "rows").
+
+    cdf float64[..., S], rs float32[..., S, 2]  ->  float64[..., NB, 32] with NB = ceil(S/16): block b holds
+    the 16 CDF entries 16b..16b+15 (8-byte words 0..15; entries >= S are 2.0, never <= u) followed by the 16
+    {reward, noise} float pairs of the same next states (words 16..31, two floats per word)."""
+    cdf = np.asarray(cdf, np.float64)
+    rs = np.asarray(rs, np.float32)
+    S = cdf.shape[-1]
+    NB = (S + 15) // 16
+    lead = cdf.shape[:-1]
+    c = np.full(lead + (NB * 16,), 2.0, np.float64)
+    c[..., :S] = cdf
+    r = np.zeros(lead + (NB * 16, 2), np.float32)
+    r[..., :S, :] = rs
+    out = np.empty(lead + (NB, 32), np.float64)
+    out[..., :16] = c.reshape(lead + (NB, 16))
+    out[..., 16:] = np.ascontiguousarray(r.reshape(lead + (NB, 16, 2))).view(np.float64).reshape(lead + (NB, 16))
+    return out
+
+
+def from_blocked(rows, S):
+    """Inverse of to_blocked: -> (cdf float64[..., S], rs float32[..., S, 2])."""
+    rows = np.ascontiguousarray(rows, np.float64)
+    lead = rows.shape[:-2]
+    NB = rows.shape[-2]
+    cdf = np.ascontiguousarray(rows[..., :16]).reshape(lead + (NB * 16,))[..., :S]
+    rs = np.ascontiguousarray(rows[..., 16:]).view(np.float32).reshape(lead + (NB * 16, 2))[..., :S, :]
+    return cdf, rs
 
 
 def build_tables(tasks, s0_max=None, validate=True):
@@ -104,5 +136,6 @@ def build_tables(tasks, s0_max=None, validate=True):
         # `truncated = steps >= max_steps` with integer steps and a real max_steps (anymdp_env.py:114)
         max_steps[i] = int(min(math.ceil(float(t["max_steps"])), 2**31 - 1))
         obs_space[i] = int(t["ns"])
-    return dict(S=S, A=A, s0_max=int(s0_max), cdf=cdf, rs=rs, state_map=state_map, term_mask=term_mask,
+    return dict(S=S, A=A, s0_max=int(s0_max), cdf=cdf, rs=rs, rows=to_blocked(cdf, rs),
+                state_map=state_map, term_mask=term_mask,
                 s0_cdf=s0_cdf, s0_ids=s0_ids, max_steps=max_steps, obs_space=obs_space)

@@ -15,8 +15,8 @@ from ..spaces import Discrete
 from ..vector import VectorEnv
 from .tables import build_tables
 
-_TABLE_KEYS = ("cdf", "rs", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")
-_TABLE_DTYPES = dict(cdf=torch.float64, rs=torch.float32, state_map=torch.int32, term_mask=torch.int64,
+_TABLE_KEYS = ("rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")
+_TABLE_DTYPES = dict(rows=torch.float64, state_map=torch.int32, term_mask=torch.int64,
                      s0_cdf=torch.float64, s0_ids=torch.int32, max_steps=torch.int32)
 
 
@@ -38,7 +38,7 @@ class AnyMDPVecEnv(VectorEnv):
         """tasks: one reference task dict, a list of them, or a dict of prebuilt tables (numpy arrays or
         device tensors, keys as xenoverse_amd.anymdp.tables.build_tables returns).  env_task_index[i] is
         the task of env i (default: envs split evenly and contiguously over tasks)."""
-        if isinstance(tasks, dict) and "cdf" in tasks:
+        if isinstance(tasks, dict) and "rows" in tasks:
             tab = tasks
         else:
             if isinstance(tasks, dict):
@@ -81,7 +81,7 @@ class AnyMDPVecEnv(VectorEnv):
         h = C.c_void_p()
         _lib.check(self.lib.xv_anymdp_create(
             self.engine.handle, self.num_envs, n_task, S, A, s0_max,
-            _lib.ptr(dev["cdf"]), _lib.ptr(dev["rs"]), _lib.ptr(dev["state_map"]),
+            _lib.ptr(dev["rows"]), _lib.ptr(dev["state_map"]),
             _lib.ptr(dev["term_mask"]), _lib.ptr(dev["s0_cdf"]), _lib.ptr(dev["s0_ids"]),
             _lib.ptr(dev["max_steps"]), _lib.ptr(dev["env_task"]), C.byref(h)))
         self._h = h
@@ -102,6 +102,12 @@ class AnyMDPVecEnv(VectorEnv):
         self._tgt = torch.zeros((n, S), dtype=torch.float64, device=d) if self.with_transition_gt else None
         self.task_set = True
         self.need_reset = True
+
+    SEARCH = {"auto": 0, "binary": 1, "fence": 3}
+
+    def set_search(self, mode):
+        """Select how the categorical draw searches the CDF row (results are identical; see xeno.h)."""
+        _lib.check(self.lib.xv_anymdp_set_search(self._h, self.SEARCH[mode]))
 
     # ---- reset ------------------------------------------------------------------------------------
     def reset(self, *, seed=None, options=None):

@@ -3,42 +3,45 @@
 // Reproduces xenoverse/anymdp/anymdp_env.py: reset :81-90, single_step :92-110, step :112-132,
 // get_observation :145-159 (MDP branch), per env, for N envs per launch.  One wavefront lane owns one env.
 //
-// Data movement per env-step (fp64 CDF, S = 64): one 512-B CDF row, one 8-B {reward, noise} pair, a few
-// coalesced per-env words.  The row read is the whole cost, so the kernel is built around it:
+// A step is a chain of DEPENDENT memory round trips (state -> which row -> which next state -> its reward
+// and observation); at 65,536 envs per launch the kernel lives or dies by the length of that chain and by
+// the bytes each link moves.  Layout and kernel are built to make it three links:
 //
-//   * search mode W64 (S == 64): a wave owns 64 envs.  For env e of the wave the row cdf[t,s,a,:] is read
-//     by ALL 64 lanes, one fp64 each — a single coalesced 512-B global_load_dwordx2 with a scalar base.
-//     All 64 row loads of the wave are issued back to back (32 KiB in flight per wave, 128 KiB per CU), then
-//     each row is searched with one v_cmp_le_f64 against the broadcast uniform, a 64-bit ballot and a
-//     popcount:  s' = popcount(cdf[j] <= u) = numpy.searchsorted(cdf, u, 'right').  The rows live in
-//     registers; no LDS round trip and no per-lane dependent probe chain.
-//   * search mode GENERIC (any S <= 256): per-lane binary search straight from global memory
-//     (ceil(log2 S)+1 dependent probes).
+//   1. per-env words (state, steps, action, task id): struct-of-arrays, coalesced dword streams.
+//   2. per row (t,s,a) a 32-B FENCE record = the last CDF entry of blocks 0..2 of the row, and per task a
+//      128-B HEADER (terminal mask, max_steps, the s_0 distribution with its observation ids, and the 64
+//      observation ids as bytes).  k = #{fences <= u} names the one 16-entry block that contains s'
+//      (the CDF is non-decreasing, so blocks < k are entirely <= u and blocks > k entirely > u).
+//   3. that ONE 256-B block: 16 fp64 CDF entries + the 16 {reward, noise} pairs of the same next states
+//      (include/xeno.h, "rows").  It is read by 16 lanes, coalesced — a wave fetches the blocks of 4 envs per
+//      load instruction and keeps 16 such loads in flight — and searched with one v_cmp_le_f64 against the
+//      env's uniform, a 64-bit ballot and a 16-bit popcount:  s' = 16k + popcount(cdf[j] <= u), which is
+//      numpy.searchsorted(cdf, u, 'right').  The reward pair is taken from the same registers with a
+//      ds_bpermute; the observation id is a byte of the header.  No dependent gather follows.
 //
-// The per-env arrays are struct-of-arrays (lane i reads word i): every access other than the row and the
-// reward pair is a coalesced dword/byte stream.
+// Per env-step that is 32 + 256 + 128 B of table reads instead of the 512-B row + 4 gathers of a flat layout.
+// BINARY mode (any S <= 256, any s0 table) is the general per-lane fallback.
 #include "philox.h"
 #include "xv_common.h"
 
-// One 64-byte line per task holding everything a step needs besides the CDF row and the reward pair, so that
-// it is fetched by ONE load issued together with the rows (fast path: S <= 64, s0_max <= 4).  Built once at
-// create time from the ABI arrays.  Cuts the dependent-load chain of a step from six round trips to three:
-// [per-env words] -> [header + 64 rows] -> [reward pair + obs id].
-struct __attribute__((aligned(64))) AnyMDPHdr {
+// One 128-byte line per task (fast path: S <= 64, s0_max <= 4, observation ids < 256); built at create time.
+struct __attribute__((aligned(128))) AnyMDPHdr {
   uint64_t term_mask;    // bit s set <=> s terminal
   int32_t max_steps;
   uint32_t s0_ids;       // 4 x u8 inner-state ids of s_0 (padded with the last)
-  uint64_t s0_obs;       // 4 x u16 observation ids of those states: reset needs no state_map gather
+  uint32_t s0_obs;       // 4 x u8 observation ids of those states
+  uint32_t pad0;
   double s0_cdf[4];      // inclusive CDF of s_0_prob padded with 1.0
-  uint64_t pad;
+  uint64_t pad1;
+  uint32_t obs[16];      // 64 x u8: observation id of inner state s (state_mapping)
 };
-static_assert(sizeof(AnyMDPHdr) == 64, "header must be one 64-byte line");
+static_assert(sizeof(AnyMDPHdr) == 128, "header must be one 128-byte line");
 
 struct AnyMDPArgs {
   const AnyMDPHdr* hdr;  // engine-owned, nullptr when the fast path does not apply
+  const double* fence;   // engine-owned [n_rows][4] (S <= 64), nullptr otherwise
   // borrowed task tables
-  const double* cdf;
-  const float2* rs;
+  const double* rows;    // blocked rows, addressed in 8-byte units: block = 32 units
   const int32_t* state_map;
   const uint64_t* term_mask;
   const double* s0_cdf;
@@ -50,7 +53,7 @@ struct AnyMDPArgs {
   int32_t* steps;
   uint8_t* need_reset;
   uint32_t* err;
-  int n_env, n_task, S, A, s0_max, words;
+  int n_env, n_task, S, A, s0_max, words, NB;
   uint64_t seed, gid_base, tick;
 };
 
@@ -70,6 +73,7 @@ struct AnyMDPStepIO {
 struct xv_anymdp {
   xv_engine* eng;
   AnyMDPArgs a;
+  int search;  // XV_ANYMDP_SEARCH_*
 };
 
 __device__ __forceinline__ bool anymdp_is_term(const AnyMDPArgs& P, int t, uint64_t tm0, int s) {
@@ -85,73 +89,60 @@ __device__ __forceinline__ int anymdp_draw_s0(const AnyMDPArgs& P, int t, double
   return P.s0_ids[(size_t)t * P.s0_max + k];
 }
 
-__device__ __forceinline__ double xv_readlane_f64(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
+// blocked-row accessors: CDF entry j / reward pair j of row r
+__device__ __forceinline__ const double* anymdp_cdf_ptr(const AnyMDPArgs& P, uint32_t r, int j) {
+  return P.rows + ((size_t)r * P.NB + (j >> 4)) * 32 + (j & 15);
+}
+__device__ __forceinline__ float2 anymdp_rs(const AnyMDPArgs& P, uint32_t r, int j) {
+  return reinterpret_cast<const float2*>(P.rows + ((size_t)r * P.NB + (j >> 4)) * 32 + 16)[j & 15];
 }
 
-enum { SEARCH_GENERIC = 0, SEARCH_W64 = 1 };
+__device__ __forceinline__ double xv_shfl_f64(double v, int src) {
+  return __hiloint2double(__shfl(__double2hiint(v), src), __shfl(__double2loint(v), src));
+}
+
+// byte `idx` of a 16-word table held in registers (idx in 0..63): a select chain, no memory access
+__device__ __forceinline__ uint32_t anymdp_hdr_obs(const AnyMDPHdr& H, int idx) {
+  const int w = idx >> 2;
+  uint32_t v = H.obs[0];
+#pragma unroll
+  for (int q = 1; q < 16; ++q) v = (w == q) ? H.obs[q] : v;
+  return (v >> (8 * (idx & 3))) & 0xFFu;
+}
+
+enum { SEARCH_BINARY = 0, SEARCH_FENCE = 1 };
 
 // T_steps == 1: one vector step.  T_steps > 1: fused rollout, io arrays are [T][n_env], mode SAME_STEP.
-// HDR: per-task scalars come from the packed 64-B header (S <= 64, s0_max <= 4) instead of five arrays.
+// HDR: per-task scalars and observation ids come from the packed 128-B header.
 template <bool INJECT, int SEARCH, bool HDR, bool ROLLOUT>
 __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPStepIO io, int T_steps,
                                                           int mode) {
+  static_assert(SEARCH != SEARCH_FENCE || HDR, "the fence path needs the header");
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < P.n_env;
   const int ic = valid ? i : P.n_env - 1;
   const int lane = threadIdx.x & 63;
   const int S = P.S, A = P.A;
 
-  // round trip 1: per-env words (coalesced)
+  // ---- link 1: per-env words (coalesced) ----
   const int t = P.env_task[ic];
   int s = P.state[ic];
   int steps = P.steps[ic];
   int nr = P.need_reset[ic];
   int a_next = io.action[ic];
-
-  // round trip 2 (issued with the rows below): per-task scalars
-  AnyMDPHdr H;
-  int max_steps;
-  uint64_t tm0;
-  if (HDR) {
-    H = P.hdr[t];
-    max_steps = H.max_steps;
-    tm0 = H.term_mask;
-  } else {
-    max_steps = P.max_steps[t];
-    tm0 = P.term_mask[(size_t)t * P.words];
-  }
   const uint64_t gid = P.gid_base + (uint64_t)ic;
   uint32_t err = 0;
+
+  AnyMDPHdr H;
+  int max_steps = 0;
+  uint64_t tm0 = 0;
+  bool hdr_loaded = false;
 
   const int T = ROLLOUT ? T_steps : 1;   // single step: straight-line code, counted vmcnt waits
   for (int ts = 0; ts < T; ++ts) {
     const size_t o = (size_t)ts * P.n_env + ic;
-    int a = a_next;
-    if (a < 0 || a >= A) {  // reference: assert action < self.na (:97)
-      if (!(mode == XV_AUTORESET_NEXT_STEP && nr)) err |= XV_DEVERR_ACTION_RANGE;
-      a = a < 0 ? 0 : A - 1;
-    }
-    const uint32_t rowidx = ((uint32_t)t * S + s) * A + a;
 
-    // ---- issue the row reads first, so that the RNG arithmetic below overlaps their latency ----
-    double rowv[64];
-    if (SEARCH == SEARCH_W64) {
-      const double* lane_base = P.cdf + lane;
-#pragma unroll
-      for (int e = 0; e < 64; ++e) {
-        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rowidx, e);
-        rowv[e] = lane_base[(size_t)r * 64];
-      }
-      // keep all 64 loads ahead of everything below: hipcc otherwise drains the first 8 to vmcnt(0)
-      // before issuing the rest (three HBM round trips instead of one)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (ROLLOUT && ts + 1 < T) a_next = io.action[o + P.n_env];   // prefetch behind the rows
-
-    // ---- random inputs ----
+    // random inputs first: pure ALU, overlaps the latency of link 1
     double u, u_reset;
     float z;
     if (INJECT) {
@@ -166,24 +157,76 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       u_reset = xv_u53(v.x, v.y);
     }
 
-    // ---- s' = upper_bound(cdf[s,a,:], u)   (:99-100, numpy.random.choice) ----
-    int s2 = 0;
-    if (SEARCH == SEARCH_W64) {
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int e = 0; e < 64; ++e) {
-        const double ue = xv_readlane_f64(u, e);
-        const unsigned long long m = __ballot(rowv[e] <= ue);
-        const int cnt = __popcll(m);
-        if (lane == e) s2 = cnt;
+    int a = a_next;
+    if (a < 0 || a >= A) {  // reference: assert action < self.na (:97)
+      if (!(mode == XV_AUTORESET_NEXT_STEP && nr)) err |= XV_DEVERR_ACTION_RANGE;
+      a = a < 0 ? 0 : A - 1;
+    }
+    const uint32_t rowidx = ((uint32_t)t * S + s) * A + a;
+
+    // ---- link 2: fence record of the row (+ the task header, once) ----
+    double f0 = 0, f1 = 0, f2 = 0;
+    if (SEARCH == SEARCH_FENCE) {
+      const double* f = P.fence + (size_t)rowidx * 4;
+      f0 = f[0]; f1 = f[1]; f2 = f[2];
+    }
+    if (!hdr_loaded) {
+      if (HDR) {
+        H = P.hdr[t];
+        max_steps = H.max_steps;
+        tm0 = H.term_mask;
+      } else {
+        max_steps = P.max_steps[t];
+        tm0 = P.term_mask[(size_t)t * P.words];
       }
-      s2 = s2 < 63 ? s2 : 63;
+      hdr_loaded = true;
+    }
+
+    // ---- link 3: s' = upper_bound(cdf[s,a,:], u)   (:99-100, numpy.random.choice) and its reward pair ----
+    int s2;
+    float2 rsv;
+    if (SEARCH == SEARCH_FENCE) {
+      const int k = (int)(f0 <= u) + (int)(f1 <= u) + (int)(f2 <= u);   // fences of absent blocks hold 2.0
+      const uint32_t bidx = rowidx * (uint32_t)P.NB + (uint32_t)k;
+      const int g = lane >> 4, j = lane & 15;
+      double cv[16];
+      float2 rv[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {   // lanes 16g..16g+15 read the block of env 4*it+g
+        const uint32_t bi = (uint32_t)__shfl((int)bidx, it * 4 + g);
+        const double* blk = P.rows + (size_t)bi * 32;
+        cv[it] = blk[j];
+        rv[it] = reinterpret_cast<const float2*>(blk + 16)[j];
+      }
+      if (ROLLOUT && ts + 1 < T) a_next = io.action[o + P.n_env];   // prefetch behind the blocks
+      // all 32 loads stay ahead of the compare phase (hipcc would otherwise drain them in small batches)
+      __builtin_amdgcn_sched_barrier(0);
+      int cnt_own = 0;
+      float rx = 0.0f, ry = 0.0f;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int src = it * 4 + g;
+        const double ue = xv_shfl_f64(u, src);
+        const unsigned long long m = __ballot(cv[it] <= ue);
+        // owner of this iteration's group q is lane 4*it+q; it reads segment q of the ballot
+        const int cnt = __popc((unsigned)(m >> (16 * (lane & 3))) & 0xFFFFu);
+        const int pick = 16 * (lane & 3) + (cnt < 15 ? cnt : 15);
+        const float px = __shfl(rv[it].x, pick);
+        const float py = __shfl(rv[it].y, pick);
+        if ((lane >> 2) == it) {
+          cnt_own = cnt;
+          rx = px;
+          ry = py;
+        }
+      }
+      s2 = 16 * k + cnt_own;
+      s2 = s2 < S - 1 ? s2 : S - 1;
+      rsv = make_float2(rx, ry);
     } else {
-      const double* row = P.cdf + (size_t)rowidx * S;
       int lo = 0, n = S;
       while (n > 0) {
         const int half = n >> 1;
-        if (row[lo + half] <= u) {
+        if (*anymdp_cdf_ptr(P, rowidx, lo + half) <= u) {
           lo += half + 1;
           n -= half + 1;
         } else {
@@ -191,12 +234,11 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
         }
       }
       s2 = lo < S - 1 ? lo : S - 1;
+      if (ROLLOUT && ts + 1 < T) a_next = io.action[o + P.n_env];
+      rsv = anymdp_rs(P, rowidx, s2);                              // :103-104
     }
-
-    // ---- round trip 3: dependent gathers on s' ----
-    const float2 rsv = P.rs[(size_t)rowidx * S + s2];          // :103-104
-    const int obs2 = P.state_map[(size_t)t * S + s2];          // :146-148
-    const bool term2 = anymdp_is_term(P, t, tm0, s2);          // :107-108
+    const int obs2 = HDR ? (int)anymdp_hdr_obs(H, s2) : P.state_map[(size_t)t * S + s2];   // :146-148
+    const bool term2 = anymdp_is_term(P, t, tm0, s2);              // :107-108
 
     int o_obs, o_fobs = -1;
     float o_r, o_rgt;
@@ -209,7 +251,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
     } else if (mode == XV_AUTORESET_DISABLED && anymdp_is_term(P, t, tm0, s)) {
       // reference raises "given an terminated state" (:95-96): env untouched, error bit set
       err |= XV_DEVERR_STEP_TERMINAL;
-      o_obs = P.state_map[(size_t)t * S + s];
+      o_obs = HDR ? (int)anymdp_hdr_obs(H, s) : P.state_map[(size_t)t * S + s];
       o_r = 0.0f; o_rgt = 0.0f; o_term = true; o_trunc = steps >= max_steps;
     } else {
       steps += 1;                                              // :113
@@ -231,10 +273,10 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
     if (do_reset) {                                            // reset(): :85-90
       if (HDR) {
         // upper_bound over the 4 padded CDF entries; ids and obs ids come packed in the header
-        const int k = (int)(H.s0_cdf[0] <= u_reset) + (int)(H.s0_cdf[1] <= u_reset) +
-                      (int)(H.s0_cdf[2] <= u_reset);
-        s = (int)((H.s0_ids >> (8 * k)) & 0xFFu);
-        o_obs = (int)((H.s0_obs >> (16 * k)) & 0xFFFFull);
+        const int k0 = (int)(H.s0_cdf[0] <= u_reset) + (int)(H.s0_cdf[1] <= u_reset) +
+                       (int)(H.s0_cdf[2] <= u_reset);
+        s = (int)((H.s0_ids >> (8 * k0)) & 0xFFu);
+        o_obs = (int)((H.s0_obs >> (8 * k0)) & 0xFFu);
       } else {
         s = anymdp_draw_s0(P, t, u_reset);
         o_obs = P.state_map[(size_t)t * S + s];
@@ -259,26 +301,50 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
   if (err) atomicOr(P.err, err);
 }
 
-// packs the per-task scalars into 64-byte headers (once, at create time)
+// fence[r][k] = last CDF entry of block k of row r for k < NB-1, else 2.0 (never <= u)
+__global__ __launch_bounds__(256) void anymdp_build_fence_kernel(const double* rows, double* fence,
+                                                                 size_t n_rows, int NB) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_rows * 4) return;
+  const size_t r = idx >> 2;
+  const int k = (int)(idx & 3);
+  fence[idx] = (k < NB - 1) ? rows[(r * NB + k) * 32 + 15] : 2.0;
+}
+
+// packs the per-task scalars and observation ids into 128-byte headers (once, at create time)
 __global__ __launch_bounds__(256) void anymdp_pack_hdr_kernel(AnyMDPArgs P, AnyMDPHdr* hdr) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= P.n_task) return;
   AnyMDPHdr h;
   h.term_mask = P.term_mask[t];
   h.max_steps = P.max_steps[t];
-  uint32_t ids = 0;
-  uint64_t obs = 0;
+  uint32_t ids = 0, obs = 0;
   for (int k = 0; k < 4; ++k) {
     const int kk = k < P.s0_max ? k : P.s0_max - 1;
     const int sid = P.s0_ids[(size_t)t * P.s0_max + kk];
     ids |= (uint32_t)(sid & 0xFF) << (8 * k);
-    obs |= (uint64_t)(P.state_map[(size_t)t * P.S + sid] & 0xFFFF) << (16 * k);
+    obs |= (uint32_t)(P.state_map[(size_t)t * P.S + sid] & 0xFF) << (8 * k);
     h.s0_cdf[k] = k < P.s0_max ? P.s0_cdf[(size_t)t * P.s0_max + k] : 1.0;
   }
   h.s0_ids = ids;
   h.s0_obs = obs;
-  h.pad = 0;
+  h.pad0 = 0;
+  h.pad1 = 0;
+  for (int q = 0; q < 16; ++q) {
+    uint32_t w = 0;
+    for (int b = 0; b < 4; ++b) {
+      const int sidx = 4 * q + b;
+      if (sidx < P.S) w |= (uint32_t)(P.state_map[(size_t)t * P.S + sidx] & 0xFF) << (8 * b);
+    }
+    h.obs[q] = w;
+  }
   hdr[t] = h;
+}
+
+// largest observation id (decides whether ids fit the header's bytes)
+__global__ __launch_bounds__(256) void anymdp_max_obs_kernel(const int32_t* state_map, size_t n, int* out) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) atomicMax(out, state_map[idx]);
 }
 
 template <bool INJECT>
@@ -312,9 +378,9 @@ __global__ __launch_bounds__(256) void anymdp_tgt_kernel(AnyMDPArgs P, const int
   int a = action[i];
   a = a < 0 ? 0 : (a >= P.A ? P.A - 1 : a);
   const uint64_t tm0 = P.term_mask[(size_t)t * P.words];
-  const double* c = P.cdf + (((size_t)t * P.S + s) * P.A + a) * (size_t)P.S;
+  const uint32_t r = ((uint32_t)t * P.S + s) * P.A + a;
   double v = 0.0;
-  if (!anymdp_is_term(P, t, tm0, s)) v = c[j] - (j ? c[j - 1] : 0.0);
+  if (!anymdp_is_term(P, t, tm0, s)) v = *anymdp_cdf_ptr(P, r, j) - (j ? *anymdp_cdf_ptr(P, r, j - 1) : 0.0);
   out[(size_t)i * P.S + P.state_map[(size_t)t * P.S + j]] = v;
 }
 
@@ -322,16 +388,17 @@ __global__ __launch_bounds__(256) void anymdp_tgt_kernel(AnyMDPArgs P, const int
 // C-ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int A, int s0_max,
-                                const double* cdf, const float* rs, const int32_t* state_map,
-                                const uint64_t* term_mask, const double* s0_cdf, const int32_t* s0_ids,
-                                const int32_t* max_steps, const int32_t* env_task, xv_anymdp** out) {
+                                const void* rows, const int32_t* state_map, const uint64_t* term_mask,
+                                const double* s0_cdf, const int32_t* s0_ids, const int32_t* max_steps,
+                                const int32_t* env_task, xv_anymdp** out) {
   XV_CHECK_ARG(out != nullptr);
   *out = nullptr;
   XV_CHECK_ARG(e != nullptr);
   XV_CHECK_ARG(n_env > 0 && n_task > 0);
   XV_CHECK_ARG(S >= 2 && S <= 256 && A >= 2 && A <= 64 && s0_max >= 1 && s0_max <= 256);
-  XV_CHECK_ARG(cdf && rs && state_map && term_mask && s0_cdf && s0_ids && max_steps && env_task);
-  XV_CHECK_ARG((uint64_t)n_task * S * A < 0xFFFFFFFFull);  // row index is a 32-bit word on the device
+  XV_CHECK_ARG(rows && state_map && term_mask && s0_cdf && s0_ids && max_steps && env_task);
+  const int NB = (S + 15) / 16;
+  XV_CHECK_ARG((uint64_t)n_task * S * A * NB < 0xFFFFFFFFull);  // block index is a 32-bit word on the device
   XV_HIP(hipSetDevice(e->device));
   xv_anymdp* h = new (std::nothrow) xv_anymdp();
   if (!h) {
@@ -339,47 +406,74 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
     return XV_ERR_NOMEM;
   }
   h->eng = e;
+  h->search = XV_ANYMDP_SEARCH_AUTO;
   AnyMDPArgs& a = h->a;
-  a.cdf = cdf; a.rs = (const float2*)rs; a.state_map = state_map; a.term_mask = term_mask;
+  a.rows = (const double*)rows; a.state_map = state_map; a.term_mask = term_mask;
   a.s0_cdf = s0_cdf; a.s0_ids = s0_ids; a.max_steps = max_steps; a.env_task = env_task;
   a.n_env = n_env; a.n_task = n_task; a.S = S; a.A = A; a.s0_max = s0_max; a.words = (S + 63) / 64;
+  a.NB = NB;
   a.err = e->d_err;
-  a.state = nullptr; a.steps = nullptr; a.need_reset = nullptr; a.hdr = nullptr;
+  a.state = nullptr; a.steps = nullptr; a.need_reset = nullptr; a.hdr = nullptr; a.fence = nullptr;
   a.seed = e->seed; a.gid_base = e->env_id_base; a.tick = 0;
+
+  // the fast path needs S <= 64, s0_max <= 4 and observation ids that fit a byte
+  bool fast = (S <= 64 && s0_max <= 4);
+  if (fast) {
+    int* d_max = nullptr;
+    int h_max = 0;
+    XV_HIP(hipMalloc(&d_max, sizeof(int)));
+    XV_HIP(hipMemsetAsync(d_max, 0, sizeof(int), e->stream));
+    const size_t n = (size_t)n_task * S;
+    hipLaunchKernelGGL(anymdp_max_obs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream,
+                       state_map, n, d_max);
+    XV_HIP(hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    XV_HIP(hipStreamSynchronize(e->stream));
+    XV_HIP(hipFree(d_max));
+    fast = h_max < 256;
+  }
+
   AnyMDPHdr* hdr = nullptr;
-  const bool use_hdr = (S <= 64 && s0_max <= 4);
+  double* fence = nullptr;
+  const size_t n_rows = (size_t)n_task * S * A;
   hipError_t m = hipMalloc(&a.state, sizeof(int32_t) * (size_t)n_env);
-  if (m == hipSuccess && use_hdr) m = hipMalloc(&hdr, sizeof(AnyMDPHdr) * (size_t)n_task);
   if (m == hipSuccess) m = hipMalloc(&a.steps, sizeof(int32_t) * (size_t)n_env);
   if (m == hipSuccess) m = hipMalloc(&a.need_reset, (size_t)n_env);
+  if (m == hipSuccess && fast) m = hipMalloc(&hdr, sizeof(AnyMDPHdr) * (size_t)n_task);
+  if (m == hipSuccess && fast) m = hipMalloc(&fence, n_rows * 4 * sizeof(double));
   if (m == hipSuccess) m = hipMemsetAsync(a.state, 0, sizeof(int32_t) * (size_t)n_env, e->stream);
   if (m == hipSuccess) m = hipMemsetAsync(a.steps, 0, sizeof(int32_t) * (size_t)n_env, e->stream);
   if (m == hipSuccess) m = hipMemsetAsync(a.need_reset, 1, (size_t)n_env, e->stream);
   if (m != hipSuccess) {
-    xv_set_error("xv_anymdp_create: env state allocation failed: %s", hipGetErrorString(m));
-    if (a.state) hipFree(a.state);
-    if (a.steps) hipFree(a.steps);
-    if (a.need_reset) hipFree(a.need_reset);
-    if (hdr) hipFree(hdr);
+    xv_set_error("xv_anymdp_create: device allocation failed: %s", hipGetErrorString(m));
+    if (a.state) (void)hipFree(a.state);
+    if (a.steps) (void)hipFree(a.steps);
+    if (a.need_reset) (void)hipFree(a.need_reset);
+    if (hdr) (void)hipFree(hdr);
+    if (fence) (void)hipFree(fence);
     delete h;
     return XV_ERR_HIP;
   }
-  if (use_hdr) {
+  if (fast) {
     hipLaunchKernelGGL(anymdp_pack_hdr_kernel, dim3(xv_div_up(n_task, 256)), dim3(256), 0, e->stream, a, hdr);
+    hipLaunchKernelGGL(anymdp_build_fence_kernel, dim3((unsigned)((n_rows * 4 + 255) / 256)), dim3(256), 0,
+                       e->stream, a.rows, fence, n_rows, NB);
     a.hdr = hdr;
+    a.fence = fence;
   }
+  XV_LAUNCH_CHECK();
   *out = h;
   return XV_OK;
 }
 
 extern "C" int xv_anymdp_destroy(xv_anymdp* h) {
   if (!h) return XV_OK;
-  hipSetDevice(h->eng->device);
-  hipStreamSynchronize(h->eng->stream);
-  hipFree(h->a.state);
-  hipFree(h->a.steps);
-  hipFree(h->a.need_reset);
-  if (h->a.hdr) hipFree((void*)h->a.hdr);
+  (void)hipSetDevice(h->eng->device);
+  (void)hipStreamSynchronize(h->eng->stream);
+  (void)hipFree(h->a.state);
+  (void)hipFree(h->a.steps);
+  (void)hipFree(h->a.need_reset);
+  if (h->a.hdr) (void)hipFree((void*)h->a.hdr);
+  if (h->a.fence) (void)hipFree((void*)h->a.fence);
   delete h;
   return XV_OK;
 }
@@ -416,12 +510,13 @@ static int anymdp_launch_step(xv_anymdp* h, const AnyMDPStepIO& io, int T, int m
   hipLaunchKernelGGL((anymdp_step_kernel<INJECT, SEARCH, HDR, ROLL>), grid, block, 0, h->eng->stream, \
                      h->a, io, T, mode)
   const bool roll = T > 1;
-  if (h->a.S == 64 && h->a.hdr) {
-    if (roll) XV_LAUNCH_STEP(SEARCH_W64, true, true); else XV_LAUNCH_STEP(SEARCH_W64, true, false);
-  } else if (h->a.hdr) {
-    if (roll) XV_LAUNCH_STEP(SEARCH_GENERIC, true, true); else XV_LAUNCH_STEP(SEARCH_GENERIC, true, false);
+  const bool fast = h->a.hdr != nullptr;
+  if (fast && h->search != XV_ANYMDP_SEARCH_BINARY) {
+    if (roll) XV_LAUNCH_STEP(SEARCH_FENCE, true, true); else XV_LAUNCH_STEP(SEARCH_FENCE, true, false);
+  } else if (fast) {
+    if (roll) XV_LAUNCH_STEP(SEARCH_BINARY, true, true); else XV_LAUNCH_STEP(SEARCH_BINARY, true, false);
   } else {
-    if (roll) XV_LAUNCH_STEP(SEARCH_GENERIC, false, true); else XV_LAUNCH_STEP(SEARCH_GENERIC, false, false);
+    if (roll) XV_LAUNCH_STEP(SEARCH_BINARY, false, true); else XV_LAUNCH_STEP(SEARCH_BINARY, false, false);
   }
 #undef XV_LAUNCH_STEP
   XV_LAUNCH_CHECK();
@@ -474,6 +569,18 @@ extern "C" int xv_anymdp_rollout(xv_anymdp* h, int T, const int32_t* actions, in
   anymdp_bind_rng(h, (uint64_t)T);
   AnyMDPStepIO io{actions, nullptr, nullptr, nullptr, obs, reward, reward_gt, terminated, truncated, final_obs};
   return anymdp_launch_step<false>(h, io, T, XV_AUTORESET_SAME_STEP);
+}
+
+extern "C" int xv_anymdp_set_search(xv_anymdp* h, int search) {
+  XV_CHECK_ARG(h != nullptr);
+  XV_CHECK_ARG(search == XV_ANYMDP_SEARCH_AUTO || search == XV_ANYMDP_SEARCH_BINARY ||
+               search == XV_ANYMDP_SEARCH_FENCE);
+  if (search == XV_ANYMDP_SEARCH_FENCE && !h->a.hdr) {
+    xv_set_error("xv_anymdp_set_search: FENCE needs S <= 64, s0_max <= 4 and observation ids < 256");
+    return XV_ERR_UNSUPPORTED;
+  }
+  h->search = search;
+  return XV_OK;
 }
 
 extern "C" int xv_anymdp_get_state(xv_anymdp* h, int32_t* inner_state, int32_t* steps, uint8_t* need_reset) {

@@ -1,8 +1,8 @@
 // anymdp_synth.hip — synthetic AnyMDP task tables generated directly in HBM.
 //
-// The headline config has one task per env: 65,536 tasks x (S=64, A=8) = 32 GiB of fp64 CDF rows plus
-// 16 GiB of {reward, noise} pairs — more than the host can stage — so the tables are produced on the
-// device.  Integer-only construction, bit-identical to oracle/xeno_oracle.c: xo_anymdp_synth (weights are
+// The headline config has one task per env: 65,536 tasks x (S=64, A=8) = 32 GiB of blocked rows (fp64 CDF
+// entries + {reward, noise} pairs) — more than the host can stage — so the tables are produced on the
+// device, directly in the blocked layout of include/xeno.h.  Integer-only construction, bit-identical to oracle/xeno_oracle.c: xo_anymdp_synth (weights are
 // integers, partial sums exact in uint32, one IEEE fp64 division per CDF entry), so the generator itself
 // is parity-tested.  Row shape follows the reference sampler's banded transitions
 // (anymdp/task_sampler_utils.py:65-175): support of row (s,a) is a band [lo,hi) around s.
@@ -73,8 +73,7 @@ __global__ __launch_bounds__(64) void anymdp_synth_header_kernel(uint64_t seed, 
 // one wave per (task, s, a) row; lane j owns entries j, j+64, ...
 __global__ __launch_bounds__(256) void anymdp_synth_rows_kernel(uint64_t seed, int64_t task_base,
                                                                 int n_task, int S, int A,
-                                                                const uint64_t* term_mask, double* cdf,
-                                                                float2* rs) {
+                                                                const uint64_t* term_mask, double* rows) {
   const int lane = threadIdx.x & 63;
   const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const size_t n_rows = (size_t)n_task * S * A;
@@ -110,7 +109,8 @@ __global__ __launch_bounds__(256) void anymdp_synth_rows_kernel(uint64_t seed, i
     total += r;
   }
   uint32_t carry = 0;
-  const size_t row = wave * (size_t)S;
+  const int NB = (S + 15) / 16;
+  double* row = rows + wave * (size_t)NB * 32;   // blocked layout: include/xeno.h "rows"
   for (int c = 0; c < chunks; ++c) {
     const int j = c * 64 + lane;
     uint32_t incl = wt[c];  // inclusive scan over the wave
@@ -120,26 +120,31 @@ __global__ __launch_bounds__(256) void anymdp_synth_rows_kernel(uint64_t seed, i
       if (lane >= off) incl += n;
     }
     const uint32_t chunk_sum = __shfl(incl, 63);
-    if (j < S) {
-      cdf[row + j] = term ? 1.0 : (double)(carry + incl) / (double)total;
-      const xv_u32x4 w = synth_draw(seed, task, rowid, 0x100u + (uint32_t)(j >> 1));
-      const uint32_t wa = (j & 1) ? w.z : w.x, wb = (j & 1) ? w.w : w.y;
-      float2 o;
-      o.x = (float)((int32_t)(wa >> 8) - 8388608) * (1.0f / 4194304.0f);
-      o.y = (wb & 1u) ? (float)(wb >> 8) * (1.0f / 67108864.0f) : 0.0f;
-      rs[row + j] = o;
+    if (j < NB * 16) {
+      double* blk = row + (size_t)(j >> 4) * 32;
+      float2 o = make_float2(0.0f, 0.0f);
+      double cj = 2.0;   // padding entries of the last block: never <= u
+      if (j < S) {
+        cj = term ? 1.0 : (double)(carry + incl) / (double)total;
+        const xv_u32x4 w = synth_draw(seed, task, rowid, 0x100u + (uint32_t)(j >> 1));
+        const uint32_t wa = (j & 1) ? w.z : w.x, wb = (j & 1) ? w.w : w.y;
+        o.x = (float)((int32_t)(wa >> 8) - 8388608) * (1.0f / 4194304.0f);
+        o.y = (wb & 1u) ? (float)(wb >> 8) * (1.0f / 67108864.0f) : 0.0f;
+      }
+      blk[j & 15] = cj;
+      reinterpret_cast<float2*>(blk + 16)[j & 15] = o;
     }
     carry += chunk_sum;
   }
 }
 
 extern "C" int xv_anymdp_synth_tasks(xv_engine* e, uint64_t seed, int64_t task_index_base, int n_task,
-                                     int S, int A, int s0_max, double* cdf, float* rs,
+                                     int S, int A, int s0_max, void* rows,
                                      int32_t* state_map, uint64_t* term_mask, double* s0_cdf,
                                      int32_t* s0_ids, int32_t* max_steps) {
   XV_CHECK_ARG(e != nullptr && n_task > 0);
   XV_CHECK_ARG(S >= 4 && S <= 256 && A >= 2 && A <= 64 && s0_max >= 1 && s0_max <= 256);
-  XV_CHECK_ARG(cdf && rs && state_map && term_mask && s0_cdf && s0_ids && max_steps);
+  XV_CHECK_ARG(rows && state_map && term_mask && s0_cdf && s0_ids && max_steps);
   XV_HIP(hipSetDevice(e->device));
   hipLaunchKernelGGL(anymdp_synth_header_kernel, dim3(xv_div_up(n_task, 64)), dim3(64), 0, e->stream, seed,
                      task_index_base, n_task, S, s0_max, state_map, term_mask, s0_cdf, s0_ids, max_steps);
@@ -148,7 +153,7 @@ extern "C" int xv_anymdp_synth_tasks(xv_engine* e, uint64_t seed, int64_t task_i
   const size_t blocks = (n_rows + 3) / 4;
   XV_CHECK_ARG(blocks < 0x7FFFFFFFull);
   hipLaunchKernelGGL(anymdp_synth_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, e->stream, seed,
-                     task_index_base, n_task, S, A, (const uint64_t*)term_mask, cdf, (float2*)rs);
+                     task_index_base, n_task, S, A, (const uint64_t*)term_mask, (double*)rows);
   XV_LAUNCH_CHECK();
   return XV_OK;
 }
