@@ -4,7 +4,7 @@ set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/pytest_gpu.log
-for mode in fence row binary; do
+for mode in fence binary; do
   for tasks in 0 1024; do
     echo "== search=$mode tasks=$tasks"
     timeout 600 python bench.py --steps 2000 --warmup 200 --search $mode --tasks $tasks --fused --no-cpu-baseline 2>/dev/null | python -c "

@@ -24,18 +24,20 @@
 #include "philox.h"
 #include "xv_common.h"
 
+#include <cstddef>
+
 // One 128-byte line per task (fast path: S <= 64, s0_max <= 4, observation ids < 256); built at create time.
 struct __attribute__((aligned(128))) AnyMDPHdr {
   uint64_t term_mask;    // bit s set <=> s terminal
   int32_t max_steps;
   uint32_t s0_ids;       // 4 x u8 inner-state ids of s_0 (padded with the last)
   uint32_t s0_obs;       // 4 x u8 observation ids of those states
-  uint32_t pad0;
-  double s0_cdf[4];      // inclusive CDF of s_0_prob padded with 1.0
-  uint64_t pad1;
+  uint32_t pad0[3];
+  double s0_cdf[4];      // bytes 32..63: inclusive CDF of s_0_prob padded with 1.0
   uint32_t obs[16];      // 64 x u8: observation id of inner state s (state_mapping)
 };
 static_assert(sizeof(AnyMDPHdr) == 128, "header must be one 128-byte line");
+static_assert(offsetof(AnyMDPHdr, s0_cdf) == 32 && offsetof(AnyMDPHdr, obs) == 64, "register view below");
 
 struct AnyMDPArgs {
   const AnyMDPHdr* hdr;  // engine-owned, nullptr when the fast path does not apply
@@ -101,14 +103,39 @@ __device__ __forceinline__ double xv_shfl_f64(double v, int src) {
   return __hiloint2double(__shfl(__double2hiint(v), src), __shfl(__double2loint(v), src));
 }
 
-// byte `idx` of a 16-word table held in registers (idx in 0..63): a select chain, no memory access
-__device__ __forceinline__ uint32_t anymdp_hdr_obs(const AnyMDPHdr& H, int idx) {
-  const int w = idx >> 2;
-  uint32_t v = H.obs[0];
-#pragma unroll
-  for (int q = 1; q < 16; ++q) v = (w == q) ? H.obs[q] : v;
+// The header is held in named registers, never as an indexable aggregate: hipcc folds a select chain over
+// loaded values back into ONE load at a selected address (a dynamically indexed stack array in scratch, or a
+// dependent global load) — exactly the round trip this header exists to remove.  The empty asm statements
+// make each observation word an opaque register value, which keeps the 15-select tree in VALU.
+struct AnyMDPHdrRegs {
+  uint4 q0, q1, q2, q3;   // term_mask | max_steps, s0_ids, s0_obs, pad | s0_cdf[0..3]
+  uint32_t w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15;   // 64 obs ids, 1 byte each
+};
+#define XV_OPAQUE(x) asm volatile("" : "+v"(x))
+__device__ __forceinline__ AnyMDPHdrRegs anymdp_load_hdr(const AnyMDPHdr* hdr, int t) {
+  const uint4* p = reinterpret_cast<const uint4*>(hdr + t);
+  AnyMDPHdrRegs r;
+  r.q0 = p[0]; r.q1 = p[1]; r.q2 = p[2]; r.q3 = p[3];
+  const uint4 a = p[4], b = p[5], c = p[6], d = p[7];
+  r.w0 = a.x; r.w1 = a.y; r.w2 = a.z; r.w3 = a.w; r.w4 = b.x; r.w5 = b.y; r.w6 = b.z; r.w7 = b.w;
+  r.w8 = c.x; r.w9 = c.y; r.w10 = c.z; r.w11 = c.w; r.w12 = d.x; r.w13 = d.y; r.w14 = d.z; r.w15 = d.w;
+  XV_OPAQUE(r.w0); XV_OPAQUE(r.w1); XV_OPAQUE(r.w2); XV_OPAQUE(r.w3);
+  XV_OPAQUE(r.w4); XV_OPAQUE(r.w5); XV_OPAQUE(r.w6); XV_OPAQUE(r.w7);
+  XV_OPAQUE(r.w8); XV_OPAQUE(r.w9); XV_OPAQUE(r.w10); XV_OPAQUE(r.w11);
+  XV_OPAQUE(r.w12); XV_OPAQUE(r.w13); XV_OPAQUE(r.w14); XV_OPAQUE(r.w15);
+  return r;
+}
+// observation id of inner state idx (0..63): byte idx of w0..w15, by selects only
+__device__ __forceinline__ uint32_t anymdp_hdr_obs(const AnyMDPHdrRegs& H, int idx) {
+  const bool b0 = idx & 4, b1 = idx & 8, b2 = idx & 16, b3 = idx & 32;   // bits of the word index idx>>2
+  const uint32_t a0 = b0 ? H.w1 : H.w0, a1 = b0 ? H.w3 : H.w2, a2 = b0 ? H.w5 : H.w4, a3 = b0 ? H.w7 : H.w6;
+  const uint32_t a4 = b0 ? H.w9 : H.w8, a5 = b0 ? H.w11 : H.w10, a6 = b0 ? H.w13 : H.w12, a7 = b0 ? H.w15 : H.w14;
+  const uint32_t c0 = b1 ? a1 : a0, c1 = b1 ? a3 : a2, c2 = b1 ? a5 : a4, c3 = b1 ? a7 : a6;
+  const uint32_t d0 = b2 ? c1 : c0, d1 = b2 ? c3 : c2;
+  const uint32_t v = b3 ? d1 : d0;
   return (v >> (8 * (idx & 3))) & 0xFFu;
 }
+__device__ __forceinline__ double xv_u2d(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 
 enum { SEARCH_BINARY = 0, SEARCH_FENCE = 1 };
 
@@ -133,7 +160,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
   const uint64_t gid = P.gid_base + (uint64_t)ic;
   uint32_t err = 0;
 
-  AnyMDPHdr H;
+  AnyMDPHdrRegs H;
   int max_steps = 0;
   uint64_t tm0 = 0;
   bool hdr_loaded = false;
@@ -172,9 +199,9 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
     }
     if (!hdr_loaded) {
       if (HDR) {
-        H = P.hdr[t];
-        max_steps = H.max_steps;
-        tm0 = H.term_mask;
+        H = anymdp_load_hdr(P.hdr, t);
+        max_steps = (int)H.q0.z;
+        tm0 = (uint64_t)H.q0.x | ((uint64_t)H.q0.y << 32);
       } else {
         max_steps = P.max_steps[t];
         tm0 = P.term_mask[(size_t)t * P.words];
@@ -189,32 +216,41 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       const int k = (int)(f0 <= u) + (int)(f1 <= u) + (int)(f2 <= u);   // fences of absent blocks hold 2.0
       const uint32_t bidx = rowidx * (uint32_t)P.NB + (uint32_t)k;
       const int g = lane >> 4, j = lane & 15;
+      // (a) all block addresses first (16 independent ds_bpermute), then all 32 loads back to back
+      uint32_t bi[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) bi[it] = (uint32_t)__shfl((int)bidx, it * 4 + g);
       double cv[16];
       float2 rv[16];
 #pragma unroll
       for (int it = 0; it < 16; ++it) {   // lanes 16g..16g+15 read the block of env 4*it+g
-        const uint32_t bi = (uint32_t)__shfl((int)bidx, it * 4 + g);
-        const double* blk = P.rows + (size_t)bi * 32;
+        const double* blk = P.rows + (size_t)bi[it] * 32;
         cv[it] = blk[j];
         rv[it] = reinterpret_cast<const float2*>(blk + 16)[j];
       }
       if (ROLLOUT && ts + 1 < T) a_next = io.action[o + P.n_env];   // prefetch behind the blocks
-      // all 32 loads stay ahead of the compare phase (hipcc would otherwise drain them in small batches)
       __builtin_amdgcn_sched_barrier(0);
+      // (b) while the loads fly: broadcast each env's uniform to the 16 lanes that hold its block
+      double ue[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) ue[it] = xv_shfl_f64(u, it * 4 + g);
+      __builtin_amdgcn_sched_barrier(0);
+      // (c) compare + ballot + popcount; the owner of group q in iteration `it` is lane 4*it+q
       int cnt_own = 0;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const unsigned long long m = __ballot(cv[it] <= ue[it]);
+        const int cnt = __popc((unsigned)(m >> (16 * (lane & 3))) & 0xFFFFu);
+        if ((lane >> 2) == it) cnt_own = cnt;
+      }
+      // (d) the reward pair of s' sits in lane 16q + cnt of the same registers: 32 independent bpermutes
+      const int pick = 16 * (lane & 3) + (cnt_own < 15 ? cnt_own : 15);
       float rx = 0.0f, ry = 0.0f;
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
-        const int src = it * 4 + g;
-        const double ue = xv_shfl_f64(u, src);
-        const unsigned long long m = __ballot(cv[it] <= ue);
-        // owner of this iteration's group q is lane 4*it+q; it reads segment q of the ballot
-        const int cnt = __popc((unsigned)(m >> (16 * (lane & 3))) & 0xFFFFu);
-        const int pick = 16 * (lane & 3) + (cnt < 15 ? cnt : 15);
         const float px = __shfl(rv[it].x, pick);
         const float py = __shfl(rv[it].y, pick);
         if ((lane >> 2) == it) {
-          cnt_own = cnt;
           rx = px;
           ry = py;
         }
@@ -273,10 +309,10 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
     if (do_reset) {                                            // reset(): :85-90
       if (HDR) {
         // upper_bound over the 4 padded CDF entries; ids and obs ids come packed in the header
-        const int k0 = (int)(H.s0_cdf[0] <= u_reset) + (int)(H.s0_cdf[1] <= u_reset) +
-                       (int)(H.s0_cdf[2] <= u_reset);
-        s = (int)((H.s0_ids >> (8 * k0)) & 0xFFu);
-        o_obs = (int)((H.s0_obs >> (8 * k0)) & 0xFFu);
+        const int k0 = (int)(xv_u2d(H.q2.x, H.q2.y) <= u_reset) + (int)(xv_u2d(H.q2.z, H.q2.w) <= u_reset) +
+                       (int)(xv_u2d(H.q3.x, H.q3.y) <= u_reset);
+        s = (int)((H.q0.w >> (8 * k0)) & 0xFFu);
+        o_obs = (int)((H.q1.x >> (8 * k0)) & 0xFFu);
       } else {
         s = anymdp_draw_s0(P, t, u_reset);
         o_obs = P.state_map[(size_t)t * S + s];
@@ -328,8 +364,7 @@ __global__ __launch_bounds__(256) void anymdp_pack_hdr_kernel(AnyMDPArgs P, AnyM
   }
   h.s0_ids = ids;
   h.s0_obs = obs;
-  h.pad0 = 0;
-  h.pad1 = 0;
+  h.pad0[0] = h.pad0[1] = h.pad0[2] = 0;
   for (int q = 0; q < 16; ++q) {
     uint32_t w = 0;
     for (int b = 0; b < 4; ++b) {
