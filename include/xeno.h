@@ -181,6 +181,58 @@ int xv_anymdp_synth_tasks(xv_engine* e, uint64_t seed, int64_t task_index_base, 
                           int s0_max, void* rows, int32_t* state_map, uint64_t* term_mask,
                           double* s0_cdf, int32_t* s0_ids, int32_t* max_steps);
 
+/* ------------------------------------------------------------------------------------------------
+ * LinDS — reference: xenoverse/linds/linds_env.py
+ *   set_task + build_dynamics_matrices :40-76 -> xv_linds_create (ZOH discretisation done on the host in
+ *                                                fp64: xenoverse_amd/linds/tables.py)
+ *   reset :108-131                            -> xv_linds_reset
+ *   step  :133-169 (dynamics :78-80, get_observation :83-91, get_inner_cmd :93-98,
+ *                   RandomFourier.__call__ utils/random_nn.py:362-368)  -> xv_linds_step
+ *
+ * fp32 on the device (north_star: float dynamics within 1e-5 rel of the fp64 reference).  Batch-wide padded
+ * dims: NS in {16, 32} (state), NA in {8, 16} (= pad_action_dim), NO in {16, 32} (= pad_observation_dim =
+ * pad_command_dim); smaller tasks are zero-padded, which is exact.  Matrices are stored transposed (k-major).
+ * Env state x is component-major float[NS][n_env] (lane i reads word i of every component: coalesced).
+ * ---------------------------------------------------------------------------------------------- */
+#define XV_LINDS_KMAX 6
+typedef struct xv_linds_tables {
+  const float* phiT;        /* [n_task][NS][NS]  phiT[k][j] = Phi[j][k],  Phi = e^{A dt} */
+  const float* gamT;        /* [n_task][NA][NS]  gamT[k][j] = Gamma[j][k] */
+  const float* cT;          /* [n_task][NS][NO]  cT[k][j]   = ld_C[j][k] */
+  const float* xt;          /* [n_task][NS]      ld_X * dt */
+  const float* y0;          /* [n_task][NO]      ld_Y */
+  const float* valid;       /* [n_task][NO]      target_valid as 0/1 */
+  const float* cmd0;        /* [n_task][NO]      static command */
+  const float* four_coef;   /* [n_task][KMAX][NO][2]  Fourier coefficients (sin, cos) */
+  const double* four_omega; /* [n_task][KMAX]    Fourier orders */
+  const double* four_period;/* [n_task]          RandomFourier.max_steps (1000) */
+  const float* scal;        /* [n_task][8]  action_cost, reward_base, terminate_punish, reward_factor,
+                                            noise_drift*dt, dt, 0, 0 */
+  const int32_t* ints;      /* [n_task][4]  max_steps, target_delay, n_init, n_fourier_terms (0: static) */
+  const float* init;        /* [n_task][NI][NS]  initial_states */
+} xv_linds_tables;
+
+int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int NA, int NO, int NI,
+                    const xv_linds_tables* tables, const int32_t* env_task, xv_linds** out);
+int xv_linds_destroy(xv_linds* h);
+/* reset: x = initial_states[k], k uniform (linds_env.py:117 uses random.choice); obs = C x + Y; command =
+ * cmd(0); error = ||(obs - cmd) * valid||.  obs/cmd float[n_env][NO], error float[n_env]; all nullable. */
+int xv_linds_reset(xv_linds* h, const uint8_t* mask, float* obs, float* cmd, float* error);
+int xv_linds_reset_injected(xv_linds* h, const uint8_t* mask, const int32_t* init_index, float* obs,
+                            float* cmd, float* error);
+/* one vector step.  action float[n_env][NA] (raw, unclipped: the action cost uses it as given, :164);
+ * outputs obs/cmd float[n_env][NO] (info["command"] = cmd(steps)), reward, error (info["error"]), flags;
+ * final_obs float[n_env][NO] nullable (SAME_STEP).  Process noise: NS Box-Muller normals per env from Philox. */
+int xv_linds_step(xv_linds* h, const float* action, float* obs, float* reward, uint8_t* terminated,
+                  uint8_t* truncated, float* cmd, float* error, float* final_obs, int autoreset_mode);
+/* parity hook: z float[NS][n_env] standard normals, init_index int32[n_env] (initial state used on reset) */
+int xv_linds_step_injected(xv_linds* h, const float* action, const float* z, const int32_t* init_index,
+                           float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, float* cmd,
+                           float* error, float* final_obs, int autoreset_mode);
+/* env.state accessor (:185-187): x float[NS][n_env], steps int32[n_env], need_reset uint8[n_env]; nullable */
+int xv_linds_get_state(xv_linds* h, float* x, int32_t* steps, uint8_t* need_reset);
+int xv_linds_set_state(xv_linds* h, const float* x, const int32_t* steps, const uint8_t* need_reset);
+
 #ifdef __cplusplus
 }
 #endif

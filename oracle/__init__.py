@@ -169,3 +169,92 @@ def anymdp_synth(seed, task_index_base, n_task, S, A, s0_max):
                           C.c_int(A), C.c_int(s0_max), _p(t["cdf"]), _p(t["rs"]), _p(t["state_map"]),
                           _p(t["term_mask"]), _p(t["s0_cdf"]), _p(t["s0_ids"]), _p(t["max_steps"]))
     return t
+
+
+# ---------------------------------------------------------------------------------------------------
+# LinDS
+# ---------------------------------------------------------------------------------------------------
+class _LinDSStruct(C.Structure):
+    _fields_ = [("n_env", C.c_int), ("n_task", C.c_int), ("NS", C.c_int), ("NA", C.c_int), ("NO", C.c_int),
+                ("NI", C.c_int)] + [(k, C.c_void_p) for k in
+                                    ("phiT", "gamT", "cT", "xt", "y0", "valid", "cmd0", "four_coef", "four_omega",
+                                     "four_period", "scal", "ints", "init", "env_task", "x", "steps",
+                                     "need_reset")] + [("err_flags", C.c_uint32)]
+
+
+class LinDSOracle(object):
+    """Batched CPU LinDS over the device table layout (xenoverse_amd.linds.tables.build_tables)."""
+    _F32 = ("phiT", "gamT", "cT", "xt", "y0", "valid", "cmd0", "four_coef", "scal", "init")
+
+    def __init__(self, tables, env_task):
+        t = tables
+        self.NS, self.NA, self.NO, self.NI = int(t["NS"]), int(t["NA"]), int(t["NO"]), int(t["NI"])
+        self.env_task = np.ascontiguousarray(env_task, np.int32)
+        self.n_env = len(self.env_task)
+        self.n_task = t["phiT"].shape[0]
+        k = {n: np.ascontiguousarray(t[n], np.float32) for n in self._F32}
+        k["four_omega"] = np.ascontiguousarray(t["four_omega"], np.float64)
+        k["four_period"] = np.ascontiguousarray(t["four_period"], np.float64)
+        k["ints"] = np.ascontiguousarray(t["ints"], np.int32)
+        self._keep = k
+        self.x = np.zeros((self.NS, self.n_env), np.float32)
+        self.steps = np.zeros(self.n_env, np.int32)
+        self.need_reset = np.ones(self.n_env, np.uint8)
+        self._h = _LinDSStruct(self.n_env, self.n_task, self.NS, self.NA, self.NO, self.NI,
+                               *[_p(k[n]) for n in ("phiT", "gamT", "cT", "xt", "y0", "valid", "cmd0", "four_coef",
+                                                    "four_omega", "four_period", "scal", "ints", "init")],
+                               _p(self.env_task), _p(self.x), _p(self.steps), _p(self.need_reset), 0)
+
+    @property
+    def err_flags(self):
+        return int(self._h.err_flags)
+
+    def _outs(self):
+        n, no = self.n_env, self.NO
+        return dict(obs=np.zeros((n, no), np.float32), reward=np.zeros(n, np.float32),
+                    terminated=np.zeros(n, np.uint8), truncated=np.zeros(n, np.uint8),
+                    cmd=np.zeros((n, no), np.float32), error=np.zeros(n, np.float32),
+                    final_obs=np.zeros((n, no), np.float32))
+
+    def cmd(self, task, t):
+        out = np.zeros(self.NO, np.float32)
+        lib().xo_linds_cmd(C.byref(self._h), C.c_int(task), C.c_int(t), _p(out))
+        return out
+
+    def reset_injected(self, init_index, mask=None):
+        o = self._outs()
+        idx = np.ascontiguousarray(init_index, np.int32)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        lib().xo_linds_reset_injected(C.byref(self._h), _p(m), _p(idx), _p(o["obs"]), _p(o["cmd"]), _p(o["error"]))
+        return o
+
+    def reset(self, seed, gid_base, tick, mask=None):
+        o = self._outs()
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        lib().xo_linds_reset(C.byref(self._h), C.c_uint64(seed), C.c_uint64(gid_base), C.c_uint64(tick), _p(m),
+                             _p(o["obs"]), _p(o["cmd"]), _p(o["error"]))
+        return o
+
+    def step_injected(self, action, z, init_index, mode):
+        o = self._outs()
+        a = np.ascontiguousarray(action, np.float32).reshape(self.n_env, self.NA)
+        z = np.ascontiguousarray(z, np.float32).reshape(self.NS, self.n_env)
+        idx = np.ascontiguousarray(init_index, np.int32)
+        lib().xo_linds_step_injected(C.byref(self._h), _p(a), _p(z), _p(idx), _p(o["obs"]), _p(o["reward"]),
+                                     _p(o["terminated"]), _p(o["truncated"]), _p(o["cmd"]), _p(o["error"]),
+                                     _p(o["final_obs"]), C.c_int(mode))
+        return o
+
+    def step(self, seed, gid_base, tick, action, mode, n_threads=1):
+        o = self._outs()
+        a = np.ascontiguousarray(action, np.float32).reshape(self.n_env, self.NA)
+        lib().xo_linds_step(C.byref(self._h), C.c_uint64(seed), C.c_uint64(gid_base), C.c_uint64(tick), _p(a),
+                            _p(o["obs"]), _p(o["reward"]), _p(o["terminated"]), _p(o["truncated"]), _p(o["cmd"]),
+                            _p(o["error"]), _p(o["final_obs"]), C.c_int(mode), C.c_int(n_threads))
+        return o
+
+
+def linds_yorder(NS):
+    ord_ = np.zeros(32, np.int32)
+    n = lib().xo_linds_yorder(C.c_int(NS), _p(ord_))
+    return ord_[:n].copy()

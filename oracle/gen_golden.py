@@ -152,7 +152,115 @@ def gen_anymdp():
         print("skip 64x8: task cache not ready (run oracle/sample_ref_tasks.py 64 8 1; ~9 min)")
 
 
-FAMILIES = {"anymdp": gen_anymdp}
+def _linds_task_arrays(task):
+    dyn = str(task["target_type"]) == "dynamic_target"
+    out = dict(state_dim=np.int64(task["state_dim"]), observation_dim=np.int64(task["observation_dim"]),
+               action_dim=np.int64(task["action_dim"]), max_steps=np.int64(task["max_steps"]),
+               ld_A=np.asarray(task["ld_A"], np.float64), ld_B=np.asarray(task["ld_B"], np.float64),
+               ld_C=np.asarray(task["ld_C"], np.float64), ld_X=np.asarray(task["ld_X"], np.float64),
+               ld_Y=np.asarray(task["ld_Y"], np.float64), action_cost=np.float64(task["action_cost"]),
+               reward_base=np.float64(task["reward_base"]), terminate_punish=np.float64(task["terminate_punish"]),
+               reward_factor=np.float64(task["reward_factor"]),
+               target_valid=np.asarray(task["target_valid"], np.int64), is_dynamic=np.int64(dyn),
+               initial_states=np.stack([np.asarray(x, np.float64) for x in task["initial_states"]]),
+               noise_drift=np.float64(task["noise_drift"]), target_delay=np.int64(task["target_delay"]))
+    if dyn:
+        c = task["command"]
+        out["four_orders"] = np.array([float(o) for o, _ in c.coeffs], np.float64)
+        out["four_coeffs"] = np.stack([np.asarray(f, np.float64) for _, f in c.coeffs])
+        out["four_period"] = np.float64(c.max_steps)
+    else:
+        out["command"] = np.asarray(task["command"], np.float64)
+    return out
+
+
+def gen_linds_one(name, task, T=512, seed0=5000, act_scale=1.5):
+    """G-L for one task: a T-step trajectory through the reference LinearDSEnv.step()/reset(), manual reset on
+    done.  numpy's global RNG is seeded before every step (process noise) and the stdlib RNG before every reset
+    (linds_env.py:117 uses random.choice); both draws are replayed and stored."""
+    import random as pyrandom
+    LinearDSEnv, _ = _refimport.linds()
+    import xenoverse.linds.linds_env as envmod
+    envmod.pseudo_random_seed = lambda *a, **k: 12345   # reset()'s reseeding of numpy: irrelevant, made inert
+
+    env = LinearDSEnv()   # dt=0.1, pads 16/16/8 (linds_env.py:16-19)
+    env.set_task(task)
+    ns = int(task["state_dim"])
+    n_init = len(task["initial_states"])
+    rng = np.random.RandomState(seed0)
+
+    def ref_reset(seed):
+        pyrandom.seed(int(seed))
+        idx = pyrandom.Random(int(seed)).randrange(n_init)   # what random.choice(list) draws
+        obs, info = env.reset()
+        assert np.array_equal(env._state, np.asarray(task["initial_states"][idx]))
+        return idx, np.asarray(obs, np.float64), np.asarray(info["command"], np.float64), float(info["error"])
+
+    acts = rng.uniform(-act_scale, act_scale, size=(T, env.pad_action_dim))
+    acts[rng.random_sample(T) < 0.3] *= 0.5
+    z = np.zeros((T, ns)); x_after = np.zeros((T, ns)); obs = np.zeros((T, 16)); cmd = np.zeros((T, 16))
+    reward = np.zeros(T); error = np.zeros(T); term = np.zeros(T, np.uint8); trunc = np.zeros(T, np.uint8)
+    steps = np.zeros(T, np.int64)
+    reset_idx = np.full(T, -1, np.int64); reset_obs = np.zeros((T, 16)); reset_cmd = np.zeros((T, 16))
+    reset_err = np.zeros(T)
+    init_idx, init_obs, init_cmd, init_err = ref_reset(seed0 + 1)
+    for t in range(T):
+        np.random.seed(seed0 + 100 + t)
+        o, r, te, tr, info = env.step(acts[t])
+        z[t] = np.random.RandomState(seed0 + 100 + t).standard_normal(ns)
+        x_after[t] = env._state
+        obs[t] = o; cmd[t] = info["command"]; reward[t] = r; error[t] = info["error"]
+        term[t] = te; trunc[t] = tr; steps[t] = info["steps"]
+        if te or tr:
+            reset_idx[t], reset_obs[t], reset_cmd[t], reset_err[t] = ref_reset(seed0 + 10000 + t)
+    out = _linds_task_arrays(task)
+    out.update(ref_phi=env.ld_phi, ref_gamma=env.ld_gamma, ref_xt=env.ld_Xt, dt=np.float64(env.dt),
+               tr_action=acts, tr_z=z, tr_x=x_after, tr_obs=obs, tr_cmd=cmd, tr_reward=reward, tr_error=error,
+               tr_term=term, tr_trunc=trunc, tr_steps=steps, tr_reset_idx=reset_idx, tr_reset_obs=reset_obs,
+               tr_reset_cmd=reset_cmd, tr_reset_err=reset_err,
+               init_idx=np.int64(init_idx), init_obs=init_obs, init_cmd=init_cmd, init_err=np.float64(init_err))
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; type", str(task["target_type"]), "delay",
+          int(task["target_delay"]), "terminated:", int(term.sum()), "truncated:", int(trunc.sum()))
+
+
+def gen_linds():
+    _, ts = _refimport.linds()
+    import random as pyrandom
+    got = {"dynamic_target": 0, "static_target": 0}
+    k = 0
+    tasks = []
+    while len(tasks) < 4:
+        k += 1
+        task = ts.LinearDSSampler(16, 8, 8, seed=k)   # not reproducible even with a seed (SURVEY L8): arrays are stored
+        ty = str(task["target_type"])
+        want = "dynamic_target" if len(tasks) in (0, 2, 3) else "static_target"
+        if ty != want:
+            continue
+        if want == "static_target" and not np.any(task["command"]):
+            continue
+        tasks.append(task)
+    tasks[0]["noise_drift"] = 0.0
+    tasks[1]["noise_drift"] = 0.013
+    tasks[2]["noise_drift"] = 0.02
+    tasks[2]["max_steps"] = 60                       # truncation at steps >= max_steps - 1
+    tasks[3]["initial_states"] = list(tasks[3]["initial_states"]) + [6.0 * np.random.RandomState(3).randn(16)]
+    for i, task in enumerate(tasks):
+        gen_linds_one("linds_16x8x8_%d" % i, task, seed0=5000 + 1000 * i)
+    # one (32, 8, 8) task: the reference sampler's initial-state rejection loop does not terminate at ns = 32
+    # (SURVEY.md §7), so its own building blocks are used with hand-built initial states
+    np.random.seed(77)
+    A, B, Cm, X, Y = ts.sample_variants_(32, 8, 8)
+    task = dict(state_dim=32, observation_dim=8, action_dim=8, max_steps=400, ld_A=A, ld_B=B, ld_C=Cm, ld_X=X,
+                ld_Y=Y, action_cost=0.01, reward_base=0.1, terminate_punish=3.0, reward_factor=0.5,
+                target_valid=ts.sample_target_spaces_(8), target_type="dynamic_target",
+                initial_states=[0.3 * np.random.randn(32) for _ in range(3)], noise_drift=0.01,
+                command=ts.RandomFourier(8), target_delay=7)
+    gen_linds_one("linds_32x8x8_0", task, T=384, seed0=9000)
+
+
+FAMILIES = {"anymdp": gen_anymdp, "linds": gen_linds}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

@@ -319,3 +319,213 @@ void xo_anymdp_synth(uint64_t seed, int64_t task_index_base, int n_task, int S, 
     }
   }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * LinDS — reference: linds/linds_env.py (dynamics :78-80, get_observation :83-91, get_inner_cmd :93-98,
+ * reset :108-131, step :133-169) and utils/random_nn.py:346-368 (RandomFourier.__call__).
+ *
+ * The reference computes in fp64; the device computes in fp32 (north_star: float dynamics within 1e-5 rel)
+ * with every product-sum spelled as an fmaf chain in a FIXED order, restated here operation for operation so
+ * that device-vs-oracle is bit-exact on the state/observation path:
+ *   x'_j = fmaf chain over k = 0..NS-1 of Phi[j][k]*x[k], continued over k = 0..NA-1 of Gamma[j][k]*act[k],
+ *          then + Xt[j], then fmaf(noise_scale, z_j, .)
+ *   y_j  = fmaf chain over k in xo_linds_yorder() of C[j][k]*x'[k], then + Y[j]
+ * ---------------------------------------------------------------------------------------------- */
+int xo_linds_yorder(int NS, int* ord) {
+  /* accumulator register r of lane-half h of a 32x32 MFMA tile holds row (r&3) + 8*(r>>2) + 4*h; a k-slab of
+   * the next 32x32x2 product takes (h=0, h=1) of one register */
+  int n = 0;
+  for (int r = 0; r < 16; ++r)
+    for (int hh = 0; hh < 2; ++hh) {
+      int k = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (k < NS) ord[n++] = k;
+    }
+  return n;
+}
+
+static inline const float* L_scal(const xo_linds* h, int t) { return h->scal + (size_t)t * 8; }
+static inline const int32_t* L_ints(const xo_linds* h, int t) { return h->ints + (size_t)t * 4; }
+
+void xo_linds_cmd(const xo_linds* h, int t, int tt, float* out) {
+  const int NO = h->NO;
+  const int nf = L_ints(h, t)[3];
+  const float* valid = h->valid + (size_t)t * NO;
+  if (nf == 0) { /* static target: command * target_valid (:95-96) */
+    for (int j = 0; j < NO; ++j) out[j] = h->cmd0[(size_t)t * NO + j] * valid[j];
+    return;
+  }
+  for (int j = 0; j < NO; ++j) out[j] = 0.0f;
+  for (int k = 0; k < nf; ++k) { /* random_nn.py:362-368: x = t/max_steps; y += c0*sin(order*x) + c1*cos(order*x) */
+    double ang = h->four_omega[(size_t)t * XO_LINDS_KMAX + k] * ((double)tt / h->four_period[t]);
+    ang -= 6.283185307179586476925286766559 * rint(ang * 0.15915494309189533576888376337251);
+    float sn = (float)sin(ang), cs = (float)cos(ang);
+    const float* c = h->four_coef + (((size_t)t * XO_LINDS_KMAX + k) * NO) * 2;
+    for (int j = 0; j < NO; ++j) {
+      out[j] = fmaf(c[2 * j], sn, out[j]);
+      out[j] = fmaf(c[2 * j + 1], cs, out[j]);
+    }
+  }
+  for (int j = 0; j < NO; ++j) out[j] *= valid[j]; /* :98 */
+}
+
+static inline void linds_observe(const xo_linds* h, int t, const float* xs, float* y) {
+  int ord[32];
+  const int n = xo_linds_yorder(h->NS, ord);
+  for (int j = 0; j < h->NO; ++j) {
+    float acc = 0.0f;
+    for (int p = 0; p < n; ++p)
+      acc = fmaf(h->cT[((size_t)t * h->NS + ord[p]) * h->NO + j], xs[ord[p]], acc);
+    y[j] = acc + h->y0[(size_t)t * h->NO + j]; /* :85 */
+  }
+}
+
+static inline float linds_err(const xo_linds* h, int t, const float* y, const float* cmd) {
+  /* error = || (obs[:no] - cmd) * target_valid ||  (:127, :153) */
+  float acc = 0.0f;
+  for (int j = 0; j < h->NO; ++j) {
+    float d = (y[j] - cmd[j]) * h->valid[(size_t)t * h->NO + j];
+    acc = fmaf(d, d, acc);
+  }
+  return sqrtf(acc);
+}
+
+static void linds_reset_one(xo_linds* h, int i, int idx, float* obs, float* cmd, float* error) {
+  const int t = h->env_task[i], NS = h->NS, NO = h->NO;
+  const int n_init = L_ints(h, t)[2];
+  if (idx < 0) idx = 0;
+  if (idx >= n_init) idx = n_init - 1;
+  float xs[32];
+  for (int k = 0; k < NS; ++k) { /* :117 */
+    xs[k] = h->init[((size_t)t * h->NI + idx) * NS + k];
+    h->x[(size_t)k * h->n_env + i] = xs[k];
+  }
+  h->steps[i] = 0;
+  h->need_reset[i] = 0;
+  float y[32], c[32];
+  linds_observe(h, t, xs, y);
+  xo_linds_cmd(h, t, 0, c); /* :120-126: the last pre-filled command is cmd(0) */
+  if (obs) for (int j = 0; j < NO; ++j) obs[(size_t)i * NO + j] = y[j];
+  if (cmd) for (int j = 0; j < NO; ++j) cmd[(size_t)i * NO + j] = c[j];
+  if (error) error[i] = linds_err(h, t, y, c);
+}
+
+void xo_linds_reset_injected(xo_linds* h, const uint8_t* mask, const int32_t* init_index, float* obs,
+                             float* cmd, float* error) {
+  for (int i = 0; i < h->n_env; ++i)
+    if (!mask || mask[i]) linds_reset_one(h, i, init_index[i], obs, cmd, error);
+}
+
+static void linds_step_one(xo_linds* h, int i, const float* a_raw, const float* z /*[NS] for this env*/,
+                           int init_idx, float* obs, float* reward, uint8_t* terminated,
+                           uint8_t* truncated, float* cmd, float* error, float* final_obs, int mode) {
+  const int t = h->env_task[i], NS = h->NS, NA = h->NA, NO = h->NO, N = h->n_env;
+  const float* sc = L_scal(h, t);
+  const int32_t* in = L_ints(h, t);
+  if (final_obs) for (int j = 0; j < NO; ++j) final_obs[(size_t)i * NO + j] = 0.0f;
+  if (mode == 1 && h->need_reset[i]) { /* NEXT_STEP: the call after a done returns the reset observation */
+    linds_reset_one(h, i, init_idx, obs, cmd, error);
+    reward[i] = 0.0f; terminated[i] = 0; truncated[i] = 0;
+    return;
+  }
+  float xs[32], xn[32], act[32], y[32], ctrack[32], crep[32];
+  for (int k = 0; k < NS; ++k) xs[k] = h->x[(size_t)k * N + i];
+  float sa = 0.0f;
+  for (int k = 0; k < NA; ++k) { /* :138 clip; :164 cost on the RAW padded action */
+    float a = a_raw[k];
+    sa = fmaf(a, a, sa);
+    act[k] = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);
+  }
+  for (int j = 0; j < NS; ++j) { /* :78-80 */
+    float acc = 0.0f;
+    for (int k = 0; k < NS; ++k) acc = fmaf(h->phiT[((size_t)t * NS + k) * NS + j], xs[k], acc);
+    for (int k = 0; k < NA; ++k) acc = fmaf(h->gamT[((size_t)t * NA + k) * NS + j], act[k], acc);
+    acc = acc + h->xt[(size_t)t * NS + j];
+    xn[j] = fmaf(sc[4], z[j], acc);
+  }
+  linds_observe(h, t, xn, y); /* :145 */
+  const int steps = h->steps[i] + 1; /* :147 */
+  xo_linds_cmd(h, t, steps - 1 - in[1], ctrack); /* :150-151: tracked command is cmd(steps-1-delay) */
+  xo_linds_cmd(h, t, steps, crep);               /* :168: reported command is cmd(steps) */
+  const float err = linds_err(h, t, y, ctrack);  /* :153 */
+  float sc2 = 0.0f;
+  for (int j = 0; j < NO; ++j) sc2 = fmaf(y[j], y[j], sc2);
+  const float obs_scale = sqrtf(sc2); /* :154 */
+  const int term = (err > 10.0f) || (obs_scale > 20.0f); /* :156 */
+  float r = term ? -sc[2] : 0.0f; /* :158-161 */
+  float tmp = fmaf(-sc[3], err, sc[1]);
+  tmp = fmaf(-sc[0], sa, tmp);
+  r = fmaf(tmp, sc[5], r); /* :163-164 */
+  const int trunc = steps >= in[0] - 1; /* :165 */
+  for (int k = 0; k < NS; ++k) h->x[(size_t)k * N + i] = xn[k];
+  h->steps[i] = steps;
+  for (int j = 0; j < NO; ++j) { obs[(size_t)i * NO + j] = y[j]; cmd[(size_t)i * NO + j] = crep[j]; }
+  reward[i] = r; error[i] = err; terminated[i] = (uint8_t)term; truncated[i] = (uint8_t)trunc;
+  int bad = 0;
+  for (int k = 0; k < NS; ++k) if (!isfinite(xn[k])) bad = 1;
+  if (bad) h->err_flags |= 4u;
+  if (term || trunc) {
+    if (mode == 2) {
+      if (final_obs) for (int j = 0; j < NO; ++j) final_obs[(size_t)i * NO + j] = y[j];
+      linds_reset_one(h, i, init_idx, obs, cmd, error);
+    } else if (mode == 1) {
+      h->need_reset[i] = 1;
+    }
+  }
+}
+
+void xo_linds_step_injected(xo_linds* h, const float* action, const float* z, const int32_t* init_index,
+                            float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, float* cmd,
+                            float* error, float* final_obs, int mode) {
+  float zz[32];
+  for (int i = 0; i < h->n_env; ++i) {
+    for (int k = 0; k < h->NS; ++k) zz[k] = z[(size_t)k * h->n_env + i];
+    linds_step_one(h, i, action + (size_t)i * h->NA, zz, init_index[i], obs, reward, terminated, truncated,
+                   cmd, error, final_obs, mode);
+  }
+}
+
+/* free-running draws: reset index = floor(u53 * n_init) from purpose 1; normals for state component j from
+ * Philox purpose 16 + j/4: words (0,1) -> z[4q], z[4q+1] (cos, sin), words (2,3) -> z[4q+2], z[4q+3] */
+static inline int linds_draw_init(const xo_linds* h, int i, uint64_t seed, uint64_t gid, uint64_t tick) {
+  uint32_t w[4];
+  xo_env_draw(seed, gid, tick, 1, w);
+  int n = L_ints(h, h->env_task[i])[2];
+  int idx = (int)(xo_u53(w[0], w[1]) * (double)n);
+  return idx < n ? idx : n - 1;
+}
+static inline void linds_draw_noise(int NS, uint64_t seed, uint64_t gid, uint64_t tick, float* z) {
+  for (int q = 0; q * 4 < NS; ++q) {
+    uint32_t w[4];
+    float a, b, c, d;
+    xo_env_draw(seed, gid, tick, 16u + (uint32_t)q, w);
+    xo_box_muller(w[0], w[1], &a, &b);
+    xo_box_muller(w[2], w[3], &c, &d);
+    float v[4] = {a, b, c, d};
+    for (int e = 0; e < 4 && 4 * q + e < NS; ++e) z[4 * q + e] = v[e];
+  }
+}
+
+void xo_linds_reset(xo_linds* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const uint8_t* mask,
+                    float* obs, float* cmd, float* error) {
+  for (int i = 0; i < h->n_env; ++i) {
+    if (mask && !mask[i]) continue;
+    linds_reset_one(h, i, linds_draw_init(h, i, seed, gid_base + (uint64_t)i, tick), obs, cmd, error);
+  }
+}
+
+void xo_linds_step(xo_linds* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const float* action,
+                   float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, float* cmd,
+                   float* error, float* final_obs, int mode, int n_threads) {
+  (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads > 0 ? n_threads : 1) schedule(static)
+#endif
+  for (int i = 0; i < h->n_env; ++i) {
+    float zz[32];
+    const uint64_t gid = gid_base + (uint64_t)i;
+    linds_draw_noise(h->NS, seed, gid, tick, zz);
+    const int idx = linds_draw_init(h, i, seed, gid, tick);
+    linds_step_one(h, i, action + (size_t)i * h->NA, zz, idx, obs, reward, terminated, truncated, cmd,
+                   error, final_obs, mode);
+  }
+}

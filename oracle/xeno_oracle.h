@@ -66,6 +66,52 @@ void xo_anymdp_synth(uint64_t seed, int64_t task_index_base, int n_task, int S, 
                      int32_t* s0_ids, int32_t* max_steps);
 int xo_max_threads(void);
 
+/* ---------------------------------------------------------------------------------------------
+ * LinDS — reference: linds/linds_env.py.  fp32 arithmetic in the device's fixed operation order.
+ * Batch-wide padded dims NS (state), NA (= pad_action_dim), NO (= pad_observation_dim = pad_command_dim).
+ * Matrices are stored transposed (k-major), as the device reads them.
+ * ------------------------------------------------------------------------------------------- */
+#define XO_LINDS_KMAX 6
+typedef struct {
+  int n_env, n_task, NS, NA, NO, NI;
+  const float* phiT;   /* [n_task][NS][NS]  phiT[k][j] = Phi[j][k] */
+  const float* gamT;   /* [n_task][NA][NS]  gamT[k][j] = Gamma[j][k] */
+  const float* cT;     /* [n_task][NS][NO]  cT[k][j]   = C[j][k] */
+  const float* xt;     /* [n_task][NS]      X * dt */
+  const float* y0;     /* [n_task][NO]      ld_Y */
+  const float* valid;  /* [n_task][NO]      target_valid (0/1) */
+  const float* cmd0;   /* [n_task][NO]      static command */
+  const float* four_coef;    /* [n_task][KMAX][NO][2] */
+  const double* four_omega;  /* [n_task][KMAX] */
+  const double* four_period; /* [n_task] RandomFourier.max_steps */
+  const float* scal;   /* [n_task][8]: action_cost, reward_base, terminate_punish, reward_factor,
+                                       noise_drift*dt, dt, 0, 0 */
+  const int32_t* ints; /* [n_task][4]: max_steps, target_delay, n_init, four_n (0 = static target) */
+  const float* init;   /* [n_task][NI][NS] initial states */
+  const int32_t* env_task;
+  float* x;            /* [NS][n_env] component-major state */
+  int32_t* steps;
+  uint8_t* need_reset;
+  uint32_t err_flags;
+} xo_linds;
+
+/* command at integer time t (linds_env.py:93-98, utils/random_nn.py:362-368), times target_valid */
+void xo_linds_cmd(const xo_linds* h, int task, int t, float* out /*[NO]*/);
+void xo_linds_reset_injected(xo_linds* h, const uint8_t* mask, const int32_t* init_index, float* obs,
+                             float* cmd, float* error);
+void xo_linds_step_injected(xo_linds* h, const float* action /*[n_env][NA]*/, const float* z /*[NS][n_env]*/,
+                            const int32_t* init_index, float* obs /*[n_env][NO]*/, float* reward,
+                            uint8_t* terminated, uint8_t* truncated, float* cmd /*[n_env][NO]*/,
+                            float* error, float* final_obs /*nullable*/, int mode);
+void xo_linds_reset(xo_linds* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const uint8_t* mask,
+                    float* obs, float* cmd, float* error);
+void xo_linds_step(xo_linds* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const float* action,
+                   float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, float* cmd,
+                   float* error, float* final_obs, int mode, int n_threads);
+/* k order of the observation product y = C x (the order an MFMA 32x32x2 chain visits k when x' is consumed
+ * straight from the accumulator layout of the previous product): fills ord[NS], returns NS */
+int xo_linds_yorder(int NS, int* ord);
+
 #ifdef __cplusplus
 }
 #endif

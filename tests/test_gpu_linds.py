@@ -1,0 +1,176 @@
+"""GPU parity: the HIP LinDS path (through the C-ABI) vs the reference's golden trajectories (1e-5 rel, per
+step from the reference's own state) and vs the CPU oracle on seeded batches (state/observation path
+bit-exact: same fp32 fmaf chains in the same order; command/reward within 1e-5 because sinf differs)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from xenoverse_amd.linds import LinDSVecEnv, build_tables, pad_tables
+from util import close_rel, golden_files, load_linds_golden
+from test_oracle_linds import _before_states
+
+pytestmark = pytest.mark.gpu
+FILES = golden_files("linds_")
+MODES = {"disabled": 0, "next_step": 1, "same_step": 2}
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("path", FILES)
+def test_golden_every_step_from_reference_state(path):
+    g, task = load_linds_golden(path)
+    T, ns = g["tr_x"].shape
+    xb, sb = _before_states(g)
+    env = LinDSVecEnv(T, autoreset_mode="disabled")
+    env.set_task(task)
+    env.set_state(x=xb.T.astype(np.float32), steps=sb, need_reset=np.zeros(T))
+    obs, r, term, trunc, info = env.step_injected(g["tr_action"], g["tr_z"].T, np.zeros(T))
+    x, st, _ = env.get_state()
+    assert np.array_equal(_np(term).astype(np.uint8), g["tr_term"])
+    assert np.array_equal(_np(trunc).astype(np.uint8), g["tr_trunc"])
+    assert np.array_equal(_np(st), g["tr_steps"])
+    assert close_rel(_np(x)[:ns].T, g["tr_x"])
+    assert close_rel(_np(obs), g["tr_obs"])
+    assert close_rel(_np(info["command"]), g["tr_cmd"])
+    assert close_rel(_np(info["error"]), g["tr_error"])
+    assert close_rel(_np(r), g["tr_reward"])
+    assert env.check_errors() == 0
+    env.close()
+
+
+@pytest.mark.parametrize("path", FILES[:2])
+def test_golden_reset(path):
+    g, task = load_linds_golden(path)
+    done = np.nonzero(g["tr_term"] | g["tr_trunc"])[0]
+    idx = np.concatenate([[int(g["init_idx"])], g["tr_reset_idx"][done]]).astype(np.int32)
+    env = LinDSVecEnv(len(idx), autoreset_mode="disabled")
+    env.set_task(task)
+    obs, info = env.reset_injected(idx)
+    assert close_rel(_np(obs), np.concatenate([g["init_obs"][None], g["tr_reset_obs"][done]]))
+    assert close_rel(_np(info["command"]), np.concatenate([g["init_cmd"][None], g["tr_reset_cmd"][done]]))
+    assert close_rel(_np(info["error"]), np.concatenate([[float(g["init_err"])], g["tr_reset_err"][done]]))
+    env.close()
+
+
+def _batch(n_per_task, files):
+    tasks = [load_linds_golden(p)[1] for p in files]
+    for t in tasks:
+        t["max_steps"] = min(int(t["max_steps"]), 40)     # make episodes end inside the test
+    tab = pad_tables(build_tables(tasks))
+    env_task = np.repeat(np.arange(len(tasks), dtype=np.int32), n_per_task)
+    return tasks, tab, env_task
+
+
+def _cmp(dev, ora, exact_state=True):
+    obs, r, term, trunc, info = dev
+    assert np.array_equal(_np(term).astype(np.uint8), ora["terminated"])
+    assert np.array_equal(_np(trunc).astype(np.uint8), ora["truncated"])
+    no = _np(obs).shape[1]
+    if exact_state:
+        assert np.array_equal(_np(obs), ora["obs"][:, :no])
+    else:
+        assert close_rel(_np(obs), ora["obs"][:, :no])
+    assert close_rel(_np(info["command"]), ora["cmd"][:, :no], 1e-5, 2e-6)
+    assert close_rel(_np(info["error"]), ora["error"], 1e-5, 2e-6)
+    assert close_rel(_np(r), ora["reward"], 1e-5, 2e-6)
+
+
+@pytest.mark.parametrize("mode", ["disabled", "next_step", "same_step"])
+@pytest.mark.parametrize("layout", ["grouped64", "grouped32", "mixed"])
+def test_batch_injected_vs_oracle(mode, layout):
+    tasks, tab, env_task = _batch(64 if layout != "grouped32" else 32, FILES[:4])
+    rng = np.random.RandomState(3)
+    if layout == "mixed":
+        rng.shuffle(env_task)              # lanes of one wave hold different tasks: the waterfall path
+    n = len(env_task)
+    env = LinDSVecEnv(n, autoreset_mode=mode)
+    env.set_task(tasks, env_task_index=env_task)
+    ora = oracle.LinDSOracle(tab, env_task)
+    n_init = tab["ints"][env_task, 2]
+    idx0 = (rng.random_sample(n) * n_init).astype(np.int32)
+    obs, info = env.reset_injected(idx0)
+    o0 = ora.reset_injected(idx0)
+    assert np.array_equal(_np(obs), o0["obs"][:, :16])
+    ended = 0
+    for t in range(90):
+        a = rng.uniform(-1.4, 1.4, (n, 8)).astype(np.float32)
+        z = rng.standard_normal((tab["NS"], n)).astype(np.float32)
+        idx = (rng.random_sample(n) * n_init).astype(np.int32)
+        d = env.step_injected(a, z, idx)
+        o = ora.step_injected(a, z, idx, MODES[mode])
+        _cmp(d, o)
+        x, st, nr = env.get_state()
+        assert np.array_equal(_np(x), ora.x) and np.array_equal(_np(st), ora.steps)
+        assert np.array_equal(_np(nr), ora.need_reset)
+        ended += int((o["terminated"] | o["truncated"]).sum())
+        if mode == "same_step":
+            done = (o["terminated"] | o["truncated"]).astype(bool)
+            assert np.array_equal(_np(d[4]["final_obs"])[done], o["final_obs"][done][:, :16])
+        if mode == "disabled":
+            m = (o["terminated"] | o["truncated"]).astype(np.uint8)
+            if m.any():
+                env.reset_injected(idx, mask=m)
+                ora.reset_injected(idx, mask=m)
+    assert ended > 20
+    env.close()
+
+
+def test_free_running_philox_vs_oracle():
+    tasks, tab, env_task = _batch(64, FILES[:4])
+    n = len(env_task)
+    seed, base = 987654321, 5000
+    env = LinDSVecEnv(n, autoreset_mode="same_step", seed=seed, env_id_base=base)
+    env.set_task(tasks, env_task_index=env_task)
+    ora = oracle.LinDSOracle(tab, env_task)
+    tick = env.engine.tick
+    obs, info = env.reset()
+    o0 = ora.reset(seed, base, tick)
+    assert np.array_equal(_np(obs), o0["obs"][:, :16])
+    rng = np.random.RandomState(5)
+    for t in range(60):
+        a = rng.uniform(-1.2, 1.2, (n, 8)).astype(np.float32)
+        tick = env.engine.tick
+        d = env.step(a)
+        o = ora.step(seed, base, tick, a, 2)
+        _cmp(d, o, exact_state=False)      # Box-Muller: device logf/sincospif vs host double -> 1e-5
+        x, st, _ = env.get_state()
+        assert close_rel(_np(x), ora.x, 1e-5, 2e-6) and np.array_equal(_np(st), ora.steps)
+        ora.x[:] = _np(x)                  # re-sync so tolerance does not compound over the trajectory
+    env.close()
+
+
+def test_state_dim_32_task():
+    g, task = load_linds_golden([f for f in FILES if "32x8x8" in f][0])
+    tab = pad_tables(build_tables([task]))
+    assert tab["NS"] == 32
+    n = 128
+    env = LinDSVecEnv(n, autoreset_mode="same_step")
+    env.set_task(task)
+    ora = oracle.LinDSOracle(tab, np.zeros(n, np.int32))
+    rng = np.random.RandomState(0)
+    idx = rng.randint(0, 3, n).astype(np.int32)
+    env.reset_injected(idx); ora.reset_injected(idx)
+    for t in range(50):
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        z = rng.standard_normal((32, n)).astype(np.float32)
+        idx = rng.randint(0, 3, n).astype(np.int32)
+        _cmp(env.step_injected(a, z, idx), ora.step_injected(a, z, idx, 2))
+    assert np.array_equal(_np(env.get_state()[0]), ora.x)
+    env.close()
+
+
+def test_misuse_messages():
+    g, task = load_linds_golden(FILES[0])
+    env = LinDSVecEnv(4)
+    with pytest.raises(Exception, match="Must call \"set_task\" first"):
+        env.reset()
+    env.set_task(task)
+    with pytest.raises(Exception, match="before doing any actions"):
+        env.step(np.zeros((4, 8), np.float32))
+    env.reset()
+    with pytest.raises(AssertionError, match="Action shape mismatch"):
+        env.step(np.zeros((4, 5), np.float32))
+    env.close()

@@ -25,3 +25,40 @@ def close_f32(a, b, rel=1e-5, abs_=1e-6):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return np.all(np.abs(a - b) <= rel * np.abs(b) + abs_)
+
+
+class FourierCommand(object):
+    """Duck-type of the reference's RandomFourier (utils/random_nn.py:346-368): `.coeffs`, `.max_steps`."""
+
+    def __init__(self, orders, coeffs, max_steps):
+        self.coeffs = [(float(o), np.asarray(c, np.float64)) for o, c in zip(orders, coeffs)]
+        self.max_steps = float(max_steps)
+
+    def __call__(self, t):
+        x = t / self.max_steps
+        y = 0
+        for order, coeff in self.coeffs:
+            y = y + coeff[:, 0] * np.sin(order * x) + coeff[:, 1] * np.cos(order * x)
+        return y
+
+
+def load_linds_golden(path):
+    g = dict(np.load(path, allow_pickle=False))
+    dyn = bool(g["is_dynamic"])
+    task = dict(state_dim=int(g["state_dim"]), observation_dim=int(g["observation_dim"]),
+                action_dim=int(g["action_dim"]), max_steps=int(g["max_steps"]), ld_A=g["ld_A"], ld_B=g["ld_B"],
+                ld_C=g["ld_C"], ld_X=g["ld_X"], ld_Y=g["ld_Y"], action_cost=float(g["action_cost"]),
+                reward_base=float(g["reward_base"]), terminate_punish=float(g["terminate_punish"]),
+                reward_factor=float(g["reward_factor"]), target_valid=g["target_valid"],
+                target_type="dynamic_target" if dyn else "static_target",
+                initial_states=[x for x in g["initial_states"]], noise_drift=float(g["noise_drift"]),
+                target_delay=int(g["target_delay"]))
+    task["command"] = (FourierCommand(g["four_orders"], g["four_coeffs"], g["four_period"]) if dyn
+                       else g["command"])
+    return g, task
+
+
+def close_rel(a, b, rel=1e-5, abs_=1e-5):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return bool(np.all(np.abs(a - b) <= rel * np.abs(b) + abs_))

@@ -1,0 +1,486 @@
+// linds.hip — LinDS (randomised LTI control) batched step / reset kernels for gfx950 and their C-ABI.
+//
+// Reproduces xenoverse/linds/linds_env.py: dynamics :78-80, get_observation :83-91, get_inner_cmd :93-98,
+// reset :108-131, step :133-169, and RandomFourier.__call__ (utils/random_nn.py:362-368), for N envs per
+// launch in fp32.  Operation order is fixed and restated by oracle/xeno_oracle.c (xo_linds_*):
+//   x'_j = fmaf chain over k=0..NS-1 of Phi[j][k] x[k], then k=0..NA-1 of Gamma[j][k] act[k], + Xt[j],
+//          then fmaf(noise_scale, z_j, .)
+//   y_j  = fmaf chain of C[j][k] x'[k] over k in the MFMA accumulator order (linds_yorder), + Y[j]
+//
+// One lane owns one env: its state vector lives in registers (component-major global layout, so the NS loads
+// and stores of a wave are NS coalesced 256-B streams).  The task matrices are NOT read per lane: inside a
+// waterfall over the distinct tasks present in a wave the task index is wave-uniform, so Phi/Gamma/C rows
+// arrive through the scalar cache as SGPR operands of v_fma_f32 (s_load_dwordx16) — 6 KB per (wave, task)
+// instead of 6 KB per env.  With envs grouped by task (64 per task = one wave per task) every wave makes one
+// pass.
+#include "philox.h"
+#include "xv_common.h"
+
+struct LinDSArgs {
+  xv_linds_tables T;
+  const int32_t* env_task;
+  float* x;            // [NS][n_env]
+  int32_t* steps;
+  uint8_t* need_reset;
+  uint32_t* err;
+  int n_env, n_task, NS, NA, NO, NI;
+  uint64_t seed, gid_base, tick;
+};
+
+struct LinDSStepIO {
+  const float* action;      // [n_env][NA]
+  const float* z;           // [NS][n_env]  (INJECT)
+  const int32_t* init_index;// [n_env]      (INJECT)
+  float* obs;               // [n_env][NO]
+  float* reward;
+  uint8_t* terminated;
+  uint8_t* truncated;
+  float* cmd;               // [n_env][NO]
+  float* error;
+  float* final_obs;         // nullable
+};
+
+struct xv_linds {
+  xv_engine* eng;
+  LinDSArgs a;
+};
+
+// Task tables are read-only for the lifetime of a launch: reading them through the constant address space lets
+// hipcc turn every wave-uniform access into an s_load (scalar cache, SGPR operand) instead of 64 identical
+// vector loads.  (A plain `const float*` stays a vector global_load even when its address is uniform.)
+#define XV_CONST_AS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const XV_CONST_AS T* xv_cptr(const T* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (const XV_CONST_AS T*)p;
+#pragma clang diagnostic pop
+}
+
+// k order of the observation product: the order in which a 32x32x2 MFMA chain visits k when x' is consumed
+// from the accumulator layout of the previous product (register r, lane-half h -> row (r&3)+8(r>>2)+4h)
+__host__ __device__ constexpr int linds_yorder_at(int p) {
+  return ((p >> 1) & 3) + 8 * ((p >> 1) >> 2) + 4 * (p & 1);
+}
+
+// command at integer time tt, times target_valid (uniform task tu; per-lane time)
+template <int NO>
+__device__ __forceinline__ void linds_cmd(const LinDSArgs& P, int tu, int nf, int tt, float (&out)[NO]) {
+  const XV_CONST_AS float* valid = xv_cptr(P.T.valid) + (size_t)tu * NO;
+  if (nf == 0) {   // static target: command * target_valid (:95-96)
+    const XV_CONST_AS float* c0 = xv_cptr(P.T.cmd0) + (size_t)tu * NO;
+#pragma unroll
+    for (int j = 0; j < NO; ++j) out[j] = c0[j] * valid[j];
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < NO; ++j) out[j] = 0.0f;
+  const double inv_period_t = (double)tt / xv_cptr(P.T.four_period)[tu];
+  for (int k = 0; k < nf; ++k) {   // random_nn.py:362-368
+    double ang = xv_cptr(P.T.four_omega)[(size_t)tu * XV_LINDS_KMAX + k] * inv_period_t;
+    ang -= 6.283185307179586476925286766559 * rint(ang * 0.15915494309189533576888376337251);
+    float sn, cs;
+    sincosf((float)ang, &sn, &cs);
+    const XV_CONST_AS float* c = xv_cptr(P.T.four_coef) + (((size_t)tu * XV_LINDS_KMAX + k) * NO) * 2;
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+      out[j] = fmaf(c[2 * j], sn, out[j]);
+      out[j] = fmaf(c[2 * j + 1], cs, out[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NO; ++j) out[j] *= valid[j];   // :98
+}
+
+// y = C x + Y with the fixed k order (uniform task tu)
+template <int NS, int NO>
+__device__ __forceinline__ void linds_observe(const LinDSArgs& P, int tu, const float (&xs)[NS], float (&y)[NO]) {
+  const XV_CONST_AS float* cT = xv_cptr(P.T.cT) + (size_t)tu * NS * NO;
+  const XV_CONST_AS float* y0 = xv_cptr(P.T.y0) + (size_t)tu * NO;
+#pragma unroll
+  for (int j = 0; j < NO; ++j) y[j] = 0.0f;
+#pragma unroll
+  for (int p = 0; p < 32; ++p) {
+    const int k = linds_yorder_at(p);
+    if (k < NS) {
+#pragma unroll
+      for (int j = 0; j < NO; ++j) y[j] = fmaf(cT[k * NO + j], xs[k], y[j]);
+      __builtin_amdgcn_sched_barrier(0);   // one row of scalar loads at a time (see linds_step_kernel)
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NO; ++j) y[j] = y[j] + y0[j];   // :85
+}
+
+template <int NO>
+__device__ __forceinline__ float linds_err(const LinDSArgs& P, int tu, const float (&y)[NO], const float (&c)[NO]) {
+  float acc = 0.0f;
+  const XV_CONST_AS float* valid = xv_cptr(P.T.valid) + (size_t)tu * NO;
+#pragma unroll
+  for (int j = 0; j < NO; ++j) {   // :127, :153
+    const float d = (y[j] - c[j]) * valid[j];
+    acc = fmaf(d, d, acc);
+  }
+  return sqrtf(acc);
+}
+
+template <int N>
+__device__ __forceinline__ void linds_store_row(float* dst, const float (&v)[N]) {
+  float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+  for (int q = 0; q < N / 4; ++q) d4[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+// reset of one env inside the uniform-task region: x = initial_states[idx]; obs; cmd(0); error
+template <int NS, int NO>
+__device__ __forceinline__ void linds_reset_env(const LinDSArgs& P, int tu, int nf, int n_init, int idx,
+                                                float (&xs)[NS], float (&y)[NO], float (&c)[NO], float& err) {
+  idx = idx < 0 ? 0 : (idx >= n_init ? n_init - 1 : idx);
+  const float* x0 = P.T.init + ((size_t)tu * P.NI + idx) * NS;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) xs[k] = x0[k];   // :117
+  linds_observe<NS, NO>(P, tu, xs, y);
+  linds_cmd<NO>(P, tu, nf, 0, c);                // :120-126: the last pre-filled command is cmd(0)
+  err = linds_err<NO>(P, tu, y, c);
+}
+
+__device__ __forceinline__ int linds_draw_init(const LinDSArgs& P, uint64_t gid, int n_init) {
+  const xv_u32x4 v = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_RESET);
+  const int idx = (int)(xv_u53(v.x, v.y) * (double)n_init);
+  return idx < n_init ? idx : n_init - 1;
+}
+
+template <int NS, int NA, int NO, bool INJECT>
+__global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepIO io, int mode) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n_env) return;
+  const int N = P.n_env;
+  const int t = P.env_task[i];
+  const uint64_t gid = P.gid_base + (uint64_t)i;
+
+  float xs[NS], a_raw[NA], z[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) xs[k] = P.x[(size_t)k * N + i];
+  {
+    const float4* a4 = reinterpret_cast<const float4*>(io.action + (size_t)i * NA);
+#pragma unroll
+    for (int q = 0; q < NA / 4; ++q) {
+      const float4 v = a4[q];
+      a_raw[4 * q] = v.x; a_raw[4 * q + 1] = v.y; a_raw[4 * q + 2] = v.z; a_raw[4 * q + 3] = v.w;
+    }
+  }
+  int steps = P.steps[i];
+  int nr = P.need_reset[i];
+  int init_idx = 0;
+  if (INJECT) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) z[k] = io.z[(size_t)k * N + i];
+    init_idx = io.init_index[i];
+  } else {
+#pragma unroll
+    for (int q = 0; q < NS / 4; ++q) {   // purpose 16+q: words (0,1) -> z[4q], z[4q+1]; (2,3) -> z[4q+2], z[4q+3]
+      const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_NOISE + (uint32_t)q);
+      xv_box_muller(w.x, w.y, &z[4 * q], &z[4 * q + 1]);
+      xv_box_muller(w.z, w.w, &z[4 * q + 2], &z[4 * q + 3]);
+    }
+  }
+
+  float y[NO], crep[NO], fobs[NO];
+  float o_r = 0.0f, o_err = 0.0f;
+  bool o_term = false, o_trunc = false, wrote_fobs = false;
+  uint32_t err = 0;
+
+  // waterfall over the distinct tasks of this wave: inside, `tu` is wave-uniform (SGPR) and so is every
+  // table address derived from it -> scalar loads, broadcast operands
+  for (;;) {
+    const int tu_cmp = __builtin_amdgcn_readfirstlane(t);
+    // hipcc's equality propagation rewrites the compared value as the per-lane `t` inside the branch, which would
+    // turn every table address divergent (vector loads + spills): the copy used inside is laundered through an
+    // SGPR-constrained empty asm BEFORE the branch, so the compiler cannot relate it to `t`
+    int tu = tu_cmp;
+    asm volatile("" : "+s"(tu));
+    if (t == tu_cmp) {
+      const XV_CONST_AS float* sc = xv_cptr(P.T.scal) + (size_t)tu * 8;
+      const XV_CONST_AS int32_t* in = xv_cptr(P.T.ints) + (size_t)tu * 4;
+      const int max_steps = in[0], delay = in[1], n_init = in[2], nf = in[3];
+      if (!INJECT) init_idx = linds_draw_init(P, gid, n_init);
+      if (mode == XV_AUTORESET_NEXT_STEP && nr) {
+        // the call after a done ignores the action and returns the reset observation
+        linds_reset_env<NS, NO>(P, tu, nf, n_init, init_idx, xs, y, crep, o_err);
+        steps = 0;
+        nr = 0;
+      } else {
+        float sa = 0.0f, act[NA];
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {   // :138 clip; :164 cost on the RAW padded action
+          sa = fmaf(a_raw[k], a_raw[k], sa);
+          act[k] = a_raw[k] < -1.0f ? -1.0f : (a_raw[k] > 1.0f ? 1.0f : a_raw[k]);
+        }
+        float xn[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) xn[j] = 0.0f;
+        const XV_CONST_AS float* phiT = xv_cptr(P.T.phiT) + (size_t)tu * NS * NS;
+        const XV_CONST_AS float* gamT = xv_cptr(P.T.gamT) + (size_t)tu * NA * NS;
+        const XV_CONST_AS float* xtv = xv_cptr(P.T.xt) + (size_t)tu * NS;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {   // :78-80, Phi x
+#pragma unroll
+          for (int j = 0; j < NS; ++j) xn[j] = fmaf(phiT[k * NS + j], xs[k], xn[j]);
+          // without this hipcc hoists all ~160 s_load_dwordx16 of the three products to the top and spills
+          // ~2,500 SGPRs into VGPR lanes (v_writelane/v_readlane dominate the kernel)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {   // + Gamma act
+#pragma unroll
+          for (int j = 0; j < NS; ++j) xn[j] = fmaf(gamT[k * NS + j], act[k], xn[j]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const float noise_scale = sc[4];
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {   // + Xt + noise
+          xn[j] = xn[j] + xtv[j];
+          xn[j] = fmaf(noise_scale, z[j], xn[j]);
+          bad = bad || !(fabsf(xn[j]) <= 3.0e38f);
+        }
+        if (bad) err |= XV_DEVERR_NONFINITE;
+        linds_observe<NS, NO>(P, tu, xn, y);      // :145
+        steps += 1;                               // :147
+        float ctrack[NO];
+        linds_cmd<NO>(P, tu, nf, steps - 1 - delay, ctrack);   // :150-151 tracked command
+        linds_cmd<NO>(P, tu, nf, steps, crep);                 // :168 reported command
+        o_err = linds_err<NO>(P, tu, y, ctrack);               // :153
+        float sc2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NO; ++j) sc2 = fmaf(y[j], y[j], sc2);
+        const float obs_scale = sqrtf(sc2);                    // :154
+        o_term = (o_err > 10.0f) || (obs_scale > 20.0f);       // :156
+        o_r = o_term ? -sc[2] : 0.0f;                          // :158-161
+        float tmp = fmaf(-sc[3], o_err, sc[1]);
+        tmp = fmaf(-sc[0], sa, tmp);
+        o_r = fmaf(tmp, sc[5], o_r);                           // :163-164
+        o_trunc = steps >= max_steps - 1;                      // :165
+#pragma unroll
+        for (int k = 0; k < NS; ++k) xs[k] = xn[k];
+        if (o_term || o_trunc) {
+          if (mode == XV_AUTORESET_SAME_STEP) {
+#pragma unroll
+            for (int j = 0; j < NO; ++j) fobs[j] = y[j];
+            wrote_fobs = true;
+            linds_reset_env<NS, NO>(P, tu, nf, n_init, init_idx, xs, y, crep, o_err);
+            steps = 0;
+          } else if (mode == XV_AUTORESET_NEXT_STEP) {
+            nr = 1;
+          }
+        }
+      }
+      break;
+    }
+  }
+
+#pragma unroll
+  for (int k = 0; k < NS; ++k) P.x[(size_t)k * N + i] = xs[k];
+  P.steps[i] = steps;
+  P.need_reset[i] = (uint8_t)nr;
+  linds_store_row<NO>(io.obs + (size_t)i * NO, y);
+  linds_store_row<NO>(io.cmd + (size_t)i * NO, crep);
+  io.reward[i] = o_r;
+  io.error[i] = o_err;
+  io.terminated[i] = o_term ? 1 : 0;
+  io.truncated[i] = o_trunc ? 1 : 0;
+  if (io.final_obs) {
+    if (!wrote_fobs) {
+#pragma unroll
+      for (int j = 0; j < NO; ++j) fobs[j] = 0.0f;
+    }
+    linds_store_row<NO>(io.final_obs + (size_t)i * NO, fobs);
+  }
+  if (err) atomicOr(P.err, err);
+}
+
+template <int NS, int NO, bool INJECT>
+__global__ __launch_bounds__(256) void linds_reset_kernel(LinDSArgs P, const uint8_t* mask,
+                                                          const int32_t* init_index, float* obs, float* cmd,
+                                                          float* error) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n_env) return;
+  if (mask && !mask[i]) return;
+  const int N = P.n_env;
+  const int t = P.env_task[i];
+  float xs[NS], y[NO], c[NO];
+  float e = 0.0f;
+  for (;;) {
+    const int tu_cmp = __builtin_amdgcn_readfirstlane(t);
+    int tu = tu_cmp;
+    asm volatile("" : "+s"(tu));   // keep the task index scalar (see linds_step_kernel)
+    if (t == tu_cmp) {
+      const XV_CONST_AS int32_t* in = xv_cptr(P.T.ints) + (size_t)tu * 4;
+      const int n_init = in[2], nf = in[3];
+      const int idx = INJECT ? init_index[i] : linds_draw_init(P, P.gid_base + (uint64_t)i, n_init);
+      linds_reset_env<NS, NO>(P, tu, nf, n_init, idx, xs, y, c, e);
+      break;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) P.x[(size_t)k * N + i] = xs[k];
+  P.steps[i] = 0;
+  P.need_reset[i] = 0;
+  if (obs) linds_store_row<NO>(obs + (size_t)i * NO, y);
+  if (cmd) linds_store_row<NO>(cmd + (size_t)i * NO, c);
+  if (error) error[i] = e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int NA, int NO, int NI,
+                               const xv_linds_tables* tables, const int32_t* env_task, xv_linds** out) {
+  XV_CHECK_ARG(out != nullptr);
+  *out = nullptr;
+  XV_CHECK_ARG(e != nullptr && tables != nullptr && env_task != nullptr);
+  XV_CHECK_ARG(n_env > 0 && n_task > 0 && NI > 0);
+  XV_CHECK_ARG((NS == 16 || NS == 32) && (NA == 8 || NA == 16) && (NO == 16 || NO == 32));
+  XV_CHECK_ARG(tables->phiT && tables->gamT && tables->cT && tables->xt && tables->y0 && tables->valid &&
+               tables->cmd0 && tables->four_coef && tables->four_omega && tables->four_period &&
+               tables->scal && tables->ints && tables->init);
+  XV_HIP(hipSetDevice(e->device));
+  xv_linds* h = new (std::nothrow) xv_linds();
+  if (!h) {
+    xv_set_error("xv_linds_create: out of host memory");
+    return XV_ERR_NOMEM;
+  }
+  h->eng = e;
+  LinDSArgs& a = h->a;
+  a.T = *tables;
+  a.env_task = env_task;
+  a.n_env = n_env; a.n_task = n_task; a.NS = NS; a.NA = NA; a.NO = NO; a.NI = NI;
+  a.err = e->d_err;
+  a.seed = e->seed; a.gid_base = e->env_id_base; a.tick = 0;
+  a.x = nullptr; a.steps = nullptr; a.need_reset = nullptr;
+  hipError_t m = hipMalloc(&a.x, sizeof(float) * (size_t)NS * n_env);
+  if (m == hipSuccess) m = hipMalloc(&a.steps, sizeof(int32_t) * (size_t)n_env);
+  if (m == hipSuccess) m = hipMalloc(&a.need_reset, (size_t)n_env);
+  if (m == hipSuccess) m = hipMemsetAsync(a.x, 0, sizeof(float) * (size_t)NS * n_env, e->stream);
+  if (m == hipSuccess) m = hipMemsetAsync(a.steps, 0, sizeof(int32_t) * (size_t)n_env, e->stream);
+  if (m == hipSuccess) m = hipMemsetAsync(a.need_reset, 1, (size_t)n_env, e->stream);
+  if (m != hipSuccess) {
+    xv_set_error("xv_linds_create: device allocation failed: %s", hipGetErrorString(m));
+    if (a.x) (void)hipFree(a.x);
+    if (a.steps) (void)hipFree(a.steps);
+    if (a.need_reset) (void)hipFree(a.need_reset);
+    delete h;
+    return XV_ERR_HIP;
+  }
+  *out = h;
+  return XV_OK;
+}
+
+extern "C" int xv_linds_destroy(xv_linds* h) {
+  if (!h) return XV_OK;
+  (void)hipSetDevice(h->eng->device);
+  (void)hipStreamSynchronize(h->eng->stream);
+  (void)hipFree(h->a.x);
+  (void)hipFree(h->a.steps);
+  (void)hipFree(h->a.need_reset);
+  delete h;
+  return XV_OK;
+}
+
+static inline void linds_bind_rng(xv_linds* h, uint64_t ticks) {
+  h->a.seed = h->eng->seed;
+  h->a.gid_base = h->eng->env_id_base;
+  h->a.tick = h->eng->tick;
+  h->eng->tick += ticks;
+}
+
+#define LINDS_DISPATCH(FN, ...)                                                                      \
+  do {                                                                                               \
+    const int key = (h->a.NS == 32 ? 4 : 0) | (h->a.NA == 16 ? 2 : 0) | (h->a.NO == 32 ? 1 : 0);    \
+    switch (key) {                                                                                   \
+      case 0: FN(16, 8, 16, __VA_ARGS__); break;                                                     \
+      case 1: FN(16, 8, 32, __VA_ARGS__); break;                                                     \
+      case 2: FN(16, 16, 16, __VA_ARGS__); break;                                                    \
+      case 3: FN(16, 16, 32, __VA_ARGS__); break;                                                    \
+      case 4: FN(32, 8, 16, __VA_ARGS__); break;                                                     \
+      case 5: FN(32, 8, 32, __VA_ARGS__); break;                                                     \
+      case 6: FN(32, 16, 16, __VA_ARGS__); break;                                                    \
+      default: FN(32, 16, 32, __VA_ARGS__); break;                                                   \
+    }                                                                                                \
+  } while (0)
+
+template <bool INJECT>
+static int linds_launch_step(xv_linds* h, const LinDSStepIO& io, int mode) {
+  const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
+#define LINDS_STEP(NS_, NA_, NO_, dummy) \
+  hipLaunchKernelGGL((linds_step_kernel<NS_, NA_, NO_, INJECT>), grid, block, 0, h->eng->stream, h->a, io, mode)
+  LINDS_DISPATCH(LINDS_STEP, 0);
+#undef LINDS_STEP
+  XV_LAUNCH_CHECK();
+  return XV_OK;
+}
+
+template <bool INJECT>
+static int linds_launch_reset(xv_linds* h, const uint8_t* mask, const int32_t* init_index, float* obs,
+                              float* cmd, float* error) {
+  const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
+#define LINDS_RESET(NS_, NA_, NO_, dummy)                                                              \
+  hipLaunchKernelGGL((linds_reset_kernel<NS_, NO_, INJECT>), grid, block, 0, h->eng->stream, h->a, mask, \
+                     init_index, obs, cmd, error)
+  LINDS_DISPATCH(LINDS_RESET, 0);
+#undef LINDS_RESET
+  XV_LAUNCH_CHECK();
+  return XV_OK;
+}
+
+extern "C" int xv_linds_reset(xv_linds* h, const uint8_t* mask, float* obs, float* cmd, float* error) {
+  XV_CHECK_ARG(h != nullptr);
+  linds_bind_rng(h, 1);
+  return linds_launch_reset<false>(h, mask, nullptr, obs, cmd, error);
+}
+
+extern "C" int xv_linds_reset_injected(xv_linds* h, const uint8_t* mask, const int32_t* init_index,
+                                       float* obs, float* cmd, float* error) {
+  XV_CHECK_ARG(h != nullptr && init_index != nullptr);
+  linds_bind_rng(h, 0);
+  return linds_launch_reset<true>(h, mask, init_index, obs, cmd, error);
+}
+
+extern "C" int xv_linds_step(xv_linds* h, const float* action, float* obs, float* reward, uint8_t* terminated,
+                             uint8_t* truncated, float* cmd, float* error, float* final_obs,
+                             int autoreset_mode) {
+  XV_CHECK_ARG(h && action && obs && reward && terminated && truncated && cmd && error);
+  XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
+  linds_bind_rng(h, 1);
+  LinDSStepIO io{action, nullptr, nullptr, obs, reward, terminated, truncated, cmd, error, final_obs};
+  return linds_launch_step<false>(h, io, autoreset_mode);
+}
+
+extern "C" int xv_linds_step_injected(xv_linds* h, const float* action, const float* z,
+                                      const int32_t* init_index, float* obs, float* reward,
+                                      uint8_t* terminated, uint8_t* truncated, float* cmd, float* error,
+                                      float* final_obs, int autoreset_mode) {
+  XV_CHECK_ARG(h && action && z && init_index && obs && reward && terminated && truncated && cmd && error);
+  XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
+  linds_bind_rng(h, 0);
+  LinDSStepIO io{action, z, init_index, obs, reward, terminated, truncated, cmd, error, final_obs};
+  return linds_launch_step<true>(h, io, autoreset_mode);
+}
+
+extern "C" int xv_linds_get_state(xv_linds* h, float* x, int32_t* steps, uint8_t* need_reset) {
+  XV_CHECK_ARG(h != nullptr);
+  const size_t n = (size_t)h->a.n_env;
+  if (x) XV_HIP(hipMemcpyAsync(x, h->a.x, n * h->a.NS * 4, hipMemcpyDeviceToDevice, h->eng->stream));
+  if (steps) XV_HIP(hipMemcpyAsync(steps, h->a.steps, n * 4, hipMemcpyDeviceToDevice, h->eng->stream));
+  if (need_reset) XV_HIP(hipMemcpyAsync(need_reset, h->a.need_reset, n, hipMemcpyDeviceToDevice, h->eng->stream));
+  return XV_OK;
+}
+
+extern "C" int xv_linds_set_state(xv_linds* h, const float* x, const int32_t* steps, const uint8_t* need_reset) {
+  XV_CHECK_ARG(h != nullptr);
+  const size_t n = (size_t)h->a.n_env;
+  if (x) XV_HIP(hipMemcpyAsync(h->a.x, x, n * h->a.NS * 4, hipMemcpyDeviceToDevice, h->eng->stream));
+  if (steps) XV_HIP(hipMemcpyAsync(h->a.steps, steps, n * 4, hipMemcpyDeviceToDevice, h->eng->stream));
+  if (need_reset) XV_HIP(hipMemcpyAsync(h->a.need_reset, need_reset, n, hipMemcpyDeviceToDevice, h->eng->stream));
+  return XV_OK;
+}

@@ -1,0 +1,249 @@
+"""LinDSVecEnv — N randomised LTI control environments stepped per kernel launch on one MI355X.
+
+Mirrors the reference's per-env interface (xenoverse/linds/linds_env.py: LinearDSEnv.__init__ :16-38,
+set_task :40-65, reset :108-131, step :133-169, get_future_inner_cmds :171-183, state :185-187) behind the
+gymnasium VectorEnv surface.  Same task dicts, same info keys (`steps`, `command`,
+`command_type` on reset, `error`), same exception messages for misuse.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..engine import AUTORESET
+from ..spaces import Box
+from ..vector import VectorEnv
+from .tables import build_tables
+
+_F32 = ("phiT", "gamT", "cT", "xt", "y0", "valid", "cmd0", "four_coef", "scal", "init")
+_F64 = ("four_omega", "four_period")
+
+
+class _Tables(C.Structure):   # xv_linds_tables (include/xeno.h)
+    _fields_ = [(k, C.c_void_p) for k in ("phiT", "gamT", "cT", "xt", "y0", "valid", "cmd0", "four_coef",
+                                          "four_omega", "four_period", "scal", "ints", "init")]
+
+
+def _pad_to(n, choices):
+    for c in choices:
+        if n <= c:
+            return c
+    raise ValueError("dimension %d exceeds the supported maximum %d" % (n, choices[-1]))
+
+
+def pad_tables(tab):
+    """Zero-pad the batch dims to the kernel's compiled sizes (NS in {16,32}, NA in {8,16}, NO in {16,32}).
+    Zero padding is exact: fmaf(0, x, acc) == acc."""
+    NS, NA, NO = _pad_to(tab["NS"], (16, 32)), _pad_to(tab["NA"], (8, 16)), _pad_to(tab["NO"], (16, 32))
+    if (NS, NA, NO) == (tab["NS"], tab["NA"], tab["NO"]):
+        return tab
+    n = tab["phiT"].shape[0]
+    out = dict(tab, NS=NS, NA=NA, NO=NO)
+
+    def z(shape, dt=np.float32):
+        return np.zeros(shape, dt)
+    s, a, o = tab["NS"], tab["NA"], tab["NO"]
+    out["phiT"] = z((n, NS, NS)); out["phiT"][:, :s, :s] = tab["phiT"]
+    out["gamT"] = z((n, NA, NS)); out["gamT"][:, :a, :s] = tab["gamT"]
+    out["cT"] = z((n, NS, NO)); out["cT"][:, :s, :o] = tab["cT"]
+    out["xt"] = z((n, NS)); out["xt"][:, :s] = tab["xt"]
+    out["y0"] = z((n, NO)); out["y0"][:, :o] = tab["y0"]
+    out["valid"] = z((n, NO)); out["valid"][:, :o] = tab["valid"]
+    out["cmd0"] = z((n, NO)); out["cmd0"][:, :o] = tab["cmd0"]
+    out["four_coef"] = z(tab["four_coef"].shape[:2] + (NO, 2)); out["four_coef"][:, :, :o] = tab["four_coef"]
+    out["init"] = z((n, tab["NI"], NS)); out["init"][:, :, :s] = tab["init"]
+    return out
+
+
+class LinDSVecEnv(VectorEnv):
+    def __init__(self, num_envs, dt=0.1, max_steps=1000, pad_observation_dim=16, pad_command_dim=16,
+                 pad_action_dim=8, device="cuda:0", seed=0, env_id_base=0, autoreset_mode="same_step",
+                 to_numpy=False, engine=None):
+        super().__init__(num_envs, device=device, seed=seed, env_id_base=env_id_base,
+                         autoreset_mode=autoreset_mode, to_numpy=to_numpy, engine=engine)
+        self.dt = dt
+        self.max_steps = max_steps
+        self.pad_observation_dim = pad_observation_dim
+        self.pad_command_dim = pad_command_dim
+        self.pad_action_dim = pad_action_dim
+        self._set_spaces(Box(-np.inf, np.inf, shape=(pad_observation_dim,), dtype=np.float32),
+                         Box(-1, 1, shape=(pad_action_dim,), dtype=np.float32))
+        self._h = None
+
+    def set_task(self, tasks, env_task_index=None):
+        """tasks: one reference task dict, a list of them, or prebuilt tables (linds.tables.build_tables)."""
+        if isinstance(tasks, dict) and "phiT" in tasks:
+            tab = tasks
+        else:
+            tab = build_tables(tasks, dt=self.dt, pad_observation_dim=self.pad_observation_dim,
+                               pad_action_dim=self.pad_action_dim, pad_command_dim=self.pad_command_dim)
+        self.user_dims = (int(tab["NA"]), int(tab["NO"]))
+        tab = pad_tables(tab)
+        d = self.device
+        dev = {}
+        for k in _F32:
+            dev[k] = torch.as_tensor(np.ascontiguousarray(tab[k], np.float32)).to(d) if not torch.is_tensor(tab[k]) \
+                else tab[k].to(d, torch.float32).contiguous()
+        for k in _F64:
+            dev[k] = torch.as_tensor(np.ascontiguousarray(tab[k], np.float64)).to(d) if not torch.is_tensor(tab[k]) \
+                else tab[k].to(d, torch.float64).contiguous()
+        dev["ints"] = torch.as_tensor(np.ascontiguousarray(tab["ints"], np.int32)).to(d) \
+            if not torch.is_tensor(tab["ints"]) else tab["ints"].to(d, torch.int32).contiguous()
+        n_task = int(dev["phiT"].shape[0])
+        if env_task_index is None:
+            if self.num_envs % n_task != 0:
+                raise ValueError("num_envs is not a multiple of the task count; pass env_task_index")
+            env_task = torch.arange(self.num_envs, device=d, dtype=torch.int32) // (self.num_envs // n_task)
+        else:
+            env_task = self._dev(env_task_index, torch.int32)
+            if env_task.shape != (self.num_envs,) or int(env_task.min()) < 0 or int(env_task.max()) >= n_task:
+                raise ValueError("env_task_index must be (num_envs,) with entries in [0, n_task)")
+        dev["env_task"] = env_task.contiguous()
+        self.NS, self.NA, self.NO, self.NI = int(tab["NS"]), int(tab["NA"]), int(tab["NO"]), int(tab["NI"])
+        if self._h is not None:
+            self.lib.xv_linds_destroy(self._h)
+            self._h = None
+        ct = _Tables(*[_lib.ptr(dev[k]) for k in ("phiT", "gamT", "cT", "xt", "y0", "valid", "cmd0", "four_coef",
+                                                   "four_omega", "four_period", "scal", "ints", "init")])
+        h = C.c_void_p()
+        _lib.check(self.lib.xv_linds_create(self.engine.handle, self.num_envs, n_task, self.NS, self.NA, self.NO,
+                                            self.NI, C.byref(ct), _lib.ptr(dev["env_task"]), C.byref(h)))
+        self._h = h
+        self._tab = dev
+        self.n_task = n_task
+        n = self.num_envs
+        self._obs = torch.zeros((n, self.NO), dtype=torch.float32, device=d)
+        self._cmd = torch.zeros((n, self.NO), dtype=torch.float32, device=d)
+        self._fobs = torch.zeros((n, self.NO), dtype=torch.float32, device=d)
+        self._reward = torch.zeros(n, dtype=torch.float32, device=d)
+        self._error = torch.zeros(n, dtype=torch.float32, device=d)
+        self._term = torch.zeros(n, dtype=torch.uint8, device=d)
+        self._trunc = torch.zeros(n, dtype=torch.uint8, device=d)
+        self._steps = torch.zeros(n, dtype=torch.int32, device=d)
+        self._command_type = np.where(tab["ints"][:, 3] > 0, "dynamic_target", "static_target") \
+            if not torch.is_tensor(tab["ints"]) else None
+        self.task_set = True
+        self.need_reset = True
+
+    # -- helpers ------------------------------------------------------------------------------------
+    def _user_obs(self, t):
+        return t[:, :self.user_dims[1]]
+
+    def _action(self, actions):
+        a = self._dev(actions, torch.float32)
+        na_user = self.user_dims[0]
+        if a.shape != (self.num_envs, na_user):
+            # reference: assert numpy.shape(action) == (self.pad_action_dim,) (linds_env.py:137)
+            raise AssertionError(f"Action shape mismatch: expected {(self.num_envs, na_user)}, got {tuple(a.shape)}")
+        if na_user != self.NA:
+            p = torch.zeros((self.num_envs, self.NA), dtype=torch.float32, device=self.device)
+            p[:, :na_user] = a
+            a = p
+        return a.contiguous()
+
+    def _steps_now(self):
+        _lib.check(self.lib.xv_linds_get_state(self._h, None, _lib.ptr(self._steps), None))
+        return self._steps.clone()
+
+    def _infos(self, with_final):
+        infos = {"steps": self._out(self._steps_now()), "command": self._out(self._user_obs(self._cmd).clone()),
+                 "error": self._out(self._error.clone())}
+        if with_final and self.autoreset_mode == "same_step":
+            infos["final_obs"] = self._out(self._user_obs(self._fobs).clone())
+            infos["_final_obs"] = self._out((self._term | self._trunc).bool())
+        return infos
+
+    # -- API ----------------------------------------------------------------------------------------
+    def reset(self, *, seed=None, options=None):
+        self._require_task()
+        if seed is not None:
+            self.engine.tick = (int(seed) & 0xFFFFFFFF) << 24
+        mask = None
+        if options is not None and options.get("reset_mask") is not None:
+            mask = self._dev(options["reset_mask"], torch.uint8)
+        _lib.check(self.lib.xv_linds_reset(self._h, _lib.ptr(mask), _lib.ptr(self._obs), _lib.ptr(self._cmd),
+                                           _lib.ptr(self._error)))
+        self.need_reset = False
+        infos = self._infos(False)
+        if self._command_type is not None:
+            infos["command_type"] = self._command_type[self._tab["env_task"].cpu().numpy()]
+        return self._out(self._user_obs(self._obs).clone()), infos
+
+    def reset_injected(self, init_index, mask=None):
+        self._require_task()
+        idx = self._dev(init_index, torch.int32)
+        m = None if mask is None else self._dev(mask, torch.uint8)
+        _lib.check(self.lib.xv_linds_reset_injected(self._h, _lib.ptr(m), _lib.ptr(idx), _lib.ptr(self._obs),
+                                                    _lib.ptr(self._cmd), _lib.ptr(self._error)))
+        self.need_reset = False
+        return self._out(self._user_obs(self._obs).clone()), self._infos(False)
+
+    def _check_step(self):
+        if (not self.task_set) or self.need_reset:
+            raise Exception("Must \"set_task\" and \"reset\" before doing any actions")   # linds_env.py:134-135
+
+    def _ret(self):
+        return (self._out(self._user_obs(self._obs).clone()), self._out(self._reward.clone()),
+                self._out(self._term.bool()), self._out(self._trunc.bool()), self._infos(True))
+
+    def step(self, actions):
+        self._check_step()
+        a = self._action(actions)
+        _lib.check(self.lib.xv_linds_step(self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward),
+                                          _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._cmd),
+                                          _lib.ptr(self._error), _lib.ptr(self._fobs),
+                                          AUTORESET[self.autoreset_mode]))
+        return self._ret()
+
+    def step_injected(self, actions, z, init_index):
+        """Parity hook: z float[NS, N] standard normals (process noise), init_index int[N] (used on reset)."""
+        self._check_step()
+        a = self._action(actions)
+        z = self._dev(z, torch.float32)
+        if z.shape[0] != self.NS:
+            p = torch.zeros((self.NS, self.num_envs), dtype=torch.float32, device=self.device)
+            p[:z.shape[0]] = z
+            z = p
+        idx = self._dev(init_index, torch.int32)
+        _lib.check(self.lib.xv_linds_step_injected(
+            self._h, _lib.ptr(a), _lib.ptr(z.contiguous()), _lib.ptr(idx), _lib.ptr(self._obs),
+            _lib.ptr(self._reward), _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._cmd),
+            _lib.ptr(self._error), _lib.ptr(self._fobs), AUTORESET[self.autoreset_mode]))
+        return self._ret()
+
+    @property
+    def state(self):
+        """env.state (linds_env.py:185-187): float[N, NS]"""
+        x = torch.empty((self.NS, self.num_envs), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.xv_linds_get_state(self._h, _lib.ptr(x), None, None))
+        return self._out(x.t().contiguous())
+
+    def get_state(self):
+        x = torch.empty((self.NS, self.num_envs), dtype=torch.float32, device=self.device)
+        st = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
+        nr = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.xv_linds_get_state(self._h, _lib.ptr(x), _lib.ptr(st), _lib.ptr(nr)))
+        return x, st, nr
+
+    def set_state(self, x=None, steps=None, need_reset=None):
+        """x float[NS_user or NS, N] component-major"""
+        xs = None
+        if x is not None:
+            xs = self._dev(x, torch.float32)
+            if xs.shape[0] != self.NS:
+                p = torch.zeros((self.NS, self.num_envs), dtype=torch.float32, device=self.device)
+                p[:xs.shape[0]] = xs
+                xs = p
+            xs = xs.contiguous()
+        st = None if steps is None else self._dev(steps, torch.int32)
+        nr = None if need_reset is None else self._dev(need_reset, torch.uint8)
+        _lib.check(self.lib.xv_linds_set_state(self._h, _lib.ptr(xs), _lib.ptr(st), _lib.ptr(nr)))
+        self.engine.sync()
+        self.need_reset = False
+
+    def close_extras(self, **kwargs):
+        if self._h is not None:
+            self.lib.xv_linds_destroy(self._h)
+            self._h = None
+        self._tab = None
