@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
 
   float y[NO], crep[NO], fobs[NO];
   float o_r = 0.0f, o_err = 0.0f;
-  bool o_term = false, o_trunc = false, wrote_fobs = false;
+  // flags are per-lane integers (VGPRs): as bools they are SGPR lane masks that must survive later waterfall passes
+  int o_term = 0, o_trunc = 0, wrote_fobs = 0;
   uint32_t err = 0;
 
   // waterfall over the distinct tasks of this wave: inside, `tu` is wave-uniform (SGPR) and so is every
@@ -255,19 +256,19 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
 #pragma unroll
         for (int j = 0; j < NO; ++j) sc2 = fmaf(y[j], y[j], sc2);
         const float obs_scale = sqrtf(sc2);                    // :154
-        o_term = (o_err > 10.0f) || (obs_scale > 20.0f);       // :156
+        o_term = ((o_err > 10.0f) || (obs_scale > 20.0f)) ? 1 : 0;   // :156
         o_r = o_term ? -sc[2] : 0.0f;                          // :158-161
         float tmp = fmaf(-sc[3], o_err, sc[1]);
         tmp = fmaf(-sc[0], sa, tmp);
         o_r = fmaf(tmp, sc[5], o_r);                           // :163-164
-        o_trunc = steps >= max_steps - 1;                      // :165
+        o_trunc = (steps >= max_steps - 1) ? 1 : 0;            // :165
 #pragma unroll
         for (int k = 0; k < NS; ++k) xs[k] = xn[k];
         if (o_term || o_trunc) {
           if (mode == XV_AUTORESET_SAME_STEP) {
 #pragma unroll
             for (int j = 0; j < NO; ++j) fobs[j] = y[j];
-            wrote_fobs = true;
+            wrote_fobs = 1;
             linds_reset_env<NS, NO>(P, tu, nf, n_init, init_idx, xs, y, crep, o_err);
             steps = 0;
           } else if (mode == XV_AUTORESET_NEXT_STEP) {
@@ -287,8 +288,8 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
   linds_store_row<NO>(io.cmd + (size_t)i * NO, crep);
   io.reward[i] = o_r;
   io.error[i] = o_err;
-  io.terminated[i] = o_term ? 1 : 0;
-  io.truncated[i] = o_trunc ? 1 : 0;
+  io.terminated[i] = (uint8_t)o_term;
+  io.truncated[i] = (uint8_t)o_trunc;
   if (io.final_obs) {
     if (!wrote_fobs) {
 #pragma unroll
