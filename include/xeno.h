@@ -215,6 +215,16 @@ typedef struct xv_linds_tables {
 int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int NA, int NO, int NI,
                     const xv_linds_tables* tables, const int32_t* env_task, xv_linds** out);
 int xv_linds_destroy(xv_linds* h);
+/* kernel selection (results are identical, bit for bit on the state/observation path):
+ *   MFMA    one wave per 32-env tile, x' = Phi x + Gamma a and y = C x' on v_mfma_f32_32x32x2_f32; needs every
+ *           aligned group of 32 envs to share one task (e.g. 64 envs per task)
+ *   SCALAR  one lane per env, task matrices as scalar-cache broadcast operands, waterfall over the tasks of a
+ *           wave: any env -> task mapping
+ *   AUTO    MFMA when the layout allows it */
+#define XV_LINDS_PATH_AUTO 0
+#define XV_LINDS_PATH_MFMA 1
+#define XV_LINDS_PATH_SCALAR 2
+int xv_linds_set_path(xv_linds* h, int path);
 /* reset: x = initial_states[k], k uniform (linds_env.py:117 uses random.choice); obs = C x + Y; command =
  * cmd(0); error = ||(obs - cmd) * valid||.  obs/cmd float[n_env][NO], error float[n_env]; all nullable. */
 int xv_linds_reset(xv_linds* h, const uint8_t* mask, float* obs, float* cmd, float* error);

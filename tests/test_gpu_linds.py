@@ -19,13 +19,15 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+@pytest.mark.parametrize("kernel", ["mfma", "scalar"])
 @pytest.mark.parametrize("path", FILES)
-def test_golden_every_step_from_reference_state(path):
+def test_golden_every_step_from_reference_state(path, kernel):
     g, task = load_linds_golden(path)
     T, ns = g["tr_x"].shape
     xb, sb = _before_states(g)
     env = LinDSVecEnv(T, autoreset_mode="disabled")
     env.set_task(task)
+    env.set_path(kernel)
     env.set_state(x=xb.T.astype(np.float32), steps=sb, need_reset=np.zeros(T))
     obs, r, term, trunc, info = env.step_injected(g["tr_action"], g["tr_z"].T, np.zeros(T))
     x, st, _ = env.get_state()
@@ -79,15 +81,22 @@ def _cmp(dev, ora, exact_state=True):
 
 
 @pytest.mark.parametrize("mode", ["disabled", "next_step", "same_step"])
-@pytest.mark.parametrize("layout", ["grouped64", "grouped32", "mixed"])
-def test_batch_injected_vs_oracle(mode, layout):
-    tasks, tab, env_task = _batch(64 if layout != "grouped32" else 32, FILES[:4])
+@pytest.mark.parametrize("layout,path", [("grouped64", "mfma"), ("grouped64", "scalar"), ("grouped32", "mfma"),
+                                         ("grouped32", "scalar"), ("ragged", "mfma"), ("mixed", "auto")])
+def test_batch_injected_vs_oracle(mode, layout, path):
+    tasks, tab, env_task = _batch(64 if layout not in ("grouped32", "ragged") else 32, FILES[:4])
     rng = np.random.RandomState(3)
     if layout == "mixed":
         rng.shuffle(env_task)              # lanes of one wave hold different tasks: the waterfall path
+    if layout == "ragged":
+        env_task = env_task[:-13]          # last tile is partial
     n = len(env_task)
     env = LinDSVecEnv(n, autoreset_mode=mode)
     env.set_task(tasks, env_task_index=env_task)
+    env.set_path(path)
+    if layout == "mixed":
+        with pytest.raises(Exception):
+            env.set_path("mfma")           # tiles are not task-uniform
     ora = oracle.LinDSOracle(tab, env_task)
     n_init = tab["ints"][env_task, 2]
     idx0 = (rng.random_sample(n) * n_init).astype(np.int32)
@@ -142,13 +151,15 @@ def test_free_running_philox_vs_oracle():
     env.close()
 
 
-def test_state_dim_32_task():
+@pytest.mark.parametrize("path", ["mfma", "scalar"])
+def test_state_dim_32_task(path):
     g, task = load_linds_golden([f for f in FILES if "32x8x8" in f][0])
     tab = pad_tables(build_tables([task]))
     assert tab["NS"] == 32
     n = 128
     env = LinDSVecEnv(n, autoreset_mode="same_step")
     env.set_task(task)
+    env.set_path(path)
     ora = oracle.LinDSOracle(tab, np.zeros(n, np.int32))
     rng = np.random.RandomState(0)
     idx = rng.randint(0, 3, n).astype(np.int32)

@@ -39,6 +39,7 @@ SIGNATURES = {
     "xv_anymdp_synth_tasks": [c_void_p, c_u64, c_i64, c_int, c_int, c_int, c_int] + [c_void_p] * 6,
     "xv_linds_create": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, C.POINTER(c_void_p)],
     "xv_linds_destroy": [c_void_p],
+    "xv_linds_set_path": [c_void_p, c_int],
     "xv_linds_reset": [c_void_p] + [c_void_p] * 4,
     "xv_linds_reset_injected": [c_void_p] + [c_void_p] * 5,
     "xv_linds_step": [c_void_p] + [c_void_p] * 8 + [c_int],

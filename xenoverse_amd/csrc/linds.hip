@@ -43,6 +43,8 @@ struct LinDSStepIO {
 struct xv_linds {
   xv_engine* eng;
   LinDSArgs a;
+  bool tiles_uniform;   // every aligned 32-env group shares a task -> MFMA path
+  int path;             // XV_LINDS_PATH_*
 };
 
 // Task tables are read-only for the lifetime of a launch: reading them through the constant address space lets
@@ -333,6 +335,229 @@ __global__ __launch_bounds__(256) void linds_reset_kernel(LinDSArgs P, const uin
 }
 
 // ------------------------------------------------------------------------------------------------
+// MFMA path: one wave = one tile of 32 envs that share a task (checked at create time).
+//
+//   x'^T = Phi X^T + Gamma A^T   as  D[j][env] = sum_k A[j][k] B[k][env]   with v_mfma_f32_32x32x2_f32:
+//     A operand (lane l = 32h + c): Phi[j = c][k = 2kk + h] = phiT[k][c]   -- a coalesced 128-B segment per half
+//     B operand:                    x_env(c)[k = 2kk + h]  = X[k][tile + c] -- the component-major state, coalesced
+//     D (16 regs): register r of lane (c, h) = x'_env(c)[ j = (r&3) + 8(r>>2) + 4h ]
+//   so every env's new state sits in the two lanes (c,0), (c,1), 16 components each, and — the point of this
+//   orientation — register r of a lane IS the B operand of k-slab r of the next product
+//   y^T = C x'^T  (A operand C[jo = c][k = j(r,h)] = cT[k][c]).  No LDS, no shuffles between the two products.
+//   The MFMA accumulates D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) in k order, bit for bit the fmaf chains of
+//   the scalar kernel and of the oracle (k = 0..NS-1, then Gamma; y in linds_yorder).
+//   Per-env scalar work (commands, error, reward, flags) is done redundantly by both lanes of an env after one
+//   __shfl_xor(.., 32) per observation component.
+// ------------------------------------------------------------------------------------------------
+typedef float xv_f32x16 __attribute__((ext_vector_type(16)));
+
+// cond ? hi : lo on two register values, opaque to hipcc (which otherwise folds a select of two array elements
+// into one dynamically indexed stack access, i.e. scratch memory)
+__device__ __forceinline__ float xv_sel_opaque(int cond, float lo, float hi) {
+  asm volatile("" : "+v"(lo), "+v"(hi));
+  return cond ? hi : lo;
+}
+
+__device__ __forceinline__ int linds_row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// y (all NO components, canonical order) of the tile's envs for state registers xr (this lane's 16 components)
+template <int NS, int NO>
+__device__ __forceinline__ void linds_observe_mfma(const LinDSArgs& P, int t, int c, int h,
+                                                   const xv_f32x16& xr, float (&yfull)[NO]) {
+  const float* cT = P.T.cT + (size_t)t * NS * NO;
+  xv_f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < NS / 2; ++r) {
+    const int k = linds_row_of(r, h);
+    const float a = (c < NO) ? cT[k * NO + c] : 0.0f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xr[r], acc, 0, 0, 0);
+  }
+  const XV_CONST_AS float* y0 = xv_cptr(P.T.y0) + (size_t)t * NO;
+  // this lane holds jo = linds_row_of(r', h) for r' < NO/2; the other half of the env holds the rest
+#pragma unroll
+  for (int jo = 0; jo < NO; ++jo) {
+    const int rr = (jo & 3) + 4 * (jo >> 3), hh = (jo >> 2) & 1;
+    const float mine = acc[rr];
+    const float other = __shfl_xor(mine, 32);
+    yfull[jo] = ((hh == h) ? mine : other) + y0[jo];   // :85
+  }
+}
+
+template <int NS, int NA, int NO, bool INJECT>
+__global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDSStepIO io, int mode) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int tile0 = wave * 32;
+  if (tile0 >= P.n_env) return;   // wave-uniform
+  const int N = P.n_env;
+  const int c = lane & 31, h = lane >> 5;
+  const bool valid = tile0 + c < N;
+  const int e = valid ? tile0 + c : N - 1;
+  const int t = __builtin_amdgcn_readfirstlane(P.env_task[tile0]);
+  const uint64_t gid = P.gid_base + (uint64_t)e;
+  constexpr int NR = NS / 2;   // registers of the accumulator that hold real state components
+
+  const XV_CONST_AS float* sc = xv_cptr(P.T.scal) + (size_t)t * 8;
+  const XV_CONST_AS int32_t* in = xv_cptr(P.T.ints) + (size_t)t * 4;
+  const int max_steps = in[0], delay = in[1], n_init = in[2], nf = in[3];
+
+  int steps = P.steps[e];
+  int nr = P.need_reset[e];
+  float a_raw[NA];
+  {
+    const float4* a4 = reinterpret_cast<const float4*>(io.action + (size_t)e * NA);
+#pragma unroll
+    for (int q = 0; q < NA / 4; ++q) {
+      const float4 v = a4[q];
+      a_raw[4 * q] = v.x; a_raw[4 * q + 1] = v.y; a_raw[4 * q + 2] = v.z; a_raw[4 * q + 3] = v.w;
+    }
+  }
+  int init_idx;
+  if (INJECT) init_idx = io.init_index[e];
+  else init_idx = linds_draw_init(P, gid, n_init);
+
+  // ---- x' = Phi x + Gamma act  (:78-80) ----
+  const float* phiT = P.T.phiT + (size_t)t * NS * NS;
+  const float* gamT = P.T.gamT + (size_t)t * NA * NS;
+  xv_f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int kk = 0; kk < NS / 2; ++kk) {
+    const int k = 2 * kk + h;
+    const float a = (c < NS) ? phiT[k * NS + c] : 0.0f;
+    const float b = P.x[(size_t)k * N + e];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  float sa = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NA; ++k) sa = fmaf(a_raw[k], a_raw[k], sa);   // :164 cost on the RAW padded action
+#pragma unroll
+  for (int kk = 0; kk < NA / 2; ++kk) {
+    const int k = 2 * kk + h;
+    const float ar = xv_sel_opaque(h, a_raw[2 * kk], a_raw[2 * kk + 1]);
+    const float b = ar < -1.0f ? -1.0f : (ar > 1.0f ? 1.0f : ar);   // :138 clip
+    const float a = (c < NS) ? gamT[k * NS + c] : 0.0f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  // + Xt + noise on this lane's NR components
+  const float noise_scale = sc[4];
+  float zr[NR];
+  if (INJECT) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) zr[r] = io.z[(size_t)linds_row_of(r, h) * N + e];
+  } else {
+#pragma unroll
+    for (int rr = 0; rr < NR / 4; ++rr) {   // components 4q..4q+3 come from Philox call q = 2 rr + h
+      const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_NOISE + (uint32_t)(2 * rr + h));
+      xv_box_muller(w.x, w.y, &zr[4 * rr], &zr[4 * rr + 1]);
+      xv_box_muller(w.z, w.w, &zr[4 * rr + 2], &zr[4 * rr + 3]);
+    }
+  }
+  const float* xtv = P.T.xt + (size_t)t * NS;
+  xv_f32x16 xn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int bad = 0;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    float v = acc[r] + xtv[linds_row_of(r, h)];
+    v = fmaf(noise_scale, zr[r], v);
+    bad |= !(fabsf(v) <= 3.0e38f);
+    xn[r] = v;
+  }
+
+  // ---- y = C x' + Y (:145), commands, error, reward, flags ----
+  float y[NO], ctrack[NO], crep[NO], fobs[NO];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) fobs[j] = 0.0f;
+  linds_observe_mfma<NS, NO>(P, t, c, h, xn, y);
+  const int steps_new = steps + 1;                            // :147
+  linds_cmd<NO>(P, t, nf, steps_new - 1 - delay, ctrack);     // :150-151 tracked command
+  linds_cmd<NO>(P, t, nf, steps_new, crep);                   // :168 reported command
+  float o_err = linds_err<NO>(P, t, y, ctrack);               // :153
+  float sc2 = 0.0f;
+#pragma unroll
+  for (int j = 0; j < NO; ++j) sc2 = fmaf(y[j], y[j], sc2);
+  const float obs_scale = sqrtf(sc2);                         // :154
+  int o_term = ((o_err > 10.0f) || (obs_scale > 20.0f)) ? 1 : 0;   // :156
+  float o_r = o_term ? -sc[2] : 0.0f;                         // :158-161
+  float tmp = fmaf(-sc[3], o_err, sc[1]);
+  tmp = fmaf(-sc[0], sa, tmp);
+  o_r = fmaf(tmp, sc[5], o_r);                                // :163-164
+  int o_trunc = (steps_new >= max_steps - 1) ? 1 : 0;         // :165
+
+  // ---- which envs (re)start this call ----
+  const bool skip = (mode == XV_AUTORESET_NEXT_STEP) && nr;   // the call after a done: reset only
+  const bool done = !skip && (o_term || o_trunc);
+  const bool do_reset = skip || (done && mode == XV_AUTORESET_SAME_STEP);
+  int wrote_fobs = 0;
+  if (skip) {
+    o_r = 0.0f; o_term = 0; o_trunc = 0; bad = 0;
+  } else {
+    steps = steps_new;
+    if (done && mode == XV_AUTORESET_NEXT_STEP) nr = 1;
+  }
+  if (__ballot(do_reset) != 0ull) {   // wave-uniform: one more observation product for the restarted envs
+    const int idx = init_idx < 0 ? 0 : (init_idx >= n_init ? n_init - 1 : init_idx);
+    const float* x0 = P.T.init + ((size_t)t * P.NI + idx) * NS;
+    xv_f32x16 xr = xn;
+    if (do_reset) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) xr[r] = x0[linds_row_of(r, h)];   // :117
+    }
+    float yr[NO], c0[NO];
+    linds_observe_mfma<NS, NO>(P, t, c, h, xr, yr);
+    linds_cmd<NO>(P, t, nf, 0, c0);                // :120-126
+    const float e0 = linds_err<NO>(P, t, yr, c0);
+    if (do_reset) {
+      if (!skip) {
+#pragma unroll
+        for (int j = 0; j < NO; ++j) fobs[j] = y[j];
+        wrote_fobs = 1;
+      }
+      xn = xr;
+#pragma unroll
+      for (int j = 0; j < NO; ++j) { y[j] = yr[j]; crep[j] = c0[j]; }
+      o_err = e0;
+      steps = 0;
+      nr = 0;
+    }
+  }
+  if (skip) bad = 0;
+
+  // ---- stores ----
+  if (valid) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) P.x[(size_t)linds_row_of(r, h) * N + e] = xn[r];
+    // each half stores half of the observation / command row
+    float oh[NO / 2], ch[NO / 2], fh[NO / 2];
+#pragma unroll
+    for (int q = 0; q < NO / 2; ++q) {
+      oh[q] = xv_sel_opaque(h, y[q], y[NO / 2 + q]);
+      ch[q] = xv_sel_opaque(h, crep[q], crep[NO / 2 + q]);
+      fh[q] = wrote_fobs ? xv_sel_opaque(h, fobs[q], fobs[NO / 2 + q]) : 0.0f;
+    }
+    const size_t ro = (size_t)e * NO + (size_t)h * (NO / 2);
+    linds_store_row<NO / 2>(io.obs + ro, oh);
+    linds_store_row<NO / 2>(io.cmd + ro, ch);
+    if (io.final_obs) linds_store_row<NO / 2>(io.final_obs + ro, fh);
+    if (h == 0) {
+      P.steps[e] = steps;
+      P.need_reset[e] = (uint8_t)nr;
+      io.reward[e] = o_r;
+      io.error[e] = o_err;
+      io.terminated[e] = (uint8_t)o_term;
+      io.truncated[e] = (uint8_t)o_trunc;
+    }
+  }
+  if (bad && valid) atomicOr(P.err, (uint32_t)XV_DEVERR_NONFINITE);
+}
+
+// every aligned group of 32 envs shares one task?  (decides MFMA vs scalar-broadcast path)
+__global__ __launch_bounds__(256) void linds_check_tiles_kernel(const int32_t* env_task, int n_env, int* not_uniform) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_env) return;
+  if (env_task[i] != env_task[i & ~31]) atomicOr(not_uniform, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int NA, int NO, int NI,
@@ -373,7 +598,30 @@ extern "C" int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int 
     delete h;
     return XV_ERR_HIP;
   }
+  {
+    int* d_flag = nullptr;
+    int h_flag = 1;
+    XV_HIP(hipMalloc(&d_flag, sizeof(int)));
+    XV_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), e->stream));
+    hipLaunchKernelGGL(linds_check_tiles_kernel, dim3(xv_div_up(n_env, 256)), dim3(256), 0, e->stream, env_task,
+                       n_env, d_flag);
+    XV_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    XV_HIP(hipStreamSynchronize(e->stream));
+    XV_HIP(hipFree(d_flag));
+    h->tiles_uniform = (h_flag == 0);
+    h->path = XV_LINDS_PATH_AUTO;
+  }
   *out = h;
+  return XV_OK;
+}
+
+extern "C" int xv_linds_set_path(xv_linds* h, int path) {
+  XV_CHECK_ARG(h != nullptr && path >= 0 && path <= 2);
+  if (path == XV_LINDS_PATH_MFMA && !h->tiles_uniform) {
+    xv_set_error("xv_linds_set_path: MFMA needs every aligned group of 32 envs to share one task");
+    return XV_ERR_UNSUPPORTED;
+  }
+  h->path = path;
   return XV_OK;
 }
 
@@ -412,11 +660,21 @@ static inline void linds_bind_rng(xv_linds* h, uint64_t ticks) {
 
 template <bool INJECT>
 static int linds_launch_step(xv_linds* h, const LinDSStepIO& io, int mode) {
-  const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
+  const dim3 block(256);
+  const bool mfma = h->tiles_uniform && h->path != XV_LINDS_PATH_SCALAR;
+  if (mfma) {
+    const dim3 grid(xv_div_up(xv_div_up(h->a.n_env, 32), 4));   // one wave per 32-env tile, 4 tiles per block
+#define LINDS_STEP_M(NS_, NA_, NO_, dummy) \
+  hipLaunchKernelGGL((linds_step_mfma_kernel<NS_, NA_, NO_, INJECT>), grid, block, 0, h->eng->stream, h->a, io, mode)
+    LINDS_DISPATCH(LINDS_STEP_M, 0);
+#undef LINDS_STEP_M
+  } else {
+    const dim3 grid(xv_div_up(h->a.n_env, 256));
 #define LINDS_STEP(NS_, NA_, NO_, dummy) \
   hipLaunchKernelGGL((linds_step_kernel<NS_, NA_, NO_, INJECT>), grid, block, 0, h->eng->stream, h->a, io, mode)
-  LINDS_DISPATCH(LINDS_STEP, 0);
+    LINDS_DISPATCH(LINDS_STEP, 0);
 #undef LINDS_STEP
+  }
   XV_LAUNCH_CHECK();
   return XV_OK;
 }

@@ -126,6 +126,12 @@ class LinDSVecEnv(VectorEnv):
         self.task_set = True
         self.need_reset = True
 
+    PATH = {"auto": 0, "mfma": 1, "scalar": 2}
+
+    def set_path(self, path):
+        """Select the step kernel ("auto", "mfma", "scalar"); results are identical (include/xeno.h)."""
+        _lib.check(self.lib.xv_linds_set_path(self._h, self.PATH[path]))
+
     # -- helpers ------------------------------------------------------------------------------------
     def _user_obs(self, t):
         return t[:, :self.user_dims[1]]
