@@ -243,6 +243,30 @@ int xv_linds_step_injected(xv_linds* h, const float* action, const float* z, con
 int xv_linds_get_state(xv_linds* h, float* x, int32_t* steps, uint8_t* need_reset);
 int xv_linds_set_state(xv_linds* h, const float* x, const int32_t* steps, const uint8_t* need_reset);
 
+/* ------------------------------------------------------------------------------------------------
+ * CartPole — reference: xenoverse/metacontrol/random_cartpole.py (set_task :46-50, step :52-61, reset
+ * :63-75).  The physics is gymnasium's CartPoleEnv.step (third-party dependency, `gymnasium>=1.0.0` in the
+ * reference's setup.py:42, not vendored and not installed here): restated from the public gymnasium 1.x
+ * source equations — PARITY UNPINNED.  fp32 state float[4][n_env] (x, x_dot, theta, theta_dot).
+ *   params float[n_task][4] = gravity, masscart, masspole, length (sample_cartpole :13-29)
+ *   reset_scale float[4]    = reset_bounds_scale (registered default [0.45, 0.90, 0.13, 1.0])
+ *   frameskip               = physics sub-steps per step (registered default 1)
+ *   max_steps               <= 0: never truncates, as the reference (no TimeLimit registered)
+ * ---------------------------------------------------------------------------------------------- */
+int xv_cartpole_create(xv_engine* e, int n_env, int n_task, int frameskip, int max_steps, const float* params,
+                       const float* reset_scale, const int32_t* env_task, xv_cartpole** out);
+int xv_cartpole_destroy(xv_cartpole* h);
+int xv_cartpole_reset(xv_cartpole* h, const uint8_t* mask, float* obs /*[n_env][4]*/);
+int xv_cartpole_reset_injected(xv_cartpole* h, const uint8_t* mask, const float* u /*[4][n_env] in [0,1)*/,
+                               float* obs);
+int xv_cartpole_step(xv_cartpole* h, const int32_t* action, float* obs, float* reward, uint8_t* terminated,
+                     uint8_t* truncated, float* final_obs, int autoreset_mode);
+int xv_cartpole_step_injected(xv_cartpole* h, const int32_t* action, const float* u_reset, float* obs,
+                              float* reward, uint8_t* terminated, uint8_t* truncated, float* final_obs,
+                              int autoreset_mode);
+int xv_cartpole_get_state(xv_cartpole* h, float* state /*[4][n_env]*/, int32_t* steps, uint8_t* need_reset);
+int xv_cartpole_set_state(xv_cartpole* h, const float* state, const int32_t* steps, const uint8_t* need_reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -258,3 +258,62 @@ def linds_yorder(NS):
     ord_ = np.zeros(32, np.int32)
     n = lib().xo_linds_yorder(C.c_int(NS), _p(ord_))
     return ord_[:n].copy()
+
+
+# ---------------------------------------------------------------------------------------------------
+# CartPole
+# ---------------------------------------------------------------------------------------------------
+class _CartPoleStruct(C.Structure):
+    _fields_ = [("n_env", C.c_int), ("n_task", C.c_int), ("frameskip", C.c_int), ("max_steps", C.c_int),
+                ("params", C.c_void_p), ("reset_scale", C.c_void_p), ("env_task", C.c_void_p),
+                ("state", C.c_void_p), ("steps", C.c_void_p), ("need_reset", C.c_void_p),
+                ("err_flags", C.c_uint32)]
+
+
+class CartPoleOracle(object):
+    def __init__(self, params, env_task, frameskip=1, max_steps=0, reset_scale=(0.45, 0.90, 0.13, 1.0)):
+        self.params = np.ascontiguousarray(params, np.float32).reshape(-1, 4)
+        self.env_task = np.ascontiguousarray(env_task, np.int32)
+        self.n_env = len(self.env_task)
+        self.scale = np.ascontiguousarray(reset_scale, np.float32)
+        self.state = np.zeros((4, self.n_env), np.float32)
+        self.steps = np.zeros(self.n_env, np.int32)
+        self.need_reset = np.ones(self.n_env, np.uint8)
+        self._h = _CartPoleStruct(self.n_env, len(self.params), frameskip, max_steps, _p(self.params),
+                                  _p(self.scale), _p(self.env_task), _p(self.state), _p(self.steps),
+                                  _p(self.need_reset), 0)
+
+    def _outs(self):
+        n = self.n_env
+        return dict(obs=np.zeros((n, 4), np.float32), reward=np.zeros(n, np.float32),
+                    terminated=np.zeros(n, np.uint8), truncated=np.zeros(n, np.uint8),
+                    final_obs=np.zeros((n, 4), np.float32))
+
+    def reset_injected(self, u, mask=None):
+        obs = np.zeros((self.n_env, 4), np.float32)
+        u = np.ascontiguousarray(u, np.float32).reshape(4, self.n_env)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        lib().xo_cartpole_reset_injected(C.byref(self._h), _p(m), _p(u), _p(obs))
+        return obs
+
+    def reset(self, seed, gid_base, tick, mask=None):
+        obs = np.zeros((self.n_env, 4), np.float32)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        lib().xo_cartpole_reset(C.byref(self._h), C.c_uint64(seed), C.c_uint64(gid_base), C.c_uint64(tick), _p(m), _p(obs))
+        return obs
+
+    def step_injected(self, action, u_reset, mode):
+        o = self._outs()
+        a = np.ascontiguousarray(action, np.int32)
+        u = np.ascontiguousarray(u_reset, np.float32).reshape(4, self.n_env)
+        lib().xo_cartpole_step_injected(C.byref(self._h), _p(a), _p(u), _p(o["obs"]), _p(o["reward"]),
+                                        _p(o["terminated"]), _p(o["truncated"]), _p(o["final_obs"]), C.c_int(mode))
+        return o
+
+    def step(self, seed, gid_base, tick, action, mode):
+        o = self._outs()
+        a = np.ascontiguousarray(action, np.int32)
+        lib().xo_cartpole_step(C.byref(self._h), C.c_uint64(seed), C.c_uint64(gid_base), C.c_uint64(tick), _p(a),
+                               _p(o["obs"]), _p(o["reward"]), _p(o["terminated"]), _p(o["truncated"]),
+                               _p(o["final_obs"]), C.c_int(mode))
+        return o

@@ -529,3 +529,107 @@ void xo_linds_step(xo_linds* h, uint64_t seed, uint64_t gid_base, uint64_t tick,
                    error, final_obs, mode);
   }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * CartPole — metacontrol/random_cartpole.py :46-75 over gymnasium CartPoleEnv.step (Euler integrator,
+ * force_mag 10, tau 0.02, x_threshold 2.4, theta_threshold 12 deg).  PARITY UNPINNED (gymnasium absent).
+ * ---------------------------------------------------------------------------------------------- */
+static void cartpole_reset_one(xo_cartpole* h, int i, const float u[4], float* obs) {
+  /* state = uniform(-1, 1, 4) * reset_bounds_scale  (random_cartpole.py:70) */
+  for (int k = 0; k < 4; ++k) {
+    float v = fmaf(2.0f, u[k], -1.0f) * h->reset_scale[k];
+    h->state[(size_t)k * h->n_env + i] = v;
+    if (obs) obs[(size_t)i * 4 + k] = v;
+  }
+  h->steps[i] = 0;
+  h->need_reset[i] = 0;
+}
+
+static void cartpole_step_one(xo_cartpole* h, int i, int action, const float u_reset[4], float* obs,
+                              float* reward, uint8_t* terminated, uint8_t* truncated, float* final_obs, int mode) {
+  const int N = h->n_env, t = h->env_task[i];
+  if (final_obs) for (int k = 0; k < 4; ++k) final_obs[(size_t)i * 4 + k] = 0.0f;
+  if (mode == 1 && h->need_reset[i]) {
+    cartpole_reset_one(h, i, u_reset, obs);
+    reward[i] = 0.0f; terminated[i] = 0; truncated[i] = 0;
+    return;
+  }
+  if (action != 0 && action != 1) { h->err_flags |= 1u; action = action > 0 ? 1 : 0; }
+  const float gravity = h->params[t * 4 + 0], masscart = h->params[t * 4 + 1], masspole = h->params[t * 4 + 2],
+              length = h->params[t * 4 + 3];
+  const float polemass_length = masspole * length;  /* :49 */
+  const float total_mass = masspole + masscart;     /* :50 */
+  float x = h->state[i], xd = h->state[(size_t)N + i], th = h->state[(size_t)2 * N + i], thd = h->state[(size_t)3 * N + i];
+  const float force = action == 1 ? 10.0f : -10.0f;
+  float total_reward = 0.0f;
+  int term = 0;
+  for (int f = 0; f < h->frameskip; ++f) { /* :56-60 */
+    const float cs = cosf(th), sn = sinf(th);
+    const float temp = (force + polemass_length * thd * thd * sn) / total_mass;
+    const float thacc = (gravity * sn - cs * temp) / (length * (4.0f / 3.0f - masspole * cs * cs / total_mass));
+    const float xacc = temp - polemass_length * thacc * cs / total_mass;
+    x = x + 0.02f * xd;
+    xd = xd + 0.02f * xacc;
+    th = th + 0.02f * thd;
+    thd = thd + 0.02f * thacc;
+    term = (x < -2.4f) || (x > 2.4f) || (th < -0.20943951f) || (th > 0.20943951f);
+    total_reward += 1.0f;
+    if (term) break;
+  }
+  const int steps = h->steps[i] + 1;
+  const int trunc = h->max_steps > 0 && steps >= h->max_steps;
+  h->state[i] = x; h->state[(size_t)N + i] = xd; h->state[(size_t)2 * N + i] = th; h->state[(size_t)3 * N + i] = thd;
+  h->steps[i] = steps;
+  obs[(size_t)i * 4 + 0] = x; obs[(size_t)i * 4 + 1] = xd; obs[(size_t)i * 4 + 2] = th; obs[(size_t)i * 4 + 3] = thd;
+  reward[i] = total_reward; terminated[i] = (uint8_t)term; truncated[i] = (uint8_t)trunc;
+  if (term || trunc) {
+    if (mode == 2) {
+      if (final_obs) for (int k = 0; k < 4; ++k) final_obs[(size_t)i * 4 + k] = obs[(size_t)i * 4 + k];
+      cartpole_reset_one(h, i, u_reset, obs);
+    } else if (mode == 1) {
+      h->need_reset[i] = 1;
+    }
+  }
+}
+
+void xo_cartpole_reset_injected(xo_cartpole* h, const uint8_t* mask, const float* u, float* obs) {
+  for (int i = 0; i < h->n_env; ++i) {
+    if (mask && !mask[i]) continue;
+    float uu[4];
+    for (int k = 0; k < 4; ++k) uu[k] = u[(size_t)k * h->n_env + i];
+    cartpole_reset_one(h, i, uu, obs);
+  }
+}
+
+void xo_cartpole_step_injected(xo_cartpole* h, const int32_t* action, const float* u_reset, float* obs,
+                               float* reward, uint8_t* terminated, uint8_t* truncated, float* final_obs, int mode) {
+  for (int i = 0; i < h->n_env; ++i) {
+    float uu[4];
+    for (int k = 0; k < 4; ++k) uu[k] = u_reset[(size_t)k * h->n_env + i];
+    cartpole_step_one(h, i, action[i], uu, obs, reward, terminated, truncated, final_obs, mode);
+  }
+}
+
+static inline void cartpole_draw(uint64_t seed, uint64_t gid, uint64_t tick, float u[4]) {
+  uint32_t w[4];
+  xo_env_draw(seed, gid, tick, 1, w);
+  for (int k = 0; k < 4; ++k) u[k] = (float)(w[k] >> 8) * (1.0f / 16777216.0f);
+}
+
+void xo_cartpole_reset(xo_cartpole* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const uint8_t* mask, float* obs) {
+  for (int i = 0; i < h->n_env; ++i) {
+    if (mask && !mask[i]) continue;
+    float u[4];
+    cartpole_draw(seed, gid_base + (uint64_t)i, tick, u);
+    cartpole_reset_one(h, i, u, obs);
+  }
+}
+
+void xo_cartpole_step(xo_cartpole* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const int32_t* action,
+                      float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, float* final_obs, int mode) {
+  for (int i = 0; i < h->n_env; ++i) {
+    float u[4];
+    cartpole_draw(seed, gid_base + (uint64_t)i, tick, u);
+    cartpole_step_one(h, i, action[i], u, obs, reward, terminated, truncated, final_obs, mode);
+  }
+}

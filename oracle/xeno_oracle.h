@@ -112,6 +112,29 @@ void xo_linds_step(xo_linds* h, uint64_t seed, uint64_t gid_base, uint64_t tick,
  * straight from the accumulator layout of the previous product): fills ord[NS], returns NS */
 int xo_linds_yorder(int NS, int* ord);
 
+/* ---------------------------------------------------------------------------------------------
+ * CartPole — reference: metacontrol/random_cartpole.py (set_task :46-50, step :52-61, reset :63-75) over
+ * gymnasium's CartPoleEnv.step (third-party, not vendored: PARITY UNPINNED, restated from the public
+ * gymnasium 1.x source equations).  fp32 state, component-major [4][n_env].
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int n_env, n_task, frameskip, max_steps; /* max_steps <= 0: never truncates (the reference registers no TimeLimit) */
+  const float* params;    /* [n_task][4]: gravity, masscart, masspole, length */
+  const float* reset_scale; /* [4] reset_bounds_scale */
+  const int32_t* env_task;
+  float* state;           /* [4][n_env]: x, x_dot, theta, theta_dot */
+  int32_t* steps;
+  uint8_t* need_reset;
+  uint32_t err_flags;
+} xo_cartpole;
+void xo_cartpole_reset_injected(xo_cartpole* h, const uint8_t* mask, const float* u /*[4][n_env] in [0,1)*/,
+                                float* obs /*[n_env][4]*/);
+void xo_cartpole_step_injected(xo_cartpole* h, const int32_t* action, const float* u_reset, float* obs,
+                               float* reward, uint8_t* terminated, uint8_t* truncated, float* final_obs, int mode);
+void xo_cartpole_reset(xo_cartpole* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const uint8_t* mask, float* obs);
+void xo_cartpole_step(xo_cartpole* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const int32_t* action,
+                      float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, float* final_obs, int mode);
+
 #ifdef __cplusplus
 }
 #endif

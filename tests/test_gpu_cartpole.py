@@ -1,0 +1,80 @@
+"""GPU parity: HIP CartPole (C-ABI) vs the CPU oracle on seeded batches (same fp32 expressions; sincosf differs
+in the last bit between device and host libm -> 1e-5 rel) and vs the fp64 statement of gymnasium's equations."""
+import numpy as np
+import pytest
+
+import oracle
+from xenoverse_amd.metacontrol import CartPoleVecEnv, sample_cartpole
+from test_oracle_cartpole import gym_cartpole_step_f64
+
+pytestmark = pytest.mark.gpu
+MODES = {"disabled": 0, "next_step": 1, "same_step": 2}
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("mode", ["disabled", "next_step", "same_step"])
+@pytest.mark.parametrize("frameskip", [1, 5])
+def test_batch_vs_oracle(mode, frameskip):
+    n, n_task = 1000, 50
+    tasks = [sample_cartpole(seed=k) for k in range(n_task)]
+    params = np.array([[t["gravity"], t["masscart"], t["masspole"], t["length"]] for t in tasks], np.float32)
+    env_task = (np.arange(n) % n_task).astype(np.int32)
+    env = CartPoleVecEnv(n, frameskip=frameskip, autoreset_mode=mode, max_steps=60)
+    env.set_task(tasks, env_task_index=env_task)
+    ora = oracle.CartPoleOracle(params, env_task, frameskip=frameskip, max_steps=60)
+    rng = np.random.RandomState(1)
+    u0 = rng.random_sample((4, n)).astype(np.float32)
+    assert np.array_equal(_np(env.reset_injected(u0)), ora.reset_injected(u0))
+    ended = 0
+    for t in range(150):
+        a = rng.randint(0, 2, n).astype(np.int32)
+        u = rng.random_sample((4, n)).astype(np.float32)
+        obs, r, term, trunc, info = env.step_injected(a, u)
+        o = ora.step_injected(a, u, MODES[mode])
+        assert np.allclose(_np(obs), o["obs"], rtol=1e-5, atol=1e-6)
+        near = (np.abs(np.abs(ora.state[0]) - 2.4) < 1e-4) | (np.abs(np.abs(ora.state[2]) - 0.20943951) < 1e-5)
+        assert np.array_equal(_np(term).astype(np.uint8)[~near], o["terminated"][~near])
+        assert np.array_equal(_np(trunc).astype(np.uint8), o["truncated"])
+        assert np.array_equal(_np(r)[~near], o["reward"][~near])
+        s, st, nr = env.get_state()
+        ora.state[:] = _np(s); ora.steps[:] = _np(st); ora.need_reset[:] = _np(nr)   # re-sync: no compounding
+        done = (o["terminated"] | o["truncated"]).astype(bool)
+        ended += int(done.sum())
+        if mode == "disabled" and done.any():
+            ur = rng.random_sample((4, n)).astype(np.float32)
+            env.reset_injected(ur, mask=done.astype(np.uint8)); ora.reset_injected(ur, mask=done.astype(np.uint8))
+    assert ended > 500
+    assert env.check_errors() == 0
+    env.close()
+
+
+def test_free_running_and_fp64_equations():
+    n = 256
+    tasks = [sample_cartpole(seed=100 + k) for k in range(n)]
+    params = np.array([[t["gravity"], t["masscart"], t["masspole"], t["length"]] for t in tasks], np.float32)
+    seed, base = 31, 1 << 20
+    env = CartPoleVecEnv(n, frameskip=1, seed=seed, env_id_base=base, autoreset_mode="same_step")
+    env.set_task(tasks)
+    ora = oracle.CartPoleOracle(params, np.arange(n), frameskip=1)
+    tick = env.engine.tick
+    obs, _ = env.reset()
+    assert np.array_equal(_np(obs), ora.reset(seed, base, tick))
+    rng = np.random.RandomState(2)
+    for t in range(100):
+        a = rng.randint(0, 2, n).astype(np.int32)
+        before = _np(env.get_state()[0]).astype(np.float64)
+        tick = env.engine.tick
+        obs, r, term, trunc, info = env.step(a)
+        o = ora.step(seed, base, tick, a, 2)
+        assert np.allclose(_np(obs), o["obs"], rtol=1e-5, atol=1e-6)
+        fo = _np(info["final_obs"])
+        for i in range(0, n, 29):
+            s64, _, term64 = gym_cartpole_step_f64(before[:, i], a[i], *params[i].astype(np.float64))
+            got = fo[i] if bool(term[i]) else _np(obs)[i]
+            assert np.allclose(got, s64, rtol=1e-5, atol=1e-6)
+        s, st, nr = env.get_state()
+        ora.state[:] = _np(s); ora.steps[:] = _np(st)
+    env.close()

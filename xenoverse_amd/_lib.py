@@ -46,6 +46,14 @@ SIGNATURES = {
     "xv_linds_step_injected": [c_void_p] + [c_void_p] * 10 + [c_int],
     "xv_linds_get_state": [c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_linds_set_state": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "xv_cartpole_create": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, C.POINTER(c_void_p)],
+    "xv_cartpole_destroy": [c_void_p],
+    "xv_cartpole_reset": [c_void_p, c_void_p, c_void_p],
+    "xv_cartpole_reset_injected": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "xv_cartpole_step": [c_void_p] + [c_void_p] * 6 + [c_int],
+    "xv_cartpole_step_injected": [c_void_p] + [c_void_p] * 7 + [c_int],
+    "xv_cartpole_get_state": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "xv_cartpole_set_state": [c_void_p, c_void_p, c_void_p, c_void_p],
 }
 _RESTYPE = {"xv_last_error": C.c_char_p, "xv_engine_stream": c_void_p}
 
