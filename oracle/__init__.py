@@ -317,3 +317,62 @@ class CartPoleOracle(object):
                                _p(o["obs"]), _p(o["reward"]), _p(o["terminated"]), _p(o["truncated"]),
                                _p(o["final_obs"]), C.c_int(mode))
         return o
+
+
+# ---------------------------------------------------------------------------------------------------
+# MazeWorld
+# ---------------------------------------------------------------------------------------------------
+class _MazeStruct(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("n_env", "n_task", "NG", "n_cmd", "max_steps", "W", "H",
+                                       "command_in_observation")] + \
+               [("collision_dist", C.c_double), ("visibility", C.c_double)] + \
+               [(k, C.c_void_p) for k in ("walls", "texts", "landmarks", "ints", "dbl", "commands", "lm_coord",
+                                          "tex_walls", "tex_grounds", "tex_ceilings", "env_task", "pos", "ori",
+                                          "grid", "steps", "cmd_idx", "cmd_age", "need_reset", "collision")]
+
+
+class MazeOracle(object):
+    """tables: xenoverse_amd.mazeworld.tables.build_tables; textures: dict(walls, grounds, ceilings) float32"""
+
+    def __init__(self, tables, textures, env_task, resolution=(32, 32), max_steps=5000, visibility_3D=12.0,
+                 collision_dist=0.20, command_in_observation=False):
+        t = tables
+        self.env_task = np.ascontiguousarray(env_task, np.int32)
+        self.n_env = n = len(self.env_task)
+        self.W, self.H = int(resolution[0]), int(resolution[1])
+        self._keep = dict(walls=np.ascontiguousarray(t["walls"], np.int8),
+                          texts=np.ascontiguousarray(t["texts"], np.int32),
+                          landmarks=np.ascontiguousarray(t["landmarks"], np.int8),
+                          ints=np.ascontiguousarray(t["ints"], np.int32), dbl=np.ascontiguousarray(t["dbl"], np.float64),
+                          commands=np.ascontiguousarray(t["commands"], np.int32),
+                          lm_coord=np.ascontiguousarray(t["lm_coord"], np.int32),
+                          tw=np.ascontiguousarray(textures["walls"], np.float32),
+                          tg=np.ascontiguousarray(textures["grounds"], np.float32),
+                          tc=np.ascontiguousarray(textures["ceilings"], np.float32))
+        k = self._keep
+        self.pos = np.zeros((2, n), np.float64); self.ori = np.zeros(n, np.float64)
+        self.grid = np.zeros((2, n), np.int32); self.steps = np.zeros(n, np.int32)
+        self.cmd_idx = np.zeros(n, np.int32); self.cmd_age = np.zeros(n, np.int32)
+        self.need_reset = np.ones(n, np.uint8); self.collision = np.zeros(n, np.float64)
+        self._h = _MazeStruct(n, k["walls"].shape[0], int(t["NG"]), int(t["n_cmd"]), int(max_steps), self.W, self.H,
+                              int(bool(command_in_observation)), float(collision_dist), float(visibility_3D),
+                              _p(k["walls"]), _p(k["texts"]), _p(k["landmarks"]), _p(k["ints"]), _p(k["dbl"]),
+                              _p(k["commands"]), _p(k["lm_coord"]), _p(k["tw"]), _p(k["tg"]), _p(k["tc"]),
+                              _p(self.env_task), _p(self.pos), _p(self.ori), _p(self.grid), _p(self.steps),
+                              _p(self.cmd_idx), _p(self.cmd_age), _p(self.need_reset), _p(self.collision))
+
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        lib().xo_maze_reset(C.byref(self._h), _p(m))
+
+    def step(self, action, mode):
+        a = np.ascontiguousarray(action, np.float64).reshape(self.n_env, 2)
+        r = np.zeros(self.n_env, np.float32); te = np.zeros(self.n_env, np.uint8); tr = np.zeros(self.n_env, np.uint8)
+        lib().xo_maze_step(C.byref(self._h), _p(a), _p(r), _p(te), _p(tr), C.c_int(mode))
+        return r, te, tr
+
+    def render(self, n_threads=1):
+        f = np.zeros((self.n_env, self.W, self.H, 3), np.uint8)
+        c = np.zeros((self.n_env, 3), np.float32)
+        lib().xo_maze_render(C.byref(self._h), _p(f), _p(c), C.c_int(n_threads))
+        return f, c

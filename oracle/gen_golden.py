@@ -18,6 +18,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
 import _refimport  # noqa: E402
 import sample_ref_tasks  # noqa: E402
 
@@ -260,7 +261,100 @@ def gen_linds():
     gen_linds_one("linds_32x8x8_0", task, T=384, seed0=9000)
 
 
-FAMILIES = {"anymdp": gen_anymdp, "linds": gen_linds}
+def _maze_task_arrays(task):
+    return dict(start=np.asarray(task["start"], np.int64), cell_walls=np.asarray(task["cell_walls"], np.int8),
+                cell_texts=np.asarray(task["cell_texts"], np.int64), cell_size=np.float64(task["cell_size"]),
+                ground_text=np.int64(task["ground_text"]), ceiling_text=np.int64(task["ceiling_text"]),
+                step_reward=np.float64(task["step_reward"]), goal_reward=np.float64(task["goal_reward"]),
+                collision_reward=np.float64(task["collision_reward"]), wall_height=np.float64(task["wall_height"]),
+                agent_height=np.float64(task["agent_height"]), fol_angle=np.float64(task["fol_angle"]),
+                commands_sequence=np.asarray(task["commands_sequence"], np.int64),
+                landmarks_coordinates=np.asarray(task["landmarks_coordinates"], np.int64),
+                cell_landmarks=np.asarray(task["cell_landmarks"], np.int8))
+
+
+def gen_maze_one(name, task, T=256, max_steps=5000, seed0=0, res=32):
+    """G-M for one task: a scripted trajectory through the reference MazeWorldContinuous3D.step(); pose, rules
+    and frames recorded per step.  A few `inject` events place the agent next to its goal / advance the
+    command age, so that goal reaching, the 500-step command limit and truncation all occur."""
+    Maze, mts, dyn, rc = _refimport.mazeworld()
+    env = Maze(enable_render=False, resolution=(res, res), max_steps=max_steps, visibility_3D=12.0,
+               command_in_observation=False, action_space_type="Discrete16")
+    env.set_task(task)
+    core = env.maze_core
+    obs0, info0 = env.reset()
+    rng = np.random.RandomState(seed0)
+    acts = rng.choice(16, size=T, p=np.array([2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 6, 3, 3, 3, 3]) / 30.0)
+    rec = {k: [] for k in ("pos", "ori", "grid", "reward", "cmd_idx", "cmd_age", "term", "trunc", "steps",
+                           "collision", "cmd_rgb")}
+    inj_pose = np.full((T, 3), np.nan)     # pose forced BEFORE step t
+    inj_age = np.full(T, -1, np.int64)     # _commands_exists forced BEFORE step t
+    frames = np.zeros((T, res, res, 3), np.uint8)
+    cs = float(task["cell_size"])
+    for t in range(T):
+        if t in (60, 130):   # stand in a free cell next to the current goal, facing it
+            g = core._landmarks_coordinates[core._command]
+            for d, ang in (((-1, 0), 0.0), ((1, 0), 3.1415926), ((0, -1), 1.5707963), ((0, 1), -1.5707963)):
+                c = (g[0] + d[0], g[1] + d[1])
+                if core._cell_walls[c] == 0:
+                    core._agent_loc = [c[0] * cs + 0.5 * cs, c[1] * cs + 0.5 * cs]
+                    core._agent_ori = ang
+                    inj_pose[t] = [core._agent_loc[0], core._agent_loc[1], ang]
+                    acts[t:t + 6] = 11          # walk forward at full speed
+                    break
+        if t == 200:
+            core._commands_exists = 498
+            inj_age[t] = 498
+        obs, r, term, trunc, info = env.step(int(acts[t]))
+        frames[t] = obs
+        rec["pos"].append(np.array(core._agent_loc, np.float64)); rec["ori"].append(float(core._agent_ori))
+        rec["grid"].append(np.array(core._agent_grid, np.int64)); rec["reward"].append(float(r))
+        rec["cmd_idx"].append(int(core._commands_sequence_idx)); rec["cmd_age"].append(int(core._commands_exists))
+        rec["term"].append(int(term)); rec["trunc"].append(int(trunc)); rec["steps"].append(int(info["steps"]))
+        rec["collision"].append(float(core._collision_punish / task["collision_reward"]))
+        rec["cmd_rgb"].append(np.asarray(info["command"], np.float32))
+        env.need_reset = False      # keep stepping after truncation, as the core allows
+    # a few continuous actions (python floats, as the Discrete tables hand them over)
+    cont = np.array([[0.37, -0.8], [-1.7, 0.9], [0.0, 1.0], [0.013, 0.61], [-0.22, -1.4], [0.5, 0.5]])
+    cont_pose = []
+    for a in cont:
+        core.do_action([float(a[0]), float(a[1])])
+        cont_pose.append([core._agent_loc[0], core._agent_loc[1], float(core._agent_ori)])
+    # frames at 64x64 for a subset of the recorded poses, straight from maze_view
+    idx64 = np.arange(0, T, 32)
+    f64 = np.zeros((len(idx64), 64, 64, 3), np.uint8)
+    M = mts.MAZE_TASK_MANAGER
+    for q, t in enumerate(idx64):
+        img, _ = rc.maze_view(np.array(rec["pos"][t], dtype=np.float32), rec["ori"][t], core._agent_height,
+                              core._cell_walls, core._cell_landmarks, core._cell_texts, core._cell_size,
+                              M.textlib_walls, M.textlib_grounds[core._ground_text],
+                              M.textlib_ceilings[core._ceiling_text], core._wall_height, 1.0, 12.0, 0.20,
+                              core._fol_angle, 64, 64, rc.landmarks_rgb_arr)
+        f64[q] = img.astype("uint8")
+    out = _maze_task_arrays(task)
+    out.update(max_steps=np.int64(max_steps), res=np.int64(res), actions=acts.astype(np.int64), inj_pose=inj_pose,
+               inj_age=inj_age, frame0=np.asarray(obs0, np.uint8), frames=frames[::8], frame_steps=np.arange(0, T, 8),
+               frames64=f64, frames64_steps=idx64, cont_actions=cont, cont_pose=np.array(cont_pose),
+               **{"tr_" + k: np.array(v) for k, v in rec.items()})
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; goals reached:",
+          int(np.sum(np.diff(np.array(rec["cmd_idx"])) > 0)), "truncated:", int(np.sum(rec["trunc"])),
+          "contact steps:", int(np.sum(np.array(rec["collision"]) > 0)))
+
+
+def gen_maze():
+    Maze, mts, dyn, rc = _refimport.mazeworld()
+    from xenoverse_amd.mazeworld.textures import make_texture_library
+    lib = make_texture_library(8, 4, 4, seed=0)    # the reference's JPG assets are not used (nor copied)
+    M = mts.MAZE_TASK_MANAGER
+    M.textlib_walls, M.textlib_grounds, M.textlib_ceilings = lib["walls"], lib["grounds"], lib["ceilings"]
+    for k in range(3):
+        task = mts.MazeTaskSampler(n_range=(15, 16), seed=k, verbose=False)
+        gen_maze_one("maze_15_seed%d" % k, task, max_steps=(5000 if k else 230), seed0=100 + k)
+
+
+FAMILIES = {"anymdp": gen_anymdp, "linds": gen_linds, "maze": gen_maze}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

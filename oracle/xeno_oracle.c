@@ -633,3 +633,417 @@ void xo_cartpole_step(xo_cartpole* h, uint64_t seed, uint64_t gid_base, uint64_t
     cartpole_step_one(h, i, action[i], u, obs, reward, terminated, truncated, final_obs, mode);
   }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * MazeWorld
+ * ---------------------------------------------------------------------------------------------- */
+#define MZ_PI 3.1415926      /* dynamics.py:7-8: the reference's own truncated constants */
+#define MZ_TPI 6.2831852
+
+static double mz_angle_norm(double t) { /* dynamics.py:48-54 */
+  while (t > MZ_PI) t -= MZ_TPI;
+  while (t < -MZ_PI) t += MZ_TPI;
+  return t;
+}
+
+/* dynamics.py:56-69: distance to / nearest point on the segment l1-l2 */
+static double mz_nearest_point(const double p[2], const double l1[2], const double l2[2], double np_[2]) {
+  double u0 = l2[0] - l1[0], u1 = l2[1] - l1[1];
+  const double edge = sqrt(u0 * u0 + u1 * u1);
+  const double m = edge > 1.0e-6 ? edge : 1.0e-6;
+  u0 /= m; u1 /= m;
+  const double d1 = (p[0] - l1[0]) * u0 + (p[1] - l1[1]) * u1;
+  if (d1 > edge) { np_[0] = l2[0]; np_[1] = l2[1]; }
+  else if (d1 < 0) { np_[0] = l1[0]; np_[1] = l1[1]; }
+  else { np_[0] = l1[0] + d1 * u0; np_[1] = l1[1] + d1 * u1; }
+  const double a = p[0] - np_[0], b = p[1] - np_[1];
+  return sqrt(a * a + b * b);
+}
+
+/* dynamics.py:71-96: soft push-out force from the wall cell whose centre is at -dv (cell units) */
+static void mz_collision_force(const double dv[2], double cell_size, double col_dist, double f[2]) {
+  static const double O10[2] = {0.5, 0.5}, O01[2] = {-0.5, 0.5}, Om0[2] = {-0.5, -0.5}, O0m[2] = {0.5, -0.5};
+  const double dist = sqrt(dv[0] * dv[0] + dv[1] * dv[1]);
+  const double eff = col_dist / cell_size;
+  f[0] = f[1] = 0.0;
+  if (dist > 0.708 + eff) return;
+  if (fabs(dv[0]) < 0.5 && fabs(dv[1]) < 0.5) { /* centre inside the wall cell: :77-78 */
+    const double s = 0.50 / (dist > 1.0e-6 ? dist : 1.0e-6) * (0.708 + eff - dist) * cell_size;
+    f[0] = s * dv[0]; f[1] = s * dv[1];
+    return;
+  }
+  const int x_pos = dv[0] + dv[1] > 0, y_pos = dv[1] - dv[0] > 0;
+  double np_[2], d;
+  if (x_pos && y_pos) d = mz_nearest_point(dv, O10, O01, np_);
+  else if (!x_pos && y_pos) d = mz_nearest_point(dv, O01, Om0, np_);
+  else if (!x_pos && !y_pos) d = mz_nearest_point(dv, Om0, O0m, np_);
+  else d = mz_nearest_point(dv, O0m, O10, np_);
+  if (eff < d) return;
+  double o0 = dv[0] - np_[0], o1 = dv[1] - np_[1];
+  const double on = sqrt(o0 * o0 + o1 * o1);
+  const double inv = 1.0 / (on > 1.0e-6 ? on : 1.0e-6);
+  o0 *= inv; o1 *= inv;
+  const double s = 0.50 * (eff - d) * cell_size;
+  f[0] = s * o0; f[1] = s * o1;
+}
+
+/* dynamics.py:158-187 with vector_move_no_collision :98-123 inlined: delta_t = 1.0 in 100 sub-steps of 0.01 */
+void xo_maze_move(double* ori_io, double pos[2], double turn_rate, double walk_speed, const int8_t* walls, int n,
+                  int NG, double cell_size, double col_dist, double* collision) {
+  double ori = *ori_io, p0 = pos[0], p1 = pos[1], coll = 0.0;
+  const double t_prec = 0.01, delta_t = 1.0;
+  const int iteration = (int)(delta_t / t_prec);
+  for (int it = 0; it < iteration + 1; ++it) {
+    const double rem = delta_t - it * t_prec;
+    const double dt = rem < t_prec ? rem : t_prec;
+    if (dt < 1.0e-8) continue;
+    const double d_theta = turn_rate * dt, arc = walk_speed * dt;
+    const double c_t = cos(ori), s_t = sin(ori), c_dt = cos(0.5 * d_theta), s_dt = sin(0.5 * d_theta);
+    const double n_ori = mz_angle_norm(ori + d_theta);
+    double dx, dy;
+    if (fabs(d_theta) < 1.0e-8) { dx = c_t * arc; dy = s_t * arc; }
+    else {
+      const double rad = walk_speed / turn_rate, off = 2.0 * s_dt * rad;
+      const double c_n = c_t * c_dt - s_t * s_dt, s_n = c_t * s_dt + s_t * c_dt;
+      dx = c_n * off; dy = s_n * off;
+    }
+    ori = n_ori;
+    const double e0 = p0 + dx, e1 = p1 + dy;
+    const double c0 = e0 / cell_size, c1 = e1 / cell_size;
+    double f0 = 0.0, f1 = 0.0;
+    for (int i = -1; i < 2; ++i)
+      for (int j = -1; j < 2; ++j) {
+        const int wi = i + (int)c0, wj = j + (int)c1;
+        if (wi > -1 && wi < n && wj > -1 && wj < n && walls[wi * NG + wj] > 0) {
+          const double dv[2] = {c0 - floor(c0) - (double)(float)(i + 0.5), c1 - floor(c1) - (double)(float)(j + 0.5)};
+          double f[2];
+          mz_collision_force(dv, cell_size, col_dist, f);
+          f0 += f[0]; f1 += f[1];
+        }
+      }
+    p0 = f0 + e0; p1 = f1 + e1;
+    coll += sqrt(f0 * f0 + f1 * f1);
+  }
+  *ori_io = ori; pos[0] = p0; pos[1] = p1;
+  if (collision) *collision = coll;
+}
+
+void xo_maze_reset(xo_maze* h, const uint8_t* mask) { /* maze_base.py:83-105 */
+  for (int e = 0; e < h->n_env; ++e) {
+    if (mask && !mask[e]) continue;
+    const int t = h->env_task[e];
+    const int32_t* in = h->ints + (size_t)t * 8;
+    const double cs = h->dbl[(size_t)t * 8];
+    h->grid[e] = in[1]; h->grid[(size_t)h->n_env + e] = in[2];
+    h->pos[e] = in[1] * cs + 0.5 * cs;                       /* get_cell_center :215-218 */
+    h->pos[(size_t)h->n_env + e] = in[2] * cs + 0.5 * cs;
+    h->ori[e] = 0.0;
+    h->cmd_idx[e] = 0; h->cmd_age[e] = 0; h->steps[e] = 0; h->need_reset[e] = 0;
+    h->collision[e] = 0.0;
+  }
+}
+
+void xo_maze_step(xo_maze* h, const double* action, float* reward, uint8_t* terminated, uint8_t* truncated,
+                  int mode) {
+  const int N = h->n_env;
+  for (int e = 0; e < N; ++e) {
+    const int t = h->env_task[e];
+    const int32_t* in = h->ints + (size_t)t * 8;
+    const double* db = h->dbl + (size_t)t * 8;
+    if (mode == 1 && h->need_reset[e]) {
+      uint8_t m = 1;
+      xo_maze tmp = *h; (void)tmp;
+      /* reset this env only */
+      const double cs = db[0];
+      h->grid[e] = in[1]; h->grid[(size_t)N + e] = in[2];
+      h->pos[e] = in[1] * cs + 0.5 * cs; h->pos[(size_t)N + e] = in[2] * cs + 0.5 * cs;
+      h->ori[e] = 0.0; h->cmd_idx[e] = 0; h->cmd_age[e] = 0; h->steps[e] = 0; h->need_reset[e] = 0;
+      (void)m;
+      reward[e] = 0.0f; terminated[e] = 0; truncated[e] = 0;
+      continue;
+    }
+    /* do_action: maze_continuous_3d.py:49-62 */
+    double tr = action[2 * e], ws = action[2 * e + 1];
+    tr = (tr < -1.0 ? -1.0 : (tr > 1.0 ? 1.0 : tr)) * MZ_PI;
+    ws = ws < -1.0 ? -1.0 : (ws > 1.0 ? 1.0 : ws);
+    double p[2] = {h->pos[e], h->pos[(size_t)N + e]}, ori = h->ori[e], coll;
+    xo_maze_move(&ori, p, tr, ws, h->walls + (size_t)t * h->NG * h->NG, in[0], h->NG, db[0], h->collision_dist, &coll);
+    h->pos[e] = p[0]; h->pos[(size_t)N + e] = p[1]; h->ori[e] = ori; h->collision[e] = coll;
+    const int g0 = (int)(p[0] / db[0]), g1 = (int)(p[1] / db[0]); /* get_loc_grid :220-223 */
+    h->grid[e] = g0; h->grid[(size_t)N + e] = g1;
+    /* evaluation_rule: maze_base.py:107-119 */
+    const int steps = h->steps[e] + 1;
+    int age = h->cmd_age[e] + 1, idx = h->cmd_idx[e];
+    const int cmd = h->commands[(size_t)t * h->n_cmd + (idx < h->n_cmd ? idx : h->n_cmd - 1)];
+    const int32_t* lc = h->lm_coord + ((size_t)t * XO_MAZE_LMAX + cmd) * 2;
+    const int at_goal = (idx < h->n_cmd) && lc[0] == g0 && lc[1] == g1;
+    /* instant_rewards is a float32 array holding goal_reward at the active command's cell (:61-69, :96) */
+    const float r = (at_goal ? (float)db[5] : 0.0f) + (float)db[4];
+    int term = 0;
+    if (at_goal || age >= 500) { /* reach_goal() or step_limits() -> refresh_command (:54-70) */
+      idx += 1; age = 0;
+      if (idx > h->n_cmd - 1) term = 1;
+    }
+    const int trunc = steps > h->max_steps - 1; /* :212-213 */
+    h->steps[e] = steps; h->cmd_age[e] = age; h->cmd_idx[e] = idx;
+    reward[e] = r; terminated[e] = (uint8_t)term; truncated[e] = (uint8_t)trunc;
+    if (term || trunc) {
+      if (mode == 2) {
+        const double cs = db[0];
+        h->grid[e] = in[1]; h->grid[(size_t)N + e] = in[2];
+        h->pos[e] = in[1] * cs + 0.5 * cs; h->pos[(size_t)N + e] = in[2] * cs + 0.5 * cs;
+        h->ori[e] = 0.0; h->cmd_idx[e] = 0; h->cmd_age[e] = 0; h->steps[e] = 0;
+      } else if (mode == 1) {
+        h->need_reset[e] = 1;
+      }
+    }
+  }
+}
+
+/* ray_caster_utils.py:11-25 */
+static const float MZ_LANDMARK_RGB[XO_MAZE_LMAX][3] = {
+    {0, 255, 0}, {255, 0, 0}, {0, 0, 255}, {0, 255, 255}, {255, 0, 255}, {255, 255, 0}, {128, 128, 255},
+    {128, 255, 128}, {255, 128, 128}, {0, 96, 128}, {96, 0, 128}, {0, 128, 96}, {96, 128, 0}, {128, 96, 0},
+    {128, 0, 96}};
+
+/* interpolate, ray_caster_utils.py:123-140: 4x4 taps, distance-weighted, wrap-around; sum_r is a float32
+ * array accumulated as float32(float64(sum_r) + wht * tex), the return value is float64 */
+static void mz_interpolate(const float* tex /*[256][256][3]*/, double i, double j, double d, double px, double py,
+                           double out[3]) {
+  double d2 = d * d;
+  if (d2 < 1.0e-8) d2 = 1.0e-8;
+  const int ib = (int)i, jb = (int)j;
+  double sum_wht = 0.0;
+  float sr[3] = {0.0f, 0.0f, 0.0f};
+  for (int x = ib - 1; x < ib + 3; ++x)
+    for (int y = jb - 1; y < jb + 3; ++y) {
+      const double a = ((double)x - i) * px, b = ((double)y - j) * py;
+      const double dist = a * a + b * b;
+      double wht = 1.0 - 10 * dist / d2;
+      if (wht > 1.0) wht = 1.0;
+      if (wht < 0.01) wht = 0.01;
+      sum_wht += wht;
+      const int xv = ((x % 256) + 256) % 256, yv = ((y % 256) + 256) % 256;
+      const float* tp = tex + ((size_t)xv * 256 + yv) * 3;
+      for (int c = 0; c < 3; ++c) sr[c] = (float)((double)sr[c] + wht * (double)tp[c]);
+    }
+  for (int c = 0; c < 3; ++c) out[c] = (double)sr[c] / sum_wht;
+}
+
+static inline int32_t mz_clip_int(double v) { /* numpy.clip(v, 0, 255) stored into an int32 array */
+  if (v < 0.0) v = 0.0;
+  if (v > 255.0) v = 255.0;
+  return (int32_t)v;
+}
+
+/* maze_view, ray_caster_utils.py:142-320, for one env.  Typing follows the reference as it executes under
+ * NumPy >= 2 scalar promotion (python floats are weak): per-column tables are float32, DDA_2D runs entirely
+ * in float32 (its python-float operands are weak), floor/ceiling/texture math is float64. */
+static void mz_view(const xo_maze* h, int e, int32_t* rgb /*[W][H][3]*/) {
+  const int t = h->env_task[e], W = h->W, H = h->H, NG = h->NG, N = h->n_env;
+  const int32_t* in = h->ints + (size_t)t * 8;
+  const double* db = h->dbl + (size_t)t * 8;
+  const int n = in[0];
+  const double cell_size = db[0], ceil_height = db[1], vision_height = db[2], fol = db[3];
+  const double visibility = h->visibility, l_focal = 0.20, text_size = 1.0;
+  const int8_t* walls = h->walls + (size_t)t * NG * NG;
+  const int8_t* transp = h->landmarks + (size_t)t * NG * NG;
+  const int32_t* texts = h->texts + (size_t)t * NG * NG;
+  const float* ground = h->tex_grounds + (size_t)in[3] * 256 * 256 * 3;
+  const float* ceil_t = h->tex_ceilings + (size_t)in[4] * 256 * 256 * 3;
+  const float pos[2] = {(float)h->pos[e], (float)h->pos[(size_t)N + e]}; /* maze_continuous_3d.py:97 */
+  const double ori = h->ori[e];
+
+  const double half_h = tan(fol / 2) * l_focal;
+  const double half_v = half_h * H / W;
+  const double pixel_size = 2.0 * half_h / W;
+  const double s_ori = sin(ori), c_ori = cos(ori);
+  const double pixel_factor = pixel_size / l_focal;
+  const double percell = cell_size / text_size;
+  const double tps = text_size / 256;
+
+  for (int k = 0; k < W * H * 3; ++k) rgb[k] = 1; /* FAR_RGB */
+  float cos_hp_a[1024], cos_abs[1024], sin_abs[1024];
+  double tan_hp = (-0.5 - W / 2.0) * pixel_factor;
+  for (int d_h = 0; d_h < W; ++d_h) { /* :170-177 */
+    tan_hp += pixel_factor;
+    const double cos_hp = sqrt(1.0 / (1.0 + tan_hp * tan_hp));
+    const double sin_hp = tan_hp * cos_hp;
+    sin_abs[d_h] = (float)(sin_hp * c_ori + cos_hp * s_ori);
+    cos_abs[d_h] = (float)(cos_hp * c_ori - sin_hp * s_ori);
+    cos_hp_a[d_h] = (float)cos_hp;
+  }
+  double eff_distance = 0.0; /* survives into the wall loop (quirk i) */
+
+  for (int d_v = H - 1; d_v > H / 2; --d_v) { /* floor :180-211 */
+    const double v_screen = (d_v + 0.5) * pixel_size - half_v;
+    const double distance = vision_height / v_screen * l_focal;
+    double light = v_screen / l_focal;
+    if (light > 1.0) light = 1.0;
+    if (distance > visibility) continue;
+    for (int d_h = 0; d_h < W; ++d_h) {
+      eff_distance = distance / (double)cos_hp_a[d_h];
+      double alpha = 2.0 * eff_distance / visibility - 1.0;
+      if (alpha < 0.0) alpha = 0.0;
+      if (alpha > 1.0) alpha = 1.0;
+      alpha *= light;
+      const double hit_x = eff_distance * (double)cos_abs[d_h] + (double)pos[0];
+      const double hit_y = eff_distance * (double)sin_abs[d_h] + (double)pos[1];
+      double fi = hit_x / cell_size, fj = hit_y / cell_size;
+      double d_i = fi - floor(fi), d_j = fj - floor(fj);
+      const int i = (int)fi, j = (int)fj;
+      const double eff_ps = eff_distance * pixel_size / l_focal;
+      if (i < n && i >= 0 && j < n && j >= 0) {
+        d_i *= percell; d_j *= percell;
+        d_i -= floor(d_i); d_j -= floor(d_j);
+        d_i *= 256; d_j *= 256;
+        double col[3];
+        mz_interpolate(ground, d_i, d_j, eff_ps, tps, tps, col);
+        int32_t* px = rgb + ((size_t)d_h * H + d_v) * 3;
+        for (int c = 0; c < 3; ++c) px[c] = mz_clip_int(light * (alpha * 1.0 + (1.0 - alpha) * col[c]));
+      }
+    }
+  }
+  for (int d_v = 0; d_v < H / 2; ++d_v) { /* ceiling :214-244 */
+    const double v_screen = half_v - (d_v + 0.5) * pixel_size;
+    const double distance = (ceil_height - vision_height) / v_screen * l_focal;
+    double light = v_screen / l_focal;
+    if (light > 1.0) light = 1.0;
+    if (distance > visibility) continue;
+    for (int d_h = 0; d_h < W; ++d_h) {
+      eff_distance = distance / (double)cos_hp_a[d_h];
+      double alpha = 2.0 * eff_distance / visibility - 1.0;
+      if (alpha < 0.0) alpha = 0.0;
+      if (alpha > 1.0) alpha = 1.0;
+      const double hit_x = eff_distance * (double)cos_abs[d_h] + (double)pos[0];
+      const double hit_y = eff_distance * (double)sin_abs[d_h] + (double)pos[1];
+      double fi = hit_x / cell_size, fj = hit_y / cell_size;
+      double d_i = fi - floor(fi), d_j = fj - floor(fj);
+      const int i = (int)fi, j = (int)fj;
+      const double eff_ps = eff_distance * pixel_size / l_focal;
+      if (i < n && i >= 0 && j < n && j >= 0) {
+        d_i *= percell; d_j *= percell;
+        d_i -= floor(d_i); d_j -= floor(d_j);
+        d_i *= 256; d_j *= 256;
+        double col[3];
+        mz_interpolate(ceil_t, d_i, d_j, eff_ps, tps, tps, col);
+        int32_t* px = rgb + ((size_t)d_h * H + d_v) * 3;
+        for (int c = 0; c < 3; ++c) px[c] = mz_clip_int(light * (alpha * 1.0 + (1.0 - alpha) * col[c]));
+      }
+    }
+  }
+  const float cs_f = (float)cell_size, eps_f = (float)1.0e-8, vis_f = (float)visibility, lf_f = (float)l_focal;
+  for (int d_h = 0; d_h < W; ++d_h) { /* walls :247-318 */
+    const int i0 = (int)(pos[0] / cs_f), j0 = (int)(pos[1] / cs_f);
+    /* ---- DDA_2D :47-115, float32 ---- */
+    const float co = cos_abs[d_h], so = sin_abs[d_h];
+    const float c_sign = co < 0 ? -1.0f : 1.0f, s_sign = so < 0 ? -1.0f : 1.0f;
+    const float ddx = fabsf(co) < eps_f ? fabsf(cs_f / eps_f) : fabsf(cs_f / co);
+    const float ddy = fabsf(so) < eps_f ? fabsf(cs_f / eps_f) : fabsf(cs_f / so);
+    const float d_x = co > 0 ? ((float)((i0 + 1) * cell_size) - pos[0]) : ((float)(i0 * cell_size) - pos[0]);
+    const float d_y = so > 0 ? ((float)((j0 + 1) * cell_size) - pos[1]) : ((float)(j0 * cell_size) - pos[1]);
+    float sdx = fabsf(co) < eps_f ? c_sign * (d_x / eps_f) : d_x / co;
+    float sdy = fabsf(so) < eps_f ? s_sign * (d_y / eps_f) : d_y / so;
+    const int di = co > 0 ? 1 : -1, dj = so > 0 ? 1 : -1;
+    int hi = i0, hj = j0, hit_side = 0, n_tr = 0;
+    float hit_dist = 0.0f;
+    float tr_dist[64];
+    int tr_id[64];
+    while (hit_dist < vis_f) {
+      if (sdx < sdy) {
+        hi += di; sdy -= sdx; hit_dist += sdx;
+        if (transp[hi * NG + hj] > -1 && n_tr < 64) { tr_dist[n_tr] = hit_dist; tr_id[n_tr++] = transp[hi * NG + hj]; }
+        if (hi < 0 || hi >= n) { if (hj < 0 || hj >= n) { hit_dist = 1.0e+6f; break; } }
+        else if (walls[hi * NG + hj] > 0) { hit_side = 0; break; }
+        sdx = ddx;
+      } else {
+        hj += dj; sdx -= sdy; hit_dist += sdy;
+        if (transp[hi * NG + hj] > -1 && n_tr < 64) { tr_dist[n_tr] = hit_dist; tr_id[n_tr++] = transp[hi * NG + hj]; }
+        if (hi < 0 || hi >= n) { if (hj < 0 || hj >= n) { hit_dist = 1.0e+6f; break; } }
+        else if (walls[hi * NG + hj] > 0) { hit_side = 1; break; }
+        sdy = ddy;
+      }
+    }
+    /* ---- wall column :258-298 ---- */
+    float alpha = 2.0f * hit_dist / vis_f - 1.0f;
+    if (alpha < 0.0f) alpha = 0.0f;
+    if (alpha > 1.0f) alpha = 1.0f;
+    const int text_id = texts[hi * NG + hj];
+    const float hit_pt_x = hit_dist * co + pos[0], hit_pt_y = hit_dist * so + pos[1];
+    float local_h, light;
+    if (hit_side == 0) { local_h = hit_pt_y / cs_f; local_h -= floorf(local_h); light = fabsf(co); }
+    else { local_h = hit_pt_x / cs_f; local_h -= floorf(local_h); light = fabsf(so); }
+    float ratio = hit_dist * cos_hp_a[d_h] / lf_f;
+    if (fabsf(ratio) < eps_f) ratio = ratio > 0 ? eps_f : -eps_f;
+    const float top_v = (float)(ceil_height - vision_height) / ratio, bot_v = (float)vision_height / ratio;
+    int v_s = (int)((half_v - (double)top_v) / pixel_size), v_e = (int)((half_v + (double)bot_v) / pixel_size);
+    if (v_s < 0) v_s = 0;
+    if (v_e > H) v_e = H;
+    const float* wt = h->tex_walls + (size_t)text_id * 256 * 256 * 3;
+    for (int d_v = v_s; d_v < v_e; ++d_v) {
+      const double local_v = (half_v - (d_v + 0.5) * pixel_size) * (double)ratio + vision_height;
+      float d_i = local_h * (float)percell;
+      double d_j = local_v / text_size;
+      d_i -= floorf(d_i); d_j -= floor(d_j);
+      const int ti = (int)(256.0f * d_i), tj = (int)(256 * d_j);
+      const double eff_ps = eff_distance * pixel_size / l_focal; /* stale eff_distance: quirk (i) */
+      double col[3];
+      mz_interpolate(wt, (double)ti, (double)tj, eff_ps, tps, tps, col);
+      int32_t* px = rgb + ((size_t)d_h * H + d_v) * 3;
+      for (int c = 0; c < 3; ++c) {
+        const double blend = (double)(float)(alpha * 1.0f) + (double)(1.0f - alpha) * col[c];
+        px[c] = mz_clip_int((double)light * blend);
+      }
+    }
+    /* ---- transparent landmark overlays, far to near :301-318 ---- */
+    for (int q = n_tr - 1; q >= 0; --q) {
+      const float hd = tr_dist[q];
+      float r2 = hd * cos_hp_a[d_h] / lf_f;
+      if (fabsf(r2) < eps_f) r2 = r2 > 0 ? eps_f : -eps_f;
+      const float tv = (float)(ceil_height - vision_height) / r2, bv = (float)vision_height / r2;
+      int s2 = (int)((half_v - (double)tv) / pixel_size), e2 = (int)((half_v + (double)bv) / pixel_size);
+      if (s2 < 0) s2 = 0;
+      if (e2 > H) e2 = H;
+      float a2 = 2.0f * hd / vis_f - 1.0f;
+      if (a2 < 0.0f) a2 = 0.0f;
+      if (a2 > 1.0f) a2 = 1.0f;
+      for (int d_v = s2; d_v < e2; ++d_v) {
+        int32_t* px = rgb + ((size_t)d_h * H + d_v) * 3;
+        for (int c = 0; c < 3; ++c) {
+          const float inner = (1.0f - a2) * MZ_LANDMARK_RGB[tr_id[q]][c] + a2 * 1.0f;
+          const float tinted = 0.30f * inner;
+          px[c] = mz_clip_int((1.0 - 0.30) * (double)px[c] + (double)tinted);
+        }
+      }
+    }
+  }
+  if (h->command_in_observation) { /* maze_continuous_3d.py:23-29,102-107 */
+    const int idx = h->cmd_idx[e] < h->n_cmd ? h->cmd_idx[e] : h->n_cmd - 1;
+    const int cmd = h->commands[(size_t)t * h->n_cmd + idx];
+    const int sx = (int)(0.25 * H), sy = (int)(0.10 * H), ex = (int)(0.25 * H + 0.50 * H), ey = (int)(0.10 * H + 0.05 * W);
+    for (int x = sx; x < ex && x < W; ++x)
+      for (int y = sy; y < ey && y < H; ++y)
+        for (int c = 0; c < 3; ++c) rgb[((size_t)x * H + y) * 3 + c] = (int32_t)MZ_LANDMARK_RGB[cmd][c];
+  }
+}
+
+void xo_maze_render(const xo_maze* h, uint8_t* frames, float* command_rgb, int n_threads) {
+  const size_t fsz = (size_t)h->W * h->H * 3;
+  (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads > 0 ? n_threads : 1) schedule(dynamic, 1)
+#endif
+  for (int e = 0; e < h->n_env; ++e) {
+    int32_t* rgb = (int32_t*)malloc(fsz * sizeof(int32_t));
+    mz_view(h, e, rgb);
+    if (frames)
+      for (size_t k = 0; k < fsz; ++k) frames[(size_t)e * fsz + k] = (uint8_t)rgb[k]; /* astype('uint8') :113 */
+    free(rgb);
+    if (command_rgb) {
+      const int t = h->env_task[e];
+      const int idx = h->cmd_idx[e] < h->n_cmd ? h->cmd_idx[e] : h->n_cmd - 1;
+      const int cmd = h->commands[(size_t)t * h->n_cmd + idx];
+      for (int c = 0; c < 3; ++c) command_rgb[(size_t)e * 3 + c] = MZ_LANDMARK_RGB[cmd][c];
+    }
+  }
+}

@@ -135,6 +135,46 @@ void xo_cartpole_reset(xo_cartpole* h, uint64_t seed, uint64_t gid_base, uint64_
 void xo_cartpole_step(xo_cartpole* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const int32_t* action,
                       float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, float* final_obs, int mode);
 
+/* ---------------------------------------------------------------------------------------------
+ * MazeWorld — reference: mazeworld/envs/dynamics.py (move/collision), maze_base.py (rules),
+ * maze_continuous_3d.py (do_action, update_observation), ray_caster_utils.py (DDA_2D, interpolate, maze_view).
+ * Pose in fp64 as the reference; ray-caster with the reference's mixed f32/f64 typing (see xeno_oracle.c).
+ * ------------------------------------------------------------------------------------------- */
+#define XO_MAZE_LMAX 15
+typedef struct {
+  int n_env, n_task, NG, n_cmd, max_steps, W, H, command_in_observation;
+  double collision_dist, visibility;
+  const int8_t* walls;       /* [n_task][NG][NG] cell_walls (pitch NG) */
+  const int32_t* texts;      /* [n_task][NG][NG] cell_texts */
+  const int8_t* landmarks;   /* [n_task][NG][NG] cell_landmarks (-1: none) */
+  const int32_t* ints;       /* [n_task][8]: n, start_i, start_j, ground_text, ceiling_text, n_landmarks, 0, 0 */
+  const double* dbl;         /* [n_task][8]: cell_size, wall_height, agent_height, fol_angle, step_reward,
+                                             goal_reward, collision_reward, 0 */
+  const int32_t* commands;   /* [n_task][n_cmd] commands_sequence */
+  const int32_t* lm_coord;   /* [n_task][LMAX][2] landmarks_coordinates */
+  const float* tex_walls;    /* [n_tex][256][256][3] */
+  const float* tex_grounds;
+  const float* tex_ceilings;
+  const int32_t* env_task;
+  double* pos;               /* [2][n_env] */
+  double* ori;               /* [n_env] */
+  int32_t* grid;             /* [2][n_env] */
+  int32_t* steps;
+  int32_t* cmd_idx;
+  int32_t* cmd_age;          /* _commands_exists */
+  uint8_t* need_reset;
+  double* collision;         /* [n_env] accumulated |force| of the last move (info only) */
+} xo_maze;
+void xo_maze_reset(xo_maze* h, const uint8_t* mask);
+/* action: (turn_rate, walk_speed) double[n_env][2] as handed to do_action (maze_continuous_3d.py:49) */
+void xo_maze_step(xo_maze* h, const double* action, float* reward, uint8_t* terminated, uint8_t* truncated,
+                  int mode);
+/* frames uint8[n_env][W][H][3] (maze_view + astype uint8); command RGB float[n_env][3] (info["command"]) */
+void xo_maze_render(const xo_maze* h, uint8_t* frames, float* command_rgb, int n_threads);
+/* one move, exposed for unit tests: dynamics.py:158-187 */
+void xo_maze_move(double* ori, double pos[2], double turn_rate, double walk_speed, const int8_t* walls, int n,
+                  int NG, double cell_size, double col_dist, double* collision);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,3 +62,22 @@ def close_rel(a, b, rel=1e-5, abs_=1e-5):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return bool(np.all(np.abs(a - b) <= rel * np.abs(b) + abs_))
+
+
+def load_maze_golden(path):
+    g = dict(np.load(path, allow_pickle=False))
+    task = dict(start=tuple(int(x) for x in g["start"]), cell_walls=g["cell_walls"], cell_texts=g["cell_texts"],
+                cell_size=float(g["cell_size"]), ground_text=int(g["ground_text"]), ceiling_text=int(g["ceiling_text"]),
+                step_reward=float(g["step_reward"]), goal_reward=float(g["goal_reward"]),
+                collision_reward=float(g["collision_reward"]), wall_height=float(g["wall_height"]),
+                agent_height=float(g["agent_height"]), fol_angle=float(g["fol_angle"]),
+                commands_sequence=g["commands_sequence"],
+                landmarks_coordinates=[tuple(int(v) for v in x) for x in g["landmarks_coordinates"]],
+                cell_landmarks=g["cell_landmarks"])
+    return g, task
+
+
+def frame_mismatch(a, b):
+    """fraction of channel values that differ, and the largest absolute difference"""
+    d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+    return float(np.mean(d > 0)), int(d.max())
