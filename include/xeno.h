@@ -267,6 +267,56 @@ int xv_cartpole_step_injected(xv_cartpole* h, const int32_t* action, const float
 int xv_cartpole_get_state(xv_cartpole* h, float* state /*[4][n_env]*/, int32_t* steps, uint8_t* need_reset);
 int xv_cartpole_set_state(xv_cartpole* h, const float* state, const int32_t* steps, const uint8_t* need_reset);
 
+/* ------------------------------------------------------------------------------------------------
+ * MazeWorld — reference: xenoverse/mazeworld/envs
+ *   MazeBase.set_task            maze_base.py:23-52                 -> xv_maze_create (+ host tables)
+ *   MazeBase.reset               maze_base.py:83-105                -> xv_maze_reset
+ *   MazeWorldEnvBase.step        maze_env.py:50-66, do_action maze_continuous_3d.py:49-62,
+ *     vector_move_with_collision dynamics.py:48-123,158-187, evaluation_rule maze_base.py:54-81,107-119
+ *                                                                   -> xv_maze_step (move + rules kernel)
+ *   update_observation           maze_continuous_3d.py:96-113, maze_view / DDA_2D / interpolate
+ *                                ray_caster_utils.py:47-320         -> ray-cast kernel (frames)
+ * Pose is fp64 as in the reference.  Frames are uint8[n_env][W][H][3] (the reference's (W,H,3) layout).
+ * ---------------------------------------------------------------------------------------------- */
+#define XV_MAZE_LMAX 15
+typedef struct xv_maze_tables {
+  const int8_t* walls;      /* [n_task][NG][NG] cell_walls, pitch NG (cells beyond a task's n are walls) */
+  const int32_t* texts;     /* [n_task][NG][NG] cell_texts (wall texture id) */
+  const int8_t* landmarks;  /* [n_task][NG][NG] cell_landmarks (-1: none) */
+  const int32_t* ints;      /* [n_task][8]: n, start_i, start_j, ground_text, ceiling_text, n_landmarks, 0, 0 */
+  const double* dbl;        /* [n_task][8]: cell_size, wall_height, agent_height, fol_angle, step_reward,
+                                            goal_reward, collision_reward, tan(fol_angle/2) (host fp64) */
+  const int32_t* commands;  /* [n_task][n_cmd] commands_sequence */
+  const int32_t* lm_coord;  /* [n_task][XV_MAZE_LMAX][2] landmarks_coordinates */
+  const float* tex_walls;   /* [n][256][256][3] float32 in [0,255], as MazeTaskManager loads them */
+  const float* tex_grounds;
+  const float* tex_ceilings;
+} xv_maze_tables;
+
+#define XV_MAZE_ACTION_CONTINUOUS 0 /* action = double[n_env][2] (turn_rate, walk_speed) */
+#define XV_MAZE_ACTION_DISCRETE16 1 /* action = int32[n_env], DEFAULT_ACTION_SPACE_16 (dynamics.py:16-27) */
+#define XV_MAZE_ACTION_DISCRETE32 2 /* action = int32[n_env], DEFAULT_ACTION_SPACE_32 (dynamics.py:29-46) */
+
+int xv_maze_create(xv_engine* e, int n_env, int n_task, int NG, int n_cmd, int max_steps, int W, int H,
+                   int command_in_observation, double collision_dist, double visibility_3D,
+                   const xv_maze_tables* tables, const int32_t* env_task, xv_maze** out);
+int xv_maze_destroy(xv_maze* h);
+/* frames (nullable) uint8[n_env][W][H][3]; command_rgb (nullable) float[n_env][3] = info["command"] */
+int xv_maze_reset(xv_maze* h, const uint8_t* mask, uint8_t* frames, float* command_rgb);
+/* one vector step: move + rules, then the frame of every env.  final_frames (nullable): the pre-reset frame of
+ * envs that ended this step (SAME_STEP); rendering it costs a second ray-cast launch. */
+int xv_maze_step(xv_maze* h, const void* action, int action_mode, uint8_t* frames, float* reward,
+                 uint8_t* terminated, uint8_t* truncated, float* command_rgb, uint8_t* final_frames,
+                 int autoreset_mode);
+/* state accessors (device pointers, each nullable): pos double[2][n_env], ori double[n_env],
+ * grid int32[2][n_env], steps/cmd_idx/cmd_age int32[n_env], need_reset uint8[n_env], collision double[n_env] */
+int xv_maze_get_state(xv_maze* h, double* pos, double* ori, int32_t* grid, int32_t* steps, int32_t* cmd_idx,
+                      int32_t* cmd_age, uint8_t* need_reset, double* collision);
+int xv_maze_set_state(xv_maze* h, const double* pos, const double* ori, const int32_t* steps,
+                      const int32_t* cmd_idx, const int32_t* cmd_age, const uint8_t* need_reset);
+/* render the current state only (no step) */
+int xv_maze_render(xv_maze* h, uint8_t* frames, float* command_rgb);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,158 @@
+"""GPU parity: HIP MazeWorld (move/collision + rules + ray-caster, through the C-ABI) vs the reference's golden
+trajectories and frames, and vs the CPU oracle on seeded batches.  Pose is fp64 (device sin/cos differ from
+libm in the last bits: 1e-9 abs); integer paths (grid cell, command index/age, flags) are exact; frames are
+within +-1 LSB on <= 0.5 % of the values."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from xenoverse_amd.mazeworld import MazeWorldVecEnv, build_tables, make_texture_library
+from util import frame_mismatch, golden_files, load_maze_golden
+
+pytestmark = pytest.mark.gpu
+FILES = golden_files("maze_")
+_TEX = None
+
+
+def tex():
+    global _TEX
+    if _TEX is None:
+        _TEX = make_texture_library(8, 4, 4, seed=0)
+    return _TEX
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("path", FILES)
+def test_golden_trajectory(path):
+    g, task = load_maze_golden(path)
+    res = int(g["res"])
+    env = MazeWorldVecEnv(1, resolution=(res, res), max_steps=int(g["max_steps"]), textures=tex(),
+                          autoreset_mode="disabled", action_space_type="Discrete16")
+    env.set_task(task)
+    f0, info0 = env.reset()
+    frac, worst = frame_mismatch(_np(f0)[0], g["frame0"])
+    assert frac <= 0.005 and worst <= 1
+    T = len(g["actions"])
+    fsteps = {int(s): k for k, s in enumerate(g["frame_steps"])}
+    bad_frames = []
+    for t in range(T):
+        if not np.isnan(g["inj_pose"][t, 0]):
+            env.set_state(pos=g["inj_pose"][t, :2].reshape(2, 1), ori=g["inj_pose"][t, 2:3])
+        if g["inj_age"][t] >= 0:
+            env.set_state(cmd_age=[int(g["inj_age"][t])])
+        frames, r, term, trunc, info = env.step([int(g["actions"][t])])
+        st = env.get_state()
+        assert np.max(np.abs(_np(st["pos"])[:, 0] - g["tr_pos"][t])) < 1e-9
+        assert abs(float(st["ori"][0]) - g["tr_ori"][t]) < 1e-9
+        assert np.array_equal(_np(st["grid"])[:, 0], g["tr_grid"][t])
+        assert int(st["cmd_idx"][0]) == g["tr_cmd_idx"][t] and int(st["cmd_age"][0]) == g["tr_cmd_age"][t]
+        assert int(info["steps"][0]) == g["tr_steps"][t]
+        assert bool(term[0]) == bool(g["tr_term"][t]) and bool(trunc[0]) == bool(g["tr_trunc"][t])
+        assert np.float32(r[0].item()) == np.float32(g["tr_reward"][t])
+        assert abs(float(st["collision"][0]) - g["tr_collision"][t]) < 1e-9
+        assert np.array_equal(_np(info["command"])[0], g["tr_cmd_rgb"][t])
+        if t in fsteps:
+            frac, worst = frame_mismatch(_np(frames)[0], g["frames"][fsteps[t]])
+            bad_frames.append((frac, worst))
+    assert max(w for _, w in bad_frames) <= 1 and np.mean([f for f, _ in bad_frames]) <= 0.005
+    # continuous actions after the script
+    envc = MazeWorldVecEnv(1, resolution=(res, res), textures=tex(), autoreset_mode="disabled",
+                           action_space_type="Continuous")
+    envc.set_task(task)
+    envc.reset()
+    envc.set_state(pos=g["tr_pos"][T - 1].reshape(2, 1), ori=g["tr_ori"][T - 1:T])
+    for a, ref in zip(g["cont_actions"], g["cont_pose"]):
+        envc.step(a.reshape(1, 2))
+        st = envc.get_state()
+        assert np.max(np.abs(np.r_[_np(st["pos"])[:, 0], float(st["ori"][0])] - ref)) < 1e-9
+    env.close(); envc.close()
+
+
+@pytest.mark.parametrize("path", FILES)
+@pytest.mark.parametrize("res", [64])
+def test_golden_frames_64(path, res):
+    g, task = load_maze_golden(path)
+    steps = g["frames64_steps"]
+    n = len(steps)
+    env = MazeWorldVecEnv(n, resolution=(res, res), textures=tex(), autoreset_mode="disabled")
+    env.set_task(task)
+    env.reset()
+    env.set_state(pos=g["tr_pos"][steps].T.copy(), ori=g["tr_ori"][steps].copy(), cmd_idx=g["tr_cmd_idx"][steps])
+    f = _np(env.render_frames())
+    frac, worst = frame_mismatch(f, g["frames64"])
+    assert frac <= 0.005 and worst <= 1, (frac, worst)
+    env.close()
+
+
+@pytest.mark.parametrize("res,stage", [((32, 32), True), ((48, 40), True), ((256, 256), False)])
+def test_batch_vs_oracle_frames_and_state(res, stage):
+    """3 mazes x 8 envs each, random discrete actions: state vs the oracle every step, frames on some steps
+    (256x256, the registered resolution, takes the build-in-global path of the ray-cast kernel)"""
+    tasks = [load_maze_golden(p)[1] for p in FILES]
+    tab = build_tables(tasks)
+    per = 8 if res[0] <= 64 else 2
+    env_task = np.repeat(np.arange(len(tasks), dtype=np.int32), per)
+    n = len(env_task)
+    env = MazeWorldVecEnv(n, resolution=res, textures=tex(), autoreset_mode="same_step", max_steps=25,
+                          action_space_type="Discrete32")
+    env.set_task(tasks, env_task_index=env_task)
+    ora = oracle.MazeOracle(tab, tex(), env_task, resolution=res, max_steps=25)
+    from xenoverse_amd.mazeworld import DEFAULT_ACTION_SPACE_32
+    table = np.array(DEFAULT_ACTION_SPACE_32, np.float64)
+    f0, _ = env.reset()
+    ora.reset()
+    fo, co = ora.render(n_threads=8)
+    frac, worst = frame_mismatch(_np(f0), fo)
+    assert frac <= 0.005 and worst <= 1
+    rng = np.random.RandomState(4)
+    n_steps = 30 if res[0] <= 64 else 3
+    for t in range(n_steps):
+        a = rng.randint(0, 32, n).astype(np.int32)
+        frames, r, term, trunc, info = env.step(a)
+        ro, teo, tro = ora.step(table[a], 2)
+        st = env.get_state()
+        assert np.max(np.abs(_np(st["pos"]) - ora.pos)) < 1e-9 and np.max(np.abs(_np(st["ori"]) - ora.ori)) < 1e-9
+        assert np.array_equal(_np(st["grid"]), ora.grid) and np.array_equal(_np(st["steps"]), ora.steps)
+        assert np.array_equal(_np(term).astype(np.uint8), teo) and np.array_equal(_np(trunc).astype(np.uint8), tro)
+        assert np.array_equal(_np(r), ro)
+        ora.pos[:] = _np(st["pos"]); ora.ori[:] = _np(st["ori"])      # no compounding of last-bit differences
+        if t % 5 == 0 or tro.any():
+            fo, co = ora.render(n_threads=8)
+            frac, worst = frame_mismatch(_np(frames), fo)
+            assert frac <= 0.005 and worst <= 1, (t, frac, worst)
+            assert np.array_equal(_np(info["command"]), co)
+    if res[0] <= 64:
+        assert env.get_state()["steps"].max() < 25      # truncation + SAME_STEP reset happened
+    env.close()
+
+
+def test_command_bar_and_final_obs():
+    g, task = load_maze_golden(FILES[0])
+    env = MazeWorldVecEnv(4, resolution=(32, 32), textures=tex(), autoreset_mode="same_step", max_steps=3,
+                          command_in_observation=True, with_final_obs=True)
+    env.set_task(task)
+    f0, _ = env.reset()
+    ora = oracle.MazeOracle(build_tables([task]), tex(), np.zeros(4, np.int32), resolution=(32, 32), max_steps=3,
+                            command_in_observation=True)
+    ora.reset()
+    assert frame_mismatch(_np(f0), ora.render()[0])[1] <= 1
+    for t in range(3):
+        frames, r, term, trunc, info = env.step(np.full(4, 11, np.int32))
+    assert bool(trunc.all())
+    # the returned frame is the reset frame; final_obs is the frame at the truncated pose
+    assert frame_mismatch(_np(frames), _np(f0))[0] == 0.0
+    assert frame_mismatch(_np(info["final_obs"]), _np(f0))[0] > 0.01
+    env.close()
+
+
+def test_misuse():
+    env = MazeWorldVecEnv(2, resolution=(32, 32), textures=tex())
+    with pytest.raises(Exception, match="Must call \"set_task\" before reset"):
+        env.reset()
+    with pytest.raises(ValueError, match="Invalid Action Space Type"):
+        MazeWorldVecEnv(2, action_space_type="Discrete8")
+    env.close()

@@ -54,6 +54,14 @@ SIGNATURES = {
     "xv_cartpole_step_injected": [c_void_p] + [c_void_p] * 7 + [c_int],
     "xv_cartpole_get_state": [c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_cartpole_set_state": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "xv_maze_create": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, C.c_double, C.c_double,
+                       c_void_p, c_void_p, C.POINTER(c_void_p)],
+    "xv_maze_destroy": [c_void_p],
+    "xv_maze_reset": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "xv_maze_step": [c_void_p, c_void_p, c_int] + [c_void_p] * 6 + [c_int],
+    "xv_maze_get_state": [c_void_p] + [c_void_p] * 8,
+    "xv_maze_set_state": [c_void_p] + [c_void_p] * 6,
+    "xv_maze_render": [c_void_p, c_void_p, c_void_p],
 }
 _RESTYPE = {"xv_last_error": C.c_char_p, "xv_engine_stream": c_void_p}
 

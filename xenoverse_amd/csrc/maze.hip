@@ -1,0 +1,703 @@
+// maze.hip — MazeWorld batched move/collision + rules kernel and first-person ray-cast kernel for gfx950.
+//
+// Reproduces xenoverse/mazeworld/envs: dynamics.py:48-123,158-187 (unicycle arc + soft wall push-out in 100
+// sub-steps of 0.01), maze_continuous_3d.py:49-62 (do_action), maze_base.py:54-119,212-223 (command / reward
+// rules), ray_caster_utils.py:47-320 (DDA_2D, interpolate, maze_view).  Same operations in the same types and
+// order as oracle/xeno_oracle.c (mz_*), which reproduces the reference's frames bit for bit.
+//
+//   move kernel : one lane per env, pose in fp64 registers.  The agent moves < 1 unit per step and cells are
+//                 >= 1.5 units, so every 3x3 wall neighbourhood of the 100 sub-steps lies in the 5x5 cells
+//                 around the starting cell: they are fetched ONCE into a 25-bit register mask; the sub-step
+//                 loop touches no memory.
+//   ray-cast    : one workgroup per env frame, one lane per screen column d_h (the reference's per-column
+//                 tables become per-lane registers), loop over rows d_v.  The frame is staged in LDS as bytes
+//                 and leaves with coalesced 16-byte stores; the wall stage overwrites floor/ceiling and the
+//                 landmark overlays read-modify-write there, as the reference does on its int32 array.
+#include "philox.h"
+#include "xv_common.h"
+
+#include <cstring>
+
+#define MZ_PI 3.1415926     // dynamics.py:7-8, the reference's own truncated constants
+#define MZ_TPI 6.2831852
+
+struct MazeArgs {
+  xv_maze_tables T;
+  const int32_t* env_task;
+  double* pos;       // [2][n_env]
+  double* ori;
+  int32_t* grid;     // [2][n_env]
+  int32_t* steps;
+  int32_t* cmd_idx;
+  int32_t* cmd_age;
+  uint8_t* need_reset;
+  double* collision;
+  // pose of envs that ended this step, kept for the optional final frame
+  double* fin_pose;  // [3][n_env]
+  int32_t* fin_cmd;  // [n_env]
+  uint8_t* fin_flag; // [n_env]
+  uint32_t* err;
+  int n_env, n_task, NG, n_cmd, max_steps, W, H, command_in_observation;
+  double collision_dist, visibility;
+};
+
+struct xv_maze {
+  xv_engine* eng;
+  MazeArgs a;
+};
+
+static const size_t MAZE_LDS_STAGE_MAX = 150 * 1024;   // LDS is 160 KiB per CU
+
+__device__ const double MZ_ACT16[16][2] = {{0.0, 0.5}, {0.05, 0.0}, {-0.05, 0.0}, {0.1, 0.0}, {-0.1, 0.0}, {0.2, 0.0},
+                                           {-0.2, 0.0}, {0.3, 0.0}, {-0.3, 0.0}, {0.5, 0.0}, {-0.5, 0.0}, {0.0, 1.0},
+                                           {0.05, 1.0}, {-0.05, 1.0}, {0.10, 1.0}, {-0.10, 1.0}};
+__device__ const double MZ_ACT32[32][2] = {
+    {0.0, 0.2}, {0.02, 0.0}, {-0.02, 0.0}, {0.05, 0.0}, {-0.05, 0.0}, {0.1, 0.0}, {-0.1, 0.0}, {0.2, 0.0},
+    {-0.2, 0.0}, {0.3, 0.0}, {-0.3, 0.0}, {0.4, 0.0}, {-0.4, 0.0}, {0.5, 0.0}, {-0.5, 0.0}, {0.0, 0.5},
+    {0.0, 1.0}, {0.02, 0.5}, {0.02, 1.0}, {-0.02, 0.5}, {-0.02, 1.0}, {0.05, 0.5}, {0.05, 1.0}, {-0.05, 0.5},
+    {-0.05, 1.0}, {0.10, 0.5}, {0.10, 1.0}, {-0.10, 0.5}, {-0.10, 1.0}, {0.0, -0.2}, {0.1, -0.2}, {-0.1, -0.2}};
+// ray_caster_utils.py:11-25
+__device__ const float MZ_LANDMARK_RGB[XV_MAZE_LMAX][3] = {
+    {0, 255, 0}, {255, 0, 0}, {0, 0, 255}, {0, 255, 255}, {255, 0, 255}, {255, 255, 0}, {128, 128, 255},
+    {128, 255, 128}, {255, 128, 128}, {0, 96, 128}, {96, 0, 128}, {0, 128, 96}, {96, 128, 0}, {128, 96, 0},
+    {128, 0, 96}};
+
+__device__ __forceinline__ double mz_angle_norm(double t) {   // dynamics.py:48-54
+  while (t > MZ_PI) t -= MZ_TPI;
+  while (t < -MZ_PI) t += MZ_TPI;
+  return t;
+}
+
+// dynamics.py:56-69
+__device__ __forceinline__ double mz_nearest_point(double p0, double p1, double l10, double l11, double l20,
+                                                   double l21, double& n0, double& n1) {
+  double u0 = l20 - l10, u1 = l21 - l11;
+  const double edge = sqrt(u0 * u0 + u1 * u1);
+  const double m = edge > 1.0e-6 ? edge : 1.0e-6;
+  u0 /= m; u1 /= m;
+  const double d1 = (p0 - l10) * u0 + (p1 - l11) * u1;
+  if (d1 > edge) { n0 = l20; n1 = l21; }
+  else if (d1 < 0) { n0 = l10; n1 = l11; }
+  else { n0 = l10 + d1 * u0; n1 = l11 + d1 * u1; }
+  const double a = p0 - n0, b = p1 - n1;
+  return sqrt(a * a + b * b);
+}
+
+// dynamics.py:71-96
+__device__ __forceinline__ void mz_collision_force(double v0, double v1, double cell_size, double col_dist,
+                                                   double& f0, double& f1) {
+  const double dist = sqrt(v0 * v0 + v1 * v1);
+  const double eff = col_dist / cell_size;
+  f0 = 0.0; f1 = 0.0;
+  if (dist > 0.708 + eff) return;
+  if (fabs(v0) < 0.5 && fabs(v1) < 0.5) {
+    const double s = 0.50 / (dist > 1.0e-6 ? dist : 1.0e-6) * (0.708 + eff - dist) * cell_size;
+    f0 = s * v0; f1 = s * v1;
+    return;
+  }
+  const bool x_pos = v0 + v1 > 0, y_pos = v1 - v0 > 0;
+  double n0, n1, d;
+  if (x_pos && y_pos) d = mz_nearest_point(v0, v1, 0.5, 0.5, -0.5, 0.5, n0, n1);
+  else if (!x_pos && y_pos) d = mz_nearest_point(v0, v1, -0.5, 0.5, -0.5, -0.5, n0, n1);
+  else if (!x_pos && !y_pos) d = mz_nearest_point(v0, v1, -0.5, -0.5, 0.5, -0.5, n0, n1);
+  else d = mz_nearest_point(v0, v1, 0.5, -0.5, 0.5, 0.5, n0, n1);
+  if (eff < d) return;
+  double o0 = v0 - n0, o1 = v1 - n1;
+  const double on = sqrt(o0 * o0 + o1 * o1);
+  const double inv = 1.0 / (on > 1.0e-6 ? on : 1.0e-6);
+  o0 *= inv; o1 *= inv;
+  const double s = 0.50 * (eff - d) * cell_size;
+  f0 = s * o0; f1 = s * o1;
+}
+
+__device__ __forceinline__ void mz_reset_env(const MazeArgs& P, int e, int t) {   // maze_base.py:83-105
+  const int32_t* in = P.T.ints + (size_t)t * 8;
+  const double cs = P.T.dbl[(size_t)t * 8];
+  const size_t N = (size_t)P.n_env;
+  P.grid[e] = in[1]; P.grid[N + e] = in[2];
+  P.pos[e] = in[1] * cs + 0.5 * cs;        // get_cell_center :215-218
+  P.pos[N + e] = in[2] * cs + 0.5 * cs;
+  P.ori[e] = 0.0;
+  P.cmd_idx[e] = 0; P.cmd_age[e] = 0; P.steps[e] = 0; P.need_reset[e] = 0; P.collision[e] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void maze_reset_kernel(MazeArgs P, const uint8_t* mask) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= P.n_env) return;
+  if (mask && !mask[e]) return;
+  mz_reset_env(P, e, P.env_task[e]);
+}
+
+__global__ __launch_bounds__(256) void maze_step_kernel(MazeArgs P, const void* action, int action_mode,
+                                                        float* reward, uint8_t* terminated, uint8_t* truncated,
+                                                        int mode) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= P.n_env) return;
+  const size_t N = (size_t)P.n_env;
+  const int t = P.env_task[e];
+  const int32_t* in = P.T.ints + (size_t)t * 8;
+  const double* db = P.T.dbl + (size_t)t * 8;
+  P.fin_flag[e] = 0;
+  if (mode == XV_AUTORESET_NEXT_STEP && P.need_reset[e]) {
+    mz_reset_env(P, e, t);
+    reward[e] = 0.0f; terminated[e] = 0; truncated[e] = 0;
+    return;
+  }
+  // ---- action -> (turn_rate, walk_speed): maze_env.py:151-162, maze_continuous_3d.py:49-52 ----
+  double tr, ws;
+  uint32_t err = 0;
+  if (action_mode == XV_MAZE_ACTION_CONTINUOUS) {
+    const double* a = (const double*)action;
+    tr = a[2 * (size_t)e]; ws = a[2 * (size_t)e + 1];
+  } else {
+    int a = ((const int32_t*)action)[e];
+    const int na = action_mode == XV_MAZE_ACTION_DISCRETE16 ? 16 : 32;
+    if (a < 0 || a >= na) { err |= XV_DEVERR_ACTION_RANGE; a = a < 0 ? 0 : na - 1; }
+    if (action_mode == XV_MAZE_ACTION_DISCRETE16) { tr = MZ_ACT16[a][0]; ws = MZ_ACT16[a][1]; }
+    else { tr = MZ_ACT32[a][0]; ws = MZ_ACT32[a][1]; }
+  }
+  const double turn_rate = (tr < -1.0 ? -1.0 : (tr > 1.0 ? 1.0 : tr)) * MZ_PI;
+  const double walk_speed = ws < -1.0 ? -1.0 : (ws > 1.0 ? 1.0 : ws);
+
+  // ---- vector_move_with_collision: dynamics.py:158-187 ----
+  const int n = in[0], NG = P.NG;
+  const double cell_size = db[0], col_dist = P.collision_dist;
+  double p0 = P.pos[e], p1 = P.pos[N + e], ori = P.ori[e], coll = 0.0;
+  // walls of the 5x5 cells around the starting cell, one bit each (out-of-range cells: no wall, as :180)
+  const int ci = (int)(p0 / cell_size), cj = (int)(p1 / cell_size);
+  const int8_t* walls = P.T.walls + (size_t)t * NG * NG;
+  uint32_t patch = 0;
+#pragma unroll
+  for (int a = 0; a < 5; ++a)
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+      const int wi = ci + a - 2, wj = cj + b - 2;
+      if (wi > -1 && wi < n && wj > -1 && wj < n && walls[wi * NG + wj] > 0) patch |= 1u << (a * 5 + b);
+    }
+  const double t_prec = 0.01, delta_t = 1.0;
+  const int iteration = (int)(delta_t / t_prec);
+  bool left_patch = false;
+  for (int it = 0; it < iteration + 1; ++it) {
+    const double rem = delta_t - it * t_prec;
+    const double dt = rem < t_prec ? rem : t_prec;
+    if (dt < 1.0e-8) continue;
+    // vector_move_no_collision: dynamics.py:98-123
+    const double d_theta = turn_rate * dt, arc = walk_speed * dt;
+    const double c_t = cos(ori), s_t = sin(ori), c_dt = cos(0.5 * d_theta), s_dt = sin(0.5 * d_theta);
+    const double n_ori = mz_angle_norm(ori + d_theta);
+    double dx, dy;
+    if (fabs(d_theta) < 1.0e-8) { dx = c_t * arc; dy = s_t * arc; }
+    else {
+      const double rad = walk_speed / turn_rate, off = 2.0 * s_dt * rad;
+      const double c_n = c_t * c_dt - s_t * s_dt, s_n = c_t * s_dt + s_t * c_dt;
+      dx = c_n * off; dy = s_n * off;
+    }
+    ori = n_ori;
+    const double e0 = p0 + dx, e1 = p1 + dy;
+    const double c0 = e0 / cell_size, c1 = e1 / cell_size;
+    const int b0 = (int)c0, b1 = (int)c1;
+    double f0 = 0.0, f1 = 0.0;
+    for (int i = -1; i < 2; ++i)
+      for (int j = -1; j < 2; ++j) {
+        const int a = b0 + i - ci + 2, b = b1 + j - cj + 2;
+        bool wall;
+        if (a >= 0 && a < 5 && b >= 0 && b < 5) wall = (patch >> (a * 5 + b)) & 1u;
+        else {   // cannot happen for cell_size >= 1 (|move| <= 1); kept exact by falling back to memory
+          left_patch = true;
+          const int wi = b0 + i, wj = b1 + j;
+          wall = wi > -1 && wi < n && wj > -1 && wj < n && walls[wi * NG + wj] > 0;
+        }
+        if (wall) {
+          double g0, g1;
+          mz_collision_force(c0 - floor(c0) - (double)(float)(i + 0.5), c1 - floor(c1) - (double)(float)(j + 0.5),
+                             cell_size, col_dist, g0, g1);
+          f0 += g0; f1 += g1;
+        }
+      }
+    p0 = f0 + e0; p1 = f1 + e1;
+    coll += sqrt(f0 * f0 + f1 * f1);
+  }
+  (void)left_patch;
+  if (!(fabs(p0) <= 1.0e300) || !(fabs(p1) <= 1.0e300)) err |= XV_DEVERR_NONFINITE;
+  const int g0 = (int)(p0 / cell_size), g1 = (int)(p1 / cell_size);   // get_loc_grid: maze_base.py:220-223
+
+  // ---- evaluation_rule: maze_base.py:107-119 ----
+  const int steps = P.steps[e] + 1;
+  int age = P.cmd_age[e] + 1, idx = P.cmd_idx[e];
+  const int cmd = P.T.commands[(size_t)t * P.n_cmd + (idx < P.n_cmd ? idx : P.n_cmd - 1)];
+  const int32_t* lc = P.T.lm_coord + ((size_t)t * XV_MAZE_LMAX + cmd) * 2;
+  const bool at_goal = (idx < P.n_cmd) && lc[0] == g0 && lc[1] == g1;
+  // instant_rewards is a float32 array holding goal_reward at the active command's cell (:61-69, :96)
+  const float r = (at_goal ? (float)db[5] : 0.0f) + (float)db[4];
+  int term = 0;
+  if (at_goal || age >= 500) {   // reach_goal() or step_limits() -> refresh_command (:54-70)
+    idx += 1; age = 0;
+    if (idx > P.n_cmd - 1) term = 1;
+  }
+  const int trunc = (steps > P.max_steps - 1) ? 1 : 0;   // :212-213
+
+  P.pos[e] = p0; P.pos[N + e] = p1; P.ori[e] = ori; P.collision[e] = coll;
+  P.grid[e] = g0; P.grid[N + e] = g1;
+  P.steps[e] = steps; P.cmd_age[e] = age; P.cmd_idx[e] = idx;
+  reward[e] = r; terminated[e] = (uint8_t)term; truncated[e] = (uint8_t)trunc;
+  if (term || trunc) {
+    if (mode == XV_AUTORESET_SAME_STEP) {
+      P.fin_pose[e] = p0; P.fin_pose[N + e] = p1; P.fin_pose[2 * N + e] = ori;
+      P.fin_cmd[e] = idx; P.fin_flag[e] = 1;
+      mz_reset_env(P, e, t);
+    } else if (mode == XV_AUTORESET_NEXT_STEP) {
+      P.need_reset[e] = 1;
+    }
+  }
+  if (err) atomicOr(P.err, err);
+}
+
+// interpolate, ray_caster_utils.py:123-140 (see oracle mz_interpolate for the typing)
+__device__ __forceinline__ void mz_interpolate(const float* __restrict__ tex, double i, double j, double d,
+                                               double px, double py, double (&out)[3]) {
+  double d2 = d * d;
+  if (d2 < 1.0e-8) d2 = 1.0e-8;
+  const int ib = (int)i, jb = (int)j;
+  double sum_wht = 0.0;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+  for (int xx = -1; xx < 3; ++xx) {
+    const int x = ib + xx;
+    const double a = ((double)x - i) * px;
+    const int xv = x & 255;   // python's non-negative x % 256
+#pragma unroll
+    for (int yy = -1; yy < 3; ++yy) {
+      const int y = jb + yy;
+      const double b = ((double)y - j) * py;
+      const double dist = a * a + b * b;
+      double wht = 1.0 - 10 * dist / d2;
+      wht = wht > 1.0 ? 1.0 : wht;
+      wht = wht < 0.01 ? 0.01 : wht;
+      sum_wht += wht;
+      const float* tp = tex + ((size_t)xv * 256 + (y & 255)) * 3;
+      s0 = (float)((double)s0 + wht * (double)tp[0]);
+      s1 = (float)((double)s1 + wht * (double)tp[1]);
+      s2 = (float)((double)s2 + wht * (double)tp[2]);
+    }
+  }
+  out[0] = (double)s0 / sum_wht; out[1] = (double)s1 / sum_wht; out[2] = (double)s2 / sum_wht;
+}
+
+__device__ __forceinline__ uint8_t mz_clip_u8(double v) {   // numpy.clip(v, 0, 255) -> int32 -> uint8
+  v = v < 0.0 ? 0.0 : v;
+  v = v > 255.0 ? 255.0 : v;
+  return (uint8_t)(int)v;
+}
+
+// One workgroup per frame, one lane per column.  FINAL: render the stored pre-reset pose of flagged envs.
+// STAGE: the frame is built in LDS and leaves with 16-byte stores (frames up to ~150 KB, e.g. 224x224);
+// larger frames (the registered 256x256 = 192 KB) are built in place in global memory, each lane owning the
+// contiguous H*3 bytes of its column.
+template <bool FINAL, bool STAGE>
+__global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* frames, float* command_rgb) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];   // STAGE: [W][H][3] bytes
+  __shared__ float s_cos_last_v;
+  const int e = blockIdx.x;
+  if (FINAL && !P.fin_flag[e]) return;   // block-uniform
+  const int W = P.W, H = P.H, NG = P.NG;
+  const size_t N = (size_t)P.n_env;
+  const int t = P.env_task[e];
+  const int32_t* in = P.T.ints + (size_t)t * 8;
+  const double* db = P.T.dbl + (size_t)t * 8;
+  const int n = in[0];
+  const double cell_size = db[0], ceil_height = db[1], vision_height = db[2];
+  const double visibility = P.visibility, l_focal = 0.20, text_size = 1.0;
+  const int8_t* walls = P.T.walls + (size_t)t * NG * NG;
+  const int8_t* transp = P.T.landmarks + (size_t)t * NG * NG;
+  const int32_t* texts = P.T.texts + (size_t)t * NG * NG;
+  const float* ground = P.T.tex_grounds + (size_t)in[3] * 256 * 256 * 3;
+  const float* ceil_t = P.T.tex_ceilings + (size_t)in[4] * 256 * 256 * 3;
+  const double pe0 = FINAL ? P.fin_pose[e] : P.pos[e];
+  const double pe1 = FINAL ? P.fin_pose[N + e] : P.pos[N + e];
+  const double ori = FINAL ? P.fin_pose[2 * N + e] : P.ori[e];
+  const int cmd_idx_e = FINAL ? P.fin_cmd[e] : P.cmd_idx[e];
+  const float pos0 = (float)pe0, pos1 = (float)pe1;   // maze_continuous_3d.py:97: pose cast to float32
+
+  const double half_h = db[7] * l_focal;               // numpy.tan(vision_angle_h / 2) * l_focal (host fp64)
+  const double half_v = half_h * H / W;
+  const double pixel_size = 2.0 * half_h / W;
+  const double s_ori = sin(ori), c_ori = cos(ori);
+  const double pixel_factor = pixel_size / l_focal;
+  const double percell = cell_size / text_size;
+  const double tps = text_size / 256;
+  float* s_cos_last = &s_cos_last_v;
+  const size_t fsz = (size_t)W * H * 3;
+  uint8_t* dst = frames + (size_t)e * fsz;
+  uint8_t* lds = STAGE ? lds_dyn : dst;   // where the frame is built
+
+  for (int d_h = threadIdx.x; d_h < W; d_h += blockDim.x) {
+    // ---- per-column tables :170-177 (the reference accumulates tan_hp column by column) ----
+    double tan_hp = (-0.5 - W / 2.0) * pixel_factor;
+    for (int q = 0; q <= d_h; ++q) tan_hp += pixel_factor;
+    const double cos_hp = sqrt(1.0 / (1.0 + tan_hp * tan_hp));
+    const double sin_hp = tan_hp * cos_hp;
+    const float sin_abs = (float)(sin_hp * c_ori + cos_hp * s_ori);
+    const float cos_abs = (float)(cos_hp * c_ori - sin_hp * s_ori);
+    const float cos_hp_f = (float)cos_hp;
+    if (d_h == W - 1) *s_cos_last = cos_hp_f;
+    uint8_t* col = lds + (size_t)d_h * H * 3;
+    for (int k = 0; k < H * 3; ++k) col[k] = 1;   // FAR_RGB :165-166
+
+    // ---- floor :180-211 ----
+    for (int d_v = H - 1; d_v > H / 2; --d_v) {
+      const double v_screen = (d_v + 0.5) * pixel_size - half_v;
+      const double distance = vision_height / v_screen * l_focal;
+      double light = v_screen / l_focal;
+      light = light > 1.0 ? 1.0 : light;
+      if (distance > visibility) continue;
+      const double eff = distance / (double)cos_hp_f;
+      double alpha = 2.0 * eff / visibility - 1.0;
+      alpha = alpha < 0.0 ? 0.0 : alpha;
+      alpha = alpha > 1.0 ? 1.0 : alpha;
+      alpha *= light;
+      const double hit_x = eff * (double)cos_abs + (double)pos0, hit_y = eff * (double)sin_abs + (double)pos1;
+      const double fi = hit_x / cell_size, fj = hit_y / cell_size;
+      double d_i = fi - floor(fi), d_j = fj - floor(fj);
+      const int i = (int)fi, j = (int)fj;
+      const double eff_ps = eff * pixel_size / l_focal;
+      if (i < n && i >= 0 && j < n && j >= 0) {
+        d_i *= percell; d_j *= percell;
+        d_i -= floor(d_i); d_j -= floor(d_j);
+        d_i *= 256; d_j *= 256;
+        double c[3];
+        mz_interpolate(ground, d_i, d_j, eff_ps, tps, tps, c);
+        uint8_t* px = col + d_v * 3;
+        px[0] = mz_clip_u8(light * (alpha * 1.0 + (1.0 - alpha) * c[0]));
+        px[1] = mz_clip_u8(light * (alpha * 1.0 + (1.0 - alpha) * c[1]));
+        px[2] = mz_clip_u8(light * (alpha * 1.0 + (1.0 - alpha) * c[2]));
+      }
+    }
+    // ---- ceiling :214-244 ----
+    for (int d_v = 0; d_v < H / 2; ++d_v) {
+      const double v_screen = half_v - (d_v + 0.5) * pixel_size;
+      const double distance = (ceil_height - vision_height) / v_screen * l_focal;
+      double light = v_screen / l_focal;
+      light = light > 1.0 ? 1.0 : light;
+      if (distance > visibility) continue;
+      const double eff = distance / (double)cos_hp_f;
+      double alpha = 2.0 * eff / visibility - 1.0;
+      alpha = alpha < 0.0 ? 0.0 : alpha;
+      alpha = alpha > 1.0 ? 1.0 : alpha;
+      const double hit_x = eff * (double)cos_abs + (double)pos0, hit_y = eff * (double)sin_abs + (double)pos1;
+      const double fi = hit_x / cell_size, fj = hit_y / cell_size;
+      double d_i = fi - floor(fi), d_j = fj - floor(fj);
+      const int i = (int)fi, j = (int)fj;
+      const double eff_ps = eff * pixel_size / l_focal;
+      if (i < n && i >= 0 && j < n && j >= 0) {
+        d_i *= percell; d_j *= percell;
+        d_i -= floor(d_i); d_j -= floor(d_j);
+        d_i *= 256; d_j *= 256;
+        double c[3];
+        mz_interpolate(ceil_t, d_i, d_j, eff_ps, tps, tps, c);
+        uint8_t* px = col + d_v * 3;
+        px[0] = mz_clip_u8(light * (alpha * 1.0 + (1.0 - alpha) * c[0]));
+        px[1] = mz_clip_u8(light * (alpha * 1.0 + (1.0 - alpha) * c[1]));
+        px[2] = mz_clip_u8(light * (alpha * 1.0 + (1.0 - alpha) * c[2]));
+      }
+    }
+  }
+  __syncthreads();
+  // quirk (i), SURVEY.md M5: the wall stage filters with the eff_distance left over by the LAST floor/ceiling
+  // pixel the reference painted: last ceiling row within visibility (else last floor row), column W-1
+  double eff_stale = 0.0;
+  {
+    const float cos_last = *s_cos_last;
+    bool found = false;
+    for (int d_v = H / 2 - 1; d_v >= 0 && !found; --d_v) {
+      const double v_screen = half_v - (d_v + 0.5) * pixel_size;
+      const double distance = (ceil_height - vision_height) / v_screen * l_focal;
+      if (!(distance > visibility)) { eff_stale = distance / (double)cos_last; found = true; }
+    }
+    for (int d_v = H / 2 + 1; d_v <= H - 1 && !found; ++d_v) {
+      const double v_screen = (d_v + 0.5) * pixel_size - half_v;
+      const double distance = vision_height / v_screen * l_focal;
+      if (!(distance > visibility)) { eff_stale = distance / (double)cos_last; found = true; }
+    }
+  }
+  const float cs_f = (float)cell_size, eps_f = (float)1.0e-8, vis_f = (float)visibility, lf_f = (float)l_focal;
+  for (int d_h = threadIdx.x; d_h < W; d_h += blockDim.x) {
+    double tan_hp = (-0.5 - W / 2.0) * pixel_factor;
+    for (int q = 0; q <= d_h; ++q) tan_hp += pixel_factor;
+    const double cos_hp = sqrt(1.0 / (1.0 + tan_hp * tan_hp));
+    const double sin_hp = tan_hp * cos_hp;
+    const float so = (float)(sin_hp * c_ori + cos_hp * s_ori);
+    const float co = (float)(cos_hp * c_ori - sin_hp * s_ori);
+    const float cos_hp_f = (float)cos_hp;
+    uint8_t* col = lds + (size_t)d_h * H * 3;
+    // ---- DDA_2D :47-115, float32 ----
+    const int i0 = (int)(pos0 / cs_f), j0 = (int)(pos1 / cs_f);
+    const float c_sign = co < 0 ? -1.0f : 1.0f, s_sign = so < 0 ? -1.0f : 1.0f;
+    const float ddx = fabsf(co) < eps_f ? fabsf(cs_f / eps_f) : fabsf(cs_f / co);
+    const float ddy = fabsf(so) < eps_f ? fabsf(cs_f / eps_f) : fabsf(cs_f / so);
+    const float d_x = co > 0 ? ((float)((i0 + 1) * cell_size) - pos0) : ((float)(i0 * cell_size) - pos0);
+    const float d_y = so > 0 ? ((float)((j0 + 1) * cell_size) - pos1) : ((float)(j0 * cell_size) - pos1);
+    float sdx = fabsf(co) < eps_f ? c_sign * (d_x / eps_f) : d_x / co;
+    float sdy = fabsf(so) < eps_f ? s_sign * (d_y / eps_f) : d_y / so;
+    const int di = co > 0 ? 1 : -1, dj = so > 0 ? 1 : -1;
+    int hi = i0, hj = j0, hit_side = 0, n_tr = 0;
+    float hit_dist = 0.0f;
+    // landmark cells crossed by this ray: at most one per DDA step within visibility; 16 slots cover any maze
+    float tr_dist[16];
+    int tr_id[16];
+    while (hit_dist < vis_f) {
+      int crossed;
+      if (sdx < sdy) {
+        hi += di; sdy -= sdx; hit_dist += sdx;
+        crossed = (hi >= 0 && hi < NG && hj >= 0 && hj < NG) ? transp[hi * NG + hj] : -1;
+        if (crossed > -1 && n_tr < 16) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) if (q == n_tr) { tr_dist[q] = hit_dist; tr_id[q] = crossed; }
+          ++n_tr;
+        }
+        if (hi < 0 || hi >= n) { if (hj < 0 || hj >= n) { hit_dist = 1.0e+6f; break; } }
+        else if (hj >= 0 && hj < NG && walls[hi * NG + hj] > 0) { hit_side = 0; break; }
+        sdx = ddx;
+      } else {
+        hj += dj; sdx -= sdy; hit_dist += sdy;
+        crossed = (hi >= 0 && hi < NG && hj >= 0 && hj < NG) ? transp[hi * NG + hj] : -1;
+        if (crossed > -1 && n_tr < 16) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) if (q == n_tr) { tr_dist[q] = hit_dist; tr_id[q] = crossed; }
+          ++n_tr;
+        }
+        if (hi < 0 || hi >= n) { if (hj < 0 || hj >= n) { hit_dist = 1.0e+6f; break; } }
+        else if (hj >= 0 && hj < NG && walls[hi * NG + hj] > 0) { hit_side = 1; break; }
+        sdy = ddy;
+      }
+    }
+    // ---- wall column :258-298 ----
+    float alpha = 2.0f * hit_dist / vis_f - 1.0f;
+    alpha = alpha < 0.0f ? 0.0f : alpha;
+    alpha = alpha > 1.0f ? 1.0f : alpha;
+    const bool in_grid = hi >= 0 && hi < NG && hj >= 0 && hj < NG;
+    const int text_id = in_grid ? texts[hi * NG + hj] : 0;
+    const float hit_pt_x = hit_dist * co + pos0, hit_pt_y = hit_dist * so + pos1;
+    float local_h, light;
+    if (hit_side == 0) { local_h = hit_pt_y / cs_f; local_h -= floorf(local_h); light = fabsf(co); }
+    else { local_h = hit_pt_x / cs_f; local_h -= floorf(local_h); light = fabsf(so); }
+    float ratio = hit_dist * cos_hp_f / lf_f;
+    if (fabsf(ratio) < eps_f) ratio = ratio > 0 ? eps_f : -eps_f;
+    const float top_v = (float)(ceil_height - vision_height) / ratio, bot_v = (float)vision_height / ratio;
+    int v_s = (int)((half_v - (double)top_v) / pixel_size), v_e = (int)((half_v + (double)bot_v) / pixel_size);
+    v_s = v_s < 0 ? 0 : v_s;
+    v_e = v_e > H ? H : v_e;
+    const float* wt = P.T.tex_walls + (size_t)text_id * 256 * 256 * 3;
+    const double eff_ps_w = eff_stale * pixel_size / l_focal;
+    const float a_far = alpha * 1.0f, a_near = 1.0f - alpha;
+    for (int d_v = v_s; d_v < v_e; ++d_v) {
+      const double local_v = (half_v - (d_v + 0.5) * pixel_size) * (double)ratio + vision_height;
+      float d_i = local_h * (float)percell;
+      double d_j = local_v / text_size;
+      d_i -= floorf(d_i); d_j -= floor(d_j);
+      const int ti = (int)(256.0f * d_i), tj = (int)(256 * d_j);
+      double c[3];
+      mz_interpolate(wt, (double)ti, (double)tj, eff_ps_w, tps, tps, c);
+      uint8_t* px = col + d_v * 3;
+      px[0] = mz_clip_u8((double)light * ((double)a_far + (double)a_near * c[0]));
+      px[1] = mz_clip_u8((double)light * ((double)a_far + (double)a_near * c[1]));
+      px[2] = mz_clip_u8((double)light * ((double)a_far + (double)a_near * c[2]));
+    }
+    // ---- transparent landmark overlays, far to near :301-318 ----
+    for (int q = n_tr - 1; q >= 0; --q) {
+      float hd = 0.0f;
+      int lid = 0;
+#pragma unroll
+      for (int z = 0; z < 16; ++z) if (z == q) { hd = tr_dist[z]; lid = tr_id[z]; }
+      float r2 = hd * cos_hp_f / lf_f;
+      if (fabsf(r2) < eps_f) r2 = r2 > 0 ? eps_f : -eps_f;
+      const float tv = (float)(ceil_height - vision_height) / r2, bv = (float)vision_height / r2;
+      int s2 = (int)((half_v - (double)tv) / pixel_size), e2 = (int)((half_v + (double)bv) / pixel_size);
+      s2 = s2 < 0 ? 0 : s2;
+      e2 = e2 > H ? H : e2;
+      float a2 = 2.0f * hd / vis_f - 1.0f;
+      a2 = a2 < 0.0f ? 0.0f : a2;
+      a2 = a2 > 1.0f ? 1.0f : a2;
+      float tint[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) tint[c] = 0.30f * ((1.0f - a2) * MZ_LANDMARK_RGB[lid][c] + a2 * 1.0f);
+      for (int d_v = s2; d_v < e2; ++d_v) {
+        uint8_t* px = col + d_v * 3;
+        px[0] = mz_clip_u8((1.0 - 0.30) * (double)px[0] + (double)tint[0]);
+        px[1] = mz_clip_u8((1.0 - 0.30) * (double)px[1] + (double)tint[1]);
+        px[2] = mz_clip_u8((1.0 - 0.30) * (double)px[2] + (double)tint[2]);
+      }
+    }
+  }
+  __syncthreads();
+  const int idxc = cmd_idx_e < P.n_cmd ? cmd_idx_e : P.n_cmd - 1;
+  const int cmd = P.T.commands[(size_t)t * P.n_cmd + idxc];
+  if (P.command_in_observation) {   // maze_continuous_3d.py:23-29,102-107
+    const int sx = (int)(0.25 * H), sy = (int)(0.10 * H), ex = (int)(0.25 * H + 0.50 * H), ey = (int)(0.10 * H + 0.05 * W);
+    for (int x = sx + threadIdx.x; x < ex && x < W; x += blockDim.x)
+      for (int y = sy; y < ey && y < H; ++y)
+        for (int c = 0; c < 3; ++c) lds[((size_t)x * H + y) * 3 + c] = (uint8_t)(int)MZ_LANDMARK_RGB[cmd][c];
+    __syncthreads();
+  }
+  // ---- frame out: coalesced 16-byte stores ----
+  if (STAGE) {
+    if ((fsz & 15) == 0) {
+      const uint4* s4 = reinterpret_cast<const uint4*>(lds);
+      uint4* d4 = reinterpret_cast<uint4*>(dst);
+      for (size_t k = threadIdx.x; k < fsz / 16; k += blockDim.x) d4[k] = s4[k];
+    } else {
+      for (size_t k = threadIdx.x; k < fsz; k += blockDim.x) dst[k] = lds[k];
+    }
+  }
+  if (command_rgb && threadIdx.x < 3) command_rgb[(size_t)e * 3 + threadIdx.x] = MZ_LANDMARK_RGB[cmd][threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" int xv_maze_create(xv_engine* e, int n_env, int n_task, int NG, int n_cmd, int max_steps, int W, int H,
+                              int command_in_observation, double collision_dist, double visibility_3D,
+                              const xv_maze_tables* tables, const int32_t* env_task, xv_maze** out) {
+  XV_CHECK_ARG(out != nullptr);
+  *out = nullptr;
+  XV_CHECK_ARG(e && tables && env_task && n_env > 0 && n_task > 0);
+  XV_CHECK_ARG(NG >= 3 && NG <= 64 && n_cmd >= 1 && W >= 2 && H >= 2 && W <= 1024 && H <= 1024);
+  XV_CHECK_ARG(tables->walls && tables->texts && tables->landmarks && tables->ints && tables->dbl &&
+               tables->commands && tables->lm_coord && tables->tex_walls && tables->tex_grounds &&
+               tables->tex_ceilings);
+  XV_HIP(hipSetDevice(e->device));
+  xv_maze* h = new (std::nothrow) xv_maze();
+  if (!h) {
+    xv_set_error("xv_maze_create: out of host memory");
+    return XV_ERR_NOMEM;
+  }
+  h->eng = e;
+  MazeArgs& a = h->a;
+  memset(&a, 0, sizeof(a));
+  a.T = *tables; a.env_task = env_task;
+  a.n_env = n_env; a.n_task = n_task; a.NG = NG; a.n_cmd = n_cmd; a.max_steps = max_steps; a.W = W; a.H = H;
+  a.command_in_observation = command_in_observation;
+  a.collision_dist = collision_dist; a.visibility = visibility_3D;
+  a.err = e->d_err;
+  const size_t n = (size_t)n_env;
+  hipError_t m = hipMalloc(&a.pos, 16 * n);
+  if (m == hipSuccess) m = hipMalloc(&a.ori, 8 * n);
+  if (m == hipSuccess) m = hipMalloc(&a.grid, 8 * n);
+  if (m == hipSuccess) m = hipMalloc(&a.steps, 4 * n);
+  if (m == hipSuccess) m = hipMalloc(&a.cmd_idx, 4 * n);
+  if (m == hipSuccess) m = hipMalloc(&a.cmd_age, 4 * n);
+  if (m == hipSuccess) m = hipMalloc(&a.need_reset, n);
+  if (m == hipSuccess) m = hipMalloc(&a.collision, 8 * n);
+  if (m == hipSuccess) m = hipMalloc(&a.fin_pose, 24 * n);
+  if (m == hipSuccess) m = hipMalloc(&a.fin_cmd, 4 * n);
+  if (m == hipSuccess) m = hipMalloc(&a.fin_flag, n);
+  if (m == hipSuccess) m = hipMemsetAsync(a.need_reset, 1, n, e->stream);
+  if (m == hipSuccess) m = hipMemsetAsync(a.fin_flag, 0, n, e->stream);
+  if (m != hipSuccess) {
+    xv_set_error("xv_maze_create: device allocation failed: %s", hipGetErrorString(m));
+    void* ps[] = {a.pos, a.ori, a.grid, a.steps, a.cmd_idx, a.cmd_age, a.need_reset, a.collision, a.fin_pose,
+                  a.fin_cmd, a.fin_flag};
+    for (void* p : ps) if (p) (void)hipFree(p);
+    delete h;
+    return XV_ERR_HIP;
+  }
+  hipLaunchKernelGGL(maze_reset_kernel, dim3(xv_div_up(n_env, 256)), dim3(256), 0, e->stream, a,
+                     (const uint8_t*)nullptr);
+  XV_HIP(hipMemsetAsync(a.need_reset, 1, n, e->stream));
+  // the ray-cast kernel stages a whole frame in LDS when it fits: raise the dynamic LDS limit past 64 KiB
+  const size_t lds_bytes = ((size_t)W * H * 3 + 15) & ~(size_t)15;
+  if (lds_bytes <= MAZE_LDS_STAGE_MAX && lds_bytes > 48 * 1024) {
+    XV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&maze_raycast_kernel<false, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    XV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&maze_raycast_kernel<true, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  }
+  XV_LAUNCH_CHECK();
+  *out = h;
+  return XV_OK;
+}
+
+extern "C" int xv_maze_destroy(xv_maze* h) {
+  if (!h) return XV_OK;
+  (void)hipSetDevice(h->eng->device);
+  (void)hipStreamSynchronize(h->eng->stream);
+  MazeArgs& a = h->a;
+  void* ps[] = {a.pos, a.ori, a.grid, a.steps, a.cmd_idx, a.cmd_age, a.need_reset, a.collision, a.fin_pose,
+                a.fin_cmd, a.fin_flag};
+  for (void* p : ps) if (p) (void)hipFree(p);
+  delete h;
+  return XV_OK;
+}
+
+static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, bool final) {
+  const MazeArgs& a = h->a;
+  const int threads = a.W <= 64 ? 64 : (a.W <= 128 ? 128 : 256);
+  const size_t lds_bytes = ((size_t)a.W * a.H * 3 + 15) & ~(size_t)15;
+  const bool stage = lds_bytes <= MAZE_LDS_STAGE_MAX;
+  float* crgb = final ? nullptr : command_rgb;
+#define MAZE_RC(F, S) \
+  hipLaunchKernelGGL((maze_raycast_kernel<F, S>), dim3(a.n_env), dim3(threads), (S) ? lds_bytes : 0, h->eng->stream, a, frames, crgb)
+  if (final) { if (stage) MAZE_RC(true, true); else MAZE_RC(true, false); }
+  else { if (stage) MAZE_RC(false, true); else MAZE_RC(false, false); }
+#undef MAZE_RC
+  XV_LAUNCH_CHECK();
+  return XV_OK;
+}
+
+extern "C" int xv_maze_render(xv_maze* h, uint8_t* frames, float* command_rgb) {
+  XV_CHECK_ARG(h != nullptr && frames != nullptr);
+  return maze_launch_render(h, frames, command_rgb, false);
+}
+
+extern "C" int xv_maze_reset(xv_maze* h, const uint8_t* mask, uint8_t* frames, float* command_rgb) {
+  XV_CHECK_ARG(h != nullptr);
+  hipLaunchKernelGGL(maze_reset_kernel, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream, h->a, mask);
+  XV_LAUNCH_CHECK();
+  if (frames) return maze_launch_render(h, frames, command_rgb, false);
+  return XV_OK;
+}
+
+extern "C" int xv_maze_step(xv_maze* h, const void* action, int action_mode, uint8_t* frames, float* reward,
+                            uint8_t* terminated, uint8_t* truncated, float* command_rgb, uint8_t* final_frames,
+                            int autoreset_mode) {
+  XV_CHECK_ARG(h && action && reward && terminated && truncated);
+  XV_CHECK_ARG(action_mode >= 0 && action_mode <= 2 && autoreset_mode >= 0 && autoreset_mode <= 2);
+  hipLaunchKernelGGL(maze_step_kernel, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream, h->a, action,
+                     action_mode, reward, terminated, truncated, autoreset_mode);
+  XV_LAUNCH_CHECK();
+  if (final_frames && autoreset_mode == XV_AUTORESET_SAME_STEP) {
+    const int rc = maze_launch_render(h, final_frames, nullptr, true);
+    if (rc != XV_OK) return rc;
+  }
+  if (frames) return maze_launch_render(h, frames, command_rgb, false);
+  return XV_OK;
+}
+
+extern "C" int xv_maze_get_state(xv_maze* h, double* pos, double* ori, int32_t* grid, int32_t* steps,
+                                 int32_t* cmd_idx, int32_t* cmd_age, uint8_t* need_reset, double* collision) {
+  XV_CHECK_ARG(h != nullptr);
+  const size_t n = (size_t)h->a.n_env;
+  hipStream_t s = h->eng->stream;
+  if (pos) XV_HIP(hipMemcpyAsync(pos, h->a.pos, 16 * n, hipMemcpyDeviceToDevice, s));
+  if (ori) XV_HIP(hipMemcpyAsync(ori, h->a.ori, 8 * n, hipMemcpyDeviceToDevice, s));
+  if (grid) XV_HIP(hipMemcpyAsync(grid, h->a.grid, 8 * n, hipMemcpyDeviceToDevice, s));
+  if (steps) XV_HIP(hipMemcpyAsync(steps, h->a.steps, 4 * n, hipMemcpyDeviceToDevice, s));
+  if (cmd_idx) XV_HIP(hipMemcpyAsync(cmd_idx, h->a.cmd_idx, 4 * n, hipMemcpyDeviceToDevice, s));
+  if (cmd_age) XV_HIP(hipMemcpyAsync(cmd_age, h->a.cmd_age, 4 * n, hipMemcpyDeviceToDevice, s));
+  if (need_reset) XV_HIP(hipMemcpyAsync(need_reset, h->a.need_reset, n, hipMemcpyDeviceToDevice, s));
+  if (collision) XV_HIP(hipMemcpyAsync(collision, h->a.collision, 8 * n, hipMemcpyDeviceToDevice, s));
+  return XV_OK;
+}
+
+extern "C" int xv_maze_set_state(xv_maze* h, const double* pos, const double* ori, const int32_t* steps,
+                                 const int32_t* cmd_idx, const int32_t* cmd_age, const uint8_t* need_reset) {
+  XV_CHECK_ARG(h != nullptr);
+  const size_t n = (size_t)h->a.n_env;
+  hipStream_t s = h->eng->stream;
+  if (pos) XV_HIP(hipMemcpyAsync(h->a.pos, pos, 16 * n, hipMemcpyDeviceToDevice, s));
+  if (ori) XV_HIP(hipMemcpyAsync(h->a.ori, ori, 8 * n, hipMemcpyDeviceToDevice, s));
+  if (steps) XV_HIP(hipMemcpyAsync(h->a.steps, steps, 4 * n, hipMemcpyDeviceToDevice, s));
+  if (cmd_idx) XV_HIP(hipMemcpyAsync(h->a.cmd_idx, cmd_idx, 4 * n, hipMemcpyDeviceToDevice, s));
+  if (cmd_age) XV_HIP(hipMemcpyAsync(h->a.cmd_age, cmd_age, 4 * n, hipMemcpyDeviceToDevice, s));
+  if (need_reset) XV_HIP(hipMemcpyAsync(h->a.need_reset, need_reset, n, hipMemcpyDeviceToDevice, s));
+  return XV_OK;
+}

@@ -1,0 +1,4 @@
+"""MazeWorld on MI355X.  Drop-in for the step/reset/observation path of `xenoverse.mazeworld`."""
+from .tables import DEFAULT_ACTION_SPACE_16, DEFAULT_ACTION_SPACE_32, build_tables  # noqa: F401
+from .textures import make_texture_library  # noqa: F401
+from .vec_env import MazeWorldVecEnv  # noqa: F401

@@ -51,6 +51,7 @@ def build_tables(tasks):
         ints[i, :6] = [n, int(t["start"][0]), int(t["start"][1]), int(t["ground_text"]), int(t["ceiling_text"]), len(lm)]
         dbl[i, :7] = [t["cell_size"], t["wall_height"], t["agent_height"], t["fol_angle"], t["step_reward"],
                       t["goal_reward"], t["collision_reward"]]
+        dbl[i, 7] = np.tan(float(t["fol_angle"]) / 2)    # numpy.tan(vision_angle_h / 2), ray_caster_utils.py:145
         commands[i] = np.asarray(t["commands_sequence"], np.int64)
         lm_coord[i, :len(lm)] = lm
     return dict(NG=NG, n_cmd=n_cmd, walls=walls, texts=texts, landmarks=landmarks, ints=ints, dbl=dbl,
