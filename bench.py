@@ -131,26 +131,19 @@ def main():
     env.reset()
     ring = env.step_many(1, actions)   # allocates the [P, N] output ring
 
-    # optional exchange step: all-gather of the finished rollout chunk (obs/act/rew/flags, 14 B per record)
-    gather_stream = None
+    # exchange step: all-gather of each finished T-step rollout chunk (14-B records) over RCCL,
+    # on a side stream so that it overlaps the next chunk's stepping.  Stepping itself needs no collective.
     do_gather = world > 1 and not args.no_allgather
+    gather = None
+    gather_note = "none"
     if do_gather:
-        rec = torch.empty((P, n_env, 14), dtype=torch.uint8, device=env.device)
-        gathered = torch.empty((world, P, n_env, 14), dtype=torch.uint8, device=env.device)
-        gather_stream = torch.cuda.Stream(device=env.device)
-
-    def pack_and_gather():
-        # pack the chunk into 14-B records and all-gather it on a side stream, overlapped with stepping
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        with torch.cuda.stream(gather_stream):
-            gather_stream.wait_event(ev)
-            rec[..., 0:4] = ring["obs"].view(torch.uint8).view(P, n_env, 4)
-            rec[..., 4:8] = actions.view(torch.uint8).view(P, n_env, 4)
-            rec[..., 8:12] = ring["reward"].view(torch.uint8).view(P, n_env, 4)
-            rec[..., 12] = ring["terminated"]
-            rec[..., 13] = ring["truncated"]
-            dist.all_gather_into_tensor(gathered, rec)
+        try:
+            from xenoverse_amd.distributed import REC_BYTES, RolloutGather, pack_records
+            gather = RolloutGather((P, n_env, REC_BYTES), device=env.device)
+            gather_note = "all_gather of %d-step rollout chunks, %d B/record (RCCL, side stream)" % (P, REC_BYTES)
+        except Exception as ex:   # never lose the measurement to a collective set-up problem
+            gather = None
+            gather_note = "all_gather unavailable: %r" % (ex,)
 
     def run(k_steps):
         done = 0
@@ -158,10 +151,13 @@ def main():
             n = min(P, k_steps - done)
             env.step_many(n, actions, out=ring)
             done += n
-            if do_gather and n == P:
-                pack_and_gather()
-        if do_gather:
-            torch.cuda.current_stream().wait_stream(gather_stream)
+            if gather is not None and n == P:
+                gather.wait()        # the previous chunk must have left before its buffer is repacked
+                pack_records(ring["obs"], actions, ring["reward"], ring["terminated"], ring["truncated"],
+                             out=gather.local)
+                gather.launch()
+        if gather is not None:
+            gather.wait()
 
     def barrier():
         if dist is not None:
@@ -216,7 +212,7 @@ def main():
                        "table_gib_per_gpu": round(n_task * S * A * S * 16 / 2**30, 2),
                        "launch": "one step kernel per vector step (xv_anymdp_step_many)",
                        "search": search,
-                       "exchange": ("all_gather of %d-step rollout chunks (RCCL)" % P) if do_gather else "none",
+                       "exchange": gather_note,
                        "device_error_flags": errs},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

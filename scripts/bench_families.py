@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Per-family measurements beside bench.py's AnyMDP headline: BASELINE.json configs 3 (linds), 4 (mazeworld) and
+the CartPole leg of config 5, one GPU.  One JSON line per family: env-steps/s, average launch time of each
+kernel (HIP events on the launch stream) and the HBM roofline fraction from the algorithmic bytes of
+SURVEY.md §8(d): linds 432 B (+96 B amortised matrices), cartpole 74 B, maze 3*W*H + 64 B.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+HBM_PEAK = 8000.0
+
+
+def timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / steps      # us per call
+
+
+def bench_linds(args):
+    from xenoverse_amd.linds import LinDSVecEnv, LinearDSSampler
+    n_task, per = 1024, 64
+    n = n_task * per
+    t0 = time.time()
+    tasks = []
+    for k in range(64):        # 64 distinct sampled tasks, tiled to 1,024 (tables are per task index anyway)
+        t = LinearDSSampler(32, 8, 8, seed=k)
+        t["max_steps"] = 500
+        tasks.append(t)
+    tasks = [tasks[k % 64] for k in range(n_task)]
+    out = {}
+    for path in ("mfma", "scalar"):
+        env = LinDSVecEnv(n, autoreset_mode="same_step", seed=1)
+        env.set_task(tasks)
+        env.set_path(path)
+        env.reset()
+        a = torch.rand((n, 8), device=env.device) * 2 - 1
+        from xenoverse_amd import _lib
+        from xenoverse_amd.engine import AUTORESET
+
+        def step():
+            _lib.check(env.lib.xv_linds_step(env._h, _lib.ptr(a), _lib.ptr(env._obs), _lib.ptr(env._reward),
+                                             _lib.ptr(env._term), _lib.ptr(env._trunc), _lib.ptr(env._cmd),
+                                             _lib.ptr(env._error), _lib.ptr(env._fobs), AUTORESET["same_step"]))
+        us = timed(step, args.steps, args.warmup)
+        out[path] = us
+        env.close()
+    algo = 432 * n
+    best = min(out.values())
+    return {"family": "linds", "workload": "ns=32 na=8 no=8 (pads 16/8/16), 65,536 envs = 1,024 tasks x 64",
+            "env_steps_per_s": n / (best * 1e-6), "us_per_step": out, "dtype": "f32",
+            "roofline": {"bound": "hbm", "achieved": algo / (best * 1e-6) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
+                         "frac": algo / (best * 1e-6) / 1e9 / HBM_PEAK, "algorithmic_bytes_per_env_step": 432},
+            "mfma_flops_per_env_step": 3072, "achieved_tflops": 3072 * n / (out["mfma"] * 1e-6) / 1e12,
+            "setup_s": round(time.time() - t0, 1)}
+
+
+def bench_cartpole(args):
+    from xenoverse_amd.metacontrol import CartPoleVecEnv, sample_cartpole
+    from xenoverse_amd import _lib
+    from xenoverse_amd.engine import AUTORESET
+    n = 65536
+    env = CartPoleVecEnv(n, frameskip=1, autoreset_mode="same_step", seed=1)
+    env.set_task([sample_cartpole(seed=k) for k in range(1024)])
+    env.reset()
+    a = torch.randint(0, 2, (n,), device=env.device, dtype=torch.int32)
+
+    def step():
+        _lib.check(env.lib.xv_cartpole_step(env._h, _lib.ptr(a), _lib.ptr(env._obs), _lib.ptr(env._reward),
+                                            _lib.ptr(env._term), _lib.ptr(env._trunc), _lib.ptr(env._fobs),
+                                            AUTORESET["same_step"]))
+    us = timed(step, args.steps, args.warmup)
+    env.close()
+    algo = 74 * n
+    return {"family": "cartpole", "workload": "65,536 envs, 1,024 tasks, frameskip 1", "dtype": "f32",
+            "env_steps_per_s": n / (us * 1e-6), "us_per_step": us,
+            "roofline": {"bound": "hbm", "achieved": algo / (us * 1e-6) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
+                         "frac": algo / (us * 1e-6) / 1e9 / HBM_PEAK, "algorithmic_bytes_per_env_step": 74,
+                         "note": "4.8 MB per launch: launch-latency bound, not bandwidth bound"}}
+
+
+def bench_maze(args, res):
+    from xenoverse_amd.mazeworld import MazeTaskSampler, MazeWorldVecEnv, make_texture_library
+    from xenoverse_amd import _lib
+    from xenoverse_amd.engine import AUTORESET
+    n_task, per = 256, 64
+    n = n_task * per
+    tasks = [MazeTaskSampler(n_range=(15, 16), seed=k, n_wall_textures=8, n_ground_textures=4, n_ceiling_textures=4)
+             for k in range(n_task)]
+    env = MazeWorldVecEnv(n, resolution=(res, res), textures=make_texture_library(8, 4, 4, seed=0),
+                          autoreset_mode="same_step", action_space_type="Discrete16")
+    env.set_task(tasks)
+    env.reset()
+    a = torch.randint(0, 16, (n,), device=env.device, dtype=torch.int32)
+    steps = max(3, args.steps // (40 if res <= 64 else 400))
+
+    def move():
+        _lib.check(env.lib.xv_maze_step(env._h, _lib.ptr(a), 1, None, _lib.ptr(env._reward), _lib.ptr(env._term),
+                                        _lib.ptr(env._trunc), None, None, AUTORESET["same_step"]))
+
+    def render():
+        _lib.check(env.lib.xv_maze_render(env._h, _lib.ptr(env._frames), _lib.ptr(env._cmd_rgb)))
+
+    def full():
+        _lib.check(env.lib.xv_maze_step(env._h, _lib.ptr(a), 1, _lib.ptr(env._frames), _lib.ptr(env._reward),
+                                        _lib.ptr(env._term), _lib.ptr(env._trunc), _lib.ptr(env._cmd_rgb), None,
+                                        AUTORESET["same_step"]))
+    us_move = timed(move, steps, 2)
+    us_render = timed(render, steps, 2)
+    us_full = timed(full, steps, 2)
+    env.close()
+    algo = (3 * res * res + 64) * n
+    return {"family": "mazeworld", "workload": "15x15 mazes, 16,384 envs = 256 tasks x 64, %dx%d frames" % (res, res),
+            "dtype": "f64 pose, f32/f64 ray-caster, u8 frames", "env_steps_per_s": n / (us_full * 1e-6),
+            "us_per_step": {"move+rules": us_move, "raycast": us_render, "step (both)": us_full},
+            "roofline": {"bound": "hbm", "achieved": algo / (us_full * 1e-6) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
+                         "frac": algo / (us_full * 1e-6) / 1e9 / HBM_PEAK,
+                         "algorithmic_bytes_per_env_step": 3 * res * res + 64,
+                         "note": "the 16-tap fp64 texture filter (ALU), not HBM, bounds the ray-caster"}}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--families", default="linds,cartpole,maze64,maze256")
+    args = ap.parse_args()
+    for f in args.families.split(","):
+        if f == "linds":
+            r = bench_linds(args)
+        elif f == "cartpole":
+            r = bench_cartpole(args)
+        elif f.startswith("maze"):
+            r = bench_maze(args, int(f[4:]))
+        else:
+            continue
+        print(json.dumps(r), flush=True)

@@ -1,0 +1,111 @@
+"""N > 1 path on CPU: world_size-2 `gloo` processes exercise the sharding helpers and the rollout all-gather
+(the same code runs over RCCL/xGMI with backend "nccl" on the GPUs)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from xenoverse_amd.distributed import (REC_BYTES, RolloutGather, pack_records, shard_env_task, shard_range,
+                                       unpack_records)
+
+
+def test_shard_range_partitions_exactly():
+    for n in (1, 7, 8, 65536, 65537, 262144):
+        for world in (1, 2, 3, 8):
+            ends = [shard_range(n, r, world) for r in range(world)]
+            assert ends[0][0] == 0 and ends[-1][1] == n
+            assert all(ends[r][1] == ends[r + 1][0] for r in range(world - 1))
+            sizes = [hi - lo for lo, hi in ends]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_shard_env_task_renumbers_tasks():
+    env_task = np.repeat(np.arange(10), 7)
+    for world in (1, 2, 4):
+        seen = []
+        for r in range(world):
+            lo, hi, local, ids = shard_env_task(env_task, r, world)
+            assert np.array_equal(ids[local], env_task[lo:hi])
+            assert local.min() == 0 and local.max() == len(ids) - 1
+            seen.append(np.arange(lo, hi))
+        assert np.array_equal(np.concatenate(seen), np.arange(len(env_task)))
+
+
+def test_record_packing_roundtrip():
+    T, N = 5, 33
+    g = torch.Generator().manual_seed(0)
+    obs = torch.randint(0, 64, (T, N), generator=g, dtype=torch.int32)
+    act = torch.randint(0, 8, (T, N), generator=g, dtype=torch.int32)
+    rew = torch.randn((T, N), generator=g)
+    te = (torch.rand((T, N), generator=g) < 0.1).to(torch.uint8)
+    tr = (torch.rand((T, N), generator=g) < 0.1).to(torch.uint8)
+    rec = pack_records(obs, act, rew, te, tr)
+    assert rec.shape == (T, N, REC_BYTES) and rec.dtype == torch.uint8
+    o2, a2, r2, te2, tr2 = unpack_records(rec)
+    assert torch.equal(o2, obs) and torch.equal(a2, act) and torch.equal(r2, rew)
+    assert torch.equal(te2, te) and torch.equal(tr2, tr)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, T, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_range(n_total, rank, world)
+        n = hi - lo
+        # each rank fabricates the records of ITS envs from the global env id, so the gathered batch is checkable
+        gid = torch.arange(lo, hi, dtype=torch.int32)
+        obs = (gid[None, :] * 3 + torch.arange(T, dtype=torch.int32)[:, None]) % 64
+        act = (gid[None, :] + torch.arange(T, dtype=torch.int32)[:, None]) % 8
+        rew = gid[None, :].float() * 0.5 + torch.arange(T)[:, None].float()
+        te = ((gid[None, :] + torch.arange(T, dtype=torch.int32)[:, None]) % 5 == 0).to(torch.uint8)
+        tr = torch.zeros((T, n), dtype=torch.uint8)
+        g = RolloutGather((T, n, REC_BYTES), device="cpu")
+        pack_records(obs, act, rew, te, tr, out=g.local)
+        g.launch()
+        out = g.wait()
+        # every rank sees every shard; rank order == env order
+        full = torch.cat([out[r] for r in range(world)], dim=1)
+        o2, a2, r2, te2, _ = unpack_records(full)
+        gid_all = torch.arange(0, n_total, dtype=torch.int32)
+        ok = bool(torch.equal(o2, (gid_all[None, :] * 3 + torch.arange(T, dtype=torch.int32)[:, None]) % 64)
+                  and torch.equal(a2, (gid_all[None, :] + torch.arange(T, dtype=torch.int32)[:, None]) % 8)
+                  and torch.equal(r2, gid_all[None, :].float() * 0.5 + torch.arange(T)[:, None].float())
+                  and torch.equal(te2, ((gid_all[None, :] + torch.arange(T, dtype=torch.int32)[:, None]) % 5 == 0).to(torch.uint8)))
+        # max-over-ranks timing reduction used by bench.py
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        q.put((rank, ok, float(t[0])))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_world_size_2_gloo_allgather_of_rollout_chunks():
+    world, n_total, T = 2, 64, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=90) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert sorted(r for r, _, _ in res) == [0, 1]
+    assert all(ok for _, ok, _ in res)
+    assert all(tmax == 2.0 for _, _, tmax in res)

@@ -1,0 +1,66 @@
+"""Host task samplers (CPU): the reference's dict schemas and invariants; tasks flow through the table builders."""
+import numpy as np
+
+from xenoverse_amd.linds import LinearDSSampler, LinearDSSamplerRandomDim, build_tables as linds_tables
+from xenoverse_amd.mazeworld import MazeTaskSampler, Resampler, build_tables as maze_tables
+from xenoverse_amd.mazeworld.task_sampler import genmaze
+
+
+def _connected(w):
+    free = np.argwhere(w == 0)
+    seen = {tuple(free[0])}
+    stack = [tuple(free[0])]
+    while stack:
+        i, j = stack.pop()
+        for d in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+            c = (i + d[0], j + d[1])
+            if w[c] == 0 and c not in seen:
+                seen.add(c); stack.append(c)
+    return len(seen) == len(free)
+
+
+def test_genmaze_connected_border_density():
+    for n in (7, 15, 25):
+        for loops in (False, True):
+            w = genmaze(n, np.random.RandomState(n), allow_loops=loops, wall_density=0.3)
+            assert w.shape == (n, n) and w.dtype == np.int8
+            assert w[0].all() and w[-1].all() and w[:, 0].all() and w[:, -1].all()
+            assert _connected(w)
+            if loops:
+                assert w[1:-1, 1:-1].mean() <= 0.45
+
+
+def test_maze_task_schema_and_determinism():
+    keys = {"start", "cell_walls", "cell_texts", "cell_size", "ground_text", "ceiling_text", "step_reward",
+            "goal_reward", "collision_reward", "wall_height", "agent_height", "fol_angle", "commands_sequence",
+            "landmarks_coordinates", "cell_landmarks"}
+    t = MazeTaskSampler(n_range=(15, 16), seed=3)
+    assert set(t) == keys and t["cell_walls"].shape == (15, 15)
+    assert 1.5 <= t["cell_size"] <= 4.5 and 2 <= t["wall_height"] <= 6 and 1.6 <= t["agent_height"] <= 2.0
+    assert len(t["commands_sequence"]) == 200 and 5 <= len(t["landmarks_coordinates"]) <= 14
+    assert np.all(np.diff(t["commands_sequence"]) != 0)
+    assert t["cell_walls"][t["start"]] == 0 and t["cell_landmarks"][t["start"]] == -1
+    for q, c in enumerate(t["landmarks_coordinates"]):
+        assert t["cell_walls"][c] == 0 and t["cell_landmarks"][c] == q
+    assert abs(t["goal_reward"] - 15 * np.sqrt(15) / 60) < 1e-12
+    t2 = MazeTaskSampler(n_range=(15, 16), seed=3)
+    assert np.array_equal(t["cell_walls"], t2["cell_walls"]) and t["start"] == t2["start"]
+    r = Resampler(t, seed=1)
+    assert np.array_equal(r["cell_walls"], t["cell_walls"]) and not np.array_equal(r["commands_sequence"], t["commands_sequence"])
+    tab = maze_tables([t, MazeTaskSampler(n_range=(9, 10), seed=4)])
+    assert tab["NG"] == 15 and tab["walls"].shape == (2, 15, 15) and np.all(tab["walls"][1, 9:, :] == 1)
+
+
+def test_linds_task_schema_all_dims_terminate():
+    for dims in ((16, 8, 8), (32, 8, 8), (32, 8, 16), (4, 2, 3)):
+        t = LinearDSSampler(*dims, seed=dims[0])
+        assert t["ld_A"].shape == (dims[0], dims[0]) and t["ld_B"].shape == (dims[0], dims[1])
+        assert t["ld_C"].shape == (dims[2], dims[0]) and 100 <= t["max_steps"] < 1000
+        assert t["target_type"] in ("static_target", "dynamic_target") and len(t["initial_states"]) >= 1
+        cmd = t["command"] if t["target_type"] == "static_target" else t["command"](-t["target_delay"])
+        for x0 in t["initial_states"]:
+            assert np.linalg.norm((cmd - t["ld_C"] @ x0 - t["ld_Y"]) * t["target_valid"]) <= 3.0
+        tab = linds_tables([t], pad_observation_dim=16)
+        assert tab["phiT"].shape[1] == dims[0]
+    t = LinearDSSamplerRandomDim(seed=5)
+    assert t["state_dim"] <= 16

@@ -1,0 +1,126 @@
+"""LinearDSSampler / LinearDSSamplerRandomDim — randomised LTI control tasks with the reference's signature and
+dict schema (xenoverse/linds/task_sampler.py:60-154, building blocks :12-58; RandomFourier
+xenoverse/utils/random_nn.py:346-368; weights_and_biases :45-53).
+
+The reference sampler is not reproducible even with a seed (pseudo_random_seed adds the seed to a nanosecond
+timestamp, utils/random_nn.py:9-16); this one is deterministic given `seed`.  One documented deviation: the
+reference's initial-state rejection loop (:108-132) accepts with probability ~5e-4 at state_dim=32 and never
+returns in practice; here initial states that fail the test are shrunk toward the origin until
+they pass, so the sampler terminates for every dimension.
+"""
+import numpy as np
+
+
+class RandomFourier(object):
+    """y(t) = sum_k c_k[:,0] sin(w_k t/max_steps) + c_k[:,1] cos(w_k t/max_steps); w_0 = 0, 1..max_item further terms"""
+
+    def __init__(self, ndim, max_order=16, max_item=5, max_steps=1000, box_size=2, rng=None):
+        rng = rng if rng is not None else np.random
+        n_items = rng.randint(1, max_item + 1)
+        self.coeffs = [(0, rng.normal(size=(ndim, 2)) * rng.exponential(scale=box_size / np.sqrt(n_items), size=(ndim, 2)))]
+        self.max_steps = max_steps
+        for _ in range(n_items):
+            order = rng.randint(1, max_order + 1) + rng.normal(scale=1.0)
+            factor = rng.normal(size=(ndim, 2)) * rng.exponential(scale=box_size / np.sqrt(n_items), size=(ndim, 2))
+            self.coeffs.append((order, factor))
+
+    def __call__(self, t):
+        x = t / self.max_steps
+        y = 0
+        for order, coeff in self.coeffs:
+            y = y + coeff[:, 0] * np.sin(order * x) + coeff[:, 1] * np.cos(order * x)
+        return y
+
+
+def _weights_and_biases(rng, n_in, n_out, need_bias=False):
+    w = rng.normal(0, np.sqrt(2.0 / (n_in + n_out)), size=(n_out, n_in)) * 3      # xavier_normal_init(gain=3)
+    b = 0.1 * rng.normal(size=[n_out]) if need_bias else np.zeros(shape=[n_out])
+    return w, b
+
+
+def _sample_variants(rng, ns, na, no):
+    AB, X = _weights_and_biases(rng, ns + na, ns, need_bias=True)
+    C, Y = _weights_and_biases(rng, ns, no, need_bias=False)
+    A = AB[:, :ns] * rng.choice([0.01, 0.02, 0.05, 0.1, 0.2])
+    B = AB[:, ns:]
+    X = X * rng.choice([0.0, 0.05, 0.1])
+    trim = rng.randint(3)
+    if trim == 0:      # banded
+        width = rng.randint(2, max(ns // 2, 3) + 1)
+        if width < ns:
+            i, j = np.indices((ns, ns))
+            A = np.where(np.abs(i - j) > width, 0.0, A)
+    elif trim == 1:    # triangular
+        width = rng.randint(-1, max(ns // 4, 2) + 1)
+        if width < ns:
+            i, j = np.indices((ns, ns))
+            A = np.where(j < i + width, 0.0, A)
+    return A, B, C, X, Y
+
+
+def LinearDSSampler(state_dim=16, action_dim=8, observation_dim=8, seed=None, verbose=False):
+    rng = np.random.RandomState(seed)
+    task = dict(state_dim=state_dim, observation_dim=observation_dim, action_dim=action_dim)
+    task["max_steps"] = int(rng.randint(100, 1000))
+    while True:
+        A, B, C, X, Y = _sample_variants(rng, state_dim, action_dim, observation_dim)
+        if (np.linalg.matrix_rank(B) > min(action_dim, state_dim) - 1 and
+                np.linalg.matrix_rank(C) > min(observation_dim, state_dim) - 1):
+            break
+    task.update(ld_A=A, ld_B=B, ld_C=C, ld_X=X, ld_Y=Y)
+    task["action_cost"] = max(rng.uniform(-1.0, 1.0) * rng.exponential(0.05), 0.0)
+    task["reward_base"] = rng.exponential(0.10)
+    task["terminate_punish"] = rng.exponential(scale=5.0) * rng.choice([0, 1, 1])
+    task["reward_factor"] = rng.exponential(scale=0.50)
+    eps = min(rng.uniform(0.2, 1.2), 1.0)
+    tv = np.zeros((observation_dim,))
+    while np.sum(tv) < 0.5:
+        tv = rng.binomial(1, eps, size=(observation_dim,))
+    task["target_valid"] = tv
+    task["target_type"] = str(rng.choice(["dynamic_target", "dynamic_target", "static_target"]))
+    task["noise_drift"] = float(np.clip(rng.uniform(-0.02, 0.02), 0.0, 0.02))
+
+    def close_enough(x0, cmd):
+        return np.linalg.norm((cmd - C @ x0 - Y) * tv) <= 3.0 and np.linalg.norm(x0) <= 10.0
+
+    for attempt in range(256):   # the reference re-draws command AND initial states until all pass (:108-132)
+        born_loc = int(max(rng.exponential(scale=1.0), 1))
+        if task["target_type"] == "static_target":
+            task["command"] = rng.randn(observation_dim) * rng.choice([0, 1])
+            task["target_delay"] = 0
+            cmd = task["command"]
+        else:
+            task["command"] = RandomFourier(observation_dim, rng=rng)
+            task["target_delay"] = max(int(rng.randint(-10, 30)), 0)
+            cmd = task["command"](-task["target_delay"])
+        states = []
+        for _ in range(born_loc):
+            x0 = rng.randn(state_dim)
+            for _ in range(24):   # shrink toward the origin instead of rejecting forever (module docstring)
+                if close_enough(x0, cmd):
+                    break
+                x0 = 0.7 * x0
+            states.append(x0)
+        if all(close_enough(x0, cmd) for x0 in states):
+            break
+    else:   # last resort: start on the least-squares pre-image of the command
+        M = tv[:, None] * C
+        x_ls = np.linalg.pinv(M) @ (tv * (cmd - Y))
+        x_ls *= min(1.0, 9.0 / max(np.linalg.norm(x_ls), 1e-9))
+        states = [x_ls + 0.01 * rng.randn(state_dim) for _ in range(born_loc)]
+    task["initial_states"] = states
+    return task
+
+
+def LinearDSSamplerRandomDim(max_state_dim=16, max_observation_dim=16, max_action_dim=8, seed=None, verbose=False):
+    assert max_state_dim >= 2, "max_state_dim should be at least 2"
+    assert max_action_dim >= 1, "max_action_dim should be at least 1"
+    rng = np.random.RandomState(seed)
+    state_dim = int(rng.randint(1, max_state_dim + 1))
+    min_action_dim = max(1, (state_dim + 1) // 2)
+    max_action_dim = max(min(max_action_dim, state_dim * 3 // 2), min_action_dim)
+    min_observation_dim = max(1, state_dim // 4)
+    max_observation_dim = max(min(max_observation_dim, state_dim * 3 // 2), min_observation_dim)
+    action_dim = int(rng.randint(min_action_dim, max_action_dim + 1))
+    observation_dim = int(rng.randint(min_observation_dim, max_observation_dim + 1))
+    return LinearDSSampler(state_dim, action_dim, observation_dim, seed=None if seed is None else seed + 1)

@@ -2,3 +2,4 @@
 from .tables import DEFAULT_ACTION_SPACE_16, DEFAULT_ACTION_SPACE_32, build_tables  # noqa: F401
 from .textures import make_texture_library  # noqa: F401
 from .vec_env import MazeWorldVecEnv  # noqa: F401
+from .task_sampler import MazeTaskSampler, Resampler  # noqa: F401
