@@ -93,6 +93,25 @@ def cpu_baseline(seconds, seed):
                       "%d vector steps in %.1f s" % (cores, n_env, n_env, k, dt)}
 
 
+def pmc_traffic(n_env, n_task, search):
+    """HBM bytes per launch of the step kernel from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes, gfx950 x2 read correction; scripts/gpu_pmc.sh -> profiles/*pmc_traffic*.json).  Counters cannot
+    be read from inside this process, so the figure is the profiled one for the same workload, or null."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            k = d.get("bench_key", {})
+            want = "2a" if n_task == n_env else "2b"
+            if k.get("workload") == want and k.get("search") == search and k.get("envs_per_gpu") == n_env:
+                for name, v in d["kernels"].items():
+                    if "step_kernel" in name:
+                        return v["traffic_bytes_per_launch_corrected"], os.path.basename(f)
+        except Exception:
+            pass
+    return None, None
+
+
 def main():
     args = parse()
     import torch
@@ -199,6 +218,7 @@ def main():
         kern_us = ev_ms * 1e3 / args.steps
         algo = ALGO_BYTES_PER_ENV_STEP[8] * n_env
         achieved = algo / (kern_us * 1e-6) / 1e9
+        traffic, traffic_src = pmc_traffic(n_env, n_task, search)
         out = {
             "metric": "env-steps/sec (whole node), anymdp |S|=64 |A|=8, 65k envs/GPU",
             "value": total_steps / wall, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
@@ -215,7 +235,7 @@ def main():
                        "exchange": gather_note,
                        "device_error_flags": errs},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "anymdp_step_kernel<search=%s>" % search, "avg_launch_us": kern_us,
                          "algorithmic_bytes_per_launch": algo},
         }
