@@ -360,18 +360,26 @@ __device__ __forceinline__ float xv_sel_opaque(int cond, float lo, float hi) {
 
 __device__ __forceinline__ int linds_row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// y (all NO components, canonical order) of the tile's envs for state registers xr (this lane's 16 components)
+// C fragments of this lane for the observation product: ca[r] = C[jo = c][k = row_of(r, h)] (0 for c >= NO).
+// Loaded once, up front and without a branch (a `c < NO ? load : 0` becomes a branch + vmcnt(0) per MFMA).
 template <int NS, int NO>
-__device__ __forceinline__ void linds_observe_mfma(const LinDSArgs& P, int t, int c, int h,
-                                                   const xv_f32x16& xr, float (&yfull)[NO]) {
+__device__ __forceinline__ void linds_load_c_frag(const LinDSArgs& P, int t, int c, int h, float (&ca)[NS / 2]) {
   const float* cT = P.T.cT + (size_t)t * NS * NO;
-  xv_f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int cc = c < NO ? c : NO - 1;
 #pragma unroll
   for (int r = 0; r < NS / 2; ++r) {
-    const int k = linds_row_of(r, h);
-    const float a = (c < NO) ? cT[k * NO + c] : 0.0f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xr[r], acc, 0, 0, 0);
+    const float v = cT[linds_row_of(r, h) * NO + cc];
+    ca[r] = c < NO ? v : 0.0f;
   }
+}
+
+// y (all NO components, canonical order) of the tile's envs for state registers xr (this lane's 16 components)
+template <int NS, int NO>
+__device__ __forceinline__ void linds_observe_mfma(const LinDSArgs& P, int t, int h, const float (&ca)[NS / 2],
+                                                   const xv_f32x16& xr, float (&yfull)[NO]) {
+  xv_f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < NS / 2; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[r], xr[r], acc, 0, 0, 0);
   const XV_CONST_AS float* y0 = xv_cptr(P.T.y0) + (size_t)t * NO;
   // this lane holds jo = linds_row_of(r', h) for r' < NO/2; the other half of the env holds the rest
 #pragma unroll
@@ -416,27 +424,41 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
   if (INJECT) init_idx = io.init_index[e];
   else init_idx = linds_draw_init(P, gid, n_init);
 
-  // ---- x' = Phi x + Gamma act  (:78-80) ----
+  // ---- all operand fragments first: every load of the step is in flight before the first MFMA ----
   const float* phiT = P.T.phiT + (size_t)t * NS * NS;
   const float* gamT = P.T.gamT + (size_t)t * NA * NS;
-  xv_f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const float* xtv = P.T.xt + (size_t)t * NS;
+  const int cs = c < NS ? c : NS - 1;
+  float pa[NS / 2], pb[NS / 2], ga[NA / 2], ca[NR], xtr[NR];
 #pragma unroll
   for (int kk = 0; kk < NS / 2; ++kk) {
     const int k = 2 * kk + h;
-    const float a = (c < NS) ? phiT[k * NS + c] : 0.0f;
-    const float b = P.x[(size_t)k * N + e];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    const float v = phiT[k * NS + cs];
+    pa[kk] = c < NS ? v : 0.0f;
+    pb[kk] = P.x[(size_t)k * N + e];
   }
+#pragma unroll
+  for (int kk = 0; kk < NA / 2; ++kk) {
+    const float v = gamT[(2 * kk + h) * NS + cs];
+    ga[kk] = c < NS ? v : 0.0f;
+  }
+  linds_load_c_frag<NS, NO>(P, t, c, h, ca);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) xtr[r] = xtv[linds_row_of(r, h)];
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- x' = Phi x + Gamma act  (:78-80) ----
+  xv_f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int kk = 0; kk < NS / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], pb[kk], acc, 0, 0, 0);
   float sa = 0.0f;
 #pragma unroll
   for (int k = 0; k < NA; ++k) sa = fmaf(a_raw[k], a_raw[k], sa);   // :164 cost on the RAW padded action
 #pragma unroll
   for (int kk = 0; kk < NA / 2; ++kk) {
-    const int k = 2 * kk + h;
     const float ar = xv_sel_opaque(h, a_raw[2 * kk], a_raw[2 * kk + 1]);
     const float b = ar < -1.0f ? -1.0f : (ar > 1.0f ? 1.0f : ar);   // :138 clip
-    const float a = (c < NS) ? gamT[k * NS + c] : 0.0f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[kk], b, acc, 0, 0, 0);
   }
   // + Xt + noise on this lane's NR components
   const float noise_scale = sc[4];
@@ -452,12 +474,11 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
       xv_box_muller(w.z, w.w, &zr[4 * rr + 2], &zr[4 * rr + 3]);
     }
   }
-  const float* xtv = P.T.xt + (size_t)t * NS;
   xv_f32x16 xn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int bad = 0;
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
-    float v = acc[r] + xtv[linds_row_of(r, h)];
+    float v = acc[r] + xtr[r];
     v = fmaf(noise_scale, zr[r], v);
     bad |= !(fabsf(v) <= 3.0e38f);
     xn[r] = v;
@@ -467,10 +488,20 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
   float y[NO], ctrack[NO], crep[NO], fobs[NO];
 #pragma unroll
   for (int j = 0; j < NO; ++j) fobs[j] = 0.0f;
-  linds_observe_mfma<NS, NO>(P, t, c, h, xn, y);
+  linds_observe_mfma<NS, NO>(P, t, h, ca, xn, y);
   const int steps_new = steps + 1;                            // :147
-  linds_cmd<NO>(P, t, nf, steps_new - 1 - delay, ctrack);     // :150-151 tracked command
-  linds_cmd<NO>(P, t, nf, steps_new, crep);                   // :168 reported command
+  {
+    // the two lanes of an env share the command work: half 0 evaluates the tracked command cmd(steps-1-delay)
+    // (:150-151), half 1 the reported one cmd(steps) (:168); one __shfl_xor per component exchanges them
+    float cmine[NO];
+    linds_cmd<NO>(P, t, nf, h ? steps_new : steps_new - 1 - delay, cmine);
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+      const float cother = __shfl_xor(cmine[j], 32);
+      ctrack[j] = xv_sel_opaque(h, cmine[j], cother);
+      crep[j] = xv_sel_opaque(h, cother, cmine[j]);
+    }
+  }
   float o_err = linds_err<NO>(P, t, y, ctrack);               // :153
   float sc2 = 0.0f;
 #pragma unroll
@@ -503,7 +534,7 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
       for (int r = 0; r < NR; ++r) xr[r] = x0[linds_row_of(r, h)];   // :117
     }
     float yr[NO], c0[NO];
-    linds_observe_mfma<NS, NO>(P, t, c, h, xr, yr);
+    linds_observe_mfma<NS, NO>(P, t, h, ca, xr, yr);
     linds_cmd<NO>(P, t, nf, 0, c0);                // :120-126
     const float e0 = linds_err<NO>(P, t, yr, c0);
     if (do_reset) {
