@@ -122,12 +122,18 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                      % (args.gpus, args.gpus))
+    if os.environ.get("XV_BENCH_SHARE_GPU"):   # functional test of the N>1 path on a 1-GPU box (not a measurement)
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("XV_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from xenoverse_amd import _lib
     from xenoverse_amd.anymdp import AnyMDPVecEnv
@@ -164,39 +170,53 @@ def main():
             gather = None
             gather_note = "all_gather unavailable: %r" % (ex,)
 
-    def run(k_steps):
+    def run(k_steps, with_gather=False):
         done = 0
         while done < k_steps:
             n = min(P, k_steps - done)
             env.step_many(n, actions, out=ring)
             done += n
-            if gather is not None and n == P:
+            if with_gather and n == P:
                 gather.wait()        # the previous chunk must have left before its buffer is repacked
                 pack_records(ring["obs"], actions, ring["reward"], ring["terminated"], ring["truncated"],
                              out=gather.local)
                 gather.launch()
-        if gather is not None:
+        if with_gather:
             gather.wait()
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup)
-    barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    run(args.steps)
-    e1.record()
-    barrier()
-    wall = time.perf_counter() - t0
-    ev_ms = e0.elapsed_time(e1)           # HIP events on the stream the step kernels were launched on
-    if dist is not None:
-        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=env.device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, ev_ms = float(tt[0]), float(tt[1])
+    def timed_pass(with_gather):
+        run(args.warmup, with_gather)
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        run(args.steps, with_gather)
+        e1.record()
+        barrier()
+        w = time.perf_counter() - t0
+        ms = e0.elapsed_time(e1)          # HIP events on the stream the step kernels were launched on
+        if dist is not None:              # MAX over ranks
+            tt = torch.tensor([w, ms], dtype=torch.float64,
+                              device=env.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            w, ms = float(tt[0]), float(tt[1])
+        return w, ms
+
+    # pass 1 (the reported value): sharded stepping, no data-path collective — envs are independent
+    wall, ev_ms = timed_pass(False)
+    # pass 2 (N > 1): the same with every finished rollout chunk all-gathered to all ranks, overlapped
+    wall_g = None
+    if gather is not None:
+        try:
+            wall_g, _ = timed_pass(True)
+        except Exception as ex:
+            gather_note += "; failed: %r" % (ex,)
     errs = env.check_errors()
 
     fused = None
@@ -241,6 +261,10 @@ def main():
         }
         if fused is not None:
             out["fused_rollout_env_steps_per_s_rank0"] = fused
+        if wall_g is not None:
+            chunks = args.steps // P
+            out["with_allgather"] = {"value": total_steps / wall_g, "unit": "env-steps/s",
+                                     "gathered_GB_per_s_per_rank": chunks * P * n_env * 14 * (world - 1) / wall_g / 1e9}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.seed)
         else:

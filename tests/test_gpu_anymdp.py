@@ -366,3 +366,76 @@ def test_device_philox_kat():
     out = _np(eng.philox(torch.from_numpy(ctrs.view(np.int32)).cuda(), torch.from_numpy(key.view(np.int32)).cuda()))
     assert np.array_equal(out.view(np.uint32), oracle.philox4x32_10(ctrs, key))
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE full size (config 2a): 65,536 envs, one synthetic task per env = 32 GiB of rows in HBM.
+# Too large for the oracle as a whole -> size-independent properties + an oracle check of a subset of envs
+# (the synthetic generator is a pure function of (seed, task index), so the CPU can rebuild just those tasks).
+# ---------------------------------------------------------------------------------------------------
+def test_full_size_config_2a_properties_and_subset_vs_oracle():
+    import ctypes as C
+    from xenoverse_amd import _lib
+    free, total = torch.cuda.mem_get_info()
+    if free < 40 * 2**30:
+        pytest.skip("needs ~34 GiB of free HBM")
+    n_env, S, A, T = 65536, 64, 8, 24
+    seed_tab, seed = 1235, 1234
+    env = AnyMDPVecEnv(n_env, seed=seed, autoreset_mode="same_step")
+    d = env.device
+    NB = 4
+    t = dict(S=S, A=A, s0_max=4,
+             rows=torch.empty((n_env, S, A, NB, 32), dtype=torch.float64, device=d),
+             state_map=torch.empty((n_env, S), dtype=torch.int32, device=d),
+             term_mask=torch.empty((n_env, 1), dtype=torch.int64, device=d),
+             s0_cdf=torch.empty((n_env, 4), dtype=torch.float64, device=d),
+             s0_ids=torch.empty((n_env, 4), dtype=torch.int32, device=d),
+             max_steps=torch.empty(n_env, dtype=torch.int32, device=d))
+    _lib.check(env.lib.xv_anymdp_synth_tasks(env.engine.handle, seed_tab, 0, n_env, S, A, 4, *[_lib.ptr(t[k]) for k in
+               ("rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")]))
+    env.set_task(t, env_task_index=torch.arange(n_env, dtype=torch.int32, device=d))
+    # oracle for a scattered subset of envs (first/last waves, a wave in the middle, odd stragglers)
+    sub = np.r_[0:64, 30000:30064, 65472:65536, [777, 4242, 51234]]
+    tabs = [oracle.anymdp_synth(seed=seed_tab, task_index_base=int(i), n_task=1, S=S, A=A, s0_max=4) for i in sub]
+    tab = {k: (np.concatenate([x[k] for x in tabs]) if isinstance(tabs[0][k], np.ndarray) else tabs[0][k]) for k in tabs[0]}
+    ora = oracle.AnyMDPOracle(tab, np.arange(len(sub), dtype=np.int32))
+    tick = env.engine.tick
+    obs, _ = env.reset()
+    for q, i in enumerate(sub):       # the oracle draws with each env's GLOBAL id
+        o1 = oracle.AnyMDPOracle({k: (v[q:q + 1] if isinstance(v, np.ndarray) else v) for k, v in tab.items()}, [0])
+        assert o1.reset(seed, int(i), tick)[0] == int(obs[i])
+        ora.state[q], ora.steps[q], ora.need_reset[q] = o1.state[0], 0, 0
+    g = torch.Generator(device=d); g.manual_seed(5)
+    term_mask = t["term_mask"][:, 0]
+    n_done = 0
+    for step in range(T):
+        a = torch.randint(0, A, (n_env,), generator=g, device=d, dtype=torch.int32)
+        tick = env.engine.tick
+        s_before, st_before, _ = env.get_state()
+        obs, r, term, trunc, info = env.step(a)
+        s_after, st_after, _ = env.get_state()
+        done = term | trunc
+        # -- properties over all 65,536 envs --
+        assert int(obs.min()) >= 0 and int(obs.max()) < S
+        fo = info["final_obs"]
+        inv = torch.empty_like(t["state_map"]); inv.scatter_(1, t["state_map"].long(), torch.arange(S, device=d, dtype=torch.int32).expand(n_env, S))
+        s_next = torch.where(done, inv.gather(1, fo.clamp(min=0).long()[:, None])[:, 0], s_after)   # inner next state
+        assert torch.equal(((term_mask >> s_next.long()) & 1).bool(), term)               # terminated <=> s' in s_e
+        assert torch.equal(trunc, (st_before + 1) >= t["max_steps"])                       # truncation rule
+        assert torch.equal(st_after, torch.where(done, torch.zeros_like(st_after), st_before + 1))
+        assert bool(((s_after[done] >= 0) & (s_after[done] <= 2)).all())                   # resets land in s_0 = {0,1,2}
+        assert torch.equal(obs, t["state_map"].gather(1, s_after.long()[:, None])[:, 0])   # obs = state_mapping[state]
+        lo = torch.clamp(s_before - 33, min=0); hi = torch.clamp(s_before + 17, max=S)    # band of the synthetic rows
+        assert bool(((s_next >= lo) & (s_next < hi)).all())
+        assert bool(torch.isfinite(r).all())
+        n_done += int(done.sum())
+        # -- subset vs oracle, draw for draw --
+        for q, i in enumerate(sub):
+            o1 = oracle.AnyMDPOracle({k: (v[q:q + 1] if isinstance(v, np.ndarray) else v) for k, v in tab.items()}, [0])
+            o1.state[0], o1.steps[0], o1.need_reset[0] = ora.state[q], ora.steps[q], 0
+            eo, er, ergt, eterm, etrunc, efo = o1.step(seed, int(i), tick, [int(a[i])], 2)
+            assert eo[0] == int(obs[i]) and eterm[0] == int(term[i]) and etrunc[0] == int(trunc[i])
+            assert efo[0] == int(fo[i]) and abs(er[0] - float(r[i])) <= 1e-5 * abs(er[0]) + 2e-6
+            ora.state[q], ora.steps[q] = o1.state[0], o1.steps[0]
+    assert n_done > 65536 and env.check_errors() == 0
+    env.close()
