@@ -152,6 +152,25 @@ int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const int32_t* ac
 int xv_anymdp_rollout(xv_anymdp* h, int T, const int32_t* actions, int32_t* obs, float* reward,
                       float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs);
 
+/* POMDP / multi-token POMDP (task_type "POMDP", "MTPOMDP"; anymdp_env.py:39-44,116-128,148-157;
+ * task_sampler.py:67-118).  Observations are d_obs categorical draws from observation_transition[k][state]
+ * (n_obs symbols each); an action is d_act tokens applied in turn by single_step, rewards summed, stopping at
+ * the first termination.  obs_cdf: double [n_task][d_obs][S][n_obs] inclusive CDF rows (host fp64, as
+ * numpy.random.choice forms them).  After this call use the *_tokens entry points:
+ *   action int32[n_env][d_act];  obs / final_obs int32[n_env][d_obs]
+ *   injected draws: u double[d_act][n_env], z float[d_act][n_env] (one pair per token), u_obs double[d_obs][n_env]
+ *   (observation after the step), u_reset double[n_env], u_obs_reset double[d_obs][n_env] (used if the env resets) */
+int xv_anymdp_set_observation_model(xv_anymdp* h, int n_obs, int d_obs, int d_act, const double* obs_cdf);
+int xv_anymdp_reset_tokens(xv_anymdp* h, const uint8_t* mask, int32_t* obs);
+int xv_anymdp_reset_tokens_injected(xv_anymdp* h, const uint8_t* mask, const double* u_reset,
+                                    const double* u_obs_reset, int32_t* obs);
+int xv_anymdp_step_tokens(xv_anymdp* h, const int32_t* action, int32_t* obs, float* reward, float* reward_gt,
+                          uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int autoreset_mode);
+int xv_anymdp_step_tokens_injected(xv_anymdp* h, const int32_t* action, const double* u, const float* z,
+                                   const double* u_obs, const double* u_reset, const double* u_obs_reset,
+                                   int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated,
+                                   uint8_t* truncated, int32_t* final_obs, int autoreset_mode);
+
 /* How s' = upper_bound(cdf row, u) is evaluated; both modes return the same index (parity-tested).
  *   AUTO    FENCE when available (S <= 64, s0_max <= 4, observation ids < 256), else BINARY
  *   BINARY  per-lane binary search over the row's CDF entries in global memory (any S), then a

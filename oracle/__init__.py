@@ -376,3 +376,61 @@ class MazeOracle(object):
         c = np.zeros((self.n_env, 3), np.float32)
         lib().xo_maze_render(C.byref(self._h), _p(f), _p(c), C.c_int(n_threads))
         return f, c
+
+
+# ---------------------------------------------------------------------------------------------------
+# AnyMDP POMDP / MTPOMDP
+# ---------------------------------------------------------------------------------------------------
+class _AnyMDPTokStruct(C.Structure):
+    _fields_ = [("m", C.c_void_p), ("n_obs", C.c_int), ("d_obs", C.c_int), ("d_act", C.c_int), ("obs_cdf", C.c_void_p)]
+
+
+class AnyMDPTokOracle(AnyMDPOracle):
+    """POMDP / multi-token POMDP on top of AnyMDPOracle.  obs_cdf float64[n_task, d_obs, S, n_obs]."""
+
+    def __init__(self, tables, env_task, obs_cdf, d_act):
+        super().__init__(tables, env_task)
+        self.obs_cdf = np.ascontiguousarray(obs_cdf, np.float64)
+        _, self.d_obs, _, self.n_obs = self.obs_cdf.shape
+        self.d_act = int(d_act)
+        self._t = _AnyMDPTokStruct(C.cast(C.pointer(self._h), C.c_void_p), self.n_obs, self.d_obs, self.d_act,
+                                   _p(self.obs_cdf))
+
+    def _touts(self):
+        n = self.n_env
+        return (np.zeros((n, self.d_obs), np.int32), np.zeros(n, np.float32), np.zeros(n, np.float32),
+                np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.full((n, self.d_obs), -1, np.int32))
+
+    def tok_reset_injected(self, u_reset, u_obs_reset, mask=None):
+        obs = np.full((self.n_env, self.d_obs), -1, np.int32)
+        ur = np.ascontiguousarray(u_reset, np.float64)
+        uo = np.ascontiguousarray(u_obs_reset, np.float64).reshape(self.d_obs, self.n_env)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        lib().xo_anymdp_tok_reset_injected(C.byref(self._t), _p(m), _p(ur), _p(uo), _p(obs))
+        return obs
+
+    def tok_reset(self, seed, gid_base, tick, mask=None):
+        obs = np.full((self.n_env, self.d_obs), -1, np.int32)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        lib().xo_anymdp_tok_reset(C.byref(self._t), C.c_uint64(seed), C.c_uint64(gid_base), C.c_uint64(tick), _p(m), _p(obs))
+        return obs
+
+    def tok_step_injected(self, action, u, z, u_obs, u_reset, u_obs_reset, mode):
+        obs, rew, rgt, term, trunc, fobs = self._touts()
+        n = self.n_env
+        a = np.ascontiguousarray(action, np.int32).reshape(n, self.d_act)
+        u = np.ascontiguousarray(u, np.float64).reshape(self.d_act, n)
+        z = np.ascontiguousarray(z, np.float32).reshape(self.d_act, n)
+        uo = np.ascontiguousarray(u_obs, np.float64).reshape(self.d_obs, n)
+        ur = np.ascontiguousarray(u_reset, np.float64)
+        uor = np.ascontiguousarray(u_obs_reset, np.float64).reshape(self.d_obs, n)
+        lib().xo_anymdp_tok_step_injected(C.byref(self._t), _p(a), _p(u), _p(z), _p(uo), _p(ur), _p(uor), _p(obs),
+                                          _p(rew), _p(rgt), _p(term), _p(trunc), _p(fobs), C.c_int(mode))
+        return obs, rew, rgt, term, trunc, fobs
+
+    def tok_step(self, seed, gid_base, tick, action, mode):
+        obs, rew, rgt, term, trunc, fobs = self._touts()
+        a = np.ascontiguousarray(action, np.int32).reshape(self.n_env, self.d_act)
+        lib().xo_anymdp_tok_step(C.byref(self._t), C.c_uint64(seed), C.c_uint64(gid_base), C.c_uint64(tick), _p(a),
+                                 _p(obs), _p(rew), _p(rgt), _p(term), _p(trunc), _p(fobs), C.c_int(mode))
+        return obs, rew, rgt, term, trunc, fobs

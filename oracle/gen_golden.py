@@ -142,7 +142,77 @@ def gen_anymdp_one(name, task, n_tuples=4096, n_traj=1536, seed0=1000):
           "episodes ended:", int((tr_term | tr_trunc).sum()), "truncations:", int(tr_trunc.sum()))
 
 
+def gen_anymdp_tok_one(name, task, T=768, seed0=31000):
+    """POMDP / MTPOMDP: a step()/reset() trajectory with the draws replayed in the reference's call order
+    (per action token: choice, normal; then the observation choices; anymdp_env.py:116-128,148-157)."""
+    AnyMDPEnv, _ = _refimport.anymdp()
+    import xenoverse.anymdp.anymdp_env as envmod
+    env = AnyMDPEnv(max_steps=5000)
+    env.set_task(task)
+    mt = task["task_type"] == "MTPOMDP"
+    da = int(task["da"]) if mt else 1
+    do = int(task["do"]) if mt else 1
+    na, n = int(task["na"]), len(task["state_mapping"])
+    s_e = set(int(x) for x in np.asarray(task["s_e"]).reshape(-1))
+    cdfT = np.cumsum(task["transition"], -1)
+    cdfT = cdfT / np.where(cdfT[..., -1:] == 0, 1, cdfT[..., -1:])
+    inject = {"seed": 0}
+    envmod.pseudo_random_seed = lambda *a, **k: inject["seed"]
+    rng = np.random.RandomState(seed0)
+
+    def ref_reset(seed):
+        inject["seed"] = int(seed)
+        obs, info = env.reset()
+        rs = np.random.RandomState(int(seed))
+        u_r = rs.random_sample()
+        u_o = np.array([rs.random_sample() for _ in range(do)])
+        return np.atleast_1d(np.asarray(obs, np.int64)), u_r, u_o
+
+    acts = rng.randint(0, na, (T, da)).astype(np.int64)
+    U = np.full((T, da), 0.5); Z = np.zeros((T, da)); UO = np.zeros((T, do)); UR = np.zeros(T); UOR = np.zeros((T, do))
+    obs = np.zeros((T, do), np.int64); rew = np.zeros(T); rgt = np.zeros(T)
+    term = np.zeros(T, np.uint8); trunc = np.zeros(T, np.uint8); steps = np.zeros(T, np.int64)
+    state = np.zeros(T, np.int64); reset_obs = np.full((T, do), -1, np.int64); set_steps = np.full(T, -1, np.int64)
+    init_obs, init_ur, init_uo = ref_reset(seed0 + 7)
+    init_state = int(env._state)
+    for t in range(T):
+        if t == T // 3:
+            env.steps = int(np.ceil(float(task["max_steps"]))) - 3
+            set_steps[t] = env.steps
+        s_cur = int(env._state)
+        np.random.seed(seed0 + 100 + t)
+        o, r, te, tr, info = env.step(acts[t] if mt else int(acts[t, 0]))
+        rs = np.random.RandomState(seed0 + 100 + t)
+        for k in range(da):   # replay in the reference's order, stopping where its token loop stopped
+            U[t, k] = rs.random_sample(); Z[t, k] = rs.standard_normal()
+            s_cur = int(np.searchsorted(cdfT[s_cur, acts[t, k]], U[t, k], side="right"))
+            if s_cur in s_e:
+                break
+        assert s_cur == int(env._state)
+        UO[t] = [rs.random_sample() for _ in range(do)]
+        obs[t] = np.atleast_1d(np.asarray(o, np.int64)); rew[t] = r; rgt[t] = info["reward_gt"]
+        term[t] = te; trunc[t] = tr; steps[t] = info["steps"]; state[t] = env._state
+        if te or tr:
+            reset_obs[t], UR[t], UOR[t] = ref_reset(seed0 + 50000 + t)
+    out = _task_arrays(task)
+    obsT = np.stack([np.asarray(m, np.float64) for m in task["observation_transition"]]) if mt else \
+        np.asarray(task["observation_transition"], np.float64)[None]
+    out.update(no=np.int64(task["no"]), do=np.int64(do), da=np.int64(da), is_mt=np.int64(mt),
+               observation_transition=obsT, tr_a=acts, tr_u=U, tr_z=Z, tr_uo=UO, tr_ur=UR, tr_uor=UOR, tr_obs=obs,
+               tr_r=rew, tr_rgt=rgt, tr_term=term, tr_trunc=trunc, tr_steps=steps, tr_state=state,
+               tr_reset_obs=reset_obs, tr_set_steps=set_steps, init_obs=init_obs, init_ur=np.float64(init_ur),
+               init_uo=init_uo, init_state=np.int64(init_state))
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; type", task["task_type"], "da", da, "do", do,
+          "ended:", int((term | trunc).sum()), "trunc:", int(trunc.sum()))
+
+
 def gen_anymdp():
+    gen_anymdp_tok_one("anymdptok_pomdp_16x4_seed5", sample_ref_tasks.get(16, 4, 5, "pomdp"))
+    gen_anymdp_tok_one("anymdptok_mtpomdp_16x4_seed6", sample_ref_tasks.get(16, 4, 6, "mtpomdp"), seed0=47000)
+    # seed 0's MDP has terminal states (s_e = [4, 5, 11]): exercises the early break of the token loop
+    gen_anymdp_tok_one("anymdptok_mtpomdp_16x4_seed0", sample_ref_tasks.get(16, 4, 0, "mtpomdp"), seed0=53000)
     for seed in range(4):
         task = sample_ref_tasks.get(16, 4, seed)
         gen_anymdp_one("anymdp_16x4_seed%d" % seed, task, seed0=1000 + 7919 * seed)

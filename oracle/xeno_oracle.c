@@ -1047,3 +1047,136 @@ void xo_maze_render(const xo_maze* h, uint8_t* frames, float* command_rgb, int n
     }
   }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * AnyMDP POMDP / MTPOMDP — anymdp_env.py:112-132 (token loop :116-126) and get_observation :148-157.
+ * Draw order of the reference within one step(): per action token (u, z), then d_obs observation uniforms;
+ * a reset draws the s_0 uniform, then d_obs observation uniforms.
+ * Philox purposes (free-running): token k -> 32+k (words 0,1: u; 2,3: z); observation token k -> 64+k
+ * (words 0,1: after a step; words 2,3: after a reset); s_0 -> 1.
+ * ---------------------------------------------------------------------------------------------- */
+static void tok_observe(const xo_anymdp_tok* h, int i, const double* u_obs /*[d_obs][n_env]*/, int32_t* obs) {
+  const xo_anymdp* m = h->m;
+  const int t = m->env_task[i], s = m->state[i];
+  for (int k = 0; k < h->d_obs; ++k) {
+    const double* row = h->obs_cdf + ((((size_t)t * h->d_obs + k) * m->S) + s) * (size_t)h->n_obs;
+    obs[(size_t)i * h->d_obs + k] = xo_upper_bound(row, h->n_obs, u_obs[(size_t)k * m->n_env + i]); /* :150-157 */
+  }
+}
+
+static void tok_reset_one(xo_anymdp_tok* h, int i, double u_reset, const double* u_obs_reset, int32_t* obs) {
+  anymdp_reset_one(h->m, i, u_reset, 0);
+  if (obs) tok_observe(h, i, u_obs_reset, obs);
+}
+
+void xo_anymdp_tok_reset_injected(xo_anymdp_tok* h, const uint8_t* mask, const double* u_reset,
+                                  const double* u_obs_reset, int32_t* obs) {
+  for (int i = 0; i < h->m->n_env; ++i)
+    if (!mask || mask[i]) tok_reset_one(h, i, u_reset[i], u_obs_reset, obs);
+}
+
+static void tok_step_one(xo_anymdp_tok* h, int i, const int32_t* action, const double* u, const float* z,
+                         const double* u_obs, double u_reset, const double* u_obs_reset, int32_t* obs,
+                         float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated,
+                         int32_t* final_obs, int mode) {
+  xo_anymdp* m = h->m;
+  const int S = m->S, A = m->A, N = m->n_env, t = m->env_task[i];
+  if (final_obs) for (int k = 0; k < h->d_obs; ++k) final_obs[(size_t)i * h->d_obs + k] = -1;
+  if (mode == 1 && m->need_reset[i]) {
+    tok_reset_one(h, i, u_reset, u_obs_reset, obs);
+    reward[i] = 0.0f; reward_gt[i] = 0.0f; terminated[i] = 0; truncated[i] = 0;
+    return;
+  }
+  if (mode == 0 && is_terminal(m, t, m->state[i])) { /* reference raises (:95-96) */
+    m->err_flags |= 2u;
+    tok_observe(h, i, u_obs, obs);
+    reward[i] = 0.0f; reward_gt[i] = 0.0f; terminated[i] = 1;
+    truncated[i] = (uint8_t)(m->steps[i] >= m->max_steps[t]);
+    return;
+  }
+  const int steps = m->steps[i] + 1;            /* :113 once per step, not per token */
+  const int trunc = steps >= m->max_steps[t];   /* :114 */
+  float rsum = 0.0f, rgsum = 0.0f;
+  int term = 0, s = m->state[i];
+  for (int k = 0; k < h->d_act; ++k) {          /* :120-126 */
+    int a = action[(size_t)i * h->d_act + k];
+    if (a < 0 || a >= A) { m->err_flags |= 1u; a = a < 0 ? 0 : A - 1; }
+    const size_t row = (((size_t)t * S + s) * A + a) * (size_t)S;
+    const int s2 = xo_upper_bound(m->cdf + row, S, u[(size_t)k * N + i]);
+    const float r_gt = m->rs[(row + s2) * 2], sg = m->rs[(row + s2) * 2 + 1];
+    rsum = rsum + fmaf(sg, z[(size_t)k * N + i], r_gt);
+    rgsum = rgsum + r_gt;
+    s = s2;
+    if (is_terminal(m, t, s2)) { term = 1; break; }
+  }
+  m->state[i] = s; m->steps[i] = steps;
+  reward[i] = rsum; reward_gt[i] = rgsum; terminated[i] = (uint8_t)term; truncated[i] = (uint8_t)trunc;
+  tok_observe(h, i, u_obs, obs);
+  if (term || trunc) {
+    if (mode == 2) {
+      if (final_obs) for (int k = 0; k < h->d_obs; ++k) final_obs[(size_t)i * h->d_obs + k] = obs[(size_t)i * h->d_obs + k];
+      tok_reset_one(h, i, u_reset, u_obs_reset, obs);
+    } else if (mode == 1) {
+      m->need_reset[i] = 1;
+    }
+  }
+}
+
+void xo_anymdp_tok_step_injected(xo_anymdp_tok* h, const int32_t* action, const double* u, const float* z,
+                                 const double* u_obs, const double* u_reset, const double* u_obs_reset,
+                                 int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated,
+                                 uint8_t* truncated, int32_t* final_obs, int mode) {
+  for (int i = 0; i < h->m->n_env; ++i)
+    tok_step_one(h, i, action, u, z, u_obs, u_reset[i], u_obs_reset, obs, reward, reward_gt, terminated,
+                 truncated, final_obs, mode);
+}
+
+static void tok_draws(const xo_anymdp_tok* h, uint64_t seed, uint64_t gid, uint64_t tick, int i, double* u,
+                      float* z, double* u_obs, double* u_reset, double* u_obs_reset) {
+  const int N = h->m->n_env;
+  uint32_t w[4];
+  for (int k = 0; k < h->d_act; ++k) {
+    xo_env_draw(seed, gid, tick, 32u + (uint32_t)k, w);
+    u[(size_t)k * N + i] = xo_u53(w[0], w[1]);
+    xo_box_muller(w[2], w[3], &z[(size_t)k * N + i], 0);
+  }
+  for (int k = 0; k < h->d_obs; ++k) {
+    xo_env_draw(seed, gid, tick, 64u + (uint32_t)k, w);
+    u_obs[(size_t)k * N + i] = xo_u53(w[0], w[1]);
+    u_obs_reset[(size_t)k * N + i] = xo_u53(w[2], w[3]);
+  }
+  xo_env_draw(seed, gid, tick, 1, w);
+  u_reset[i] = xo_u53(w[0], w[1]);
+}
+
+void xo_anymdp_tok_reset(xo_anymdp_tok* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const uint8_t* mask,
+                         int32_t* obs) {
+  const int N = h->m->n_env;
+  double* uo = (double*)malloc(sizeof(double) * (size_t)h->d_obs * N);
+  for (int i = 0; i < N; ++i) {
+    if (mask && !mask[i]) continue;
+    uint32_t w[4];
+    for (int k = 0; k < h->d_obs; ++k) {
+      xo_env_draw(seed, gid_base + (uint64_t)i, tick, 64u + (uint32_t)k, w);
+      uo[(size_t)k * N + i] = xo_u53(w[2], w[3]);
+    }
+    xo_env_draw(seed, gid_base + (uint64_t)i, tick, 1, w);
+    tok_reset_one(h, i, xo_u53(w[0], w[1]), uo, obs);
+  }
+  free(uo);
+}
+
+void xo_anymdp_tok_step(xo_anymdp_tok* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const int32_t* action,
+                        int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated,
+                        int32_t* final_obs, int mode) {
+  const int N = h->m->n_env;
+  double* u = (double*)malloc(sizeof(double) * (size_t)h->d_act * N);
+  float* z = (float*)malloc(sizeof(float) * (size_t)h->d_act * N);
+  double* uo = (double*)malloc(sizeof(double) * (size_t)h->d_obs * N);
+  double* uor = (double*)malloc(sizeof(double) * (size_t)h->d_obs * N);
+  double* ur = (double*)malloc(sizeof(double) * (size_t)N);
+  for (int i = 0; i < N; ++i) tok_draws(h, seed, gid_base + (uint64_t)i, tick, i, u, z, uo, ur, uor);
+  xo_anymdp_tok_step_injected(h, action, u, z, uo, ur, uor, obs, reward, reward_gt, terminated, truncated,
+                              final_obs, mode);
+  free(u); free(z); free(uo); free(uor); free(ur);
+}

@@ -64,6 +64,23 @@ void xo_anymdp_transition_gt(const xo_anymdp* h, const int32_t* action, double* 
 void xo_anymdp_synth(uint64_t seed, int64_t task_index_base, int n_task, int S, int A, int s0_max,
                      double* cdf, float* rs, int32_t* state_map, uint64_t* term_mask, double* s0_cdf,
                      int32_t* s0_ids, int32_t* max_steps);
+/* POMDP / MTPOMDP (anymdp_env.py:116-128,148-157): d_act action tokens per step, d_obs observation draws */
+typedef struct {
+  xo_anymdp* m;
+  int n_obs, d_obs, d_act;
+  const double* obs_cdf; /* [n_task][d_obs][S][n_obs] */
+} xo_anymdp_tok;
+void xo_anymdp_tok_reset_injected(xo_anymdp_tok* h, const uint8_t* mask, const double* u_reset,
+                                  const double* u_obs_reset, int32_t* obs);
+void xo_anymdp_tok_step_injected(xo_anymdp_tok* h, const int32_t* action, const double* u, const float* z,
+                                 const double* u_obs, const double* u_reset, const double* u_obs_reset,
+                                 int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated,
+                                 uint8_t* truncated, int32_t* final_obs, int mode);
+void xo_anymdp_tok_reset(xo_anymdp_tok* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const uint8_t* mask,
+                         int32_t* obs);
+void xo_anymdp_tok_step(xo_anymdp_tok* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const int32_t* action,
+                        int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated,
+                        int32_t* final_obs, int mode);
 int xo_max_threads(void);
 
 /* ---------------------------------------------------------------------------------------------

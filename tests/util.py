@@ -81,3 +81,16 @@ def frame_mismatch(a, b):
     """fraction of channel values that differ, and the largest absolute difference"""
     d = np.abs(a.astype(np.int32) - b.astype(np.int32))
     return float(np.mean(d > 0)), int(d.max())
+
+
+def load_anymdp_tok_golden(path):
+    g = dict(np.load(path, allow_pickle=False))
+    mt = bool(g["is_mt"])
+    task = dict(ns=int(g["ns"]), na=int(g["na"]), max_steps=float(g["max_steps"]), state_mapping=g["state_mapping"],
+                task_type="MTPOMDP" if mt else "POMDP", s_0=g["s_0"], s_0_prob=g["s_0_prob"], s_e=g["s_e"],
+                transition=g["transition"], reward=g["reward"], reward_noise=g["reward_noise"], no=int(g["no"]))
+    if mt:
+        task.update(do=int(g["do"]), da=int(g["da"]), observation_transition=[m for m in g["observation_transition"]])
+    else:
+        task["observation_transition"] = g["observation_transition"][0]
+    return g, task

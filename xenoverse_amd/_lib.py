@@ -33,6 +33,11 @@ SIGNATURES = {
     "xv_anymdp_step_many": [c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int],
     "xv_anymdp_rollout": [c_void_p, c_int] + [c_void_p] * 7,
     "xv_anymdp_set_search": [c_void_p, c_int],
+    "xv_anymdp_set_observation_model": [c_void_p, c_int, c_int, c_int, c_void_p],
+    "xv_anymdp_reset_tokens": [c_void_p, c_void_p, c_void_p],
+    "xv_anymdp_reset_tokens_injected": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "xv_anymdp_step_tokens": [c_void_p] + [c_void_p] * 7 + [c_int],
+    "xv_anymdp_step_tokens_injected": [c_void_p] + [c_void_p] * 12 + [c_int],
     "xv_anymdp_get_state": [c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_anymdp_set_state": [c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_anymdp_transition_gt": [c_void_p, c_void_p, c_void_p],

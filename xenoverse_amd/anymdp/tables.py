@@ -139,3 +139,30 @@ def build_tables(tasks, s0_max=None, validate=True):
     return dict(S=S, A=A, s0_max=int(s0_max), cdf=cdf, rs=rs, rows=to_blocked(cdf, rs),
                 state_map=state_map, term_mask=term_mask,
                 s0_cdf=s0_cdf, s0_ids=s0_ids, max_steps=max_steps, obs_space=obs_space)
+
+
+def build_obs_tables(tasks, S):
+    """POMDP / MTPOMDP observation model -> (obs_cdf float64[n_task, d_obs, S, n_obs], n_obs, d_obs, d_act).
+    task["observation_transition"]: f64[n, no] (POMDP, task_sampler.py:78-87) or a list of `do` such matrices
+    (MTPOMDP, :103-117); CDF rows formed as numpy.random.choice forms them (anymdp_env.py:150-157)."""
+    if isinstance(tasks, dict):
+        tasks = [tasks]
+    ttype = tasks[0]["task_type"]
+    if any(t["task_type"] != ttype for t in tasks):
+        raise ValueError("all tasks of one batch must share the task_type")
+    if ttype == "MTPOMDP":
+        d_obs, d_act = int(tasks[0]["do"]), int(tasks[0]["da"])
+    elif ttype == "POMDP":
+        d_obs, d_act = 1, 1
+    else:
+        raise ValueError("task_type %r has no observation model" % (ttype,))
+    n_obs = int(tasks[0]["no"])
+    out = np.ones((len(tasks), d_obs, S, n_obs), np.float64)
+    for i, t in enumerate(tasks):
+        mats = t["observation_transition"] if ttype == "MTPOMDP" else [t["observation_transition"]]
+        if len(mats) != d_obs or int(t["no"]) != n_obs or (ttype == "MTPOMDP" and int(t["da"]) != d_act):
+            raise ValueError("all tasks of one batch must share no / do / da")
+        for k, m in enumerate(mats):
+            m = np.asarray(m, np.float64)
+            out[i, k, :m.shape[0], :] = row_cdf(m)
+    return out, n_obs, d_obs, d_act

@@ -76,6 +76,8 @@ struct xv_anymdp {
   xv_engine* eng;
   AnyMDPArgs a;
   int search;  // XV_ANYMDP_SEARCH_*
+  const double* obs_cdf;   // observation model (POMDP / MTPOMDP), nullptr for MDP
+  int n_obs, d_obs, d_act;
 };
 
 __device__ __forceinline__ bool anymdp_is_term(const AnyMDPArgs& P, int t, uint64_t tm0, int s) {
@@ -420,6 +422,157 @@ __global__ __launch_bounds__(256) void anymdp_tgt_kernel(AnyMDPArgs P, const int
 }
 
 // ------------------------------------------------------------------------------------------------
+// POMDP / multi-token POMDP (anymdp_env.py:116-128 token loop, :148-157 observation draws).  One lane per env,
+// per-lane binary searches: d_act transition draws, then d_obs observation draws from obs_cdf[t][k][s][:].
+// Draw order and Philox purposes as oracle/xeno_oracle.c (tok_*).
+// ------------------------------------------------------------------------------------------------
+struct AnyMDPTokArgs {
+  const double* obs_cdf;   // [n_task][d_obs][S][n_obs]
+  int n_obs, d_obs, d_act;
+};
+
+struct AnyMDPTokIO {
+  const int32_t* action;       // [n_env][d_act]
+  const double* u;             // [d_act][n_env]   (INJECT)
+  const float* z;              // [d_act][n_env]
+  const double* u_obs;         // [d_obs][n_env]
+  const double* u_reset;       // [n_env]
+  const double* u_obs_reset;   // [d_obs][n_env]
+  int32_t* obs;                // [n_env][d_obs]
+  float* reward;
+  float* reward_gt;
+  uint8_t* terminated;
+  uint8_t* truncated;
+  int32_t* final_obs;          // [n_env][d_obs], nullable
+};
+
+__device__ __forceinline__ int xv_upper_bound_f64(const double* row, int n, double u) {
+  int lo = 0, m = n;
+  while (m > 0) {
+    const int half = m >> 1;
+    if (row[lo + half] <= u) { lo += half + 1; m -= half + 1; }
+    else m = half;
+  }
+  return lo < n - 1 ? lo : n - 1;
+}
+
+// observation tokens of inner state s (after a step: RESET=false, after a reset: RESET=true)
+template <bool INJECT, bool RESET>
+__device__ __forceinline__ void anymdp_tok_observe(const AnyMDPArgs& P, const AnyMDPTokArgs& K, const AnyMDPTokIO& io,
+                                                   int i, int t, int s, uint64_t gid, int32_t* out) {
+  for (int k = 0; k < K.d_obs; ++k) {
+    double u;
+    if (INJECT) {
+      u = (RESET ? io.u_obs_reset : io.u_obs)[(size_t)k * P.n_env + i];
+    } else {
+      const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick, 64u + (uint32_t)k);
+      u = RESET ? xv_u53(w.z, w.w) : xv_u53(w.x, w.y);
+    }
+    const double* row = K.obs_cdf + ((((size_t)t * K.d_obs + k) * P.S) + s) * (size_t)K.n_obs;
+    out[(size_t)i * K.d_obs + k] = xv_upper_bound_f64(row, K.n_obs, u);
+  }
+}
+
+template <bool INJECT>
+__global__ __launch_bounds__(256) void anymdp_tok_step_kernel(AnyMDPArgs P, AnyMDPTokArgs K, AnyMDPTokIO io, int mode) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n_env) return;
+  const int S = P.S, A = P.A, N = P.n_env;
+  const int t = P.env_task[i];
+  const uint64_t gid = P.gid_base + (uint64_t)i;
+  const uint64_t tm0 = P.term_mask[(size_t)t * P.words];
+  const int max_steps = P.max_steps[t];
+  int s = P.state[i], steps = P.steps[i], nr = P.need_reset[i];
+  uint32_t err = 0;
+  if (io.final_obs) for (int k = 0; k < K.d_obs; ++k) io.final_obs[(size_t)i * K.d_obs + k] = -1;
+  float rsum = 0.0f, rgsum = 0.0f;
+  int term = 0, trunc = 0;
+  bool do_reset = false;
+  if (mode == XV_AUTORESET_NEXT_STEP && nr) {
+    do_reset = true;
+  } else if (mode == XV_AUTORESET_DISABLED && anymdp_is_term(P, t, tm0, s)) {
+    err |= XV_DEVERR_STEP_TERMINAL;   // reference raises (:95-96)
+    anymdp_tok_observe<INJECT, false>(P, K, io, i, t, s, gid, io.obs);
+    term = 1; trunc = steps >= max_steps;
+  } else {
+    steps += 1;                       // :113, once per step
+    trunc = steps >= max_steps;       // :114
+    for (int k = 0; k < K.d_act; ++k) {   // :120-126
+      int a = io.action[(size_t)i * K.d_act + k];
+      if (a < 0 || a >= A) { err |= XV_DEVERR_ACTION_RANGE; a = a < 0 ? 0 : A - 1; }
+      double u;
+      float z;
+      if (INJECT) {
+        u = io.u[(size_t)k * N + i];
+        z = io.z[(size_t)k * N + i];
+      } else {
+        const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick, 32u + (uint32_t)k);
+        u = xv_u53(w.x, w.y);
+        z = xv_normal1(w.z, w.w);
+      }
+      const uint32_t rowidx = ((uint32_t)t * S + s) * A + a;
+      int lo = 0, m = S;
+      while (m > 0) {
+        const int half = m >> 1;
+        if (*anymdp_cdf_ptr(P, rowidx, lo + half) <= u) { lo += half + 1; m -= half + 1; }
+        else m = half;
+      }
+      const int s2 = lo < S - 1 ? lo : S - 1;
+      const float2 rsv = anymdp_rs(P, rowidx, s2);
+      rsum = rsum + fmaf(rsv.y, z, rsv.x);
+      rgsum = rgsum + rsv.x;
+      s = s2;
+      if (anymdp_is_term(P, t, tm0, s2)) { term = 1; break; }
+    }
+    anymdp_tok_observe<INJECT, false>(P, K, io, i, t, s, gid, io.obs);
+    if (term || trunc) {
+      if (mode == XV_AUTORESET_SAME_STEP) {
+        if (io.final_obs)
+          for (int k = 0; k < K.d_obs; ++k) io.final_obs[(size_t)i * K.d_obs + k] = io.obs[(size_t)i * K.d_obs + k];
+        do_reset = true;
+      } else if (mode == XV_AUTORESET_NEXT_STEP) {
+        nr = 1;
+      }
+    }
+  }
+  if (do_reset) {
+    double ur;
+    if (INJECT) ur = io.u_reset[i];
+    else {
+      const xv_u32x4 v = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_RESET);
+      ur = xv_u53(v.x, v.y);
+    }
+    s = anymdp_draw_s0(P, t, ur);
+    steps = 0;
+    nr = 0;
+    anymdp_tok_observe<INJECT, true>(P, K, io, i, t, s, gid, io.obs);
+  }
+  P.state[i] = s; P.steps[i] = steps; P.need_reset[i] = (uint8_t)nr;
+  io.reward[i] = rsum; io.reward_gt[i] = rgsum;
+  io.terminated[i] = (uint8_t)term; io.truncated[i] = (uint8_t)trunc;
+  if (err) atomicOr(P.err, err);
+}
+
+template <bool INJECT>
+__global__ __launch_bounds__(256) void anymdp_tok_reset_kernel(AnyMDPArgs P, AnyMDPTokArgs K, AnyMDPTokIO io,
+                                                               const uint8_t* mask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n_env) return;
+  if (mask && !mask[i]) return;
+  const int t = P.env_task[i];
+  const uint64_t gid = P.gid_base + (uint64_t)i;
+  double ur;
+  if (INJECT) ur = io.u_reset[i];
+  else {
+    const xv_u32x4 v = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_RESET);
+    ur = xv_u53(v.x, v.y);
+  }
+  const int s = anymdp_draw_s0(P, t, ur);
+  P.state[i] = s; P.steps[i] = 0; P.need_reset[i] = 0;
+  if (io.obs) anymdp_tok_observe<INJECT, true>(P, K, io, i, t, s, gid, io.obs);
+}
+
+// ------------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int A, int s0_max,
@@ -442,6 +595,7 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
   }
   h->eng = e;
   h->search = XV_ANYMDP_SEARCH_AUTO;
+  h->obs_cdf = nullptr; h->n_obs = 0; h->d_obs = 0; h->d_act = 0;
   AnyMDPArgs& a = h->a;
   a.rows = (const double*)rows; a.state_map = state_map; a.term_mask = term_mask;
   a.s0_cdf = s0_cdf; a.s0_ids = s0_ids; a.max_steps = max_steps; a.env_task = env_task;
@@ -642,6 +796,67 @@ extern "C" int xv_anymdp_transition_gt(xv_anymdp* h, const int32_t* action, doub
   const size_t total = (size_t)h->a.n_env * h->a.S;
   hipLaunchKernelGGL(anymdp_tgt_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->eng->stream,
                      h->a, action, out);
+  XV_LAUNCH_CHECK();
+  return XV_OK;
+}
+
+// ---- POMDP / MTPOMDP entry points ----
+extern "C" int xv_anymdp_set_observation_model(xv_anymdp* h, int n_obs, int d_obs, int d_act, const double* obs_cdf) {
+  XV_CHECK_ARG(h && obs_cdf && n_obs >= 1 && d_obs >= 1 && d_obs <= 64 && d_act >= 1 && d_act <= 64);
+  h->obs_cdf = obs_cdf; h->n_obs = n_obs; h->d_obs = d_obs; h->d_act = d_act;
+  return XV_OK;
+}
+
+template <bool INJECT>
+static int anymdp_tok_launch_step(xv_anymdp* h, const AnyMDPTokIO& io, int mode) {
+  AnyMDPTokArgs K{h->obs_cdf, h->n_obs, h->d_obs, h->d_act};
+  hipLaunchKernelGGL(anymdp_tok_step_kernel<INJECT>, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
+                     h->a, K, io, mode);
+  XV_LAUNCH_CHECK();
+  return XV_OK;
+}
+
+extern "C" int xv_anymdp_step_tokens(xv_anymdp* h, const int32_t* action, int32_t* obs, float* reward,
+                                     float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs,
+                                     int autoreset_mode) {
+  XV_CHECK_ARG(h && h->obs_cdf && action && obs && reward && reward_gt && terminated && truncated);
+  XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
+  anymdp_bind_rng(h, 1);
+  AnyMDPTokIO io{action, nullptr, nullptr, nullptr, nullptr, nullptr, obs, reward, reward_gt, terminated, truncated, final_obs};
+  return anymdp_tok_launch_step<false>(h, io, autoreset_mode);
+}
+
+extern "C" int xv_anymdp_step_tokens_injected(xv_anymdp* h, const int32_t* action, const double* u, const float* z,
+                                              const double* u_obs, const double* u_reset, const double* u_obs_reset,
+                                              int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated,
+                                              uint8_t* truncated, int32_t* final_obs, int autoreset_mode) {
+  XV_CHECK_ARG(h && h->obs_cdf && action && u && z && u_obs && u_reset && u_obs_reset && obs && reward && reward_gt &&
+               terminated && truncated);
+  XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
+  anymdp_bind_rng(h, 0);
+  AnyMDPTokIO io{action, u, z, u_obs, u_reset, u_obs_reset, obs, reward, reward_gt, terminated, truncated, final_obs};
+  return anymdp_tok_launch_step<true>(h, io, autoreset_mode);
+}
+
+extern "C" int xv_anymdp_reset_tokens(xv_anymdp* h, const uint8_t* mask, int32_t* obs) {
+  XV_CHECK_ARG(h && h->obs_cdf);
+  anymdp_bind_rng(h, 1);
+  AnyMDPTokArgs K{h->obs_cdf, h->n_obs, h->d_obs, h->d_act};
+  AnyMDPTokIO io{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, obs, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(anymdp_tok_reset_kernel<false>, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
+                     h->a, K, io, mask);
+  XV_LAUNCH_CHECK();
+  return XV_OK;
+}
+
+extern "C" int xv_anymdp_reset_tokens_injected(xv_anymdp* h, const uint8_t* mask, const double* u_reset,
+                                               const double* u_obs_reset, int32_t* obs) {
+  XV_CHECK_ARG(h && h->obs_cdf && u_reset && u_obs_reset);
+  anymdp_bind_rng(h, 0);
+  AnyMDPTokArgs K{h->obs_cdf, h->n_obs, h->d_obs, h->d_act};
+  AnyMDPTokIO io{nullptr, nullptr, nullptr, nullptr, u_reset, u_obs_reset, obs, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(anymdp_tok_reset_kernel<true>, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
+                     h->a, K, io, mask);
   XV_LAUNCH_CHECK();
   return XV_OK;
 }
