@@ -64,3 +64,62 @@ def test_linds_task_schema_all_dims_terminate():
         assert tab["phiT"].shape[1] == dims[0]
     t = LinearDSSamplerRandomDim(seed=5)
     assert t["state_dim"] <= 16
+
+
+def test_anymdp_task_sampler_schema_and_validity():
+    import time
+    from xenoverse_amd.anymdp import AnyMDPTaskSampler, AnyPOMDPTaskSampler, MultiTokensAnyPOMDPTaskSampler
+    from xenoverse_amd.anymdp import build_obs_tables, build_tables, validate_task
+    from xenoverse_amd.anymdp.task_sampler import check_task
+    t0 = time.time()
+    t = AnyMDPTaskSampler(16, 4, seed=0)
+    assert set(t) >= {"ns", "na", "max_steps", "state_mapping", "task_type", "s_0", "s_0_prob", "s_e", "transition",
+                      "reward", "reward_noise", "final_goal_terminate"}
+    assert t["transition"].shape == (16, 4, 16) == t["reward"].shape == t["reward_noise"].shape
+    assert 100 <= t["max_steps"] <= 128 and sorted(t["state_mapping"]) == list(range(16))
+    validate_task(t)                                  # the checks AnyMDPEnv.set_task performs
+    assert check_task(t)
+    assert np.all(t["transition"][list(t["s_e"])] == 0) and np.all(t["reward_noise"] >= 0)
+    t2 = AnyMDPTaskSampler(16, 4, seed=0)
+    assert np.array_equal(t["transition"], t2["transition"]) and t["max_steps"] == t2["max_steps"]
+    t64 = AnyMDPTaskSampler(64, 8, seed=1)            # the reference needs ~9 minutes for this without numba
+    validate_task(t64)
+    assert time.time() - t0 < 120
+    nnz = (t64["transition"] > 0).sum(-1)
+    assert nnz.max() <= 64 // 2 + 64 // 4 + 4          # banded rows
+    p = AnyPOMDPTaskSampler(16, 4, observation_space=16, seed=2)
+    assert p["task_type"] == "POMDP" and p["observation_transition"].shape == (16, 16)
+    assert np.allclose(p["observation_transition"].sum(1), 1.0)
+    m = MultiTokensAnyPOMDPTaskSampler(16, 4, observation_space=16, seed=3)
+    assert m["task_type"] == "MTPOMDP" and len(m["observation_transition"]) == m["do"] == 4 and m["da"] == 2
+    tab = build_tables([m])
+    cdf, n_obs, d_obs, d_act = build_obs_tables([m], tab["S"])
+    assert cdf.shape == (1, 4, 16, 16) and (n_obs, d_obs, d_act) == (16, 4, 2)
+
+
+def test_acceptance_rule_agrees_with_reference_when_available():
+    """container-only cross-check: the reference's check_valuefunction and value iteration vs this restatement"""
+    import os
+    import pickle
+    import sys
+    import pytest
+    cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_cache")
+    if not (os.path.isdir("/root/reference/xenoverse") and os.path.isdir(cache)):
+        pytest.skip("reference tree / sampled-task cache not present (build container only)")
+    sys.path.insert(0, os.path.join(os.path.dirname(cache)))
+    import _refimport
+    _refimport.setup()
+    from xenoverse.anymdp.solver import check_valuefunction, update_value_matrix
+    from xenoverse_amd.anymdp import AnyMDPTaskSampler
+    from xenoverse_amd.anymdp.task_sampler import check_task, value_iteration
+    for f in sorted(os.listdir(cache)):
+        if "mdp_16_4" not in f:
+            continue
+        task = pickle.load(open(os.path.join(cache, f), "rb"))
+        assert check_task(task)                       # every task the reference accepted passes here too
+        gamma = 2.0 ** (-1.0 / 16)
+        q_ref = update_value_matrix(task["transition"], task["reward"], gamma, np.zeros((16, task["na"])))
+        q = value_iteration(task["transition"], task["reward"], gamma)
+        assert np.max(np.abs(q - q_ref)) < 5e-3 * (1 + np.abs(q_ref).max())
+    mine = AnyMDPTaskSampler(16, 4, seed=11)
+    assert check_valuefunction(mine)                  # and a task sampled here passes the reference's own test
