@@ -439,3 +439,18 @@ def test_full_size_config_2a_properties_and_subset_vs_oracle():
             ora.state[q], ora.steps[q] = o1.state[0], o1.steps[0]
     assert n_done > 65536 and env.check_errors() == 0
     env.close()
+
+
+def test_gt_transition_and_reward_accessors():
+    """get_gt_transition / get_gt_reward (anymdp_env.py:161-165): tensors re-indexed by observation id"""
+    g, task = load_anymdp_golden(FILES[0])
+    env = AnyMDPVecEnv(4)
+    env.set_task(task)
+    sm = g["state_mapping"]
+    T_obs = np.zeros_like(g["transition"]); R_obs = np.zeros_like(g["reward"])
+    for i, si in enumerate(sm):
+        T_obs[si][:, sm] = g["transition"][i]
+        R_obs[si][:, sm] = g["reward"][i]
+    assert np.max(np.abs(env.get_gt_transition() - T_obs)) < 1e-12
+    assert np.allclose(env.get_gt_reward(), R_obs, rtol=1e-6, atol=1e-6)
+    env.close()

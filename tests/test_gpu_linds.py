@@ -185,3 +185,19 @@ def test_misuse_messages():
     with pytest.raises(AssertionError, match="Action shape mismatch"):
         env.step(np.zeros((4, 5), np.float32))
     env.close()
+
+
+def test_get_future_inner_cmds():
+    """linds_env.py:171-183: the queue of tracked commands, cmd(steps - delay + k) * target_valid"""
+    g, task = load_linds_golden(FILES[0])          # dynamic target with a delay
+    env = LinDSVecEnv(3, autoreset_mode="disabled")
+    env.set_task(task)
+    env.reset_injected([int(g["init_idx"])] * 3)
+    for t in range(5):
+        env.step_injected(np.tile(g["tr_action"][t], (3, 1)), np.tile(g["tr_z"][t][:, None], (1, 3)), [0, 0, 0])
+    K = 7
+    fut = env.get_future_inner_cmds(K)
+    d, valid = int(task["target_delay"]), np.asarray(task["target_valid"], np.float64)
+    ref = np.stack([task["command"](5 - d + k) * valid for k in range(K)])
+    assert np.allclose(fut[0, :, :8], ref, rtol=1e-5, atol=1e-5) and np.allclose(fut[0], fut[2])
+    env.close()

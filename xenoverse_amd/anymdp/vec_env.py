@@ -305,6 +305,31 @@ class AnyMDPVecEnv(VectorEnv):
         idx = self._tab["env_task"].long() * self.S + s.long()
         return self._out(self._tab["state_map"].reshape(-1)[idx])
 
+    def get_gt_transition(self, task=0):
+        """transition_obs of one task: the transition tensor re-indexed by observation ids
+        (anymdp_env.py:12-20,61-63,161-162) — what the reference's solvers read.  float64[ns, na, ns] (host)."""
+        from .tables import from_blocked
+        cdf, _ = from_blocked(self._tab["rows"][task].cpu().numpy(), self.S)
+        T = np.diff(np.concatenate([np.zeros(cdf.shape[:-1] + (1,)), cdf], -1), axis=-1)
+        tm = int(self._tab["term_mask"][task, 0].item()) if self.S <= 64 else None
+        sm = self._tab["state_map"][task].cpu().numpy()
+        out = np.zeros((self.ns, self.A, self.ns))
+        for i in range(self.S):
+            if tm is not None and (tm >> i) & 1:
+                continue        # rows of terminal states are all-zero in the reference
+            out[sm[i]][:, sm] = T[i]
+        return out
+
+    def get_gt_reward(self, task=0):
+        """reward_obs of one task (anymdp_env.py:164-165), fp32 table values as float64[ns, na, ns] (host)"""
+        from .tables import from_blocked
+        _, rs = from_blocked(self._tab["rows"][task].cpu().numpy(), self.S)
+        sm = self._tab["state_map"][task].cpu().numpy()
+        out = np.zeros((self.ns, self.A, self.ns))
+        for i in range(self.S):
+            out[sm[i]][:, sm] = rs[i, :, :, 0]
+        return out
+
     def get_state(self):
         n, d = self.num_envs, self.device
         s = torch.empty(n, dtype=torch.int32, device=d)

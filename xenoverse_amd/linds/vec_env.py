@@ -225,6 +225,25 @@ class LinDSVecEnv(VectorEnv):
         _lib.check(self.lib.xv_linds_get_state(self._h, _lib.ptr(x), None, None))
         return self._out(x.t().contiguous())
 
+    def get_future_inner_cmds(self, K):
+        """the next K inner commands of every env, starting with the one tracked at the next step
+        (linds_env.py:171-183): float32[N, K, NO] on the host; command(t) = cmd_fn(t) * target_valid."""
+        st = self._steps_now().cpu().numpy()
+        t = self._tab
+        task = t["env_task"].cpu().numpy()
+        ints = t["ints"].cpu().numpy()[task]
+        delay, nf = ints[:, 1], ints[:, 3]
+        tt = st[:, None] - delay[:, None] + np.arange(K)[None, :]                     # [N, K]
+        om = t["four_omega"].cpu().numpy()[task]                                       # [N, KMAX]
+        per = t["four_period"].cpu().numpy()[task]
+        co = t["four_coef"].cpu().numpy()[task].astype(np.float64)                     # [N, KMAX, NO, 2]
+        ang = om[:, None, :] * (tt[:, :, None] / per[:, None, None])                   # [N, K, KMAX]
+        live = (np.arange(om.shape[1])[None, :] < nf[:, None])[:, None, :, None]
+        dyn = ((np.sin(ang)[..., None] * co[:, None, :, :, 0] + np.cos(ang)[..., None] * co[:, None, :, :, 1]) * live).sum(2)
+        static = t["cmd0"].cpu().numpy()[task][:, None, :].astype(np.float64)
+        cmd = np.where((nf > 0)[:, None, None], dyn, static) * t["valid"].cpu().numpy()[task][:, None, :]
+        return cmd[..., :self.user_dims[1]].astype(np.float32)
+
     def get_state(self):
         x = torch.empty((self.NS, self.num_envs), dtype=torch.float32, device=self.device)
         st = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
