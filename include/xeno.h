@@ -183,6 +183,13 @@ int xv_anymdp_step_tokens_injected(xv_anymdp* h, const int32_t* action, const do
 #define XV_ANYMDP_SEARCH_FENCE 3
 int xv_anymdp_set_search(xv_anymdp* h, int search);
 
+/* fused teacher rollout: like xv_anymdp_rollout, but the action of every step comes from a per-task greedy table
+ * greedy uint8[n_task][S] (argmax_a Q[inner_state], the policy of AnyMDPSolverOpt, anymdp_solver_opt.py:38-51) and is
+ * replaced by a uniform action with probability epsilon; the actions taken are written to actions_out[T][n_env]. */
+int xv_anymdp_rollout_teacher(xv_anymdp* h, int T, const uint8_t* greedy, float epsilon, int32_t* actions_out,
+                              int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated,
+                              uint8_t* truncated, int32_t* final_obs);
+
 /* env.inner_state / env.steps accessors (anymdp_env.py:138-143); device int32[n_env] each, nullable */
 int xv_anymdp_get_state(xv_anymdp* h, int32_t* inner_state, int32_t* steps, uint8_t* need_reset);
 int xv_anymdp_set_state(xv_anymdp* h, const int32_t* inner_state, const int32_t* steps,

@@ -454,3 +454,39 @@ def test_gt_transition_and_reward_accessors():
     assert np.max(np.abs(env.get_gt_transition() - T_obs)) < 1e-12
     assert np.allclose(env.get_gt_reward(), R_obs, rtol=1e-6, atol=1e-6)
     env.close()
+
+
+def test_teacher_rollout_on_device():
+    """fused rollout driven by the optimal-policy table: actions are argmax_a Q[state]; equals stepping with them"""
+    from xenoverse_amd.anymdp.teacher import optimal_policy_table
+    tasks = [load_anymdp_golden(p)[1] for p in golden_files("anymdp_16x4")[:4]]
+    greedy = optimal_policy_table(tasks)
+    n, T = 128, 40
+    env_task = np.repeat(np.arange(4, dtype=np.int32), 32)
+    outs = []
+    for fused in (True, False):
+        env = AnyMDPVecEnv(n, seed=3, autoreset_mode="same_step")
+        env.set_task(tasks, env_task_index=env_task)
+        env.reset()
+        if fused:
+            s0 = _np(env.inner_state).copy()
+            o = env.rollout_teacher(T, greedy, epsilon=0.0)
+            outs.append({k: _np(v) for k, v in o.items()})
+            assert np.array_equal(outs[0]["action"][0], greedy[env_task, s0])
+        else:
+            rec = {k: [] for k in ("action", "obs", "reward", "terminated")}
+            for t in range(T):
+                a = greedy[env_task, _np(env.inner_state)].astype(np.int32)
+                obs, r, term, trunc, info = env.step(a)
+                rec["action"].append(a); rec["obs"].append(_np(obs)); rec["reward"].append(_np(r))
+                rec["terminated"].append(_np(term).astype(np.uint8))
+            outs.append({k: np.stack(v) for k, v in rec.items()})
+        env.close()
+    for k in ("action", "obs", "reward", "terminated"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    # the teacher is better than random: compare average reward_gt per step
+    env = AnyMDPVecEnv(n, seed=3, autoreset_mode="same_step"); env.set_task(tasks, env_task_index=env_task); env.reset()
+    opt = float(env.rollout_teacher(200, greedy, 0.0)["reward_gt"].mean())
+    rnd = float(env.rollout_teacher(200, greedy, 1.0)["reward_gt"].mean())
+    assert opt > rnd
+    env.close()

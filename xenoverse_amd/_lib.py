@@ -38,6 +38,7 @@ SIGNATURES = {
     "xv_anymdp_reset_tokens_injected": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_anymdp_step_tokens": [c_void_p] + [c_void_p] * 7 + [c_int],
     "xv_anymdp_step_tokens_injected": [c_void_p] + [c_void_p] * 12 + [c_int],
+    "xv_anymdp_rollout_teacher": [c_void_p, c_int, c_void_p, C.c_float] + [c_void_p] * 7,
     "xv_anymdp_get_state": [c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_anymdp_set_state": [c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_anymdp_transition_gt": [c_void_p, c_void_p, c_void_p],

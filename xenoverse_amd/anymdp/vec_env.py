@@ -265,6 +265,27 @@ class AnyMDPVecEnv(VectorEnv):
             _lib.ptr(out["terminated"]), _lib.ptr(out["truncated"]), _lib.ptr(out.get("final_obs"))))
         return out
 
+    def rollout_teacher(self, T, greedy, epsilon=0.0):
+        """Fused T-step rollout driven on the device by a teacher: greedy uint8[n_task, S] (e.g.
+        `teacher.optimal_policy_table(tasks)`), epsilon-greedy.  -> dict of [T, N] device tensors incl. "action"."""
+        self._check_step()
+        g = self._dev(greedy, torch.uint8)
+        assert g.shape == (self.n_task, self.S)
+        d, n = self.device, self.num_envs
+        out = dict(action=torch.empty((T, n), dtype=torch.int32, device=d),
+                   obs=torch.empty((T, n), dtype=torch.int32, device=d),
+                   reward=torch.empty((T, n), dtype=torch.float32, device=d),
+                   reward_gt=torch.empty((T, n), dtype=torch.float32, device=d),
+                   terminated=torch.empty((T, n), dtype=torch.uint8, device=d),
+                   truncated=torch.empty((T, n), dtype=torch.uint8, device=d),
+                   final_obs=torch.empty((T, n), dtype=torch.int32, device=d))
+        _lib.check(self.lib.xv_anymdp_rollout_teacher(
+            self._h, int(T), _lib.ptr(g), float(epsilon), _lib.ptr(out["action"]), _lib.ptr(out["obs"]),
+            _lib.ptr(out["reward"]), _lib.ptr(out["reward_gt"]), _lib.ptr(out["terminated"]),
+            _lib.ptr(out["truncated"]), _lib.ptr(out["final_obs"])))
+        self.engine.sync()
+        return out
+
     def step_many(self, n_steps, actions, out=None):
         """n_steps back-to-back step launches issued from C.  actions int32[P, N] is cycled with period P;
         `out` holds [P, N] ring buffers (allocated when None) — slot k % P receives step k."""

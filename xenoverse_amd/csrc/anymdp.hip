@@ -70,6 +70,10 @@ struct AnyMDPStepIO {
   uint8_t* terminated;
   uint8_t* truncated;
   int32_t* final_obs;     // nullable
+  // teacher rollout (nullable): action = greedy[task][state] w.p. 1-epsilon, else uniform; written to action_out
+  const uint8_t* greedy;
+  int32_t* action_out;
+  float epsilon;
 };
 
 struct xv_anymdp {
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
   int s = P.state[ic];
   int steps = P.steps[ic];
   int nr = P.need_reset[ic];
-  int a_next = io.action[ic];
+  int a_next = io.action ? io.action[ic] : 0;
   const uint64_t gid = P.gid_base + (uint64_t)ic;
   uint32_t err = 0;
 
@@ -187,6 +191,14 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
     }
 
     int a = a_next;
+    if (io.greedy) {   // teacher policy: argmax_a Q[inner_state] (anymdp_solver_opt.py:38-51), epsilon-greedy
+      a = io.greedy[(size_t)t * S + s];
+      if (io.epsilon > 0.0f) {
+        const xv_u32x4 e = xv_env_draw(P.seed, gid, P.tick + (uint64_t)ts, 2u);
+        if ((float)(e.x >> 8) * (1.0f / 16777216.0f) < io.epsilon) a = (int)(e.y % (uint32_t)A);
+      }
+      if (valid) io.action_out[o] = a;
+    }
     if (a < 0 || a >= A) {  // reference: assert action < self.na (:97)
       if (!(mode == XV_AUTORESET_NEXT_STEP && nr)) err |= XV_DEVERR_ACTION_RANGE;
       a = a < 0 ? 0 : A - 1;
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
         cv[it] = blk[j];
         rv[it] = reinterpret_cast<const float2*>(blk + 16)[j];
       }
-      if (ROLLOUT && ts + 1 < T) a_next = io.action[o + P.n_env];   // prefetch behind the blocks
+      if (ROLLOUT && io.action && ts + 1 < T) a_next = io.action[o + P.n_env];   // prefetch behind the blocks
       __builtin_amdgcn_sched_barrier(0);
       // (b) while the loads fly: broadcast each env's uniform to the 16 lanes that hold its block
       double ue[16];
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
         }
       }
       s2 = lo < S - 1 ? lo : S - 1;
-      if (ROLLOUT && ts + 1 < T) a_next = io.action[o + P.n_env];
+      if (ROLLOUT && io.action && ts + 1 < T) a_next = io.action[o + P.n_env];
       rsv = anymdp_rs(P, rowidx, s2);                              // :103-104
     }
     const int obs2 = HDR ? (int)anymdp_hdr_obs(H, s2) : P.state_map[(size_t)t * S + s2];   // :146-148
@@ -718,7 +730,7 @@ extern "C" int xv_anymdp_step(xv_anymdp* h, const int32_t* action, int32_t* obs,
   XV_CHECK_ARG(h && action && obs && reward && reward_gt && terminated && truncated);
   XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
   anymdp_bind_rng(h, 1);
-  AnyMDPStepIO io{action, nullptr, nullptr, nullptr, obs, reward, reward_gt, terminated, truncated, final_obs};
+  AnyMDPStepIO io{action, nullptr, nullptr, nullptr, obs, reward, reward_gt, terminated, truncated, final_obs, nullptr, nullptr, 0.0f};
   return anymdp_launch_step<false>(h, io, 1, autoreset_mode);
 }
 
@@ -729,7 +741,7 @@ extern "C" int xv_anymdp_step_injected(xv_anymdp* h, const int32_t* action, cons
   XV_CHECK_ARG(h && action && u && z && u_reset && obs && reward && reward_gt && terminated && truncated);
   XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
   anymdp_bind_rng(h, 0);
-  AnyMDPStepIO io{action, u, z, u_reset, obs, reward, reward_gt, terminated, truncated, final_obs};
+  AnyMDPStepIO io{action, u, z, u_reset, obs, reward, reward_gt, terminated, truncated, final_obs, nullptr, nullptr, 0.0f};
   return anymdp_launch_step<true>(h, io, 1, autoreset_mode);
 }
 
@@ -744,7 +756,7 @@ extern "C" int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const 
     const size_t off = (size_t)(k % period) * n;
     anymdp_bind_rng(h, 1);
     AnyMDPStepIO io{actions + off, nullptr, nullptr, nullptr, obs + off, reward + off, reward_gt + off,
-                    terminated + off, truncated + off, final_obs ? final_obs + off : nullptr};
+                    terminated + off, truncated + off, final_obs ? final_obs + off : nullptr, nullptr, nullptr, 0.0f};
     const int rc = anymdp_launch_step<false>(h, io, 1, autoreset_mode);
     if (rc != XV_OK) return rc;
   }
@@ -756,7 +768,19 @@ extern "C" int xv_anymdp_rollout(xv_anymdp* h, int T, const int32_t* actions, in
                                  int32_t* final_obs) {
   XV_CHECK_ARG(h && T > 0 && actions && obs && reward && reward_gt && terminated && truncated);
   anymdp_bind_rng(h, (uint64_t)T);
-  AnyMDPStepIO io{actions, nullptr, nullptr, nullptr, obs, reward, reward_gt, terminated, truncated, final_obs};
+  AnyMDPStepIO io{actions, nullptr, nullptr, nullptr, obs, reward, reward_gt, terminated, truncated, final_obs, nullptr, nullptr, 0.0f};
+  return anymdp_launch_step<false>(h, io, T, XV_AUTORESET_SAME_STEP);
+}
+
+extern "C" int xv_anymdp_rollout_teacher(xv_anymdp* h, int T, const uint8_t* greedy, float epsilon, int32_t* actions_out,
+                                         int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated,
+                                         uint8_t* truncated, int32_t* final_obs) {
+  XV_CHECK_ARG(h && T > 0 && greedy && actions_out && obs && reward && reward_gt && terminated && truncated);
+  XV_CHECK_ARG(epsilon >= 0.0f && epsilon <= 1.0f);
+  anymdp_bind_rng(h, (uint64_t)T);
+  AnyMDPStepIO io{nullptr, nullptr, nullptr, nullptr, obs, reward, reward_gt, terminated, truncated, final_obs, greedy,
+                  actions_out, epsilon};
+  // T == 1 must still take the rollout instantiation (it is the one that honours the teacher fields per step)
   return anymdp_launch_step<false>(h, io, T, XV_AUTORESET_SAME_STEP);
 }
 
