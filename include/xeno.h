@@ -317,6 +317,9 @@ typedef struct xv_maze_tables {
   const float* tex_walls;   /* [n][256][256][3] float32 in [0,255], as MazeTaskManager loads them */
   const float* tex_grounds;
   const float* tex_ceilings;
+  int32_t n_tex_walls;      /* library sizes.  When every texel is an integer in [0,255] (decoded 8-bit images, as the */
+  int32_t n_tex_grounds;    /* reference's are) the engine keeps a packed RGBX-byte copy and the ray-caster reads the  */
+  int32_t n_tex_ceilings;   /* four y-taps of a filter row with one 16-byte load; results are identical.              */
 } xv_maze_tables;
 
 #define XV_MAZE_ACTION_CONTINUOUS 0 /* action = double[n_env][2] (turn_rate, walk_speed) */

@@ -130,6 +130,29 @@ def test_batch_vs_oracle_frames_and_state(res, stage):
     env.close()
 
 
+def test_float_textures_take_general_path():
+    """non-integer texels disable the packed byte copy; frames still follow the oracle, and with integer texels
+    the packed path (one 16-byte load per filter row) gives the same frames as the float path"""
+    tasks = [load_maze_golden(p)[1] for p in FILES]
+    tab = build_tables(tasks)
+    env_task = np.repeat(np.arange(len(tasks), dtype=np.int32), 4)
+    n = len(env_task)
+    lib_int = tex()
+    lib_flt = {k: (v * np.float32(0.97) + np.float32(0.3)).astype(np.float32) for k, v in lib_int.items()}
+    for lib in (lib_flt, lib_int):
+        env = MazeWorldVecEnv(n, resolution=(40, 40), textures=lib, autoreset_mode="same_step", max_steps=25, seed=3)
+        env.set_task(tasks, env_task_index=env_task)
+        ora = oracle.MazeOracle(tab, lib, env_task, resolution=(40, 40), max_steps=25)
+        f0, _ = env.reset()
+        st = env.get_state()
+        ora.reset()
+        ora.pos[:] = _np(st["pos"]); ora.ori[:] = _np(st["ori"])
+        fo, _ = ora.render(n_threads=8)
+        frac, worst = frame_mismatch(_np(f0), fo)
+        assert frac <= 0.005 and worst <= 1, (frac, worst)
+        env.close()
+
+
 def test_command_bar_and_final_obs():
     g, task = load_maze_golden(FILES[0])
     env = MazeWorldVecEnv(4, resolution=(32, 32), textures=tex(), autoreset_mode="same_step", max_steps=3,

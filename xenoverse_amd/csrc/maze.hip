@@ -32,6 +32,10 @@ struct MazeArgs {
   int32_t* cmd_age;
   uint8_t* need_reset;
   double* collision;
+  // packed RGBX-byte copies of the texture libraries ([n][256][MZ_TEX_PITCH] uint32), nullptr if not integral
+  const uint32_t* pk_walls;
+  const uint32_t* pk_grounds;
+  const uint32_t* pk_ceilings;
   // pose of envs that ended this step, kept for the optional final frame
   double* fin_pose;  // [3][n_env]
   int32_t* fin_cmd;  // [n_env]
@@ -47,6 +51,7 @@ struct xv_maze {
 };
 
 static const size_t MAZE_LDS_STAGE_MAX = 150 * 1024;   // LDS is 160 KiB per CU
+#define MZ_TEX_PITCH 260   // 256 texels + 3 wrapped ones (+1 pad): the 4 y-taps of a filter row never wrap
 
 __device__ const double MZ_ACT16[16][2] = {{0.0, 0.5}, {0.05, 0.0}, {-0.05, 0.0}, {0.1, 0.0}, {-0.1, 0.0}, {0.2, 0.0},
                                            {-0.2, 0.0}, {0.3, 0.0}, {-0.3, 0.0}, {0.5, 0.0}, {-0.5, 0.0}, {0.0, 1.0},
@@ -252,35 +257,76 @@ __global__ __launch_bounds__(256) void maze_step_kernel(MazeArgs P, const void* 
   if (err) atomicOr(P.err, err);
 }
 
-// interpolate, ray_caster_utils.py:123-140 (see oracle mz_interpolate for the typing)
-__device__ __forceinline__ void mz_interpolate(const float* __restrict__ tex, double i, double j, double d,
+// interpolate, ray_caster_utils.py:123-140 (see oracle mz_interpolate for the typing).
+// PACKED: the texture is the engine's RGBX-byte copy with padded rows: the four y-taps of filter row x are the
+// 16 contiguous bytes at [x & 255][(jb - 1) & 255 ...], one global_load_dwordx4 instead of 12 dword loads.  Texel
+// values are the same integers, so every operation below sees the same operands as the float path.
+template <bool PACKED>
+__device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, double i, double j, double d,
                                                double px, double py, double (&out)[3]) {
   double d2 = d * d;
   if (d2 < 1.0e-8) d2 = 1.0e-8;
   const int ib = (int)i, jb = (int)j;
   double sum_wht = 0.0;
   float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+  double bb[4];
+#pragma unroll
+  for (int yy = -1; yy < 3; ++yy) {
+    const double b = ((double)(jb + yy) - j) * py;
+    bb[yy + 1] = b * b;
+  }
 #pragma unroll
   for (int xx = -1; xx < 3; ++xx) {
     const int x = ib + xx;
     const double a = ((double)x - i) * px;
+    const double aa = a * a;
     const int xv = x & 255;   // python's non-negative x % 256
+    uint32_t q[4];
+    if (PACKED) {
+      const uint32_t* row = static_cast<const uint32_t*>(texv) + (size_t)xv * MZ_TEX_PITCH + ((jb - 1) & 255);
+      const uint4 v = *reinterpret_cast<const uint4*>(row);   // dword-aligned 16-byte load
+      q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+    }
 #pragma unroll
     for (int yy = -1; yy < 3; ++yy) {
-      const int y = jb + yy;
-      const double b = ((double)y - j) * py;
-      const double dist = a * a + b * b;
+      const double dist = aa + bb[yy + 1];
       double wht = 1.0 - 10 * dist / d2;
       wht = wht > 1.0 ? 1.0 : wht;
       wht = wht < 0.01 ? 0.01 : wht;
       sum_wht += wht;
-      const float* tp = tex + ((size_t)xv * 256 + (y & 255)) * 3;
-      s0 = (float)((double)s0 + wht * (double)tp[0]);
-      s1 = (float)((double)s1 + wht * (double)tp[1]);
-      s2 = (float)((double)s2 + wht * (double)tp[2]);
+      float t0, t1, t2;
+      if (PACKED) {
+        const uint32_t p = q[yy + 1];
+        t0 = (float)(p & 0xFFu); t1 = (float)((p >> 8) & 0xFFu); t2 = (float)((p >> 16) & 0xFFu);
+      } else {
+        const float* tp = static_cast<const float*>(texv) + ((size_t)xv * 256 + ((jb + yy) & 255)) * 3;
+        t0 = tp[0]; t1 = tp[1]; t2 = tp[2];
+      }
+      s0 = (float)((double)s0 + wht * (double)t0);
+      s1 = (float)((double)s1 + wht * (double)t1);
+      s2 = (float)((double)s2 + wht * (double)t2);
     }
   }
   out[0] = (double)s0 / sum_wht; out[1] = (double)s1 / sum_wht; out[2] = (double)s2 / sum_wht;
+}
+
+// texel (x, y) of library entry k -> packed RGBX word at [k][x][y], rows padded with 3 wrapped texels
+__global__ __launch_bounds__(256) void maze_pack_tex_kernel(const float* tex, uint32_t* pk, int n_tex) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)n_tex * 256 * MZ_TEX_PITCH;
+  if (idx >= total) return;
+  const int y = (int)(idx % MZ_TEX_PITCH);
+  const size_t kx = idx / MZ_TEX_PITCH;
+  const float* tp = tex + (kx * 256 + (size_t)(y & 255)) * 3;
+  pk[idx] = (uint32_t)tp[0] | ((uint32_t)tp[1] << 8) | ((uint32_t)tp[2] << 16);
+}
+
+// are all texels integers in [0, 255]?
+__global__ __launch_bounds__(256) void maze_tex_integral_kernel(const float* tex, size_t n, int* not_integral) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const float v = tex[idx];
+  if (!(v >= 0.0f && v <= 255.0f && v == floorf(v))) atomicOr(not_integral, 1);
 }
 
 __device__ __forceinline__ uint8_t mz_clip_u8(double v) {   // numpy.clip(v, 0, 255) -> int32 -> uint8
@@ -293,7 +339,7 @@ __device__ __forceinline__ uint8_t mz_clip_u8(double v) {   // numpy.clip(v, 0, 
 // STAGE: the frame is built in LDS and leaves with 16-byte stores (frames up to ~150 KB, e.g. 224x224);
 // larger frames (the registered 256x256 = 192 KB) are built in place in global memory, each lane owning the
 // contiguous H*3 bytes of its column.
-template <bool FINAL, bool STAGE>
+template <bool FINAL, bool STAGE, bool PACKED>
 __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* frames, float* command_rgb) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];   // STAGE: [W][H][3] bytes
   __shared__ float s_cos_last_v;
@@ -310,8 +356,10 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
   const int8_t* walls = P.T.walls + (size_t)t * NG * NG;
   const int8_t* transp = P.T.landmarks + (size_t)t * NG * NG;
   const int32_t* texts = P.T.texts + (size_t)t * NG * NG;
-  const float* ground = P.T.tex_grounds + (size_t)in[3] * 256 * 256 * 3;
-  const float* ceil_t = P.T.tex_ceilings + (size_t)in[4] * 256 * 256 * 3;
+  const void* ground = PACKED ? (const void*)(P.pk_grounds + (size_t)in[3] * 256 * MZ_TEX_PITCH)
+                              : (const void*)(P.T.tex_grounds + (size_t)in[3] * 256 * 256 * 3);
+  const void* ceil_t = PACKED ? (const void*)(P.pk_ceilings + (size_t)in[4] * 256 * MZ_TEX_PITCH)
+                              : (const void*)(P.T.tex_ceilings + (size_t)in[4] * 256 * 256 * 3);
   const double pe0 = FINAL ? P.fin_pose[e] : P.pos[e];
   const double pe1 = FINAL ? P.fin_pose[N + e] : P.pos[N + e];
   const double ori = FINAL ? P.fin_pose[2 * N + e] : P.ori[e];
@@ -365,7 +413,7 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
         d_i -= floor(d_i); d_j -= floor(d_j);
         d_i *= 256; d_j *= 256;
         double c[3];
-        mz_interpolate(ground, d_i, d_j, eff_ps, tps, tps, c);
+        mz_interpolate<PACKED>(ground, d_i, d_j, eff_ps, tps, tps, c);
         uint8_t* px = col + d_v * 3;
         px[0] = mz_clip_u8(light * (alpha * 1.0 + (1.0 - alpha) * c[0]));
         px[1] = mz_clip_u8(light * (alpha * 1.0 + (1.0 - alpha) * c[1]));
@@ -393,7 +441,7 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
         d_i -= floor(d_i); d_j -= floor(d_j);
         d_i *= 256; d_j *= 256;
         double c[3];
-        mz_interpolate(ceil_t, d_i, d_j, eff_ps, tps, tps, c);
+        mz_interpolate<PACKED>(ceil_t, d_i, d_j, eff_ps, tps, tps, c);
         uint8_t* px = col + d_v * 3;
         px[0] = mz_clip_u8(light * (alpha * 1.0 + (1.0 - alpha) * c[0]));
         px[1] = mz_clip_u8(light * (alpha * 1.0 + (1.0 - alpha) * c[1]));
@@ -486,7 +534,8 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
     int v_s = (int)((half_v - (double)top_v) / pixel_size), v_e = (int)((half_v + (double)bot_v) / pixel_size);
     v_s = v_s < 0 ? 0 : v_s;
     v_e = v_e > H ? H : v_e;
-    const float* wt = P.T.tex_walls + (size_t)text_id * 256 * 256 * 3;
+    const void* wt = PACKED ? (const void*)(P.pk_walls + (size_t)text_id * 256 * MZ_TEX_PITCH)
+                            : (const void*)(P.T.tex_walls + (size_t)text_id * 256 * 256 * 3);
     const double eff_ps_w = eff_stale * pixel_size / l_focal;
     const float a_far = alpha * 1.0f, a_near = 1.0f - alpha;
     for (int d_v = v_s; d_v < v_e; ++d_v) {
@@ -496,7 +545,7 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
       d_i -= floorf(d_i); d_j -= floor(d_j);
       const int ti = (int)(256.0f * d_i), tj = (int)(256 * d_j);
       double c[3];
-      mz_interpolate(wt, (double)ti, (double)tj, eff_ps_w, tps, tps, c);
+      mz_interpolate<PACKED>(wt, (double)ti, (double)tj, eff_ps_w, tps, tps, c);
       uint8_t* px = col + d_v * 3;
       px[0] = mz_clip_u8((double)light * ((double)a_far + (double)a_near * c[0]));
       px[1] = mz_clip_u8((double)light * ((double)a_far + (double)a_near * c[1]));
@@ -603,12 +652,46 @@ extern "C" int xv_maze_create(xv_engine* e, int n_env, int n_task, int NG, int n
   hipLaunchKernelGGL(maze_reset_kernel, dim3(xv_div_up(n_env, 256)), dim3(256), 0, e->stream, a,
                      (const uint8_t*)nullptr);
   XV_HIP(hipMemsetAsync(a.need_reset, 1, n, e->stream));
+  // packed byte textures when the libraries are integer-valued (they are for decoded 8-bit images)
+  if (tables->n_tex_walls > 0 && tables->n_tex_grounds > 0 && tables->n_tex_ceilings > 0) {
+    int* d_flag = nullptr;
+    int h_flag = 1;
+    XV_HIP(hipMalloc(&d_flag, sizeof(int)));
+    XV_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), e->stream));
+    const float* libs[3] = {tables->tex_walls, tables->tex_grounds, tables->tex_ceilings};
+    const int cnt[3] = {tables->n_tex_walls, tables->n_tex_grounds, tables->n_tex_ceilings};
+    for (int k = 0; k < 3; ++k) {
+      const size_t nt = (size_t)cnt[k] * 256 * 256 * 3;
+      hipLaunchKernelGGL(maze_tex_integral_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, e->stream, libs[k],
+                         nt, d_flag);
+    }
+    XV_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    XV_HIP(hipStreamSynchronize(e->stream));
+    XV_HIP(hipFree(d_flag));
+    if (h_flag == 0) {
+      uint32_t* pk[3] = {nullptr, nullptr, nullptr};
+      bool ok = true;
+      for (int k = 0; k < 3 && ok; ++k) {
+        const size_t words = (size_t)cnt[k] * 256 * MZ_TEX_PITCH + 4;
+        ok = hipMalloc(&pk[k], words * sizeof(uint32_t)) == hipSuccess;
+        if (ok)
+          hipLaunchKernelGGL(maze_pack_tex_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, e->stream,
+                             libs[k], pk[k], cnt[k]);
+      }
+      if (ok) { a.pk_walls = pk[0]; a.pk_grounds = pk[1]; a.pk_ceilings = pk[2]; }
+      else { for (int k = 0; k < 3; ++k) if (pk[k]) (void)hipFree(pk[k]); (void)hipGetLastError(); }
+    }
+  }
   // the ray-cast kernel stages a whole frame in LDS when it fits: raise the dynamic LDS limit past 64 KiB
   const size_t lds_bytes = ((size_t)W * H * 3 + 15) & ~(size_t)15;
   if (lds_bytes <= MAZE_LDS_STAGE_MAX && lds_bytes > 48 * 1024) {
-    XV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&maze_raycast_kernel<false, true>),
+    XV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&maze_raycast_kernel<false, true, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    XV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&maze_raycast_kernel<true, true>),
+    XV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&maze_raycast_kernel<true, true, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    XV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&maze_raycast_kernel<false, true, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    XV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&maze_raycast_kernel<true, true, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   }
   XV_LAUNCH_CHECK();
@@ -622,7 +705,7 @@ extern "C" int xv_maze_destroy(xv_maze* h) {
   (void)hipStreamSynchronize(h->eng->stream);
   MazeArgs& a = h->a;
   void* ps[] = {a.pos, a.ori, a.grid, a.steps, a.cmd_idx, a.cmd_age, a.need_reset, a.collision, a.fin_pose,
-                a.fin_cmd, a.fin_flag};
+                a.fin_cmd, a.fin_flag, (void*)a.pk_walls, (void*)a.pk_grounds, (void*)a.pk_ceilings};
   for (void* p : ps) if (p) (void)hipFree(p);
   delete h;
   return XV_OK;
@@ -634,10 +717,13 @@ static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, b
   const size_t lds_bytes = ((size_t)a.W * a.H * 3 + 15) & ~(size_t)15;
   const bool stage = lds_bytes <= MAZE_LDS_STAGE_MAX;
   float* crgb = final ? nullptr : command_rgb;
-#define MAZE_RC(F, S) \
-  hipLaunchKernelGGL((maze_raycast_kernel<F, S>), dim3(a.n_env), dim3(threads), (S) ? lds_bytes : 0, h->eng->stream, a, frames, crgb)
-  if (final) { if (stage) MAZE_RC(true, true); else MAZE_RC(true, false); }
-  else { if (stage) MAZE_RC(false, true); else MAZE_RC(false, false); }
+  const bool packed = a.pk_walls != nullptr;
+#define MAZE_RC(F, S, K) \
+  hipLaunchKernelGGL((maze_raycast_kernel<F, S, K>), dim3(a.n_env), dim3(threads), (S) ? lds_bytes : 0, h->eng->stream, a, frames, crgb)
+#define MAZE_RC2(F, S) do { if (packed) MAZE_RC(F, S, true); else MAZE_RC(F, S, false); } while (0)
+  if (final) { if (stage) MAZE_RC2(true, true); else MAZE_RC2(true, false); }
+  else { if (stage) MAZE_RC2(false, true); else MAZE_RC2(false, false); }
+#undef MAZE_RC2
 #undef MAZE_RC
   XV_LAUNCH_CHECK();
   return XV_OK;

@@ -20,7 +20,8 @@ from .textures import make_texture_library
 
 class _Tables(C.Structure):   # xv_maze_tables (include/xeno.h)
     _fields_ = [(k, C.c_void_p) for k in ("walls", "texts", "landmarks", "ints", "dbl", "commands", "lm_coord",
-                                          "tex_walls", "tex_grounds", "tex_ceilings")]
+                                          "tex_walls", "tex_grounds", "tex_ceilings")] + \
+               [(k, C.c_int32) for k in ("n_tex_walls", "n_tex_grounds", "n_tex_ceilings")]
 
 
 class MazeWorldVecEnv(VectorEnv):
@@ -86,7 +87,9 @@ class MazeWorldVecEnv(VectorEnv):
             self.lib.xv_maze_destroy(self._h)
             self._h = None
         ct = _Tables(*[_lib.ptr(dev[k]) for k in ("walls", "texts", "landmarks", "ints", "dbl", "commands",
-                                                   "lm_coord", "tex_walls", "tex_grounds", "tex_ceilings")])
+                                                   "lm_coord", "tex_walls", "tex_grounds", "tex_ceilings")],
+                     int(dev["tex_walls"].shape[0]), int(dev["tex_grounds"].shape[0]),
+                     int(dev["tex_ceilings"].shape[0]))
         h = C.c_void_p()
         W, H = self.resolution
         _lib.check(self.lib.xv_maze_create(self.engine.handle, self.num_envs, n_task, int(tab["NG"]),
