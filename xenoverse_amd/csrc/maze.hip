@@ -261,11 +261,21 @@ __global__ __launch_bounds__(256) void maze_step_kernel(MazeArgs P, const void* 
 // PACKED: the texture is the engine's RGBX-byte copy with padded rows: the four y-taps of filter row x are the
 // 16 contiguous bytes at [x & 255][(jb - 1) & 255 ...], one global_load_dwordx4 instead of 12 dword loads.  Texel
 // values are the same integers, so every operation below sees the same operands as the float path.
+//
+// The weight 1 - 10*dist/d2 divides by the same d2 for all 16 taps.  hipcc expands an fp64 division into
+// div_scale / rcp / two Newton steps on the reciprocal / q0 = n*y / r = fma(-d,q0,n) / q = fma(r,y,q0) / div_fixup;
+// the scale and fixup steps only act on operands near the ends of the exponent range (d2 is in [1e-8, ~1e3] and
+// n = 10*dist is 0 or in [~1e-40, 1e4] here).  The refined reciprocal y is hoisted out of the tap loop and each
+// tap keeps the last three operations: the same correctly rounded quotient, 3 instructions instead of 14.
+// dist >= 0 and d2 > 0 make the reference's upper clamp (wht > 1 -> 1) unreachable; the lower one is a v_max_f64.
 template <bool PACKED>
 __device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, double i, double j, double d,
                                                double px, double py, double (&out)[3]) {
   double d2 = d * d;
   if (d2 < 1.0e-8) d2 = 1.0e-8;
+  double y = __builtin_amdgcn_rcp(d2);
+  y = __builtin_fma(y, __builtin_fma(-d2, y, 1.0), y);
+  y = __builtin_fma(y, __builtin_fma(-d2, y, 1.0), y);
   const int ib = (int)i, jb = (int)j;
   double sum_wht = 0.0;
   float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
@@ -290,9 +300,10 @@ __device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, do
 #pragma unroll
     for (int yy = -1; yy < 3; ++yy) {
       const double dist = aa + bb[yy + 1];
-      double wht = 1.0 - 10 * dist / d2;
-      wht = wht > 1.0 ? 1.0 : wht;
-      wht = wht < 0.01 ? 0.01 : wht;
+      const double num = 10 * dist;
+      const double q0 = num * y;
+      const double quo = __builtin_fma(__builtin_fma(-d2, q0, num), y, q0);   // == num / d2
+      const double wht = __builtin_fmax(1.0 - quo, 0.01);
       sum_wht += wht;
       float t0, t1, t2;
       if (PACKED) {
@@ -342,7 +353,6 @@ __device__ __forceinline__ uint8_t mz_clip_u8(double v) {   // numpy.clip(v, 0, 
 template <bool FINAL, bool STAGE, bool PACKED>
 __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* frames, float* command_rgb) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];   // STAGE: [W][H][3] bytes
-  __shared__ float s_cos_last_v;
   const int e = blockIdx.x;
   if (FINAL && !P.fin_flag[e]) return;   // block-uniform
   const int W = P.W, H = P.H, NG = P.NG;
@@ -373,109 +383,39 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
   const double pixel_factor = pixel_size / l_focal;
   const double percell = cell_size / text_size;
   const double tps = text_size / 256;
-  float* s_cos_last = &s_cos_last_v;
   const size_t fsz = (size_t)W * H * 3;
   uint8_t* dst = frames + (size_t)e * fsz;
   uint8_t* lds = STAGE ? lds_dyn : dst;   // where the frame is built
 
-  for (int d_h = threadIdx.x; d_h < W; d_h += blockDim.x) {
-    // ---- per-column tables :170-177 (the reference accumulates tan_hp column by column) ----
-    double tan_hp = (-0.5 - W / 2.0) * pixel_factor;
-    for (int q = 0; q <= d_h; ++q) tan_hp += pixel_factor;
-    const double cos_hp = sqrt(1.0 / (1.0 + tan_hp * tan_hp));
-    const double sin_hp = tan_hp * cos_hp;
-    const float sin_abs = (float)(sin_hp * c_ori + cos_hp * s_ori);
-    const float cos_abs = (float)(cos_hp * c_ori - sin_hp * s_ori);
-    const float cos_hp_f = (float)cos_hp;
-    if (d_h == W - 1) *s_cos_last = cos_hp_f;
-    uint8_t* col = lds + (size_t)d_h * H * 3;
-    for (int k = 0; k < H * 3; ++k) col[k] = 1;   // FAR_RGB :165-166
-
-    // ---- floor :180-211 ----
-    for (int d_v = H - 1; d_v > H / 2; --d_v) {
-      const double v_screen = (d_v + 0.5) * pixel_size - half_v;
-      const double distance = vision_height / v_screen * l_focal;
-      double light = v_screen / l_focal;
-      light = light > 1.0 ? 1.0 : light;
-      if (distance > visibility) continue;
-      const double eff = distance / (double)cos_hp_f;
-      double alpha = 2.0 * eff / visibility - 1.0;
-      alpha = alpha < 0.0 ? 0.0 : alpha;
-      alpha = alpha > 1.0 ? 1.0 : alpha;
-      alpha *= light;
-      const double hit_x = eff * (double)cos_abs + (double)pos0, hit_y = eff * (double)sin_abs + (double)pos1;
-      const double fi = hit_x / cell_size, fj = hit_y / cell_size;
-      double d_i = fi - floor(fi), d_j = fj - floor(fj);
-      const int i = (int)fi, j = (int)fj;
-      const double eff_ps = eff * pixel_size / l_focal;
-      if (i < n && i >= 0 && j < n && j >= 0) {
-        d_i *= percell; d_j *= percell;
-        d_i -= floor(d_i); d_j -= floor(d_j);
-        d_i *= 256; d_j *= 256;
-        double c[3];
-        mz_interpolate<PACKED>(ground, d_i, d_j, eff_ps, tps, tps, c);
-        uint8_t* px = col + d_v * 3;
-        px[0] = mz_clip_u8(light * (alpha * 1.0 + (1.0 - alpha) * c[0]));
-        px[1] = mz_clip_u8(light * (alpha * 1.0 + (1.0 - alpha) * c[1]));
-        px[2] = mz_clip_u8(light * (alpha * 1.0 + (1.0 - alpha) * c[2]));
-      }
-    }
-    // ---- ceiling :214-244 ----
-    for (int d_v = 0; d_v < H / 2; ++d_v) {
-      const double v_screen = half_v - (d_v + 0.5) * pixel_size;
-      const double distance = (ceil_height - vision_height) / v_screen * l_focal;
-      double light = v_screen / l_focal;
-      light = light > 1.0 ? 1.0 : light;
-      if (distance > visibility) continue;
-      const double eff = distance / (double)cos_hp_f;
-      double alpha = 2.0 * eff / visibility - 1.0;
-      alpha = alpha < 0.0 ? 0.0 : alpha;
-      alpha = alpha > 1.0 ? 1.0 : alpha;
-      const double hit_x = eff * (double)cos_abs + (double)pos0, hit_y = eff * (double)sin_abs + (double)pos1;
-      const double fi = hit_x / cell_size, fj = hit_y / cell_size;
-      double d_i = fi - floor(fi), d_j = fj - floor(fj);
-      const int i = (int)fi, j = (int)fj;
-      const double eff_ps = eff * pixel_size / l_focal;
-      if (i < n && i >= 0 && j < n && j >= 0) {
-        d_i *= percell; d_j *= percell;
-        d_i -= floor(d_i); d_j -= floor(d_j);
-        d_i *= 256; d_j *= 256;
-        double c[3];
-        mz_interpolate<PACKED>(ceil_t, d_i, d_j, eff_ps, tps, tps, c);
-        uint8_t* px = col + d_v * 3;
-        px[0] = mz_clip_u8(light * (alpha * 1.0 + (1.0 - alpha) * c[0]));
-        px[1] = mz_clip_u8(light * (alpha * 1.0 + (1.0 - alpha) * c[1]));
-        px[2] = mz_clip_u8(light * (alpha * 1.0 + (1.0 - alpha) * c[2]));
-      }
-    }
-  }
-  __syncthreads();
   // quirk (i), SURVEY.md M5: the wall stage filters with the eff_distance left over by the LAST floor/ceiling
-  // pixel the reference painted: last ceiling row within visibility (else last floor row), column W-1
-  double eff_stale = 0.0;
-  {
-    const float cos_last = *s_cos_last;
-    bool found = false;
-    for (int d_v = H / 2 - 1; d_v >= 0 && !found; --d_v) {
-      const double v_screen = half_v - (d_v + 0.5) * pixel_size;
-      const double distance = (ceil_height - vision_height) / v_screen * l_focal;
-      if (!(distance > visibility)) { eff_stale = distance / (double)cos_last; found = true; }
-    }
-    for (int d_v = H / 2 + 1; d_v <= H - 1 && !found; ++d_v) {
-      const double v_screen = (d_v + 0.5) * pixel_size - half_v;
-      const double distance = vision_height / v_screen * l_focal;
-      if (!(distance > visibility)) { eff_stale = distance / (double)cos_last; found = true; }
-    }
-  }
+  // pixel the reference painted: last ceiling row within visibility (else last floor row), column W-1.
+  // It depends on the pose-free screen geometry only, so every lane derives it (no exchange).
+  const double cmh = ceil_height - vision_height;
   const float cs_f = (float)cell_size, eps_f = (float)1.0e-8, vis_f = (float)visibility, lf_f = (float)l_focal;
   for (int d_h = threadIdx.x; d_h < W; d_h += blockDim.x) {
-    double tan_hp = (-0.5 - W / 2.0) * pixel_factor;
-    for (int q = 0; q <= d_h; ++q) tan_hp += pixel_factor;
+    // ---- per-column tables :170-177 (the reference accumulates tan_hp column by column) ----
+    double tan_hp = (-0.5 - W / 2.0) * pixel_factor, tan_acc = tan_hp;
+    for (int q = 0; q < W; ++q) { tan_acc += pixel_factor; if (q == d_h) tan_hp = tan_acc; }
     const double cos_hp = sqrt(1.0 / (1.0 + tan_hp * tan_hp));
     const double sin_hp = tan_hp * cos_hp;
     const float so = (float)(sin_hp * c_ori + cos_hp * s_ori);
     const float co = (float)(cos_hp * c_ori - sin_hp * s_ori);
     const float cos_hp_f = (float)cos_hp;
+    const float cos_last = (float)sqrt(1.0 / (1.0 + tan_acc * tan_acc));
+    double eff_stale = 0.0;
+    {
+      bool found = false;
+      for (int d_v = H / 2 - 1; d_v >= 0 && !found; --d_v) {
+        const double v_screen = half_v - (d_v + 0.5) * pixel_size;
+        const double distance = cmh / v_screen * l_focal;
+        if (!(distance > visibility)) { eff_stale = distance / (double)cos_last; found = true; }
+      }
+      for (int d_v = H / 2 + 1; d_v <= H - 1 && !found; ++d_v) {
+        const double v_screen = (d_v + 0.5) * pixel_size - half_v;
+        const double distance = vision_height / v_screen * l_focal;
+        if (!(distance > visibility)) { eff_stale = distance / (double)cos_last; found = true; }
+      }
+    }
     uint8_t* col = lds + (size_t)d_h * H * 3;
     // ---- DDA_2D :47-115, float32 ----
     const int i0 = (int)(pos0 / cs_f), j0 = (int)(pos1 / cs_f);
@@ -518,38 +458,85 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
         sdy = ddy;
       }
     }
-    // ---- wall column :258-298 ----
-    float alpha = 2.0f * hit_dist / vis_f - 1.0f;
-    alpha = alpha < 0.0f ? 0.0f : alpha;
-    alpha = alpha > 1.0f ? 1.0f : alpha;
+    // ---- wall column parameters :258-298 ----
+    float alpha_w = 2.0f * hit_dist / vis_f - 1.0f;
+    alpha_w = alpha_w < 0.0f ? 0.0f : alpha_w;
+    alpha_w = alpha_w > 1.0f ? 1.0f : alpha_w;
     const bool in_grid = hi >= 0 && hi < NG && hj >= 0 && hj < NG;
     const int text_id = in_grid ? texts[hi * NG + hj] : 0;
     const float hit_pt_x = hit_dist * co + pos0, hit_pt_y = hit_dist * so + pos1;
-    float local_h, light;
-    if (hit_side == 0) { local_h = hit_pt_y / cs_f; local_h -= floorf(local_h); light = fabsf(co); }
-    else { local_h = hit_pt_x / cs_f; local_h -= floorf(local_h); light = fabsf(so); }
+    float local_h, light_w;
+    if (hit_side == 0) { local_h = hit_pt_y / cs_f; local_h -= floorf(local_h); light_w = fabsf(co); }
+    else { local_h = hit_pt_x / cs_f; local_h -= floorf(local_h); light_w = fabsf(so); }
     float ratio = hit_dist * cos_hp_f / lf_f;
     if (fabsf(ratio) < eps_f) ratio = ratio > 0 ? eps_f : -eps_f;
-    const float top_v = (float)(ceil_height - vision_height) / ratio, bot_v = (float)vision_height / ratio;
+    const float top_v = (float)cmh / ratio, bot_v = (float)vision_height / ratio;
     int v_s = (int)((half_v - (double)top_v) / pixel_size), v_e = (int)((half_v + (double)bot_v) / pixel_size);
     v_s = v_s < 0 ? 0 : v_s;
     v_e = v_e > H ? H : v_e;
     const void* wt = PACKED ? (const void*)(P.pk_walls + (size_t)text_id * 256 * MZ_TEX_PITCH)
                             : (const void*)(P.T.tex_walls + (size_t)text_id * 256 * 256 * 3);
     const double eff_ps_w = eff_stale * pixel_size / l_focal;
-    const float a_far = alpha * 1.0f, a_near = 1.0f - alpha;
-    for (int d_v = v_s; d_v < v_e; ++d_v) {
-      const double local_v = (half_v - (d_v + 0.5) * pixel_size) * (double)ratio + vision_height;
+    float wall_ti;
+    {
       float d_i = local_h * (float)percell;
-      double d_j = local_v / text_size;
-      d_i -= floorf(d_i); d_j -= floor(d_j);
-      const int ti = (int)(256.0f * d_i), tj = (int)(256 * d_j);
-      double c[3];
-      mz_interpolate<PACKED>(wt, (double)ti, (double)tj, eff_ps_w, tps, tps, c);
+      d_i -= floorf(d_i);
+      wall_ti = (float)(int)(256.0f * d_i);
+    }
+    const double a_far_w = (double)(alpha_w * 1.0f), a_near_w = (double)(1.0f - alpha_w);
+
+    // ---- one pass over the column.  The reference paints floor (:180-211), ceiling (:214-244) and then the wall
+    // segment [v_s, v_e) over them (:258-298); a floor/ceiling pixel under the wall is a dead store, so each pixel
+    // is filtered once with the parameters of the stage that owns it.  Every lane runs exactly H iterations and
+    // there is a single copy of the 16-tap filter.  Unpainted pixels keep FAR_RGB = 1 (:165-166).
+    for (int d_v = 0; d_v < H; ++d_v) {
+      bool paint = false;
+      const void* tx = wt;
+      double f_i = 0.0, f_j = 0.0, f_d = eff_ps_w, L = (double)light_w, A = a_far_w, B = a_near_w;
+      if (d_v >= v_s && d_v < v_e) {
+        const double local_v = (half_v - (d_v + 0.5) * pixel_size) * (double)ratio + vision_height;
+        double d_j = local_v / text_size;
+        d_j -= floor(d_j);
+        f_i = (double)wall_ti;
+        f_j = (double)(int)(256 * d_j);
+        paint = true;
+      } else if (d_v != H / 2) {
+        const bool is_floor = d_v > H / 2;   // wave-uniform
+        const double v_screen = is_floor ? (d_v + 0.5) * pixel_size - half_v : half_v - (d_v + 0.5) * pixel_size;
+        const double distance = (is_floor ? vision_height : cmh) / v_screen * l_focal;
+        double light = v_screen / l_focal;
+        light = light > 1.0 ? 1.0 : light;
+        if (!(distance > visibility)) {
+          const double eff = distance / (double)cos_hp_f;
+          double alpha = 2.0 * eff / visibility - 1.0;
+          alpha = alpha < 0.0 ? 0.0 : alpha;
+          alpha = alpha > 1.0 ? 1.0 : alpha;
+          if (is_floor) alpha *= light;   // :189, the floor only
+          const double hit_x = eff * (double)co + (double)pos0, hit_y = eff * (double)so + (double)pos1;
+          const double fi = hit_x / cell_size, fj = hit_y / cell_size;
+          double d_i = fi - floor(fi), d_j = fj - floor(fj);
+          const int i = (int)fi, j = (int)fj;
+          if (i < n && i >= 0 && j < n && j >= 0) {
+            d_i *= percell; d_j *= percell;
+            d_i -= floor(d_i); d_j -= floor(d_j);
+            f_i = d_i * 256; f_j = d_j * 256;
+            f_d = eff * pixel_size / l_focal;
+            tx = is_floor ? ground : ceil_t;
+            L = light; A = alpha * 1.0; B = 1.0 - alpha;
+            paint = true;
+          }
+        }
+      }
       uint8_t* px = col + d_v * 3;
-      px[0] = mz_clip_u8((double)light * ((double)a_far + (double)a_near * c[0]));
-      px[1] = mz_clip_u8((double)light * ((double)a_far + (double)a_near * c[1]));
-      px[2] = mz_clip_u8((double)light * ((double)a_far + (double)a_near * c[2]));
+      if (paint) {
+        double c[3];
+        mz_interpolate<PACKED>(tx, f_i, f_j, f_d, tps, tps, c);
+        px[0] = mz_clip_u8(L * (A + B * c[0]));
+        px[1] = mz_clip_u8(L * (A + B * c[1]));
+        px[2] = mz_clip_u8(L * (A + B * c[2]));
+      } else {
+        px[0] = 1; px[1] = 1; px[2] = 1;
+      }
     }
     // ---- transparent landmark overlays, far to near :301-318 ----
     for (int q = n_tr - 1; q >= 0; --q) {
@@ -559,7 +546,7 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
       for (int z = 0; z < 16; ++z) if (z == q) { hd = tr_dist[z]; lid = tr_id[z]; }
       float r2 = hd * cos_hp_f / lf_f;
       if (fabsf(r2) < eps_f) r2 = r2 > 0 ? eps_f : -eps_f;
-      const float tv = (float)(ceil_height - vision_height) / r2, bv = (float)vision_height / r2;
+      const float tv = (float)cmh / r2, bv = (float)vision_height / r2;
       int s2 = (int)((half_v - (double)tv) / pixel_size), e2 = (int)((half_v + (double)bv) / pixel_size);
       s2 = s2 < 0 ? 0 : s2;
       e2 = e2 > H ? H : e2;
