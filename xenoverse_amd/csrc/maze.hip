@@ -10,9 +10,11 @@
 //                 around the starting cell: they are fetched ONCE into a 25-bit register mask; the sub-step
 //                 loop touches no memory.
 //   ray-cast    : one workgroup per env frame, one lane per screen column d_h (the reference's per-column
-//                 tables become per-lane registers), loop over rows d_v.  The frame is staged in LDS as bytes
-//                 and leaves with coalesced 16-byte stores; the wall stage overwrites floor/ceiling and the
+//                 tables become per-lane registers), ONE loop over rows d_v: each pixel is filtered once, by
+//                 the stage (wall / floor / ceiling) whose store survives in the reference.  The frame is
+//                 staged in LDS as bytes, in chunks of rows, and leaves with coalesced 16-byte stores; the
 //                 landmark overlays read-modify-write there, as the reference does on its int32 array.
+//                 Integer-valued texture libraries are read from a packed RGBX-byte copy (16 B per filter row).
 #include "philox.h"
 #include "xv_common.h"
 
@@ -32,6 +34,7 @@ struct MazeArgs {
   int32_t* cmd_age;
   uint8_t* need_reset;
   double* collision;
+  int HC;   // rows per LDS chunk of the ray-caster
   // packed RGBX-byte copies of the texture libraries ([n][256][MZ_TEX_PITCH] uint32), nullptr if not integral
   const uint32_t* pk_walls;
   const uint32_t* pk_grounds;
@@ -50,7 +53,8 @@ struct xv_maze {
   MazeArgs a;
 };
 
-static const size_t MAZE_LDS_STAGE_MAX = 150 * 1024;   // LDS is 160 KiB per CU
+static const size_t MAZE_LDS_CHUNK_MAX = 50176;   // 256 columns x (64 rows x 3 + 4) bytes: three workgroups per 160-KiB CU
+static inline int maze_rc_threads(int W) { return W <= 64 ? 64 : (W <= 128 ? 128 : 256); }
 #define MZ_TEX_PITCH 260   // 256 texels + 3 wrapped ones (+1 pad): the 4 y-taps of a filter row never wrap
 
 __device__ const double MZ_ACT16[16][2] = {{0.0, 0.5}, {0.05, 0.0}, {-0.05, 0.0}, {0.1, 0.0}, {-0.1, 0.0}, {0.2, 0.0},
@@ -347,12 +351,12 @@ __device__ __forceinline__ uint8_t mz_clip_u8(double v) {   // numpy.clip(v, 0, 
 }
 
 // One workgroup per frame, one lane per column.  FINAL: render the stored pre-reset pose of flagged envs.
-// STAGE: the frame is built in LDS and leaves with 16-byte stores (frames up to ~150 KB, e.g. 224x224);
-// larger frames (the registered 256x256 = 192 KB) are built in place in global memory, each lane owning the
-// contiguous H*3 bytes of its column.
-template <bool FINAL, bool STAGE, bool PACKED>
+// The frame is built in LDS in chunks of P.HC rows ([column][HC*3 + 4] bytes: the pad makes the per-lane byte
+// writes bank-conflict free) and each chunk leaves with 16-byte stores; a 64x64 frame is one chunk, the registered
+// 256x256 frame four chunks of 64 rows (49 KiB of LDS, three workgroups per CU).
+template <bool FINAL, bool PACKED>
 __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* frames, float* command_rgb) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds_dyn[];   // STAGE: [W][H][3] bytes
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int e = blockIdx.x;
   if (FINAL && !P.fin_flag[e]) return;   // block-uniform
   const int W = P.W, H = P.H, NG = P.NG;
@@ -385,14 +389,18 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
   const double tps = text_size / 256;
   const size_t fsz = (size_t)W * H * 3;
   uint8_t* dst = frames + (size_t)e * fsz;
-  uint8_t* lds = STAGE ? lds_dyn : dst;   // where the frame is built
+  const int HC = P.HC, cstride = HC * 3 + 4;
+  const int idxc = cmd_idx_e < P.n_cmd ? cmd_idx_e : P.n_cmd - 1;
+  const int cmd = P.T.commands[(size_t)t * P.n_cmd + idxc];
 
   // quirk (i), SURVEY.md M5: the wall stage filters with the eff_distance left over by the LAST floor/ceiling
   // pixel the reference painted: last ceiling row within visibility (else last floor row), column W-1.
   // It depends on the pose-free screen geometry only, so every lane derives it (no exchange).
   const double cmh = ceil_height - vision_height;
   const float cs_f = (float)cell_size, eps_f = (float)1.0e-8, vis_f = (float)visibility, lf_f = (float)l_focal;
-  for (int d_h = threadIdx.x; d_h < W; d_h += blockDim.x) {
+  for (int g0 = 0; g0 < W; g0 += blockDim.x) {
+    // lanes past the last column repeat it (no divergence); the flush below copies real columns only
+    const int d_h = min(g0 + (int)threadIdx.x, W - 1);
     // ---- per-column tables :170-177 (the reference accumulates tan_hp column by column) ----
     double tan_hp = (-0.5 - W / 2.0) * pixel_factor, tan_acc = tan_hp;
     for (int q = 0; q < W; ++q) { tan_acc += pixel_factor; if (q == d_h) tan_hp = tan_acc; }
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
         if (!(distance > visibility)) { eff_stale = distance / (double)cos_last; found = true; }
       }
     }
-    uint8_t* col = lds + (size_t)d_h * H * 3;
+    uint8_t* col = lds + (size_t)threadIdx.x * cstride;
     // ---- DDA_2D :47-115, float32 ----
     const int i0 = (int)(pos0 / cs_f), j0 = (int)(pos1 / cs_f);
     const float c_sign = co < 0 ? -1.0f : 1.0f, s_sign = so < 0 ? -1.0f : 1.0f;
@@ -489,99 +497,111 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
     // segment [v_s, v_e) over them (:258-298); a floor/ceiling pixel under the wall is a dead store, so each pixel
     // is filtered once with the parameters of the stage that owns it.  Every lane runs exactly H iterations and
     // there is a single copy of the 16-tap filter.  Unpainted pixels keep FAR_RGB = 1 (:165-166).
-    for (int d_v = 0; d_v < H; ++d_v) {
-      bool paint = false;
-      const void* tx = wt;
-      double f_i = 0.0, f_j = 0.0, f_d = eff_ps_w, L = (double)light_w, A = a_far_w, B = a_near_w;
-      if (d_v >= v_s && d_v < v_e) {
-        const double local_v = (half_v - (d_v + 0.5) * pixel_size) * (double)ratio + vision_height;
-        double d_j = local_v / text_size;
-        d_j -= floor(d_j);
-        f_i = (double)wall_ti;
-        f_j = (double)(int)(256 * d_j);
-        paint = true;
-      } else if (d_v != H / 2) {
-        const bool is_floor = d_v > H / 2;   // wave-uniform
-        const double v_screen = is_floor ? (d_v + 0.5) * pixel_size - half_v : half_v - (d_v + 0.5) * pixel_size;
-        const double distance = (is_floor ? vision_height : cmh) / v_screen * l_focal;
-        double light = v_screen / l_focal;
-        light = light > 1.0 ? 1.0 : light;
-        if (!(distance > visibility)) {
-          const double eff = distance / (double)cos_hp_f;
-          double alpha = 2.0 * eff / visibility - 1.0;
-          alpha = alpha < 0.0 ? 0.0 : alpha;
-          alpha = alpha > 1.0 ? 1.0 : alpha;
-          if (is_floor) alpha *= light;   // :189, the floor only
-          const double hit_x = eff * (double)co + (double)pos0, hit_y = eff * (double)so + (double)pos1;
-          const double fi = hit_x / cell_size, fj = hit_y / cell_size;
-          double d_i = fi - floor(fi), d_j = fj - floor(fj);
-          const int i = (int)fi, j = (int)fj;
-          if (i < n && i >= 0 && j < n && j >= 0) {
-            d_i *= percell; d_j *= percell;
-            d_i -= floor(d_i); d_j -= floor(d_j);
-            f_i = d_i * 256; f_j = d_j * 256;
-            f_d = eff * pixel_size / l_focal;
-            tx = is_floor ? ground : ceil_t;
-            L = light; A = alpha * 1.0; B = 1.0 - alpha;
-            paint = true;
+    for (int c0 = 0; c0 < H; c0 += HC) {
+      const int c1 = min(c0 + HC, H);
+      for (int d_v = c0; d_v < c1; ++d_v) {
+        bool paint = false;
+        const void* tx = wt;
+        double f_i = 0.0, f_j = 0.0, f_d = eff_ps_w, L = (double)light_w, A = a_far_w, B = a_near_w;
+        if (d_v >= v_s && d_v < v_e) {
+          const double local_v = (half_v - (d_v + 0.5) * pixel_size) * (double)ratio + vision_height;
+          double d_j = local_v / text_size;
+          d_j -= floor(d_j);
+          f_i = (double)wall_ti;
+          f_j = (double)(int)(256 * d_j);
+          paint = true;
+        } else if (d_v != H / 2) {
+          const bool is_floor = d_v > H / 2;   // wave-uniform
+          const double v_screen = is_floor ? (d_v + 0.5) * pixel_size - half_v : half_v - (d_v + 0.5) * pixel_size;
+          const double distance = (is_floor ? vision_height : cmh) / v_screen * l_focal;
+          double light = v_screen / l_focal;
+          light = light > 1.0 ? 1.0 : light;
+          if (!(distance > visibility)) {
+            const double eff = distance / (double)cos_hp_f;
+            double alpha = 2.0 * eff / visibility - 1.0;
+            alpha = alpha < 0.0 ? 0.0 : alpha;
+            alpha = alpha > 1.0 ? 1.0 : alpha;
+            if (is_floor) alpha *= light;   // :189, the floor only
+            const double hit_x = eff * (double)co + (double)pos0, hit_y = eff * (double)so + (double)pos1;
+            const double fi = hit_x / cell_size, fj = hit_y / cell_size;
+            double d_i = fi - floor(fi), d_j = fj - floor(fj);
+            const int i = (int)fi, j = (int)fj;
+            if (i < n && i >= 0 && j < n && j >= 0) {
+              d_i *= percell; d_j *= percell;
+              d_i -= floor(d_i); d_j -= floor(d_j);
+              f_i = d_i * 256; f_j = d_j * 256;
+              f_d = eff * pixel_size / l_focal;
+              tx = is_floor ? ground : ceil_t;
+              L = light; A = alpha * 1.0; B = 1.0 - alpha;
+              paint = true;
+            }
+          }
+        }
+        uint8_t* px = col + (d_v - c0) * 3;
+        if (paint) {
+          double c[3];
+          mz_interpolate<PACKED>(tx, f_i, f_j, f_d, tps, tps, c);
+          px[0] = mz_clip_u8(L * (A + B * c[0]));
+          px[1] = mz_clip_u8(L * (A + B * c[1]));
+          px[2] = mz_clip_u8(L * (A + B * c[2]));
+        } else {
+          px[0] = 1; px[1] = 1; px[2] = 1;
+        }
+      }
+      // ---- transparent landmark overlays, far to near :301-318 ----
+      for (int q = n_tr - 1; q >= 0; --q) {
+        float hd = 0.0f;
+        int lid = 0;
+#pragma unroll
+        for (int z = 0; z < 16; ++z) if (z == q) { hd = tr_dist[z]; lid = tr_id[z]; }
+        float r2 = hd * cos_hp_f / lf_f;
+        if (fabsf(r2) < eps_f) r2 = r2 > 0 ? eps_f : -eps_f;
+        const float tv = (float)cmh / r2, bv = (float)vision_height / r2;
+        int s2 = (int)((half_v - (double)tv) / pixel_size), e2 = (int)((half_v + (double)bv) / pixel_size);
+        s2 = s2 < c0 ? c0 : s2;
+        e2 = e2 > c1 ? c1 : e2;
+        float a2 = 2.0f * hd / vis_f - 1.0f;
+        a2 = a2 < 0.0f ? 0.0f : a2;
+        a2 = a2 > 1.0f ? 1.0f : a2;
+        float tint[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tint[c] = 0.30f * ((1.0f - a2) * MZ_LANDMARK_RGB[lid][c] + a2 * 1.0f);
+        for (int d_v = s2; d_v < e2; ++d_v) {
+          uint8_t* px = col + (d_v - c0) * 3;
+          px[0] = mz_clip_u8((1.0 - 0.30) * (double)px[0] + (double)tint[0]);
+          px[1] = mz_clip_u8((1.0 - 0.30) * (double)px[1] + (double)tint[1]);
+          px[2] = mz_clip_u8((1.0 - 0.30) * (double)px[2] + (double)tint[2]);
+        }
+      }
+      // ---- command bar, maze_continuous_3d.py:23-29,102-107 (its x range is derived from H, as there) ----
+      if (P.command_in_observation) {
+        const int sx = (int)(0.25 * H), sy = (int)(0.10 * H), ex = (int)(0.25 * H + 0.50 * H), ey = (int)(0.10 * H + 0.05 * W);
+        if (d_h >= sx && d_h < ex)
+          for (int y = max(sy, c0); y < ey && y < c1; ++y)
+            for (int c = 0; c < 3; ++c) col[(y - c0) * 3 + c] = (uint8_t)(int)MZ_LANDMARK_RGB[cmd][c];
+      }
+      __syncthreads();
+      // ---- chunk out: column k's rows [c0, c1) are (c1 - c0) * 3 contiguous bytes of the frame ----
+      {
+        const int ncols = min((int)blockDim.x, W - g0), run = (c1 - c0) * 3;
+        uint8_t* gdst = dst + ((size_t)g0 * H + c0) * 3;
+        if (((H * 3) & 15) == 0 && ((c0 * 3) & 15) == 0 && (run & 15) == 0) {
+          const int vpr = run >> 4;
+          for (int k = threadIdx.x; k < ncols * vpr; k += blockDim.x) {
+            const int c = k / vpr, v = k - c * vpr;
+            const uint32_t* sp = reinterpret_cast<const uint32_t*>(lds + (size_t)c * cstride + v * 16);
+            uint4 val;
+            val.x = sp[0]; val.y = sp[1]; val.z = sp[2]; val.w = sp[3];
+            *reinterpret_cast<uint4*>(gdst + (size_t)c * H * 3 + v * 16) = val;
+          }
+        } else {
+          for (int k = threadIdx.x; k < ncols * run; k += blockDim.x) {
+            const int c = k / run, v = k - c * run;
+            gdst[(size_t)c * H * 3 + v] = lds[(size_t)c * cstride + v];
           }
         }
       }
-      uint8_t* px = col + d_v * 3;
-      if (paint) {
-        double c[3];
-        mz_interpolate<PACKED>(tx, f_i, f_j, f_d, tps, tps, c);
-        px[0] = mz_clip_u8(L * (A + B * c[0]));
-        px[1] = mz_clip_u8(L * (A + B * c[1]));
-        px[2] = mz_clip_u8(L * (A + B * c[2]));
-      } else {
-        px[0] = 1; px[1] = 1; px[2] = 1;
-      }
-    }
-    // ---- transparent landmark overlays, far to near :301-318 ----
-    for (int q = n_tr - 1; q >= 0; --q) {
-      float hd = 0.0f;
-      int lid = 0;
-#pragma unroll
-      for (int z = 0; z < 16; ++z) if (z == q) { hd = tr_dist[z]; lid = tr_id[z]; }
-      float r2 = hd * cos_hp_f / lf_f;
-      if (fabsf(r2) < eps_f) r2 = r2 > 0 ? eps_f : -eps_f;
-      const float tv = (float)cmh / r2, bv = (float)vision_height / r2;
-      int s2 = (int)((half_v - (double)tv) / pixel_size), e2 = (int)((half_v + (double)bv) / pixel_size);
-      s2 = s2 < 0 ? 0 : s2;
-      e2 = e2 > H ? H : e2;
-      float a2 = 2.0f * hd / vis_f - 1.0f;
-      a2 = a2 < 0.0f ? 0.0f : a2;
-      a2 = a2 > 1.0f ? 1.0f : a2;
-      float tint[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) tint[c] = 0.30f * ((1.0f - a2) * MZ_LANDMARK_RGB[lid][c] + a2 * 1.0f);
-      for (int d_v = s2; d_v < e2; ++d_v) {
-        uint8_t* px = col + d_v * 3;
-        px[0] = mz_clip_u8((1.0 - 0.30) * (double)px[0] + (double)tint[0]);
-        px[1] = mz_clip_u8((1.0 - 0.30) * (double)px[1] + (double)tint[1]);
-        px[2] = mz_clip_u8((1.0 - 0.30) * (double)px[2] + (double)tint[2]);
-      }
-    }
-  }
-  __syncthreads();
-  const int idxc = cmd_idx_e < P.n_cmd ? cmd_idx_e : P.n_cmd - 1;
-  const int cmd = P.T.commands[(size_t)t * P.n_cmd + idxc];
-  if (P.command_in_observation) {   // maze_continuous_3d.py:23-29,102-107
-    const int sx = (int)(0.25 * H), sy = (int)(0.10 * H), ex = (int)(0.25 * H + 0.50 * H), ey = (int)(0.10 * H + 0.05 * W);
-    for (int x = sx + threadIdx.x; x < ex && x < W; x += blockDim.x)
-      for (int y = sy; y < ey && y < H; ++y)
-        for (int c = 0; c < 3; ++c) lds[((size_t)x * H + y) * 3 + c] = (uint8_t)(int)MZ_LANDMARK_RGB[cmd][c];
-    __syncthreads();
-  }
-  // ---- frame out: coalesced 16-byte stores ----
-  if (STAGE) {
-    if ((fsz & 15) == 0) {
-      const uint4* s4 = reinterpret_cast<const uint4*>(lds);
-      uint4* d4 = reinterpret_cast<uint4*>(dst);
-      for (size_t k = threadIdx.x; k < fsz / 16; k += blockDim.x) d4[k] = s4[k];
-    } else {
-      for (size_t k = threadIdx.x; k < fsz; k += blockDim.x) dst[k] = lds[k];
+      __syncthreads();
     }
   }
   if (command_rgb && threadIdx.x < 3) command_rgb[(size_t)e * 3 + threadIdx.x] = MZ_LANDMARK_RGB[cmd][threadIdx.x];
@@ -669,17 +689,15 @@ extern "C" int xv_maze_create(xv_engine* e, int n_env, int n_task, int NG, int n
       else { for (int k = 0; k < 3; ++k) if (pk[k]) (void)hipFree(pk[k]); (void)hipGetLastError(); }
     }
   }
-  // the ray-cast kernel stages a whole frame in LDS when it fits: raise the dynamic LDS limit past 64 KiB
-  const size_t lds_bytes = ((size_t)W * H * 3 + 15) & ~(size_t)15;
-  if (lds_bytes <= MAZE_LDS_STAGE_MAX && lds_bytes > 48 * 1024) {
-    XV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&maze_raycast_kernel<false, true, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    XV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&maze_raycast_kernel<true, true, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    XV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&maze_raycast_kernel<false, true, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    XV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&maze_raycast_kernel<true, true, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  // ray-caster LDS chunk: the whole column if it fits in MAZE_LDS_CHUNK_MAX, else a multiple of 16 rows
+  {
+    const int threads = maze_rc_threads(W);
+    int hc = H;
+    if ((size_t)threads * (H * 3 + 4) > MAZE_LDS_CHUNK_MAX) {
+      hc = (int)((MAZE_LDS_CHUNK_MAX / threads - 4) / 3) & ~15;
+      if (hc < 16) hc = 16;
+    }
+    a.HC = hc;
   }
   XV_LAUNCH_CHECK();
   *out = h;
@@ -700,17 +718,14 @@ extern "C" int xv_maze_destroy(xv_maze* h) {
 
 static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, bool final) {
   const MazeArgs& a = h->a;
-  const int threads = a.W <= 64 ? 64 : (a.W <= 128 ? 128 : 256);
-  const size_t lds_bytes = ((size_t)a.W * a.H * 3 + 15) & ~(size_t)15;
-  const bool stage = lds_bytes <= MAZE_LDS_STAGE_MAX;
+  const int threads = maze_rc_threads(a.W);
+  const size_t lds_bytes = ((size_t)threads * (a.HC * 3 + 4) + 15) & ~(size_t)15;
   float* crgb = final ? nullptr : command_rgb;
   const bool packed = a.pk_walls != nullptr;
-#define MAZE_RC(F, S, K) \
-  hipLaunchKernelGGL((maze_raycast_kernel<F, S, K>), dim3(a.n_env), dim3(threads), (S) ? lds_bytes : 0, h->eng->stream, a, frames, crgb)
-#define MAZE_RC2(F, S) do { if (packed) MAZE_RC(F, S, true); else MAZE_RC(F, S, false); } while (0)
-  if (final) { if (stage) MAZE_RC2(true, true); else MAZE_RC2(true, false); }
-  else { if (stage) MAZE_RC2(false, true); else MAZE_RC2(false, false); }
-#undef MAZE_RC2
+#define MAZE_RC(F, K) \
+  hipLaunchKernelGGL((maze_raycast_kernel<F, K>), dim3(a.n_env), dim3(threads), lds_bytes, h->eng->stream, a, frames, crgb)
+  if (final) { if (packed) MAZE_RC(true, true); else MAZE_RC(true, false); }
+  else { if (packed) MAZE_RC(false, true); else MAZE_RC(false, false); }
 #undef MAZE_RC
   XV_LAUNCH_CHECK();
   return XV_OK;
