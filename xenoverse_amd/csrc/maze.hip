@@ -270,16 +270,28 @@ __global__ __launch_bounds__(256) void maze_step_kernel(MazeArgs P, const void* 
 // div_scale / rcp / two Newton steps on the reciprocal / q0 = n*y / r = fma(-d,q0,n) / q = fma(r,y,q0) / div_fixup;
 // the scale and fixup steps only act on operands near the ends of the exponent range (d2 is in [1e-8, ~1e3] and
 // n = 10*dist is 0 or in [~1e-40, 1e4] here).  The refined reciprocal y is hoisted out of the tap loop and each
-// tap keeps the last three operations: the same correctly rounded quotient, 3 instructions instead of 14.
+// tap keeps the last three operations: the same correctly rounded quotient, 3 instructions instead of 14
+// (scripts/devtools/check_div.hip: 0 mismatches against hipcc's division in 1.3e10 quotients over these ranges).
+// The ray-caster's other divisions by per-column / per-task constants use the same helper.
 // dist >= 0 and d2 > 0 make the reference's upper clamp (wht > 1 -> 1) unreachable; the lower one is a v_max_f64.
+struct MzDivisor { double b, y; };
+__device__ __forceinline__ MzDivisor mz_divisor(double b) {
+  double y = __builtin_amdgcn_rcp(b);
+  y = __builtin_fma(y, __builtin_fma(-b, y, 1.0), y);
+  y = __builtin_fma(y, __builtin_fma(-b, y, 1.0), y);
+  return {b, y};
+}
+__device__ __forceinline__ double mz_div(double a, const MzDivisor& r) {   // == a / r.b (see above)
+  const double q0 = a * r.y;
+  return __builtin_fma(__builtin_fma(-r.b, q0, a), r.y, q0);
+}
+
 template <bool PACKED>
 __device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, double i, double j, double d,
                                                double px, double py, double (&out)[3]) {
   double d2 = d * d;
   if (d2 < 1.0e-8) d2 = 1.0e-8;
-  double y = __builtin_amdgcn_rcp(d2);
-  y = __builtin_fma(y, __builtin_fma(-d2, y, 1.0), y);
-  y = __builtin_fma(y, __builtin_fma(-d2, y, 1.0), y);
+  const MzDivisor D2 = mz_divisor(d2);
   const int ib = (int)i, jb = (int)j;
   double sum_wht = 0.0;
   float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
@@ -304,10 +316,7 @@ __device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, do
 #pragma unroll
     for (int yy = -1; yy < 3; ++yy) {
       const double dist = aa + bb[yy + 1];
-      const double num = 10 * dist;
-      const double q0 = num * y;
-      const double quo = __builtin_fma(__builtin_fma(-d2, q0, num), y, q0);   // == num / d2
-      const double wht = __builtin_fmax(1.0 - quo, 0.01);
+      const double wht = __builtin_fmax(1.0 - mz_div(10 * dist, D2), 0.01);
       sum_wht += wht;
       float t0, t1, t2;
       if (PACKED) {
@@ -322,7 +331,8 @@ __device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, do
       s2 = (float)((double)s2 + wht * (double)t2);
     }
   }
-  out[0] = (double)s0 / sum_wht; out[1] = (double)s1 / sum_wht; out[2] = (double)s2 / sum_wht;
+  const MzDivisor SW = mz_divisor(sum_wht);   // in [0.16, 16]
+  out[0] = mz_div((double)s0, SW); out[1] = mz_div((double)s1, SW); out[2] = mz_div((double)s2, SW);
 }
 
 // texel (x, y) of library entry k -> packed RGBX word at [k][x][y], rows padded with 3 wrapped texels
@@ -390,6 +400,19 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
   const size_t fsz = (size_t)W * H * 3;
   uint8_t* dst = frames + (size_t)e * fsz;
   const int HC = P.HC, cstride = HC * 3 + 4;
+  // per-row table {distance to the floor/ceiling point, light} (:182-186, :216-219): rows only, shared by all columns
+  double2* rowtab = reinterpret_cast<double2*>(lds + (((size_t)blockDim.x * cstride + 15) & ~(size_t)15));
+  for (int d_v = threadIdx.x; d_v < H; d_v += blockDim.x) {
+    const bool is_floor = d_v > H / 2;
+    const double v_screen = is_floor ? (d_v + 0.5) * pixel_size - half_v : half_v - (d_v + 0.5) * pixel_size;
+    double distance = (is_floor ? vision_height : ceil_height - vision_height) / v_screen * l_focal;
+    double light = v_screen / l_focal;
+    light = light > 1.0 ? 1.0 : light;
+    if (d_v == H / 2) distance = __builtin_huge_val();   // the middle row belongs to neither loop
+    rowtab[d_v] = make_double2(distance, light);
+  }
+  __syncthreads();
+  const MzDivisor R_vis = mz_divisor(visibility), R_cs = mz_divisor(cell_size), R_lf = mz_divisor(l_focal);
   const int idxc = cmd_idx_e < P.n_cmd ? cmd_idx_e : P.n_cmd - 1;
   const int cmd = P.T.commands[(size_t)t * P.n_cmd + idxc];
 
@@ -414,13 +437,11 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
     {
       bool found = false;
       for (int d_v = H / 2 - 1; d_v >= 0 && !found; --d_v) {
-        const double v_screen = half_v - (d_v + 0.5) * pixel_size;
-        const double distance = cmh / v_screen * l_focal;
+        const double distance = rowtab[d_v].x;
         if (!(distance > visibility)) { eff_stale = distance / (double)cos_last; found = true; }
       }
       for (int d_v = H / 2 + 1; d_v <= H - 1 && !found; ++d_v) {
-        const double v_screen = (d_v + 0.5) * pixel_size - half_v;
-        const double distance = vision_height / v_screen * l_focal;
+        const double distance = rowtab[d_v].x;
         if (!(distance > visibility)) { eff_stale = distance / (double)cos_last; found = true; }
       }
     }
@@ -492,6 +513,7 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
       wall_ti = (float)(int)(256.0f * d_i);
     }
     const double a_far_w = (double)(alpha_w * 1.0f), a_near_w = (double)(1.0f - alpha_w);
+    const MzDivisor R_cos = mz_divisor((double)cos_hp_f);
 
     // ---- one pass over the column.  The reference paints floor (:180-211), ceiling (:214-244) and then the wall
     // segment [v_s, v_e) over them (:258-298); a floor/ceiling pixel under the wall is a dead store, so each pixel
@@ -510,27 +532,25 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
           f_i = (double)wall_ti;
           f_j = (double)(int)(256 * d_j);
           paint = true;
-        } else if (d_v != H / 2) {
+        } else {
           const bool is_floor = d_v > H / 2;   // wave-uniform
-          const double v_screen = is_floor ? (d_v + 0.5) * pixel_size - half_v : half_v - (d_v + 0.5) * pixel_size;
-          const double distance = (is_floor ? vision_height : cmh) / v_screen * l_focal;
-          double light = v_screen / l_focal;
-          light = light > 1.0 ? 1.0 : light;
+          const double2 dl = rowtab[d_v];
+          const double distance = dl.x, light = dl.y;
           if (!(distance > visibility)) {
-            const double eff = distance / (double)cos_hp_f;
-            double alpha = 2.0 * eff / visibility - 1.0;
+            const double eff = mz_div(distance, R_cos);
+            double alpha = mz_div(2.0 * eff, R_vis) - 1.0;
             alpha = alpha < 0.0 ? 0.0 : alpha;
             alpha = alpha > 1.0 ? 1.0 : alpha;
             if (is_floor) alpha *= light;   // :189, the floor only
             const double hit_x = eff * (double)co + (double)pos0, hit_y = eff * (double)so + (double)pos1;
-            const double fi = hit_x / cell_size, fj = hit_y / cell_size;
+            const double fi = mz_div(hit_x, R_cs), fj = mz_div(hit_y, R_cs);
             double d_i = fi - floor(fi), d_j = fj - floor(fj);
             const int i = (int)fi, j = (int)fj;
             if (i < n && i >= 0 && j < n && j >= 0) {
               d_i *= percell; d_j *= percell;
               d_i -= floor(d_i); d_j -= floor(d_j);
               f_i = d_i * 256; f_j = d_j * 256;
-              f_d = eff * pixel_size / l_focal;
+              f_d = mz_div(eff * pixel_size, R_lf);
               tx = is_floor ? ground : ceil_t;
               L = light; A = alpha * 1.0; B = 1.0 - alpha;
               paint = true;
@@ -719,7 +739,7 @@ extern "C" int xv_maze_destroy(xv_maze* h) {
 static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, bool final) {
   const MazeArgs& a = h->a;
   const int threads = maze_rc_threads(a.W);
-  const size_t lds_bytes = ((size_t)threads * (a.HC * 3 + 4) + 15) & ~(size_t)15;
+  const size_t lds_bytes = (((size_t)threads * (a.HC * 3 + 4) + 15) & ~(size_t)15) + (size_t)a.H * 16;
   float* crgb = final ? nullptr : command_rgb;
   const bool packed = a.pk_walls != nullptr;
 #define MAZE_RC(F, K) \
