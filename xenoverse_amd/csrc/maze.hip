@@ -355,9 +355,7 @@ __global__ __launch_bounds__(256) void maze_tex_integral_kernel(const float* tex
 }
 
 __device__ __forceinline__ uint8_t mz_clip_u8(double v) {   // numpy.clip(v, 0, 255) -> int32 -> uint8
-  v = v < 0.0 ? 0.0 : v;
-  v = v > 255.0 ? 255.0 : v;
-  return (uint8_t)(int)v;
+  return (uint8_t)(int)__builtin_fmin(__builtin_fmax(v, 0.0), 255.0);   // v_max/v_min_f64: no NaNs reach here
 }
 
 // One workgroup per frame, one lane per column.  FINAL: render the stored pre-reset pose of flagged envs.
@@ -539,8 +537,7 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
           if (!(distance > visibility)) {
             const double eff = mz_div(distance, R_cos);
             double alpha = mz_div(2.0 * eff, R_vis) - 1.0;
-            alpha = alpha < 0.0 ? 0.0 : alpha;
-            alpha = alpha > 1.0 ? 1.0 : alpha;
+            alpha = __builtin_fmin(__builtin_fmax(alpha, 0.0), 1.0);
             if (is_floor) alpha *= light;   // :189, the floor only
             const double hit_x = eff * (double)co + (double)pos0, hit_y = eff * (double)so + (double)pos1;
             const double fi = mz_div(hit_x, R_cs), fj = mz_div(hit_y, R_cs);
