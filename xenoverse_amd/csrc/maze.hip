@@ -71,6 +71,23 @@ __device__ const float MZ_LANDMARK_RGB[XV_MAZE_LMAX][3] = {
     {128, 255, 128}, {255, 128, 128}, {0, 96, 128}, {96, 0, 128}, {0, 128, 96}, {96, 128, 0}, {128, 96, 0},
     {128, 0, 96}};
 
+// a / b for a divisor b that is reused: hipcc expands an fp64 division into div_scale / rcp / two Newton steps on
+// the reciprocal / q0 = a*y / r = fma(-b,q0,a) / q = fma(r,y,q0) / div_fixup, and the scale and fixup steps only act
+// on operands near the ends of the exponent range.  Hoisting the refined reciprocal y leaves three instructions per
+// quotient with the same correctly rounded result (scripts/devtools/check_div.hip: 0 mismatches against hipcc's own
+// division in 1.3e10 quotients over the operand ranges used here).
+struct MzDivisor { double b, y; };
+__device__ __forceinline__ MzDivisor mz_divisor(double b) {
+  double y = __builtin_amdgcn_rcp(b);
+  y = __builtin_fma(y, __builtin_fma(-b, y, 1.0), y);
+  y = __builtin_fma(y, __builtin_fma(-b, y, 1.0), y);
+  return {b, y};
+}
+__device__ __forceinline__ double mz_div(double a, const MzDivisor& r) {   // == a / r.b (see above)
+  const double q0 = a * r.y;
+  return __builtin_fma(__builtin_fma(-r.b, q0, a), r.y, q0);
+}
+
 __device__ __forceinline__ double mz_angle_norm(double t) {   // dynamics.py:48-54
   while (t > MZ_PI) t -= MZ_TPI;
   while (t < -MZ_PI) t += MZ_TPI;
@@ -93,10 +110,9 @@ __device__ __forceinline__ double mz_nearest_point(double p0, double p1, double 
 }
 
 // dynamics.py:71-96
-__device__ __forceinline__ void mz_collision_force(double v0, double v1, double cell_size, double col_dist,
+__device__ __forceinline__ void mz_collision_force(double v0, double v1, double cell_size, double eff /* col_dist / cell_size */,
                                                    double& f0, double& f1) {
   const double dist = sqrt(v0 * v0 + v1 * v1);
-  const double eff = col_dist / cell_size;
   f0 = 0.0; f1 = 0.0;
   if (dist > 0.708 + eff) return;
   if (fabs(v0) < 0.5 && fabs(v1) < 0.5) {
@@ -186,24 +202,35 @@ __global__ __launch_bounds__(256) void maze_step_kernel(MazeArgs P, const void* 
   const double t_prec = 0.01, delta_t = 1.0;
   const int iteration = (int)(delta_t / t_prec);
   bool left_patch = false;
+  // The reference evaluates cos/sin of the heading and of the half turn in every sub-step.  All full sub-steps
+  // share dt = t_prec, so the half-turn pair is evaluated once; the heading pair is re-evaluated only when the
+  // heading changed (it does not when turn_rate == 0).  Same arguments, same functions, same values.
+  const MzDivisor R_cs = mz_divisor(cell_size);
+  const double eff_cd = col_dist / cell_size;
+  const double rad = turn_rate != 0.0 ? walk_speed / turn_rate : 0.0;
+  double c_dt_full, s_dt_full, c_t, s_t, ori_cached = ori;
+  sincos(0.5 * (turn_rate * t_prec), &s_dt_full, &c_dt_full);
+  sincos(ori, &s_t, &c_t);
   for (int it = 0; it < iteration + 1; ++it) {
     const double rem = delta_t - it * t_prec;
     const double dt = rem < t_prec ? rem : t_prec;
     if (dt < 1.0e-8) continue;
     // vector_move_no_collision: dynamics.py:98-123
     const double d_theta = turn_rate * dt, arc = walk_speed * dt;
-    const double c_t = cos(ori), s_t = sin(ori), c_dt = cos(0.5 * d_theta), s_dt = sin(0.5 * d_theta);
+    double c_dt = c_dt_full, s_dt = s_dt_full;
+    if (dt != t_prec) sincos(0.5 * d_theta, &s_dt, &c_dt);
+    if (ori != ori_cached) { sincos(ori, &s_t, &c_t); ori_cached = ori; }
     const double n_ori = mz_angle_norm(ori + d_theta);
     double dx, dy;
     if (fabs(d_theta) < 1.0e-8) { dx = c_t * arc; dy = s_t * arc; }
     else {
-      const double rad = walk_speed / turn_rate, off = 2.0 * s_dt * rad;
+      const double off = 2.0 * s_dt * rad;
       const double c_n = c_t * c_dt - s_t * s_dt, s_n = c_t * s_dt + s_t * c_dt;
       dx = c_n * off; dy = s_n * off;
     }
     ori = n_ori;
     const double e0 = p0 + dx, e1 = p1 + dy;
-    const double c0 = e0 / cell_size, c1 = e1 / cell_size;
+    const double c0 = mz_div(e0, R_cs), c1 = mz_div(e1, R_cs);
     const int b0 = (int)c0, b1 = (int)c1;
     double f0 = 0.0, f1 = 0.0;
     for (int i = -1; i < 2; ++i)
@@ -219,7 +246,7 @@ __global__ __launch_bounds__(256) void maze_step_kernel(MazeArgs P, const void* 
         if (wall) {
           double g0, g1;
           mz_collision_force(c0 - floor(c0) - (double)(float)(i + 0.5), c1 - floor(c1) - (double)(float)(j + 0.5),
-                             cell_size, col_dist, g0, g1);
+                             cell_size, eff_cd, g0, g1);
           f0 += g0; f1 += g1;
         }
       }
@@ -266,26 +293,9 @@ __global__ __launch_bounds__(256) void maze_step_kernel(MazeArgs P, const void* 
 // 16 contiguous bytes at [x & 255][(jb - 1) & 255 ...], one global_load_dwordx4 instead of 12 dword loads.  Texel
 // values are the same integers, so every operation below sees the same operands as the float path.
 //
-// The weight 1 - 10*dist/d2 divides by the same d2 for all 16 taps.  hipcc expands an fp64 division into
-// div_scale / rcp / two Newton steps on the reciprocal / q0 = n*y / r = fma(-d,q0,n) / q = fma(r,y,q0) / div_fixup;
-// the scale and fixup steps only act on operands near the ends of the exponent range (d2 is in [1e-8, ~1e3] and
-// n = 10*dist is 0 or in [~1e-40, 1e4] here).  The refined reciprocal y is hoisted out of the tap loop and each
-// tap keeps the last three operations: the same correctly rounded quotient, 3 instructions instead of 14
-// (scripts/devtools/check_div.hip: 0 mismatches against hipcc's division in 1.3e10 quotients over these ranges).
-// The ray-caster's other divisions by per-column / per-task constants use the same helper.
+// The weight 1 - 10*dist/d2 divides by the same d2 for all 16 taps (d2 in [1e-8, ~1e3], 10*dist 0 or in
+// [~1e-40, 1e4]): mz_div, 3 instructions per tap instead of 14.
 // dist >= 0 and d2 > 0 make the reference's upper clamp (wht > 1 -> 1) unreachable; the lower one is a v_max_f64.
-struct MzDivisor { double b, y; };
-__device__ __forceinline__ MzDivisor mz_divisor(double b) {
-  double y = __builtin_amdgcn_rcp(b);
-  y = __builtin_fma(y, __builtin_fma(-b, y, 1.0), y);
-  y = __builtin_fma(y, __builtin_fma(-b, y, 1.0), y);
-  return {b, y};
-}
-__device__ __forceinline__ double mz_div(double a, const MzDivisor& r) {   // == a / r.b (see above)
-  const double q0 = a * r.y;
-  return __builtin_fma(__builtin_fma(-r.b, q0, a), r.y, q0);
-}
-
 template <bool PACKED>
 __device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, double i, double j, double d,
                                                double px, double py, double (&out)[3]) {
@@ -766,7 +776,7 @@ extern "C" int xv_maze_step(xv_maze* h, const void* action, int action_mode, uin
                             int autoreset_mode) {
   XV_CHECK_ARG(h && action && reward && terminated && truncated);
   XV_CHECK_ARG(action_mode >= 0 && action_mode <= 2 && autoreset_mode >= 0 && autoreset_mode <= 2);
-  hipLaunchKernelGGL(maze_step_kernel, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream, h->a, action,
+  hipLaunchKernelGGL(maze_step_kernel, dim3(xv_div_up(h->a.n_env, 64)), dim3(64), 0, h->eng->stream, h->a, action,
                      action_mode, reward, terminated, truncated, autoreset_mode);
   XV_LAUNCH_CHECK();
   if (final_frames && autoreset_mode == XV_AUTORESET_SAME_STEP) {
