@@ -124,13 +124,20 @@ def bench_maze(args, res):
     us_full = timed(full, steps, 2)
     env.close()
     algo = (3 * res * res + 64) * n
+    # the ray-caster is bound by fp64 VALU issue, not HBM: a painted pixel needs >= 16 taps x (8 weight + 3 x 5 colour)
+    # = 368 fp64-pipe instructions + ~40 of geometry; peak = 1024 SIMDs x 64 lanes x 2.4 GHz / 4 cycles per wave-instr
+    valu_ops = 408.0 * res * res * n
+    valu_peak = 1024 * 64 * 2.4e9 / 4
     return {"family": "mazeworld", "workload": "15x15 mazes, 16,384 envs = 256 tasks x 64, %dx%d frames" % (res, res),
             "dtype": "f64 pose, f32/f64 ray-caster, u8 frames", "env_steps_per_s": n / (us_full * 1e-6),
             "us_per_step": {"move+rules": us_move, "raycast": us_render, "step (both)": us_full},
             "roofline": {"bound": "hbm", "achieved": algo / (us_full * 1e-6) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
                          "frac": algo / (us_full * 1e-6) / 1e9 / HBM_PEAK,
                          "algorithmic_bytes_per_env_step": 3 * res * res + 64,
-                         "note": "the 16-tap fp64 texture filter (ALU), not HBM, bounds the ray-caster"}}
+                         "note": "the 16-tap fp64 texture filter (VALU issue), not HBM, bounds the ray-caster"},
+            "valu_f64": {"achieved": valu_ops / (us_render * 1e-6) / 1e12, "peak": valu_peak / 1e12,
+                         "unit": "T lane-instr/s", "frac": valu_ops / (us_render * 1e-6) / valu_peak,
+                         "model": "408 fp64-pipe instructions per pixel (all pixels counted as painted)"}}
 
 
 if __name__ == "__main__":
