@@ -5,7 +5,7 @@
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Workload = BASELINE.json configs[1]: anymdp |S|=64, |A|=8, 65,536 envs per GPU, synthetic tasks generated on
-the device.  Default task sharing is "distinct" (2a: one task per env, 32 GiB of
+the device.  Default task sharing is "distinct" (2a: one task per env, 44 GiB of
 tables per GPU, every table read misses every cache); --tasks 1024 gives "shared" (2b).
 A "step" is one vector step of all envs of a rank = one launch of the step kernel; K steps are K back-to-back
 launches (xv_anymdp_step_many), auto-reset SAME_STEP, actions pre-generated on the device.
@@ -48,9 +48,9 @@ def parse():
 def make_tables(eng, torch, _lib, n_task, task_base, seed, S=64, A=8, s0_max=4):
     d = eng.device
     words = (S + 63) // 64
-    NB = (S + 15) // 16
+    from xenoverse_amd.anymdp import row_lines
     t = dict(S=S, A=A, s0_max=s0_max,
-             rows=torch.empty((n_task, S, A, NB, 32), dtype=torch.float64, device=d),
+             rows=torch.empty((n_task, S, A, row_lines(S), 16), dtype=torch.float64, device=d),
              state_map=torch.empty((n_task, S), dtype=torch.int32, device=d),
              term_mask=torch.empty((n_task, words), dtype=torch.int64, device=d),
              s0_cdf=torch.empty((n_task, s0_max), dtype=torch.float64, device=d),
@@ -103,7 +103,7 @@ def pmc_traffic(n_env, n_task, search):
             d = json.load(open(f))
             k = d.get("bench_key", {})
             want = "2a" if n_task == n_env else "2b"
-            if k.get("workload") == want and k.get("search") == search and k.get("envs_per_gpu") == n_env:
+            if k.get("workload") == want and k.get("search") in (search, "auto") and k.get("envs_per_gpu") == n_env:
                 for name, v in d["kernels"].items():
                     if "step_kernel" in name:
                         return v["traffic_bytes_per_launch_corrected"], os.path.basename(f)
@@ -249,7 +249,7 @@ def main():
                                    % (n_env, n_task, "2a distinct: one task per env" if n_task == n_env
                                       else "2b shared"),
                        "envs_per_gpu": n_env, "tasks_per_gpu": n_task, "S": S, "A": A,
-                       "table_gib_per_gpu": round(n_task * S * A * S * 16 / 2**30, 2),
+                       "table_gib_per_gpu": round(n_task * S * A * (1 + (S + 6) // 7) * 128 / 2**30, 2),
                        "launch": "one step kernel per vector step (xv_anymdp_step_many)",
                        "search": search,
                        "exchange": gather_note,

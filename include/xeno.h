@@ -91,15 +91,20 @@ int xv_philox4x32_10(xv_engine* e, const uint32_t* ctr, const uint32_t* key, uin
  *   reset     :81-90   -> xv_anymdp_reset
  *   step      :112-132 -> xv_anymdp_step / _step_injected   (single_step :92-110, get_observation :145-159)
  *
- * Table layout (device memory, borrowed):
- *   rows       [n_task][S][A][NB] blocks of 256 bytes, NB = ceil(S/16).  Block b of row (t,s,a) holds
- *                double cdf[16]   entries 16b..16b+15 of the inclusive CDF of transition[s,a,:], i.e.
- *                                 cumsum(row)/cumsum(row)[-1] computed on the host in fp64 exactly as
- *                                 numpy.random.choice does (entries >= S hold 2.0; rows of terminal
- *                                 states, all-zero in the reference, hold 1.0)
- *                float2 rs[16]    {reward[s,a,s'], reward_noise[s,a,s']} of the same 16 next states
- *              so the one 256-B record that decides s' also carries its reward: no dependent gather.
- *              xenoverse_amd.anymdp.tables.to_blocked builds it from the reference's task arrays.
+ * Table layout (device memory, borrowed for the life of the handle):
+ *   rows       [n_task][S][A] row records of XV_ANYMDP_ROW_LINES(S) = 1 + NB lines of 128 bytes, NB = ceil(S/7).
+ *                line 0      FENCE: double[16]; fence[k] = the CDF entry of the last next-state of block k for
+ *                            k < NB-1, 2.0 beyond.                       -- written by xv_anymdp_create --
+ *                line 1 + k  BLOCK k: 7 entries of 16 bytes {double cdf; float reward; float reward_noise} for next
+ *                            states 7k..7k+6, then 16 bytes {uint16 obs[7]; uint8 term_bits; uint8 0}: observation id
+ *                            and terminal flag of the same next states.  -- metadata written by xv_anymdp_create --
+ *              cdf = entries of the inclusive CDF of transition[s,a,:], i.e. cumsum(row)/cumsum(row)[-1] computed on
+ *              the host in fp64 exactly as numpy.random.choice does (entries >= S hold 2.0 and a zero reward pair;
+ *              rows of terminal states, all-zero in the reference, hold 1.0); reward pair = {reward[s,a,s'],
+ *              reward_noise[s,a,s']}.  The caller fills the ENTRIES (xenoverse_amd.anymdp.tables.to_blocked builds them
+ *              from the reference's task arrays); xv_anymdp_create completes fence and metadata IN PLACE from the
+ *              entries, state_map and term_mask, so the two 128-byte lines that decide s' also carry its reward,
+ *              observation and termination: a step reads two table lines and follows no dependent gather.
  *   state_map  int32  [n_task][S]         inner state -> observation id (task["state_mapping"])
  *   term_mask  uint64 [n_task][(S+63)/64] bit s set <=> s in task["s_e"]
  *   s0_cdf     double [n_task][s0_max]    inclusive CDF of task["s_0_prob"] (padded with 1.0)
@@ -108,8 +113,9 @@ int xv_philox4x32_10(xv_engine* e, const uint32_t* ctr, const uint32_t* key, uin
  *   env_task   int32  [n_env]             env -> task index
  * Supported: 2 <= S <= 256, 2 <= A <= 64, 1 <= s0_max <= 256.
  * ---------------------------------------------------------------------------------------------- */
+#define XV_ANYMDP_ROW_LINES(S) (1 + ((S) + 6) / 7)
 int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int A, int s0_max,
-                     const void* rows, const int32_t* state_map,
+                     void* rows, const int32_t* state_map,
                      const uint64_t* term_mask, const double* s0_cdf, const int32_t* s0_ids,
                      const int32_t* max_steps, const int32_t* env_task, xv_anymdp** out);
 int xv_anymdp_destroy(xv_anymdp* h);
@@ -172,12 +178,12 @@ int xv_anymdp_step_tokens_injected(xv_anymdp* h, const int32_t* action, const do
                                    uint8_t* truncated, int32_t* final_obs, int autoreset_mode);
 
 /* How s' = upper_bound(cdf row, u) is evaluated; both modes return the same index (parity-tested).
- *   AUTO    FENCE when available (S <= 64, s0_max <= 4, observation ids < 256), else BINARY
- *   BINARY  per-lane binary search over the row's CDF entries in global memory (any S), then a
- *           dependent read of the reward pair
- *   FENCE   a 32-B fence record per row (the last CDF entry of blocks 0..2; table built at create time)
- *           selects the ONE 256-B block that is read — by 16 lanes, coalesced — and counted with a
- *           compare + ballot + popcount; the reward pair comes out of the same block */
+ *   AUTO    FENCE when available (S <= 112, s0_max <= 4, observation ids < 65536), else BINARY
+ *   BINARY  per-lane binary search over the row's CDF entries in global memory (any S), then dependent reads of
+ *           the reward pair, observation id and terminal flag
+ *   FENCE   the row's fence line selects the ONE 128-byte block that is read; both lines are read by 8 lanes,
+ *           coalesced, and counted with a compare + ballot + popcount; reward pair, observation id and terminal
+ *           flag come out of the same block; per-env reset records replace the per-task s_0 tables */
 #define XV_ANYMDP_SEARCH_AUTO 0
 #define XV_ANYMDP_SEARCH_BINARY 1
 #define XV_ANYMDP_SEARCH_FENCE 3
@@ -200,7 +206,7 @@ int xv_anymdp_set_state(xv_anymdp* h, const int32_t* inner_state, const int32_t*
 int xv_anymdp_transition_gt(xv_anymdp* h, const int32_t* action, double* out);
 
 /* Synthetic task tables written directly in device memory (bench / stress configs whose tables exceed
- * host memory: 65,536 distinct tasks of S=64, A=8 are 32 GiB).  Deterministic in (seed, task index);
+ * host memory: 65,536 distinct tasks of S=64, A=8 are 44 GiB).  Writes the row ENTRIES (see "rows").  Deterministic in (seed, task index);
  * restated bit-for-bit by oracle/xeno_oracle.c: xo_anymdp_synth.  Band-limited rows as produced by the
  * reference sampler's sample_transition (task_sampler_utils.py:65-175), uniform weights. */
 int xv_anymdp_synth_tasks(xv_engine* e, uint64_t seed, int64_t task_index_base, int n_task, int S, int A,

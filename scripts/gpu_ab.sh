@@ -1,9 +1,8 @@
 #!/bin/bash
-# A/B of the AnyMDP search modes on one box (same device, back to back).
+# AnyMDP headline: search modes x task sharing on one box (same device, back to back).
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/pytest_gpu.log
 for mode in fence binary; do
   for tasks in 0 1024; do
     echo "== search=$mode tasks=$tasks"

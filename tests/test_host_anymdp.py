@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from xenoverse_amd.anymdp.tables import build_tables, from_blocked, row_cdf, to_blocked, validate_task
+from xenoverse_amd.anymdp.tables import build_tables, from_blocked, row_cdf, row_lines, to_blocked, validate_task
 from util import golden_files, load_anymdp_golden
 
 
@@ -63,19 +63,22 @@ def test_mixed_action_spaces_rejected():
 
 @pytest.mark.parametrize("S", [8, 16, 20, 64, 100, 256])
 def test_blocked_row_layout(S):
-    """include/xeno.h "rows": block b = 16 fp64 CDF entries then 16 {reward, noise} float pairs"""
+    """include/xeno.h "rows": fence line + blocks of 7 entries {cdf, reward, noise} + 16 bytes of metadata"""
     rng = np.random.RandomState(S)
     cdf = np.sort(rng.random_sample((2, 3, S)), axis=-1)
     rs = rng.standard_normal((2, 3, S, 2)).astype(np.float32)
     rows = to_blocked(cdf, rs)
-    NB = (S + 15) // 16
-    assert rows.shape == (2, 3, NB, 32) and rows.dtype == np.float64
-    raw = rows.reshape(2, 3, NB * 256 // 8).view(np.uint8).reshape(2, 3, NB, 256)
-    for j in sorted({0, 1, min(15, S - 1), S // 2, S - 1}):
-        b, q = divmod(j, 16)
-        assert np.array_equal(raw[..., b, 8 * q:8 * q + 8].copy().view(np.float64)[..., 0], cdf[..., j])
-        assert np.array_equal(raw[..., b, 128 + 8 * q:128 + 8 * q + 8].copy().view(np.float32), rs[..., j, :])
-    if S % 16:
-        assert np.all(rows[..., NB - 1, S % 16:16] == 2.0)      # padding never compares <= u
+    NB = (S + 6) // 7
+    assert row_lines(S) == 1 + NB
+    assert rows.shape == (2, 3, 1 + NB, 16) and rows.dtype == np.float64
+    raw = rows.view(np.uint8).reshape(2, 3, 1 + NB, 128)
+    for j in sorted({0, 1, min(6, S - 1), S // 2, S - 1}):   # entry j: block j // 7, slot j % 7, 16 bytes
+        ent = raw[:, :, 1 + j // 7, 16 * (j % 7):16 * (j % 7) + 16]
+        assert np.array_equal(np.ascontiguousarray(ent[..., :8]).view(np.float64)[..., 0], cdf[..., j])
+        assert np.array_equal(np.ascontiguousarray(ent[..., 8:]).view(np.float32), rs[..., j, :])
+    assert np.all(raw[:, :, 0, :] == 0) and np.all(raw[:, :, 1:, 112:] == 0)   # fence / metadata: the engine's
+    if S % 7:
+        pad = np.ascontiguousarray(raw[:, :, NB, 16 * (S % 7):112]).view(np.float64).reshape(2, 3, -1, 2)
+        assert np.all(pad[..., 0] == 2.0) and np.all(pad[..., 1] == 0.0)      # padding never compares <= u
     c2, r2 = from_blocked(rows, S)
     assert np.array_equal(c2, cdf) and np.array_equal(r2, rs)

@@ -18,7 +18,7 @@ def test_npz_batches_roundtrip(tmp_path):
     _, a = load_anymdp_golden(golden_files("anymdp_16x4")[0])
     tasks_io.save_task_batch(tmp_path / "a.npz", "anymdp", [a, a])
     fam, tab = tasks_io.load_task_batch(tmp_path / "a.npz")
-    assert fam == "anymdp" and tab["rows"].shape == (2, 16, 4, 1, 32) and tab["S"] == 16 and tab["A"] == 4
+    assert fam == "anymdp" and tab["rows"].shape == (2, 16, 4, 4, 16) and tab["S"] == 16 and tab["A"] == 4
     tasks_io.save_task_batch(tmp_path / "l.npz", "linds", [LinearDSSampler(16, 8, 8, seed=k) for k in range(3)])
     fam, tab = tasks_io.load_task_batch(tmp_path / "l.npz")
     assert fam == "linds" and tab["phiT"].shape == (3, 16, 16) and tab["NS"] == 16

@@ -4,8 +4,9 @@ Reference: `AnyMDPEnv.set_task` (xenoverse/anymdp/anymdp_env.py:32-79) copies ev
 onto the env object and validates it; `single_step` (:99-100) then calls `numpy.random.choice(n, p=row)`
 each step, which internally forms `cdf = cumsum(row); cdf /= cdf[-1]` and searches it.  Here that CDF is
 formed ONCE per task, on the host, in fp64 with numpy's own cumsum/divide so that every bit equals what
-`choice` would compute, and laid out for the device (layout: include/xeno.h, "AnyMDP": rows blocked by 16
-next states, each 256-byte block carrying its CDF entries and its {reward, noise} pairs).
+`choice` would compute, and laid out for the device (layout: include/xeno.h, "AnyMDP": row records of 128-byte
+lines — a fence line and blocks of 7 next states carrying CDF entry, {reward, noise} pair, observation id and
+terminal flag).
 
 Task dict schema: ns, na, max_steps (float), state_mapping int[n], task_type,
 s_0 int[k], s_0_prob f64[k], s_e int[m], transition/reward/reward_noise f64[n,na,n].
@@ -53,35 +54,46 @@ def row_cdf(T):
     return c
 
 
-def to_blocked(cdf, rs):
-    """Flat per-row arrays -> the device's blocked row layout (include/xeno.h, "rows").
+BLK = 7          # next states per 128-byte block (include/xeno.h, "rows")
 
-    cdf float64[..., S], rs float32[..., S, 2]  ->  float64[..., NB, 32] with NB = ceil(S/16): block b holds
-    the 16 CDF entries 16b..16b+15 (8-byte words 0..15; entries >= S are 2.0, never <= u) followed by the 16
-    {reward, noise} float pairs of the same next states (words 16..31, two floats per word)."""
+
+def row_lines(S):
+    """Lines of 128 bytes per row record: the fence line + ceil(S/7) blocks (XV_ANYMDP_ROW_LINES)."""
+    return 1 + (S + BLK - 1) // BLK
+
+
+def to_blocked(cdf, rs):
+    """Flat per-row arrays -> the device's row records (include/xeno.h, "rows").
+
+    cdf float64[..., S], rs float32[..., S, 2]  ->  float64[..., 1 + NB, 16] with NB = ceil(S/7): line 1+b holds
+    7 entries of {cdf (8 B), reward, noise (4 B each)} for next states 7b..7b+6; entries past S hold cdf 2.0
+    (never <= u) and a zero pair.  Line 0 (fence) and the last 16 bytes of every block (observation ids and
+    terminal flags) are left zero: xv_anymdp_create completes them on the device."""
     cdf = np.asarray(cdf, np.float64)
     rs = np.asarray(rs, np.float32)
     S = cdf.shape[-1]
-    NB = (S + 15) // 16
+    NB = (S + BLK - 1) // BLK
     lead = cdf.shape[:-1]
-    c = np.full(lead + (NB * 16,), 2.0, np.float64)
+    c = np.full(lead + (NB * BLK,), 2.0, np.float64)
     c[..., :S] = cdf
-    r = np.zeros(lead + (NB * 16, 2), np.float32)
+    r = np.zeros(lead + (NB * BLK, 2), np.float32)
     r[..., :S, :] = rs
-    out = np.empty(lead + (NB, 32), np.float64)
-    out[..., :16] = c.reshape(lead + (NB, 16))
-    out[..., 16:] = np.ascontiguousarray(r.reshape(lead + (NB, 16, 2))).view(np.float64).reshape(lead + (NB, 16))
+    out = np.zeros(lead + (1 + NB, 16), np.float64)
+    ent = out[..., 1:, :14].reshape(lead + (NB, BLK, 2))     # a view: 7 entries x {cdf, pair}
+    ent[..., 0] = c.reshape(lead + (NB, BLK))
+    ent[..., 1] = np.ascontiguousarray(r.reshape(lead + (NB, BLK, 2))).view(np.float64).reshape(lead + (NB, BLK))
     return out
 
 
 def from_blocked(rows, S):
-    """Inverse of to_blocked: -> (cdf float64[..., S], rs float32[..., S, 2])."""
+    """Inverse of to_blocked: -> (cdf float64[..., S], rs float32[..., S, 2]); fence and metadata are ignored."""
     rows = np.ascontiguousarray(rows, np.float64)
     lead = rows.shape[:-2]
-    NB = rows.shape[-2]
-    cdf = np.ascontiguousarray(rows[..., :16]).reshape(lead + (NB * 16,))[..., :S]
-    rs = np.ascontiguousarray(rows[..., 16:]).view(np.float32).reshape(lead + (NB * 16, 2))[..., :S, :]
-    return cdf, rs
+    NB = rows.shape[-2] - 1
+    ent = rows[..., 1:, :14].reshape(lead + (NB, BLK, 2))
+    cdf = np.ascontiguousarray(ent[..., 0]).reshape(lead + (NB * BLK,))[..., :S]
+    rs = np.ascontiguousarray(ent[..., 1]).view(np.float32).reshape(lead + (NB * BLK, 2))[..., :S, :]
+    return np.ascontiguousarray(cdf), np.ascontiguousarray(rs)
 
 
 def build_tables(tasks, s0_max=None, validate=True):

@@ -3,59 +3,55 @@
 // Reproduces xenoverse/anymdp/anymdp_env.py: reset :81-90, single_step :92-110, step :112-132,
 // get_observation :145-159 (MDP branch), per env, for N envs per launch.  One wavefront lane owns one env.
 //
-// A step is a chain of DEPENDENT memory round trips (state -> which row -> which next state -> its reward
-// and observation); at 65,536 envs per launch the kernel lives or dies by the length of that chain and by
-// the bytes each link moves.  Layout and kernel are built to make it three links:
+// A step is a chain of DEPENDENT memory accesses (state -> which row -> which next state -> its reward and
+// observation).  With one task per env every table access is a random 128-byte HBM line (measured,
+// scripts/devtools/gather_granularity.hip: the fetch granule is 128 B, ~5e10 random lines/s, and a lane-divergent
+// load instruction costs the texture-addresser once per distinct line), so the kernel is priced in LINES and in
+// dependent LEVELS.  Layout and kernel make a step two lines in two levels:
 //
-//   1. per-env words (state, steps, action, task id): struct-of-arrays, coalesced dword streams.
-//   2. per row (t,s,a) a 32-B FENCE record = the last CDF entry of blocks 0..2 of the row, and per task a
-//      128-B HEADER (terminal mask, max_steps, the s_0 distribution with its observation ids, and the 64
-//      observation ids as bytes).  k = #{fences <= u} names the one 16-entry block that contains s'
-//      (the CDF is non-decreasing, so blocks < k are entirely <= u and blocks > k entirely > u).
-//   3. that ONE 256-B block: 16 fp64 CDF entries + the 16 {reward, noise} pairs of the same next states
-//      (include/xeno.h, "rows").  It is read by 16 lanes, coalesced — a wave fetches the blocks of 4 envs per
-//      load instruction and keeps 16 such loads in flight — and searched with one v_cmp_le_f64 against the
-//      env's uniform, a 64-bit ballot and a 16-bit popcount:  s' = 16k + popcount(cdf[j] <= u), which is
-//      numpy.searchsorted(cdf, u, 'right').  The reward pair is taken from the same registers with a
-//      ds_bpermute; the observation id is a byte of the header.  No dependent gather follows.
+//   1. per-env words — state, steps, action, task id and a 36-byte reset record (s_0 CDF, ids, observation ids,
+//      max_steps; built per env at create time) — struct-of-arrays, coalesced streams, no dependency.
+//   2. the FENCE line of row (t,s,a): 16 doubles, fence[k] = the CDF entry of the last next-state of block k.
+//      k = #{fence <= u} names the one block that contains s' (the CDF is non-decreasing).
+//   3. that ONE 128-byte BLOCK: 7 entries {fp64 cdf, reward, noise} and 16 bytes holding the observation id and
+//      terminal flag of the same 7 next states.  s' = 7k + #{cdf <= u} is numpy.searchsorted(cdf, u, 'right');
+//      reward, observation and termination come out of the same line.  No dependent gather follows.
 //
-// Per env-step that is 32 + 256 + 128 B of table reads instead of the 512-B row + 4 gathers of a flat layout.
+// Both lines are read cooperatively: 8 lanes x 16 B per env, 8 envs per load instruction, 8 instructions per
+// level kept in flight together; the search is v_cmp_le_f64 + 64-bit ballot + 8-bit popcount, and results
+// return to the owning lane by ds_bpermute.  Per env-step: 2 x 128 B of table lines + ~90 B of streams
+// (the first layout read a 32-B fence record, a 256-B block and a 128-B task header: 4 lines).
 // BINARY mode (any S <= 256, any s0 table) is the general per-lane fallback.
 #include "philox.h"
 #include "xv_common.h"
 
 #include <cstddef>
+#include <cstring>
 
-// One 128-byte line per task (fast path: S <= 64, s0_max <= 4, observation ids < 256); built at create time.
-struct __attribute__((aligned(128))) AnyMDPHdr {
-  uint64_t term_mask;    // bit s set <=> s terminal
-  int32_t max_steps;
-  uint32_t s0_ids;       // 4 x u8 inner-state ids of s_0 (padded with the last)
-  uint32_t s0_obs;       // 4 x u8 observation ids of those states
-  uint32_t pad0[3];
-  double s0_cdf[4];      // bytes 32..63: inclusive CDF of s_0_prob padded with 1.0
-  uint32_t obs[16];      // 64 x u8: observation id of inner state s (state_mapping)
-};
-static_assert(sizeof(AnyMDPHdr) == 128, "header must be one 128-byte line");
-static_assert(offsetof(AnyMDPHdr, s0_cdf) == 32 && offsetof(AnyMDPHdr, obs) == 64, "register view below");
+#define XV_ANYMDP_BLK 7   // next states per block
 
 struct AnyMDPArgs {
-  const AnyMDPHdr* hdr;  // engine-owned, nullptr when the fast path does not apply
-  const double* fence;   // engine-owned [n_rows][4] (S <= 64), nullptr otherwise
   // borrowed task tables
-  const double* rows;    // blocked rows, addressed in 8-byte units: block = 32 units
+  const uint4* lines;    // rows in 16-byte units; a line = 8 units; row r starts at line r * RL
   const int32_t* state_map;
   const uint64_t* term_mask;
   const double* s0_cdf;
   const int32_t* s0_ids;
   const int32_t* max_steps;
   const int32_t* env_task;
+  // engine-owned per-env reset record (fast path), struct-of-arrays
+  const double2* rs_c01;     // s0_cdf[0], s0_cdf[1]   (padded with 1.0)
+  const double* rs_c2;       // s0_cdf[2]
+  const uint32_t* rs_ids;    // 4 x u8: inner state id (7 bits) | terminal flag << 7, padded with the last
+  const uint2* rs_obs;       // 4 x u16 observation ids of those states
+  const int32_t* rs_max_steps;
   // engine-owned env state
   int32_t* state;
   int32_t* steps;
   uint8_t* need_reset;
+  uint8_t* cur_term;         // current inner state is terminal (the reference raises when stepping from it, :95-96)
   uint32_t* err;
-  int n_env, n_task, S, A, s0_max, words, NB;
+  int n_env, n_task, S, A, s0_max, words, NB, RL;   // RL = 1 + NB lines per row
   uint64_t seed, gid_base, tick;
 };
 
@@ -80,6 +76,7 @@ struct xv_anymdp {
   xv_engine* eng;
   AnyMDPArgs a;
   int search;  // XV_ANYMDP_SEARCH_*
+  bool fast;   // fence lines, block metadata and reset records are built
   const double* obs_cdf;   // observation model (POMDP / MTPOMDP), nullptr for MDP
   int n_obs, d_obs, d_act;
 };
@@ -97,64 +94,33 @@ __device__ __forceinline__ int anymdp_draw_s0(const AnyMDPArgs& P, int t, double
   return P.s0_ids[(size_t)t * P.s0_max + k];
 }
 
-// blocked-row accessors: CDF entry j / reward pair j of row r
-__device__ __forceinline__ const double* anymdp_cdf_ptr(const AnyMDPArgs& P, uint32_t r, int j) {
-  return P.rows + ((size_t)r * P.NB + (j >> 4)) * 32 + (j & 15);
+// row accessors: the 16-byte entry of next state j of row r = {double cdf; float reward; float noise}
+__device__ __forceinline__ const uint4* anymdp_entry_ptr(const AnyMDPArgs& P, uint32_t r, int j) {
+  const int b = j / XV_ANYMDP_BLK;
+  return P.lines + ((size_t)r * P.RL + 1 + b) * 8 + (j - b * XV_ANYMDP_BLK);
+}
+__device__ __forceinline__ double anymdp_cdf(const AnyMDPArgs& P, uint32_t r, int j) {
+  return *reinterpret_cast<const double*>(anymdp_entry_ptr(P, r, j));
 }
 __device__ __forceinline__ float2 anymdp_rs(const AnyMDPArgs& P, uint32_t r, int j) {
-  return reinterpret_cast<const float2*>(P.rows + ((size_t)r * P.NB + (j >> 4)) * 32 + 16)[j & 15];
+  return reinterpret_cast<const float2*>(anymdp_entry_ptr(P, r, j))[1];
 }
 
 __device__ __forceinline__ double xv_shfl_f64(double v, int src) {
   return __hiloint2double(__shfl(__double2hiint(v), src), __shfl(__double2loint(v), src));
 }
-
-// The header is held in named registers, never as an indexable aggregate: hipcc folds a select chain over
-// loaded values back into ONE load at a selected address (a dynamically indexed stack array in scratch, or a
-// dependent global load) — exactly the round trip this header exists to remove.  The empty asm statements
-// make each observation word an opaque register value, which keeps the 15-select tree in VALU.
-struct AnyMDPHdrRegs {
-  uint4 q0, q1, q2, q3;   // term_mask | max_steps, s0_ids, s0_obs, pad | s0_cdf[0..3]
-  uint32_t w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15;   // 64 obs ids, 1 byte each
-};
-#define XV_OPAQUE(x) asm volatile("" : "+v"(x))
-__device__ __forceinline__ AnyMDPHdrRegs anymdp_load_hdr(const AnyMDPHdr* hdr, int t) {
-  const uint4* p = reinterpret_cast<const uint4*>(hdr + t);
-  AnyMDPHdrRegs r;
-  r.q0 = p[0]; r.q1 = p[1]; r.q2 = p[2]; r.q3 = p[3];
-  const uint4 a = p[4], b = p[5], c = p[6], d = p[7];
-  r.w0 = a.x; r.w1 = a.y; r.w2 = a.z; r.w3 = a.w; r.w4 = b.x; r.w5 = b.y; r.w6 = b.z; r.w7 = b.w;
-  r.w8 = c.x; r.w9 = c.y; r.w10 = c.z; r.w11 = c.w; r.w12 = d.x; r.w13 = d.y; r.w14 = d.z; r.w15 = d.w;
-  XV_OPAQUE(r.w0); XV_OPAQUE(r.w1); XV_OPAQUE(r.w2); XV_OPAQUE(r.w3);
-  XV_OPAQUE(r.w4); XV_OPAQUE(r.w5); XV_OPAQUE(r.w6); XV_OPAQUE(r.w7);
-  XV_OPAQUE(r.w8); XV_OPAQUE(r.w9); XV_OPAQUE(r.w10); XV_OPAQUE(r.w11);
-  XV_OPAQUE(r.w12); XV_OPAQUE(r.w13); XV_OPAQUE(r.w14); XV_OPAQUE(r.w15);
-  return r;
-}
-// observation id of inner state idx (0..63): byte idx of w0..w15, by selects only
-__device__ __forceinline__ uint32_t anymdp_hdr_obs(const AnyMDPHdrRegs& H, int idx) {
-  const bool b0 = idx & 4, b1 = idx & 8, b2 = idx & 16, b3 = idx & 32;   // bits of the word index idx>>2
-  const uint32_t a0 = b0 ? H.w1 : H.w0, a1 = b0 ? H.w3 : H.w2, a2 = b0 ? H.w5 : H.w4, a3 = b0 ? H.w7 : H.w6;
-  const uint32_t a4 = b0 ? H.w9 : H.w8, a5 = b0 ? H.w11 : H.w10, a6 = b0 ? H.w13 : H.w12, a7 = b0 ? H.w15 : H.w14;
-  const uint32_t c0 = b1 ? a1 : a0, c1 = b1 ? a3 : a2, c2 = b1 ? a5 : a4, c3 = b1 ? a7 : a6;
-  const uint32_t d0 = b2 ? c1 : c0, d1 = b2 ? c3 : c2;
-  const uint32_t v = b3 ? d1 : d0;
-  return (v >> (8 * (idx & 3))) & 0xFFu;
-}
 __device__ __forceinline__ double xv_u2d(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 
-enum { SEARCH_BINARY = 0, SEARCH_FENCE = 1 };
-
 // T_steps == 1: one vector step.  T_steps > 1: fused rollout, io arrays are [T][n_env], mode SAME_STEP.
-// HDR: per-task scalars and observation ids come from the packed 128-B header.
-template <bool INJECT, int SEARCH, bool HDR, bool ROLLOUT>
+// FAST: fence line + block line, per-env reset record; otherwise per-lane binary search and per-task tables.
+template <bool INJECT, bool FAST, bool ROLLOUT>
 __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPStepIO io, int T_steps,
                                                           int mode) {
-  static_assert(SEARCH != SEARCH_FENCE || HDR, "the fence path needs the header");
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < P.n_env;
   const int ic = valid ? i : P.n_env - 1;
   const int lane = threadIdx.x & 63;
+  const int g = lane >> 3, j = lane & 7;   // FAST: lanes 8g..8g+7 read unit j of a line together
   const int S = P.S, A = P.A;
 
   // ---- link 1: per-env words (coalesced) ----
@@ -162,14 +128,24 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
   int s = P.state[ic];
   int steps = P.steps[ic];
   int nr = P.need_reset[ic];
+  int cterm = P.cur_term[ic];
   int a_next = io.action ? io.action[ic] : 0;
   const uint64_t gid = P.gid_base + (uint64_t)ic;
   uint32_t err = 0;
 
-  AnyMDPHdrRegs H;
-  int max_steps = 0;
+  double2 rc01 = make_double2(1.0, 1.0);
+  double rc2 = 1.0;
+  uint32_t rids = 0;
+  uint2 robs = make_uint2(0u, 0u);
+  int max_steps;
   uint64_t tm0 = 0;
-  bool hdr_loaded = false;
+  if (FAST) {
+    rc01 = P.rs_c01[ic]; rc2 = P.rs_c2[ic]; rids = P.rs_ids[ic]; robs = P.rs_obs[ic];
+    max_steps = P.rs_max_steps[ic];
+  } else {
+    max_steps = P.max_steps[t];
+    tm0 = P.term_mask[(size_t)t * P.words];
+  }
 
   const int T = ROLLOUT ? T_steps : 1;   // single step: straight-line code, counted vmcnt waits
   for (int ts = 0; ts < T; ++ts) {
@@ -205,78 +181,76 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
     }
     const uint32_t rowidx = ((uint32_t)t * S + s) * A + a;
 
-    // ---- link 2: fence record of the row (+ the task header, once) ----
-    double f0 = 0, f1 = 0, f2 = 0;
-    if (SEARCH == SEARCH_FENCE) {
-      const double* f = P.fence + (size_t)rowidx * 4;
-      f0 = f[0]; f1 = f[1]; f2 = f[2];
-    }
-    if (!hdr_loaded) {
-      if (HDR) {
-        H = anymdp_load_hdr(P.hdr, t);
-        max_steps = (int)H.q0.z;
-        tm0 = (uint64_t)H.q0.x | ((uint64_t)H.q0.y << 32);
-      } else {
-        max_steps = P.max_steps[t];
-        tm0 = P.term_mask[(size_t)t * P.words];
-      }
-      hdr_loaded = true;
-    }
-
-    // ---- link 3: s' = upper_bound(cdf[s,a,:], u)   (:99-100, numpy.random.choice) and its reward pair ----
-    int s2;
+    // ---- s' = upper_bound(cdf[s,a,:], u)   (:99-100, numpy.random.choice), its reward pair (:103-104),
+    //      observation id (:146-148) and terminal flag (:107-108) ----
+    int s2, obs2;
+    bool term2;
     float2 rsv;
-    if (SEARCH == SEARCH_FENCE) {
-      const int k = (int)(f0 <= u) + (int)(f1 <= u) + (int)(f2 <= u);   // fences of absent blocks hold 2.0
-      const uint32_t bidx = rowidx * (uint32_t)P.NB + (uint32_t)k;
-      const int g = lane >> 4, j = lane & 15;
-      // (a) all block addresses first (16 independent ds_bpermute), then all 32 loads back to back
-      uint32_t bi[16];
+    if (FAST) {
+      const uint32_t fl = rowidx * (uint32_t)P.RL;   // fence line of the row
+      // link 2: fence lines.  Iteration `it` serves envs 8*it .. 8*it+7: lanes 8q..8q+7 read the line of env 8*it+q.
+      uint32_t li[8];
 #pragma unroll
-      for (int it = 0; it < 16; ++it) bi[it] = (uint32_t)__shfl((int)bidx, it * 4 + g);
-      double cv[16];
-      float2 rv[16];
+      for (int it = 0; it < 8; ++it) li[it] = (uint32_t)__shfl((int)fl, it * 8 + g);
+      uint4 fv[8];
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {   // lanes 16g..16g+15 read the block of env 4*it+g
-        const double* blk = P.rows + (size_t)bi[it] * 32;
-        cv[it] = blk[j];
-        rv[it] = reinterpret_cast<const float2*>(blk + 16)[j];
+      for (int it = 0; it < 8; ++it) fv[it] = P.lines[(size_t)li[it] * 8 + j];
+      __builtin_amdgcn_sched_barrier(0);
+      // while the loads fly: each env's uniform goes to the 8 lanes that hold its lines
+      double ue[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) ue[it] = xv_shfl_f64(u, it * 8 + g);
+      __builtin_amdgcn_sched_barrier(0);
+      // k = #{fence <= u}: two compares per lane, two ballots, the owner (lane 8*it+q) counts byte q
+      int k_own = 0;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const unsigned long long m0 = __ballot(xv_u2d(fv[it].x, fv[it].y) <= ue[it]);
+        const unsigned long long m1 = __ballot(xv_u2d(fv[it].z, fv[it].w) <= ue[it]);
+        const int cnt = __popc((unsigned)(m0 >> (8 * j)) & 0xFFu) + __popc((unsigned)(m1 >> (8 * j)) & 0xFFu);
+        if (g == it) k_own = cnt;
       }
+      k_own = k_own < P.NB - 1 ? k_own : P.NB - 1;   // fences of absent blocks hold 2.0: cannot exceed
+      // link 3: the block
+      const uint32_t bl = fl + 1u + (uint32_t)k_own;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) li[it] = (uint32_t)__shfl((int)bl, it * 8 + g);
+      uint4 bv[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) bv[it] = P.lines[(size_t)li[it] * 8 + j];
       if (ROLLOUT && io.action && ts + 1 < T) a_next = io.action[o + P.n_env];   // prefetch behind the blocks
       __builtin_amdgcn_sched_barrier(0);
-      // (b) while the loads fly: broadcast each env's uniform to the 16 lanes that hold its block
-      double ue[16];
-#pragma unroll
-      for (int it = 0; it < 16; ++it) ue[it] = xv_shfl_f64(u, it * 4 + g);
-      __builtin_amdgcn_sched_barrier(0);
-      // (c) compare + ballot + popcount; the owner of group q in iteration `it` is lane 4*it+q
       int cnt_own = 0;
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const unsigned long long m = __ballot(cv[it] <= ue[it]);
-        const int cnt = __popc((unsigned)(m >> (16 * (lane & 3))) & 0xFFFFu);
-        if ((lane >> 2) == it) cnt_own = cnt;
-      }
-      // (d) the reward pair of s' sits in lane 16q + cnt of the same registers: 32 independent bpermutes
-      const int pick = 16 * (lane & 3) + (cnt_own < 15 ? cnt_own : 15);
       float rx = 0.0f, ry = 0.0f;
+      uint32_t meta_own = 0;
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const float px = __shfl(rv[it].x, pick);
-        const float py = __shfl(rv[it].y, pick);
-        if ((lane >> 2) == it) {
-          rx = px;
-          ry = py;
-        }
+      for (int it = 0; it < 8; ++it) {
+        // unit 7 of a block is its metadata, not an entry
+        const unsigned long long m = __ballot(j < 7 && xv_u2d(bv[it].x, bv[it].y) <= ue[it]);
+        // reader side: the count of the env this lane group serves; the metadata lane extracts that entry's
+        // observation id and terminal flag, so the owner needs ONE word from it
+        int cg = __popc((unsigned)(m >> (8 * g)) & 0x7Fu);
+        cg = cg < 6 ? cg : 6;
+        const uint32_t mw = cg < 2 ? bv[it].x : (cg < 4 ? bv[it].y : (cg < 6 ? bv[it].z : bv[it].w));
+        const uint32_t packed = ((mw >> (16 * (cg & 1))) & 0xFFFFu) | (((bv[it].w >> (16 + cg)) & 1u) << 16);
+        // owner side: lane 8*it+q owns the env whose line sits in lanes 8q..8q+7
+        int co = __popc((unsigned)(m >> (8 * j)) & 0x7Fu);
+        const int cc = co < 6 ? co : 6;
+        const float px = __shfl(__uint_as_float(bv[it].z), 8 * j + cc);
+        const float py = __shfl(__uint_as_float(bv[it].w), 8 * j + cc);
+        const uint32_t pm = (uint32_t)__shfl((int)packed, 8 * j + 7);
+        if (g == it) { cnt_own = co; rx = px; ry = py; meta_own = pm; }
       }
-      s2 = 16 * k + cnt_own;
+      s2 = XV_ANYMDP_BLK * k_own + cnt_own;
       s2 = s2 < S - 1 ? s2 : S - 1;
       rsv = make_float2(rx, ry);
+      obs2 = (int)(meta_own & 0xFFFFu);
+      term2 = (meta_own >> 16) & 1u;
     } else {
       int lo = 0, n = S;
       while (n > 0) {
         const int half = n >> 1;
-        if (*anymdp_cdf_ptr(P, rowidx, lo + half) <= u) {
+        if (anymdp_cdf(P, rowidx, lo + half) <= u) {
           lo += half + 1;
           n -= half + 1;
         } else {
@@ -285,10 +259,10 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       }
       s2 = lo < S - 1 ? lo : S - 1;
       if (ROLLOUT && io.action && ts + 1 < T) a_next = io.action[o + P.n_env];
-      rsv = anymdp_rs(P, rowidx, s2);                              // :103-104
+      rsv = anymdp_rs(P, rowidx, s2);
+      obs2 = P.state_map[(size_t)t * S + s2];
+      term2 = anymdp_is_term(P, t, tm0, s2);
     }
-    const int obs2 = HDR ? (int)anymdp_hdr_obs(H, s2) : P.state_map[(size_t)t * S + s2];   // :146-148
-    const bool term2 = anymdp_is_term(P, t, tm0, s2);              // :107-108
 
     int o_obs, o_fobs = -1;
     float o_r, o_rgt;
@@ -298,10 +272,10 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       // the call after a done ignores the action and returns the reset observation
       do_reset = true;
       o_r = 0.0f; o_rgt = 0.0f; o_term = false; o_trunc = false; o_obs = 0;
-    } else if (mode == XV_AUTORESET_DISABLED && anymdp_is_term(P, t, tm0, s)) {
+    } else if (mode == XV_AUTORESET_DISABLED && cterm) {
       // reference raises "given an terminated state" (:95-96): env untouched, error bit set
       err |= XV_DEVERR_STEP_TERMINAL;
-      o_obs = HDR ? (int)anymdp_hdr_obs(H, s) : P.state_map[(size_t)t * S + s];
+      o_obs = P.state_map[(size_t)t * S + s];
       o_r = 0.0f; o_rgt = 0.0f; o_term = true; o_trunc = steps >= max_steps;
     } else {
       steps += 1;                                              // :113
@@ -310,6 +284,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       o_r = fmaf(rsv.y, z, rsv.x);                             // :105 normal(mu, sigma) = mu + sigma*z
       o_term = term2;
       s = s2;
+      cterm = term2 ? 1 : 0;
       o_obs = obs2;
       if (o_term || o_trunc) {
         if (mode == XV_AUTORESET_SAME_STEP) {
@@ -321,14 +296,16 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       }
     }
     if (do_reset) {                                            // reset(): :85-90
-      if (HDR) {
-        // upper_bound over the 4 padded CDF entries; ids and obs ids come packed in the header
-        const int k0 = (int)(xv_u2d(H.q2.x, H.q2.y) <= u_reset) + (int)(xv_u2d(H.q2.z, H.q2.w) <= u_reset) +
-                       (int)(xv_u2d(H.q3.x, H.q3.y) <= u_reset);
-        s = (int)((H.q0.w >> (8 * k0)) & 0xFFu);
-        o_obs = (int)((H.q1.x >> (8 * k0)) & 0xFFu);
+      if (FAST) {
+        // upper_bound over the 4 padded CDF entries; ids, terminal flags and observation ids come packed
+        const int k0 = (int)(rc01.x <= u_reset) + (int)(rc01.y <= u_reset) + (int)(rc2 <= u_reset);
+        const uint32_t idb = (rids >> (8 * k0)) & 0xFFu;
+        s = (int)(idb & 0x7Fu);
+        cterm = (int)(idb >> 7);
+        o_obs = (int)(((k0 < 2 ? robs.x : robs.y) >> (16 * (k0 & 1))) & 0xFFFFu);
       } else {
         s = anymdp_draw_s0(P, t, u_reset);
+        cterm = anymdp_is_term(P, t, tm0, s) ? 1 : 0;
         o_obs = P.state_map[(size_t)t * S + s];
       }
       steps = 0;
@@ -347,50 +324,73 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
     P.state[i] = s;
     P.steps[i] = steps;
     P.need_reset[i] = (uint8_t)nr;
+    P.cur_term[i] = (uint8_t)cterm;
   }
   if (err) atomicOr(P.err, err);
 }
 
-// fence[r][k] = last CDF entry of block k of row r for k < NB-1, else 2.0 (never <= u)
-__global__ __launch_bounds__(256) void anymdp_build_fence_kernel(const double* rows, double* fence,
-                                                                 size_t n_rows, int NB) {
+// Completes the rows in place (create time): fence line and per-block metadata.  One thread per (row, k < 16).
+//   fence[k] = CDF entry of the last next-state of block k for k < NB-1, else 2.0 (never <= u)
+//   meta of block k = {u16 obs[7]; u8 term_bits; u8 0} of next states 7k..7k+6 (clamped to S-1, as s' is)
+__global__ __launch_bounds__(256) void anymdp_finish_rows_kernel(AnyMDPArgs P, uint4* lines_rw, size_t n_rows) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n_rows * 4) return;
-  const size_t r = idx >> 2;
-  const int k = (int)(idx & 3);
-  fence[idx] = (k < NB - 1) ? rows[(r * NB + k) * 32 + 15] : 2.0;
+  if (idx >= n_rows * 16) return;
+  const size_t r = idx >> 4;
+  const int k = (int)(idx & 15);
+  const int t = (int)(r / ((size_t)P.S * P.A));
+  uint4* row = lines_rw + r * (size_t)P.RL * 8;
+  double f = 2.0;
+  if (k < P.NB - 1) f = reinterpret_cast<const double*>(row + (size_t)(1 + k) * 8 + (XV_ANYMDP_BLK - 1))[0];
+  reinterpret_cast<double*>(row)[k] = f;
+  if (k < P.NB) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    uint32_t tb = 0;
+    for (int e = 0; e < XV_ANYMDP_BLK; ++e) {
+      int sn = XV_ANYMDP_BLK * k + e;
+      sn = sn < P.S - 1 ? sn : P.S - 1;
+      const uint32_t ob = (uint32_t)P.state_map[(size_t)t * P.S + sn] & 0xFFFFu;
+      w[e >> 1] |= ob << (16 * (e & 1));
+      if ((P.term_mask[(size_t)t * P.words + (sn >> 6)] >> (sn & 63)) & 1ull) tb |= 1u << e;
+    }
+    w[3] |= tb << 16;
+    row[(size_t)(1 + k) * 8 + 7] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
 }
 
-// packs the per-task scalars and observation ids into 128-byte headers (once, at create time)
-__global__ __launch_bounds__(256) void anymdp_pack_hdr_kernel(AnyMDPArgs P, AnyMDPHdr* hdr) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= P.n_task) return;
-  AnyMDPHdr h;
-  h.term_mask = P.term_mask[t];
-  h.max_steps = P.max_steps[t];
-  uint32_t ids = 0, obs = 0;
+// per-env reset records (create time): the s_0 distribution of the env's task, ready for coalesced reads
+__global__ __launch_bounds__(256) void anymdp_env_records_kernel(AnyMDPArgs P, double2* c01, double* c2, uint32_t* ids,
+                                                                 uint2* obs, int32_t* max_steps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n_env) return;
+  const int t = P.env_task[i];
+  double c[4];
+  uint32_t idw = 0, ob[4];
   for (int k = 0; k < 4; ++k) {
     const int kk = k < P.s0_max ? k : P.s0_max - 1;
     const int sid = P.s0_ids[(size_t)t * P.s0_max + kk];
-    ids |= (uint32_t)(sid & 0xFF) << (8 * k);
-    obs |= (uint32_t)(P.state_map[(size_t)t * P.S + sid] & 0xFF) << (8 * k);
-    h.s0_cdf[k] = k < P.s0_max ? P.s0_cdf[(size_t)t * P.s0_max + k] : 1.0;
+    const uint32_t tb = (P.term_mask[(size_t)t * P.words + (sid >> 6)] >> (sid & 63)) & 1ull ? 1u : 0u;
+    idw |= (((uint32_t)sid & 0x7Fu) | (tb << 7)) << (8 * k);
+    ob[k] = (uint32_t)P.state_map[(size_t)t * P.S + sid] & 0xFFFFu;
+    c[k] = k < P.s0_max ? P.s0_cdf[(size_t)t * P.s0_max + k] : 1.0;
   }
-  h.s0_ids = ids;
-  h.s0_obs = obs;
-  h.pad0[0] = h.pad0[1] = h.pad0[2] = 0;
-  for (int q = 0; q < 16; ++q) {
-    uint32_t w = 0;
-    for (int b = 0; b < 4; ++b) {
-      const int sidx = 4 * q + b;
-      if (sidx < P.S) w |= (uint32_t)(P.state_map[(size_t)t * P.S + sidx] & 0xFF) << (8 * b);
-    }
-    h.obs[q] = w;
-  }
-  hdr[t] = h;
+  c01[i] = make_double2(c[0], c[1]);
+  c2[i] = c[2];
+  ids[i] = idw;
+  obs[i] = make_uint2(ob[0] | (ob[1] << 16), ob[2] | (ob[3] << 16));
+  max_steps[i] = P.max_steps[t];
 }
 
-// largest observation id (decides whether ids fit the header's bytes)
+// cur_term[i] = (state[i] in s_e), after xv_anymdp_set_state
+__global__ __launch_bounds__(256) void anymdp_fix_term_kernel(AnyMDPArgs P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n_env) return;
+  const int t = P.env_task[i];
+  int s = P.state[i];
+  s = s < 0 ? 0 : (s >= P.S ? P.S - 1 : s);
+  P.cur_term[i] = (uint8_t)((P.term_mask[(size_t)t * P.words + (s >> 6)] >> (s & 63)) & 1ull);
+}
+
+// largest observation id (decides whether ids fit the 16-bit block metadata)
 __global__ __launch_bounds__(256) void anymdp_max_obs_kernel(const int32_t* state_map, size_t n, int* out) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < n) atomicMax(out, state_map[idx]);
@@ -414,6 +414,7 @@ __global__ __launch_bounds__(256) void anymdp_reset_kernel(AnyMDPArgs P, const u
   P.state[i] = s;
   P.steps[i] = 0;
   P.need_reset[i] = 0;
+  P.cur_term[i] = (uint8_t)((P.term_mask[(size_t)t * P.words + (s >> 6)] >> (s & 63)) & 1ull);
   if (obs) obs[i] = P.state_map[(size_t)t * P.S + s];
 }
 
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(256) void anymdp_tgt_kernel(AnyMDPArgs P, const int
   const uint64_t tm0 = P.term_mask[(size_t)t * P.words];
   const uint32_t r = ((uint32_t)t * P.S + s) * P.A + a;
   double v = 0.0;
-  if (!anymdp_is_term(P, t, tm0, s)) v = *anymdp_cdf_ptr(P, r, j) - (j ? *anymdp_cdf_ptr(P, r, j - 1) : 0.0);
+  if (!anymdp_is_term(P, t, tm0, s)) v = anymdp_cdf(P, r, j) - (j ? anymdp_cdf(P, r, j - 1) : 0.0);
   out[(size_t)i * P.S + P.state_map[(size_t)t * P.S + j]] = v;
 }
 
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_kernel(AnyMDPArgs P, AnyM
       int lo = 0, m = S;
       while (m > 0) {
         const int half = m >> 1;
-        if (*anymdp_cdf_ptr(P, rowidx, lo + half) <= u) { lo += half + 1; m -= half + 1; }
+        if (anymdp_cdf(P, rowidx, lo + half) <= u) { lo += half + 1; m -= half + 1; }
         else m = half;
       }
       const int s2 = lo < S - 1 ? lo : S - 1;
@@ -560,6 +561,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_kernel(AnyMDPArgs P, AnyM
     anymdp_tok_observe<INJECT, true>(P, K, io, i, t, s, gid, io.obs);
   }
   P.state[i] = s; P.steps[i] = steps; P.need_reset[i] = (uint8_t)nr;
+  P.cur_term[i] = (uint8_t)(anymdp_is_term(P, t, tm0, s) ? 1 : 0);
   io.reward[i] = rsum; io.reward_gt[i] = rgsum;
   io.terminated[i] = (uint8_t)term; io.truncated[i] = (uint8_t)trunc;
   if (err) atomicOr(P.err, err);
@@ -581,6 +583,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_reset_kernel(AnyMDPArgs P, Any
   }
   const int s = anymdp_draw_s0(P, t, ur);
   P.state[i] = s; P.steps[i] = 0; P.need_reset[i] = 0;
+  P.cur_term[i] = (uint8_t)((P.term_mask[(size_t)t * P.words + (s >> 6)] >> (s & 63)) & 1ull);
   if (io.obs) anymdp_tok_observe<INJECT, true>(P, K, io, i, t, s, gid, io.obs);
 }
 
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_reset_kernel(AnyMDPArgs P, Any
 // C-ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int A, int s0_max,
-                                const void* rows, const int32_t* state_map, const uint64_t* term_mask,
+                                void* rows, const int32_t* state_map, const uint64_t* term_mask,
                                 const double* s0_cdf, const int32_t* s0_ids, const int32_t* max_steps,
                                 const int32_t* env_task, xv_anymdp** out) {
   XV_CHECK_ARG(out != nullptr);
@@ -597,8 +600,8 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
   XV_CHECK_ARG(n_env > 0 && n_task > 0);
   XV_CHECK_ARG(S >= 2 && S <= 256 && A >= 2 && A <= 64 && s0_max >= 1 && s0_max <= 256);
   XV_CHECK_ARG(rows && state_map && term_mask && s0_cdf && s0_ids && max_steps && env_task);
-  const int NB = (S + 15) / 16;
-  XV_CHECK_ARG((uint64_t)n_task * S * A * NB < 0xFFFFFFFFull);  // block index is a 32-bit word on the device
+  const int NB = (S + XV_ANYMDP_BLK - 1) / XV_ANYMDP_BLK, RL = 1 + NB;
+  XV_CHECK_ARG((uint64_t)n_task * S * A * RL < 0xFFFFFFFFull);  // line index is a 32-bit word on the device
   XV_HIP(hipSetDevice(e->device));
   xv_anymdp* h = new (std::nothrow) xv_anymdp();
   if (!h) {
@@ -607,18 +610,19 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
   }
   h->eng = e;
   h->search = XV_ANYMDP_SEARCH_AUTO;
+  h->fast = false;
   h->obs_cdf = nullptr; h->n_obs = 0; h->d_obs = 0; h->d_act = 0;
   AnyMDPArgs& a = h->a;
-  a.rows = (const double*)rows; a.state_map = state_map; a.term_mask = term_mask;
+  memset(&a, 0, sizeof(a));
+  a.lines = (const uint4*)rows; a.state_map = state_map; a.term_mask = term_mask;
   a.s0_cdf = s0_cdf; a.s0_ids = s0_ids; a.max_steps = max_steps; a.env_task = env_task;
   a.n_env = n_env; a.n_task = n_task; a.S = S; a.A = A; a.s0_max = s0_max; a.words = (S + 63) / 64;
-  a.NB = NB;
+  a.NB = NB; a.RL = RL;
   a.err = e->d_err;
-  a.state = nullptr; a.steps = nullptr; a.need_reset = nullptr; a.hdr = nullptr; a.fence = nullptr;
   a.seed = e->seed; a.gid_base = e->env_id_base; a.tick = 0;
 
-  // the fast path needs S <= 64, s0_max <= 4 and observation ids that fit a byte
-  bool fast = (S <= 64 && s0_max <= 4);
+  // the fast path needs a fence that fits one line (NB <= 16), s0_max <= 4 and observation ids that fit 16 bits
+  bool fast = (NB <= 16 && s0_max <= 4);
   if (fast) {
     int* d_max = nullptr;
     int h_max = 0;
@@ -630,36 +634,39 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
     XV_HIP(hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     XV_HIP(hipStreamSynchronize(e->stream));
     XV_HIP(hipFree(d_max));
-    fast = h_max < 256;
+    fast = h_max < 65536;
   }
 
-  AnyMDPHdr* hdr = nullptr;
-  double* fence = nullptr;
-  const size_t n_rows = (size_t)n_task * S * A;
-  hipError_t m = hipMalloc(&a.state, sizeof(int32_t) * (size_t)n_env);
-  if (m == hipSuccess) m = hipMalloc(&a.steps, sizeof(int32_t) * (size_t)n_env);
-  if (m == hipSuccess) m = hipMalloc(&a.need_reset, (size_t)n_env);
-  if (m == hipSuccess && fast) m = hipMalloc(&hdr, sizeof(AnyMDPHdr) * (size_t)n_task);
-  if (m == hipSuccess && fast) m = hipMalloc(&fence, n_rows * 4 * sizeof(double));
-  if (m == hipSuccess) m = hipMemsetAsync(a.state, 0, sizeof(int32_t) * (size_t)n_env, e->stream);
-  if (m == hipSuccess) m = hipMemsetAsync(a.steps, 0, sizeof(int32_t) * (size_t)n_env, e->stream);
-  if (m == hipSuccess) m = hipMemsetAsync(a.need_reset, 1, (size_t)n_env, e->stream);
+  double2* c01 = nullptr; double* c2 = nullptr; uint32_t* ids = nullptr; uint2* robs = nullptr; int32_t* rms = nullptr;
+  const size_t n_rows = (size_t)n_task * S * A, ne = (size_t)n_env;
+  hipError_t m = hipMalloc(&a.state, sizeof(int32_t) * ne);
+  if (m == hipSuccess) m = hipMalloc(&a.steps, sizeof(int32_t) * ne);
+  if (m == hipSuccess) m = hipMalloc(&a.need_reset, ne);
+  if (m == hipSuccess) m = hipMalloc(&a.cur_term, ne);
+  if (m == hipSuccess && fast) m = hipMalloc(&c01, sizeof(double2) * ne);
+  if (m == hipSuccess && fast) m = hipMalloc(&c2, sizeof(double) * ne);
+  if (m == hipSuccess && fast) m = hipMalloc(&ids, sizeof(uint32_t) * ne);
+  if (m == hipSuccess && fast) m = hipMalloc(&robs, sizeof(uint2) * ne);
+  if (m == hipSuccess && fast) m = hipMalloc(&rms, sizeof(int32_t) * ne);
+  if (m == hipSuccess) m = hipMemsetAsync(a.state, 0, sizeof(int32_t) * ne, e->stream);
+  if (m == hipSuccess) m = hipMemsetAsync(a.steps, 0, sizeof(int32_t) * ne, e->stream);
+  if (m == hipSuccess) m = hipMemsetAsync(a.need_reset, 1, ne, e->stream);
+  if (m == hipSuccess) m = hipMemsetAsync(a.cur_term, 0, ne, e->stream);
   if (m != hipSuccess) {
     xv_set_error("xv_anymdp_create: device allocation failed: %s", hipGetErrorString(m));
-    if (a.state) (void)hipFree(a.state);
-    if (a.steps) (void)hipFree(a.steps);
-    if (a.need_reset) (void)hipFree(a.need_reset);
-    if (hdr) (void)hipFree(hdr);
-    if (fence) (void)hipFree(fence);
+    void* ps[] = {a.state, a.steps, a.need_reset, a.cur_term, c01, c2, ids, robs, rms};
+    for (void* q : ps) if (q) (void)hipFree(q);
     delete h;
     return XV_ERR_HIP;
   }
   if (fast) {
-    hipLaunchKernelGGL(anymdp_pack_hdr_kernel, dim3(xv_div_up(n_task, 256)), dim3(256), 0, e->stream, a, hdr);
-    hipLaunchKernelGGL(anymdp_build_fence_kernel, dim3((unsigned)((n_rows * 4 + 255) / 256)), dim3(256), 0,
-                       e->stream, a.rows, fence, n_rows, NB);
-    a.hdr = hdr;
-    a.fence = fence;
+    XV_CHECK_ARG(n_rows * 16 / 256 + 1 < 0x7FFFFFFFull);
+    hipLaunchKernelGGL(anymdp_finish_rows_kernel, dim3((unsigned)((n_rows * 16 + 255) / 256)), dim3(256), 0, e->stream, a,
+                       (uint4*)rows, n_rows);
+    hipLaunchKernelGGL(anymdp_env_records_kernel, dim3(xv_div_up(n_env, 256)), dim3(256), 0, e->stream, a, c01, c2, ids,
+                       robs, rms);
+    a.rs_c01 = c01; a.rs_c2 = c2; a.rs_ids = ids; a.rs_obs = robs; a.rs_max_steps = rms;
+    h->fast = true;
   }
   XV_LAUNCH_CHECK();
   *out = h;
@@ -670,11 +677,10 @@ extern "C" int xv_anymdp_destroy(xv_anymdp* h) {
   if (!h) return XV_OK;
   (void)hipSetDevice(h->eng->device);
   (void)hipStreamSynchronize(h->eng->stream);
-  (void)hipFree(h->a.state);
-  (void)hipFree(h->a.steps);
-  (void)hipFree(h->a.need_reset);
-  if (h->a.hdr) (void)hipFree((void*)h->a.hdr);
-  if (h->a.fence) (void)hipFree((void*)h->a.fence);
+  AnyMDPArgs& a = h->a;
+  void* ps[] = {a.state, a.steps, a.need_reset, a.cur_term, (void*)a.rs_c01, (void*)a.rs_c2, (void*)a.rs_ids,
+                (void*)a.rs_obs, (void*)a.rs_max_steps};
+  for (void* q : ps) if (q) (void)hipFree(q);
   delete h;
   return XV_OK;
 }
@@ -707,17 +713,13 @@ extern "C" int xv_anymdp_reset_injected(xv_anymdp* h, const uint8_t* mask, const
 template <bool INJECT>
 static int anymdp_launch_step(xv_anymdp* h, const AnyMDPStepIO& io, int T, int mode) {
   const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
-#define XV_LAUNCH_STEP(SEARCH, HDR, ROLL)                                                          \
-  hipLaunchKernelGGL((anymdp_step_kernel<INJECT, SEARCH, HDR, ROLL>), grid, block, 0, h->eng->stream, \
-                     h->a, io, T, mode)
-  const bool roll = T > 1;
-  const bool fast = h->a.hdr != nullptr;
-  if (fast && h->search != XV_ANYMDP_SEARCH_BINARY) {
-    if (roll) XV_LAUNCH_STEP(SEARCH_FENCE, true, true); else XV_LAUNCH_STEP(SEARCH_FENCE, true, false);
-  } else if (fast) {
-    if (roll) XV_LAUNCH_STEP(SEARCH_BINARY, true, true); else XV_LAUNCH_STEP(SEARCH_BINARY, true, false);
+#define XV_LAUNCH_STEP(FAST, ROLL)                                                                \
+  hipLaunchKernelGGL((anymdp_step_kernel<INJECT, FAST, ROLL>), grid, block, 0, h->eng->stream, h->a, io, T, mode)
+  const bool roll = T > 1 || io.greedy != nullptr;
+  if (h->fast && h->search != XV_ANYMDP_SEARCH_BINARY) {
+    if (roll) XV_LAUNCH_STEP(true, true); else XV_LAUNCH_STEP(true, false);
   } else {
-    if (roll) XV_LAUNCH_STEP(SEARCH_BINARY, false, true); else XV_LAUNCH_STEP(SEARCH_BINARY, false, false);
+    if (roll) XV_LAUNCH_STEP(false, true); else XV_LAUNCH_STEP(false, false);
   }
 #undef XV_LAUNCH_STEP
   XV_LAUNCH_CHECK();
@@ -788,8 +790,8 @@ extern "C" int xv_anymdp_set_search(xv_anymdp* h, int search) {
   XV_CHECK_ARG(h != nullptr);
   XV_CHECK_ARG(search == XV_ANYMDP_SEARCH_AUTO || search == XV_ANYMDP_SEARCH_BINARY ||
                search == XV_ANYMDP_SEARCH_FENCE);
-  if (search == XV_ANYMDP_SEARCH_FENCE && !h->a.hdr) {
-    xv_set_error("xv_anymdp_set_search: FENCE needs S <= 64, s0_max <= 4 and observation ids < 256");
+  if (search == XV_ANYMDP_SEARCH_FENCE && !h->fast) {
+    xv_set_error("xv_anymdp_set_search: FENCE needs S <= 112, s0_max <= 4 and observation ids < 65536");
     return XV_ERR_UNSUPPORTED;
   }
   h->search = search;
@@ -812,6 +814,10 @@ extern "C" int xv_anymdp_set_state(xv_anymdp* h, const int32_t* inner_state, con
   if (inner_state) XV_HIP(hipMemcpyAsync(h->a.state, inner_state, n * 4, hipMemcpyDeviceToDevice, h->eng->stream));
   if (steps) XV_HIP(hipMemcpyAsync(h->a.steps, steps, n * 4, hipMemcpyDeviceToDevice, h->eng->stream));
   if (need_reset) XV_HIP(hipMemcpyAsync(h->a.need_reset, need_reset, n, hipMemcpyDeviceToDevice, h->eng->stream));
+  if (inner_state) {
+    hipLaunchKernelGGL(anymdp_fix_term_kernel, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream, h->a);
+    XV_LAUNCH_CHECK();
+  }
   return XV_OK;
 }
 

@@ -1,8 +1,8 @@
 // anymdp_synth.hip — synthetic AnyMDP task tables generated directly in HBM.
 //
-// The headline config has one task per env: 65,536 tasks x (S=64, A=8) = 32 GiB of blocked rows (fp64 CDF
-// entries + {reward, noise} pairs) — more than the host can stage — so the tables are produced on the
-// device, directly in the blocked layout of include/xeno.h.  Integer-only construction, bit-identical to oracle/xeno_oracle.c: xo_anymdp_synth (weights are
+// The headline config has one task per env: 65,536 tasks x (S=64, A=8) = 44 GiB of row records (fp64 CDF
+// entries + {reward, noise} pairs in 128-byte blocks, a fence line per row) — more than the host can stage —
+// so the tables are produced on the device, directly in the row layout of include/xeno.h.  Integer-only construction, bit-identical to oracle/xeno_oracle.c: xo_anymdp_synth (weights are
 // integers, partial sums exact in uint32, one IEEE fp64 division per CDF entry), so the generator itself
 // is parity-tested.  Row shape follows the reference sampler's banded transitions
 // (anymdp/task_sampler_utils.py:65-175): support of row (s,a) is a band [lo,hi) around s.
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64) void anymdp_synth_header_kernel(uint64_t seed, 
 // one wave per (task, s, a) row; lane j owns entries j, j+64, ...
 __global__ __launch_bounds__(256) void anymdp_synth_rows_kernel(uint64_t seed, int64_t task_base,
                                                                 int n_task, int S, int A,
-                                                                const uint64_t* term_mask, double* rows) {
+                                                                const uint64_t* term_mask, void* rows) {
   const int lane = threadIdx.x & 63;
   const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const size_t n_rows = (size_t)n_task * S * A;
@@ -109,8 +109,10 @@ __global__ __launch_bounds__(256) void anymdp_synth_rows_kernel(uint64_t seed, i
     total += r;
   }
   uint32_t carry = 0;
-  const int NB = (S + 15) / 16;
-  double* row = rows + wave * (size_t)NB * 32;   // blocked layout: include/xeno.h "rows"
+  // row record: include/xeno.h "rows" — line 0 (fence) and the metadata unit of each block are completed by
+  // xv_anymdp_create; here only the 16-byte entries {cdf, reward, noise}, 7 per 128-byte block
+  const int NB = (S + 6) / 7;
+  uint4* row = reinterpret_cast<uint4*>(rows) + wave * (size_t)(1 + NB) * 8;
   for (int c = 0; c < chunks; ++c) {
     const int j = c * 64 + lane;
     uint32_t incl = wt[c];  // inclusive scan over the wave
@@ -120,21 +122,23 @@ __global__ __launch_bounds__(256) void anymdp_synth_rows_kernel(uint64_t seed, i
       if (lane >= off) incl += n;
     }
     const uint32_t chunk_sum = __shfl(incl, 63);
-    if (j < NB * 16) {
-      double* blk = row + (size_t)(j >> 4) * 32;
-      float2 o = make_float2(0.0f, 0.0f);
-      double cj = 2.0;   // padding entries of the last block: never <= u
-      if (j < S) {
-        cj = term ? 1.0 : (double)(carry + incl) / (double)total;
-        const xv_u32x4 w = synth_draw(seed, task, rowid, 0x100u + (uint32_t)(j >> 1));
-        const uint32_t wa = (j & 1) ? w.z : w.x, wb = (j & 1) ? w.w : w.y;
-        o.x = (float)((int32_t)(wa >> 8) - 8388608) * (1.0f / 4194304.0f);
-        o.y = (wb & 1u) ? (float)(wb >> 8) * (1.0f / 67108864.0f) : 0.0f;
-      }
-      blk[j & 15] = cj;
-      reinterpret_cast<float2*>(blk + 16)[j & 15] = o;
+    if (j < S) {
+      const double cj = term ? 1.0 : (double)(carry + incl) / (double)total;
+      const xv_u32x4 w = synth_draw(seed, task, rowid, 0x100u + (uint32_t)(j >> 1));
+      const uint32_t wa = (j & 1) ? w.z : w.x, wb = (j & 1) ? w.w : w.y;
+      const float r = (float)((int32_t)(wa >> 8) - 8388608) * (1.0f / 4194304.0f);
+      const float sg = (wb & 1u) ? (float)(wb >> 8) * (1.0f / 67108864.0f) : 0.0f;
+      const int b = j / 7;
+      row[(size_t)(1 + b) * 8 + (j - 7 * b)] =
+          make_uint4((uint32_t)__double2loint(cj), (uint32_t)__double2hiint(cj), __float_as_uint(r), __float_as_uint(sg));
     }
     carry += chunk_sum;
+  }
+  // padding entries of the last block: cdf 2.0 (never <= u), zero reward pair
+  const int jp = S + lane;
+  if (jp < NB * 7) {
+    const int b = jp / 7;
+    row[(size_t)(1 + b) * 8 + (jp - 7 * b)] = make_uint4((uint32_t)__double2loint(2.0), (uint32_t)__double2hiint(2.0), 0u, 0u);
   }
 }
 
@@ -153,7 +157,7 @@ extern "C" int xv_anymdp_synth_tasks(xv_engine* e, uint64_t seed, int64_t task_i
   const size_t blocks = (n_rows + 3) / 4;
   XV_CHECK_ARG(blocks < 0x7FFFFFFFull);
   hipLaunchKernelGGL(anymdp_synth_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, e->stream, seed,
-                     task_index_base, n_task, S, A, (const uint64_t*)term_mask, (double*)rows);
+                     task_index_base, n_task, S, A, (const uint64_t*)term_mask, rows);
   XV_LAUNCH_CHECK();
   return XV_OK;
 }
