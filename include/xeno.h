@@ -257,6 +257,11 @@ int xv_linds_destroy(xv_linds* h);
 #define XV_LINDS_PATH_MFMA 1
 #define XV_LINDS_PATH_SCALAR 2
 int xv_linds_set_path(xv_linds* h, int path);
+/* get_inner_cmd (linds_env.py:93-98) depends on (task, integer time) only; xv_linds_create tabulates it per task
+ * ([max_steps + 2 + delay][NO] floats, with the kernels' own evaluation code, if the table fits 2 GiB) and a step
+ * reads two rows instead of evaluating 2 x NO x n_fourier sin/cos pairs.  enable = 0 evaluates directly (same
+ * bits; parity-tested).  Returns XV_ERR_UNSUPPORTED when enable = 1 and no table was built. */
+int xv_linds_set_command_table(xv_linds* h, int enable);
 /* reset: x = initial_states[k], k uniform (linds_env.py:117 uses random.choice); obs = C x + Y; command =
  * cmd(0); error = ||(obs - cmd) * valid||.  obs/cmd float[n_env][NO], error float[n_env]; all nullable. */
 int xv_linds_reset(xv_linds* h, const uint8_t* mask, float* obs, float* cmd, float* error);

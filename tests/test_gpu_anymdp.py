@@ -209,13 +209,25 @@ def test_s64_wave_kernel_vs_oracle(n_env, n_task, search):
     env.close()
 
 
-@pytest.mark.parametrize("S,A,n_task", [(16, 4, 6), (100, 5, 3), (256, 3, 2), (8, 2, 5)])
-def test_generic_kernel_other_sizes_vs_oracle(S, A, n_task):
+@pytest.mark.parametrize("S,A,n_task,obs_offset", [(16, 4, 6, 0), (100, 5, 3, 0), (256, 3, 2, 0), (8, 2, 5, 0),
+                                                    (7, 2, 3, 0), (112, 3, 2, 0), (113, 3, 2, 0),
+                                                    (64, 8, 4, 65000), (64, 8, 4, 70000)])
+def test_generic_kernel_other_sizes_vs_oracle(S, A, n_task, obs_offset):
+    """block-count boundaries of the fence path (S = 7: one block; S = 112: 16 blocks, the last fence line that
+    fits; S = 113 and S = 256: per-lane binary search) and observation ids at the 16-bit metadata limit
+    (ids < 65536 stay on the fence path, larger ones fall back)"""
     tab = oracle.anymdp_synth(seed=5, task_index_base=0, n_task=n_task, S=S, A=A, s0_max=3)
+    tab["state_map"] = tab["state_map"] + np.int32(obs_offset)
     n_env = 50 * n_task
     env_task = np.repeat(np.arange(n_task, dtype=np.int32), 50)
     env = AnyMDPVecEnv(n_env, autoreset_mode="same_step")
     env.set_task(_dev_tables(tab), env_task_index=env_task)
+    expect_fast = S <= 112 and obs_offset + S <= 65536
+    if expect_fast:
+        env.set_search("fence")
+    else:
+        with pytest.raises(Exception, match="FENCE needs"):
+            env.set_search("fence")
     ora = oracle.AnyMDPOracle(tab, env_task)
     rng = np.random.RandomState(S)
     u0 = rng.random_sample(n_env)

@@ -127,6 +127,39 @@ def test_batch_injected_vs_oracle(mode, layout, path):
     env.close()
 
 
+@pytest.mark.parametrize("path", ["mfma", "scalar"])
+def test_command_table_equals_direct_evaluation(path):
+    """the per-task table of get_inner_cmd values (built at set_task) gives bit-identical steps to evaluating the
+    Fourier terms in the kernel, also past the end of the table (auto-reset disabled, envs stepped on after
+    truncation) and right after resets"""
+    tasks, tab, env_task = _batch(64, FILES[:4])
+    n = len(env_task)
+    rng = np.random.RandomState(8)
+    acts = rng.uniform(-0.3, 0.3, (70, n, 8)).astype(np.float32)
+    zs = rng.standard_normal((70, tab["NS"], n)).astype(np.float32)
+    n_init = tab["ints"][env_task, 2]
+    idxs = (rng.random_sample((70, n)) * n_init).astype(np.int32)
+    outs = []
+    for table in (True, False):
+        env = LinDSVecEnv(n, autoreset_mode="disabled")
+        env.set_task(tasks, env_task_index=env_task)
+        env.set_path(path)
+        env.set_command_table(table)
+        obs, info = env.reset_injected(idxs[0])
+        rec = [_np(obs), _np(info["command"])]
+        for t in range(70):            # max_steps is 40: the last 30 steps run past the table
+            o, r, te, tr, info = env.step_injected(acts[t], zs[t], idxs[t])
+            rec += [_np(o), _np(r), _np(info["command"]), _np(info["error"]), _np(te), _np(tr)]
+            if t == 20:
+                m = np.zeros(n, np.uint8); m[::3] = 1
+                env.reset_injected(idxs[t], mask=m)
+        assert int(_np(env.get_state()[1]).max()) > 45
+        outs.append(rec)
+        env.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
 def test_free_running_philox_vs_oracle():
     tasks, tab, env_task = _batch(64, FILES[:4])
     n = len(env_task)

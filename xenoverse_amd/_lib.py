@@ -46,6 +46,7 @@ SIGNATURES = {
     "xv_linds_create": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, C.POINTER(c_void_p)],
     "xv_linds_destroy": [c_void_p],
     "xv_linds_set_path": [c_void_p, c_int],
+    "xv_linds_set_command_table": [c_void_p, c_int],
     "xv_linds_reset": [c_void_p] + [c_void_p] * 4,
     "xv_linds_reset_injected": [c_void_p] + [c_void_p] * 5,
     "xv_linds_step": [c_void_p] + [c_void_p] * 8 + [c_int],

@@ -25,6 +25,10 @@ struct LinDSArgs {
   uint32_t* err;
   int n_env, n_task, NS, NA, NO, NI;
   uint64_t seed, gid_base, tick;
+  // engine-built command table (nullptr if it would not fit the budget): cmd_tab[task][tt - ct_tmin][NO] holds
+  // get_inner_cmd at integer time tt, already multiplied by target_valid, for tt in [ct_tmin, ct_tmin + ct_len)
+  const float* cmd_tab;
+  int ct_len, ct_tmin;
 };
 
 struct LinDSStepIO {
@@ -45,6 +49,7 @@ struct xv_linds {
   LinDSArgs a;
   bool tiles_uniform;   // every aligned 32-env group shares a task -> MFMA path
   int path;             // XV_LINDS_PATH_*
+  float* cmd_tab;       // owned; a.cmd_tab points here while the table is enabled
 };
 
 // Task tables are read-only for the lifetime of a launch: reading them through the constant address space lets
@@ -94,6 +99,25 @@ __device__ __forceinline__ void linds_cmd(const LinDSArgs& P, int tu, int nf, in
   for (int j = 0; j < NO; ++j) out[j] *= valid[j];   // :98
 }
 
+// The command of an env depends on (task, integer time) only, and a step needs it at two times (tracked and
+// reported), 2 x NO x nf sin/cos pairs per env-step when evaluated directly.  The engine tabulates it once per
+// task at create time with the function above (same code, same bits); a step then reads two 64-B rows.  Times
+// outside the table (an env stepped on past truncation with auto-reset disabled) are evaluated directly.
+template <int NO>
+__device__ __forceinline__ void linds_cmd_at(const LinDSArgs& P, int tu, int nf, int tt, float (&out)[NO]) {
+  const int idx = tt - P.ct_tmin;
+  if (P.cmd_tab != nullptr && idx >= 0 && idx < P.ct_len) {
+    const float4* p = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)tu * P.ct_len + idx) * NO);
+#pragma unroll
+    for (int q = 0; q < NO / 4; ++q) {
+      const float4 v = p[q];
+      out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w;
+    }
+  } else {
+    linds_cmd<NO>(P, tu, nf, tt, out);
+  }
+}
+
 // y = C x + Y with the fixed k order (uniform task tu)
 template <int NS, int NO>
 __device__ __forceinline__ void linds_observe(const LinDSArgs& P, int tu, const float (&xs)[NS], float (&y)[NO]) {
@@ -133,6 +157,25 @@ __device__ __forceinline__ void linds_store_row(float* dst, const float (&v)[N])
   for (int q = 0; q < N / 4; ++q) d4[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
+template <int NO>
+__global__ __launch_bounds__(256) void linds_build_cmd_tab_kernel(LinDSArgs P, float* tab) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)P.n_task * P.ct_len) return;
+  const int t = (int)(idx / P.ct_len), k = (int)(idx % P.ct_len);
+  float out[NO];
+  linds_cmd<NO>(P, t, P.T.ints[(size_t)t * 4 + 3], k + P.ct_tmin, out);
+  linds_store_row<NO>(tab + idx * NO, out);
+}
+
+// max over tasks of max_steps and of the command delay (sizes the command table)
+__global__ __launch_bounds__(256) void linds_max_ints_kernel(const int32_t* ints, int n_task, int* out2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_task) return;
+  atomicMax(out2, ints[(size_t)t * 4]);
+  atomicMax(out2 + 1, ints[(size_t)t * 4 + 1]);
+}
+
+
 // reset of one env inside the uniform-task region: x = initial_states[idx]; obs; cmd(0); error
 template <int NS, int NO>
 __device__ __forceinline__ void linds_reset_env(const LinDSArgs& P, int tu, int nf, int n_init, int idx,
@@ -142,7 +185,7 @@ __device__ __forceinline__ void linds_reset_env(const LinDSArgs& P, int tu, int 
 #pragma unroll
   for (int k = 0; k < NS; ++k) xs[k] = x0[k];   // :117
   linds_observe<NS, NO>(P, tu, xs, y);
-  linds_cmd<NO>(P, tu, nf, 0, c);                // :120-126: the last pre-filled command is cmd(0)
+  linds_cmd_at<NO>(P, tu, nf, 0, c);                // :120-126: the last pre-filled command is cmd(0)
   err = linds_err<NO>(P, tu, y, c);
 }
 
@@ -251,8 +294,8 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
         linds_observe<NS, NO>(P, tu, xn, y);      // :145
         steps += 1;                               // :147
         float ctrack[NO];
-        linds_cmd<NO>(P, tu, nf, steps - 1 - delay, ctrack);   // :150-151 tracked command
-        linds_cmd<NO>(P, tu, nf, steps, crep);                 // :168 reported command
+        linds_cmd_at<NO>(P, tu, nf, steps - 1 - delay, ctrack);   // :150-151 tracked command
+        linds_cmd_at<NO>(P, tu, nf, steps, crep);                 // :168 reported command
         o_err = linds_err<NO>(P, tu, y, ctrack);               // :153
         float sc2 = 0.0f;
 #pragma unroll
@@ -494,7 +537,7 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
     // the two lanes of an env share the command work: half 0 evaluates the tracked command cmd(steps-1-delay)
     // (:150-151), half 1 the reported one cmd(steps) (:168); one __shfl_xor per component exchanges them
     float cmine[NO];
-    linds_cmd<NO>(P, t, nf, h ? steps_new : steps_new - 1 - delay, cmine);
+    linds_cmd_at<NO>(P, t, nf, h ? steps_new : steps_new - 1 - delay, cmine);
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
       const float cother = __shfl_xor(cmine[j], 32);
@@ -535,7 +578,7 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
     }
     float yr[NO], c0[NO];
     linds_observe_mfma<NS, NO>(P, t, h, ca, xr, yr);
-    linds_cmd<NO>(P, t, nf, 0, c0);                // :120-126
+    linds_cmd_at<NO>(P, t, nf, 0, c0);                // :120-126
     const float e0 = linds_err<NO>(P, t, yr, c0);
     if (do_reset) {
       if (!skip) {
@@ -642,6 +685,36 @@ extern "C" int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int 
     h->tiles_uniform = (h_flag == 0);
     h->path = XV_LINDS_PATH_AUTO;
   }
+  // command table: [n_task][max_steps_max + 2 + delay_max][NO] floats, within a 2-GiB budget
+  a.cmd_tab = nullptr; a.ct_len = 0; a.ct_tmin = 0;
+  h->cmd_tab = nullptr;
+  {
+    int* d2 = nullptr;
+    int h2[2] = {0, 0};
+    XV_HIP(hipMalloc(&d2, 2 * sizeof(int)));
+    XV_HIP(hipMemsetAsync(d2, 0, 2 * sizeof(int), e->stream));
+    hipLaunchKernelGGL(linds_max_ints_kernel, dim3(xv_div_up(n_task, 256)), dim3(256), 0, e->stream, tables->ints, n_task, d2);
+    XV_HIP(hipMemcpyAsync(h2, d2, 2 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    XV_HIP(hipStreamSynchronize(e->stream));
+    XV_HIP(hipFree(d2));
+    const long long len = (long long)h2[0] + 2 + h2[1];
+    const unsigned long long bytes = (unsigned long long)n_task * (unsigned long long)len * NO * sizeof(float);
+    float* tab = nullptr;
+    if (h2[0] > 0 && h2[1] >= 0 && len < (1 << 20) && bytes <= (2ull << 30) && hipMalloc(&tab, bytes) == hipSuccess) {
+      a.ct_len = (int)len;
+      a.ct_tmin = -(1 + h2[1]);
+      const size_t n = (size_t)n_task * a.ct_len;
+      if (NO == 16)
+        hipLaunchKernelGGL((linds_build_cmd_tab_kernel<16>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, a, tab);
+      else
+        hipLaunchKernelGGL((linds_build_cmd_tab_kernel<32>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, a, tab);
+      a.cmd_tab = tab;
+      h->cmd_tab = tab;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  XV_LAUNCH_CHECK();
   *out = h;
   return XV_OK;
 }
@@ -656,6 +729,16 @@ extern "C" int xv_linds_set_path(xv_linds* h, int path) {
   return XV_OK;
 }
 
+extern "C" int xv_linds_set_command_table(xv_linds* h, int enable) {
+  XV_CHECK_ARG(h != nullptr);
+  if (enable && !h->cmd_tab) {
+    xv_set_error("xv_linds_set_command_table: no table was built (over the 2-GiB budget or allocation failed)");
+    return XV_ERR_UNSUPPORTED;
+  }
+  h->a.cmd_tab = enable ? h->cmd_tab : nullptr;
+  return XV_OK;
+}
+
 extern "C" int xv_linds_destroy(xv_linds* h) {
   if (!h) return XV_OK;
   (void)hipSetDevice(h->eng->device);
@@ -663,6 +746,7 @@ extern "C" int xv_linds_destroy(xv_linds* h) {
   (void)hipFree(h->a.x);
   (void)hipFree(h->a.steps);
   (void)hipFree(h->a.need_reset);
+  if (h->cmd_tab) (void)hipFree(h->cmd_tab);
   delete h;
   return XV_OK;
 }

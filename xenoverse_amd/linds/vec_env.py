@@ -132,6 +132,11 @@ class LinDSVecEnv(VectorEnv):
         """Select the step kernel ("auto", "mfma", "scalar"); results are identical (include/xeno.h)."""
         _lib.check(self.lib.xv_linds_set_path(self._h, self.PATH[path]))
 
+    def set_command_table(self, enable):
+        """Use the per-task table of get_inner_cmd values built at set_task (default) or evaluate the Fourier
+        terms in every step; the results are identical."""
+        _lib.check(self.lib.xv_linds_set_command_table(self._h, 1 if enable else 0))
+
     # -- helpers ------------------------------------------------------------------------------------
     def _user_obs(self, t):
         return t[:, :self.user_dims[1]]
