@@ -58,6 +58,7 @@ typedef struct xv_engine xv_engine;
 typedef struct xv_anymdp xv_anymdp;
 typedef struct xv_linds xv_linds;
 typedef struct xv_cartpole xv_cartpole;
+typedef struct xv_acrobot xv_acrobot;
 typedef struct xv_maze xv_maze;
 
 /* ------------------------------------------------------------------------------------------------
@@ -303,6 +304,32 @@ int xv_cartpole_step_injected(xv_cartpole* h, const int32_t* action, const float
                               int autoreset_mode);
 int xv_cartpole_get_state(xv_cartpole* h, float* state /*[4][n_env]*/, int32_t* steps, uint8_t* need_reset);
 int xv_cartpole_set_state(xv_cartpole* h, const float* state, const int32_t* steps, const uint8_t* need_reset);
+
+/* ------------------------------------------------------------------------------------------------
+ * Acrobot — reference: xenoverse/metacontrol/random_acrobot.py (_dsdt :58-96, _terminal :98-101, set_task
+ * :103-106, step :108-117 = `frameskip` repeats of gymnasium's AcrobotEnv.step, reset :119-130).  The integrator
+ * around _dsdt (rk4 over [0, 0.2], wrap to [-pi, pi], velocity bounds 4 pi / 9 pi, torques {-1, 0, +1}, "book"
+ * dynamics, no torque noise) is gymnasium's: third-party, not vendored, PARITY UNPINNED for that part; _dsdt and
+ * _terminal are pinned to the reference's own code (tests/golden/acrobot_dsdt.npz).
+ *   params double[n_task][7] = link_length_1, link_length_2, link_mass_1, link_mass_2, link_com_1, link_com_2,
+ *                              gravity (sample_acrobot :14-39)
+ *   reset_scale double[4] (device), scale_is_vector: reset_bounds_scale was given as a list (the reset state is then
+ *   a float64 product) or as a scalar (float32 product, and the reset observation uses float32 cos/sin, as numpy does)
+ *   fp64 state [4][n_env] = theta1, theta2, dtheta1, dtheta2; obs float[n_env][6] = cos/sin(theta1), cos/sin(theta2),
+ *   dtheta1, dtheta2; action in {0, 1, 2}; reward = -1 per sub-step until the terminating one; max_steps <= 0: no
+ *   truncation (the reference registers no TimeLimit).  Injected reset draws u double[4][n_env] in [0, 1).
+ * ---------------------------------------------------------------------------------------------- */
+int xv_acrobot_create(xv_engine* e, int n_env, int n_task, int frameskip, int max_steps, const double* params,
+                      const double* reset_scale, int scale_is_vector, const int32_t* env_task, xv_acrobot** out);
+int xv_acrobot_destroy(xv_acrobot* h);
+int xv_acrobot_reset(xv_acrobot* h, const uint8_t* mask, float* obs /*[n_env][6]*/);
+int xv_acrobot_reset_injected(xv_acrobot* h, const uint8_t* mask, const double* u /*[4][n_env] in [0,1)*/, float* obs);
+int xv_acrobot_step(xv_acrobot* h, const int32_t* action, float* obs, float* reward, uint8_t* terminated,
+                    uint8_t* truncated, float* final_obs, int autoreset_mode);
+int xv_acrobot_step_injected(xv_acrobot* h, const int32_t* action, const double* u_reset, float* obs, float* reward,
+                             uint8_t* terminated, uint8_t* truncated, float* final_obs, int autoreset_mode);
+int xv_acrobot_get_state(xv_acrobot* h, double* state /*[4][n_env]*/, int32_t* steps, uint8_t* need_reset);
+int xv_acrobot_set_state(xv_acrobot* h, const double* state, const int32_t* steps, const uint8_t* need_reset);
 
 /* ------------------------------------------------------------------------------------------------
  * MazeWorld — reference: xenoverse/mazeworld/envs

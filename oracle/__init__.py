@@ -320,6 +320,90 @@ class CartPoleOracle(object):
 
 
 # ---------------------------------------------------------------------------------------------------
+# Acrobot
+# ---------------------------------------------------------------------------------------------------
+class _AcrobotStruct(C.Structure):
+    _fields_ = [("n_env", C.c_int), ("n_task", C.c_int), ("frameskip", C.c_int), ("max_steps", C.c_int),
+                ("scale_is_vector", C.c_int), ("params", C.c_void_p), ("reset_scale", C.c_void_p),
+                ("env_task", C.c_void_p), ("state", C.c_void_p), ("fresh", C.c_void_p), ("steps", C.c_void_p),
+                ("need_reset", C.c_void_p), ("err_flags", C.c_uint32)]
+
+
+def acrobot_dsdt(params, y):
+    """RandomAcrobotEnv._dsdt for rows of params[n][7], y[n][5] -> [n][5]"""
+    params = np.ascontiguousarray(params, np.float64).reshape(-1, 7)
+    y = np.ascontiguousarray(y, np.float64).reshape(-1, 5)
+    out = np.zeros_like(y)
+    f = lib().xo_acrobot_dsdt
+    for i in range(len(y)):
+        f(_p(params[i]), _p(y[i]), _p(out[i]))
+    return out
+
+
+def acrobot_terminal(params, s):
+    params = np.ascontiguousarray(params, np.float64).reshape(-1, 7)
+    s = np.ascontiguousarray(s, np.float64).reshape(-1, 4)
+    f = lib().xo_acrobot_terminal
+    f.restype = C.c_int
+    return np.array([f(_p(params[i]), _p(s[i])) for i in range(len(s))], np.uint8)
+
+
+class AcrobotOracle(object):
+    def __init__(self, params, env_task, frameskip=1, max_steps=0, reset_scale=0.10):
+        self.params = np.ascontiguousarray(params, np.float64).reshape(-1, 7)
+        self.env_task = np.ascontiguousarray(env_task, np.int32)
+        self.n_env = len(self.env_task)
+        vec = not np.isscalar(reset_scale)
+        self.scale = np.ascontiguousarray(reset_scale if vec else [reset_scale] * 4, np.float64)
+        self.state = np.zeros((4, self.n_env), np.float64)
+        self.fresh = np.zeros(self.n_env, np.uint8)
+        self.steps = np.zeros(self.n_env, np.int32)
+        self.need_reset = np.ones(self.n_env, np.uint8)
+        self._h = _AcrobotStruct(self.n_env, len(self.params), frameskip, max_steps, int(vec), _p(self.params),
+                                 _p(self.scale), _p(self.env_task), _p(self.state), _p(self.fresh), _p(self.steps),
+                                 _p(self.need_reset), 0)
+
+    @property
+    def err_flags(self):
+        return int(self._h.err_flags)
+
+    def _outs(self):
+        n = self.n_env
+        return dict(obs=np.zeros((n, 6), np.float32), reward=np.zeros(n, np.float32),
+                    terminated=np.zeros(n, np.uint8), truncated=np.zeros(n, np.uint8),
+                    final_obs=np.zeros((n, 6), np.float32))
+
+    def reset_injected(self, u, mask=None):
+        obs = np.zeros((self.n_env, 6), np.float32)
+        u = np.ascontiguousarray(u, np.float64).reshape(4, self.n_env)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        lib().xo_acrobot_reset_injected(C.byref(self._h), _p(m), _p(u), _p(obs))
+        return obs
+
+    def reset(self, seed, gid_base, tick, mask=None):
+        obs = np.zeros((self.n_env, 6), np.float32)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        lib().xo_acrobot_reset(C.byref(self._h), C.c_uint64(seed), C.c_uint64(gid_base), C.c_uint64(tick), _p(m), _p(obs))
+        return obs
+
+    def step_injected(self, action, u_reset, mode):
+        o = self._outs()
+        a = np.ascontiguousarray(action, np.int32)
+        u = np.ascontiguousarray(u_reset, np.float64).reshape(4, self.n_env)
+        lib().xo_acrobot_step_injected(C.byref(self._h), _p(a), _p(u), _p(o["obs"]), _p(o["reward"]),
+                                       _p(o["terminated"]), _p(o["truncated"]), _p(o["final_obs"]), C.c_int(mode))
+        return o
+
+    def step(self, seed, gid_base, tick, action, mode):
+        o = self._outs()
+        a = np.ascontiguousarray(action, np.int32)
+        lib().xo_acrobot_step(C.byref(self._h), C.c_uint64(seed), C.c_uint64(gid_base), C.c_uint64(tick), _p(a),
+                              _p(o["obs"]), _p(o["reward"]), _p(o["terminated"]), _p(o["truncated"]),
+                              _p(o["final_obs"]), C.c_int(mode))
+        return o
+
+
+# ---------------------------------------------------------------------------------------------------
 # MazeWorld
 # ---------------------------------------------------------------------------------------------------
 class _MazeStruct(C.Structure):

@@ -424,7 +424,50 @@ def gen_maze():
         gen_maze_one("maze_15_seed%d" % k, task, max_steps=(5000 if k else 230), seed0=100 + k)
 
 
-FAMILIES = {"anymdp": gen_anymdp, "linds": gen_linds, "maze": gen_maze}
+def gen_acrobot():
+    """The reference's OWN Acrobot code: RandomAcrobotEnv._dsdt and ._terminal (random_acrobot.py:58-101), called on
+    random inputs with tasks drawn over sample_acrobot's ranges, and the reset-state formula (:123-125).  The
+    integrator around them (AcrobotEnv.step / rk4 / wrap / bound) is gymnasium's and is not installed: unpinned."""
+    import importlib.util
+    _refimport.setup()
+    path = os.path.join(_refimport.REF_ROOT, "xenoverse", "metacontrol", "random_acrobot.py")
+    spec = importlib.util.spec_from_file_location("_ref_random_acrobot", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.RandomState(20260901)
+    n = 2000
+    keys = ("link_length_1", "link_length_2", "link_mass_1", "link_mass_2", "link_com_1", "link_com_2", "gravity")
+    prm = np.zeros((n, 7)); y = np.zeros((n, 5)); out = np.zeros((n, 5)); term = np.zeros(n, np.uint8)
+    for i in range(n):
+        env = object.__new__(mod.RandomAcrobotEnv)
+        l1, l2 = float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.5, 3.0))
+        task = dict(link_length_1=l1, link_length_2=l2, link_mass_1=float(rng.uniform(0.5, 3.0)),
+                    link_mass_2=float(rng.uniform(0.5, 3.0)), link_com_1=float(rng.uniform(0.25, 0.75)) * l1,
+                    link_com_2=float(rng.uniform(0.25, 0.75)) * l2, gravity=float(rng.uniform(1.0, 15.0)))
+        for k, v in task.items():         # what set_task does (:103-106), without its print
+            setattr(env, k, v)
+        prm[i] = [task[k] for k in keys]
+        s = np.array([rng.uniform(-np.pi, np.pi), rng.uniform(-np.pi, np.pi), rng.uniform(-4 * np.pi, 4 * np.pi),
+                      rng.uniform(-9 * np.pi, 9 * np.pi), float(rng.randint(0, 3) - 1)], np.float64)
+        if i % 5 == 0:
+            s[:4] *= 0.05                  # near the hanging rest pose, where episodes start
+        y[i] = s
+        out[i] = np.asarray(env._dsdt(s), np.float64)
+        env.state = s[:4]
+        term[i] = env._terminal()
+    # reset(): uniform(-1, 1, 4).astype(float32) * reset_bounds_scale for the scalar (registered) and list forms
+    u = rng.random_sample((64, 4))
+    r32 = (-1.0 + 2.0 * u).astype(np.float32)
+    reset_scalar = (r32 * 0.10).astype(np.float64)                         # float32 array * python float
+    scale_vec = np.array([0.3, 0.2, 0.1, 0.05])
+    reset_vector = r32 * scale_vec                                         # float32 array * float64 array
+    assert (r32 * 0.10).dtype == np.float32 and reset_vector.dtype == np.float64
+    np.savez_compressed(os.path.join(GOLD, "acrobot_dsdt.npz"), params=prm, y=y, dsdt=out, terminal=term,
+                        reset_u=u, reset_scalar=reset_scalar, reset_vector=reset_vector, scale_vec=scale_vec)
+    print("acrobot_dsdt.npz: %d derivative vectors, %d terminal" % (n, int(term.sum())))
+
+
+FAMILIES = {"anymdp": gen_anymdp, "linds": gen_linds, "maze": gen_maze, "acrobot": gen_acrobot}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

@@ -635,6 +635,169 @@ void xo_cartpole_step(xo_cartpole* h, uint64_t seed, uint64_t gid_base, uint64_t
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Acrobot — metacontrol/random_acrobot.py over gymnasium AcrobotEnv (dt 0.2, torques {-1,0,+1}, MAX_VEL 4pi/9pi,
+ * book dynamics, no torque noise).  Every expression keeps the reference's Python evaluation order.
+ * ---------------------------------------------------------------------------------------------- */
+#define AC_PI 3.141592653589793 /* numpy.pi */
+
+/* random_acrobot.py:58-96 (book_or_nips == "book", the gymnasium default) */
+void xo_acrobot_dsdt(const double prm[7], const double y[5], double out[5]) {
+  const double l1 = prm[0], l2 = prm[1], m1 = prm[2], m2 = prm[3], lc1 = prm[4], lc2 = prm[5], g = prm[6];
+  const double I1 = m1 * (lc1 * lc1 + (l1 - lc1) * (l1 - lc1)) / 6.0;
+  const double I2 = m2 * (lc2 * lc2 + (l2 - lc2) * (l2 - lc2)) / 6.0;
+  const double a = y[4], theta1 = y[0], theta2 = y[1], dtheta1 = y[2], dtheta2 = y[3];
+  const double c2 = cos(theta2), s2 = sin(theta2);
+  const double d1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + 2 * l1 * lc2 * c2) + I1 + I2;
+  const double d2 = m2 * (lc2 * lc2 + l1 * lc2 * c2) + I2;
+  const double phi2 = m2 * lc2 * g * cos(theta1 + theta2 - AC_PI / 2.0);
+  const double phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * s2 - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * s2 +
+                      (m1 * lc1 + m2 * l1) * g * cos(theta1 - AC_PI / 2) + phi2;
+  const double ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * s2 - phi2) /
+                          (m2 * (lc2 * lc2) + I2 - d2 * d2 / d1);
+  const double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
+  out[0] = dtheta1; out[1] = dtheta2; out[2] = ddtheta1; out[3] = ddtheta2; out[4] = 0.0;
+}
+
+/* random_acrobot.py:98-101 */
+int xo_acrobot_terminal(const double prm[7], const double s[4]) { return -cos(s[0]) - cos(s[1] + s[0]) > prm[0]; }
+
+static double ac_wrap(double x, double m, double M) { /* gymnasium acrobot.wrap */
+  const double diff = M - m;
+  while (x > M) x = x - diff;
+  while (x < m) x = x + diff;
+  return x;
+}
+static double ac_bound(double x, double m, double M) { /* min(max(x, m), M) with Python's comparison semantics */
+  const double t = (m > x) ? m : x; /* max(x, m): returns x unless m > x */
+  return (M < t) ? M : t;           /* min(t, M): returns t unless M < t */
+}
+
+/* one AcrobotEnv.step: rk4 over [0, dt], wrap, bound, terminal */
+static int acrobot_substep(const double prm[7], double s[4], double torque) {
+  const double dt = 0.2, dt2 = dt / 2.0;
+  double y0[5] = {s[0], s[1], s[2], s[3], torque}, k1[5], k2[5], k3[5], k4[5], y[5];
+  xo_acrobot_dsdt(prm, y0, k1);
+  for (int i = 0; i < 5; ++i) y[i] = y0[i] + dt2 * k1[i];
+  xo_acrobot_dsdt(prm, y, k2);
+  for (int i = 0; i < 5; ++i) y[i] = y0[i] + dt2 * k2[i];
+  xo_acrobot_dsdt(prm, y, k3);
+  for (int i = 0; i < 5; ++i) y[i] = y0[i] + dt * k3[i];
+  xo_acrobot_dsdt(prm, y, k4);
+  double ns[4];
+  for (int i = 0; i < 4; ++i) ns[i] = y0[i] + dt / 6.0 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+  s[0] = ac_wrap(ns[0], -AC_PI, AC_PI);
+  s[1] = ac_wrap(ns[1], -AC_PI, AC_PI);
+  s[2] = ac_bound(ns[2], -4 * AC_PI, 4 * AC_PI);
+  s[3] = ac_bound(ns[3], -9 * AC_PI, 9 * AC_PI);
+  return xo_acrobot_terminal(prm, s);
+}
+
+static void acrobot_obs(const xo_acrobot* h, int i, float* o) { /* AcrobotEnv._get_ob -> float32[6] */
+  const size_t N = (size_t)h->n_env;
+  const double s0 = h->state[i], s1 = h->state[N + i], s2 = h->state[2 * N + i], s3 = h->state[3 * N + i];
+  if (h->fresh[i] && !h->scale_is_vector) { /* the state is a float32 array: numpy's cos/sin stay in float32 */
+    o[0] = cosf((float)s0); o[1] = sinf((float)s0); o[2] = cosf((float)s1); o[3] = sinf((float)s1);
+  } else {
+    o[0] = (float)cos(s0); o[1] = (float)sin(s0); o[2] = (float)cos(s1); o[3] = (float)sin(s1);
+  }
+  o[4] = (float)s2; o[5] = (float)s3;
+}
+
+static void acrobot_reset_one(xo_acrobot* h, int i, const double u[4], float* obs) {
+  /* state = uniform(-1, 1, 4).astype(float32) * reset_bounds_scale   (random_acrobot.py:123-125) */
+  const size_t N = (size_t)h->n_env;
+  for (int k = 0; k < 4; ++k) {
+    const float f = (float)(-1.0 + 2.0 * u[k]);
+    h->state[k * N + i] = h->scale_is_vector ? (double)f * h->reset_scale[k] : (double)(f * (float)h->reset_scale[k]);
+  }
+  h->fresh[i] = 1;
+  h->steps[i] = 0;
+  h->need_reset[i] = 0;
+  if (obs) acrobot_obs(h, i, obs + (size_t)i * 6);
+}
+
+static void acrobot_step_one(xo_acrobot* h, int i, int action, const double u_reset[4], float* obs, float* reward,
+                             uint8_t* terminated, uint8_t* truncated, float* final_obs, int mode) {
+  const size_t N = (size_t)h->n_env;
+  const double* prm = h->params + (size_t)h->env_task[i] * 7;
+  if (final_obs) for (int k = 0; k < 6; ++k) final_obs[(size_t)i * 6 + k] = 0.0f;
+  if (mode == 1 && h->need_reset[i]) {
+    acrobot_reset_one(h, i, u_reset, obs);
+    reward[i] = 0.0f; terminated[i] = 0; truncated[i] = 0;
+    return;
+  }
+  if (action < 0 || action > 2) { h->err_flags |= 1u; action = action < 0 ? 0 : 2; }
+  const double torque = (double)(action - 1); /* AVAIL_TORQUE = [-1.0, 0.0, +1] */
+  double s[4] = {h->state[i], h->state[N + i], h->state[2 * N + i], h->state[3 * N + i]};
+  double total_reward = 0.0;
+  int term = 0;
+  for (int f = 0; f < h->frameskip; ++f) { /* :112-116 */
+    term = acrobot_substep(prm, s, torque);
+    total_reward += term ? 0.0 : -1.0;
+    if (term) break;
+  }
+  for (int k = 0; k < 4; ++k) h->state[k * N + i] = s[k];
+  h->fresh[i] = 0;
+  const int steps = h->steps[i] + 1;
+  const int trunc = h->max_steps > 0 && steps >= h->max_steps;
+  h->steps[i] = steps;
+  acrobot_obs(h, i, obs + (size_t)i * 6);
+  reward[i] = (float)total_reward; terminated[i] = (uint8_t)term; truncated[i] = (uint8_t)trunc;
+  if (term || trunc) {
+    if (mode == 2) {
+      if (final_obs) for (int k = 0; k < 6; ++k) final_obs[(size_t)i * 6 + k] = obs[(size_t)i * 6 + k];
+      acrobot_reset_one(h, i, u_reset, obs);
+    } else if (mode == 1) {
+      h->need_reset[i] = 1;
+    }
+  }
+}
+
+void xo_acrobot_reset_injected(xo_acrobot* h, const uint8_t* mask, const double* u, float* obs) {
+  for (int i = 0; i < h->n_env; ++i) {
+    if (mask && !mask[i]) continue;
+    double uu[4];
+    for (int k = 0; k < 4; ++k) uu[k] = u[(size_t)k * h->n_env + i];
+    acrobot_reset_one(h, i, uu, obs);
+  }
+}
+
+void xo_acrobot_step_injected(xo_acrobot* h, const int32_t* action, const double* u_reset, float* obs, float* reward,
+                              uint8_t* terminated, uint8_t* truncated, float* final_obs, int mode) {
+  for (int i = 0; i < h->n_env; ++i) {
+    double uu[4];
+    for (int k = 0; k < 4; ++k) uu[k] = u_reset[(size_t)k * h->n_env + i];
+    acrobot_step_one(h, i, action[i], uu, obs, reward, terminated, truncated, final_obs, mode);
+  }
+}
+
+/* reset draws: two Philox calls (purposes 1 and 3), a 53-bit uniform from each word pair */
+static inline void acrobot_draw(uint64_t seed, uint64_t gid, uint64_t tick, double u[4]) {
+  uint32_t w[4], v[4];
+  xo_env_draw(seed, gid, tick, 1, w);
+  xo_env_draw(seed, gid, tick, 3, v);
+  u[0] = xo_u53(w[0], w[1]); u[1] = xo_u53(w[2], w[3]); u[2] = xo_u53(v[0], v[1]); u[3] = xo_u53(v[2], v[3]);
+}
+
+void xo_acrobot_reset(xo_acrobot* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const uint8_t* mask, float* obs) {
+  for (int i = 0; i < h->n_env; ++i) {
+    if (mask && !mask[i]) continue;
+    double u[4];
+    acrobot_draw(seed, gid_base + (uint64_t)i, tick, u);
+    acrobot_reset_one(h, i, u, obs);
+  }
+}
+
+void xo_acrobot_step(xo_acrobot* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const int32_t* action, float* obs,
+                     float* reward, uint8_t* terminated, uint8_t* truncated, float* final_obs, int mode) {
+  for (int i = 0; i < h->n_env; ++i) {
+    double u[4];
+    acrobot_draw(seed, gid_base + (uint64_t)i, tick, u);
+    acrobot_step_one(h, i, action[i], u, obs, reward, terminated, truncated, final_obs, mode);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * MazeWorld
  * ---------------------------------------------------------------------------------------------- */
 #define MZ_PI 3.1415926      /* dynamics.py:7-8: the reference's own truncated constants */

@@ -153,6 +153,35 @@ void xo_cartpole_step(xo_cartpole* h, uint64_t seed, uint64_t gid_base, uint64_t
                       float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, float* final_obs, int mode);
 
 /* ---------------------------------------------------------------------------------------------
+ * Acrobot — reference: metacontrol/random_acrobot.py (_dsdt :58-96, _terminal :98-101, set_task :103-106,
+ * step :108-117, reset :119-130) over gymnasium's AcrobotEnv.step / rk4 / wrap / bound (third-party, not vendored:
+ * that part is PARITY UNPINNED, restated from the public gymnasium 1.x source).  The reference's own _dsdt and
+ * _terminal ARE pinned (tests/golden/acrobot_dsdt.npz, generated by calling them).  fp64 state, [4][n_env].
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int n_env, n_task, frameskip, max_steps; /* max_steps <= 0: never truncates (the reference registers no TimeLimit) */
+  int scale_is_vector;      /* reset_bounds_scale given as a list (float64 product) or a scalar (float32 product) */
+  const double* params;     /* [n_task][7]: link_length_1, link_length_2, link_mass_1, link_mass_2, link_com_1,
+                               link_com_2, gravity (sample_acrobot :14-39) */
+  const double* reset_scale;/* [4] */
+  const int32_t* env_task;
+  double* state;            /* [4][n_env]: theta1, theta2, dtheta1, dtheta2 */
+  uint8_t* fresh;           /* state still holds the float32 reset values (the reference's obs is then float32 math) */
+  int32_t* steps;
+  uint8_t* need_reset;
+  uint32_t err_flags;
+} xo_acrobot;
+void xo_acrobot_dsdt(const double prm[7], const double s_aug[5], double out[5]);
+int xo_acrobot_terminal(const double prm[7], const double s[4]);
+void xo_acrobot_reset_injected(xo_acrobot* h, const uint8_t* mask, const double* u /*[4][n_env] in [0,1)*/,
+                               float* obs /*[n_env][6]*/);
+void xo_acrobot_step_injected(xo_acrobot* h, const int32_t* action, const double* u_reset, float* obs,
+                              float* reward, uint8_t* terminated, uint8_t* truncated, float* final_obs, int mode);
+void xo_acrobot_reset(xo_acrobot* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const uint8_t* mask, float* obs);
+void xo_acrobot_step(xo_acrobot* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const int32_t* action,
+                     float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, float* final_obs, int mode);
+
+/* ---------------------------------------------------------------------------------------------
  * MazeWorld — reference: mazeworld/envs/dynamics.py (move/collision), maze_base.py (rules),
  * maze_continuous_3d.py (do_action, update_observation), ray_caster_utils.py (DDA_2D, interpolate, maze_view).
  * Pose in fp64 as the reference; ray-caster with the reference's mixed f32/f64 typing (see xeno_oracle.c).

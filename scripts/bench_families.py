@@ -93,6 +93,34 @@ def bench_cartpole(args):
                          "note": "4.8 MB per launch: launch-latency bound, not bandwidth bound"}}
 
 
+def bench_acrobot(args):
+    from xenoverse_amd.metacontrol import AcrobotVecEnv, sample_acrobot
+    from xenoverse_amd import _lib
+    from xenoverse_amd.engine import AUTORESET
+    n = 65536
+    out = {}
+    for fs in (1, 5):
+        env = AcrobotVecEnv(n, frameskip=fs, autoreset_mode="same_step", seed=1, max_steps=500)
+        env.set_task([sample_acrobot(seed=k) for k in range(1024)])
+        env.reset()
+        a = torch.randint(0, 3, (n,), device=env.device, dtype=torch.int32)
+
+        def step():
+            _lib.check(env.lib.xv_acrobot_step(env._h, _lib.ptr(a), _lib.ptr(env._obs), _lib.ptr(env._reward),
+                                               _lib.ptr(env._term), _lib.ptr(env._trunc), _lib.ptr(env._fobs),
+                                               AUTORESET["same_step"]))
+        out[fs] = timed(step, args.steps, args.warmup)
+        env.close()
+    algo = (64 + 4 + 24 + 4 + 2 + 24 + 56) * n      # fp64 state r/w, action, obs, reward, flags, final_obs, task params
+    us = out[1]
+    return {"family": "acrobot", "workload": "65,536 envs, 1,024 tasks, rk4 in fp64", "dtype": "f64",
+            "env_steps_per_s": n / (us * 1e-6), "us_per_step": {"frameskip 1": out[1], "frameskip 5": out[5]},
+            "roofline": {"bound": "hbm", "achieved": algo / (us * 1e-6) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
+                         "frac": algo / (us * 1e-6) / 1e9 / HBM_PEAK, "algorithmic_bytes_per_env_step": algo // n,
+                         "note": "11 MB per launch; 4 dsdt evaluations (8 fp64 sin/cos) per sub-step: latency / "
+                                 "VALU bound, not bandwidth bound"}}
+
+
 def bench_maze(args, res):
     from xenoverse_amd.mazeworld import MazeTaskSampler, MazeWorldVecEnv, make_texture_library
     from xenoverse_amd import _lib
@@ -144,13 +172,15 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--families", default="linds,cartpole,maze64,maze256")
+    ap.add_argument("--families", default="linds,cartpole,acrobot,maze64,maze256")
     args = ap.parse_args()
     for f in args.families.split(","):
         if f == "linds":
             r = bench_linds(args)
         elif f == "cartpole":
             r = bench_cartpole(args)
+        elif f == "acrobot":
+            r = bench_acrobot(args)
         elif f.startswith("maze"):
             r = bench_maze(args, int(f[4:]))
         else:

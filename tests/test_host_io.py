@@ -28,7 +28,9 @@ def test_npz_batches_roundtrip(tmp_path):
 
 
 def test_registry_ids_match_reference():
-    assert set(registration.REGISTRY) == {"anymdp-v0", "linear-dynamics-v0", "mazeworld-v2", "random-cartpole-v0"}
+    assert set(registration.REGISTRY) == {"anymdp-v0", "linear-dynamics-v0", "mazeworld-v2", "random-cartpole-v0",
+                                          "random-acrobot-v0"}
+    assert registration.REGISTRY["random-acrobot-v0"][1] == {"frameskip": 1, "reset_bounds_scale": 0.10}
     assert registration.REGISTRY["mazeworld-v2"][1]["resolution"] == (256, 256)
     assert registration.REGISTRY["random-cartpole-v0"][1]["frameskip"] == 1
     registration.register_with_gymnasium()     # must not raise without gymnasium

@@ -61,6 +61,14 @@ SIGNATURES = {
     "xv_cartpole_step_injected": [c_void_p] + [c_void_p] * 7 + [c_int],
     "xv_cartpole_get_state": [c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_cartpole_set_state": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "xv_acrobot_create": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, C.POINTER(c_void_p)],
+    "xv_acrobot_destroy": [c_void_p],
+    "xv_acrobot_reset": [c_void_p, c_void_p, c_void_p],
+    "xv_acrobot_reset_injected": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "xv_acrobot_step": [c_void_p] + [c_void_p] * 6 + [c_int],
+    "xv_acrobot_step_injected": [c_void_p] + [c_void_p] * 7 + [c_int],
+    "xv_acrobot_get_state": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "xv_acrobot_set_state": [c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_maze_create": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, C.c_double, C.c_double,
                        c_void_p, c_void_p, C.POINTER(c_void_p)],
     "xv_maze_destroy": [c_void_p],

@@ -1,0 +1,153 @@
+"""AcrobotVecEnv — N domain-randomised Acrobots per kernel launch.
+
+Mirrors xenoverse/metacontrol/random_acrobot.py: sample_acrobot :14-39, RandomAcrobotEnv.__init__ :43-55
+(frameskip, reset_bounds_scale), _dsdt :58-96, _terminal :98-101, set_task :103-106, step :108-117, reset :119-130;
+registered id `random-acrobot-v0` uses frameskip=1, reset_bounds_scale=0.10 (metacontrol/__init__.py:27-33).
+The integrator around _dsdt is gymnasium's AcrobotEnv (not installed here): that part is unpinned, see
+include/xeno.h.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..engine import AUTORESET
+from ..spaces import Box, Discrete
+from ..vector import VectorEnv
+from .cartpole import _versatile
+
+TASK_KEYS = ("link_length_1", "link_length_2", "link_mass_1", "link_mass_2", "link_com_1", "link_com_2", "gravity")
+
+
+def sample_acrobot(link_length_1=True, link_length_2=True, link_mass_1=True, link_mass_2=True, link_com_1=True,
+                   link_com_2=True, gravity=True, seed=None):
+    """Same ranges and keys as the reference sampler (random_acrobot.py:14-39).  The reference is time-seeded
+    and not reproducible; `seed` (optional) makes this one reproducible."""
+    rng = np.random.RandomState(seed)
+    l1 = _versatile(link_length_1, (0.5, 3.0), 1.0, rng)
+    l2 = _versatile(link_length_2, (0.5, 3.0), 1.0, rng)
+    m1 = _versatile(link_mass_1, (0.5, 3.0), 1.0, rng)
+    m2 = _versatile(link_mass_2, (0.5, 3.0), 1.0, rng)
+    c1 = _versatile(link_com_1, (0.25, 0.75), 0.5, rng) * l1
+    c2 = _versatile(link_com_2, (0.25, 0.75), 0.5, rng) * l2
+    g = _versatile(gravity, (1.0, 15.0), 9.8, rng)
+    return {"link_length_1": l1, "link_length_2": l2, "link_mass_1": m1, "link_mass_2": m2, "link_com_1": c1,
+            "link_com_2": c2, "gravity": g}
+
+
+class AcrobotVecEnv(VectorEnv):
+    def __init__(self, num_envs, frameskip=5, reset_bounds_scale=0.10, max_steps=0, device="cuda:0", seed=0,
+                 env_id_base=0, autoreset_mode="same_step", to_numpy=False, engine=None):
+        super().__init__(num_envs, device=device, seed=seed, env_id_base=env_id_base,
+                         autoreset_mode=autoreset_mode, to_numpy=to_numpy, engine=engine)
+        self.frameskip = int(frameskip)
+        if isinstance(reset_bounds_scale, (list, tuple, np.ndarray)):
+            assert len(reset_bounds_scale) == 4, "reset_bounds_scale should be a list of 4 elements"
+            self.reset_bounds_scale = np.asarray(reset_bounds_scale, np.float64)
+            self._scale_is_vector = True
+        else:
+            self.reset_bounds_scale = np.full(4, float(reset_bounds_scale), np.float64)
+            self._scale_is_vector = False
+        self.max_steps = int(max_steps)
+        hi = np.array([1.0, 1.0, 1.0, 1.0, 4 * np.pi, 9 * np.pi], np.float32)   # AcrobotEnv.observation_space
+        self._set_spaces(Box(-hi, hi, dtype=np.float32), Discrete(3))
+        self._h = None
+
+    def set_task(self, tasks, env_task_index=None):
+        if isinstance(tasks, dict):
+            tasks = [tasks]
+        params = np.array([[t[k] for k in TASK_KEYS] for t in tasks], np.float64)
+        d = self.device
+        n_task = len(tasks)
+        if env_task_index is None:
+            if self.num_envs % n_task != 0:
+                raise ValueError("num_envs is not a multiple of the task count; pass env_task_index")
+            env_task = torch.arange(self.num_envs, device=d, dtype=torch.int32) // (self.num_envs // n_task)
+        else:
+            env_task = self._dev(env_task_index, torch.int32)
+        self._tab = dict(params=torch.from_numpy(params).to(d), scale=torch.from_numpy(self.reset_bounds_scale).to(d),
+                         env_task=env_task.contiguous())
+        if self._h is not None:
+            self.lib.xv_acrobot_destroy(self._h)
+        h = C.c_void_p()
+        _lib.check(self.lib.xv_acrobot_create(self.engine.handle, self.num_envs, n_task, self.frameskip, self.max_steps,
+                                              _lib.ptr(self._tab["params"]), _lib.ptr(self._tab["scale"]),
+                                              1 if self._scale_is_vector else 0, _lib.ptr(self._tab["env_task"]),
+                                              C.byref(h)))
+        self._h = h
+        n = self.num_envs
+        self._obs = torch.zeros((n, 6), dtype=torch.float32, device=d)
+        self._fobs = torch.zeros((n, 6), dtype=torch.float32, device=d)
+        self._reward = torch.zeros(n, dtype=torch.float32, device=d)
+        self._term = torch.zeros(n, dtype=torch.uint8, device=d)
+        self._trunc = torch.zeros(n, dtype=torch.uint8, device=d)
+        self.task_set = True
+        self.need_reset = True
+
+    def reset(self, *, seed=None, options=None):
+        self._require_task()
+        if seed is not None:
+            self.engine.tick = (int(seed) & 0xFFFFFFFF) << 24
+        mask = None
+        if options is not None and options.get("reset_mask") is not None:
+            mask = self._dev(options["reset_mask"], torch.uint8)
+        _lib.check(self.lib.xv_acrobot_reset(self._h, _lib.ptr(mask), _lib.ptr(self._obs)))
+        self.need_reset = False
+        return self._out(self._obs.clone()), {}
+
+    def reset_injected(self, u, mask=None):
+        self._require_task()
+        u = self._dev(u, torch.float64)
+        m = None if mask is None else self._dev(mask, torch.uint8)
+        _lib.check(self.lib.xv_acrobot_reset_injected(self._h, _lib.ptr(m), _lib.ptr(u), _lib.ptr(self._obs)))
+        self.need_reset = False
+        return self._out(self._obs.clone())
+
+    def _ret(self):
+        infos = {}
+        if self.autoreset_mode == "same_step":
+            infos["final_obs"] = self._out(self._fobs.clone())
+            infos["_final_obs"] = self._out((self._term | self._trunc).bool())
+        return (self._out(self._obs.clone()), self._out(self._reward.clone()), self._out(self._term.bool()),
+                self._out(self._trunc.bool()), infos)
+
+    def step(self, actions):
+        if (not self.task_set) or self.need_reset:
+            raise Exception("Must \"set_task\" and \"reset\" before doing any actions")
+        a = self._dev(actions, torch.int32)
+        assert a.shape == (self.num_envs,)
+        _lib.check(self.lib.xv_acrobot_step(self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward),
+                                            _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._fobs),
+                                            AUTORESET[self.autoreset_mode]))
+        return self._ret()
+
+    def step_injected(self, actions, u_reset):
+        a = self._dev(actions, torch.int32)
+        u = self._dev(u_reset, torch.float64)
+        _lib.check(self.lib.xv_acrobot_step_injected(self._h, _lib.ptr(a), _lib.ptr(u), _lib.ptr(self._obs),
+                                                     _lib.ptr(self._reward), _lib.ptr(self._term),
+                                                     _lib.ptr(self._trunc), _lib.ptr(self._fobs),
+                                                     AUTORESET[self.autoreset_mode]))
+        return self._ret()
+
+    def get_state(self):
+        n, d = self.num_envs, self.device
+        s = torch.empty((4, n), dtype=torch.float64, device=d)
+        st = torch.empty(n, dtype=torch.int32, device=d)
+        nr = torch.empty(n, dtype=torch.uint8, device=d)
+        _lib.check(self.lib.xv_acrobot_get_state(self._h, _lib.ptr(s), _lib.ptr(st), _lib.ptr(nr)))
+        return s, st, nr
+
+    def set_state(self, state=None, steps=None, need_reset=None):
+        s = None if state is None else self._dev(state, torch.float64)
+        st = None if steps is None else self._dev(steps, torch.int32)
+        nr = None if need_reset is None else self._dev(need_reset, torch.uint8)
+        _lib.check(self.lib.xv_acrobot_set_state(self._h, _lib.ptr(s), _lib.ptr(st), _lib.ptr(nr)))
+        self.engine.sync()
+        self.need_reset = False
+
+    def close_extras(self, **kwargs):
+        if self._h is not None:
+            self.lib.xv_acrobot_destroy(self._h)
+            self._h = None

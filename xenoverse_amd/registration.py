@@ -1,5 +1,5 @@
 """Environment ids.  The reference registers `anymdp-v0`, `linear-dynamics-v0`, `mazeworld-v2` and
-`random-cartpole-v0` with gymnasium (anymdp/__init__.py:24-30, linds/__init__.py:21-35, mazeworld/__init__.py:19-33,
+`random-cartpole-v0` / `random-acrobot-v0` with gymnasium (anymdp/__init__.py:24-30, linds/__init__.py:21-35, mazeworld/__init__.py:19-33,
 metacontrol/__init__.py:20-26).  `make_vec(id, num_envs, **kw)` builds the batched engine with the same registered
 keyword defaults; when gymnasium is importable the ids are also registered as vector entry points."""
 import importlib
@@ -13,6 +13,7 @@ REGISTRY = {
                       "visibility_3D": 12.0, "command_in_observation": False, "action_space_type": "Discrete16"}),
     "random-cartpole-v0": ("xenoverse_amd.metacontrol:CartPoleVecEnv",
                            {"frameskip": 1, "reset_bounds_scale": [0.45, 0.90, 0.13, 1.0]}),
+    "random-acrobot-v0": ("xenoverse_amd.metacontrol:AcrobotVecEnv", {"frameskip": 1, "reset_bounds_scale": 0.10}),
 }
 
 
