@@ -121,6 +121,75 @@ def bench_acrobot(args):
                                  "VALU bound, not bandwidth bound"}}
 
 
+def bench_mixed(args):
+    """BASELINE.json config 5, the per-GPU share: 16,384 anymdp (2b: 256 tasks x 64) + 8,192 linds (128 tasks x 64)
+    + 8,192 cartpole, one launch per family per vector step, families on separate HIP streams (xenoverse_amd.mixed)
+    vs the same launches serialised on one stream."""
+    from xenoverse_amd import Engine, _lib
+    from xenoverse_amd.anymdp import AnyMDPVecEnv, row_lines
+    from xenoverse_amd.engine import AUTORESET
+    from xenoverse_amd.linds import LinDSVecEnv, LinearDSSampler
+    from xenoverse_amd.metacontrol import CartPoleVecEnv, sample_cartpole
+    from xenoverse_amd.mixed import MixedBatch
+    na, nl, nc, S, A = 16384, 8192, 8192, 64, 8
+    ltasks = [LinearDSSampler(32, 8, 8, seed=k % 32) for k in range(nl // 64)]
+    for t in ltasks:
+        t["max_steps"] = 500
+    ctasks = [sample_cartpole(seed=k) for k in range(1024)]
+    res = {}
+    for label, mixed in (("three streams", True), ("one stream", False)):
+        if mixed:
+            mb = MixedBatch("cuda:0", seed=3, streams="separate")
+            ea = mb.add("a", AnyMDPVecEnv, na)
+            el = mb.add("l", LinDSVecEnv, nl)
+            ec = mb.add("c", CartPoleVecEnv, nc, frameskip=1)
+        else:
+            ea, el, ec = AnyMDPVecEnv(na, seed=3), LinDSVecEnv(nl, seed=3), CartPoleVecEnv(nc, seed=3, frameskip=1)
+        d = ea.device
+        n_task = na // 64
+        tab = dict(S=S, A=A, s0_max=4, rows=torch.empty((n_task, S, A, row_lines(S), 16), dtype=torch.float64, device=d),
+                   state_map=torch.empty((n_task, S), dtype=torch.int32, device=d),
+                   term_mask=torch.empty((n_task, 1), dtype=torch.int64, device=d),
+                   s0_cdf=torch.empty((n_task, 4), dtype=torch.float64, device=d),
+                   s0_ids=torch.empty((n_task, 4), dtype=torch.int32, device=d),
+                   max_steps=torch.empty(n_task, dtype=torch.int32, device=d))
+        _lib.check(ea.lib.xv_anymdp_synth_tasks(ea.engine.handle, 7, 0, n_task, S, A, 4, *[_lib.ptr(tab[k]) for k in
+                   ("rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")]))
+        ea.engine.sync()
+        if mixed:
+            mb.set_task({"a": tab, "l": ltasks, "c": ctasks})
+            mb.reset()
+        else:
+            ea.set_task(tab); el.set_task(ltasks); ec.set_task(ctasks)
+            ea.reset(); el.reset(); ec.reset()
+        torch.cuda.synchronize()
+        aa = torch.randint(0, A, (na,), device=d, dtype=torch.int32)
+        al = torch.rand((nl, 8), device=d) * 2 - 1
+        ac = torch.randint(0, 2, (nc,), device=d, dtype=torch.int32)
+        mode = AUTORESET["same_step"]
+
+        def launch_all():
+            _lib.check(ea.lib.xv_anymdp_step(ea._h, _lib.ptr(aa), _lib.ptr(ea._obs), _lib.ptr(ea._reward), _lib.ptr(ea._reward_gt),
+                                             _lib.ptr(ea._term), _lib.ptr(ea._trunc), _lib.ptr(ea._final_obs), mode))
+            _lib.check(el.lib.xv_linds_step(el._h, _lib.ptr(al), _lib.ptr(el._obs), _lib.ptr(el._reward), _lib.ptr(el._term),
+                                            _lib.ptr(el._trunc), _lib.ptr(el._cmd), _lib.ptr(el._error), _lib.ptr(el._fobs), mode))
+            _lib.check(ec.lib.xv_cartpole_step(ec._h, _lib.ptr(ac), _lib.ptr(ec._obs), _lib.ptr(ec._reward), _lib.ptr(ec._term),
+                                               _lib.ptr(ec._trunc), _lib.ptr(ec._fobs), mode))
+
+        def step():
+            launch_all()
+            if mixed:      # the caller's stream waits for the three family streams, and they wait for it (next actions)
+                mb.sync()
+                for st in mb.streams.values():
+                    st.wait_stream(torch.cuda.current_stream())
+        res[label] = timed(step, args.steps, args.warmup)
+        (mb.close() if mixed else [e.close() for e in (ea, el, ec)])
+    n = na + nl + nc
+    best = min(res.values())
+    return {"family": "mixed (config 5, per-GPU share)", "workload": "16,384 anymdp(2b) + 8,192 linds(32,8,8) + 8,192 cartpole",
+            "env_steps_per_s": n / (best * 1e-6), "us_per_vector_step": res, "dtype": "f64/f32"}
+
+
 def bench_maze(args, res):
     from xenoverse_amd.mazeworld import MazeTaskSampler, MazeWorldVecEnv, make_texture_library
     from xenoverse_amd import _lib
@@ -181,6 +250,8 @@ if __name__ == "__main__":
             r = bench_cartpole(args)
         elif f == "acrobot":
             r = bench_acrobot(args)
+        elif f == "mixed":
+            r = bench_mixed(args)
         elif f.startswith("maze"):
             r = bench_maze(args, int(f[4:]))
         else:

@@ -28,7 +28,7 @@ def _anymdp_tables(n_task):
     return out
 
 
-def _run(n_a, n_l, n_c, lo_frac=(0.0, 1.0), mixed=True, T=12, seed=5):
+def _run(n_a, n_l, n_c, lo_frac=(0.0, 1.0), mixed=True, T=12, seed=5, streams="separate"):
     """step the three families for T steps; returns per-family stacked observations / rewards"""
     full = dict(a=512, l=256, c=256)
     sl = {k: (int(lo_frac[0] * v), int(lo_frac[1] * v)) for k, v in full.items()}
@@ -44,7 +44,7 @@ def _run(n_a, n_l, n_c, lo_frac=(0.0, 1.0), mixed=True, T=12, seed=5):
                 c=rng.randint(0, 2, (T, full["c"])).astype(np.int32))
     rec = {k: [] for k in "alc"}
     if mixed:
-        mb = MixedBatch("cuda:0", seed=seed)
+        mb = MixedBatch("cuda:0", seed=seed, streams=streams)
         mb.add("a", AnyMDPVecEnv, len(et_a), env_id_base=sl["a"][0])
         mb.add("l", LinDSVecEnv, len(et_l), env_id_base=sl["l"][0])
         mb.add("c", CartPoleVecEnv, len(et_c), env_id_base=sl["c"][0], frameskip=1)
@@ -70,8 +70,9 @@ def _run(n_a, n_l, n_c, lo_frac=(0.0, 1.0), mixed=True, T=12, seed=5):
     return {k: (np.stack([x[0] for x in v]), np.stack([x[1] for x in v])) for k, v in rec.items()}
 
 
-def test_mixed_equals_standalone():
-    m = _run(0, 0, 0, mixed=True)
+@pytest.mark.parametrize("streams", ["separate", "shared"])
+def test_mixed_equals_standalone(streams):
+    m = _run(0, 0, 0, mixed=True, streams=streams)
     s = _run(0, 0, 0, mixed=False)
     for k in "alc":
         assert np.array_equal(m[k][0], s[k][0]) and np.array_equal(m[k][1], s[k][1]), k
