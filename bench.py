@@ -88,9 +88,21 @@ def cpu_baseline(seconds, seed):
         if time.perf_counter() - t0 >= seconds:
             break
     dt = time.perf_counter() - t0
-    return {"value": n_env * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "oracle/xeno_oracle.c step (OpenMP, %d threads), %d envs x %d distinct S=64,A=8 tasks, "
-                      "%d vector steps in %.1f s" % (cores, n_env, n_env, k, dt)}
+    out = {"value": n_env * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": "oracle/xeno_oracle.c step (OpenMP, %d threads), %d envs x %d distinct S=64,A=8 tasks, "
+                     "%d vector steps in %.1f s" % (cores, n_env, n_env, k, dt)}
+    # secondary line: the reference's own execution style — one env per Python object, one
+    # step() per call, NumPy global RNG — on ONE core, same task shape, bounded to a few seconds
+    try:
+        from oracle import py_ref_style
+        sub = {kk: (v[:64] if hasattr(v, "shape") else v) for kk, v in tab.items()}
+        v, n_py = py_ref_style.time_python_loop(sub, min(3.0, seconds))
+        out["python_loop"] = {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "port",
+                              "sample": "oracle/py_ref_style.py: %d env objects stepped one by one (the reference's "
+                                        "style), S=64,A=8, one core" % n_py}
+    except Exception as ex:   # never lose the bench line to the secondary baseline
+        out["python_loop"] = {"error": repr(ex)}
+    return out
 
 
 def pmc_traffic(n_env, n_task, search):
