@@ -463,9 +463,8 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
       a_raw[4 * q] = v.x; a_raw[4 * q + 1] = v.y; a_raw[4 * q + 2] = v.z; a_raw[4 * q + 3] = v.w;
     }
   }
-  int init_idx;
-  if (INJECT) init_idx = io.init_index[e];
-  else init_idx = linds_draw_init(P, gid, n_init);
+  int init_idx = 0;
+  if (INJECT) init_idx = io.init_index[e];   // free-running: drawn below, only in waves that restart an env
 
   // ---- all operand fragments first: every load of the step is in flight before the first MFMA ----
   const float* phiT = P.T.phiT + (size_t)t * NS * NS;
@@ -569,6 +568,7 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
     if (done && mode == XV_AUTORESET_NEXT_STEP) nr = 1;
   }
   if (__ballot(do_reset) != 0ull) {   // wave-uniform: one more observation product for the restarted envs
+    if (!INJECT) init_idx = linds_draw_init(P, gid, n_init);
     const int idx = init_idx < 0 ? 0 : (init_idx >= n_init ? n_init - 1 : init_idx);
     const float* x0 = P.T.init + ((size_t)t * P.NI + idx) * NS;
     xv_f32x16 xr = xn;
