@@ -123,3 +123,20 @@ def test_acceptance_rule_agrees_with_reference_when_available():
         assert np.max(np.abs(q - q_ref)) < 5e-3 * (1 + np.abs(q_ref).max())
     mine = AnyMDPTaskSampler(16, 4, seed=11)
     assert check_valuefunction(mine)                  # and a task sampled here passes the reference's own test
+
+
+def test_sample_batch_returns_stacked_tables():
+    """every sampler module has sample_batch(n, **kw) -> one dict of stacked arrays, which
+    set_task accepts as it is; task k equals the k-th individually sampled task"""
+    from xenoverse_amd.anymdp import task_sampler as a_ts
+    from xenoverse_amd.anymdp.tables import build_tables as a_build, row_lines
+    from xenoverse_amd.linds import task_sampler as l_ts
+    from xenoverse_amd.mazeworld import task_sampler as m_ts
+    b = a_ts.sample_batch(3, seed=5, state_space=16, action_space=4)
+    assert b["rows"].shape == (3, 16, 4, row_lines(16), 16) and b["state_map"].shape == (3, 16)
+    one = a_build([a_ts.AnyMDPTaskSampler(16, 4, seed=6)])
+    assert np.array_equal(b["rows"][1], one["rows"][0]) and np.array_equal(b["max_steps"][1:2], one["max_steps"])
+    lb = l_ts.sample_batch(2, seed=1, state_dim=16, action_dim=8, observation_dim=8)
+    assert lb["phiT"].shape[0] == 2 and lb["NS"] == 16
+    mb = m_ts.sample_batch(2, seed=3, n_range=(9, 10))
+    assert mb["walls"].shape[0] == 2 and mb["walls"].shape[1:] == (9, 9)

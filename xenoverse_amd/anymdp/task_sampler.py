@@ -286,3 +286,12 @@ def MultiTokensAnyPOMDPTaskSampler(state_space=256, action_space=5, min_state_sp
     task["observation_transition"] = [_obs_matrix(rng, task["state_mapping"].shape[0], observation_space, density,
                                                   maximum_distribution) for _ in range(observation_tokens)]
     return task
+
+
+def sample_batch(n, sampler=None, seed=None, **kwargs):
+    """n tasks from `sampler` (default AnyMDPTaskSampler; task k uses seed + k) as ONE dict of stacked arrays — the
+    struct-of-arrays tables `AnyMDPVecEnv.set_task` uploads as they are (anymdp.tables.build_tables)."""
+    from .tables import build_tables
+    sampler = AnyMDPTaskSampler if sampler is None else sampler
+    base = np.random.SeedSequence(seed).generate_state(1)[0] if seed is None else int(seed)
+    return build_tables([sampler(seed=base + k, **kwargs) for k in range(n)])

@@ -124,3 +124,15 @@ def LinearDSSamplerRandomDim(max_state_dim=16, max_observation_dim=16, max_actio
     action_dim = int(rng.randint(min_action_dim, max_action_dim + 1))
     observation_dim = int(rng.randint(min_observation_dim, max_observation_dim + 1))
     return LinearDSSampler(state_dim, action_dim, observation_dim, seed=None if seed is None else seed + 1)
+
+
+def sample_batch(n, sampler=None, seed=None, dt=0.1, pad_observation_dim=16, pad_action_dim=8, pad_command_dim=16,
+                 **kwargs):
+    """n tasks from `sampler` (default LinearDSSampler; task k uses seed + k) as ONE dict of stacked arrays — the
+    tables `LinDSVecEnv.set_task` uploads as they are (linds.tables.build_tables, ZOH-discretised on the host)."""
+    from .tables import build_tables
+    sampler = LinearDSSampler if sampler is None else sampler
+    base = np.random.SeedSequence(seed).generate_state(1)[0] if seed is None else int(seed)
+    return build_tables([sampler(seed=base + k, **kwargs) for k in range(n)], dt=dt,
+                        pad_observation_dim=pad_observation_dim, pad_action_dim=pad_action_dim,
+                        pad_command_dim=pad_command_dim)

@@ -136,3 +136,11 @@ def Resampler(task, resample_cmd=True, resample_start=True, resample_landmarks=F
     if resample_cmd:
         new["commands_sequence"] = _sample_cmds(rng, k, len(task["commands_sequence"]))
     return new
+
+
+def sample_batch(n, seed=None, **kwargs):
+    """n mazes from MazeTaskSampler (task k uses seed + k) as ONE dict of stacked arrays — the tables
+    `MazeWorldVecEnv.set_task` uploads as they are (mazeworld.tables.build_tables)."""
+    from .tables import build_tables
+    base = np.random.SeedSequence(seed).generate_state(1)[0] if seed is None else int(seed)
+    return build_tables([MazeTaskSampler(seed=base + k, **kwargs) for k in range(n)])
