@@ -138,14 +138,27 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dist = None
+    dist_note = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("XV_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+                probe = torch.ones(1, device="cuda:%d" % local)
+                dist.all_reduce(probe)                          # fail here, not inside the timed region
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group(backend)
+        except Exception as ex:   # keep the scaling measurement alive: barrier and MAX over ranks through gloo
+            dist_note = "RCCL unavailable (%r): gloo used for the barrier and the MAX over ranks, no all-gather" % (ex,)
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group("gloo")
+            except Exception as ex2:
+                sys.exit("bench.py: no usable torch.distributed backend: %r / %r" % (ex, ex2))
 
     from xenoverse_amd import _lib
     from xenoverse_amd.anymdp import AnyMDPVecEnv
@@ -170,9 +183,9 @@ def main():
 
     # exchange step: all-gather of each finished T-step rollout chunk (14-B records) over RCCL,
     # on a side stream so that it overlaps the next chunk's stepping.  Stepping itself needs no collective.
-    do_gather = world > 1 and not args.no_allgather
+    do_gather = world > 1 and not args.no_allgather and dist_note is None
     gather = None
-    gather_note = "none"
+    gather_note = dist_note or "none"
     if do_gather:
         try:
             from xenoverse_amd.distributed import REC_BYTES, RolloutGather, pack_records
