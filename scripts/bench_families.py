@@ -121,6 +121,46 @@ def bench_acrobot(args):
                                  "VALU bound, not bandwidth bound"}}
 
 
+def bench_anymdp_tok(args):
+    """multi-token POMDP path (anymdp_env.py:116-128,148-157): d_act transition draws + d_obs observation draws per
+    step, per-lane binary searches.  65,536 envs, 1,024 synthetic tasks (S=64, A=8), n_obs=64, d_obs=2, d_act=2."""
+    import ctypes as C
+    from xenoverse_amd import _lib
+    from xenoverse_amd.anymdp import AnyMDPVecEnv, row_lines
+    from xenoverse_amd.engine import AUTORESET
+    n, n_task, S, A, n_obs, d_obs, d_act = 65536, 1024, 64, 8, 64, 2, 2
+    env = AnyMDPVecEnv(n, seed=1, autoreset_mode="same_step")
+    d = env.device
+    tab = dict(S=S, A=A, s0_max=4, rows=torch.empty((n_task, S, A, row_lines(S), 16), dtype=torch.float64, device=d),
+               state_map=torch.empty((n_task, S), dtype=torch.int32, device=d),
+               term_mask=torch.empty((n_task, 1), dtype=torch.int64, device=d),
+               s0_cdf=torch.empty((n_task, 4), dtype=torch.float64, device=d),
+               s0_ids=torch.empty((n_task, 4), dtype=torch.int32, device=d),
+               max_steps=torch.empty(n_task, dtype=torch.int32, device=d))
+    _lib.check(env.lib.xv_anymdp_synth_tasks(env.engine.handle, 7, 0, n_task, S, A, 4, *[_lib.ptr(tab[k]) for k in
+               ("rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")]))
+    env.set_task(tab)
+    w = torch.rand((n_task, d_obs, S, n_obs), dtype=torch.float64, device=d) + 0.05
+    obs_cdf = torch.cumsum(w, -1)
+    obs_cdf = (obs_cdf / obs_cdf[..., -1:]).contiguous()
+    obs_cdf[..., -1] = 1.0
+    _lib.check(env.lib.xv_anymdp_set_observation_model(env._h, n_obs, d_obs, d_act, _lib.ptr(obs_cdf)))
+    tobs = torch.zeros((n, d_obs), dtype=torch.int32, device=d)
+    tfobs = torch.zeros((n, d_obs), dtype=torch.int32, device=d)
+    _lib.check(env.lib.xv_anymdp_reset_tokens(env._h, None, _lib.ptr(tobs)))
+    a = torch.randint(0, A, (n, d_act), device=d, dtype=torch.int32)
+
+    def step():
+        _lib.check(env.lib.xv_anymdp_step_tokens(env._h, _lib.ptr(a), _lib.ptr(tobs), _lib.ptr(env._reward),
+                                                 _lib.ptr(env._reward_gt), _lib.ptr(env._term), _lib.ptr(env._trunc),
+                                                 _lib.ptr(tfobs), AUTORESET["same_step"]))
+    us = timed(step, args.steps, args.warmup)
+    env.close()
+    return {"family": "anymdp multi-token POMDP", "workload": "65,536 envs, 1,024 tasks, S=64 A=8 n_obs=64 d_obs=2 d_act=2",
+            "dtype": "f64", "env_steps_per_s": n / (us * 1e-6), "us_per_step": us,
+            "note": "per-lane binary searches (general path); 2 transition + 2 observation draws per env-step"}
+
+
 def bench_mixed(args):
     """BASELINE.json config 5, the per-GPU share: 16,384 anymdp (2b: 256 tasks x 64) + 8,192 linds (128 tasks x 64)
     + 8,192 cartpole, one launch per family per vector step, families on separate HIP streams (xenoverse_amd.mixed)
@@ -252,6 +292,8 @@ if __name__ == "__main__":
             r = bench_acrobot(args)
         elif f == "mixed":
             r = bench_mixed(args)
+        elif f == "anymdp_tok":
+            r = bench_anymdp_tok(args)
         elif f.startswith("maze"):
             r = bench_maze(args, int(f[4:]))
         else:
