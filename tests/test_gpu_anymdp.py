@@ -501,3 +501,61 @@ def test_teacher_rollout_on_device():
     rnd = float(env.rollout_teacher(200, greedy, 1.0)["reward_gt"].mean())
     assert opt > rnd
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# adversarial CDF rows: plateaus (zero-probability states) across block boundaries, all mass on the first / last
+# state, u exactly on / one ulp around every stored entry.  Expected: numpy.searchsorted(cdf, u, 'right').
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("search", ["fence", "binary"])
+@pytest.mark.parametrize("S", [7, 8, 20, 64])
+def test_adversarial_rows_match_searchsorted(S, search):
+    rng = np.random.RandomState(S)
+    A = 2
+    pdfs = []
+    e0 = np.zeros(S); e0[0] = 1.0; pdfs.append(e0)                       # everything on the first state
+    eL = np.zeros(S); eL[S - 1] = 1.0; pdfs.append(eL)                   # ... on the last
+    pdfs.append(np.full(S, 1.0 / S))
+    for lo, hi in ((5, 9), (6, 7), (0, 6), (S - 3, S), (13, 15)):       # plateaus straddling 7-entry block edges
+        p = rng.random_sample(S) + 0.01
+        p[max(0, min(lo, S - 1)):min(hi, S)] = 0.0
+        if p.sum() == 0:
+            p[0] = 1.0
+        pdfs.append(p / p.sum())
+    p = np.zeros(S); p[::max(1, S // 3)] = 1.0; pdfs.append(p / p.sum())  # three spikes
+    while len(pdfs) < S * A:
+        p = rng.random_sample(S) * (rng.random_sample(S) < 0.3)
+        if p.sum() == 0:
+            p[rng.randint(S)] = 1.0
+        pdfs.append(p / p.sum())
+    T = np.array(pdfs[:S * A]).reshape(S, A, S)
+    cdf = np.cumsum(T, -1)
+    cdf = cdf / cdf[..., -1:]
+    rs = rng.standard_normal((1, S, A, S, 2)).astype(np.float32)
+    tab = dict(S=S, A=A, s0_max=1, cdf=cdf[None], rs=rs, state_map=rng.permutation(S).astype(np.int32)[None],
+               term_mask=np.zeros((1, 1), np.uint64), s0_cdf=np.ones((1, 1)), s0_ids=np.zeros((1, 1), np.int32),
+               max_steps=np.array([10 ** 6], np.int32))
+    # every (row, probe): u on each stored entry, one ulp below / above, 0, tiny, just below 1
+    probes, rows_sa = [], []
+    for s in range(S):
+        for a in range(A):
+            c = cdf[s, a]
+            us = np.concatenate([c, np.nextafter(c, 0.0), np.nextafter(c, 2.0), [0.0, 5e-324, 1e-300, 0.5]])
+            us = us[(us >= 0.0) & (us < 1.0)]
+            probes.append(us); rows_sa.append(np.tile([[s, a]], (len(us), 1)))
+    u = np.concatenate(probes)
+    sa = np.concatenate(rows_sa)
+    n = len(u)
+    env = AnyMDPVecEnv(n, autoreset_mode="disabled")
+    env.set_task(_dev_tables(tab), env_task_index=np.zeros(n, np.int32))
+    env.set_search(search)
+    env.reset_injected(np.zeros(n))
+    env.set_state(inner_state=sa[:, 0].astype(np.int32))
+    obs, r, term, trunc, info = env.step_injected(sa[:, 1].astype(np.int32), u, np.zeros(n, np.float32), np.zeros(n))
+    exp = np.array([min(int(np.searchsorted(cdf[s, a], uu, side="right")), S - 1) for (s, a), uu in zip(sa, u)])
+    got = _np(env.inner_state)
+    assert np.array_equal(got, exp)
+    assert np.array_equal(_np(obs), tab["state_map"][0][exp])
+    assert np.array_equal(_np(info["reward_gt"]), rs[0, sa[:, 0], sa[:, 1], exp, 0])
+    assert env.check_errors() == 0
+    env.close()
