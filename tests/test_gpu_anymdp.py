@@ -559,3 +559,33 @@ def test_adversarial_rows_match_searchsorted(S, search):
     assert np.array_equal(_np(info["reward_gt"]), rs[0, sa[:, 0], sa[:, 1], exp, 0])
     assert env.check_errors() == 0
     env.close()
+
+
+def test_copy_false_returns_views_of_alternating_output_sets():
+    """copy=False: same values as copy=True; what a step returned stays intact through the next step and is
+    overwritten by the one after (two output sets used alternately)"""
+    tab = oracle.anymdp_synth(seed=3, task_index_base=0, n_task=4, S=64, A=8, s0_max=4)
+    n = 256
+    outs = {}
+    for copy in (True, False):
+        env = AnyMDPVecEnv(n, seed=9, autoreset_mode="same_step", copy=copy)
+        env.set_task(_dev_tables(tab))
+        env.reset()
+        rng = np.random.RandomState(0)
+        rec, kept = [], []
+        for t in range(12):
+            o = env.step(rng.randint(0, 8, n).astype(np.int32))
+            rec.append([_np(o[0]), _np(o[1]), _np(o[2]), _np(o[3]), _np(o[4]["steps"]), _np(o[4]["reward_gt"]),
+                        _np(o[4]["final_obs"]), _np(o[4]["_final_obs"])])
+            kept.append(o)
+            if t >= 1:      # the previous step's tensors are still what they were
+                prev = kept[t - 1]
+                assert np.array_equal(_np(prev[0]), rec[t - 1][0]) and np.array_equal(_np(prev[1]), rec[t - 1][1])
+            if t >= 2 and not copy:
+                assert kept[t - 2][0].data_ptr() == o[0].data_ptr()          # the set is reused two steps later
+        assert o[2].dtype == torch.bool and o[4]["_final_obs"].dtype == torch.bool
+        outs[copy] = rec
+        env.close()
+    for a, b in zip(outs[True], outs[False]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)

@@ -22,13 +22,20 @@ _TABLE_DTYPES = dict(rows=torch.float64, state_map=torch.int32, term_mask=torch.
 
 class AnyMDPVecEnv(VectorEnv):
     def __init__(self, num_envs, max_steps=5000, device="cuda:0", seed=0, env_id_base=0,
-                 autoreset_mode="same_step", to_numpy=False, engine=None, with_transition_gt=False):
+                 autoreset_mode="same_step", to_numpy=False, engine=None, with_transition_gt=False, copy=True):
         """`max_steps` is kept for signature parity with AnyMDPEnv(max_steps); as in the reference it is
-        overridden by each task's own `max_steps` at set_task (anymdp_env.py:23-34)."""
+        overridden by each task's own `max_steps` at set_task (anymdp_env.py:23-34).
+
+        copy (as gymnasium's SyncVectorEnv(copy=...)): True returns fresh tensors from every step().  False returns
+        views of two engine-owned output sets used alternately — what step() returned stays valid until the step
+        after the next one — and takes the per-step host cost from ~50 us (clones, bool conversions) to a launch, a
+        16-KB copy and one fused op (`scripts/bench_python_step.py`)."""
         super().__init__(num_envs, device=device, seed=seed, env_id_base=env_id_base,
                          autoreset_mode=autoreset_mode, to_numpy=to_numpy, engine=engine)
         self.max_steps = max_steps
         self.with_transition_gt = bool(with_transition_gt)
+        self.copy = bool(copy)
+        self._ring = None
         self._set_spaces(Discrete(1), Discrete(1))   # placeholders until set_task, as in the reference
         self._h = None
         self._tab = None
@@ -117,6 +124,20 @@ class AnyMDPVecEnv(VectorEnv):
         self._final_obs = torch.full((n,), -1, dtype=torch.int32, device=d)
         self._steps = torch.zeros(n, dtype=torch.int32, device=d)
         self._tgt = torch.zeros((n, S), dtype=torch.float64, device=d) if self.with_transition_gt else None
+        self._ring = None
+        if (not self.copy) and (not self.to_numpy) and self._tok is None and not self.with_transition_gt:
+            self._ring, self._ring_pos = [], 0
+            for _ in range(2):
+                b = dict(obs=torch.zeros(n, dtype=torch.int32, device=d), reward=torch.zeros(n, dtype=torch.float32, device=d),
+                         reward_gt=torch.zeros(n, dtype=torch.float32, device=d),
+                         term=torch.zeros(n, dtype=torch.uint8, device=d), trunc=torch.zeros(n, dtype=torch.uint8, device=d),
+                         final_obs=torch.full((n,), -1, dtype=torch.int32, device=d),
+                         steps=torch.zeros(n, dtype=torch.int32, device=d), done=torch.zeros(n, dtype=torch.uint8, device=d))
+                b["term_b"], b["trunc_b"], b["done_b"] = (b[k].view(torch.bool) for k in ("term", "trunc", "done"))
+                b["args"] = tuple(C.c_void_p(b[k].data_ptr()) for k in
+                                  ("obs", "reward", "reward_gt", "term", "trunc", "final_obs"))
+                b["steps_p"] = C.c_void_p(b["steps"].data_ptr())
+                self._ring.append(b)
         self.task_set = True
         self.need_reset = True
 
@@ -224,6 +245,18 @@ class AnyMDPVecEnv(VectorEnv):
         a = self._dev(actions, torch.int32)
         if a.shape != (self.num_envs,):
             raise AssertionError(f"Action {tuple(a.shape)} is out of range")
+        if self._ring is not None:      # copy=False: outputs are views of the output set this step writes
+            b = self._ring[self._ring_pos]
+            self._ring_pos ^= 1
+            lib, mode = self.lib, AUTORESET[self.autoreset_mode]
+            _lib.check(lib.xv_anymdp_step(self._h, C.c_void_p(a.data_ptr()), *b["args"], mode))
+            _lib.check(lib.xv_anymdp_get_state(self._h, None, b["steps_p"], None))
+            infos = {"steps": b["steps"], "reward_gt": b["reward_gt"]}
+            if mode == 2:
+                torch.bitwise_or(b["term"], b["trunc"], out=b["done"])
+                infos["final_obs"] = b["final_obs"]
+                infos["_final_obs"] = b["done_b"]
+            return b["obs"], b["reward"], b["term_b"], b["trunc_b"], infos
         _lib.check(self.lib.xv_anymdp_step(
             self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward), _lib.ptr(self._reward_gt),
             _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._final_obs),
