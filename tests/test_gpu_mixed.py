@@ -86,3 +86,43 @@ def test_rank_shards_reproduce_the_unsharded_batch():
             lo, hi = shard_range(n, r, 2)
             assert np.array_equal(full[k][0][:, lo:hi], part[k][0]), (k, r)
             assert np.array_equal(full[k][1][:, lo:hi], part[k][1]), (k, r)
+
+
+@pytest.mark.parametrize("family", ["linds", "cartpole", "acrobot", "maze"])
+def test_copy_false_gives_the_same_values(family):
+    """copy=False returns views of the engine-owned output buffers (no per-step device copies): same values"""
+    from xenoverse_amd.metacontrol import AcrobotVecEnv, sample_acrobot
+    from xenoverse_amd.mazeworld import MazeTaskSampler, MazeWorldVecEnv, make_texture_library
+    rng = np.random.RandomState(0)
+    recs = []
+    for copy in (True, False):
+        if family == "linds":
+            env = LinDSVecEnv(128, seed=4, copy=copy)
+            env.set_task([LinearDSSampler(16, 8, 8, seed=k) for k in range(2)])
+            acts = rng.uniform(-1, 1, (6, 128, 8)).astype(np.float32) if copy else acts
+        elif family == "cartpole":
+            env = CartPoleVecEnv(128, seed=4, frameskip=1, copy=copy)
+            env.set_task([sample_cartpole(seed=k) for k in range(4)])
+            acts = rng.randint(0, 2, (6, 128)).astype(np.int32) if copy else acts
+        elif family == "acrobot":
+            env = AcrobotVecEnv(128, seed=4, frameskip=1, copy=copy)
+            env.set_task([sample_acrobot(seed=k) for k in range(4)])
+            acts = rng.randint(0, 3, (6, 128)).astype(np.int32) if copy else acts
+        else:
+            env = MazeWorldVecEnv(16, seed=4, resolution=(32, 32), textures=make_texture_library(8, 4, 4, seed=0),
+                                  max_steps=4, copy=copy)
+            env.set_task([MazeTaskSampler(n_range=(9, 10), seed=k, n_wall_textures=8, n_ground_textures=4,
+                                          n_ceiling_textures=4) for k in range(2)])
+            acts = rng.randint(0, 16, (6, 16)).astype(np.int32) if copy else acts
+        obs, info = env.reset()
+        rec = [obs.detach().cpu().numpy().copy()]
+        for t in range(6):
+            o = env.step(acts[t])
+            rec += [o[k].detach().cpu().numpy().copy() for k in range(4)]
+            rec += [v.detach().cpu().numpy().copy() for k, v in sorted(o[4].items())]
+            assert o[2].dtype == torch.bool
+        recs.append(rec)
+        env.close()
+    assert len(recs[0]) == len(recs[1])
+    for a, b in zip(*recs):
+        assert np.array_equal(a, b)

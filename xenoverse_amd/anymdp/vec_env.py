@@ -31,7 +31,7 @@ class AnyMDPVecEnv(VectorEnv):
         after the next one — and takes the per-step host cost from ~50 us (clones, bool conversions) to a launch, a
         16-KB copy and one fused op (`scripts/bench_python_step.py`)."""
         super().__init__(num_envs, device=device, seed=seed, env_id_base=env_id_base,
-                         autoreset_mode=autoreset_mode, to_numpy=to_numpy, engine=engine)
+                         autoreset_mode=autoreset_mode, to_numpy=to_numpy, engine=engine, copy=copy)
         self.max_steps = max_steps
         self.with_transition_gt = bool(with_transition_gt)
         self.copy = bool(copy)

@@ -59,9 +59,9 @@ def pad_tables(tab):
 class LinDSVecEnv(VectorEnv):
     def __init__(self, num_envs, dt=0.1, max_steps=1000, pad_observation_dim=16, pad_command_dim=16,
                  pad_action_dim=8, device="cuda:0", seed=0, env_id_base=0, autoreset_mode="same_step",
-                 to_numpy=False, engine=None):
+                 to_numpy=False, engine=None, copy=True):
         super().__init__(num_envs, device=device, seed=seed, env_id_base=env_id_base,
-                         autoreset_mode=autoreset_mode, to_numpy=to_numpy, engine=engine)
+                         autoreset_mode=autoreset_mode, to_numpy=to_numpy, engine=engine, copy=copy)
         self.dt = dt
         self.max_steps = max_steps
         self.pad_observation_dim = pad_observation_dim
@@ -158,10 +158,10 @@ class LinDSVecEnv(VectorEnv):
         return self._steps.clone()
 
     def _infos(self, with_final):
-        infos = {"steps": self._out(self._steps_now()), "command": self._out(self._user_obs(self._cmd).clone()),
-                 "error": self._out(self._error.clone())}
+        infos = {"steps": self._out(self._steps_now()), "command": self._o(self._user_obs(self._cmd)),
+                 "error": self._o(self._error)}
         if with_final and self.autoreset_mode == "same_step":
-            infos["final_obs"] = self._out(self._user_obs(self._fobs).clone())
+            infos["final_obs"] = self._o(self._user_obs(self._fobs))
             infos["_final_obs"] = self._out((self._term | self._trunc).bool())
         return infos
 
@@ -179,7 +179,7 @@ class LinDSVecEnv(VectorEnv):
         infos = self._infos(False)
         if self._command_type is not None:
             infos["command_type"] = self._command_type[self._tab["env_task"].cpu().numpy()]
-        return self._out(self._user_obs(self._obs).clone()), infos
+        return self._o(self._user_obs(self._obs)), infos
 
     def reset_injected(self, init_index, mask=None):
         self._require_task()
@@ -188,15 +188,15 @@ class LinDSVecEnv(VectorEnv):
         _lib.check(self.lib.xv_linds_reset_injected(self._h, _lib.ptr(m), _lib.ptr(idx), _lib.ptr(self._obs),
                                                     _lib.ptr(self._cmd), _lib.ptr(self._error)))
         self.need_reset = False
-        return self._out(self._user_obs(self._obs).clone()), self._infos(False)
+        return self._o(self._user_obs(self._obs)), self._infos(False)
 
     def _check_step(self):
         if (not self.task_set) or self.need_reset:
             raise Exception("Must \"set_task\" and \"reset\" before doing any actions")   # linds_env.py:134-135
 
     def _ret(self):
-        return (self._out(self._user_obs(self._obs).clone()), self._out(self._reward.clone()),
-                self._out(self._term.bool()), self._out(self._trunc.bool()), self._infos(True))
+        return (self._o(self._user_obs(self._obs)), self._o(self._reward),
+                self._ob(self._term), self._ob(self._trunc), self._infos(True))
 
     def step(self, actions):
         self._check_step()

@@ -30,13 +30,13 @@ class MazeWorldVecEnv(VectorEnv):
     def __init__(self, num_envs, enable_render=False, render_scale=480, max_steps=5000, resolution=(320, 320),
                  visibility_3D=12.0, command_in_observation=False, action_space_type="Discrete16",
                  collision_dist=0.20, textures=None, device="cuda:0", seed=0, env_id_base=0,
-                 autoreset_mode="same_step", to_numpy=False, engine=None, with_final_obs=False):
+                 autoreset_mode="same_step", to_numpy=False, engine=None, copy=True, with_final_obs=False):
         """Constructor arguments as MazeWorldContinuous3D (maze_env.py:110-118); the registered id `mazeworld-v2`
         uses resolution (256, 256), max_steps 5000, visibility_3D 12.0, Discrete16 (mazeworld/__init__.py:19-33).
         `textures`: dict(walls, grounds, ceilings) of float32 [n,256,256,3] arrays; default = the procedural
         library (the reference's JPG assets are not redistributed)."""
         super().__init__(num_envs, device=device, seed=seed, env_id_base=env_id_base,
-                         autoreset_mode=autoreset_mode, to_numpy=to_numpy, engine=engine)
+                         autoreset_mode=autoreset_mode, to_numpy=to_numpy, engine=engine, copy=copy)
         if enable_render:
             raise NotImplementedError("pygame rendering is out of scope of the GPU engine (use the frames)")
         if action_space_type not in self.ACTION_MODES:
@@ -121,8 +121,8 @@ class MazeWorldVecEnv(VectorEnv):
             mask = self._dev(options["reset_mask"], torch.uint8)
         _lib.check(self.lib.xv_maze_reset(self._h, _lib.ptr(mask), _lib.ptr(self._frames), _lib.ptr(self._cmd_rgb)))
         self.need_reset = False
-        return self._out(self._frames.clone()), {"steps": self._out(self._steps_now()),
-                                                  "command": self._out(self._cmd_rgb.clone())}
+        return self._o(self._frames), {"steps": self._out(self._steps_now()),
+                                                  "command": self._o(self._cmd_rgb)}
 
     def step(self, actions):
         if self.need_reset:
@@ -139,17 +139,17 @@ class MazeWorldVecEnv(VectorEnv):
         _lib.check(self.lib.xv_maze_step(self._h, _lib.ptr(a), mode, _lib.ptr(self._frames), _lib.ptr(self._reward),
                                          _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._cmd_rgb),
                                          _lib.ptr(self._final), AUTORESET[self.autoreset_mode]))
-        infos = {"steps": self._out(steps_before), "command": self._out(self._cmd_rgb.clone())}
+        infos = {"steps": self._out(steps_before), "command": self._o(self._cmd_rgb)}
         if self.with_final_obs and self.autoreset_mode == "same_step":
-            infos["final_obs"] = self._out(self._final.clone())
+            infos["final_obs"] = self._o(self._final)
             infos["_final_obs"] = self._out((self._term | self._trunc).bool())
-        return (self._out(self._frames.clone()), self._out(self._reward.clone()), self._out(self._term.bool()),
-                self._out(self._trunc.bool()), infos)
+        return (self._o(self._frames), self._o(self._reward), self._ob(self._term),
+                self._ob(self._trunc), infos)
 
     def render_frames(self):
         """frames of the current state, without stepping"""
         _lib.check(self.lib.xv_maze_render(self._h, _lib.ptr(self._frames), _lib.ptr(self._cmd_rgb)))
-        return self._out(self._frames.clone())
+        return self._o(self._frames)
 
     def get_state(self):
         n, d = self.num_envs, self.device

@@ -39,9 +39,9 @@ def sample_cartpole(gravity_scope=True, masscart_scope=True, masspole_scope=True
 class CartPoleVecEnv(VectorEnv):
     def __init__(self, num_envs, frameskip=5, reset_bounds_scale=(0.45, 0.90, 0.13, 1.0), max_steps=0,
                  device="cuda:0", seed=0, env_id_base=0, autoreset_mode="same_step", to_numpy=False,
-                 engine=None):
+                 engine=None, copy=True):
         super().__init__(num_envs, device=device, seed=seed, env_id_base=env_id_base,
-                         autoreset_mode=autoreset_mode, to_numpy=to_numpy, engine=engine)
+                         autoreset_mode=autoreset_mode, to_numpy=to_numpy, engine=engine, copy=copy)
         self.frameskip = int(frameskip)
         rs = list(reset_bounds_scale)
         assert len(rs) == 4, "reset_bounds_scale should be a list of 4 elements"
@@ -91,7 +91,7 @@ class CartPoleVecEnv(VectorEnv):
             mask = self._dev(options["reset_mask"], torch.uint8)
         _lib.check(self.lib.xv_cartpole_reset(self._h, _lib.ptr(mask), _lib.ptr(self._obs)))
         self.need_reset = False
-        return self._out(self._obs.clone()), {}
+        return self._o(self._obs), {}
 
     def reset_injected(self, u, mask=None):
         self._require_task()
@@ -99,15 +99,15 @@ class CartPoleVecEnv(VectorEnv):
         m = None if mask is None else self._dev(mask, torch.uint8)
         _lib.check(self.lib.xv_cartpole_reset_injected(self._h, _lib.ptr(m), _lib.ptr(u), _lib.ptr(self._obs)))
         self.need_reset = False
-        return self._out(self._obs.clone())
+        return self._o(self._obs)
 
     def _ret(self):
         infos = {}
         if self.autoreset_mode == "same_step":
-            infos["final_obs"] = self._out(self._fobs.clone())
+            infos["final_obs"] = self._o(self._fobs)
             infos["_final_obs"] = self._out((self._term | self._trunc).bool())
-        return (self._out(self._obs.clone()), self._out(self._reward.clone()), self._out(self._term.bool()),
-                self._out(self._trunc.bool()), infos)
+        return (self._o(self._obs), self._o(self._reward), self._ob(self._term),
+                self._ob(self._trunc), infos)
 
     def step(self, actions):
         if (not self.task_set) or self.need_reset:

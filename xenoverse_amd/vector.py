@@ -14,7 +14,7 @@ class VectorEnv(object):
     spec = None
 
     def __init__(self, num_envs, device="cuda:0", seed=0, env_id_base=0, autoreset_mode="same_step",
-                 to_numpy=False, engine=None):
+                 to_numpy=False, engine=None, copy=True):
         if autoreset_mode not in AUTORESET:
             raise ValueError("autoreset_mode must be one of %s" % sorted(AUTORESET))
         self.num_envs = int(num_envs)
@@ -25,6 +25,9 @@ class VectorEnv(object):
         self.autoreset_mode = autoreset_mode
         self.metadata = dict(type(self).metadata, autoreset_mode=autoreset_mode)
         self.to_numpy = bool(to_numpy)
+        # copy (as gymnasium's SyncVectorEnv(copy=...)): True returns fresh tensors from every call; False returns
+        # views of engine-owned output buffers, valid until the next step()/reset() (no per-step device copies)
+        self.copy = bool(copy)
         self.closed = False
         self.task_set = False
         self.single_observation_space = None
@@ -50,6 +53,14 @@ class VectorEnv(object):
 
     def _out(self, t):
         return t.cpu().numpy() if self.to_numpy else t
+
+    def _o(self, t):
+        """an output buffer -> what the caller receives (a copy unless copy=False)"""
+        return self._out(t.clone() if (self.copy and not self.to_numpy) else t)
+
+    def _ob(self, t):
+        """a uint8 0/1 flag buffer -> bool tensor (zero-copy view when copy=False)"""
+        return self._out(t.bool() if (self.copy or self.to_numpy) else t.view(torch.bool))
 
     def _require_task(self):
         if not self.task_set:
