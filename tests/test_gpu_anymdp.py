@@ -589,3 +589,41 @@ def test_copy_false_returns_views_of_alternating_output_sets():
     for a, b in zip(outs[True], outs[False]):
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("search", ["fence", "binary"])
+def test_step_many_graph_replay_equals_plain_launches(search):
+    """whole ring cycles of step_many are replayed from a hipGraph whose kernels read the launch tick from device
+    memory: identical to plain launches, also with a remainder, with ordinary steps in between (the device tick must
+    follow the engine's) and after switching to another set of ring buffers (graph rebuilt)"""
+    tab = oracle.anymdp_synth(seed=12, task_index_base=0, n_task=8, S=64, A=8, s0_max=4)
+    n, P = 512, 8
+    rng = np.random.RandomState(5)
+    acts = rng.randint(0, 8, (P, n)).astype(np.int32)
+    acts2 = rng.randint(0, 8, (P, n)).astype(np.int32)
+    single = rng.randint(0, 8, n).astype(np.int32)
+    res = []
+    for graph in (True, False):
+        env = AnyMDPVecEnv(n, seed=77, autoreset_mode="same_step")
+        env.set_task(_dev_tables(tab))
+        env.set_search(search)
+        env.set_step_many_graph(graph)
+        env.reset()
+        rec = []
+        ring = env.step_many(3 * P + 5, acts)                    # 3 cycles + remainder
+        rec.append({k: _np(v).copy() for k, v in ring.items()})
+        o = env.step(single)                                      # an ordinary step moves the engine tick
+        rec.append({"obs": _np(o[0]), "reward": _np(o[1])})
+        ring = env.step_many(2 * P, acts, out=ring)               # same arrays: cached graph, tick re-synchronised
+        rec.append({k: _np(v).copy() for k, v in ring.items()})
+        ring2 = env.step_many(P, acts2)                           # other arrays: graph rebuilt
+        rec.append({k: _np(v).copy() for k, v in ring2.items()})
+        s, st, _ = env.get_state()
+        rec.append({"state": _np(s), "steps": _np(st)})
+        assert env.check_errors() == 0
+        res.append(rec)
+        env.close()
+    for a, b in zip(*res):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+    assert res[0][0]["terminated"].sum() > 50

@@ -340,6 +340,10 @@ class AnyMDPVecEnv(VectorEnv):
             _lib.ptr(out.get("final_obs")), AUTORESET[self.autoreset_mode]))
         return out
 
+    def set_step_many_graph(self, enable):
+        """step_many replays whole ring cycles from a hipGraph (default) or issues plain launches; same results."""
+        _lib.check(self.lib.xv_anymdp_set_step_many_graph(self._h, 1 if enable else 0))
+
     # ---- accessors (anymdp_env.py:134-165) ----------------------------------------------------------
     def _get_steps(self):
         _lib.check(self.lib.xv_anymdp_get_state(self._h, None, _lib.ptr(self._steps), None))

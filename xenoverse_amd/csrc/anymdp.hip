@@ -53,6 +53,7 @@ struct AnyMDPArgs {
   uint32_t* err;
   int n_env, n_task, S, A, s0_max, words, NB, RL;   // RL = 1 + NB lines per row
   uint64_t seed, gid_base, tick;
+  const uint64_t* tick_dev;   // graph replay: the launch tick is *tick_dev + tick (tick = node index); else nullptr
 };
 
 struct AnyMDPStepIO {
@@ -79,7 +80,22 @@ struct xv_anymdp {
   bool fast;   // fence lines, block metadata and reset records are built
   const double* obs_cdf;   // observation model (POMDP / MTPOMDP), nullptr for MDP
   int n_obs, d_obs, d_act;
+  // xv_anymdp_step_many: one ring cycle (period launches + a tick update) as an instantiated hipGraph
+  bool graph_enabled, graph_failed;
+  hipGraph_t graph;
+  hipGraphExec_t graph_exec;
+  uint64_t* d_tick;          // device copy of the launch tick the graph's kernels read
+  uint64_t d_tick_value;     // what *d_tick holds once the stream has drained
+  bool d_tick_valid;
+  struct {
+    int period, mode, search, fast;
+    uint64_t seed, gid_base;
+    const void* ptrs[7];
+  } graph_key;
 };
+
+__global__ void anymdp_set_tick_kernel(uint64_t* t, uint64_t v) { *t = v; }
+__global__ void anymdp_advance_tick_kernel(uint64_t* t, uint64_t dv) { *t += dv; }
 
 __device__ __forceinline__ bool anymdp_is_term(const AnyMDPArgs& P, int t, uint64_t tm0, int s) {
   if (P.words == 1) return (tm0 >> s) & 1ull;
@@ -147,6 +163,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
     tm0 = P.term_mask[(size_t)t * P.words];
   }
 
+  const uint64_t tick0 = P.tick_dev ? *P.tick_dev + P.tick : P.tick;
   const int T = ROLLOUT ? T_steps : 1;   // single step: straight-line code, counted vmcnt waits
   for (int ts = 0; ts < T; ++ts) {
     const size_t o = (size_t)ts * P.n_env + ic;
@@ -159,10 +176,10 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       z = io.z[o];
       u_reset = io.u_reset[o];
     } else {
-      const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick + (uint64_t)ts, XV_DRAW_STEP);
+      const xv_u32x4 w = xv_env_draw(P.seed, gid, tick0 + (uint64_t)ts, XV_DRAW_STEP);
       u = xv_u53(w.x, w.y);
       z = xv_normal1(w.z, w.w);
-      const xv_u32x4 v = xv_env_draw(P.seed, gid, P.tick + (uint64_t)ts, XV_DRAW_RESET);
+      const xv_u32x4 v = xv_env_draw(P.seed, gid, tick0 + (uint64_t)ts, XV_DRAW_RESET);
       u_reset = xv_u53(v.x, v.y);
     }
 
@@ -170,7 +187,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
     if (io.greedy) {   // teacher policy: argmax_a Q[inner_state] (anymdp_solver_opt.py:38-51), epsilon-greedy
       a = io.greedy[(size_t)t * S + s];
       if (io.epsilon > 0.0f) {
-        const xv_u32x4 e = xv_env_draw(P.seed, gid, P.tick + (uint64_t)ts, 2u);
+        const xv_u32x4 e = xv_env_draw(P.seed, gid, tick0 + (uint64_t)ts, 2u);
         if ((float)(e.x >> 8) * (1.0f / 16777216.0f) < io.epsilon) a = (int)(e.y % (uint32_t)A);
       }
       if (valid) io.action_out[o] = a;
@@ -612,6 +629,9 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
   h->search = XV_ANYMDP_SEARCH_AUTO;
   h->fast = false;
   h->obs_cdf = nullptr; h->n_obs = 0; h->d_obs = 0; h->d_act = 0;
+  h->graph_enabled = true; h->graph_failed = false; h->graph = nullptr; h->graph_exec = nullptr;
+  h->d_tick = nullptr; h->d_tick_value = 0; h->d_tick_valid = false;
+  memset(&h->graph_key, 0, sizeof(h->graph_key));
   AnyMDPArgs& a = h->a;
   memset(&a, 0, sizeof(a));
   a.lines = (const uint4*)rows; a.state_map = state_map; a.term_mask = term_mask;
@@ -681,6 +701,9 @@ extern "C" int xv_anymdp_destroy(xv_anymdp* h) {
   void* ps[] = {a.state, a.steps, a.need_reset, a.cur_term, (void*)a.rs_c01, (void*)a.rs_c2, (void*)a.rs_ids,
                 (void*)a.rs_obs, (void*)a.rs_max_steps};
   for (void* q : ps) if (q) (void)hipFree(q);
+  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  if (h->graph) (void)hipGraphDestroy(h->graph);
+  if (h->d_tick) (void)hipFree(h->d_tick);
   delete h;
   return XV_OK;
 }
@@ -747,6 +770,68 @@ extern "C" int xv_anymdp_step_injected(xv_anymdp* h, const int32_t* action, cons
   return anymdp_launch_step<true>(h, io, 1, autoreset_mode);
 }
 
+// One ring cycle of xv_anymdp_step_many as a graph: `period` step-kernel nodes in a chain (node j reads actions slot j,
+// writes output slot j, draws with tick *d_tick + j) and a node that advances *d_tick by `period`.  Back-to-back
+// dependent launches cost ~3.3 us each on a stream and ~1.6 us as graph nodes (scripts/devtools/graph_floor.hip).
+static bool anymdp_ensure_graph(xv_anymdp* h, int period, const int32_t* actions, int32_t* obs, float* reward,
+                                float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
+  const bool fast = h->fast && h->search != XV_ANYMDP_SEARCH_BINARY;
+  const void* ptrs[7] = {actions, obs, reward, reward_gt, terminated, truncated, final_obs};
+  auto& K = h->graph_key;
+  if (h->graph_exec && K.period == period && K.mode == mode && K.search == h->search && K.fast == (int)fast &&
+      K.seed == h->eng->seed && K.gid_base == h->eng->env_id_base && memcmp(K.ptrs, ptrs, sizeof(ptrs)) == 0)
+    return true;
+  if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+  if (!h->d_tick && hipMalloc(&h->d_tick, sizeof(uint64_t)) != hipSuccess) return false;
+  if (hipGraphCreate(&h->graph, 0) != hipSuccess) return false;
+  const size_t n = (size_t)h->a.n_env;
+  const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
+  void* fn = fast ? reinterpret_cast<void*>(&anymdp_step_kernel<false, true, false>)
+                  : reinterpret_cast<void*>(&anymdp_step_kernel<false, false, false>);
+  hipGraphNode_t prev = nullptr;
+  for (int j = 0; j <= period; ++j) {
+    hipKernelNodeParams np;
+    memset(&np, 0, sizeof(np));
+    AnyMDPArgs a = h->a;
+    a.seed = h->eng->seed; a.gid_base = h->eng->env_id_base;
+    a.tick = (uint64_t)j; a.tick_dev = h->d_tick;
+    const size_t off = (size_t)j * n;
+    AnyMDPStepIO io{actions + off, nullptr, nullptr, nullptr, obs + off, reward + off, reward_gt + off, terminated + off,
+                    truncated + off, final_obs ? final_obs + off : nullptr, nullptr, nullptr, 0.0f};
+    int T = 1, md = mode;
+    uint64_t dv = (uint64_t)period;
+    void* step_params[] = {&a, &io, &T, &md};
+    void* tick_params[] = {&h->d_tick, &dv};
+    if (j < period) {
+      np.func = fn; np.gridDim = grid; np.blockDim = block; np.kernelParams = step_params;
+    } else {
+      np.func = reinterpret_cast<void*>(&anymdp_advance_tick_kernel); np.gridDim = dim3(1); np.blockDim = dim3(1);
+      np.kernelParams = tick_params;
+    }
+    hipGraphNode_t node;
+    if (hipGraphAddKernelNode(&node, h->graph, prev ? &prev : nullptr, prev ? 1 : 0, &np) != hipSuccess) return false;
+    prev = node;
+  }
+  if (hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0) != hipSuccess) { h->graph_exec = nullptr; return false; }
+  K.period = period; K.mode = mode; K.search = h->search; K.fast = (int)fast;
+  K.seed = h->eng->seed; K.gid_base = h->eng->env_id_base;
+  memcpy(K.ptrs, ptrs, sizeof(ptrs));
+  return true;
+}
+
+extern "C" int xv_anymdp_set_step_many_graph(xv_anymdp* h, int enable) {
+  XV_CHECK_ARG(h != nullptr);
+  h->graph_enabled = enable != 0;
+  return XV_OK;
+}
+
+extern "C" int xv_anymdp_step_many_graph_state(xv_anymdp* h) {   // 0 plain launches, 1 graph built and in use, -1 failed
+  if (!h) return 0;
+  if (h->graph_failed) return -1;
+  return (h->graph_enabled && h->graph_exec) ? 1 : 0;
+}
+
 extern "C" int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const int32_t* actions,
                                    int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated,
                                    uint8_t* truncated, int32_t* final_obs, int autoreset_mode) {
@@ -754,7 +839,32 @@ extern "C" int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const 
   XV_CHECK_ARG(actions && obs && reward && reward_gt && terminated && truncated);
   XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
   const size_t n = (size_t)h->a.n_env;
-  for (int k = 0; k < n_steps; ++k) {
+  int k = 0;
+  // whole ring cycles: replay the graph
+  const int cycles = n_steps / period;
+  if (cycles > 0 && period > 1 && h->graph_enabled && !h->graph_failed) {
+    bool ok = anymdp_ensure_graph(h, period, actions, obs, reward, reward_gt, terminated, truncated, final_obs,
+                                  autoreset_mode);
+    if (ok && !(h->d_tick_valid && h->d_tick_value == h->eng->tick)) {
+      hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, h->eng->stream, h->d_tick, h->eng->tick);
+      ok = hipGetLastError() == hipSuccess;
+    }
+    for (int c = 0; ok && c < cycles; ++c) {
+      ok = hipGraphLaunch(h->graph_exec, h->eng->stream) == hipSuccess;
+      if (ok) {
+        h->eng->tick += (uint64_t)period;
+        h->d_tick_value = h->eng->tick;
+        h->d_tick_valid = true;
+        k += period;
+      }
+    }
+    if (!ok) {   // same kernels, plain launches; never retried on this handle
+      (void)hipGetLastError();
+      h->graph_failed = true;
+      h->d_tick_valid = false;
+    }
+  }
+  for (; k < n_steps; ++k) {
     const size_t off = (size_t)(k % period) * n;
     anymdp_bind_rng(h, 1);
     AnyMDPStepIO io{actions + off, nullptr, nullptr, nullptr, obs + off, reward + off, reward_gt + off,
