@@ -42,6 +42,8 @@ def parse():
                     help="N>1: skip the RCCL all-gather of rollout chunks (pure replicas)")
     ap.add_argument("--search", default="auto", choices=["auto", "binary", "fence"])
     ap.add_argument("--fused", action="store_true", help="also time the fused T-step rollout kernel")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="xv_anymdp_step_many: replay ring cycles from a hipGraph (auto: only for small batches)")
     return ap.parse_args()
 
 
@@ -173,6 +175,7 @@ def main():
     env_task = (torch.arange(n_env, device=env.device, dtype=torch.int32) // per).contiguous()
     env.set_task(tab, env_task_index=env_task)
     env.set_search(args.search)
+    env.set_step_many_graph(args.graph)
     search = {"auto": "fence"}.get(args.search, args.search)
     P = args.period
     g = torch.Generator(device=env.device)

@@ -152,11 +152,12 @@ int xv_anymdp_step_injected(xv_anymdp* h, const int32_t* action, const double* u
 int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const int32_t* actions, int32_t* obs,
                         float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated,
                         int32_t* final_obs, int autoreset_mode);
-/* Whole ring cycles of xv_anymdp_step_many are replayed from an instantiated hipGraph (period kernel nodes + a
- * tick update; built on first use, rebuilt when the arrays, period or mode change): dependent launches cost ~1.6 us
- * as graph nodes instead of ~3.3 us as stream launches.  Same kernels, same results (parity-tested).  enable = 0
- * issues plain launches. */
-int xv_anymdp_set_step_many_graph(xv_anymdp* h, int enable);
+/* Whole ring cycles of xv_anymdp_step_many can be replayed from an instantiated hipGraph (period kernel nodes that
+ * read the launch tick from device memory + a tick update; built on first use, rebuilt when the arrays, period or
+ * mode change).  Same kernels, same results (parity-tested).  mode: 0 plain launches, 1 graph, 2 auto (default):
+ * graph for n_env <= 8,192, where the stream's launch rate is the limiter (7-9 % faster at 1,024-4,096 envs; at
+ * 65,536 envs the step loop is not launch-bound and plain launches are slightly faster). */
+int xv_anymdp_set_step_many_graph(xv_anymdp* h, int mode);
 /* 1: a graph is built and in use, 0: plain launches, -1: graph construction or launch failed (plain launches used) */
 int xv_anymdp_step_many_graph_state(xv_anymdp* h);
 

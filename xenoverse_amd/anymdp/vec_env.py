@@ -340,9 +340,11 @@ class AnyMDPVecEnv(VectorEnv):
             _lib.ptr(out.get("final_obs")), AUTORESET[self.autoreset_mode]))
         return out
 
-    def set_step_many_graph(self, enable):
-        """step_many replays whole ring cycles from a hipGraph (default) or issues plain launches; same results."""
-        _lib.check(self.lib.xv_anymdp_set_step_many_graph(self._h, 1 if enable else 0))
+    def set_step_many_graph(self, mode):
+        """step_many replays whole ring cycles from a hipGraph (True / "on"), issues plain launches (False / "off")
+        or decides by batch size ("auto", the default: graph up to 8,192 envs); same results either way."""
+        m = {"off": 0, "on": 1, "auto": 2}.get(mode, 1 if mode is True else (0 if mode is False else mode))
+        _lib.check(self.lib.xv_anymdp_set_step_many_graph(self._h, int(m)))
 
     # ---- accessors (anymdp_env.py:134-165) ----------------------------------------------------------
     def _get_steps(self):

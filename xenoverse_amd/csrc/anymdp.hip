@@ -81,7 +81,8 @@ struct xv_anymdp {
   const double* obs_cdf;   // observation model (POMDP / MTPOMDP), nullptr for MDP
   int n_obs, d_obs, d_act;
   // xv_anymdp_step_many: one ring cycle (period launches + a tick update) as an instantiated hipGraph
-  bool graph_enabled, graph_failed;
+  int graph_mode;            // 0 off, 1 on, 2 auto: on for n_env <= XV_ANYMDP_GRAPH_AUTO_MAX
+  bool graph_failed;
   hipGraph_t graph;
   hipGraphExec_t graph_exec;
   uint64_t* d_tick;          // device copy of the launch tick the graph's kernels read
@@ -129,7 +130,8 @@ __device__ __forceinline__ double xv_u2d(uint32_t lo, uint32_t hi) { return __hi
 
 // T_steps == 1: one vector step.  T_steps > 1: fused rollout, io arrays are [T][n_env], mode SAME_STEP.
 // FAST: fence line + block line, per-env reset record; otherwise per-lane binary search and per-task tables.
-template <bool INJECT, bool FAST, bool ROLLOUT>
+// TICKDEV: the launch tick is *P.tick_dev + P.tick (graph replay); otherwise P.tick (a kernel argument).
+template <bool INJECT, bool FAST, bool ROLLOUT, bool TICKDEV = false>
 __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPStepIO io, int T_steps,
                                                           int mode) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
     tm0 = P.term_mask[(size_t)t * P.words];
   }
 
-  const uint64_t tick0 = P.tick_dev ? *P.tick_dev + P.tick : P.tick;
+  const uint64_t tick0 = TICKDEV ? *P.tick_dev + P.tick : P.tick;
   const int T = ROLLOUT ? T_steps : 1;   // single step: straight-line code, counted vmcnt waits
   for (int ts = 0; ts < T; ++ts) {
     const size_t o = (size_t)ts * P.n_env + ic;
@@ -629,7 +631,7 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
   h->search = XV_ANYMDP_SEARCH_AUTO;
   h->fast = false;
   h->obs_cdf = nullptr; h->n_obs = 0; h->d_obs = 0; h->d_act = 0;
-  h->graph_enabled = true; h->graph_failed = false; h->graph = nullptr; h->graph_exec = nullptr;
+  h->graph_mode = 2; h->graph_failed = false; h->graph = nullptr; h->graph_exec = nullptr;
   h->d_tick = nullptr; h->d_tick_value = 0; h->d_tick_valid = false;
   memset(&h->graph_key, 0, sizeof(h->graph_key));
   AnyMDPArgs& a = h->a;
@@ -787,8 +789,8 @@ static bool anymdp_ensure_graph(xv_anymdp* h, int period, const int32_t* actions
   if (hipGraphCreate(&h->graph, 0) != hipSuccess) return false;
   const size_t n = (size_t)h->a.n_env;
   const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
-  void* fn = fast ? reinterpret_cast<void*>(&anymdp_step_kernel<false, true, false>)
-                  : reinterpret_cast<void*>(&anymdp_step_kernel<false, false, false>);
+  void* fn = fast ? reinterpret_cast<void*>(&anymdp_step_kernel<false, true, false, true>)
+                  : reinterpret_cast<void*>(&anymdp_step_kernel<false, false, false, true>);
   hipGraphNode_t prev = nullptr;
   for (int j = 0; j <= period; ++j) {
     hipKernelNodeParams np;
@@ -820,16 +822,23 @@ static bool anymdp_ensure_graph(xv_anymdp* h, int period, const int32_t* actions
   return true;
 }
 
-extern "C" int xv_anymdp_set_step_many_graph(xv_anymdp* h, int enable) {
-  XV_CHECK_ARG(h != nullptr);
-  h->graph_enabled = enable != 0;
+// measured (scripts/devtools/graph_step_many.py, config 2b): graph replay wins 7-9 % at 1,024-4,096 envs, nothing at
+// 16,384 and loses 3 % at 65,536 in config 2a (its kernels read the tick from memory; the stream is not the limiter)
+#define XV_ANYMDP_GRAPH_AUTO_MAX 8192
+static inline bool anymdp_graph_wanted(const xv_anymdp* h) {
+  return h->graph_mode == 1 || (h->graph_mode == 2 && h->a.n_env <= XV_ANYMDP_GRAPH_AUTO_MAX);
+}
+
+extern "C" int xv_anymdp_set_step_many_graph(xv_anymdp* h, int mode) {
+  XV_CHECK_ARG(h != nullptr && mode >= 0 && mode <= 2);
+  h->graph_mode = mode;
   return XV_OK;
 }
 
 extern "C" int xv_anymdp_step_many_graph_state(xv_anymdp* h) {   // 0 plain launches, 1 graph built and in use, -1 failed
   if (!h) return 0;
   if (h->graph_failed) return -1;
-  return (h->graph_enabled && h->graph_exec) ? 1 : 0;
+  return (anymdp_graph_wanted(h) && h->graph_exec) ? 1 : 0;
 }
 
 extern "C" int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const int32_t* actions,
@@ -842,7 +851,7 @@ extern "C" int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const 
   int k = 0;
   // whole ring cycles: replay the graph
   const int cycles = n_steps / period;
-  if (cycles > 0 && period > 1 && h->graph_enabled && !h->graph_failed) {
+  if (cycles > 0 && period > 1 && anymdp_graph_wanted(h) && !h->graph_failed) {
     bool ok = anymdp_ensure_graph(h, period, actions, obs, reward, reward_gt, terminated, truncated, final_obs,
                                   autoreset_mode);
     if (ok && !(h->d_tick_valid && h->d_tick_value == h->eng->tick)) {
