@@ -32,7 +32,10 @@
 extern "C" {
 #endif
 
-#define XV_ABI_VERSION 1
+/* 2: AnyMDP rows are records of 128-byte lines (fence line + 7-entry blocks), completed in place by
+ *    xv_anymdp_create; xv_maze_tables carries the texture-library sizes; Acrobot family; command-table and
+ *    graph-replay switches */
+#define XV_ABI_VERSION 2
 
 /* return codes */
 #define XV_OK 0

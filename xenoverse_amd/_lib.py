@@ -89,6 +89,9 @@ class XenoError(RuntimeError):
     pass
 
 
+ABI_VERSION = 2      # include/xeno.h XV_ABI_VERSION
+
+
 def load():
     """Load libxeno_hip.so; raise (never fall back) when it is absent."""
     global _lib
@@ -103,6 +106,9 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing: loud by design
         fn.argtypes = args
         fn.restype = _RESTYPE.get(name, c_int)
+    if lib.xv_abi_version() != ABI_VERSION:
+        raise XenoError("libxeno_hip.so has ABI version %d, this package binds version %d: rebuild with "
+                        "`python -m xenoverse_amd.build --force`" % (lib.xv_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 
