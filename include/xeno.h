@@ -208,6 +208,15 @@ int xv_anymdp_rollout_teacher(xv_anymdp* h, int T, const uint8_t* greedy, float 
                               int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated,
                               uint8_t* truncated, int32_t* final_obs);
 
+/* Value iteration for every task of the handle, one workgroup per task (the reference's ground-truth teacher,
+ * anymdp_solver_opt.py:30-51, for whole task batches): synchronous sweeps
+ *   Q[s,a] <- sum_s' T[s,a,s'] (R[s,a,s'] + gamma max_a' Q[s',a'])   until rms(Q_new - Q) <= tol or max_iter sweeps,
+ * T recovered from the row records (rows of terminal states are zero), R the tables' fp32 rewards.
+ * q_out double[n_task][S][A], greedy_out uint8[n_task][S] (first argmax_a, the table xv_anymdp_rollout_teacher
+ * reads), iters_out int32[n_task]; each nullable, at least one of the first two given. */
+int xv_anymdp_solve(xv_anymdp* h, double gamma, double tol, int max_iter, double* q_out, uint8_t* greedy_out,
+                    int32_t* iters_out);
+
 /* env.inner_state / env.steps accessors (anymdp_env.py:138-143); device int32[n_env] each, nullable */
 int xv_anymdp_get_state(xv_anymdp* h, int32_t* inner_state, int32_t* steps, uint8_t* need_reset);
 int xv_anymdp_set_state(xv_anymdp* h, const int32_t* inner_state, const int32_t* steps,

@@ -627,3 +627,43 @@ def test_step_many_graph_replay_equals_plain_launches(search):
         for k in a:
             assert np.array_equal(a[k], b[k]), k
     assert res[0][0]["terminated"].sum() > 50
+
+
+@pytest.mark.parametrize("case", ["golden16", "synth64", "synth100", "sampled64"])
+def test_device_value_iteration_vs_numpy(case):
+    """xv_anymdp_solve (register path for S <= 64, S*A <= 512; strided path otherwise) against the host value
+    iteration on the same tables: same number of sweeps, Q to 1e-9, greedy actions equal wherever the best two
+    Q values are not within 1e-7 of each other"""
+    from xenoverse_amd.anymdp.task_sampler import value_iteration
+    from xenoverse_amd.anymdp import from_blocked
+    if case == "golden16":
+        tasks = [load_anymdp_golden(p)[1] for p in FILES if "16x4" in p]
+        tab = build_tables(tasks)
+    elif case == "sampled64":
+        tab = build_tables([load_anymdp_golden(p)[1] for p in FILES if "64x8" in p])
+    else:
+        S, A = (64, 8) if case == "synth64" else (100, 5)
+        tab = oracle.anymdp_synth(seed=21, task_index_base=0, n_task=6, S=S, A=A, s0_max=3)
+    S, A = tab["S"], tab["A"]
+    n_task = len(tab["max_steps"])
+    env = AnyMDPVecEnv(n_task * 2)
+    env.set_task(_dev_tables(tab) if "rows" not in tab else tab)
+    q, g, it = env.solve(gamma=0.99)
+    q, g, it = _np(q), _np(g), _np(it)
+    cdf, rs = from_blocked(_np(env._tab["rows"]), S)
+    for t in range(n_task):
+        T = np.diff(np.concatenate([np.zeros((S, A, 1)), cdf[t]], -1), axis=-1)
+        term = np.array([(int(np.asarray(tab["term_mask"]).view(np.uint64)[t][s >> 6]) >> (s & 63)) & 1 for s in range(S)], bool)
+        T[term] = 0.0
+        Qh = value_iteration(T, rs[t][..., 0].astype(np.float64), 0.99)
+        assert np.allclose(q[t], Qh, rtol=1e-9, atol=1e-9), np.abs(q[t] - Qh).max()
+        srt = np.sort(Qh, 1)
+        clear = (srt[:, -1] - srt[:, -2]) > 1e-7
+        assert np.array_equal(g[t][clear], Qh.argmax(1)[clear])
+    assert it.min() > 10 and it.max() < 20000
+    # the teacher rollout solves on the device when no table is given
+    env.reset()
+    out = env.rollout_teacher(8)
+    st = _np(env.get_state()[0])
+    assert out["action"].shape == (8, n_task * 2) and st.shape == (n_task * 2,)
+    env.close()

@@ -32,6 +32,7 @@ SIGNATURES = {
     "xv_anymdp_step_injected": [c_void_p] + [c_void_p] * 10 + [c_int],
     "xv_anymdp_step_many": [c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int],
     "xv_anymdp_set_step_many_graph": [c_void_p, c_int],
+    "xv_anymdp_solve": [c_void_p, C.c_double, C.c_double, c_int, c_void_p, c_void_p, c_void_p],
     "xv_anymdp_step_many_graph_state": [c_void_p],
     "xv_anymdp_rollout": [c_void_p, c_int] + [c_void_p] * 7,
     "xv_anymdp_set_search": [c_void_p, c_int],

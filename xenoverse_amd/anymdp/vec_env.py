@@ -298,10 +298,28 @@ class AnyMDPVecEnv(VectorEnv):
             _lib.ptr(out["terminated"]), _lib.ptr(out["truncated"]), _lib.ptr(out.get("final_obs"))))
         return out
 
-    def rollout_teacher(self, T, greedy, epsilon=0.0):
+    def solve(self, gamma=0.99, tol=1.0e-4, max_iter=20000, return_q=True):
+        """Value iteration for every task of the batch on the device (one workgroup per task; the ground-truth
+        teacher of AnyMDPSolverOpt, anymdp_solver_opt.py:30-51).  -> (Q float64[n_task, S, A] or None,
+        greedy uint8[n_task, S], sweeps int32[n_task])"""
+        self._require_task()
+        d = self.device
+        q = torch.empty((self.n_task, self.S, self.A), dtype=torch.float64, device=d) if return_q else None
+        g = torch.empty((self.n_task, self.S), dtype=torch.uint8, device=d)
+        it = torch.empty(self.n_task, dtype=torch.int32, device=d)
+        _lib.check(self.lib.xv_anymdp_solve(self._h, float(gamma), float(tol), int(max_iter), _lib.ptr(q), _lib.ptr(g),
+                                            _lib.ptr(it)))
+        return q, g, it
+
+    def rollout_teacher(self, T, greedy=None, epsilon=0.0, gamma=0.99):
         """Fused T-step rollout driven on the device by a teacher: greedy uint8[n_task, S] (e.g.
-        `teacher.optimal_policy_table(tasks)`), epsilon-greedy.  -> dict of [T, N] device tensors incl. "action"."""
+        `teacher.optimal_policy_table(tasks)`; None: solved on the device with `solve(gamma)` and cached),
+        epsilon-greedy.  -> dict of [T, N] device tensors incl. "action"."""
         self._check_step()
+        if greedy is None:
+            if getattr(self, "_greedy_cache", None) is None or self._greedy_cache[0] != (id(self._tab), gamma):
+                self._greedy_cache = ((id(self._tab), gamma), self.solve(gamma, return_q=False)[1])
+            greedy = self._greedy_cache[1]
         g = self._dev(greedy, torch.uint8)
         assert g.shape == (self.n_task, self.S)
         d, n = self.device, self.num_envs

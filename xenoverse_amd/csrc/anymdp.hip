@@ -607,6 +607,123 @@ __global__ __launch_bounds__(256) void anymdp_tok_reset_kernel(AnyMDPArgs P, Any
 }
 
 // ------------------------------------------------------------------------------------------------
+// Value iteration on the device, one workgroup per task (the optimal-policy teacher of the reference,
+// anymdp_solver_opt.py:30-51, for whole task batches; the same synchronous sweep as
+// xenoverse_amd.anymdp.task_sampler.value_iteration):
+//     Q[s,a] <- ER[s,a] + gamma * sum_s' T[s,a,s'] * max_a' Q[s',a']        until rms(Q_new - Q) <= tol
+// T is recovered from the row records (p_j = cdf_j - cdf_{j-1}; rows of terminal states are zero, as in the
+// reference), ER[s,a] = sum_j p_j * R[s,a,j] with the fp32 rewards of the tables.
+// REG (S <= 64, S*A <= 512): thread (s,a) keeps its T row in 64 fp64 registers for the whole solve; per sweep each
+// wave loads V once (lane j <- V[j]) and feeds it to 64 FMAs through v_readlane (SGPR operand), so a sweep touches
+// LDS only for the 4-KB Q exchange.  Otherwise: thread-strided loops over (s,a) with T re-read from the rows.
+// ------------------------------------------------------------------------------------------------
+template <bool REG>
+__global__ __launch_bounds__(512) void anymdp_solve_kernel(AnyMDPArgs P, double gamma, double tol, int max_iter,
+                                                           double* q_out, uint8_t* greedy_out, int32_t* iters_out) {
+  extern __shared__ __attribute__((aligned(16))) double solve_lds[];   // Q[S*A] | V[S] | red[blockDim]
+  const int t = blockIdx.x, tid = threadIdx.x, S = P.S, A = P.A, SA = S * A;
+  double* Qs = solve_lds;
+  double* Vs = Qs + SA;
+  double* red = Vs + ((S + 63) & ~63);
+  const uint64_t* tm = P.term_mask + (size_t)t * P.words;
+  double Trow[REG ? 64 : 1];
+  double er = 0.0;
+  const int s_own = REG ? tid / A : 0, a_own = REG ? tid - s_own * A : 0;
+  const bool own = REG && tid < SA;
+  if (REG) {
+#pragma unroll
+    for (int j = 0; j < 64; ++j) Trow[j] = 0.0;
+    if (own && !((tm[s_own >> 6] >> (s_own & 63)) & 1ull)) {
+      const uint32_t r = ((uint32_t)t * S + s_own) * A + a_own;
+      double prev = 0.0;
+#pragma unroll
+      for (int j = 0; j < 64; ++j) {
+        if (j < S) {
+          const uint4 e = *anymdp_entry_ptr(P, r, j);
+          const double c = xv_u2d(e.x, e.y);
+          Trow[j] = c - prev;
+          prev = c;
+          er = fma(Trow[j], (double)__uint_as_float(e.z), er);
+        }
+      }
+    }
+  }
+  for (int k = tid; k < SA; k += blockDim.x) Qs[k] = 0.0;
+  for (int k = tid; k < ((S + 63) & ~63); k += blockDim.x) Vs[k] = 0.0;   // V of absent states multiplies T = 0
+  __syncthreads();
+  int it = 0;
+  for (; it < max_iter; ++it) {
+    for (int j = tid; j < S; j += blockDim.x) {   // V = max_a Q
+      double v = Qs[j * A];
+      for (int a = 1; a < A; ++a) v = fmax(v, Qs[j * A + a]);
+      Vs[j] = v;
+    }
+    __syncthreads();
+    double d2 = 0.0;
+    if (REG) {
+      const double vlane = Vs[threadIdx.x & 63];   // S <= 64: lane j of every wave holds V[j] (V of absent states: unused)
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < 64; ++j) {
+        const double vj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(vlane), j),
+                                           __builtin_amdgcn_readlane(__double2loint(vlane), j));
+        acc = fma(Trow[j], vj, acc);
+      }
+      const double qn = fma(gamma, acc, er);
+      if (own) {
+        const double q = Qs[tid];
+        d2 = (qn - q) * (qn - q);
+      }
+      __syncthreads();      // everyone has read the old Q
+      if (own) Qs[tid] = qn;
+    } else {
+      // strided over (s,a); the new Q is staged behind red[] and copied after the barrier
+      for (int k = tid; k < SA; k += blockDim.x) {
+        const int s = k / A, a = k - s * A;
+        double qn = 0.0;
+        if (!((tm[s >> 6] >> (s & 63)) & 1ull)) {
+          const uint32_t r = ((uint32_t)t * S + s) * A + a;
+          double prev = 0.0, acc = 0.0, e_r = 0.0;
+          for (int j = 0; j < S; ++j) {
+            const uint4 e = *anymdp_entry_ptr(P, r, j);
+            const double c = xv_u2d(e.x, e.y), p = c - prev;
+            prev = c;
+            e_r = fma(p, (double)__uint_as_float(e.z), e_r);
+            acc = fma(p, Vs[j], acc);
+          }
+          qn = fma(gamma, acc, e_r);
+        }
+        const double q = Qs[k];
+        d2 += (qn - q) * (qn - q);
+        Qs[SA + ((S + 63) & ~63) + blockDim.x + k] = qn;   // staging area behind red[]
+      }
+      __syncthreads();
+      for (int k = tid; k < SA; k += blockDim.x) Qs[k] = Qs[SA + ((S + 63) & ~63) + blockDim.x + k];
+    }
+    // deterministic tree reduction of the squared update
+    red[tid] = d2;
+    __syncthreads();
+    for (int w = blockDim.x >> 1; w > 0; w >>= 1) {
+      if (tid < w) red[tid] += red[tid + w];
+      __syncthreads();
+    }
+    const double diff = sqrt(red[0] / (double)SA);
+    __syncthreads();
+    if (diff <= tol) { ++it; break; }
+  }
+  if (q_out) for (int k = tid; k < SA; k += blockDim.x) q_out[(size_t)t * SA + k] = Qs[k];
+  if (greedy_out) {
+    for (int j = tid; j < S; j += blockDim.x) {   // numpy.argmax: the first maximum
+      int best = 0;
+      double v = Qs[j * A];
+      for (int a = 1; a < A; ++a) if (Qs[j * A + a] > v) { v = Qs[j * A + a]; best = a; }
+      greedy_out[(size_t)t * S + j] = (uint8_t)best;
+    }
+  }
+  if (iters_out && tid == 0) iters_out[t] = it;
+}
+
+// ------------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int A, int s0_max,
@@ -903,6 +1020,33 @@ extern "C" int xv_anymdp_rollout_teacher(xv_anymdp* h, int T, const uint8_t* gre
                   actions_out, epsilon};
   // T == 1 must still take the rollout instantiation (it is the one that honours the teacher fields per step)
   return anymdp_launch_step<false>(h, io, T, XV_AUTORESET_SAME_STEP);
+}
+
+extern "C" int xv_anymdp_solve(xv_anymdp* h, double gamma, double tol, int max_iter, double* q_out,
+                               uint8_t* greedy_out, int32_t* iters_out) {
+  XV_CHECK_ARG(h != nullptr && (q_out || greedy_out));
+  XV_CHECK_ARG(gamma > 0.0 && gamma < 1.0 && tol > 0.0 && max_iter > 0);
+  const AnyMDPArgs& a = h->a;
+  const int SA = a.S * a.A, Sp = (a.S + 63) & ~63;
+  const bool reg = a.S <= 64 && SA <= 512;
+  const int threads = 512;
+  const size_t lds = sizeof(double) * ((size_t)SA + Sp + threads + (reg ? 0 : SA));
+  if (lds > 150 * 1024) {
+    xv_set_error("xv_anymdp_solve: S*A = %d does not fit the workgroup's LDS", SA);
+    return XV_ERR_UNSUPPORTED;
+  }
+  if (reg) {
+    hipLaunchKernelGGL(anymdp_solve_kernel<true>, dim3(a.n_task), dim3(threads), lds, h->eng->stream, a, gamma, tol,
+                       max_iter, q_out, greedy_out, iters_out);
+  } else {
+    if (lds > 48 * 1024)
+      XV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&anymdp_solve_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(anymdp_solve_kernel<false>, dim3(a.n_task), dim3(threads), lds, h->eng->stream, a, gamma, tol,
+                       max_iter, q_out, greedy_out, iters_out);
+  }
+  XV_LAUNCH_CHECK();
+  return XV_OK;
 }
 
 extern "C" int xv_anymdp_set_search(xv_anymdp* h, int search) {
