@@ -67,3 +67,9 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
                 assert "xeno_oracle.h" not in src.replace("oracle/xeno_oracle.c", ""), os.path.join(dp, f)
+
+
+def test_graft_entry_build_runs():
+    """the driver's build hook: compiles (incrementally) every HIP source, the CPU checker, and loads the library"""
+    import __graft_entry__ as ge
+    ge.build()
