@@ -294,7 +294,7 @@ def main():
             chunks = args.steps // P
             out["with_allgather"] = {"value": total_steps / wall_g, "unit": "env-steps/s",
                                      "gathered_GB_per_s_per_rank": chunks * P * n_env * 14 * (world - 1) / wall_g / 1e9}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU line is measured at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.seed)
         else:
             out["cpu_baseline"] = None
