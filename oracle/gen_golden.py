@@ -467,7 +467,19 @@ def gen_acrobot():
     print("acrobot_dsdt.npz: %d derivative vectors, %d terminal" % (n, int(term.sum())))
 
 
-FAMILIES = {"anymdp": gen_anymdp, "linds": gen_linds, "maze": gen_maze, "acrobot": gen_acrobot}
+def gen_garnet():
+    """One seeded task of the reference's GarnetTaskSampler (task_sampler.py:120-160): the build's sampler follows the
+    same draw order on RandomState(seed) and must reproduce it bit for bit."""
+    _refimport.setup()
+    from xenoverse.anymdp.task_sampler import GarnetTaskSampler
+    g = GarnetTaskSampler(8, 2, b=2, sigma=0.1, seed=3)
+    np.savez_compressed(os.path.join(GOLD, "garnet_8x2_seed3.npz"), max_steps=np.float64(g["max_steps"]),
+                        state_mapping=np.asarray(g["state_mapping"], np.int64), transition=g["transition"],
+                        reward=g["reward"])
+    print("garnet_8x2_seed3.npz")
+
+
+FAMILIES = {"anymdp": gen_anymdp, "linds": gen_linds, "maze": gen_maze, "acrobot": gen_acrobot, "garnet": gen_garnet}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

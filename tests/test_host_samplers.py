@@ -1,5 +1,6 @@
 """Host task samplers (CPU): the reference's dict schemas and invariants; tasks flow through the table builders."""
 import numpy as np
+import pytest
 
 from xenoverse_amd.linds import LinearDSSampler, LinearDSSamplerRandomDim, build_tables as linds_tables
 from xenoverse_amd.mazeworld import MazeTaskSampler, Resampler, build_tables as maze_tables
@@ -140,3 +141,23 @@ def test_sample_batch_returns_stacked_tables():
     assert lb["phiT"].shape[0] == 2 and lb["NS"] == 16
     mb = m_ts.sample_batch(2, seed=3, n_range=(9, 10))
     assert mb["walls"].shape[0] == 2 and mb["walls"].shape[1:] == (9, 9)
+
+
+def test_garnet_sampler_reproduces_the_reference_task():
+    """GarnetTaskSampler(8, 2, b=2, sigma=0.1, seed=3) equals the task the reference sampled (fixture from
+    oracle/gen_golden.py garnet), bit for bit; structure: b non-zeros per row summing to 1, no terminal states"""
+    import os
+    from xenoverse_amd.anymdp import GarnetTaskSampler
+    from xenoverse_amd.anymdp.tables import build_tables
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "garnet_8x2_seed3.npz"))
+    t = GarnetTaskSampler(8, 2, b=2, sigma=0.1, seed=3)
+    assert float(t["max_steps"]) == float(g["max_steps"])
+    assert np.array_equal(t["state_mapping"], g["state_mapping"])
+    assert np.array_equal(t["transition"], g["transition"]) and np.array_equal(t["reward"], g["reward"])
+    big = GarnetTaskSampler(32, 5, min_state_space=10, b=3, seed=1)
+    T = big["transition"]
+    assert np.all((T > 0).sum(-1) == 3) and np.allclose(T.sum(-1), 1.0) and len(big["s_e"]) == 0
+    tab = build_tables([big])
+    assert tab["S"] == T.shape[0] and tab["A"] == 5
+    with pytest.raises(ValueError):
+        GarnetTaskSampler(8, 2, b=1)

@@ -256,6 +256,47 @@ def AnyMDPTaskSampler(state_space=64, action_space=5, min_state_space=None, seed
     return task
 
 
+def GarnetTaskSampler(state_space=128, action_space=5, min_state_space=None, b=2, sigma=0.1, seed=None, verbose=False):
+    """Garnet MDPs (reference task_sampler.py:120-160, task_sampler_utils.py:274-313): every (s, a) row puts a random
+    partition of 1 on `b` distinct next states, rewards are N(0, sigma), no terminal states, s_0 = {0}, no reward
+    noise.  The draws follow the reference's order on a RandomState(seed), so a seeded task equals the reference's
+    (checked in the build container and by tests/golden/garnet_8x2_seed3.npz).  b >= 2 (the reference's b = 1 path
+    raises a NameError)."""
+    rng = np.random.RandomState(seed)
+    assert (state_space >= 8 or state_space == 1), "State Space must be at least 8 or 1 (Multi-armed Bandit)!"
+    if b < 2 or b > state_space:
+        raise ValueError("b must satisfy 2 <= b <= state_space")
+    if state_space < 2:
+        max_steps = 1
+    else:
+        lower = max(4.0 * state_space, 100)
+        upper = max(min(8.0 * state_space, 500), lower + 1)
+        max_steps = rng.uniform(lower, upper)
+    if min_state_space is None:
+        real = state_space
+    else:
+        min_state_space = min(min_state_space, state_space)
+        assert (min_state_space >= 8), "Minimum State Space must be at least 8!"
+        real = rng.randint(min_state_space, state_space + 1)
+    task = {"ns": state_space, "na": action_space, "max_steps": max_steps,
+            "state_mapping": rng.permutation(state_space)[:real], "task_type": "MDP"}
+    assert real >= 8, "ns must be at least 8 for MDP"
+    transition = np.zeros((real, action_space, real))
+    arr = np.arange(real)
+    for i in range(real):
+        for j in range(action_space):
+            sample = rng.choice(arr, size=b, replace=False)
+            cuts = rng.random_sample(b - 1)
+            cuts.sort()
+            cuts = np.concatenate(([0], cuts, [1]))
+            transition[i, j, sample] = cuts[1:] - cuts[:-1]
+    reward = rng.normal(size=(real, action_space, real)) * sigma + 0.0
+    task.update({"s_0": np.array([0]), "s_0_prob": np.array([1.0]), "s_e": np.array([], dtype=int),
+                 "transition": transition, "reward": reward, "reward_noise": np.zeros((real, action_space, real)),
+                 "final_goal_terminate": False})
+    return task
+
+
 def _obs_matrix(rng, n_states, n_obs, density, maximum_distribution):
     density = min(density, maximum_distribution / n_obs)
     m = sp.random(n_states, n_obs, density=density, format="csr", random_state=rng).toarray()
