@@ -280,7 +280,8 @@ int xv_linds_destroy(xv_linds* h);
 int xv_linds_set_path(xv_linds* h, int path);
 /* get_inner_cmd (linds_env.py:93-98) depends on (task, integer time) only; xv_linds_create tabulates it per task
  * ([max_steps + 2 + delay][NO] floats, with the kernels' own evaluation code, if the table fits 2 GiB) and a step
- * reads two rows instead of evaluating 2 x NO x n_fourier sin/cos pairs.  enable = 0 evaluates directly (same
+ * reads two rows instead of evaluating 2 x NO x n_fourier sin/cos pairs; likewise the observation and tracking error of
+ * every initial state ([n_task][NI][NO+4] floats), read by restarting envs.  enable = 0 evaluates both directly (same
  * bits; parity-tested).  Returns XV_ERR_UNSUPPORTED when enable = 1 and no table was built. */
 int xv_linds_set_command_table(xv_linds* h, int enable);
 /* reset: x = initial_states[k], k uniform (linds_env.py:117 uses random.choice); obs = C x + Y; command =

@@ -29,6 +29,9 @@ struct LinDSArgs {
   // get_inner_cmd at integer time tt, already multiplied by target_valid, for tt in [ct_tmin, ct_tmin + ct_len)
   const float* cmd_tab;
   int ct_len, ct_tmin;
+  // engine-built reset table: rst_tab[task][init index][NO + 4] = the observation of initial_states[idx] (NO floats)
+  // and its tracking error against cmd(0) (slot NO): a restarting env reads 80 B instead of redoing y = C x + Y
+  const float* rst_tab;
 };
 
 struct LinDSStepIO {
@@ -50,6 +53,7 @@ struct xv_linds {
   bool tiles_uniform;   // every aligned 32-env group shares a task -> MFMA path
   int path;             // XV_LINDS_PATH_*
   float* cmd_tab;       // owned; a.cmd_tab points here while the table is enabled
+  float* rst_tab;       // owned; likewise
 };
 
 // Task tables are read-only for the lifetime of a launch: reading them through the constant address space lets
@@ -184,9 +188,33 @@ __device__ __forceinline__ void linds_reset_env(const LinDSArgs& P, int tu, int 
   const float* x0 = P.T.init + ((size_t)tu * P.NI + idx) * NS;
 #pragma unroll
   for (int k = 0; k < NS; ++k) xs[k] = x0[k];   // :117
-  linds_observe<NS, NO>(P, tu, xs, y);
   linds_cmd_at<NO>(P, tu, nf, 0, c);                // :120-126: the last pre-filled command is cmd(0)
+  if (P.rst_tab != nullptr) {
+    const float* row = P.rst_tab + ((size_t)tu * P.NI + idx) * (NO + 4);
+#pragma unroll
+    for (int j = 0; j < NO; ++j) y[j] = row[j];
+    err = row[NO];
+    return;
+  }
+  linds_observe<NS, NO>(P, tu, xs, y);
   err = linds_err<NO>(P, tu, y, c);
+}
+
+// builds rst_tab with the functions above (same code, same bits as evaluating at reset time)
+template <int NS, int NO>
+__global__ __launch_bounds__(256) void linds_build_reset_tab_kernel(LinDSArgs P, float* tab) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)P.n_task * P.NI) return;
+  const int t = (int)(idx / P.NI), k = (int)(idx % P.NI);
+  const int n_init = P.T.ints[(size_t)t * 4 + 2], nf = P.T.ints[(size_t)t * 4 + 3];
+  float xs[NS], y[NO], c[NO], e = 0.0f;
+  LinDSArgs Q = P;
+  Q.rst_tab = nullptr;
+  linds_reset_env<NS, NO>(Q, t, nf, n_init > 0 ? n_init : 1, k < n_init ? k : 0, xs, y, c, e);
+  float* row = tab + idx * (NO + 4);
+#pragma unroll
+  for (int j = 0; j < NO; ++j) row[j] = y[j];
+  row[NO] = e; row[NO + 1] = 0.0f; row[NO + 2] = 0.0f; row[NO + 3] = 0.0f;
 }
 
 __device__ __forceinline__ int linds_draw_init(const LinDSArgs& P, uint64_t gid, int n_init) {
@@ -576,10 +604,20 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
 #pragma unroll
       for (int r = 0; r < NR; ++r) xr[r] = x0[linds_row_of(r, h)];   // :117
     }
-    float yr[NO], c0[NO];
-    linds_observe_mfma<NS, NO>(P, t, h, ca, xr, yr);
+    float yr[NO], c0[NO], e0;
     linds_cmd_at<NO>(P, t, nf, 0, c0);                // :120-126
-    const float e0 = linds_err<NO>(P, t, yr, c0);
+    if (P.rst_tab != nullptr) {                        // observation and error of initial_states[idx], tabulated
+      const float4* row = reinterpret_cast<const float4*>(P.rst_tab + ((size_t)t * P.NI + idx) * (NO + 4));
+#pragma unroll
+      for (int q = 0; q < NO / 4; ++q) {
+        const float4 v = row[q];
+        yr[4 * q] = v.x; yr[4 * q + 1] = v.y; yr[4 * q + 2] = v.z; yr[4 * q + 3] = v.w;
+      }
+      e0 = row[NO / 4].x;
+    } else {
+      linds_observe_mfma<NS, NO>(P, t, h, ca, xr, yr);
+      e0 = linds_err<NO>(P, t, yr, c0);
+    }
     if (do_reset) {
       if (!skip) {
 #pragma unroll
@@ -686,8 +724,8 @@ extern "C" int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int 
     h->path = XV_LINDS_PATH_AUTO;
   }
   // command table: [n_task][max_steps_max + 2 + delay_max][NO] floats, within a 2-GiB budget
-  a.cmd_tab = nullptr; a.ct_len = 0; a.ct_tmin = 0;
-  h->cmd_tab = nullptr;
+  a.cmd_tab = nullptr; a.ct_len = 0; a.ct_tmin = 0; a.rst_tab = nullptr;
+  h->cmd_tab = nullptr; h->rst_tab = nullptr;
   {
     int* d2 = nullptr;
     int h2[2] = {0, 0};
@@ -714,6 +752,23 @@ extern "C" int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int 
       (void)hipGetLastError();
     }
   }
+  {   // reset table: [n_task][NI][NO + 4] floats
+    float* rt = nullptr;
+    const size_t nrow = (size_t)n_task * NI;
+    if (hipMalloc(&rt, nrow * (NO + 4) * sizeof(float)) == hipSuccess) {
+      const dim3 grid((unsigned)((nrow + 255) / 256)), block(256);
+#define LINDS_RST(NS_, NO_) hipLaunchKernelGGL((linds_build_reset_tab_kernel<NS_, NO_>), grid, block, 0, e->stream, a, rt)
+      if (NS == 16 && NO == 16) LINDS_RST(16, 16);
+      else if (NS == 16) LINDS_RST(16, 32);
+      else if (NO == 16) LINDS_RST(32, 16);
+      else LINDS_RST(32, 32);
+#undef LINDS_RST
+      a.rst_tab = rt;
+      h->rst_tab = rt;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   XV_LAUNCH_CHECK();
   *out = h;
   return XV_OK;
@@ -736,6 +791,7 @@ extern "C" int xv_linds_set_command_table(xv_linds* h, int enable) {
     return XV_ERR_UNSUPPORTED;
   }
   h->a.cmd_tab = enable ? h->cmd_tab : nullptr;
+  h->a.rst_tab = enable ? h->rst_tab : nullptr;
   return XV_OK;
 }
 
@@ -747,6 +803,7 @@ extern "C" int xv_linds_destroy(xv_linds* h) {
   (void)hipFree(h->a.steps);
   (void)hipFree(h->a.need_reset);
   if (h->cmd_tab) (void)hipFree(h->cmd_tab);
+  if (h->rst_tab) (void)hipFree(h->rst_tab);
   delete h;
   return XV_OK;
 }
