@@ -1,14 +1,24 @@
 """GPU parity of the POMDP / multi-token POMDP path: reference goldens and seeded batches vs the oracle."""
 import numpy as np
 import pytest
+import torch
 
 import oracle
-from xenoverse_amd.anymdp import AnyMDPVecEnv, build_obs_tables, build_tables
+from xenoverse_amd.anymdp import AnyMDPVecEnv, build_obs_tables, build_tables, to_blocked
 from util import close_f32, golden_files, load_anymdp_tok_golden
 
 pytestmark = pytest.mark.gpu
 FILES = golden_files("anymdptok_")
 MODES = {"disabled": 0, "next_step": 1, "same_step": 2}
+
+
+def _dev_tables(tab, dev="cuda:0"):
+    out = dict(S=tab["S"], A=tab["A"], s0_max=tab["s0_max"])
+    tab = dict(tab, rows=to_blocked(tab["cdf"], tab["rs"]))
+    for k in ("rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps"):
+        v = np.ascontiguousarray(tab[k])
+        out[k] = torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).to(dev)
+    return out
 
 
 def _np(t):
@@ -86,3 +96,55 @@ def test_batch_vs_oracle_injected_and_free_running(mode):
             env.reset_tokens_injected(ur2, uor2, mask=o[3]); ora.tok_reset_injected(ur2, uor2, mask=o[3])
     assert ended > 50
     env.close()
+
+
+@pytest.mark.parametrize("n_obs,d_obs,d_act,search", [(64, 3, 2, "fence"), (22, 2, 3, "fence"), (15, 2, 2, "fence"),
+                                                     (64, 3, 2, "binary")])
+def test_synthetic_observation_models_vs_oracle(n_obs, d_obs, d_act, search):
+    """S=64, A=8 synthetic tasks with random observation models of several shapes (n_obs 64 / 22 / 15, up to 3
+    tokens) against the oracle: injected draws incl. exact CDF entries, all three auto-reset modes in turn"""
+    S, A, n_task = 64, 8, 6
+    tab = oracle.anymdp_synth(seed=17, task_index_base=0, n_task=n_task, S=S, A=A, s0_max=3)
+    rng = np.random.RandomState(n_obs)
+    w = rng.random_sample((n_task, d_obs, S, n_obs)) * (rng.random_sample((n_task, d_obs, S, n_obs)) < 0.5) + 1e-3
+    obs_cdf = np.cumsum(w, -1)
+    obs_cdf = obs_cdf / obs_cdf[..., -1:]
+    n = 333
+    env_task = (np.arange(n) * 7 % n_task).astype(np.int32)
+    for mode in ("same_step", "next_step", "disabled"):
+        env = AnyMDPVecEnv(n, autoreset_mode=mode, seed=5)
+        dev = {k: v for k, v in _dev_tables(tab).items()}
+        env.set_task(dev, env_task_index=env_task)
+        oc = torch.from_numpy(np.ascontiguousarray(obs_cdf)).cuda()
+        from xenoverse_amd import _lib
+        _lib.check(env.lib.xv_anymdp_set_observation_model(env._h, n_obs, d_obs, d_act, _lib.ptr(oc)))
+        env._tok = (d_obs, d_act); env.task_type = "MTPOMDP"
+        env._tobs = torch.zeros((n, d_obs), dtype=torch.int32, device="cuda")
+        env._tfobs = torch.full((n, d_obs), -1, dtype=torch.int32, device="cuda")
+        env.set_search(search)
+        ora = oracle.AnyMDPTokOracle(tab, env_task, obs_cdf, d_act)
+        ur0, uo0 = rng.random_sample(n), rng.random_sample((d_obs, n))
+        assert np.array_equal(_np(env.reset_tokens_injected(ur0, uo0)), ora.tok_reset_injected(ur0, uo0))
+        ended = 0
+        for t in range(40):
+            a = rng.randint(0, A, (n, d_act)).astype(np.int32)
+            u, z = rng.random_sample((d_act, n)), rng.standard_normal((d_act, n)).astype(np.float32)
+            uo, ur, uor = rng.random_sample((d_obs, n)), rng.random_sample(n), rng.random_sample((d_obs, n))
+            k = rng.randint(0, n, 6)       # draws that hit a stored observation-CDF entry exactly
+            uo[0, k] = np.minimum(obs_cdf[env_task[k], 0, ora.state[k], rng.randint(0, n_obs, 6)], np.nextafter(1.0, 0))
+            obs, r, term, trunc, info = env.step_tokens_injected(a, u, z, uo, ur, uor)
+            o = ora.tok_step_injected(a, u, z, uo, ur, uor, MODES[mode])
+            assert np.array_equal(_np(obs), o[0]) and np.array_equal(_np(r), o[1])
+            assert np.array_equal(_np(info["reward_gt"]), o[2])
+            assert np.array_equal(_np(term).astype(np.uint8), o[3]) and np.array_equal(_np(trunc).astype(np.uint8), o[4])
+            if mode == "same_step":
+                assert np.array_equal(_np(info["final_obs"]), o[5])
+            s, st, nr = env.get_state()
+            assert np.array_equal(_np(s), ora.state) and np.array_equal(_np(st), ora.steps)
+            assert np.array_equal(_np(nr), ora.need_reset)
+            ended += int((o[3] | o[4]).sum())
+            if mode == "disabled" and o[3].any():
+                ur2, uor2 = rng.random_sample(n), rng.random_sample((d_obs, n))
+                env.reset_tokens_injected(ur2, uor2, mask=o[3]); ora.tok_reset_injected(ur2, uor2, mask=o[3])
+        assert ended > 30
+        env.close()
