@@ -225,10 +225,10 @@ class AnyMDPVecEnv(VectorEnv):
             raise Exception("Must \"set_task\" and \"reset\" before doing any actions")
 
     def _infos(self, actions):
-        infos = {"steps": self._out(self._get_steps()), "reward_gt": self._out(self._reward_gt.clone())}
+        infos = {"steps": self._out(self._get_steps()), "reward_gt": self._of(self._reward_gt)}
         if self.autoreset_mode == "same_step":
-            infos["final_obs"] = self._out(self._final_obs.clone())
-            infos["_final_obs"] = self._out((self._term | self._trunc).bool())
+            infos["final_obs"] = self._of(self._final_obs)
+            infos["_final_obs"] = self._out((self._term | self._trunc).view(torch.bool))
         if self.with_transition_gt:
             _lib.check(self.lib.xv_anymdp_transition_gt(self._h, _lib.ptr(actions), _lib.ptr(self._tgt)))
             infos["transition_gt"] = self._out(self._tgt.clone())
@@ -257,12 +257,14 @@ class AnyMDPVecEnv(VectorEnv):
                 infos["final_obs"] = b["final_obs"]
                 infos["_final_obs"] = b["done_b"]
             return b["obs"], b["reward"], b["term_b"], b["trunc_b"], infos
+        # copy=True without copies: the step writes every output for every env, so fresh buffers are swapped in
+        self._renew("_obs", "_reward", "_reward_gt", "_term", "_trunc", "_final_obs")
         _lib.check(self.lib.xv_anymdp_step(
             self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward), _lib.ptr(self._reward_gt),
             _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._final_obs),
             AUTORESET[self.autoreset_mode]))
-        return (self._out(self._obs.clone()), self._out(self._reward.clone()),
-                self._out(self._term.bool()), self._out(self._trunc.bool()), self._infos(a))
+        return (self._of(self._obs), self._of(self._reward), self._obf(self._term), self._obf(self._trunc),
+                self._infos(a))
 
     def step_injected(self, actions, u, z, u_reset):
         """Parity hook (C-ABI xv_anymdp_step_injected): random inputs supplied per env."""
@@ -271,12 +273,13 @@ class AnyMDPVecEnv(VectorEnv):
         u = self._dev(u, torch.float64)
         z = self._dev(z, torch.float32)
         ur = self._dev(u_reset, torch.float64)
+        self._renew("_obs", "_reward", "_reward_gt", "_term", "_trunc", "_final_obs")
         _lib.check(self.lib.xv_anymdp_step_injected(
             self._h, _lib.ptr(a), _lib.ptr(u), _lib.ptr(z), _lib.ptr(ur), _lib.ptr(self._obs),
             _lib.ptr(self._reward), _lib.ptr(self._reward_gt), _lib.ptr(self._term), _lib.ptr(self._trunc),
             _lib.ptr(self._final_obs), AUTORESET[self.autoreset_mode]))
-        return (self._out(self._obs.clone()), self._out(self._reward.clone()),
-                self._out(self._term.bool()), self._out(self._trunc.bool()), self._infos(a))
+        return (self._of(self._obs), self._of(self._reward), self._obf(self._term), self._obf(self._trunc),
+                self._infos(a))
 
     def rollout(self, actions, out=None):
         """Fused open-loop rollout: actions int32[T, N] -> dict of [T, N] device tensors, one launch.
@@ -366,8 +369,9 @@ class AnyMDPVecEnv(VectorEnv):
 
     # ---- accessors (anymdp_env.py:134-165) ----------------------------------------------------------
     def _get_steps(self):
+        self._renew("_steps")
         _lib.check(self.lib.xv_anymdp_get_state(self._h, None, _lib.ptr(self._steps), None))
-        return self._steps.clone()
+        return self._steps if (self.copy and not self.to_numpy) else self._steps.clone()
 
     @property
     def inner_state(self):

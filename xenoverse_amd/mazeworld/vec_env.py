@@ -136,15 +136,16 @@ class MazeWorldVecEnv(VectorEnv):
             assert a.shape == (self.num_envs,)
         # reference quirk: info["steps"] is read BEFORE do_action (maze_env.py:57)
         steps_before = self._steps_now()
+        self._renew("_frames", "_reward", "_term", "_trunc", "_cmd_rgb")   # all fully written by the step
         _lib.check(self.lib.xv_maze_step(self._h, _lib.ptr(a), mode, _lib.ptr(self._frames), _lib.ptr(self._reward),
                                          _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._cmd_rgb),
                                          _lib.ptr(self._final), AUTORESET[self.autoreset_mode]))
-        infos = {"steps": self._out(steps_before), "command": self._o(self._cmd_rgb)}
+        infos = {"steps": self._out(steps_before), "command": self._of(self._cmd_rgb)}
         if self.with_final_obs and self.autoreset_mode == "same_step":
             infos["final_obs"] = self._o(self._final)
             infos["_final_obs"] = self._out((self._term | self._trunc).bool())
-        return (self._o(self._frames), self._o(self._reward), self._ob(self._term),
-                self._ob(self._trunc), infos)
+        return (self._of(self._frames), self._of(self._reward), self._obf(self._term),
+                self._obf(self._trunc), infos)
 
     def render_frames(self):
         """frames of the current state, without stepping"""

@@ -107,16 +107,17 @@ class AcrobotVecEnv(VectorEnv):
     def _ret(self):
         infos = {}
         if self.autoreset_mode == "same_step":
-            infos["final_obs"] = self._o(self._fobs)
+            infos["final_obs"] = self._of(self._fobs)
             infos["_final_obs"] = self._out((self._term | self._trunc).bool())
-        return (self._o(self._obs), self._o(self._reward), self._ob(self._term),
-                self._ob(self._trunc), infos)
+        return (self._of(self._obs), self._of(self._reward), self._obf(self._term),
+                self._obf(self._trunc), infos)
 
     def step(self, actions):
         if (not self.task_set) or self.need_reset:
             raise Exception("Must \"set_task\" and \"reset\" before doing any actions")
         a = self._dev(actions, torch.int32)
         assert a.shape == (self.num_envs,)
+        self._renew("_obs", "_reward", "_term", "_trunc", "_fobs")      # all fully written by the step
         _lib.check(self.lib.xv_acrobot_step(self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward),
                                             _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._fobs),
                                             AUTORESET[self.autoreset_mode]))
@@ -125,6 +126,7 @@ class AcrobotVecEnv(VectorEnv):
     def step_injected(self, actions, u_reset):
         a = self._dev(actions, torch.int32)
         u = self._dev(u_reset, torch.float64)
+        self._renew("_obs", "_reward", "_term", "_trunc", "_fobs")
         _lib.check(self.lib.xv_acrobot_step_injected(self._h, _lib.ptr(a), _lib.ptr(u), _lib.ptr(self._obs),
                                                      _lib.ptr(self._reward), _lib.ptr(self._term),
                                                      _lib.ptr(self._trunc), _lib.ptr(self._fobs),

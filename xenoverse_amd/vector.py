@@ -58,6 +58,22 @@ class VectorEnv(object):
         """an output buffer -> what the caller receives (a copy unless copy=False)"""
         return self._out(t.clone() if (self.copy and not self.to_numpy) else t)
 
+    def _renew(self, *names):
+        """copy=True without copies: before a launch that fully overwrites these output buffers, swap in fresh
+        ones — the tensors handed out by the previous call are then never written again (use with _of / _obf)"""
+        if self.copy and not self.to_numpy:
+            for name in names:
+                t = getattr(self, name)
+                if t is not None:
+                    setattr(self, name, torch.empty_like(t))
+
+    def _of(self, t):
+        """an output buffer that was renewed before the launch (or copy=False): handed out as it is"""
+        return self._out(t)
+
+    def _obf(self, t):
+        return self._out(t.bool() if self.to_numpy else t.view(torch.bool))
+
     def _ob(self, t):
         """a uint8 0/1 flag buffer -> bool tensor (zero-copy view when copy=False)"""
         return self._out(t.bool() if (self.copy or self.to_numpy) else t.view(torch.bool))
