@@ -96,9 +96,10 @@ int xv_philox4x32_10(xv_engine* e, const uint32_t* ctr, const uint32_t* key, uin
  *   step      :112-132 -> xv_anymdp_step / _step_injected   (single_step :92-110, get_observation :145-159)
  *
  * Table layout (device memory, borrowed for the life of the handle):
- *   rows       [n_task][S][A] row records of XV_ANYMDP_ROW_LINES(S) = 1 + NB lines of 128 bytes, NB = ceil(S/7).
- *                line 0      FENCE: double[16]; fence[k] = the CDF entry of the last next-state of block k for
- *                            k < NB-1, 2.0 beyond.                       -- written by xv_anymdp_create --
+ *   rows       [n_task][S][A] row records of XV_ANYMDP_ROW_LINES(S) = 1 + NB lines of 128 bytes; NB = ceil(S/7) rounded
+ *              up to a multiple of G = ceil(ceil(S/7)/16) (G = 1 up to S = 112, 2 up to 224, 3 up to 256).
+ *                line 0      FENCE: double[16]; fence[k] = the CDF entry of the last next-state of block group k
+ *                            (G consecutive blocks) for k < NB/G - 1, 2.0 beyond.  -- written by xv_anymdp_create --
  *                line 1 + k  BLOCK k: 7 entries of 16 bytes {double cdf; float reward; float reward_noise} for next
  *                            states 7k..7k+6, then 16 bytes {uint16 obs[7]; uint8 term_bits; uint8 0}: observation id
  *                            and terminal flag of the same next states.  -- metadata written by xv_anymdp_create --
@@ -117,7 +118,10 @@ int xv_philox4x32_10(xv_engine* e, const uint32_t* ctr, const uint32_t* key, uin
  *   env_task   int32  [n_env]             env -> task index
  * Supported: 2 <= S <= 256, 2 <= A <= 64, 1 <= s0_max <= 256.
  * ---------------------------------------------------------------------------------------------- */
-#define XV_ANYMDP_ROW_LINES(S) (1 + ((S) + 6) / 7)
+/* blocks per row: ceil(S/7) rounded up to a multiple of G = ceil(blocks/16); lines per row: one more (the fence) */
+#define XV_ANYMDP_ROW_G(S) (((((S) + 6) / 7) + 15) / 16)
+#define XV_ANYMDP_ROW_BLOCKS(S) ((((S) + 6) / 7 + XV_ANYMDP_ROW_G(S) - 1) / XV_ANYMDP_ROW_G(S) * XV_ANYMDP_ROW_G(S))
+#define XV_ANYMDP_ROW_LINES(S) (1 + XV_ANYMDP_ROW_BLOCKS(S))
 int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int A, int s0_max,
                      void* rows, const int32_t* state_map,
                      const uint64_t* term_mask, const double* s0_cdf, const int32_t* s0_ids,
@@ -190,10 +194,10 @@ int xv_anymdp_step_tokens_injected(xv_anymdp* h, const int32_t* action, const do
                                    uint8_t* truncated, int32_t* final_obs, int autoreset_mode);
 
 /* How s' = upper_bound(cdf row, u) is evaluated; both modes return the same index (parity-tested).
- *   AUTO    FENCE when available (S <= 112, s0_max <= 4, observation ids < 65536), else BINARY
+ *   AUTO    FENCE when available (s0_max <= 4, observation ids < 65536, max_steps < 2^27), else BINARY
  *   BINARY  per-lane binary search over the row's CDF entries in global memory (any S), then dependent reads of
  *           the reward pair, observation id and terminal flag
- *   FENCE   the row's fence line selects the ONE 128-byte block that is read; both lines are read by 8 lanes,
+ *   FENCE   the row's fence line selects the G 128-byte blocks (one for S <= 112) that are read, by 8 lanes each,
  *           coalesced, and counted with a compare + ballot + popcount; reward pair, observation id and terminal
  *           flag come out of the same block; per-env reset records replace the per-task s_0 tables */
 #define XV_ANYMDP_SEARCH_AUTO 0

@@ -210,19 +210,21 @@ def test_s64_wave_kernel_vs_oracle(n_env, n_task, search):
 
 
 @pytest.mark.parametrize("S,A,n_task,obs_offset", [(16, 4, 6, 0), (100, 5, 3, 0), (256, 3, 2, 0), (8, 2, 5, 0),
-                                                    (7, 2, 3, 0), (112, 3, 2, 0), (113, 3, 2, 0),
+                                                    (7, 2, 3, 0), (112, 3, 2, 0), (113, 3, 2, 0), (128, 5, 2, 0),
+                                                    (224, 2, 2, 0), (225, 2, 2, 0),
                                                     (64, 8, 4, 65000), (64, 8, 4, 70000)])
 def test_generic_kernel_other_sizes_vs_oracle(S, A, n_task, obs_offset):
-    """block-count boundaries of the fence path (S = 7: one block; S = 112: 16 blocks, the last fence line that
-    fits; S = 113 and S = 256: per-lane binary search) and observation ids at the 16-bit metadata limit
-    (ids < 65536 stay on the fence path, larger ones fall back)"""
+    """block-count boundaries of the fence path (S = 7: one block; S = 112: 16 blocks, one per fence entry; S = 113
+    .. 224: two blocks per fence entry; S = 225 .. 256: three) and observation ids at the 16-bit metadata limit
+    (ids < 65536 stay on the fence path, larger ones fall back to the per-lane binary search); every case is also
+    run with search = binary"""
     tab = oracle.anymdp_synth(seed=5, task_index_base=0, n_task=n_task, S=S, A=A, s0_max=3)
     tab["state_map"] = tab["state_map"] + np.int32(obs_offset)
     n_env = 50 * n_task
     env_task = np.repeat(np.arange(n_task, dtype=np.int32), 50)
     env = AnyMDPVecEnv(n_env, autoreset_mode="same_step")
     env.set_task(_dev_tables(tab), env_task_index=env_task)
-    expect_fast = S <= 112 and obs_offset + S <= 65536
+    expect_fast = obs_offset + S <= 65536
     if expect_fast:
         env.set_search("fence")
     else:
@@ -233,8 +235,14 @@ def test_generic_kernel_other_sizes_vs_oracle(S, A, n_task, obs_offset):
     u0 = rng.random_sample(n_env)
     assert np.array_equal(_np(env.reset_injected(u0)), ora.reset_injected(u0))
     for t in range(80):
+        if t == 40:
+            env.set_search("binary")       # the same states continue on the per-lane path
         a = rng.randint(0, A, n_env).astype(np.int32)
         u, z, ur = rng.random_sample(n_env), rng.standard_normal(n_env).astype(np.float32), rng.random_sample(n_env)
+        if t % 3 == 0:                     # exact CDF entries, incl. the fence values at block-group edges
+            k = rng.randint(0, n_env, 8)
+            rows = tab["cdf"][env_task[k], ora.state[k], a[k]]
+            u[k] = np.minimum(rows[np.arange(8), rng.randint(0, S, 8)], np.nextafter(1.0, 0.0))
         _compare_step(env.step_injected(a, u, z, ur), ora.step_injected(a, u, z, ur, 2))
     env.close()
 
@@ -508,7 +516,7 @@ def test_teacher_rollout_on_device():
 # state, u exactly on / one ulp around every stored entry.  Expected: numpy.searchsorted(cdf, u, 'right').
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("search", ["fence", "binary"])
-@pytest.mark.parametrize("S", [7, 8, 20, 64])
+@pytest.mark.parametrize("S", [7, 8, 20, 64, 130, 250])
 def test_adversarial_rows_match_searchsorted(S, search):
     rng = np.random.RandomState(S)
     A = 2
@@ -533,7 +541,8 @@ def test_adversarial_rows_match_searchsorted(S, search):
     cdf = cdf / cdf[..., -1:]
     rs = rng.standard_normal((1, S, A, S, 2)).astype(np.float32)
     tab = dict(S=S, A=A, s0_max=1, cdf=cdf[None], rs=rs, state_map=rng.permutation(S).astype(np.int32)[None],
-               term_mask=np.zeros((1, 1), np.uint64), s0_cdf=np.ones((1, 1)), s0_ids=np.zeros((1, 1), np.int32),
+               term_mask=np.zeros((1, (S + 63) // 64), np.uint64), s0_cdf=np.ones((1, 1)),
+               s0_ids=np.zeros((1, 1), np.int32),
                max_steps=np.array([10 ** 6], np.int32))
     # every (row, probe): u on each stored entry, one ulp below / above, 0, tiny, just below 1
     probes, rows_sa = [], []
@@ -554,7 +563,8 @@ def test_adversarial_rows_match_searchsorted(S, search):
     obs, r, term, trunc, info = env.step_injected(sa[:, 1].astype(np.int32), u, np.zeros(n, np.float32), np.zeros(n))
     exp = np.array([min(int(np.searchsorted(cdf[s, a], uu, side="right")), S - 1) for (s, a), uu in zip(sa, u)])
     got = _np(env.inner_state)
-    assert np.array_equal(got, exp)
+    bad = np.nonzero(got != exp)[0]
+    assert len(bad) == 0, (len(bad), [(int(sa[b, 0]), int(sa[b, 1]), float(u[b]), int(got[b]), int(exp[b])) for b in bad[:12]])
     assert np.array_equal(_np(obs), tab["state_map"][0][exp])
     assert np.array_equal(_np(info["reward_gt"]), rs[0, sa[:, 0], sa[:, 1], exp, 0])
     assert env.check_errors() == 0

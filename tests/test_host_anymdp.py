@@ -68,8 +68,9 @@ def test_blocked_row_layout(S):
     cdf = np.sort(rng.random_sample((2, 3, S)), axis=-1)
     rs = rng.standard_normal((2, 3, S, 2)).astype(np.float32)
     rows = to_blocked(cdf, rs)
-    NB = (S + 6) // 7
-    assert row_lines(S) == 1 + NB
+    from xenoverse_amd.anymdp.tables import row_blocks
+    NB = row_blocks(S)        # ceil(S/7) rounded up to a multiple of G = ceil(ceil(S/7)/16)
+    assert NB >= (S + 6) // 7 and NB % ((((S + 6) // 7) + 15) // 16) == 0 and row_lines(S) == 1 + NB
     assert rows.shape == (2, 3, 1 + NB, 16) and rows.dtype == np.float64
     raw = rows.view(np.uint8).reshape(2, 3, 1 + NB, 128)
     for j in sorted({0, 1, min(6, S - 1), S // 2, S - 1}):   # entry j: block j // 7, slot j % 7, 16 bytes
@@ -77,8 +78,7 @@ def test_blocked_row_layout(S):
         assert np.array_equal(np.ascontiguousarray(ent[..., :8]).view(np.float64)[..., 0], cdf[..., j])
         assert np.array_equal(np.ascontiguousarray(ent[..., 8:]).view(np.float32), rs[..., j, :])
     assert np.all(raw[:, :, 0, :] == 0) and np.all(raw[:, :, 1:, 112:] == 0)   # fence / metadata: the engine's
-    if S % 7:
-        pad = np.ascontiguousarray(raw[:, :, NB, 16 * (S % 7):112]).view(np.float64).reshape(2, 3, -1, 2)
-        assert np.all(pad[..., 0] == 2.0) and np.all(pad[..., 1] == 0.0)      # padding never compares <= u
+    ent_all = np.ascontiguousarray(raw[:, :, 1:, :112]).view(np.float64).reshape(2, 3, NB * 7, 2)
+    assert np.all(ent_all[:, :, S:, 0] == 2.0) and np.all(ent_all[:, :, S:, 1] == 0.0)   # padding never compares <= u
     c2, r2 = from_blocked(rows, S)
     assert np.array_equal(c2, cdf) and np.array_equal(r2, rs)

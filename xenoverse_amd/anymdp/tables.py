@@ -57,22 +57,30 @@ def row_cdf(T):
 BLK = 7          # next states per 128-byte block (include/xeno.h, "rows")
 
 
+def row_blocks(S):
+    """Blocks per row record: ceil(S/7), rounded up to a multiple of G = ceil(blocks/16) — a fence entry names G whole
+    blocks, so the 16-entry fence line covers any S <= 256 (G = 1 up to S = 112, 2 up to 224, 3 beyond)."""
+    nb = (S + BLK - 1) // BLK
+    g = (nb + 15) // 16
+    return (nb + g - 1) // g * g
+
+
 def row_lines(S):
-    """Lines of 128 bytes per row record: the fence line + ceil(S/7) blocks (XV_ANYMDP_ROW_LINES)."""
-    return 1 + (S + BLK - 1) // BLK
+    """Lines of 128 bytes per row record: the fence line + row_blocks(S) blocks (XV_ANYMDP_ROW_LINES)."""
+    return 1 + row_blocks(S)
 
 
 def to_blocked(cdf, rs):
     """Flat per-row arrays -> the device's row records (include/xeno.h, "rows").
 
-    cdf float64[..., S], rs float32[..., S, 2]  ->  float64[..., 1 + NB, 16] with NB = ceil(S/7): line 1+b holds
+    cdf float64[..., S], rs float32[..., S, 2]  ->  float64[..., 1 + NB, 16] with NB = row_blocks(S): line 1+b holds
     7 entries of {cdf (8 B), reward, noise (4 B each)} for next states 7b..7b+6; entries past S hold cdf 2.0
     (never <= u) and a zero pair.  Line 0 (fence) and the last 16 bytes of every block (observation ids and
     terminal flags) are left zero: xv_anymdp_create completes them on the device."""
     cdf = np.asarray(cdf, np.float64)
     rs = np.asarray(rs, np.float32)
     S = cdf.shape[-1]
-    NB = (S + BLK - 1) // BLK
+    NB = row_blocks(S)
     lead = cdf.shape[:-1]
     c = np.full(lead + (NB * BLK,), 2.0, np.float64)
     c[..., :S] = cdf

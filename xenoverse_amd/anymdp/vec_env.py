@@ -71,6 +71,12 @@ class AnyMDPVecEnv(VectorEnv):
             assert dev[k].dtype == _TABLE_DTYPES[k], (k, dev[k].dtype)
         S, A, s0_max = int(tab["S"]), int(tab["A"]), int(tab["s0_max"])
         n_task = int(dev["max_steps"].shape[0])
+        from .tables import row_lines
+        want = dict(rows=(n_task, S, A, row_lines(S), 16), state_map=(n_task, S), term_mask=(n_task, (S + 63) // 64),
+                    s0_cdf=(n_task, s0_max), s0_ids=(n_task, s0_max), max_steps=(n_task,))
+        for k, shp in want.items():      # the device reads these extents: a short table is an out-of-bounds read
+            if tuple(dev[k].shape) != shp:
+                raise ValueError("table %r has shape %s, expected %s" % (k, tuple(dev[k].shape), shp))
         if env_task_index is None:
             if self.num_envs % n_task != 0:
                 raise ValueError("num_envs (%d) is not a multiple of the task count (%d); pass "

@@ -42,16 +42,16 @@ struct AnyMDPArgs {
   // engine-owned per-env reset record (fast path), struct-of-arrays
   const double2* rs_c01;     // s0_cdf[0], s0_cdf[1]   (padded with 1.0)
   const double* rs_c2;       // s0_cdf[2]
-  const uint32_t* rs_ids;    // 4 x u8: inner state id (7 bits) | terminal flag << 7, padded with the last
+  const uint32_t* rs_ids;    // 4 x u8 inner state ids of s_0, padded with the last
   const uint2* rs_obs;       // 4 x u16 observation ids of those states
-  const int32_t* rs_max_steps;
+  const int32_t* rs_max_steps;   // bits 0..26 max_steps, bits 27..30 terminal flags of those four states
   // engine-owned env state
   int32_t* state;
   int32_t* steps;
   uint8_t* need_reset;
   uint8_t* cur_term;         // current inner state is terminal (the reference raises when stepping from it, :95-96)
   uint32_t* err;
-  int n_env, n_task, S, A, s0_max, words, NB, RL;   // RL = 1 + NB lines per row
+  int n_env, n_task, S, A, s0_max, words, NB, RL, G;   // RL = 1 + NB lines per row; G blocks per fence entry
   uint64_t seed, gid_base, tick;
   const uint64_t* tick_dev;   // graph replay: the launch tick is *tick_dev + tick (tick = node index); else nullptr
 };
@@ -130,10 +130,14 @@ __device__ __forceinline__ double xv_u2d(uint32_t lo, uint32_t hi) { return __hi
 
 // T_steps == 1: one vector step.  T_steps > 1: fused rollout, io arrays are [T][n_env], mode SAME_STEP.
 // FAST: fence line + block line, per-env reset record; otherwise per-lane binary search and per-task tables.
+// G: 0 = per-lane binary search and per-task tables; 1..3 = fence path, a fence entry names G consecutive blocks
+//    (G = 1 for S <= 112, 2 for S <= 224, 3 beyond: the fence always fits one line, the last level reads G lines).
 // TICKDEV: the launch tick is *P.tick_dev + P.tick (graph replay); otherwise P.tick (a kernel argument).
-template <bool INJECT, bool FAST, bool ROLLOUT, bool TICKDEV = false>
+template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false>
 __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPStepIO io, int T_steps,
                                                           int mode) {
+  constexpr bool FAST = G > 0;
+  constexpr int GG = G > 0 ? G : 1;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < P.n_env;
   const int ic = valid ? i : P.n_env - 1;
@@ -156,10 +160,13 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
   uint32_t rids = 0;
   uint2 robs = make_uint2(0u, 0u);
   int max_steps;
+  uint32_t s0_term = 0;
   uint64_t tm0 = 0;
   if (FAST) {
     rc01 = P.rs_c01[ic]; rc2 = P.rs_c2[ic]; rids = P.rs_ids[ic]; robs = P.rs_obs[ic];
-    max_steps = P.rs_max_steps[ic];
+    max_steps = P.rs_max_steps[ic];   // bits 0..26: max_steps, bits 27..30: terminal flags of the four s_0 states
+    s0_term = ((uint32_t)max_steps >> 27) & 0xFu;
+    max_steps &= 0x7FFFFFF;
   } else {
     max_steps = P.max_steps[t];
     tm0 = P.term_mask[(size_t)t * P.words];
@@ -229,14 +236,17 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
         const int cnt = __popc((unsigned)(m0 >> (8 * j)) & 0xFFu) + __popc((unsigned)(m1 >> (8 * j)) & 0xFFu);
         if (g == it) k_own = cnt;
       }
-      k_own = k_own < P.NB - 1 ? k_own : P.NB - 1;   // fences of absent blocks hold 2.0: cannot exceed
-      // link 3: the block
-      const uint32_t bl = fl + 1u + (uint32_t)k_own;
+      const int NF = P.NB / GG;
+      k_own = k_own < NF - 1 ? k_own : NF - 1;       // fences of absent groups hold 2.0: cannot exceed
+      // link 3: the GG block lines the fence entry names
+      const uint32_t bl = fl + 1u + (uint32_t)k_own * GG;
 #pragma unroll
       for (int it = 0; it < 8; ++it) li[it] = (uint32_t)__shfl((int)bl, it * 8 + g);
-      uint4 bv[8];
+      uint4 bv[8][GG];
 #pragma unroll
-      for (int it = 0; it < 8; ++it) bv[it] = P.lines[(size_t)li[it] * 8 + j];
+      for (int it = 0; it < 8; ++it)
+#pragma unroll
+        for (int q = 0; q < GG; ++q) bv[it][q] = P.lines[((size_t)li[it] + q) * 8 + j];
       if (ROLLOUT && io.action && ts + 1 < T) a_next = io.action[o + P.n_env];   // prefetch behind the blocks
       __builtin_amdgcn_sched_barrier(0);
       int cnt_own = 0;
@@ -244,22 +254,43 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       uint32_t meta_own = 0;
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        // unit 7 of a block is its metadata, not an entry
-        const unsigned long long m = __ballot(j < 7 && xv_u2d(bv[it].x, bv[it].y) <= ue[it]);
-        // reader side: the count of the env this lane group serves; the metadata lane extracts that entry's
-        // observation id and terminal flag, so the owner needs ONE word from it
-        int cg = __popc((unsigned)(m >> (8 * g)) & 0x7Fu);
-        cg = cg < 6 ? cg : 6;
-        const uint32_t mw = cg < 2 ? bv[it].x : (cg < 4 ? bv[it].y : (cg < 6 ? bv[it].z : bv[it].w));
-        const uint32_t packed = ((mw >> (16 * (cg & 1))) & 0xFFFFu) | (((bv[it].w >> (16 + cg)) & 1u) << 16);
-        // owner side: lane 8*it+q owns the env whose line sits in lanes 8q..8q+7
-        int co = __popc((unsigned)(m >> (8 * j)) & 0x7Fu);
-        const int cc = co < 6 ? co : 6;
-        const float px = __shfl(__uint_as_float(bv[it].z), 8 * j + cc);
-        const float py = __shfl(__uint_as_float(bv[it].w), 8 * j + cc);
+        // unit 7 of a block is its metadata, not an entry.  cg: the count of the env this lane group serves
+        // (reader side); co: the count of the env this lane owns, whose lines sit in lanes 8q..8q+7 (owner side)
+        int cg = 0, co = 0;
+#pragma unroll
+        for (int q = 0; q < GG; ++q) {
+          const unsigned long long m = __ballot(j < 7 && xv_u2d(bv[it][q].x, bv[it][q].y) <= ue[it]);
+          cg += __popc((unsigned)(m >> (8 * g)) & 0x7Fu);
+          co += __popc((unsigned)(m >> (8 * j)) & 0x7Fu);
+        }
+        // the metadata lane extracts the chosen entry's observation id and terminal flag: the owner needs ONE word
+        int lg = cg / XV_ANYMDP_BLK;
+        lg = lg < GG - 1 ? lg : GG - 1;
+        int sg = cg - XV_ANYMDP_BLK * lg;
+        sg = sg < 6 ? sg : 6;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int q = 0; q < GG; ++q) {
+          const uint4 b4 = bv[it][q];
+          const uint32_t mw = sg < 2 ? b4.x : (sg < 4 ? b4.y : (sg < 6 ? b4.z : b4.w));
+          const uint32_t pk = ((mw >> (16 * (sg & 1))) & 0xFFFFu) | (((b4.w >> (16 + sg)) & 1u) << 16);
+          if (q == lg) packed = pk;
+        }
+        int lo_ = co / XV_ANYMDP_BLK;
+        lo_ = lo_ < GG - 1 ? lo_ : GG - 1;
+        int so = co - XV_ANYMDP_BLK * lo_;
+        so = so < 6 ? so : 6;
+        float px = 0.0f, py = 0.0f;
+#pragma unroll
+        for (int q = 0; q < GG; ++q) {
+          const float x = __shfl(__uint_as_float(bv[it][q].z), 8 * j + so);
+          const float y = __shfl(__uint_as_float(bv[it][q].w), 8 * j + so);
+          if (q == lo_) { px = x; py = y; }
+        }
         const uint32_t pm = (uint32_t)__shfl((int)packed, 8 * j + 7);
         if (g == it) { cnt_own = co; rx = px; ry = py; meta_own = pm; }
       }
+      k_own *= GG;
       s2 = XV_ANYMDP_BLK * k_own + cnt_own;
       s2 = s2 < S - 1 ? s2 : S - 1;
       rsv = make_float2(rx, ry);
@@ -318,9 +349,8 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       if (FAST) {
         // upper_bound over the 4 padded CDF entries; ids, terminal flags and observation ids come packed
         const int k0 = (int)(rc01.x <= u_reset) + (int)(rc01.y <= u_reset) + (int)(rc2 <= u_reset);
-        const uint32_t idb = (rids >> (8 * k0)) & 0xFFu;
-        s = (int)(idb & 0x7Fu);
-        cterm = (int)(idb >> 7);
+        s = (int)((rids >> (8 * k0)) & 0xFFu);
+        cterm = (int)((s0_term >> k0) & 1u);
         o_obs = (int)(((k0 < 2 ? robs.x : robs.y) >> (16 * (k0 & 1))) & 0xFFFFu);
       } else {
         s = anymdp_draw_s0(P, t, u_reset);
@@ -348,19 +378,22 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
   if (err) atomicOr(P.err, err);
 }
 
-// Completes the rows in place (create time): fence line and per-block metadata.  One thread per (row, k < 16).
-//   fence[k] = CDF entry of the last next-state of block k for k < NB-1, else 2.0 (never <= u)
-//   meta of block k = {u16 obs[7]; u8 term_bits; u8 0} of next states 7k..7k+6 (clamped to S-1, as s' is)
+// Completes the rows in place (create time): fence line and per-block metadata.  One thread per (row, k < 64).
+//   fence[k] (k < 16) = CDF entry of the last next-state of block group k (G blocks) for k < NB/G - 1, else 2.0
+//   meta of block k (k < NB) = {u16 obs[7]; u8 term_bits; u8 0} of next states 7k..7k+6 (clamped to S-1, as s' is)
 __global__ __launch_bounds__(256) void anymdp_finish_rows_kernel(AnyMDPArgs P, uint4* lines_rw, size_t n_rows) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n_rows * 16) return;
-  const size_t r = idx >> 4;
-  const int k = (int)(idx & 15);
+  if (idx >= n_rows * 64) return;
+  const size_t r = idx >> 6;
+  const int k = (int)(idx & 63);
   const int t = (int)(r / ((size_t)P.S * P.A));
   uint4* row = lines_rw + r * (size_t)P.RL * 8;
-  double f = 2.0;
-  if (k < P.NB - 1) f = reinterpret_cast<const double*>(row + (size_t)(1 + k) * 8 + (XV_ANYMDP_BLK - 1))[0];
-  reinterpret_cast<double*>(row)[k] = f;
+  if (k < 16) {
+    double f = 2.0;
+    if (k < P.NB / P.G - 1)
+      f = reinterpret_cast<const double*>(row + (size_t)(1 + P.G * (k + 1) - 1) * 8 + (XV_ANYMDP_BLK - 1))[0];
+    reinterpret_cast<double*>(row)[k] = f;
+  }
   if (k < P.NB) {
     uint32_t w[4] = {0, 0, 0, 0};
     uint32_t tb = 0;
@@ -383,12 +416,13 @@ __global__ __launch_bounds__(256) void anymdp_env_records_kernel(AnyMDPArgs P, d
   if (i >= P.n_env) return;
   const int t = P.env_task[i];
   double c[4];
-  uint32_t idw = 0, ob[4];
+  uint32_t idw = 0, tbits = 0, ob[4];
   for (int k = 0; k < 4; ++k) {
     const int kk = k < P.s0_max ? k : P.s0_max - 1;
     const int sid = P.s0_ids[(size_t)t * P.s0_max + kk];
     const uint32_t tb = (P.term_mask[(size_t)t * P.words + (sid >> 6)] >> (sid & 63)) & 1ull ? 1u : 0u;
-    idw |= (((uint32_t)sid & 0x7Fu) | (tb << 7)) << (8 * k);
+    idw |= ((uint32_t)sid & 0xFFu) << (8 * k);
+    tbits |= tb << k;
     ob[k] = (uint32_t)P.state_map[(size_t)t * P.S + sid] & 0xFFFFu;
     c[k] = k < P.s0_max ? P.s0_cdf[(size_t)t * P.s0_max + k] : 1.0;
   }
@@ -396,7 +430,7 @@ __global__ __launch_bounds__(256) void anymdp_env_records_kernel(AnyMDPArgs P, d
   c2[i] = c[2];
   ids[i] = idw;
   obs[i] = make_uint2(ob[0] | (ob[1] << 16), ob[2] | (ob[3] << 16));
-  max_steps[i] = P.max_steps[t];
+  max_steps[i] = (int32_t)(((uint32_t)P.max_steps[t] & 0x7FFFFFFu) | (tbits << 27));
 }
 
 // cur_term[i] = (state[i] in s_e), after xv_anymdp_set_state
@@ -736,7 +770,10 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
   XV_CHECK_ARG(n_env > 0 && n_task > 0);
   XV_CHECK_ARG(S >= 2 && S <= 256 && A >= 2 && A <= 64 && s0_max >= 1 && s0_max <= 256);
   XV_CHECK_ARG(rows && state_map && term_mask && s0_cdf && s0_ids && max_steps && env_task);
-  const int NB = (S + XV_ANYMDP_BLK - 1) / XV_ANYMDP_BLK, RL = 1 + NB;
+  // blocks per row: ceil(S/7), rounded up to a multiple of G = ceil(blocks/16) so that a fence entry always names
+  // G whole blocks (XV_ANYMDP_ROW_LINES)
+  const int NB0 = (S + XV_ANYMDP_BLK - 1) / XV_ANYMDP_BLK, G = (NB0 + 15) / 16;
+  const int NB = (NB0 + G - 1) / G * G, RL = 1 + NB;
   XV_CHECK_ARG((uint64_t)n_task * S * A * RL < 0xFFFFFFFFull);  // line index is a 32-bit word on the device
   XV_HIP(hipSetDevice(e->device));
   xv_anymdp* h = new (std::nothrow) xv_anymdp();
@@ -756,12 +793,12 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
   a.lines = (const uint4*)rows; a.state_map = state_map; a.term_mask = term_mask;
   a.s0_cdf = s0_cdf; a.s0_ids = s0_ids; a.max_steps = max_steps; a.env_task = env_task;
   a.n_env = n_env; a.n_task = n_task; a.S = S; a.A = A; a.s0_max = s0_max; a.words = (S + 63) / 64;
-  a.NB = NB; a.RL = RL;
+  a.NB = NB; a.RL = RL; a.G = G;
   a.err = e->d_err;
   a.seed = e->seed; a.gid_base = e->env_id_base; a.tick = 0;
 
-  // the fast path needs a fence that fits one line (NB <= 16), s0_max <= 4 and observation ids that fit 16 bits
-  bool fast = (NB <= 16 && s0_max <= 4);
+  // the fast path needs s0_max <= 4, observation ids that fit 16 bits and max_steps < 2^27 (checked below)
+  bool fast = (G <= 3 && s0_max <= 4);
   if (fast) {
     int* d_max = nullptr;
     int h_max = 0;
@@ -774,6 +811,18 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
     XV_HIP(hipStreamSynchronize(e->stream));
     XV_HIP(hipFree(d_max));
     fast = h_max < 65536;
+  }
+  if (fast) {   // max_steps shares its per-env word with four flags: it must fit 27 bits
+    int* d_max = nullptr;
+    int h_max = 0;
+    XV_HIP(hipMalloc(&d_max, sizeof(int)));
+    XV_HIP(hipMemsetAsync(d_max, 0, sizeof(int), e->stream));
+    hipLaunchKernelGGL(anymdp_max_obs_kernel, dim3((unsigned)((n_task + 255) / 256)), dim3(256), 0, e->stream, max_steps,
+                       (size_t)n_task, d_max);
+    XV_HIP(hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    XV_HIP(hipStreamSynchronize(e->stream));
+    XV_HIP(hipFree(d_max));
+    fast = h_max < (1 << 27);
   }
 
   double2* c01 = nullptr; double* c2 = nullptr; uint32_t* ids = nullptr; uint2* robs = nullptr; int32_t* rms = nullptr;
@@ -799,8 +848,8 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
     return XV_ERR_HIP;
   }
   if (fast) {
-    XV_CHECK_ARG(n_rows * 16 / 256 + 1 < 0x7FFFFFFFull);
-    hipLaunchKernelGGL(anymdp_finish_rows_kernel, dim3((unsigned)((n_rows * 16 + 255) / 256)), dim3(256), 0, e->stream, a,
+    XV_CHECK_ARG(n_rows * 64 / 256 + 1 < 0x7FFFFFFFull);
+    hipLaunchKernelGGL(anymdp_finish_rows_kernel, dim3((unsigned)((n_rows * 64 + 255) / 256)), dim3(256), 0, e->stream, a,
                        (uint4*)rows, n_rows);
     hipLaunchKernelGGL(anymdp_env_records_kernel, dim3(xv_div_up(n_env, 256)), dim3(256), 0, e->stream, a, c01, c2, ids,
                        robs, rms);
@@ -855,14 +904,18 @@ extern "C" int xv_anymdp_reset_injected(xv_anymdp* h, const uint8_t* mask, const
 template <bool INJECT>
 static int anymdp_launch_step(xv_anymdp* h, const AnyMDPStepIO& io, int T, int mode) {
   const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
-#define XV_LAUNCH_STEP(FAST, ROLL)                                                                \
-  hipLaunchKernelGGL((anymdp_step_kernel<INJECT, FAST, ROLL>), grid, block, 0, h->eng->stream, h->a, io, T, mode)
+#define XV_LAUNCH_STEP(GV, ROLL)                                                                  \
+  hipLaunchKernelGGL((anymdp_step_kernel<INJECT, GV, ROLL>), grid, block, 0, h->eng->stream, h->a, io, T, mode)
+#define XV_LAUNCH_STEP_G(GV) do { if (roll) XV_LAUNCH_STEP(GV, true); else XV_LAUNCH_STEP(GV, false); } while (0)
   const bool roll = T > 1 || io.greedy != nullptr;
   if (h->fast && h->search != XV_ANYMDP_SEARCH_BINARY) {
-    if (roll) XV_LAUNCH_STEP(true, true); else XV_LAUNCH_STEP(true, false);
+    if (h->a.G == 1) XV_LAUNCH_STEP_G(1);
+    else if (h->a.G == 2) XV_LAUNCH_STEP_G(2);
+    else XV_LAUNCH_STEP_G(3);
   } else {
-    if (roll) XV_LAUNCH_STEP(false, true); else XV_LAUNCH_STEP(false, false);
+    XV_LAUNCH_STEP_G(0);
   }
+#undef XV_LAUNCH_STEP_G
 #undef XV_LAUNCH_STEP
   XV_LAUNCH_CHECK();
   return XV_OK;
@@ -906,8 +959,10 @@ static bool anymdp_ensure_graph(xv_anymdp* h, int period, const int32_t* actions
   if (hipGraphCreate(&h->graph, 0) != hipSuccess) return false;
   const size_t n = (size_t)h->a.n_env;
   const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
-  void* fn = fast ? reinterpret_cast<void*>(&anymdp_step_kernel<false, true, false, true>)
-                  : reinterpret_cast<void*>(&anymdp_step_kernel<false, false, false, true>);
+  void* fn = !fast ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 0, false, true>)
+             : h->a.G == 1 ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 1, false, true>)
+             : h->a.G == 2 ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 2, false, true>)
+                           : reinterpret_cast<void*>(&anymdp_step_kernel<false, 3, false, true>);
   hipGraphNode_t prev = nullptr;
   for (int j = 0; j <= period; ++j) {
     hipKernelNodeParams np;
@@ -1054,7 +1109,7 @@ extern "C" int xv_anymdp_set_search(xv_anymdp* h, int search) {
   XV_CHECK_ARG(search == XV_ANYMDP_SEARCH_AUTO || search == XV_ANYMDP_SEARCH_BINARY ||
                search == XV_ANYMDP_SEARCH_FENCE);
   if (search == XV_ANYMDP_SEARCH_FENCE && !h->fast) {
-    xv_set_error("xv_anymdp_set_search: FENCE needs S <= 112, s0_max <= 4 and observation ids < 65536");
+    xv_set_error("xv_anymdp_set_search: FENCE needs s0_max <= 4, observation ids < 65536 and max_steps < 2^27");
     return XV_ERR_UNSUPPORTED;
   }
   h->search = search;

@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256) void anymdp_synth_rows_kernel(uint64_t seed, i
   uint32_t carry = 0;
   // row record: include/xeno.h "rows" — line 0 (fence) and the metadata unit of each block are completed by
   // xv_anymdp_create; here only the 16-byte entries {cdf, reward, noise}, 7 per 128-byte block
-  const int NB = (S + 6) / 7;
+  const int NB0 = (S + 6) / 7, G = (NB0 + 15) / 16;
+  const int NB = (NB0 + G - 1) / G * G;   // XV_ANYMDP_ROW_LINES(S) - 1
   uint4* row = reinterpret_cast<uint4*>(rows) + wave * (size_t)(1 + NB) * 8;
   for (int c = 0; c < chunks; ++c) {
     const int j = c * 64 + lane;
