@@ -1,6 +1,6 @@
 """Import the Python reference (/root/reference) inside THIS build container only.
 
-Test tooling: used by oracle/gen_golden.py and oracle/check_against_reference.py to validate the
+Test tooling: used by oracle/gen_golden.py and oracle/sample_ref_tasks.py to validate the
 restatement in oracle/ and to emit the fixtures under tests/golden/.  Nothing here, and nothing
 under /root/reference, travels to the GPU box or is imported by the product or by tests.
 
