@@ -677,3 +677,23 @@ def test_device_value_iteration_vs_numpy(case):
     st = _np(env.get_state()[0])
     assert out["action"].shape == (8, n_task * 2) and st.shape == (n_task * 2,)
     env.close()
+
+
+def test_bandit_tasks_terminate_every_step():
+    from xenoverse_amd.anymdp import AnyMDPTaskSampler
+    tasks = [AnyMDPTaskSampler(1, 4, seed=k) for k in range(3)]
+    n = 96
+    env = AnyMDPVecEnv(n, autoreset_mode="same_step", seed=2)
+    env.set_task(tasks)
+    obs, _ = env.reset()
+    exp_obs = np.repeat([int(t["state_mapping"][0]) for t in tasks], n // 3)
+    assert np.array_equal(_np(obs), exp_obs)
+    rng = np.random.RandomState(0)
+    for _ in range(5):
+        a = rng.randint(0, 4, n).astype(np.int32)
+        obs, r, term, trunc, info = env.step(a)
+        assert _np(term).all() and np.array_equal(_np(obs), exp_obs) and np.array_equal(_np(info["final_obs"]), exp_obs)
+        rgt = np.array([tasks[i // (n // 3)]["reward"][0, a[i], 0] for i in range(n)], np.float32)
+        assert np.array_equal(_np(info["reward_gt"]), rgt)
+    assert env.check_errors() == 0
+    env.close()

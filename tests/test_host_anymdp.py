@@ -82,3 +82,16 @@ def test_blocked_row_layout(S):
     assert np.all(ent_all[:, :, S:, 0] == 2.0) and np.all(ent_all[:, :, S:, 1] == 0.0)   # padding never compares <= u
     c2, r2 = from_blocked(rows, S)
     assert np.array_equal(c2, cdf) and np.array_equal(r2, rs)
+
+
+def test_bandit_task_is_embedded_in_two_states():
+    """state_space = 1 (multi-armed bandit): the reference terminates every step; the tables hold the state and an
+    absorbing terminal copy of it"""
+    from xenoverse_amd.anymdp import AnyMDPTaskSampler
+    t = AnyMDPTaskSampler(1, 5, seed=0)
+    tab = build_tables([t])
+    assert tab["S"] == 2 and tab["A"] == 5
+    assert np.array_equal(tab["cdf"][0, 0], np.tile([0.0, 1.0], (5, 1)))
+    assert np.array_equal(tab["rs"][0, 0, :, 1, 0], t["reward"][0, :, 0].astype(np.float32))
+    assert int(tab["term_mask"][0, 0]) == 2 and tab["state_map"][0, 0] == tab["state_map"][0, 1]
+    assert tab["s0_ids"][0, 0] == 0 and tab["max_steps"][0] == 1

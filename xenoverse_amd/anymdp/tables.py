@@ -120,7 +120,10 @@ def build_tables(tasks, s0_max=None, validate=True):
         if int(t["na"]) != A:
             raise ValueError("all tasks of one batch must share the action space size `na`")
     n_list = [int(np.asarray(t["transition"]).shape[0]) for t in tasks]
-    S = max(n_list)
+    # single-state tasks (multi-armed bandits, state_space = 1): the reference terminates every step (`ns < 2`,
+    # anymdp_env.py:107-108).  They are embedded in two inner states: 0 = the state, 1 = an absorbing terminal copy
+    # of it with the same observation id; every action moves 0 -> 1 and carries R[0, a, 0].
+    S = max(max(n_list), 2)
     if not (2 <= S <= S_MAX) or not (2 <= A <= A_MAX):
         raise ValueError(f"unsupported sizes S={S}, A={A} (need 2<=S<={S_MAX}, 2<=A<={A_MAX})")
     k_max = max(len(np.atleast_1d(t["s_0"])) for t in tasks)
@@ -140,12 +143,19 @@ def build_tables(tasks, s0_max=None, validate=True):
     obs_space = np.zeros(n_task, np.int32)
     for i, t in enumerate(tasks):
         n = n_list[i]
-        cdf[i, :n, :, :n] = row_cdf(t["transition"])
-        rs[i, :n, :, :n, 0] = np.asarray(t["reward"], np.float64)
-        rs[i, :n, :, :n, 1] = np.asarray(t["reward_noise"], np.float64)
-        state_map[i, :n] = np.asarray(t["state_mapping"], np.int64)
-        for s in np.asarray(t["s_e"], np.int64).reshape(-1):
-            term_mask[i, int(s) >> 6] |= np.uint64(1) << np.uint64(int(s) & 63)
+        if n == 1:
+            cdf[i, 0, :, 0] = 0.0          # cdf = [0, 1, 1, ...]: upper_bound(u) = 1 for every u in [0, 1)
+            rs[i, 0, :, 1, 0] = np.asarray(t["reward"], np.float64)[0, :, 0]
+            rs[i, 0, :, 1, 1] = np.asarray(t["reward_noise"], np.float64)[0, :, 0]
+            state_map[i, :2] = int(np.asarray(t["state_mapping"], np.int64).reshape(-1)[0])
+            term_mask[i, 0] |= np.uint64(2)
+        else:
+            cdf[i, :n, :, :n] = row_cdf(t["transition"])
+            rs[i, :n, :, :n, 0] = np.asarray(t["reward"], np.float64)
+            rs[i, :n, :, :n, 1] = np.asarray(t["reward_noise"], np.float64)
+            state_map[i, :n] = np.asarray(t["state_mapping"], np.int64)
+            for s in np.asarray(t["s_e"], np.int64).reshape(-1):
+                term_mask[i, int(s) >> 6] |= np.uint64(1) << np.uint64(int(s) & 63)
         s0 = np.atleast_1d(np.asarray(t["s_0"], np.int64))
         p0 = np.atleast_1d(np.asarray(t["s_0_prob"], np.float64))
         c0 = np.cumsum(p0)
