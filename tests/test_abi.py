@@ -73,3 +73,18 @@ def test_graft_entry_build_runs():
     """the driver's build hook: compiles (incrementally) every HIP source, the CPU checker, and loads the library"""
     import __graft_entry__ as ge
     ge.build()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/xeno.h is the contract for non-Python callers: it must compile as C99 on its own, and its row-size
+    macros must agree with the Python table builder"""
+    import subprocess
+    from xenoverse_amd.anymdp.tables import row_lines
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "h.c"
+    checks = " && ".join("XV_ANYMDP_ROW_LINES(%d) == %d" % (S, row_lines(S)) for S in (2, 7, 8, 64, 112, 113, 128, 224, 225, 256))
+    src.write_text('#include "xeno.h"\nint main(void) { return (%s) ? 0 : 1; }\n' % checks)
+    exe = str(tmp_path / "h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                           str(src), "-o", exe])
+    assert subprocess.call([exe]) == 0
