@@ -157,12 +157,13 @@ class LinDSVecEnv(VectorEnv):
         _lib.check(self.lib.xv_linds_get_state(self._h, None, _lib.ptr(self._steps), None))
         return self._steps.clone()
 
-    def _infos(self, with_final):
-        infos = {"steps": self._out(self._steps_now()), "command": self._o(self._user_obs(self._cmd)),
-                 "error": self._o(self._error)}
+    def _infos(self, with_final, fresh=False):
+        o = self._of if fresh else self._o      # fresh: the buffers were renewed before the launch (step paths)
+        infos = {"steps": self._out(self._steps_now()), "command": o(self._user_obs(self._cmd)),
+                 "error": o(self._error)}
         if with_final and self.autoreset_mode == "same_step":
-            infos["final_obs"] = self._o(self._user_obs(self._fobs))
-            infos["_final_obs"] = self._out((self._term | self._trunc).bool())
+            infos["final_obs"] = o(self._user_obs(self._fobs))
+            infos["_final_obs"] = self._out((self._term | self._trunc).view(torch.bool))
         return infos
 
     # -- API ----------------------------------------------------------------------------------------
@@ -194,13 +195,16 @@ class LinDSVecEnv(VectorEnv):
         if (not self.task_set) or self.need_reset:
             raise Exception("Must \"set_task\" and \"reset\" before doing any actions")   # linds_env.py:134-135
 
+    _STEP_OUTPUTS = ("_obs", "_reward", "_term", "_trunc", "_cmd", "_error", "_fobs")   # all fully written by a step
+
     def _ret(self):
-        return (self._o(self._user_obs(self._obs)), self._o(self._reward),
-                self._ob(self._term), self._ob(self._trunc), self._infos(True))
+        return (self._of(self._user_obs(self._obs)), self._of(self._reward),
+                self._obf(self._term), self._obf(self._trunc), self._infos(True, fresh=True))
 
     def step(self, actions):
         self._check_step()
         a = self._action(actions)
+        self._renew(*self._STEP_OUTPUTS)
         _lib.check(self.lib.xv_linds_step(self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward),
                                           _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._cmd),
                                           _lib.ptr(self._error), _lib.ptr(self._fobs),
@@ -217,6 +221,7 @@ class LinDSVecEnv(VectorEnv):
             p[:z.shape[0]] = z
             z = p
         idx = self._dev(init_index, torch.int32)
+        self._renew(*self._STEP_OUTPUTS)
         _lib.check(self.lib.xv_linds_step_injected(
             self._h, _lib.ptr(a), _lib.ptr(z.contiguous()), _lib.ptr(idx), _lib.ptr(self._obs),
             _lib.ptr(self._reward), _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._cmd),
