@@ -285,7 +285,9 @@ def main():
                        "device_error_flags": errs},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "anymdp_step_kernel<search=%s>" % search, "avg_launch_us": kern_us,
+                         "kernel": "anymdp_step_kernel<false, %d, false, false>  (INJECT, blocks per fence entry | "
+                                   "0 = binary search, ROLLOUT, TICKDEV)" % (1 if search == "fence" else 0),
+                         "avg_launch_us": kern_us,
                          "algorithmic_bytes_per_launch": algo},
         }
         if fused is not None:
