@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--gather-timeout", type=int, default=120, help="N>1: seconds allowed for the all-gather pass")
     ap.add_argument("--no-allgather", action="store_true",
                     help="N>1: skip the RCCL all-gather of rollout chunks (pure replicas)")
     ap.add_argument("--search", default="auto", choices=["auto", "binary", "fence"])
@@ -187,7 +188,9 @@ def main():
 
     # exchange step: all-gather of each finished T-step rollout chunk (14-B records) over RCCL,
     # on a side stream so that it overlaps the next chunk's stepping.  Stepping itself needs no collective.
-    do_gather = world > 1 and not args.no_allgather and dist_note is None
+    # the all-gather runs on device buffers: RCCL only (gloo would stage 16 MB per rank and chunk through the host)
+    do_gather = world > 1 and not args.no_allgather and dist_note is None and \
+        (dist.get_backend() == "nccl" or bool(os.environ.get("XV_BENCH_FORCE_GATHER")))   # the latter: watchdog tests
     gather = None
     gather_note = dist_note or "none"
     if do_gather:
@@ -239,13 +242,20 @@ def main():
 
     # pass 1 (the reported value): sharded stepping, no data-path collective — envs are independent
     wall, ev_ms = timed_pass(False)
-    # pass 2 (N > 1): the same with every finished rollout chunk all-gathered to all ranks, overlapped
+    # pass 2 (N > 1): the same with every finished rollout chunk all-gathered to all ranks, overlapped.  A watchdog
+    # guards it: should the collective stall, rank 0 still prints the pass-1 line (the measurement) and every rank exits.
     wall_g = None
+    state = {"emit": None}
     if gather is not None:
-        try:
-            wall_g, _ = timed_pass(True)
-        except Exception as ex:
-            gather_note += "; failed: %r" % (ex,)
+        import threading
+
+        def _bail():
+            if rank == 0 and state["emit"] is not None:
+                state["emit"]("all_gather pass did not finish within %d s: skipped" % args.gather_timeout)
+            os._exit(0)
+        state["pass1"] = (wall, ev_ms)
+        watchdog = threading.Timer(args.gather_timeout, _bail)
+        watchdog.daemon = True
     errs = env.check_errors()
 
     fused = None
@@ -262,7 +272,10 @@ def main():
         torch.cuda.synchronize()
         fused = n_env * T * reps / (f0.elapsed_time(f1) * 1e-3)
 
-    if rank == 0:
+    def report(extra_note=None):
+        if rank != 0 or state.get("done"):
+            return
+        state["done"] = True
         total_steps = world * n_env * args.steps
         kern_us = ev_ms * 1e3 / args.steps
         algo = ALGO_BYTES_PER_ENV_STEP[8] * n_env
@@ -281,7 +294,7 @@ def main():
                        "table_gib_per_gpu": round(n_task * S * A * (1 + (S + 6) // 7) * 128 / 2**30, 2),
                        "launch": "one step kernel per vector step (xv_anymdp_step_many)",
                        "search": search,
-                       "exchange": gather_note,
+                       "exchange": gather_note if extra_note is None else gather_note + "; " + extra_note,
                        "device_error_flags": errs},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -295,12 +308,22 @@ def main():
         if wall_g is not None:
             chunks = args.steps // P
             out["with_allgather"] = {"value": total_steps / wall_g, "unit": "env-steps/s",
-                                     "gathered_GB_per_s_per_rank": chunks * P * n_env * 14 * (world - 1) / wall_g / 1e9}
+                                     "gathered_GB_per_s_per_rank": chunks * P * n_env * REC_BYTES * (world - 1) / wall_g / 1e9}
         if not args.no_cpu_baseline and world == 1:      # the CPU line is measured at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.seed)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+
+    if gather is not None:      # pass 2, guarded
+        state["emit"] = report
+        watchdog.start()
+        try:
+            wall_g, _ = timed_pass(True)
+        except Exception as ex:
+            gather_note += "; failed: %r" % (ex,)
+        watchdog.cancel()
+    report()
     env.close()
     if dist is not None:
         dist.barrier()

@@ -89,6 +89,15 @@ int xv_engine_set_tick(xv_engine* e, uint64_t tick);
 /* Philox4x32-10 known-answer hook: fills out[4*n] on the device from ctr[4*n], key[2] (device ptrs). */
 int xv_philox4x32_10(xv_engine* e, const uint32_t* ctr, const uint32_t* key, uint32_t* out, int n);
 
+/* Rollout records for the trajectory all-gather (the one exchange step of the path): an AnyMDP env-step packed into ONE
+ * 8-byte word — bits 0-15 observation id, 16-23 action, 24 terminated, 25 truncated, 32-63 reward (fp32 bits).
+ * n records; arrays are device pointers; launched on `hip_stream` (NULL = the default stream).  The reference
+ * counterpart is the per-step tuple its rollout loops append (anymdp/test_utils.py:42-60). */
+int xv_pack_rollout(void* hip_stream, size_t n, const int32_t* obs, const int32_t* action, const float* reward,
+                    const uint8_t* terminated, const uint8_t* truncated, uint64_t* out);
+int xv_unpack_rollout(void* hip_stream, size_t n, const uint64_t* rec, int32_t* obs, int32_t* action, float* reward,
+                      uint8_t* terminated, uint8_t* truncated);
+
 /* ------------------------------------------------------------------------------------------------
  * AnyMDP — reference: xenoverse/anymdp/anymdp_env.py
  *   set_task  :32-79   -> xv_anymdp_create   (tables prepared host-side: see xenoverse_amd/anymdp)

@@ -126,3 +126,21 @@ def test_copy_false_gives_the_same_values(family):
     assert len(recs[0]) == len(recs[1])
     for a, b in zip(*recs):
         assert np.array_equal(a, b)
+
+
+def test_rollout_record_packing_on_device_matches_host_format():
+    """xv_pack_rollout / xv_unpack_rollout: one 8-byte record per env-step, the same bits as the torch (CPU) packer"""
+    from xenoverse_amd.distributed import REC_BYTES, pack_records, unpack_records
+    g = torch.Generator().manual_seed(1)
+    T, N = 7, 1000
+    obs = torch.randint(0, 65536, (T, N), generator=g, dtype=torch.int32)
+    act = torch.randint(0, 256, (T, N), generator=g, dtype=torch.int32)
+    rew = torch.randn((T, N), generator=g)
+    te = (torch.rand((T, N), generator=g) < 0.3).to(torch.uint8)
+    tr = (torch.rand((T, N), generator=g) < 0.3).to(torch.uint8)
+    host = pack_records(obs, act, rew, te, tr)
+    dev = pack_records(obs.cuda(), act.cuda(), rew.cuda(), te.cuda(), tr.cuda())
+    assert dev.shape == (T, N, REC_BYTES) and torch.equal(dev.cpu(), host)
+    o, a, r, t1, t2 = unpack_records(dev)
+    assert torch.equal(o.cpu(), obs) and torch.equal(a.cpu(), act) and torch.equal(r.cpu(), rew)
+    assert torch.equal(t1.cpu(), te) and torch.equal(t2.cpu(), tr)

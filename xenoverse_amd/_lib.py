@@ -15,6 +15,8 @@ c_void_p, c_int, c_u64, c_i64, c_u32 = C.c_void_p, C.c_int, C.c_uint64, C.c_int6
 # tests/test_abi.py parses the header and checks that every declared symbol is exported and bound.
 SIGNATURES = {
     "xv_abi_version": [],
+    "xv_pack_rollout": [c_void_p, C.c_size_t] + [c_void_p] * 6,
+    "xv_unpack_rollout": [c_void_p, C.c_size_t] + [c_void_p] * 6,
     "xv_last_error": [],
     "xv_engine_create": [c_int, c_u64, c_u64, c_void_p, C.POINTER(c_void_p)],
     "xv_engine_destroy": [c_void_p],

@@ -106,3 +106,54 @@ extern "C" int xv_philox4x32_10(xv_engine* e, const uint32_t* ctr, const uint32_
   XV_LAUNCH_CHECK();
   return XV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Rollout records for the one exchange step of the path: an AnyMDP env-step as ONE 8-byte word
+//   bits 0-15 observation id | 16-23 action | 24 terminated | 25 truncated | 32-63 reward (fp32 bits)
+// so that the all-gather of a T-step chunk moves 8 B per env-step (the field-by-field form is 14 B) and the
+// pack is one coalesced 8-byte store per record.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xv_pack_rollout_kernel(size_t n, const int32_t* obs, const int32_t* action,
+                                                              const float* reward, const uint8_t* terminated,
+                                                              const uint8_t* truncated, uint64_t* out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t lo = ((uint32_t)obs[i] & 0xFFFFu) | (((uint32_t)action[i] & 0xFFu) << 16) |
+                      ((terminated[i] ? 1u : 0u) << 24) | ((truncated[i] ? 1u : 0u) << 25);
+  out[i] = (uint64_t)lo | ((uint64_t)__float_as_uint(reward[i]) << 32);
+}
+
+__global__ __launch_bounds__(256) void xv_unpack_rollout_kernel(size_t n, const uint64_t* rec, int32_t* obs, int32_t* action,
+                                                                float* reward, uint8_t* terminated, uint8_t* truncated) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t r = rec[i];
+  const uint32_t lo = (uint32_t)r;
+  obs[i] = (int32_t)(lo & 0xFFFFu);
+  action[i] = (int32_t)((lo >> 16) & 0xFFu);
+  terminated[i] = (uint8_t)((lo >> 24) & 1u);
+  truncated[i] = (uint8_t)((lo >> 25) & 1u);
+  reward[i] = __uint_as_float((uint32_t)(r >> 32));
+}
+
+extern "C" int xv_pack_rollout(void* hip_stream, size_t n, const int32_t* obs, const int32_t* action, const float* reward,
+                               const uint8_t* terminated, const uint8_t* truncated, uint64_t* out) {
+  XV_CHECK_ARG(obs && action && reward && terminated && truncated && out);
+  if (n == 0) return XV_OK;
+  XV_CHECK_ARG((n + 255) / 256 < 0x7FFFFFFFull);
+  hipLaunchKernelGGL(xv_pack_rollout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, n, obs,
+                     action, reward, terminated, truncated, out);
+  XV_LAUNCH_CHECK();
+  return XV_OK;
+}
+
+extern "C" int xv_unpack_rollout(void* hip_stream, size_t n, const uint64_t* rec, int32_t* obs, int32_t* action, float* reward,
+                                 uint8_t* terminated, uint8_t* truncated) {
+  XV_CHECK_ARG(rec && obs && action && reward && terminated && truncated);
+  if (n == 0) return XV_OK;
+  XV_CHECK_ARG((n + 255) / 256 < 0x7FFFFFFFull);
+  hipLaunchKernelGGL(xv_unpack_rollout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, n,
+                     rec, obs, action, reward, terminated, truncated);
+  XV_LAUNCH_CHECK();
+  return XV_OK;
+}

@@ -10,7 +10,7 @@ is RCCL over xGMI on ROCm, "gloo" on CPU (tests) — one in-place `all_gather_in
 import numpy as np
 import torch
 
-REC_BYTES = 14   # obs i32 | action i32 | reward f32 | terminated u8 | truncated u8   
+REC_BYTES = 8    # one 64-bit word per env-step: obs u16 | action u8 | flags u8 | reward f32   (include/xeno.h)
 
 
 def shard_range(n_total, rank, world):
@@ -32,26 +32,49 @@ def shard_env_task(env_task, rank, world):
 
 
 def pack_records(obs, action, reward, terminated, truncated, out=None):
-    """[T, N] int32 / int32 / float32 / uint8 / uint8 -> uint8 [T, N, 14] records (one per env-step)"""
+    """[T, N] int32 / int32 / float32 / uint8 / uint8 -> uint8 [T, N, 8]: one 64-bit record per env-step (obs < 65536,
+    action < 256).  Device tensors are packed by one HIP kernel (xv_pack_rollout, a coalesced 8-byte store per
+    record) on the current stream; CPU tensors (the gloo tests of the N > 1 path) with torch integer ops."""
     T, N = obs.shape
     if out is None:
         out = torch.empty((T, N, REC_BYTES), dtype=torch.uint8, device=obs.device)
-    out[..., 0:4] = obs.contiguous().view(torch.uint8).view(T, N, 4)
-    out[..., 4:8] = action.contiguous().view(torch.uint8).view(T, N, 4)
-    out[..., 8:12] = reward.contiguous().view(torch.uint8).view(T, N, 4)
-    out[..., 12] = terminated
-    out[..., 13] = truncated
+    if obs.is_cuda:
+        from . import _lib
+        lib = _lib.load()
+        args = [obs.contiguous(), action.contiguous(), reward.contiguous(), terminated.contiguous(), truncated.contiguous()]
+        assert out.is_contiguous()
+        st = torch.cuda.current_stream(obs.device).cuda_stream
+        _lib.check(lib.xv_pack_rollout(st, T * N, *[_lib.ptr(a) for a in args], _lib.ptr(out)))
+        return out
+    lo = (obs.to(torch.int64) & 0xFFFF) | ((action.to(torch.int64) & 0xFF) << 16) | \
+         ((terminated != 0).to(torch.int64) << 24) | ((truncated != 0).to(torch.int64) << 25)
+    hi = reward.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    out.copy_((lo | (hi << 32)).contiguous().view(torch.uint8).view(T, N, REC_BYTES))
     return out
 
 
 def unpack_records(rec):
-    """inverse of pack_records (rec uint8 [..., 14])"""
+    """inverse of pack_records (rec uint8 [..., 8]) -> obs int32, action int32, reward float32, terminated, truncated uint8"""
     r = rec.contiguous()
-    lead = r.shape[:-1]
-    obs = r[..., 0:4].contiguous().view(torch.int32).view(lead)
-    act = r[..., 4:8].contiguous().view(torch.int32).view(lead)
-    rew = r[..., 8:12].contiguous().view(torch.float32).view(lead)
-    return obs, act, rew, r[..., 12], r[..., 13]
+    lead = tuple(r.shape[:-1])
+    if r.is_cuda:
+        from . import _lib
+        lib = _lib.load()
+        d = r.device
+        obs = torch.empty(lead, dtype=torch.int32, device=d); act = torch.empty(lead, dtype=torch.int32, device=d)
+        rew = torch.empty(lead, dtype=torch.float32, device=d)
+        te = torch.empty(lead, dtype=torch.uint8, device=d); tr = torch.empty(lead, dtype=torch.uint8, device=d)
+        st = torch.cuda.current_stream(d).cuda_stream
+        _lib.check(lib.xv_unpack_rollout(st, obs.numel(), _lib.ptr(r), _lib.ptr(obs), _lib.ptr(act), _lib.ptr(rew),
+                                         _lib.ptr(te), _lib.ptr(tr)))
+        return obs, act, rew, te, tr
+    w = r.view(torch.int64).view(lead)
+    obs = (w & 0xFFFF).to(torch.int32)
+    act = ((w >> 16) & 0xFF).to(torch.int32)
+    te = ((w >> 24) & 1).to(torch.uint8)
+    tr = ((w >> 25) & 1).to(torch.uint8)
+    rew = (w >> 32).to(torch.int32).view(torch.float32)      # arithmetic shift keeps the 32 reward bits
+    return obs, act, rew, te, tr
 
 
 class RolloutGather(object):
