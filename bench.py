@@ -10,14 +10,25 @@ tables per GPU, every table read misses every cache); --tasks 1024 gives "shared
 A "step" is one vector step of all envs of a rank = one launch of the step kernel; K steps are K back-to-back
 launches (xv_anymdp_step_many), auto-reset SAME_STEP, actions pre-generated on the device.
 
+Timing: W warm-up steps, then the K-step batch is timed R times (`--repeats`, default 25); every repetition is
+bracketed by a barrier + device synchronisation on both sides and by HIP events on the launch stream, the MAX over
+ranks is taken per repetition and the MEDIAN repetition is reported (`steps` stays K; `repeats` = R).  With the
+driver's K = 20 one repetition is a 0.15 ms region, which a single sample cannot resolve.
+
 One JSON line on rank 0: metric/value/unit/... as the driver's contract says, plus
-  roofline      HBM bound for the step kernel (algorithmic 562 B per env-step)
-  cpu_baseline  the C oracle (a port of the reference's step()) on the host cores, bounded sample
+  roofline      HBM bound for the step kernel: `achieved`/`frac` from the algorithmic 562 B per env-step (SURVEY.md
+                §8(d)); `traffic` = bytes the kernel really moved (PMC counters of the committed profile of THIS
+                kernel source, else null), `frac_traffic` = traffic / launch time / peak
+  cpu_baseline  SURVEY.md §8(d): the reference's execution style (one env per Python object, one step() per call,
+                NumPy global RNG; oracle/py_ref_style.py) in P = os.cpu_count() processes; `c_oracle` = the
+                vectorised C oracle (OpenMP) on a working set that does not fit the last-level cache
+  rccl / rccl_ranks   N > 1: whether the RCCL process group came up and what all_reduce(ones) returned
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -25,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_ENV_STEP = {8: 8 * 64 + 50}   # w*S + 50, w = 8 (fp64 CDF), S = 64  -> 562 B
 HBM_PEAK_GBS = 8000.0
+EXIT_WATCHDOG = 3
 
 
 def parse():
@@ -32,20 +44,146 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=25, help="the K-step batch is timed this many times; median reported")
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--tasks", type=int, default=0, help="tasks per GPU (0 = one per env, config 2a)")
     ap.add_argument("--period", type=int, default=32, help="rollout-chunk ring length T")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--gather-timeout", type=int, default=120, help="N>1: seconds allowed for the all-gather pass")
+    ap.add_argument("--cpu-table-gib", type=float, default=16.0, help="working set of the C-oracle CPU line")
+    ap.add_argument("--gather-timeout", type=int, default=120,
+                    help="N>1: seconds allowed for process-group set-up and for the all-gather pass")
     ap.add_argument("--no-allgather", action="store_true",
                     help="N>1: skip the RCCL all-gather of rollout chunks (pure replicas)")
     ap.add_argument("--search", default="auto", choices=["auto", "binary", "fence"])
     ap.add_argument("--fused", action="store_true", help="also time the fused T-step rollout kernel")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="xv_anymdp_step_many: replay ring cycles from a hipGraph (auto: only for small batches)")
+    ap.add_argument("--sweep-envs", default=None,
+                    help="comma list of envs/GPU (e.g. 16384,32768,65536,131072,262144): time the 2a step at each size "
+                         "and write --sweep-out instead of the bench line")
+    ap.add_argument("--sweep-out", default=os.path.join(ROOT, "gpurun_out", "anymdp_envs_sweep.json"))
+    ap.add_argument("--exchange-selftest", action="store_true",
+                    help="N>1 control flow (process group, watchdog, pack -> all-gather -> unpack, MAX over ranks) on "
+                         "fabricated CPU records, no GPU and no stepping: a functional test, not a measurement")
     return ap.parse_args()
+
+
+# -----------------------------------------------------------------------------------------------------------
+# CPU baseline.  Runs BEFORE anything touches the GPU: line A forks worker processes.
+# -----------------------------------------------------------------------------------------------------------
+def _mem_available_gib():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                return int(ln.split()[1]) / 2**20
+    except Exception:
+        pass
+    return 8.0
+
+
+def _py_worker(args):
+    idx, n_obj, seconds, seed = args
+    import oracle
+    from oracle import py_ref_style
+    tab = oracle.anymdp_synth(seed=seed, task_index_base=idx * n_obj, n_task=n_obj, S=64, A=8, s0_max=4)
+    v, n = py_ref_style.time_python_loop(tab, seconds, seed=idx)
+    return v, n
+
+
+def cpu_line_a(seconds, seed):
+    """the reference's execution style in P = os.cpu_count() processes, each stepping its own env objects"""
+    import multiprocessing as mp
+    P = os.cpu_count() or 1
+    n_obj = 32 if _mem_available_gib() > 0.2 * P else 8          # ~0.1 GiB per worker at 32 objects
+    ctx = mp.get_context("fork")          # no exec; nothing in this process has touched the GPU yet
+    t0 = time.perf_counter()
+    with ctx.Pool(P) as pool:
+        res = pool.map(_py_worker, [(i, n_obj, seconds, seed) for i in range(P)], chunksize=1)
+    return {"value": float(sum(v for v, _ in res)), "unit": "env-steps/s", "cores": P, "kind": "port",
+            "sample": "oracle/py_ref_style.py: the reference's style (one env per Python object, one step() per call, "
+                      "NumPy global RNG) in %d processes x %d env objects (S=64, A=8, one synthetic task per object), "
+                      "%.0f s each, aggregate (%.1f s wall incl. set-up)" % (P, n_obj, seconds, time.perf_counter() - t0)}
+
+
+def cpu_line_b(seconds, seed, table_gib):
+    """the vectorised C oracle (OpenMP, all host threads) on a table set that does not fit the last-level cache"""
+    import numpy as np
+    import oracle
+    cores = max(1, min(os.cpu_count() or 1, oracle.lib().xo_max_threads()))
+    gib = min(table_gib, 0.4 * _mem_available_gib())
+    n_task = max(64, int(gib * 2**30) // (64 * 8 * 64 * 16) // 64 * 64)      # 512 KiB of flat tables per task
+    per = max(1, 65536 // n_task)
+    n_env = n_task * per
+    t0 = time.perf_counter()
+    tab = oracle.anymdp_synth(seed=seed, task_index_base=0, n_task=n_task, S=64, A=8, s0_max=4)
+    t_synth = time.perf_counter() - t0
+    env_task = (np.arange(n_env, dtype=np.int32) % n_task).astype(np.int32)   # neighbours use different tasks
+    ora = oracle.AnyMDPOracle(tab, env_task)
+    ora.reset(seed, 0, 0)
+    rng = np.random.RandomState(0)
+    acts = rng.randint(0, 8, (64, n_env)).astype(np.int32)
+    for k in range(5):
+        ora.step(seed, 0, 1 + k, acts[k % 64], 2, n_threads=cores)
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        for _ in range(10):
+            ora.step(seed, 0, 100 + k, acts[k % 64], 2, n_threads=cores)
+            k += 1
+        if time.perf_counter() - t0 >= seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n_env * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "oracle/xeno_oracle.c step (OpenMP, %d threads), %d envs over %d distinct S=64,A=8 tasks "
+                      "(%.1f GiB of tables, built in %.1f s), %d vector steps in %.1f s"
+                      % (cores, n_env, n_task, n_task * 512 / 2**20, t_synth, k, dt)}
+
+
+def cpu_baseline(seconds, seed, table_gib):
+    try:
+        out = cpu_line_a(seconds, seed)           # forks: before the OpenMP runtime of line B starts threads here
+    except Exception as ex:                       # never lose the bench line to the baseline
+        out = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (ex,)}
+    try:
+        out["c_oracle"] = cpu_line_b(seconds, seed, table_gib)
+    except Exception as ex:
+        out["c_oracle"] = {"error": repr(ex)}
+    return out
+
+
+def under_profiler():
+    e = os.environ
+    return "rocprof" in e.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in e)
+
+
+# -----------------------------------------------------------------------------------------------------------
+def kernel_source_hash():
+    from xenoverse_amd.build import source_hash
+    return source_hash(("anymdp.hip", "philox.h", "xv_common.h"))
+
+
+def pmc_traffic(n_env, n_task, search):
+    """HBM bytes per launch of the step kernel from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes, gfx950 x2 read correction; scripts/gpu_pmc.sh -> profiles/*pmc_traffic*.json).  Counters cannot
+    be read from inside this process, so the figure is the profiled one for the same workload AND the same kernel
+    source (hash of csrc/anymdp.hip + headers recorded with the profile) — a stale profile yields null."""
+    import glob
+    want_src = kernel_source_hash()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            k = d.get("bench_key", {})
+            want = "2a" if n_task == n_env else "2b"
+            if k.get("workload") == want and k.get("search") in (search, "auto") and k.get("envs_per_gpu") == n_env \
+                    and k.get("kernel_source_sha16") == want_src:
+                for name, v in d["kernels"].items():
+                    if "step_kernel" in name:
+                        return v["traffic_bytes_per_launch_corrected"], os.path.basename(f)
+        except Exception:
+            pass
+    return None, None
 
 
 def make_tables(eng, torch, _lib, n_task, task_base, seed, S=64, A=8, s0_max=4):
@@ -66,138 +204,170 @@ def make_tables(eng, torch, _lib, n_task, task_base, seed, S=64, A=8, s0_max=4):
     return t
 
 
-def cpu_baseline(seconds, seed):
-    """The CPU oracle (a C port of the reference's step(), pinned to the reference's golden vectors) on the
-    host cores: same workload shape (S=64, A=8, one synthetic task per env, random actions, SAME_STEP
-    auto-reset), on a bounded sample of envs, all host threads."""
-    import numpy as np
-    import oracle
-    n_task, per = 2048, 32        # 1 GiB of flat tables; 32 envs per task so that a vector step is >= 0.1 ms of work
-    n_env = n_task * per          # per thread and the OpenMP fork/join does not dominate
-    cores = max(1, min(os.cpu_count() or 1, oracle.lib().xo_max_threads()))
-    tab = oracle.anymdp_synth(seed=seed, task_index_base=0, n_task=n_task, S=64, A=8, s0_max=4)
-    env_task = (np.arange(n_env, dtype=np.int32) % n_task).astype(np.int32)   # neighbours use different tasks
-    ora = oracle.AnyMDPOracle(tab, env_task)
-    ora.reset(seed, 0, 0)
-    rng = np.random.RandomState(0)
-    acts = rng.randint(0, 8, (64, n_env)).astype(np.int32)
-    for k in range(5):
-        ora.step(seed, 0, 1 + k, acts[k % 64], 2, n_threads=cores)
-    t0 = time.perf_counter()
-    k = 0
-    while True:
-        for _ in range(10):
-            ora.step(seed, 0, 100 + k, acts[k % 64], 2, n_threads=cores)
-            k += 1
-        if time.perf_counter() - t0 >= seconds:
-            break
-    dt = time.perf_counter() - t0
-    out = {"value": n_env * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-           "sample": "oracle/xeno_oracle.c step (OpenMP, %d threads), %d envs over %d distinct S=64,A=8 tasks "
-                     "(1 GiB of tables), %d vector steps in %.1f s" % (cores, n_env, n_task, k, dt)}
-    # secondary line (SURVEY.md §8(d)): the reference's own execution style — one env per Python object, one
-    # step() per call, NumPy global RNG — on ONE core, same task shape, bounded to a few seconds
-    try:
-        from oracle import py_ref_style
-        sub = {kk: (v[:64] if hasattr(v, "shape") else v) for kk, v in tab.items()}
-        v, n_py = py_ref_style.time_python_loop(sub, min(3.0, seconds))
-        out["python_loop"] = {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "port",
-                              "sample": "oracle/py_ref_style.py: %d env objects stepped one by one (the reference's "
-                                        "style), S=64,A=8, one core" % n_py}
-    except Exception as ex:   # never lose the bench line to the secondary baseline
-        out["python_loop"] = {"error": repr(ex)}
-    return out
+class Watchdog(object):
+    """N > 1: a stalled collective (set-up, probe or the all-gather pass) must not hang the job.  When the deadline
+    passes, rank 0 prints whatever `emit` has been armed with (the pass-1 measurement, flagged) and EVERY rank leaves
+    with a non-zero code — never a re-exec, never a retry in-process."""
 
+    def __init__(self, seconds, rank):
+        self.seconds, self.rank = seconds, rank
+        self.lock = threading.Lock()
+        self.emit = None
+        self.timer = None
+        self.stage = "start"
 
-def pmc_traffic(n_env, n_task, search):
-    """HBM bytes per launch of the step kernel from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate passes, gfx950 x2 read correction; scripts/gpu_pmc.sh -> profiles/*pmc_traffic*.json).  Counters cannot
-    be read from inside this process, so the figure is the profiled one for the same workload, or null."""
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+    def arm(self, stage):
+        self.cancel()
+        self.stage = stage
+        self.timer = threading.Timer(self.seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def cancel(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def _fire(self):
+        msg = "%s did not finish within %d s" % (self.stage, self.seconds)
         try:
-            d = json.load(open(f))
-            k = d.get("bench_key", {})
-            want = "2a" if n_task == n_env else "2b"
-            if k.get("workload") == want and k.get("search") in (search, "auto") and k.get("envs_per_gpu") == n_env:
-                for name, v in d["kernels"].items():
-                    if "step_kernel" in name:
-                        return v["traffic_bytes_per_launch_corrected"], os.path.basename(f)
-        except Exception:
+            if self.rank == 0 and self.emit is not None:
+                self.emit(timeout_note=msg)
+            else:
+                sys.stderr.write("bench.py rank %d: %s\n" % (self.rank, msg))
+                sys.stderr.flush()
+        finally:
+            os._exit(EXIT_WATCHDOG)
+
+
+def init_distributed(args, torch, local, wd, cpu_only):
+    """-> (dist or None, info dict with rccl / rccl_ranks / note)"""
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = "gloo" if cpu_only else os.environ.get("XV_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+    info = {"rccl": False, "rccl_ranks": None, "note": None, "backend": backend}
+    wd.arm("process-group set-up (%s)" % backend)
+    try:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            probe = torch.ones(1, device="cuda:%d" % local)
+            dist.all_reduce(probe)                          # fail here, not inside the timed region
+            torch.cuda.synchronize()
+            info["rccl"], info["rccl_ranks"] = True, int(probe.item())
+        else:
+            dist.init_process_group(backend)
+            probe = torch.ones(1)
+            dist.all_reduce(probe)
+            info["ranks_seen"] = int(probe.item())
+    except Exception as ex:   # keep the scaling measurement alive: barrier and MAX over ranks through gloo
+        info["note"] = "RCCL unavailable (%r): gloo used for the barrier and the MAX over ranks, no all-gather" % (ex,)
+        info["backend"] = "gloo"
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group("gloo")
+        except Exception as ex2:
+            sys.exit("bench.py: no usable torch.distributed backend: %r / %r" % (ex, ex2))
+    wd.cancel()
+    return dist, info
+
+
+def spin_sync(torch, ev):
+    """device synchronisation without the wake-up latency of a blocking wait: poll the last event, then synchronise"""
+    if ev is not None:
+        while not ev.query():
             pass
-    return None, None
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def median(xs):
+    s = sorted(xs)
+    n = len(s)
+    return s[n // 2] if n % 2 else 0.5 * (s[n // 2 - 1] + s[n // 2])
 
 
 def main():
     args = parse()
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                 % (args.gpus, args.gpus))
+    selftest = args.exchange_selftest
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and not selftest and not args.sweep_envs \
+            and not under_profiler():
+        cpu = cpu_baseline(args.cpu_seconds, args.seed, args.cpu_table_gib)      # before the GPU is touched
+
+    import torch
     if os.environ.get("XV_BENCH_SHARE_GPU"):   # functional test of the N>1 path on a 1-GPU box (not a measurement)
         local = 0
-    torch.cuda.set_device(local)
-    dist = None
-    dist_note = None
+    if not selftest:
+        torch.cuda.set_device(local)
+    wd = Watchdog(args.gather_timeout, rank)
+    dist, dinfo = None, {"rccl": None, "rccl_ranks": None, "note": None, "backend": None}
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("XV_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
-        try:
-            if backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-                probe = torch.ones(1, device="cuda:%d" % local)
-                dist.all_reduce(probe)                          # fail here, not inside the timed region
-                torch.cuda.synchronize()
-            else:
-                dist.init_process_group(backend)
-        except Exception as ex:   # keep the scaling measurement alive: barrier and MAX over ranks through gloo
-            dist_note = "RCCL unavailable (%r): gloo used for the barrier and the MAX over ranks, no all-gather" % (ex,)
-            try:
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                dist.init_process_group("gloo")
-            except Exception as ex2:
-                sys.exit("bench.py: no usable torch.distributed backend: %r / %r" % (ex, ex2))
+        dist, dinfo = init_distributed(args, torch, local, wd, cpu_only=selftest)
 
-    from xenoverse_amd import _lib
-    from xenoverse_amd.anymdp import AnyMDPVecEnv
+    if args.sweep_envs:
+        return sweep(args, torch, local)
 
+    from xenoverse_amd.distributed import REC_BYTES, RolloutGather, pack_records, unpack_records
     n_env = args.envs
     n_task = args.tasks if args.tasks > 0 else n_env
-    S, A = 64, 8
-    env = AnyMDPVecEnv(n_env, device="cuda:%d" % local, seed=args.seed, env_id_base=rank * n_env,
-                       autoreset_mode="same_step")
-    tab = make_tables(env.engine, torch, _lib, n_task, rank * n_task, args.seed + 1, S, A)
-    per = n_env // n_task
-    env_task = (torch.arange(n_env, device=env.device, dtype=torch.int32) // per).contiguous()
-    env.set_task(tab, env_task_index=env_task)
-    env.set_search(args.search)
-    env.set_step_many_graph(args.graph)
+    S, A, P = 64, 8, args.period
     search = {"auto": "fence"}.get(args.search, args.search)
-    P = args.period
-    g = torch.Generator(device=env.device)
-    g.manual_seed(args.seed + 17 * rank)
-    actions = torch.randint(0, A, (P, n_env), generator=g, device=env.device, dtype=torch.int32)
-    env.reset()
-    ring = env.step_many(1, actions)   # allocates the [P, N] output ring
+    env = None
+    if not selftest:
+        from xenoverse_amd import _lib
+        from xenoverse_amd.anymdp import AnyMDPVecEnv
+        env = AnyMDPVecEnv(n_env, device="cuda:%d" % local, seed=args.seed, env_id_base=rank * n_env,
+                           autoreset_mode="same_step")
+        tab = make_tables(env.engine, torch, _lib, n_task, rank * n_task, args.seed + 1, S, A)
+        per = n_env // n_task
+        env_task = (torch.arange(n_env, device=env.device, dtype=torch.int32) // per).contiguous()
+        env.set_task(tab, env_task_index=env_task)
+        env.set_search(args.search)
+        env.set_step_many_graph(args.graph)
+        device = env.device
+        g = torch.Generator(device=device)
+        g.manual_seed(args.seed + 17 * rank)
+        actions = torch.randint(0, A, (P, n_env), generator=g, device=device, dtype=torch.int32)
+        env.reset()
+        ring = env.step_many(1, actions)   # allocates the [P, N] output ring
 
-    # exchange step (SURVEY.md §8(e)): all-gather of each finished T-step rollout chunk (14-B records) over RCCL,
-    # on a side stream so that it overlaps the next chunk's stepping.  Stepping itself needs no collective.
-    # the all-gather runs on device buffers: RCCL only (gloo would stage 16 MB per rank and chunk through the host)
-    do_gather = world > 1 and not args.no_allgather and dist_note is None and \
-        (dist.get_backend() == "nccl" or bool(os.environ.get("XV_BENCH_FORCE_GATHER")))   # the latter: watchdog tests
+        def step_many(n):
+            env.step_many(n, actions, out=ring)
+    else:      # fabricated records: a function of (global env id, step) so that the gathered batch can be checked
+        device = torch.device("cpu")
+        n_env = min(n_env, 4096)
+        gid = torch.arange(rank * n_env, (rank + 1) * n_env, dtype=torch.int32)
+        tt = torch.arange(P, dtype=torch.int32)[:, None]
+        actions = (gid[None, :] + tt) % A
+
+        def fabricate(gid):
+            return dict(obs=(gid[None, :] * 3 + tt) % S, reward=gid[None, :].float() * 0.5 + tt.float(),
+                        terminated=((gid[None, :] + tt) % 5 == 0).to(torch.uint8),
+                        truncated=((gid[None, :] + tt) % 7 == 0).to(torch.uint8))
+        ring = fabricate(gid)
+
+        def step_many(n):
+            pass
+
+    # exchange step (SURVEY.md §8(e)): all-gather of each finished T-step rollout chunk (8-byte records) on a side
+    # stream so that it overlaps the next chunk's stepping.  Stepping itself needs no collective.  On GPUs the
+    # all-gather runs over RCCL only (gloo would stage 16 MB per rank through the host).
+    do_gather = world > 1 and not args.no_allgather and dinfo["note"] is None and \
+        (selftest or dist.get_backend() == "nccl" or bool(os.environ.get("XV_BENCH_FORCE_GATHER")))
     gather = None
-    gather_note = dist_note or "none"
+    gather_note = dinfo["note"] or "none"
     if do_gather:
         try:
-            from xenoverse_amd.distributed import REC_BYTES, RolloutGather, pack_records
-            gather = RolloutGather((P, n_env, REC_BYTES), device=env.device)
-            gather_note = "all_gather of %d-step rollout chunks, %d B/record (RCCL, side stream)" % (P, REC_BYTES)
+            gather = RolloutGather((P, n_env, REC_BYTES), device=device)
+            gather_note = "all_gather of %d-step rollout chunks, %d B/record (%s, side stream)" \
+                          % (P, REC_BYTES, "RCCL" if dinfo["rccl"] else dinfo["backend"])
         except Exception as ex:   # never lose the measurement to a collective set-up problem
             gather = None
             gather_note = "all_gather unavailable: %r" % (ex,)
@@ -206,7 +376,7 @@ def main():
         done = 0
         while done < k_steps:
             n = min(P, k_steps - done)
-            env.step_many(n, actions, out=ring)
+            step_many(n)
             done += n
             if with_gather and n == P:
                 gather.wait()        # the previous chunk must have left before its buffer is repacked
@@ -216,50 +386,105 @@ def main():
         if with_gather:
             gather.wait()
 
-    def barrier():
-        torch.cuda.synchronize()
+    gpu = not selftest
+
+    def barrier(ev=None):
+        if gpu:
+            spin_sync(torch, ev)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if gpu:
+            torch.cuda.synchronize()
 
-    def timed_pass(with_gather):
+    def timed_pass(with_gather, repeats):
+        """-> (median wall seconds of a K-step batch, median event ms) after MAX over ranks per repetition"""
         run(args.warmup, with_gather)
-        barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record()
-        run(args.steps, with_gather)
-        e1.record()
-        barrier()
-        w = time.perf_counter() - t0
-        ms = e0.elapsed_time(e1)          # HIP events on the stream the step kernels were launched on
-        if dist is not None:              # MAX over ranks
-            tt = torch.tensor([w, ms], dtype=torch.float64,
-                              device=env.device if dist.get_backend() == "nccl" else "cpu")
+        walls, evs = [], []
+        for _ in range(repeats):
+            barrier()
+            e0 = e1 = None
+            if gpu:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            if gpu:
+                e0.record()
+            run(args.steps, with_gather)
+            if gpu:
+                e1.record()
+            barrier(e1)
+            walls.append(time.perf_counter() - t0)
+            evs.append(e0.elapsed_time(e1) if gpu else walls[-1] * 1e3)   # HIP events on the launch stream
+        tt = torch.tensor([walls, evs], dtype=torch.float64)
+        if dist is not None:              # MAX over ranks, per repetition
+            if dist.get_backend() == "nccl":
+                tt = tt.to(device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            w, ms = float(tt[0]), float(tt[1])
-        return w, ms
+            tt = tt.cpu()
+        return median(tt[0].tolist()), median(tt[1].tolist()), tt[0].tolist()
+
+    R = max(1, args.repeats)
+    state = {"done": False, "wall_g": None, "fused": None, "errs": None, "selftest": None}
+    report_lock = threading.Lock()
 
     # pass 1 (the reported value): sharded stepping, no data-path collective — envs are independent
-    wall, ev_ms = timed_pass(False)
-    # pass 2 (N > 1): the same with every finished rollout chunk all-gathered to all ranks, overlapped.  A watchdog
-    # guards it: should the collective stall, rank 0 still prints the pass-1 line (the measurement) and every rank exits.
-    wall_g = None
-    state = {"emit": None}
-    if gather is not None:
-        import threading
+    wall, ev_ms, walls = timed_pass(False, R)
+    state["errs"] = env.check_errors() if env is not None else 0
 
-        def _bail():
-            if rank == 0 and state["emit"] is not None:
-                state["emit"]("all_gather pass did not finish within %d s: skipped" % args.gather_timeout)
-            os._exit(0)
-        state["pass1"] = (wall, ev_ms)
-        watchdog = threading.Timer(args.gather_timeout, _bail)
-        watchdog.daemon = True
-    errs = env.check_errors()
+    def report(timeout_note=None):
+        with report_lock:
+            if rank != 0 or state["done"]:
+                return
+            state["done"] = True
+            total_steps = world * n_env * args.steps
+            kern_us = ev_ms * 1e3 / args.steps
+            algo = ALGO_BYTES_PER_ENV_STEP[8] * n_env
+            achieved = algo / (kern_us * 1e-6) / 1e9
+            traffic, traffic_src = (None, None) if selftest else pmc_traffic(n_env, n_task, search)
+            exchange = gather_note if timeout_note is None else gather_note + "; " + timeout_note
+            out = {
+                "metric": "env-steps/sec (whole node), anymdp |S|=64 |A|=8, 65k envs/GPU",
+                "value": total_steps / wall, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "repeats": R, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "timing": {"statistic": "median over `repeats` repetitions of the `steps`-step batch, each bracketed by "
+                                        "barrier + device sync, MAX over ranks per repetition",
+                           "wall_ms_min": min(walls) * 1e3, "wall_ms_median": wall * 1e3, "wall_ms_max": max(walls) * 1e3},
+                "config": {"workload": "anymdp S=64 A=8, %d envs/GPU, %d tasks/GPU (%s), fp64 CDF rows, "
+                                       "SAME_STEP auto-reset, random actions"
+                                       % (n_env, n_task, "2a distinct: one task per env" if n_task == n_env
+                                          else "2b shared"),
+                           "envs_per_gpu": n_env, "tasks_per_gpu": n_task, "S": S, "A": A,
+                           "table_gib_per_gpu": round(n_task * S * A * (1 + (S + 6) // 7) * 128 / 2**30, 2),
+                           "launch": "one step kernel per vector step (xv_anymdp_step_many)",
+                           "search": search, "exchange": exchange, "device_error_flags": state["errs"]},
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                             "frac_traffic": None if traffic is None else traffic / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                             "traffic_over_algorithmic": None if traffic is None else traffic / algo,
+                             "kernel": "anymdp_step_kernel<false, %d, false, false>  (INJECT, blocks per fence entry | "
+                                       "0 = binary search, ROLLOUT, TICKDEV)" % (1 if search == "fence" else 0),
+                             "kernel_source_sha16": None if selftest else kernel_source_hash(),
+                             "avg_launch_us": kern_us, "algorithmic_bytes_per_launch": algo},
+                "rccl": dinfo["rccl"], "rccl_ranks": dinfo["rccl_ranks"],
+                "allgather_timeout": timeout_note is not None,
+            }
+            if selftest:
+                out["mode"] = "exchange-selftest: fabricated CPU records, no stepping — NOT a measurement"
+                out["value"] = out["ms_per_step"] = None
+                out["roofline"] = None
+                out["selftest"] = state["selftest"]
+                out["ranks_seen"] = dinfo.get("ranks_seen")
+            if state["fused"] is not None:
+                out["fused_rollout_env_steps_per_s_rank0"] = state["fused"]
+            if state["wall_g"] is not None:
+                chunks = args.steps // P
+                out["with_allgather"] = {"value": total_steps / state["wall_g"], "unit": "env-steps/s",
+                                         "gathered_GB_per_s_per_rank":
+                                             chunks * P * n_env * REC_BYTES * (world - 1) / state["wall_g"] / 1e9}
+            out["cpu_baseline"] = cpu if world == 1 else None      # the CPU lines are measured at N = 1 only
+            print(json.dumps(out), flush=True)
 
-    fused = None
-    if args.fused:
+    if args.fused and env is not None:
         T = P
         env.rollout(actions)
         torch.cuda.synchronize()
@@ -270,64 +495,99 @@ def main():
             env.rollout(actions, out=ring)
         f1.record()
         torch.cuda.synchronize()
-        fused = n_env * T * reps / (f0.elapsed_time(f1) * 1e-3)
+        state["fused"] = n_env * T * reps / (f0.elapsed_time(f1) * 1e-3)
 
-    def report(extra_note=None):
-        if rank != 0 or state.get("done"):
-            return
-        state["done"] = True
-        total_steps = world * n_env * args.steps
-        kern_us = ev_ms * 1e3 / args.steps
-        algo = ALGO_BYTES_PER_ENV_STEP[8] * n_env
-        achieved = algo / (kern_us * 1e-6) / 1e9
-        traffic, traffic_src = pmc_traffic(n_env, n_task, search)
-        out = {
-            "metric": "env-steps/sec (whole node), anymdp |S|=64 |A|=8, 65k envs/GPU",
-            "value": total_steps / wall, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "anymdp S=64 A=8, %d envs/GPU, %d tasks/GPU (%s), fp64 CDF rows, "
-                                   "SAME_STEP auto-reset, random actions"
-                                   % (n_env, n_task, "2a distinct: one task per env" if n_task == n_env
-                                      else "2b shared"),
-                       "envs_per_gpu": n_env, "tasks_per_gpu": n_task, "S": S, "A": A,
-                       "table_gib_per_gpu": round(n_task * S * A * (1 + (S + 6) // 7) * 128 / 2**30, 2),
-                       "launch": "one step kernel per vector step (xv_anymdp_step_many)",
-                       "search": search,
-                       "exchange": gather_note if extra_note is None else gather_note + "; " + extra_note,
-                       "device_error_flags": errs},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "anymdp_step_kernel<false, %d, false, false>  (INJECT, blocks per fence entry | "
-                                   "0 = binary search, ROLLOUT, TICKDEV)" % (1 if search == "fence" else 0),
-                         "avg_launch_us": kern_us,
-                         "algorithmic_bytes_per_launch": algo},
-        }
-        if fused is not None:
-            out["fused_rollout_env_steps_per_s_rank0"] = fused
-        if wall_g is not None:
-            chunks = args.steps // P
-            out["with_allgather"] = {"value": total_steps / wall_g, "unit": "env-steps/s",
-                                     "gathered_GB_per_s_per_rank": chunks * P * n_env * REC_BYTES * (world - 1) / wall_g / 1e9}
-        if not args.no_cpu_baseline and world == 1:      # the CPU line is measured at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.seed)
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-
-    if gather is not None:      # pass 2, guarded
-        state["emit"] = report
-        watchdog.start()
+    if gather is not None:      # pass 2 (N > 1): every finished rollout chunk all-gathered to all ranks, overlapped
+        wd.emit = report
+        wd.arm("the all-gather pass")
         try:
-            wall_g, _ = timed_pass(True)
+            if os.environ.get("XV_BENCH_TEST_STALL") and rank == 1:     # watchdog test: one rank never joins
+                time.sleep(10 * args.gather_timeout)
+            state["wall_g"] = timed_pass(True, max(1, min(R, 5)))[0]
+            if selftest:      # every rank sees every shard, rank order == env order
+                run(P, True)
+                full = torch.cat([gather.out[r] for r in range(world)], dim=1)
+                o2, a2, r2, te2, tr2 = unpack_records(full)
+                ref = fabricate(torch.arange(0, world * n_env, dtype=torch.int32))
+                ok = torch.equal(o2, ref["obs"]) and torch.equal(r2, ref["reward"]) and \
+                    torch.equal(te2, ref["terminated"]) and torch.equal(tr2, ref["truncated"]) and \
+                    torch.equal(a2, (torch.arange(0, world * n_env, dtype=torch.int32)[None, :] + tt) % A)
+                flag = torch.tensor([1.0 if ok else 0.0])
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                state["selftest"] = "ok" if flag.item() == 1.0 else "MISMATCH"
         except Exception as ex:
             gather_note += "; failed: %r" % (ex,)
-        watchdog.cancel()
+        wd.cancel()
     report()
-    env.close()
+    if env is not None:
+        env.close()
     if dist is not None:
+        wd.arm("final barrier")
         dist.barrier()
         dist.destroy_process_group()
+        wd.cancel()
+    if selftest and rank == 0 and state["selftest"] != "ok":
+        sys.exit(1)
+
+
+def sweep(args, torch, local):
+    """2a step time against the batch size: where the latency floor of the three dependent levels stops mattering"""
+    from xenoverse_amd import _lib
+    from xenoverse_amd.anymdp import AnyMDPVecEnv
+    S, A, P = 64, 8, args.period
+    rows = []
+    for n_env in [int(x) for x in args.sweep_envs.split(",")]:
+        need = n_env * S * A * (1 + (S + 6) // 7) * 128
+        free, _ = torch.cuda.mem_get_info()
+        if need + (4 << 30) > free:
+            rows.append({"envs": n_env, "skipped": "needs %.0f GiB of rows, %.0f GiB free" % (need / 2**30, free / 2**30)})
+            continue
+        env = AnyMDPVecEnv(n_env, device="cuda:%d" % local, seed=args.seed, autoreset_mode="same_step")
+        tab = make_tables(env.engine, torch, _lib, n_env, 0, args.seed + 1, S, A)
+        env.set_task(tab, env_task_index=torch.arange(n_env, device=env.device, dtype=torch.int32))
+        env.set_search(args.search)
+        env.set_step_many_graph("off")
+        g = torch.Generator(device=env.device)
+        g.manual_seed(args.seed)
+        actions = torch.randint(0, A, (P, n_env), generator=g, device=env.device, dtype=torch.int32)
+        env.reset()
+        ring = env.step_many(args.warmup, actions)
+        torch.cuda.synchronize()
+        us = []
+        for _ in range(max(3, args.repeats // 5)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            env.step_many(args.steps, actions, out=ring)
+            e1.record()
+            torch.cuda.synchronize()
+            us.append(e0.elapsed_time(e1) * 1e3 / args.steps)
+        t = median(us)
+        fus = None
+        try:
+            env.rollout(actions, out=ring)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                env.rollout(actions, out=ring)
+            e1.record()
+            torch.cuda.synchronize()
+            fus = e0.elapsed_time(e1) * 1e3 / (8 * P)
+        except Exception:
+            pass
+        algo = ALGO_BYTES_PER_ENV_STEP[8] * n_env
+        rows.append({"envs": n_env, "table_gib": round(need / 2**30, 1), "us_per_step": t,
+                     "env_steps_per_s": n_env / (t * 1e-6), "random_128B_lines_per_s": 2 * n_env / (t * 1e-6),
+                     "algorithmic_GBs": algo / (t * 1e-6) / 1e9, "frac": algo / (t * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "fused_rollout_us_per_step": fus, "device_error_flags": env.check_errors()})
+        env.close()
+        del tab, env, ring, actions
+        torch.cuda.empty_cache()
+    out = {"what": "anymdp 2a (one task per env, S=64, A=8, fence search, plain launches): step time against envs/GPU",
+           "steps": args.steps, "warmup": args.warmup, "kernel_source_sha16": kernel_source_hash(), "rows": rows}
+    os.makedirs(os.path.dirname(args.sweep_out), exist_ok=True)
+    json.dump(out, open(args.sweep_out, "w"), indent=1)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

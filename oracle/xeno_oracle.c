@@ -242,6 +242,8 @@ void xo_anymdp_synth(uint64_t seed, int64_t task_index_base, int n_task, int S, 
                      double* cdf, float* rs, int32_t* state_map, uint64_t* term_mask, double* s0_cdf,
                      int32_t* s0_ids, int32_t* max_steps) {
   const int words = (S + 63) / 64;
+  /* tasks are independent (every draw is keyed by the task index): large batches are built by all host threads */
+#pragma omp parallel for schedule(static) if (n_task >= 256)
   for (int tl = 0; tl < n_task; ++tl) {
     const uint64_t task = (uint64_t)(task_index_base + tl);
     uint32_t w[4];

@@ -7,13 +7,18 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from xenoverse_amd.build import source_hash
 
 workload, search, envs, cmd = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only beside them) -- " + cmd,
        "units": "counter values are KB; gfx950 correction per MI355X_MICROARCH.md HBM section: read bytes = 2 x FETCH_SIZE, "
                 "WRITE_SIZE exact",
-       "kernels": {}, "bench_key": {"workload": workload, "search": search, "envs_per_gpu": envs}}
+       "kernels": {}, "bench_key": {"workload": workload, "search": search, "envs_per_gpu": envs,
+                                      "kernel_source_sha16": source_hash(("anymdp.hip", "philox.h", "xv_common.h"))}}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     fs = glob.glob("gpurun_out/pmc_%s/**/*counter_collection.csv" % c, recursive=True)
     if not fs:

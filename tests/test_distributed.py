@@ -109,3 +109,40 @@ def test_world_size_2_gloo_allgather_of_rollout_chunks():
     assert sorted(r for r, _, _ in res) == [0, 1]
     assert all(ok for _, ok, _ in res)
     assert all(tmax == 2.0 for _, _, tmax in res)
+
+
+def _run_bench_selftest(extra_env, extra_args, timeout=240):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "64",
+           "--warmup", "32", "--repeats", "3", "--envs", "512", "--exchange-selftest"] + extra_args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    return r, [json.loads(ln) for ln in lines]
+
+
+@pytest.mark.timeout(300)
+def test_bench_py_two_ranks_end_to_end_on_gloo():
+    """bench.py --gpus 2 through torch.distributed.run: process group, barriers, MAX over ranks, pack -> all-gather ->
+    unpack of every rollout chunk and the JSON line — on fabricated CPU records (no GPU here), checked on every rank"""
+    r, out = _run_bench_selftest({}, [])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(out) == 1                      # rank 0 only
+    d = out[0]
+    assert d["n_gpus"] == 2 and d["selftest"] == "ok" and d["ranks_seen"] == 2 and d["repeats"] == 3
+    assert d["allgather_timeout"] is False and d["rccl"] is False and d["with_allgather"]["value"] > 0
+    assert d["value"] is None and "NOT a measurement" in d["mode"] and d["cpu_baseline"] is None
+
+
+@pytest.mark.timeout(300)
+def test_bench_py_watchdog_exits_nonzero_and_keeps_the_pass1_line():
+    """a rank that never joins the all-gather pass: every rank leaves with a non-zero code, rank 0 still prints the
+    pass-1 line, flagged machine-readably"""
+    r, out = _run_bench_selftest({"XV_BENCH_TEST_STALL": "1"}, ["--gather-timeout", "6"])
+    assert r.returncode != 0
+    assert len(out) == 1 and out[0]["allgather_timeout"] is True
+    assert "did not finish within 6 s" in out[0]["config"]["exchange"]

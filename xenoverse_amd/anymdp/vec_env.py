@@ -163,6 +163,7 @@ class AnyMDPVecEnv(VectorEnv):
         mask = None
         if options is not None and options.get("reset_mask") is not None:
             mask = self._dev(options["reset_mask"], torch.uint8)
+        self._detach("_obs")
         if self._tok is not None:
             _lib.check(self.lib.xv_anymdp_reset_tokens(self._h, _lib.ptr(mask), _lib.ptr(self._tobs)))
             self.need_reset = False
@@ -220,6 +221,7 @@ class AnyMDPVecEnv(VectorEnv):
         self._require_task()
         u = self._dev(u, torch.float64)
         m = None if mask is None else self._dev(mask, torch.uint8)
+        self._detach("_obs")
         _lib.check(self.lib.xv_anymdp_reset_injected(self._h, _lib.ptr(m), _lib.ptr(u), _lib.ptr(self._obs)))
         self.need_reset = False
         return self._out(self._obs.clone())

@@ -29,6 +29,16 @@ def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def source_hash(names):
+    """sha256[:16] of the named csrc files, in order: ties a committed profile to the kernel source it measured"""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(CSRC, n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _deps_mtime():
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hs.append(os.path.join(os.path.dirname(HERE), "include", "xeno.h"))

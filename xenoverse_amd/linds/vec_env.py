@@ -174,6 +174,7 @@ class LinDSVecEnv(VectorEnv):
         mask = None
         if options is not None and options.get("reset_mask") is not None:
             mask = self._dev(options["reset_mask"], torch.uint8)
+        self._detach("_obs", "_cmd", "_error")
         _lib.check(self.lib.xv_linds_reset(self._h, _lib.ptr(mask), _lib.ptr(self._obs), _lib.ptr(self._cmd),
                                            _lib.ptr(self._error)))
         self.need_reset = False
@@ -186,6 +187,7 @@ class LinDSVecEnv(VectorEnv):
         self._require_task()
         idx = self._dev(init_index, torch.int32)
         m = None if mask is None else self._dev(mask, torch.uint8)
+        self._detach("_obs", "_cmd", "_error")
         _lib.check(self.lib.xv_linds_reset_injected(self._h, _lib.ptr(m), _lib.ptr(idx), _lib.ptr(self._obs),
                                                     _lib.ptr(self._cmd), _lib.ptr(self._error)))
         self.need_reset = False

@@ -82,6 +82,8 @@ class MazeWorldVecEnv(VectorEnv):
             env_task = torch.arange(self.num_envs, device=d, dtype=torch.int32) // (self.num_envs // n_task)
         else:
             env_task = self._dev(env_task_index, torch.int32)
+            if env_task.shape != (self.num_envs,) or int(env_task.min()) < 0 or int(env_task.max()) >= n_task:
+                raise ValueError("env_task_index must be (num_envs,) with entries in [0, n_task)")
         dev["env_task"] = env_task.contiguous()
         if self._h is not None:
             self.lib.xv_maze_destroy(self._h)
@@ -119,6 +121,7 @@ class MazeWorldVecEnv(VectorEnv):
         mask = None
         if options is not None and options.get("reset_mask") is not None:
             mask = self._dev(options["reset_mask"], torch.uint8)
+        self._detach("_frames", "_cmd_rgb")
         _lib.check(self.lib.xv_maze_reset(self._h, _lib.ptr(mask), _lib.ptr(self._frames), _lib.ptr(self._cmd_rgb)))
         self.need_reset = False
         return self._o(self._frames), {"steps": self._out(self._steps_now()),
@@ -149,6 +152,7 @@ class MazeWorldVecEnv(VectorEnv):
 
     def render_frames(self):
         """frames of the current state, without stepping"""
+        self._detach("_frames", "_cmd_rgb")
         _lib.check(self.lib.xv_maze_render(self._h, _lib.ptr(self._frames), _lib.ptr(self._cmd_rgb)))
         return self._o(self._frames)
 

@@ -63,6 +63,8 @@ class CartPoleVecEnv(VectorEnv):
             env_task = torch.arange(self.num_envs, device=d, dtype=torch.int32) // (self.num_envs // n_task)
         else:
             env_task = self._dev(env_task_index, torch.int32)
+            if env_task.shape != (self.num_envs,) or int(env_task.min()) < 0 or int(env_task.max()) >= n_task:
+                raise ValueError("env_task_index must be (num_envs,) with entries in [0, n_task)")
         self._tab = dict(params=torch.from_numpy(params).to(d), scale=torch.from_numpy(self.reset_bounds_scale).to(d),
                          env_task=env_task.contiguous())
         if self._h is not None:
@@ -89,6 +91,7 @@ class CartPoleVecEnv(VectorEnv):
         mask = None
         if options is not None and options.get("reset_mask") is not None:
             mask = self._dev(options["reset_mask"], torch.uint8)
+        self._detach("_obs")
         _lib.check(self.lib.xv_cartpole_reset(self._h, _lib.ptr(mask), _lib.ptr(self._obs)))
         self.need_reset = False
         return self._o(self._obs), {}
@@ -97,6 +100,7 @@ class CartPoleVecEnv(VectorEnv):
         self._require_task()
         u = self._dev(u, torch.float32)
         m = None if mask is None else self._dev(mask, torch.uint8)
+        self._detach("_obs")
         _lib.check(self.lib.xv_cartpole_reset_injected(self._h, _lib.ptr(m), _lib.ptr(u), _lib.ptr(self._obs)))
         self.need_reset = False
         return self._o(self._obs)

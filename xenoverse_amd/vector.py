@@ -67,6 +67,16 @@ class VectorEnv(object):
                 if t is not None:
                     setattr(self, name, torch.empty_like(t))
 
+    def _detach(self, *names):
+        """copy=True before a launch that overwrites output buffers only in part (masked reset, render of the
+        current state): the launch writes into private clones, so tensors handed out earlier keep their values
+        and the entries the launch does not touch keep theirs"""
+        if self.copy and not self.to_numpy:
+            for name in names:
+                t = getattr(self, name, None)
+                if t is not None:
+                    setattr(self, name, t.clone())
+
     def _of(self, t):
         """an output buffer that was renewed before the launch (or copy=False): handed out as it is"""
         return self._out(t)
