@@ -20,7 +20,7 @@ One JSON line on rank 0: metric/value/unit/... as the driver's contract says, pl
                 §8(d)); `traffic` = bytes the kernel really moved (PMC counters of the committed profile of THIS
                 kernel source, else null), `frac_traffic` = traffic / launch time / peak
   cpu_baseline  SURVEY.md §8(d): the reference's execution style (one env per Python object, one step() per call,
-                NumPy global RNG; oracle/py_ref_style.py) in P = os.cpu_count() processes; `c_oracle` = the
+                NumPy global RNG; oracle/py_ref_style.py) in P = usable CPUs processes; `c_oracle` = the
                 vectorised C oracle (OpenMP) on a working set that does not fit the last-level cache
   rccl / rccl_ranks   N > 1: whether the RCCL process group came up and what all_reduce(ones) returned
 """
@@ -83,6 +83,31 @@ def _mem_available_gib():
     return 8.0
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (os.cpu_count() reports the
+    machine's, which oversubscribes a quota-limited container and collapses OpenMP's spinning barriers)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            pass
+    return n
+
+
 def _py_worker(args):
     idx, n_obj, seconds, seed = args
     import oracle
@@ -95,7 +120,7 @@ def _py_worker(args):
 def cpu_line_a(seconds, seed):
     """the reference's execution style in P = os.cpu_count() processes, each stepping its own env objects"""
     import multiprocessing as mp
-    P = os.cpu_count() or 1
+    P = usable_cpus()
     n_obj = 32 if _mem_available_gib() > 0.2 * P else 8          # ~0.1 GiB per worker at 32 objects
     ctx = mp.get_context("fork")          # no exec; nothing in this process has touched the GPU yet
     t0 = time.perf_counter()
@@ -103,15 +128,16 @@ def cpu_line_a(seconds, seed):
         res = pool.map(_py_worker, [(i, n_obj, seconds, seed) for i in range(P)], chunksize=1)
     return {"value": float(sum(v for v, _ in res)), "unit": "env-steps/s", "cores": P, "kind": "port",
             "sample": "oracle/py_ref_style.py: the reference's style (one env per Python object, one step() per call, "
-                      "NumPy global RNG) in %d processes x %d env objects (S=64, A=8, one synthetic task per object), "
-                      "%.0f s each, aggregate (%.1f s wall incl. set-up)" % (P, n_obj, seconds, time.perf_counter() - t0)}
+                      "NumPy global RNG) in P = %d processes (usable CPUs; os.cpu_count() = %s) x %d env objects (S=64, A=8, one "
+                      "synthetic task per object), %.0f s each, aggregate (%.1f s wall incl. set-up)"
+                      % (P, os.cpu_count(), n_obj, seconds, time.perf_counter() - t0)}
 
 
 def cpu_line_b(seconds, seed, table_gib):
     """the vectorised C oracle (OpenMP, all host threads) on a table set that does not fit the last-level cache"""
     import numpy as np
     import oracle
-    cores = max(1, min(os.cpu_count() or 1, oracle.lib().xo_max_threads()))
+    cores = max(1, min(usable_cpus(), oracle.lib().xo_max_threads()))
     gib = min(table_gib, 0.4 * _mem_available_gib())
     n_task = max(64, int(gib * 2**30) // (64 * 8 * 64 * 16) // 64 * 64)      # 512 KiB of flat tables per task
     per = max(1, 65536 // n_task)

@@ -35,7 +35,7 @@ extern "C" {
 /* 2: AnyMDP rows are records of 128-byte lines (fence line + 7-entry blocks), completed in place by
  *    xv_anymdp_create; xv_maze_tables carries the texture-library sizes; Acrobot family; command-table and
  *    graph-replay switches */
-#define XV_ABI_VERSION 2
+#define XV_ABI_VERSION 3
 
 /* return codes */
 #define XV_OK 0
@@ -230,6 +230,16 @@ int xv_anymdp_rollout_teacher(xv_anymdp* h, int T, const uint8_t* greedy, float 
 int xv_anymdp_solve(xv_anymdp* h, double gamma, double tol, int max_iter, double* q_out, uint8_t* greedy_out,
                     int32_t* iters_out);
 
+/* HOST function (host pointers, no device work): value iteration in the reference's own order of operations —
+ * update_value_matrix (solver.py:57-82, max_iteration = -1): damped Gauss-Seidel sweeps over (s, a) on the value
+ * matrix in place, V(s') = max_a (is_greedy) or numpy.mean_a of the CURRENT matrix, damping 1, .8, .64, .512, .5, ...,
+ * until rms(old - new) <= 1e-4; fp64, every product and sum rounded separately, numpy's pairwise summation for the
+ * means.  The seed-compatible task sampler (task_sampler.py:15-65, task_sampler_utils.py:177-256) feeds these values
+ * back into the reward tensor, so they have to match to the bit.  t_mat, r_mat double[ns][na][ns]; vm double[ns][na]
+ * holds the starting point and receives the result; sweeps_out nullable. */
+int xv_anymdp_value_iteration_gs(const double* t_mat, const double* r_mat, int ns, int na, double gamma,
+                                 int is_greedy, double* vm, int32_t* sweeps_out);
+
 /* env.inner_state / env.steps accessors (anymdp_env.py:138-143); device int32[n_env] each, nullable */
 int xv_anymdp_get_state(xv_anymdp* h, int32_t* inner_state, int32_t* steps, uint8_t* need_reset);
 int xv_anymdp_set_state(xv_anymdp* h, const int32_t* inner_state, const int32_t* steps,
@@ -282,11 +292,13 @@ int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int NA, int NO,
                     const xv_linds_tables* tables, const int32_t* env_task, xv_linds** out);
 int xv_linds_destroy(xv_linds* h);
 /* kernel selection (results are identical, bit for bit on the state/observation path):
- *   MFMA    one wave per 32-env tile, x' = Phi x + Gamma a and y = C x' on v_mfma_f32_32x32x2_f32; needs every
- *           aligned group of 32 envs to share one task (e.g. 64 envs per task)
+ *   MFMA    one wave per tile of 32 envs that share a task, x' = Phi x + Gamma a and y = C x' on
+ *           v_mfma_f32_32x32x2_f32.  When the caller's env -> task map does not put 32 envs of one task side by side,
+ *           xv_linds_create orders the engine's own state by task (32-slot tiles per task, the last one padded) and the
+ *           kernel reaches actions / outputs through a slot -> env index: any map, same results
  *   SCALAR  one lane per env, task matrices as scalar-cache broadcast operands, waterfall over the tasks of a
- *           wave: any env -> task mapping
- *   AUTO    MFMA when the layout allows it */
+ *           wave: any env -> task mapping (the independent second implementation the parity tests compare with)
+ *   AUTO    MFMA */
 #define XV_LINDS_PATH_AUTO 0
 #define XV_LINDS_PATH_MFMA 1
 #define XV_LINDS_PATH_SCALAR 2

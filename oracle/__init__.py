@@ -24,7 +24,7 @@ _lib = None
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("xeno_oracle.c", "xeno_oracle.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("xeno_oracle.c", "xeno_oracle_sampler.c", "xeno_oracle.h", "Makefile")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -38,6 +38,8 @@ def lib():
         _lib.xo_u53.restype = C.c_double
         _lib.xo_upper_bound.restype = C.c_int
         _lib.xo_max_threads.restype = C.c_int
+        _lib.xo_np_pairwise_sum.restype = C.c_double
+        _lib.xo_update_value_matrix.restype = C.c_int
     return _lib
 
 
@@ -518,3 +520,22 @@ class AnyMDPTokOracle(AnyMDPOracle):
         lib().xo_anymdp_tok_step(C.byref(self._t), C.c_uint64(seed), C.c_uint64(gid_base), C.c_uint64(tick), _p(a),
                                  _p(obs), _p(rew), _p(rgt), _p(term), _p(trunc), _p(fobs), C.c_int(mode))
         return obs, rew, rgt, term, trunc, fobs
+
+
+# ---------------------------------------------------------------------------------------------------
+# AnyMDP task sampler arithmetic (xeno_oracle_sampler.c)
+# ---------------------------------------------------------------------------------------------------
+def np_pairwise_sum(a):
+    a = np.ascontiguousarray(a, np.float64).reshape(-1)
+    return lib().xo_np_pairwise_sum(_p(a), C.c_int64(a.size))
+
+
+def update_value_matrix(t_mat, r_mat, gamma, vm, is_greedy=True):
+    """solver.py:57-82 in the reference's order of operations -> (value matrix, sweeps)"""
+    t = np.ascontiguousarray(t_mat, np.float64)
+    r = np.ascontiguousarray(r_mat, np.float64)
+    ns, na, _ = t.shape
+    out = np.array(vm, np.float64, order="C", copy=True).reshape(ns, na)
+    it = lib().xo_update_value_matrix(_p(t), _p(r), C.c_int(ns), C.c_int(na), C.c_double(float(gamma)), _p(out),
+                                      C.c_int(1 if is_greedy else 0))
+    return out, int(it)

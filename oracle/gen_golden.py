@@ -479,7 +479,86 @@ def gen_garnet():
     print("garnet_8x2_seed3.npz")
 
 
-FAMILIES = {"anymdp": gen_anymdp, "linds": gen_linds, "maze": gen_maze, "acrobot": gen_acrobot, "garnet": gen_garnet}
+def gen_anymdp_vi():
+    """The reference's own update_value_matrix (solver.py:57-82) on reference-sampled tasks: greedy and uniform-policy
+    values at the repair loop's gamma (0.99) and at check_valuefunction's gamma (2^(-1/ns)), plus a warm-started chain
+    with shifted terminal rewards (how sample_mdp's repair loop calls it).  Pins oracle xo_update_value_matrix."""
+    _refimport.setup()
+    from xenoverse.anymdp.solver import update_value_matrix
+    out = {}
+    for seed in (0, 2):
+        task = sample_ref_tasks.get(16, 4, seed)
+        T, R = np.asarray(task["transition"], np.float64), np.asarray(task["reward"], np.float64)
+        ns, na, _ = T.shape
+        out["T%d" % seed], out["R%d" % seed] = T, R
+        for gi, gamma in enumerate((0.99, float(np.power(2, -1.0 / ns)))):
+            for greedy in (1, 0):
+                out["vm_s%d_g%d_%d" % (seed, gi, greedy)] = update_value_matrix(T, R, gamma, np.zeros((ns, na)),
+                                                                               is_greedy=bool(greedy))
+        out["gamma%d" % seed] = np.array([0.99, float(np.power(2, -1.0 / ns))])
+        vm = np.zeros((ns, na))
+        bonus = np.zeros(ns)
+        rng = np.random.RandomState(seed)
+        for k in range(3):        # warm starts, as the repair loop does
+            vm = update_value_matrix(T, R + bonus[None, None, :], 0.99, vm)
+            out["chain_s%d_%d" % (seed, k)] = np.copy(vm)
+            out["chain_bonus_s%d_%d" % (seed, k)] = np.copy(bonus)
+            bonus[-1] += rng.uniform(1.0, 10.0)
+            bonus[rng.randint(0, ns - 1)] -= rng.uniform(1.0, 10.0)
+    np.savez_compressed(os.path.join(GOLD, "anymdp_vi_ref.npz"), **out)
+    print("anymdp_vi_ref.npz", os.path.getsize(os.path.join(GOLD, "anymdp_vi_ref.npz")) // 1024, "KiB")
+
+
+def gen_anymdp_sampled(n=32, seed0=100):
+    """n tasks of the reference's AnyMDPTaskSampler(16, 4, seed = seed0 + k) with the sampler's own bookkeeping: how
+    many candidates sample_mdp produced, how many of them could not be repaired (None) and how many
+    check_valuefunction rejected.  Used (a) for the seed-compatibility test of the build's sampler and (b) as the
+    reference population for the distribution tests of the device sampler."""
+    _, ts = _refimport.anymdp()
+    import numpy.random as npr
+    counts = {"cand": 0, "none": 0, "rej": 0}
+    real_sample, real_check = ts.sample_mdp, ts.check_valuefunction
+
+    def sample_mdp(*a, **k):
+        r = real_sample(*a, **k)
+        counts["cand"] += 1
+        counts["none"] += r is None
+        return r
+
+    def check(*a, **k):
+        ok = real_check(*a, **k)
+        counts["rej"] += not ok
+        return ok
+    ts.sample_mdp, ts.check_valuefunction = sample_mdp, check
+    keys = ("transition", "reward", "reward_noise")
+    out = {k: [] for k in keys}
+    meta = {k: [] for k in ("max_steps", "state_mapping", "s_e_mask", "s_0_mask", "s_0_prob", "goal", "n_cand", "n_none",
+                            "n_rej", "seed")}
+    try:
+        for k in range(n):
+            for c in counts:
+                counts[c] = 0
+            task = ts.AnyMDPTaskSampler(16, 4, seed=seed0 + k)
+            for kk in keys:
+                out[kk].append(np.asarray(task[kk], np.float64))
+            se = np.zeros(16, np.uint8); se[np.asarray(task["s_e"], np.int64).reshape(-1)] = 1
+            s0 = np.zeros(16, np.uint8); s0[np.asarray(task["s_0"], np.int64)] = 1
+            p0 = np.zeros(16); p0[np.asarray(task["s_0"], np.int64)] = task["s_0_prob"]
+            meta["max_steps"].append(task["max_steps"]); meta["state_mapping"].append(task["state_mapping"])
+            meta["s_e_mask"].append(se); meta["s_0_mask"].append(s0); meta["s_0_prob"].append(p0)
+            meta["goal"].append(bool(task["final_goal_terminate"]))
+            meta["n_cand"].append(counts["cand"]); meta["n_none"].append(counts["none"]); meta["n_rej"].append(counts["rej"])
+            meta["seed"].append(seed0 + k)
+            print("seed", seed0 + k, dict(counts), flush=True)
+    finally:
+        ts.sample_mdp, ts.check_valuefunction = real_sample, real_check
+    path = os.path.join(GOLD, "anymdp_refsampled_16x4.npz")
+    np.savez_compressed(path, **{k: np.stack(v) for k, v in out.items()}, **{k: np.asarray(v) for k, v in meta.items()})
+    print("anymdp_refsampled_16x4.npz", os.path.getsize(path) // 1024, "KiB")
+
+
+FAMILIES = {"anymdp": gen_anymdp, "linds": gen_linds, "maze": gen_maze, "acrobot": gen_acrobot, "garnet": gen_garnet,
+            "anymdp_vi": gen_anymdp_vi, "anymdp_sampled": gen_anymdp_sampled}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

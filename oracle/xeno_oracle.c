@@ -958,6 +958,7 @@ void xo_maze_step(xo_maze* h, const double* action, float* reward, uint8_t* term
         h->grid[e] = in[1]; h->grid[(size_t)N + e] = in[2];
         h->pos[e] = in[1] * cs + 0.5 * cs; h->pos[(size_t)N + e] = in[2] * cs + 0.5 * cs;
         h->ori[e] = 0.0; h->cmd_idx[e] = 0; h->cmd_age[e] = 0; h->steps[e] = 0;
+        h->collision[e] = 0.0; /* as xo_maze_reset does */
       } else if (mode == 1) {
         h->need_reset[e] = 1;
       }

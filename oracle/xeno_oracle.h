@@ -83,6 +83,11 @@ void xo_anymdp_tok_step(xo_anymdp_tok* h, uint64_t seed, uint64_t gid_base, uint
                         int32_t* final_obs, int mode);
 int xo_max_threads(void);
 
+/* ---- task-sampler arithmetic (xeno_oracle_sampler.c) ---- */
+double xo_np_pairwise_sum(const double* a, int64_t n);
+int xo_update_value_matrix(const double* t_mat, const double* r_mat, int ns, int na, double gamma, double* vm,
+                           int is_greedy);
+
 /* ---------------------------------------------------------------------------------------------
  * LinDS — reference: linds/linds_env.py.  fp32 arithmetic in the device's fixed operation order.
  * Batch-wide padded dims NS (state), NA (= pad_action_dim), NO (= pad_observation_dim = pad_command_dim).

@@ -82,7 +82,8 @@ def _cmp(dev, ora, exact_state=True):
 
 @pytest.mark.parametrize("mode", ["disabled", "next_step", "same_step"])
 @pytest.mark.parametrize("layout,path", [("grouped64", "mfma"), ("grouped64", "scalar"), ("grouped32", "mfma"),
-                                         ("grouped32", "scalar"), ("ragged", "mfma"), ("mixed", "auto")])
+                                         ("grouped32", "scalar"), ("ragged", "mfma"), ("mixed", "mfma"),
+                                         ("mixed", "scalar"), ("odd_counts", "mfma")])
 def test_batch_injected_vs_oracle(mode, layout, path):
     tasks, tab, env_task = _batch(64 if layout not in ("grouped32", "ragged") else 32, FILES[:4])
     rng = np.random.RandomState(3)
@@ -90,13 +91,13 @@ def test_batch_injected_vs_oracle(mode, layout, path):
         rng.shuffle(env_task)              # lanes of one wave hold different tasks: the waterfall path
     if layout == "ragged":
         env_task = env_task[:-13]          # last tile is partial
+    if layout == "odd_counts":             # tasks with 1 / 33 / 64 / 7 envs, interleaved: padded tiles in the slot layout
+        env_task = np.array([0] * 1 + [1] * 33 + [2] * 64 + [3] * 7, np.int32)
+        rng.shuffle(env_task)
     n = len(env_task)
     env = LinDSVecEnv(n, autoreset_mode=mode)
     env.set_task(tasks, env_task_index=env_task)
     env.set_path(path)
-    if layout == "mixed":
-        with pytest.raises(Exception):
-            env.set_path("mfma")           # tiles are not task-uniform
     ora = oracle.LinDSOracle(tab, env_task)
     n_init = tab["ints"][env_task, 2]
     idx0 = (rng.random_sample(n) * n_init).astype(np.int32)
@@ -233,4 +234,33 @@ def test_get_future_inner_cmds():
     d, valid = int(task["target_delay"]), np.asarray(task["target_valid"], np.float64)
     ref = np.stack([task["command"](5 - d + k) * valid for k in range(K)])
     assert np.allclose(fut[0, :, :8], ref, rtol=1e-5, atol=1e-5) and np.allclose(fut[0], fut[2])
+    env.close()
+
+
+def test_state_accessors_under_the_slot_layout():
+    """an interleaved env -> task map makes the engine keep its state in slot order (tiles of 32 per task); get_state /
+    set_state / `state` speak the caller's env order, and a step after set_state equals the oracle's from that state"""
+    tasks, tab, env_task = _batch(40, FILES[:4])
+    rng = np.random.RandomState(12)
+    rng.shuffle(env_task)
+    n = len(env_task)
+    env = LinDSVecEnv(n, autoreset_mode="disabled")
+    env.set_task(tasks, env_task_index=env_task)
+    ora = oracle.LinDSOracle(tab, env_task)
+    idx = np.zeros(n, np.int32)
+    env.reset_injected(idx); ora.reset_injected(idx)
+    x0 = rng.uniform(-0.2, 0.2, (tab["NS"], n)).astype(np.float32)
+    st0 = rng.randint(0, 20, n).astype(np.int32)
+    env.set_state(x=x0, steps=st0, need_reset=np.zeros(n, np.uint8))
+    ora.x[:] = x0; ora.steps[:] = st0; ora.need_reset[:] = 0
+    x, st, nr = env.get_state()
+    assert np.array_equal(_np(x), x0) and np.array_equal(_np(st), st0) and not _np(nr).any()
+    assert np.array_equal(_np(env.state), x0.T)
+    for path in ("mfma", "scalar"):
+        env.set_path(path)
+        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        z = rng.standard_normal((tab["NS"], n)).astype(np.float32)
+        _cmp(env.step_injected(a, z, idx), ora.step_injected(a, z, idx, 0))
+        x, st, nr = env.get_state()
+        assert np.array_equal(_np(x), ora.x) and np.array_equal(_np(st), ora.steps)
     env.close()

@@ -98,6 +98,94 @@ def test_anymdp_task_sampler_schema_and_validity():
     assert cdf.shape == (1, 4, 16, 16) and (n_obs, d_obs, d_act) == (16, 4, 2)
 
 
+def _numpy_matches_fixture_host():
+    """The fixtures were written on a host whose NumPy evaluates exp/log with its AVX512 kernels; those differ from the
+    scalar/AVX2 kernels in the last bit for a few per cent of the arguments, so the reference itself gives (slightly)
+    different task tensors per machine class.  Bit-for-bit equality is asserted where this fingerprint matches."""
+    x = np.linspace(-30.0, 0.0, 4097)
+    import hashlib
+    return hashlib.sha256(np.exp(x).tobytes()).hexdigest()[:16] == "b3409591d6bdf429"
+
+
+def _same(a, b, exact):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.array_equal(a, b) if exact else (a.shape == b.shape and np.allclose(a, b, rtol=1e-9, atol=1e-12))
+
+
+@pytest.mark.parametrize("name,ns,na,seed", [("anymdp_16x4_seed0", 16, 4, 0), ("anymdp_16x4_seed1", 16, 4, 1),
+                                             ("anymdp_16x4_seed2", 16, 4, 2), ("anymdp_16x4_seed3", 16, 4, 3),
+                                             ("anymdp_64x8_seed1", 64, 8, 1)])
+def test_seeded_anymdp_sampler_reproduces_the_reference_task(name, ns, na, seed):
+    """AnyMDPTaskSampler(ns, na, seed) == the task the reference's sampler returned for that seed (the fixtures' task
+    tensors): same random stream, same draw order, same value-iteration arithmetic in the repair loop"""
+    import os
+    from util import GOLD, load_anymdp_golden
+    from xenoverse_amd.anymdp import AnyMDPTaskSampler
+    g, ref = load_anymdp_golden(os.path.join(GOLD, name + ".npz"))
+    t = AnyMDPTaskSampler(ns, na, seed=seed)
+    exact = _numpy_matches_fixture_host()
+    assert float(t["max_steps"]) == float(ref["max_steps"])
+    for k in ("state_mapping", "s_0", "s_e"):
+        assert np.array_equal(np.asarray(t[k]).reshape(-1), np.asarray(ref[k]).reshape(-1)), k
+    for k in ("s_0_prob", "transition", "reward", "reward_noise"):
+        assert _same(t[k], ref[k], exact), k
+
+
+@pytest.mark.parametrize("name,kind,seed", [("anymdptok_pomdp_16x4_seed5", "pomdp", 5),
+                                            ("anymdptok_mtpomdp_16x4_seed0", "mt", 0),
+                                            ("anymdptok_mtpomdp_16x4_seed6", "mt", 6)])
+def test_seeded_pomdp_samplers_reproduce_the_reference_tasks(name, kind, seed):
+    """the emission matrices come from the SAME stream, right after the MDP (task_sampler.py:78-87,103-117)"""
+    import os
+    from util import GOLD, load_anymdp_tok_golden
+    from xenoverse_amd.anymdp import AnyPOMDPTaskSampler, MultiTokensAnyPOMDPTaskSampler
+    g, ref = load_anymdp_tok_golden(os.path.join(GOLD, name + ".npz"))
+    fn = AnyPOMDPTaskSampler if kind == "pomdp" else MultiTokensAnyPOMDPTaskSampler
+    t = fn(16, 4, observation_space=16, seed=seed)
+    exact = _numpy_matches_fixture_host()
+    assert np.array_equal(t["state_mapping"], ref["state_mapping"]) and np.array_equal(t["s_e"], ref["s_e"])
+    for k in ("transition", "reward", "reward_noise"):
+        assert _same(t[k], ref[k], exact), k
+    assert _same(np.asarray(t["observation_transition"]), np.asarray(ref["observation_transition"]), True)
+
+
+def test_seeded_sampler_reproduces_32_reference_sampled_tasks():
+    """tests/golden/anymdp_refsampled_16x4.npz: 32 tasks of the reference's sampler (seeds 100..131) with its own
+    candidate / unrepairable / rejected counts — the build's sampler walks the same candidates"""
+    import os
+    from util import GOLD
+    from xenoverse_amd.anymdp import task_sampler as ts
+    g = np.load(os.path.join(GOLD, "anymdp_refsampled_16x4.npz"))
+    exact = _numpy_matches_fixture_host()
+    counts = {"cand": 0, "none": 0, "rej": 0}
+    real_cand, real_acc = ts._ReferenceStream.candidate, ts.reference_acceptance
+
+    def cand(self, *a, **k):
+        r = real_cand(self, *a, **k)
+        counts["cand"] += 1
+        counts["none"] += r is None
+        return r
+
+    def acc(task):
+        ok = real_acc(task)
+        counts["rej"] += not ok
+        return ok
+    ts._ReferenceStream.candidate, ts.reference_acceptance = cand, acc
+    try:
+        for k, seed in enumerate(g["seed"]):
+            for c in counts:
+                counts[c] = 0
+            t = ts.AnyMDPTaskSampler(16, 4, seed=int(seed))
+            assert (counts["cand"], counts["none"], counts["rej"]) == (g["n_cand"][k], g["n_none"][k], g["n_rej"][k]), seed
+            assert float(t["max_steps"]) == float(g["max_steps"][k])
+            assert np.array_equal(np.nonzero(g["s_e_mask"][k])[0], np.asarray(t["s_e"], np.int64).reshape(-1))
+            assert bool(t["final_goal_terminate"]) == bool(g["goal"][k])
+            for kk in ("transition", "reward", "reward_noise"):
+                assert _same(t[kk], g[kk][k], exact), (seed, kk)
+    finally:
+        ts._ReferenceStream.candidate, ts.reference_acceptance = real_cand, real_acc
+
+
 def test_acceptance_rule_agrees_with_reference_when_available():
     """container-only cross-check: the reference's check_valuefunction and value iteration vs this restatement"""
     import os

@@ -36,6 +36,7 @@ SIGNATURES = {
     "xv_anymdp_set_step_many_graph": [c_void_p, c_int],
     "xv_anymdp_solve": [c_void_p, C.c_double, C.c_double, c_int, c_void_p, c_void_p, c_void_p],
     "xv_anymdp_step_many_graph_state": [c_void_p],
+    "xv_anymdp_value_iteration_gs": [c_void_p, c_void_p, c_int, c_int, C.c_double, c_int, c_void_p, c_void_p],
     "xv_anymdp_rollout": [c_void_p, c_int] + [c_void_p] * 7,
     "xv_anymdp_set_search": [c_void_p, c_int],
     "xv_anymdp_set_observation_model": [c_void_p, c_int, c_int, c_int, c_void_p],
@@ -92,7 +93,7 @@ class XenoError(RuntimeError):
     pass
 
 
-ABI_VERSION = 2      # include/xeno.h XV_ABI_VERSION
+ABI_VERSION = 3      # include/xeno.h XV_ABI_VERSION
 
 
 def load():

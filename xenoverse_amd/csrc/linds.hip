@@ -13,6 +13,8 @@
 // arrive through the scalar cache as SGPR operands of v_fma_f32 (s_load_dwordx16) — 6 KB per (wave, task)
 // instead of 6 KB per env.  With envs grouped by task (64 per task = one wave per task) every wave makes one
 // pass.
+#include <vector>
+
 #include "philox.h"
 #include "xv_common.h"
 
@@ -32,6 +34,15 @@ struct LinDSArgs {
   // engine-built reset table: rst_tab[task][init index][NO + 4] = the observation of initial_states[idx] (NO floats)
   // and its tracking error against cmd(0) (slot NO): a restarting env reads 80 B instead of redoing y = C x + Y
   const float* rst_tab;
+  // Slot layout (nullptr / n_slot == n_env: identity).  When the caller's env -> task map does not put 32 envs of one
+  // task side by side, the engine orders its own state by task instead: envs are sorted by task (stably) and packed
+  // into tiles of 32 slots, a task's last tile padded with empty slots (slot_env = -1).  State arrays (x, steps,
+  // need_reset) are indexed by SLOT with stride n_slot; everything the caller sees (actions, outputs, global env id of
+  // the random draws) stays indexed by ENV, so results do not depend on the layout.
+  const int32_t* slot_env;   // [n_slot] env of a slot or -1
+  const int32_t* env_slot;   // [n_env]  slot of an env
+  const int32_t* tile_task;  // [n_slot / 32]
+  int n_slot;
 };
 
 struct LinDSStepIO {
@@ -50,7 +61,8 @@ struct LinDSStepIO {
 struct xv_linds {
   xv_engine* eng;
   LinDSArgs a;
-  bool tiles_uniform;   // every aligned 32-env group shares a task -> MFMA path
+  bool tiles_uniform;   // every aligned 32-env group of the CALLER's order shares a task (else: slot layout)
+  int32_t *d_slot_env, *d_env_slot, *d_tile_task;   // owned; null in the identity layout
   int path;             // XV_LINDS_PATH_*
   float* cmd_tab;       // owned; a.cmd_tab points here while the table is enabled
   float* rst_tab;       // owned; likewise
@@ -228,12 +240,14 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
   const int N = P.n_env;
+  const int NSL = P.n_slot;
+  const int si = P.env_slot ? P.env_slot[i] : i;   // where this env's state lives
   const int t = P.env_task[i];
   const uint64_t gid = P.gid_base + (uint64_t)i;
 
-  float xs[NS], a_raw[NA], z[NS];
+  float xs[NS], a_raw[NA];
 #pragma unroll
-  for (int k = 0; k < NS; ++k) xs[k] = P.x[(size_t)k * N + i];
+  for (int k = 0; k < NS; ++k) xs[k] = P.x[(size_t)k * NSL + si];
   {
     const float4* a4 = reinterpret_cast<const float4*>(io.action + (size_t)i * NA);
 #pragma unroll
@@ -242,21 +256,10 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
       a_raw[4 * q] = v.x; a_raw[4 * q + 1] = v.y; a_raw[4 * q + 2] = v.z; a_raw[4 * q + 3] = v.w;
     }
   }
-  int steps = P.steps[i];
-  int nr = P.need_reset[i];
+  int steps = P.steps[si];
+  int nr = P.need_reset[si];
   int init_idx = 0;
-  if (INJECT) {
-#pragma unroll
-    for (int k = 0; k < NS; ++k) z[k] = io.z[(size_t)k * N + i];
-    init_idx = io.init_index[i];
-  } else {
-#pragma unroll
-    for (int q = 0; q < NS / 4; ++q) {   // purpose 16+q: words (0,1) -> z[4q], z[4q+1]; (2,3) -> z[4q+2], z[4q+3]
-      const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_NOISE + (uint32_t)q);
-      xv_box_muller(w.x, w.y, &z[4 * q], &z[4 * q + 1]);
-      xv_box_muller(w.z, w.w, &z[4 * q + 2], &z[4 * q + 3]);
-    }
-  }
+  if (INJECT) init_idx = io.init_index[i];
 
   float y[NO], crep[NO], fobs[NO];
   float o_r = 0.0f, o_err = 0.0f;
@@ -313,10 +316,23 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
         const float noise_scale = sc[4];
         bool bad = false;
 #pragma unroll
-        for (int j = 0; j < NS; ++j) {   // + Xt + noise
-          xn[j] = xn[j] + xtv[j];
-          xn[j] = fmaf(noise_scale, z[j], xn[j]);
-          bad = bad || !(fabsf(xn[j]) <= 3.0e38f);
+        for (int q = 0; q < NS / 4; ++q) {   // + Xt + noise, four components at a time (the normals are made here, not
+          float z[4];                        // held in 32 registers across the products: that spilled to scratch)
+          if (INJECT) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) z[k] = io.z[(size_t)(4 * q + k) * N + i];
+          } else {   // purpose 16+q: words (0,1) -> z[4q], z[4q+1]; (2,3) -> z[4q+2], z[4q+3]
+            const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_NOISE + (uint32_t)q);
+            xv_box_muller_fast(w.x, w.y, &z[0], &z[1]);
+            xv_box_muller_fast(w.z, w.w, &z[2], &z[3]);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int j = 4 * q + k;
+            xn[j] = xn[j] + xtv[j];
+            xn[j] = fmaf(noise_scale, z[k], xn[j]);
+            bad = bad || !(fabsf(xn[j]) <= 3.0e38f);
+          }
         }
         if (bad) err |= XV_DEVERR_NONFINITE;
         linds_observe<NS, NO>(P, tu, xn, y);      // :145
@@ -354,9 +370,9 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
   }
 
 #pragma unroll
-  for (int k = 0; k < NS; ++k) P.x[(size_t)k * N + i] = xs[k];
-  P.steps[i] = steps;
-  P.need_reset[i] = (uint8_t)nr;
+  for (int k = 0; k < NS; ++k) P.x[(size_t)k * NSL + si] = xs[k];
+  P.steps[si] = steps;
+  P.need_reset[si] = (uint8_t)nr;
   linds_store_row<NO>(io.obs + (size_t)i * NO, y);
   linds_store_row<NO>(io.cmd + (size_t)i * NO, crep);
   io.reward[i] = o_r;
@@ -380,7 +396,8 @@ __global__ __launch_bounds__(256) void linds_reset_kernel(LinDSArgs P, const uin
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
   if (mask && !mask[i]) return;
-  const int N = P.n_env;
+  const int NSL = P.n_slot;
+  const int si = P.env_slot ? P.env_slot[i] : i;
   const int t = P.env_task[i];
   float xs[NS], y[NO], c[NO];
   float e = 0.0f;
@@ -397,9 +414,9 @@ __global__ __launch_bounds__(256) void linds_reset_kernel(LinDSArgs P, const uin
     }
   }
 #pragma unroll
-  for (int k = 0; k < NS; ++k) P.x[(size_t)k * N + i] = xs[k];
-  P.steps[i] = 0;
-  P.need_reset[i] = 0;
+  for (int k = 0; k < NS; ++k) P.x[(size_t)k * NSL + si] = xs[k];
+  P.steps[si] = 0;
+  P.need_reset[si] = 0;
   if (obs) linds_store_row<NO>(obs + (size_t)i * NO, y);
   if (cmd) linds_store_row<NO>(cmd + (size_t)i * NO, c);
   if (error) error[i] = e;
@@ -467,12 +484,17 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
   const int lane = threadIdx.x & 63;
   const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int tile0 = wave * 32;
-  if (tile0 >= P.n_env) return;   // wave-uniform
-  const int N = P.n_env;
+  if (tile0 >= P.n_slot) return;   // wave-uniform
+  const int N = P.n_env;           // stride of the caller's env-ordered arrays
+  const int NSL = P.n_slot;        // stride of the engine's slot-ordered state
   const int c = lane & 31, h = lane >> 5;
-  const bool valid = tile0 + c < N;
-  const int e = valid ? tile0 + c : N - 1;
-  const int t = __builtin_amdgcn_readfirstlane(P.env_task[tile0]);
+  // es: this lane's state slot; e: the env it serves (its I/O rows and the global id of its draws)
+  int e_raw = tile0 + c;
+  if (P.slot_env != nullptr) e_raw = P.slot_env[tile0 + c < NSL ? tile0 + c : NSL - 1];
+  const bool valid = tile0 + c < NSL && e_raw >= 0 && e_raw < N;
+  const int es = tile0 + c < NSL ? tile0 + c : NSL - 1;
+  const int e = valid ? e_raw : 0;
+  const int t = __builtin_amdgcn_readfirstlane(P.tile_task ? P.tile_task[wave] : P.env_task[tile0]);
   const uint64_t gid = P.gid_base + (uint64_t)e;
   constexpr int NR = NS / 2;   // registers of the accumulator that hold real state components
 
@@ -480,8 +502,8 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
   const XV_CONST_AS int32_t* in = xv_cptr(P.T.ints) + (size_t)t * 4;
   const int max_steps = in[0], delay = in[1], n_init = in[2], nf = in[3];
 
-  int steps = P.steps[e];
-  int nr = P.need_reset[e];
+  int steps = P.steps[es];
+  int nr = P.need_reset[es];
   float a_raw[NA];
   {
     const float4* a4 = reinterpret_cast<const float4*>(io.action + (size_t)e * NA);
@@ -505,7 +527,7 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
     const int k = 2 * kk + h;
     const float v = phiT[k * NS + cs];
     pa[kk] = c < NS ? v : 0.0f;
-    pb[kk] = P.x[(size_t)k * N + e];
+    pb[kk] = P.x[(size_t)k * NSL + es];
   }
 #pragma unroll
   for (int kk = 0; kk < NA / 2; ++kk) {
@@ -515,6 +537,36 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
   linds_load_c_frag<NS, NO>(P, t, c, h, ca);
 #pragma unroll
   for (int r = 0; r < NR; ++r) xtr[r] = xtv[linds_row_of(r, h)];
+  // the two lanes of an env share the command work: half 0 fetches the tracked command cmd(steps - delay) (:150-151),
+  // half 1 the reported one cmd(steps + 1) (:168).  The table row is requested here, with everything else, so that
+  // its latency (a second dependent level: steps -> row address) runs under the products; a time outside the table
+  // is evaluated directly further down
+  const int steps_new = steps + 1;                            // :147
+  const int cmd_time = h ? steps_new : steps_new - 1 - delay;
+  const int cmd_idx = cmd_time - P.ct_tmin;
+  const bool cmd_in_tab = P.cmd_tab != nullptr && cmd_idx >= 0 && cmd_idx < P.ct_len;
+  float cmine[NO];
+  if (P.cmd_tab != nullptr) {
+    const float4* p = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + (cmd_in_tab ? cmd_idx : 0)) * NO);
+#pragma unroll
+    for (int q = 0; q < NO / 4; ++q) {
+      const float4 v = p[q];
+      cmine[4 * q] = v.x; cmine[4 * q + 1] = v.y; cmine[4 * q + 2] = v.z; cmine[4 * q + 3] = v.w;
+    }
+  }
+  // process noise: independent of every load above, so it is computed while they are in flight
+  float zr[NR];
+  if (INJECT) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) zr[r] = io.z[(size_t)linds_row_of(r, h) * N + e];
+  } else {
+#pragma unroll
+    for (int rr = 0; rr < NR / 4; ++rr) {   // components 4q..4q+3 come from Philox call q = 2 rr + h
+      const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_NOISE + (uint32_t)(2 * rr + h));
+      xv_box_muller_fast(w.x, w.y, &zr[4 * rr], &zr[4 * rr + 1]);
+      xv_box_muller_fast(w.z, w.w, &zr[4 * rr + 2], &zr[4 * rr + 3]);
+    }
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- x' = Phi x + Gamma act  (:78-80) ----
@@ -532,18 +584,6 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
   }
   // + Xt + noise on this lane's NR components
   const float noise_scale = sc[4];
-  float zr[NR];
-  if (INJECT) {
-#pragma unroll
-    for (int r = 0; r < NR; ++r) zr[r] = io.z[(size_t)linds_row_of(r, h) * N + e];
-  } else {
-#pragma unroll
-    for (int rr = 0; rr < NR / 4; ++rr) {   // components 4q..4q+3 come from Philox call q = 2 rr + h
-      const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_NOISE + (uint32_t)(2 * rr + h));
-      xv_box_muller(w.x, w.y, &zr[4 * rr], &zr[4 * rr + 1]);
-      xv_box_muller(w.z, w.w, &zr[4 * rr + 2], &zr[4 * rr + 3]);
-    }
-  }
   xv_f32x16 xn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int bad = 0;
 #pragma unroll
@@ -559,12 +599,11 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
 #pragma unroll
   for (int j = 0; j < NO; ++j) fobs[j] = 0.0f;
   linds_observe_mfma<NS, NO>(P, t, h, ca, xn, y);
-  const int steps_new = steps + 1;                            // :147
   {
-    // the two lanes of an env share the command work: half 0 evaluates the tracked command cmd(steps-1-delay)
-    // (:150-151), half 1 the reported one cmd(steps) (:168); one __shfl_xor per component exchanges them
-    float cmine[NO];
-    linds_cmd_at<NO>(P, t, nf, h ? steps_new : steps_new - 1 - delay, cmine);
+    if (__ballot(!cmd_in_tab) != 0ull) {   // rare: no table, or an env stepped on outside it (auto-reset disabled)
+      if (!cmd_in_tab) linds_cmd<NO>(P, t, nf, cmd_time, cmine);
+    }
+    // one __shfl_xor per component exchanges the two commands between the halves
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
       const float cother = __shfl_xor(cmine[j], 32);
@@ -637,7 +676,7 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
   // ---- stores ----
   if (valid) {
 #pragma unroll
-    for (int r = 0; r < NR; ++r) P.x[(size_t)linds_row_of(r, h) * N + e] = xn[r];
+    for (int r = 0; r < NR; ++r) P.x[(size_t)linds_row_of(r, h) * NSL + es] = xn[r];
     // each half stores half of the observation / command row
     float oh[NO / 2], ch[NO / 2], fh[NO / 2];
 #pragma unroll
@@ -651,8 +690,8 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
     linds_store_row<NO / 2>(io.cmd + ro, ch);
     if (io.final_obs) linds_store_row<NO / 2>(io.final_obs + ro, fh);
     if (h == 0) {
-      P.steps[e] = steps;
-      P.need_reset[e] = (uint8_t)nr;
+      P.steps[es] = steps;
+      P.need_reset[es] = (uint8_t)nr;
       io.reward[e] = o_r;
       io.error[e] = o_err;
       io.terminated[e] = (uint8_t)o_term;
@@ -696,32 +735,87 @@ extern "C" int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int 
   a.err = e->d_err;
   a.seed = e->seed; a.gid_base = e->env_id_base; a.tick = 0;
   a.x = nullptr; a.steps = nullptr; a.need_reset = nullptr;
-  hipError_t m = hipMalloc(&a.x, sizeof(float) * (size_t)NS * n_env);
-  if (m == hipSuccess) m = hipMalloc(&a.steps, sizeof(int32_t) * (size_t)n_env);
-  if (m == hipSuccess) m = hipMalloc(&a.need_reset, (size_t)n_env);
-  if (m == hipSuccess) m = hipMemsetAsync(a.x, 0, sizeof(float) * (size_t)NS * n_env, e->stream);
-  if (m == hipSuccess) m = hipMemsetAsync(a.steps, 0, sizeof(int32_t) * (size_t)n_env, e->stream);
-  if (m == hipSuccess) m = hipMemsetAsync(a.need_reset, 1, (size_t)n_env, e->stream);
+  a.slot_env = nullptr; a.env_slot = nullptr; a.tile_task = nullptr; a.n_slot = n_env;
+  h->d_slot_env = nullptr; h->d_env_slot = nullptr; h->d_tile_task = nullptr;
+  hipError_t m = hipSuccess;
+  {
+    int* d_flag = nullptr;
+    int h_flag = 1;
+    m = hipMalloc(&d_flag, sizeof(int));
+    if (m == hipSuccess) m = hipMemsetAsync(d_flag, 0, sizeof(int), e->stream);
+    if (m == hipSuccess) {
+      hipLaunchKernelGGL(linds_check_tiles_kernel, dim3(xv_div_up(n_env, 256)), dim3(256), 0, e->stream, env_task,
+                         n_env, d_flag);
+      m = hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+    }
+    if (m == hipSuccess) m = hipStreamSynchronize(e->stream);
+    if (d_flag) (void)hipFree(d_flag);
+    h->tiles_uniform = (h_flag == 0);
+    h->path = XV_LINDS_PATH_AUTO;
+  }
+  if (m == hipSuccess && !h->tiles_uniform) {
+    // slot layout: stable counting sort of the envs by task, every task's envs packed into whole 32-slot tiles
+    std::vector<int32_t> et((size_t)n_env);
+    m = hipMemcpy(et.data(), env_task, sizeof(int32_t) * (size_t)n_env, hipMemcpyDeviceToHost);
+    if (m == hipSuccess) {
+      std::vector<int64_t> first((size_t)n_task + 1, 0);
+      bool ok = true;
+      for (int i = 0; i < n_env; ++i) {
+        if (et[i] < 0 || et[i] >= n_task) { ok = false; break; }
+        first[(size_t)et[i] + 1] += 1;
+      }
+      if (!ok) {
+        xv_set_error("xv_linds_create: env_task entry outside [0, n_task)");
+        delete h;
+        return XV_ERR_INVALID;
+      }
+      int64_t n_slot = 0;
+      std::vector<int64_t> base((size_t)n_task);
+      for (int t = 0; t < n_task; ++t) {
+        base[t] = n_slot;
+        n_slot += (first[(size_t)t + 1] + 31) / 32 * 32;
+      }
+      if (n_slot > (int64_t)1 << 30) {
+        xv_set_error("xv_linds_create: slot layout too large");
+        delete h;
+        return XV_ERR_UNSUPPORTED;
+      }
+      std::vector<int32_t> slot_env((size_t)n_slot, -1), env_slot((size_t)n_env), tile_task((size_t)(n_slot / 32));
+      std::vector<int64_t> fill(base);
+      for (int i = 0; i < n_env; ++i) {
+        const int64_t sl = fill[et[i]]++;
+        slot_env[(size_t)sl] = i;
+        env_slot[i] = (int32_t)sl;
+      }
+      for (int t = 0; t < n_task; ++t)
+        for (int64_t q = base[t] / 32; q < (t + 1 < n_task ? base[t + 1] : n_slot) / 32; ++q) tile_task[(size_t)q] = t;
+      a.n_slot = (int)n_slot;
+      m = hipMalloc(&h->d_slot_env, sizeof(int32_t) * (size_t)n_slot);
+      if (m == hipSuccess) m = hipMalloc(&h->d_env_slot, sizeof(int32_t) * (size_t)n_env);
+      if (m == hipSuccess) m = hipMalloc(&h->d_tile_task, sizeof(int32_t) * (size_t)(n_slot / 32));
+      if (m == hipSuccess) m = hipMemcpy(h->d_slot_env, slot_env.data(), sizeof(int32_t) * (size_t)n_slot, hipMemcpyHostToDevice);
+      if (m == hipSuccess) m = hipMemcpy(h->d_env_slot, env_slot.data(), sizeof(int32_t) * (size_t)n_env, hipMemcpyHostToDevice);
+      if (m == hipSuccess) m = hipMemcpy(h->d_tile_task, tile_task.data(), sizeof(int32_t) * (size_t)(n_slot / 32), hipMemcpyHostToDevice);
+      a.slot_env = h->d_slot_env; a.env_slot = h->d_env_slot; a.tile_task = h->d_tile_task;
+    }
+  }
+  const size_t nsl = (size_t)a.n_slot;
+  if (m == hipSuccess) m = hipMalloc(&a.x, sizeof(float) * (size_t)NS * nsl);
+  if (m == hipSuccess) m = hipMalloc(&a.steps, sizeof(int32_t) * nsl);
+  if (m == hipSuccess) m = hipMalloc(&a.need_reset, nsl);
+  if (m == hipSuccess) m = hipMemsetAsync(a.x, 0, sizeof(float) * (size_t)NS * nsl, e->stream);
+  if (m == hipSuccess) m = hipMemsetAsync(a.steps, 0, sizeof(int32_t) * nsl, e->stream);
+  if (m == hipSuccess) m = hipMemsetAsync(a.need_reset, 1, nsl, e->stream);
   if (m != hipSuccess) {
     xv_set_error("xv_linds_create: device allocation failed: %s", hipGetErrorString(m));
     if (a.x) (void)hipFree(a.x);
     if (a.steps) (void)hipFree(a.steps);
     if (a.need_reset) (void)hipFree(a.need_reset);
+    if (h->d_slot_env) (void)hipFree(h->d_slot_env);
+    if (h->d_env_slot) (void)hipFree(h->d_env_slot);
+    if (h->d_tile_task) (void)hipFree(h->d_tile_task);
     delete h;
     return XV_ERR_HIP;
-  }
-  {
-    int* d_flag = nullptr;
-    int h_flag = 1;
-    XV_HIP(hipMalloc(&d_flag, sizeof(int)));
-    XV_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), e->stream));
-    hipLaunchKernelGGL(linds_check_tiles_kernel, dim3(xv_div_up(n_env, 256)), dim3(256), 0, e->stream, env_task,
-                       n_env, d_flag);
-    XV_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    XV_HIP(hipStreamSynchronize(e->stream));
-    XV_HIP(hipFree(d_flag));
-    h->tiles_uniform = (h_flag == 0);
-    h->path = XV_LINDS_PATH_AUTO;
   }
   // command table: [n_task][max_steps_max + 2 + delay_max][NO] floats, within a 2-GiB budget
   a.cmd_tab = nullptr; a.ct_len = 0; a.ct_tmin = 0; a.rst_tab = nullptr;
@@ -776,11 +870,7 @@ extern "C" int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int 
 
 extern "C" int xv_linds_set_path(xv_linds* h, int path) {
   XV_CHECK_ARG(h != nullptr && path >= 0 && path <= 2);
-  if (path == XV_LINDS_PATH_MFMA && !h->tiles_uniform) {
-    xv_set_error("xv_linds_set_path: MFMA needs every aligned group of 32 envs to share one task");
-    return XV_ERR_UNSUPPORTED;
-  }
-  h->path = path;
+  h->path = path;   // both kernels serve any env -> task map (the MFMA kernel through the engine's slot layout)
   return XV_OK;
 }
 
@@ -802,6 +892,9 @@ extern "C" int xv_linds_destroy(xv_linds* h) {
   (void)hipFree(h->a.x);
   (void)hipFree(h->a.steps);
   (void)hipFree(h->a.need_reset);
+  if (h->d_slot_env) (void)hipFree(h->d_slot_env);
+  if (h->d_env_slot) (void)hipFree(h->d_env_slot);
+  if (h->d_tile_task) (void)hipFree(h->d_tile_task);
   if (h->cmd_tab) (void)hipFree(h->cmd_tab);
   if (h->rst_tab) (void)hipFree(h->rst_tab);
   delete h;
@@ -833,9 +926,9 @@ static inline void linds_bind_rng(xv_linds* h, uint64_t ticks) {
 template <bool INJECT>
 static int linds_launch_step(xv_linds* h, const LinDSStepIO& io, int mode) {
   const dim3 block(256);
-  const bool mfma = h->tiles_uniform && h->path != XV_LINDS_PATH_SCALAR;
+  const bool mfma = h->path != XV_LINDS_PATH_SCALAR;
   if (mfma) {
-    const dim3 grid(xv_div_up(xv_div_up(h->a.n_env, 32), 4));   // one wave per 32-env tile, 4 tiles per block
+    const dim3 grid(xv_div_up(xv_div_up(h->a.n_slot, 32), 4));   // one wave per 32-slot tile, 4 tiles per block
 #define LINDS_STEP_M(NS_, NA_, NO_, dummy) \
   hipLaunchKernelGGL((linds_step_mfma_kernel<NS_, NA_, NO_, INJECT>), grid, block, 0, h->eng->stream, h->a, io, mode)
     LINDS_DISPATCH(LINDS_STEP_M, 0);
@@ -898,8 +991,30 @@ extern "C" int xv_linds_step_injected(xv_linds* h, const float* action, const fl
   return linds_launch_step<true>(h, io, autoreset_mode);
 }
 
+// state <-> caller order when the engine keeps it in slot order
+template <bool TO_ENV>
+__global__ __launch_bounds__(256) void linds_permute_state_kernel(LinDSArgs P, float* x, int32_t* steps, uint8_t* need_reset) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n_env) return;
+  const int N = P.n_env, NSL = P.n_slot, si = P.env_slot[i];
+  if (x) {
+    for (int k = 0; k < P.NS; ++k) {
+      if (TO_ENV) x[(size_t)k * N + i] = P.x[(size_t)k * NSL + si];
+      else P.x[(size_t)k * NSL + si] = x[(size_t)k * N + i];
+    }
+  }
+  if (steps) { if (TO_ENV) steps[i] = P.steps[si]; else P.steps[si] = steps[i]; }
+  if (need_reset) { if (TO_ENV) need_reset[i] = P.need_reset[si]; else P.need_reset[si] = need_reset[i]; }
+}
+
 extern "C" int xv_linds_get_state(xv_linds* h, float* x, int32_t* steps, uint8_t* need_reset) {
   XV_CHECK_ARG(h != nullptr);
+  if (h->a.env_slot != nullptr) {
+    hipLaunchKernelGGL((linds_permute_state_kernel<true>), dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
+                       h->a, x, steps, need_reset);
+    XV_LAUNCH_CHECK();
+    return XV_OK;
+  }
   const size_t n = (size_t)h->a.n_env;
   if (x) XV_HIP(hipMemcpyAsync(x, h->a.x, n * h->a.NS * 4, hipMemcpyDeviceToDevice, h->eng->stream));
   if (steps) XV_HIP(hipMemcpyAsync(steps, h->a.steps, n * 4, hipMemcpyDeviceToDevice, h->eng->stream));
@@ -909,6 +1024,12 @@ extern "C" int xv_linds_get_state(xv_linds* h, float* x, int32_t* steps, uint8_t
 
 extern "C" int xv_linds_set_state(xv_linds* h, const float* x, const int32_t* steps, const uint8_t* need_reset) {
   XV_CHECK_ARG(h != nullptr);
+  if (h->a.env_slot != nullptr) {
+    hipLaunchKernelGGL((linds_permute_state_kernel<false>), dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
+                       h->a, const_cast<float*>(x), const_cast<int32_t*>(steps), const_cast<uint8_t*>(need_reset));
+    XV_LAUNCH_CHECK();
+    return XV_OK;
+  }
   const size_t n = (size_t)h->a.n_env;
   if (x) XV_HIP(hipMemcpyAsync(h->a.x, x, n * h->a.NS * 4, hipMemcpyDeviceToDevice, h->eng->stream));
   if (steps) XV_HIP(hipMemcpyAsync(h->a.steps, steps, n * 4, hipMemcpyDeviceToDevice, h->eng->stream));
