@@ -295,7 +295,8 @@ def test_step_then_masked_reset_keeps_returned_tensors():
     obs = env.step(np.zeros(n, np.int32))[0]
     keep = obs.clone()
     o2, _ = env.reset(options={"reset_mask": mask})
-    assert torch.equal(obs, keep) and torch.equal(o2[~mt], keep[~mt]) and bool((o2[mt] <= 2).all())
+    assert torch.equal(obs, keep) and torch.equal(o2[~mt], keep[~mt])
+    assert bool((env.inner_state[mt] <= 2).all())            # the masked envs restarted in s_0 = {0, 1, 2}
     env.close()
     # linds
     env = LinDSVecEnv(n, autoreset_mode="disabled", seed=1)
