@@ -292,9 +292,9 @@ int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int NA, int NO,
                     const xv_linds_tables* tables, const int32_t* env_task, xv_linds** out);
 int xv_linds_destroy(xv_linds* h);
 /* kernel selection (results are identical, bit for bit on the state/observation path):
- *   MFMA    one wave per tile of 32 envs that share a task, x' = Phi x + Gamma a and y = C x' on
- *           v_mfma_f32_32x32x2_f32.  When the caller's env -> task map does not put 32 envs of one task side by side,
- *           xv_linds_create orders the engine's own state by task (32-slot tiles per task, the last one padded) and the
+ *   MFMA    one wave per tile of 16 envs that share a task, x' = Phi x + Gamma a and y = C x' on
+ *           v_mfma_f32_16x16x4_f32.  When the caller's env -> task map does not put 16 envs of one task side by side,
+ *           xv_linds_create orders the engine's own state by task (16-slot tiles per task, the last one padded) and the
  *           kernel reaches actions / outputs through a slot -> env index: any map, same results
  *   SCALAR  one lane per env, task matrices as scalar-cache broadcast operands, waterfall over the tasks of a
  *           wave: any env -> task mapping (the independent second implementation the parity tests compare with)

@@ -334,12 +334,12 @@ void xo_anymdp_synth(uint64_t seed, int64_t task_index_base, int n_task, int S, 
  *   y_j  = fmaf chain over k in xo_linds_yorder() of C[j][k]*x'[k], then + Y[j]
  * ---------------------------------------------------------------------------------------------- */
 int xo_linds_yorder(int NS, int* ord) {
-  /* accumulator register r of lane-half h of a 32x32 MFMA tile holds row (r&3) + 8*(r>>2) + 4*h; a k-slab of
-   * the next 32x32x2 product takes (h=0, h=1) of one register */
+  /* the device forms y = C x' with 16x16x4 matrix instructions fed straight from the accumulators of x': M-tile m,
+   * register r of lane group g holds row 16 m + 4 g + r, and slab s = 4 m + r adds its four k's in g order */
   int n = 0;
-  for (int r = 0; r < 16; ++r)
-    for (int hh = 0; hh < 2; ++hh) {
-      int k = (r & 3) + 8 * (r >> 2) + 4 * hh;
+  for (int s = 0; s < 8; ++s)
+    for (int g = 0; g < 4; ++g) {
+      int k = 16 * (s >> 2) + 4 * g + (s & 3);
       if (k < NS) ord[n++] = k;
     }
   return n;

@@ -34,14 +34,14 @@ struct LinDSArgs {
   // engine-built reset table: rst_tab[task][init index][NO + 4] = the observation of initial_states[idx] (NO floats)
   // and its tracking error against cmd(0) (slot NO): a restarting env reads 80 B instead of redoing y = C x + Y
   const float* rst_tab;
-  // Slot layout (nullptr / n_slot == n_env: identity).  When the caller's env -> task map does not put 32 envs of one
+  // Slot layout (nullptr / n_slot == n_env: identity).  When the caller's env -> task map does not put 16 envs of one
   // task side by side, the engine orders its own state by task instead: envs are sorted by task (stably) and packed
-  // into tiles of 32 slots, a task's last tile padded with empty slots (slot_env = -1).  State arrays (x, steps,
+  // into tiles of 16 slots, a task's last tile padded with empty slots (slot_env = -1).  State arrays (x, steps,
   // need_reset) are indexed by SLOT with stride n_slot; everything the caller sees (actions, outputs, global env id of
   // the random draws) stays indexed by ENV, so results do not depend on the layout.
   const int32_t* slot_env;   // [n_slot] env of a slot or -1
   const int32_t* env_slot;   // [n_env]  slot of an env
-  const int32_t* tile_task;  // [n_slot / 32]
+  const int32_t* tile_task;  // [n_slot / 16]
   int n_slot;
 };
 
@@ -61,7 +61,7 @@ struct LinDSStepIO {
 struct xv_linds {
   xv_engine* eng;
   LinDSArgs a;
-  bool tiles_uniform;   // every aligned 32-env group of the CALLER's order shares a task (else: slot layout)
+  bool tiles_uniform;   // every aligned 16-env group of the CALLER's order shares a task (else: slot layout)
   int32_t *d_slot_env, *d_env_slot, *d_tile_task;   // owned; null in the identity layout
   int path;             // XV_LINDS_PATH_*
   float* cmd_tab;       // owned; a.cmd_tab points here while the table is enabled
@@ -80,10 +80,11 @@ __device__ __forceinline__ const XV_CONST_AS T* xv_cptr(const T* p) {
 #pragma clang diagnostic pop
 }
 
-// k order of the observation product: the order in which a 32x32x2 MFMA chain visits k when x' is consumed
-// from the accumulator layout of the previous product (register r, lane-half h -> row (r&3)+8(r>>2)+4h)
+// k order of the observation product: the order in which a chain of 16x16x4 MFMAs visits k when x' is consumed from
+// the accumulator layout of the previous product (M-tile m, register r, lane group g hold row 16 m + 4 g + r; slab
+// s = 4 m + r adds its four k's in g order): position p = 4 s + g
 __host__ __device__ constexpr int linds_yorder_at(int p) {
-  return ((p >> 1) & 3) + 8 * ((p >> 1) >> 2) + 4 * (p & 1);
+  return 16 * (p >> 4) + 4 * (p & 3) + ((p >> 2) & 3);
 }
 
 // command at integer time tt, times target_valid (uniform task tu; per-lane time)
@@ -423,80 +424,53 @@ __global__ __launch_bounds__(256) void linds_reset_kernel(LinDSArgs P, const uin
 }
 
 // ------------------------------------------------------------------------------------------------
-// MFMA path: one wave = one tile of 32 envs that share a task (checked at create time).
+// MFMA path: one wave = one tile of 16 envs that share a task (the caller's order, or the engine's slot layout).
 //
-//   x'^T = Phi X^T + Gamma A^T   as  D[j][env] = sum_k A[j][k] B[k][env]   with v_mfma_f32_32x32x2_f32:
-//     A operand (lane l = 32h + c): Phi[j = c][k = 2kk + h] = phiT[k][c]   -- a coalesced 128-B segment per half
-//     B operand:                    x_env(c)[k = 2kk + h]  = X[k][tile + c] -- the component-major state, coalesced
-//     D (16 regs): register r of lane (c, h) = x'_env(c)[ j = (r&3) + 8(r>>2) + 4h ]
-//   so every env's new state sits in the two lanes (c,0), (c,1), 16 components each, and — the point of this
-//   orientation — register r of a lane IS the B operand of k-slab r of the next product
-//   y^T = C x'^T  (A operand C[jo = c][k = j(r,h)] = cT[k][c]).  No LDS, no shuffles between the two products.
-//   The MFMA accumulates D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) in k order, bit for bit the fmaf chains of
-//   the scalar kernel and of the oracle (k = 0..NS-1, then Gamma; y in linds_yorder).
-//   Per-env scalar work (commands, error, reward, flags) is done redundantly by both lanes of an env after one
-//   __shfl_xor(.., 32) per observation component.
+//   v_mfma_f32_16x16x4_f32, lane l = 16 g + n:   A[i = n][k = g]   B[k = g][col = n]   D reg r = D[row = 4 g + r][col = n]
+//   (probed on gfx950, scripts/devtools/mfma16_probe.hip: the four k-products are added to the accumulator as an
+//   ascending fmaf chain — bit for bit the chains of the scalar kernel and of the oracle).
+//
+//   x'^T = Phi X^T + Gamma A^T, rows in M-tiles of 16:  D_m[j = 16 m + row][env]:
+//     A operand of k-slab kk: Phi[16 m + n][4 kk + g] = phiT[4 kk + g][16 m + n]   -- 64-B segments of phiT rows
+//     B operand:              x_env(n)[4 kk + g]      = X[4 kk + g][tile + n]      -- the component-major state
+//     so lane (n, g) ends up with x'_env(n)[16 m + 4 g + r] in register r of tile m — exactly the four components
+//     Philox call q = 4 m + g provides the process noise for, and
+//   y^T = C x'^T takes those registers as its B operands directly: slab s = 4 m + r multiplies the k-group
+//     {16 m + 4 g + r : g = 0..3} (A operand C[16 mo + n][that k] = cT[k][16 mo + n]).  No LDS, no shuffles between
+//     the products; the price is the k order of y, linds_yorder_at, which scalar kernel and oracle follow.
+//   Half the tile width of a 32x32x2 formulation: twice the waves for the same batch (4 per SIMD at 65,536 envs) and
+//   a quarter of the MFMA latency per k (8 passes per 4 k instead of 16 per 2) — this kernel is latency-bound.
+//   Per-env scalar work (error, reward, flags) is done redundantly by the four lanes of an env; each lane stores its
+//   own 16-byte quarter of the observation / command rows.
 // ------------------------------------------------------------------------------------------------
-typedef float xv_f32x16 __attribute__((ext_vector_type(16)));
+typedef float xv_f32x4 __attribute__((ext_vector_type(4)));
 
-// cond ? hi : lo on two register values, opaque to hipcc (which otherwise folds a select of two array elements
-// into one dynamically indexed stack access, i.e. scratch memory)
-__device__ __forceinline__ float xv_sel_opaque(int cond, float lo, float hi) {
-  asm volatile("" : "+v"(lo), "+v"(hi));
-  return cond ? hi : lo;
-}
-
-__device__ __forceinline__ int linds_row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// C fragments of this lane for the observation product: ca[r] = C[jo = c][k = row_of(r, h)] (0 for c >= NO).
-// Loaded once, up front and without a branch (a `c < NO ? load : 0` becomes a branch + vmcnt(0) per MFMA).
-template <int NS, int NO>
-__device__ __forceinline__ void linds_load_c_frag(const LinDSArgs& P, int t, int c, int h, float (&ca)[NS / 2]) {
-  const float* cT = P.T.cT + (size_t)t * NS * NO;
-  const int cc = c < NO ? c : NO - 1;
-#pragma unroll
-  for (int r = 0; r < NS / 2; ++r) {
-    const float v = cT[linds_row_of(r, h) * NO + cc];
-    ca[r] = c < NO ? v : 0.0f;
-  }
-}
-
-// y (all NO components, canonical order) of the tile's envs for state registers xr (this lane's 16 components)
-template <int NS, int NO>
-__device__ __forceinline__ void linds_observe_mfma(const LinDSArgs& P, int t, int h, const float (&ca)[NS / 2],
-                                                   const xv_f32x16& xr, float (&yfull)[NO]) {
-  xv_f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int r = 0; r < NS / 2; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[r], xr[r], acc, 0, 0, 0);
-  const XV_CONST_AS float* y0 = xv_cptr(P.T.y0) + (size_t)t * NO;
-  // this lane holds jo = linds_row_of(r', h) for r' < NO/2; the other half of the env holds the rest
-#pragma unroll
-  for (int jo = 0; jo < NO; ++jo) {
-    const int rr = (jo & 3) + 4 * (jo >> 3), hh = (jo >> 2) & 1;
-    const float mine = acc[rr];
-    const float other = __shfl_xor(mine, 32);
-    yfull[jo] = ((hh == h) ? mine : other) + y0[jo];   // :85
-  }
+// v[g] for a lane-varying g in 0..3, opaque to hipcc (which otherwise folds a select over array elements into one
+// dynamically indexed stack access, i.e. scratch memory)
+__device__ __forceinline__ float xv_sel4(int g, float a, float b, float c, float d) {
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  const float lo = (g & 1) ? b : a, hi = (g & 1) ? d : c;
+  return (g & 2) ? hi : lo;
 }
 
 template <int NS, int NA, int NO, bool INJECT>
-__global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDSStepIO io, int mode) {
+__device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const LinDSStepIO& io, int mode) {
   const int lane = threadIdx.x & 63;
   const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  const int tile0 = wave * 32;
+  const int tile0 = wave * 16;
   if (tile0 >= P.n_slot) return;   // wave-uniform
   const int N = P.n_env;           // stride of the caller's env-ordered arrays
   const int NSL = P.n_slot;        // stride of the engine's slot-ordered state
-  const int c = lane & 31, h = lane >> 5;
+  const int n = lane & 15, g = lane >> 4;
+  constexpr int MT = NS / 16, MO = NO / 16, KS = NS / 4, KA = NA / 4;
   // es: this lane's state slot; e: the env it serves (its I/O rows and the global id of its draws)
-  int e_raw = tile0 + c;
-  if (P.slot_env != nullptr) e_raw = P.slot_env[tile0 + c < NSL ? tile0 + c : NSL - 1];
-  const bool valid = tile0 + c < NSL && e_raw >= 0 && e_raw < N;
-  const int es = tile0 + c < NSL ? tile0 + c : NSL - 1;
+  const int es = tile0 + n < NSL ? tile0 + n : NSL - 1;
+  int e_raw = tile0 + n;
+  if (P.slot_env != nullptr) e_raw = P.slot_env[es];
+  const bool valid = tile0 + n < NSL && e_raw >= 0 && e_raw < N;
   const int e = valid ? e_raw : 0;
   const int t = __builtin_amdgcn_readfirstlane(P.tile_task ? P.tile_task[wave] : P.env_task[tile0]);
   const uint64_t gid = P.gid_base + (uint64_t)e;
-  constexpr int NR = NS / 2;   // registers of the accumulator that hold real state components
 
   const XV_CONST_AS float* sc = xv_cptr(P.T.scal) + (size_t)t * 8;
   const XV_CONST_AS int32_t* in = xv_cptr(P.T.ints) + (size_t)t * 4;
@@ -519,96 +493,134 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
   // ---- all operand fragments first: every load of the step is in flight before the first MFMA ----
   const float* phiT = P.T.phiT + (size_t)t * NS * NS;
   const float* gamT = P.T.gamT + (size_t)t * NA * NS;
+  const float* cT = P.T.cT + (size_t)t * NS * NO;
   const float* xtv = P.T.xt + (size_t)t * NS;
-  const int cs = c < NS ? c : NS - 1;
-  float pa[NS / 2], pb[NS / 2], ga[NA / 2], ca[NR], xtr[NR];
+  float pa[MT][KS], pb[KS], ga[MT][KA], ca[MO][KS], xtr[MT][4];
 #pragma unroll
-  for (int kk = 0; kk < NS / 2; ++kk) {
-    const int k = 2 * kk + h;
-    const float v = phiT[k * NS + cs];
-    pa[kk] = c < NS ? v : 0.0f;
+  for (int kk = 0; kk < KS; ++kk) {
+    const int k = 4 * kk + g;
     pb[kk] = P.x[(size_t)k * NSL + es];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) pa[m][kk] = phiT[k * NS + 16 * m + n];
   }
 #pragma unroll
-  for (int kk = 0; kk < NA / 2; ++kk) {
-    const float v = gamT[(2 * kk + h) * NS + cs];
-    ga[kk] = c < NS ? v : 0.0f;
-  }
-  linds_load_c_frag<NS, NO>(P, t, c, h, ca);
+  for (int kk = 0; kk < KA; ++kk)
 #pragma unroll
-  for (int r = 0; r < NR; ++r) xtr[r] = xtv[linds_row_of(r, h)];
-  // the two lanes of an env share the command work: half 0 fetches the tracked command cmd(steps - delay) (:150-151),
-  // half 1 the reported one cmd(steps + 1) (:168).  The table row is requested here, with everything else, so that
-  // its latency (a second dependent level: steps -> row address) runs under the products; a time outside the table
+    for (int m = 0; m < MT; ++m) ga[m][kk] = gamT[(4 * kk + g) * NS + 16 * m + n];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 16 * (s >> 2) + 4 * g + (s & 3);
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo) ca[mo][s] = cT[k * NO + 16 * mo + n];
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xtr[m][r] = xtv[16 * m + 4 * g + r];
+  // command rows, requested with everything else so that their latency (a second dependent level: steps -> row
+  // address) runs under the products: the tracked command cmd(steps - delay) in full (:150-151; the error needs all
+  // of it) and this lane's quarter of the reported one cmd(steps + 1) (:168).  A time outside the table (or no table)
   // is evaluated directly further down
   const int steps_new = steps + 1;                            // :147
-  const int cmd_time = h ? steps_new : steps_new - 1 - delay;
-  const int cmd_idx = cmd_time - P.ct_tmin;
-  const bool cmd_in_tab = P.cmd_tab != nullptr && cmd_idx >= 0 && cmd_idx < P.ct_len;
-  float cmine[NO];
+  const int trk_time = steps_new - 1 - delay, rep_time = steps_new;
+  const int trk_idx = trk_time - P.ct_tmin, rep_idx = rep_time - P.ct_tmin;
+  const bool trk_in = P.cmd_tab != nullptr && trk_idx >= 0 && trk_idx < P.ct_len;
+  const bool rep_in = P.cmd_tab != nullptr && rep_idx >= 0 && rep_idx < P.ct_len;
+  float ctrack[NO], crep[MO][4];
   if (P.cmd_tab != nullptr) {
-    const float4* p = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + (cmd_in_tab ? cmd_idx : 0)) * NO);
+    const float4* p = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + (trk_in ? trk_idx : 0)) * NO);
 #pragma unroll
     for (int q = 0; q < NO / 4; ++q) {
       const float4 v = p[q];
-      cmine[4 * q] = v.x; cmine[4 * q + 1] = v.y; cmine[4 * q + 2] = v.z; cmine[4 * q + 3] = v.w;
+      ctrack[4 * q] = v.x; ctrack[4 * q + 1] = v.y; ctrack[4 * q + 2] = v.z; ctrack[4 * q + 3] = v.w;
+    }
+    const float4* pr = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + (rep_in ? rep_idx : 0)) * NO);
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo) {
+      const float4 v = pr[4 * mo + g];
+      crep[mo][0] = v.x; crep[mo][1] = v.y; crep[mo][2] = v.z; crep[mo][3] = v.w;
     }
   }
-  // process noise: independent of every load above, so it is computed while they are in flight
-  float zr[NR];
-  if (INJECT) {
+  // process noise: independent of every load above, so it is computed while they are in flight.  Philox call
+  // q = 4 m + g yields the normals of components 4 q .. 4 q + 3 = 16 m + 4 g + r
+  float zr[MT][4];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) zr[r] = io.z[(size_t)linds_row_of(r, h) * N + e];
-  } else {
+  for (int m = 0; m < MT; ++m) {
+    if (INJECT) {
 #pragma unroll
-    for (int rr = 0; rr < NR / 4; ++rr) {   // components 4q..4q+3 come from Philox call q = 2 rr + h
-      const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_NOISE + (uint32_t)(2 * rr + h));
-      xv_box_muller_fast(w.x, w.y, &zr[4 * rr], &zr[4 * rr + 1]);
-      xv_box_muller_fast(w.z, w.w, &zr[4 * rr + 2], &zr[4 * rr + 3]);
+      for (int r = 0; r < 4; ++r) zr[m][r] = io.z[(size_t)(16 * m + 4 * g + r) * N + e];
+    } else {
+      const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_NOISE + (uint32_t)(4 * m + g));
+      xv_box_muller_fast(w.x, w.y, &zr[m][0], &zr[m][1]);
+      xv_box_muller_fast(w.z, w.w, &zr[m][2], &zr[m][3]);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---- x' = Phi x + Gamma act  (:78-80) ----
-  xv_f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // ---- x' = Phi x + Gamma act  (:78-80): MT independent accumulator chains, interleaved ----
+  xv_f32x4 acc[MT];
 #pragma unroll
-  for (int kk = 0; kk < NS / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], pb[kk], acc, 0, 0, 0);
+  for (int m = 0; m < MT; ++m) acc[m] = xv_f32x4{0, 0, 0, 0};
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[m][kk], pb[kk], acc[m], 0, 0, 0);
   float sa = 0.0f;
 #pragma unroll
   for (int k = 0; k < NA; ++k) sa = fmaf(a_raw[k], a_raw[k], sa);   // :164 cost on the RAW padded action
 #pragma unroll
-  for (int kk = 0; kk < NA / 2; ++kk) {
-    const float ar = xv_sel_opaque(h, a_raw[2 * kk], a_raw[2 * kk + 1]);
+  for (int kk = 0; kk < KA; ++kk) {
+    const float ar = xv_sel4(g, a_raw[4 * kk], a_raw[4 * kk + 1], a_raw[4 * kk + 2], a_raw[4 * kk + 3]);
     const float b = ar < -1.0f ? -1.0f : (ar > 1.0f ? 1.0f : ar);   // :138 clip
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[kk], b, acc, 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[m][kk], b, acc[m], 0, 0, 0);
   }
-  // + Xt + noise on this lane's NR components
+  // + Xt + noise on this lane's components
   const float noise_scale = sc[4];
-  xv_f32x16 xn = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  xv_f32x4 xn[MT];
   int bad = 0;
 #pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    float v = acc[r] + xtr[r];
-    v = fmaf(noise_scale, zr[r], v);
-    bad |= !(fabsf(v) <= 3.0e38f);
-    xn[r] = v;
-  }
-
-  // ---- y = C x' + Y (:145), commands, error, reward, flags ----
-  float y[NO], ctrack[NO], crep[NO], fobs[NO];
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-  for (int j = 0; j < NO; ++j) fobs[j] = 0.0f;
-  linds_observe_mfma<NS, NO>(P, t, h, ca, xn, y);
-  {
-    if (__ballot(!cmd_in_tab) != 0ull) {   // rare: no table, or an env stepped on outside it (auto-reset disabled)
-      if (!cmd_in_tab) linds_cmd<NO>(P, t, nf, cmd_time, cmine);
+    for (int r = 0; r < 4; ++r) {
+      float v = acc[m][r] + xtr[m][r];
+      v = fmaf(noise_scale, zr[m][r], v);
+      bad |= !(fabsf(v) <= 3.0e38f);
+      xn[m][r] = v;
     }
-    // one __shfl_xor per component exchanges the two commands between the halves
+
+  // ---- y = C x' + Y (:145): slab s = 4 m + r takes register r of tile m ----
+  const XV_CONST_AS float* y0 = xv_cptr(P.T.y0) + (size_t)t * NO;
+  xv_f32x4 ym[MO];   // this lane's rows 16 mo + 4 g + r
 #pragma unroll
-    for (int j = 0; j < NO; ++j) {
-      const float cother = __shfl_xor(cmine[j], 32);
-      ctrack[j] = xv_sel_opaque(h, cmine[j], cother);
-      crep[j] = xv_sel_opaque(h, cother, cmine[j]);
+  for (int mo = 0; mo < MO; ++mo) ym[mo] = xv_f32x4{0, 0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo)
+      ym[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[mo][s], xn[s >> 2][s & 3], ym[mo], 0, 0, 0);
+#pragma unroll
+  for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ym[mo][r] = ym[mo][r] + xv_sel4(g, y0[16 * mo + r], y0[16 * mo + 4 + r], y0[16 * mo + 8 + r], y0[16 * mo + 12 + r]);   // :85
+  // the whole observation of the env in every one of its lanes, canonical order (error and scale are chains over j)
+  float y[NO];
+#pragma unroll
+  for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+    for (int gs = 0; gs < 4; ++gs)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[16 * mo + 4 * gs + r] = __shfl(ym[mo][r], n + 16 * gs);
+  if (__ballot(!(trk_in && rep_in)) != 0ull) {   // rare: no table, or an env stepped on outside it (auto-reset disabled)
+    if (!trk_in) linds_cmd<NO>(P, t, nf, trk_time, ctrack);
+    if (!rep_in) {
+      float full[NO];
+      linds_cmd<NO>(P, t, nf, rep_time, full);
+#pragma unroll
+      for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          crep[mo][r] = xv_sel4(g, full[16 * mo + r], full[16 * mo + 4 + r], full[16 * mo + 8 + r], full[16 * mo + 12 + r]);
     }
   }
   float o_err = linds_err<NO>(P, t, y, ctrack);               // :153
@@ -628,44 +640,74 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
   const bool done = !skip && (o_term || o_trunc);
   const bool do_reset = skip || (done && mode == XV_AUTORESET_SAME_STEP);
   int wrote_fobs = 0;
+  xv_f32x4 fobs[MO];
+#pragma unroll
+  for (int mo = 0; mo < MO; ++mo) fobs[mo] = xv_f32x4{0, 0, 0, 0};
   if (skip) {
     o_r = 0.0f; o_term = 0; o_trunc = 0; bad = 0;
   } else {
     steps = steps_new;
     if (done && mode == XV_AUTORESET_NEXT_STEP) nr = 1;
   }
-  if (__ballot(do_reset) != 0ull) {   // wave-uniform: one more observation product for the restarted envs
+  if (__ballot(do_reset) != 0ull) {   // wave-uniform: the restarted envs take their initial state
     if (!INJECT) init_idx = linds_draw_init(P, gid, n_init);
     const int idx = init_idx < 0 ? 0 : (init_idx >= n_init ? n_init - 1 : init_idx);
     const float* x0 = P.T.init + ((size_t)t * P.NI + idx) * NS;
-    xv_f32x16 xr = xn;
-    if (do_reset) {
+    xv_f32x4 xr[MT];
 #pragma unroll
-      for (int r = 0; r < NR; ++r) xr[r] = x0[linds_row_of(r, h)];   // :117
+    for (int m = 0; m < MT; ++m) {
+      xr[m] = xn[m];
+      if (do_reset) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xr[m][r] = x0[16 * m + 4 * g + r];   // :117
+      }
     }
-    float yr[NO], c0[NO], e0;
+    float c0[NO], e0;
     linds_cmd_at<NO>(P, t, nf, 0, c0);                // :120-126
+    xv_f32x4 yr[MO];
     if (P.rst_tab != nullptr) {                        // observation and error of initial_states[idx], tabulated
       const float4* row = reinterpret_cast<const float4*>(P.rst_tab + ((size_t)t * P.NI + idx) * (NO + 4));
 #pragma unroll
-      for (int q = 0; q < NO / 4; ++q) {
-        const float4 v = row[q];
-        yr[4 * q] = v.x; yr[4 * q + 1] = v.y; yr[4 * q + 2] = v.z; yr[4 * q + 3] = v.w;
+      for (int mo = 0; mo < MO; ++mo) {
+        const float4 v = row[4 * mo + g];
+        yr[mo][0] = v.x; yr[mo][1] = v.y; yr[mo][2] = v.z; yr[mo][3] = v.w;
       }
       e0 = row[NO / 4].x;
     } else {
-      linds_observe_mfma<NS, NO>(P, t, h, ca, xr, yr);
-      e0 = linds_err<NO>(P, t, yr, c0);
+#pragma unroll
+      for (int mo = 0; mo < MO; ++mo) yr[mo] = xv_f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo)
+          yr[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[mo][s], xr[s >> 2][s & 3], yr[mo], 0, 0, 0);
+      float yfull[NO];
+#pragma unroll
+      for (int mo = 0; mo < MO; ++mo) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yr[mo][r] = yr[mo][r] + xv_sel4(g, y0[16 * mo + r], y0[16 * mo + 4 + r], y0[16 * mo + 8 + r], y0[16 * mo + 12 + r]);
+#pragma unroll
+        for (int gs = 0; gs < 4; ++gs)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) yfull[16 * mo + 4 * gs + r] = __shfl(yr[mo][r], n + 16 * gs);
+      }
+      e0 = linds_err<NO>(P, t, yfull, c0);
     }
     if (do_reset) {
       if (!skip) {
 #pragma unroll
-        for (int j = 0; j < NO; ++j) fobs[j] = y[j];
+        for (int mo = 0; mo < MO; ++mo) fobs[mo] = ym[mo];
         wrote_fobs = 1;
       }
-      xn = xr;
 #pragma unroll
-      for (int j = 0; j < NO; ++j) { y[j] = yr[j]; crep[j] = c0[j]; }
+      for (int m = 0; m < MT; ++m) xn[m] = xr[m];
+#pragma unroll
+      for (int mo = 0; mo < MO; ++mo) {
+        ym[mo] = yr[mo];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          crep[mo][r] = xv_sel4(g, c0[16 * mo + r], c0[16 * mo + 4 + r], c0[16 * mo + 8 + r], c0[16 * mo + 12 + r]);
+      }
       o_err = e0;
       steps = 0;
       nr = 0;
@@ -676,20 +718,19 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
   // ---- stores ----
   if (valid) {
 #pragma unroll
-    for (int r = 0; r < NR; ++r) P.x[(size_t)linds_row_of(r, h) * NSL + es] = xn[r];
-    // each half stores half of the observation / command row
-    float oh[NO / 2], ch[NO / 2], fh[NO / 2];
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int q = 0; q < NO / 2; ++q) {
-      oh[q] = xv_sel_opaque(h, y[q], y[NO / 2 + q]);
-      ch[q] = xv_sel_opaque(h, crep[q], crep[NO / 2 + q]);
-      fh[q] = wrote_fobs ? xv_sel_opaque(h, fobs[q], fobs[NO / 2 + q]) : 0.0f;
+      for (int r = 0; r < 4; ++r) P.x[(size_t)(16 * m + 4 * g + r) * NSL + es] = xn[m][r];
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo) {   // each lane stores its own 16-byte quarter of the rows
+      const size_t ro = (size_t)e * NO + 16 * mo + 4 * g;
+      *reinterpret_cast<float4*>(io.obs + ro) = make_float4(ym[mo][0], ym[mo][1], ym[mo][2], ym[mo][3]);
+      *reinterpret_cast<float4*>(io.cmd + ro) = make_float4(crep[mo][0], crep[mo][1], crep[mo][2], crep[mo][3]);
+      if (io.final_obs)
+        *reinterpret_cast<float4*>(io.final_obs + ro) =
+            wrote_fobs ? make_float4(fobs[mo][0], fobs[mo][1], fobs[mo][2], fobs[mo][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const size_t ro = (size_t)e * NO + (size_t)h * (NO / 2);
-    linds_store_row<NO / 2>(io.obs + ro, oh);
-    linds_store_row<NO / 2>(io.cmd + ro, ch);
-    if (io.final_obs) linds_store_row<NO / 2>(io.final_obs + ro, fh);
-    if (h == 0) {
+    if (g == 0) {
       P.steps[es] = steps;
       P.need_reset[es] = (uint8_t)nr;
       io.reward[e] = o_r;
@@ -701,11 +742,23 @@ __global__ __launch_bounds__(256) void linds_step_mfma_kernel(LinDSArgs P, LinDS
   if (bad && valid) atomicOr(P.err, (uint32_t)XV_DEVERR_NONFINITE);
 }
 
-// every aligned group of 32 envs shares one task?  (decides MFMA vs scalar-broadcast path)
+// two entry points over the same body: with 16 observation rows the step fits 128 registers and is capped there
+// (4 waves per SIMD: the kernel is latency-bound); with 32 rows the cap would spill, so it runs at 2-3 waves per SIMD
+template <int NS, int NA, int NO, bool INJECT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void linds_step_mfma_kernel(LinDSArgs P, LinDSStepIO io, int mode) {
+  linds_step_mfma_body<NS, NA, NO, INJECT>(P, io, mode);
+}
+template <int NS, int NA, int NO, bool INJECT>
+__global__ __launch_bounds__(256) void linds_step_mfma_wide_kernel(LinDSArgs P, LinDSStepIO io, int mode) {
+  linds_step_mfma_body<NS, NA, NO, INJECT>(P, io, mode);
+}
+
+// every aligned group of 16 envs shares one task?  (else the engine builds its slot layout)
 __global__ __launch_bounds__(256) void linds_check_tiles_kernel(const int32_t* env_task, int n_env, int* not_uniform) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_env) return;
-  if (env_task[i] != env_task[i & ~31]) atomicOr(not_uniform, 1);
+  if (env_task[i] != env_task[i & ~15]) atomicOr(not_uniform, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -754,7 +807,7 @@ extern "C" int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int 
     h->path = XV_LINDS_PATH_AUTO;
   }
   if (m == hipSuccess && !h->tiles_uniform) {
-    // slot layout: stable counting sort of the envs by task, every task's envs packed into whole 32-slot tiles
+    // slot layout: stable counting sort of the envs by task, every task's envs packed into whole 16-slot tiles
     std::vector<int32_t> et((size_t)n_env);
     m = hipMemcpy(et.data(), env_task, sizeof(int32_t) * (size_t)n_env, hipMemcpyDeviceToHost);
     if (m == hipSuccess) {
@@ -773,14 +826,14 @@ extern "C" int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int 
       std::vector<int64_t> base((size_t)n_task);
       for (int t = 0; t < n_task; ++t) {
         base[t] = n_slot;
-        n_slot += (first[(size_t)t + 1] + 31) / 32 * 32;
+        n_slot += (first[(size_t)t + 1] + 15) / 16 * 16;
       }
       if (n_slot > (int64_t)1 << 30) {
         xv_set_error("xv_linds_create: slot layout too large");
         delete h;
         return XV_ERR_UNSUPPORTED;
       }
-      std::vector<int32_t> slot_env((size_t)n_slot, -1), env_slot((size_t)n_env), tile_task((size_t)(n_slot / 32));
+      std::vector<int32_t> slot_env((size_t)n_slot, -1), env_slot((size_t)n_env), tile_task((size_t)(n_slot / 16));
       std::vector<int64_t> fill(base);
       for (int i = 0; i < n_env; ++i) {
         const int64_t sl = fill[et[i]]++;
@@ -788,14 +841,14 @@ extern "C" int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int 
         env_slot[i] = (int32_t)sl;
       }
       for (int t = 0; t < n_task; ++t)
-        for (int64_t q = base[t] / 32; q < (t + 1 < n_task ? base[t + 1] : n_slot) / 32; ++q) tile_task[(size_t)q] = t;
+        for (int64_t q = base[t] / 16; q < (t + 1 < n_task ? base[t + 1] : n_slot) / 16; ++q) tile_task[(size_t)q] = t;
       a.n_slot = (int)n_slot;
       m = hipMalloc(&h->d_slot_env, sizeof(int32_t) * (size_t)n_slot);
       if (m == hipSuccess) m = hipMalloc(&h->d_env_slot, sizeof(int32_t) * (size_t)n_env);
-      if (m == hipSuccess) m = hipMalloc(&h->d_tile_task, sizeof(int32_t) * (size_t)(n_slot / 32));
+      if (m == hipSuccess) m = hipMalloc(&h->d_tile_task, sizeof(int32_t) * (size_t)(n_slot / 16));
       if (m == hipSuccess) m = hipMemcpy(h->d_slot_env, slot_env.data(), sizeof(int32_t) * (size_t)n_slot, hipMemcpyHostToDevice);
       if (m == hipSuccess) m = hipMemcpy(h->d_env_slot, env_slot.data(), sizeof(int32_t) * (size_t)n_env, hipMemcpyHostToDevice);
-      if (m == hipSuccess) m = hipMemcpy(h->d_tile_task, tile_task.data(), sizeof(int32_t) * (size_t)(n_slot / 32), hipMemcpyHostToDevice);
+      if (m == hipSuccess) m = hipMemcpy(h->d_tile_task, tile_task.data(), sizeof(int32_t) * (size_t)(n_slot / 16), hipMemcpyHostToDevice);
       a.slot_env = h->d_slot_env; a.env_slot = h->d_env_slot; a.tile_task = h->d_tile_task;
     }
   }
@@ -928,9 +981,14 @@ static int linds_launch_step(xv_linds* h, const LinDSStepIO& io, int mode) {
   const dim3 block(256);
   const bool mfma = h->path != XV_LINDS_PATH_SCALAR;
   if (mfma) {
-    const dim3 grid(xv_div_up(xv_div_up(h->a.n_slot, 32), 4));   // one wave per 32-slot tile, 4 tiles per block
-#define LINDS_STEP_M(NS_, NA_, NO_, dummy) \
-  hipLaunchKernelGGL((linds_step_mfma_kernel<NS_, NA_, NO_, INJECT>), grid, block, 0, h->eng->stream, h->a, io, mode)
+    const dim3 grid(xv_div_up(xv_div_up(h->a.n_slot, 16), 4));   // one wave per 16-slot tile, 4 tiles per block
+#define LINDS_STEP_M(NS_, NA_, NO_, dummy)                                                                            \
+  do {                                                                                                                \
+    if (NO_ == 16)                                                                                                    \
+      hipLaunchKernelGGL((linds_step_mfma_kernel<NS_, NA_, 16, INJECT>), grid, block, 0, h->eng->stream, h->a, io, mode); \
+    else                                                                                                              \
+      hipLaunchKernelGGL((linds_step_mfma_wide_kernel<NS_, NA_, 32, INJECT>), grid, block, 0, h->eng->stream, h->a, io, mode); \
+  } while (0)
     LINDS_DISPATCH(LINDS_STEP_M, 0);
 #undef LINDS_STEP_M
   } else {
