@@ -240,6 +240,30 @@ int xv_anymdp_solve(xv_anymdp* h, double gamma, double tol, int max_iter, double
 int xv_anymdp_value_iteration_gs(const double* t_mat, const double* r_mat, int ns, int na, double gamma,
                                  int is_greedy, double* vm, int32_t* sweeps_out);
 
+/* Task sampler on the device: AnyMDPTaskSampler's generative model and acceptance test (task_sampler.py:15-65,
+ * task_sampler_utils.py:65-256, solver.py:84-148) for n_cand candidate tasks per launch, one workgroup per candidate,
+ * candidate index cand_base + i.  Every random quantity is Philox4x32-10(counter = {candidate, index, purpose}, key =
+ * seed): same distributions as the reference, reproducible per (seed, candidate), NOT NumPy's stream (the
+ * seed-compatible sampler is host code).  Value iteration: synchronous sweeps to rms update <= 1e-4.
+ * status[i]: 0 accepted | 1 terminal rewards not repairable in 5 rounds (sample_mdp returns None) | 2 value gap between
+ * optimal and uniform policy < 2 | 3 long-run occupancy too concentrated (gini <= 0.70 or entropy <= 0.35) | 4 no
+ * convergence.  Accepted candidates write slot i of the step engine's tables (rows / state_map / term_mask / s0_cdf /
+ * s0_ids / max_steps, exactly what xv_anymdp_create takes; pass env_task entries that point at accepted slots); the
+ * dense fp64 tensors and `info` (nullable) are written for every candidate.  Supported: 8 <= S <= 64, S * A <= 512. */
+typedef struct {
+  int32_t status, goal, n_s0, repair_rounds;
+  int32_t s0[4];
+  int32_t sweeps[8];       /* value-iteration sweeps: repair rounds 0..4, acceptance greedy [5] and uniform [6] */
+  int32_t band_lo[256], band_hi[256], state_map[256];
+  uint8_t s_e[256];
+  double max_steps, gini, ent, gap_min;
+  double s0_prob[4];
+} xv_anymdp_cand_info;
+int xv_anymdp_sample_tasks(xv_engine* e, uint64_t seed, int64_t cand_base, int n_cand, int S, int A, int s0_max,
+                           void* rows, int32_t* state_map, uint64_t* term_mask, double* s0_cdf, int32_t* s0_ids,
+                           int32_t* max_steps, double* transition, double* reward, double* reward_noise,
+                           xv_anymdp_cand_info* info, int32_t* status);
+
 /* env.inner_state / env.steps accessors (anymdp_env.py:138-143); device int32[n_env] each, nullable */
 int xv_anymdp_get_state(xv_anymdp* h, int32_t* inner_state, int32_t* steps, uint8_t* need_reset);
 int xv_anymdp_set_state(xv_anymdp* h, const int32_t* inner_state, const int32_t* steps,

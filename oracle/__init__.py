@@ -539,3 +539,26 @@ def update_value_matrix(t_mat, r_mat, gamma, vm, is_greedy=True):
     it = lib().xo_update_value_matrix(_p(t), _p(r), C.c_int(ns), C.c_int(na), C.c_double(float(gamma)), _p(out),
                                       C.c_int(1 if is_greedy else 0))
     return out, int(it)
+
+
+class CandInfo(C.Structure):
+    _fields_ = [("status", C.c_int32), ("goal", C.c_int32), ("n_s0", C.c_int32), ("repair_rounds", C.c_int32),
+                ("s0", C.c_int32 * 4), ("sweeps", C.c_int32 * 8), ("band_lo", C.c_int32 * 256),
+                ("band_hi", C.c_int32 * 256), ("state_map", C.c_int32 * 256), ("s_e", C.c_uint8 * 256),
+                ("max_steps", C.c_double), ("gini", C.c_double), ("ent", C.c_double), ("gap_min", C.c_double),
+                ("s0_prob", C.c_double * 4)]
+
+
+def anymdp_sample_candidate(seed, cand, ns, na):
+    """one candidate of the device task sampler, restated on the CPU -> dict (status 0 = accepted)"""
+    T = np.zeros((ns, na, ns)); R = np.zeros((ns, na, ns)); noise = np.zeros((ns, na, ns))
+    info = CandInfo()
+    f = lib().xo_anymdp_sample_candidate
+    f.restype = C.c_int
+    st = f(C.c_uint64(seed), C.c_uint64(cand), C.c_int(ns), C.c_int(na), _p(T), _p(R), _p(noise), C.byref(info))
+    n0 = info.n_s0
+    return dict(status=int(st), transition=T, reward=R, reward_noise=noise, max_steps=info.max_steps, goal=bool(info.goal),
+                s_0=np.array(info.s0[:n0], np.int64), s_0_prob=np.array(info.s0_prob[:n0]),
+                s_e=np.nonzero(np.frombuffer(info.s_e, np.uint8)[:ns])[0], state_mapping=np.array(info.state_map[:ns], np.int64),
+                band_lo=np.array(info.band_lo[:ns]), band_hi=np.array(info.band_hi[:ns]), sweeps=np.array(info.sweeps[:]),
+                repair_rounds=info.repair_rounds, gini=info.gini, ent=info.ent, gap_min=info.gap_min)

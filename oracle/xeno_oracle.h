@@ -87,6 +87,18 @@ int xo_max_threads(void);
 double xo_np_pairwise_sum(const double* a, int64_t n);
 int xo_update_value_matrix(const double* t_mat, const double* r_mat, int ns, int na, double gamma, double* vm,
                            int is_greedy);
+/* one candidate of the device task sampler (counter-based draws); see xeno_oracle_sampler.c part 2 */
+typedef struct {
+  int32_t status, goal, n_s0, repair_rounds;
+  int32_t s0[4];
+  int32_t sweeps[8];       /* repair rounds 0..4, then acceptance greedy [5] and uniform [6] */
+  int32_t band_lo[256], band_hi[256], state_map[256];
+  uint8_t s_e[256];
+  double max_steps, gini, ent, gap_min;
+  double s0_prob[4];
+} xo_cand_info;
+int xo_anymdp_sample_candidate(uint64_t seed, uint64_t cand, int ns, int na, double* T, double* R, double* noise,
+                               xo_cand_info* info);
 
 /* ---------------------------------------------------------------------------------------------
  * LinDS — reference: linds/linds_env.py.  fp32 arithmetic in the device's fixed operation order.

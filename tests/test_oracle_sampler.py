@@ -67,3 +67,51 @@ def test_product_host_value_iteration_equals_the_oracle(ns, na):
             _lib.check(lib.xv_anymdp_value_iteration_gs(T.ctypes.data, R.ctypes.data, ns, na, gamma, greedy,
                                                         vm.ctypes.data, C.addressof(it)))
             assert np.array_equal(vm, ref) and it.value == sweeps, (ns, na, greedy, gamma)
+
+
+def test_device_algorithm_population_matches_the_reference_stream_population():
+    """The device sampler's algorithm (restated in the oracle: counter-based draws, synchronous value iteration) and the
+    reference's own stream of candidates (the seeded host sampler, pinned bit for bit to the reference by the golden
+    tasks) are two samplers of ONE distribution: over ~700 candidates each, the share of unrepairable and of accepted
+    candidates, the pitfall count, goal share, band width, non-zeros per row, largest transition probability and the
+    reward spread agree within sampling error (4 sigma of the difference of two independent means)."""
+    from xenoverse_amd.anymdp import task_sampler as ts
+    ns, na = 16, 4
+
+    def shape_stats(T, s_e, lo, hi):
+        live = [s for s in range(ns) if s not in set(s_e)]
+        return dict(bw=np.mean([hi[s] - lo[s] for s in live]), nnz=np.mean([(T[s] > 0).sum(-1).mean() for s in live]),
+                    tmax=np.mean([T[s].max(-1).mean() for s in live]))
+    ref = []
+    for seed in range(5000, 5220):
+        rng = np.random.RandomState(seed)
+        task, real = ts._task_head(rng, ns, na, None)
+        for _ in range(60):
+            g = ts._ReferenceStream(rng, real, na)
+            res = g.candidate()
+            rec = dict(none=float(res is None), pits=float(len(g.s_e)), goal=float(g.goal_terminates), n_s0=float(len(g.s_0)),
+                       **shape_stats(g.T, g.s_e, g.lo, g.hi))
+            rec["acc"] = 0.0
+            if res is not None:
+                task.update(res)
+                rec["acc"] = float(ts.reference_acceptance(task))
+                rec["rstd"] = float(res["reward"].std())
+                rec["nzn"] = float((res["reward_noise"] > 0).mean())
+            ref.append(rec)
+            if rec["acc"]:
+                break
+    dev = []
+    for c in range(len(ref)):
+        d = oracle.anymdp_sample_candidate(4242, c, ns, na)
+        rec = dict(none=float(d["status"] == 1), acc=float(d["status"] == 0), pits=float(len(d["s_e"])), goal=float(d["goal"]),
+                   n_s0=float(len(d["s_0"])), **shape_stats(d["transition"], d["s_e"], d["band_lo"], d["band_hi"]))
+        if d["status"] != 1:
+            rec["rstd"] = float(d["reward"].std())
+            rec["nzn"] = float((d["reward_noise"] > 0).mean())
+        dev.append(rec)
+    assert len(ref) > 500
+    for k in ("none", "acc", "pits", "goal", "n_s0", "bw", "nnz", "tmax", "rstd", "nzn"):
+        a = np.array([r[k] for r in ref if k in r])
+        b = np.array([r[k] for r in dev if k in r])
+        se = np.sqrt(a.var() / len(a) + b.var() / len(b))
+        assert abs(a.mean() - b.mean()) <= 4 * se + 1e-12, (k, a.mean(), b.mean(), se)
