@@ -98,6 +98,19 @@ int xv_pack_rollout(void* hip_stream, size_t n, const int32_t* obs, const int32_
 int xv_unpack_rollout(void* hip_stream, size_t n, const uint64_t* rec, int32_t* obs, int32_t* action, float* reward,
                       uint8_t* terminated, uint8_t* truncated);
 
+/* The all-gather of finished rollout chunks over RCCL directly (no torch.distributed needed):
+ * every rank contributes `bytes_per_rank` bytes at `local` and receives all ranks' chunks, rank-major, at `global`
+ * (device pointers; ncclAllGather of a uint8 payload on the engine's stream, asynchronous like every other call).
+ * Communicator: rank 0 calls xv_rccl_unique_id (128 bytes, host buffer) and hands the id to the other ranks by any
+ * channel; every rank then calls xv_rccl_comm_create (collective).  librccl.so is opened on first use: on a host
+ * without it these entry points return XV_ERR_UNSUPPORTED and everything else works.  The reference has no counterpart
+ * (one env object per process, no multi-device path); stepping itself never communicates. */
+#define XV_RCCL_ID_BYTES 128
+int xv_rccl_unique_id(void* out128);
+int xv_rccl_comm_create(xv_engine* e, int world, int rank, const void* id128, void** comm_out);
+int xv_rccl_comm_destroy(void* comm);
+int xv_rollout_allgather(xv_engine* e, void* rccl_comm, const void* local, void* global, size_t bytes_per_rank);
+
 /* ------------------------------------------------------------------------------------------------
  * AnyMDP — reference: xenoverse/anymdp/anymdp_env.py
  *   set_task  :32-79   -> xv_anymdp_create   (tables prepared host-side: see xenoverse_amd/anymdp)

@@ -505,8 +505,8 @@ def gen_anymdp_vi():
             out["chain_bonus_s%d_%d" % (seed, k)] = np.copy(bonus)
             bonus[-1] += rng.uniform(1.0, 10.0)
             bonus[rng.randint(0, ns - 1)] -= rng.uniform(1.0, 10.0)
-    np.savez_compressed(os.path.join(GOLD, "anymdp_vi_ref.npz"), **out)
-    print("anymdp_vi_ref.npz", os.path.getsize(os.path.join(GOLD, "anymdp_vi_ref.npz")) // 1024, "KiB")
+    np.savez_compressed(os.path.join(GOLD, "sampler_vi_ref.npz"), **out)
+    print("sampler_vi_ref.npz", os.path.getsize(os.path.join(GOLD, "sampler_vi_ref.npz")) // 1024, "KiB")
 
 
 def gen_anymdp_sampled(n=32, seed0=100):
@@ -552,9 +552,9 @@ def gen_anymdp_sampled(n=32, seed0=100):
             print("seed", seed0 + k, dict(counts), flush=True)
     finally:
         ts.sample_mdp, ts.check_valuefunction = real_sample, real_check
-    path = os.path.join(GOLD, "anymdp_refsampled_16x4.npz")
+    path = os.path.join(GOLD, "sampler_refpop_16x4.npz")
     np.savez_compressed(path, **{k: np.stack(v) for k, v in out.items()}, **{k: np.asarray(v) for k, v in meta.items()})
-    print("anymdp_refsampled_16x4.npz", os.path.getsize(path) // 1024, "KiB")
+    print("sampler_refpop_16x4.npz", os.path.getsize(path) // 1024, "KiB")
 
 
 FAMILIES = {"anymdp": gen_anymdp, "linds": gen_linds, "maze": gen_maze, "acrobot": gen_acrobot, "garnet": gen_garnet,

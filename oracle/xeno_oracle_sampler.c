@@ -9,7 +9,7 @@
  * >= 1.9, numpy/_core/src/umath/loops_utils.h.src `@TYPE@_pairwise_sum`: < 8 elements a plain loop, <= 128 elements
  * eight running partial sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus the tail, larger blocks split in
  * halves rounded to a multiple of 8); restated here and pinned by tests/test_oracle_sampler.py against numpy itself
- * and against value matrices computed by the reference's own update_value_matrix (tests/golden/anymdp_vi_*.npz).
+ * and against value matrices computed by the reference's own update_value_matrix (tests/golden/sampler_vi_ref.npz).
  */
 #include <math.h>
 #include <stdint.h>
@@ -94,7 +94,7 @@ int xo_update_value_matrix(const double* t_mat, const double* r_mat, int ns, int
  * normal / exponential / integer draws, the same clipping, retry and widening rules); the stream is not, so a seed names
  * a different task than in the reference.  What this file pins is the device implementation: same draws, same formulas
  * -> integers equal, floats to ~1e-12 (libm vs device libm in log / sincos / exp).  The equivalence with the reference's
- * distribution is tested separately against a reference-sampled population (tests/golden/anymdp_refsampled_16x4.npz).
+ * distribution is tested separately against a reference-sampled population (tests/golden/sampler_refpop_16x4.npz).
  * Value iteration here is the synchronous (Jacobi) sweep, Q <- ER + gamma T V(Q), iterated to rms update <= 1e-4: the
  * same fixed point and the same stopping rule as the reference's damped Gauss-Seidel, in a form that parallelises.
  * ===================================================================================================================*/

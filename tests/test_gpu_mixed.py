@@ -144,3 +144,27 @@ def test_rollout_record_packing_on_device_matches_host_format():
     o, a, r, t1, t2 = unpack_records(dev)
     assert torch.equal(o.cpu(), obs) and torch.equal(a.cpu(), act) and torch.equal(r.cpu(), rew)
     assert torch.equal(t1.cpu(), te) and torch.equal(t2.cpu(), tr)
+
+
+def test_rollout_allgather_over_rccl_through_the_c_abi():
+    """xv_rccl_unique_id / xv_rccl_comm_create / xv_rollout_allgather on the GPU of this box: a one-rank communicator
+    (what a 1-GPU box can host) gathers a packed rollout chunk on the side stream — RCCL itself executes; ranks > 1 use
+    the same calls with the id carried by a TCP store (covered on CPU by the gloo tests of the torch transport)"""
+    from xenoverse_amd.distributed import REC_BYTES, RolloutGather, pack_records, unpack_records
+    T, N = 32, 4096
+    g = torch.Generator(device="cuda").manual_seed(3)
+    obs = torch.randint(0, 64, (T, N), generator=g, device="cuda", dtype=torch.int32)
+    act = torch.randint(0, 8, (T, N), generator=g, device="cuda", dtype=torch.int32)
+    rew = torch.randn((T, N), generator=g, device="cuda")
+    te = (torch.rand((T, N), generator=g, device="cuda") < 0.2).to(torch.uint8)
+    tr = (torch.rand((T, N), generator=g, device="cuda") < 0.1).to(torch.uint8)
+    rg = RolloutGather((T, N, REC_BYTES), device="cuda:0", transport="rccl", rank=0, world=1)
+    for _ in range(3):
+        pack_records(obs, act, rew, te, tr, out=rg.local)
+        rg.launch()
+        out = rg.wait()
+    torch.cuda.synchronize()
+    assert out.shape == (1, T, N, REC_BYTES) and torch.equal(out[0], rg.local)
+    o2, a2, r2, te2, tr2 = unpack_records(out[0])
+    assert torch.equal(o2, obs) and torch.equal(a2, act) and torch.equal(r2, rew) and torch.equal(te2, te) and torch.equal(tr2, tr)
+    rg.close()

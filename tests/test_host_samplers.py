@@ -150,12 +150,12 @@ def test_seeded_pomdp_samplers_reproduce_the_reference_tasks(name, kind, seed):
 
 
 def test_seeded_sampler_reproduces_32_reference_sampled_tasks():
-    """tests/golden/anymdp_refsampled_16x4.npz: 32 tasks of the reference's sampler (seeds 100..131) with its own
+    """tests/golden/sampler_refpop_16x4.npz: 32 tasks of the reference's sampler (seeds 100..131) with its own
     candidate / unrepairable / rejected counts — the build's sampler walks the same candidates"""
     import os
     from util import GOLD
     from xenoverse_amd.anymdp import task_sampler as ts
-    g = np.load(os.path.join(GOLD, "anymdp_refsampled_16x4.npz"))
+    g = np.load(os.path.join(GOLD, "sampler_refpop_16x4.npz"))
     exact = _numpy_matches_fixture_host()
     counts = {"cand": 0, "none": 0, "rej": 0}
     real_cand, real_acc = ts._ReferenceStream.candidate, ts.reference_acceptance

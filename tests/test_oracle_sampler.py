@@ -1,5 +1,5 @@
 """The sampler arithmetic of the oracle (oracle/xeno_oracle_sampler.c) pinned to the reference: value matrices the
-reference's own update_value_matrix produced (tests/golden/anymdp_vi_ref.npz, oracle/gen_golden.py anymdp_vi) must come
+reference's own update_value_matrix produced (tests/golden/sampler_vi_ref.npz, oracle/gen_golden.py anymdp_vi) must come
 out bit for bit, NumPy's pairwise summation must equal numpy itself, and the product's host value iteration
 (libxeno_hip.so xv_anymdp_value_iteration_gs — host code, no GPU) must equal the oracle's on random MDPs."""
 import ctypes as C
@@ -22,7 +22,7 @@ def test_pairwise_sum_equals_numpy():
 
 
 def test_update_value_matrix_equals_the_reference_bit_for_bit():
-    g = np.load(os.path.join(GOLD, "anymdp_vi_ref.npz"))
+    g = np.load(os.path.join(GOLD, "sampler_vi_ref.npz"))
     for seed in (0, 2):
         T, R = g["T%d" % seed], g["R%d" % seed]
         ns, na, _ = T.shape

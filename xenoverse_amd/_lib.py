@@ -18,6 +18,10 @@ SIGNATURES = {
     "xv_pack_rollout": [c_void_p, C.c_size_t] + [c_void_p] * 6,
     "xv_unpack_rollout": [c_void_p, C.c_size_t] + [c_void_p] * 6,
     "xv_last_error": [],
+    "xv_rccl_unique_id": [c_void_p],
+    "xv_rccl_comm_create": [c_void_p, c_int, c_int, c_void_p, C.POINTER(c_void_p)],
+    "xv_rccl_comm_destroy": [c_void_p],
+    "xv_rollout_allgather": [c_void_p, c_void_p, c_void_p, c_void_p, C.c_size_t],
     "xv_engine_create": [c_int, c_u64, c_u64, c_void_p, C.POINTER(c_void_p)],
     "xv_engine_destroy": [c_void_p],
     "xv_engine_sync": [c_void_p],

@@ -381,10 +381,11 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
 // Completes the rows in place (create time): fence line and per-block metadata.  One thread per (row, k < 64).
 //   fence[k] (k < 16) = CDF entry of the last next-state of block group k (G blocks) for k < NB/G - 1, else 2.0
 //   meta of block k (k < NB) = {u16 obs[7]; u8 term_bits; u8 0} of next states 7k..7k+6 (clamped to S-1, as s' is)
-__global__ __launch_bounds__(256) void anymdp_finish_rows_kernel(AnyMDPArgs P, uint4* lines_rw, size_t n_rows) {
+__global__ __launch_bounds__(256) void anymdp_finish_rows_kernel(AnyMDPArgs P, uint4* lines_rw, size_t row_base,
+                                                                 size_t n_rows) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_rows * 64) return;
-  const size_t r = idx >> 6;
+  const size_t r = row_base + (idx >> 6);
   const int k = (int)(idx & 63);
   const int t = (int)(r / ((size_t)P.S * P.A));
   uint4* row = lines_rw + r * (size_t)P.RL * 8;
@@ -799,30 +800,36 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
 
   // the fast path needs s0_max <= 4, observation ids that fit 16 bits and max_steps < 2^27 (checked below)
   bool fast = (G <= 3 && s0_max <= 4);
-  if (fast) {
+  // largest entry of a device int array; every exit path releases the scratch word (the handle is released by the caller
+  // of the lambda: nothing else has been allocated yet)
+  auto device_max = [&](const int32_t* p, size_t n, int* out_max) -> hipError_t {
     int* d_max = nullptr;
+    hipError_t r = hipMalloc(&d_max, sizeof(int));
+    if (r == hipSuccess) r = hipMemsetAsync(d_max, 0, sizeof(int), e->stream);
+    if (r == hipSuccess) {
+      hipLaunchKernelGGL(anymdp_max_obs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, p, n, d_max);
+      r = hipMemcpyAsync(out_max, d_max, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+    }
+    if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+    if (d_max) (void)hipFree(d_max);
+    return r;
+  };
+  {
     int h_max = 0;
-    XV_HIP(hipMalloc(&d_max, sizeof(int)));
-    XV_HIP(hipMemsetAsync(d_max, 0, sizeof(int), e->stream));
-    const size_t n = (size_t)n_task * S;
-    hipLaunchKernelGGL(anymdp_max_obs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream,
-                       state_map, n, d_max);
-    XV_HIP(hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    XV_HIP(hipStreamSynchronize(e->stream));
-    XV_HIP(hipFree(d_max));
-    fast = h_max < 65536;
-  }
-  if (fast) {   // max_steps shares its per-env word with four flags: it must fit 27 bits
-    int* d_max = nullptr;
-    int h_max = 0;
-    XV_HIP(hipMalloc(&d_max, sizeof(int)));
-    XV_HIP(hipMemsetAsync(d_max, 0, sizeof(int), e->stream));
-    hipLaunchKernelGGL(anymdp_max_obs_kernel, dim3((unsigned)((n_task + 255) / 256)), dim3(256), 0, e->stream, max_steps,
-                       (size_t)n_task, d_max);
-    XV_HIP(hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    XV_HIP(hipStreamSynchronize(e->stream));
-    XV_HIP(hipFree(d_max));
-    fast = h_max < (1 << 27);
+    hipError_t r = hipSuccess;
+    if (fast) {
+      r = device_max(state_map, (size_t)n_task * S, &h_max);
+      fast = r == hipSuccess && h_max < 65536;
+    }
+    if (fast) {   // max_steps shares its per-env word with four flags: it must fit 27 bits
+      r = device_max(max_steps, (size_t)n_task, &h_max);
+      fast = r == hipSuccess && h_max < (1 << 27);
+    }
+    if (r != hipSuccess) {
+      xv_set_error("xv_anymdp_create: table probe failed: %s", hipGetErrorString(r));
+      delete h;
+      return XV_ERR_HIP;
+    }
   }
 
   double2* c01 = nullptr; double* c2 = nullptr; uint32_t* ids = nullptr; uint2* robs = nullptr; int32_t* rms = nullptr;
@@ -848,9 +855,12 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
     return XV_ERR_HIP;
   }
   if (fast) {
-    XV_CHECK_ARG(n_rows * 64 / 256 + 1 < 0x7FFFFFFFull);
-    hipLaunchKernelGGL(anymdp_finish_rows_kernel, dim3((unsigned)((n_rows * 64 + 255) / 256)), dim3(256), 0, e->stream, a,
-                       (uint4*)rows, n_rows);
+    const size_t chunk = (size_t)1 << 24;      // rows per launch: a launch holds fewer than 2^32 threads
+    for (size_t r0 = 0; r0 < n_rows; r0 += chunk) {
+      const size_t nr = n_rows - r0 < chunk ? n_rows - r0 : chunk;
+      hipLaunchKernelGGL(anymdp_finish_rows_kernel, dim3((unsigned)((nr * 64 + 255) / 256)), dim3(256), 0, e->stream, a,
+                         (uint4*)rows, r0, nr);
+    }
     hipLaunchKernelGGL(anymdp_env_records_kernel, dim3(xv_div_up(n_env, 256)), dim3(256), 0, e->stream, a, c01, c2, ids,
                        robs, rms);
     a.rs_c01 = c01; a.rs_c2 = c2; a.rs_ids = ids; a.rs_obs = robs; a.rs_max_steps = rms;

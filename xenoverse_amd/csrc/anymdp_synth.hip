@@ -154,11 +154,17 @@ extern "C" int xv_anymdp_synth_tasks(xv_engine* e, uint64_t seed, int64_t task_i
   hipLaunchKernelGGL(anymdp_synth_header_kernel, dim3(xv_div_up(n_task, 64)), dim3(64), 0, e->stream, seed,
                      task_index_base, n_task, S, s0_max, state_map, term_mask, s0_cdf, s0_ids, max_steps);
   XV_LAUNCH_CHECK();
-  const size_t n_rows = (size_t)n_task * S * A;
-  const size_t blocks = (n_rows + 3) / 4;
-  XV_CHECK_ARG(blocks < 0x7FFFFFFFull);
-  hipLaunchKernelGGL(anymdp_synth_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, e->stream, seed,
-                     task_index_base, n_task, S, A, (const uint64_t*)term_mask, rows);
-  XV_LAUNCH_CHECK();
+  // one wave per row: a launch holds at most 2^32 threads, so large batches go in chunks of whole tasks
+  const int words = (S + 63) / 64;
+  const size_t row_bytes = (size_t)XV_ANYMDP_ROW_LINES(S) * 128;
+  const int chunk = (int)((size_t)(1u << 22) * 4 / ((size_t)S * A));     // tasks per launch: <= 2^22 blocks
+  for (int t0 = 0; t0 < n_task; t0 += chunk) {
+    const int nt = n_task - t0 < chunk ? n_task - t0 : chunk;
+    const size_t blocks = ((size_t)nt * S * A + 3) / 4;
+    hipLaunchKernelGGL(anymdp_synth_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, e->stream, seed,
+                       task_index_base + t0, nt, S, A, (const uint64_t*)term_mask + (size_t)t0 * words,
+                       static_cast<char*>(rows) + (size_t)t0 * S * A * row_bytes);
+    XV_LAUNCH_CHECK();
+  }
   return XV_OK;
 }

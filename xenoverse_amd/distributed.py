@@ -77,23 +77,88 @@ def unpack_records(rec):
     return obs, act, rew, te, tr
 
 
+class RcclComm(object):
+    """A RCCL communicator made through the C-ABI (xv_rccl_*), without torch.distributed: rank 0 creates the 128-byte
+    unique id, a `torch.distributed.TCPStore` (plain key-value rendezvous, no process group) carries it to the others.
+    rank / world / address default to the launcher's environment (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT + 1)."""
+
+    def __init__(self, engine, rank=None, world=None, host=None, port=None, timeout_s=120):
+        import ctypes as C
+        import datetime
+        import os
+        from . import _lib
+        self.lib = engine.lib
+        self.engine = engine
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        ident = C.create_string_buffer(128)
+        if self.world > 1:
+            from torch.distributed import TCPStore
+            host = host or os.environ.get("MASTER_ADDR", "127.0.0.1")
+            port = int(port or int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            store = TCPStore(host, port, self.world, self.rank == 0, timeout=datetime.timedelta(seconds=timeout_s))
+            if self.rank == 0:
+                _lib.check(self.lib.xv_rccl_unique_id(ident))
+                store.set("xv_rccl_id", ident.raw)
+            else:
+                ident.raw = store.get("xv_rccl_id")
+            self._store = store
+        else:
+            _lib.check(self.lib.xv_rccl_unique_id(ident))
+        h = C.c_void_p()
+        _lib.check(self.lib.xv_rccl_comm_create(engine.handle, self.world, self.rank, ident, C.byref(h)))
+        self.handle = h
+
+    def all_gather(self, local, out):
+        """out[world, ...] <- every rank's `local` (device tensors), asynchronously on the engine's stream"""
+        from . import _lib
+        assert local.is_cuda and out.is_cuda and local.is_contiguous() and out.is_contiguous()
+        nbytes = local.numel() * local.element_size()
+        assert out.numel() * out.element_size() == nbytes * self.world
+        _lib.check(self.lib.xv_rollout_allgather(self.engine.handle, self.handle, _lib.ptr(local), _lib.ptr(out), nbytes))
+
+    def close(self):
+        if getattr(self, "handle", None) is not None:
+            self.lib.xv_rccl_comm_destroy(self.handle)
+            self.handle = None
+
+
 class RolloutGather(object):
     """All-gather of equally sized per-rank rollout chunks.  On GPU it runs on its own HIP stream so that the
-    next chunk's stepping overlaps the transfer; call wait() before reading `out`."""
+    next chunk's stepping overlaps the transfer; call wait() before reading `out`.
+    transport: "torch" = torch.distributed (backend "nccl" is RCCL on ROCm, "gloo" on CPU); "rccl" = ncclAllGather through
+    the C-ABI (xv_rollout_allgather) on a communicator made without a process group."""
 
-    def __init__(self, chunk_shape, dtype=torch.uint8, device="cpu", group=None):
-        import torch.distributed as dist
-        self.dist = dist
-        self.group = group
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
-        self.local = torch.empty(tuple(chunk_shape), dtype=dtype, device=device)
-        self.out = torch.empty((self.world,) + tuple(chunk_shape), dtype=dtype, device=device)
+    def __init__(self, chunk_shape, dtype=torch.uint8, device="cpu", group=None, transport="torch", rank=None, world=None):
+        self.transport = transport
         self.is_cuda = torch.device(device).type == "cuda"
         self.stream = torch.cuda.Stream(device=device) if self.is_cuda else None
+        if transport == "rccl":
+            if not self.is_cuda:
+                raise ValueError("the rccl transport moves device buffers")
+            from .engine import Engine
+            self._engine = Engine(device, stream=self.stream)       # the collective is launched on the side stream
+            self.comm = RcclComm(self._engine, rank=rank, world=world)
+            self.world, self.rank = self.comm.world, self.comm.rank
+        else:
+            import torch.distributed as dist
+            self.dist = dist
+            self.group = group
+            self.world = dist.get_world_size(group)
+            self.rank = dist.get_rank(group)
+        self.local = torch.empty(tuple(chunk_shape), dtype=dtype, device=device)
+        self.out = torch.empty((self.world,) + tuple(chunk_shape), dtype=dtype, device=device)
         self._use_into = True
 
+    def close(self):
+        if self.transport == "rccl":
+            self.comm.close()
+            self._engine.close()
+
     def _gather(self):
+        if self.transport == "rccl":
+            self.comm.all_gather(self.local, self.out)
+            return
         if self._use_into:
             try:
                 self.dist.all_gather_into_tensor(self.out, self.local, group=self.group)
