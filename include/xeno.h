@@ -466,6 +466,20 @@ int xv_maze_set_state(xv_maze* h, const double* pos, const double* ori, const in
                       const int32_t* cmd_idx, const int32_t* cmd_age, const uint8_t* need_reset);
 /* render the current state only (no step) */
 int xv_maze_render(xv_maze* h, uint8_t* frames, float* command_rgb);
+/* Texture filter of the ray-caster (interpolate, ray_caster_utils.py:123-140).  EXACT (default): the reference's
+ * float64/float32 typing, frames identical to the oracle's.  F32: the same 4x4 distance-weighted taps evaluated in
+ * float32 — opt-in, ~3x less arithmetic per pixel; frames stay within SURVEY.md M5's budget against the reference
+ * (+-1 level on <= 0.5 % of the values; a value moves only where the exact colour lies within ~1e-4 of an integer). */
+/* The move / collision / rules kernel (results identical; NINE_LANES is the default): LANE_PER_ENV walks the 100
+ * sub-steps of an env in one lane; NINE_LANES gives an env the nine lanes of its 3x3 wall neighbourhood, evaluates the
+ * position-independent part of all sub-steps (heading, sin / cos, displacement) in parallel first and keeps only the
+ * position chain sequential (dynamics.py:98-123,158-187). */
+#define XV_MAZE_MOVE_LANE_PER_ENV 0
+#define XV_MAZE_MOVE_NINE_LANES 1
+int xv_maze_set_move_kernel(xv_maze* h, int kernel);
+#define XV_MAZE_FILTER_EXACT 0
+#define XV_MAZE_FILTER_F32 1
+int xv_maze_set_precision(xv_maze* h, int filter);
 
 #ifdef __cplusplus
 }

@@ -230,7 +230,7 @@ def bench_mixed(args):
             "env_steps_per_s": n / (best * 1e-6), "us_per_vector_step": res, "dtype": "f64/f32"}
 
 
-def bench_maze(args, res):
+def bench_maze(args, res, precision="exact"):
     from xenoverse_amd.mazeworld import MazeTaskSampler, MazeWorldVecEnv, make_texture_library
     from xenoverse_amd import _lib
     from xenoverse_amd.engine import AUTORESET
@@ -239,7 +239,7 @@ def bench_maze(args, res):
     tasks = [MazeTaskSampler(n_range=(15, 16), seed=k, n_wall_textures=8, n_ground_textures=4, n_ceiling_textures=4)
              for k in range(n_task)]
     env = MazeWorldVecEnv(n, resolution=(res, res), textures=make_texture_library(8, 4, 4, seed=0),
-                          autoreset_mode="same_step", action_space_type="Discrete16")
+                          autoreset_mode="same_step", action_space_type="Discrete16", precision=precision)
     env.set_task(tasks)
     env.reset()
     a = torch.randint(0, 16, (n,), device=env.device, dtype=torch.int32)
@@ -265,7 +265,8 @@ def bench_maze(args, res):
     # = 368 fp64-pipe instructions + ~40 of geometry; peak = 1024 SIMDs x 64 lanes x 2.4 GHz / 4 cycles per wave-instr
     valu_ops = 408.0 * res * res * n
     valu_peak = 1024 * 64 * 2.4e9 / 4
-    return {"family": "mazeworld", "workload": "15x15 mazes, 16,384 envs = 256 tasks x 64, %dx%d frames" % (res, res),
+    return {"family": "mazeworld", "filter": precision,
+            "workload": "15x15 mazes, 16,384 envs = 256 tasks x 64, %dx%d frames" % (res, res),
             "dtype": "f64 pose, f32/f64 ray-caster, u8 frames", "env_steps_per_s": n / (us_full * 1e-6),
             "us_per_step": {"move+rules": us_move, "raycast": us_render, "step (both)": us_full},
             "roofline": {"bound": "hbm", "achieved": algo / (us_full * 1e-6) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
@@ -295,7 +296,7 @@ if __name__ == "__main__":
         elif f == "anymdp_tok":
             r = bench_anymdp_tok(args)
         elif f.startswith("maze"):
-            r = bench_maze(args, int(f[4:]))
+            r = bench_maze(args, int(f[4:].split("_")[0]), "f32" if f.endswith("_f32") else "exact")
         else:
             continue
         print(json.dumps(r), flush=True)

@@ -179,3 +179,82 @@ def test_misuse():
     with pytest.raises(ValueError, match="Invalid Action Space Type"):
         MazeWorldVecEnv(2, action_space_type="Discrete8")
     env.close()
+
+
+@pytest.mark.parametrize("path", FILES)
+def test_f32_filter_stays_within_the_frame_budget_on_reference_frames(path):
+    """precision="f32" (opt-in): the reference's own 64x64 and 32x32 frames within +-1 level on <= 0.5 % of the values"""
+    g, task = load_maze_golden(path)
+    for key_f, key_s, res in (("frames64", "frames64_steps", 64), ("frames", "frame_steps", int(g["res"]))):
+        steps = g[key_s]
+        env = MazeWorldVecEnv(len(steps), resolution=(res, res), textures=tex(), autoreset_mode="disabled", precision="f32")
+        env.set_task(task)
+        env.reset()
+        env.set_state(pos=g["tr_pos"][steps].T.copy(), ori=g["tr_ori"][steps].copy(), cmd_idx=g["tr_cmd_idx"][steps])
+        f = _np(env.render_frames())
+        frac, worst = frame_mismatch(f, g[key_f])
+        assert frac <= 0.005 and worst <= 1, (key_f, frac, worst)
+        env.close()
+
+
+@pytest.mark.parametrize("res", [(64, 64), (256, 256)])
+def test_f32_filter_vs_exact_and_oracle_on_a_batch(res):
+    """3 mazes x 16 random poses: f32 frames vs the oracle's exact ones (budget) and vs the exact device path"""
+    tasks = [load_maze_golden(p)[1] for p in FILES]
+    tab = build_tables(tasks)
+    per = 16 if res[0] <= 64 else 3
+    env_task = np.repeat(np.arange(len(tasks), dtype=np.int32), per)
+    n = len(env_task)
+    rng = np.random.RandomState(6)
+    frames = {}
+    for prec in ("exact", "f32"):
+        env = MazeWorldVecEnv(n, resolution=res, textures=tex(), autoreset_mode="disabled", precision=prec, seed=1)
+        env.set_task(tasks, env_task_index=env_task)
+        env.reset()
+        if prec == "exact":
+            a = rng.randint(0, 16, (12, n)).astype(np.int32)
+        for t in range(12):
+            out = env.step(a[t])
+        frames[prec] = _np(out[0])
+        st = env.get_state()
+        env.close()
+    ora = oracle.MazeOracle(tab, tex(), env_task, resolution=res)
+    ora.reset()
+    ora.pos[:] = _np(st["pos"]); ora.ori[:] = _np(st["ori"]); ora.cmd_idx[:] = _np(st["cmd_idx"])
+    fo, _ = ora.render(n_threads=8)
+    assert frame_mismatch(frames["exact"], fo) == (0.0, 0)
+    frac, worst = frame_mismatch(frames["f32"], fo)
+    assert frac <= 0.005 and worst <= 1, (frac, worst)
+
+
+@pytest.mark.parametrize("mode,space", [("same_step", "Discrete16"), ("next_step", "Discrete32"), ("disabled", "Continuous")])
+def test_nine_lane_move_kernel_equals_the_lane_per_env_kernel(mode, space):
+    """two arrangements of the same arithmetic (xv_maze_set_move_kernel): bit-identical state, rewards and flags over a
+    batch whose size is not a multiple of the 7 envs a wave holds, with wall contact, goal rules and resets"""
+    tasks = [load_maze_golden(p)[1] for p in FILES]
+    env_task = np.repeat(np.arange(len(tasks), dtype=np.int32), 37)[:-5]
+    n = len(env_task)
+    rng = np.random.RandomState(2)
+    T = 40
+    acts = rng.uniform(-1.2, 1.2, (T, n, 2)) if space == "Continuous" else \
+        rng.randint(0, 16 if space == "Discrete16" else 32, (T, n)).astype(np.int32)
+    recs = []
+    for kern in ("lane_per_env", "nine_lanes"):
+        env = MazeWorldVecEnv(n, resolution=(32, 32), textures=tex(), autoreset_mode=mode, max_steps=17,
+                              action_space_type=space, seed=2)
+        env.set_task(tasks, env_task_index=env_task)
+        env.set_move_kernel(kern)
+        env.reset()
+        rec = []
+        for t in range(T):
+            f, r, te, tr, info = env.step(acts[t])
+            st = env.get_state()
+            rec += [_np(r), _np(te), _np(tr)] + [_np(st[k]) for k in ("pos", "ori", "grid", "steps", "cmd_idx", "cmd_age",
+                                                                     "need_reset", "collision")]
+            if mode == "disabled" and bool((te | tr).any()):
+                env.reset(options={"reset_mask": _np(te | tr).astype(np.uint8)})
+        recs.append(rec)
+        assert any(float(x.max()) > 0 for x in rec[10::11])        # walls were touched (collision > 0 somewhere)
+        env.close()
+    for a, b in zip(*recs):
+        assert np.array_equal(a, b)

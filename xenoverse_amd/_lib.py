@@ -88,6 +88,8 @@ SIGNATURES = {
     "xv_maze_get_state": [c_void_p] + [c_void_p] * 8,
     "xv_maze_set_state": [c_void_p] + [c_void_p] * 6,
     "xv_maze_render": [c_void_p, c_void_p, c_void_p],
+    "xv_maze_set_precision": [c_void_p, c_int],
+    "xv_maze_set_move_kernel": [c_void_p, c_int],
 }
 _RESTYPE = {"xv_last_error": C.c_char_p, "xv_engine_stream": c_void_p}
 

@@ -51,6 +51,8 @@ struct MazeArgs {
 struct xv_maze {
   xv_engine* eng;
   MazeArgs a;
+  bool filter_f32 = false;   // xv_maze_set_precision
+  bool move_lanes9 = true;   // xv_maze_set_move_kernel
 };
 
 static const size_t MAZE_LDS_CHUNK_MAX = 50176;   // 256 columns x (64 rows x 3 + 4) bytes: three workgroups per 160-KiB CU
@@ -288,6 +290,170 @@ __global__ __launch_bounds__(256) void maze_step_kernel(MazeArgs P, const void* 
   if (err) atomicOr(P.err, err);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same step, re-arranged for the machine: 9 lanes per env, 7 envs per wave.
+//
+// A step is 100 sub-steps that look sequential, but only the POSITION is: the heading of sub-step k, its sin / cos and
+// therefore its collision-free displacement (dx_k, dy_k) depend on the action alone (dynamics.py:98-123 reads `ori`,
+// never `pos`).  So
+//   phase 1  every lane walks the cheap heading recurrence (two rounded additions per sub-step, in order) and the 9
+//            lanes of an env evaluate sin / cos / displacement for every ninth sub-step in parallel -> LDS;
+//   phase 2  the sequential part is what is left: p + d_k, the cell coordinates, and the push-out of the 3x3
+//            neighbourhood — one cell per lane (the lane index IS the reference's (i, j) loop position), the nine
+//            forces summed in that loop order after an exchange through LDS that is skipped while no lane of the wave
+//            touches a wall.
+// Same operations on the same operands in the same order as maze_step_kernel above -> identical results (tested), with
+// the dependent chain per sub-step cut from ~6,000 to a few hundred cycles and 9x the lanes: 16,384 envs are 2,341
+// waves instead of 256.
+// ------------------------------------------------------------------------------------------------
+constexpr int MZ_EPW = 7;      // envs per wave
+constexpr int MZ_SUBMAX = 104;
+
+__global__ __launch_bounds__(64) void maze_step9_kernel(MazeArgs P, const void* action, int action_mode, float* reward,
+                                                        uint8_t* terminated, uint8_t* truncated, int mode) {
+  __shared__ double2 s_d[MZ_EPW + 1][MZ_SUBMAX];
+  __shared__ double2 s_g[64];
+  const int lane = threadIdx.x, q = lane / 9, cell = lane - 9 * q;
+  const int e_raw = blockIdx.x * MZ_EPW + q;
+  const bool active = q < MZ_EPW && e_raw < P.n_env;
+  const int e = active ? e_raw : P.n_env - 1;     // idle lanes shadow a real env and store nothing
+  const size_t N = (size_t)P.n_env;
+  const int t = P.env_task[e];
+  const int32_t* in = P.T.ints + (size_t)t * 8;
+  const double* db = P.T.dbl + (size_t)t * 8;
+  const bool lead = active && cell == 0;
+  const bool resetting = mode == XV_AUTORESET_NEXT_STEP && P.need_reset[e];
+  // ---- action -> (turn_rate, walk_speed): maze_env.py:151-162, maze_continuous_3d.py:49-52 ----
+  double tr, ws;
+  uint32_t err = 0;
+  if (action_mode == XV_MAZE_ACTION_CONTINUOUS) {
+    const double* a = (const double*)action;
+    tr = a[2 * (size_t)e]; ws = a[2 * (size_t)e + 1];
+  } else {
+    int a = ((const int32_t*)action)[e];
+    const int na = action_mode == XV_MAZE_ACTION_DISCRETE16 ? 16 : 32;
+    if (a < 0 || a >= na) { err |= XV_DEVERR_ACTION_RANGE; a = a < 0 ? 0 : na - 1; }
+    if (action_mode == XV_MAZE_ACTION_DISCRETE16) { tr = MZ_ACT16[a][0]; ws = MZ_ACT16[a][1]; }
+    else { tr = MZ_ACT32[a][0]; ws = MZ_ACT32[a][1]; }
+  }
+  const double turn_rate = (tr < -1.0 ? -1.0 : (tr > 1.0 ? 1.0 : tr)) * MZ_PI;
+  const double walk_speed = ws < -1.0 ? -1.0 : (ws > 1.0 ? 1.0 : ws);
+  const int n = in[0], NG = P.NG;
+  const double cell_size = db[0], col_dist = P.collision_dist;
+  double p0 = P.pos[e], p1 = P.pos[N + e], ori = P.ori[e], coll = 0.0;
+  const int ci = (int)(p0 / cell_size), cj = (int)(p1 / cell_size);
+  const int8_t* walls = P.T.walls + (size_t)t * NG * NG;
+  uint32_t patch = 0;
+#pragma unroll
+  for (int a = 0; a < 5; ++a)
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+      const int wi = ci + a - 2, wj = cj + b - 2;
+      if (wi > -1 && wi < n && wj > -1 && wj < n && walls[wi * NG + wj] > 0) patch |= 1u << (a * 5 + b);
+    }
+  const double t_prec = 0.01, delta_t = 1.0;
+  const int iteration = (int)(delta_t / t_prec);
+  const MzDivisor R_cs = mz_divisor(cell_size);
+  const double eff_cd = col_dist / cell_size;
+  const double rad = turn_rate != 0.0 ? walk_speed / turn_rate : 0.0;
+  // ---- phase 1: headings of all sub-steps (sequential, cheap), displacements of this lane's sub-steps ----
+  {
+    double c_dt_full, s_dt_full, c_t = 1.0, s_t = 0.0, ori_k = ori, ori_cached = 0.0;
+    bool have = false;
+    sincos(0.5 * (turn_rate * t_prec), &s_dt_full, &c_dt_full);
+    for (int it = 0; it < iteration + 1; ++it) {
+      const double rem = delta_t - it * t_prec;
+      const double dt = rem < t_prec ? rem : t_prec;
+      if (dt < 1.0e-8) continue;
+      const double d_theta = turn_rate * dt, arc = walk_speed * dt;
+      if (it % 9 == cell) {
+        double c_dt = c_dt_full, s_dt = s_dt_full;
+        if (dt != t_prec) sincos(0.5 * d_theta, &s_dt, &c_dt);
+        if (!have || ori_k != ori_cached) { sincos(ori_k, &s_t, &c_t); ori_cached = ori_k; have = true; }
+        double dx, dy;
+        if (fabs(d_theta) < 1.0e-8) { dx = c_t * arc; dy = s_t * arc; }
+        else {
+          const double off = 2.0 * s_dt * rad;
+          const double c_n = c_t * c_dt - s_t * s_dt, s_n = c_t * s_dt + s_t * c_dt;
+          dx = c_n * off; dy = s_n * off;
+        }
+        s_d[q][it] = make_double2(dx, dy);
+      }
+      ori_k = mz_angle_norm(ori_k + d_theta);
+    }
+    ori = ori_k;
+  }
+  __syncthreads();
+  // ---- phase 2: positions (sequential), one neighbour cell per lane ----
+  const int ni = cell / 3 - 1, nj = cell - 3 * (cell / 3) - 1;     // the reference's (i, j) loop position
+  const double off_i = (double)(float)(ni + 0.5), off_j = (double)(float)(nj + 0.5);
+  for (int it = 0; it < iteration + 1; ++it) {
+    const double rem = delta_t - it * t_prec;
+    const double dt = rem < t_prec ? rem : t_prec;
+    if (dt < 1.0e-8) continue;
+    const double2 d = s_d[q][it];
+    const double e0 = p0 + d.x, e1 = p1 + d.y;
+    const double c0 = mz_div(e0, R_cs), c1 = mz_div(e1, R_cs);
+    const int b0 = (int)c0, b1 = (int)c1;
+    const int a = b0 + ni - ci + 2, b = b1 + nj - cj + 2;
+    bool wall;
+    if (a >= 0 && a < 5 && b >= 0 && b < 5) wall = (patch >> (a * 5 + b)) & 1u;
+    else {   // cannot happen for cell_size >= 1 (|move| <= 1); kept exact by falling back to memory
+      const int wi = b0 + ni, wj = b1 + nj;
+      wall = wi > -1 && wi < n && wj > -1 && wj < n && walls[wi * NG + wj] > 0;
+    }
+    double g0 = 0.0, g1 = 0.0;
+    if (wall) mz_collision_force(c0 - floor(c0) - off_i, c1 - floor(c1) - off_j, cell_size, eff_cd, g0, g1);
+    double f0 = 0.0, f1 = 0.0;
+    if (__ballot(g0 != 0.0 || g1 != 0.0) != 0ull) {   // some env of this wave touches a wall: sum in (i, j) order
+      s_g[lane] = make_double2(g0, g1);
+      __syncthreads();
+      const double2* gq = s_g + 9 * (q < MZ_EPW ? q : 0);
+#pragma unroll
+      for (int c = 0; c < 9; ++c) { f0 += gq[c].x; f1 += gq[c].y; }
+      __syncthreads();
+    }
+    p0 = f0 + e0; p1 = f1 + e1;
+    coll += sqrt(f0 * f0 + f1 * f1);
+  }
+  if (!lead) return;
+  P.fin_flag[e] = 0;
+  if (resetting) {
+    mz_reset_env(P, e, t);
+    reward[e] = 0.0f; terminated[e] = 0; truncated[e] = 0;
+    return;
+  }
+  if (!(fabs(p0) <= 1.0e300) || !(fabs(p1) <= 1.0e300)) err |= XV_DEVERR_NONFINITE;
+  const int g0i = (int)(p0 / cell_size), g1i = (int)(p1 / cell_size);   // get_loc_grid: maze_base.py:220-223
+  // ---- evaluation_rule: maze_base.py:107-119 ----
+  const int steps = P.steps[e] + 1;
+  int age = P.cmd_age[e] + 1, idx = P.cmd_idx[e];
+  const int cmd = P.T.commands[(size_t)t * P.n_cmd + (idx < P.n_cmd ? idx : P.n_cmd - 1)];
+  const int32_t* lc = P.T.lm_coord + ((size_t)t * XV_MAZE_LMAX + cmd) * 2;
+  const bool at_goal = (idx < P.n_cmd) && lc[0] == g0i && lc[1] == g1i;
+  const float r = (at_goal ? (float)db[5] : 0.0f) + (float)db[4];
+  int term = 0;
+  if (at_goal || age >= 500) {
+    idx += 1; age = 0;
+    if (idx > P.n_cmd - 1) term = 1;
+  }
+  const int trunc = (steps > P.max_steps - 1) ? 1 : 0;
+  P.pos[e] = p0; P.pos[N + e] = p1; P.ori[e] = ori; P.collision[e] = coll;
+  P.grid[e] = g0i; P.grid[N + e] = g1i;
+  P.steps[e] = steps; P.cmd_age[e] = age; P.cmd_idx[e] = idx;
+  reward[e] = r; terminated[e] = (uint8_t)term; truncated[e] = (uint8_t)trunc;
+  if (term || trunc) {
+    if (mode == XV_AUTORESET_SAME_STEP) {
+      P.fin_pose[e] = p0; P.fin_pose[N + e] = p1; P.fin_pose[2 * N + e] = ori;
+      P.fin_cmd[e] = idx; P.fin_flag[e] = 1;
+      mz_reset_env(P, e, t);
+    } else if (mode == XV_AUTORESET_NEXT_STEP) {
+      P.need_reset[e] = 1;
+    }
+  }
+  if (err) atomicOr(P.err, err);
+}
+
 // interpolate, ray_caster_utils.py:123-140 (see oracle mz_interpolate for the typing).
 // PACKED: the texture is the engine's RGBX-byte copy with padded rows: the four y-taps of filter row x are the
 // 16 contiguous bytes at [x & 255][(jb - 1) & 255 ...], one global_load_dwordx4 instead of 12 dword loads.  Texel
@@ -345,6 +511,53 @@ __device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, do
   out[0] = mz_div((double)s0, SW); out[1] = mz_div((double)s1, SW); out[2] = mz_div((double)s2, SW);
 }
 
+// Opt-in fp32 variant of the filter above (xv_maze_set_precision(XV_MAZE_FILTER_F32)): same 4x4 taps, same weights
+// 1 - 10 dist / d2 clamped at 0.01, same normalisation, evaluated in float32 with one reciprocal per pixel instead of
+// in the reference's float64 typing: 10 fp32 instructions per tap instead of ~23 fp64-rate ones.  The colour differs
+// from the exact filter by ~1e-4 of a level, i.e. a frame value moves by one level where the exact colour sits that
+// close to an integer: within SURVEY.md M5's budget (+-1 LSB on <= 0.5 % of the values; measured by the tests).
+template <bool PACKED>
+__device__ __forceinline__ void mz_interpolate_f32(const void* __restrict__ texv, double i, double j, double d,
+                                                   double ps, double (&out)[3]) {
+  const int ib = (int)i, jb = (int)j;
+  const float fi = (float)((double)ib - i), fj = (float)((double)jb - j), p = (float)ps;
+  const float d2 = fmaxf((float)(d * d), 1.0e-8f);
+  const float k10 = 10.0f / d2;
+  float sw = 0.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, bb[4];
+#pragma unroll
+  for (int yy = -1; yy < 3; ++yy) {
+    const float b = (fj + (float)yy) * p;
+    bb[yy + 1] = b * b;
+  }
+#pragma unroll
+  for (int xx = -1; xx < 3; ++xx) {
+    const float a = (fi + (float)xx) * p, aa = a * a;
+    const int xv = (ib + xx) & 255;
+    uint32_t q[4];
+    if (PACKED) {
+      const uint32_t* row = static_cast<const uint32_t*>(texv) + (size_t)xv * MZ_TEX_PITCH + ((jb - 1) & 255);
+      const uint4 v = *reinterpret_cast<const uint4*>(row);
+      q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+    }
+#pragma unroll
+    for (int yy = -1; yy < 3; ++yy) {
+      const float wht = fmaxf(fmaf(-(aa + bb[yy + 1]), k10, 1.0f), 0.01f);
+      sw += wht;
+      float t0, t1, t2;
+      if (PACKED) {
+        const uint32_t px = q[yy + 1];
+        t0 = (float)(px & 0xFFu); t1 = (float)((px >> 8) & 0xFFu); t2 = (float)((px >> 16) & 0xFFu);
+      } else {
+        const float* tp = static_cast<const float*>(texv) + ((size_t)xv * 256 + ((jb + yy) & 255)) * 3;
+        t0 = tp[0]; t1 = tp[1]; t2 = tp[2];
+      }
+      s0 = fmaf(wht, t0, s0); s1 = fmaf(wht, t1, s1); s2 = fmaf(wht, t2, s2);
+    }
+  }
+  const float inv = 1.0f / sw;
+  out[0] = (double)(s0 * inv); out[1] = (double)(s1 * inv); out[2] = (double)(s2 * inv);
+}
+
 // texel (x, y) of library entry k -> packed RGBX word at [k][x][y], rows padded with 3 wrapped texels
 __global__ __launch_bounds__(256) void maze_pack_tex_kernel(const float* tex, uint32_t* pk, int n_tex) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -372,7 +585,7 @@ __device__ __forceinline__ uint8_t mz_clip_u8(double v) {   // numpy.clip(v, 0, 
 // The frame is built in LDS in chunks of P.HC rows ([column][HC*3 + 4] bytes: the pad makes the per-lane byte
 // writes bank-conflict free) and each chunk leaves with 16-byte stores; a 64x64 frame is one chunk, the registered
 // 256x256 frame four chunks of 64 rows (49 KiB of LDS, three workgroups per CU).
-template <bool FINAL, bool PACKED>
+template <bool FINAL, bool PACKED, bool F32>
 __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* frames, float* command_rgb) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int e = blockIdx.x;
@@ -567,7 +780,8 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
         uint8_t* px = col + (d_v - c0) * 3;
         if (paint) {
           double c[3];
-          mz_interpolate<PACKED>(tx, f_i, f_j, f_d, tps, tps, c);
+          if (F32) mz_interpolate_f32<PACKED>(tx, f_i, f_j, f_d, tps, c);
+          else mz_interpolate<PACKED>(tx, f_i, f_j, f_d, tps, tps, c);
           px[0] = mz_clip_u8(L * (A + B * c[0]));
           px[1] = mz_clip_u8(L * (A + B * c[1]));
           px[2] = mz_clip_u8(L * (A + B * c[2]));
@@ -749,12 +963,26 @@ static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, b
   const size_t lds_bytes = (((size_t)threads * (a.HC * 3 + 4) + 15) & ~(size_t)15) + (size_t)a.H * 16;
   float* crgb = final ? nullptr : command_rgb;
   const bool packed = a.pk_walls != nullptr;
-#define MAZE_RC(F, K) \
-  hipLaunchKernelGGL((maze_raycast_kernel<F, K>), dim3(a.n_env), dim3(threads), lds_bytes, h->eng->stream, a, frames, crgb)
-  if (final) { if (packed) MAZE_RC(true, true); else MAZE_RC(true, false); }
-  else { if (packed) MAZE_RC(false, true); else MAZE_RC(false, false); }
+#define MAZE_RC(F, K, Q) \
+  hipLaunchKernelGGL((maze_raycast_kernel<F, K, Q>), dim3(a.n_env), dim3(threads), lds_bytes, h->eng->stream, a, frames, crgb)
+#define MAZE_RC2(F, K) do { if (h->filter_f32) MAZE_RC(F, K, true); else MAZE_RC(F, K, false); } while (0)
+  if (final) { if (packed) MAZE_RC2(true, true); else MAZE_RC2(true, false); }
+  else { if (packed) MAZE_RC2(false, true); else MAZE_RC2(false, false); }
+#undef MAZE_RC2
 #undef MAZE_RC
   XV_LAUNCH_CHECK();
+  return XV_OK;
+}
+
+extern "C" int xv_maze_set_precision(xv_maze* h, int filter) {
+  XV_CHECK_ARG(h != nullptr && (filter == XV_MAZE_FILTER_EXACT || filter == XV_MAZE_FILTER_F32));
+  h->filter_f32 = filter == XV_MAZE_FILTER_F32;
+  return XV_OK;
+}
+
+extern "C" int xv_maze_set_move_kernel(xv_maze* h, int kernel) {
+  XV_CHECK_ARG(h != nullptr && (kernel == XV_MAZE_MOVE_LANE_PER_ENV || kernel == XV_MAZE_MOVE_NINE_LANES));
+  h->move_lanes9 = kernel == XV_MAZE_MOVE_NINE_LANES;
   return XV_OK;
 }
 
@@ -776,8 +1004,12 @@ extern "C" int xv_maze_step(xv_maze* h, const void* action, int action_mode, uin
                             int autoreset_mode) {
   XV_CHECK_ARG(h && action && reward && terminated && truncated);
   XV_CHECK_ARG(action_mode >= 0 && action_mode <= 2 && autoreset_mode >= 0 && autoreset_mode <= 2);
-  hipLaunchKernelGGL(maze_step_kernel, dim3(xv_div_up(h->a.n_env, 64)), dim3(64), 0, h->eng->stream, h->a, action,
-                     action_mode, reward, terminated, truncated, autoreset_mode);
+  if (h->move_lanes9)
+    hipLaunchKernelGGL(maze_step9_kernel, dim3(xv_div_up(h->a.n_env, MZ_EPW)), dim3(64), 0, h->eng->stream, h->a, action,
+                       action_mode, reward, terminated, truncated, autoreset_mode);
+  else
+    hipLaunchKernelGGL(maze_step_kernel, dim3(xv_div_up(h->a.n_env, 64)), dim3(64), 0, h->eng->stream, h->a, action,
+                       action_mode, reward, terminated, truncated, autoreset_mode);
   XV_LAUNCH_CHECK();
   if (final_frames && autoreset_mode == XV_AUTORESET_SAME_STEP) {
     const int rc = maze_launch_render(h, final_frames, nullptr, true);

@@ -30,7 +30,8 @@ class MazeWorldVecEnv(VectorEnv):
     def __init__(self, num_envs, enable_render=False, render_scale=480, max_steps=5000, resolution=(320, 320),
                  visibility_3D=12.0, command_in_observation=False, action_space_type="Discrete16",
                  collision_dist=0.20, textures=None, device="cuda:0", seed=0, env_id_base=0,
-                 autoreset_mode="same_step", to_numpy=False, engine=None, copy=True, with_final_obs=False):
+                 autoreset_mode="same_step", to_numpy=False, engine=None, copy=True, with_final_obs=False,
+                 precision="exact"):
         """Constructor arguments as MazeWorldContinuous3D (maze_env.py:110-118); the registered id `mazeworld-v2`
         uses resolution (256, 256), max_steps 5000, visibility_3D 12.0, Discrete16 (mazeworld/__init__.py:19-33).
         `textures`: dict(walls, grounds, ceilings) of float32 [n,256,256,3] arrays; default = the procedural
@@ -49,6 +50,9 @@ class MazeWorldVecEnv(VectorEnv):
         self.action_space_type = action_space_type
         self.collision_dist = float(collision_dist)
         self.with_final_obs = bool(with_final_obs)
+        if precision not in ("exact", "f32"):
+            raise ValueError("precision must be 'exact' (the reference's typing, default) or 'f32'")
+        self.precision = precision      # "f32": texture filter in float32, +-1 level on <= 0.5 % of the frame values
         self.inner_action_list = {"Discrete16": DEFAULT_ACTION_SPACE_16, "Discrete32": DEFAULT_ACTION_SPACE_32}.get(
             action_space_type)
         act = Box(-1, 1, shape=(2,), dtype=np.float32) if action_space_type == "Continuous" else \
@@ -100,6 +104,8 @@ class MazeWorldVecEnv(VectorEnv):
                                            self.visibility_3D, C.byref(ct), _lib.ptr(dev["env_task"]), C.byref(h)))
         self._h = h
         self._tab = dev
+        if self.precision == "f32":
+            _lib.check(self.lib.xv_maze_set_precision(h, 1))
         n = self.num_envs
         self._frames = torch.zeros((n, W, H, 3), dtype=torch.uint8, device=d)
         self._final = torch.zeros((n, W, H, 3), dtype=torch.uint8, device=d) if self.with_final_obs else None
@@ -149,6 +155,10 @@ class MazeWorldVecEnv(VectorEnv):
             infos["_final_obs"] = self._out((self._term | self._trunc).bool())
         return (self._of(self._frames), self._of(self._reward), self._obf(self._term),
                 self._obf(self._trunc), infos)
+
+    def set_move_kernel(self, kernel):
+        """"nine_lanes" (default) or "lane_per_env": two arrangements of the same move / collision arithmetic"""
+        _lib.check(self.lib.xv_maze_set_move_kernel(self._h, {"lane_per_env": 0, "nine_lanes": 1}[kernel]))
 
     def render_frames(self):
         """frames of the current state, without stepping"""
