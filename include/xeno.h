@@ -368,25 +368,26 @@ int xv_linds_set_state(xv_linds* h, const float* x, const int32_t* steps, const 
  * CartPole — reference: xenoverse/metacontrol/random_cartpole.py (set_task :46-50, step :52-61, reset
  * :63-75).  The physics is gymnasium's CartPoleEnv.step (third-party dependency, `gymnasium>=1.0.0` in the
  * reference's setup.py:42, not vendored and not installed here): restated from the public gymnasium 1.x
- * source equations — PARITY UNPINNED.  fp32 state float[4][n_env] (x, x_dot, theta, theta_dot).
- *   params float[n_task][4] = gravity, masscart, masspole, length (sample_cartpole :13-29)
- *   reset_scale float[4]    = reset_bounds_scale (registered default [0.45, 0.90, 0.13, 1.0])
+ * source equations — PARITY UNPINNED.  State double[4][n_env] (x, x_dot, theta, theta_dot) and all of the Euler update
+ * in fp64, as gymnasium keeps `self.state`; only the returned observations are float32 (its np.array(..., float32)).
+ *   params double[n_task][4] = gravity, masscart, masspole, length (sample_cartpole :13-29)
+ *   reset_scale double[4]    = reset_bounds_scale (registered default [0.45, 0.90, 0.13, 1.0])
  *   frameskip               = physics sub-steps per step (registered default 1)
  *   max_steps               <= 0: never truncates, as the reference (no TimeLimit registered)
  * ---------------------------------------------------------------------------------------------- */
-int xv_cartpole_create(xv_engine* e, int n_env, int n_task, int frameskip, int max_steps, const float* params,
-                       const float* reset_scale, const int32_t* env_task, xv_cartpole** out);
+int xv_cartpole_create(xv_engine* e, int n_env, int n_task, int frameskip, int max_steps, const double* params,
+                       const double* reset_scale, const int32_t* env_task, xv_cartpole** out);
 int xv_cartpole_destroy(xv_cartpole* h);
 int xv_cartpole_reset(xv_cartpole* h, const uint8_t* mask, float* obs /*[n_env][4]*/);
-int xv_cartpole_reset_injected(xv_cartpole* h, const uint8_t* mask, const float* u /*[4][n_env] in [0,1)*/,
+int xv_cartpole_reset_injected(xv_cartpole* h, const uint8_t* mask, const double* u /*[4][n_env] in [0,1)*/,
                                float* obs);
 int xv_cartpole_step(xv_cartpole* h, const int32_t* action, float* obs, float* reward, uint8_t* terminated,
                      uint8_t* truncated, float* final_obs, int autoreset_mode);
-int xv_cartpole_step_injected(xv_cartpole* h, const int32_t* action, const float* u_reset, float* obs,
+int xv_cartpole_step_injected(xv_cartpole* h, const int32_t* action, const double* u_reset, float* obs,
                               float* reward, uint8_t* terminated, uint8_t* truncated, float* final_obs,
                               int autoreset_mode);
-int xv_cartpole_get_state(xv_cartpole* h, float* state /*[4][n_env]*/, int32_t* steps, uint8_t* need_reset);
-int xv_cartpole_set_state(xv_cartpole* h, const float* state, const int32_t* steps, const uint8_t* need_reset);
+int xv_cartpole_get_state(xv_cartpole* h, double* state /*[4][n_env]*/, int32_t* steps, uint8_t* need_reset);
+int xv_cartpole_set_state(xv_cartpole* h, const double* state, const int32_t* steps, const uint8_t* need_reset);
 
 /* ------------------------------------------------------------------------------------------------
  * Acrobot — reference: xenoverse/metacontrol/random_acrobot.py (_dsdt :58-96, _terminal :98-101, set_task
@@ -470,12 +471,15 @@ int xv_maze_render(xv_maze* h, uint8_t* frames, float* command_rgb);
  * float64/float32 typing, frames identical to the oracle's.  F32: the same 4x4 distance-weighted taps evaluated in
  * float32 — opt-in, ~3x less arithmetic per pixel; frames stay within SURVEY.md M5's budget against the reference
  * (+-1 level on <= 0.5 % of the values; a value moves only where the exact colour lies within ~1e-4 of an integer). */
-/* The move / collision / rules kernel (results identical; NINE_LANES is the default): LANE_PER_ENV walks the 100
- * sub-steps of an env in one lane; NINE_LANES gives an env the nine lanes of its 3x3 wall neighbourhood, evaluates the
- * position-independent part of all sub-steps (heading, sin / cos, displacement) in parallel first and keeps only the
- * position chain sequential (dynamics.py:98-123,158-187). */
+/* The move / collision / rules kernel (results identical; AUTO is the default): LANE_PER_ENV walks the 100 sub-steps
+ * of an env in one lane; NINE_LANES / THREE_LANES give an env the lanes of its 3x3 wall neighbourhood (one cell or one
+ * row of cells each), evaluate the position-independent part of all sub-steps (heading, sin / cos, displacement) in
+ * parallel first and keep only the position chain sequential (dynamics.py:98-123,158-187); AUTO picks nine or three
+ * lanes by the batch size. */
 #define XV_MAZE_MOVE_LANE_PER_ENV 0
 #define XV_MAZE_MOVE_NINE_LANES 1
+#define XV_MAZE_MOVE_THREE_LANES 2
+#define XV_MAZE_MOVE_AUTO 3
 int xv_maze_set_move_kernel(xv_maze* h, int kernel);
 #define XV_MAZE_FILTER_EXACT 0
 #define XV_MAZE_FILTER_F32 1

@@ -152,6 +152,33 @@ class AnyMDPOracle(object):
                                  _p(fobs), C.c_int(mode))
         return obs, rew, rgt, term, trunc, fobs
 
+    def solve(self, gamma=0.99, tol=1.0e-4, max_iter=20000):
+        """the ground-truth teacher's table as xv_anymdp_solve computes it -> (Q f64[n_task,S,A], greedy u8[n_task,S], sweeps)"""
+        q = np.zeros((self.n_task, self.S, self.A))
+        g = np.zeros((self.n_task, self.S), np.uint8)
+        it = np.zeros(self.n_task, np.int32)
+        lib().xo_anymdp_solve(C.byref(self._h), C.c_double(gamma), C.c_double(tol), C.c_int(max_iter), _p(q), _p(g), _p(it))
+        return q, g, it
+
+    def rollout_teacher(self, seed, gid_base, tick0, T, greedy, epsilon=0.0):
+        """xv_anymdp_rollout_teacher restated: per step the action is greedy[task, inner state] (the policy of
+        AnyMDPSolverOpt, anymdp_solver_opt.py:38-51), replaced by a uniform action with probability epsilon (draw
+        purpose 2 of the step's tick: word 0 -> 24-bit uniform, word 1 -> action), then one SAME_STEP step."""
+        greedy = np.asarray(greedy)
+        keys = ("action", "obs", "reward", "reward_gt", "terminated", "truncated", "final_obs")
+        rec = {k: [] for k in keys}
+        for ts in range(T):
+            a = greedy[self.env_task, self.state].astype(np.int32)
+            if epsilon > 0.0:
+                for i in range(self.n_env):
+                    w = env_draw(seed, gid_base + i, tick0 + ts, 2)
+                    if np.float32(int(w[0]) >> 8) * np.float32(1.0 / 16777216.0) < np.float32(epsilon):
+                        a[i] = int(w[1]) % self.A
+            o = self.step(seed, gid_base, tick0 + ts, a, 2)
+            for k, v in zip(keys, (a,) + o):
+                rec[k].append(np.array(v, copy=True))
+        return {k: np.stack(v) for k, v in rec.items()}
+
     def transition_gt(self, action):
         a = np.ascontiguousarray(action, np.int32)
         out = np.zeros((self.n_env, self.S), np.float64)
@@ -274,11 +301,11 @@ class _CartPoleStruct(C.Structure):
 
 class CartPoleOracle(object):
     def __init__(self, params, env_task, frameskip=1, max_steps=0, reset_scale=(0.45, 0.90, 0.13, 1.0)):
-        self.params = np.ascontiguousarray(params, np.float32).reshape(-1, 4)
+        self.params = np.ascontiguousarray(params, np.float64).reshape(-1, 4)
         self.env_task = np.ascontiguousarray(env_task, np.int32)
         self.n_env = len(self.env_task)
-        self.scale = np.ascontiguousarray(reset_scale, np.float32)
-        self.state = np.zeros((4, self.n_env), np.float32)
+        self.scale = np.ascontiguousarray(reset_scale, np.float64)
+        self.state = np.zeros((4, self.n_env), np.float64)
         self.steps = np.zeros(self.n_env, np.int32)
         self.need_reset = np.ones(self.n_env, np.uint8)
         self._h = _CartPoleStruct(self.n_env, len(self.params), frameskip, max_steps, _p(self.params),
@@ -293,7 +320,7 @@ class CartPoleOracle(object):
 
     def reset_injected(self, u, mask=None):
         obs = np.zeros((self.n_env, 4), np.float32)
-        u = np.ascontiguousarray(u, np.float32).reshape(4, self.n_env)
+        u = np.ascontiguousarray(u, np.float64).reshape(4, self.n_env)
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         lib().xo_cartpole_reset_injected(C.byref(self._h), _p(m), _p(u), _p(obs))
         return obs
@@ -307,7 +334,7 @@ class CartPoleOracle(object):
     def step_injected(self, action, u_reset, mode):
         o = self._outs()
         a = np.ascontiguousarray(action, np.int32)
-        u = np.ascontiguousarray(u_reset, np.float32).reshape(4, self.n_env)
+        u = np.ascontiguousarray(u_reset, np.float64).reshape(4, self.n_env)
         lib().xo_cartpole_step_injected(C.byref(self._h), _p(a), _p(u), _p(o["obs"]), _p(o["reward"]),
                                         _p(o["terminated"]), _p(o["truncated"]), _p(o["final_obs"]), C.c_int(mode))
         return o

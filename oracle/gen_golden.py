@@ -424,6 +424,34 @@ def gen_maze():
         gen_maze_one("maze_15_seed%d" % k, task, max_steps=(5000 if k else 230), seed0=100 + k)
 
 
+def gen_maze_sampled(n_tasks=24, seed0=10):
+    """Tasks of the reference's MazeTaskSampler over its default size range (and a few without loops): topology,
+    textures, landmarks, start, commands — the build's sampler consumes the same stream and must return the same task."""
+    Maze, mts, dyn, rc = _refimport.mazeworld()
+    from xenoverse_amd.mazeworld.textures import make_texture_library
+    lib = make_texture_library(8, 4, 4, seed=0)
+    M = mts.MAZE_TASK_MANAGER
+    M.textlib_walls, M.textlib_grounds, M.textlib_ceilings = lib["walls"], lib["grounds"], lib["ceilings"]
+    out = {k: [] for k in ("seed", "allow_loops", "n", "cell_walls", "cell_texts", "cell_landmarks", "start", "n_landmarks",
+                           "landmarks", "commands", "scalars")}
+    for k in range(n_tasks):
+        loops = (k % 4) != 3
+        t = mts.MazeTaskSampler(seed=seed0 + k, allow_loops=loops, commands_sequence=32, verbose=False)
+        n = t["cell_walls"].shape[0]
+        pad = lambda a, fill: np.pad(np.asarray(a), ((0, 25 - n), (0, 25 - n)), constant_values=fill)
+        out["seed"].append(seed0 + k); out["allow_loops"].append(loops); out["n"].append(n)
+        out["cell_walls"].append(pad(t["cell_walls"], 1).astype(np.int8)); out["cell_texts"].append(pad(t["cell_texts"], 0).astype(np.int64))
+        out["cell_landmarks"].append(pad(t["cell_landmarks"], -1).astype(np.int8)); out["start"].append(np.asarray(t["start"], np.int64))
+        lm = np.full((15, 2), -1, np.int64); lm[:len(t["landmarks_coordinates"])] = np.asarray(t["landmarks_coordinates"], np.int64)
+        out["landmarks"].append(lm); out["n_landmarks"].append(len(t["landmarks_coordinates"]))
+        out["commands"].append(np.asarray(t["commands_sequence"], np.int64))
+        out["scalars"].append([t["cell_size"], t["wall_height"], t["agent_height"], t["fol_angle"], t["goal_reward"],
+                               t["ground_text"], t["ceiling_text"]])
+    path = os.path.join(GOLD, "sampler_refmazes.npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in out.items()})
+    print("sampler_refmazes.npz", os.path.getsize(path) // 1024, "KiB")
+
+
 def gen_acrobot():
     """The reference's OWN Acrobot code: RandomAcrobotEnv._dsdt and ._terminal (random_acrobot.py:58-101), called on
     random inputs with tasks drawn over sample_acrobot's ranges, and the reset-state formula (:123-125).  The
@@ -558,7 +586,7 @@ def gen_anymdp_sampled(n=32, seed0=100):
 
 
 FAMILIES = {"anymdp": gen_anymdp, "linds": gen_linds, "maze": gen_maze, "acrobot": gen_acrobot, "garnet": gen_garnet,
-            "anymdp_vi": gen_anymdp_vi, "anymdp_sampled": gen_anymdp_sampled}
+            "anymdp_vi": gen_anymdp_vi, "anymdp_sampled": gen_anymdp_sampled, "maze_sampled": gen_maze_sampled}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

@@ -536,18 +536,21 @@ void xo_linds_step(xo_linds* h, uint64_t seed, uint64_t gid_base, uint64_t tick,
  * CartPole — metacontrol/random_cartpole.py :46-75 over gymnasium CartPoleEnv.step (Euler integrator,
  * force_mag 10, tau 0.02, x_threshold 2.4, theta_threshold 12 deg).  PARITY UNPINNED (gymnasium absent).
  * ---------------------------------------------------------------------------------------------- */
-static void cartpole_reset_one(xo_cartpole* h, int i, const float u[4], float* obs) {
-  /* state = uniform(-1, 1, 4) * reset_bounds_scale  (random_cartpole.py:70) */
+static void cartpole_reset_one(xo_cartpole* h, int i, const double u[4], float* obs) {
+  /* state = uniform(-1, 1, 4) * reset_bounds_scale (random_cartpole.py:70): a float64 array; the observation is its
+   * float32 cast (:75) */
   for (int k = 0; k < 4; ++k) {
-    float v = fmaf(2.0f, u[k], -1.0f) * h->reset_scale[k];
+    double v = fma(2.0, u[k], -1.0) * h->reset_scale[k];
     h->state[(size_t)k * h->n_env + i] = v;
-    if (obs) obs[(size_t)i * 4 + k] = v;
+    if (obs) obs[(size_t)i * 4 + k] = (float)v;
   }
   h->steps[i] = 0;
   h->need_reset[i] = 0;
 }
 
-static void cartpole_step_one(xo_cartpole* h, int i, int action, const float u_reset[4], float* obs,
+/* gymnasium CartPoleEnv.step keeps `self.state` and all of its arithmetic in float64 (Python floats / numpy float64)
+ * and casts only the returned observation to float32; so does this restatement. */
+static void cartpole_step_one(xo_cartpole* h, int i, int action, const double u_reset[4], float* obs,
                               float* reward, uint8_t* terminated, uint8_t* truncated, float* final_obs, int mode) {
   const int N = h->n_env, t = h->env_task[i];
   if (final_obs) for (int k = 0; k < 4; ++k) final_obs[(size_t)i * 4 + k] = 0.0f;
@@ -557,24 +560,25 @@ static void cartpole_step_one(xo_cartpole* h, int i, int action, const float u_r
     return;
   }
   if (action != 0 && action != 1) { h->err_flags |= 1u; action = action > 0 ? 1 : 0; }
-  const float gravity = h->params[t * 4 + 0], masscart = h->params[t * 4 + 1], masspole = h->params[t * 4 + 2],
-              length = h->params[t * 4 + 3];
-  const float polemass_length = masspole * length;  /* :49 */
-  const float total_mass = masspole + masscart;     /* :50 */
-  float x = h->state[i], xd = h->state[(size_t)N + i], th = h->state[(size_t)2 * N + i], thd = h->state[(size_t)3 * N + i];
-  const float force = action == 1 ? 10.0f : -10.0f;
+  const double gravity = h->params[t * 4 + 0], masscart = h->params[t * 4 + 1], masspole = h->params[t * 4 + 2],
+               length = h->params[t * 4 + 3];
+  const double polemass_length = masspole * length;  /* :49 */
+  const double total_mass = masspole + masscart;     /* :50 */
+  double x = h->state[i], xd = h->state[(size_t)N + i], th = h->state[(size_t)2 * N + i], thd = h->state[(size_t)3 * N + i];
+  const double force = action == 1 ? 10.0 : -10.0;
+  const double theta_threshold = 12 * 2 * 3.141592653589793 / 360, x_threshold = 2.4, tau = 0.02;
   float total_reward = 0.0f;
   int term = 0;
   for (int f = 0; f < h->frameskip; ++f) { /* :56-60 */
-    const float cs = cosf(th), sn = sinf(th);
-    const float temp = (force + polemass_length * thd * thd * sn) / total_mass;
-    const float thacc = (gravity * sn - cs * temp) / (length * (4.0f / 3.0f - masspole * cs * cs / total_mass));
-    const float xacc = temp - polemass_length * thacc * cs / total_mass;
-    x = x + 0.02f * xd;
-    xd = xd + 0.02f * xacc;
-    th = th + 0.02f * thd;
-    thd = thd + 0.02f * thacc;
-    term = (x < -2.4f) || (x > 2.4f) || (th < -0.20943951f) || (th > 0.20943951f);
+    const double cs = cos(th), sn = sin(th);
+    const double temp = (force + polemass_length * (thd * thd) * sn) / total_mass;
+    const double thacc = (gravity * sn - cs * temp) / (length * (4.0 / 3.0 - masspole * (cs * cs) / total_mass));
+    const double xacc = temp - polemass_length * thacc * cs / total_mass;
+    x = x + tau * xd;
+    xd = xd + tau * xacc;
+    th = th + tau * thd;
+    thd = thd + tau * thacc;
+    term = (x < -x_threshold) || (x > x_threshold) || (th < -theta_threshold) || (th > theta_threshold);
     total_reward += 1.0f;
     if (term) break;
   }
@@ -582,7 +586,8 @@ static void cartpole_step_one(xo_cartpole* h, int i, int action, const float u_r
   const int trunc = h->max_steps > 0 && steps >= h->max_steps;
   h->state[i] = x; h->state[(size_t)N + i] = xd; h->state[(size_t)2 * N + i] = th; h->state[(size_t)3 * N + i] = thd;
   h->steps[i] = steps;
-  obs[(size_t)i * 4 + 0] = x; obs[(size_t)i * 4 + 1] = xd; obs[(size_t)i * 4 + 2] = th; obs[(size_t)i * 4 + 3] = thd;
+  obs[(size_t)i * 4 + 0] = (float)x; obs[(size_t)i * 4 + 1] = (float)xd; obs[(size_t)i * 4 + 2] = (float)th;
+  obs[(size_t)i * 4 + 3] = (float)thd;
   reward[i] = total_reward; terminated[i] = (uint8_t)term; truncated[i] = (uint8_t)trunc;
   if (term || trunc) {
     if (mode == 2) {
@@ -594,34 +599,34 @@ static void cartpole_step_one(xo_cartpole* h, int i, int action, const float u_r
   }
 }
 
-void xo_cartpole_reset_injected(xo_cartpole* h, const uint8_t* mask, const float* u, float* obs) {
+void xo_cartpole_reset_injected(xo_cartpole* h, const uint8_t* mask, const double* u, float* obs) {
   for (int i = 0; i < h->n_env; ++i) {
     if (mask && !mask[i]) continue;
-    float uu[4];
+    double uu[4];
     for (int k = 0; k < 4; ++k) uu[k] = u[(size_t)k * h->n_env + i];
     cartpole_reset_one(h, i, uu, obs);
   }
 }
 
-void xo_cartpole_step_injected(xo_cartpole* h, const int32_t* action, const float* u_reset, float* obs,
+void xo_cartpole_step_injected(xo_cartpole* h, const int32_t* action, const double* u_reset, float* obs,
                                float* reward, uint8_t* terminated, uint8_t* truncated, float* final_obs, int mode) {
   for (int i = 0; i < h->n_env; ++i) {
-    float uu[4];
+    double uu[4];
     for (int k = 0; k < 4; ++k) uu[k] = u_reset[(size_t)k * h->n_env + i];
     cartpole_step_one(h, i, action[i], uu, obs, reward, terminated, truncated, final_obs, mode);
   }
 }
 
-static inline void cartpole_draw(uint64_t seed, uint64_t gid, uint64_t tick, float u[4]) {
+static inline void cartpole_draw(uint64_t seed, uint64_t gid, uint64_t tick, double u[4]) {
   uint32_t w[4];
   xo_env_draw(seed, gid, tick, 1, w);
-  for (int k = 0; k < 4; ++k) u[k] = (float)(w[k] >> 8) * (1.0f / 16777216.0f);
+  for (int k = 0; k < 4; ++k) u[k] = (double)w[k] * (1.0 / 4294967296.0);
 }
 
 void xo_cartpole_reset(xo_cartpole* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const uint8_t* mask, float* obs) {
   for (int i = 0; i < h->n_env; ++i) {
     if (mask && !mask[i]) continue;
-    float u[4];
+    double u[4];
     cartpole_draw(seed, gid_base + (uint64_t)i, tick, u);
     cartpole_reset_one(h, i, u, obs);
   }
@@ -630,7 +635,7 @@ void xo_cartpole_reset(xo_cartpole* h, uint64_t seed, uint64_t gid_base, uint64_
 void xo_cartpole_step(xo_cartpole* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const int32_t* action,
                       float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, float* final_obs, int mode) {
   for (int i = 0; i < h->n_env; ++i) {
-    float u[4];
+    double u[4];
     cartpole_draw(seed, gid_base + (uint64_t)i, tick, u);
     cartpole_step_one(h, i, action[i], u, obs, reward, terminated, truncated, final_obs, mode);
   }

@@ -87,6 +87,9 @@ int xo_max_threads(void);
 double xo_np_pairwise_sum(const double* a, int64_t n);
 int xo_update_value_matrix(const double* t_mat, const double* r_mat, int ns, int na, double gamma, double* vm,
                            int is_greedy);
+/* value iteration for every task of an oracle handle, as xv_anymdp_solve runs it (xeno_oracle_sampler.c part 3) */
+void xo_anymdp_solve(const xo_anymdp* h, double gamma, double tol, int max_iter, double* q_out, uint8_t* greedy_out,
+                     int32_t* iters_out);
 /* one candidate of the device task sampler (counter-based draws); see xeno_oracle_sampler.c part 2 */
 typedef struct {
   int32_t status, goal, n_s0, repair_rounds;
@@ -153,17 +156,17 @@ int xo_linds_yorder(int NS, int* ord);
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
   int n_env, n_task, frameskip, max_steps; /* max_steps <= 0: never truncates (the reference registers no TimeLimit) */
-  const float* params;    /* [n_task][4]: gravity, masscart, masspole, length */
-  const float* reset_scale; /* [4] reset_bounds_scale */
+  const double* params;    /* [n_task][4]: gravity, masscart, masspole, length */
+  const double* reset_scale; /* [4] reset_bounds_scale */
   const int32_t* env_task;
-  float* state;           /* [4][n_env]: x, x_dot, theta, theta_dot */
+  double* state;           /* [4][n_env]: x, x_dot, theta, theta_dot (float64, as gymnasium keeps it) */
   int32_t* steps;
   uint8_t* need_reset;
   uint32_t err_flags;
 } xo_cartpole;
-void xo_cartpole_reset_injected(xo_cartpole* h, const uint8_t* mask, const float* u /*[4][n_env] in [0,1)*/,
+void xo_cartpole_reset_injected(xo_cartpole* h, const uint8_t* mask, const double* u /*[4][n_env] in [0,1)*/,
                                 float* obs /*[n_env][4]*/);
-void xo_cartpole_step_injected(xo_cartpole* h, const int32_t* action, const float* u_reset, float* obs,
+void xo_cartpole_step_injected(xo_cartpole* h, const int32_t* action, const double* u_reset, float* obs,
                                float* reward, uint8_t* terminated, uint8_t* truncated, float* final_obs, int mode);
 void xo_cartpole_reset(xo_cartpole* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const uint8_t* mask, float* obs);
 void xo_cartpole_step(xo_cartpole* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const int32_t* action,

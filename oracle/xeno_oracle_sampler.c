@@ -493,3 +493,64 @@ int xo_anymdp_sample_candidate(uint64_t seed, uint64_t cand, int ns, int na, dou
   free(pot); free(rpos); free(npos); free(rsa); free(nsa); free(bonus); free(er); free(q);
   return status;
 }
+
+/* =====================================================================================================================
+ * Part 3: the ground-truth teacher (AnyMDPSolverOpt, anymdp_solver_opt.py:30-51) as the device computes it for whole
+ * task batches (xv_anymdp_solve): value iteration on the tasks' own tables — T recovered from the inclusive CDF rows
+ * (p_j = cdf_j - cdf_{j-1}; rows of terminal states are zero, as in the reference), R the fp32 table rewards —
+ * synchronous sweeps Q <- ER + gamma T max_a Q until rms(Q_new - Q) <= tol or max_iter sweeps; greedy = first argmax.
+ * ===================================================================================================================*/
+void xo_anymdp_solve(const xo_anymdp* h, double gamma, double tol, int max_iter, double* q_out, uint8_t* greedy_out,
+                     int32_t* iters_out) {
+  const int S = h->S, A = h->A, SA = S * A;
+  double* T = (double*)malloc(sizeof(double) * (size_t)SA * S);
+  double* er = (double*)malloc(sizeof(double) * SA);
+  double* q = (double*)malloc(sizeof(double) * SA);
+  double* qn = (double*)malloc(sizeof(double) * SA);
+  double* v = (double*)malloc(sizeof(double) * S);
+  for (int t = 0; t < h->n_task; ++t) {
+    for (int s = 0; s < S; ++s) {
+      const int term = (int)((h->term_mask[(size_t)t * ((S + 63) / 64) + (s >> 6)] >> (s & 63)) & 1u);
+      for (int a = 0; a < A; ++a) {
+        const size_t row = (((size_t)t * S + s) * A + a) * (size_t)S;
+        double prev = 0.0, e = 0.0;
+        for (int j = 0; j < S; ++j) {
+          const double c = h->cdf[row + j];
+          const double p = term ? 0.0 : c - prev;
+          prev = c;
+          T[((size_t)s * A + a) * S + j] = p;
+          e = fma(p, (double)h->rs[(row + j) * 2], e);
+        }
+        er[s * A + a] = e;
+      }
+    }
+    for (int k = 0; k < SA; ++k) q[k] = 0.0;
+    int it = 0;
+    for (; it < max_iter;) {
+      for (int j = 0; j < S; ++j) {
+        double x = q[j * A];
+        for (int a = 1; a < A; ++a) x = q[j * A + a] > x ? q[j * A + a] : x;
+        v[j] = x;
+      }
+      double d2 = 0.0;
+      for (int k = 0; k < SA; ++k) {
+        double acc = 0.0;
+        for (int j = 0; j < S; ++j) acc = fma(T[(size_t)k * S + j], v[j], acc);
+        qn[k] = fma(gamma, acc, er[k]);
+        d2 += (qn[k] - q[k]) * (qn[k] - q[k]);
+      }
+      memcpy(q, qn, sizeof(double) * SA);
+      ++it;
+      if (sqrt(d2 / (double)SA) <= tol) break;
+    }
+    if (q_out) memcpy(q_out + (size_t)t * SA, q, sizeof(double) * SA);
+    if (greedy_out)
+      for (int s = 0; s < S; ++s) {
+        int best = 0;
+        for (int a = 1; a < A; ++a) if (q[s * A + a] > q[s * A + best]) best = a;
+        greedy_out[(size_t)t * S + s] = (uint8_t)best;
+      }
+    if (iters_out) iters_out[t] = it;
+  }
+  free(T); free(er); free(q); free(qn); free(v);
+}

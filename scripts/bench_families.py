@@ -230,7 +230,7 @@ def bench_mixed(args):
             "env_steps_per_s": n / (best * 1e-6), "us_per_vector_step": res, "dtype": "f64/f32"}
 
 
-def bench_maze(args, res, precision="exact"):
+def bench_maze(args, res, precision="exact", move_kernel="auto"):
     from xenoverse_amd.mazeworld import MazeTaskSampler, MazeWorldVecEnv, make_texture_library
     from xenoverse_amd import _lib
     from xenoverse_amd.engine import AUTORESET
@@ -241,6 +241,7 @@ def bench_maze(args, res, precision="exact"):
     env = MazeWorldVecEnv(n, resolution=(res, res), textures=make_texture_library(8, 4, 4, seed=0),
                           autoreset_mode="same_step", action_space_type="Discrete16", precision=precision)
     env.set_task(tasks)
+    env.set_move_kernel(move_kernel)
     env.reset()
     a = torch.randint(0, 16, (n,), device=env.device, dtype=torch.int32)
     steps = max(3, args.steps // (40 if res <= 64 else 400))
@@ -265,7 +266,7 @@ def bench_maze(args, res, precision="exact"):
     # = 368 fp64-pipe instructions + ~40 of geometry; peak = 1024 SIMDs x 64 lanes x 2.4 GHz / 4 cycles per wave-instr
     valu_ops = 408.0 * res * res * n
     valu_peak = 1024 * 64 * 2.4e9 / 4
-    return {"family": "mazeworld", "filter": precision,
+    return {"family": "mazeworld", "filter": precision, "move_kernel": move_kernel,
             "workload": "15x15 mazes, 16,384 envs = 256 tasks x 64, %dx%d frames" % (res, res),
             "dtype": "f64 pose, f32/f64 ray-caster, u8 frames", "env_steps_per_s": n / (us_full * 1e-6),
             "us_per_step": {"move+rules": us_move, "raycast": us_render, "step (both)": us_full},
@@ -296,7 +297,10 @@ if __name__ == "__main__":
         elif f == "anymdp_tok":
             r = bench_anymdp_tok(args)
         elif f.startswith("maze"):
-            r = bench_maze(args, int(f[4:].split("_")[0]), "f32" if f.endswith("_f32") else "exact")
+            tok = f[4:].split("_")
+            mv = {"m1": "lane_per_env", "m3": "three_lanes", "m9": "nine_lanes"}
+            r = bench_maze(args, int(tok[0]), "f32" if "f32" in tok else "exact",
+                           next((mv[t] for t in tok if t in mv), "auto"))
         else:
             continue
         print(json.dumps(r), flush=True)

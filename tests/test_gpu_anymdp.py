@@ -503,6 +503,23 @@ def test_teacher_rollout_on_device():
         env.close()
     for k in ("action", "obs", "reward", "terminated"):
         assert np.array_equal(outs[0][k], outs[1][k]), k
+    # ... and the oracle's restatement of the teacher rollout (greedy and epsilon-greedy), draw for draw
+    from xenoverse_amd.anymdp import build_tables
+    tab = build_tables(tasks)
+    for eps in (0.0, 0.3):
+        env = AnyMDPVecEnv(n, seed=11, env_id_base=4000, autoreset_mode="same_step")
+        env.set_task(tasks, env_task_index=env_task)
+        ora = oracle.AnyMDPOracle(tab, env_task)
+        tick = env.engine.tick
+        obs, _ = env.reset()
+        assert np.array_equal(_np(obs), ora.reset(11, 4000, tick))
+        tick = env.engine.tick
+        dev = env.rollout_teacher(T, greedy, epsilon=eps)
+        ref = ora.rollout_teacher(11, 4000, tick, T, greedy, epsilon=eps)
+        for k in ("action", "obs", "terminated", "truncated", "final_obs"):
+            assert np.array_equal(_np(dev[k]), ref[k]), (eps, k)
+        assert np.allclose(_np(dev["reward"]), ref["reward"], rtol=1e-5, atol=2e-6)
+        env.close()
     # the teacher is better than random: compare average reward_gt per step
     env = AnyMDPVecEnv(n, seed=3, autoreset_mode="same_step"); env.set_task(tasks, env_task_index=env_task); env.reset()
     opt = float(env.rollout_teacher(200, greedy, 0.0)["reward_gt"].mean())
@@ -640,10 +657,10 @@ def test_step_many_graph_replay_equals_plain_launches(search):
 
 
 @pytest.mark.parametrize("case", ["golden16", "synth64", "synth100", "sampled64"])
-def test_device_value_iteration_vs_numpy(case):
-    """xv_anymdp_solve (register path for S <= 64, S*A <= 512; strided path otherwise) against the host value
-    iteration on the same tables: same number of sweeps, Q to 1e-9, greedy actions equal wherever the best two
-    Q values are not within 1e-7 of each other"""
+def test_device_value_iteration_vs_oracle_and_numpy(case):
+    """xv_anymdp_solve (register path for S <= 64, S*A <= 512; strided path otherwise) against the oracle's restatement
+    (xo_anymdp_solve: same tables, same sweeps) and the host value iteration: sweep counts equal, Q to 1e-9, greedy
+    actions equal wherever the best two Q values are not within 1e-7 of each other"""
     from xenoverse_amd.anymdp.task_sampler import value_iteration
     from xenoverse_amd.anymdp import from_blocked
     if case == "golden16":
@@ -661,6 +678,14 @@ def test_device_value_iteration_vs_numpy(case):
     q, g, it = env.solve(gamma=0.99)
     q, g, it = _np(q), _np(g), _np(it)
     cdf, rs = from_blocked(_np(env._tab["rows"]), S)
+    otab = dict(S=S, A=A, s0_max=int(tab["s0_max"]), cdf=cdf, rs=rs, state_map=_np(env._tab["state_map"]),
+                term_mask=_np(env._tab["term_mask"]).view(np.uint64), s0_cdf=_np(env._tab["s0_cdf"]),
+                s0_ids=_np(env._tab["s0_ids"]), max_steps=_np(env._tab["max_steps"]))
+    qo, go, ito = oracle.AnyMDPOracle(otab, np.zeros(1, np.int32)).solve(0.99)
+    assert np.max(np.abs(it.astype(np.int64) - ito)) <= 1 and np.allclose(q, qo, rtol=1e-9, atol=1e-9)
+    srt_o = np.sort(qo, -1)
+    clear_o = (srt_o[..., -1] - srt_o[..., -2]) > 1e-7
+    assert np.array_equal(g[clear_o], go[clear_o])
     for t in range(n_task):
         T = np.diff(np.concatenate([np.zeros((S, A, 1)), cdf[t]], -1), axis=-1)
         term = np.array([(int(np.asarray(tab["term_mask"]).view(np.uint64)[t][s >> 6]) >> (s & 63)) & 1 for s in range(S)], bool)

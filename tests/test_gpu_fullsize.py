@@ -234,7 +234,7 @@ def test_config5_mixed_share_of_rank_vs_oracles(rank):
     ora_l = oracle.LinDSOracle(ltab, et_l)
     # cartpole: 1,024 tasks, neighbours on different tasks
     ctasks = [sample_cartpole(seed=1000 * rank + k) for k in range(1024)]
-    params = np.array([[t["gravity"], t["masscart"], t["masspole"], t["length"]] for t in ctasks], np.float32)
+    params = np.array([[t["gravity"], t["masscart"], t["masspole"], t["length"]] for t in ctasks], np.float64)
     et_c = (np.arange(nc) % 1024).astype(np.int32)
     ora_c = oracle.CartPoleOracle(params, et_c, frameskip=1, max_steps=40)
     mb.set_task({"a": (ta, et_a), "l": (ltasks, et_l), "c": (ctasks, et_c)})

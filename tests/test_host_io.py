@@ -34,3 +34,35 @@ def test_registry_ids_match_reference():
     assert registration.REGISTRY["mazeworld-v2"][1]["resolution"] == (256, 256)
     assert registration.REGISTRY["random-cartpole-v0"][1]["frameskip"] == 1
     registration.register_with_gymnasium()     # must not raise without gymnasium
+
+
+def test_reference_ids_register_as_vector_entry_points(monkeypatch):
+    """with a gymnasium present (a minimal stand-in here: registry + register), the reference's own ids get the batched
+    engine as `vector_entry_point`; an id the reference package registered first keeps its scalar entry point"""
+    import sys
+    import types
+    from xenoverse_amd import registration
+    reg = {}
+
+    class Spec(object):
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    def register(id, entry_point=None, vector_entry_point=None, kwargs=None, **other):
+        reg[id] = Spec(id=id, entry_point=entry_point, vector_entry_point=vector_entry_point, kwargs=kwargs or {})
+    gym = types.ModuleType("gymnasium")
+    envs = types.ModuleType("gymnasium.envs")
+    regmod = types.ModuleType("gymnasium.envs.registration")
+    regmod.register, regmod.registry = register, reg
+    gym.envs, envs.registration = envs, regmod
+    for name, mod in (("gymnasium", gym), ("gymnasium.envs", envs), ("gymnasium.envs.registration", regmod)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    reg["anymdp-v0"] = Spec(id="anymdp-v0", entry_point="xenoverse.anymdp:AnyMDPEnv", vector_entry_point=None, kwargs={"max_steps": 5000})
+    assert registration.register_with_gymnasium() is True
+    assert reg["anymdp-v0"].entry_point == "xenoverse.anymdp:AnyMDPEnv"
+    assert reg["anymdp-v0"].vector_entry_point == "xenoverse_amd.anymdp:AnyMDPVecEnv"
+    for env_id in ("linear-dynamics-v0", "mazeworld-v2", "random-cartpole-v0", "random-acrobot-v0"):
+        assert reg[env_id].entry_point is None and reg[env_id].vector_entry_point.startswith("xenoverse_amd.")
+        assert reg["xenoverse-amd/" + env_id].vector_entry_point == reg[env_id].vector_entry_point
+    assert reg["mazeworld-v2"].kwargs["resolution"] == (256, 256)
+    assert registration.register_with_gymnasium() is True and len(reg) == 10     # idempotent

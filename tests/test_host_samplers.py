@@ -52,6 +52,40 @@ def test_maze_task_schema_and_determinism():
     assert tab["NG"] == 15 and tab["walls"].shape == (2, 15, 15) and np.all(tab["walls"][1, 9:, :] == 1)
 
 
+def test_seeded_maze_sampler_reproduces_reference_tasks():
+    """MazeTaskSampler(seed=k) equals the reference's task for that seed: the three 15x15 tasks inside the maze fixtures
+    and 24 more over the default size range, with and without loops (tests/golden/sampler_refmazes.npz): topology with
+    its large rooms, textures, landmarks, start, commands, scalars"""
+    import os
+    from util import GOLD, golden_files, load_maze_golden
+    kw = dict(n_wall_textures=8, n_ground_textures=4, n_ceiling_textures=4)
+    for k, p in enumerate(golden_files("maze_")):
+        g, ref = load_maze_golden(p)
+        t = MazeTaskSampler(n_range=(15, 16), seed=k, **kw)
+        for key in ("cell_walls", "cell_texts", "commands_sequence", "cell_landmarks"):
+            assert np.array_equal(np.asarray(t[key]), np.asarray(ref[key])), (k, key)
+        for key in ("cell_size", "wall_height", "agent_height", "fol_angle", "goal_reward", "ground_text", "ceiling_text"):
+            assert float(t[key]) == float(ref[key]), (k, key)
+        assert tuple(t["start"]) == tuple(ref["start"])
+        assert [tuple(x) for x in t["landmarks_coordinates"]] == [tuple(x) for x in ref["landmarks_coordinates"]]
+    g = np.load(os.path.join(GOLD, "sampler_refmazes.npz"))
+    rooms = 0
+    for k, seed in enumerate(g["seed"]):
+        t = MazeTaskSampler(seed=int(seed), allow_loops=bool(g["allow_loops"][k]), commands_sequence=32, **kw)
+        n = int(g["n"][k])
+        assert t["cell_walls"].shape == (n, n)
+        assert np.array_equal(t["cell_walls"], g["cell_walls"][k][:n, :n]), seed
+        assert np.array_equal(t["cell_texts"], g["cell_texts"][k][:n, :n]) and np.array_equal(t["cell_landmarks"], g["cell_landmarks"][k][:n, :n])
+        assert tuple(t["start"]) == tuple(g["start"][k]) and np.array_equal(t["commands_sequence"], g["commands"][k])
+        nl = int(g["n_landmarks"][k])
+        assert [tuple(x) for x in t["landmarks_coordinates"]] == [tuple(x) for x in g["landmarks"][k][:nl]]
+        sc = [t["cell_size"], t["wall_height"], t["agent_height"], t["fol_angle"], t["goal_reward"], t["ground_text"], t["ceiling_text"]]
+        assert np.array_equal(np.asarray(sc, np.float64), g["scalars"][k])
+        w = t["cell_walls"]          # a 2x2 block of open cells can only come from a large room (or loops at low density)
+        rooms += int(((w[:-1, :-1] + w[1:, :-1] + w[:-1, 1:] + w[1:, 1:]) == 0).any())
+    assert rooms >= len(g["seed"]) // 2
+
+
 def test_linds_task_schema_all_dims_terminate():
     for dims in ((16, 8, 8), (32, 8, 8), (32, 8, 16), (4, 2, 3)):
         t = LinearDSSampler(*dims, seed=dims[0])

@@ -39,7 +39,7 @@ def test_matches_fp64_equations_per_step_and_termination():
     n = 512
     params = np.stack([rng.uniform(1, 11, n), rng.uniform(0.5, 2, n), rng.uniform(0.05, 0.2, n), rng.uniform(0.25, 1, n)], 1)
     o = oracle.CartPoleOracle(params, np.arange(n), frameskip=1)
-    u0 = rng.random_sample((4, n)).astype(np.float32)
+    u0 = rng.random_sample((4, n))
     o.reset_injected(u0)
     n_term = 0
     for t in range(200):
@@ -47,11 +47,12 @@ def test_matches_fp64_equations_per_step_and_termination():
         before = o.state.astype(np.float64).copy()
         out = o.step_injected(a, rng.random_sample((4, n)), 0)
         for i in range(0, n, 37):
-            s, r, term = gym_cartpole_step_f64(before[:, i], a[i], *params[i].astype(np.float32).astype(np.float64))
-            assert np.allclose(out["obs"][i], s, rtol=1e-5, atol=1e-6)
-            # thresholds: flags equal unless the fp64 value sits within float rounding of the threshold
-            if abs(abs(s[0]) - 2.4) > 1e-5 and abs(abs(s[2]) - 0.20943951) > 1e-6:
-                assert bool(out["terminated"][i]) == term
+            s, r, term = gym_cartpole_step_f64(before[:, i], a[i], *params[i])
+            # the oracle computes in float64 like gymnasium: the state agrees to rounding, the observation is its
+            # float32 cast, the termination flag is the same decision
+            assert np.allclose(o.state[:, i] if not term else s, s, rtol=1e-13, atol=1e-15)
+            assert np.array_equal(out["obs"][i], s.astype(np.float32)) or np.allclose(out["obs"][i], s, rtol=2e-7, atol=1e-9)
+            assert bool(out["terminated"][i]) == term
         done = out["terminated"].astype(bool)
         n_term += int(done.sum())
         if done.any():

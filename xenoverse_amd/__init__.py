@@ -8,3 +8,6 @@ __version__ = "0.1.0"
 
 from ._lib import XenoError, load as load_library  # noqa: F401
 from .engine import Engine  # noqa: F401
+from .registration import make_vec, register_with_gymnasium  # noqa: F401,E402
+
+register_with_gymnasium()      # the reference's ids as vector entry points when gymnasium is importable

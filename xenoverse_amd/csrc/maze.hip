@@ -53,6 +53,7 @@ struct xv_maze {
   MazeArgs a;
   bool filter_f32 = false;   // xv_maze_set_precision
   bool move_lanes9 = true;   // xv_maze_set_move_kernel
+  int move_lanes = 0;        // 0: by batch size; 3 or 9: forced (xv_maze_set_move_kernel)
 };
 
 static const size_t MAZE_LDS_CHUNK_MAX = 50176;   // 256 columns x (64 rows x 3 + 4) bytes: three workgroups per 160-KiB CU
@@ -306,14 +307,18 @@ __global__ __launch_bounds__(256) void maze_step_kernel(MazeArgs P, const void* 
 // the dependent chain per sub-step cut from ~6,000 to a few hundred cycles and 9x the lanes: 16,384 envs are 2,341
 // waves instead of 256.
 // ------------------------------------------------------------------------------------------------
-constexpr int MZ_EPW = 7;      // envs per wave
 constexpr int MZ_SUBMAX = 104;
 
+// L lanes per env (9: one neighbour cell each; 3: one row of three cells each), 64 / L envs per wave.  Which one is
+// faster is a matter of filling the chip: every lane of an env repeats the position arithmetic, so more lanes per env
+// mean more waves issuing the same instructions (xv_maze_step picks L from the batch size).
+template <int L>
 __global__ __launch_bounds__(64) void maze_step9_kernel(MazeArgs P, const void* action, int action_mode, float* reward,
                                                         uint8_t* terminated, uint8_t* truncated, int mode) {
+  constexpr int MZ_EPW = 64 / L, CPL = 9 / L;      // envs per wave, cells per lane
   __shared__ double2 s_d[MZ_EPW + 1][MZ_SUBMAX];
-  __shared__ double2 s_g[64];
-  const int lane = threadIdx.x, q = lane / 9, cell = lane - 9 * q;
+  __shared__ double2 s_g[(MZ_EPW + 1) * 9];
+  const int lane = threadIdx.x, q = lane / L, cell = lane - L * q;   // `cell`: this lane's index within its env
   const int e_raw = blockIdx.x * MZ_EPW + q;
   const bool active = q < MZ_EPW && e_raw < P.n_env;
   const int e = active ? e_raw : P.n_env - 1;     // idle lanes shadow a real env and store nothing
@@ -361,15 +366,24 @@ __global__ __launch_bounds__(64) void maze_step9_kernel(MazeArgs P, const void* 
     double c_dt_full, s_dt_full, c_t = 1.0, s_t = 0.0, ori_k = ori, ori_cached = 0.0;
     bool have = false;
     sincos(0.5 * (turn_rate * t_prec), &s_dt_full, &c_dt_full);
-    for (int it = 0; it < iteration + 1; ++it) {
-      const double rem = delta_t - it * t_prec;
-      const double dt = rem < t_prec ? rem : t_prec;
-      if (dt < 1.0e-8) continue;
-      const double d_theta = turn_rate * dt, arc = walk_speed * dt;
-      if (it % 9 == cell) {
+    // groups of L sub-steps: all lanes walk the recurrence together and each keeps the heading of ITS sub-step of
+    // the group (a select); the expensive part then runs once per group with every lane busy, not once per sub-step
+    for (int base = 0; base < iteration + 1; base += L) {
+      double my_ori = 0.0, my_dt = 0.0;
+      bool mine = false;
+      for (int c = 0; c < L && base + c < iteration + 1; ++c) {
+        const int it = base + c;
+        const double rem = delta_t - it * t_prec;
+        const double dt = rem < t_prec ? rem : t_prec;
+        if (dt < 1.0e-8) continue;
+        if (c == cell) { my_ori = ori_k; my_dt = dt; mine = true; }
+        ori_k = mz_angle_norm(ori_k + turn_rate * dt);
+      }
+      if (mine) {
+        const double d_theta = turn_rate * my_dt, arc = walk_speed * my_dt;
         double c_dt = c_dt_full, s_dt = s_dt_full;
-        if (dt != t_prec) sincos(0.5 * d_theta, &s_dt, &c_dt);
-        if (!have || ori_k != ori_cached) { sincos(ori_k, &s_t, &c_t); ori_cached = ori_k; have = true; }
+        if (my_dt != t_prec) sincos(0.5 * d_theta, &s_dt, &c_dt);
+        if (!have || my_ori != ori_cached) { sincos(my_ori, &s_t, &c_t); ori_cached = my_ori; have = true; }
         double dx, dy;
         if (fabs(d_theta) < 1.0e-8) { dx = c_t * arc; dy = s_t * arc; }
         else {
@@ -377,16 +391,13 @@ __global__ __launch_bounds__(64) void maze_step9_kernel(MazeArgs P, const void* 
           const double c_n = c_t * c_dt - s_t * s_dt, s_n = c_t * s_dt + s_t * c_dt;
           dx = c_n * off; dy = s_n * off;
         }
-        s_d[q][it] = make_double2(dx, dy);
+        s_d[q][base + cell] = make_double2(dx, dy);
       }
-      ori_k = mz_angle_norm(ori_k + d_theta);
     }
     ori = ori_k;
   }
   __syncthreads();
-  // ---- phase 2: positions (sequential), one neighbour cell per lane ----
-  const int ni = cell / 3 - 1, nj = cell - 3 * (cell / 3) - 1;     // the reference's (i, j) loop position
-  const double off_i = (double)(float)(ni + 0.5), off_j = (double)(float)(nj + 0.5);
+  // ---- phase 2: positions (sequential), CPL neighbour cells per lane ----
   for (int it = 0; it < iteration + 1; ++it) {
     const double rem = delta_t - it * t_prec;
     const double dt = rem < t_prec ? rem : t_prec;
@@ -395,26 +406,44 @@ __global__ __launch_bounds__(64) void maze_step9_kernel(MazeArgs P, const void* 
     const double e0 = p0 + d.x, e1 = p1 + d.y;
     const double c0 = mz_div(e0, R_cs), c1 = mz_div(e1, R_cs);
     const int b0 = (int)c0, b1 = (int)c1;
-    const int a = b0 + ni - ci + 2, b = b1 + nj - cj + 2;
-    bool wall;
-    if (a >= 0 && a < 5 && b >= 0 && b < 5) wall = (patch >> (a * 5 + b)) & 1u;
-    else {   // cannot happen for cell_size >= 1 (|move| <= 1); kept exact by falling back to memory
-      const int wi = b0 + ni, wj = b1 + nj;
-      wall = wi > -1 && wi < n && wj > -1 && wj < n && walls[wi * NG + wj] > 0;
+    const double fr0 = c0 - floor(c0), fr1 = c1 - floor(c1);
+    double g0[CPL], g1[CPL];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int idx = cell * CPL + k;                       // the reference's (i, j) loop position
+      const int ni = idx / 3 - 1, nj = idx - 3 * (idx / 3) - 1;
+      const int a = b0 + ni - ci + 2, b = b1 + nj - cj + 2;
+      bool wall;
+      if (a >= 0 && a < 5 && b >= 0 && b < 5) wall = (patch >> (a * 5 + b)) & 1u;
+      else {   // cannot happen for cell_size >= 1 (|move| <= 1); kept exact by falling back to memory
+        const int wi = b0 + ni, wj = b1 + nj;
+        wall = wi > -1 && wi < n && wj > -1 && wj < n && walls[wi * NG + wj] > 0;
+      }
+      g0[k] = 0.0; g1[k] = 0.0;
+      if (wall) {
+        // exact-zero filter: the force vanishes unless the agent is within eff of the wall cell's box — the distance
+        // to the facing edge is at least the Chebyshev distance max(|v0|, |v1|) - 0.5, and the reference returns zero
+        // for eff < distance (dynamics.py:93-94).  The 1e-9 guard keeps the rounding of that distance on the safe
+        // side; inside the band the reference's own arithmetic decides.
+        const double v0 = fr0 - (double)(float)(ni + 0.5), v1 = fr1 - (double)(float)(nj + 0.5);
+        const double cheb = __builtin_fmax(fabs(v0), fabs(v1)) - 0.5;
+        if (!(cheb > eff_cd + 1.0e-9)) mz_collision_force(v0, v1, cell_size, eff_cd, g0[k], g1[k]);
+      }
+      any = any || g0[k] != 0.0 || g1[k] != 0.0;
     }
-    double g0 = 0.0, g1 = 0.0;
-    if (wall) mz_collision_force(c0 - floor(c0) - off_i, c1 - floor(c1) - off_j, cell_size, eff_cd, g0, g1);
     double f0 = 0.0, f1 = 0.0;
-    if (__ballot(g0 != 0.0 || g1 != 0.0) != 0ull) {   // some env of this wave touches a wall: sum in (i, j) order
-      s_g[lane] = make_double2(g0, g1);
+    if (__ballot(any) != 0ull) {   // some env of this wave touches a wall: sum the nine forces in (i, j) order
+      double2* gq = s_g + 9 * q;
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) gq[cell * CPL + k] = make_double2(g0[k], g1[k]);
       __syncthreads();
-      const double2* gq = s_g + 9 * (q < MZ_EPW ? q : 0);
 #pragma unroll
       for (int c = 0; c < 9; ++c) { f0 += gq[c].x; f1 += gq[c].y; }
       __syncthreads();
     }
     p0 = f0 + e0; p1 = f1 + e1;
-    coll += sqrt(f0 * f0 + f1 * f1);
+    if (f0 != 0.0 || f1 != 0.0) coll += sqrt(f0 * f0 + f1 * f1);      // + sqrt(0) = + 0 otherwise
   }
   if (!lead) return;
   P.fin_flag[e] = 0;
@@ -981,8 +1010,10 @@ extern "C" int xv_maze_set_precision(xv_maze* h, int filter) {
 }
 
 extern "C" int xv_maze_set_move_kernel(xv_maze* h, int kernel) {
-  XV_CHECK_ARG(h != nullptr && (kernel == XV_MAZE_MOVE_LANE_PER_ENV || kernel == XV_MAZE_MOVE_NINE_LANES));
-  h->move_lanes9 = kernel == XV_MAZE_MOVE_NINE_LANES;
+  XV_CHECK_ARG(h != nullptr && (kernel == XV_MAZE_MOVE_LANE_PER_ENV || kernel == XV_MAZE_MOVE_NINE_LANES ||
+                                kernel == XV_MAZE_MOVE_THREE_LANES || kernel == XV_MAZE_MOVE_AUTO));
+  h->move_lanes9 = kernel != XV_MAZE_MOVE_LANE_PER_ENV;
+  h->move_lanes = kernel == XV_MAZE_MOVE_NINE_LANES ? 9 : (kernel == XV_MAZE_MOVE_THREE_LANES ? 3 : 0);
   return XV_OK;
 }
 
@@ -1004,8 +1035,13 @@ extern "C" int xv_maze_step(xv_maze* h, const void* action, int action_mode, uin
                             int autoreset_mode) {
   XV_CHECK_ARG(h && action && reward && terminated && truncated);
   XV_CHECK_ARG(action_mode >= 0 && action_mode <= 2 && autoreset_mode >= 0 && autoreset_mode <= 2);
-  if (h->move_lanes9)
-    hipLaunchKernelGGL(maze_step9_kernel, dim3(xv_div_up(h->a.n_env, MZ_EPW)), dim3(64), 0, h->eng->stream, h->a, action,
+  // lanes per env: enough waves to give every SIMD work, no more (the lanes of an env repeat the position arithmetic)
+  const int lanes = h->move_lanes > 0 ? h->move_lanes : ((long long)h->a.n_env * 9 <= 64LL * 1536 ? 9 : 3);
+  if (h->move_lanes9 && lanes == 9)
+    hipLaunchKernelGGL(maze_step9_kernel<9>, dim3(xv_div_up(h->a.n_env, 7)), dim3(64), 0, h->eng->stream, h->a, action,
+                       action_mode, reward, terminated, truncated, autoreset_mode);
+  else if (h->move_lanes9)
+    hipLaunchKernelGGL(maze_step9_kernel<3>, dim3(xv_div_up(h->a.n_env, 21)), dim3(64), 0, h->eng->stream, h->a, action,
                        action_mode, reward, terminated, truncated, autoreset_mode);
   else
     hipLaunchKernelGGL(maze_step_kernel, dim3(xv_div_up(h->a.n_env, 64)), dim3(64), 0, h->eng->stream, h->a, action,

@@ -1,11 +1,13 @@
-"""MazeTaskSampler / Resampler — procedural maze tasks with the reference's signature and dict schema.
+"""MazeTaskSampler / Resampler — procedural maze tasks with the reference's signature, dict schema and random stream.
 
-Reference: xenoverse/mazeworld/envs/task_sampler.py (MazeTaskManager.sample_task :92-177, resample_task
-:179-225) and xenoverse/utils/grid_ops.py (genmaze_by_primwall :74-162).  Same keys, dtypes and value ranges
-(SURVEY.md §8(a) M1, M7).  The topology generator is a re-statement of the idea (odd-lattice rooms joined by a
-randomised Prim spanning tree, then extra walls opened until the wall density target is met when loops are
-allowed); it does NOT reproduce the reference's random stream, so a given seed yields a different — equally
-distributed in kind — maze.  Deterministic given `seed`.
+Reference: xenoverse/mazeworld/envs/task_sampler.py (gentext :14-29, gentargets :34-46, genstart :48-52,
+MazeTaskManager.sample_task :92-177, resample_task :179-225) and xenoverse/utils/grid_ops.py (Rectangle :13-49,
+genmaze_largeroom :49-72, genmaze_by_primwall :74-162).  The sampler is a function of NumPy's legacy stream after
+`numpy.random.seed(seed)`; this module consumes a `RandomState(seed)` in the same order — first a few large rooms dug
+out of the interior, then walls released Prim-style until every open region is connected (and, with loops allowed, until
+the wall density target is met) — so `MazeTaskSampler(seed=k)` returns the reference's maze for that seed, given the
+same texture-library sizes (tests/golden/maze_15_seed*.npz hold three reference-sampled tasks).  The reference reads
+the library sizes from its JPG folder (37 walls / 29 grounds / 21 ceilings); here they are arguments.
 """
 from copy import deepcopy
 
@@ -14,40 +16,104 @@ import numpy as np
 PI = 3.1415926   # the reference's constant (mazeworld/envs/dynamics.py:7)
 
 
-def genmaze(n, rng, allow_loops=True, wall_density=0.30):
-    """int8[n, n], 1 = wall; border all walls; rooms on the odd lattice, all connected"""
-    assert n % 2 == 1 and n >= 7
-    w = np.ones((n, n), np.int8)
-    rooms = [(i, j) for i in range(1, n - 1, 2) for j in range(1, n - 1, 2)]
-    for c in rooms:
-        w[c] = 0
-    # randomised Prim over the room lattice
-    start = rooms[rng.randint(len(rooms))]
-    seen = {start}
-    frontier = []
+def _dig_rooms(n, rng, n_rooms, size_range=(2, 4), tries=5):
+    """genmaze_largeroom: up to `n_rooms` rectangles of 2..4 cells a side placed without touching each other.
+    -> (occupied int8[n, n], walls int8[n, n], rooms [(r0, c0, r1, c1) in interior coordinates])"""
+    m = n - 2
+    occ = np.zeros((m, m), np.int8)
+    rooms = []
+    for _ in range(n_rooms):
+        for _ in range(tries):
+            h = rng.randint(size_range[0], size_range[1] + 1)          # randint, randint: the rectangle's sides
+            w = rng.randint(size_range[0], size_range[1] + 1)
+            # window sums of the occupancy map: a placement is free where its whole window is empty
+            c = np.cumsum(np.cumsum(np.pad(occ.astype(np.int64), ((1, 0), (1, 0))), 0), 1)
+            win = c[h:, w:] - c[:-h, w:] - c[h:, :-w] + c[:-h, :-w]
+            rows, cols = np.where(win < 0.5)
+            if rows.shape[0] == 0:
+                continue
+            k = rng.randint(0, rows.shape[0])                          # randint: which free placement
+            r0, c0 = int(rows[k]), int(cols[k])
+            r1, c1 = r0 + h - 1, c0 + w - 1
+            occ[max(0, r0 - 1):min(m, r1 + 2), max(0, c0 - 1):min(m, c1 + 2)] = 1    # the room and a one-cell margin
+            rooms.append((r0, c0, r1, c1))
+            break
+    walls = np.ones((m, m), np.int8)
+    for r0, c0, r1, c1 in rooms:
+        walls[r0:r1 + 1, c0:c1 + 1] = 0
+    occ_full = np.ones((n, n), np.int8)
+    wall_full = np.ones((n, n), np.int8)
+    occ_full[1:n - 1, 1:n - 1] = occ
+    wall_full[1:n - 1, 1:n - 1] = walls
+    return occ_full, wall_full, rooms
 
-    def push(c):
-        for d in ((2, 0), (-2, 0), (0, 2), (0, -2)):
-            nb = (c[0] + d[0], c[1] + d[1])
-            if 0 < nb[0] < n - 1 and 0 < nb[1] < n - 1 and nb not in seen:
-                frontier.append((c, nb))
-    push(start)
-    while frontier:
-        c, nb = frontier.pop(rng.randint(len(frontier)))
-        if nb in seen:
-            continue
-        w[(c[0] + nb[0]) // 2, (c[1] + nb[1]) // 2] = 0
-        seen.add(nb)
-        push(nb)
-    if allow_loops:   # open further interior walls until the density target is met
-        inner = (n - 2) * (n - 2)
-        cand = [(i, j) for i in range(1, n - 1) for j in range(1, n - 1) if w[i, j] and ((i % 2) != (j % 2))]
-        rng.shuffle(cand)
-        for c in cand:
-            if w[1:-1, 1:-1].sum() <= inner * wall_density:
+
+def genmaze(n, rng, allow_loops=True, wall_density=0.30):
+    """genmaze_by_primwall: int8[n, n], 1 = wall; border all walls.  Regions: every odd-lattice cell outside the rooms'
+    margins and every room; a shuffled pass over the walls releases the first wall that joins two regions (or, once
+    all are joined and loops are allowed, closes a loop / a random one with probability 0.2 per wall looked at); repeat
+    until one region is left and the wall share is at most `wall_density`."""
+    occ, walls, rooms = _dig_rooms(n, rng, rng.randint(0, (n - 2) ** 2 // 16))        # randint: how many rooms
+    for i in range(1, n, 2):
+        for j in range(1, n, 2):
+            if not occ[i, j]:
+                walls[i, j] = 0
+    pending = {}            # interior walls still standing, in row-major insertion order
+    region = {}             # open cell -> region id
+    members = {}            # region id -> cells
+    nxt = 0
+    for i in range(1, n - 1):
+        for j in range(1, n - 1):
+            if walls[i, j]:
+                pending[i, j] = 0
+            elif not occ[i, j]:
+                region[i, j] = nxt
+                members[nxt] = [(i, j)]
+                nxt += 1
+    for r0, c0, r1, c1 in rooms:
+        members[nxt] = []
+        for i in range(r0 + 1, r1 + 2):
+            for j in range(c0 + 1, c1 + 2):
+                region[i, j] = nxt
+                members[nxt].append((i, j))
+        nxt += 1
+    budget = (n - 2) * (n - 2) * wall_density
+    while len(members) > 1 or (allow_loops and np.sum(walls[1:-1, 1:-1]) > budget):
+        order = list(pending.keys())
+        rng.shuffle(order)                                           # shuffle: the pass order
+        keep, losers = -1, {}
+        i = j = 0
+        for i, j in order:
+            keep, losers, seen, most = -1, {}, {}, 1
+            for a, b in ((i - 1, j), (i + 1, j), (i, j - 1), (i, j + 1)):
+                if 0 < a < n and 0 < b < n and walls[a, b] < 1:
+                    rid = region[a, b]
+                    seen[rid] = seen.get(rid, 0) + 1
+                    most = max(most, seen[rid])
+                    if rid < keep or keep < 0:       # the smallest region id survives a merge
+                        if keep >= 0:
+                            losers[keep] = True
+                        keep = rid
+                    elif rid != keep:
+                        losers[rid] = True
+            if losers and most < 2:                  # joins regions without closing a loop
                 break
-            w[c] = 0
-    return w
+            if losers and most > 1 and allow_loops:
+                break
+            if allow_loops and len(members) < 2 and rng.random_sample() < 0.2:       # random(): only once all is joined
+                break
+        if keep < 0:                                 # the wall the pass ended on touches no open cell: next pass
+            continue
+        members[keep].append((i, j))
+        region[i, j] = keep
+        walls[i, j] = 0
+        del pending[i, j]
+        for rid in losers:
+            members[keep].extend(members[rid])
+            for cell in members[rid]:
+                region[cell] = keep
+            del members[rid]
+    return walls
 
 
 def _sample_cmds(rng, n_landmarks, length):

@@ -157,8 +157,10 @@ class MazeWorldVecEnv(VectorEnv):
                 self._obf(self._trunc), infos)
 
     def set_move_kernel(self, kernel):
-        """"nine_lanes" (default) or "lane_per_env": two arrangements of the same move / collision arithmetic"""
-        _lib.check(self.lib.xv_maze_set_move_kernel(self._h, {"lane_per_env": 0, "nine_lanes": 1}[kernel]))
+        """"auto" (default: nine or three lanes per env by batch size), "nine_lanes", "three_lanes" or "lane_per_env":
+        arrangements of the same move / collision arithmetic, identical results"""
+        _lib.check(self.lib.xv_maze_set_move_kernel(self._h, {"lane_per_env": 0, "nine_lanes": 1, "three_lanes": 2,
+                                                              "auto": 3}[kernel]))
 
     def render_frames(self):
         """frames of the current state, without stepping"""

@@ -45,7 +45,7 @@ class CartPoleVecEnv(VectorEnv):
         self.frameskip = int(frameskip)
         rs = list(reset_bounds_scale)
         assert len(rs) == 4, "reset_bounds_scale should be a list of 4 elements"
-        self.reset_bounds_scale = np.asarray(rs, np.float32)
+        self.reset_bounds_scale = np.asarray(rs, np.float64)
         self.max_steps = int(max_steps)
         hi = np.array([4.8, np.finfo(np.float32).max, 0.41887903, np.finfo(np.float32).max], np.float32)
         self._set_spaces(Box(-hi, hi, dtype=np.float32), Discrete(2))
@@ -54,7 +54,7 @@ class CartPoleVecEnv(VectorEnv):
     def set_task(self, tasks, env_task_index=None):
         if isinstance(tasks, dict):
             tasks = [tasks]
-        params = np.array([[t["gravity"], t["masscart"], t["masspole"], t["length"]] for t in tasks], np.float32)
+        params = np.array([[t["gravity"], t["masscart"], t["masspole"], t["length"]] for t in tasks], np.float64)
         d = self.device
         n_task = len(tasks)
         if env_task_index is None:
@@ -98,7 +98,7 @@ class CartPoleVecEnv(VectorEnv):
 
     def reset_injected(self, u, mask=None):
         self._require_task()
-        u = self._dev(u, torch.float32)
+        u = self._dev(u, torch.float64)
         m = None if mask is None else self._dev(mask, torch.uint8)
         self._detach("_obs")
         _lib.check(self.lib.xv_cartpole_reset_injected(self._h, _lib.ptr(m), _lib.ptr(u), _lib.ptr(self._obs)))
@@ -126,7 +126,7 @@ class CartPoleVecEnv(VectorEnv):
 
     def step_injected(self, actions, u_reset):
         a = self._dev(actions, torch.int32)
-        u = self._dev(u_reset, torch.float32)
+        u = self._dev(u_reset, torch.float64)
         self._renew("_obs", "_reward", "_term", "_trunc", "_fobs")
         _lib.check(self.lib.xv_cartpole_step_injected(self._h, _lib.ptr(a), _lib.ptr(u), _lib.ptr(self._obs),
                                                       _lib.ptr(self._reward), _lib.ptr(self._term),
@@ -136,14 +136,14 @@ class CartPoleVecEnv(VectorEnv):
 
     def get_state(self):
         n, d = self.num_envs, self.device
-        s = torch.empty((4, n), dtype=torch.float32, device=d)
+        s = torch.empty((4, n), dtype=torch.float64, device=d)
         st = torch.empty(n, dtype=torch.int32, device=d)
         nr = torch.empty(n, dtype=torch.uint8, device=d)
         _lib.check(self.lib.xv_cartpole_get_state(self._h, _lib.ptr(s), _lib.ptr(st), _lib.ptr(nr)))
         return s, st, nr
 
     def set_state(self, state=None, steps=None, need_reset=None):
-        s = None if state is None else self._dev(state, torch.float32)
+        s = None if state is None else self._dev(state, torch.float64)
         st = None if steps is None else self._dev(steps, torch.int32)
         nr = None if need_reset is None else self._dev(need_reset, torch.uint8)
         _lib.check(self.lib.xv_cartpole_set_state(self._h, _lib.ptr(s), _lib.ptr(st), _lib.ptr(nr)))

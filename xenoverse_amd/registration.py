@@ -26,14 +26,30 @@ def make_vec(env_id, num_envs, **kwargs):
 
 
 def register_with_gymnasium():
-    """no-op when gymnasium is not installed"""
+    """Register the reference's OWN ids (`anymdp-v0`, `linear-dynamics-v0`, `mazeworld-v2`, `random-cartpole-v0`,
+    `random-acrobot-v0`) with gymnasium as VECTOR entry points, so that `gymnasium.make_vec("anymdp-v0", num_envs=N)`
+    builds the batched engine.  An id that is already registered (the reference package imported first: it registers
+    scalar `entry_point`s) keeps its scalar entry point — `gymnasium.make(id)` still builds the reference's env — and
+    gains the vector one.  The same specs are also available as `xenoverse-amd/<id>`.  No-op (False) without gymnasium."""
     try:
-        from gymnasium.envs.registration import register
+        from gymnasium.envs.registration import register, registry
     except Exception:
         return False
     for env_id, (entry, defaults) in REGISTRY.items():
-        try:
-            register(id="xenoverse-amd/" + env_id, vector_entry_point=entry, kwargs=defaults)
-        except Exception:
-            pass
+        scalar = None
+        old = registry.get(env_id) if hasattr(registry, "get") else None
+        if old is not None:
+            if getattr(old, "vector_entry_point", None) == entry:
+                continue
+            scalar = getattr(old, "entry_point", None)
+        for name, kw in ((env_id, dict(entry_point=scalar) if scalar is not None else {}), ("xenoverse-amd/" + env_id, {})):
+            try:
+                if name in registry and name != env_id:
+                    continue
+                if name == env_id and old is not None:
+                    registry.pop(env_id, None)
+                register(id=name, vector_entry_point=entry, kwargs=dict(defaults), order_enforce=False,
+                         disable_env_checker=True, **kw)
+            except Exception:
+                pass
     return True

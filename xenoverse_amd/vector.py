@@ -8,7 +8,13 @@ from .engine import AUTORESET, Engine
 from .spaces import batch_space
 
 
-class VectorEnv(object):
+try:      # gymnasium >= 1.0 present: be a gymnasium.vector.VectorEnv (isinstance checks of wrappers / trainers hold)
+    from gymnasium.vector import VectorEnv as _GymVectorEnv
+except Exception:      # not installed: the same surface on a plain class
+    _GymVectorEnv = object
+
+
+class VectorEnv(_GymVectorEnv):
     metadata = {"autoreset_mode": "same_step"}
     render_mode = None
     spec = None
