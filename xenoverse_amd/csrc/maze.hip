@@ -138,6 +138,35 @@ __device__ __forceinline__ void mz_collision_force(double v0, double v1, double 
   f0 = s * o0; f1 = s * o1;
 }
 
+// mz_collision_force for a point already known to lie within eff (+1e-9) of the wall cell's box in Chebyshev
+// distance.  Outside the box the reference's first test, |v| > 0.708 + eff -> 0, cannot fire there and change a result:
+// a point within eff of the box is at most sqrt(0.5) + eff < 0.708 + eff from its centre, and farther points already get
+// zero from the edge test — so |v| (a square root nothing else uses) is not formed.  Same values otherwise.
+__device__ __forceinline__ void mz_collision_force_near(double v0, double v1, double cell_size, double eff, double& f0,
+                                                        double& f1) {
+  f0 = 0.0; f1 = 0.0;
+  if (fabs(v0) < 0.5 && fabs(v1) < 0.5) {
+    const double dist = sqrt(v0 * v0 + v1 * v1);
+    if (dist > 0.708 + eff) return;
+    const double s = 0.50 / (dist > 1.0e-6 ? dist : 1.0e-6) * (0.708 + eff - dist) * cell_size;
+    f0 = s * v0; f1 = s * v1;
+    return;
+  }
+  const bool x_pos = v0 + v1 > 0, y_pos = v1 - v0 > 0;
+  double n0, n1, d;
+  if (x_pos && y_pos) d = mz_nearest_point(v0, v1, 0.5, 0.5, -0.5, 0.5, n0, n1);
+  else if (!x_pos && y_pos) d = mz_nearest_point(v0, v1, -0.5, 0.5, -0.5, -0.5, n0, n1);
+  else if (!x_pos && !y_pos) d = mz_nearest_point(v0, v1, -0.5, -0.5, 0.5, -0.5, n0, n1);
+  else d = mz_nearest_point(v0, v1, 0.5, -0.5, 0.5, 0.5, n0, n1);
+  if (eff < d) return;
+  double o0 = v0 - n0, o1 = v1 - n1;
+  const double on = sqrt(o0 * o0 + o1 * o1);
+  const double inv = 1.0 / (on > 1.0e-6 ? on : 1.0e-6);
+  o0 *= inv; o1 *= inv;
+  const double s = 0.50 * (eff - d) * cell_size;
+  f0 = s * o0; f1 = s * o1;
+}
+
 __device__ __forceinline__ void mz_reset_env(const MazeArgs& P, int e, int t) {   // maze_base.py:83-105
   const int32_t* in = P.T.ints + (size_t)t * 8;
   const double cs = P.T.dbl[(size_t)t * 8];
@@ -349,13 +378,24 @@ __global__ __launch_bounds__(64) void maze_step9_kernel(MazeArgs P, const void* 
   const int ci = (int)(p0 / cell_size), cj = (int)(p1 / cell_size);
   const int8_t* walls = P.T.walls + (size_t)t * NG * NG;
   uint32_t patch = 0;
+  {   // all 25 bytes requested at once from clamped addresses (a branch per cell would be 25 dependent round trips)
+    int8_t wv[25];
 #pragma unroll
-  for (int a = 0; a < 5; ++a)
+    for (int a = 0; a < 5; ++a)
 #pragma unroll
-    for (int b = 0; b < 5; ++b) {
-      const int wi = ci + a - 2, wj = cj + b - 2;
-      if (wi > -1 && wi < n && wj > -1 && wj < n && walls[wi * NG + wj] > 0) patch |= 1u << (a * 5 + b);
-    }
+      for (int b = 0; b < 5; ++b) {
+        const int wi = ci + a - 2, wj = cj + b - 2;
+        const int ri = wi < 0 ? 0 : (wi >= NG ? NG - 1 : wi), rj = wj < 0 ? 0 : (wj >= NG ? NG - 1 : wj);
+        wv[a * 5 + b] = walls[ri * NG + rj];
+      }
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        const int wi = ci + a - 2, wj = cj + b - 2;
+        if (wi > -1 && wi < n && wj > -1 && wj < n && wv[a * 5 + b] > 0) patch |= 1u << (a * 5 + b);
+      }
+  }
   const double t_prec = 0.01, delta_t = 1.0;
   const int iteration = (int)(delta_t / t_prec);
   const MzDivisor R_cs = mz_divisor(cell_size);
@@ -428,7 +468,7 @@ __global__ __launch_bounds__(64) void maze_step9_kernel(MazeArgs P, const void* 
         // side; inside the band the reference's own arithmetic decides.
         const double v0 = fr0 - (double)(float)(ni + 0.5), v1 = fr1 - (double)(float)(nj + 0.5);
         const double cheb = __builtin_fmax(fabs(v0), fabs(v1)) - 0.5;
-        if (!(cheb > eff_cd + 1.0e-9)) mz_collision_force(v0, v1, cell_size, eff_cd, g0[k], g1[k]);
+        if (!(cheb > eff_cd + 1.0e-9)) mz_collision_force_near(v0, v1, cell_size, eff_cd, g0[k], g1[k]);
       }
       any = any || g0[k] != 0.0 || g1[k] != 0.0;
     }
@@ -1036,7 +1076,8 @@ extern "C" int xv_maze_step(xv_maze* h, const void* action, int action_mode, uin
   XV_CHECK_ARG(h && action && reward && terminated && truncated);
   XV_CHECK_ARG(action_mode >= 0 && action_mode <= 2 && autoreset_mode >= 0 && autoreset_mode <= 2);
   // lanes per env: enough waves to give every SIMD work, no more (the lanes of an env repeat the position arithmetic)
-  const int lanes = h->move_lanes > 0 ? h->move_lanes : ((long long)h->a.n_env * 9 <= 64LL * 1536 ? 9 : 3);
+  // (measured at 16,384 envs: 169 us with nine lanes, 225 us with three, 269 us with the lane-per-env kernel)
+  const int lanes = h->move_lanes > 0 ? h->move_lanes : (h->a.n_env <= 32768 ? 9 : 3);
   if (h->move_lanes9 && lanes == 9)
     hipLaunchKernelGGL(maze_step9_kernel<9>, dim3(xv_div_up(h->a.n_env, 7)), dim3(64), 0, h->eng->stream, h->a, action,
                        action_mode, reward, terminated, truncated, autoreset_mode);
