@@ -452,6 +452,40 @@ def gen_maze_sampled(n_tasks=24, seed0=10):
     print("sampler_refmazes.npz", os.path.getsize(path) // 1024, "KiB")
 
 
+def gen_linds_sampled():
+    """Tasks of the reference's LinearDSSampler with its seeding function pinned: the reference seeds NumPy with
+    timestamp + system random + seed (utils/random_nn.py:9-16, non-reproducible), so for the fixture pseudo_random_seed
+    is replaced by `numpy.random.seed(seed)` — the sampler's own code then runs on a known stream."""
+    _, ts = _refimport.linds()
+    ts.pseudo_random_seed = lambda seed=0: np.random.seed(seed)
+    out = {k: [] for k in ("seed", "dims", "max_steps", "A", "B", "C", "X", "Y", "scal", "valid", "is_dyn", "n_init", "init",
+                           "noise_drift", "delay", "cmd", "four_n", "four_orders", "four_coeffs")}
+    cases = [(16, 8, 8, s) for s in range(10)] + [(8, 4, 4, 20), (8, 4, 4, 21), (4, 2, 3, 30), (16, 8, 8, 77)]
+    for ns, na, no, seed in cases:
+        t = ts.LinearDSSampler(ns, na, no, seed=seed)
+        pad2 = lambda a, r, c: np.pad(np.asarray(a, np.float64), ((0, r - np.shape(a)[0]), (0, c - np.shape(a)[1])))
+        pad1 = lambda a, n: np.pad(np.asarray(a, np.float64), (0, n - len(a)))
+        out["seed"].append(seed); out["dims"].append([ns, na, no]); out["max_steps"].append(t["max_steps"])
+        out["A"].append(pad2(t["ld_A"], 16, 16)); out["B"].append(pad2(t["ld_B"], 16, 8)); out["C"].append(pad2(t["ld_C"], 16, 16))
+        out["X"].append(pad1(t["ld_X"], 16)); out["Y"].append(pad1(t["ld_Y"], 16))
+        out["scal"].append([t["action_cost"], t["reward_base"], t["terminate_punish"], t["reward_factor"]])
+        out["valid"].append(pad1(t["target_valid"], 16)); dyn = t["target_type"] == "dynamic_target"
+        out["is_dyn"].append(dyn); out["n_init"].append(len(t["initial_states"]))
+        init = np.zeros((8, 16)); init[:len(t["initial_states"]), :ns] = np.asarray(t["initial_states"])[:8]
+        out["init"].append(init); out["noise_drift"].append(t["noise_drift"]); out["delay"].append(t["target_delay"])
+        cmd = np.zeros(16); orders = np.zeros(6); coeffs = np.zeros((6, 16, 2)); n_terms = 0
+        if dyn:
+            n_terms = len(t["command"].coeffs)
+            for k, (o, c) in enumerate(t["command"].coeffs):
+                orders[k] = o; coeffs[k, :no] = c
+        else:
+            cmd[:no] = t["command"]
+        out["cmd"].append(cmd); out["four_n"].append(n_terms); out["four_orders"].append(orders); out["four_coeffs"].append(coeffs)
+    path = os.path.join(GOLD, "sampler_reflinds.npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in out.items()})
+    print("sampler_reflinds.npz", os.path.getsize(path) // 1024, "KiB")
+
+
 def gen_acrobot():
     """The reference's OWN Acrobot code: RandomAcrobotEnv._dsdt and ._terminal (random_acrobot.py:58-101), called on
     random inputs with tasks drawn over sample_acrobot's ranges, and the reset-state formula (:123-125).  The
@@ -586,7 +620,8 @@ def gen_anymdp_sampled(n=32, seed0=100):
 
 
 FAMILIES = {"anymdp": gen_anymdp, "linds": gen_linds, "maze": gen_maze, "acrobot": gen_acrobot, "garnet": gen_garnet,
-            "anymdp_vi": gen_anymdp_vi, "anymdp_sampled": gen_anymdp_sampled, "maze_sampled": gen_maze_sampled}
+            "anymdp_vi": gen_anymdp_vi, "anymdp_sampled": gen_anymdp_sampled, "maze_sampled": gen_maze_sampled,
+            "linds_sampled": gen_linds_sampled}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

@@ -86,6 +86,34 @@ def test_seeded_maze_sampler_reproduces_reference_tasks():
     assert rooms >= len(g["seed"]) // 2
 
 
+def test_linds_sampler_follows_the_reference_stream():
+    """tests/golden/sampler_reflinds.npz: 14 tasks of the reference's LinearDSSampler with its (timestamp-based) seeding
+    function pinned to numpy.random.seed(seed) — LinearDSSampler(seed=k) consumes a RandomState(k) in the same order and
+    returns the same task, including the cases where the rejection loop ran for dozens of draws"""
+    import os
+    from util import GOLD
+    g = np.load(os.path.join(GOLD, "sampler_reflinds.npz"))
+    for k, seed in enumerate(g["seed"]):
+        ns, na, no = [int(x) for x in g["dims"][k]]
+        t = LinearDSSampler(ns, na, no, seed=int(seed))
+        assert t["max_steps"] == g["max_steps"][k]
+        assert np.array_equal(t["ld_A"], g["A"][k][:ns, :ns]) and np.array_equal(t["ld_B"], g["B"][k][:ns, :na])
+        assert np.array_equal(t["ld_C"], g["C"][k][:no, :ns]) and np.array_equal(t["ld_X"], g["X"][k][:ns])
+        assert np.array_equal(t["ld_Y"], g["Y"][k][:no])
+        assert np.array_equal([t["action_cost"], t["reward_base"], t["terminate_punish"], t["reward_factor"]], g["scal"][k])
+        assert np.array_equal(t["target_valid"], g["valid"][k][:no])
+        assert (t["target_type"] == "dynamic_target") == bool(g["is_dyn"][k])
+        n0 = int(g["n_init"][k])
+        assert len(t["initial_states"]) == n0 and np.array_equal(np.asarray(t["initial_states"])[:8], g["init"][k][:min(8, n0), :ns])
+        assert float(t["noise_drift"]) == g["noise_drift"][k] and t["target_delay"] == g["delay"][k]
+        if g["is_dyn"][k]:
+            assert len(t["command"].coeffs) == g["four_n"][k]
+            for i, (o, c) in enumerate(t["command"].coeffs):
+                assert float(o) == g["four_orders"][k][i] and np.array_equal(c, g["four_coeffs"][k][i][:no])
+        else:
+            assert np.array_equal(t["command"], g["cmd"][k][:no])
+
+
 def test_linds_task_schema_all_dims_terminate():
     for dims in ((16, 8, 8), (32, 8, 8), (32, 8, 16), (4, 2, 3)):
         t = LinearDSSampler(*dims, seed=dims[0])

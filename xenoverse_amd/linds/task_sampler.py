@@ -1,11 +1,16 @@
-"""LinearDSSampler / LinearDSSamplerRandomDim — randomised LTI control tasks with the reference's signature and
-dict schema (xenoverse/linds/task_sampler.py:60-154, building blocks :12-58; RandomFourier
+"""LinearDSSampler / LinearDSSamplerRandomDim — randomised LTI control tasks with the reference's signature, dict schema
+and draw order (xenoverse/linds/task_sampler.py:60-154, building blocks :12-58; RandomFourier
 xenoverse/utils/random_nn.py:346-368; weights_and_biases :45-53).
 
-The reference sampler is not reproducible even with a seed (pseudo_random_seed adds the seed to a nanosecond
-timestamp, utils/random_nn.py:9-16); this one is deterministic given `seed`.  One documented deviation: the
-reference's initial-state rejection loop (:108-132) accepts with probability ~5e-4 at state_dim=32 and never
-returns in practice; here initial states that fail the test are shrunk toward the origin until
+The reference seeds NumPy with `timestamp + system random + seed` (pseudo_random_seed, utils/random_nn.py:9-16), so its
+sampler is not reproducible even with a seed.  What IS fixed is the function from NumPy's stream to the task; this
+module consumes a `RandomState(seed)` in the reference's order, so `LinearDSSampler(16, 8, 8, seed=k)` equals what the
+reference returns when its generator is in the state `numpy.random.seed(k)` leaves it in
+(tests/golden/sampler_reflinds.npz, written with the reference's seeding function pinned to exactly that).
+One documented deviation: the reference's initial-state rejection loop (:108-132) has no bound; its acceptance
+probability depends on the task (a few per cent for some (16, 8, 8) tasks, ~5e-4 at state_dim = 32, ~0 at (32, 8, 16),
+SURVEY.md §7), so there it can run for minutes or forever.  Here the loop follows the reference for up to 20,000
+draws (tens of microseconds each); only then are the initial states of the last draw shrunk toward the origin until
 they pass, so the sampler terminates for every dimension.
 """
 import numpy as np
@@ -44,7 +49,7 @@ def _sample_variants(rng, ns, na, no):
     A = AB[:, :ns] * rng.choice([0.01, 0.02, 0.05, 0.1, 0.2])
     B = AB[:, ns:]
     X = X * rng.choice([0.0, 0.05, 0.1])
-    trim = rng.randint(3)
+    trim = int(rng.choice(3))          # choice over the three trimming rules (:52-53)
     if trim == 0:      # banded
         width = rng.randint(2, max(ns // 2, 3) + 1)
         if width < ns:
@@ -56,6 +61,9 @@ def _sample_variants(rng, ns, na, no):
             i, j = np.indices((ns, ns))
             A = np.where(j < i + width, 0.0, A)
     return A, B, C, X, Y
+
+
+MAX_DRAWS = 20000      # rejected (initial states, command) draws before the shrinking fallback
 
 
 def LinearDSSampler(state_dim=16, action_dim=8, observation_dim=8, seed=None, verbose=False):
@@ -78,29 +86,28 @@ def LinearDSSampler(state_dim=16, action_dim=8, observation_dim=8, seed=None, ve
         tv = rng.binomial(1, eps, size=(observation_dim,))
     task["target_valid"] = tv
     task["target_type"] = str(rng.choice(["dynamic_target", "dynamic_target", "static_target"]))
-    task["noise_drift"] = float(np.clip(rng.uniform(-0.02, 0.02), 0.0, 0.02))
 
     def close_enough(x0, cmd):
-        return np.linalg.norm((cmd - C @ x0 - Y) * tv) <= 3.0 and np.linalg.norm(x0) <= 10.0
+        return not (np.linalg.norm((cmd - C @ x0 - Y) * tv) > 3.0 or np.linalg.norm(x0) > 10.0)
 
-    for attempt in range(256):   # the reference re-draws command AND initial states until all pass (:108-132)
-        born_loc = int(max(rng.exponential(scale=1.0), 1))
+    for attempt in range(MAX_DRAWS + 1):   # the reference re-draws everything below until all initial states pass
+        born_loc = int(max(rng.exponential(scale=1.0), 1))                 # exponential: how many initial states
+        states = [rng.randn(state_dim) for _ in range(born_loc)]          # randn(ns) each
+        task["noise_drift"] = np.clip(rng.uniform(-0.02, 0.02), 0.0, 0.02)   # uniform
         if task["target_type"] == "static_target":
-            task["command"] = rng.randn(observation_dim) * rng.choice([0, 1])
+            task["command"] = rng.randn(observation_dim) * rng.choice([0, 1])   # randn(no), choice
             task["target_delay"] = 0
             cmd = task["command"]
         else:
             task["command"] = RandomFourier(observation_dim, rng=rng)
-            task["target_delay"] = max(int(rng.randint(-10, 30)), 0)
+            task["target_delay"] = max(rng.randint(-10, 30), 0)                  # randint
             cmd = task["command"](-task["target_delay"])
-        states = []
-        for _ in range(born_loc):
-            x0 = rng.randn(state_dim)
-            for _ in range(24):   # shrink toward the origin instead of rejecting forever (module docstring)
-                if close_enough(x0, cmd):
-                    break
-                x0 = 0.7 * x0
-            states.append(x0)
+        if attempt >= MAX_DRAWS:     # the deviation: shrink toward the origin instead of rejecting forever
+            for k in range(len(states)):
+                for _ in range(24):
+                    if close_enough(states[k], cmd):
+                        break
+                    states[k] = 0.7 * states[k]
         if all(close_enough(x0, cmd) for x0 in states):
             break
     else:   # last resort: start on the least-squares pre-image of the command
