@@ -360,6 +360,13 @@ int xv_linds_step(xv_linds* h, const float* action, float* obs, float* reward, u
 int xv_linds_step_injected(xv_linds* h, const float* action, const float* z, const int32_t* init_index,
                            float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, float* cmd,
                            float* error, float* final_obs, int autoreset_mode);
+/* Fused roll-out: T steps in one launch (SAME_STEP auto-reset, free-running noise), the state resident in registers
+ * between the steps; equals T calls of xv_linds_step bit for bit (step t draws with the tick the t-th call would use).
+ * action float[T][n_env][NA]; obs float[T][n_env][NO], reward float[T][n_env], terminated / truncated uint8[T][n_env];
+ * cmd, error, final_obs as in xv_linds_step with a leading T, nullable.  The reference counterpart is the loop its
+ * users write around step() (linds/test.py). */
+int xv_linds_rollout(xv_linds* h, int T, const float* action, float* obs, float* reward, uint8_t* terminated,
+                     uint8_t* truncated, float* cmd, float* error, float* final_obs);
 /* env.state accessor (:185-187): x float[NS][n_env], steps int32[n_env], need_reset uint8[n_env]; nullable */
 int xv_linds_get_state(xv_linds* h, float* x, int32_t* steps, uint8_t* need_reset);
 int xv_linds_set_state(xv_linds* h, const float* x, const int32_t* steps, const uint8_t* need_reset);

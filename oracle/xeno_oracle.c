@@ -329,9 +329,11 @@ void xo_anymdp_synth(uint64_t seed, int64_t task_index_base, int n_task, int S, 
  * The reference computes in fp64; the device computes in fp32 (north_star: float dynamics within 1e-5 rel)
  * with every product-sum spelled as an fmaf chain in a FIXED order, restated here operation for operation so
  * that device-vs-oracle is bit-exact on the state/observation path:
- *   x'_j = fmaf chain over k = 0..NS-1 of Phi[j][k]*x[k], continued over k = 0..NA-1 of Gamma[j][k]*act[k],
+ *   x'_j = fmaf chain over k in xo_linds_yorder() of Phi[j][k]*x[k], continued over k = 0..NA-1 of Gamma[j][k]*act[k],
  *          then + Xt[j], then fmaf(noise_scale, z_j, .)
  *   y_j  = fmaf chain over k in xo_linds_yorder() of C[j][k]*x'[k], then + Y[j]
+ * (both products visit the state components in the order in which the device's matrix instructions find them in its
+ *  accumulator registers, so that a state never has to be re-arranged between steps: see xo_linds_yorder)
  * ---------------------------------------------------------------------------------------------- */
 int xo_linds_yorder(int NS, int* ord) {
   /* the device forms y = C x' with 16x16x4 matrix instructions fed straight from the accumulators of x': M-tile m,
@@ -437,9 +439,11 @@ static void linds_step_one(xo_linds* h, int i, const float* a_raw, const float* 
     sa = fmaf(a, a, sa);
     act[k] = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);
   }
+  int kord[32];
+  const int n_ord = xo_linds_yorder(NS, kord);
   for (int j = 0; j < NS; ++j) { /* :78-80 */
     float acc = 0.0f;
-    for (int k = 0; k < NS; ++k) acc = fmaf(h->phiT[((size_t)t * NS + k) * NS + j], xs[k], acc);
+    for (int p = 0; p < n_ord; ++p) acc = fmaf(h->phiT[((size_t)t * NS + kord[p]) * NS + j], xs[kord[p]], acc);
     for (int k = 0; k < NA; ++k) acc = fmaf(h->gamT[((size_t)t * NA + k) * NS + j], act[k], acc);
     acc = acc + h->xt[(size_t)t * NS + j];
     xn[j] = fmaf(sc[4], z[j], acc);

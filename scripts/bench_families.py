@@ -58,9 +58,17 @@ def bench_linds(args):
                                              _lib.ptr(env._error), _lib.ptr(env._fobs), AUTORESET["same_step"]))
         us = timed(step, args.steps, args.warmup)
         out[path] = us
+        if path == "mfma":      # fused roll-out: T steps per launch, state resident in registers
+            T = 64
+            aT = torch.rand((T, n, 8), device=env.device) * 2 - 1
+            ro = env.rollout(aT)
+
+            def roll():
+                env.rollout(aT, out=ro)
+            out["rollout_T64_per_step"] = timed(roll, max(args.steps // T, 5), 2) / T
         env.close()
     algo = 432 * n
-    best = min(out.values())
+    best = min(out["mfma"], out["scalar"])
     return {"family": "linds", "workload": "ns=32 na=8 no=8 (pads 16/8/16), 65,536 envs = 1,024 tasks x 64",
             "env_steps_per_s": n / (best * 1e-6), "us_per_step": out, "dtype": "f32",
             "roofline": {"bound": "hbm", "achieved": algo / (best * 1e-6) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",

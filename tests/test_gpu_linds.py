@@ -264,3 +264,72 @@ def test_state_accessors_under_the_slot_layout():
         x, st, nr = env.get_state()
         assert np.array_equal(_np(x), ora.x) and np.array_equal(_np(st), ora.steps)
     env.close()
+
+
+@pytest.mark.parametrize("layout", ["grouped64", "mixed_dims", "scattered"])
+def test_fused_rollout_equals_single_steps(layout):
+    """xv_linds_rollout: T steps in one launch (state resident in registers) = T calls of xv_linds_step, bit for bit,
+    through episode ends (short max_steps -> SAME_STEP resets inside the launch) and under the slot layout"""
+    if layout == "mixed_dims":
+        files = FILES[:2] + [f for f in FILES if "32x8x8" in f][:1]
+    else:
+        files = FILES[:4]
+    tasks = []
+    for f in files:
+        t = load_linds_golden(f)[1]
+        t["max_steps"] = 23
+        tasks.append(t)
+    if layout == "scattered":
+        env_task = np.random.RandomState(2).randint(0, len(tasks), 1000).astype(np.int32)
+    else:
+        env_task = np.repeat(np.arange(len(tasks), dtype=np.int32), 64)
+    n, T = len(env_task), 70
+    acts = np.random.RandomState(3).uniform(-1.3, 1.3, (T, n, 8)).astype(np.float32)
+    recs = []
+    for fused in (False, True):
+        env = LinDSVecEnv(n, autoreset_mode="same_step", seed=77, env_id_base=123)
+        env.set_task(tasks, env_task_index=env_task)
+        env.reset()
+        if fused:
+            a = env.rollout(acts[:30])
+            b = env.rollout(acts[30:])          # a second launch continues where the first stopped
+            rec = {k: np.concatenate([_np(a[k]), _np(b[k])]) for k in a}
+        else:
+            rows = []
+            for t in range(T):
+                o, r, te, tr, info = env.step(acts[t])
+                rows.append(dict(obs=_np(o), reward=_np(r), terminated=_np(te).astype(np.uint8),
+                                 truncated=_np(tr).astype(np.uint8), command=_np(info["command"]),
+                                 error=_np(info["error"]), final_obs=_np(info["final_obs"])))
+            rec = {k: np.stack([row[k] for row in rows]) for k in rows[0]}
+        x, st, nr = env.get_state()
+        rec.update(x=_np(x), steps=_np(st), tick=np.int64(env.engine.tick))
+        recs.append(rec)
+        env.close()
+    assert recs[0]["truncated"].sum() > 0
+    for k in recs[0]:
+        a, b = recs[0][k], recs[1][k]
+        if k in ("obs", "command", "final_obs"):
+            b = b[..., :a.shape[-1]]
+        assert np.array_equal(a, b), k
+
+
+def test_fused_rollout_vs_oracle():
+    tasks, tab, env_task = _batch(64, FILES[:3])
+    n, T = len(env_task), 25
+    seed, base = 4242, 900
+    env = LinDSVecEnv(n, autoreset_mode="same_step", seed=seed, env_id_base=base)
+    env.set_task(tasks, env_task_index=env_task)
+    ora = oracle.LinDSOracle(tab, env_task)
+    tick = env.engine.tick
+    env.reset(); ora.reset(seed, base, tick)
+    x, st, _ = env.get_state()
+    ora.x[:] = _np(x)
+    acts = np.random.RandomState(8).uniform(-1, 1, (T, n, 8)).astype(np.float32)
+    tick = env.engine.tick
+    out = env.rollout(acts)
+    for t in range(T):
+        o = ora.step(seed, base, tick + t, acts[t], 2)
+        assert close_rel(_np(out["obs"][t]), o["obs"], 2e-4, 2e-5), t     # noise tolerance compounds over T (no re-sync)
+        assert np.array_equal(_np(out["truncated"][t]), o["truncated"])
+    env.close()

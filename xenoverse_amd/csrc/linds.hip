@@ -3,9 +3,11 @@
 // Reproduces xenoverse/linds/linds_env.py: dynamics :78-80, get_observation :83-91, get_inner_cmd :93-98,
 // reset :108-131, step :133-169, and RandomFourier.__call__ (utils/random_nn.py:362-368), for N envs per
 // launch in fp32.  Operation order is fixed and restated by oracle/xeno_oracle.c (xo_linds_*):
-//   x'_j = fmaf chain over k=0..NS-1 of Phi[j][k] x[k], then k=0..NA-1 of Gamma[j][k] act[k], + Xt[j],
-//          then fmaf(noise_scale, z_j, .)
-//   y_j  = fmaf chain of C[j][k] x'[k] over k in the MFMA accumulator order (linds_yorder), + Y[j]
+//   x'_j = fmaf chain of Phi[j][k] x[k] over k in the MFMA accumulator order (linds_yorder), then k=0..NA-1 of
+//          Gamma[j][k] act[k], + Xt[j], then fmaf(noise_scale, z_j, .)
+//   y_j  = fmaf chain of C[j][k] x'[k] over k in the same order, + Y[j]
+// (the accumulator order for BOTH products: the new state comes out of the matrix unit in exactly the registers the
+//  next state product reads its operands from, so a fused multi-step kernel never re-arranges a state)
 //
 // One lane owns one env: its state vector lives in registers (component-major global layout, so the NS loads
 // and stores of a wave are NS coalesced 256-B streams).  The task matrices are NOT read per lane: inside a
@@ -301,12 +303,15 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
         const XV_CONST_AS float* gamT = xv_cptr(P.T.gamT) + (size_t)tu * NA * NS;
         const XV_CONST_AS float* xtv = xv_cptr(P.T.xt) + (size_t)tu * NS;
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {   // :78-80, Phi x
+        for (int p = 0; p < 32; ++p) {   // :78-80, Phi x, k in linds_yorder
+          const int k = linds_yorder_at(p);
+          if (k < NS) {
 #pragma unroll
-          for (int j = 0; j < NS; ++j) xn[j] = fmaf(phiT[k * NS + j], xs[k], xn[j]);
-          // without this hipcc hoists all ~160 s_load_dwordx16 of the three products to the top and spills
-          // ~2,500 SGPRs into VGPR lanes (v_writelane/v_readlane dominate the kernel)
-          __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < NS; ++j) xn[j] = fmaf(phiT[k * NS + j], xs[k], xn[j]);
+            // without this hipcc hoists all ~160 s_load_dwordx16 of the three products to the top and spills
+            // ~2,500 SGPRs into VGPR lanes (v_writelane/v_readlane dominate the kernel)
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
 #pragma unroll
         for (int k = 0; k < NA; ++k) {   // + Gamma act
@@ -430,14 +435,15 @@ __global__ __launch_bounds__(256) void linds_reset_kernel(LinDSArgs P, const uin
 //   (probed on gfx950, scripts/devtools/mfma16_probe.hip: the four k-products are added to the accumulator as an
 //   ascending fmaf chain — bit for bit the chains of the scalar kernel and of the oracle).
 //
-//   x'^T = Phi X^T + Gamma A^T, rows in M-tiles of 16:  D_m[j = 16 m + row][env]:
-//     A operand of k-slab kk: Phi[16 m + n][4 kk + g] = phiT[4 kk + g][16 m + n]   -- 64-B segments of phiT rows
-//     B operand:              x_env(n)[4 kk + g]      = X[4 kk + g][tile + n]      -- the component-major state
-//     so lane (n, g) ends up with x'_env(n)[16 m + 4 g + r] in register r of tile m — exactly the four components
-//     Philox call q = 4 m + g provides the process noise for, and
-//   y^T = C x'^T takes those registers as its B operands directly: slab s = 4 m + r multiplies the k-group
-//     {16 m + 4 g + r : g = 0..3} (A operand C[16 mo + n][that k] = cT[k][16 mo + n]).  No LDS, no shuffles between
-//     the products; the price is the k order of y, linds_yorder_at, which scalar kernel and oracle follow.
+//   x'^T = Phi X^T + Gamma A^T, rows in M-tiles of 16:  D_m[j = 16 m + row][env]: lane (n, g) ends up with
+//     x'_env(n)[16 m + 4 g + r] in register r of tile m — exactly the four components Philox call q = 4 m + g provides
+//     the process noise for.  Those registers are the B operands of BOTH products that consume the state: slab
+//     s = 4 m + r multiplies the k-group {16 m + 4 g + r : g = 0..3}
+//       y^T = C x'^T            (A operand C[16 mo + n][that k]  = cT[k][16 mo + n])
+//       x''^T = Phi x'^T + ...  (A operand Phi[16 m' + n][that k] = phiT[k][16 m' + n], 64-B segments of phiT rows)
+//     No LDS, no shuffles between the products nor between steps (the fused roll-out kernel keeps the state in these
+//     registers for T steps); the price is the k order of the two chains, linds_yorder_at, which scalar kernel and
+//     oracle follow.  From memory the B operand of slab s is X[16 (s>>2) + 4 g + (s&3)][tile + n], coalesced.
 //   Half the tile width of a 32x32x2 formulation: twice the waves for the same batch (4 per SIMD at 65,536 envs) and
 //   a quarter of the MFMA latency per k (8 passes per 4 k instead of 16 per 2) — this kernel is latency-bound.
 //   Per-env scalar work (error, reward, flags) is done redundantly by the four lanes of an env; each lane stores its
@@ -497,8 +503,8 @@ __device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const L
   const float* xtv = P.T.xt + (size_t)t * NS;
   float pa[MT][KS], pb[KS], ga[MT][KA], ca[MO][KS], xtr[MT][4];
 #pragma unroll
-  for (int kk = 0; kk < KS; ++kk) {
-    const int k = 4 * kk + g;
+  for (int kk = 0; kk < KS; ++kk) {   // slab kk multiplies the k-group {16 (kk>>2) + 4 g + (kk&3)}: linds_yorder
+    const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
     pb[kk] = P.x[(size_t)k * NSL + es];
 #pragma unroll
     for (int m = 0; m < MT; ++m) pa[m][kk] = phiT[k * NS + 16 * m + n];
@@ -740,6 +746,291 @@ __device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const L
     }
   }
   if (bad && valid) atomicOr(P.err, (uint32_t)XV_DEVERR_NONFINITE);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused roll-out: T steps of the tile in one launch, SAME_STEP auto-reset, free-running noise.  The task's operand
+// fragments are loaded once and the state never leaves the registers the matrix unit wrote it to (see the k order
+// above); per step only the action row and the two command rows come in and the outputs go out.  Step t draws with
+// tick0 + t, so the result equals T calls of xv_linds_step bit for bit (tested).
+// ------------------------------------------------------------------------------------------------
+struct LinDSRolloutIO {
+  const float* action;      // [T][n_env][NA]
+  float* obs;               // [T][n_env][NO]
+  float* reward;            // [T][n_env]
+  uint8_t* terminated;
+  uint8_t* truncated;
+  float* cmd;               // [T][n_env][NO]  nullable
+  float* error;             // [T][n_env]      nullable
+  float* final_obs;         // [T][n_env][NO]  nullable
+};
+
+template <int NS, int NA, int NO>
+__global__ __launch_bounds__(256) void linds_rollout_mfma_kernel(LinDSArgs P, LinDSRolloutIO io, int T) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int tile0 = wave * 16;
+  if (tile0 >= P.n_slot) return;   // wave-uniform
+  const int N = P.n_env, NSL = P.n_slot;
+  const int n = lane & 15, g = lane >> 4;
+  constexpr int MT = NS / 16, MO = NO / 16, KS = NS / 4, KA = NA / 4;
+  const int es = tile0 + n < NSL ? tile0 + n : NSL - 1;
+  int e_raw = tile0 + n;
+  if (P.slot_env != nullptr) e_raw = P.slot_env[es];
+  const bool valid = tile0 + n < NSL && e_raw >= 0 && e_raw < N;
+  const int e = valid ? e_raw : 0;
+  const int t = __builtin_amdgcn_readfirstlane(P.tile_task ? P.tile_task[wave] : P.env_task[tile0]);
+  const uint64_t gid = P.gid_base + (uint64_t)e;
+  const XV_CONST_AS float* sc = xv_cptr(P.T.scal) + (size_t)t * 8;
+  const XV_CONST_AS int32_t* in = xv_cptr(P.T.ints) + (size_t)t * 4;
+  const int max_steps = in[0], delay = in[1], n_init = in[2], nf = in[3];
+  const float noise_scale = sc[4];
+  const XV_CONST_AS float* y0 = xv_cptr(P.T.y0) + (size_t)t * NO;
+
+  // ---- once per launch: the task's operand fragments and the state ----
+  const float* phiT = P.T.phiT + (size_t)t * NS * NS;
+  const float* gamT = P.T.gamT + (size_t)t * NA * NS;
+  const float* cT = P.T.cT + (size_t)t * NS * NO;
+  const float* xtv = P.T.xt + (size_t)t * NS;
+  float pa[MT][KS], ga[MT][KA], ca[MO][KS], xtr[MT][4], y0r[MO][4];
+  xv_f32x4 xs[MT];
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
+    xs[kk >> 2][kk & 3] = P.x[(size_t)k * NSL + es];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) pa[m][kk] = phiT[k * NS + 16 * m + n];
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo) ca[mo][kk] = cT[k * NO + 16 * mo + n];
+  }
+#pragma unroll
+  for (int kk = 0; kk < KA; ++kk)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ga[m][kk] = gamT[(4 * kk + g) * NS + 16 * m + n];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xtr[m][r] = xtv[16 * m + 4 * g + r];
+#pragma unroll
+  for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y0r[mo][r] = xv_sel4(g, y0[16 * mo + r], y0[16 * mo + 4 + r], y0[16 * mo + 8 + r], y0[16 * mo + 12 + r]);
+  int steps = P.steps[es];
+  int bad_any = 0;
+
+  for (int ts = 0; ts < T; ++ts) {
+    const uint64_t tick = P.tick + (uint64_t)ts;
+    const size_t ob = (size_t)ts * N + e;          // this step's slot of the [T][n_env] outputs
+    float a_raw[NA];
+    {
+      const float4* a4 = reinterpret_cast<const float4*>(io.action + ob * NA);
+#pragma unroll
+      for (int q = 0; q < NA / 4; ++q) {
+        const float4 v = a4[q];
+        a_raw[4 * q] = v.x; a_raw[4 * q + 1] = v.y; a_raw[4 * q + 2] = v.z; a_raw[4 * q + 3] = v.w;
+      }
+    }
+    const int steps_new = steps + 1;                            // :147
+    const int trk_time = steps_new - 1 - delay, rep_time = steps_new;
+    const int trk_idx = trk_time - P.ct_tmin, rep_idx = rep_time - P.ct_tmin;
+    const bool trk_in = P.cmd_tab != nullptr && trk_idx >= 0 && trk_idx < P.ct_len;
+    const bool rep_in = P.cmd_tab != nullptr && rep_idx >= 0 && rep_idx < P.ct_len;
+    float ctrack[NO], crep[MO][4];
+    if (P.cmd_tab != nullptr) {
+      const float4* p = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + (trk_in ? trk_idx : 0)) * NO);
+#pragma unroll
+      for (int q = 0; q < NO / 4; ++q) {
+        const float4 v = p[q];
+        ctrack[4 * q] = v.x; ctrack[4 * q + 1] = v.y; ctrack[4 * q + 2] = v.z; ctrack[4 * q + 3] = v.w;
+      }
+      const float4* pr = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + (rep_in ? rep_idx : 0)) * NO);
+#pragma unroll
+      for (int mo = 0; mo < MO; ++mo) {
+        const float4 v = pr[4 * mo + g];
+        crep[mo][0] = v.x; crep[mo][1] = v.y; crep[mo][2] = v.z; crep[mo][3] = v.w;
+      }
+    }
+    float zr[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const xv_u32x4 w = xv_env_draw(P.seed, gid, tick, XV_DRAW_NOISE + (uint32_t)(4 * m + g));
+      xv_box_muller_fast(w.x, w.y, &zr[m][0], &zr[m][1]);
+      xv_box_muller_fast(w.z, w.w, &zr[m][2], &zr[m][3]);
+    }
+    // ---- x' = Phi x + Gamma act ----
+    xv_f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = xv_f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[m][kk], xs[kk >> 2][kk & 3], acc[m], 0, 0, 0);
+    float sa = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NA; ++k) sa = fmaf(a_raw[k], a_raw[k], sa);
+#pragma unroll
+    for (int kk = 0; kk < KA; ++kk) {
+      const float ar = xv_sel4(g, a_raw[4 * kk], a_raw[4 * kk + 1], a_raw[4 * kk + 2], a_raw[4 * kk + 3]);
+      const float b = ar < -1.0f ? -1.0f : (ar > 1.0f ? 1.0f : ar);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[m][kk], b, acc[m], 0, 0, 0);
+    }
+    xv_f32x4 xn[MT];
+    int bad = 0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[m][r] + xtr[m][r];
+        v = fmaf(noise_scale, zr[m][r], v);
+        bad |= !(fabsf(v) <= 3.0e38f);
+        xn[m][r] = v;
+      }
+    // ---- y = C x' + Y ----
+    xv_f32x4 ym[MO];
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo) ym[mo] = xv_f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int mo = 0; mo < MO; ++mo)
+        ym[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[mo][s], xn[s >> 2][s & 3], ym[mo], 0, 0, 0);
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ym[mo][r] = ym[mo][r] + y0r[mo][r];
+    float y[NO];
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+      for (int gs = 0; gs < 4; ++gs)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[16 * mo + 4 * gs + r] = __shfl(ym[mo][r], n + 16 * gs);
+    if (__ballot(!(trk_in && rep_in)) != 0ull) {
+      if (!trk_in) linds_cmd<NO>(P, t, nf, trk_time, ctrack);
+      if (!rep_in) {
+        float full[NO];
+        linds_cmd<NO>(P, t, nf, rep_time, full);
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            crep[mo][r] = xv_sel4(g, full[16 * mo + r], full[16 * mo + 4 + r], full[16 * mo + 8 + r], full[16 * mo + 12 + r]);
+      }
+    }
+    float o_err = linds_err<NO>(P, t, y, ctrack);
+    float sc2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NO; ++j) sc2 = fmaf(y[j], y[j], sc2);
+    const float obs_scale = sqrtf(sc2);
+    const int o_term = ((o_err > 10.0f) || (obs_scale > 20.0f)) ? 1 : 0;
+    float o_r = o_term ? -sc[2] : 0.0f;
+    float tmp = fmaf(-sc[3], o_err, sc[1]);
+    tmp = fmaf(-sc[0], sa, tmp);
+    o_r = fmaf(tmp, sc[5], o_r);
+    const int o_trunc = (steps_new >= max_steps - 1) ? 1 : 0;
+    const bool do_reset = o_term || o_trunc;
+    steps = steps_new;
+    int wrote_fobs = 0;
+    xv_f32x4 fobs[MO];
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo) fobs[mo] = xv_f32x4{0, 0, 0, 0};
+    if (__ballot(do_reset) != 0ull) {
+      const xv_u32x4 v = xv_env_draw(P.seed, gid, tick, XV_DRAW_RESET);
+      int idx = (int)(xv_u53(v.x, v.y) * (double)n_init);
+      idx = idx < n_init ? idx : n_init - 1;
+      idx = idx < 0 ? 0 : idx;
+      const float* x0 = P.T.init + ((size_t)t * P.NI + idx) * NS;
+      xv_f32x4 xr[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        xr[m] = xn[m];
+        if (do_reset) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xr[m][r] = x0[16 * m + 4 * g + r];
+        }
+      }
+      float c0[NO], e0;
+      linds_cmd_at<NO>(P, t, nf, 0, c0);
+      xv_f32x4 yr[MO];
+      if (P.rst_tab != nullptr) {
+        const float4* row = reinterpret_cast<const float4*>(P.rst_tab + ((size_t)t * P.NI + idx) * (NO + 4));
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo) {
+          const float4 q4 = row[4 * mo + g];
+          yr[mo][0] = q4.x; yr[mo][1] = q4.y; yr[mo][2] = q4.z; yr[mo][3] = q4.w;
+        }
+        e0 = row[NO / 4].x;
+      } else {
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo) yr[mo] = xv_f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+          for (int mo = 0; mo < MO; ++mo)
+            yr[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[mo][s], xr[s >> 2][s & 3], yr[mo], 0, 0, 0);
+        float yfull[NO];
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) yr[mo][r] = yr[mo][r] + y0r[mo][r];
+#pragma unroll
+          for (int gs = 0; gs < 4; ++gs)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yfull[16 * mo + 4 * gs + r] = __shfl(yr[mo][r], n + 16 * gs);
+        }
+        e0 = linds_err<NO>(P, t, yfull, c0);
+      }
+      if (do_reset) {
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo) fobs[mo] = ym[mo];
+        wrote_fobs = 1;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xn[m] = xr[m];
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo) {
+          ym[mo] = yr[mo];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            crep[mo][r] = xv_sel4(g, c0[16 * mo + r], c0[16 * mo + 4 + r], c0[16 * mo + 8 + r], c0[16 * mo + 12 + r]);
+        }
+        o_err = e0;
+        steps = 0;
+      }
+    }
+    bad_any |= bad;
+    if (valid) {
+#pragma unroll
+      for (int mo = 0; mo < MO; ++mo) {
+        const size_t ro = ob * NO + 16 * mo + 4 * g;
+        *reinterpret_cast<float4*>(io.obs + ro) = make_float4(ym[mo][0], ym[mo][1], ym[mo][2], ym[mo][3]);
+        if (io.cmd) *reinterpret_cast<float4*>(io.cmd + ro) = make_float4(crep[mo][0], crep[mo][1], crep[mo][2], crep[mo][3]);
+        if (io.final_obs)
+          *reinterpret_cast<float4*>(io.final_obs + ro) =
+              wrote_fobs ? make_float4(fobs[mo][0], fobs[mo][1], fobs[mo][2], fobs[mo][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (g == 0) {
+        io.reward[ob] = o_r;
+        if (io.error) io.error[ob] = o_err;
+        io.terminated[ob] = (uint8_t)o_term;
+        io.truncated[ob] = (uint8_t)o_trunc;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xs[m] = xn[m];
+  }
+  if (valid) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P.x[(size_t)(16 * m + 4 * g + r) * NSL + es] = xs[m][r];
+    if (g == 0) {
+      P.steps[es] = steps;
+      P.need_reset[es] = 0;
+    }
+  }
+  if (bad_any && valid) atomicOr(P.err, (uint32_t)XV_DEVERR_NONFINITE);
 }
 
 // two entry points over the same body: with 16 observation rows the step fits 128 registers and is capped there
@@ -1063,6 +1354,20 @@ __global__ __launch_bounds__(256) void linds_permute_state_kernel(LinDSArgs P, f
   }
   if (steps) { if (TO_ENV) steps[i] = P.steps[si]; else P.steps[si] = steps[i]; }
   if (need_reset) { if (TO_ENV) need_reset[i] = P.need_reset[si]; else P.need_reset[si] = need_reset[i]; }
+}
+
+extern "C" int xv_linds_rollout(xv_linds* h, int T, const float* action, float* obs, float* reward, uint8_t* terminated,
+                                uint8_t* truncated, float* cmd, float* error, float* final_obs) {
+  XV_CHECK_ARG(h && action && obs && reward && terminated && truncated && T > 0);
+  linds_bind_rng(h, (uint64_t)T);
+  LinDSRolloutIO io{action, obs, reward, terminated, truncated, cmd, error, final_obs};
+  const dim3 block(256), grid(xv_div_up(xv_div_up(h->a.n_slot, 16), 4));
+#define LINDS_ROLL(NS_, NA_, NO_, dummy) \
+  hipLaunchKernelGGL((linds_rollout_mfma_kernel<NS_, NA_, NO_>), grid, block, 0, h->eng->stream, h->a, io, T)
+  LINDS_DISPATCH(LINDS_ROLL, 0);
+#undef LINDS_ROLL
+  XV_LAUNCH_CHECK();
+  return XV_OK;
 }
 
 extern "C" int xv_linds_get_state(xv_linds* h, float* x, int32_t* steps, uint8_t* need_reset) {

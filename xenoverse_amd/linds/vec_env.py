@@ -230,6 +230,36 @@ class LinDSVecEnv(VectorEnv):
             _lib.ptr(self._error), _lib.ptr(self._fobs), AUTORESET[self.autoreset_mode]))
         return self._ret()
 
+    def rollout(self, actions, out=None, with_info=True):
+        """Fused open-loop roll-out: actions float32[T, N, na] -> dict of [T, N(, NO)] device tensors, one launch with the
+        state resident in registers between the steps.  Equals T calls of step() with SAME_STEP auto-reset, bit for bit."""
+        self._check_step()
+        a = self._dev(actions, torch.float32)
+        T = int(a.shape[0])
+        na_user = self.user_dims[0]
+        if a.shape != (T, self.num_envs, na_user):
+            raise AssertionError(f"Action shape mismatch: expected {(T, self.num_envs, na_user)}, got {tuple(a.shape)}")
+        if na_user != self.NA:
+            p = torch.zeros((T, self.num_envs, self.NA), dtype=torch.float32, device=self.device)
+            p[..., :na_user] = a
+            a = p
+        a = a.contiguous()
+        d, n = self.device, self.num_envs
+        if out is None:
+            out = dict(obs=torch.empty((T, n, self.NO), dtype=torch.float32, device=d),
+                       reward=torch.empty((T, n), dtype=torch.float32, device=d),
+                       terminated=torch.empty((T, n), dtype=torch.uint8, device=d),
+                       truncated=torch.empty((T, n), dtype=torch.uint8, device=d))
+            if with_info:
+                out.update(command=torch.empty((T, n, self.NO), dtype=torch.float32, device=d),
+                           error=torch.empty((T, n), dtype=torch.float32, device=d),
+                           final_obs=torch.empty((T, n, self.NO), dtype=torch.float32, device=d))
+        _lib.check(self.lib.xv_linds_rollout(self._h, T, _lib.ptr(a), _lib.ptr(out["obs"]), _lib.ptr(out["reward"]),
+                                             _lib.ptr(out["terminated"]), _lib.ptr(out["truncated"]),
+                                             _lib.ptr(out.get("command")), _lib.ptr(out.get("error")),
+                                             _lib.ptr(out.get("final_obs"))))
+        return out
+
     @property
     def state(self):
         """env.state (linds_env.py:185-187): float[N, NS]"""
