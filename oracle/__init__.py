@@ -490,6 +490,56 @@ class MazeOracle(object):
         lib().xo_maze_render(C.byref(self._h), _p(f), _p(c), C.c_int(n_threads))
         return f, c
 
+    def expose(self, seed, gid_base, tick, prob=0.05):
+        """maze_core._cell_exposed of the present pose: uint8[n_env, NG, NG] (ray_caster_utils.py:250-255)"""
+        NG = self._h.NG
+        ex = np.zeros((self.n_env, NG, NG), np.uint8)
+        lib().xo_maze_expose(C.byref(self._h), C.c_uint64(seed), C.c_uint64(gid_base), C.c_uint64(tick),
+                             C.c_double(prob), _p(ex))
+        return ex
+
+
+class _MazeAgentStruct(C.Structure):
+    _fields_ = [("env", C.c_void_p), ("stm_size", C.c_int), ("oracle_agent", C.c_int), ("keep_ratio", C.c_double),
+                ("na", C.c_int), ("actions", C.c_void_p), ("stm", C.c_void_p), ("stm_len", C.c_void_p),
+                ("ltm", C.c_void_p), ("mask", C.c_void_p), ("cost", C.c_void_p), ("path", C.c_void_p)]
+
+
+class MazeAgentOracle(object):
+    """SmartSLAMAgent / OracleAgent over a MazeOracle's envs (xeno_oracle_agent.c)"""
+    STM_MAX = 8
+
+    def __init__(self, maze, actions, short_term_memory_size=3, memory_keep_ratio=1.0, oracle_agent=False):
+        self.maze = maze
+        n, NG = maze.n_env, maze._h.NG
+        self.NG = NG
+        self.actions = np.ascontiguousarray(actions, np.float64).reshape(-1, 2)
+        self.stm = np.zeros((n, self.STM_MAX, NG, NG), np.uint8); self.stm_len = np.zeros(n, np.int32)
+        self.ltm = np.zeros((n, NG, NG), np.uint8); self.mask = np.zeros((n, NG, NG), np.uint8)
+        self.cost = np.zeros((n, NG, NG), np.float64); self.path = np.zeros((n, 5), np.int32)
+        assert short_term_memory_size < self.STM_MAX
+        self._h = _MazeAgentStruct(C.cast(C.pointer(maze._h), C.c_void_p), int(short_term_memory_size),
+                                   int(bool(oracle_agent)), float(memory_keep_ratio), len(self.actions),
+                                   _p(self.actions), _p(self.stm), _p(self.stm_len), _p(self.ltm), _p(self.mask),
+                                   _p(self.cost), _p(self.path))
+
+    def act(self, exposed, u_keep=None):
+        ex = np.ascontiguousarray(exposed, np.uint8)
+        assert ex.shape == (self.maze.n_env, self.NG, self.NG)
+        uk = None if u_keep is None else np.ascontiguousarray(u_keep, np.float64)
+        a = np.zeros(self.maze.n_env, np.int32)
+        lib().xo_maze_agent_act(C.byref(self._h), _p(ex), _p(uk), _p(a))
+        return a
+
+
+def maze_search_action(ori, targ1, targ2, actions):
+    a = np.ascontiguousarray(actions, np.float64).reshape(-1, 2)
+    t1 = np.ascontiguousarray(targ1, np.float64)
+    t2 = None if targ2 is None else np.ascontiguousarray(targ2, np.float64)
+    f = lib().xo_maze_search_action
+    f.restype = C.c_int
+    return int(f(C.c_double(ori), _p(t1), _p(t2), _p(a), C.c_int(len(a))))
+
 
 # ---------------------------------------------------------------------------------------------------
 # AnyMDP POMDP / MTPOMDP

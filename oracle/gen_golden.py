@@ -424,6 +424,69 @@ def gen_maze():
         gen_maze_one("maze_15_seed%d" % k, task, max_steps=(5000 if k else 230), seed0=100 + k)
 
 
+def gen_maze_agent_one(name, task, T, action_space, agent_kind, res=32, seed0=0, expose_all=False):
+    """The reference's SmartSLAMAgent / OracleAgent driving its own MazeWorldContinuous3D: per agent.step() the env
+    state it read (pose, cell, command, maze_core._cell_exposed) and what it produced (action, _mask_info, _cost_map,
+    first two path cells).  expose_all: `random.random` of the ray caster returns 0.0, so _cell_exposed holds every cell
+    DDA_2D lists (pins the cell lists; the 5 % sampling itself is an unseeded stream in the reference)."""
+    import random
+    Maze, mts, dyn, rc = _refimport.mazeworld()
+    from xenoverse.mazeworld.agents.smart_slam_agent import SmartSLAMAgent
+    from xenoverse.mazeworld.agents.oracle_agent import OracleAgent
+    env = Maze(enable_render=False, resolution=(res, res), max_steps=5000, visibility_3D=12.0,
+               command_in_observation=False, action_space_type=action_space)
+    env.set_task(task)
+    core = env.maze_core
+    random.seed(seed0)
+    real_random = rc.random.random
+    if expose_all:
+        rc.random.random = lambda: 0.0
+    try:
+        obs, info = env.reset()
+        agent = (OracleAgent if agent_kind == "oracle" else SmartSLAMAgent)(maze_env=env, render=False)
+        n = core._cell_walls.shape[0]
+        rec = {k: [] for k in ("pos", "ori", "grid", "command", "cmd_idx", "steps", "exposed", "action", "mask", "cost",
+                               "path_len", "path01")}
+        r = 0
+        for t in range(T):
+            rec["pos"].append(np.array(core._agent_loc, np.float64)); rec["ori"].append(float(core._agent_ori))
+            rec["grid"].append(np.array(core._agent_grid, np.int64)); rec["command"].append(int(core._command))
+            rec["cmd_idx"].append(int(core._commands_sequence_idx)); rec["steps"].append(int(core.steps))
+            rec["exposed"].append(np.array(core._cell_exposed, np.uint8))
+            a = agent.step(obs, r)
+            rec["action"].append(int(a)); rec["mask"].append(np.array(agent._mask_info, np.uint8))
+            rec["cost"].append(np.array(agent._cost_map, np.float64)); rec["path_len"].append(len(agent._path))
+            p = [tuple(int(v) for v in q) for q in agent._path[:2]] + [(-1, -1)]
+            rec["path01"].append(np.array(p[:2], np.int64))
+            obs, r, term, trunc, info = env.step(a)
+            if term or trunc:
+                break
+    finally:
+        rc.random.random = real_random
+    out = _maze_task_arrays(task)
+    out.update(res=np.int64(res), n_actions=np.int64(len(env.list_actions)), agent_kind=np.int64(agent_kind == "oracle"),
+               expose_all=np.int64(expose_all), **{k: np.asarray(v) for k, v in rec.items()})
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, len(rec["action"]), "steps", os.path.getsize(path) // 1024, "KiB")
+
+
+def gen_maze_agent():
+    Maze, mts, dyn, rc = _refimport.mazeworld()
+    from xenoverse_amd.mazeworld.textures import make_texture_library
+    lib = make_texture_library(8, 4, 4, seed=0)
+    M = mts.MAZE_TASK_MANAGER
+    M.textlib_walls, M.textlib_grounds, M.textlib_ceilings = lib["walls"], lib["grounds"], lib["ceilings"]
+    t11 = mts.MazeTaskSampler(n_range=(11, 12), seed=3, verbose=False)
+    t15 = mts.MazeTaskSampler(n_range=(15, 16), seed=5, verbose=False)
+    t21 = mts.MazeTaskSampler(n_range=(21, 22), seed=7, verbose=False)
+    gen_maze_agent_one("agent_slam_11_d16", t11, 260, "Discrete16", "slam", seed0=1)
+    gen_maze_agent_one("agent_slam_15_d32", t15, 320, "Discrete32", "slam", seed0=2)
+    gen_maze_agent_one("agent_slam_21_d16", t21, 200, "Discrete16", "slam", seed0=3)
+    gen_maze_agent_one("agent_oracle_15_d16", t15, 200, "Discrete16", "oracle", seed0=4)
+    gen_maze_agent_one("agent_slam_11_all", t11, 80, "Discrete16", "slam", seed0=5, expose_all=True)
+
+
 def gen_maze_sampled(n_tasks=24, seed0=10):
     """Tasks of the reference's MazeTaskSampler over its default size range (and a few without loops): topology,
     textures, landmarks, start, commands — the build's sampler consumes the same stream and must return the same task."""
@@ -621,7 +684,7 @@ def gen_anymdp_sampled(n=32, seed0=100):
 
 FAMILIES = {"anymdp": gen_anymdp, "linds": gen_linds, "maze": gen_maze, "acrobot": gen_acrobot, "garnet": gen_garnet,
             "anymdp_vi": gen_anymdp_vi, "anymdp_sampled": gen_anymdp_sampled, "maze_sampled": gen_maze_sampled,
-            "linds_sampled": gen_linds_sampled}
+            "linds_sampled": gen_linds_sampled, "maze_agent": gen_maze_agent}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

@@ -44,6 +44,14 @@ void xo_env_draw(uint64_t seed, uint64_t gid, uint64_t tick, uint32_t purpose, u
   xo_philox4x32_10(ctr, key, out);
 }
 
+/* draw family with a wide sub-index: the sub-index enters the key (xv_env_draw_sub of csrc/philox.h) */
+void xo_env_draw_sub(uint64_t seed, uint64_t gid, uint64_t tick, uint32_t purpose, uint32_t sub, uint32_t out[4]) {
+  uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)tick,
+                     (purpose & 0xFFu) | ((uint32_t)(tick >> 32) << 8)};
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32) ^ (0x80000000u | sub)};
+  xo_philox4x32_10(ctr, key, out);
+}
+
 /* numpy legacy random_sample: (a>>5, b>>6) -> 53-bit double */
 double xo_u53(uint32_t a, uint32_t b) {
   return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
@@ -1199,6 +1207,76 @@ static void mz_view(const xo_maze* h, int e, int32_t* rgb /*[W][H][3]*/) {
     for (int x = sx; x < ex && x < W; ++x)
       for (int y = sy; y < ey && y < H; ++y)
         for (int c = 0; c < 3; ++c) rgb[((size_t)x * H + y) * 3 + c] = (int32_t)MZ_LANDMARK_RGB[cmd][c];
+  }
+}
+
+/* cell_exposed of maze_view (ray_caster_utils.py:153,250-255): every column's DDA_2D (:47-115) lists the cells its ray
+ * crosses within 0.6 * visibility (the agent's own cell first, the wall cell it stops at last) and maze_view marks each
+ * listed cell with probability 0.05 (`random.random() < 0.05`, an unseeded stream in the reference).  Here the k-th
+ * listed cell of column d_h takes word k & 3 of xo_env_draw_sub(seed, gid, tick, 5, 64 * d_h + (k >> 2)) and is
+ * marked iff word * 2^-32 < prob; prob >= 1 marks every listed cell (used to pin the cell lists themselves).
+ * Same float32 DDA as mz_view above. */
+#define XO_DRAW_EXPOSE 5u
+void xo_maze_expose(const xo_maze* h, uint64_t seed, uint64_t gid_base, uint64_t tick, double prob, uint8_t* exposed) {
+  const int W = h->W, NG = h->NG, N = h->n_env;
+  for (int e = 0; e < N; ++e) {
+    const int t = h->env_task[e];
+    const int32_t* in = h->ints + (size_t)t * 8;
+    const double* db = h->dbl + (size_t)t * 8;
+    const int n = in[0];
+    const double cell_size = db[0], fol = db[3], visibility = h->visibility, l_focal = 0.20;
+    const int8_t* walls = h->walls + (size_t)t * NG * NG;
+    uint8_t* ex = exposed + (size_t)e * NG * NG;
+    memset(ex, 0, (size_t)NG * NG);
+    const float pos[2] = {(float)h->pos[e], (float)h->pos[(size_t)N + e]};
+    const double ori = h->ori[e];
+    const double half_h = tan(fol / 2) * l_focal;
+    const double pixel_size = 2.0 * half_h / W;
+    const double s_ori = sin(ori), c_ori = cos(ori);
+    const double pixel_factor = pixel_size / l_focal;
+    const float cs_f = (float)cell_size, eps_f = (float)1.0e-8, vis_f = (float)visibility;
+    const float vis06 = (float)(visibility * 0.60);   /* float32 hit_dist against a Python float: compared in float32 */
+    const uint64_t gid = gid_base + (uint64_t)e;
+    double tan_hp = (-0.5 - W / 2.0) * pixel_factor;
+    for (int d_h = 0; d_h < W; ++d_h) {
+      tan_hp += pixel_factor;
+      const double cos_hp = sqrt(1.0 / (1.0 + tan_hp * tan_hp));
+      const double sin_hp = tan_hp * cos_hp;
+      const float so = (float)(sin_hp * c_ori + cos_hp * s_ori);
+      const float co = (float)(cos_hp * c_ori - sin_hp * s_ori);
+      const int i0 = (int)(pos[0] / cs_f), j0 = (int)(pos[1] / cs_f);
+      const float c_sign = co < 0 ? -1.0f : 1.0f, s_sign = so < 0 ? -1.0f : 1.0f;
+      const float ddx = fabsf(co) < eps_f ? fabsf(cs_f / eps_f) : fabsf(cs_f / co);
+      const float ddy = fabsf(so) < eps_f ? fabsf(cs_f / eps_f) : fabsf(cs_f / so);
+      const float d_x = co > 0 ? ((float)((i0 + 1) * cell_size) - pos[0]) : ((float)(i0 * cell_size) - pos[0]);
+      const float d_y = so > 0 ? ((float)((j0 + 1) * cell_size) - pos[1]) : ((float)(j0 * cell_size) - pos[1]);
+      float sdx = fabsf(co) < eps_f ? c_sign * (d_x / eps_f) : d_x / co;
+      float sdy = fabsf(so) < eps_f ? s_sign * (d_y / eps_f) : d_y / so;
+      const int di = co > 0 ? 1 : -1, dj = so > 0 ? 1 : -1;
+      int hi = i0, hj = j0, k = 0;
+      float hit_dist = 0.0f;
+      uint32_t w[4] = {0, 0, 0, 0};
+#define MZ_EXPOSE(ci, cj)                                                                      \
+  do {                                                                                         \
+    if ((k & 3) == 0) xo_env_draw_sub(seed, gid, tick, XO_DRAW_EXPOSE, 64u * (uint32_t)d_h + (uint32_t)(k >> 2), w); \
+    const int hit_ = prob >= 1.0 || (double)w[k & 3] * (1.0 / 4294967296.0) < prob;            \
+    if (hit_ && (ci) >= 0 && (ci) < n && (cj) >= 0 && (cj) < n) ex[(ci) * NG + (cj)] = 1;      \
+    if (k < 255) ++k;                                                                          \
+  } while (0)
+      MZ_EXPOSE(i0, j0);
+      while (hit_dist < vis_f) {
+        const int xstep = sdx < sdy;
+        if (xstep) { hi += di; sdy -= sdx; hit_dist += sdx; }
+        else { hj += dj; sdx -= sdy; hit_dist += sdy; }
+        if (hi < 0 || hi >= n) { if (hj < 0 || hj >= n) break; }
+        else {
+          if (hit_dist <= vis06) MZ_EXPOSE(hi, hj);
+          if (hj >= 0 && hj < n && walls[hi * NG + hj] > 0) break;
+        }
+        if (xstep) sdx = ddx; else sdy = ddy;
+      }
+#undef MZ_EXPOSE
+    }
   }
 }
 

@@ -22,6 +22,7 @@ void xo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out
 void xo_env_draw(uint64_t seed, uint64_t gid, uint64_t tick, uint32_t purpose, uint32_t out[4]);
 /* numpy random_sample construction from two 32-bit words: ((a>>5)*2^26 + (b>>6)) / 2^53 */
 double xo_u53(uint32_t a, uint32_t b);
+void xo_env_draw_sub(uint64_t seed, uint64_t gid, uint64_t tick, uint32_t purpose, uint32_t sub, uint32_t out[4]);
 /* Box-Muller pair from two words (float): z0 = r cos(2 pi u2), z1 = r sin(2 pi u2) */
 void xo_box_muller(uint32_t a, uint32_t b, float* z0, float* z1);
 
@@ -237,6 +238,32 @@ void xo_maze_step(xo_maze* h, const double* action, float* reward, uint8_t* term
                   int mode);
 /* frames uint8[n_env][W][H][3] (maze_view + astype uint8); command RGB float[n_env][3] (info["command"]) */
 void xo_maze_render(const xo_maze* h, uint8_t* frames, float* command_rgb, int n_threads);
+/* cell_exposed of maze_view (ray_caster_utils.py:153,250-255): uint8[n_env][NG][NG]; see xeno_oracle.c */
+void xo_maze_expose(const xo_maze* h, uint64_t seed, uint64_t gid_base, uint64_t tick, double prob, uint8_t* exposed);
+
+/* SmartSLAMAgent / OracleAgent (mazeworld/agents/agent_base.py:10-107, smart_slam_agent.py:105-231, oracle_agent.py):
+ * the rule-based teacher.  One agent per env, a new one whenever the env starts an episode (steps == 0). */
+#define XO_AGENT_STM_MAX 8
+typedef struct {
+  const xo_maze* env;
+  int stm_size;              /* short_term_memory_size (3) */
+  int oracle_agent;          /* OracleAgent: long-term memory all ones */
+  double keep_ratio;         /* memory_keep_ratio (1.0) */
+  int na;                    /* 16 or 32 */
+  const double* actions;     /* [na][2] maze_env.list_actions: (turn_rate / PI, walk_speed) */
+  uint8_t* stm;              /* [n_env][STM_MAX][NG*NG], oldest first */
+  int32_t* stm_len;          /* [n_env] */
+  uint8_t* ltm;              /* [n_env][NG*NG] */
+  uint8_t* mask;             /* [n_env][NG*NG] _mask_info after the last act */
+  double* cost;              /* [n_env][NG*NG] _cost_map after the last act */
+  int32_t* path;             /* [n_env][5]: len(path), path[0], path[1] (-1 if absent) after the last act */
+} xo_maze_agent;
+/* agent.step(): update_common_info + policy.  exposed uint8[n_env][NG*NG] = maze_core._cell_exposed of the present
+ * observation; u_keep double[n_env][NG*NG] in [0,1) or NULL (only read when keep_ratio < 1).  action int32[n_env] */
+void xo_maze_agent_act(xo_maze_agent* a, const uint8_t* exposed, const double* u_keep, int32_t* action);
+/* search_optimal_action (dynamics.py:126-156), exposed for unit tests; targ2 NULL = None */
+int xo_maze_search_action(double ori, const double targ1[2], const double* targ2, const double* actions, int na);
+
 /* one move, exposed for unit tests: dynamics.py:158-187 */
 void xo_maze_move(double* ori, double pos[2], double turn_rate, double walk_speed, const int8_t* walls, int n,
                   int NG, double cell_size, double col_dist, double* collision);

@@ -43,6 +43,17 @@ __host__ __device__ __forceinline__ xv_u32x4 xv_env_draw(uint64_t seed, uint64_t
                           (uint32_t)(seed >> 32));
 }
 
+// a draw family with a wide sub-index (ray x cell of the maze exposure map, cell of the memory-keep map): the
+// sub-index goes into the key, so that every (purpose, sub) is its own Philox stream
+#define XV_DRAW_EXPOSE 5u  // sub = 64 * column + (k >> 2): word k & 3 decides the k-th cell the column's ray lists
+#define XV_DRAW_KEEP 6u    // sub = cell >> 2: word cell & 3 -> long-term-memory keep draw of the maze teacher
+__host__ __device__ __forceinline__ xv_u32x4 xv_env_draw_sub(uint64_t seed, uint64_t gid, uint64_t tick,
+                                                               uint32_t purpose, uint32_t sub) {
+  return xv_philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)tick,
+                          (purpose & 0xFFu) | ((uint32_t)(tick >> 32) << 8), (uint32_t)seed,
+                          (uint32_t)(seed >> 32) ^ (0x80000000u | sub));
+}
+
 // numpy legacy random_sample: two 32-bit words -> 53-bit double in [0,1)
 __host__ __device__ __forceinline__ double xv_u53(uint32_t a, uint32_t b) {
   return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
