@@ -34,8 +34,9 @@ extern "C" {
 
 /* 2: AnyMDP rows are records of 128-byte lines (fence line + 7-entry blocks), completed in place by
  *    xv_anymdp_create; xv_maze_tables carries the texture-library sizes; Acrobot family; command-table and
- *    graph-replay switches */
-#define XV_ABI_VERSION 3
+ *    graph-replay switches
+ * 4: xv_linds_rollout; the maze teachers (xv_maze_agent_*) */
+#define XV_ABI_VERSION 4
 
 /* return codes */
 #define XV_OK 0
@@ -491,6 +492,33 @@ int xv_maze_set_move_kernel(xv_maze* h, int kernel);
 #define XV_MAZE_FILTER_EXACT 0
 #define XV_MAZE_FILTER_F32 1
 int xv_maze_set_precision(xv_maze* h, int filter);
+
+/* ---------------------------------------------------------------------------------------------
+ * MazeWorld rule-based teachers — reference: xenoverse/mazeworld/agents
+ *   AgentBase.__init__ / update_common_info / valid_neighbors   agent_base.py:10-107
+ *   SmartSLAMAgent.update_cost_map / policy / retrieve_path / exploration / navigate_landmarks_navigate /
+ *     path_to_action                                            smart_slam_agent.py:105-231
+ *   OracleAgent (long-term memory of ones)                      oracle_agent.py
+ *   search_optimal_action                                       envs/dynamics.py:126-156
+ *   maze_view's cell_exposed (what the agent remembers)         envs/ray_caster_utils.py:47-115,250-255
+ * One agent per env of an xv_maze, all decisions of a batch in one launch (csrc/maze_agent.hip).  An env that starts an
+ * episode (steps == 0) gets a new agent, as the reference's loops construct one after reset().
+ * ------------------------------------------------------------------------------------------- */
+typedef struct xv_maze_agent xv_maze_agent;
+/* short_term_memory_size (3), memory_keep_ratio (1.0): the AgentBase keyword arguments; oracle_agent != 0: OracleAgent;
+ * n_actions 16 | 32: the env's Discrete16 / Discrete32 table (maze_env.list_actions); keep_cost_map != 0 keeps the
+ * _cost_map of the last decision readable through xv_maze_agent_get (n_env * NG * NG doubles). */
+int xv_maze_agent_create(xv_maze* env, int short_term_memory_size, double memory_keep_ratio, int oracle_agent,
+                         int n_actions, int keep_cost_map, xv_maze_agent** out);
+int xv_maze_agent_destroy(xv_maze_agent* g);
+/* agent.step(observation, r) for every env: update_common_info + policy on the env's present state.
+ * action int32[n_env]: index into the Discrete table, ready for xv_maze_step.  exposed_inject: NULL = the cells are
+ * exposed as maze_view does it (the W columns' DDA, each listed cell with probability 0.05, draws keyed by
+ * (seed, env id, tick, column, cell)); else uint8[n_env][NG][NG] = maze_core._cell_exposed handed in (parity hook). */
+int xv_maze_agent_act(xv_maze_agent* g, const uint8_t* exposed_inject, int32_t* action);
+/* state of the last decision, each nullable: _mask_info uint8[n_env][NG][NG], _cost_map double[n_env][NG][NG],
+ * path int32[n_env][5] = {len(path), path[0], path[1]}, cell_exposed uint8[n_env][NG][NG] */
+int xv_maze_agent_get(xv_maze_agent* g, uint8_t* mask, double* cost, int32_t* path, uint8_t* exposed);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,13 @@ def u53(a, b):
     return lib().xo_u53(C.c_uint32(int(a)), C.c_uint32(int(b)))
 
 
+def env_draw_sub(seed, gid, tick, purpose, sub):
+    out = np.empty(4, dtype=np.uint32)
+    lib().xo_env_draw_sub(C.c_uint64(int(seed)), C.c_uint64(int(gid)), C.c_uint64(int(tick)), C.c_uint32(int(purpose)),
+                          C.c_uint32(int(sub)), _p(out))
+    return out
+
+
 def env_draw(seed, gid, tick, purpose):
     out = np.empty(4, dtype=np.uint32)
     lib().xo_env_draw(C.c_uint64(seed), C.c_uint64(gid), C.c_uint64(tick), C.c_uint32(purpose), _p(out))

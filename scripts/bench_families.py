@@ -287,6 +287,43 @@ def bench_maze(args, res, precision="exact", move_kernel="auto"):
                          "model": "408 fp64-pipe instructions per pixel (all pixels counted as painted)"}}
 
 
+def bench_teacher(args, res=64):
+    """the maze teachers deciding for 16,384 envs on the device, and the teacher-driven roll-out"""
+    from xenoverse_amd.mazeworld import (MazeTaskSampler, MazeWorldVecEnv, OracleAgent, SmartSLAMAgent,
+                                         make_texture_library)
+    from xenoverse_amd import _lib
+    from xenoverse_amd.engine import AUTORESET
+    n_task, per = 256, 64
+    n = n_task * per
+    tasks = [MazeTaskSampler(n_range=(15, 16), seed=k, n_wall_textures=8, n_ground_textures=4, n_ceiling_textures=4)
+             for k in range(n_task)]
+    out = {}
+    for name, cls in (("smart_slam", SmartSLAMAgent), ("oracle", OracleAgent)):
+        env = MazeWorldVecEnv(n, resolution=(res, res), textures=make_texture_library(8, 4, 4, seed=0),
+                              autoreset_mode="same_step", action_space_type="Discrete16", max_steps=2000)
+        env.set_task(tasks)
+        env.reset()
+        agent = cls(maze_env=env)
+        act = agent._action
+
+        def decide():
+            _lib.check(env.lib.xv_maze_agent_act(agent._h, None, _lib.ptr(act)))
+
+        def full():
+            decide()
+            _lib.check(env.lib.xv_maze_step(env._h, _lib.ptr(act), 1, _lib.ptr(env._frames), _lib.ptr(env._reward),
+                                            _lib.ptr(env._term), _lib.ptr(env._trunc), _lib.ptr(env._cmd_rgb), None,
+                                            AUTORESET["same_step"]))
+        for _ in range(60):        # let the memories fill before timing
+            full()
+        us_dec = timed(decide, 20, 2)
+        us_full = timed(full, 20, 2)
+        out[name] = {"decide_us": us_dec, "decide+step_us": us_full, "env_steps_per_s": n / (us_full * 1e-6)}
+        agent.close(); env.close()
+    return {"family": "mazeworld teachers", "workload": "15x15 mazes, 16,384 envs = 256 tasks x 64, %dx%d frames, "
+            "one decision per env-step" % (res, res), "dtype": "f64 cost maps, bitmap memories", "agents": out}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=400)
@@ -304,6 +341,8 @@ if __name__ == "__main__":
             r = bench_mixed(args)
         elif f == "anymdp_tok":
             r = bench_anymdp_tok(args)
+        elif f == "teacher":
+            r = bench_teacher(args)
         elif f.startswith("maze"):
             tok = f[4:].split("_")
             mv = {"m1": "lane_per_env", "m3": "three_lanes", "m9": "nine_lanes"}

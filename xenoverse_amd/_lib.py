@@ -91,6 +91,10 @@ SIGNATURES = {
     "xv_maze_render": [c_void_p, c_void_p, c_void_p],
     "xv_maze_set_precision": [c_void_p, c_int],
     "xv_maze_set_move_kernel": [c_void_p, c_int],
+    "xv_maze_agent_create": [c_void_p, c_int, C.c_double, c_int, c_int, c_int, c_void_p],
+    "xv_maze_agent_destroy": [c_void_p],
+    "xv_maze_agent_act": [c_void_p, c_void_p, c_void_p],
+    "xv_maze_agent_get": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
 }
 _RESTYPE = {"xv_last_error": C.c_char_p, "xv_engine_stream": c_void_p}
 
@@ -101,7 +105,7 @@ class XenoError(RuntimeError):
     pass
 
 
-ABI_VERSION = 3      # include/xeno.h XV_ABI_VERSION
+ABI_VERSION = 4      # include/xeno.h XV_ABI_VERSION
 
 
 def load():

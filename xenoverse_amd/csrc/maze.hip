@@ -15,59 +15,14 @@
 //                 staged in LDS as bytes, in chunks of rows, and leaves with coalesced 16-byte stores; the
 //                 landmark overlays read-modify-write there, as the reference does on its int32 array.
 //                 Integer-valued texture libraries are read from a packed RGBX-byte copy (16 B per filter row).
-#include "philox.h"
-#include "xv_common.h"
+#include "maze_common.h"
 
 #include <cstring>
-
-#define MZ_PI 3.1415926     // dynamics.py:7-8, the reference's own truncated constants
-#define MZ_TPI 6.2831852
-
-struct MazeArgs {
-  xv_maze_tables T;
-  const int32_t* env_task;
-  double* pos;       // [2][n_env]
-  double* ori;
-  int32_t* grid;     // [2][n_env]
-  int32_t* steps;
-  int32_t* cmd_idx;
-  int32_t* cmd_age;
-  uint8_t* need_reset;
-  double* collision;
-  int HC;   // rows per LDS chunk of the ray-caster
-  // packed RGBX-byte copies of the texture libraries ([n][256][MZ_TEX_PITCH] uint32), nullptr if not integral
-  const uint32_t* pk_walls;
-  const uint32_t* pk_grounds;
-  const uint32_t* pk_ceilings;
-  // pose of envs that ended this step, kept for the optional final frame
-  double* fin_pose;  // [3][n_env]
-  int32_t* fin_cmd;  // [n_env]
-  uint8_t* fin_flag; // [n_env]
-  uint32_t* err;
-  int n_env, n_task, NG, n_cmd, max_steps, W, H, command_in_observation;
-  double collision_dist, visibility;
-};
-
-struct xv_maze {
-  xv_engine* eng;
-  MazeArgs a;
-  bool filter_f32 = false;   // xv_maze_set_precision
-  bool move_lanes9 = true;   // xv_maze_set_move_kernel
-  int move_lanes = 0;        // 0: by batch size; 3 or 9: forced (xv_maze_set_move_kernel)
-};
 
 static const size_t MAZE_LDS_CHUNK_MAX = 50176;   // 256 columns x (64 rows x 3 + 4) bytes: three workgroups per 160-KiB CU
 static inline int maze_rc_threads(int W) { return W <= 64 ? 64 : (W <= 128 ? 128 : 256); }
 #define MZ_TEX_PITCH 260   // 256 texels + 3 wrapped ones (+1 pad): the 4 y-taps of a filter row never wrap
 
-__device__ const double MZ_ACT16[16][2] = {{0.0, 0.5}, {0.05, 0.0}, {-0.05, 0.0}, {0.1, 0.0}, {-0.1, 0.0}, {0.2, 0.0},
-                                           {-0.2, 0.0}, {0.3, 0.0}, {-0.3, 0.0}, {0.5, 0.0}, {-0.5, 0.0}, {0.0, 1.0},
-                                           {0.05, 1.0}, {-0.05, 1.0}, {0.10, 1.0}, {-0.10, 1.0}};
-__device__ const double MZ_ACT32[32][2] = {
-    {0.0, 0.2}, {0.02, 0.0}, {-0.02, 0.0}, {0.05, 0.0}, {-0.05, 0.0}, {0.1, 0.0}, {-0.1, 0.0}, {0.2, 0.0},
-    {-0.2, 0.0}, {0.3, 0.0}, {-0.3, 0.0}, {0.4, 0.0}, {-0.4, 0.0}, {0.5, 0.0}, {-0.5, 0.0}, {0.0, 0.5},
-    {0.0, 1.0}, {0.02, 0.5}, {0.02, 1.0}, {-0.02, 0.5}, {-0.02, 1.0}, {0.05, 0.5}, {0.05, 1.0}, {-0.05, 0.5},
-    {-0.05, 1.0}, {0.10, 0.5}, {0.10, 1.0}, {-0.10, 0.5}, {-0.10, 1.0}, {0.0, -0.2}, {0.1, -0.2}, {-0.1, -0.2}};
 // ray_caster_utils.py:11-25
 __device__ const float MZ_LANDMARK_RGB[XV_MAZE_LMAX][3] = {
     {0, 255, 0}, {255, 0, 0}, {0, 0, 255}, {0, 255, 255}, {255, 0, 255}, {255, 255, 0}, {128, 128, 255},
@@ -89,12 +44,6 @@ __device__ __forceinline__ MzDivisor mz_divisor(double b) {
 __device__ __forceinline__ double mz_div(double a, const MzDivisor& r) {   // == a / r.b (see above)
   const double q0 = a * r.y;
   return __builtin_fma(__builtin_fma(-r.b, q0, a), r.y, q0);
-}
-
-__device__ __forceinline__ double mz_angle_norm(double t) {   // dynamics.py:48-54
-  while (t > MZ_PI) t -= MZ_TPI;
-  while (t < -MZ_PI) t += MZ_TPI;
-  return t;
 }
 
 // dynamics.py:56-69
@@ -1112,12 +1061,25 @@ extern "C" int xv_maze_get_state(xv_maze* h, double* pos, double* ori, int32_t* 
   return XV_OK;
 }
 
+// _agent_grid follows _agent_loc (get_loc_grid, maze_base.py:220-223) when a pose is handed in
+__global__ __launch_bounds__(256) void maze_regrid_kernel(MazeArgs P) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= P.n_env) return;
+  const double cell_size = P.T.dbl[(size_t)P.env_task[e] * 8];
+  P.grid[e] = (int)(P.pos[e] / cell_size);
+  P.grid[(size_t)P.n_env + e] = (int)(P.pos[(size_t)P.n_env + e] / cell_size);
+}
+
 extern "C" int xv_maze_set_state(xv_maze* h, const double* pos, const double* ori, const int32_t* steps,
                                  const int32_t* cmd_idx, const int32_t* cmd_age, const uint8_t* need_reset) {
   XV_CHECK_ARG(h != nullptr);
   const size_t n = (size_t)h->a.n_env;
   hipStream_t s = h->eng->stream;
-  if (pos) XV_HIP(hipMemcpyAsync(h->a.pos, pos, 16 * n, hipMemcpyDeviceToDevice, s));
+  if (pos) {
+    XV_HIP(hipMemcpyAsync(h->a.pos, pos, 16 * n, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(maze_regrid_kernel, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, s, h->a);
+    XV_LAUNCH_CHECK();
+  }
   if (ori) XV_HIP(hipMemcpyAsync(h->a.ori, ori, 8 * n, hipMemcpyDeviceToDevice, s));
   if (steps) XV_HIP(hipMemcpyAsync(h->a.steps, steps, 4 * n, hipMemcpyDeviceToDevice, s));
   if (cmd_idx) XV_HIP(hipMemcpyAsync(h->a.cmd_idx, cmd_idx, 4 * n, hipMemcpyDeviceToDevice, s));

@@ -3,3 +3,4 @@ from .tables import DEFAULT_ACTION_SPACE_16, DEFAULT_ACTION_SPACE_32, build_tabl
 from .textures import make_texture_library  # noqa: F401
 from .vec_env import MazeWorldVecEnv  # noqa: F401
 from .task_sampler import MazeTaskSampler, Resampler  # noqa: F401
+from .agents import AgentBase, OracleAgent, SmartSLAMAgent, teacher_rollout  # noqa: F401
