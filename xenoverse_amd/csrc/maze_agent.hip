@@ -50,6 +50,7 @@ __device__ __forceinline__ bool ag_bit(const uint32_t* m, int c) { return (m[c >
 // class byte of a cell: bit 0 known (in _mask_info), bit 1 wall (god_info < 0)
 #define AG_KNOWN 1
 #define AG_WALL 2
+#define AG_EFF 4     // retrieve_path's eff_targets: the agent's cell and the known cells it can step to
 
 __device__ const int AG_NB[8][2] = {{-1, 0}, {1, 0}, {0, 1}, {0, -1}, {-1, -1}, {-1, 1}, {1, -1}, {1, 1}};   // agent_base.py:27
 
@@ -83,6 +84,8 @@ __global__ __launch_bounds__(256) void maze_agent_kernel(MazeArgs P, AgentArgs A
   uint32_t* ex = reinterpret_cast<uint32_t*>(cost + G2);                 // [WORDS]
   uint32_t* mk = ex + WORDS;                                             // [WORDS]
   uint8_t* cls = reinterpret_cast<uint8_t*>(mk + WORDS);                 // [G2]
+  uint8_t* inm = cls + G2;                                               // [G2] bit q: the step from c - NB[q] to c is valid
+  int16_t* nxt = reinterpret_cast<int16_t*>(inm + G2 + (G2 & 1));        // [G2] retrieve_path's choice at each cell, or -1
   __shared__ int sh_changed, sh_goal, sh_len, sh_p[4];
   __shared__ double sh_u[256];
   __shared__ int sh_i[256];
@@ -216,32 +219,43 @@ __global__ __launch_bounds__(256) void maze_agent_kernel(MazeArgs P, AgentArgs A
     }
   }
   __syncthreads();
+  // edges are fixed while the costs settle: valid_neighbors(center = o) lists o -> c (agent_base.py:48-71), one bit per
+  // direction; the start cells the agent can step to directly (retrieve_path's eff_targets, :177-179) get a flag
+  for (int c = tid; c < G2; c += nth) {
+    const int x = c / NG, y = c - x * NG;
+    int m = 0;
+    if (x < n && y < n)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int ox = x - AG_NB[q][0], oy = y - AG_NB[q][1];
+        if (ox >= 0 && ox < n && oy >= 0 && oy < n && ag_valid(cls, n, NG, ox, oy, AG_NB[q][0], AG_NB[q][1], true)) m |= 1 << q;
+      }
+    inm[c] = (uint8_t)m;
+  }
+  __syncthreads();
+  if (tid < 9) {
+    const int dx = tid == 0 ? 0 : AG_NB[tid - 1][0], dy = tid == 0 ? 0 : AG_NB[tid - 1][1];
+    if (tid == 0 || ag_valid(cls, n, NG, cx, cy, dx, dy, false)) cls[(cx + dx) * NG + cy + dy] |= AG_EFF;
+  }
   const double W_DIAG = sqrt(2.0);
   for (int sweep = 0; sweep < 4 * G2; ++sweep) {
     if (tid == 0) sh_changed = 0;
     __syncthreads();
     bool any = false;
     for (int c = tid; c < G2; c += nth) {
+      const int m = inm[c];
+      if (m == 0) continue;
       const int x = c / NG, y = c - x * NG;
-      if (x >= n || y >= n) continue;
-      const int cn = cls[c];
-      if ((cn & AG_WALL) && (cn & AG_KNOWN)) continue;          // nobody steps onto a known wall
+      const bool known = cls[c] & AG_KNOWN;
+      const double w_s = known ? 1.0 : 10 + 1.0, w_d = known ? W_DIAG : 10 + W_DIAG;
       double best = cost[c];
       bool better = false;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int dx = AG_NB[q][0], dy = AG_NB[q][1];
-        const int ox = x - dx, oy = y - dy;                     // the neighbour this cell is reached from
-        if (ox < 0 || ox >= n || oy < 0 || oy >= n) continue;
-        if (dx * dy != 0) {
-          const int a = cls[x * NG + oy], b = cls[ox * NG + y];
-          if ((a & AG_WALL) || (b & AG_WALL) || !(a & AG_KNOWN) || !(b & AG_KNOWN)) continue;
+      for (int q = 0; q < 8; ++q)
+        if (m & (1 << q)) {
+          const double cand = cost[(x - AG_NB[q][0]) * NG + (y - AG_NB[q][1])] + (q < 4 ? w_s : w_d);
+          if (best > cand) { best = cand; better = true; }
         }
-        const double dc = dx * dy == 0 ? 1.0 : W_DIAG;
-        const double w = (cn & AG_KNOWN) ? dc : 10 + dc;
-        const double cand = cost[ox * NG + oy] + w;
-        if (best > cand) { best = cand; better = true; }
-      }
       if (better) { cost[c] = best; any = true; }
     }
     if (any) sh_changed = 1;
@@ -249,6 +263,26 @@ __global__ __launch_bounds__(256) void maze_agent_kernel(MazeArgs P, AgentArgs A
     if (!sh_changed) break;
     __syncthreads();
   }
+  // retrieve_path's choice at every cell (:186-199): among the valid steps to cells cheaper than this one (and below 1e4),
+  // the first strictly smallest in neighbour order
+  for (int c = tid; c < G2; c += nth) {
+    const int x = c / NG, y = c - x * NG;
+    int best = -1;
+    if (x < n && y < n) {
+      double min_cost = cost[c];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int nx = x + AG_NB[q][0], ny = y + AG_NB[q][1];
+        if (nx < 0 || nx >= n || ny < 0 || ny >= n) continue;
+        if (!(inm[nx * NG + ny] & (1 << q))) continue;         // the step c -> (nx, ny) is the edge into (nx, ny) from c
+        const double cv = cost[nx * NG + ny];
+        if (cv > 1.0e+4) continue;
+        if (cv < min_cost) { min_cost = cv; best = nx * NG + ny; }
+      }
+    }
+    nxt[c] = (int16_t)best;
+  }
+  __syncthreads();
 
   // ---- target: navigate_landmarks_navigate (:223-230), else exploration (:213-221) ----
   const int idxc = P.cmd_idx[e] < P.n_cmd ? P.cmd_idx[e] : P.n_cmd - 1;
@@ -296,30 +330,15 @@ __global__ __launch_bounds__(256) void maze_agent_kernel(MazeArgs P, AgentArgs A
     if (goal >= 0) {
       const int gx = goal / NG, gy = goal - gx * NG;
       a0 = gx; a1 = gy;
-      double cur = cost[goal];
-      int sx = gx, sy = gy;
-      while (sx != cx || sy != cy) {
-        bool flag = false;                                    // reached a cell the agent can step to directly
-        if (sx == cx && sy == cy) flag = true;
-        for (int q = 0; q < 8; ++q)
-          if (sx == cx + AG_NB[q][0] && sy == cy + AG_NB[q][1] && ag_valid(cls, n, NG, cx, cy, AG_NB[q][0], AG_NB[q][1], false))
-            flag = true;
-        if (flag) break;
-        double min_cost = cur;
-        int mx = -1, my = -1;
-        for (int q = 0; q < 8; ++q) {
-          if (!ag_valid(cls, n, NG, sx, sy, AG_NB[q][0], AG_NB[q][1], true)) continue;
-          const int nx = sx + AG_NB[q][0], ny = sy + AG_NB[q][1];
-          const double cv = cost[nx * NG + ny];
-          if (cv > 1.0e+4) continue;
-          if (cv < min_cost) { min_cost = cv; mx = nx; my = ny; }
-        }
-        if (mx > -1) {
-          sx = mx; sy = my;
-          c0 = b0; c1 = b1; b0 = a0; b1 = a1; a0 = sx; a1 = sy;
-          ++len;
-          cur = cost[sx * NG + sy];
-        } else break;
+      int sel = goal;
+      const int cur_cell = cx * NG + cy;
+      while (sel != cur_cell) {
+        if (cls[sel] & AG_EFF) break;                         // a cell the agent can step to directly
+        const int p = nxt[sel];
+        if (p < 0) break;
+        sel = p;
+        c0 = b0; c1 = b1; b0 = a0; b1 = a1; a0 = sel / NG; a1 = sel - a0 * NG;
+        ++len;
       }
       if (len > 2) {
         const double dx = a0 + 0.5 - gf0, dy = a1 + 0.5 - gf1;
@@ -465,8 +484,10 @@ extern "C" int xv_maze_agent_act(xv_maze_agent* g, const uint8_t* exposed_inject
   eng->tick += 1;
   const MazeArgs& m = g->env->a;
   const size_t G2 = (size_t)m.NG * m.NG;
-  const size_t lds = G2 * 8 + (size_t)a.words * 8 + ((G2 + 15) & ~(size_t)15);
-  hipLaunchKernelGGL(maze_agent_kernel, dim3(m.n_env), dim3(256), lds, eng->stream, m, a, exposed_inject, action);
+  const size_t lds = G2 * 8 + (size_t)a.words * 8 + 2 * G2 + 2 + 2 * G2 + 16;
+  // small mazes: one wave per env (its barriers cost nothing and four times as many envs are resident per CU)
+  const int threads = G2 <= 1024 ? 64 : 256;
+  hipLaunchKernelGGL(maze_agent_kernel, dim3(m.n_env), dim3(threads), lds, eng->stream, m, a, exposed_inject, action);
   XV_LAUNCH_CHECK();
   return XV_OK;
 }
