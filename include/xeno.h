@@ -35,7 +35,7 @@ extern "C" {
 /* 2: AnyMDP rows are records of 128-byte lines (fence line + 7-entry blocks), completed in place by
  *    xv_anymdp_create; xv_maze_tables carries the texture-library sizes; Acrobot family; command-table and
  *    graph-replay switches
- * 4: xv_linds_rollout; the maze teachers (xv_maze_agent_*) */
+ * 4: xv_linds_rollout, xv_cartpole_rollout, xv_acrobot_rollout; the maze teachers (xv_maze_agent_*) */
 #define XV_ABI_VERSION 4
 
 /* return codes */
@@ -391,6 +391,10 @@ int xv_cartpole_reset_injected(xv_cartpole* h, const uint8_t* mask, const double
                                float* obs);
 int xv_cartpole_step(xv_cartpole* h, const int32_t* action, float* obs, float* reward, uint8_t* terminated,
                      uint8_t* truncated, float* final_obs, int autoreset_mode);
+/* T steps in one launch, the state in registers between them: action int32[T][n_env], outputs with a leading T
+ * (obs float[T][n_env][4] ...); equals T calls of xv_cartpole_step (step t draws with the tick the t-th call would) */
+int xv_cartpole_rollout(xv_cartpole* h, int T, const int32_t* action, float* obs, float* reward, uint8_t* terminated,
+                        uint8_t* truncated, float* final_obs, int autoreset_mode);
 int xv_cartpole_step_injected(xv_cartpole* h, const int32_t* action, const double* u_reset, float* obs,
                               float* reward, uint8_t* terminated, uint8_t* truncated, float* final_obs,
                               int autoreset_mode);
@@ -418,6 +422,9 @@ int xv_acrobot_reset(xv_acrobot* h, const uint8_t* mask, float* obs /*[n_env][6]
 int xv_acrobot_reset_injected(xv_acrobot* h, const uint8_t* mask, const double* u /*[4][n_env] in [0,1)*/, float* obs);
 int xv_acrobot_step(xv_acrobot* h, const int32_t* action, float* obs, float* reward, uint8_t* terminated,
                     uint8_t* truncated, float* final_obs, int autoreset_mode);
+/* T steps in one launch, as xv_cartpole_rollout: action int32[T][n_env], obs float[T][n_env][6] ... */
+int xv_acrobot_rollout(xv_acrobot* h, int T, const int32_t* action, float* obs, float* reward, uint8_t* terminated,
+                       uint8_t* truncated, float* final_obs, int autoreset_mode);
 int xv_acrobot_step_injected(xv_acrobot* h, const int32_t* action, const double* u_reset, float* obs, float* reward,
                              uint8_t* terminated, uint8_t* truncated, float* final_obs, int autoreset_mode);
 int xv_acrobot_get_state(xv_acrobot* h, double* state /*[4][n_env]*/, int32_t* steps, uint8_t* need_reset);

@@ -92,12 +92,18 @@ def bench_cartpole(args):
                                             _lib.ptr(env._term), _lib.ptr(env._trunc), _lib.ptr(env._fobs),
                                             AUTORESET["same_step"]))
     us = timed(step, args.steps, args.warmup)
+    T = 64
+    aT = torch.randint(0, 2, (T, n), device=env.device, dtype=torch.int32)
+    ro = env.rollout(aT)
+    us_roll = timed(lambda: env.rollout(aT, out=ro), max(args.steps // T, 5), 2) / T
     env.close()
     algo = 74 * n
     return {"family": "cartpole", "workload": "65,536 envs, 1,024 tasks, frameskip 1", "dtype": "f32",
-            "env_steps_per_s": n / (us * 1e-6), "us_per_step": us,
+            "env_steps_per_s": n / (us * 1e-6), "us_per_step": us, "rollout_T64_us_per_step": us_roll,
+            "rollout_env_steps_per_s": n / (us_roll * 1e-6),
             "roofline": {"bound": "hbm", "achieved": algo / (us * 1e-6) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
-                         "frac": algo / (us * 1e-6) / 1e9 / HBM_PEAK, "algorithmic_bytes_per_env_step": 74,
+                         "frac": algo / (us * 1e-6) / 1e9 / HBM_PEAK, "frac_rollout": algo / (us_roll * 1e-6) / 1e9 / HBM_PEAK,
+                         "algorithmic_bytes_per_env_step": 74,
                          "note": "4.8 MB per launch: launch-latency bound, not bandwidth bound"}}
 
 
@@ -118,11 +124,17 @@ def bench_acrobot(args):
                                                _lib.ptr(env._term), _lib.ptr(env._trunc), _lib.ptr(env._fobs),
                                                AUTORESET["same_step"]))
         out[fs] = timed(step, args.steps, args.warmup)
+        if fs == 1:
+            T = 64
+            aT = torch.randint(0, 3, (T, n), device=env.device, dtype=torch.int32)
+            ro = env.rollout(aT)
+            us_roll = timed(lambda: env.rollout(aT, out=ro), max(args.steps // T, 5), 2) / T
         env.close()
     algo = (64 + 4 + 24 + 4 + 2 + 24 + 56) * n      # fp64 state r/w, action, obs, reward, flags, final_obs, task params
     us = out[1]
     return {"family": "acrobot", "workload": "65,536 envs, 1,024 tasks, rk4 in fp64", "dtype": "f64",
-            "env_steps_per_s": n / (us * 1e-6), "us_per_step": {"frameskip 1": out[1], "frameskip 5": out[5]},
+            "env_steps_per_s": n / (us * 1e-6), "us_per_step": {"frameskip 1": out[1], "frameskip 5": out[5], "rollout_T64 frameskip 1": us_roll},
+            "rollout_env_steps_per_s": n / (us_roll * 1e-6),
             "roofline": {"bound": "hbm", "achieved": algo / (us * 1e-6) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
                          "frac": algo / (us * 1e-6) / 1e9 / HBM_PEAK, "algorithmic_bytes_per_env_step": algo // n,
                          "note": "11 MB per launch; 4 dsdt evaluations (8 fp64 sin/cos) per sub-step: latency / "

@@ -111,3 +111,35 @@ def test_free_running_philox_and_misuse():
     env.step(np.full(n, 7, np.int32))
     assert env.check_errors() & 1            # action out of range
     env.close()
+
+
+@pytest.mark.parametrize("mode", ["same_step", "next_step"])
+def test_fused_rollout_equals_single_steps(mode):
+    """xv_acrobot_rollout: T steps in one launch = T calls of xv_acrobot_step bit for bit, through episode ends"""
+    n, T = 600, 90
+    tasks = [sample_acrobot(seed=k) for k in range(40)]
+    env_task = np.arange(n) % 40
+    acts = np.random.RandomState(1).randint(0, 3, (T, n)).astype(np.int32)
+    recs = []
+    for fused in (False, True):
+        env = AcrobotVecEnv(n, frameskip=2, seed=9, env_id_base=40, autoreset_mode=mode, max_steps=20)
+        env.set_task(tasks, env_task_index=env_task)
+        env.reset()
+        if fused:
+            a = env.rollout(acts[:40]); b = env.rollout(acts[40:])
+            rec = {k: np.concatenate([_np(a[k]), _np(b[k])]) for k in a}
+        else:
+            rows = []
+            for t in range(T):
+                o, r, te, tr, info = env.step(acts[t])
+                rows.append(dict(obs=_np(o), reward=_np(r), terminated=_np(te).astype(np.uint8),
+                                 truncated=_np(tr).astype(np.uint8), final_obs=_np(info["final_obs"]) if "final_obs" in info
+                                 else None))
+            rec = {k: np.stack([row[k] for row in rows]) for k in rows[0] if rows[0][k] is not None}
+        st = env.get_state()
+        rec.update(state=_np(st[0]), steps=_np(st[1]), tick=np.int64(env.engine.tick))
+        recs.append(rec)
+        env.close()
+    assert recs[0]["truncated"].sum() > 0
+    for k in recs[0]:
+        assert np.array_equal(recs[0][k], recs[1][k]), k

@@ -79,3 +79,35 @@ def test_free_running_and_fp64_equations():
         s, st, nr = env.get_state()
         ora.state[:] = _np(s); ora.steps[:] = _np(st)
     env.close()
+
+
+@pytest.mark.parametrize("mode", ["same_step", "next_step"])
+def test_fused_rollout_equals_single_steps(mode):
+    """xv_cartpole_rollout: T steps in one launch = T calls of xv_cartpole_step bit for bit, through episode ends"""
+    n, T = 1000, 120
+    tasks = [sample_cartpole(seed=k) for k in range(50)]
+    env_task = np.arange(n) % 50
+    acts = np.random.RandomState(1).randint(0, 2, (T, n)).astype(np.int32)
+    recs = []
+    for fused in (False, True):
+        env = CartPoleVecEnv(n, frameskip=2, seed=9, env_id_base=40, autoreset_mode=mode, max_steps=30)
+        env.set_task(tasks, env_task_index=env_task)
+        env.reset()
+        if fused:
+            a = env.rollout(acts[:50]); b = env.rollout(acts[50:])
+            rec = {k: np.concatenate([_np(a[k]), _np(b[k])]) for k in a}
+        else:
+            rows = []
+            for t in range(T):
+                o, r, te, tr, info = env.step(acts[t])
+                rows.append(dict(obs=_np(o), reward=_np(r), terminated=_np(te).astype(np.uint8),
+                                 truncated=_np(tr).astype(np.uint8), final_obs=_np(info["final_obs"]) if "final_obs" in info
+                                 else None))
+            rec = {k: np.stack([row[k] for row in rows]) for k in rows[0] if rows[0][k] is not None}
+        st = env.get_state()
+        rec.update(state=_np(st[0]), steps=_np(st[1]), tick=np.int64(env.engine.tick))
+        recs.append(rec)
+        env.close()
+    assert recs[0]["terminated"].sum() > 0 and recs[0]["truncated"].sum() > 0
+    for k in recs[0]:
+        assert np.array_equal(recs[0][k], recs[1][k]), k

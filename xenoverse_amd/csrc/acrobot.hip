@@ -83,14 +83,14 @@ __device__ __forceinline__ void acrobot_obs(const double (&s)[4], bool f32, floa
 }
 
 template <bool INJECT>
-__device__ __forceinline__ void acrobot_reset_state(const AcrobotArgs& P, const double* u_in, int i, double (&s)[4]) {
+__device__ __forceinline__ void acrobot_reset_state(const AcrobotArgs& P, const double* u_in, int i, uint64_t tick, double (&s)[4]) {
   double u[4];
   if (INJECT) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) u[k] = u_in[(size_t)k * P.n_env + i];
   } else {
-    const xv_u32x4 w = xv_env_draw(P.seed, P.gid_base + (uint64_t)i, P.tick, XV_DRAW_RESET);
-    const xv_u32x4 v = xv_env_draw(P.seed, P.gid_base + (uint64_t)i, P.tick, 3u);
+    const xv_u32x4 w = xv_env_draw(P.seed, P.gid_base + (uint64_t)i, tick, XV_DRAW_RESET);
+    const xv_u32x4 v = xv_env_draw(P.seed, P.gid_base + (uint64_t)i, tick, 3u);
     u[0] = xv_u53(w.x, w.y); u[1] = xv_u53(w.z, w.w); u[2] = xv_u53(v.x, v.y); u[3] = xv_u53(v.z, v.w);
   }
   // state = uniform(-1, 1, 4).astype(float32) * reset_bounds_scale   (:123-125)
@@ -107,7 +107,8 @@ __device__ __forceinline__ void acrobot_store_obs(float* dst, const float (&o)[6
 }
 
 template <bool INJECT>
-__global__ __launch_bounds__(64) void acrobot_step_kernel(AcrobotArgs P, AcrobotIO io, int mode) {
+__global__ __launch_bounds__(64) void acrobot_step_kernel(AcrobotArgs P, AcrobotIO io, int mode, int T) {
+  // T steps per launch (xv_acrobot_rollout; T = 1 for xv_acrobot_step), state in registers, step ts draws with tick + ts
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
   const size_t N = (size_t)P.n_env;
@@ -115,18 +116,20 @@ __global__ __launch_bounds__(64) void acrobot_step_kernel(AcrobotArgs P, Acrobot
   int steps = P.steps[i];
   int nr = P.need_reset[i];
   int fresh = P.fresh[i];
-  int action = io.action[i];
+  uint32_t err = 0;
   const double* prm = P.params + (size_t)P.env_task[i] * 7;
   AcrobotTask K;
   K.l1 = prm[0]; K.m1 = prm[2]; K.m2 = prm[3]; K.lc1 = prm[4]; K.lc2 = prm[5]; K.g = prm[6];
   const double l2 = prm[1];
   K.I1 = K.m1 * (K.lc1 * K.lc1 + (K.l1 - K.lc1) * (K.l1 - K.lc1)) / 6.0;
   K.I2 = K.m2 * (K.lc2 * K.lc2 + (l2 - K.lc2) * (l2 - K.lc2)) / 6.0;
+  for (int ts = 0; ts < T; ++ts) {
+  const size_t ob = (size_t)ts * N + i;
+  int action = io.action[ob];
   float reward = 0.0f;
   int term = 0, trunc = 0;
   float fobs[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   bool do_reset = false;
-  uint32_t err = 0;
   if (mode == XV_AUTORESET_NEXT_STEP && nr) {
     do_reset = true;
   } else {
@@ -176,22 +179,23 @@ __global__ __launch_bounds__(64) void acrobot_step_kernel(AcrobotArgs P, Acrobot
     }
   }
   if (do_reset) {
-    acrobot_reset_state<INJECT>(P, io.u_reset, i, s);
+    acrobot_reset_state<INJECT>(P, io.u_reset, i, P.tick + (uint64_t)ts, s);
     fresh = 1;
     steps = 0;
     nr = 0;
+  }
+  float o[6];
+  acrobot_obs(s, fresh && !P.scale_is_vector, o);
+  acrobot_store_obs(io.obs + ob * 6, o);
+  io.reward[ob] = reward;
+  io.terminated[ob] = (uint8_t)term;
+  io.truncated[ob] = (uint8_t)trunc;
+  if (io.final_obs) acrobot_store_obs(io.final_obs + ob * 6, fobs);
   }
   P.state[i] = s[0]; P.state[N + i] = s[1]; P.state[2 * N + i] = s[2]; P.state[3 * N + i] = s[3];
   P.steps[i] = steps;
   P.need_reset[i] = (uint8_t)nr;
   P.fresh[i] = (uint8_t)fresh;
-  float o[6];
-  acrobot_obs(s, fresh && !P.scale_is_vector, o);
-  acrobot_store_obs(io.obs + (size_t)i * 6, o);
-  io.reward[i] = reward;
-  io.terminated[i] = (uint8_t)term;
-  io.truncated[i] = (uint8_t)trunc;
-  if (io.final_obs) acrobot_store_obs(io.final_obs + (size_t)i * 6, fobs);
   if (err) atomicOr(P.err, err);
 }
 
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(64) void acrobot_reset_kernel(AcrobotArgs P, const 
   if (mask && !mask[i]) return;
   const size_t N = (size_t)P.n_env;
   double s[4];
-  acrobot_reset_state<INJECT>(P, u, i, s);
+  acrobot_reset_state<INJECT>(P, u, i, P.tick, s);
   P.state[i] = s[0]; P.state[N + i] = s[1]; P.state[2 * N + i] = s[2]; P.state[3 * N + i] = s[3];
   P.steps[i] = 0;
   P.need_reset[i] = 0;
@@ -298,7 +302,19 @@ extern "C" int xv_acrobot_step(xv_acrobot* h, const int32_t* action, float* obs,
   acrobot_bind_rng(h, 1);
   AcrobotIO io{action, nullptr, obs, reward, terminated, truncated, final_obs};
   hipLaunchKernelGGL(acrobot_step_kernel<false>, dim3(xv_div_up(h->a.n_env, 64)), dim3(64), 0, h->eng->stream, h->a, io,
-                     autoreset_mode);
+                     autoreset_mode, 1);
+  XV_LAUNCH_CHECK();
+  return XV_OK;
+}
+
+extern "C" int xv_acrobot_rollout(xv_acrobot* h, int T, const int32_t* action, float* obs, float* reward,
+                                  uint8_t* terminated, uint8_t* truncated, float* final_obs, int autoreset_mode) {
+  XV_CHECK_ARG(h && action && obs && reward && terminated && truncated && T > 0);
+  XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
+  acrobot_bind_rng(h, (uint64_t)T);
+  AcrobotIO io{action, nullptr, obs, reward, terminated, truncated, final_obs};
+  hipLaunchKernelGGL(acrobot_step_kernel<false>, dim3(xv_div_up(h->a.n_env, 64)), dim3(64), 0, h->eng->stream, h->a, io,
+                     autoreset_mode, T);
   XV_LAUNCH_CHECK();
   return XV_OK;
 }
@@ -311,7 +327,7 @@ extern "C" int xv_acrobot_step_injected(xv_acrobot* h, const int32_t* action, co
   acrobot_bind_rng(h, 0);
   AcrobotIO io{action, u_reset, obs, reward, terminated, truncated, final_obs};
   hipLaunchKernelGGL(acrobot_step_kernel<true>, dim3(xv_div_up(h->a.n_env, 64)), dim3(64), 0, h->eng->stream, h->a, io,
-                     autoreset_mode);
+                     autoreset_mode, 1);
   XV_LAUNCH_CHECK();
   return XV_OK;
 }

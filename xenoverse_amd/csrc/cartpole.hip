@@ -41,12 +41,12 @@ struct xv_cartpole {
 struct CpState { double x, xd, th, thd; };
 
 template <bool INJECT>
-__device__ __forceinline__ CpState cartpole_reset_state(const CartPoleArgs& P, const double* u_in, int i) {
+__device__ __forceinline__ CpState cartpole_reset_state(const CartPoleArgs& P, const double* u_in, int i, uint64_t tick) {
   double u0, u1, u2, u3;
   if (INJECT) {
     u0 = u_in[i]; u1 = u_in[(size_t)P.n_env + i]; u2 = u_in[(size_t)2 * P.n_env + i]; u3 = u_in[(size_t)3 * P.n_env + i];
   } else {
-    const xv_u32x4 w = xv_env_draw(P.seed, P.gid_base + (uint64_t)i, P.tick, XV_DRAW_RESET);
+    const xv_u32x4 w = xv_env_draw(P.seed, P.gid_base + (uint64_t)i, tick, XV_DRAW_RESET);
     u0 = (double)w.x * (1.0 / 4294967296.0); u1 = (double)w.y * (1.0 / 4294967296.0);
     u2 = (double)w.z * (1.0 / 4294967296.0); u3 = (double)w.w * (1.0 / 4294967296.0);
   }
@@ -56,20 +56,24 @@ __device__ __forceinline__ CpState cartpole_reset_state(const CartPoleArgs& P, c
 }
 
 template <bool INJECT>
-__global__ __launch_bounds__(256) void cartpole_step_kernel(CartPoleArgs P, CartPoleIO io, int mode) {
+__global__ __launch_bounds__(256) void cartpole_step_kernel(CartPoleArgs P, CartPoleIO io, int mode, int T) {
+  // T steps per launch (xv_cartpole_rollout; T = 1 for xv_cartpole_step): the state stays in registers, step ts reads
+  // action[ts][i], writes row ts of the outputs and draws with tick + ts — the same values as T launches of one step
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
   const size_t N = (size_t)P.n_env;
   double x = P.state[i], xd = P.state[N + i], th = P.state[2 * N + i], thd = P.state[3 * N + i];
   int steps = P.steps[i];
   int nr = P.need_reset[i];
-  int action = io.action[i];
   const double* prm = P.params + (size_t)P.env_task[i] * 4;
+  uint32_t err = 0;
+  for (int ts = 0; ts < T; ++ts) {
+  const size_t o = (size_t)ts * N + i;
+  int action = io.action[o];
   float reward = 0.0f;
   int term = 0, trunc = 0;
   float4 fobs = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   bool do_reset = false;
-  uint32_t err = 0;
   if (mode == XV_AUTORESET_NEXT_STEP && nr) {
     do_reset = true;
   } else {
@@ -109,19 +113,20 @@ __global__ __launch_bounds__(256) void cartpole_step_kernel(CartPoleArgs P, Cart
     }
   }
   if (do_reset) {
-    const CpState s0 = cartpole_reset_state<INJECT>(P, io.u_reset, i);
+    const CpState s0 = cartpole_reset_state<INJECT>(P, io.u_reset, i, P.tick + (uint64_t)ts);
     x = s0.x; xd = s0.xd; th = s0.th; thd = s0.thd;
     steps = 0;
     nr = 0;
   }
+  reinterpret_cast<float4*>(io.obs)[o] = make_float4((float)x, (float)xd, (float)th, (float)thd);   // the float32 cast of :75
+  io.reward[o] = reward;
+  io.terminated[o] = (uint8_t)term;
+  io.truncated[o] = (uint8_t)trunc;
+  if (io.final_obs) reinterpret_cast<float4*>(io.final_obs)[o] = fobs;
+  }
   P.state[i] = x; P.state[N + i] = xd; P.state[2 * N + i] = th; P.state[3 * N + i] = thd;
   P.steps[i] = steps;
   P.need_reset[i] = (uint8_t)nr;
-  reinterpret_cast<float4*>(io.obs)[i] = make_float4((float)x, (float)xd, (float)th, (float)thd);   // the float32 cast of :75
-  io.reward[i] = reward;
-  io.terminated[i] = (uint8_t)term;
-  io.truncated[i] = (uint8_t)trunc;
-  if (io.final_obs) reinterpret_cast<float4*>(io.final_obs)[i] = fobs;
   if (err) atomicOr(P.err, err);
 }
 
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) void cartpole_reset_kernel(CartPoleArgs P, con
   if (i >= P.n_env) return;
   if (mask && !mask[i]) return;
   const size_t N = (size_t)P.n_env;
-  const CpState s0 = cartpole_reset_state<INJECT>(P, u, i);
+  const CpState s0 = cartpole_reset_state<INJECT>(P, u, i, P.tick);
   P.state[i] = s0.x; P.state[N + i] = s0.xd; P.state[2 * N + i] = s0.th; P.state[3 * N + i] = s0.thd;
   P.steps[i] = 0;
   P.need_reset[i] = 0;
@@ -228,7 +233,19 @@ extern "C" int xv_cartpole_step(xv_cartpole* h, const int32_t* action, float* ob
   cartpole_bind_rng(h, 1);
   CartPoleIO io{action, nullptr, obs, reward, terminated, truncated, final_obs};
   hipLaunchKernelGGL(cartpole_step_kernel<false>, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
-                     h->a, io, autoreset_mode);
+                     h->a, io, autoreset_mode, 1);
+  XV_LAUNCH_CHECK();
+  return XV_OK;
+}
+
+extern "C" int xv_cartpole_rollout(xv_cartpole* h, int T, const int32_t* action, float* obs, float* reward,
+                                   uint8_t* terminated, uint8_t* truncated, float* final_obs, int autoreset_mode) {
+  XV_CHECK_ARG(h && action && obs && reward && terminated && truncated && T > 0);
+  XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
+  cartpole_bind_rng(h, (uint64_t)T);
+  CartPoleIO io{action, nullptr, obs, reward, terminated, truncated, final_obs};
+  hipLaunchKernelGGL(cartpole_step_kernel<false>, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
+                     h->a, io, autoreset_mode, T);
   XV_LAUNCH_CHECK();
   return XV_OK;
 }
@@ -241,7 +258,7 @@ extern "C" int xv_cartpole_step_injected(xv_cartpole* h, const int32_t* action, 
   cartpole_bind_rng(h, 0);
   CartPoleIO io{action, u_reset, obs, reward, terminated, truncated, final_obs};
   hipLaunchKernelGGL(cartpole_step_kernel<true>, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
-                     h->a, io, autoreset_mode);
+                     h->a, io, autoreset_mode, 1);
   XV_LAUNCH_CHECK();
   return XV_OK;
 }

@@ -124,6 +124,25 @@ class CartPoleVecEnv(VectorEnv):
                                              AUTORESET[self.autoreset_mode]))
         return self._ret()
 
+    def rollout(self, actions, out=None):
+        """Fused open-loop roll-out: actions int32[T, N] -> dict of [T, N(, 4)] device tensors from one launch with the
+        state in registers between the steps; equals T calls of step() bit for bit."""
+        if (not self.task_set) or self.need_reset:
+            raise Exception("Must \"set_task\" and \"reset\" before doing any actions")
+        a = self._dev(actions, torch.int32).contiguous()
+        T, n, d = int(a.shape[0]), self.num_envs, self.device
+        assert a.shape == (T, n)
+        if out is None:
+            out = dict(obs=torch.empty((T, n, 4), dtype=torch.float32, device=d),
+                       reward=torch.empty((T, n), dtype=torch.float32, device=d),
+                       terminated=torch.empty((T, n), dtype=torch.uint8, device=d),
+                       truncated=torch.empty((T, n), dtype=torch.uint8, device=d),
+                       final_obs=torch.empty((T, n, 4), dtype=torch.float32, device=d))
+        _lib.check(self.lib.xv_cartpole_rollout(self._h, T, _lib.ptr(a), _lib.ptr(out["obs"]), _lib.ptr(out["reward"]),
+                                          _lib.ptr(out["terminated"]), _lib.ptr(out["truncated"]),
+                                          _lib.ptr(out.get("final_obs")), AUTORESET[self.autoreset_mode]))
+        return out
+
     def step_injected(self, actions, u_reset):
         a = self._dev(actions, torch.int32)
         u = self._dev(u_reset, torch.float64)
