@@ -499,6 +499,14 @@ int xv_maze_set_move_kernel(xv_maze* h, int kernel);
 #define XV_MAZE_FILTER_EXACT 0
 #define XV_MAZE_FILTER_F32 1
 int xv_maze_set_precision(xv_maze* h, int filter);
+/* Which typing of the reference's ray-caster source the frames follow.  NUMPY2 (default): its @njit functions run as plain
+ * Python under NumPy >= 2 (Python floats are weak, so DDA_2D and the wall-column geometry stay in the float32 of the
+ * per-column tables) — the typing the golden frames were generated with.  NUMBA: the types numba infers for the same
+ * source (float32 op float64 -> float64: DDA_2D and the wall-column geometry in float64).  The two differ on 0.06 % of
+ * the frame values (tests/test_oracle_maze.py); NUMBA is unpinned (numba is not installed in the build container). */
+#define XV_MAZE_TYPING_NUMPY2 0
+#define XV_MAZE_TYPING_NUMBA 1
+int xv_maze_set_typing(xv_maze* h, int typing);
 
 /* ---------------------------------------------------------------------------------------------
  * MazeWorld rule-based teachers — reference: xenoverse/mazeworld/agents

@@ -491,10 +491,12 @@ class MazeOracle(object):
         lib().xo_maze_step(C.byref(self._h), _p(a), _p(r), _p(te), _p(tr), C.c_int(mode))
         return r, te, tr
 
-    def render(self, n_threads=1):
+    def render(self, n_threads=1, typing="stub"):
+        """typing "stub": the reference's source as plain Python under NumPy 2 (the pinned one); "numba": DDA and
+        wall-column geometry in float64, as numba types the same source (unpinned)"""
         f = np.zeros((self.n_env, self.W, self.H, 3), np.uint8)
         c = np.zeros((self.n_env, 3), np.float32)
-        lib().xo_maze_render(C.byref(self._h), _p(f), _p(c), C.c_int(n_threads))
+        lib().xo_maze_render_typed(C.byref(self._h), _p(f), _p(c), C.c_int(n_threads), C.c_int(typing == "numba"))
         return f, c
 
     def expose(self, seed, gid_base, tick, prob=0.05):

@@ -1022,7 +1022,7 @@ static inline int32_t mz_clip_int(double v) { /* numpy.clip(v, 0, 255) stored in
 /* maze_view, ray_caster_utils.py:142-320, for one env.  Typing follows the reference as it executes under
  * NumPy >= 2 scalar promotion (python floats are weak): per-column tables are float32, DDA_2D runs entirely
  * in float32 (its python-float operands are weak), floor/ceiling/texture math is float64. */
-static void mz_view(const xo_maze* h, int e, int32_t* rgb /*[W][H][3]*/) {
+static void mz_view(const xo_maze* h, int e, int32_t* rgb /*[W][H][3]*/, int typing_f64) {
   const int t = h->env_task[e], W = h->W, H = h->H, NG = h->NG, N = h->n_env;
   const int32_t* in = h->ints + (size_t)t * 8;
   const double* db = h->dbl + (size_t)t * 8;
@@ -1115,89 +1115,24 @@ static void mz_view(const xo_maze* h, int e, int32_t* rgb /*[W][H][3]*/) {
       }
     }
   }
-  const float cs_f = (float)cell_size, eps_f = (float)1.0e-8, vis_f = (float)visibility, lf_f = (float)l_focal;
+  const float cs_f = (float)cell_size;
   for (int d_h = 0; d_h < W; ++d_h) { /* walls :247-318 */
-    const int i0 = (int)(pos[0] / cs_f), j0 = (int)(pos[1] / cs_f);
-    /* ---- DDA_2D :47-115, float32 ---- */
-    const float co = cos_abs[d_h], so = sin_abs[d_h];
-    const float c_sign = co < 0 ? -1.0f : 1.0f, s_sign = so < 0 ? -1.0f : 1.0f;
-    const float ddx = fabsf(co) < eps_f ? fabsf(cs_f / eps_f) : fabsf(cs_f / co);
-    const float ddy = fabsf(so) < eps_f ? fabsf(cs_f / eps_f) : fabsf(cs_f / so);
-    const float d_x = co > 0 ? ((float)((i0 + 1) * cell_size) - pos[0]) : ((float)(i0 * cell_size) - pos[0]);
-    const float d_y = so > 0 ? ((float)((j0 + 1) * cell_size) - pos[1]) : ((float)(j0 * cell_size) - pos[1]);
-    float sdx = fabsf(co) < eps_f ? c_sign * (d_x / eps_f) : d_x / co;
-    float sdy = fabsf(so) < eps_f ? s_sign * (d_y / eps_f) : d_y / so;
-    const int di = co > 0 ? 1 : -1, dj = so > 0 ? 1 : -1;
-    int hi = i0, hj = j0, hit_side = 0, n_tr = 0;
-    float hit_dist = 0.0f;
-    float tr_dist[64];
-    int tr_id[64];
-    while (hit_dist < vis_f) {
-      if (sdx < sdy) {
-        hi += di; sdy -= sdx; hit_dist += sdx;
-        if (transp[hi * NG + hj] > -1 && n_tr < 64) { tr_dist[n_tr] = hit_dist; tr_id[n_tr++] = transp[hi * NG + hj]; }
-        if (hi < 0 || hi >= n) { if (hj < 0 || hj >= n) { hit_dist = 1.0e+6f; break; } }
-        else if (walls[hi * NG + hj] > 0) { hit_side = 0; break; }
-        sdx = ddx;
-      } else {
-        hj += dj; sdx -= sdy; hit_dist += sdy;
-        if (transp[hi * NG + hj] > -1 && n_tr < 64) { tr_dist[n_tr] = hit_dist; tr_id[n_tr++] = transp[hi * NG + hj]; }
-        if (hi < 0 || hi >= n) { if (hj < 0 || hj >= n) { hit_dist = 1.0e+6f; break; } }
-        else if (walls[hi * NG + hj] > 0) { hit_side = 1; break; }
-        sdy = ddy;
-      }
-    }
-    /* ---- wall column :258-298 ---- */
-    float alpha = 2.0f * hit_dist / vis_f - 1.0f;
-    if (alpha < 0.0f) alpha = 0.0f;
-    if (alpha > 1.0f) alpha = 1.0f;
-    const int text_id = texts[hi * NG + hj];
-    const float hit_pt_x = hit_dist * co + pos[0], hit_pt_y = hit_dist * so + pos[1];
-    float local_h, light;
-    if (hit_side == 0) { local_h = hit_pt_y / cs_f; local_h -= floorf(local_h); light = fabsf(co); }
-    else { local_h = hit_pt_x / cs_f; local_h -= floorf(local_h); light = fabsf(so); }
-    float ratio = hit_dist * cos_hp_a[d_h] / lf_f;
-    if (fabsf(ratio) < eps_f) ratio = ratio > 0 ? eps_f : -eps_f;
-    const float top_v = (float)(ceil_height - vision_height) / ratio, bot_v = (float)vision_height / ratio;
-    int v_s = (int)((half_v - (double)top_v) / pixel_size), v_e = (int)((half_v + (double)bot_v) / pixel_size);
-    if (v_s < 0) v_s = 0;
-    if (v_e > H) v_e = H;
-    const float* wt = h->tex_walls + (size_t)text_id * 256 * 256 * 3;
-    for (int d_v = v_s; d_v < v_e; ++d_v) {
-      const double local_v = (half_v - (d_v + 0.5) * pixel_size) * (double)ratio + vision_height;
-      float d_i = local_h * (float)percell;
-      double d_j = local_v / text_size;
-      d_i -= floorf(d_i); d_j -= floor(d_j);
-      const int ti = (int)(256.0f * d_i), tj = (int)(256 * d_j);
-      const double eff_ps = eff_distance * pixel_size / l_focal; /* stale eff_distance: quirk (i) */
-      double col[3];
-      mz_interpolate(wt, (double)ti, (double)tj, eff_ps, tps, tps, col);
-      int32_t* px = rgb + ((size_t)d_h * H + d_v) * 3;
-      for (int c = 0; c < 3; ++c) {
-        const double blend = (double)(float)(alpha * 1.0f) + (double)(1.0f - alpha) * col[c];
-        px[c] = mz_clip_int((double)light * blend);
-      }
-    }
-    /* ---- transparent landmark overlays, far to near :301-318 ---- */
-    for (int q = n_tr - 1; q >= 0; --q) {
-      const float hd = tr_dist[q];
-      float r2 = hd * cos_hp_a[d_h] / lf_f;
-      if (fabsf(r2) < eps_f) r2 = r2 > 0 ? eps_f : -eps_f;
-      const float tv = (float)(ceil_height - vision_height) / r2, bv = (float)vision_height / r2;
-      int s2 = (int)((half_v - (double)tv) / pixel_size), e2 = (int)((half_v + (double)bv) / pixel_size);
-      if (s2 < 0) s2 = 0;
-      if (e2 > H) e2 = H;
-      float a2 = 2.0f * hd / vis_f - 1.0f;
-      if (a2 < 0.0f) a2 = 0.0f;
-      if (a2 > 1.0f) a2 = 1.0f;
-      for (int d_v = s2; d_v < e2; ++d_v) {
-        int32_t* px = rgb + ((size_t)d_h * H + d_v) * 3;
-        for (int c = 0; c < 3; ++c) {
-          const float inner = (1.0f - a2) * MZ_LANDMARK_RGB[tr_id[q]][c] + a2 * 1.0f;
-          const float tinted = 0.30f * inner;
-          px[c] = mz_clip_int((1.0 - 0.30) * (double)px[c] + (double)tinted);
-        }
-      }
+    if (!typing_f64) {
+#define REAL float
+#define RFABS fabsf
+#define RFLOOR floorf
+#include "mz_wall_stage.inc"
+#undef REAL
+#undef RFABS
+#undef RFLOOR
+    } else {
+#define REAL double
+#define RFABS fabs
+#define RFLOOR floor
+#include "mz_wall_stage.inc"
+#undef REAL
+#undef RFABS
+#undef RFLOOR
     }
   }
   if (h->command_in_observation) { /* maze_continuous_3d.py:23-29,102-107 */
@@ -1281,6 +1216,10 @@ void xo_maze_expose(const xo_maze* h, uint64_t seed, uint64_t gid_base, uint64_t
 }
 
 void xo_maze_render(const xo_maze* h, uint8_t* frames, float* command_rgb, int n_threads) {
+  xo_maze_render_typed(h, frames, command_rgb, n_threads, 0);
+}
+
+void xo_maze_render_typed(const xo_maze* h, uint8_t* frames, float* command_rgb, int n_threads, int typing_f64) {
   const size_t fsz = (size_t)h->W * h->H * 3;
   (void)n_threads;
 #ifdef _OPENMP
@@ -1288,7 +1227,7 @@ void xo_maze_render(const xo_maze* h, uint8_t* frames, float* command_rgb, int n
 #endif
   for (int e = 0; e < h->n_env; ++e) {
     int32_t* rgb = (int32_t*)malloc(fsz * sizeof(int32_t));
-    mz_view(h, e, rgb);
+    mz_view(h, e, rgb, typing_f64);
     if (frames)
       for (size_t k = 0; k < fsz; ++k) frames[(size_t)e * fsz + k] = (uint8_t)rgb[k]; /* astype('uint8') :113 */
     free(rgb);

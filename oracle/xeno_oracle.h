@@ -238,6 +238,9 @@ void xo_maze_step(xo_maze* h, const double* action, float* reward, uint8_t* term
                   int mode);
 /* frames uint8[n_env][W][H][3] (maze_view + astype uint8); command RGB float[n_env][3] (info["command"]) */
 void xo_maze_render(const xo_maze* h, uint8_t* frames, float* command_rgb, int n_threads);
+/* typing_f64 != 0: DDA_2D and the wall-column geometry in float64, as numba types the reference's source (unpinned: numba
+ * is not installed here; used to measure the distance between the two typings) */
+void xo_maze_render_typed(const xo_maze* h, uint8_t* frames, float* command_rgb, int n_threads, int typing_f64);
 /* cell_exposed of maze_view (ray_caster_utils.py:153,250-255): uint8[n_env][NG][NG]; see xeno_oracle.c */
 void xo_maze_expose(const xo_maze* h, uint64_t seed, uint64_t gid_base, uint64_t tick, double prob, uint8_t* exposed);
 

@@ -603,8 +603,12 @@ __device__ __forceinline__ uint8_t mz_clip_u8(double v) {   // numpy.clip(v, 0, 
 // The frame is built in LDS in chunks of P.HC rows ([column][HC*3 + 4] bytes: the pad makes the per-lane byte
 // writes bank-conflict free) and each chunk leaves with 16-byte stores; a 64x64 frame is one chunk, the registered
 // 256x256 frame four chunks of 64 rows (49 KiB of LDS, three workgroups per CU).
-template <bool FINAL, bool PACKED, bool F32>
+// NB (xv_maze_set_typing(XV_MAZE_TYPING_NUMBA)): DDA_2D and the wall-column geometry in float64, the types numba infers
+// for the reference's source (float32 table entry op float64 -> float64); default float32 = the same source run as plain
+// Python under NumPy 2, which the golden frames were made with (oracle/mz_wall_stage.inc holds both, REAL = float / double).
+template <bool FINAL, bool PACKED, bool F32, bool NB>
 __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* frames, float* command_rgb) {
+  using RT = typename std::conditional<NB, double, float>::type;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int e = blockIdx.x;
   if (FINAL && !P.fin_flag[e]) return;   // block-uniform
@@ -659,7 +663,7 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
   // pixel the reference painted: last ceiling row within visibility (else last floor row), column W-1.
   // It depends on the pose-free screen geometry only, so every lane derives it (no exchange).
   const double cmh = ceil_height - vision_height;
-  const float cs_f = (float)cell_size, eps_f = (float)1.0e-8, vis_f = (float)visibility, lf_f = (float)l_focal;
+  const float cs_f = (float)cell_size;
   for (int g0 = 0; g0 < W; g0 += blockDim.x) {
     // lanes past the last column repeat it (no divergence); the flush below copies real columns only
     const int d_h = min(g0 + (int)threadIdx.x, W - 1);
@@ -668,8 +672,9 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
     for (int q = 0; q < W; ++q) { tan_acc += pixel_factor; if (q == d_h) tan_hp = tan_acc; }
     const double cos_hp = sqrt(1.0 / (1.0 + tan_hp * tan_hp));
     const double sin_hp = tan_hp * cos_hp;
-    const float so = (float)(sin_hp * c_ori + cos_hp * s_ori);
-    const float co = (float)(cos_hp * c_ori - sin_hp * s_ori);
+    const float so32 = (float)(sin_hp * c_ori + cos_hp * s_ori);
+    const float co32 = (float)(cos_hp * c_ori - sin_hp * s_ori);
+    const RT so = (RT)so32, co = (RT)co32;
     const float cos_hp_f = (float)cos_hp;
     const float cos_last = (float)sqrt(1.0 / (1.0 + tan_acc * tan_acc));
     double eff_stale = 0.0;
@@ -685,22 +690,23 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
       }
     }
     uint8_t* col = lds + (size_t)threadIdx.x * cstride;
-    // ---- DDA_2D :47-115, float32 ----
+    // ---- DDA_2D :47-115, in RT ----
     const int i0 = (int)(pos0 / cs_f), j0 = (int)(pos1 / cs_f);
-    const float c_sign = co < 0 ? -1.0f : 1.0f, s_sign = so < 0 ? -1.0f : 1.0f;
-    const float ddx = fabsf(co) < eps_f ? fabsf(cs_f / eps_f) : fabsf(cs_f / co);
-    const float ddy = fabsf(so) < eps_f ? fabsf(cs_f / eps_f) : fabsf(cs_f / so);
-    const float d_x = co > 0 ? ((float)((i0 + 1) * cell_size) - pos0) : ((float)(i0 * cell_size) - pos0);
-    const float d_y = so > 0 ? ((float)((j0 + 1) * cell_size) - pos1) : ((float)(j0 * cell_size) - pos1);
-    float sdx = fabsf(co) < eps_f ? c_sign * (d_x / eps_f) : d_x / co;
-    float sdy = fabsf(so) < eps_f ? s_sign * (d_y / eps_f) : d_y / so;
+    const RT cs_r = (RT)cell_size, eps_r = (RT)1.0e-8, vis_r = (RT)visibility, lf_r = (RT)l_focal;
+    const RT c_sign = co < 0 ? (RT)-1 : (RT)1, s_sign = so < 0 ? (RT)-1 : (RT)1;
+    const RT ddx = xv_abs(co) < eps_r ? xv_abs(cs_r / eps_r) : xv_abs(cs_r / co);
+    const RT ddy = xv_abs(so) < eps_r ? xv_abs(cs_r / eps_r) : xv_abs(cs_r / so);
+    const RT d_x = co > 0 ? ((RT)((i0 + 1) * cell_size) - (RT)pos0) : ((RT)(i0 * cell_size) - (RT)pos0);
+    const RT d_y = so > 0 ? ((RT)((j0 + 1) * cell_size) - (RT)pos1) : ((RT)(j0 * cell_size) - (RT)pos1);
+    RT sdx = xv_abs(co) < eps_r ? c_sign * (d_x / eps_r) : d_x / co;
+    RT sdy = xv_abs(so) < eps_r ? s_sign * (d_y / eps_r) : d_y / so;
     const int di = co > 0 ? 1 : -1, dj = so > 0 ? 1 : -1;
     int hi = i0, hj = j0, hit_side = 0, n_tr = 0;
-    float hit_dist = 0.0f;
+    RT hit_dist = 0;
     // landmark cells crossed by this ray: at most one per DDA step within visibility; 16 slots cover any maze
-    float tr_dist[16];
+    RT tr_dist[16];
     int tr_id[16];
-    while (hit_dist < vis_f) {
+    while (hit_dist < vis_r) {
       int crossed;
       if (sdx < sdy) {
         hi += di; sdy -= sdx; hit_dist += sdx;
@@ -710,7 +716,7 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
           for (int q = 0; q < 16; ++q) if (q == n_tr) { tr_dist[q] = hit_dist; tr_id[q] = crossed; }
           ++n_tr;
         }
-        if (hi < 0 || hi >= n) { if (hj < 0 || hj >= n) { hit_dist = 1.0e+6f; break; } }
+        if (hi < 0 || hi >= n) { if (hj < 0 || hj >= n) { hit_dist = (RT)1.0e+6; break; } }
         else if (hj >= 0 && hj < NG && walls[hi * NG + hj] > 0) { hit_side = 0; break; }
         sdx = ddx;
       } else {
@@ -721,24 +727,25 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
           for (int q = 0; q < 16; ++q) if (q == n_tr) { tr_dist[q] = hit_dist; tr_id[q] = crossed; }
           ++n_tr;
         }
-        if (hi < 0 || hi >= n) { if (hj < 0 || hj >= n) { hit_dist = 1.0e+6f; break; } }
+        if (hi < 0 || hi >= n) { if (hj < 0 || hj >= n) { hit_dist = (RT)1.0e+6; break; } }
         else if (hj >= 0 && hj < NG && walls[hi * NG + hj] > 0) { hit_side = 1; break; }
         sdy = ddy;
       }
     }
     // ---- wall column parameters :258-298 ----
-    float alpha_w = 2.0f * hit_dist / vis_f - 1.0f;
-    alpha_w = alpha_w < 0.0f ? 0.0f : alpha_w;
-    alpha_w = alpha_w > 1.0f ? 1.0f : alpha_w;
+    RT alpha_w = (RT)2 * hit_dist / vis_r - (RT)1;
+    alpha_w = alpha_w < 0 ? (RT)0 : alpha_w;
+    alpha_w = alpha_w > 1 ? (RT)1 : alpha_w;
     const bool in_grid = hi >= 0 && hi < NG && hj >= 0 && hj < NG;
     const int text_id = in_grid ? texts[hi * NG + hj] : 0;
-    const float hit_pt_x = hit_dist * co + pos0, hit_pt_y = hit_dist * so + pos1;
-    float local_h, light_w;
-    if (hit_side == 0) { local_h = hit_pt_y / cs_f; local_h -= floorf(local_h); light_w = fabsf(co); }
-    else { local_h = hit_pt_x / cs_f; local_h -= floorf(local_h); light_w = fabsf(so); }
-    float ratio = hit_dist * cos_hp_f / lf_f;
-    if (fabsf(ratio) < eps_f) ratio = ratio > 0 ? eps_f : -eps_f;
-    const float top_v = (float)cmh / ratio, bot_v = (float)vision_height / ratio;
+    const RT hit_pt_x = hit_dist * co + (RT)pos0, hit_pt_y = hit_dist * so + (RT)pos1;
+    RT local_h;
+    float light_w;
+    if (hit_side == 0) { local_h = hit_pt_y / cs_r; local_h -= xv_floor(local_h); light_w = fabsf(co32); }
+    else { local_h = hit_pt_x / cs_r; local_h -= xv_floor(local_h); light_w = fabsf(so32); }
+    RT ratio = hit_dist * (RT)cos_hp_f / lf_r;
+    if (xv_abs(ratio) < eps_r) ratio = ratio > 0 ? eps_r : -eps_r;
+    const RT top_v = (RT)cmh / ratio, bot_v = (RT)vision_height / ratio;
     int v_s = (int)((half_v - (double)top_v) / pixel_size), v_e = (int)((half_v + (double)bot_v) / pixel_size);
     v_s = v_s < 0 ? 0 : v_s;
     v_e = v_e > H ? H : v_e;
@@ -747,11 +754,11 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
     const double eff_ps_w = eff_stale * pixel_size / l_focal;
     float wall_ti;
     {
-      float d_i = local_h * (float)percell;
-      d_i -= floorf(d_i);
-      wall_ti = (float)(int)(256.0f * d_i);
+      RT d_i = local_h * (RT)percell;
+      d_i -= xv_floor(d_i);
+      wall_ti = (float)(int)((RT)256 * d_i);
     }
-    const double a_far_w = (double)(alpha_w * 1.0f), a_near_w = (double)(1.0f - alpha_w);
+    const double a_far_w = (double)(RT)(alpha_w * (RT)1), a_near_w = (double)((RT)1 - alpha_w);
     const MzDivisor R_cos = mz_divisor((double)cos_hp_f);
 
     // ---- one pass over the column.  The reference paints floor (:180-211), ceiling (:214-244) and then the wall
@@ -809,22 +816,22 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
       }
       // ---- transparent landmark overlays, far to near :301-318 ----
       for (int q = n_tr - 1; q >= 0; --q) {
-        float hd = 0.0f;
+        RT hd = 0;
         int lid = 0;
 #pragma unroll
         for (int z = 0; z < 16; ++z) if (z == q) { hd = tr_dist[z]; lid = tr_id[z]; }
-        float r2 = hd * cos_hp_f / lf_f;
-        if (fabsf(r2) < eps_f) r2 = r2 > 0 ? eps_f : -eps_f;
-        const float tv = (float)cmh / r2, bv = (float)vision_height / r2;
+        RT r2 = hd * (RT)cos_hp_f / lf_r;
+        if (xv_abs(r2) < eps_r) r2 = r2 > 0 ? eps_r : -eps_r;
+        const RT tv = (RT)cmh / r2, bv = (RT)vision_height / r2;
         int s2 = (int)((half_v - (double)tv) / pixel_size), e2 = (int)((half_v + (double)bv) / pixel_size);
         s2 = s2 < c0 ? c0 : s2;
         e2 = e2 > c1 ? c1 : e2;
-        float a2 = 2.0f * hd / vis_f - 1.0f;
-        a2 = a2 < 0.0f ? 0.0f : a2;
-        a2 = a2 > 1.0f ? 1.0f : a2;
-        float tint[3];
+        RT a2 = (RT)2 * hd / vis_r - (RT)1;
+        a2 = a2 < 0 ? (RT)0 : a2;
+        a2 = a2 > 1 ? (RT)1 : a2;
+        RT tint[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) tint[c] = 0.30f * ((1.0f - a2) * MZ_LANDMARK_RGB[lid][c] + a2 * 1.0f);
+        for (int c = 0; c < 3; ++c) tint[c] = (RT)0.30 * (((RT)1 - a2) * (RT)MZ_LANDMARK_RGB[lid][c] + a2 * (RT)1);
         for (int d_v = s2; d_v < e2; ++d_v) {
           uint8_t* px = col + (d_v - c0) * 3;
           px[0] = mz_clip_u8((1.0 - 0.30) * (double)px[0] + (double)tint[0]);
@@ -981,9 +988,13 @@ static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, b
   const size_t lds_bytes = (((size_t)threads * (a.HC * 3 + 4) + 15) & ~(size_t)15) + (size_t)a.H * 16;
   float* crgb = final ? nullptr : command_rgb;
   const bool packed = a.pk_walls != nullptr;
-#define MAZE_RC(F, K, Q) \
-  hipLaunchKernelGGL((maze_raycast_kernel<F, K, Q>), dim3(a.n_env), dim3(threads), lds_bytes, h->eng->stream, a, frames, crgb)
-#define MAZE_RC2(F, K) do { if (h->filter_f32) MAZE_RC(F, K, true); else MAZE_RC(F, K, false); } while (0)
+#define MAZE_RC(F, K, Q, B) \
+  hipLaunchKernelGGL((maze_raycast_kernel<F, K, Q, B>), dim3(a.n_env), dim3(threads), lds_bytes, h->eng->stream, a, frames, crgb)
+#define MAZE_RC2(F, K)                                                                  \
+  do {                                                                                  \
+    if (h->typing_numba) { if (h->filter_f32) MAZE_RC(F, K, true, true); else MAZE_RC(F, K, false, true); }   \
+    else { if (h->filter_f32) MAZE_RC(F, K, true, false); else MAZE_RC(F, K, false, false); }                 \
+  } while (0)
   if (final) { if (packed) MAZE_RC2(true, true); else MAZE_RC2(true, false); }
   else { if (packed) MAZE_RC2(false, true); else MAZE_RC2(false, false); }
 #undef MAZE_RC2
@@ -995,6 +1006,12 @@ static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, b
 extern "C" int xv_maze_set_precision(xv_maze* h, int filter) {
   XV_CHECK_ARG(h != nullptr && (filter == XV_MAZE_FILTER_EXACT || filter == XV_MAZE_FILTER_F32));
   h->filter_f32 = filter == XV_MAZE_FILTER_F32;
+  return XV_OK;
+}
+
+extern "C" int xv_maze_set_typing(xv_maze* h, int typing) {
+  XV_CHECK_ARG(h != nullptr && (typing == XV_MAZE_TYPING_NUMPY2 || typing == XV_MAZE_TYPING_NUMBA));
+  h->typing_numba = typing == XV_MAZE_TYPING_NUMBA;
   return XV_OK;
 }
 

@@ -4,6 +4,8 @@
 #include "philox.h"
 #include "xv_common.h"
 
+#include <type_traits>
+
 #define MZ_PI 3.1415926     // dynamics.py:7-8, the reference's own truncated constants
 #define MZ_TPI 6.2831852
 
@@ -36,6 +38,7 @@ struct xv_maze {
   xv_engine* eng;
   MazeArgs a;
   bool filter_f32 = false;   // xv_maze_set_precision
+  bool typing_numba = false; // xv_maze_set_typing
   bool move_lanes9 = true;   // xv_maze_set_move_kernel
   int move_lanes = 0;        // 0: by batch size; 3 or 9: forced (xv_maze_set_move_kernel)
 };
@@ -55,3 +58,8 @@ __device__ __forceinline__ double mz_angle_norm(double t) {   // dynamics.py:48-
   return t;
 }
 
+
+__device__ __forceinline__ float xv_abs(float v) { return fabsf(v); }
+__device__ __forceinline__ double xv_abs(double v) { return fabs(v); }
+__device__ __forceinline__ float xv_floor(float v) { return floorf(v); }
+__device__ __forceinline__ double xv_floor(double v) { return floor(v); }

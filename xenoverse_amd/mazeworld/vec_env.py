@@ -31,7 +31,7 @@ class MazeWorldVecEnv(VectorEnv):
                  visibility_3D=12.0, command_in_observation=False, action_space_type="Discrete16",
                  collision_dist=0.20, textures=None, device="cuda:0", seed=0, env_id_base=0,
                  autoreset_mode="same_step", to_numpy=False, engine=None, copy=True, with_final_obs=False,
-                 precision="exact"):
+                 precision="exact", typing="numpy2"):
         """Constructor arguments as MazeWorldContinuous3D (maze_env.py:110-118); the registered id `mazeworld-v2`
         uses resolution (256, 256), max_steps 5000, visibility_3D 12.0, Discrete16 (mazeworld/__init__.py:19-33).
         `textures`: dict(walls, grounds, ceilings) of float32 [n,256,256,3] arrays; default = the procedural
@@ -52,6 +52,10 @@ class MazeWorldVecEnv(VectorEnv):
         self.with_final_obs = bool(with_final_obs)
         if precision not in ("exact", "f32"):
             raise ValueError("precision must be 'exact' (the reference's typing, default) or 'f32'")
+        if typing not in ("numpy2", "numba"):
+            raise ValueError("typing must be 'numpy2' (the reference's source as plain Python under NumPy 2, default) or "
+                             "'numba' (the types numba infers: DDA and wall-column geometry in float64)")
+        self.typing = typing
         self.precision = precision      # "f32": texture filter in float32, +-1 level on <= 0.5 % of the frame values
         self.inner_action_list = {"Discrete16": DEFAULT_ACTION_SPACE_16, "Discrete32": DEFAULT_ACTION_SPACE_32}.get(
             action_space_type)
@@ -106,6 +110,8 @@ class MazeWorldVecEnv(VectorEnv):
         self._tab = dev
         if self.precision == "f32":
             _lib.check(self.lib.xv_maze_set_precision(h, 1))
+        if self.typing == "numba":
+            _lib.check(self.lib.xv_maze_set_typing(h, 1))
         n = self.num_envs
         self._frames = torch.zeros((n, W, H, 3), dtype=torch.uint8, device=d)
         self._final = torch.zeros((n, W, H, 3), dtype=torch.uint8, device=d) if self.with_final_obs else None
