@@ -391,14 +391,33 @@ static inline void linds_observe(const xo_linds* h, int t, const float* xs, floa
   }
 }
 
+/* The sums over the observation rows run as four fmaf chains — chain g over the rows j = 16 mo + 4 g + r (mo, r
+ * ascending), the rows one lane group of the device's matrix kernel holds — combined as (p0 + p1) + (p2 + p3)
+ * (csrc/linds.hip: linds_err / linds_sumsq / linds_quad_sum). */
 static inline float linds_err(const xo_linds* h, int t, const float* y, const float* cmd) {
   /* error = || (obs[:no] - cmd) * target_valid ||  (:127, :153) */
-  float acc = 0.0f;
-  for (int j = 0; j < h->NO; ++j) {
-    float d = (y[j] - cmd[j]) * h->valid[(size_t)t * h->NO + j];
-    acc = fmaf(d, d, acc);
+  float p[4];
+  for (int g = 0; g < 4; ++g) {
+    float acc = 0.0f;
+    for (int mo = 0; mo < h->NO / 16; ++mo)
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * mo + 4 * g + r;
+        float d = (y[j] - cmd[j]) * h->valid[(size_t)t * h->NO + j];
+        acc = fmaf(d, d, acc);
+      }
+    p[g] = acc;
   }
-  return sqrtf(acc);
+  return sqrtf((p[0] + p[1]) + (p[2] + p[3]));
+}
+static inline float linds_sumsq(const xo_linds* h, const float* y) {
+  float p[4];
+  for (int g = 0; g < 4; ++g) {
+    float acc = 0.0f;
+    for (int mo = 0; mo < h->NO / 16; ++mo)
+      for (int r = 0; r < 4; ++r) acc = fmaf(y[16 * mo + 4 * g + r], y[16 * mo + 4 * g + r], acc);
+    p[g] = acc;
+  }
+  return (p[0] + p[1]) + (p[2] + p[3]);
 }
 
 static void linds_reset_one(xo_linds* h, int i, int idx, float* obs, float* cmd, float* error) {
@@ -461,9 +480,7 @@ static void linds_step_one(xo_linds* h, int i, const float* a_raw, const float* 
   xo_linds_cmd(h, t, steps - 1 - in[1], ctrack); /* :150-151: tracked command is cmd(steps-1-delay) */
   xo_linds_cmd(h, t, steps, crep);               /* :168: reported command is cmd(steps) */
   const float err = linds_err(h, t, y, ctrack);  /* :153 */
-  float sc2 = 0.0f;
-  for (int j = 0; j < NO; ++j) sc2 = fmaf(y[j], y[j], sc2);
-  const float obs_scale = sqrtf(sc2); /* :154 */
+  const float obs_scale = sqrtf(linds_sumsq(h, y)); /* :154 */
   const int term = (err > 10.0f) || (obs_scale > 20.0f); /* :156 */
   float r = term ? -sc[2] : 0.0f; /* :158-161 */
   float tmp = fmaf(-sc[3], err, sc[1]);

@@ -157,16 +157,49 @@ __device__ __forceinline__ void linds_observe(const LinDSArgs& P, int tu, const 
   for (int j = 0; j < NO; ++j) y[j] = y[j] + y0[j];   // :85
 }
 
+// Sums over the observation rows (tracking error :127,:153, observation scale :154) run as FOUR fmaf chains, chain g over
+// the rows j = 16 mo + 4 g + r (mo, r ascending) — the rows lane group g of the matrix kernel holds after y = C x' — and
+// are combined as (p0 + p1) + (p2 + p3), which is what two xor-shuffles (16, 32) produce in every lane.  Oracle and
+// scalar kernel use the same order (xeno_oracle.c: linds_err, linds_sumsq).
 template <int NO>
 __device__ __forceinline__ float linds_err(const LinDSArgs& P, int tu, const float (&y)[NO], const float (&c)[NO]) {
-  float acc = 0.0f;
   const XV_CONST_AS float* valid = xv_cptr(P.T.valid) + (size_t)tu * NO;
+  float p[4];
 #pragma unroll
-  for (int j = 0; j < NO; ++j) {   // :127, :153
-    const float d = (y[j] - c[j]) * valid[j];
-    acc = fmaf(d, d, acc);
+  for (int g = 0; g < 4; ++g) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int mo = 0; mo < NO / 16; ++mo)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * mo + 4 * g + r;
+        const float d = (y[j] - c[j]) * valid[j];
+        acc = fmaf(d, d, acc);
+      }
+    p[g] = acc;
   }
-  return sqrtf(acc);
+  return sqrtf((p[0] + p[1]) + (p[2] + p[3]));
+}
+template <int NO>
+__device__ __forceinline__ float linds_sumsq(const float (&y)[NO]) {
+  float p[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int mo = 0; mo < NO / 16; ++mo)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = fmaf(y[16 * mo + 4 * g + r], y[16 * mo + 4 * g + r], acc);
+    p[g] = acc;
+  }
+  return (p[0] + p[1]) + (p[2] + p[3]);
+}
+// the same two sums from a lane's own rows (register r of tile mo = row 16 mo + 4 g + r), combined across the four lane
+// groups of an env: identical bits in all four
+template <int MO>
+__device__ __forceinline__ float linds_quad_sum(float part) {
+  part = part + __shfl_xor(part, 16);
+  return part + __shfl_xor(part, 32);
 }
 
 template <int N>
@@ -347,10 +380,7 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
         linds_cmd_at<NO>(P, tu, nf, steps - 1 - delay, ctrack);   // :150-151 tracked command
         linds_cmd_at<NO>(P, tu, nf, steps, crep);                 // :168 reported command
         o_err = linds_err<NO>(P, tu, y, ctrack);               // :153
-        float sc2 = 0.0f;
-#pragma unroll
-        for (int j = 0; j < NO; ++j) sc2 = fmaf(y[j], y[j], sc2);
-        const float obs_scale = sqrtf(sc2);                    // :154
+        const float obs_scale = sqrtf(linds_sumsq<NO>(y));     // :154
         o_term = ((o_err > 10.0f) || (obs_scale > 20.0f)) ? 1 : 0;   // :156
         o_r = o_term ? -sc[2] : 0.0f;                          // :158-161
         float tmp = fmaf(-sc[3], o_err, sc[1]);
@@ -453,6 +483,14 @@ typedef float xv_f32x4 __attribute__((ext_vector_type(4)));
 
 // v[g] for a lane-varying g in 0..3, opaque to hipcc (which otherwise folds a select over array elements into one
 // dynamically indexed stack access, i.e. scratch memory)
+// hipcc (ROCm 7.2) counts the wait states between an MFMA and the first VALU read of its result along the fall-through
+// path only: when the read sits behind a conditional branch taken on the common path (the "outside the command table"
+// test below), the taken path gets `s_nop 0` where 10 wait states are due, and the LAST result register (row 4 g + 3) is
+// read before the matrix unit has written it — observed as wrong observation rows 3, 7, 11, 15 while the state stayed
+// right.  The chains whose results are consumed after a branch are therefore followed by the wait states themselves.
+// (the asm names the accumulator tuple as an in/out AGPR operand, which orders it after the MFMA and before the reads)
+__device__ __forceinline__ void xv_mfma_settle(xv_f32x4& acc) { asm volatile("s_nop 7\n\ts_nop 3" : "+a"(acc)); }
+
 __device__ __forceinline__ float xv_sel4(int g, float a, float b, float c, float d) {
   asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
   const float lo = (g & 1) ? b : a, hi = (g & 1) ? d : c;
@@ -532,19 +570,24 @@ __device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const L
   const int trk_idx = trk_time - P.ct_tmin, rep_idx = rep_time - P.ct_tmin;
   const bool trk_in = P.cmd_tab != nullptr && trk_idx >= 0 && trk_idx < P.ct_len;
   const bool rep_in = P.cmd_tab != nullptr && rep_idx >= 0 && rep_idx < P.ct_len;
-  float ctrack[NO], crep[MO][4];
+  float ctr[MO][4], crep[MO][4];   // this lane's rows 16 mo + 4 g + r of the two commands
   if (P.cmd_tab != nullptr) {
     const float4* p = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + (trk_in ? trk_idx : 0)) * NO);
-#pragma unroll
-    for (int q = 0; q < NO / 4; ++q) {
-      const float4 v = p[q];
-      ctrack[4 * q] = v.x; ctrack[4 * q + 1] = v.y; ctrack[4 * q + 2] = v.z; ctrack[4 * q + 3] = v.w;
-    }
     const float4* pr = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + (rep_in ? rep_idx : 0)) * NO);
 #pragma unroll
     for (int mo = 0; mo < MO; ++mo) {
-      const float4 v = pr[4 * mo + g];
+      const float4 u = p[4 * mo + g], v = pr[4 * mo + g];
+      ctr[mo][0] = u.x; ctr[mo][1] = u.y; ctr[mo][2] = u.z; ctr[mo][3] = u.w;
       crep[mo][0] = v.x; crep[mo][1] = v.y; crep[mo][2] = v.z; crep[mo][3] = v.w;
+    }
+  }
+  float vld[MO][4];
+  {
+    const float* vp = P.T.valid + (size_t)t * NO;
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo) {
+      const float4 v = *reinterpret_cast<const float4*>(vp + 16 * mo + 4 * g);
+      vld[mo][0] = v.x; vld[mo][1] = v.y; vld[mo][2] = v.z; vld[mo][3] = v.w;
     }
   }
   // process noise: independent of every load above, so it is computed while they are in flight.  Philox call
@@ -606,21 +649,22 @@ __device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const L
     for (int mo = 0; mo < MO; ++mo)
       ym[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[mo][s], xn[s >> 2][s & 3], ym[mo], 0, 0, 0);
 #pragma unroll
+  for (int mo = 0; mo < MO; ++mo) xv_mfma_settle(ym[mo]);
+#pragma unroll
   for (int mo = 0; mo < MO; ++mo)
 #pragma unroll
     for (int r = 0; r < 4; ++r) ym[mo][r] = ym[mo][r] + xv_sel4(g, y0[16 * mo + r], y0[16 * mo + 4 + r], y0[16 * mo + 8 + r], y0[16 * mo + 12 + r]);   // :85
-  // the whole observation of the env in every one of its lanes, canonical order (error and scale are chains over j)
-  float y[NO];
-#pragma unroll
-  for (int mo = 0; mo < MO; ++mo)
-#pragma unroll
-    for (int gs = 0; gs < 4; ++gs)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) y[16 * mo + 4 * gs + r] = __shfl(ym[mo][r], n + 16 * gs);
   if (__ballot(!(trk_in && rep_in)) != 0ull) {   // rare: no table, or an env stepped on outside it (auto-reset disabled)
-    if (!trk_in) linds_cmd<NO>(P, t, nf, trk_time, ctrack);
+    float full[NO];
+    if (!trk_in) {
+      linds_cmd<NO>(P, t, nf, trk_time, full);
+#pragma unroll
+      for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ctr[mo][r] = xv_sel4(g, full[16 * mo + r], full[16 * mo + 4 + r], full[16 * mo + 8 + r], full[16 * mo + 12 + r]);
+    }
     if (!rep_in) {
-      float full[NO];
       linds_cmd<NO>(P, t, nf, rep_time, full);
 #pragma unroll
       for (int mo = 0; mo < MO; ++mo)
@@ -629,11 +673,19 @@ __device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const L
           crep[mo][r] = xv_sel4(g, full[16 * mo + r], full[16 * mo + 4 + r], full[16 * mo + 8 + r], full[16 * mo + 12 + r]);
     }
   }
-  float o_err = linds_err<NO>(P, t, y, ctrack);               // :153
-  float sc2 = 0.0f;
+  // tracking error (:153) and observation scale (:154): chain g over this lane's own rows, the four lane groups of an
+  // env combined by two xor-shuffles — the order linds_err / linds_sumsq define
+  float pe = 0.0f, ps = 0.0f;
 #pragma unroll
-  for (int j = 0; j < NO; ++j) sc2 = fmaf(y[j], y[j], sc2);
-  const float obs_scale = sqrtf(sc2);                         // :154
+  for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float d = (ym[mo][r] - ctr[mo][r]) * vld[mo][r];
+      pe = fmaf(d, d, pe);
+      ps = fmaf(ym[mo][r], ym[mo][r], ps);
+    }
+  float o_err = sqrtf(linds_quad_sum<MO>(pe));
+  const float obs_scale = sqrtf(linds_quad_sum<MO>(ps));
   int o_term = ((o_err > 10.0f) || (obs_scale > 20.0f)) ? 1 : 0;   // :156
   float o_r = o_term ? -sc[2] : 0.0f;                         // :158-161
   float tmp = fmaf(-sc[3], o_err, sc[1]);
@@ -687,6 +739,8 @@ __device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const L
 #pragma unroll
         for (int mo = 0; mo < MO; ++mo)
           yr[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[mo][s], xr[s >> 2][s & 3], yr[mo], 0, 0, 0);
+#pragma unroll
+      for (int mo = 0; mo < MO; ++mo) xv_mfma_settle(yr[mo]);
       float yfull[NO];
 #pragma unroll
       for (int mo = 0; mo < MO; ++mo) {
@@ -785,7 +839,6 @@ __global__ __launch_bounds__(256) void linds_rollout_mfma_kernel(LinDSArgs P, Li
   const XV_CONST_AS int32_t* in = xv_cptr(P.T.ints) + (size_t)t * 4;
   const int max_steps = in[0], delay = in[1], n_init = in[2], nf = in[3];
   const float noise_scale = sc[4];
-  const XV_CONST_AS float* y0 = xv_cptr(P.T.y0) + (size_t)t * NO;
 
   // ---- once per launch: the task's operand fragments and the state ----
   const float* phiT = P.T.phiT + (size_t)t * NS * NS;
@@ -811,10 +864,18 @@ __global__ __launch_bounds__(256) void linds_rollout_mfma_kernel(LinDSArgs P, Li
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) xtr[m][r] = xtv[16 * m + 4 * g + r];
+  float vld[MO][4];
+  {
+    const float* vp = P.T.valid + (size_t)t * NO;
+    const float* yp = P.T.y0 + (size_t)t * NO;
 #pragma unroll
-  for (int mo = 0; mo < MO; ++mo)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) y0r[mo][r] = xv_sel4(g, y0[16 * mo + r], y0[16 * mo + 4 + r], y0[16 * mo + 8 + r], y0[16 * mo + 12 + r]);
+    for (int mo = 0; mo < MO; ++mo) {
+      const float4 v = *reinterpret_cast<const float4*>(vp + 16 * mo + 4 * g);
+      const float4 w = *reinterpret_cast<const float4*>(yp + 16 * mo + 4 * g);
+      vld[mo][0] = v.x; vld[mo][1] = v.y; vld[mo][2] = v.z; vld[mo][3] = v.w;
+      y0r[mo][0] = w.x; y0r[mo][1] = w.y; y0r[mo][2] = w.z; y0r[mo][3] = w.w;
+    }
+  }
   int steps = P.steps[es];
   int bad_any = 0;
 
@@ -835,18 +896,14 @@ __global__ __launch_bounds__(256) void linds_rollout_mfma_kernel(LinDSArgs P, Li
     const int trk_idx = trk_time - P.ct_tmin, rep_idx = rep_time - P.ct_tmin;
     const bool trk_in = P.cmd_tab != nullptr && trk_idx >= 0 && trk_idx < P.ct_len;
     const bool rep_in = P.cmd_tab != nullptr && rep_idx >= 0 && rep_idx < P.ct_len;
-    float ctrack[NO], crep[MO][4];
+    float ctr[MO][4], crep[MO][4];
     if (P.cmd_tab != nullptr) {
       const float4* p = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + (trk_in ? trk_idx : 0)) * NO);
-#pragma unroll
-      for (int q = 0; q < NO / 4; ++q) {
-        const float4 v = p[q];
-        ctrack[4 * q] = v.x; ctrack[4 * q + 1] = v.y; ctrack[4 * q + 2] = v.z; ctrack[4 * q + 3] = v.w;
-      }
       const float4* pr = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + (rep_in ? rep_idx : 0)) * NO);
 #pragma unroll
       for (int mo = 0; mo < MO; ++mo) {
-        const float4 v = pr[4 * mo + g];
+        const float4 u = p[4 * mo + g], v = pr[4 * mo + g];
+        ctr[mo][0] = u.x; ctr[mo][1] = u.y; ctr[mo][2] = u.z; ctr[mo][3] = u.w;
         crep[mo][0] = v.x; crep[mo][1] = v.y; crep[mo][2] = v.z; crep[mo][3] = v.w;
       }
     }
@@ -897,20 +954,22 @@ __global__ __launch_bounds__(256) void linds_rollout_mfma_kernel(LinDSArgs P, Li
       for (int mo = 0; mo < MO; ++mo)
         ym[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[mo][s], xn[s >> 2][s & 3], ym[mo], 0, 0, 0);
 #pragma unroll
+    for (int mo = 0; mo < MO; ++mo) xv_mfma_settle(ym[mo]);
+#pragma unroll
     for (int mo = 0; mo < MO; ++mo)
 #pragma unroll
       for (int r = 0; r < 4; ++r) ym[mo][r] = ym[mo][r] + y0r[mo][r];
-    float y[NO];
-#pragma unroll
-    for (int mo = 0; mo < MO; ++mo)
-#pragma unroll
-      for (int gs = 0; gs < 4; ++gs)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y[16 * mo + 4 * gs + r] = __shfl(ym[mo][r], n + 16 * gs);
     if (__ballot(!(trk_in && rep_in)) != 0ull) {
-      if (!trk_in) linds_cmd<NO>(P, t, nf, trk_time, ctrack);
+      float full[NO];
+      if (!trk_in) {
+        linds_cmd<NO>(P, t, nf, trk_time, full);
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            ctr[mo][r] = xv_sel4(g, full[16 * mo + r], full[16 * mo + 4 + r], full[16 * mo + 8 + r], full[16 * mo + 12 + r]);
+      }
       if (!rep_in) {
-        float full[NO];
         linds_cmd<NO>(P, t, nf, rep_time, full);
 #pragma unroll
         for (int mo = 0; mo < MO; ++mo)
@@ -919,11 +978,17 @@ __global__ __launch_bounds__(256) void linds_rollout_mfma_kernel(LinDSArgs P, Li
             crep[mo][r] = xv_sel4(g, full[16 * mo + r], full[16 * mo + 4 + r], full[16 * mo + 8 + r], full[16 * mo + 12 + r]);
       }
     }
-    float o_err = linds_err<NO>(P, t, y, ctrack);
-    float sc2 = 0.0f;
+    float pe = 0.0f, ps = 0.0f;
 #pragma unroll
-    for (int j = 0; j < NO; ++j) sc2 = fmaf(y[j], y[j], sc2);
-    const float obs_scale = sqrtf(sc2);
+    for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = (ym[mo][r] - ctr[mo][r]) * vld[mo][r];
+        pe = fmaf(d, d, pe);
+        ps = fmaf(ym[mo][r], ym[mo][r], ps);
+      }
+    float o_err = sqrtf(linds_quad_sum<MO>(pe));
+    const float obs_scale = sqrtf(linds_quad_sum<MO>(ps));
     const int o_term = ((o_err > 10.0f) || (obs_scale > 20.0f)) ? 1 : 0;
     float o_r = o_term ? -sc[2] : 0.0f;
     float tmp = fmaf(-sc[3], o_err, sc[1]);
@@ -970,6 +1035,8 @@ __global__ __launch_bounds__(256) void linds_rollout_mfma_kernel(LinDSArgs P, Li
 #pragma unroll
           for (int mo = 0; mo < MO; ++mo)
             yr[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[mo][s], xr[s >> 2][s & 3], yr[mo], 0, 0, 0);
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo) xv_mfma_settle(yr[mo]);
         float yfull[NO];
 #pragma unroll
         for (int mo = 0; mo < MO; ++mo) {
