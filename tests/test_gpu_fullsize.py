@@ -180,6 +180,81 @@ def test_config4_maze_16384_envs_state_and_frames_vs_oracle():
     env.close()
 
 
+def test_config4_maze_teachers_16384_envs_vs_oracle():
+    """SURVEY 8(f)3 at config-4 size: the device SmartSLAMAgent decides for all 16,384 envs and drives them through
+    episode ends; every env's exposure map, memory, path head and action against the oracle agent, every step"""
+    from xenoverse_amd.mazeworld import (DEFAULT_ACTION_SPACE_16, MazeTaskSampler, MazeWorldVecEnv, SmartSLAMAgent,
+                                         build_tables, make_texture_library)
+    n_task, per, res = 256, 64, (64, 64)
+    n = n_task * per
+    tex = make_texture_library(8, 4, 4, seed=0)
+    tasks = [MazeTaskSampler(n_range=(15, 16), seed=k, n_wall_textures=8, n_ground_textures=4, n_ceiling_textures=4)
+             for k in range(n_task)]
+    tab = build_tables(tasks)
+    env_task = np.repeat(np.arange(n_task, dtype=np.int32), per)
+    seed, base, max_steps = 11, 1 << 30, 8
+    env = MazeWorldVecEnv(n, resolution=res, textures=tex, autoreset_mode="same_step", max_steps=max_steps,
+                          action_space_type="Discrete16", seed=seed, env_id_base=base)
+    env.set_task(tasks, env_task_index=env_task)
+    ora = oracle.MazeOracle(tab, tex, env_task, resolution=res, max_steps=max_steps)
+    table = np.array(DEFAULT_ACTION_SPACE_16, np.float64)
+    env.reset(); ora.reset()
+    agent = SmartSLAMAgent(maze_env=env)
+    oag = oracle.MazeAgentOracle(ora, table)
+    wrong = 0
+    for t in range(12):
+        tick = env.engine.tick
+        a = _np(agent.step())
+        s = {k: _np(v) for k, v in agent.inspect().items()}
+        ex = ora.expose(seed, base, tick)
+        assert np.array_equal(s["exposed"], ex), t
+        ao = oag.act(ex)
+        assert np.array_equal(s["mask"], oag.mask), t
+        assert np.array_equal(s["path"], oag.path), t
+        wrong += int((a != ao).sum())
+        env.step(a)
+        ora.step(table[a], 2)
+        st = env.get_state()
+        assert np.array_equal(_np(st["steps"]), ora.steps) and np.array_equal(_np(st["grid"]), ora.grid)
+        ora.pos[:] = _np(st["pos"]); ora.ori[:] = _np(st["ori"])
+    assert wrong <= n * 12 // 100000, wrong      # an action is an argmin over fp64 costs: ties at the last bit may flip
+    assert int(ora.steps.max()) < max_steps      # every env restarted once, with a fresh agent memory
+    agent.close(); env.close()
+
+
+def test_fused_rollouts_at_full_size_equal_single_steps():
+    """xv_linds_rollout / xv_cartpole_rollout at 65,536 envs: one launch of T steps = T launches, bit for bit"""
+    from xenoverse_amd.linds import LinDSVecEnv
+    from xenoverse_amd.metacontrol import CartPoleVecEnv, sample_cartpole
+    n, T = 65536, 24
+    ltasks = _linds_tasks(1024)
+    ctasks = [sample_cartpole(seed=k) for k in range(1024)]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    la = torch.rand((T, n, 8), generator=g, device="cuda") * 2.4 - 1.2
+    ca = torch.randint(0, 2, (T, n), generator=g, device="cuda", dtype=torch.int32)
+    for cls, tasks, acts, kw in ((LinDSVecEnv, ltasks, la, {}), (CartPoleVecEnv, ctasks, ca, dict(frameskip=1, max_steps=17))):
+        outs = []
+        for fused in (False, True):
+            env = cls(n, autoreset_mode="same_step", seed=3, env_id_base=1 << 33, **kw)
+            env.set_task(tasks)
+            env.reset()
+            if fused:
+                r = env.rollout(acts)
+                rec = [r["obs"], r["reward"], r["terminated"], r["truncated"]]
+            else:
+                rows = [env.step(acts[t]) for t in range(T)]
+                rec = [torch.stack([row[k] for row in rows]) for k in range(4)]
+                rec[2] = rec[2].to(torch.uint8); rec[3] = rec[3].to(torch.uint8)
+            rec.append(env.get_state()[0].clone())
+            outs.append(rec)
+            env.close()
+        assert int(outs[0][3].sum()) > 0
+        for a, b in zip(*outs):
+            if a.ndim == 3 and a.shape[-1] != b.shape[-1]:
+                b = b[..., :a.shape[-1]]
+            assert torch.equal(a, b), cls.__name__
+
+
 # ---------------------------------------------------------------------------------------------------
 # config 5: the mixed batch's per-GPU share, as a given rank of 8
 # ---------------------------------------------------------------------------------------------------
