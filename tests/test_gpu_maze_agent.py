@@ -136,3 +136,47 @@ def test_teachers_reach_their_goals():
             known = agent.inspect()["mask"].sum(dim=(1, 2)).float().mean().item()
             assert known > 30
         agent.close(); env.close()
+
+
+def test_large_mazes_take_the_multi_wave_path():
+    """35x35 and 41x41 mazes (more than 1,024 cells: four waves per env with workgroup barriers instead of one wave),
+    Discrete32, against the oracle agent through restarts"""
+    from xenoverse_amd.mazeworld import MazeTaskSampler
+    tasks = [MazeTaskSampler(n_range=(35, 36), seed=1, n_wall_textures=8, n_ground_textures=4, n_ceiling_textures=4),
+             MazeTaskSampler(n_range=(41, 42), seed=2, n_wall_textures=8, n_ground_textures=4, n_ceiling_textures=4)]
+    tab = build_tables(tasks)
+    env_task = np.repeat(np.arange(2, dtype=np.int32), 5)
+    n = len(env_task)
+    seed, base = 5, 9
+    env = MazeWorldVecEnv(n, resolution=(48, 32), textures=tex(), autoreset_mode="same_step", max_steps=60,
+                          action_space_type="Discrete32", seed=seed, env_id_base=base)
+    env.set_task(tasks, env_task_index=env_task)
+    ora = oracle.MazeOracle(tab, tex(), env_task, resolution=(48, 32), max_steps=60)
+    table = np.array(DEFAULT_ACTION_SPACE_32, np.float64)
+    env.reset(); ora.reset()
+    agent = SmartSLAMAgent(maze_env=env, keep_cost_map=True)
+    oag = oracle.MazeAgentOracle(ora, table)
+    wrong = 0
+    for t in range(90):
+        tick = env.engine.tick
+        a = _np(agent.step())
+        s = {k: _np(v) for k, v in agent.inspect(cost=True).items()}
+        ex = ora.expose(seed, base, tick)
+        assert np.array_equal(s["exposed"], ex), t
+        ao = oag.act(ex)
+        assert np.array_equal(s["mask"], oag.mask) and np.array_equal(s["path"], oag.path), t
+        for e in range(n):
+            m = tasks[env_task[e]]["cell_walls"].shape[0]
+            assert np.allclose(s["cost"][e, :m, :m], oag.cost[e, :m, :m], rtol=1e-12, atol=1e-12), (t, e)
+        wrong += int((a != ao).sum())
+        frames = env.step(a)[0]; ora.step(table[a], 2)
+        st = env.get_state()
+        assert np.max(np.abs(_np(st["pos"]) - ora.pos)) < 1e-9
+        ora.pos[:] = _np(st["pos"]); ora.ori[:] = _np(st["ori"])
+        assert np.array_equal(_np(st["steps"]), ora.steps)
+        if t % 30 == 0:      # grids beyond 32 x 32 through the move and ray-cast kernels as well
+            from util import frame_mismatch
+            frac, worst = frame_mismatch(_np(frames), ora.render(n_threads=4)[0])
+            assert frac <= 0.005 and worst <= 1, (t, frac, worst)
+    assert wrong == 0, wrong
+    agent.close(); env.close()

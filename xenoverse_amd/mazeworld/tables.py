@@ -4,7 +4,7 @@ Task dict schema: SURVEY.md §8(a) M1 (keys as produced by mazeworld/envs/task_s
 import numpy as np
 
 LMAX = 15          # LandmarksRGB has 15 colours (ray_caster_utils.py:11-25); the sampler caps at 15 (:124-126)
-NG_MAX = 32
+NG_MAX = 64      # xv_maze_create accepts grids up to 64 x 64
 
 DEFAULT_ACTION_SPACE_16 = [(0.0, 0.5), (0.05, 0.0), (-0.05, 0.0), (0.1, 0.0), (-0.1, 0.0), (0.2, 0.0), (-0.2, 0.0),
                            (0.3, 0.0), (-0.3, 0.0), (0.5, 0.0), (-0.5, 0.0), (0.0, 1.0), (0.05, 1.0), (-0.05, 1.0),
