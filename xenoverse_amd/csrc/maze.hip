@@ -101,12 +101,23 @@ __device__ __forceinline__ void mz_collision_force_near(double v0, double v1, do
     f0 = s * v0; f1 = s * v1;
     return;
   }
+  // nearest_point (dynamics.py:56-69) on the facing edge of the unit box.  The four edges differ in their end points
+  // only, so the end points are selected and the arithmetic runs once for the whole wave instead of once per quadrant
+  // present in it; and every edge has length sqrt(1) = 1 exactly, so the reference's normalisation `line_vec /
+  // max(1e-6, edge)` returns line_vec itself: neither the square root nor the two divisions are formed.  Same values.
   const bool x_pos = v0 + v1 > 0, y_pos = v1 - v0 > 0;
-  double n0, n1, d;
-  if (x_pos && y_pos) d = mz_nearest_point(v0, v1, 0.5, 0.5, -0.5, 0.5, n0, n1);
-  else if (!x_pos && y_pos) d = mz_nearest_point(v0, v1, -0.5, 0.5, -0.5, -0.5, n0, n1);
-  else if (!x_pos && !y_pos) d = mz_nearest_point(v0, v1, -0.5, -0.5, 0.5, -0.5, n0, n1);
-  else d = mz_nearest_point(v0, v1, 0.5, -0.5, 0.5, 0.5, n0, n1);
+  const double l10 = x_pos ? 0.5 : -0.5;                                               // x of the first end point
+  const double l11 = y_pos ? 0.5 : -0.5;                                               // y of the first end point
+  const double l20 = (x_pos == y_pos) ? (x_pos ? -0.5 : 0.5) : l10;                    // second end point
+  const double l21 = (x_pos == y_pos) ? l11 : (x_pos ? 0.5 : -0.5);
+  const double u0 = l20 - l10, u1 = l21 - l11, edge = 1.0;
+  const double d1 = (v0 - l10) * u0 + (v1 - l11) * u1;
+  double n0, n1;
+  if (d1 > edge) { n0 = l20; n1 = l21; }
+  else if (d1 < 0) { n0 = l10; n1 = l11; }
+  else { n0 = l10 + d1 * u0; n1 = l11 + d1 * u1; }
+  const double a = v0 - n0, b = v1 - n1;
+  const double d = sqrt(a * a + b * b);
   if (eff < d) return;
   double o0 = v0 - n0, o1 = v1 - n1;
   const double on = sqrt(o0 * o0 + o1 * o1);
