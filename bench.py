@@ -56,7 +56,10 @@ def parse():
                     help="N>1: seconds allowed for process-group set-up and for the all-gather pass")
     ap.add_argument("--no-allgather", action="store_true",
                     help="N>1: skip the RCCL all-gather of rollout chunks (pure replicas)")
-    ap.add_argument("--search", default="auto", choices=["auto", "binary", "fence"])
+    ap.add_argument("--search", default="auto", choices=["auto", "binary", "fence", "bucket"],
+                    help="auto: bucket search (one table line per env-step, 32 bucket lines per row) when its lines fit the "
+                         "free HBM, else fence search (two dependent lines)")
+    ap.add_argument("--buckets", type=int, default=32, choices=[16, 32, 64])
     ap.add_argument("--fused", action="store_true", help="also time the fused T-step rollout kernel")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="xv_anymdp_step_many: replay ring cycles from a hipGraph (auto: only for small batches)")
@@ -212,6 +215,26 @@ def pmc_traffic(n_env, n_task, search):
     return None, None
 
 
+def choose_search(env, torch, args, n_task, S, A):
+    """-> (search actually used, GiB of bucket lines).  auto: bucket search if its lines fit beside the rows."""
+    want = args.search
+    if want in ("auto", "bucket"):
+        need = n_task * S * A * args.buckets * 128
+        free, _ = torch.cuda.mem_get_info()
+        if want == "bucket" or need + (8 << 30) <= free:
+            try:
+                env.set_search("bucket", n_bucket=args.buckets)
+                return "bucket", need / 2**30
+            except Exception as ex:
+                if want == "bucket":
+                    raise
+                print("bench: bucket lines not built (%s): fence search" % (ex,), file=sys.stderr)
+        env.set_search("fence")
+        return "fence", 0.0
+    env.set_search(want)
+    return want, 0.0
+
+
 def make_tables(eng, torch, _lib, n_task, task_base, seed, S=64, A=8, s0_max=4):
     d = eng.device
     words = (S + 63) // 64
@@ -345,6 +368,7 @@ def main():
     n_task = args.tasks if args.tasks > 0 else n_env
     S, A, P = 64, 8, args.period
     search = {"auto": "fence"}.get(args.search, args.search)
+    bucket_gib = 0.0
     env = None
     if not selftest:
         from xenoverse_amd import _lib
@@ -355,7 +379,7 @@ def main():
         per = n_env // n_task
         env_task = (torch.arange(n_env, device=env.device, dtype=torch.int32) // per).contiguous()
         env.set_task(tab, env_task_index=env_task)
-        env.set_search(args.search)
+        search, bucket_gib = choose_search(env, torch, args, n_task, S, A)
         env.set_step_many_graph(args.graph)
         device = env.device
         g = torch.Generator(device=device)
@@ -481,14 +505,16 @@ def main():
                                           else "2b shared"),
                            "envs_per_gpu": n_env, "tasks_per_gpu": n_task, "S": S, "A": A,
                            "table_gib_per_gpu": round(n_task * S * A * (1 + (S + 6) // 7) * 128 / 2**30, 2),
+                           "bucket_lines_gib_per_gpu": round(bucket_gib, 2),
                            "launch": "one step kernel per vector step (xv_anymdp_step_many)",
                            "search": search, "exchange": exchange, "device_error_flags": state["errs"]},
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                              "frac_traffic": None if traffic is None else traffic / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                              "traffic_over_algorithmic": None if traffic is None else traffic / algo,
-                             "kernel": "anymdp_step_kernel<false, %d, false, false>  (INJECT, blocks per fence entry | "
-                                       "0 = binary search, ROLLOUT, TICKDEV)" % (1 if search == "fence" else 0),
+                             "kernel": "anymdp_step_kernel<false, %d, false, false%s>  (INJECT, blocks per fence entry | "
+                                       "0 = binary search, ROLLOUT, TICKDEV, BUCKET)"
+                                       % (0 if search == "binary" else 1, ", true" if search == "bucket" else ""),
                              "kernel_source_sha16": None if selftest else kernel_source_hash(),
                              "avg_launch_us": kern_us, "algorithmic_bytes_per_launch": algo},
                 "rccl": dinfo["rccl"], "rccl_ranks": dinfo["rccl_ranks"],
@@ -571,7 +597,7 @@ def sweep(args, torch, local):
         env = AnyMDPVecEnv(n_env, device="cuda:%d" % local, seed=args.seed, autoreset_mode="same_step")
         tab = make_tables(env.engine, torch, _lib, n_env, 0, args.seed + 1, S, A)
         env.set_task(tab, env_task_index=torch.arange(n_env, device=env.device, dtype=torch.int32))
-        env.set_search(args.search)
+        used, _ = choose_search(env, torch, args, n_env, S, A)
         env.set_step_many_graph("off")
         g = torch.Generator(device=env.device)
         g.manual_seed(args.seed)
@@ -602,8 +628,9 @@ def sweep(args, torch, local):
         except Exception:
             pass
         algo = ALGO_BYTES_PER_ENV_STEP[8] * n_env
-        rows.append({"envs": n_env, "table_gib": round(need / 2**30, 1), "us_per_step": t,
-                     "env_steps_per_s": n_env / (t * 1e-6), "random_128B_lines_per_s": 2 * n_env / (t * 1e-6),
+        rows.append({"envs": n_env, "table_gib": round(need / 2**30, 1), "search": used, "us_per_step": t,
+                     "env_steps_per_s": n_env / (t * 1e-6),
+                     "random_128B_lines_per_s": (1 if used == "bucket" else 2) * n_env / (t * 1e-6),
                      "algorithmic_GBs": algo / (t * 1e-6) / 1e9, "frac": algo / (t * 1e-6) / 1e9 / HBM_PEAK_GBS,
                      "fused_rollout_us_per_step": fus, "device_error_flags": env.check_errors()})
         env.close()

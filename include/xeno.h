@@ -35,7 +35,8 @@ extern "C" {
 /* 2: AnyMDP rows are records of 128-byte lines (fence line + 7-entry blocks), completed in place by
  *    xv_anymdp_create; xv_maze_tables carries the texture-library sizes; Acrobot family; command-table and
  *    graph-replay switches
- * 4: xv_linds_rollout, xv_cartpole_rollout, xv_acrobot_rollout; the maze teachers (xv_maze_agent_*) */
+ * 4: xv_linds_rollout, xv_cartpole_rollout, xv_acrobot_rollout; the maze teachers (xv_maze_agent_*);
+ *    xv_maze_set_typing; AnyMDP bucket search (xv_anymdp_build_buckets) */
 #define XV_ABI_VERSION 4
 
 /* return codes */
@@ -226,7 +227,16 @@ int xv_anymdp_step_tokens_injected(xv_anymdp* h, const int32_t* action, const do
 #define XV_ANYMDP_SEARCH_AUTO 0
 #define XV_ANYMDP_SEARCH_BINARY 1
 #define XV_ANYMDP_SEARCH_FENCE 3
+/*   BUCKET  (after xv_anymdp_build_buckets) one line in one dependent level: the row's probability axis is cut into
+ *           n_bucket equal buckets and bucket line (row, k) holds the 7 entries starting at #{cdf <= k / n_bucket}, so the
+ *           line that contains s' is named by the row and the env's own uniform, floor(u * n_bucket), with no fence read;
+ *           a wave in which some env's s' lies beyond its line (more than 7 next states inside one bucket) takes the
+ *           FENCE path for that step.  Identical results; costs n_task * S * A * n_bucket * 128 bytes of HBM. */
+#define XV_ANYMDP_SEARCH_BUCKET 4
 int xv_anymdp_set_search(xv_anymdp* h, int search);
+/* builds (n_bucket = 16 | 32 | 64) or frees (0) the engine-owned bucket lines of this handle's rows; FENCE layout with
+ * S <= 112 only.  XV_ERR_NOMEM when they do not fit. */
+int xv_anymdp_build_buckets(xv_anymdp* h, int n_bucket);
 
 /* fused teacher rollout: like xv_anymdp_rollout, but the action of every step comes from a per-task greedy table
  * greedy uint8[n_task][S] (argmax_a Q[inner_state], the policy of AnyMDPSolverOpt, anymdp_solver_opt.py:38-51) and is

@@ -172,7 +172,7 @@ def test_config1_free_running_philox_vs_oracle(mode):
 # ---------------------------------------------------------------------------------------------------
 # S = 64 wave-cooperative kernel (headline shape), synthetic tasks, ragged env count
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("search", ["fence", "binary"])
+@pytest.mark.parametrize("search", ["fence", "binary", "bucket"])
 @pytest.mark.parametrize("n_env,n_task", [(2048, 32), (1000, 8), (64, 64), (37, 3)])
 def test_s64_wave_kernel_vs_oracle(n_env, n_task, search):
     tab = oracle.anymdp_synth(seed=99, task_index_base=5, n_task=n_task, S=64, A=8, s0_max=4)
@@ -280,7 +280,7 @@ def test_device_synth_generator_bit_exact(S, A, n_task, s0_max):
     eng.close()
 
 
-@pytest.mark.parametrize("search", ["fence", "binary"])
+@pytest.mark.parametrize("search", ["fence", "binary", "bucket"])
 def test_golden_64x8_tuples_all_search_modes(search):
     g, task = load_anymdp_golden([f for f in FILES if "64x8" in f][0])
     n = len(g["ss_s"])
@@ -720,5 +720,50 @@ def test_bandit_tasks_terminate_every_step():
         assert _np(term).all() and np.array_equal(_np(obs), exp_obs) and np.array_equal(_np(info["final_obs"]), exp_obs)
         rgt = np.array([tasks[i // (n // 3)]["reward"][0, a[i], 0] for i in range(n)], np.float32)
         assert np.array_equal(_np(info["reward_gt"]), rgt)
+    assert env.check_errors() == 0
+    env.close()
+
+
+@pytest.mark.parametrize("n_bucket", [16, 32, 64])
+def test_bucket_search_with_rows_that_overflow_a_line(n_bucket):
+    """bucket search: rows built so that one bucket of probability 1 / n_bucket holds far more than 7 next states (a
+    run of tiny probabilities) force the per-wave fall-back to the fence path; others resolve in the one line.  Injected
+    uniforms incl. exact CDF entries and bucket edges: identical to the oracle and to the fence search."""
+    S, A, n_task, n_env = 100, 3, 5, 1500
+    rng = np.random.RandomState(n_bucket)
+    T = np.zeros((n_task, S, A, S))
+    for t in range(n_task):
+        for s_ in range(S):
+            for a in range(A):
+                w = rng.uniform(0.2, 1.0, S) * (rng.random_sample(S) < 0.3)
+                w[rng.randint(0, S)] += 1.0
+                if (s_ + a) % 2 == 0:                       # a run of 30 states of probability ~1e-4 each
+                    lo = rng.randint(0, S - 30)
+                    w[lo:lo + 30] = 1e-4 * rng.uniform(0.5, 1.5, 30) * w.sum()
+                T[t, s_, a] = w / w.sum()
+    cdf = np.cumsum(T, axis=-1); cdf /= cdf[..., -1:]
+    rs = rng.standard_normal((n_task, S, A, S, 2)).astype(np.float32)
+    tab = dict(S=S, A=A, s0_max=2, cdf=cdf, rs=rs, state_map=np.tile(np.arange(S, dtype=np.int32), (n_task, 1)),
+               term_mask=np.zeros((n_task, 2), np.uint64), s0_cdf=np.tile(np.array([0.5, 1.0]), (n_task, 1)),
+               s0_ids=np.tile(np.array([0, 1], np.int32), (n_task, 1)), max_steps=np.full(n_task, 1000, np.int32))
+    env_task = rng.randint(0, n_task, n_env).astype(np.int32)
+    env = AnyMDPVecEnv(n_env, autoreset_mode="same_step", seed=1)
+    env.set_task(_dev_tables(tab), env_task_index=env_task)
+    env.set_search("bucket", n_bucket=n_bucket)
+    ora = oracle.AnyMDPOracle(tab, env_task)
+    ur0 = rng.random_sample(n_env)
+    env.reset_injected(ur0); ora.reset_injected(ur0)
+    for t in range(40):
+        a = rng.randint(0, A, n_env).astype(np.int32)
+        u, z, ur = rng.random_sample(n_env), rng.standard_normal(n_env).astype(np.float32), rng.random_sample(n_env)
+        k = rng.randint(0, n_env, 64)
+        rows = cdf[env_task[k], ora.state[k], a[k]]
+        u[k[:32]] = np.minimum(rows[np.arange(32), rng.randint(0, S, 32)], np.nextafter(1.0, 0.0))   # exact CDF entries
+        u[k[32:]] = rng.randint(0, n_bucket, 32) / n_bucket                                           # exact bucket edges
+        d = env.step_injected(a, u, z, ur)
+        o = ora.step_injected(a, u, z, ur, 2)
+        _compare_step(d, o)
+        s_, st, _ = env.get_state()
+        assert np.array_equal(_np(s_), ora.state)
     assert env.check_errors() == 0
     env.close()

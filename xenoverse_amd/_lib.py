@@ -44,6 +44,7 @@ SIGNATURES = {
     "xv_anymdp_value_iteration_gs": [c_void_p, c_void_p, c_int, c_int, C.c_double, c_int, c_void_p, c_void_p],
     "xv_anymdp_rollout": [c_void_p, c_int] + [c_void_p] * 7,
     "xv_anymdp_set_search": [c_void_p, c_int],
+    "xv_anymdp_build_buckets": [c_void_p, c_int],
     "xv_anymdp_set_observation_model": [c_void_p, c_int, c_int, c_int, c_void_p],
     "xv_anymdp_reset_tokens": [c_void_p, c_void_p, c_void_p],
     "xv_anymdp_reset_tokens_injected": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],

@@ -101,6 +101,7 @@ class AnyMDPVecEnv(VectorEnv):
             _lib.ptr(dev["term_mask"]), _lib.ptr(dev["s0_cdf"]), _lib.ptr(dev["s0_ids"]),
             _lib.ptr(dev["max_steps"]), _lib.ptr(dev["env_task"]), C.byref(h)))
         self._h = h
+        self._n_bucket = 0
         self._tab = dev       # keeps the borrowed device tables alive
         self.S, self.A, self.s0_max, self.n_task = S, A, s0_max, n_task
         ns = int(np.max(tab["obs_space"])) if "obs_space" in tab else S
@@ -147,10 +148,15 @@ class AnyMDPVecEnv(VectorEnv):
         self.task_set = True
         self.need_reset = True
 
-    SEARCH = {"auto": 0, "binary": 1, "fence": 3}
+    SEARCH = {"auto": 0, "binary": 1, "fence": 3, "bucket": 4}
 
-    def set_search(self, mode):
-        """Select how the categorical draw searches the CDF row (results are identical; see xeno.h)."""
+    def set_search(self, mode, n_bucket=32):
+        """Select how the categorical draw searches the CDF row (results are identical; see xeno.h).  "bucket" builds
+        n_task * S * A * n_bucket * 128 bytes of bucket lines (once) and makes a step one table line in one dependent
+        level; raises if they do not fit."""
+        if mode == "bucket" and getattr(self, "_n_bucket", 0) != n_bucket:
+            _lib.check(self.lib.xv_anymdp_build_buckets(self._h, int(n_bucket)))
+            self._n_bucket = n_bucket
         _lib.check(self.lib.xv_anymdp_set_search(self._h, self.SEARCH[mode]))
 
     # ---- reset ------------------------------------------------------------------------------------

@@ -22,6 +22,13 @@
 // return to the owning lane by ds_bpermute.  Per env-step: 2 x 128 B of table lines + ~90 B of streams
 // (the first layout read a 32-B fence record, a 256-B block and a 128-B task header: 4 lines).
 // BINARY mode (any S <= 256, any s0 table) is the general per-lane fallback.
+//
+// BUCKET mode (xv_anymdp_build_buckets, opt-in: it spends memory) removes level 2.  The row's probability axis is cut
+// into NBK equal buckets; bucket line (row, k) holds the 7 entries that start at I[k] = #{cdf <= k / NBK} — the first
+// candidates for any u in [k / NBK, (k + 1) / NBK) — in the block format, with I[k] in the spare metadata byte.  The
+// line's address follows from the row index and the env's own uniform (k = floor(u * NBK), no memory), so a step is ONE
+// table line in ONE dependent level: s' = I[k] + #{cdf <= u}.  If all 7 entries are <= u (more than 7 next states
+// inside one bucket of probability 1 / NBK: rare for NBK = 32) the wave takes the fence path instead — same result.
 #include "philox.h"
 #include "xv_common.h"
 
@@ -52,6 +59,8 @@ struct AnyMDPArgs {
   uint8_t* cur_term;         // current inner state is terminal (the reference raises when stepping from it, :95-96)
   uint32_t* err;
   int n_env, n_task, S, A, s0_max, words, NB, RL, G;   // RL = 1 + NB lines per row; G blocks per fence entry
+  const uint4* bucket;   // [row][NBK] bucket lines (engine-owned, xv_anymdp_build_buckets); nullptr if not built
+  int NBK;
   uint64_t seed, gid_base, tick;
   const uint64_t* tick_dev;   // graph replay: the launch tick is *tick_dev + tick (tick = node index); else nullptr
 };
@@ -78,6 +87,7 @@ struct xv_anymdp {
   AnyMDPArgs a;
   int search;  // XV_ANYMDP_SEARCH_*
   bool fast;   // fence lines, block metadata and reset records are built
+  uint4* bucket_rw;   // owned: the bucket lines
   const double* obs_cdf;   // observation model (POMDP / MTPOMDP), nullptr for MDP
   int n_obs, d_obs, d_act;
   // xv_anymdp_step_many: one ring cycle (period launches + a tick update) as an instantiated hipGraph
@@ -133,7 +143,8 @@ __device__ __forceinline__ double xv_u2d(uint32_t lo, uint32_t hi) { return __hi
 // G: 0 = per-lane binary search and per-task tables; 1..3 = fence path, a fence entry names G consecutive blocks
 //    (G = 1 for S <= 112, 2 for S <= 224, 3 beyond: the fence always fits one line, the last level reads G lines).
 // TICKDEV: the launch tick is *P.tick_dev + P.tick (graph replay); otherwise P.tick (a kernel argument).
-template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false>
+// BK: bucket mode (G == 1 only): the step's table line is named by (row, floor(u * NBK)).
+template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false, bool BK = false>
 __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPStepIO io, int T_steps,
                                                           int mode) {
   constexpr bool FAST = G > 0;
@@ -212,7 +223,48 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
     int s2, obs2;
     bool term2;
     float2 rsv;
-    if (FAST) {
+    bool need_fence = true;
+    if (BK) {
+      // the ONE line: bucket floor(u * NBK) of the row.  Iteration `it` serves envs 8*it .. 8*it+7 as below.
+      const uint32_t bk = rowidx * (uint32_t)P.NBK + (uint32_t)(int)(u * (double)P.NBK);
+      uint32_t li[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) li[it] = (uint32_t)__shfl((int)bk, it * 8 + g);
+      uint4 bv[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) bv[it] = P.bucket[(size_t)li[it] * 8 + j];
+      __builtin_amdgcn_sched_barrier(0);
+      double ue[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) ue[it] = xv_shfl_f64(u, it * 8 + g);
+      __builtin_amdgcn_sched_barrier(0);
+      int cnt_own = 0;
+      float rx = 0.0f, ry = 0.0f;
+      uint32_t meta_own = 0;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const unsigned long long m = __ballot(j < 7 && xv_u2d(bv[it].x, bv[it].y) <= ue[it]);
+        const int cg = __popc((unsigned)(m >> (8 * g)) & 0x7Fu);   // reader side: the env this lane group serves
+        const int co = __popc((unsigned)(m >> (8 * j)) & 0x7Fu);   // owner side: the env this lane owns
+        const int sg = cg < 6 ? cg : 6;
+        const uint4 b4 = bv[it];
+        const uint32_t mw = sg < 2 ? b4.x : (sg < 4 ? b4.y : (sg < 6 ? b4.z : b4.w));
+        // observation id, terminal flag of the chosen entry and the line's first next-state index, one word
+        const uint32_t packed = ((mw >> (16 * (sg & 1))) & 0xFFFFu) | (((b4.w >> (16 + sg)) & 1u) << 16) | ((b4.w >> 24) << 17);
+        const int so = co < 6 ? co : 6;
+        const float px = __shfl(__uint_as_float(b4.z), 8 * j + so);
+        const float py = __shfl(__uint_as_float(b4.w), 8 * j + so);
+        const uint32_t pm = (uint32_t)__shfl((int)packed, 8 * j + 7);
+        if (g == it) { cnt_own = co; rx = px; ry = py; meta_own = pm; }
+      }
+      s2 = (int)(meta_own >> 17) + cnt_own;
+      s2 = s2 < S - 1 ? s2 : S - 1;
+      rsv = make_float2(rx, ry);
+      obs2 = (int)(meta_own & 0xFFFFu);
+      term2 = (meta_own >> 16) & 1u;
+      need_fence = __ballot(cnt_own >= XV_ANYMDP_BLK) != 0ull;   // wave-uniform: some env's s' lies beyond its line
+    }
+    if (FAST && need_fence) {
       const uint32_t fl = rowidx * (uint32_t)P.RL;   // fence line of the row
       // link 2: fence lines.  Iteration `it` serves envs 8*it .. 8*it+7: lanes 8q..8q+7 read the line of env 8*it+q.
       uint32_t li[8];
@@ -296,7 +348,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       rsv = make_float2(rx, ry);
       obs2 = (int)(meta_own & 0xFFFFu);
       term2 = (meta_own >> 16) & 1u;
-    } else {
+    } else if (!FAST) {
       int lo = 0, n = S;
       while (n > 0) {
         const int half = n >> 1;
@@ -407,6 +459,50 @@ __global__ __launch_bounds__(256) void anymdp_finish_rows_kernel(AnyMDPArgs P, u
     }
     w[3] |= tb << 16;
     row[(size_t)(1 + k) * 8 + 7] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+// Bucket lines (xv_anymdp_build_buckets): one wave per row, lane q and q + 64, ... each write one 16-byte unit.
+//   line (row, k), unit m < 7: the entry of next state I[k] + m (cdf 2.0 past the row), I[k] = #{cdf <= k / NBK}
+//   unit 7: the block metadata of those seven states (clamped to S - 1, as s' is) with I[k] in bits 24..31 of .w
+__global__ __launch_bounds__(256) void anymdp_build_buckets_kernel(AnyMDPArgs P, uint4* bucket, size_t row_base,
+                                                                   size_t n_rows, int NBK) {
+  const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (w >= n_rows) return;
+  const int lane = threadIdx.x & 63;
+  const size_t r = row_base + w;
+  const int t = (int)(r / ((size_t)P.S * P.A));
+  const uint4* row = P.lines + r * (size_t)P.RL * 8;
+  for (int q = lane; q < NBK * 8; q += 64) {
+    const int k = q >> 3, m = q & 7;
+    const double thr = (double)k / (double)NBK;
+    int lo = 0, n = P.S;                       // I = #{cdf <= thr} (upper bound; the CDF is non-decreasing)
+    while (n > 0) {
+      const int half = n >> 1;
+      const int jj = lo + half;
+      const double c = reinterpret_cast<const double*>(row + (size_t)(1 + jj / XV_ANYMDP_BLK) * 8 + (jj % XV_ANYMDP_BLK))[0];
+      if (c <= thr) { lo += half + 1; n -= half + 1; } else n = half;
+    }
+    const int I = lo < 255 ? lo : 255;
+    uint4 out;
+    if (m < 7) {
+      const int jn = I + m;
+      if (jn < P.S) out = row[(size_t)(1 + jn / XV_ANYMDP_BLK) * 8 + (jn % XV_ANYMDP_BLK)];
+      else out = make_uint4(0u, 0x40000000u, 0u, 0u);      // cdf 2.0, zero reward pair
+    } else {
+      uint32_t wd[4] = {0, 0, 0, 0};
+      uint32_t tb = 0;
+      for (int e = 0; e < XV_ANYMDP_BLK; ++e) {
+        int sn = I + e;
+        sn = sn < P.S - 1 ? sn : P.S - 1;
+        const uint32_t ob = (uint32_t)P.state_map[(size_t)t * P.S + sn] & 0xFFFFu;
+        wd[e >> 1] |= ob << (16 * (e & 1));
+        if ((P.term_mask[(size_t)t * P.words + (sn >> 6)] >> (sn & 63)) & 1ull) tb |= 1u << e;
+      }
+      wd[3] |= (tb << 16) | ((uint32_t)I << 24);
+      out = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+    }
+    bucket[(r * (size_t)NBK + k) * 8 + m] = out;
   }
 }
 
@@ -882,6 +978,7 @@ extern "C" int xv_anymdp_destroy(xv_anymdp* h) {
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   if (h->graph) (void)hipGraphDestroy(h->graph);
   if (h->d_tick) (void)hipFree(h->d_tick);
+  if (h->bucket_rw) (void)hipFree(h->bucket_rw);
   delete h;
   return XV_OK;
 }
@@ -918,7 +1015,9 @@ static int anymdp_launch_step(xv_anymdp* h, const AnyMDPStepIO& io, int T, int m
   hipLaunchKernelGGL((anymdp_step_kernel<INJECT, GV, ROLL>), grid, block, 0, h->eng->stream, h->a, io, T, mode)
 #define XV_LAUNCH_STEP_G(GV) do { if (roll) XV_LAUNCH_STEP(GV, true); else XV_LAUNCH_STEP(GV, false); } while (0)
   const bool roll = T > 1 || io.greedy != nullptr;
-  if (h->fast && h->search != XV_ANYMDP_SEARCH_BINARY) {
+  if (h->search == XV_ANYMDP_SEARCH_BUCKET && h->a.bucket != nullptr && !roll) {
+    hipLaunchKernelGGL((anymdp_step_kernel<INJECT, 1, false, false, true>), grid, block, 0, h->eng->stream, h->a, io, T, mode);
+  } else if (h->fast && h->search != XV_ANYMDP_SEARCH_BINARY) {
     if (h->a.G == 1) XV_LAUNCH_STEP_G(1);
     else if (h->a.G == 2) XV_LAUNCH_STEP_G(2);
     else XV_LAUNCH_STEP_G(3);
@@ -1008,6 +1107,7 @@ static bool anymdp_ensure_graph(xv_anymdp* h, int period, const int32_t* actions
 // 16,384 and loses 3 % at 65,536 in config 2a (its kernels read the tick from memory; the stream is not the limiter)
 #define XV_ANYMDP_GRAPH_AUTO_MAX 8192
 static inline bool anymdp_graph_wanted(const xv_anymdp* h) {
+  if (h->search == XV_ANYMDP_SEARCH_BUCKET) return false;   // the captured kernels are the fence ones
   return h->graph_mode == 1 || (h->graph_mode == 2 && h->a.n_env <= XV_ANYMDP_GRAPH_AUTO_MAX);
 }
 
@@ -1117,12 +1217,58 @@ extern "C" int xv_anymdp_solve(xv_anymdp* h, double gamma, double tol, int max_i
 extern "C" int xv_anymdp_set_search(xv_anymdp* h, int search) {
   XV_CHECK_ARG(h != nullptr);
   XV_CHECK_ARG(search == XV_ANYMDP_SEARCH_AUTO || search == XV_ANYMDP_SEARCH_BINARY ||
-               search == XV_ANYMDP_SEARCH_FENCE);
+               search == XV_ANYMDP_SEARCH_FENCE || search == XV_ANYMDP_SEARCH_BUCKET);
+  if (search == XV_ANYMDP_SEARCH_BUCKET && h->a.bucket == nullptr) {
+    xv_set_error("xv_anymdp_set_search: BUCKET needs xv_anymdp_build_buckets first");
+    return XV_ERR_UNSUPPORTED;
+  }
   if (search == XV_ANYMDP_SEARCH_FENCE && !h->fast) {
     xv_set_error("xv_anymdp_set_search: FENCE needs s0_max <= 4, observation ids < 65536 and max_steps < 2^27");
     return XV_ERR_UNSUPPORTED;
   }
   h->search = search;
+  return XV_OK;
+}
+
+extern "C" int xv_anymdp_build_buckets(xv_anymdp* h, int n_bucket) {
+  XV_CHECK_ARG(h != nullptr && (n_bucket == 0 || n_bucket == 16 || n_bucket == 32 || n_bucket == 64));
+  XV_HIP(hipSetDevice(h->eng->device));
+  if (h->bucket_rw) {
+    XV_HIP(hipStreamSynchronize(h->eng->stream));
+    (void)hipFree(h->bucket_rw);
+    h->bucket_rw = nullptr; h->a.bucket = nullptr; h->a.NBK = 0;
+    if (h->search == XV_ANYMDP_SEARCH_BUCKET) h->search = XV_ANYMDP_SEARCH_AUTO;
+  }
+  if (n_bucket == 0) return XV_OK;
+  if (!h->fast || h->a.G != 1) {
+    xv_set_error("xv_anymdp_build_buckets: needs the fence layout with one block per fence entry (S <= 112, s0_max <= 4, "
+                 "observation ids < 65536)");
+    return XV_ERR_UNSUPPORTED;
+  }
+  const size_t n_rows = (size_t)h->a.n_task * h->a.S * h->a.A;
+  const size_t bytes = n_rows * (size_t)n_bucket * 128;
+  if (n_rows * (size_t)n_bucket >= (1ull << 32)) {
+    xv_set_error("xv_anymdp_build_buckets: %zu bucket lines exceed the 32-bit line index", n_rows * (size_t)n_bucket);
+    return XV_ERR_UNSUPPORTED;
+  }
+  uint4* b = nullptr;
+  if (hipMalloc(&b, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    xv_set_error("xv_anymdp_build_buckets: cannot allocate %.1f GiB of bucket lines", (double)bytes / (double)(1ull << 30));
+    return XV_ERR_NOMEM;
+  }
+  const size_t chunk = (size_t)1 << 22;      // rows per launch: 4 rows per 256-thread block
+  for (size_t r0 = 0; r0 < n_rows; r0 += chunk) {
+    const size_t nr = n_rows - r0 < chunk ? n_rows - r0 : chunk;
+    hipLaunchKernelGGL(anymdp_build_buckets_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->eng->stream, h->a, b,
+                       r0, nr, n_bucket);
+  }
+  if (hipGetLastError() != hipSuccess) {
+    (void)hipFree(b);
+    xv_set_error("xv_anymdp_build_buckets: launch failed");
+    return XV_ERR_HIP;
+  }
+  h->bucket_rw = b; h->a.bucket = b; h->a.NBK = n_bucket;
   return XV_OK;
 }
 
