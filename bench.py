@@ -57,9 +57,9 @@ def parse():
     ap.add_argument("--no-allgather", action="store_true",
                     help="N>1: skip the RCCL all-gather of rollout chunks (pure replicas)")
     ap.add_argument("--search", default="auto", choices=["auto", "binary", "fence", "bucket"],
-                    help="auto: bucket search (one table line per env-step, 32 bucket lines per row) when its lines fit the "
+                    help="auto: bucket search (one table line per env-step, --buckets bucket lines per row) when its lines fit the "
                          "free HBM, else fence search (two dependent lines)")
-    ap.add_argument("--buckets", type=int, default=32, choices=[16, 32, 64])
+    ap.add_argument("--buckets", type=int, default=16, choices=[16, 32, 64])
     ap.add_argument("--fused", action="store_true", help="also time the fused T-step rollout kernel")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="xv_anymdp_step_many: replay ring cycles from a hipGraph (auto: only for small batches)")
