@@ -636,7 +636,7 @@ def sweep(args, torch, local):
         env.close()
         del tab, env, ring, actions
         torch.cuda.empty_cache()
-    out = {"what": "anymdp 2a (one task per env, S=64, A=8, fence search, plain launches): step time against envs/GPU",
+    out = {"what": "anymdp 2a (one task per env, S=64, A=8, bucket search where its lines fit else fence, plain launches): step time against envs/GPU",
            "steps": args.steps, "warmup": args.warmup, "kernel_source_sha16": kernel_source_hash(), "rows": rows}
     os.makedirs(os.path.dirname(args.sweep_out), exist_ok=True)
     json.dump(out, open(args.sweep_out, "w"), indent=1)

@@ -295,7 +295,7 @@ def test_golden_64x8_tuples_all_search_modes(search):
     env.close()
 
 
-@pytest.mark.parametrize("search", ["fence", "binary"])
+@pytest.mark.parametrize("search", ["fence", "binary", "bucket"])
 def test_fused_rollout_equals_stepwise(search):
     tab = oracle.anymdp_synth(seed=3, task_index_base=0, n_task=16, S=64, A=8, s0_max=4)
     n_env, T = 1024, 48
@@ -532,9 +532,11 @@ def test_teacher_rollout_on_device():
 # adversarial CDF rows: plateaus (zero-probability states) across block boundaries, all mass on the first / last
 # state, u exactly on / one ulp around every stored entry.  Expected: numpy.searchsorted(cdf, u, 'right').
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("search", ["fence", "binary"])
+@pytest.mark.parametrize("search", ["fence", "binary", "bucket"])
 @pytest.mark.parametrize("S", [7, 8, 20, 64, 130, 250])
 def test_adversarial_rows_match_searchsorted(S, search):
+    if search == "bucket" and S > 112:
+        pytest.skip("bucket lines exist for one-block-per-fence-entry rows (S <= 112)")
     rng = np.random.RandomState(S)
     A = 2
     pdfs = []

@@ -233,6 +233,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       uint4 bv[8];
 #pragma unroll
       for (int it = 0; it < 8; ++it) bv[it] = P.bucket[(size_t)li[it] * 8 + j];
+      if (ROLLOUT && io.action && ts + 1 < T) a_next = io.action[o + P.n_env];   // prefetch behind the line
       __builtin_amdgcn_sched_barrier(0);
       double ue[8];
 #pragma unroll
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       k_own = k_own < NF - 1 ? k_own : NF - 1;       // fences of absent groups hold 2.0: cannot exceed
       // link 3: the GG block lines the fence entry names
       const uint32_t bl = fl + 1u + (uint32_t)k_own * GG;
+      const bool pf = !BK;   // in bucket mode the next action was requested behind the bucket line already
 #pragma unroll
       for (int it = 0; it < 8; ++it) li[it] = (uint32_t)__shfl((int)bl, it * 8 + g);
       uint4 bv[8][GG];
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       for (int it = 0; it < 8; ++it)
 #pragma unroll
         for (int q = 0; q < GG; ++q) bv[it][q] = P.lines[((size_t)li[it] + q) * 8 + j];
-      if (ROLLOUT && io.action && ts + 1 < T) a_next = io.action[o + P.n_env];   // prefetch behind the blocks
+      if (pf && ROLLOUT && io.action && ts + 1 < T) a_next = io.action[o + P.n_env];   // prefetch behind the blocks
       __builtin_amdgcn_sched_barrier(0);
       int cnt_own = 0;
       float rx = 0.0f, ry = 0.0f;
@@ -1015,8 +1017,9 @@ static int anymdp_launch_step(xv_anymdp* h, const AnyMDPStepIO& io, int T, int m
   hipLaunchKernelGGL((anymdp_step_kernel<INJECT, GV, ROLL>), grid, block, 0, h->eng->stream, h->a, io, T, mode)
 #define XV_LAUNCH_STEP_G(GV) do { if (roll) XV_LAUNCH_STEP(GV, true); else XV_LAUNCH_STEP(GV, false); } while (0)
   const bool roll = T > 1 || io.greedy != nullptr;
-  if (h->search == XV_ANYMDP_SEARCH_BUCKET && h->a.bucket != nullptr && !roll) {
-    hipLaunchKernelGGL((anymdp_step_kernel<INJECT, 1, false, false, true>), grid, block, 0, h->eng->stream, h->a, io, T, mode);
+  if (h->search == XV_ANYMDP_SEARCH_BUCKET && h->a.bucket != nullptr) {
+    if (roll) hipLaunchKernelGGL((anymdp_step_kernel<INJECT, 1, true, false, true>), grid, block, 0, h->eng->stream, h->a, io, T, mode);
+    else hipLaunchKernelGGL((anymdp_step_kernel<INJECT, 1, false, false, true>), grid, block, 0, h->eng->stream, h->a, io, T, mode);
   } else if (h->fast && h->search != XV_ANYMDP_SEARCH_BINARY) {
     if (h->a.G == 1) XV_LAUNCH_STEP_G(1);
     else if (h->a.G == 2) XV_LAUNCH_STEP_G(2);
