@@ -180,3 +180,28 @@ def test_large_mazes_take_the_multi_wave_path():
             assert frac <= 0.005 and worst <= 1, (t, frac, worst)
     assert wrong == 0, wrong
     agent.close(); env.close()
+
+
+def test_agent_lifetime_and_misuse():
+    """agents need a Discrete action table; an env that takes a new task (or closes) releases its agents first, and a
+    stale agent refuses to step"""
+    tasks = [load_maze_golden(p)[1] for p in FILES[:2]]
+    envc = MazeWorldVecEnv(4, resolution=(16, 16), textures=tex(), action_space_type="Continuous")
+    envc.set_task(tasks[0]); envc.reset()
+    with pytest.raises(Exception, match="Discrete16 or Discrete32"):
+        SmartSLAMAgent(maze_env=envc)
+    with pytest.raises(Exception, match="Must use maze_env"):
+        SmartSLAMAgent()
+    envc.close()
+    env = MazeWorldVecEnv(4, resolution=(16, 16), textures=tex(), action_space_type="Discrete16")
+    env.set_task(tasks[0]); env.reset()
+    a1 = SmartSLAMAgent(maze_env=env)
+    a1.step()
+    env.set_task(tasks[1]); env.reset()          # new handle: a1 was closed with the old one
+    assert a1._h is None and env._agents == []
+    with pytest.raises(Exception, match="create a new agent"):
+        a1.step()
+    a2 = OracleAgent(maze_env=env)
+    assert a2.step().shape == (4,)
+    env.close()
+    assert a2._h is None

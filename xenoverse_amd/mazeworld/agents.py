@@ -35,6 +35,9 @@ class AgentBase(object):
                                                  C.byref(h)))
         self._h = h
         self._env_handle = env._h.value
+        if not hasattr(env, "_agents"):
+            env._agents = []
+        env._agents.append(self)
         self._action = torch.zeros(env.num_envs, dtype=torch.int32, device=env.device)
 
     def step(self, observation=None, r=None, exposed=None):
@@ -67,6 +70,8 @@ class AgentBase(object):
             if env._h is not None and env._h.value == self._env_handle:
                 self.lib.xv_maze_agent_destroy(self._h)
             self._h = None
+            if self in getattr(env, "_agents", ()):
+                env._agents.remove(self)
 
     def __del__(self):
         try:

@@ -93,6 +93,7 @@ class MazeWorldVecEnv(VectorEnv):
             if env_task.shape != (self.num_envs,) or int(env_task.min()) < 0 or int(env_task.max()) >= n_task:
                 raise ValueError("env_task_index must be (num_envs,) with entries in [0, n_task)")
         dev["env_task"] = env_task.contiguous()
+        self._close_agents()
         if self._h is not None:
             self.lib.xv_maze_destroy(self._h)
             self._h = None
@@ -209,7 +210,14 @@ class MazeWorldVecEnv(VectorEnv):
         ang = torch.where(ang < -np.pi, ang + 2 * np.pi, torch.where(ang > np.pi, ang - 2 * np.pi, ang))
         return self._out(torch.sqrt((d * d).sum(1))), self._out(ang)
 
+    def _close_agents(self):
+        """agents hold device memory sized by this handle's batch: they go before it does"""
+        for a in list(getattr(self, "_agents", ())):
+            a.close()
+        self._agents = []
+
     def close_extras(self, **kwargs):
+        self._close_agents()
         if self._h is not None:
             self.lib.xv_maze_destroy(self._h)
             self._h = None
