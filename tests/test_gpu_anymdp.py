@@ -393,12 +393,13 @@ def test_device_philox_kat():
 # Too large for the oracle as a whole -> size-independent properties + an oracle check of a subset of envs
 # (the synthetic generator is a pure function of (seed, task index), so the CPU can rebuild just those tasks).
 # ---------------------------------------------------------------------------------------------------
-def test_full_size_config_2a_properties_and_subset_vs_oracle():
+@pytest.mark.parametrize("search", ["fence", "bucket"])
+def test_full_size_config_2a_properties_and_subset_vs_oracle(search):
     import ctypes as C
     from xenoverse_amd import _lib
     free, total = torch.cuda.mem_get_info()
-    if free < 52 * 2**30:
-        pytest.skip("needs ~46 GiB of free HBM")
+    if free < (52 if search == "fence" else 120) * 2**30:
+        pytest.skip("needs ~46 GiB of free HBM (+64 GiB of bucket lines)")
     n_env, S, A, T = 65536, 64, 8, 24
     seed_tab, seed = 1235, 1234
     env = AnyMDPVecEnv(n_env, seed=seed, autoreset_mode="same_step")
@@ -413,6 +414,7 @@ def test_full_size_config_2a_properties_and_subset_vs_oracle():
     _lib.check(env.lib.xv_anymdp_synth_tasks(env.engine.handle, seed_tab, 0, n_env, S, A, 4, *[_lib.ptr(t[k]) for k in
                ("rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")]))
     env.set_task(t, env_task_index=torch.arange(n_env, dtype=torch.int32, device=d))
+    env.set_search(search, n_bucket=16) if search == "bucket" else env.set_search(search)
     # oracle for a scattered subset of envs (first/last waves, a wave in the middle, odd stragglers)
     sub = np.r_[0:64, 30000:30064, 65472:65536, [777, 4242, 51234]]
     tabs = [oracle.anymdp_synth(seed=seed_tab, task_index_base=int(i), n_task=1, S=S, A=A, s0_max=4) for i in sub]
@@ -486,6 +488,8 @@ def test_teacher_rollout_on_device():
     for fused in (True, False):
         env = AnyMDPVecEnv(n, seed=3, autoreset_mode="same_step")
         env.set_task(tasks, env_task_index=env_task)
+        if fused:
+            env.set_search("bucket")        # the teacher roll-out through the bucket lines, the steps through the fence
         env.reset()
         if fused:
             s0 = _np(env.inner_state).copy()
