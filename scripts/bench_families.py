@@ -175,10 +175,12 @@ def bench_anymdp_tok(args):
                                                  _lib.ptr(env._reward_gt), _lib.ptr(env._term), _lib.ptr(env._trunc),
                                                  _lib.ptr(tfobs), AUTORESET["same_step"]))
     us = timed(step, args.steps, args.warmup)
+    env.set_search("bucket", n_bucket=16)      # transitions through the bucket lines (one dependent level each)
+    us_b = timed(step, args.steps, args.warmup)
     env.close()
     return {"family": "anymdp multi-token POMDP", "workload": "65,536 envs, 1,024 tasks, S=64 A=8 n_obs=64 d_obs=2 d_act=2",
-            "dtype": "f64", "env_steps_per_s": n / (us * 1e-6), "us_per_step": us,
-            "note": "per-lane binary searches (general path); 2 transition + 2 observation draws per env-step"}
+            "dtype": "f64", "env_steps_per_s": n / (min(us, us_b) * 1e-6), "us_per_step": {"binary search": us, "bucket lines": us_b},
+            "note": "per-lane searches (general path); 2 transition + 2 observation draws per env-step"}
 
 
 def bench_mixed(args):

@@ -99,7 +99,7 @@ def test_batch_vs_oracle_injected_and_free_running(mode):
 
 
 @pytest.mark.parametrize("n_obs,d_obs,d_act,search", [(64, 3, 2, "fence"), (22, 2, 3, "fence"), (15, 2, 2, "fence"),
-                                                     (64, 3, 2, "binary")])
+                                                     (64, 3, 2, "binary"), (64, 3, 2, "bucket"), (22, 2, 3, "bucket")])
 def test_synthetic_observation_models_vs_oracle(n_obs, d_obs, d_act, search):
     """S=64, A=8 synthetic tasks with random observation models of several shapes (n_obs 64 / 22 / 15, up to 3
     tokens) against the oracle: injected draws incl. exact CDF entries, all three auto-reset modes in turn"""

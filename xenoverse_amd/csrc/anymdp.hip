@@ -640,6 +640,7 @@ __device__ __forceinline__ void anymdp_tok_observe(const AnyMDPArgs& P, const An
 
 template <bool INJECT>
 __global__ __launch_bounds__(256) void anymdp_tok_step_kernel(AnyMDPArgs P, AnyMDPTokArgs K, AnyMDPTokIO io, int mode) {
+  const bool BK = P.bucket != nullptr && P.NBK > 0;   // bucket search selected (the launcher hands the lines over only then)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
   const int S = P.S, A = P.A, N = P.n_env;
@@ -676,14 +677,35 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_kernel(AnyMDPArgs P, AnyM
         z = xv_normal1(w.z, w.w);
       }
       const uint32_t rowidx = ((uint32_t)t * S + s) * A + a;
-      int lo = 0, m = S;
-      while (m > 0) {
-        const int half = m >> 1;
-        if (anymdp_cdf(P, rowidx, lo + half) <= u) { lo += half + 1; m -= half + 1; }
-        else m = half;
+      int lo = -1;
+      float2 rsv = make_float2(0.0f, 0.0f);
+      if (BK) {   // bucket line of (row, floor(u * NBK)), read per lane: the 7 candidate entries in one dependent level
+        const uint4* bl = P.bucket + ((size_t)rowidx * P.NBK + (size_t)(int)(u * (double)P.NBK)) * 8;
+        uint4 en[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) en[q] = bl[q];
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) cnt += xv_u2d(en[q].x, en[q].y) <= u ? 1 : 0;
+        if (cnt < 7) {
+          lo = (int)(en[7].w >> 24) + cnt;
+#pragma unroll
+          for (int q = 0; q < 7; ++q)
+            if (q == cnt) rsv = make_float2(__uint_as_float(en[q].z), __uint_as_float(en[q].w));
+        }
+      }
+      if (lo < 0) {   // no bucket lines, or s' lies beyond the line: search the row
+        lo = 0;
+        int m = S;
+        while (m > 0) {
+          const int half = m >> 1;
+          if (anymdp_cdf(P, rowidx, lo + half) <= u) { lo += half + 1; m -= half + 1; }
+          else m = half;
+        }
+        lo = lo < S - 1 ? lo : S - 1;
+        rsv = anymdp_rs(P, rowidx, lo);
       }
       const int s2 = lo < S - 1 ? lo : S - 1;
-      const float2 rsv = anymdp_rs(P, rowidx, s2);
       rsum = rsum + fmaf(rsv.y, z, rsv.x);
       rgsum = rgsum + rsv.x;
       s = s2;
@@ -1317,8 +1339,10 @@ extern "C" int xv_anymdp_set_observation_model(xv_anymdp* h, int n_obs, int d_ob
 template <bool INJECT>
 static int anymdp_tok_launch_step(xv_anymdp* h, const AnyMDPTokIO& io, int mode) {
   AnyMDPTokArgs K{h->obs_cdf, h->n_obs, h->d_obs, h->d_act};
+  AnyMDPArgs a = h->a;
+  if (h->search != XV_ANYMDP_SEARCH_BUCKET) a.bucket = nullptr;
   hipLaunchKernelGGL(anymdp_tok_step_kernel<INJECT>, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
-                     h->a, K, io, mode);
+                     a, K, io, mode);
   XV_LAUNCH_CHECK();
   return XV_OK;
 }
