@@ -49,3 +49,21 @@ out = mb.step({"anymdp": torch.zeros(1024, dtype=torch.int32, device="cuda"),
                "cartpole": torch.ones(512, dtype=torch.int32, device="cuda")})
 print({k: tuple(v[0].shape) for k, v in out.items()})
 mb.close()
+
+# 5. mazes with the rule-based teacher on the device: SmartSLAMAgent explores, then walks to the commanded landmarks
+from xenoverse_amd.mazeworld import MazeTaskSampler, MazeWorldVecEnv, SmartSLAMAgent, teacher_rollout  # noqa: E402
+menv = MazeWorldVecEnv(256, resolution=(64, 64), action_space_type="Discrete16", max_steps=500)
+menv.set_task([MazeTaskSampler(n_range=(11, 16), seed=k) for k in range(8)])
+menv.reset()
+agent = SmartSLAMAgent(maze_env=menv)              # the reference's constructor keywords
+data = teacher_rollout(menv, agent, T=300)
+print("maze teacher: goals reached per env in 300 steps: %.2f" % ((data["reward"] > 0.1).sum().item() / 256))
+menv.close()
+
+# 6. memory for speed: one table line per AnyMDP step (identical results)
+env = AnyMDPVecEnv(num_envs=4096, seed=0)
+env.set_task(tasks)
+env.set_search("bucket")
+env.reset()
+print("bucket search:", tuple(env.rollout(torch.zeros((16, 4096), dtype=torch.int32, device=env.device))["obs"].shape))
+env.close()
