@@ -366,7 +366,7 @@ def main():
     from xenoverse_amd.distributed import REC_BYTES, RolloutGather, pack_records, unpack_records
     n_env = args.envs
     n_task = args.tasks if args.tasks > 0 else n_env
-    S, A, P = 64, 8, args.period
+    S, A, P = 64, 8, min(args.period, max(args.steps, 1))   # a ring no longer than the timed batch: whole cycles can replay
     search = {"auto": "fence"}.get(args.search, args.search)
     bucket_gib = 0.0
     env = None
@@ -380,7 +380,10 @@ def main():
         env_task = (torch.arange(n_env, device=env.device, dtype=torch.int32) // per).contiguous()
         env.set_task(tab, env_task_index=env_task)
         search, bucket_gib = choose_search(env, torch, args, n_task, S, A)
-        env.set_step_many_graph(args.graph)
+        # a short timed batch is one submission when its ring cycle replays from a hipGraph (20 steps: 154 instead of
+        # 173 us); thousands of steps of a large batch are not launch-bound and plain launches are 2-3 % faster there
+        graph_mode = args.graph if args.graph != "auto" else ("on" if (args.steps <= 128 or n_env <= 8192) else "off")
+        env.set_step_many_graph(graph_mode)
         device = env.device
         g = torch.Generator(device=device)
         g.manual_seed(args.seed + 17 * rank)
@@ -479,6 +482,9 @@ def main():
     # pass 1 (the reported value): sharded stepping, no data-path collective — envs are independent
     wall, ev_ms, walls = timed_pass(False, R)
     state["errs"] = env.check_errors() if env is not None else 0
+    state["graph"] = 0
+    if env is not None and graph_mode == "on" and args.steps >= P and int(env.lib.xv_anymdp_step_many_graph_state(env._h)) >= 0:
+        state["graph"] = 1
 
     def report(timeout_note=None):
         with report_lock:
@@ -506,7 +512,9 @@ def main():
                            "envs_per_gpu": n_env, "tasks_per_gpu": n_task, "S": S, "A": A,
                            "table_gib_per_gpu": round(n_task * S * A * (1 + (S + 6) // 7) * 128 / 2**30, 2),
                            "bucket_lines_gib_per_gpu": round(bucket_gib, 2),
-                           "launch": "one step kernel per vector step (xv_anymdp_step_many)",
+                           "launch": "one step kernel per vector step (xv_anymdp_step_many%s)"
+                                     % (", ring cycles of %d steps replayed from a hipGraph" % P if state.get("graph") == 1 else
+                                        ", plain launches"),
                            "search": search, "exchange": exchange, "device_error_flags": state["errs"]},
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -186,10 +186,12 @@ int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const int32_t* ac
 /* Whole ring cycles of xv_anymdp_step_many can be replayed from an instantiated hipGraph (period kernel nodes that
  * read the launch tick from device memory + a tick update; built on first use, rebuilt when the arrays, period or
  * mode change).  Same kernels, same results (parity-tested).  mode: 0 plain launches, 1 graph, 2 auto (default):
- * graph for n_env <= 8,192, where the stream's launch rate is the limiter (7-9 % faster at 1,024-4,096 envs; at
- * 65,536 envs the step loop is not launch-bound and plain launches are slightly faster). */
+ * graph for n_env <= 8,192, where the stream's launch rate is the limiter (7-9 % faster at 1,024-4,096 envs), and for
+ * calls of n_steps <= 128, where one submission instead of n_steps shortens the burst (20 steps of 65,536 envs: 154
+ * instead of 173 us); long runs of large batches are not launch-bound and plain launches are 2-3 % faster there. */
 int xv_anymdp_set_step_many_graph(xv_anymdp* h, int mode);
-/* 1: a graph is built and in use, 0: plain launches, -1: graph construction or launch failed (plain launches used) */
+/* 1: the last xv_anymdp_step_many replayed the graph, 0: plain launches, -1: graph construction or launch failed (plain
+ * launches used) */
 int xv_anymdp_step_many_graph_state(xv_anymdp* h);
 
 /* fused rollout: T vector steps in one launch with pre-generated actions[T][n_env] (open-loop / random

@@ -624,7 +624,7 @@ def test_copy_false_returns_views_of_alternating_output_sets():
             assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("search", ["fence", "binary"])
+@pytest.mark.parametrize("search", ["fence", "binary", "bucket"])
 def test_step_many_graph_replay_equals_plain_launches(search):
     """whole ring cycles of step_many are replayed from a hipGraph whose kernels read the launch tick from device
     memory: identical to plain launches, also with a remainder, with ordinary steps in between (the device tick must

@@ -377,7 +377,8 @@ class AnyMDPVecEnv(VectorEnv):
 
     def set_step_many_graph(self, mode):
         """step_many replays whole ring cycles from a hipGraph (True / "on"), issues plain launches (False / "off")
-        or decides by batch size ("auto", the default: graph up to 8,192 envs); same results either way."""
+        or decides ("auto", the default: graph up to 8,192 envs and for calls of at most 128 steps); same results
+        either way."""
         m = {"off": 0, "on": 1, "auto": 2}.get(mode, 1 if mode is True else (0 if mode is False else mode))
         _lib.check(self.lib.xv_anymdp_set_step_many_graph(self._h, int(m)))
 

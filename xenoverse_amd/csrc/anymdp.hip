@@ -93,6 +93,7 @@ struct xv_anymdp {
   // xv_anymdp_step_many: one ring cycle (period launches + a tick update) as an instantiated hipGraph
   int graph_mode;            // 0 off, 1 on, 2 auto: on for n_env <= XV_ANYMDP_GRAPH_AUTO_MAX
   bool graph_failed;
+  bool graph_used_last;      // the last xv_anymdp_step_many replayed the graph
   hipGraph_t graph;
   hipGraphExec_t graph_exec;
   uint64_t* d_tick;          // device copy of the launch tick the graph's kernels read
@@ -1093,7 +1094,9 @@ static bool anymdp_ensure_graph(xv_anymdp* h, int period, const int32_t* actions
   if (hipGraphCreate(&h->graph, 0) != hipSuccess) return false;
   const size_t n = (size_t)h->a.n_env;
   const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
-  void* fn = !fast ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 0, false, true>)
+  const bool bk = h->search == XV_ANYMDP_SEARCH_BUCKET && h->a.bucket != nullptr;
+  void* fn = bk ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 1, false, true, true>)
+             : !fast ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 0, false, true>)
              : h->a.G == 1 ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 1, false, true>)
              : h->a.G == 2 ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 2, false, true>)
                            : reinterpret_cast<void*>(&anymdp_step_kernel<false, 3, false, true>);
@@ -1129,11 +1132,14 @@ static bool anymdp_ensure_graph(xv_anymdp* h, int period, const int32_t* actions
 }
 
 // measured (scripts/devtools/graph_step_many.py, config 2b): graph replay wins 7-9 % at 1,024-4,096 envs, nothing at
-// 16,384 and loses 3 % at 65,536 in config 2a (its kernels read the tick from memory; the stream is not the limiter)
+// 16,384 and loses 2-3 % at 65,536 in config 2a when thousands of steps are issued (its kernels read the tick from memory;
+// the stream is not the limiter) — but a SHORT burst is one submission instead of n_steps: 20 steps of 65,536 envs take
+// 154 instead of 173 us.  AUTO: small batches, or short bursts.
 #define XV_ANYMDP_GRAPH_AUTO_MAX 8192
-static inline bool anymdp_graph_wanted(const xv_anymdp* h) {
-  if (h->search == XV_ANYMDP_SEARCH_BUCKET) return false;   // the captured kernels are the fence ones
-  return h->graph_mode == 1 || (h->graph_mode == 2 && h->a.n_env <= XV_ANYMDP_GRAPH_AUTO_MAX);
+#define XV_ANYMDP_GRAPH_AUTO_STEPS 128
+static inline bool anymdp_graph_wanted(const xv_anymdp* h, int n_steps) {
+  return h->graph_mode == 1 ||
+         (h->graph_mode == 2 && (h->a.n_env <= XV_ANYMDP_GRAPH_AUTO_MAX || n_steps <= XV_ANYMDP_GRAPH_AUTO_STEPS));
 }
 
 extern "C" int xv_anymdp_set_step_many_graph(xv_anymdp* h, int mode) {
@@ -1145,7 +1151,7 @@ extern "C" int xv_anymdp_set_step_many_graph(xv_anymdp* h, int mode) {
 extern "C" int xv_anymdp_step_many_graph_state(xv_anymdp* h) {   // 0 plain launches, 1 graph built and in use, -1 failed
   if (!h) return 0;
   if (h->graph_failed) return -1;
-  return (anymdp_graph_wanted(h) && h->graph_exec) ? 1 : 0;
+  return (h->graph_mode != 0 && h->graph_exec && h->graph_used_last) ? 1 : 0;
 }
 
 extern "C" int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const int32_t* actions,
@@ -1158,7 +1164,8 @@ extern "C" int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const 
   int k = 0;
   // whole ring cycles: replay the graph
   const int cycles = n_steps / period;
-  if (cycles > 0 && period > 1 && anymdp_graph_wanted(h) && !h->graph_failed) {
+  h->graph_used_last = false;
+  if (cycles > 0 && period > 1 && anymdp_graph_wanted(h, n_steps) && !h->graph_failed) {
     bool ok = anymdp_ensure_graph(h, period, actions, obs, reward, reward_gt, terminated, truncated, final_obs,
                                   autoreset_mode);
     if (ok && !(h->d_tick_valid && h->d_tick_value == h->eng->tick)) {
@@ -1171,6 +1178,7 @@ extern "C" int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const 
         h->eng->tick += (uint64_t)period;
         h->d_tick_value = h->eng->tick;
         h->d_tick_valid = true;
+        h->graph_used_last = true;
         k += period;
       }
     }
