@@ -236,8 +236,8 @@ int xv_anymdp_step_tokens_injected(xv_anymdp* h, const int32_t* action, const do
  *           FENCE path for that step.  Identical results; costs n_task * S * A * n_bucket * 128 bytes of HBM. */
 #define XV_ANYMDP_SEARCH_BUCKET 4
 int xv_anymdp_set_search(xv_anymdp* h, int search);
-/* builds (n_bucket = 16 | 32 | 64) or frees (0) the engine-owned bucket lines of this handle's rows; FENCE layout with
- * S <= 112 only.  XV_ERR_NOMEM when they do not fit. */
+/* builds (n_bucket = 16 | 32 | 64) or frees (0) the engine-owned bucket lines of this handle's rows (FENCE layout, any
+ * S <= 256).  XV_ERR_NOMEM when they do not fit. */
 int xv_anymdp_build_buckets(xv_anymdp* h, int n_bucket);
 
 /* fused teacher rollout: like xv_anymdp_rollout, but the action of every step comes from a per-task greedy table

@@ -539,8 +539,6 @@ def test_teacher_rollout_on_device():
 @pytest.mark.parametrize("search", ["fence", "binary", "bucket"])
 @pytest.mark.parametrize("S", [7, 8, 20, 64, 130, 250])
 def test_adversarial_rows_match_searchsorted(S, search):
-    if search == "bucket" and S > 112:
-        pytest.skip("bucket lines exist for one-block-per-fence-entry rows (S <= 112)")
     rng = np.random.RandomState(S)
     A = 2
     pdfs = []

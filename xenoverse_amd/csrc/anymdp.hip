@@ -144,7 +144,7 @@ __device__ __forceinline__ double xv_u2d(uint32_t lo, uint32_t hi) { return __hi
 // G: 0 = per-lane binary search and per-task tables; 1..3 = fence path, a fence entry names G consecutive blocks
 //    (G = 1 for S <= 112, 2 for S <= 224, 3 beyond: the fence always fits one line, the last level reads G lines).
 // TICKDEV: the launch tick is *P.tick_dev + P.tick (graph replay); otherwise P.tick (a kernel argument).
-// BK: bucket mode (G == 1 only): the step's table line is named by (row, floor(u * NBK)).
+// BK: bucket mode: the step's table line is named by (row, floor(u * NBK)); G only shapes the fence fall-back.
 template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false, bool BK = false>
 __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPStepIO io, int T_steps,
                                                           int mode) {
@@ -1041,8 +1041,15 @@ static int anymdp_launch_step(xv_anymdp* h, const AnyMDPStepIO& io, int T, int m
 #define XV_LAUNCH_STEP_G(GV) do { if (roll) XV_LAUNCH_STEP(GV, true); else XV_LAUNCH_STEP(GV, false); } while (0)
   const bool roll = T > 1 || io.greedy != nullptr;
   if (h->search == XV_ANYMDP_SEARCH_BUCKET && h->a.bucket != nullptr) {
-    if (roll) hipLaunchKernelGGL((anymdp_step_kernel<INJECT, 1, true, false, true>), grid, block, 0, h->eng->stream, h->a, io, T, mode);
-    else hipLaunchKernelGGL((anymdp_step_kernel<INJECT, 1, false, false, true>), grid, block, 0, h->eng->stream, h->a, io, T, mode);
+#define XV_LAUNCH_BK(GV)                                                                                                  \
+  do {                                                                                                                     \
+    if (roll) hipLaunchKernelGGL((anymdp_step_kernel<INJECT, GV, true, false, true>), grid, block, 0, h->eng->stream, h->a, io, T, mode);  \
+    else hipLaunchKernelGGL((anymdp_step_kernel<INJECT, GV, false, false, true>), grid, block, 0, h->eng->stream, h->a, io, T, mode);      \
+  } while (0)
+    if (h->a.G == 1) XV_LAUNCH_BK(1);
+    else if (h->a.G == 2) XV_LAUNCH_BK(2);
+    else XV_LAUNCH_BK(3);
+#undef XV_LAUNCH_BK
   } else if (h->fast && h->search != XV_ANYMDP_SEARCH_BINARY) {
     if (h->a.G == 1) XV_LAUNCH_STEP_G(1);
     else if (h->a.G == 2) XV_LAUNCH_STEP_G(2);
@@ -1095,7 +1102,9 @@ static bool anymdp_ensure_graph(xv_anymdp* h, int period, const int32_t* actions
   const size_t n = (size_t)h->a.n_env;
   const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
   const bool bk = h->search == XV_ANYMDP_SEARCH_BUCKET && h->a.bucket != nullptr;
-  void* fn = bk ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 1, false, true, true>)
+  void* fn = bk ? (h->a.G == 1 ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 1, false, true, true>)
+                   : h->a.G == 2 ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 2, false, true, true>)
+                                 : reinterpret_cast<void*>(&anymdp_step_kernel<false, 3, false, true, true>))
              : !fast ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 0, false, true>)
              : h->a.G == 1 ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 1, false, true>)
              : h->a.G == 2 ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 2, false, true>)
@@ -1273,9 +1282,8 @@ extern "C" int xv_anymdp_build_buckets(xv_anymdp* h, int n_bucket) {
     if (h->search == XV_ANYMDP_SEARCH_BUCKET) h->search = XV_ANYMDP_SEARCH_AUTO;
   }
   if (n_bucket == 0) return XV_OK;
-  if (!h->fast || h->a.G != 1) {
-    xv_set_error("xv_anymdp_build_buckets: needs the fence layout with one block per fence entry (S <= 112, s0_max <= 4, "
-                 "observation ids < 65536)");
+  if (!h->fast) {
+    xv_set_error("xv_anymdp_build_buckets: needs the fence layout (s0_max <= 4, observation ids < 65536, max_steps < 2^27)");
     return XV_ERR_UNSUPPORTED;
   }
   const size_t n_rows = (size_t)h->a.n_task * h->a.S * h->a.A;
