@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256) void maze_step_kernel(MazeArgs P, const void* 
 // waves instead of 256.
 // ------------------------------------------------------------------------------------------------
 constexpr int MZ_SUBMAX = 104;
+constexpr int MZ_NSUB = 100;     // sub-steps of a move that are not skipped (see the note in maze_step9_kernel)
 
 // L lanes per env (9: one neighbour cell each; 3: one row of three cells each), 64 / L envs per wave.  Which one is
 // faster is a matter of filling the chip: every lane of an env repeats the position arithmetic, so more lanes per env
@@ -356,8 +357,7 @@ __global__ __launch_bounds__(64) void maze_step9_kernel(MazeArgs P, const void* 
         if (wi > -1 && wi < n && wj > -1 && wj < n && wv[a * 5 + b] > 0) patch |= 1u << (a * 5 + b);
       }
   }
-  const double t_prec = 0.01, delta_t = 1.0;
-  const int iteration = (int)(delta_t / t_prec);
+  const double t_prec = 0.01;
   const MzDivisor R_cs = mz_divisor(cell_size);
   const double eff_cd = col_dist / cell_size;
   const double rad = turn_rate != 0.0 ? walk_speed / turn_rate : 0.0;
@@ -368,21 +368,20 @@ __global__ __launch_bounds__(64) void maze_step9_kernel(MazeArgs P, const void* 
     sincos(0.5 * (turn_rate * t_prec), &s_dt_full, &c_dt_full);
     // groups of L sub-steps: all lanes walk the recurrence together and each keeps the heading of ITS sub-step of
     // the group (a select); the expensive part then runs once per group with every lane busy, not once per sub-step
-    for (int base = 0; base < iteration + 1; base += L) {
-      double my_ori = 0.0, my_dt = 0.0;
+    // The reference's loop runs i = 0 .. 100 with t_res = min(delta_t - i * t_prec, t_prec) and skips t_res < 1e-8
+    // (dynamics.py:166-169).  With delta_t = 1 and t_prec = 0.01 in fp64: 1 - i * 0.01 >= 0.01 for every i <= 99 (the
+    // smallest, i = 99, is 0.010000000000000009) and exactly 0 for i = 100 — i.e. MZ_NSUB = 100 sub-steps of t_res = t_prec,
+    // the 101st skipped.  So the step length is a constant of the loop, not a per-iteration computation.
+    const double d_theta = turn_rate * t_prec, arc = walk_speed * t_prec;
+    for (int base = 0; base < MZ_NSUB; base += L) {
+      double my_ori = 0.0;
       bool mine = false;
-      for (int c = 0; c < L && base + c < iteration + 1; ++c) {
-        const int it = base + c;
-        const double rem = delta_t - it * t_prec;
-        const double dt = rem < t_prec ? rem : t_prec;
-        if (dt < 1.0e-8) continue;
-        if (c == cell) { my_ori = ori_k; my_dt = dt; mine = true; }
-        ori_k = mz_angle_norm(ori_k + turn_rate * dt);
+      for (int c = 0; c < L && base + c < MZ_NSUB; ++c) {
+        if (c == cell) { my_ori = ori_k; mine = true; }
+        ori_k = mz_angle_norm(ori_k + d_theta);
       }
       if (mine) {
-        const double d_theta = turn_rate * my_dt, arc = walk_speed * my_dt;
-        double c_dt = c_dt_full, s_dt = s_dt_full;
-        if (my_dt != t_prec) sincos(0.5 * d_theta, &s_dt, &c_dt);
+        const double c_dt = c_dt_full, s_dt = s_dt_full;
         if (!have || my_ori != ori_cached) { sincos(my_ori, &s_t, &c_t); ori_cached = my_ori; have = true; }
         double dx, dy;
         if (fabs(d_theta) < 1.0e-8) { dx = c_t * arc; dy = s_t * arc; }
@@ -398,10 +397,7 @@ __global__ __launch_bounds__(64) void maze_step9_kernel(MazeArgs P, const void* 
   }
   __syncthreads();
   // ---- phase 2: positions (sequential), CPL neighbour cells per lane ----
-  for (int it = 0; it < iteration + 1; ++it) {
-    const double rem = delta_t - it * t_prec;
-    const double dt = rem < t_prec ? rem : t_prec;
-    if (dt < 1.0e-8) continue;
+  for (int it = 0; it < MZ_NSUB; ++it) {
     const double2 d = s_d[q][it];
     const double e0 = p0 + d.x, e1 = p1 + d.y;
     const double c0 = mz_div(e0, R_cs), c1 = mz_div(e1, R_cs);
