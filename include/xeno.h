@@ -37,7 +37,7 @@ extern "C" {
  *    graph-replay switches
  * 4: xv_linds_rollout, xv_cartpole_rollout, xv_acrobot_rollout; the maze teachers (xv_maze_agent_*);
  *    xv_maze_set_typing; AnyMDP bucket search (xv_anymdp_build_buckets) */
-#define XV_ABI_VERSION 4
+#define XV_ABI_VERSION 5
 
 /* return codes */
 #define XV_OK 0
@@ -111,6 +111,7 @@ int xv_unpack_rollout(void* hip_stream, size_t n, const uint64_t* rec, int32_t* 
 int xv_rccl_unique_id(void* out128);
 int xv_rccl_comm_create(xv_engine* e, int world, int rank, const void* id128, void** comm_out);
 int xv_rccl_comm_destroy(void* comm);
+int xv_rccl_comm_count(void* comm, int* count_out);   /* ncclCommCount: how many ranks the communicator really spans */
 int xv_rollout_allgather(xv_engine* e, void* rccl_comm, const void* local, void* global, size_t bytes_per_rank);
 
 /* ------------------------------------------------------------------------------------------------
@@ -128,7 +129,7 @@ int xv_rollout_allgather(xv_engine* e, void* rccl_comm, const void* local, void*
  *                            states 7k..7k+6, then 16 bytes {uint16 obs[7]; uint8 term_bits; uint8 0}: observation id
  *                            and terminal flag of the same next states.  -- metadata written by xv_anymdp_create --
  *              cdf = entries of the inclusive CDF of transition[s,a,:], i.e. cumsum(row)/cumsum(row)[-1] computed on
- *              the host in fp64 exactly as numpy.random.choice does (entries >= S hold 2.0 and a zero reward pair;
+ *              the host in fp64 exactly as numpy.random.choice does (entries >= S hold 2.0; xv_anymdp_create gives them the reward pair of entry S-1, what a clamped s' gets;
  *              rows of terminal states, all-zero in the reference, hold 1.0); reward pair = {reward[s,a,s'],
  *              reward_noise[s,a,s']}.  The caller fills the ENTRIES (xenoverse_amd.anymdp.tables.to_blocked builds them
  *              from the reference's task arrays); xv_anymdp_create completes fence and metadata IN PLACE from the
@@ -265,6 +266,10 @@ int xv_anymdp_solve(xv_anymdp* h, double gamma, double tol, int max_iter, double
  * holds the starting point and receives the result; sweeps_out nullable. */
 int xv_anymdp_value_iteration_gs(const double* t_mat, const double* r_mat, int ns, int na, double gamma,
                                  int is_greedy, double* vm, int32_t* sweeps_out);
+/* Order of the np.mean reductions inside it (process-wide): 0 = NumPy's pairwise summation — the reference run as plain
+ * Python, which produced the golden fixtures (default) — 1 = one sequential loop, what a numba-compiled
+ * update_value_matrix does (solver.py:57 is @njit); mode 1 is not pinned by any fixture (numba is absent here). */
+int xv_anymdp_value_iteration_set_summation(int mode);
 
 /* Task sampler on the device: AnyMDPTaskSampler's generative model and acceptance test (task_sampler.py:15-65,
  * task_sampler_utils.py:65-256, solver.py:84-148) for n_cand candidate tasks per launch, one workgroup per candidate,

@@ -771,3 +771,83 @@ def test_bucket_search_with_rows_that_overflow_a_line(n_bucket):
         assert np.array_equal(_np(s_), ora.state)
     assert env.check_errors() == 0
     env.close()
+
+
+@pytest.mark.parametrize("S", [20, 21, 64])
+def test_rows_whose_cdf_ends_below_one_clamp_alike_in_every_search(S):
+    """caller-supplied rows whose last CDF entry stays below 1 (not what numpy.random.choice builds, but what the C-ABI
+    accepts): for u >= cdf[S-1] the draw clamps to s' = S-1 and takes THAT entry's reward pair — in the per-lane search,
+    on the fence path (padding entries of the last block) and in the bucket lines alike, as the oracle does."""
+    A, n_task, n_env = 3, 4, 1024
+    rng = np.random.RandomState(S)
+    T = rng.uniform(0.1, 1.0, (n_task, S, A, S)) * (rng.random_sample((n_task, S, A, S)) < 0.5)
+    T[..., 0] += 0.05
+    cdf = np.cumsum(T, axis=-1)
+    cdf /= cdf[..., -1:]
+    cdf *= rng.uniform(0.90, 1.0, (n_task, S, A, 1))          # rows end at 0.90 .. 1.0
+    rs = rng.standard_normal((n_task, S, A, S, 2)).astype(np.float32)
+    tab = dict(S=S, A=A, s0_max=2, cdf=cdf, rs=rs, state_map=np.tile(np.arange(S, dtype=np.int32)[::-1], (n_task, 1)),
+               term_mask=np.zeros((n_task, 1), np.uint64), s0_cdf=np.tile(np.array([0.5, 1.0]), (n_task, 1)),
+               s0_ids=np.tile(np.array([0, 1], np.int32), (n_task, 1)), max_steps=np.full(n_task, 1000, np.int32))
+    env_task = rng.randint(0, n_task, n_env).astype(np.int32)
+    for search in ("binary", "fence", "bucket"):
+        env = AnyMDPVecEnv(n_env, autoreset_mode="same_step", seed=1)
+        env.set_task(_dev_tables(tab), env_task_index=env_task)
+        env.set_search(search, n_bucket=16) if search == "bucket" else env.set_search(search)
+        ora = oracle.AnyMDPOracle(tab, env_task)
+        r2 = np.random.RandomState(3)
+        ur0 = r2.random_sample(n_env)
+        env.reset_injected(ur0); ora.reset_injected(ur0)
+        beyond = 0
+        for t in range(12):
+            a = r2.randint(0, A, n_env).astype(np.int32)
+            u, z, ur = r2.random_sample(n_env), r2.standard_normal(n_env).astype(np.float32), r2.random_sample(n_env)
+            last = cdf[env_task, ora.state, a, -1]
+            k = r2.random_sample(n_env) < 0.5                  # half of the envs draw at or beyond the row's last entry
+            u[k] = np.minimum(last[k] + r2.uniform(0.0, 0.05, k.sum()) * (r2.random_sample(k.sum()) < 0.8),
+                              np.nextafter(1.0, 0.0))
+            beyond += int((u >= last).sum())
+            d = env.step_injected(a, u, z, ur)
+            o = ora.step_injected(a, u, z, ur, 2)
+            _compare_step(d, o)
+            s_, _, _ = env.get_state()
+            assert np.array_equal(_np(s_), ora.state)
+        assert beyond > 2000 and env.check_errors() == 0
+        env.close()
+
+
+def test_rebuilding_the_bucket_lines_drops_the_cached_step_many_graph():
+    """the step_many graph bakes the bucket lines' address and count into its kernel nodes: rebuilding the lines with
+    another n_bucket (or dropping them) between two replays must not replay the old graph"""
+    tab = oracle.anymdp_synth(seed=12, task_index_base=0, n_task=8, S=64, A=8, s0_max=4)
+    n, P = 512, 8
+    acts = np.random.RandomState(5).randint(0, 8, (P, n)).astype(np.int32)
+    res = []
+    for variant in ("rebuild", "fence"):
+        env = AnyMDPVecEnv(n, seed=77, autoreset_mode="same_step")
+        env.set_task(_dev_tables(tab))
+        env.set_step_many_graph(True)
+        env.reset()
+        rec = []
+        if variant == "rebuild":
+            env.set_search("bucket", n_bucket=32)
+        else:
+            env.set_search("fence")
+        ring = env.step_many(2 * P, acts)
+        rec.append({k: _np(v).copy() for k, v in ring.items()})
+        if variant == "rebuild":
+            env.set_search("bucket", n_bucket=64)          # frees the 32-bucket lines the graph was built on
+            torch.empty(1 << 26, dtype=torch.uint8, device="cuda:0").fill_(0xFF)   # scribble over freed memory
+        ring = env.step_many(2 * P, acts, out=ring)
+        rec.append({k: _np(v).copy() for k, v in ring.items()})
+        if variant == "rebuild":
+            assert env.lib.xv_anymdp_build_buckets(env._h, 0) == 0    # lines dropped: search falls back to AUTO
+            env._n_bucket = 0
+        ring = env.step_many(2 * P, acts, out=ring)
+        rec.append({k: _np(v).copy() for k, v in ring.items()})
+        assert env.check_errors() == 0
+        res.append(rec)
+        env.close()
+    for a, b in zip(*res):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k

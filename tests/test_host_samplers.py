@@ -311,3 +311,51 @@ def test_garnet_sampler_reproduces_the_reference_task():
     assert tab["S"] == T.shape[0] and tab["A"] == 5
     with pytest.raises(ValueError):
         GarnetTaskSampler(8, 2, b=1)
+
+
+def test_vi_summation_orders():
+    """`update_value_matrix` is @njit in the reference: numba reduces np.mean sequentially, the interpreter pairwise.  The
+    C++ Gauss-Seidel offers both; the sequential order is checked against a plain Python restatement of the sweep
+    (solver.py:57-82) with sequential sums, the default stays the pairwise one the fixtures pin."""
+    from xenoverse_amd.anymdp.task_sampler import gauss_seidel_values, set_vi_summation
+    rng = np.random.RandomState(5)
+    ns, na = 6, 9                                   # na >= 8: the two orders can differ
+    T = rng.rand(ns, na, ns) * (rng.rand(ns, na, ns) < 0.6)
+    T[..., 0] += 1e-3
+    T /= T.sum(-1, keepdims=True)
+    R = rng.randn(ns, na, ns)
+    gamma = 0.9
+
+    def seq_mean(v):
+        acc = 0.0
+        for x in v:
+            acc += float(x)
+        return acc / len(v)
+
+    def sweep_sequential():
+        vm = np.zeros((ns, na))
+        diff, alpha = 1.0, 1.0
+        while diff > 1e-4:
+            old = vm.copy()
+            for s in range(ns):
+                for a in range(na):
+                    exp_q = 0.0
+                    for sn in range(ns):
+                        if T[s, a, sn] == 0.0:
+                            continue
+                        exp_q += T[s, a, sn] * (gamma * seq_mean(vm[sn]) + R[s, a, sn])
+                    vm[s, a] += alpha * (exp_q - vm[s, a])
+            diff = np.sqrt(seq_mean(((old - vm) ** 2).ravel()))
+            alpha = max(0.80 * alpha, 0.50)
+        return vm
+
+    try:
+        set_vi_summation("numba")
+        got = gauss_seidel_values(T, R, gamma, greedy=False)
+        assert np.array_equal(got, sweep_sequential())
+    finally:
+        set_vi_summation("numpy")
+    ref = gauss_seidel_values(T, R, gamma, greedy=False)
+    assert np.allclose(ref, got, rtol=0, atol=1e-9)
+    with pytest.raises(KeyError):
+        set_vi_summation("other")

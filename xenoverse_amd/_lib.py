@@ -21,6 +21,7 @@ SIGNATURES = {
     "xv_rccl_unique_id": [c_void_p],
     "xv_rccl_comm_create": [c_void_p, c_int, c_int, c_void_p, C.POINTER(c_void_p)],
     "xv_rccl_comm_destroy": [c_void_p],
+    "xv_rccl_comm_count": [c_void_p, C.POINTER(c_int)],
     "xv_rollout_allgather": [c_void_p, c_void_p, c_void_p, c_void_p, C.c_size_t],
     "xv_engine_create": [c_int, c_u64, c_u64, c_void_p, C.POINTER(c_void_p)],
     "xv_engine_destroy": [c_void_p],
@@ -41,6 +42,7 @@ SIGNATURES = {
     "xv_anymdp_solve": [c_void_p, C.c_double, C.c_double, c_int, c_void_p, c_void_p, c_void_p],
     "xv_anymdp_step_many_graph_state": [c_void_p],
     "xv_anymdp_sample_tasks": [c_void_p, c_u64, c_i64, c_int, c_int, c_int, c_int] + [c_void_p] * 11,
+    "xv_anymdp_value_iteration_set_summation": [c_int],
     "xv_anymdp_value_iteration_gs": [c_void_p, c_void_p, c_int, c_int, C.c_double, c_int, c_void_p, c_void_p],
     "xv_anymdp_rollout": [c_void_p, c_int] + [c_void_p] * 7,
     "xv_anymdp_set_search": [c_void_p, c_int],
@@ -109,7 +111,7 @@ class XenoError(RuntimeError):
     pass
 
 
-ABI_VERSION = 4      # include/xeno.h XV_ABI_VERSION
+ABI_VERSION = 5      # include/xeno.h XV_ABI_VERSION
 
 
 def load():

@@ -12,7 +12,10 @@ speed of the interpreted loop: 64x8 tasks in seconds instead of ~9 minutes).  Re
 seed=k)`, `(64, 8, seed=1)` and the POMDP variants equal the reference's tasks bit for bit (tests/golden/anymdp_*,
 tests/test_host_samplers.py) on a host whose NumPy takes the same SIMD paths as the one that wrote the fixtures
 (`numpy.exp` differs in the last bit between NumPy's AVX512 and scalar kernels: the reference itself is only
-reproducible per machine class).
+reproducible per machine class).  "The reference" here is the reference run as plain Python (its `@njit` functions
+interpreted — numba is not installable in the build image — which is how the fixtures were made): NumPy reduces the
+`np.mean` calls of `update_value_matrix` pairwise, a numba-compiled run reduces them sequentially, and the last bits of
+those means can differ.  `set_vi_summation("numba")` selects the sequential order (not pinned by any fixture).
 
 Throughput sampling of fresh tasks by the thousand is a different job: `device_sampler.sample_batch_device` runs the
 same generative model with counter-based randomness on the GPU (not stream-compatible, distribution-tested).
@@ -22,6 +25,13 @@ import numpy as np
 import scipy.sparse as sp
 
 EPS = 1e-10
+
+
+def set_vi_summation(order="numpy"):
+    """order of the np.mean reductions inside the C++ Gauss-Seidel value iteration: "numpy" (pairwise; the interpreted
+    reference, pinned by the fixtures; default) or "numba" (one sequential loop, as numba compiles np.mean; unpinned)"""
+    from .. import _lib
+    _lib.check(_lib.load().xv_anymdp_value_iteration_set_summation({"numpy": 0, "numba": 1}[order]))
 
 
 def value_iteration(T, R, gamma, greedy=True, tol=1.0e-4, max_iter=20000):

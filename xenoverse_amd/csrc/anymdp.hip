@@ -100,9 +100,10 @@ struct xv_anymdp {
   uint64_t d_tick_value;     // what *d_tick holds once the stream has drained
   bool d_tick_valid;
   struct {
-    int period, mode, search, fast;
+    int period, mode, search, fast, nbk;
     uint64_t seed, gid_base;
     const void* ptrs[7];
+    const void* bucket;   // the bucket lines and their count are baked into the kernel nodes' arguments
   } graph_key;
 };
 
@@ -462,6 +463,15 @@ __global__ __launch_bounds__(256) void anymdp_finish_rows_kernel(AnyMDPArgs P, u
     }
     w[3] |= tb << 16;
     row[(size_t)(1 + k) * 8 + 7] = make_uint4(w[0], w[1], w[2], w[3]);
+    // padding entries (next states >= S): cdf 2.0 and the reward pair of next state S-1 — the pair a clamped s' must
+    // get when u >= cdf[S-1] (a caller-supplied row whose last CDF entry stays below 1), as the per-lane search reads it
+    if (XV_ANYMDP_BLK * (k + 1) > P.S) {
+      const int jl = P.S - 1;
+      const uint4 last = row[(size_t)(1 + jl / XV_ANYMDP_BLK) * 8 + (jl % XV_ANYMDP_BLK)];
+      for (int e = 0; e < XV_ANYMDP_BLK; ++e)
+        if (XV_ANYMDP_BLK * k + e >= P.S)
+          row[(size_t)(1 + k) * 8 + e] = make_uint4(0u, 0x40000000u, last.z, last.w);
+    }
   }
 }
 
@@ -490,8 +500,12 @@ __global__ __launch_bounds__(256) void anymdp_build_buckets_kernel(AnyMDPArgs P,
     uint4 out;
     if (m < 7) {
       const int jn = I + m;
-      if (jn < P.S) out = row[(size_t)(1 + jn / XV_ANYMDP_BLK) * 8 + (jn % XV_ANYMDP_BLK)];
-      else out = make_uint4(0u, 0x40000000u, 0u, 0u);      // cdf 2.0, zero reward pair
+      if (jn < P.S) {
+        out = row[(size_t)(1 + jn / XV_ANYMDP_BLK) * 8 + (jn % XV_ANYMDP_BLK)];
+      } else {   // cdf 2.0 and the reward pair of next state S-1 (what a clamped s' gets, see anymdp_finish_rows_kernel)
+        const uint4 last = row[(size_t)(1 + (P.S - 1) / XV_ANYMDP_BLK) * 8 + ((P.S - 1) % XV_ANYMDP_BLK)];
+        out = make_uint4(0u, 0x40000000u, last.z, last.w);
+      }
     } else {
       uint32_t wd[4] = {0, 0, 0, 0};
       uint32_t tb = 0;
@@ -1093,6 +1107,7 @@ static bool anymdp_ensure_graph(xv_anymdp* h, int period, const int32_t* actions
   const void* ptrs[7] = {actions, obs, reward, reward_gt, terminated, truncated, final_obs};
   auto& K = h->graph_key;
   if (h->graph_exec && K.period == period && K.mode == mode && K.search == h->search && K.fast == (int)fast &&
+      K.bucket == (const void*)h->a.bucket && K.nbk == h->a.NBK &&
       K.seed == h->eng->seed && K.gid_base == h->eng->env_id_base && memcmp(K.ptrs, ptrs, sizeof(ptrs)) == 0)
     return true;
   if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
@@ -1135,6 +1150,7 @@ static bool anymdp_ensure_graph(xv_anymdp* h, int period, const int32_t* actions
   }
   if (hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0) != hipSuccess) { h->graph_exec = nullptr; return false; }
   K.period = period; K.mode = mode; K.search = h->search; K.fast = (int)fast;
+  K.bucket = (const void*)h->a.bucket; K.nbk = h->a.NBK;
   K.seed = h->eng->seed; K.gid_base = h->eng->env_id_base;
   memcpy(K.ptrs, ptrs, sizeof(ptrs));
   return true;
@@ -1277,6 +1293,9 @@ extern "C" int xv_anymdp_build_buckets(xv_anymdp* h, int n_bucket) {
   XV_HIP(hipSetDevice(h->eng->device));
   if (h->bucket_rw) {
     XV_HIP(hipStreamSynchronize(h->eng->stream));
+    // an instantiated step_many graph holds the old lines' address and count in its kernel arguments: drop it with them
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
     (void)hipFree(h->bucket_rw);
     h->bucket_rw = nullptr; h->a.bucket = nullptr; h->a.NBK = 0;
     if (h->search == XV_ANYMDP_SEARCH_BUCKET) h->search = XV_ANYMDP_SEARCH_AUTO;

@@ -10,7 +10,12 @@
 //   * max_a / mean_a of a value-matrix row are cached per state and refreshed for state s after every update of
 //     vm[s, .] — what the reference recomputes inside its innermost loop;
 //   * numpy.mean is NumPy's pairwise summation (plain loop below 8 elements, eight partial sums up to 128, halves
-//     rounded to a multiple of 8 above), divided by the count.
+//     rounded to a multiple of 8 above), divided by the count.  That is what the reference executes when its @njit
+//     functions run as plain Python — how the golden fixtures were produced (numba is absent from this image) — and the
+//     default here.  A numba-compiled reference reduces np.mean as one sequential loop instead; that order is offered
+//     as summation mode 1 (xv_anymdp_value_iteration_set_summation) and is NOT pinned by any fixture.  The two differ
+//     in the last bits of means over >= 8 values (the uniform-policy values for na >= 8, the rms stopping test), which
+//     reach the task only through threshold comparisons (gap >= 2, diff > 1e-4).
 // Compiled with -ffp-contract=off like every other file: a*b+c stays two roundings, as in the interpreter.
 #include <cmath>
 #include <cstring>
@@ -18,10 +23,14 @@
 
 #include "xv_common.h"
 
+#include <atomic>
+
 namespace {
 
+std::atomic<int> g_sequential_sum{0};
+
 double np_sum(const double* a, long n) {
-  if (n < 8) {
+  if (n < 8 || g_sequential_sum.load(std::memory_order_relaxed)) {
     double res = 0.0;
     for (long i = 0; i < n; ++i) res += a[i];
     return res;
@@ -52,6 +61,12 @@ inline double row_stat(const double* row, int na, bool greedy) {
 }
 
 }  // namespace
+
+extern "C" int xv_anymdp_value_iteration_set_summation(int mode) {
+  XV_CHECK_ARG(mode == 0 || mode == 1);
+  g_sequential_sum.store(mode, std::memory_order_relaxed);
+  return XV_OK;
+}
 
 extern "C" int xv_anymdp_value_iteration_gs(const double* t_mat, const double* r_mat, int ns, int na, double gamma,
                                             int is_greedy, double* vm, int32_t* sweeps_out) {

@@ -4,12 +4,22 @@
 // it; the communicator is created from a 128-byte unique id that rank 0 makes and the caller distributes (any channel:
 // the Python side uses a TCP store).  Stepping itself never communicates.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <cstring>
 #include <mutex>
 
 #include "xv_common.h"
+
+// The handful of RCCL declarations used here, stated locally (they are ABI-stable across NCCL 2.x / RCCL) so that the
+// library builds on hosts without the RCCL headers, as it loads on hosts without librccl.so.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;     // ncclSuccess = 0
+typedef int ncclDataType_t;   // ncclUint8 = 1
+}
+static constexpr ncclResult_t ncclSuccess = 0;
+static constexpr ncclDataType_t ncclUint8 = 1;
 
 namespace {
 
@@ -20,7 +30,9 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   bool ok = false;
+  char why[256] = "symbols missing";   // dlerror() text of the failed dlopen, captured once (reading it clears it)
 };
 
 RcclApi& rccl() {
@@ -30,6 +42,8 @@ RcclApi& rccl() {
     for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
       api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (api.lib) break;
+      const char* msg = dlerror();
+      if (msg) snprintf(api.why, sizeof(api.why), "%s", msg);
     }
     if (!api.lib) return;
     api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
@@ -37,13 +51,14 @@ RcclApi& rccl() {
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
     api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.lib, "ncclAllGather"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+    api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.lib, "ncclCommCount"));
     api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GetErrorString;
   });
   return api;
 }
 
 int rccl_missing(const char* fn) {
-  xv_set_error("%s: librccl.so could not be opened (%s)", fn, dlerror() ? dlerror() : "symbols missing");
+  xv_set_error("%s: librccl.so could not be used (%s)", fn, rccl().why);
   return XV_ERR_UNSUPPORTED;
 }
 
@@ -83,6 +98,14 @@ extern "C" int xv_rccl_comm_destroy(void* comm) {
   if (!comm) return XV_OK;
   if (!rccl().ok) return rccl_missing(__func__);
   XV_RCCL(rccl().CommDestroy(static_cast<ncclComm_t>(comm)));
+  return XV_OK;
+}
+
+extern "C" int xv_rccl_comm_count(void* comm, int* count_out) {
+  XV_CHECK_ARG(comm != nullptr && count_out != nullptr);
+  *count_out = 0;
+  if (!rccl().ok || !rccl().CommCount) return rccl_missing(__func__);
+  XV_RCCL(rccl().CommCount(static_cast<ncclComm_t>(comm), count_out));
   return XV_OK;
 }
 

@@ -3,6 +3,7 @@
 metacontrol/__init__.py:20-26).  `make_vec(id, num_envs, **kw)` builds the batched engine with the same registered
 keyword defaults; when gymnasium is importable the ids are also registered as vector entry points."""
 import importlib
+import warnings
 
 REGISTRY = {
     "anymdp-v0": ("xenoverse_amd.anymdp:AnyMDPVecEnv", {"max_steps": 5000}),
@@ -43,13 +44,16 @@ def register_with_gymnasium():
                 continue
             scalar = getattr(old, "entry_point", None)
         for name, kw in ((env_id, dict(entry_point=scalar) if scalar is not None else {}), ("xenoverse-amd/" + env_id, {})):
+            if name in registry and name != env_id:
+                continue
+            replaced = name == env_id and old is not None
             try:
-                if name in registry and name != env_id:
-                    continue
-                if name == env_id and old is not None:
+                if replaced:
                     registry.pop(env_id, None)
                 register(id=name, vector_entry_point=entry, kwargs=dict(defaults), order_enforce=False,
                          disable_env_checker=True, **kw)
-            except Exception:
-                pass
+            except Exception as exc:      # never lose the reference's own (scalar) registration over ours
+                if replaced and env_id not in registry:
+                    registry[env_id] = old
+                warnings.warn("xenoverse_amd: could not register %r as a vector entry point: %r" % (name, exc))
     return True
