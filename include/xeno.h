@@ -323,7 +323,8 @@ int xv_anymdp_synth_tasks(xv_engine* e, uint64_t seed, int64_t task_index_base, 
  * fp32 on the device (north_star: float dynamics within 1e-5 rel of the fp64 reference).  Batch-wide padded
  * dims: NS in {16, 32} (state), NA in {8, 16} (= pad_action_dim), NO in {16, 32} (= pad_observation_dim =
  * pad_command_dim); smaller tasks are zero-padded, which is exact.  Matrices are stored transposed (k-major).
- * Env state x is component-major float[NS][n_env] (lane i reads word i of every component: coalesced).
+ * The engine keeps the env state in its own layout (the accumulator fragments of the matrix kernel, csrc/linds.hip);
+ * xv_linds_get_state / _set_state speak component-major float[NS][n_env] in the caller's env order.
  * ---------------------------------------------------------------------------------------------- */
 #define XV_LINDS_KMAX 6
 typedef struct xv_linds_tables {
@@ -371,7 +372,10 @@ int xv_linds_reset_injected(xv_linds* h, const uint8_t* mask, const int32_t* ini
                             float* cmd, float* error);
 /* one vector step.  action float[n_env][NA] (raw, unclipped: the action cost uses it as given, :164);
  * outputs obs/cmd float[n_env][NO] (info["command"] = cmd(steps)), reward, error (info["error"]), flags;
- * final_obs float[n_env][NO] nullable (SAME_STEP).  Process noise: NS Box-Muller normals per env from Philox. */
+ * final_obs float[n_env][NO] nullable (SAME_STEP): the rows of envs that FINISH in this call receive their last
+ * observation, every other row is left untouched (round 3: 64 B per env-step that ~93 % of the envs never needed) —
+ * read it under terminated | truncated.  Process noise: NS Box-Muller normals per env from Philox (one call per four
+ * state components' lane group: csrc/philox.h xv_box_muller16). */
 int xv_linds_step(xv_linds* h, const float* action, float* obs, float* reward, uint8_t* terminated,
                   uint8_t* truncated, float* cmd, float* error, float* final_obs, int autoreset_mode);
 /* parity hook: z float[NS][n_env] standard normals, init_index int32[n_env] (initial state used on reset) */

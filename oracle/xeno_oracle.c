@@ -66,6 +66,17 @@ void xo_box_muller(uint32_t a, uint32_t b, float* z0, float* z1) {
   if (z1) *z1 = (float)(r * sin(ang));
 }
 
+/* eight normals from one Philox call (csrc/philox.h: xv_box_muller16): word p -> pair p, radius from the high 16 bits,
+ * angle from the low 16 */
+void xo_box_muller16(uint32_t w, float* z0, float* z1) {
+  double u1 = ((double)(w >> 16) + 1.0) * (1.0 / 65536.0); /* (0,1] */
+  double u2 = (double)(w & 0xFFFFu) * (1.0 / 65536.0);     /* [0,1) */
+  double r = sqrt(-2.0 * log(u1));
+  double ang = 6.283185307179586476925286766559 * u2;
+  if (z0) *z0 = (float)(r * cos(ang));
+  if (z1) *z1 = (float)(r * sin(ang));
+}
+
 int xo_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
@@ -452,7 +463,7 @@ static void linds_step_one(xo_linds* h, int i, const float* a_raw, const float* 
   const int t = h->env_task[i], NS = h->NS, NA = h->NA, NO = h->NO, N = h->n_env;
   const float* sc = L_scal(h, t);
   const int32_t* in = L_ints(h, t);
-  if (final_obs) for (int j = 0; j < NO; ++j) final_obs[(size_t)i * NO + j] = 0.0f;
+  /* final_obs: rows of envs that finish in this call only (the device leaves the other rows untouched) */
   if (mode == 1 && h->need_reset[i]) { /* NEXT_STEP: the call after a done returns the reset observation */
     linds_reset_one(h, i, init_idx, obs, cmd, error);
     reward[i] = 0.0f; terminated[i] = 0; truncated[i] = 0;
@@ -460,10 +471,18 @@ static void linds_step_one(xo_linds* h, int i, const float* a_raw, const float* 
   }
   float xs[32], xn[32], act[32], y[32], ctrack[32], crep[32];
   for (int k = 0; k < NS; ++k) xs[k] = h->x[(size_t)k * N + i];
-  float sa = 0.0f;
-  for (int k = 0; k < NA; ++k) { /* :138 clip; :164 cost on the RAW padded action */
+  float sa; /* :164 cost on the RAW padded action, summed like the row sums: chain g over k = g, 4 + g, .. */
+  {
+    float p[4];
+    for (int g = 0; g < 4; ++g) {
+      float acc = 0.0f;
+      for (int kk = 0; kk < NA / 4; ++kk) acc = fmaf(a_raw[4 * kk + g], a_raw[4 * kk + g], acc);
+      p[g] = acc;
+    }
+    sa = (p[0] + p[1]) + (p[2] + p[3]);
+  }
+  for (int k = 0; k < NA; ++k) { /* :138 clip */
     float a = a_raw[k];
-    sa = fmaf(a, a, sa);
     act[k] = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);
   }
   int kord[32];
@@ -515,24 +534,26 @@ void xo_linds_step_injected(xo_linds* h, const float* action, const float* z, co
   }
 }
 
-/* free-running draws: reset index = floor(u53 * n_init) from purpose 1; normals for state component j from
- * Philox purpose 16 + j/4: words (0,1) -> z[4q], z[4q+1] (cos, sin), words (2,3) -> z[4q+2], z[4q+3] */
+/* free-running draws (csrc/linds.hip: linds_init_from_word, linds_noise_group): reset index = floor(w0 * n_init / 2^32)
+ * with w0 the first word of purpose 1; the normal of state component j is normal i = 4 (j >> 4) + (j & 3) of Philox
+ * purpose 16 + ((j >> 2) & 3), whose word p yields normals 2p (cos) and 2p + 1 (sin) */
 static inline int linds_draw_init(const xo_linds* h, int i, uint64_t seed, uint64_t gid, uint64_t tick) {
   uint32_t w[4];
   xo_env_draw(seed, gid, tick, 1, w);
   int n = L_ints(h, h->env_task[i])[2];
-  int idx = (int)(xo_u53(w[0], w[1]) * (double)n);
+  int idx = (int)(((uint64_t)w[0] * (uint64_t)(uint32_t)n) >> 32);
   return idx < n ? idx : n - 1;
 }
 static inline void linds_draw_noise(int NS, uint64_t seed, uint64_t gid, uint64_t tick, float* z) {
-  for (int q = 0; q * 4 < NS; ++q) {
+  for (int g = 0; g < 4; ++g) {
     uint32_t w[4];
-    float a, b, c, d;
-    xo_env_draw(seed, gid, tick, 16u + (uint32_t)q, w);
-    xo_box_muller(w[0], w[1], &a, &b);
-    xo_box_muller(w[2], w[3], &c, &d);
-    float v[4] = {a, b, c, d};
-    for (int e = 0; e < 4 && 4 * q + e < NS; ++e) z[4 * q + e] = v[e];
+    float v[8];
+    xo_env_draw(seed, gid, tick, 16u + (uint32_t)g, w);
+    for (int p = 0; p < 4; ++p) xo_box_muller16(w[p], &v[2 * p], &v[2 * p + 1]);
+    for (int i = 0; i < 8; ++i) {
+      const int j = 16 * (i >> 2) + 4 * g + (i & 3);
+      if (j < NS) z[j] = v[i];
+    }
   }
 }
 

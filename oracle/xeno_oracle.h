@@ -25,6 +25,7 @@ double xo_u53(uint32_t a, uint32_t b);
 void xo_env_draw_sub(uint64_t seed, uint64_t gid, uint64_t tick, uint32_t purpose, uint32_t sub, uint32_t out[4]);
 /* Box-Muller pair from two words (float): z0 = r cos(2 pi u2), z1 = r sin(2 pi u2) */
 void xo_box_muller(uint32_t a, uint32_t b, float* z0, float* z1);
+void xo_box_muller16(uint32_t w, float* z0, float* z1);
 
 typedef struct {
   int n_env, n_task, S, A, s0_max;

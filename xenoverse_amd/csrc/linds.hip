@@ -9,12 +9,20 @@
 // (the accumulator order for BOTH products: the new state comes out of the matrix unit in exactly the registers the
 //  next state product reads its operands from, so a fused multi-step kernel never re-arranges a state)
 //
-// One lane owns one env: its state vector lives in registers (component-major global layout, so the NS loads
-// and stores of a wave are NS coalesced 256-B streams).  The task matrices are NOT read per lane: inside a
-// waterfall over the distinct tasks present in a wave the task index is wave-uniform, so Phi/Gamma/C rows
-// arrive through the scalar cache as SGPR operands of v_fma_f32 (s_load_dwordx16) — 6 KB per (wave, task)
-// instead of 6 KB per env.  With envs grouped by task (64 per task = one wave per task) every wave makes one
-// pass.
+// The product path is the MFMA kernel (one wave per tile of 16 envs that share a task, below).  The scalar kernel — one
+// lane per env, task matrices as scalar-cache broadcast operands inside a waterfall over the wave's tasks — is kept as
+// the independent second implementation the parity tests compare it with (XV_LINDS_PATH_SCALAR; never chosen by AUTO).
+//
+// Engine-owned layouts (round 3; everything the caller sees stays in the caller's env order):
+//   state  x:   "fragment tiles" — float4 unit ((tile * MT + m) * 64 + lane) holds components 16 m + 4 g + r (r = 0..3)
+//               of slot 16 tile + n, lane = 16 g + n: exactly the four accumulator registers lane (n, g) of the matrix
+//               kernel receives for M-tile m, which are also its B operands of the next product.  A step reads and
+//               writes the state with MT coalesced 16-byte accesses per lane (linds_xidx for everybody else).
+//   sn:         one word per slot: steps | need_reset << 31.
+//   frag:       the task matrices re-arranged at create time into the A-operand fragments of the three products, a
+//               float4 list per lane: [task][q][lane] — 7 coalesced 16-byte loads per lane at (32, 8, 16) instead of
+//               28 dword loads with their address arithmetic.
+//   tvec:       [task][NS + 2 NO] = Xt | Y | target_valid, read as float4 quarters.
 #include <vector>
 
 #include "philox.h"
@@ -23,9 +31,8 @@
 struct LinDSArgs {
   xv_linds_tables T;
   const int32_t* env_task;
-  float* x;            // [NS][n_env]
-  int32_t* steps;
-  uint8_t* need_reset;
+  float* x;            // fragment tiles, see above
+  int32_t* sn;         // [n_tile * 16]  steps | need_reset << 31
   uint32_t* err;
   int n_env, n_task, NS, NA, NO, NI;
   uint64_t seed, gid_base, tick;
@@ -36,16 +43,25 @@ struct LinDSArgs {
   // engine-built reset table: rst_tab[task][init index][NO + 4] = the observation of initial_states[idx] (NO floats)
   // and its tracking error against cmd(0) (slot NO): a restarting env reads 80 B instead of redoing y = C x + Y
   const float* rst_tab;
+  const float4* frag;  // [n_task][NQ][64]
+  const float* tvec;   // [n_task][NS + 2 NO]
   // Slot layout (nullptr / n_slot == n_env: identity).  When the caller's env -> task map does not put 16 envs of one
   // task side by side, the engine orders its own state by task instead: envs are sorted by task (stably) and packed
-  // into tiles of 16 slots, a task's last tile padded with empty slots (slot_env = -1).  State arrays (x, steps,
-  // need_reset) are indexed by SLOT with stride n_slot; everything the caller sees (actions, outputs, global env id of
-  // the random draws) stays indexed by ENV, so results do not depend on the layout.
+  // into tiles of 16 slots, a task's last tile padded with empty slots (slot_env = -1).  State (x, sn) is indexed by
+  // SLOT; everything the caller sees (actions, outputs, global env id of the random draws) stays indexed by ENV, so
+  // results do not depend on the layout.
   const int32_t* slot_env;   // [n_slot] env of a slot or -1
   const int32_t* env_slot;   // [n_env]  slot of an env
   const int32_t* tile_task;  // [n_slot / 16]
   int n_slot;
 };
+
+#define XV_LINDS_NR_BIT 0x80000000u
+
+// float index of component k of slot s in the fragment-tile state (MT = NS / 16)
+__host__ __device__ __forceinline__ size_t linds_xidx(int s, int k, int MT) {
+  return ((((size_t)(s >> 4) * MT + (k >> 4)) * 64 + 16 * ((k >> 2) & 3) + (s & 15)) << 2) + (k & 3);
+}
 
 struct LinDSStepIO {
   const float* action;      // [n_env][NA]
@@ -68,6 +84,8 @@ struct xv_linds {
   int path;             // XV_LINDS_PATH_*
   float* cmd_tab;       // owned; a.cmd_tab points here while the table is enabled
   float* rst_tab;       // owned; likewise
+  float4* frag;         // owned
+  float* tvec;          // owned
 };
 
 // Task tables are read-only for the lifetime of a launch: reading them through the constant address space lets
@@ -89,6 +107,33 @@ __host__ __device__ constexpr int linds_yorder_at(int p) {
   return 16 * (p >> 4) + 4 * (p & 3) + ((p >> 2) & 3);
 }
 
+// sin / cos of an angle already reduced to [-pi, pi] in fp64: quadrant in fp64, Taylor polynomials on [-pi/4, pi/4] in
+// fp32 (truncation < 3e-8; ~25 instructions and no slow path, unlike sincosf, which this replaces: the Fourier command
+// is evaluated in a cold corner of the step kernel and must not set its register allocation).  The command table is
+// built with this same function, so table and direct evaluation agree bit for bit.
+__device__ __forceinline__ void xv_sincos_reduced(double a, float* sn, float* cs) {
+  const double q = rint(a * 0.63661977236758134308);
+  const float r = (float)fma(-q, 1.57079632679489661923, a);
+  const float r2 = r * r;
+  float s = fmaf(r2, 2.7557319e-6f, -1.9841270e-4f);
+  s = fmaf(s, r2, 8.3333333e-3f);
+  s = fmaf(s, r2, -1.6666667e-1f);
+  s = fmaf(s * r2, r, r);
+  float c = fmaf(r2, 2.4801587e-5f, -1.3888889e-3f);
+  c = fmaf(c, r2, 4.1666667e-2f);
+  c = fmaf(c, r2, -0.5f);
+  c = fmaf(c, r2, 1.0f);
+  const int qi = (int)q & 3;
+  const float s1 = (qi & 1) ? c : s, c1 = (qi & 1) ? s : c;
+  *sn = (qi & 2) ? -s1 : s1;
+  *cs = ((qi + 1) & 2) ? -c1 : c1;
+}
+__device__ __forceinline__ void linds_four_sincos(const LinDSArgs& P, int tu, int k, double inv_period_t, float* sn, float* cs) {
+  double ang = xv_cptr(P.T.four_omega)[(size_t)tu * XV_LINDS_KMAX + k] * inv_period_t;   // random_nn.py:362-368
+  ang -= 6.283185307179586476925286766559 * rint(ang * 0.15915494309189533576888376337251);
+  xv_sincos_reduced(ang, sn, cs);
+}
+
 // command at integer time tt, times target_valid (uniform task tu; per-lane time)
 template <int NO>
 __device__ __forceinline__ void linds_cmd(const LinDSArgs& P, int tu, int nf, int tt, float (&out)[NO]) {
@@ -102,11 +147,9 @@ __device__ __forceinline__ void linds_cmd(const LinDSArgs& P, int tu, int nf, in
 #pragma unroll
   for (int j = 0; j < NO; ++j) out[j] = 0.0f;
   const double inv_period_t = (double)tt / xv_cptr(P.T.four_period)[tu];
-  for (int k = 0; k < nf; ++k) {   // random_nn.py:362-368
-    double ang = xv_cptr(P.T.four_omega)[(size_t)tu * XV_LINDS_KMAX + k] * inv_period_t;
-    ang -= 6.283185307179586476925286766559 * rint(ang * 0.15915494309189533576888376337251);
+  for (int k = 0; k < nf; ++k) {
     float sn, cs;
-    sincosf((float)ang, &sn, &cs);
+    linds_four_sincos(P, tu, k, inv_period_t, &sn, &cs);
     const XV_CONST_AS float* c = xv_cptr(P.T.four_coef) + (((size_t)tu * XV_LINDS_KMAX + k) * NO) * 2;
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
@@ -116,6 +159,44 @@ __device__ __forceinline__ void linds_cmd(const LinDSArgs& P, int tu, int nf, in
   }
 #pragma unroll
   for (int j = 0; j < NO; ++j) out[j] *= valid[j];   // :98
+}
+
+// the same for the rows 16 mo + 4 g + r of one lane group only (the matrix kernel's cold path: a time outside the command
+// table, or no table): per-lane coefficient reads, four accumulators — same operations per element as above, same bits
+template <int NO>
+__device__ __forceinline__ void linds_cmd_quarter(const LinDSArgs& P, int tu, int nf, int tt, int g, float (&out)[NO / 16][4]) {
+  constexpr int MO = NO / 16;
+  const float* valid = P.T.valid + (size_t)tu * NO + 4 * g;
+  if (nf == 0) {
+    const float* c0 = P.T.cmd0 + (size_t)tu * NO + 4 * g;
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[mo][r] = c0[16 * mo + r] * valid[16 * mo + r];
+    return;
+  }
+#pragma unroll
+  for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[mo][r] = 0.0f;
+  const double inv_period_t = (double)tt / xv_cptr(P.T.four_period)[tu];
+#pragma clang loop unroll(disable)
+  for (int k = 0; k < nf; ++k) {
+    float sn, cs;
+    linds_four_sincos(P, tu, k, inv_period_t, &sn, &cs);
+    const float* c = P.T.four_coef + (((size_t)tu * XV_LINDS_KMAX + k) * NO + 4 * g) * 2;
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        out[mo][r] = fmaf(c[2 * (16 * mo + r)], sn, out[mo][r]);
+        out[mo][r] = fmaf(c[2 * (16 * mo + r) + 1], cs, out[mo][r]);
+      }
+  }
+#pragma unroll
+  for (int mo = 0; mo < MO; ++mo)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[mo][r] *= valid[16 * mo + r];
 }
 
 // The command of an env depends on (task, integer time) only, and a step needs it at two times (tracked and
@@ -194,14 +275,6 @@ __device__ __forceinline__ float linds_sumsq(const float (&y)[NO]) {
   }
   return (p[0] + p[1]) + (p[2] + p[3]);
 }
-// the same two sums from a lane's own rows (register r of tile mo = row 16 mo + 4 g + r), combined across the four lane
-// groups of an env: identical bits in all four
-template <int MO>
-__device__ __forceinline__ float linds_quad_sum(float part) {
-  part = part + __shfl_xor(part, 16);
-  return part + __shfl_xor(part, 32);
-}
-
 template <int N>
 __device__ __forceinline__ void linds_store_row(float* dst, const float (&v)[N]) {
   float4* d4 = reinterpret_cast<float4*>(dst);
@@ -265,10 +338,41 @@ __global__ __launch_bounds__(256) void linds_build_reset_tab_kernel(LinDSArgs P,
   row[NO] = e; row[NO + 1] = 0.0f; row[NO + 2] = 0.0f; row[NO + 3] = 0.0f;
 }
 
-__device__ __forceinline__ int linds_draw_init(const LinDSArgs& P, uint64_t gid, int n_init) {
-  const xv_u32x4 v = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_RESET);
-  const int idx = (int)(xv_u53(v.x, v.y) * (double)n_init);
+// initial-state index of a restarting env: floor(w0 * n_init / 2^32), w0 the first word of the env's RESET draw (one
+// v_mul_hi_u32; oracle: linds_draw_init)
+__device__ __forceinline__ int linds_init_from_word(uint32_t w0, int n_init) {
+  const int idx = (int)__umulhi(w0, (uint32_t)n_init);
   return idx < n_init ? idx : n_init - 1;
+}
+__device__ __forceinline__ int linds_draw_init(const LinDSArgs& P, uint64_t gid, uint64_t tick, int n_init) {
+  return linds_init_from_word(xv_env_draw(P.seed, gid, tick, XV_DRAW_RESET).x, n_init);
+}
+
+// Process noise of state component j: normal i = 4 (j >> 4) + (j & 3) of Philox call XV_DRAW_NOISE + ((j >> 2) & 3)
+// (philox.h: xv_box_muller16) — lane (n, g) of the matrix kernel owns components 16 m + 4 g + r, i.e. ONE call.
+template <int MT>
+__device__ __forceinline__ void linds_noise_group(const LinDSArgs& P, uint64_t gid, uint64_t tick, int g, float (&z)[MT][4]) {
+  const xv_u32x4 w = xv_env_draw(P.seed, gid, tick, XV_DRAW_NOISE + (uint32_t)g);
+  xv_box_muller16(w.x, &z[0][0], &z[0][1]);
+  xv_box_muller16(w.y, &z[0][2], &z[0][3]);
+  if (MT > 1) {
+    xv_box_muller16(w.z, &z[MT - 1][0], &z[MT - 1][1]);
+    xv_box_muller16(w.w, &z[MT - 1][2], &z[MT - 1][3]);
+  }
+}
+
+// sum of squares of the RAW padded action (:164), four fmaf chains like the row sums above: chain g over k = g, 4 + g, ...
+template <int NA>
+__device__ __forceinline__ float linds_action_sq(const float (&a)[NA]) {
+  float p[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < NA / 4; ++kk) acc = fmaf(a[4 * kk + g], a[4 * kk + g], acc);
+    p[g] = acc;
+  }
+  return (p[0] + p[1]) + (p[2] + p[3]);
 }
 
 template <int NS, int NA, int NO, bool INJECT>
@@ -276,14 +380,14 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
   const int N = P.n_env;
-  const int NSL = P.n_slot;
+  constexpr int MT = NS / 16;
   const int si = P.env_slot ? P.env_slot[i] : i;   // where this env's state lives
   const int t = P.env_task[i];
   const uint64_t gid = P.gid_base + (uint64_t)i;
 
   float xs[NS], a_raw[NA];
 #pragma unroll
-  for (int k = 0; k < NS; ++k) xs[k] = P.x[(size_t)k * NSL + si];
+  for (int k = 0; k < NS; ++k) xs[k] = P.x[linds_xidx(si, k, MT)];
   {
     const float4* a4 = reinterpret_cast<const float4*>(io.action + (size_t)i * NA);
 #pragma unroll
@@ -292,8 +396,9 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
       a_raw[4 * q] = v.x; a_raw[4 * q + 1] = v.y; a_raw[4 * q + 2] = v.z; a_raw[4 * q + 3] = v.w;
     }
   }
-  int steps = P.steps[si];
-  int nr = P.need_reset[si];
+  const uint32_t sn0 = (uint32_t)P.sn[si];
+  int steps = (int)(sn0 & ~XV_LINDS_NR_BIT);
+  int nr = (int)(sn0 >> 31);
   int init_idx = 0;
   if (INJECT) init_idx = io.init_index[i];
 
@@ -316,19 +421,17 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
       const XV_CONST_AS float* sc = xv_cptr(P.T.scal) + (size_t)tu * 8;
       const XV_CONST_AS int32_t* in = xv_cptr(P.T.ints) + (size_t)tu * 4;
       const int max_steps = in[0], delay = in[1], n_init = in[2], nf = in[3];
-      if (!INJECT) init_idx = linds_draw_init(P, gid, n_init);
+      if (!INJECT) init_idx = linds_draw_init(P, gid, P.tick, n_init);
       if (mode == XV_AUTORESET_NEXT_STEP && nr) {
         // the call after a done ignores the action and returns the reset observation
         linds_reset_env<NS, NO>(P, tu, nf, n_init, init_idx, xs, y, crep, o_err);
         steps = 0;
         nr = 0;
       } else {
-        float sa = 0.0f, act[NA];
+        float act[NA];
+        const float sa = linds_action_sq<NA>(a_raw);   // :164 cost on the RAW padded action
 #pragma unroll
-        for (int k = 0; k < NA; ++k) {   // :138 clip; :164 cost on the RAW padded action
-          sa = fmaf(a_raw[k], a_raw[k], sa);
-          act[k] = a_raw[k] < -1.0f ? -1.0f : (a_raw[k] > 1.0f ? 1.0f : a_raw[k]);
-        }
+        for (int k = 0; k < NA; ++k) act[k] = a_raw[k] < -1.0f ? -1.0f : (a_raw[k] > 1.0f ? 1.0f : a_raw[k]);   // :138 clip
         float xn[NS];
 #pragma unroll
         for (int j = 0; j < NS; ++j) xn[j] = 0.0f;
@@ -355,23 +458,25 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
         const float noise_scale = sc[4];
         bool bad = false;
 #pragma unroll
-        for (int q = 0; q < NS / 4; ++q) {   // + Xt + noise, four components at a time (the normals are made here, not
-          float z[4];                        // held in 32 registers across the products: that spilled to scratch)
+        for (int gq = 0; gq < 4; ++gq) {   // + Xt + noise: the components 16 m + 4 gq + r of one noise call at a time
+          float z[MT][4];
           if (INJECT) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) z[k] = io.z[(size_t)(4 * q + k) * N + i];
-          } else {   // purpose 16+q: words (0,1) -> z[4q], z[4q+1]; (2,3) -> z[4q+2], z[4q+3]
-            const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_NOISE + (uint32_t)q);
-            xv_box_muller_fast(w.x, w.y, &z[0], &z[1]);
-            xv_box_muller_fast(w.z, w.w, &z[2], &z[3]);
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) z[m][r] = io.z[(size_t)(16 * m + 4 * gq + r) * N + i];
+          } else {
+            linds_noise_group<MT>(P, gid, P.tick, gq, z);
           }
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int j = 4 * q + k;
-            xn[j] = xn[j] + xtv[j];
-            xn[j] = fmaf(noise_scale, z[k], xn[j]);
-            bad = bad || !(fabsf(xn[j]) <= 3.0e38f);
-          }
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int j = 16 * m + 4 * gq + r;
+              xn[j] = xn[j] + xtv[j];
+              xn[j] = fmaf(noise_scale, z[m][r], xn[j]);
+              bad = bad || !(fabsf(xn[j]) <= 3.0e38f);
+            }
         }
         if (bad) err |= XV_DEVERR_NONFINITE;
         linds_observe<NS, NO>(P, tu, xn, y);      // :145
@@ -406,22 +511,15 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
   }
 
 #pragma unroll
-  for (int k = 0; k < NS; ++k) P.x[(size_t)k * NSL + si] = xs[k];
-  P.steps[si] = steps;
-  P.need_reset[si] = (uint8_t)nr;
+  for (int k = 0; k < NS; ++k) P.x[linds_xidx(si, k, MT)] = xs[k];
+  P.sn[si] = (int32_t)((uint32_t)steps | (nr ? XV_LINDS_NR_BIT : 0u));
   linds_store_row<NO>(io.obs + (size_t)i * NO, y);
   linds_store_row<NO>(io.cmd + (size_t)i * NO, crep);
   io.reward[i] = o_r;
   io.error[i] = o_err;
   io.terminated[i] = (uint8_t)o_term;
   io.truncated[i] = (uint8_t)o_trunc;
-  if (io.final_obs) {
-    if (!wrote_fobs) {
-#pragma unroll
-      for (int j = 0; j < NO; ++j) fobs[j] = 0.0f;
-    }
-    linds_store_row<NO>(io.final_obs + (size_t)i * NO, fobs);
-  }
+  if (io.final_obs && wrote_fobs) linds_store_row<NO>(io.final_obs + (size_t)i * NO, fobs);   // rows of finished envs only
   if (err) atomicOr(P.err, err);
 }
 
@@ -432,7 +530,6 @@ __global__ __launch_bounds__(256) void linds_reset_kernel(LinDSArgs P, const uin
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
   if (mask && !mask[i]) return;
-  const int NSL = P.n_slot;
   const int si = P.env_slot ? P.env_slot[i] : i;
   const int t = P.env_task[i];
   float xs[NS], y[NO], c[NO];
@@ -444,15 +541,14 @@ __global__ __launch_bounds__(256) void linds_reset_kernel(LinDSArgs P, const uin
     if (t == tu_cmp) {
       const XV_CONST_AS int32_t* in = xv_cptr(P.T.ints) + (size_t)tu * 4;
       const int n_init = in[2], nf = in[3];
-      const int idx = INJECT ? init_index[i] : linds_draw_init(P, P.gid_base + (uint64_t)i, n_init);
+      const int idx = INJECT ? init_index[i] : linds_draw_init(P, P.gid_base + (uint64_t)i, P.tick, n_init);
       linds_reset_env<NS, NO>(P, tu, nf, n_init, idx, xs, y, c, e);
       break;
     }
   }
 #pragma unroll
-  for (int k = 0; k < NS; ++k) P.x[(size_t)k * NSL + si] = xs[k];
-  P.steps[si] = 0;
-  P.need_reset[si] = 0;
+  for (int k = 0; k < NS; ++k) P.x[linds_xidx(si, k, NS / 16)] = xs[k];
+  P.sn[si] = 0;
   if (obs) linds_store_row<NO>(obs + (size_t)i * NO, y);
   if (cmd) linds_store_row<NO>(cmd + (size_t)i * NO, c);
   if (error) error[i] = e;
@@ -497,406 +593,115 @@ __device__ __forceinline__ float xv_sel4(int g, float a, float b, float c, float
   return (g & 2) ? hi : lo;
 }
 
-template <int NS, int NA, int NO, bool INJECT>
-__device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const LinDSStepIO& io, int mode) {
-  const int lane = threadIdx.x & 63;
-  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  const int tile0 = wave * 16;
-  if (tile0 >= P.n_slot) return;   // wave-uniform
-  const int N = P.n_env;           // stride of the caller's env-ordered arrays
-  const int NSL = P.n_slot;        // stride of the engine's slot-ordered state
-  const int n = lane & 15, g = lane >> 4;
-  constexpr int MT = NS / 16, MO = NO / 16, KS = NS / 4, KA = NA / 4;
-  // es: this lane's state slot; e: the env it serves (its I/O rows and the global id of its draws)
-  const int es = tile0 + n < NSL ? tile0 + n : NSL - 1;
-  int e_raw = tile0 + n;
-  if (P.slot_env != nullptr) e_raw = P.slot_env[es];
-  const bool valid = tile0 + n < NSL && e_raw >= 0 && e_raw < N;
-  const int e = valid ? e_raw : 0;
-  const int t = __builtin_amdgcn_readfirstlane(P.tile_task ? P.tile_task[wave] : P.env_task[tile0]);
-  const uint64_t gid = P.gid_base + (uint64_t)e;
-
-  const XV_CONST_AS float* sc = xv_cptr(P.T.scal) + (size_t)t * 8;
-  const XV_CONST_AS int32_t* in = xv_cptr(P.T.ints) + (size_t)t * 4;
-  const int max_steps = in[0], delay = in[1], n_init = in[2], nf = in[3];
-
-  int steps = P.steps[es];
-  int nr = P.need_reset[es];
-  float a_raw[NA];
-  {
-    const float4* a4 = reinterpret_cast<const float4*>(io.action + (size_t)e * NA);
-#pragma unroll
-    for (int q = 0; q < NA / 4; ++q) {
-      const float4 v = a4[q];
-      a_raw[4 * q] = v.x; a_raw[4 * q + 1] = v.y; a_raw[4 * q + 2] = v.z; a_raw[4 * q + 3] = v.w;
-    }
-  }
-  int init_idx = 0;
-  if (INJECT) init_idx = io.init_index[e];   // free-running: drawn below, only in waves that restart an env
-
-  // ---- all operand fragments first: every load of the step is in flight before the first MFMA ----
-  const float* phiT = P.T.phiT + (size_t)t * NS * NS;
-  const float* gamT = P.T.gamT + (size_t)t * NA * NS;
-  const float* cT = P.T.cT + (size_t)t * NS * NO;
-  const float* xtv = P.T.xt + (size_t)t * NS;
-  float pa[MT][KS], pb[KS], ga[MT][KA], ca[MO][KS], xtr[MT][4];
-#pragma unroll
-  for (int kk = 0; kk < KS; ++kk) {   // slab kk multiplies the k-group {16 (kk>>2) + 4 g + (kk&3)}: linds_yorder
-    const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
-    pb[kk] = P.x[(size_t)k * NSL + es];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) pa[m][kk] = phiT[k * NS + 16 * m + n];
-  }
-#pragma unroll
-  for (int kk = 0; kk < KA; ++kk)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) ga[m][kk] = gamT[(4 * kk + g) * NS + 16 * m + n];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const int k = 16 * (s >> 2) + 4 * g + (s & 3);
-#pragma unroll
-    for (int mo = 0; mo < MO; ++mo) ca[mo][s] = cT[k * NO + 16 * mo + n];
-  }
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xtr[m][r] = xtv[16 * m + 4 * g + r];
-  // command rows, requested with everything else so that their latency (a second dependent level: steps -> row
-  // address) runs under the products: the tracked command cmd(steps - delay) in full (:150-151; the error needs all
-  // of it) and this lane's quarter of the reported one cmd(steps + 1) (:168).  A time outside the table (or no table)
-  // is evaluated directly further down
-  const int steps_new = steps + 1;                            // :147
-  const int trk_time = steps_new - 1 - delay, rep_time = steps_new;
-  const int trk_idx = trk_time - P.ct_tmin, rep_idx = rep_time - P.ct_tmin;
-  const bool trk_in = P.cmd_tab != nullptr && trk_idx >= 0 && trk_idx < P.ct_len;
-  const bool rep_in = P.cmd_tab != nullptr && rep_idx >= 0 && rep_idx < P.ct_len;
-  float ctr[MO][4], crep[MO][4];   // this lane's rows 16 mo + 4 g + r of the two commands
-  if (P.cmd_tab != nullptr) {
-    const float4* p = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + (trk_in ? trk_idx : 0)) * NO);
-    const float4* pr = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + (rep_in ? rep_idx : 0)) * NO);
-#pragma unroll
-    for (int mo = 0; mo < MO; ++mo) {
-      const float4 u = p[4 * mo + g], v = pr[4 * mo + g];
-      ctr[mo][0] = u.x; ctr[mo][1] = u.y; ctr[mo][2] = u.z; ctr[mo][3] = u.w;
-      crep[mo][0] = v.x; crep[mo][1] = v.y; crep[mo][2] = v.z; crep[mo][3] = v.w;
-    }
-  }
-  float vld[MO][4];
-  {
-    const float* vp = P.T.valid + (size_t)t * NO;
-#pragma unroll
-    for (int mo = 0; mo < MO; ++mo) {
-      const float4 v = *reinterpret_cast<const float4*>(vp + 16 * mo + 4 * g);
-      vld[mo][0] = v.x; vld[mo][1] = v.y; vld[mo][2] = v.z; vld[mo][3] = v.w;
-    }
-  }
-  // process noise: independent of every load above, so it is computed while they are in flight.  Philox call
-  // q = 4 m + g yields the normals of components 4 q .. 4 q + 3 = 16 m + 4 g + r
-  float zr[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    if (INJECT) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) zr[m][r] = io.z[(size_t)(16 * m + 4 * g + r) * N + e];
-    } else {
-      const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_NOISE + (uint32_t)(4 * m + g));
-      xv_box_muller_fast(w.x, w.y, &zr[m][0], &zr[m][1]);
-      xv_box_muller_fast(w.z, w.w, &zr[m][2], &zr[m][3]);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-
-  // ---- x' = Phi x + Gamma act  (:78-80): MT independent accumulator chains, interleaved ----
-  xv_f32x4 acc[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) acc[m] = xv_f32x4{0, 0, 0, 0};
-#pragma unroll
-  for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[m][kk], pb[kk], acc[m], 0, 0, 0);
-  float sa = 0.0f;
-#pragma unroll
-  for (int k = 0; k < NA; ++k) sa = fmaf(a_raw[k], a_raw[k], sa);   // :164 cost on the RAW padded action
-#pragma unroll
-  for (int kk = 0; kk < KA; ++kk) {
-    const float ar = xv_sel4(g, a_raw[4 * kk], a_raw[4 * kk + 1], a_raw[4 * kk + 2], a_raw[4 * kk + 3]);
-    const float b = ar < -1.0f ? -1.0f : (ar > 1.0f ? 1.0f : ar);   // :138 clip
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[m][kk], b, acc[m], 0, 0, 0);
-  }
-  // + Xt + noise on this lane's components
-  const float noise_scale = sc[4];
-  xv_f32x4 xn[MT];
-  int bad = 0;
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = acc[m][r] + xtr[m][r];
-      v = fmaf(noise_scale, zr[m][r], v);
-      bad |= !(fabsf(v) <= 3.0e38f);
-      xn[m][r] = v;
-    }
-
-  // ---- y = C x' + Y (:145): slab s = 4 m + r takes register r of tile m ----
-  const XV_CONST_AS float* y0 = xv_cptr(P.T.y0) + (size_t)t * NO;
-  xv_f32x4 ym[MO];   // this lane's rows 16 mo + 4 g + r
-#pragma unroll
-  for (int mo = 0; mo < MO; ++mo) ym[mo] = xv_f32x4{0, 0, 0, 0};
-#pragma unroll
-  for (int s = 0; s < KS; ++s)
-#pragma unroll
-    for (int mo = 0; mo < MO; ++mo)
-      ym[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[mo][s], xn[s >> 2][s & 3], ym[mo], 0, 0, 0);
-#pragma unroll
-  for (int mo = 0; mo < MO; ++mo) xv_mfma_settle(ym[mo]);
-#pragma unroll
-  for (int mo = 0; mo < MO; ++mo)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ym[mo][r] = ym[mo][r] + xv_sel4(g, y0[16 * mo + r], y0[16 * mo + 4 + r], y0[16 * mo + 8 + r], y0[16 * mo + 12 + r]);   // :85
-  if (__ballot(!(trk_in && rep_in)) != 0ull) {   // rare: no table, or an env stepped on outside it (auto-reset disabled)
-    float full[NO];
-    if (!trk_in) {
-      linds_cmd<NO>(P, t, nf, trk_time, full);
-#pragma unroll
-      for (int mo = 0; mo < MO; ++mo)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          ctr[mo][r] = xv_sel4(g, full[16 * mo + r], full[16 * mo + 4 + r], full[16 * mo + 8 + r], full[16 * mo + 12 + r]);
-    }
-    if (!rep_in) {
-      linds_cmd<NO>(P, t, nf, rep_time, full);
-#pragma unroll
-      for (int mo = 0; mo < MO; ++mo)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          crep[mo][r] = xv_sel4(g, full[16 * mo + r], full[16 * mo + 4 + r], full[16 * mo + 8 + r], full[16 * mo + 12 + r]);
-    }
-  }
-  // tracking error (:153) and observation scale (:154): chain g over this lane's own rows, the four lane groups of an
-  // env combined by two xor-shuffles — the order linds_err / linds_sumsq define
-  float pe = 0.0f, ps = 0.0f;
-#pragma unroll
-  for (int mo = 0; mo < MO; ++mo)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float d = (ym[mo][r] - ctr[mo][r]) * vld[mo][r];
-      pe = fmaf(d, d, pe);
-      ps = fmaf(ym[mo][r], ym[mo][r], ps);
-    }
-  float o_err = sqrtf(linds_quad_sum<MO>(pe));
-  const float obs_scale = sqrtf(linds_quad_sum<MO>(ps));
-  int o_term = ((o_err > 10.0f) || (obs_scale > 20.0f)) ? 1 : 0;   // :156
-  float o_r = o_term ? -sc[2] : 0.0f;                         // :158-161
-  float tmp = fmaf(-sc[3], o_err, sc[1]);
-  tmp = fmaf(-sc[0], sa, tmp);
-  o_r = fmaf(tmp, sc[5], o_r);                                // :163-164
-  int o_trunc = (steps_new >= max_steps - 1) ? 1 : 0;         // :165
-
-  // ---- which envs (re)start this call ----
-  const bool skip = (mode == XV_AUTORESET_NEXT_STEP) && nr;   // the call after a done: reset only
-  const bool done = !skip && (o_term || o_trunc);
-  const bool do_reset = skip || (done && mode == XV_AUTORESET_SAME_STEP);
-  int wrote_fobs = 0;
-  xv_f32x4 fobs[MO];
-#pragma unroll
-  for (int mo = 0; mo < MO; ++mo) fobs[mo] = xv_f32x4{0, 0, 0, 0};
-  if (skip) {
-    o_r = 0.0f; o_term = 0; o_trunc = 0; bad = 0;
-  } else {
-    steps = steps_new;
-    if (done && mode == XV_AUTORESET_NEXT_STEP) nr = 1;
-  }
-  if (__ballot(do_reset) != 0ull) {   // wave-uniform: the restarted envs take their initial state
-    if (!INJECT) init_idx = linds_draw_init(P, gid, n_init);
-    const int idx = init_idx < 0 ? 0 : (init_idx >= n_init ? n_init - 1 : init_idx);
-    const float* x0 = P.T.init + ((size_t)t * P.NI + idx) * NS;
-    xv_f32x4 xr[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      xr[m] = xn[m];
-      if (do_reset) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xr[m][r] = x0[16 * m + 4 * g + r];   // :117
-      }
-    }
-    float c0[NO], e0;
-    linds_cmd_at<NO>(P, t, nf, 0, c0);                // :120-126
-    xv_f32x4 yr[MO];
-    if (P.rst_tab != nullptr) {                        // observation and error of initial_states[idx], tabulated
-      const float4* row = reinterpret_cast<const float4*>(P.rst_tab + ((size_t)t * P.NI + idx) * (NO + 4));
-#pragma unroll
-      for (int mo = 0; mo < MO; ++mo) {
-        const float4 v = row[4 * mo + g];
-        yr[mo][0] = v.x; yr[mo][1] = v.y; yr[mo][2] = v.z; yr[mo][3] = v.w;
-      }
-      e0 = row[NO / 4].x;
-    } else {
-#pragma unroll
-      for (int mo = 0; mo < MO; ++mo) yr[mo] = xv_f32x4{0, 0, 0, 0};
-#pragma unroll
-      for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int mo = 0; mo < MO; ++mo)
-          yr[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[mo][s], xr[s >> 2][s & 3], yr[mo], 0, 0, 0);
-#pragma unroll
-      for (int mo = 0; mo < MO; ++mo) xv_mfma_settle(yr[mo]);
-      float yfull[NO];
-#pragma unroll
-      for (int mo = 0; mo < MO; ++mo) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) yr[mo][r] = yr[mo][r] + xv_sel4(g, y0[16 * mo + r], y0[16 * mo + 4 + r], y0[16 * mo + 8 + r], y0[16 * mo + 12 + r]);
-#pragma unroll
-        for (int gs = 0; gs < 4; ++gs)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) yfull[16 * mo + 4 * gs + r] = __shfl(yr[mo][r], n + 16 * gs);
-      }
-      e0 = linds_err<NO>(P, t, yfull, c0);
-    }
-    if (do_reset) {
-      if (!skip) {
-#pragma unroll
-        for (int mo = 0; mo < MO; ++mo) fobs[mo] = ym[mo];
-        wrote_fobs = 1;
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m) xn[m] = xr[m];
-#pragma unroll
-      for (int mo = 0; mo < MO; ++mo) {
-        ym[mo] = yr[mo];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          crep[mo][r] = xv_sel4(g, c0[16 * mo + r], c0[16 * mo + 4 + r], c0[16 * mo + 8 + r], c0[16 * mo + 12 + r]);
-      }
-      o_err = e0;
-      steps = 0;
-      nr = 0;
-    }
-  }
-  if (skip) bad = 0;
-
-  // ---- stores ----
-  if (valid) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) P.x[(size_t)(16 * m + 4 * g + r) * NSL + es] = xn[m][r];
-#pragma unroll
-    for (int mo = 0; mo < MO; ++mo) {   // each lane stores its own 16-byte quarter of the rows
-      const size_t ro = (size_t)e * NO + 16 * mo + 4 * g;
-      *reinterpret_cast<float4*>(io.obs + ro) = make_float4(ym[mo][0], ym[mo][1], ym[mo][2], ym[mo][3]);
-      *reinterpret_cast<float4*>(io.cmd + ro) = make_float4(crep[mo][0], crep[mo][1], crep[mo][2], crep[mo][3]);
-      if (io.final_obs)
-        *reinterpret_cast<float4*>(io.final_obs + ro) =
-            wrote_fobs ? make_float4(fobs[mo][0], fobs[mo][1], fobs[mo][2], fobs[mo][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (g == 0) {
-      P.steps[es] = steps;
-      P.need_reset[es] = (uint8_t)nr;
-      io.reward[e] = o_r;
-      io.error[e] = o_err;
-      io.terminated[e] = (uint8_t)o_term;
-      io.truncated[e] = (uint8_t)o_trunc;
-    }
-  }
-  if (bad && valid) atomicOr(P.err, (uint32_t)XV_DEVERR_NONFINITE);
+// (p0 + p1) + (p2 + p3) of a per-lane-group partial in every lane of the env's quad (lanes n, n + 16, n + 32, n + 48): the
+// order linds_err / linds_sumsq / linds_action_sq define.  gfx950's row / half swaps instead of two LDS-crossbar
+// permutes: v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its second,
+// v_permlane32_swap the upper half of the first with the lower half of the second; applied to two copies of a value
+// they leave {own, neighbour} in the two registers, and the addition is commutative.
+__device__ __forceinline__ float linds_quad_sum(float part) {
+  const uint32_t v = __float_as_uint(part);
+  const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const uint32_t w = __float_as_uint(s);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Fused roll-out: T steps of the tile in one launch, SAME_STEP auto-reset, free-running noise.  The task's operand
-// fragments are loaded once and the state never leaves the registers the matrix unit wrote it to (see the k order
-// above); per step only the action row and the two command rows come in and the outputs go out.  Step t draws with
-// tick0 + t, so the result equals T calls of xv_linds_step bit for bit (tested).
-// ------------------------------------------------------------------------------------------------
-struct LinDSRolloutIO {
-  const float* action;      // [T][n_env][NA]
-  float* obs;               // [T][n_env][NO]
-  float* reward;            // [T][n_env]
-  uint8_t* terminated;
-  uint8_t* truncated;
-  float* cmd;               // [T][n_env][NO]  nullable
-  float* error;             // [T][n_env]      nullable
-  float* final_obs;         // [T][n_env][NO]  nullable
-};
-
+// what a wave loads once per task: the A-operand fragments of the three products and the per-row vectors of its lane group
 template <int NS, int NA, int NO>
-__global__ __launch_bounds__(256) void linds_rollout_mfma_kernel(LinDSArgs P, LinDSRolloutIO io, int T) {
-  const int lane = threadIdx.x & 63;
-  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  const int tile0 = wave * 16;
-  if (tile0 >= P.n_slot) return;   // wave-uniform
-  const int N = P.n_env, NSL = P.n_slot;
-  const int n = lane & 15, g = lane >> 4;
-  constexpr int MT = NS / 16, MO = NO / 16, KS = NS / 4, KA = NA / 4;
-  const int es = tile0 + n < NSL ? tile0 + n : NSL - 1;
-  int e_raw = tile0 + n;
-  if (P.slot_env != nullptr) e_raw = P.slot_env[es];
-  const bool valid = tile0 + n < NSL && e_raw >= 0 && e_raw < N;
-  const int e = valid ? e_raw : 0;
-  const int t = __builtin_amdgcn_readfirstlane(P.tile_task ? P.tile_task[wave] : P.env_task[tile0]);
-  const uint64_t gid = P.gid_base + (uint64_t)e;
-  const XV_CONST_AS float* sc = xv_cptr(P.T.scal) + (size_t)t * 8;
-  const XV_CONST_AS int32_t* in = xv_cptr(P.T.ints) + (size_t)t * 4;
-  const int max_steps = in[0], delay = in[1], n_init = in[2], nf = in[3];
-  const float noise_scale = sc[4];
-
-  // ---- once per launch: the task's operand fragments and the state ----
-  const float* phiT = P.T.phiT + (size_t)t * NS * NS;
-  const float* gamT = P.T.gamT + (size_t)t * NA * NS;
-  const float* cT = P.T.cT + (size_t)t * NS * NO;
-  const float* xtv = P.T.xt + (size_t)t * NS;
-  float pa[MT][KS], ga[MT][KA], ca[MO][KS], xtr[MT][4], y0r[MO][4];
-  xv_f32x4 xs[MT];
+struct LinDSFrag {
+  static constexpr int MT = NS / 16, MO = NO / 16, KS = NS / 4, KA = NA / 4;
+  static constexpr int NF = MT * KS + MT * KA + MO * KS, NQ = (NF + 3) / 4;
+  float f[NQ * 4];
+  float xtr[MT][4], y0r[MO][4], vld[MO][4];
+  __device__ __forceinline__ float pa(int m, int kk) const { return f[m * KS + kk]; }
+  __device__ __forceinline__ float ga(int m, int kk) const { return f[MT * KS + m * KA + kk]; }
+  __device__ __forceinline__ float ca(int mo, int s) const { return f[MT * KS + MT * KA + mo * KS + s]; }
+  __device__ __forceinline__ void load(const LinDSArgs& P, int t, int lane) {
+    const float4* fq = P.frag + (size_t)t * NQ * 64 + lane;
 #pragma unroll
-  for (int kk = 0; kk < KS; ++kk) {
-    const int k = 16 * (kk >> 2) + 4 * g + (kk & 3);
-    xs[kk >> 2][kk & 3] = P.x[(size_t)k * NSL + es];
+    for (int q = 0; q < NQ; ++q) {
+      const float4 v = fq[q * 64];
+      f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+    }
+    const float* tv = P.tvec + (size_t)t * (NS + 2 * NO) + 4 * (lane >> 4);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) pa[m][kk] = phiT[k * NS + 16 * m + n];
-#pragma unroll
-    for (int mo = 0; mo < MO; ++mo) ca[mo][kk] = cT[k * NO + 16 * mo + n];
-  }
-#pragma unroll
-  for (int kk = 0; kk < KA; ++kk)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) ga[m][kk] = gamT[(4 * kk + g) * NS + 16 * m + n];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xtr[m][r] = xtv[16 * m + 4 * g + r];
-  float vld[MO][4];
-  {
-    const float* vp = P.T.valid + (size_t)t * NO;
-    const float* yp = P.T.y0 + (size_t)t * NO;
+    for (int m = 0; m < MT; ++m) {
+      const float4 v = *reinterpret_cast<const float4*>(tv + 16 * m);
+      xtr[m][0] = v.x; xtr[m][1] = v.y; xtr[m][2] = v.z; xtr[m][3] = v.w;
+    }
 #pragma unroll
     for (int mo = 0; mo < MO; ++mo) {
-      const float4 v = *reinterpret_cast<const float4*>(vp + 16 * mo + 4 * g);
-      const float4 w = *reinterpret_cast<const float4*>(yp + 16 * mo + 4 * g);
-      vld[mo][0] = v.x; vld[mo][1] = v.y; vld[mo][2] = v.z; vld[mo][3] = v.w;
-      y0r[mo][0] = w.x; y0r[mo][1] = w.y; y0r[mo][2] = w.z; y0r[mo][3] = w.w;
+      const float4 v = *reinterpret_cast<const float4*>(tv + NS + 16 * mo);
+      const float4 w = *reinterpret_cast<const float4*>(tv + NS + NO + 16 * mo);
+      y0r[mo][0] = v.x; y0r[mo][1] = v.y; y0r[mo][2] = v.z; y0r[mo][3] = v.w;
+      vld[mo][0] = w.x; vld[mo][1] = w.y; vld[mo][2] = w.z; vld[mo][3] = w.w;
     }
   }
-  int steps = P.steps[es];
-  int bad_any = 0;
+};
 
-  for (int ts = 0; ts < T; ++ts) {
-    const uint64_t tick = P.tick + (uint64_t)ts;
-    const size_t ob = (size_t)ts * N + e;          // this step's slot of the [T][n_env] outputs
-    float a_raw[NA];
-    {
-      const float4* a4 = reinterpret_cast<const float4*>(io.action + ob * NA);
-#pragma unroll
-      for (int q = 0; q < NA / 4; ++q) {
-        const float4 v = a4[q];
-        a_raw[4 * q] = v.x; a_raw[4 * q + 1] = v.y; a_raw[4 * q + 2] = v.z; a_raw[4 * q + 3] = v.w;
-      }
+// builds frag (one thread per (task, q, lane)) and tvec from the caller's tables
+__global__ __launch_bounds__(256) void linds_build_frag_kernel(LinDSArgs P, float4* frag, float* tvec) {
+  const int NS = P.NS, NA = P.NA, NO = P.NO;
+  const int MT = NS / 16, MO = NO / 16, KS = NS / 4, KA = NA / 4;
+  const int NF = MT * KS + MT * KA + MO * KS, NQ = (NF + 3) / 4;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < (size_t)P.n_task * (NS + 2 * NO)) {
+    const int t = (int)(idx / (NS + 2 * NO)), j = (int)(idx % (NS + 2 * NO));
+    tvec[idx] = j < NS ? P.T.xt[(size_t)t * NS + j]
+              : j < NS + NO ? P.T.y0[(size_t)t * NO + j - NS] : P.T.valid[(size_t)t * NO + j - NS - NO];
+  }
+  if (idx >= (size_t)P.n_task * NQ * 64) return;
+  const int lane = (int)(idx & 63), q = (int)((idx >> 6) % NQ), t = (int)((idx >> 6) / NQ);
+  const int n = lane & 15, g = lane >> 4;
+  float v[4];
+  for (int c = 0; c < 4; ++c) {
+    int fi = 4 * q + c;
+    float val = 0.0f;
+    if (fi < MT * KS) {          // pa[m][kk] = Phi[16 m + n][k],  k = 16 (kk >> 2) + 4 g + (kk & 3)   (linds_yorder)
+      const int m = fi / KS, kk = fi % KS, k = 16 * (kk >> 2) + 4 * g + (kk & 3);
+      val = P.T.phiT[((size_t)t * NS + k) * NS + 16 * m + n];
+    } else if ((fi -= MT * KS) < MT * KA) {   // ga[m][kk] = Gamma[16 m + n][4 kk + g]
+      const int m = fi / KA, kk = fi % KA;
+      val = P.T.gamT[((size_t)t * NA + 4 * kk + g) * NS + 16 * m + n];
+    } else if ((fi -= MT * KA) < MO * KS) {   // ca[mo][s] = C[16 mo + n][k],  k as above for slab s
+      const int mo = fi / KS, sl = fi % KS, k = 16 * (sl >> 2) + 4 * g + (sl & 3);
+      val = P.T.cT[((size_t)t * NS + k) * NO + 16 * mo + n];
     }
+    v[c] = val;
+  }
+  frag[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// One step of one tile, state in / out of registers.  Shared by the single-step kernel and the fused roll-out.
+//   xs    in: the tile's state fragments (this lane: components 16 m + 4 g + r); out: the state after the step / restart
+//   steps in / out; nr: need_reset, in / out
+template <int NS, int NA, int NO, bool INJECT>
+struct LinDSTileStep {
+  using F = LinDSFrag<NS, NA, NO>;
+  static constexpr int MT = F::MT, MO = F::MO, KS = F::KS, KA = F::KA;
+
+  __device__ __forceinline__ static void run(const LinDSArgs& P, const F& fr, int t, int lane, int e, bool valid, uint64_t gid,
+                                             uint64_t tick, int mode, const float* action_row, const float* z_inj, int N,
+                                             int init_inj, size_t orow /* row of this env in the [.][n_env] outputs */,
+                                             float* o_obs, float* o_cmd, float* o_fobs, float* o_reward, float* o_error,
+                                             uint8_t* o_term_p, uint8_t* o_trunc_p, xv_f32x4 (&xs)[MT], int& steps, int& nr,
+                                             int& bad_out) {
+    const int g = lane >> 4;
+    const XV_CONST_AS float* sc = xv_cptr(P.T.scal) + (size_t)t * 8;
+    const XV_CONST_AS int32_t* in = xv_cptr(P.T.ints) + (size_t)t * 4;
+    const int max_steps = in[0], delay = in[1], n_init = in[2], nf = in[3];
+
+    // ---- this step's inputs: two action words, two command quarters ----
+    float ak[KA];
+#pragma unroll
+    for (int kk = 0; kk < KA; ++kk) ak[kk] = action_row[4 * kk + g];
     const int steps_new = steps + 1;                            // :147
-    const int trk_time = steps_new - 1 - delay, rep_time = steps_new;
+    const int trk_time = steps_new - 1 - delay, rep_time = steps_new;   // tracked :150-151, reported :168
     const int trk_idx = trk_time - P.ct_tmin, rep_idx = rep_time - P.ct_tmin;
     const bool trk_in = P.cmd_tab != nullptr && trk_idx >= 0 && trk_idx < P.ct_len;
     const bool rep_in = P.cmd_tab != nullptr && rep_idx >= 0 && rep_idx < P.ct_len;
-    float ctr[MO][4], crep[MO][4];
+    float ctr[MO][4], crep[MO][4];   // this lane's rows 16 mo + 4 g + r of the two commands
     if (P.cmd_tab != nullptr) {
       const float4* p = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + (trk_in ? trk_idx : 0)) * NO);
       const float4* pr = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + (rep_in ? rep_idx : 0)) * NO);
@@ -907,14 +712,19 @@ __global__ __launch_bounds__(256) void linds_rollout_mfma_kernel(LinDSArgs P, Li
         crep[mo][0] = v.x; crep[mo][1] = v.y; crep[mo][2] = v.z; crep[mo][3] = v.w;
       }
     }
+    // process noise: independent of every load, computed while they are in flight
     float zr[MT][4];
+    if (INJECT) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const xv_u32x4 w = xv_env_draw(P.seed, gid, tick, XV_DRAW_NOISE + (uint32_t)(4 * m + g));
-      xv_box_muller_fast(w.x, w.y, &zr[m][0], &zr[m][1]);
-      xv_box_muller_fast(w.z, w.w, &zr[m][2], &zr[m][3]);
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zr[m][r] = z_inj[(size_t)(16 * m + 4 * g + r) * N + e];
+    } else {
+      linds_noise_group<MT>(P, gid, tick, g, zr);
     }
-    // ---- x' = Phi x + Gamma act ----
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- x' = Phi x + Gamma act  (:78-80): MT independent accumulator chains, interleaved ----
     xv_f32x4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = xv_f32x4{0, 0, 0, 0};
@@ -922,109 +732,114 @@ __global__ __launch_bounds__(256) void linds_rollout_mfma_kernel(LinDSArgs P, Li
     for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
       for (int m = 0; m < MT; ++m)
-        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[m][kk], xs[kk >> 2][kk & 3], acc[m], 0, 0, 0);
-    float sa = 0.0f;
-#pragma unroll
-    for (int k = 0; k < NA; ++k) sa = fmaf(a_raw[k], a_raw[k], sa);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr.pa(m, kk), xs[kk >> 2][kk & 3], acc[m], 0, 0, 0);
+    float psa = 0.0f;   // :164 cost on the RAW padded action: this lane group's chain of linds_action_sq
 #pragma unroll
     for (int kk = 0; kk < KA; ++kk) {
-      const float ar = xv_sel4(g, a_raw[4 * kk], a_raw[4 * kk + 1], a_raw[4 * kk + 2], a_raw[4 * kk + 3]);
-      const float b = ar < -1.0f ? -1.0f : (ar > 1.0f ? 1.0f : ar);
+      psa = fmaf(ak[kk], ak[kk], psa);
+      const float b = ak[kk] < -1.0f ? -1.0f : (ak[kk] > 1.0f ? 1.0f : ak[kk]);   // :138 clip
 #pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[m][kk], b, acc[m], 0, 0, 0);
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr.ga(m, kk), b, acc[m], 0, 0, 0);
     }
+    // + Xt + noise on this lane's components
+    const float noise_scale = sc[4];
     xv_f32x4 xn[MT];
     int bad = 0;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = acc[m][r] + xtr[m][r];
+        float v = acc[m][r] + fr.xtr[m][r];
         v = fmaf(noise_scale, zr[m][r], v);
         bad |= !(fabsf(v) <= 3.0e38f);
         xn[m][r] = v;
       }
-    // ---- y = C x' + Y ----
-    xv_f32x4 ym[MO];
+
+    // ---- y = C x' + Y (:145): slab s = 4 m + r takes register r of tile m ----
+    xv_f32x4 ym[MO];   // this lane's rows 16 mo + 4 g + r
 #pragma unroll
     for (int mo = 0; mo < MO; ++mo) ym[mo] = xv_f32x4{0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int mo = 0; mo < MO; ++mo)
-        ym[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[mo][s], xn[s >> 2][s & 3], ym[mo], 0, 0, 0);
+        ym[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr.ca(mo, s), xn[s >> 2][s & 3], ym[mo], 0, 0, 0);
 #pragma unroll
     for (int mo = 0; mo < MO; ++mo) xv_mfma_settle(ym[mo]);
 #pragma unroll
     for (int mo = 0; mo < MO; ++mo)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ym[mo][r] = ym[mo][r] + y0r[mo][r];
-    if (__ballot(!(trk_in && rep_in)) != 0ull) {
-      float full[NO];
-      if (!trk_in) {
-        linds_cmd<NO>(P, t, nf, trk_time, full);
-#pragma unroll
-        for (int mo = 0; mo < MO; ++mo)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            ctr[mo][r] = xv_sel4(g, full[16 * mo + r], full[16 * mo + 4 + r], full[16 * mo + 8 + r], full[16 * mo + 12 + r]);
-      }
-      if (!rep_in) {
-        linds_cmd<NO>(P, t, nf, rep_time, full);
-#pragma unroll
-        for (int mo = 0; mo < MO; ++mo)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            crep[mo][r] = xv_sel4(g, full[16 * mo + r], full[16 * mo + 4 + r], full[16 * mo + 8 + r], full[16 * mo + 12 + r]);
-      }
+      for (int r = 0; r < 4; ++r) ym[mo][r] = ym[mo][r] + fr.y0r[mo][r];   // :85
+    if (__ballot(!(trk_in && rep_in)) != 0ull) {   // rare: no table, or an env stepped on outside it (auto-reset disabled)
+      if (!trk_in) linds_cmd_quarter<NO>(P, t, nf, trk_time, g, ctr);
+      if (!rep_in) linds_cmd_quarter<NO>(P, t, nf, rep_time, g, crep);
     }
+    // tracking error (:153), observation scale (:154), action cost: chain g over this lane's own rows, the four lane
+    // groups of an env combined by linds_quad_sum — the order linds_err / linds_sumsq / linds_action_sq define
     float pe = 0.0f, ps = 0.0f;
 #pragma unroll
     for (int mo = 0; mo < MO; ++mo)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float d = (ym[mo][r] - ctr[mo][r]) * vld[mo][r];
+        const float d = (ym[mo][r] - ctr[mo][r]) * fr.vld[mo][r];
         pe = fmaf(d, d, pe);
         ps = fmaf(ym[mo][r], ym[mo][r], ps);
       }
-    float o_err = sqrtf(linds_quad_sum<MO>(pe));
-    const float obs_scale = sqrtf(linds_quad_sum<MO>(ps));
-    const int o_term = ((o_err > 10.0f) || (obs_scale > 20.0f)) ? 1 : 0;
-    float o_r = o_term ? -sc[2] : 0.0f;
+    float o_err = sqrtf(linds_quad_sum(pe));
+    const float obs_scale = sqrtf(linds_quad_sum(ps));
+    const float sa = linds_quad_sum(psa);
+    int o_term = ((o_err > 10.0f) || (obs_scale > 20.0f)) ? 1 : 0;   // :156
+    float o_r = o_term ? -sc[2] : 0.0f;                         // :158-161
     float tmp = fmaf(-sc[3], o_err, sc[1]);
     tmp = fmaf(-sc[0], sa, tmp);
-    o_r = fmaf(tmp, sc[5], o_r);
-    const int o_trunc = (steps_new >= max_steps - 1) ? 1 : 0;
-    const bool do_reset = o_term || o_trunc;
-    steps = steps_new;
-    int wrote_fobs = 0;
-    xv_f32x4 fobs[MO];
+    o_r = fmaf(tmp, sc[5], o_r);                                // :163-164
+    int o_trunc = (steps_new >= max_steps - 1) ? 1 : 0;         // :165
+
+    // ---- which envs (re)start this call ----
+    const bool skip = (mode == XV_AUTORESET_NEXT_STEP) && nr;   // the call after a done: reset only
+    const bool done = !skip && (o_term || o_trunc);
+    const bool do_reset = skip || (done && mode == XV_AUTORESET_SAME_STEP);
+    if (skip) {
+      o_r = 0.0f; o_term = 0; o_trunc = 0; bad = 0;
+    } else {
+      steps = steps_new;
+      if (done && mode == XV_AUTORESET_NEXT_STEP) nr = 1;
+    }
+    if (valid && done && mode == XV_AUTORESET_SAME_STEP && o_fobs != nullptr) {   // final observation: finished envs only
 #pragma unroll
-    for (int mo = 0; mo < MO; ++mo) fobs[mo] = xv_f32x4{0, 0, 0, 0};
-    if (__ballot(do_reset) != 0ull) {
-      const xv_u32x4 v = xv_env_draw(P.seed, gid, tick, XV_DRAW_RESET);
-      int idx = (int)(xv_u53(v.x, v.y) * (double)n_init);
-      idx = idx < n_init ? idx : n_init - 1;
-      idx = idx < 0 ? 0 : idx;
-      const float* x0 = P.T.init + ((size_t)t * P.NI + idx) * NS;
+      for (int mo = 0; mo < MO; ++mo)
+        *reinterpret_cast<float4*>(o_fobs + orow * NO + 16 * mo + 4 * g) = make_float4(ym[mo][0], ym[mo][1], ym[mo][2], ym[mo][3]);
+    }
+    if (__ballot(do_reset) != 0ull) {   // wave-uniform: the restarted envs take their initial state
+      int idx = INJECT ? init_inj : linds_draw_init(P, gid, tick, n_init);
+      idx = idx < 0 ? 0 : (idx >= n_init ? n_init - 1 : idx);
+      const float* x0 = P.T.init + ((size_t)t * P.NI + idx) * NS + 4 * g;
       xv_f32x4 xr[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        xr[m] = xn[m];
-        if (do_reset) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) xr[m][r] = x0[16 * m + 4 * g + r];
-        }
+        const float4 v = *reinterpret_cast<const float4*>(x0 + 16 * m);   // :117
+        xr[m] = do_reset ? xv_f32x4{v.x, v.y, v.z, v.w} : xn[m];
       }
-      float c0[NO], e0;
-      linds_cmd_at<NO>(P, t, nf, 0, c0);
+      float c0[MO][4];   // :120-126: the last pre-filled command is cmd(0)
+      const int z_idx = 0 - P.ct_tmin;
+      if (P.cmd_tab != nullptr && z_idx >= 0 && z_idx < P.ct_len) {
+        const float4* p = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + z_idx) * NO);
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo) {
+          const float4 v = p[4 * mo + g];
+          c0[mo][0] = v.x; c0[mo][1] = v.y; c0[mo][2] = v.z; c0[mo][3] = v.w;
+        }
+      } else {
+        linds_cmd_quarter<NO>(P, t, nf, 0, g, c0);
+      }
       xv_f32x4 yr[MO];
-      if (P.rst_tab != nullptr) {
+      float e0;
+      if (P.rst_tab != nullptr) {                        // observation and error of initial_states[idx], tabulated
         const float4* row = reinterpret_cast<const float4*>(P.rst_tab + ((size_t)t * P.NI + idx) * (NO + 4));
 #pragma unroll
         for (int mo = 0; mo < MO; ++mo) {
-          const float4 q4 = row[4 * mo + g];
-          yr[mo][0] = q4.x; yr[mo][1] = q4.y; yr[mo][2] = q4.z; yr[mo][3] = q4.w;
+          const float4 v = row[4 * mo + g];
+          yr[mo] = xv_f32x4{v.x, v.y, v.z, v.w};
         }
         e0 = row[NO / 4].x;
       } else {
@@ -1034,70 +849,152 @@ __global__ __launch_bounds__(256) void linds_rollout_mfma_kernel(LinDSArgs P, Li
         for (int s = 0; s < KS; ++s)
 #pragma unroll
           for (int mo = 0; mo < MO; ++mo)
-            yr[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[mo][s], xr[s >> 2][s & 3], yr[mo], 0, 0, 0);
+            yr[mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr.ca(mo, s), xr[s >> 2][s & 3], yr[mo], 0, 0, 0);
 #pragma unroll
         for (int mo = 0; mo < MO; ++mo) xv_mfma_settle(yr[mo]);
-        float yfull[NO];
+        float pr0 = 0.0f;
 #pragma unroll
-        for (int mo = 0; mo < MO; ++mo) {
+        for (int mo = 0; mo < MO; ++mo)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) yr[mo][r] = yr[mo][r] + y0r[mo][r];
-#pragma unroll
-          for (int gs = 0; gs < 4; ++gs)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) yfull[16 * mo + 4 * gs + r] = __shfl(yr[mo][r], n + 16 * gs);
-        }
-        e0 = linds_err<NO>(P, t, yfull, c0);
+          for (int r = 0; r < 4; ++r) {
+            yr[mo][r] = yr[mo][r] + fr.y0r[mo][r];
+            const float d = (yr[mo][r] - c0[mo][r]) * fr.vld[mo][r];
+            pr0 = fmaf(d, d, pr0);
+          }
+        e0 = sqrtf(linds_quad_sum(pr0));
       }
       if (do_reset) {
-#pragma unroll
-        for (int mo = 0; mo < MO; ++mo) fobs[mo] = ym[mo];
-        wrote_fobs = 1;
 #pragma unroll
         for (int m = 0; m < MT; ++m) xn[m] = xr[m];
 #pragma unroll
         for (int mo = 0; mo < MO; ++mo) {
           ym[mo] = yr[mo];
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            crep[mo][r] = xv_sel4(g, c0[16 * mo + r], c0[16 * mo + 4 + r], c0[16 * mo + 8 + r], c0[16 * mo + 12 + r]);
+          for (int r = 0; r < 4; ++r) crep[mo][r] = c0[mo][r];
         }
         o_err = e0;
         steps = 0;
+        nr = 0;
       }
     }
-    bad_any |= bad;
+
+    // ---- this step's outputs (the state stays with the caller of run) ----
     if (valid) {
 #pragma unroll
-      for (int mo = 0; mo < MO; ++mo) {
-        const size_t ro = ob * NO + 16 * mo + 4 * g;
-        *reinterpret_cast<float4*>(io.obs + ro) = make_float4(ym[mo][0], ym[mo][1], ym[mo][2], ym[mo][3]);
-        if (io.cmd) *reinterpret_cast<float4*>(io.cmd + ro) = make_float4(crep[mo][0], crep[mo][1], crep[mo][2], crep[mo][3]);
-        if (io.final_obs)
-          *reinterpret_cast<float4*>(io.final_obs + ro) =
-              wrote_fobs ? make_float4(fobs[mo][0], fobs[mo][1], fobs[mo][2], fobs[mo][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int mo = 0; mo < MO; ++mo) {   // each lane stores its own 16-byte quarter of the rows
+        const size_t ro = orow * NO + 16 * mo + 4 * g;
+        *reinterpret_cast<float4*>(o_obs + ro) = make_float4(ym[mo][0], ym[mo][1], ym[mo][2], ym[mo][3]);
+        if (o_cmd) *reinterpret_cast<float4*>(o_cmd + ro) = make_float4(crep[mo][0], crep[mo][1], crep[mo][2], crep[mo][3]);
       }
       if (g == 0) {
-        io.reward[ob] = o_r;
-        if (io.error) io.error[ob] = o_err;
-        io.terminated[ob] = (uint8_t)o_term;
-        io.truncated[ob] = (uint8_t)o_trunc;
+        o_reward[orow] = o_r;
+        if (o_error) o_error[orow] = o_err;
+        o_term_p[orow] = (uint8_t)o_term;
+        o_trunc_p[orow] = (uint8_t)o_trunc;
       }
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) xs[m] = xn[m];
+    bad_out |= bad;
   }
-  if (valid) {
+};
+
+// identity of the tile a wave serves
+struct LinDSTileId {
+  int lane, wave, n, g, es, e, t;
+  bool valid;
+  uint64_t gid;
+};
+__device__ __forceinline__ bool linds_tile_id(const LinDSArgs& P, LinDSTileId& id) {
+  id.lane = threadIdx.x & 63;
+  id.wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int tile0 = id.wave * 16;
+  if (tile0 >= P.n_slot) return false;   // wave-uniform
+  id.n = id.lane & 15; id.g = id.lane >> 4;
+  id.es = tile0 + id.n;                  // this lane's state slot (x and sn are allocated in whole tiles)
+  int e_raw = id.es;
+  if (P.slot_env != nullptr) e_raw = id.es < P.n_slot ? P.slot_env[id.es] : -1;
+  id.valid = id.es < P.n_slot && e_raw >= 0 && e_raw < P.n_env;
+  id.e = id.valid ? e_raw : 0;           // the env it serves: its I/O rows and the global id of its draws
+  id.t = __builtin_amdgcn_readfirstlane(P.tile_task ? P.tile_task[id.wave] : P.env_task[tile0]);
+  id.gid = P.gid_base + (uint64_t)id.e;
+  return true;
+}
+
+template <int NS, int NA, int NO, bool INJECT>
+__device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const LinDSStepIO& io, int mode) {
+  using F = LinDSFrag<NS, NA, NO>;
+  LinDSTileId id;
+  if (!linds_tile_id(P, id)) return;
+  // ---- every load of the step is in flight before the first MFMA ----
+  F fr;
+  fr.load(P, id.t, id.lane);
+  float4* xq = reinterpret_cast<float4*>(P.x) + (size_t)id.wave * F::MT * 64 + id.lane;
+  xv_f32x4 xs[F::MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) P.x[(size_t)(16 * m + 4 * g + r) * NSL + es] = xs[m][r];
-    if (g == 0) {
-      P.steps[es] = steps;
-      P.need_reset[es] = 0;
-    }
+  for (int m = 0; m < F::MT; ++m) {
+    const float4 v = xq[m * 64];
+    xs[m] = xv_f32x4{v.x, v.y, v.z, v.w};
   }
-  if (bad_any && valid) atomicOr(P.err, (uint32_t)XV_DEVERR_NONFINITE);
+  const uint32_t sn0 = (uint32_t)P.sn[id.es];
+  int steps = (int)(sn0 & ~XV_LINDS_NR_BIT), nr = (int)(sn0 >> 31), bad = 0;
+  const int init_inj = INJECT ? io.init_index[id.e] : 0;
+  LinDSTileStep<NS, NA, NO, INJECT>::run(P, fr, id.t, id.lane, id.e, id.valid, id.gid, P.tick, mode,
+                                         io.action + (size_t)id.e * NA, io.z, P.n_env, init_inj, (size_t)id.e, io.obs, io.cmd,
+                                         io.final_obs, io.reward, io.error, io.terminated, io.truncated, xs, steps, nr, bad);
+  if (id.valid) {
+#pragma unroll
+    for (int m = 0; m < F::MT; ++m) xq[m * 64] = make_float4(xs[m][0], xs[m][1], xs[m][2], xs[m][3]);
+    if (id.g == 0) P.sn[id.es] = (int32_t)((uint32_t)steps | (nr ? XV_LINDS_NR_BIT : 0u));
+    if (bad) atomicOr(P.err, (uint32_t)XV_DEVERR_NONFINITE);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused roll-out: T steps of the tile in one launch, SAME_STEP auto-reset, free-running noise.  The task's operand
+// fragments are loaded once and the state never leaves the registers the matrix unit wrote it to (see the k order
+// above); per step only two action words and two command quarters come in and the outputs go out.  Step t draws with
+// tick0 + t, so the result equals T calls of xv_linds_step bit for bit (tested).
+// ------------------------------------------------------------------------------------------------
+struct LinDSRolloutIO {
+  const float* action;      // [T][n_env][NA]
+  float* obs;               // [T][n_env][NO]
+  float* reward;            // [T][n_env]
+  uint8_t* terminated;
+  uint8_t* truncated;
+  float* cmd;               // [T][n_env][NO]  nullable
+  float* error;             // [T][n_env]      nullable
+  float* final_obs;         // [T][n_env][NO]  nullable; rows of finished envs only
+};
+
+template <int NS, int NA, int NO>
+__global__ __launch_bounds__(256) void linds_rollout_mfma_kernel(LinDSArgs P, LinDSRolloutIO io, int T) {
+  using F = LinDSFrag<NS, NA, NO>;
+  LinDSTileId id;
+  if (!linds_tile_id(P, id)) return;
+  F fr;
+  fr.load(P, id.t, id.lane);
+  float4* xq = reinterpret_cast<float4*>(P.x) + (size_t)id.wave * F::MT * 64 + id.lane;
+  xv_f32x4 xs[F::MT];
+#pragma unroll
+  for (int m = 0; m < F::MT; ++m) {
+    const float4 v = xq[m * 64];
+    xs[m] = xv_f32x4{v.x, v.y, v.z, v.w};
+  }
+  int steps = (int)((uint32_t)P.sn[id.es] & ~XV_LINDS_NR_BIT), nr = 0, bad = 0;
+  const size_t N = (size_t)P.n_env;
+  for (int ts = 0; ts < T; ++ts) {
+    const size_t ob = (size_t)ts * N + id.e;          // this step's row of the [T][n_env] outputs
+    LinDSTileStep<NS, NA, NO, false>::run(P, fr, id.t, id.lane, id.e, id.valid, id.gid, P.tick + (uint64_t)ts,
+                                          XV_AUTORESET_SAME_STEP, io.action + ob * NA, nullptr, P.n_env, 0, ob, io.obs, io.cmd,
+                                          io.final_obs, io.reward, io.error, io.terminated, io.truncated, xs, steps, nr, bad);
+  }
+  if (id.valid) {
+#pragma unroll
+    for (int m = 0; m < F::MT; ++m) xq[m * 64] = make_float4(xs[m][0], xs[m][1], xs[m][2], xs[m][3]);
+    if (id.g == 0) P.sn[id.es] = steps;
+    if (bad) atomicOr(P.err, (uint32_t)XV_DEVERR_NONFINITE);
+  }
 }
 
 // two entry points over the same body: with 16 observation rows the step fits 128 registers and is capped there
@@ -1145,7 +1042,8 @@ extern "C" int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int 
   a.n_env = n_env; a.n_task = n_task; a.NS = NS; a.NA = NA; a.NO = NO; a.NI = NI;
   a.err = e->d_err;
   a.seed = e->seed; a.gid_base = e->env_id_base; a.tick = 0;
-  a.x = nullptr; a.steps = nullptr; a.need_reset = nullptr;
+  a.x = nullptr; a.sn = nullptr; a.frag = nullptr; a.tvec = nullptr;
+  h->frag = nullptr; h->tvec = nullptr;
   a.slot_env = nullptr; a.env_slot = nullptr; a.tile_task = nullptr; a.n_slot = n_env;
   h->d_slot_env = nullptr; h->d_env_slot = nullptr; h->d_tile_task = nullptr;
   hipError_t m = hipSuccess;
@@ -1210,23 +1108,34 @@ extern "C" int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int 
       a.slot_env = h->d_slot_env; a.env_slot = h->d_env_slot; a.tile_task = h->d_tile_task;
     }
   }
-  const size_t nsl = (size_t)a.n_slot;
-  if (m == hipSuccess) m = hipMalloc(&a.x, sizeof(float) * (size_t)NS * nsl);
-  if (m == hipSuccess) m = hipMalloc(&a.steps, sizeof(int32_t) * nsl);
-  if (m == hipSuccess) m = hipMalloc(&a.need_reset, nsl);
-  if (m == hipSuccess) m = hipMemsetAsync(a.x, 0, sizeof(float) * (size_t)NS * nsl, e->stream);
-  if (m == hipSuccess) m = hipMemsetAsync(a.steps, 0, sizeof(int32_t) * nsl, e->stream);
-  if (m == hipSuccess) m = hipMemsetAsync(a.need_reset, 1, nsl, e->stream);
+  // state and counters in whole 16-slot tiles; operand fragments and row vectors per task
+  const size_t n_tile = ((size_t)a.n_slot + 15) / 16;
+  const int MTc = NS / 16, MOc = NO / 16;
+  const int NQ = (MTc * (NS / 4) + MTc * (NA / 4) + MOc * (NS / 4) + 3) / 4;
+  const size_t x_bytes = sizeof(float) * n_tile * MTc * 256, sn_bytes = sizeof(int32_t) * n_tile * 16;
+  const size_t frag_n = (size_t)n_task * NQ * 64, tvec_n = (size_t)n_task * (NS + 2 * NO);
+  if (m == hipSuccess) m = hipMalloc(&a.x, x_bytes);
+  if (m == hipSuccess) m = hipMalloc(&a.sn, sn_bytes);
+  if (m == hipSuccess) m = hipMalloc(&h->frag, sizeof(float4) * frag_n);
+  if (m == hipSuccess) m = hipMalloc(&h->tvec, sizeof(float) * tvec_n);
+  if (m == hipSuccess) m = hipMemsetAsync(a.x, 0, x_bytes, e->stream);
+  if (m == hipSuccess) m = hipMemsetD32Async((hipDeviceptr_t)a.sn, (int)XV_LINDS_NR_BIT, n_tile * 16, e->stream);   // steps 0, need_reset
   if (m != hipSuccess) {
     xv_set_error("xv_linds_create: device allocation failed: %s", hipGetErrorString(m));
     if (a.x) (void)hipFree(a.x);
-    if (a.steps) (void)hipFree(a.steps);
-    if (a.need_reset) (void)hipFree(a.need_reset);
+    if (a.sn) (void)hipFree(a.sn);
+    if (h->frag) (void)hipFree(h->frag);
+    if (h->tvec) (void)hipFree(h->tvec);
     if (h->d_slot_env) (void)hipFree(h->d_slot_env);
     if (h->d_env_slot) (void)hipFree(h->d_env_slot);
     if (h->d_tile_task) (void)hipFree(h->d_tile_task);
     delete h;
     return XV_ERR_HIP;
+  }
+  {
+    const size_t nthr = frag_n > tvec_n ? frag_n : tvec_n;
+    hipLaunchKernelGGL(linds_build_frag_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, e->stream, a, h->frag, h->tvec);
+    a.frag = h->frag; a.tvec = h->tvec;
   }
   // command table: [n_task][max_steps_max + 2 + delay_max][NO] floats, within a 2-GiB budget
   a.cmd_tab = nullptr; a.ct_len = 0; a.ct_tmin = 0; a.rst_tab = nullptr;
@@ -1301,8 +1210,9 @@ extern "C" int xv_linds_destroy(xv_linds* h) {
   (void)hipSetDevice(h->eng->device);
   (void)hipStreamSynchronize(h->eng->stream);
   (void)hipFree(h->a.x);
-  (void)hipFree(h->a.steps);
-  (void)hipFree(h->a.need_reset);
+  (void)hipFree(h->a.sn);
+  if (h->frag) (void)hipFree(h->frag);
+  if (h->tvec) (void)hipFree(h->tvec);
   if (h->d_slot_env) (void)hipFree(h->d_slot_env);
   if (h->d_env_slot) (void)hipFree(h->d_env_slot);
   if (h->d_tile_task) (void)hipFree(h->d_tile_task);
@@ -1407,20 +1317,27 @@ extern "C" int xv_linds_step_injected(xv_linds* h, const float* action, const fl
   return linds_launch_step<true>(h, io, autoreset_mode);
 }
 
-// state <-> caller order when the engine keeps it in slot order
+// engine state (fragment tiles, slot order) <-> the caller's component-major float[NS][n_env] / steps / need_reset
 template <bool TO_ENV>
 __global__ __launch_bounds__(256) void linds_permute_state_kernel(LinDSArgs P, float* x, int32_t* steps, uint8_t* need_reset) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
-  const int N = P.n_env, NSL = P.n_slot, si = P.env_slot[i];
+  const int N = P.n_env, MT = P.NS / 16, si = P.env_slot ? P.env_slot[i] : i;
   if (x) {
     for (int k = 0; k < P.NS; ++k) {
-      if (TO_ENV) x[(size_t)k * N + i] = P.x[(size_t)k * NSL + si];
-      else P.x[(size_t)k * NSL + si] = x[(size_t)k * N + i];
+      if (TO_ENV) x[(size_t)k * N + i] = P.x[linds_xidx(si, k, MT)];
+      else P.x[linds_xidx(si, k, MT)] = x[(size_t)k * N + i];
     }
   }
-  if (steps) { if (TO_ENV) steps[i] = P.steps[si]; else P.steps[si] = steps[i]; }
-  if (need_reset) { if (TO_ENV) need_reset[i] = P.need_reset[si]; else P.need_reset[si] = need_reset[i]; }
+  const uint32_t w = (uint32_t)P.sn[si];
+  if (TO_ENV) {
+    if (steps) steps[i] = (int32_t)(w & ~XV_LINDS_NR_BIT);
+    if (need_reset) need_reset[i] = (uint8_t)(w >> 31);
+  } else if (steps || need_reset) {
+    const uint32_t st = steps ? ((uint32_t)steps[i] & ~XV_LINDS_NR_BIT) : (w & ~XV_LINDS_NR_BIT);
+    const uint32_t nr = need_reset ? (need_reset[i] ? XV_LINDS_NR_BIT : 0u) : (w & XV_LINDS_NR_BIT);
+    P.sn[si] = (int32_t)(st | nr);
+  }
 }
 
 extern "C" int xv_linds_rollout(xv_linds* h, int T, const float* action, float* obs, float* reward, uint8_t* terminated,
@@ -1439,30 +1356,16 @@ extern "C" int xv_linds_rollout(xv_linds* h, int T, const float* action, float* 
 
 extern "C" int xv_linds_get_state(xv_linds* h, float* x, int32_t* steps, uint8_t* need_reset) {
   XV_CHECK_ARG(h != nullptr);
-  if (h->a.env_slot != nullptr) {
-    hipLaunchKernelGGL((linds_permute_state_kernel<true>), dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
-                       h->a, x, steps, need_reset);
-    XV_LAUNCH_CHECK();
-    return XV_OK;
-  }
-  const size_t n = (size_t)h->a.n_env;
-  if (x) XV_HIP(hipMemcpyAsync(x, h->a.x, n * h->a.NS * 4, hipMemcpyDeviceToDevice, h->eng->stream));
-  if (steps) XV_HIP(hipMemcpyAsync(steps, h->a.steps, n * 4, hipMemcpyDeviceToDevice, h->eng->stream));
-  if (need_reset) XV_HIP(hipMemcpyAsync(need_reset, h->a.need_reset, n, hipMemcpyDeviceToDevice, h->eng->stream));
+  hipLaunchKernelGGL((linds_permute_state_kernel<true>), dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
+                     h->a, x, steps, need_reset);
+  XV_LAUNCH_CHECK();
   return XV_OK;
 }
 
 extern "C" int xv_linds_set_state(xv_linds* h, const float* x, const int32_t* steps, const uint8_t* need_reset) {
   XV_CHECK_ARG(h != nullptr);
-  if (h->a.env_slot != nullptr) {
-    hipLaunchKernelGGL((linds_permute_state_kernel<false>), dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
-                       h->a, const_cast<float*>(x), const_cast<int32_t*>(steps), const_cast<uint8_t*>(need_reset));
-    XV_LAUNCH_CHECK();
-    return XV_OK;
-  }
-  const size_t n = (size_t)h->a.n_env;
-  if (x) XV_HIP(hipMemcpyAsync(h->a.x, x, n * h->a.NS * 4, hipMemcpyDeviceToDevice, h->eng->stream));
-  if (steps) XV_HIP(hipMemcpyAsync(h->a.steps, steps, n * 4, hipMemcpyDeviceToDevice, h->eng->stream));
-  if (need_reset) XV_HIP(hipMemcpyAsync(h->a.need_reset, need_reset, n, hipMemcpyDeviceToDevice, h->eng->stream));
+  hipLaunchKernelGGL((linds_permute_state_kernel<false>), dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
+                     h->a, const_cast<float*>(x), const_cast<int32_t*>(steps), const_cast<uint8_t*>(need_reset));
+  XV_LAUNCH_CHECK();
   return XV_OK;
 }

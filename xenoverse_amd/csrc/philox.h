@@ -34,7 +34,7 @@ __host__ __device__ __forceinline__ xv_u32x4 xv_philox4x32_10(uint32_t c0, uint3
 // purposes (low byte of counter word 3)
 #define XV_DRAW_STEP 0u   // words 0,1 -> transition uniform; words 2,3 -> Box-Muller normal
 #define XV_DRAW_RESET 1u  // words 0,1 -> initial-state uniform
-#define XV_DRAW_NOISE 16u // + j : j-th block of 4 normals (linds process noise)
+#define XV_DRAW_NOISE 16u // + g, g = 0..3: eight normals, the linds process noise of components 16 m + 4 g + r (below)
 
 __host__ __device__ __forceinline__ xv_u32x4 xv_env_draw(uint64_t seed, uint64_t gid, uint64_t tick,
                                                            uint32_t purpose) {
@@ -77,6 +77,17 @@ __device__ __forceinline__ void xv_box_muller(uint32_t a, uint32_t b, float* z0,
 __device__ __forceinline__ void xv_box_muller_fast(uint32_t a, uint32_t b, float* z0, float* z1) {
   const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);
   const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // -2 ln 2 * log2(u1)
+  *z0 = r * __builtin_amdgcn_cosf(u2);
+  *z1 = r * __builtin_amdgcn_sinf(u2);
+}
+// Eight normals from ONE Philox call (LinDS process noise, round 3): word p -> Box-Muller pair p, radius from the high 16
+// bits (u1 = (hi + 1) / 65536 in (0, 1]), angle from the low 16 (u2 = lo / 65536 revolutions).  65,536 radii x 65,536
+// angles per pair, |z| <= 4.71; the noise enters scaled by noise_drift * dt <= 2e-3.  Philox's 32-bit multiplies run at a
+// quarter of the VALU rate and were ~40 % of the LinDS step's instruction issue with two calls per lane.
+__device__ __forceinline__ void xv_box_muller16(uint32_t w, float* z0, float* z1) {
+  const float u1 = ((float)(w >> 16) + 1.0f) * (1.0f / 65536.0f);
+  const float u2 = (float)(w & 0xFFFFu) * (1.0f / 65536.0f);
   const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // -2 ln 2 * log2(u1)
   *z0 = r * __builtin_amdgcn_cosf(u2);
   *z1 = r * __builtin_amdgcn_sinf(u2);

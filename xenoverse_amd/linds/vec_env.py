@@ -197,7 +197,16 @@ class LinDSVecEnv(VectorEnv):
         if (not self.task_set) or self.need_reset:
             raise Exception("Must \"set_task\" and \"reset\" before doing any actions")   # linds_env.py:134-135
 
-    _STEP_OUTPUTS = ("_obs", "_reward", "_term", "_trunc", "_cmd", "_error", "_fobs")   # all fully written by a step
+    _STEP_OUTPUTS = ("_obs", "_reward", "_term", "_trunc", "_cmd", "_error")   # all fully written by a step
+
+    def _fresh_final_obs(self):
+        """the step writes final_obs rows of FINISHED envs only (64 B per env-step that ~93 % of the envs do not need):
+        copy=True / to_numpy hand out zero rows elsewhere, as before; with copy=False the rows of unfinished envs keep
+        whatever an earlier episode end left there — read them under info["_final_obs"]"""
+        if self.copy and not self.to_numpy:
+            self._fobs = torch.zeros_like(self._fobs)
+        elif self.to_numpy:
+            self._fobs.zero_()
 
     def _ret(self):
         return (self._of(self._user_obs(self._obs)), self._of(self._reward),
@@ -207,6 +216,7 @@ class LinDSVecEnv(VectorEnv):
         self._check_step()
         a = self._action(actions)
         self._renew(*self._STEP_OUTPUTS)
+        self._fresh_final_obs()
         _lib.check(self.lib.xv_linds_step(self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward),
                                           _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._cmd),
                                           _lib.ptr(self._error), _lib.ptr(self._fobs),
@@ -224,6 +234,7 @@ class LinDSVecEnv(VectorEnv):
             z = p
         idx = self._dev(init_index, torch.int32)
         self._renew(*self._STEP_OUTPUTS)
+        self._fresh_final_obs()
         _lib.check(self.lib.xv_linds_step_injected(
             self._h, _lib.ptr(a), _lib.ptr(z.contiguous()), _lib.ptr(idx), _lib.ptr(self._obs),
             _lib.ptr(self._reward), _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._cmd),
@@ -253,7 +264,8 @@ class LinDSVecEnv(VectorEnv):
             if with_info:
                 out.update(command=torch.empty((T, n, self.NO), dtype=torch.float32, device=d),
                            error=torch.empty((T, n), dtype=torch.float32, device=d),
-                           final_obs=torch.empty((T, n, self.NO), dtype=torch.float32, device=d))
+                           final_obs=torch.zeros((T, n, self.NO), dtype=torch.float32, device=d))   # written for
+                # finished envs only; a caller-supplied `out` keeps its other rows
         _lib.check(self.lib.xv_linds_rollout(self._h, T, _lib.ptr(a), _lib.ptr(out["obs"]), _lib.ptr(out["reward"]),
                                              _lib.ptr(out["terminated"]), _lib.ptr(out["truncated"]),
                                              _lib.ptr(out.get("command")), _lib.ptr(out.get("error")),
