@@ -360,7 +360,7 @@ int xv_linds_destroy(xv_linds* h);
 #define XV_LINDS_PATH_SCALAR 2
 int xv_linds_set_path(xv_linds* h, int path);
 /* get_inner_cmd (linds_env.py:93-98) depends on (task, integer time) only; xv_linds_create tabulates it per task
- * ([max_steps + 2 + delay][NO] floats, with the kernels' own evaluation code, if the table fits 2 GiB) and a step
+ * ([max_steps + 2 + delay][live columns] floats — columns past the last non-zero target_valid are identically zero and not stored — with the kernels' own evaluation code, if the table fits 2 GiB) and a step
  * reads two rows instead of evaluating 2 x NO x n_fourier sin/cos pairs; likewise the observation and tracking error of
  * every initial state ([n_task][NI][NO+4] floats), read by restarting envs.  enable = 0 evaluates both directly (same
  * bits; parity-tested).  Returns XV_ERR_UNSUPPORTED when enable = 1 and no table was built. */
@@ -378,6 +378,12 @@ int xv_linds_reset_injected(xv_linds* h, const uint8_t* mask, const int32_t* ini
  * state components' lane group: csrc/philox.h xv_box_muller16). */
 int xv_linds_step(xv_linds* h, const float* action, float* obs, float* reward, uint8_t* terminated,
                   uint8_t* truncated, float* cmd, float* error, float* final_obs, int autoreset_mode);
+/* n_steps vector steps issued back to back from C (the reference counterpart is the caller's loop around step(),
+ * linds/test.py): step k takes its actions from slot k % period of action float[period][n_env][NA] and writes slot
+ * k % period of every output ([period][n_env][NO] / [period][n_env]); equals n_steps calls of xv_linds_step. */
+int xv_linds_step_many(xv_linds* h, int n_steps, int period, const float* action, float* obs, float* reward,
+                       uint8_t* terminated, uint8_t* truncated, float* cmd, float* error, float* final_obs,
+                       int autoreset_mode);
 /* parity hook: z float[NS][n_env] standard normals, init_index int32[n_env] (initial state used on reset) */
 int xv_linds_step_injected(xv_linds* h, const float* action, const float* z, const int32_t* init_index,
                            float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, float* cmd,

@@ -544,6 +544,15 @@ static inline int linds_draw_init(const xo_linds* h, int i, uint64_t seed, uint6
   int idx = (int)(((uint64_t)w[0] * (uint64_t)(uint32_t)n) >> 32);
   return idx < n ? idx : n - 1;
 }
+/* the initial state of an env that finishes inside a STEP call comes from that step's restart word: the xor of the four
+ * words of its noise call of lane group 0 (csrc/linds.hip: linds_noise_group) — no Philox call of its own */
+static inline int linds_step_restart_index(const xo_linds* h, int i, uint64_t seed, uint64_t gid, uint64_t tick) {
+  uint32_t w[4];
+  xo_env_draw(seed, gid, tick, 16u, w);
+  int n = L_ints(h, h->env_task[i])[2];
+  int idx = (int)(((uint64_t)((w[0] ^ w[1]) ^ (w[2] ^ w[3])) * (uint64_t)(uint32_t)n) >> 32);
+  return idx < n ? idx : n - 1;
+}
 static inline void linds_draw_noise(int NS, uint64_t seed, uint64_t gid, uint64_t tick, float* z) {
   for (int g = 0; g < 4; ++g) {
     uint32_t w[4];
@@ -576,7 +585,7 @@ void xo_linds_step(xo_linds* h, uint64_t seed, uint64_t gid_base, uint64_t tick,
     float zz[32];
     const uint64_t gid = gid_base + (uint64_t)i;
     linds_draw_noise(h->NS, seed, gid, tick, zz);
-    const int idx = linds_draw_init(h, i, seed, gid, tick);
+    const int idx = linds_step_restart_index(h, i, seed, gid, tick);
     linds_step_one(h, i, action + (size_t)i * h->NA, zz, idx, obs, reward, terminated, truncated, cmd,
                    error, final_obs, mode);
   }

@@ -31,19 +31,32 @@ def timed(fn, steps, warmup):
     return e0.elapsed_time(e1) * 1e3 / steps      # us per call
 
 
-def bench_linds(args):
-    from xenoverse_amd.linds import LinDSVecEnv, LinearDSSampler
+_LINDS_TASKS = {}
+
+
+def linds_tasks(n_task, distinct=16):
+    """`distinct` tasks from the sampler (ns = 32 needs ~0.2 s of rejection sampling each), tiled to n_task: the tables
+    are per task index anyway, so every task index owns its own copy of the matrices in HBM"""
+    from xenoverse_amd.linds import LinearDSSampler
+    if distinct not in _LINDS_TASKS:
+        ts = []
+        for k in range(distinct):
+            t = LinearDSSampler(32, 8, 8, seed=k)
+            t["max_steps"] = 500
+            ts.append(t)
+        _LINDS_TASKS[distinct] = ts
+    ts = _LINDS_TASKS[distinct]
+    return [ts[k % distinct] for k in range(n_task)]
+
+
+def bench_linds(args, paths=("mfma", "scalar"), rollout=True):
+    from xenoverse_amd.linds import LinDSVecEnv
     n_task, per = 1024, 64
     n = n_task * per
     t0 = time.time()
-    tasks = []
-    for k in range(64):        # 64 distinct sampled tasks, tiled to 1,024 (tables are per task index anyway)
-        t = LinearDSSampler(32, 8, 8, seed=k)
-        t["max_steps"] = 500
-        tasks.append(t)
-    tasks = [tasks[k % 64] for k in range(n_task)]
+    tasks = linds_tasks(n_task)
     out = {}
-    for path in ("mfma", "scalar"):
+    for path in paths:
         env = LinDSVecEnv(n, autoreset_mode="same_step", seed=1)
         env.set_task(tasks)
         env.set_path(path)
@@ -58,7 +71,12 @@ def bench_linds(args):
                                              _lib.ptr(env._error), _lib.ptr(env._fobs), AUTORESET["same_step"]))
         us = timed(step, args.steps, args.warmup)
         out[path] = us
-        if path == "mfma":      # fused roll-out: T steps per launch, state resident in registers
+        if path == "mfma":      # the same launches issued from C (xv_linds_step_many): no Python between the kernels
+            aP = torch.rand((8, n, 8), device=env.device) * 2 - 1
+            ring = env.step_many(8, aP)
+            k = max(8, args.steps // 8 * 8)
+            out["mfma, launches from C"] = timed(lambda: env.step_many(k, aP, out=ring), 3, 1) / k
+        if path == "mfma" and rollout:      # fused roll-out: T steps per launch, state resident in registers
             T = 64
             aT = torch.rand((T, n, 8), device=env.device) * 2 - 1
             ro = env.rollout(aT)
@@ -68,13 +86,35 @@ def bench_linds(args):
             out["rollout_T64_per_step"] = timed(roll, max(args.steps // T, 5), 2) / T
         env.close()
     algo = 432 * n
-    best = min(out["mfma"], out["scalar"])
-    return {"family": "linds", "workload": "ns=32 na=8 no=8 (pads 16/8/16), 65,536 envs = 1,024 tasks x 64",
+    best = min(out[p] for p in out if not p.startswith("rollout"))
+    return {"family": "linds", "workload": "ns=32 na=8 no=8 (pads 16/8/16), 65,536 envs = 1,024 tasks x 64", "kernel": "linds_step_mfma_kernel<32, 8, 16, false>",
             "env_steps_per_s": n / (best * 1e-6), "us_per_step": out, "dtype": "f32",
             "roofline": {"bound": "hbm", "achieved": algo / (best * 1e-6) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
                          "frac": algo / (best * 1e-6) / 1e9 / HBM_PEAK, "algorithmic_bytes_per_env_step": 432},
             "mfma_flops_per_env_step": 3072, "achieved_tflops": 3072 * n / (out["mfma"] * 1e-6) / 1e12,
             "setup_s": round(time.time() - t0, 1)}
+
+
+def bench_linds_sweep(args):
+    """step time of the LinDS matrix kernel against the batch size (64 envs per task): fixed cost vs cost per byte"""
+    from xenoverse_amd import _lib
+    from xenoverse_amd.engine import AUTORESET
+    from xenoverse_amd.linds import LinDSVecEnv
+    rows = []
+    for n in (4096, 16384, 32768, 65536, 131072, 262144):
+        env = LinDSVecEnv(n, autoreset_mode="same_step", seed=1)
+        env.set_task(linds_tasks(n // 64))
+        env.reset()
+        a = torch.rand((n, 8), device=env.device) * 2 - 1
+
+        def step():
+            _lib.check(env.lib.xv_linds_step(env._h, _lib.ptr(a), _lib.ptr(env._obs), _lib.ptr(env._reward),
+                                             _lib.ptr(env._term), _lib.ptr(env._trunc), _lib.ptr(env._cmd),
+                                             _lib.ptr(env._error), _lib.ptr(env._fobs), AUTORESET["same_step"]))
+        us = timed(step, args.steps, args.warmup)
+        rows.append({"envs": n, "us_per_step": us, "env_steps_per_s": n / (us * 1e-6), "frac_432B": 432 * n / (us * 1e-6) / 1e9 / HBM_PEAK})
+        env.close()
+    return {"family": "linds sweep", "lib": os.environ.get("XV_LIB_PATH", "default"), "rows": rows}
 
 
 def bench_cartpole(args):
@@ -347,6 +387,10 @@ if __name__ == "__main__":
     for f in args.families.split(","):
         if f == "linds":
             r = bench_linds(args)
+        elif f == "linds_sweep":
+            r = bench_linds_sweep(args)
+        elif f == "linds_mfma":
+            r = bench_linds(args, paths=("mfma",), rollout=False)
         elif f == "cartpole":
             r = bench_cartpole(args)
         elif f == "acrobot":

@@ -333,3 +333,40 @@ def test_fused_rollout_vs_oracle():
         assert close_rel(_np(out["obs"][t]), o["obs"], 2e-4, 2e-5), t     # noise tolerance compounds over T (no re-sync)
         assert np.array_equal(_np(out["truncated"][t]), o["truncated"])
     env.close()
+
+
+def test_step_many_equals_single_steps():
+    """xv_linds_step_many: K steps issued from C over ring buffers == K calls of step() (outputs of the last ring cycle,
+    state, counters, engine tick); final_obs rows of finished envs only"""
+    tasks, tab, env_task = _batch(64, FILES[:3])
+    n, P, K = len(env_task), 8, 21
+    acts = np.random.RandomState(11).uniform(-1.2, 1.2, (P, n, 8)).astype(np.float32)
+    recs = []
+    for many in (False, True):
+        env = LinDSVecEnv(n, autoreset_mode="same_step", seed=5, env_id_base=64)
+        env.set_task(tasks, env_task_index=env_task)
+        env.reset()
+        if many:
+            ring = env.step_many(K, acts)
+            rec = {k: _np(v) for k, v in ring.items()}
+        else:
+            rows = [None] * P
+            for k in range(K):
+                o, r, te, tr, info = env.step(acts[k % P])
+                rows[k % P] = dict(obs=_np(o), reward=_np(r), terminated=_np(te).astype(np.uint8),
+                                   truncated=_np(tr).astype(np.uint8), command=_np(info["command"]), error=_np(info["error"]),
+                                   final_obs=_np(info["final_obs"]))
+            rec = {k: np.stack([row[k] for row in rows]) for k in rows[0]}
+        x, st, nr = env.get_state()
+        rec.update(x=_np(x), steps=_np(st), tick=np.int64(env.engine.tick))
+        recs.append(rec)
+        env.close()
+    done = (recs[0]["terminated"] | recs[0]["truncated"]).astype(bool)
+    assert done.sum() > 0
+    for k in recs[0]:
+        a, b = recs[0][k], recs[1][k]
+        if k in ("obs", "command", "final_obs"):
+            b = b[..., :a.shape[-1]]
+        if k == "final_obs":            # the ring's rows are written by finished envs only (earlier cycles may linger)
+            a, b = a[done], b[done]
+        assert np.array_equal(a, b), k

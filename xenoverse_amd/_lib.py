@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxeno_hip.so")
+# XV_LIB_PATH: A/B measurement of kernel variants built by scripts/devtools/build_variant.py (same ABI, same checks)
+LIB_PATH = os.environ.get("XV_LIB_PATH") or os.path.join(_HERE, "libxeno_hip.so")
 
 c_void_p, c_int, c_u64, c_i64, c_u32 = C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_uint32
 
@@ -59,6 +60,7 @@ SIGNATURES = {
     "xv_anymdp_synth_tasks": [c_void_p, c_u64, c_i64, c_int, c_int, c_int, c_int] + [c_void_p] * 6,
     "xv_linds_create": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, C.POINTER(c_void_p)],
     "xv_linds_destroy": [c_void_p],
+    "xv_linds_step_many": [c_void_p, c_int, c_int] + [c_void_p] * 8 + [c_int],
     "xv_linds_set_path": [c_void_p, c_int],
     "xv_linds_set_command_table": [c_void_p, c_int],
     "xv_linds_reset": [c_void_p] + [c_void_p] * 4,

@@ -38,8 +38,10 @@ struct LinDSArgs {
   uint64_t seed, gid_base, tick;
   // engine-built command table (nullptr if it would not fit the budget): cmd_tab[task][tt - ct_tmin][NO] holds
   // get_inner_cmd at integer time tt, already multiplied by target_valid, for tt in [ct_tmin, ct_tmin + ct_len)
+  // Rows hold the first ct_w columns only (a multiple of 4): every column past the last one whose target_valid is
+  // non-zero in some task is identically zero, so with observation_dim 8 padded to 16 a row is 32 bytes, not 64.
   const float* cmd_tab;
-  int ct_len, ct_tmin;
+  int ct_len, ct_tmin, ct_w;
   // engine-built reset table: rst_tab[task][init index][NO + 4] = the observation of initial_states[idx] (NO floats)
   // and its tracking error against cmd(0) (slot NO): a restarting env reads 80 B instead of redoing y = C x + Y
   const float* rst_tab;
@@ -54,9 +56,26 @@ struct LinDSArgs {
   const int32_t* env_slot;   // [n_env]  slot of an env
   const int32_t* tile_task;  // [n_slot / 16]
   int n_slot;
+  int task_shift;            // >= 4: env_task[i] == i >> task_shift for every env (the usual blocks of a power-of-two
+                             // number of envs per task): the tile's task is arithmetic, not a load ahead of every load
 };
 
 #define XV_LINDS_NR_BIT 0x80000000u
+
+// measurement switches (scripts/devtools/build_variant.py): kept only while an A/B is being taken
+#ifndef XV_LINDS_NT_STORES
+#define XV_LINDS_NT_STORES 1   // 1: obs / cmd / final_obs leave with non-temporal stores: written once, read by somebody else —
+#endif                         //    they must not displace the state, sn, the fragments and the command rows in the L2
+                               //    (measured at config 3: 10.25 -> 9.41 us per step, fused roll-out 7.3 -> 5.7 us per step)
+#ifndef XV_LINDS_NT_MORE
+#define XV_LINDS_NT_MORE 4     // bit 0: action reads non-temporal (measured: no gain, slower beyond 131k envs); bit 1: scalar
+#endif                         // outputs (no gain); bit 2: the state stores too (9.57 -> 9.29 us: kept)
+#ifndef XV_LINDS_WARM
+#define XV_LINDS_WARM 0        // 1: touch the rows a restarting env will read (initial state, its tabulated observation, cmd(0))
+#endif                         //    while the first loads are in flight, so that the restart reads hit the cache
+#ifndef XV_LINDS_OCC
+#define XV_LINDS_OCC 4         // waves per SIMD the (NO = 16) step kernel is capped for
+#endif
 
 // float index of component k of slot s in the fragment-tile state (MT = NS / 16)
 __host__ __device__ __forceinline__ size_t linds_xidx(int s, int k, int MT) {
@@ -207,10 +226,11 @@ template <int NO>
 __device__ __forceinline__ void linds_cmd_at(const LinDSArgs& P, int tu, int nf, int tt, float (&out)[NO]) {
   const int idx = tt - P.ct_tmin;
   if (P.cmd_tab != nullptr && idx >= 0 && idx < P.ct_len) {
-    const float4* p = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)tu * P.ct_len + idx) * NO);
+    const float4* p = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)tu * P.ct_len + idx) * P.ct_w);
 #pragma unroll
     for (int q = 0; q < NO / 4; ++q) {
-      const float4 v = p[q];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (4 * q < P.ct_w) v = p[q];
       out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w;
     }
   } else {
@@ -289,15 +309,23 @@ __global__ __launch_bounds__(256) void linds_build_cmd_tab_kernel(LinDSArgs P, f
   const int t = (int)(idx / P.ct_len), k = (int)(idx % P.ct_len);
   float out[NO];
   linds_cmd<NO>(P, t, P.T.ints[(size_t)t * 4 + 3], k + P.ct_tmin, out);
-  linds_store_row<NO>(tab + idx * NO, out);
+  float4* row = reinterpret_cast<float4*>(tab + idx * P.ct_w);
+#pragma unroll
+  for (int q = 0; q < NO / 4; ++q)
+    if (4 * q < P.ct_w) row[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
 }
 
-// max over tasks of max_steps and of the command delay (sizes the command table)
-__global__ __launch_bounds__(256) void linds_max_ints_kernel(const int32_t* ints, int n_task, int* out2) {
+// max over tasks of max_steps and of the command delay (sizes the command table), and the number of live command
+// columns: 1 + the last column whose target_valid is non-zero in some task (commands are multiplied by target_valid)
+__global__ __launch_bounds__(256) void linds_max_ints_kernel(const int32_t* ints, const float* valid, int NO, int n_task, int* out3) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_task) return;
-  atomicMax(out2, ints[(size_t)t * 4]);
-  atomicMax(out2 + 1, ints[(size_t)t * 4 + 1]);
+  atomicMax(out3, ints[(size_t)t * 4]);
+  atomicMax(out3 + 1, ints[(size_t)t * 4 + 1]);
+  int live = 0;
+  for (int j = 0; j < NO; ++j)
+    if (valid[(size_t)t * NO + j] != 0.0f) live = j + 1;
+  atomicMax(out3 + 2, live);
 }
 
 
@@ -350,8 +378,11 @@ __device__ __forceinline__ int linds_draw_init(const LinDSArgs& P, uint64_t gid,
 
 // Process noise of state component j: normal i = 4 (j >> 4) + (j & 3) of Philox call XV_DRAW_NOISE + ((j >> 2) & 3)
 // (philox.h: xv_box_muller16) — lane (n, g) of the matrix kernel owns components 16 m + 4 g + r, i.e. ONE call.
+// Returns the xor of the call's four words: for g = 0 this is the env's RESTART word of the step — an env that finishes
+// in this call draws its initial state with it (linds_init_from_word), so the auto-reset costs no Philox call of its own
+// (the noise it is derived from belongs to the episode that has just ended).
 template <int MT>
-__device__ __forceinline__ void linds_noise_group(const LinDSArgs& P, uint64_t gid, uint64_t tick, int g, float (&z)[MT][4]) {
+__device__ __forceinline__ uint32_t linds_noise_group(const LinDSArgs& P, uint64_t gid, uint64_t tick, int g, float (&z)[MT][4]) {
   const xv_u32x4 w = xv_env_draw(P.seed, gid, tick, XV_DRAW_NOISE + (uint32_t)g);
   xv_box_muller16(w.x, &z[0][0], &z[0][1]);
   xv_box_muller16(w.y, &z[0][2], &z[0][3]);
@@ -359,6 +390,12 @@ __device__ __forceinline__ void linds_noise_group(const LinDSArgs& P, uint64_t g
     xv_box_muller16(w.z, &z[MT - 1][0], &z[MT - 1][1]);
     xv_box_muller16(w.w, &z[MT - 1][2], &z[MT - 1][3]);
   }
+  return (w.x ^ w.y) ^ (w.z ^ w.w);
+}
+// the restart word for a kernel that makes no noise for the env (xo: linds_step_restart_word)
+__device__ __forceinline__ uint32_t linds_restart_word(const LinDSArgs& P, uint64_t gid, uint64_t tick) {
+  const xv_u32x4 w = xv_env_draw(P.seed, gid, tick, XV_DRAW_NOISE);
+  return (w.x ^ w.y) ^ (w.z ^ w.w);
 }
 
 // sum of squares of the RAW padded action (:164), four fmaf chains like the row sums above: chain g over k = g, 4 + g, ...
@@ -421,7 +458,7 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
       const XV_CONST_AS float* sc = xv_cptr(P.T.scal) + (size_t)tu * 8;
       const XV_CONST_AS int32_t* in = xv_cptr(P.T.ints) + (size_t)tu * 4;
       const int max_steps = in[0], delay = in[1], n_init = in[2], nf = in[3];
-      if (!INJECT) init_idx = linds_draw_init(P, gid, P.tick, n_init);
+      if (!INJECT) init_idx = linds_init_from_word(linds_restart_word(P, gid, P.tick), n_init);
       if (mode == XV_AUTORESET_NEXT_STEP && nr) {
         // the call after a done ignores the action and returns the reset observation
         linds_reset_env<NS, NO>(P, tu, nf, n_init, init_idx, xs, y, crep, o_err);
@@ -466,7 +503,7 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
 #pragma unroll
               for (int r = 0; r < 4; ++r) z[m][r] = io.z[(size_t)(16 * m + 4 * gq + r) * N + i];
           } else {
-            linds_noise_group<MT>(P, gid, P.tick, gq, z);
+            (void)linds_noise_group<MT>(P, gid, P.tick, gq, z);
           }
 #pragma unroll
           for (int m = 0; m < MT; ++m)
@@ -607,6 +644,22 @@ __device__ __forceinline__ float linds_quad_sum(float part) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+__device__ __forceinline__ void linds_store_out4(float* p, float a, float b, float c, float d) {
+#if XV_LINDS_NT_STORES
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(f4{a, b, c, d}, reinterpret_cast<f4*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+#endif
+}
+
+// the value lanes 0..15 hold, in all four 16-lane rows (lane n + 16 g <- lane n)
+__device__ __forceinline__ uint32_t linds_bcast_row0(uint32_t v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);   // a[0] = rows {0, 0, 2, 2}
+  const auto b = __builtin_amdgcn_permlane32_swap(a[0], a[0], false, false);   // b[0] = rows {0, 0, 0, 0}
+  return b[0];
+}
+
 // what a wave loads once per task: the A-operand fragments of the three products and the per-row vectors of its lane group
 template <int NS, int NA, int NO>
 struct LinDSFrag {
@@ -695,33 +748,53 @@ struct LinDSTileStep {
     // ---- this step's inputs: two action words, two command quarters ----
     float ak[KA];
 #pragma unroll
-    for (int kk = 0; kk < KA; ++kk) ak[kk] = action_row[4 * kk + g];
+    for (int kk = 0; kk < KA; ++kk)
+      ak[kk] = (XV_LINDS_NT_MORE & 1) ? __builtin_nontemporal_load(action_row + 4 * kk + g) : action_row[4 * kk + g];
     const int steps_new = steps + 1;                            // :147
     const int trk_time = steps_new - 1 - delay, rep_time = steps_new;   // tracked :150-151, reported :168
     const int trk_idx = trk_time - P.ct_tmin, rep_idx = rep_time - P.ct_tmin;
     const bool trk_in = P.cmd_tab != nullptr && trk_idx >= 0 && trk_idx < P.ct_len;
     const bool rep_in = P.cmd_tab != nullptr && rep_idx >= 0 && rep_idx < P.ct_len;
     float ctr[MO][4], crep[MO][4];   // this lane's rows 16 mo + 4 g + r of the two commands
+    float4 cu[MO], cv[MO];   // raw reads; quarters past the table's ct_w live columns read a live one and are zeroed at use
     if (P.cmd_tab != nullptr) {
-      const float4* p = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + (trk_in ? trk_idx : 0)) * NO);
-      const float4* pr = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + (rep_in ? rep_idx : 0)) * NO);
+      const float* p = P.cmd_tab + ((size_t)t * P.ct_len + (trk_in ? trk_idx : 0)) * P.ct_w;
+      const float* pr = P.cmd_tab + ((size_t)t * P.ct_len + (rep_in ? rep_idx : 0)) * P.ct_w;
 #pragma unroll
       for (int mo = 0; mo < MO; ++mo) {
-        const float4 u = p[4 * mo + g], v = pr[4 * mo + g];
-        ctr[mo][0] = u.x; ctr[mo][1] = u.y; ctr[mo][2] = u.z; ctr[mo][3] = u.w;
-        crep[mo][0] = v.x; crep[mo][1] = v.y; crep[mo][2] = v.z; crep[mo][3] = v.w;
+        const int col = 16 * mo + 4 * g;
+        const int cc = col < P.ct_w ? col : 0;
+        cu[mo] = *reinterpret_cast<const float4*>(p + cc);
+        cv[mo] = *reinterpret_cast<const float4*>(pr + cc);
       }
     }
     // process noise: independent of every load, computed while they are in flight
     float zr[MT][4];
+    uint32_t rword = 0;   // lane group 0: the env's restart word
     if (INJECT) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) zr[m][r] = z_inj[(size_t)(16 * m + 4 * g + r) * N + e];
     } else {
-      linds_noise_group<MT>(P, gid, tick, g, zr);
+      rword = linds_noise_group<MT>(P, gid, tick, g, zr);
     }
+    // the normals are made HERE, under the latency of the loads above: hipcc's IR-level sinking otherwise moves the whole
+    // Philox / Box-Muller chain behind the first product, onto the critical path (sched_barrier binds the machine
+    // scheduler only)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(zr[m][0]), "+v"(zr[m][1]), "+v"(zr[m][2]), "+v"(zr[m][3]));
+    asm volatile("" : "+v"(rword));
+#if XV_LINDS_WARM
+    float warm = 0.0f;
+    if (!INJECT) {   // one dword per lane group of the env: g = 0 the initial state, 1 its tabulated observation, 2 cmd(0)
+      const int widx = linds_init_from_word(linds_bcast_row0(rword), n_init);
+      const float* wp = g == 0 ? P.T.init + ((size_t)t * P.NI + widx) * NS
+                      : g == 1 && P.rst_tab != nullptr ? P.rst_tab + ((size_t)t * P.NI + widx) * (NO + 4)
+                      : P.cmd_tab != nullptr ? P.cmd_tab + ((size_t)t * P.ct_len + (0 - P.ct_tmin)) * P.ct_w : P.T.init;
+      warm = *reinterpret_cast<const volatile float*>(wp);
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- x' = Phi x + Gamma act  (:78-80): MT independent accumulator chains, interleaved ----
@@ -737,7 +810,8 @@ struct LinDSTileStep {
 #pragma unroll
     for (int kk = 0; kk < KA; ++kk) {
       psa = fmaf(ak[kk], ak[kk], psa);
-      const float b = ak[kk] < -1.0f ? -1.0f : (ak[kk] > 1.0f ? 1.0f : ak[kk]);   // :138 clip
+      float b = ak[kk] > 1.0f ? 1.0f : ak[kk];   // :138 clip (two selects: a NaN action stays NaN, as in the oracle)
+      b = ak[kk] < -1.0f ? -1.0f : b;
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr.ga(m, kk), b, acc[m], 0, 0, 0);
     }
@@ -770,6 +844,16 @@ struct LinDSTileStep {
     for (int mo = 0; mo < MO; ++mo)
 #pragma unroll
       for (int r = 0; r < 4; ++r) ym[mo][r] = ym[mo][r] + fr.y0r[mo][r];   // :85
+    if (P.cmd_tab != nullptr) {
+#pragma unroll
+      for (int mo = 0; mo < MO; ++mo) {
+        // the tracked command enters only through (y - c) * target_valid, which is zero in every column past ct_w: the
+        // finite value read there instead of a zero cannot show; the reported command is stored, so it is zeroed
+        const bool live = 16 * mo + 4 * g < P.ct_w;
+        ctr[mo][0] = cu[mo].x; ctr[mo][1] = cu[mo].y; ctr[mo][2] = cu[mo].z; ctr[mo][3] = cu[mo].w;
+        crep[mo][0] = live ? cv[mo].x : 0.f; crep[mo][1] = live ? cv[mo].y : 0.f; crep[mo][2] = live ? cv[mo].z : 0.f; crep[mo][3] = live ? cv[mo].w : 0.f;
+      }
+    }
     if (__ballot(!(trk_in && rep_in)) != 0ull) {   // rare: no table, or an env stepped on outside it (auto-reset disabled)
       if (!trk_in) linds_cmd_quarter<NO>(P, t, nf, trk_time, g, ctr);
       if (!rep_in) linds_cmd_quarter<NO>(P, t, nf, rep_time, g, crep);
@@ -808,10 +892,10 @@ struct LinDSTileStep {
     if (valid && done && mode == XV_AUTORESET_SAME_STEP && o_fobs != nullptr) {   // final observation: finished envs only
 #pragma unroll
       for (int mo = 0; mo < MO; ++mo)
-        *reinterpret_cast<float4*>(o_fobs + orow * NO + 16 * mo + 4 * g) = make_float4(ym[mo][0], ym[mo][1], ym[mo][2], ym[mo][3]);
+        linds_store_out4(o_fobs + orow * NO + 16 * mo + 4 * g, ym[mo][0], ym[mo][1], ym[mo][2], ym[mo][3]);
     }
     if (__ballot(do_reset) != 0ull) {   // wave-uniform: the restarted envs take their initial state
-      int idx = INJECT ? init_inj : linds_draw_init(P, gid, tick, n_init);
+      int idx = INJECT ? init_inj : linds_init_from_word(linds_bcast_row0(rword), n_init);
       idx = idx < 0 ? 0 : (idx >= n_init ? n_init - 1 : idx);
       const float* x0 = P.T.init + ((size_t)t * P.NI + idx) * NS + 4 * g;
       xv_f32x4 xr[MT];
@@ -823,10 +907,11 @@ struct LinDSTileStep {
       float c0[MO][4];   // :120-126: the last pre-filled command is cmd(0)
       const int z_idx = 0 - P.ct_tmin;
       if (P.cmd_tab != nullptr && z_idx >= 0 && z_idx < P.ct_len) {
-        const float4* p = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + z_idx) * NO);
+        const float4* p = reinterpret_cast<const float4*>(P.cmd_tab + ((size_t)t * P.ct_len + z_idx) * P.ct_w);
 #pragma unroll
         for (int mo = 0; mo < MO; ++mo) {
-          const float4 v = p[4 * mo + g];
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (16 * mo + 4 * g < P.ct_w) v = p[4 * mo + g];
           c0[mo][0] = v.x; c0[mo][1] = v.y; c0[mo][2] = v.z; c0[mo][3] = v.w;
         }
       } else {
@@ -883,19 +968,29 @@ struct LinDSTileStep {
 #pragma unroll
       for (int mo = 0; mo < MO; ++mo) {   // each lane stores its own 16-byte quarter of the rows
         const size_t ro = orow * NO + 16 * mo + 4 * g;
-        *reinterpret_cast<float4*>(o_obs + ro) = make_float4(ym[mo][0], ym[mo][1], ym[mo][2], ym[mo][3]);
-        if (o_cmd) *reinterpret_cast<float4*>(o_cmd + ro) = make_float4(crep[mo][0], crep[mo][1], crep[mo][2], crep[mo][3]);
+        linds_store_out4(o_obs + ro, ym[mo][0], ym[mo][1], ym[mo][2], ym[mo][3]);
+        if (o_cmd) linds_store_out4(o_cmd + ro, crep[mo][0], crep[mo][1], crep[mo][2], crep[mo][3]);
       }
       if (g == 0) {
+#if XV_LINDS_NT_MORE & 2
+        __builtin_nontemporal_store(o_r, o_reward + orow);
+        if (o_error) __builtin_nontemporal_store(o_err, o_error + orow);
+        __builtin_nontemporal_store((uint8_t)o_term, o_term_p + orow);
+        __builtin_nontemporal_store((uint8_t)o_trunc, o_trunc_p + orow);
+#else
         o_reward[orow] = o_r;
         if (o_error) o_error[orow] = o_err;
         o_term_p[orow] = (uint8_t)o_term;
         o_trunc_p[orow] = (uint8_t)o_trunc;
+#endif
       }
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) xs[m] = xn[m];
     bad_out |= bad;
+#if XV_LINDS_WARM
+    asm volatile("" :: "v"(warm));   // the touch's destination stays allocated until the load has landed
+#endif
   }
 };
 
@@ -916,7 +1011,8 @@ __device__ __forceinline__ bool linds_tile_id(const LinDSArgs& P, LinDSTileId& i
   if (P.slot_env != nullptr) e_raw = id.es < P.n_slot ? P.slot_env[id.es] : -1;
   id.valid = id.es < P.n_slot && e_raw >= 0 && e_raw < P.n_env;
   id.e = id.valid ? e_raw : 0;           // the env it serves: its I/O rows and the global id of its draws
-  id.t = __builtin_amdgcn_readfirstlane(P.tile_task ? P.tile_task[id.wave] : P.env_task[tile0]);
+  id.t = P.task_shift >= 4 ? (tile0 >> P.task_shift)
+                           : __builtin_amdgcn_readfirstlane(P.tile_task ? P.tile_task[id.wave] : P.env_task[tile0]);
   id.gid = P.gid_base + (uint64_t)id.e;
   return true;
 }
@@ -926,9 +1022,8 @@ __device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const L
   using F = LinDSFrag<NS, NA, NO>;
   LinDSTileId id;
   if (!linds_tile_id(P, id)) return;
-  // ---- every load of the step is in flight before the first MFMA ----
-  F fr;
-  fr.load(P, id.t, id.lane);
+  // ---- every load of the step is in flight before the first MFMA; the step counter first (the command rows wait for it) ----
+  const uint32_t sn0 = (uint32_t)P.sn[id.es];
   float4* xq = reinterpret_cast<float4*>(P.x) + (size_t)id.wave * F::MT * 64 + id.lane;
   xv_f32x4 xs[F::MT];
 #pragma unroll
@@ -936,7 +1031,8 @@ __device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const L
     const float4 v = xq[m * 64];
     xs[m] = xv_f32x4{v.x, v.y, v.z, v.w};
   }
-  const uint32_t sn0 = (uint32_t)P.sn[id.es];
+  F fr;
+  fr.load(P, id.t, id.lane);
   int steps = (int)(sn0 & ~XV_LINDS_NR_BIT), nr = (int)(sn0 >> 31), bad = 0;
   const int init_inj = INJECT ? io.init_index[id.e] : 0;
   LinDSTileStep<NS, NA, NO, INJECT>::run(P, fr, id.t, id.lane, id.e, id.valid, id.gid, P.tick, mode,
@@ -944,7 +1040,14 @@ __device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const L
                                          io.final_obs, io.reward, io.error, io.terminated, io.truncated, xs, steps, nr, bad);
   if (id.valid) {
 #pragma unroll
-    for (int m = 0; m < F::MT; ++m) xq[m * 64] = make_float4(xs[m][0], xs[m][1], xs[m][2], xs[m][3]);
+    for (int m = 0; m < F::MT; ++m) {
+#if XV_LINDS_NT_MORE & 4
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(f4{xs[m][0], xs[m][1], xs[m][2], xs[m][3]}, reinterpret_cast<f4*>(xq + m * 64));
+#else
+      xq[m * 64] = make_float4(xs[m][0], xs[m][1], xs[m][2], xs[m][3]);
+#endif
+    }
     if (id.g == 0) P.sn[id.es] = (int32_t)((uint32_t)steps | (nr ? XV_LINDS_NR_BIT : 0u));
     if (bad) atomicOr(P.err, (uint32_t)XV_DEVERR_NONFINITE);
   }
@@ -1000,8 +1103,12 @@ __global__ __launch_bounds__(256) void linds_rollout_mfma_kernel(LinDSArgs P, Li
 // two entry points over the same body: with 16 observation rows the step fits 128 registers and is capped there
 // (4 waves per SIMD: the kernel is latency-bound); with 32 rows the cap would spill, so it runs at 2-3 waves per SIMD
 template <int NS, int NA, int NO, bool INJECT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_LINDS_OCC, XV_LINDS_OCC == 4 ? 8 : XV_LINDS_OCC)))
 void linds_step_mfma_kernel(LinDSArgs P, LinDSStepIO io, int mode) {
+#if XV_LINDS_OCC < 4   // measurement only: an LDS allocation that admits XV_LINDS_OCC workgroups (= waves per SIMD) per CU
+  __shared__ float occ_pad[(XV_LINDS_OCC == 2 ? 60 : XV_LINDS_OCC == 3 ? 45 : 150) * 256];
+  if (P.n_env < 0) occ_pad[threadIdx.x] = 0.0f;
+#endif
   linds_step_mfma_body<NS, NA, NO, INJECT>(P, io, mode);
 }
 template <int NS, int NA, int NO, bool INJECT>
@@ -1009,11 +1116,12 @@ __global__ __launch_bounds__(256) void linds_step_mfma_wide_kernel(LinDSArgs P, 
   linds_step_mfma_body<NS, NA, NO, INJECT>(P, io, mode);
 }
 
-// every aligned group of 16 envs shares one task?  (else the engine builds its slot layout)
-__global__ __launch_bounds__(256) void linds_check_tiles_kernel(const int32_t* env_task, int n_env, int* not_uniform) {
+// every aligned group of 16 envs shares one task?  (else the engine builds its slot layout)   bit 1: env_task[i] != i >> shift
+__global__ __launch_bounds__(256) void linds_check_tiles_kernel(const int32_t* env_task, int n_env, int shift, int* not_uniform) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_env) return;
   if (env_task[i] != env_task[i & ~15]) atomicOr(not_uniform, 1);
+  if (shift < 4 || env_task[i] != (i >> shift)) atomicOr(not_uniform, 2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1044,7 +1152,7 @@ extern "C" int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int 
   a.seed = e->seed; a.gid_base = e->env_id_base; a.tick = 0;
   a.x = nullptr; a.sn = nullptr; a.frag = nullptr; a.tvec = nullptr;
   h->frag = nullptr; h->tvec = nullptr;
-  a.slot_env = nullptr; a.env_slot = nullptr; a.tile_task = nullptr; a.n_slot = n_env;
+  a.slot_env = nullptr; a.env_slot = nullptr; a.tile_task = nullptr; a.n_slot = n_env; a.task_shift = -1;
   h->d_slot_env = nullptr; h->d_env_slot = nullptr; h->d_tile_task = nullptr;
   hipError_t m = hipSuccess;
   {
@@ -1052,14 +1160,20 @@ extern "C" int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int 
     int h_flag = 1;
     m = hipMalloc(&d_flag, sizeof(int));
     if (m == hipSuccess) m = hipMemsetAsync(d_flag, 0, sizeof(int), e->stream);
+    int shift = -1;   // candidate: n_env = n_task << shift
+    if (n_env % n_task == 0) {
+      const int per = n_env / n_task;
+      if ((per & (per - 1)) == 0) for (shift = 0; (1 << shift) < per; ++shift) {}
+    }
     if (m == hipSuccess) {
       hipLaunchKernelGGL(linds_check_tiles_kernel, dim3(xv_div_up(n_env, 256)), dim3(256), 0, e->stream, env_task,
-                         n_env, d_flag);
+                         n_env, shift, d_flag);
       m = hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, e->stream);
     }
     if (m == hipSuccess) m = hipStreamSynchronize(e->stream);
     if (d_flag) (void)hipFree(d_flag);
-    h->tiles_uniform = (h_flag == 0);
+    h->tiles_uniform = ((h_flag & 1) == 0);
+    a.task_shift = (m == hipSuccess && (h_flag & 2) == 0) ? shift : -1;
     h->path = XV_LINDS_PATH_AUTO;
   }
   if (m == hipSuccess && !h->tiles_uniform) {
@@ -1138,23 +1252,26 @@ extern "C" int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int 
     a.frag = h->frag; a.tvec = h->tvec;
   }
   // command table: [n_task][max_steps_max + 2 + delay_max][NO] floats, within a 2-GiB budget
-  a.cmd_tab = nullptr; a.ct_len = 0; a.ct_tmin = 0; a.rst_tab = nullptr;
+  a.cmd_tab = nullptr; a.ct_len = 0; a.ct_tmin = 0; a.ct_w = NO; a.rst_tab = nullptr;
   h->cmd_tab = nullptr; h->rst_tab = nullptr;
   {
-    int* d2 = nullptr;
-    int h2[2] = {0, 0};
-    XV_HIP(hipMalloc(&d2, 2 * sizeof(int)));
-    XV_HIP(hipMemsetAsync(d2, 0, 2 * sizeof(int), e->stream));
-    hipLaunchKernelGGL(linds_max_ints_kernel, dim3(xv_div_up(n_task, 256)), dim3(256), 0, e->stream, tables->ints, n_task, d2);
-    XV_HIP(hipMemcpyAsync(h2, d2, 2 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    int* d3 = nullptr;
+    int h3[3] = {0, 0, 0};
+    XV_HIP(hipMalloc(&d3, 3 * sizeof(int)));
+    XV_HIP(hipMemsetAsync(d3, 0, 3 * sizeof(int), e->stream));
+    hipLaunchKernelGGL(linds_max_ints_kernel, dim3(xv_div_up(n_task, 256)), dim3(256), 0, e->stream, tables->ints, tables->valid,
+                       NO, n_task, d3);
+    XV_HIP(hipMemcpyAsync(h3, d3, 3 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     XV_HIP(hipStreamSynchronize(e->stream));
-    XV_HIP(hipFree(d2));
-    const long long len = (long long)h2[0] + 2 + h2[1];
-    const unsigned long long bytes = (unsigned long long)n_task * (unsigned long long)len * NO * sizeof(float);
+    XV_HIP(hipFree(d3));
+    const int ct_w = h3[2] <= 0 ? 4 : (h3[2] + 3) / 4 * 4;
+    const long long len = (long long)h3[0] + 2 + h3[1];
+    const unsigned long long bytes = (unsigned long long)n_task * (unsigned long long)len * ct_w * sizeof(float);
     float* tab = nullptr;
-    if (h2[0] > 0 && h2[1] >= 0 && len < (1 << 20) && bytes <= (2ull << 30) && hipMalloc(&tab, bytes) == hipSuccess) {
+    if (h3[0] > 0 && h3[1] >= 0 && len < (1 << 20) && bytes <= (2ull << 30) && hipMalloc(&tab, bytes) == hipSuccess) {
       a.ct_len = (int)len;
-      a.ct_tmin = -(1 + h2[1]);
+      a.ct_tmin = -(1 + h3[1]);
+      a.ct_w = ct_w;
       const size_t n = (size_t)n_task * a.ct_len;
       if (NO == 16)
         hipLaunchKernelGGL((linds_build_cmd_tab_kernel<16>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, a, tab);
@@ -1304,6 +1421,26 @@ extern "C" int xv_linds_step(xv_linds* h, const float* action, float* obs, float
   linds_bind_rng(h, 1);
   LinDSStepIO io{action, nullptr, nullptr, obs, reward, terminated, truncated, cmd, error, final_obs};
   return linds_launch_step<false>(h, io, autoreset_mode);
+}
+
+// K vector steps issued from C: step k reads actions slot k % period and writes output slot k % period of [period][...]
+// ring buffers (a host loop over xv_linds_step costs ~5 us of Python / ctypes per launch, the kernel ~9)
+extern "C" int xv_linds_step_many(xv_linds* h, int n_steps, int period, const float* action, float* obs, float* reward,
+                                  uint8_t* terminated, uint8_t* truncated, float* cmd, float* error, float* final_obs,
+                                  int autoreset_mode) {
+  XV_CHECK_ARG(h && n_steps > 0 && period > 0);
+  XV_CHECK_ARG(action && obs && reward && terminated && truncated && cmd && error);
+  XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
+  const size_t n = (size_t)h->a.n_env;
+  for (int k = 0; k < n_steps; ++k) {
+    const size_t o = (size_t)(k % period) * n;
+    linds_bind_rng(h, 1);
+    LinDSStepIO io{action + o * h->a.NA, nullptr, nullptr, obs + o * h->a.NO, reward + o, terminated + o, truncated + o,
+                   cmd + o * h->a.NO, error + o, final_obs ? final_obs + o * h->a.NO : nullptr};
+    const int rc = linds_launch_step<false>(h, io, autoreset_mode);
+    if (rc != XV_OK) return rc;
+  }
+  return XV_OK;
 }
 
 extern "C" int xv_linds_step_injected(xv_linds* h, const float* action, const float* z,

@@ -241,6 +241,36 @@ class LinDSVecEnv(VectorEnv):
             _lib.ptr(self._error), _lib.ptr(self._fobs), AUTORESET[self.autoreset_mode]))
         return self._ret()
 
+    def step_many(self, n_steps, actions, out=None):
+        """n_steps vector steps issued from C (xv_linds_step_many): actions float32[P, N, na] is a ring of P action sets,
+        step k uses slot k % P and writes slot k % P of the returned dict of [P, N(, NO)] device tensors.  Equals n_steps
+        calls of step(); `final_obs` rows are written for finished envs only."""
+        self._check_step()
+        a = self._dev(actions, torch.float32)
+        P = int(a.shape[0])
+        na_user = self.user_dims[0]
+        if a.shape != (P, self.num_envs, na_user):
+            raise AssertionError(f"Action shape mismatch: expected {(P, self.num_envs, na_user)}, got {tuple(a.shape)}")
+        if na_user != self.NA:
+            p = torch.zeros((P, self.num_envs, self.NA), dtype=torch.float32, device=self.device)
+            p[..., :na_user] = a
+            a = p
+        a = a.contiguous()
+        d, n = self.device, self.num_envs
+        if out is None:
+            out = dict(obs=torch.empty((P, n, self.NO), dtype=torch.float32, device=d),
+                       reward=torch.empty((P, n), dtype=torch.float32, device=d),
+                       terminated=torch.empty((P, n), dtype=torch.uint8, device=d),
+                       truncated=torch.empty((P, n), dtype=torch.uint8, device=d),
+                       command=torch.empty((P, n, self.NO), dtype=torch.float32, device=d),
+                       error=torch.empty((P, n), dtype=torch.float32, device=d),
+                       final_obs=torch.zeros((P, n, self.NO), dtype=torch.float32, device=d))
+        _lib.check(self.lib.xv_linds_step_many(self._h, int(n_steps), P, _lib.ptr(a), _lib.ptr(out["obs"]),
+                                               _lib.ptr(out["reward"]), _lib.ptr(out["terminated"]),
+                                               _lib.ptr(out["truncated"]), _lib.ptr(out["command"]), _lib.ptr(out["error"]),
+                                               _lib.ptr(out.get("final_obs")), AUTORESET[self.autoreset_mode]))
+        return out
+
     def rollout(self, actions, out=None, with_info=True):
         """Fused open-loop roll-out: actions float32[T, N, na] -> dict of [T, N(, NO)] device tensors, one launch with the
         state resident in registers between the steps.  Equals T calls of step() with SAME_STEP auto-reset, bit for bit."""
