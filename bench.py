@@ -67,6 +67,11 @@ def parse():
                     help="comma list of envs/GPU (e.g. 16384,32768,65536,131072,262144): time the 2a step at each size "
                          "and write --sweep-out instead of the bench line")
     ap.add_argument("--sweep-out", default=os.path.join(ROOT, "gpurun_out", "anymdp_envs_sweep.json"))
+    ap.add_argument("--no-families", action="store_true",
+                    help="N = 1: skip the `families` object (configs 3, 4 and the per-GPU share of 5, a few seconds)")
+    ap.add_argument("--transport", default="auto", choices=["auto", "torch", "rccl"],
+                    help="N > 1: how rollout chunks are all-gathered — torch.distributed (backend nccl = RCCL) or the C-ABI's "
+                         "xv_rollout_allgather over librccl directly; auto = rccl when xv_rccl_unique_id succeeds")
     ap.add_argument("--exchange-selftest", action="store_true",
                     help="N>1 control flow (process group, watchdog, pack -> all-gather -> unpack, MAX over ranks) on "
                          "fabricated CPU records, no GPU and no stepping: a functional test, not a measurement")
@@ -416,14 +421,35 @@ def main():
         (selftest or dist.get_backend() == "nccl" or bool(os.environ.get("XV_BENCH_FORCE_GATHER")))
     gather = None
     gather_note = dinfo["note"] or "none"
+    transport = {"used": None, "requested": args.transport, "note": None, "rccl_comm_count": None}
     if do_gather:
-        try:
-            gather = RolloutGather((P, n_env, REC_BYTES), device=device)
-            gather_note = "all_gather of %d-step rollout chunks, %d B/record (%s, side stream)" \
-                          % (P, REC_BYTES, "RCCL" if dinfo["rccl"] else dinfo["backend"])
-        except Exception as ex:   # never lose the measurement to a collective set-up problem
-            gather = None
-            gather_note = "all_gather unavailable: %r" % (ex,)
+        # --transport: "rccl" = the C-ABI's own collective (xv_rccl_* / xv_rollout_allgather: ncclAllGather over librccl,
+        # no torch.distributed in the data path), "torch" = all_gather_into_tensor of the process group; auto prefers rccl
+        want = args.transport
+        if want in ("auto", "rccl"):
+            if selftest or device.type != "cuda":
+                transport["note"] = "the rccl transport moves device buffers: torch used on CPU"
+            else:
+                wd.arm("RCCL communicator set-up (xv_rccl_comm_create)")
+                try:
+                    gather = RolloutGather((P, n_env, REC_BYTES), device=device, transport="rccl", rank=rank, world=world)
+                    transport["used"] = "rccl"
+                    transport["rccl_comm_count"] = gather.comm.count()
+                    gather_note = "all_gather of %d-step rollout chunks, %d B/record (xv_rollout_allgather: ncclAllGather over " \
+                                  "librccl through the C-ABI, side stream)" % (P, REC_BYTES)
+                except Exception as ex:
+                    gather = None
+                    transport["note"] = "rccl transport unavailable (%r): torch used" % (ex,)
+                wd.cancel()
+        if gather is None:
+            try:
+                gather = RolloutGather((P, n_env, REC_BYTES), device=device)
+                transport["used"] = "torch"
+                gather_note = "all_gather of %d-step rollout chunks, %d B/record (torch.distributed %s, side stream)" \
+                              % (P, REC_BYTES, "nccl = RCCL" if dinfo["rccl"] else dinfo["backend"])
+            except Exception as ex:   # never lose the measurement to a collective set-up problem
+                gather = None
+                gather_note = "all_gather unavailable: %r" % (ex,)
 
     def run(k_steps, with_gather=False):
         done = 0
@@ -525,7 +551,10 @@ def main():
                                        % (0 if search == "binary" else 1, ", true" if search == "bucket" else ""),
                              "kernel_source_sha16": None if selftest else kernel_source_hash(),
                              "avg_launch_us": kern_us, "algorithmic_bytes_per_launch": algo},
-                "rccl": dinfo["rccl"], "rccl_ranks": dinfo["rccl_ranks"],
+                "rccl": dinfo["rccl"],
+                "rccl_ranks": transport["rccl_comm_count"] if transport["rccl_comm_count"] is not None else dinfo["rccl_ranks"],
+                "transport": transport["used"], "transport_requested": transport["requested"],
+                "transport_note": transport["note"], "rccl_ranks_all_reduce": dinfo["rccl_ranks"],
                 "allgather_timeout": timeout_note is not None,
             }
             if selftest:
@@ -542,6 +571,8 @@ def main():
                                          "gathered_GB_per_s_per_rank":
                                              chunks * P * n_env * REC_BYTES * (world - 1) / state["wall_g"] / 1e9}
             out["cpu_baseline"] = cpu if world == 1 else None      # the CPU lines are measured at N = 1 only
+            if state.get("families") is not None:
+                out["families"] = state["families"]
             print(json.dumps(out), flush=True)
 
     if args.fused and env is not None:
@@ -556,6 +587,19 @@ def main():
         f1.record()
         torch.cuda.synchronize()
         state["fused"] = n_env * T * reps / (f0.elapsed_time(f1) * 1e-3)
+
+    # N = 1: configs 3, 4 and the per-GPU share of config 5 beside the headline, in the same JSON line (`families`)
+    if world == 1 and env is not None and not args.no_families and not args.sweep_envs:
+        try:
+            env.close()
+            env = None
+            del tab, ring, actions
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import bench_families
+            state["families"] = bench_families.quick_families()
+        except Exception as ex:
+            state["families"] = {"error": repr(ex)}
 
     if gather is not None:      # pass 2 (N > 1): every finished rollout chunk all-gathered to all ranks, overlapped
         wd.emit = report

@@ -122,7 +122,7 @@ int xv_rollout_allgather(xv_engine* e, void* rccl_comm, const void* local, void*
  *
  * Table layout (device memory, borrowed for the life of the handle):
  *   rows       [n_task][S][A] row records of XV_ANYMDP_ROW_LINES(S) = 1 + NB lines of 128 bytes; NB = ceil(S/7) rounded
- *              up to a multiple of G = ceil(ceil(S/7)/16) (G = 1 up to S = 112, 2 up to 224, 3 up to 256).
+ *              up to a multiple of G = ceil(ceil(S/7)/16) (G = 1 up to S = 112, 2 up to 224, 3 up to 336, 4 up to 448, 5 up to 512).
  *                line 0      FENCE: double[16]; fence[k] = the CDF entry of the last next-state of block group k
  *                            (G consecutive blocks) for k < NB/G - 1, 2.0 beyond.  -- written by xv_anymdp_create --
  *                line 1 + k  BLOCK k: 7 entries of 16 bytes {double cdf; float reward; float reward_noise} for next
@@ -141,7 +141,7 @@ int xv_rollout_allgather(xv_engine* e, void* rccl_comm, const void* local, void*
  *   s0_ids     int32  [n_task][s0_max]    task["s_0"] (padded by repeating the last id)
  *   max_steps  int32  [n_task]            ceil(task["max_steps"]): `steps >= max_steps` on integer steps
  *   env_task   int32  [n_env]             env -> task index
- * Supported: 2 <= S <= 256, 2 <= A <= 64, 1 <= s0_max <= 256.
+ * Supported: 2 <= S <= 512, 2 <= A <= 64, 1 <= s0_max <= 256.
  * ---------------------------------------------------------------------------------------------- */
 /* blocks per row: ceil(S/7) rounded up to a multiple of G = ceil(blocks/16); lines per row: one more (the fence) */
 #define XV_ANYMDP_ROW_G(S) (((((S) + 6) / 7) + 15) / 16)
@@ -238,7 +238,7 @@ int xv_anymdp_step_tokens_injected(xv_anymdp* h, const int32_t* action, const do
 #define XV_ANYMDP_SEARCH_BUCKET 4
 int xv_anymdp_set_search(xv_anymdp* h, int search);
 /* builds (n_bucket = 16 | 32 | 64) or frees (0) the engine-owned bucket lines of this handle's rows (FENCE layout, any
- * S <= 256).  XV_ERR_NOMEM when they do not fit. */
+ * S <= 512).  XV_ERR_NOMEM when they do not fit. */
 int xv_anymdp_build_buckets(xv_anymdp* h, int n_bucket);
 
 /* fused teacher rollout: like xv_anymdp_rollout, but the action of every step comes from a per-task greedy table

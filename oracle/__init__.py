@@ -83,14 +83,16 @@ class _AnyMDPStruct(C.Structure):
                 ("term_mask", C.c_void_p), ("s0_cdf", C.c_void_p), ("s0_ids", C.c_void_p),
                 ("max_steps", C.c_void_p), ("env_task", C.c_void_p),
                 ("state", C.c_void_p), ("steps", C.c_void_p), ("need_reset", C.c_void_p),
-                ("err_flags", C.c_uint32)]
+                ("err_flags", C.c_uint32), ("gid_stride", C.c_uint32)]
 
 
 class AnyMDPOracle(object):
     """Batched CPU AnyMDP over the device table layout (include/xeno.h).  `tables` is the dict made by
     xenoverse_amd.anymdp.tables.build_tables (numpy arrays)."""
 
-    def __init__(self, tables, env_task):
+    def __init__(self, tables, env_task, gid_stride=1):
+        """gid_stride: free-running draws of env i use global env id gid_base + i * gid_stride (a scattered subset of a
+        larger device batch)"""
         t = tables
         self.S, self.A, self.s0_max = int(t["S"]), int(t["A"]), int(t["s0_max"])
         self.n_task = int(t["cdf"].shape[0])
@@ -111,7 +113,7 @@ class AnyMDPOracle(object):
         self._h = _AnyMDPStruct(self.n_env, self.n_task, self.S, self.A, self.s0_max,
                                 _p(k["cdf"]), _p(k["rs"]), _p(k["state_map"]), _p(k["term_mask"]),
                                 _p(k["s0_cdf"]), _p(k["s0_ids"]), _p(k["max_steps"]), _p(self.env_task),
-                                _p(self.state), _p(self.steps), _p(self.need_reset), 0)
+                                _p(self.state), _p(self.steps), _p(self.need_reset), 0, int(gid_stride))
 
     @property
     def err_flags(self):
@@ -193,15 +195,16 @@ class AnyMDPOracle(object):
         return out
 
 
-def anymdp_synth(seed, task_index_base, n_task, S, A, s0_max):
-    """Synthetic task tables (same bits as the device generator xv_anymdp_synth_tasks)."""
+def anymdp_synth(seed, task_index_base, n_task, S, A, s0_max, task_stride=1):
+    """Synthetic task tables (same bits as the device generator xv_anymdp_synth_tasks) of the tasks
+    task_index_base + k * task_stride."""
     words = (S + 63) // 64
     t = dict(S=S, A=A, s0_max=s0_max,
              cdf=np.empty((n_task, S, A, S), np.float64), rs=np.empty((n_task, S, A, S, 2), np.float32),
              state_map=np.empty((n_task, S), np.int32), term_mask=np.empty((n_task, words), np.uint64),
              s0_cdf=np.empty((n_task, s0_max), np.float64), s0_ids=np.empty((n_task, s0_max), np.int32),
              max_steps=np.empty(n_task, np.int32))
-    lib().xo_anymdp_synth(C.c_uint64(seed), C.c_int64(task_index_base), C.c_int(n_task), C.c_int(S),
+    lib().xo_anymdp_synth_strided(C.c_uint64(seed), C.c_int64(task_index_base), C.c_int64(task_stride), C.c_int(n_task), C.c_int(S),
                           C.c_int(A), C.c_int(s0_max), _p(t["cdf"]), _p(t["rs"]), _p(t["state_map"]),
                           _p(t["term_mask"]), _p(t["s0_cdf"]), _p(t["s0_ids"]), _p(t["max_steps"]))
     return t

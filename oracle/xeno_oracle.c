@@ -178,12 +178,16 @@ void xo_anymdp_step_injected(xo_anymdp* h, const int32_t* action, const double* 
                     truncated, final_obs, mode, &h->err_flags);
 }
 
+static inline uint64_t anymdp_gid(const xo_anymdp* h, uint64_t gid_base, int i) {
+  return gid_base + (uint64_t)i * (uint64_t)(h->gid_stride ? h->gid_stride : 1u);
+}
+
 void xo_anymdp_reset(xo_anymdp* h, uint64_t seed, uint64_t gid_base, uint64_t tick, const uint8_t* mask,
                      int32_t* obs) {
   for (int i = 0; i < h->n_env; ++i) {
     if (mask && !mask[i]) continue;
     uint32_t w[4];
-    xo_env_draw(seed, gid_base + (uint64_t)i, tick, 1, w);
+    xo_env_draw(seed, anymdp_gid(h, gid_base, i), tick, 1, w);
     anymdp_reset_one(h, i, xo_u53(w[0], w[1]), obs);
   }
 }
@@ -193,8 +197,8 @@ static inline void anymdp_step_free_one(xo_anymdp* h, int i, uint64_t seed, uint
                                         float* reward, float* reward_gt, uint8_t* terminated,
                                         uint8_t* truncated, int32_t* final_obs, int mode, uint32_t* err) {
   uint32_t w[4], v[4];
-  xo_env_draw(seed, gid_base + (uint64_t)i, tick, 0, w);
-  xo_env_draw(seed, gid_base + (uint64_t)i, tick, 1, v);
+  xo_env_draw(seed, anymdp_gid(h, gid_base, i), tick, 0, w);
+  xo_env_draw(seed, anymdp_gid(h, gid_base, i), tick, 1, v);
   float z;
   xo_box_muller(w[2], w[3], &z, 0);
   anymdp_step_one(h, i, action[i], xo_u53(w[0], w[1]), z, xo_u53(v[0], v[1]), obs, reward, reward_gt,
@@ -260,11 +264,18 @@ static inline void synth_draw(uint64_t seed, uint64_t task, uint32_t c2, uint32_
 void xo_anymdp_synth(uint64_t seed, int64_t task_index_base, int n_task, int S, int A, int s0_max,
                      double* cdf, float* rs, int32_t* state_map, uint64_t* term_mask, double* s0_cdf,
                      int32_t* s0_ids, int32_t* max_steps) {
+  xo_anymdp_synth_strided(seed, task_index_base, 1, n_task, S, A, s0_max, cdf, rs, state_map, term_mask, s0_cdf, s0_ids,
+                          max_steps);
+}
+
+void xo_anymdp_synth_strided(uint64_t seed, int64_t task_index_base, int64_t task_stride, int n_task, int S, int A,
+                             int s0_max, double* cdf, float* rs, int32_t* state_map, uint64_t* term_mask, double* s0_cdf,
+                             int32_t* s0_ids, int32_t* max_steps) {
   const int words = (S + 63) / 64;
   /* tasks are independent (every draw is keyed by the task index): large batches are built by all host threads */
 #pragma omp parallel for schedule(static) if (n_task >= 256)
   for (int tl = 0; tl < n_task; ++tl) {
-    const uint64_t task = (uint64_t)(task_index_base + tl);
+    const uint64_t task = (uint64_t)(task_index_base + (int64_t)tl * task_stride);
     uint32_t w[4];
     /* header */
     synth_draw(seed, task, 0xFFFFFFFFu, 0, w);
@@ -298,7 +309,7 @@ void xo_anymdp_synth(uint64_t seed, int64_t task_index_base, int n_task, int S, 
     int n_c = S - 3, n_term = (15 * S) / 100;
     if (n_c < 0) n_c = 0;
     if (n_term > n_c) n_term = n_c;
-    int cand[256];
+    int cand[512];
     for (int k = 0; k < n_c; ++k) cand[k] = 3 + k;
     for (int k = 0; k < n_term; ++k) {
       synth_draw(seed, task, 0xFFFFFFFFu, 0x200u + (uint32_t)(k >> 2), w);
@@ -318,7 +329,7 @@ void xo_anymdp_synth(uint64_t seed, int64_t task_index_base, int n_task, int S, 
         int hi_min = s + 2 < S ? s + 2 : S;
         int hi_max = s + 17 < S ? s + 17 : S;
         int hi = hi_min + (int)(w[1] % (uint32_t)(hi_max - hi_min + 1));
-        uint32_t wt[256];
+        uint32_t wt[512];
         uint32_t total = 0;
         for (int j = 0; j < S; ++j) {
           if ((j & 3) == 0) synth_draw(seed, task, rowid, (uint32_t)(j >> 2), w);

@@ -42,6 +42,8 @@ typedef struct {
   int32_t* steps;           /* [n_env] */
   uint8_t* need_reset;      /* [n_env] */
   uint32_t err_flags;
+  uint32_t gid_stride;      /* free-running draws: env i draws as global env gid_base + i * gid_stride (0 = 1): lets a
+                             * scattered subset of a large device batch be checked env for env */
 } xo_anymdp;
 
 /* first index j with cdf[j] > u (numpy.searchsorted side='right'), clamped to n-1 */
@@ -84,6 +86,10 @@ void xo_anymdp_tok_step(xo_anymdp_tok* h, uint64_t seed, uint64_t gid_base, uint
                         int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated,
                         int32_t* final_obs, int mode);
 int xo_max_threads(void);
+/* xo_anymdp_synth for the tasks task_index_base + k * task_stride, k < n_task */
+void xo_anymdp_synth_strided(uint64_t seed, int64_t task_index_base, int64_t task_stride, int n_task, int S, int A,
+                             int s0_max, double* cdf, float* rs, int32_t* state_map, uint64_t* term_mask, double* s0_cdf,
+                             int32_t* s0_ids, int32_t* max_steps);
 
 /* ---- task-sampler arithmetic (xeno_oracle_sampler.c) ---- */
 double xo_np_pairwise_sum(const double* a, int64_t n);

@@ -223,7 +223,7 @@ def bench_anymdp_tok(args):
             "note": "per-lane searches (general path); 2 transition + 2 observation draws per env-step"}
 
 
-def bench_mixed(args):
+def bench_mixed(args, variants=("three streams", "one stream")):
     """BASELINE.json config 5, the per-GPU share: 16,384 anymdp (2b: 256 tasks x 64) + 8,192 linds (128 tasks x 64)
     + 8,192 cartpole, one launch per family per vector step, families on separate HIP streams (xenoverse_amd.mixed)
     vs the same launches serialised on one stream."""
@@ -234,12 +234,12 @@ def bench_mixed(args):
     from xenoverse_amd.metacontrol import CartPoleVecEnv, sample_cartpole
     from xenoverse_amd.mixed import MixedBatch
     na, nl, nc, S, A = 16384, 8192, 8192, 64, 8
-    ltasks = [LinearDSSampler(32, 8, 8, seed=k % 32) for k in range(nl // 64)]
-    for t in ltasks:
-        t["max_steps"] = 500
+    ltasks = linds_tasks(nl // 64)
     ctasks = [sample_cartpole(seed=k) for k in range(1024)]
     res = {}
     for label, mixed in (("three streams", True), ("one stream", False)):
+        if label not in variants:
+            continue
         if mixed:
             mb = MixedBatch("cuda:0", seed=3, streams="separate")
             ea = mb.add("a", AnyMDPVecEnv, na)
@@ -288,8 +288,62 @@ def bench_mixed(args):
         (mb.close() if mixed else [e.close() for e in (ea, el, ec)])
     n = na + nl + nc
     best = min(res.values())
+    algo = 562 * na + 432 * nl + 74 * nc
     return {"family": "mixed (config 5, per-GPU share)", "workload": "16,384 anymdp(2b) + 8,192 linds(32,8,8) + 8,192 cartpole",
-            "env_steps_per_s": n / (best * 1e-6), "us_per_vector_step": res, "dtype": "f64/f32"}
+            "env_steps_per_s": n / (best * 1e-6), "us_per_vector_step": res, "dtype": "f64/f32",
+            "roofline": {"bound": "hbm", "achieved": algo / (best * 1e-6) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
+                         "frac": algo / (best * 1e-6) / 1e9 / HBM_PEAK, "algorithmic_bytes_per_vector_step": algo,
+                         "note": "three launches of 4-10 us kernels per vector step: launch-latency bound"}}
+
+
+def quick_families(steps=200, warmup=20):
+    """the `families` object of bench.py's JSON line: BASELINE.json configs 3 (linds), 4 (mazeworld, 64x64 frames) and the
+    per-GPU share of config 5 (mixed), each timed with HIP events over back-to-back launches; a few seconds in all"""
+    a = argparse.Namespace(steps=steps, warmup=warmup)
+    out = {}
+
+    def guard(name, fn):
+        t0 = time.time()
+        try:
+            r = fn()
+        except Exception as ex:      # a family must never cost the headline line
+            r = {"error": repr(ex)}
+        r["wall_s"] = round(time.time() - t0, 1)
+        out[name] = r
+
+    def linds():
+        r = bench_linds(a, paths=("mfma",), rollout=False)
+        us = min(r["us_per_step"].values())
+        return {"config": "BASELINE configs[2]: " + r["workload"], "ms_per_step": us * 1e-3, "env_steps_per_s": r["env_steps_per_s"],
+                "us_per_step": r["us_per_step"], "dtype": "f32",
+                "roofline": {"bound": "hbm", "frac": r["roofline"]["frac"], "algorithmic_bytes": 432 * 65536, "peak": HBM_PEAK,
+                             "unit": "GB/s", "achieved": r["roofline"]["achieved"], "kernel": r["kernel"],
+                             "mfma_frac_of_157_TF": r["achieved_tflops"] / 157.3}}
+
+    def maze():
+        r = bench_maze(a, 64)
+        us = r["us_per_step"]["step (both)"]
+        return {"config": "BASELINE configs[3]: " + r["workload"], "ms_per_step": us * 1e-3, "env_steps_per_s": r["env_steps_per_s"],
+                "us_per_step": r["us_per_step"], "dtype": r["dtype"],
+                "roofline": {"bound": "hbm", "frac": r["roofline"]["frac"], "algorithmic_bytes": (3 * 64 * 64 + 64) * 16384,
+                             "peak": HBM_PEAK, "unit": "GB/s", "achieved": r["roofline"]["achieved"],
+                             "kernel": "maze_step9_kernel + maze_raycast_kernel", "valu_f64_frac": r["valu_f64"]["frac"],
+                             "note": r["roofline"]["note"]}}
+
+    def mixed():
+        r = bench_mixed(a, variants=("one stream",))
+        us = min(r["us_per_vector_step"].values())
+        return {"config": "BASELINE configs[4], one GPU's share: " + r["workload"], "ms_per_step": us * 1e-3,
+                "env_steps_per_s": r["env_steps_per_s"], "dtype": r["dtype"],
+                "roofline": {"bound": "hbm", "frac": r["roofline"]["frac"], "algorithmic_bytes": r["roofline"]["algorithmic_bytes_per_vector_step"],
+                             "peak": HBM_PEAK, "unit": "GB/s", "achieved": r["roofline"]["achieved"],
+                             "kernel": "anymdp_step_kernel + linds_step_mfma_kernel + cartpole_step_kernel, one stream",
+                             "note": r["roofline"]["note"]}}
+    guard("linds", linds)
+    guard("mazeworld_64", maze)
+    guard("mixed_share", mixed)
+    return out
+
 
 
 def bench_maze(args, res, precision="exact", move_kernel="auto"):

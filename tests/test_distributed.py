@@ -129,11 +129,14 @@ def _run_bench_selftest(extra_env, extra_args, timeout=240):
 def test_bench_py_two_ranks_end_to_end_on_gloo():
     """bench.py --gpus 2 through torch.distributed.run: process group, barriers, MAX over ranks, pack -> all-gather ->
     unpack of every rollout chunk and the JSON line — on fabricated CPU records (no GPU here), checked on every rank"""
-    r, out = _run_bench_selftest({}, [])
+    r, out = _run_bench_selftest({}, ["--transport", "rccl"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(out) == 1                      # rank 0 only
     d = out[0]
     assert d["n_gpus"] == 2 and d["selftest"] == "ok" and d["ranks_seen"] == 2 and d["repeats"] == 3
+    # --transport rccl is the C-ABI's collective over device buffers: on CPU records the torch transport serves, and says so
+    assert d["transport_requested"] == "rccl" and d["transport"] == "torch" and "torch used on CPU" in d["transport_note"]
+    assert "families" not in d
     assert d["allgather_timeout"] is False and d["rccl"] is False and d["with_allgather"]["value"] > 0
     assert d["value"] is None and "NOT a measurement" in d["mode"] and d["cpu_baseline"] is None
 
@@ -142,7 +145,8 @@ def test_bench_py_two_ranks_end_to_end_on_gloo():
 def test_bench_py_watchdog_exits_nonzero_and_keeps_the_pass1_line():
     """a rank that never joins the all-gather pass: every rank leaves with a non-zero code, rank 0 still prints the
     pass-1 line, flagged machine-readably"""
-    r, out = _run_bench_selftest({"XV_BENCH_TEST_STALL": "1"}, ["--gather-timeout", "6"])
+    r, out = _run_bench_selftest({"XV_BENCH_TEST_STALL": "1"}, ["--gather-timeout", "6", "--transport", "torch"])
     assert r.returncode != 0
     assert len(out) == 1 and out[0]["allgather_timeout"] is True
+    assert out[0]["transport"] == "torch" and out[0]["transport_requested"] == "torch" and out[0]["transport_note"] is None
     assert "did not finish within 6 s" in out[0]["config"]["exchange"]

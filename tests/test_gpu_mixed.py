@@ -159,6 +159,7 @@ def test_rollout_allgather_over_rccl_through_the_c_abi():
     te = (torch.rand((T, N), generator=g, device="cuda") < 0.2).to(torch.uint8)
     tr = (torch.rand((T, N), generator=g, device="cuda") < 0.1).to(torch.uint8)
     rg = RolloutGather((T, N, REC_BYTES), device="cuda:0", transport="rccl", rank=0, world=1)
+    assert rg.comm.count() == 1            # ncclCommCount through the C-ABI: what bench.py prints as `rccl_ranks`
     for _ in range(3):
         pack_records(obs, act, rew, te, tr, out=rg.local)
         rg.launch()

@@ -15,7 +15,7 @@ import math
 
 import numpy as np
 
-S_MAX = 256
+S_MAX = 512
 A_MAX = 64
 
 
@@ -59,7 +59,7 @@ BLK = 7          # next states per 128-byte block (include/xeno.h, "rows")
 
 def row_blocks(S):
     """Blocks per row record: ceil(S/7), rounded up to a multiple of G = ceil(blocks/16) — a fence entry names G whole
-    blocks, so the 16-entry fence line covers any S <= 256 (G = 1 up to S = 112, 2 up to 224, 3 beyond)."""
+    blocks, so the 16-entry fence line covers any S <= 512 (G = 1 up to S = 112, 2 up to 224, 3 up to 336, 4 up to 448, 5 beyond)."""
     nb = (S + BLK - 1) // BLK
     g = (nb + 15) // 16
     return (nb + g - 1) // g * g

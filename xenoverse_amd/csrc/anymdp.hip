@@ -46,17 +46,14 @@ struct AnyMDPArgs {
   const int32_t* s0_ids;
   const int32_t* max_steps;
   const int32_t* env_task;
-  // engine-owned per-env reset record (fast path), struct-of-arrays
-  const double2* rs_c01;     // s0_cdf[0], s0_cdf[1]   (padded with 1.0)
-  const double* rs_c2;       // s0_cdf[2]
-  const uint32_t* rs_ids;    // 4 x u8 inner state ids of s_0, padded with the last
-  const uint2* rs_obs;       // 4 x u16 observation ids of those states
-  const int32_t* rs_max_steps;   // bits 0..26 max_steps, bits 27..30 terminal flags of those four states
-  // engine-owned env state
-  int32_t* state;
-  int32_t* steps;
-  uint8_t* need_reset;
-  uint8_t* cur_term;         // current inner state is terminal (the reference raises when stepping from it, :95-96)
+  // engine-owned per-env reset record (fast path): three 16-byte units per env, one coalesced stream each
+  const double2* rs_a;       // s0_cdf[0], s0_cdf[1]   (padded with 1.0)
+  const uint4* rs_b;         // .xy = s0_cdf[2] (fp64 bits); .zw = 4 x u16 inner state ids of s_0, padded with the last
+  const uint4* rs_c;         // .xy = 4 x u16 observation ids of those states; .z = max_steps (bits 0..26) | terminal flags
+                             // of the four states (bits 27..30); .w = the env's task index
+  // engine-owned env state: ONE 8-byte record per env — .x = inner state (bits 0..15) | current state is terminal (bit 16:
+  // the reference raises when stepping from it, :95-96) | need_reset (bit 17); .y = steps
+  uint2* sr;
   uint32_t* err;
   int n_env, n_task, S, A, s0_max, words, NB, RL, G;   // RL = 1 + NB lines per row; G blocks per fence entry
   const uint4* bucket;   // [row][NBK] bucket lines (engine-owned, xv_anymdp_build_buckets); nullptr if not built
@@ -107,6 +104,16 @@ struct xv_anymdp {
   } graph_key;
 };
 
+#define XV_ANYMDP_SR_TERM 0x10000u
+#define XV_ANYMDP_SR_NR 0x20000u
+__device__ __forceinline__ uint2 anymdp_sr_pack(int s, int steps, int nr, int cterm) {
+  return make_uint2((uint32_t)s | (cterm ? XV_ANYMDP_SR_TERM : 0u) | (nr ? XV_ANYMDP_SR_NR : 0u), (uint32_t)steps);
+}
+
+__global__ void anymdp_init_sr_kernel(uint2* sr, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sr[i] = make_uint2(XV_ANYMDP_SR_NR, 0u);
+}
 __global__ void anymdp_set_tick_kernel(uint64_t* t, uint64_t v) { *t = v; }
 __global__ void anymdp_advance_tick_kernel(uint64_t* t, uint64_t dv) { *t += dv; }
 
@@ -142,8 +149,9 @@ __device__ __forceinline__ double xv_u2d(uint32_t lo, uint32_t hi) { return __hi
 
 // T_steps == 1: one vector step.  T_steps > 1: fused rollout, io arrays are [T][n_env], mode SAME_STEP.
 // FAST: fence line + block line, per-env reset record; otherwise per-lane binary search and per-task tables.
-// G: 0 = per-lane binary search and per-task tables; 1..3 = fence path, a fence entry names G consecutive blocks
-//    (G = 1 for S <= 112, 2 for S <= 224, 3 beyond: the fence always fits one line, the last level reads G lines).
+// G: 0 = per-lane binary search and per-task tables; 1..5 = fence path, a fence entry names G consecutive blocks
+//    (G = 1 for S <= 112, 2 for S <= 224, 3 for S <= 336, 4 for S <= 448, 5 up to 512: the fence always fits one line,
+//    the last level reads G lines).
 // TICKDEV: the launch tick is *P.tick_dev + P.tick (graph replay); otherwise P.tick (a kernel argument).
 // BK: bucket mode: the step's table line is named by (row, floor(u * NBK)); G only shapes the fence fall-back.
 template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false, bool BK = false>
@@ -158,29 +166,34 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
   const int g = lane >> 3, j = lane & 7;   // FAST: lanes 8g..8g+7 read unit j of a line together
   const int S = P.S, A = P.A;
 
-  // ---- link 1: per-env words (coalesced) ----
-  const int t = P.env_task[ic];
-  int s = P.state[ic];
-  int steps = P.steps[ic];
-  int nr = P.need_reset[ic];
-  int cterm = P.cur_term[ic];
+  // ---- link 1: per-env words (coalesced): the 8-byte env record, the action and (fast path) three 16-byte reset units ----
+  const uint2 sr0 = P.sr[ic];
+  int s = (int)(sr0.x & 0xFFFFu);
+  int steps = (int)sr0.y;
+  int nr = (sr0.x & XV_ANYMDP_SR_NR) ? 1 : 0;
+  int cterm = (sr0.x & XV_ANYMDP_SR_TERM) ? 1 : 0;
   int a_next = io.action ? io.action[ic] : 0;
   const uint64_t gid = P.gid_base + (uint64_t)ic;
   uint32_t err = 0;
 
   double2 rc01 = make_double2(1.0, 1.0);
   double rc2 = 1.0;
-  uint32_t rids = 0;
+  uint2 rids = make_uint2(0u, 0u);
   uint2 robs = make_uint2(0u, 0u);
-  int max_steps;
+  int max_steps, t;
   uint32_t s0_term = 0;
   uint64_t tm0 = 0;
   if (FAST) {
-    rc01 = P.rs_c01[ic]; rc2 = P.rs_c2[ic]; rids = P.rs_ids[ic]; robs = P.rs_obs[ic];
-    max_steps = P.rs_max_steps[ic];   // bits 0..26: max_steps, bits 27..30: terminal flags of the four s_0 states
-    s0_term = ((uint32_t)max_steps >> 27) & 0xFu;
-    max_steps &= 0x7FFFFFF;
+    rc01 = P.rs_a[ic];
+    const uint4 rb = P.rs_b[ic], rcu = P.rs_c[ic];
+    rc2 = xv_u2d(rb.x, rb.y);
+    rids = make_uint2(rb.z, rb.w);
+    robs = make_uint2(rcu.x, rcu.y);
+    s0_term = (rcu.z >> 27) & 0xFu;
+    max_steps = (int)(rcu.z & 0x7FFFFFFu);
+    t = (int)rcu.w;
   } else {
+    t = P.env_task[ic];
     max_steps = P.max_steps[t];
     tm0 = P.term_mask[(size_t)t * P.words];
   }
@@ -253,7 +266,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
         const uint4 b4 = bv[it];
         const uint32_t mw = sg < 2 ? b4.x : (sg < 4 ? b4.y : (sg < 6 ? b4.z : b4.w));
         // observation id, terminal flag of the chosen entry and the line's first next-state index, one word
-        const uint32_t packed = ((mw >> (16 * (sg & 1))) & 0xFFFFu) | (((b4.w >> (16 + sg)) & 1u) << 16) | ((b4.w >> 24) << 17);
+        const uint32_t packed = ((mw >> (16 * (sg & 1))) & 0xFFFFu) | (((b4.w >> (16 + sg)) & 1u) << 16) | ((b4.w >> 23) << 17);
         const int so = co < 6 ? co : 6;
         const float px = __shfl(__uint_as_float(b4.z), 8 * j + so);
         const float py = __shfl(__uint_as_float(b4.w), 8 * j + so);
@@ -293,58 +306,64 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       }
       const int NF = P.NB / GG;
       k_own = k_own < NF - 1 ? k_own : NF - 1;       // fences of absent groups hold 2.0: cannot exceed
-      // link 3: the GG block lines the fence entry names
+      // link 3: the GG block lines the fence entry names.  G <= 3 (S <= 336): all 8 x GG lines of the wave in flight together;
+      // G = 4, 5 (S <= 512): two batches of 4 env groups, so that the line registers stay at 80
       const uint32_t bl = fl + 1u + (uint32_t)k_own * GG;
       const bool pf = !BK;   // in bucket mode the next action was requested behind the bucket line already
-#pragma unroll
-      for (int it = 0; it < 8; ++it) li[it] = (uint32_t)__shfl((int)bl, it * 8 + g);
-      uint4 bv[8][GG];
-#pragma unroll
-      for (int it = 0; it < 8; ++it)
-#pragma unroll
-        for (int q = 0; q < GG; ++q) bv[it][q] = P.lines[((size_t)li[it] + q) * 8 + j];
-      if (pf && ROLLOUT && io.action && ts + 1 < T) a_next = io.action[o + P.n_env];   // prefetch behind the blocks
-      __builtin_amdgcn_sched_barrier(0);
+      constexpr int IB = GG > 3 ? 4 : 8;
       int cnt_own = 0;
       float rx = 0.0f, ry = 0.0f;
       uint32_t meta_own = 0;
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        // unit 7 of a block is its metadata, not an entry.  cg: the count of the env this lane group serves
-        // (reader side); co: the count of the env this lane owns, whose lines sit in lanes 8q..8q+7 (owner side)
-        int cg = 0, co = 0;
+      for (int b0 = 0; b0 < 8; b0 += IB) {
+        uint32_t lb[IB];
 #pragma unroll
-        for (int q = 0; q < GG; ++q) {
-          const unsigned long long m = __ballot(j < 7 && xv_u2d(bv[it][q].x, bv[it][q].y) <= ue[it]);
-          cg += __popc((unsigned)(m >> (8 * g)) & 0x7Fu);
-          co += __popc((unsigned)(m >> (8 * j)) & 0x7Fu);
-        }
-        // the metadata lane extracts the chosen entry's observation id and terminal flag: the owner needs ONE word
-        int lg = cg / XV_ANYMDP_BLK;
-        lg = lg < GG - 1 ? lg : GG - 1;
-        int sg = cg - XV_ANYMDP_BLK * lg;
-        sg = sg < 6 ? sg : 6;
-        uint32_t packed = 0;
+        for (int it = 0; it < IB; ++it) lb[it] = (uint32_t)__shfl((int)bl, (b0 + it) * 8 + g);
+        uint4 bv[IB][GG];
 #pragma unroll
-        for (int q = 0; q < GG; ++q) {
-          const uint4 b4 = bv[it][q];
-          const uint32_t mw = sg < 2 ? b4.x : (sg < 4 ? b4.y : (sg < 6 ? b4.z : b4.w));
-          const uint32_t pk = ((mw >> (16 * (sg & 1))) & 0xFFFFu) | (((b4.w >> (16 + sg)) & 1u) << 16);
-          if (q == lg) packed = pk;
-        }
-        int lo_ = co / XV_ANYMDP_BLK;
-        lo_ = lo_ < GG - 1 ? lo_ : GG - 1;
-        int so = co - XV_ANYMDP_BLK * lo_;
-        so = so < 6 ? so : 6;
-        float px = 0.0f, py = 0.0f;
+        for (int it = 0; it < IB; ++it)
 #pragma unroll
-        for (int q = 0; q < GG; ++q) {
-          const float x = __shfl(__uint_as_float(bv[it][q].z), 8 * j + so);
-          const float y = __shfl(__uint_as_float(bv[it][q].w), 8 * j + so);
-          if (q == lo_) { px = x; py = y; }
+          for (int q = 0; q < GG; ++q) bv[it][q] = P.lines[((size_t)lb[it] + q) * 8 + j];
+        if (b0 == 0 && pf && ROLLOUT && io.action && ts + 1 < T) a_next = io.action[o + P.n_env];   // prefetch behind the blocks
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < IB; ++it) {
+          // unit 7 of a block is its metadata, not an entry.  cg: the count of the env this lane group serves
+          // (reader side); co: the count of the env this lane owns, whose lines sit in lanes 8q..8q+7 (owner side)
+          int cg = 0, co = 0;
+#pragma unroll
+          for (int q = 0; q < GG; ++q) {
+            const unsigned long long m = __ballot(j < 7 && xv_u2d(bv[it][q].x, bv[it][q].y) <= ue[b0 + it]);
+            cg += __popc((unsigned)(m >> (8 * g)) & 0x7Fu);
+            co += __popc((unsigned)(m >> (8 * j)) & 0x7Fu);
+          }
+          // the metadata lane extracts the chosen entry's observation id and terminal flag: the owner needs ONE word
+          int lg = cg / XV_ANYMDP_BLK;
+          lg = lg < GG - 1 ? lg : GG - 1;
+          int sg = cg - XV_ANYMDP_BLK * lg;
+          sg = sg < 6 ? sg : 6;
+          uint32_t packed = 0;
+#pragma unroll
+          for (int q = 0; q < GG; ++q) {
+            const uint4 b4 = bv[it][q];
+            const uint32_t mw = sg < 2 ? b4.x : (sg < 4 ? b4.y : (sg < 6 ? b4.z : b4.w));
+            const uint32_t pk = ((mw >> (16 * (sg & 1))) & 0xFFFFu) | (((b4.w >> (16 + sg)) & 1u) << 16);
+            if (q == lg) packed = pk;
+          }
+          int lo_ = co / XV_ANYMDP_BLK;
+          lo_ = lo_ < GG - 1 ? lo_ : GG - 1;
+          int so = co - XV_ANYMDP_BLK * lo_;
+          so = so < 6 ? so : 6;
+          float px = 0.0f, py = 0.0f;
+#pragma unroll
+          for (int q = 0; q < GG; ++q) {
+            const float x = __shfl(__uint_as_float(bv[it][q].z), 8 * j + so);
+            const float y = __shfl(__uint_as_float(bv[it][q].w), 8 * j + so);
+            if (q == lo_) { px = x; py = y; }
+          }
+          const uint32_t pm = (uint32_t)__shfl((int)packed, 8 * j + 7);
+          if (g == b0 + it) { cnt_own = co; rx = px; ry = py; meta_own = pm; }
         }
-        const uint32_t pm = (uint32_t)__shfl((int)packed, 8 * j + 7);
-        if (g == it) { cnt_own = co; rx = px; ry = py; meta_own = pm; }
       }
       k_own *= GG;
       s2 = XV_ANYMDP_BLK * k_own + cnt_own;
@@ -405,7 +424,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       if (FAST) {
         // upper_bound over the 4 padded CDF entries; ids, terminal flags and observation ids come packed
         const int k0 = (int)(rc01.x <= u_reset) + (int)(rc01.y <= u_reset) + (int)(rc2 <= u_reset);
-        s = (int)((rids >> (8 * k0)) & 0xFFu);
+        s = (int)(((k0 < 2 ? rids.x : rids.y) >> (16 * (k0 & 1))) & 0xFFFFu);
         cterm = (int)((s0_term >> k0) & 1u);
         o_obs = (int)(((k0 < 2 ? robs.x : robs.y) >> (16 * (k0 & 1))) & 0xFFFFu);
       } else {
@@ -425,12 +444,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       if (io.final_obs) io.final_obs[o] = o_fobs;
     }
   }
-  if (valid) {
-    P.state[i] = s;
-    P.steps[i] = steps;
-    P.need_reset[i] = (uint8_t)nr;
-    P.cur_term[i] = (uint8_t)cterm;
-  }
+  if (valid) P.sr[i] = anymdp_sr_pack(s, steps, nr, cterm);
   if (err) atomicOr(P.err, err);
 }
 
@@ -477,7 +491,7 @@ __global__ __launch_bounds__(256) void anymdp_finish_rows_kernel(AnyMDPArgs P, u
 
 // Bucket lines (xv_anymdp_build_buckets): one wave per row, lane q and q + 64, ... each write one 16-byte unit.
 //   line (row, k), unit m < 7: the entry of next state I[k] + m (cdf 2.0 past the row), I[k] = #{cdf <= k / NBK}
-//   unit 7: the block metadata of those seven states (clamped to S - 1, as s' is) with I[k] in bits 24..31 of .w
+//   unit 7: the block metadata of those seven states (clamped to S - 1, as s' is) with I[k] in bits 23..31 of .w
 __global__ __launch_bounds__(256) void anymdp_build_buckets_kernel(AnyMDPArgs P, uint4* bucket, size_t row_base,
                                                                    size_t n_rows, int NBK) {
   const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -496,7 +510,7 @@ __global__ __launch_bounds__(256) void anymdp_build_buckets_kernel(AnyMDPArgs P,
       const double c = reinterpret_cast<const double*>(row + (size_t)(1 + jj / XV_ANYMDP_BLK) * 8 + (jj % XV_ANYMDP_BLK))[0];
       if (c <= thr) { lo += half + 1; n -= half + 1; } else n = half;
     }
-    const int I = lo < 255 ? lo : 255;
+    const int I = lo < 511 ? lo : 511;
     uint4 out;
     if (m < 7) {
       const int jn = I + m;
@@ -516,45 +530,56 @@ __global__ __launch_bounds__(256) void anymdp_build_buckets_kernel(AnyMDPArgs P,
         wd[e >> 1] |= ob << (16 * (e & 1));
         if ((P.term_mask[(size_t)t * P.words + (sn >> 6)] >> (sn & 63)) & 1ull) tb |= 1u << e;
       }
-      wd[3] |= (tb << 16) | ((uint32_t)I << 24);
+      wd[3] |= (tb << 16) | ((uint32_t)I << 23);   // 7 terminal bits at 16..22, the line's first next-state index at 23..31
       out = make_uint4(wd[0], wd[1], wd[2], wd[3]);
     }
     bucket[(r * (size_t)NBK + k) * 8 + m] = out;
   }
 }
 
-// per-env reset records (create time): the s_0 distribution of the env's task, ready for coalesced reads
-__global__ __launch_bounds__(256) void anymdp_env_records_kernel(AnyMDPArgs P, double2* c01, double* c2, uint32_t* ids,
-                                                                 uint2* obs, int32_t* max_steps) {
+// per-env reset records (create time): the s_0 distribution of the env's task, ready for coalesced 16-byte reads
+__global__ __launch_bounds__(256) void anymdp_env_records_kernel(AnyMDPArgs P, double2* ra, uint4* rb, uint4* rc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
   const int t = P.env_task[i];
   double c[4];
-  uint32_t idw = 0, tbits = 0, ob[4];
+  uint32_t tbits = 0, id[4], ob[4];
   for (int k = 0; k < 4; ++k) {
     const int kk = k < P.s0_max ? k : P.s0_max - 1;
     const int sid = P.s0_ids[(size_t)t * P.s0_max + kk];
     const uint32_t tb = (P.term_mask[(size_t)t * P.words + (sid >> 6)] >> (sid & 63)) & 1ull ? 1u : 0u;
-    idw |= ((uint32_t)sid & 0xFFu) << (8 * k);
+    id[k] = (uint32_t)sid & 0xFFFFu;
     tbits |= tb << k;
     ob[k] = (uint32_t)P.state_map[(size_t)t * P.S + sid] & 0xFFFFu;
     c[k] = k < P.s0_max ? P.s0_cdf[(size_t)t * P.s0_max + k] : 1.0;
   }
-  c01[i] = make_double2(c[0], c[1]);
-  c2[i] = c[2];
-  ids[i] = idw;
-  obs[i] = make_uint2(ob[0] | (ob[1] << 16), ob[2] | (ob[3] << 16));
-  max_steps[i] = (int32_t)(((uint32_t)P.max_steps[t] & 0x7FFFFFFu) | (tbits << 27));
+  ra[i] = make_double2(c[0], c[1]);
+  rb[i] = make_uint4((uint32_t)__double2loint(c[2]), (uint32_t)__double2hiint(c[2]), id[0] | (id[1] << 16), id[2] | (id[3] << 16));
+  rc[i] = make_uint4(ob[0] | (ob[1] << 16), ob[2] | (ob[3] << 16), ((uint32_t)P.max_steps[t] & 0x7FFFFFFu) | (tbits << 27),
+                     (uint32_t)t);
 }
 
-// cur_term[i] = (state[i] in s_e), after xv_anymdp_set_state
-__global__ __launch_bounds__(256) void anymdp_fix_term_kernel(AnyMDPArgs P) {
+// xv_anymdp_get_state / _set_state: the 8-byte env records <-> the caller's arrays (nullable each); the terminal flag of
+// a state set from outside is recomputed from term_mask
+__global__ __launch_bounds__(256) void anymdp_get_state_kernel(AnyMDPArgs P, int32_t* state, int32_t* steps, uint8_t* need_reset) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
-  const int t = P.env_task[i];
-  int s = P.state[i];
+  const uint2 r = P.sr[i];
+  if (state) state[i] = (int32_t)(r.x & 0xFFFFu);
+  if (steps) steps[i] = (int32_t)r.y;
+  if (need_reset) need_reset[i] = (r.x & XV_ANYMDP_SR_NR) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void anymdp_set_state_kernel(AnyMDPArgs P, const int32_t* state, const int32_t* steps,
+                                                               const uint8_t* need_reset) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n_env) return;
+  const uint2 r = P.sr[i];
+  int s = state ? state[i] : (int)(r.x & 0xFFFFu);
   s = s < 0 ? 0 : (s >= P.S ? P.S - 1 : s);
-  P.cur_term[i] = (uint8_t)((P.term_mask[(size_t)t * P.words + (s >> 6)] >> (s & 63)) & 1ull);
+  const int t = P.env_task[i];
+  const int cterm = state ? (int)((P.term_mask[(size_t)t * P.words + (s >> 6)] >> (s & 63)) & 1ull) : ((r.x & XV_ANYMDP_SR_TERM) ? 1 : 0);
+  const int nr = need_reset ? (need_reset[i] ? 1 : 0) : ((r.x & XV_ANYMDP_SR_NR) ? 1 : 0);
+  P.sr[i] = anymdp_sr_pack(s, steps ? steps[i] : (int)r.y, nr, cterm);
 }
 
 // largest observation id (decides whether ids fit the 16-bit block metadata)
@@ -578,10 +603,7 @@ __global__ __launch_bounds__(256) void anymdp_reset_kernel(AnyMDPArgs P, const u
     u = xv_u53(v.x, v.y);
   }
   const int s = anymdp_draw_s0(P, t, u);
-  P.state[i] = s;
-  P.steps[i] = 0;
-  P.need_reset[i] = 0;
-  P.cur_term[i] = (uint8_t)((P.term_mask[(size_t)t * P.words + (s >> 6)] >> (s & 63)) & 1ull);
+  P.sr[i] = anymdp_sr_pack(s, 0, 0, (int)((P.term_mask[(size_t)t * P.words + (s >> 6)] >> (s & 63)) & 1ull));
   if (obs) obs[i] = P.state_map[(size_t)t * P.S + s];
 }
 
@@ -591,7 +613,7 @@ __global__ __launch_bounds__(256) void anymdp_tgt_kernel(AnyMDPArgs P, const int
   const size_t total = (size_t)P.n_env * P.S;
   if (idx >= total) return;
   const int i = (int)(idx / P.S), j = (int)(idx % P.S);
-  const int t = P.env_task[i], s = P.state[i];
+  const int t = P.env_task[i], s = (int)(P.sr[i].x & 0xFFFFu);
   int a = action[i];
   a = a < 0 ? 0 : (a >= P.A ? P.A - 1 : a);
   const uint64_t tm0 = P.term_mask[(size_t)t * P.words];
@@ -663,7 +685,8 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_kernel(AnyMDPArgs P, AnyM
   const uint64_t gid = P.gid_base + (uint64_t)i;
   const uint64_t tm0 = P.term_mask[(size_t)t * P.words];
   const int max_steps = P.max_steps[t];
-  int s = P.state[i], steps = P.steps[i], nr = P.need_reset[i];
+  const uint2 sr0 = P.sr[i];
+  int s = (int)(sr0.x & 0xFFFFu), steps = (int)sr0.y, nr = (sr0.x & XV_ANYMDP_SR_NR) ? 1 : 0;
   uint32_t err = 0;
   if (io.final_obs) for (int k = 0; k < K.d_obs; ++k) io.final_obs[(size_t)i * K.d_obs + k] = -1;
   float rsum = 0.0f, rgsum = 0.0f;
@@ -703,7 +726,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_kernel(AnyMDPArgs P, AnyM
 #pragma unroll
         for (int q = 0; q < 7; ++q) cnt += xv_u2d(en[q].x, en[q].y) <= u ? 1 : 0;
         if (cnt < 7) {
-          lo = (int)(en[7].w >> 24) + cnt;
+          lo = (int)(en[7].w >> 23) + cnt;
 #pragma unroll
           for (int q = 0; q < 7; ++q)
             if (q == cnt) rsv = make_float2(__uint_as_float(en[q].z), __uint_as_float(en[q].w));
@@ -749,8 +772,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_kernel(AnyMDPArgs P, AnyM
     nr = 0;
     anymdp_tok_observe<INJECT, true>(P, K, io, i, t, s, gid, io.obs);
   }
-  P.state[i] = s; P.steps[i] = steps; P.need_reset[i] = (uint8_t)nr;
-  P.cur_term[i] = (uint8_t)(anymdp_is_term(P, t, tm0, s) ? 1 : 0);
+  P.sr[i] = anymdp_sr_pack(s, steps, nr, anymdp_is_term(P, t, tm0, s) ? 1 : 0);
   io.reward[i] = rsum; io.reward_gt[i] = rgsum;
   io.terminated[i] = (uint8_t)term; io.truncated[i] = (uint8_t)trunc;
   if (err) atomicOr(P.err, err);
@@ -771,8 +793,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_reset_kernel(AnyMDPArgs P, Any
     ur = xv_u53(v.x, v.y);
   }
   const int s = anymdp_draw_s0(P, t, ur);
-  P.state[i] = s; P.steps[i] = 0; P.need_reset[i] = 0;
-  P.cur_term[i] = (uint8_t)((P.term_mask[(size_t)t * P.words + (s >> 6)] >> (s & 63)) & 1ull);
+  P.sr[i] = anymdp_sr_pack(s, 0, 0, (int)((P.term_mask[(size_t)t * P.words + (s >> 6)] >> (s & 63)) & 1ull));
   if (io.obs) anymdp_tok_observe<INJECT, true>(P, K, io, i, t, s, gid, io.obs);
 }
 
@@ -904,7 +925,7 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
   *out = nullptr;
   XV_CHECK_ARG(e != nullptr);
   XV_CHECK_ARG(n_env > 0 && n_task > 0);
-  XV_CHECK_ARG(S >= 2 && S <= 256 && A >= 2 && A <= 64 && s0_max >= 1 && s0_max <= 256);
+  XV_CHECK_ARG(S >= 2 && S <= 512 && A >= 2 && A <= 64 && s0_max >= 1 && s0_max <= 256);
   XV_CHECK_ARG(rows && state_map && term_mask && s0_cdf && s0_ids && max_steps && env_task);
   // blocks per row: ceil(S/7), rounded up to a multiple of G = ceil(blocks/16) so that a fence entry always names
   // G whole blocks (XV_ANYMDP_ROW_LINES)
@@ -934,7 +955,7 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
   a.seed = e->seed; a.gid_base = e->env_id_base; a.tick = 0;
 
   // the fast path needs s0_max <= 4, observation ids that fit 16 bits and max_steps < 2^27 (checked below)
-  bool fast = (G <= 3 && s0_max <= 4);
+  bool fast = (G <= 5 && s0_max <= 4);
   // largest entry of a device int array; every exit path releases the scratch word (the handle is released by the caller
   // of the lambda: nothing else has been allocated yet)
   auto device_max = [&](const int32_t* p, size_t n, int* out_max) -> hipError_t {
@@ -967,24 +988,17 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
     }
   }
 
-  double2* c01 = nullptr; double* c2 = nullptr; uint32_t* ids = nullptr; uint2* robs = nullptr; int32_t* rms = nullptr;
+  double2* ra = nullptr; uint4* rb = nullptr; uint4* rc = nullptr;
   const size_t n_rows = (size_t)n_task * S * A, ne = (size_t)n_env;
-  hipError_t m = hipMalloc(&a.state, sizeof(int32_t) * ne);
-  if (m == hipSuccess) m = hipMalloc(&a.steps, sizeof(int32_t) * ne);
-  if (m == hipSuccess) m = hipMalloc(&a.need_reset, ne);
-  if (m == hipSuccess) m = hipMalloc(&a.cur_term, ne);
-  if (m == hipSuccess && fast) m = hipMalloc(&c01, sizeof(double2) * ne);
-  if (m == hipSuccess && fast) m = hipMalloc(&c2, sizeof(double) * ne);
-  if (m == hipSuccess && fast) m = hipMalloc(&ids, sizeof(uint32_t) * ne);
-  if (m == hipSuccess && fast) m = hipMalloc(&robs, sizeof(uint2) * ne);
-  if (m == hipSuccess && fast) m = hipMalloc(&rms, sizeof(int32_t) * ne);
-  if (m == hipSuccess) m = hipMemsetAsync(a.state, 0, sizeof(int32_t) * ne, e->stream);
-  if (m == hipSuccess) m = hipMemsetAsync(a.steps, 0, sizeof(int32_t) * ne, e->stream);
-  if (m == hipSuccess) m = hipMemsetAsync(a.need_reset, 1, ne, e->stream);
-  if (m == hipSuccess) m = hipMemsetAsync(a.cur_term, 0, ne, e->stream);
+  hipError_t m = hipMalloc(&a.sr, sizeof(uint2) * ne);
+  if (m == hipSuccess && fast) m = hipMalloc(&ra, sizeof(double2) * ne);
+  if (m == hipSuccess && fast) m = hipMalloc(&rb, sizeof(uint4) * ne);
+  if (m == hipSuccess && fast) m = hipMalloc(&rc, sizeof(uint4) * ne);
+  if (m == hipSuccess)   // state 0, steps 0, need_reset
+    hipLaunchKernelGGL(anymdp_init_sr_kernel, dim3(xv_div_up(n_env, 256)), dim3(256), 0, e->stream, a.sr, n_env);
   if (m != hipSuccess) {
     xv_set_error("xv_anymdp_create: device allocation failed: %s", hipGetErrorString(m));
-    void* ps[] = {a.state, a.steps, a.need_reset, a.cur_term, c01, c2, ids, robs, rms};
+    void* ps[] = {a.sr, ra, rb, rc};
     for (void* q : ps) if (q) (void)hipFree(q);
     delete h;
     return XV_ERR_HIP;
@@ -996,9 +1010,8 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
       hipLaunchKernelGGL(anymdp_finish_rows_kernel, dim3((unsigned)((nr * 64 + 255) / 256)), dim3(256), 0, e->stream, a,
                          (uint4*)rows, r0, nr);
     }
-    hipLaunchKernelGGL(anymdp_env_records_kernel, dim3(xv_div_up(n_env, 256)), dim3(256), 0, e->stream, a, c01, c2, ids,
-                       robs, rms);
-    a.rs_c01 = c01; a.rs_c2 = c2; a.rs_ids = ids; a.rs_obs = robs; a.rs_max_steps = rms;
+    hipLaunchKernelGGL(anymdp_env_records_kernel, dim3(xv_div_up(n_env, 256)), dim3(256), 0, e->stream, a, ra, rb, rc);
+    a.rs_a = ra; a.rs_b = rb; a.rs_c = rc;
     h->fast = true;
   }
   XV_LAUNCH_CHECK();
@@ -1011,8 +1024,7 @@ extern "C" int xv_anymdp_destroy(xv_anymdp* h) {
   (void)hipSetDevice(h->eng->device);
   (void)hipStreamSynchronize(h->eng->stream);
   AnyMDPArgs& a = h->a;
-  void* ps[] = {a.state, a.steps, a.need_reset, a.cur_term, (void*)a.rs_c01, (void*)a.rs_c2, (void*)a.rs_ids,
-                (void*)a.rs_obs, (void*)a.rs_max_steps};
+  void* ps[] = {a.sr, (void*)a.rs_a, (void*)a.rs_b, (void*)a.rs_c};
   for (void* q : ps) if (q) (void)hipFree(q);
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   if (h->graph) (void)hipGraphDestroy(h->graph);
@@ -1062,12 +1074,16 @@ static int anymdp_launch_step(xv_anymdp* h, const AnyMDPStepIO& io, int T, int m
   } while (0)
     if (h->a.G == 1) XV_LAUNCH_BK(1);
     else if (h->a.G == 2) XV_LAUNCH_BK(2);
-    else XV_LAUNCH_BK(3);
+    else if (h->a.G == 3) XV_LAUNCH_BK(3);
+    else if (h->a.G == 4) XV_LAUNCH_BK(4);
+    else XV_LAUNCH_BK(5);
 #undef XV_LAUNCH_BK
   } else if (h->fast && h->search != XV_ANYMDP_SEARCH_BINARY) {
     if (h->a.G == 1) XV_LAUNCH_STEP_G(1);
     else if (h->a.G == 2) XV_LAUNCH_STEP_G(2);
-    else XV_LAUNCH_STEP_G(3);
+    else if (h->a.G == 3) XV_LAUNCH_STEP_G(3);
+    else if (h->a.G == 4) XV_LAUNCH_STEP_G(4);
+    else XV_LAUNCH_STEP_G(5);
   } else {
     XV_LAUNCH_STEP_G(0);
   }
@@ -1117,13 +1133,14 @@ static bool anymdp_ensure_graph(xv_anymdp* h, int period, const int32_t* actions
   const size_t n = (size_t)h->a.n_env;
   const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
   const bool bk = h->search == XV_ANYMDP_SEARCH_BUCKET && h->a.bucket != nullptr;
-  void* fn = bk ? (h->a.G == 1 ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 1, false, true, true>)
-                   : h->a.G == 2 ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 2, false, true, true>)
-                                 : reinterpret_cast<void*>(&anymdp_step_kernel<false, 3, false, true, true>))
-             : !fast ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 0, false, true>)
-             : h->a.G == 1 ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 1, false, true>)
-             : h->a.G == 2 ? reinterpret_cast<void*>(&anymdp_step_kernel<false, 2, false, true>)
-                           : reinterpret_cast<void*>(&anymdp_step_kernel<false, 3, false, true>);
+#define XV_STEP_FN(GV, BKV) reinterpret_cast<void*>(&anymdp_step_kernel<false, GV, false, true, BKV>)
+  const int Gv = h->a.G;
+  void* fn = bk ? (Gv == 1 ? XV_STEP_FN(1, true) : Gv == 2 ? XV_STEP_FN(2, true) : Gv == 3 ? XV_STEP_FN(3, true)
+                   : Gv == 4 ? XV_STEP_FN(4, true) : XV_STEP_FN(5, true))
+             : !fast ? XV_STEP_FN(0, false)
+             : (Gv == 1 ? XV_STEP_FN(1, false) : Gv == 2 ? XV_STEP_FN(2, false) : Gv == 3 ? XV_STEP_FN(3, false)
+                : Gv == 4 ? XV_STEP_FN(4, false) : XV_STEP_FN(5, false));
+#undef XV_STEP_FN
   hipGraphNode_t prev = nullptr;
   for (int j = 0; j <= period; ++j) {
     hipKernelNodeParams np;
@@ -1334,24 +1351,18 @@ extern "C" int xv_anymdp_build_buckets(xv_anymdp* h, int n_bucket) {
 
 extern "C" int xv_anymdp_get_state(xv_anymdp* h, int32_t* inner_state, int32_t* steps, uint8_t* need_reset) {
   XV_CHECK_ARG(h != nullptr);
-  const size_t n = (size_t)h->a.n_env;
-  if (inner_state) XV_HIP(hipMemcpyAsync(inner_state, h->a.state, n * 4, hipMemcpyDeviceToDevice, h->eng->stream));
-  if (steps) XV_HIP(hipMemcpyAsync(steps, h->a.steps, n * 4, hipMemcpyDeviceToDevice, h->eng->stream));
-  if (need_reset) XV_HIP(hipMemcpyAsync(need_reset, h->a.need_reset, n, hipMemcpyDeviceToDevice, h->eng->stream));
+  hipLaunchKernelGGL(anymdp_get_state_kernel, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream, h->a,
+                     inner_state, steps, need_reset);
+  XV_LAUNCH_CHECK();
   return XV_OK;
 }
 
 extern "C" int xv_anymdp_set_state(xv_anymdp* h, const int32_t* inner_state, const int32_t* steps,
                                    const uint8_t* need_reset) {
   XV_CHECK_ARG(h != nullptr);
-  const size_t n = (size_t)h->a.n_env;
-  if (inner_state) XV_HIP(hipMemcpyAsync(h->a.state, inner_state, n * 4, hipMemcpyDeviceToDevice, h->eng->stream));
-  if (steps) XV_HIP(hipMemcpyAsync(h->a.steps, steps, n * 4, hipMemcpyDeviceToDevice, h->eng->stream));
-  if (need_reset) XV_HIP(hipMemcpyAsync(h->a.need_reset, need_reset, n, hipMemcpyDeviceToDevice, h->eng->stream));
-  if (inner_state) {
-    hipLaunchKernelGGL(anymdp_fix_term_kernel, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream, h->a);
-    XV_LAUNCH_CHECK();
-  }
+  hipLaunchKernelGGL(anymdp_set_state_kernel, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream, h->a,
+                     inner_state, steps, need_reset);
+  XV_LAUNCH_CHECK();
   return XV_OK;
 }
 

@@ -263,7 +263,7 @@ __device__ __forceinline__ void linds_observe(const LinDSArgs& P, int tu, const 
 // are combined as (p0 + p1) + (p2 + p3), which is what two xor-shuffles (16, 32) produce in every lane.  Oracle and
 // scalar kernel use the same order (xeno_oracle.c: linds_err, linds_sumsq).
 template <int NO>
-__device__ __forceinline__ float linds_err(const LinDSArgs& P, int tu, const float (&y)[NO], const float (&c)[NO]) {
+__device__ __forceinline__ float linds_errsq(const LinDSArgs& P, int tu, const float (&y)[NO], const float (&c)[NO]) {
   const XV_CONST_AS float* valid = xv_cptr(P.T.valid) + (size_t)tu * NO;
   float p[4];
 #pragma unroll
@@ -279,7 +279,7 @@ __device__ __forceinline__ float linds_err(const LinDSArgs& P, int tu, const flo
       }
     p[g] = acc;
   }
-  return sqrtf((p[0] + p[1]) + (p[2] + p[3]));
+  return (p[0] + p[1]) + (p[2] + p[3]);
 }
 template <int NO>
 __device__ __forceinline__ float linds_sumsq(const float (&y)[NO]) {
@@ -346,7 +346,7 @@ __device__ __forceinline__ void linds_reset_env(const LinDSArgs& P, int tu, int 
     return;
   }
   linds_observe<NS, NO>(P, tu, xs, y);
-  err = linds_err<NO>(P, tu, y, c);
+  err = __builtin_amdgcn_sqrtf(linds_errsq<NO>(P, tu, y, c));   // v_sqrt_f32 everywhere on the device (1 ulp of sqrtf)
 }
 
 // builds rst_tab with the functions above (same code, same bits as evaluating at reset time)
@@ -521,9 +521,10 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
         float ctrack[NO];
         linds_cmd_at<NO>(P, tu, nf, steps - 1 - delay, ctrack);   // :150-151 tracked command
         linds_cmd_at<NO>(P, tu, nf, steps, crep);                 // :168 reported command
-        o_err = linds_err<NO>(P, tu, y, ctrack);               // :153
-        const float obs_scale = sqrtf(linds_sumsq<NO>(y));     // :154
-        o_term = ((o_err > 10.0f) || (obs_scale > 20.0f)) ? 1 : 0;   // :156
+        const float s_err = linds_errsq<NO>(P, tu, y, ctrack);   // :153
+        o_err = __builtin_amdgcn_sqrtf(s_err);
+        // :154, :156 on the squares (see the matrix kernel): sqrtf(s) > c  <=>  s > nextafterf(c * c)
+        o_term = ((s_err > 100.00000762939453125f) || (linds_sumsq<NO>(y) > 400.000030517578125f)) ? 1 : 0;
         o_r = o_term ? -sc[2] : 0.0f;                          // :158-161
         float tmp = fmaf(-sc[3], o_err, sc[1]);
         tmp = fmaf(-sc[0], sa, tmp);
@@ -869,10 +870,14 @@ struct LinDSTileStep {
         pe = fmaf(d, d, pe);
         ps = fmaf(ym[mo][r], ym[mo][r], ps);
       }
-    float o_err = sqrtf(linds_quad_sum(pe));
-    const float obs_scale = sqrtf(linds_quad_sum(ps));
+    // error > 10 or obs_scale > 20 (:156) decided on the SQUARES: for a correctly rounded square root sqrtf(s) > c holds
+    // exactly when s > nextafterf(c * c) (checked over +-5e6 floats around 100 and 400), so the flag does not depend on
+    // which square root is used: the observation scale needs none, and the error output takes the one-instruction
+    // v_sqrt_f32 (1 ulp; the oracle uses sqrtf — the flags agree exactly, the error to 1 ulp)
+    const float s_err = linds_quad_sum(pe), s_obs = linds_quad_sum(ps);
+    float o_err = __builtin_amdgcn_sqrtf(s_err);
     const float sa = linds_quad_sum(psa);
-    int o_term = ((o_err > 10.0f) || (obs_scale > 20.0f)) ? 1 : 0;   // :156
+    int o_term = ((s_err > 100.00000762939453125f) || (s_obs > 400.000030517578125f)) ? 1 : 0;   // :156
     float o_r = o_term ? -sc[2] : 0.0f;                         // :158-161
     float tmp = fmaf(-sc[3], o_err, sc[1]);
     tmp = fmaf(-sc[0], sa, tmp);
@@ -898,11 +903,11 @@ struct LinDSTileStep {
       int idx = INJECT ? init_inj : linds_init_from_word(linds_bcast_row0(rword), n_init);
       idx = idx < 0 ? 0 : (idx >= n_init ? n_init - 1 : idx);
       const float* x0 = P.T.init + ((size_t)t * P.NI + idx) * NS + 4 * g;
-      xv_f32x4 xr[MT];
+      xv_f32x4 xr[MT];   // every lane reads the initial state its restart word names; only restarting envs keep it
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const float4 v = *reinterpret_cast<const float4*>(x0 + 16 * m);   // :117
-        xr[m] = do_reset ? xv_f32x4{v.x, v.y, v.z, v.w} : xn[m];
+        xr[m] = xv_f32x4{v.x, v.y, v.z, v.w};
       }
       float c0[MO][4];   // :120-126: the last pre-filled command is cmd(0)
       const int z_idx = 0 - P.ct_tmin;
@@ -946,7 +951,7 @@ struct LinDSTileStep {
             const float d = (yr[mo][r] - c0[mo][r]) * fr.vld[mo][r];
             pr0 = fmaf(d, d, pr0);
           }
-        e0 = sqrtf(linds_quad_sum(pr0));
+        e0 = __builtin_amdgcn_sqrtf(linds_quad_sum(pr0));
       }
       if (do_reset) {
 #pragma unroll

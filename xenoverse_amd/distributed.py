@@ -117,6 +117,14 @@ class RcclComm(object):
         assert out.numel() * out.element_size() == nbytes * self.world
         _lib.check(self.lib.xv_rollout_allgather(self.engine.handle, self.handle, _lib.ptr(local), _lib.ptr(out), nbytes))
 
+    def count(self):
+        """ncclCommCount: the number of ranks the communicator really spans"""
+        import ctypes as C
+        from . import _lib
+        n = C.c_int(0)
+        _lib.check(self.lib.xv_rccl_comm_count(self.handle, C.byref(n)))
+        return int(n.value)
+
     def close(self):
         if getattr(self, "handle", None) is not None:
             self.lib.xv_rccl_comm_destroy(self.handle)
