@@ -203,23 +203,37 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
   for (int ts = 0; ts < T; ++ts) {
     const size_t o = (size_t)ts * P.n_env + ic;
 
-    // random inputs first: pure ALU, overlaps the latency of link 1
-    double u, u_reset;
-    float z;
+    // the transition uniform first: pure ALU under the latency of link 1, and the only draw the table address waits for.
+    // The reward normal and the restart uniform (a second Philox call) are made by late_draws() AFTER the step's table
+    // line has been requested, under its latency — one wave per SIMD runs here, so every instruction in front of that
+    // request is exposed (round 3: the compiler had placed both calls in front of it)
+    double u, u_reset = 0.0;
+    float z = 0.0f;
+    xv_u32x4 w{0u, 0u, 0u, 0u};
     if (INJECT) {
       u = io.u[o];
-      z = io.z[o];
-      u_reset = io.u_reset[o];
     } else {
-      const xv_u32x4 w = xv_env_draw(P.seed, gid, tick0 + (uint64_t)ts, XV_DRAW_STEP);
+      w = xv_env_draw(P.seed, gid, tick0 + (uint64_t)ts, XV_DRAW_STEP);
       u = xv_u53(w.x, w.y);
-      z = xv_normal1(w.z, w.w);
-      const xv_u32x4 v = xv_env_draw(P.seed, gid, tick0 + (uint64_t)ts, XV_DRAW_RESET);
-      u_reset = xv_u53(v.x, v.y);
     }
+    auto late_draws = [&]() {
+      if (INJECT) {
+        z = io.z[o];
+        u_reset = io.u_reset[o];
+      } else {
+        z = xv_normal1(w.z, w.w);
+        const xv_u32x4 v = xv_env_draw(P.seed, gid, tick0 + (uint64_t)ts, XV_DRAW_RESET);
+        u_reset = xv_u53(v.x, v.y);
+        // pinned where late_draws() is called: without this hipcc's IR-level sinking moves both chains down to their
+        // first use, behind the whole search, where nothing hides them
+        int ulo = __double2loint(u_reset), uhi = __double2hiint(u_reset);
+        asm volatile("" : "+v"(z), "+v"(ulo), "+v"(uhi));
+        u_reset = __hiloint2double(uhi, ulo);
+      }
+    };
 
     int a = a_next;
-    if (io.greedy) {   // teacher policy: argmax_a Q[inner_state] (anymdp_solver_opt.py:38-51), epsilon-greedy
+    if (ROLLOUT && io.greedy) {   // teacher policy: argmax_a Q[inner_state] (anymdp_solver_opt.py:38-51), epsilon-greedy
       a = io.greedy[(size_t)t * S + s];
       if (io.epsilon > 0.0f) {
         const xv_u32x4 e = xv_env_draw(P.seed, gid, tick0 + (uint64_t)ts, 2u);
@@ -249,6 +263,8 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
 #pragma unroll
       for (int it = 0; it < 8; ++it) bv[it] = P.bucket[(size_t)li[it] * 8 + j];
       if (ROLLOUT && io.action && ts + 1 < T) a_next = io.action[o + P.n_env];   // prefetch behind the line
+      __builtin_amdgcn_sched_barrier(0);
+      late_draws();
       __builtin_amdgcn_sched_barrier(0);
       double ue[8];
 #pragma unroll
@@ -290,6 +306,10 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
 #pragma unroll
       for (int it = 0; it < 8; ++it) fv[it] = P.lines[(size_t)li[it] * 8 + j];
       __builtin_amdgcn_sched_barrier(0);
+      if (!BK) {
+        late_draws();
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // while the loads fly: each env's uniform goes to the 8 lanes that hold its lines
       double ue[8];
 #pragma unroll
@@ -372,6 +392,7 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
       obs2 = (int)(meta_own & 0xFFFFu);
       term2 = (meta_own >> 16) & 1u;
     } else if (!FAST) {
+      late_draws();
       int lo = 0, n = S;
       while (n > 0) {
         const int half = n >> 1;
