@@ -515,6 +515,32 @@ def gen_maze_sampled(n_tasks=24, seed0=10):
     print("sampler_refmazes.npz", os.path.getsize(path) // 1024, "KiB")
 
 
+def gen_maze_refcounts(seeds=(0, 1, 2, 3, 40, 41)):
+    """Tasks of the reference's MazeTaskSampler with ITS OWN texture folder behind it (37 / 29 / 21 images; only the
+    folder's sizes enter a task — texture ids are drawn below them): what `MazeTaskSampler(seed=k)` must return with
+    its default library sizes.  Arrays only; no image is read into the fixture."""
+    Maze, mts, dyn, rc = _refimport.mazeworld()
+    M = mts.MAZE_TASK_MANAGER
+    counts = [int(len(M.textlib_walls)), int(len(M.textlib_grounds)), int(len(M.textlib_ceilings))]
+    out = {k: [] for k in ("seed", "n", "cell_walls", "cell_texts", "cell_landmarks", "start", "commands", "landmarks",
+                           "n_landmarks", "scalars")}
+    for seed in seeds:
+        t = mts.MazeTaskSampler(seed=seed, commands_sequence=32, verbose=False)
+        n = t["cell_walls"].shape[0]
+        pad = lambda a: np.pad(np.asarray(a), ((0, 25 - n), (0, 25 - n)))
+        lm = np.zeros((15, 2), np.int64); lm[:len(t["landmarks_coordinates"])] = np.asarray(t["landmarks_coordinates"])
+        out["seed"].append(seed); out["n"].append(n)
+        out["cell_walls"].append(pad(t["cell_walls"])); out["cell_texts"].append(pad(t["cell_texts"]))
+        out["cell_landmarks"].append(pad(t["cell_landmarks"])); out["start"].append(np.asarray(t["start"]))
+        out["commands"].append(np.asarray(t["commands_sequence"])); out["landmarks"].append(lm)
+        out["n_landmarks"].append(len(t["landmarks_coordinates"]))
+        out["scalars"].append([t["cell_size"], t["wall_height"], t["agent_height"], t["fol_angle"], t["goal_reward"],
+                               t["ground_text"], t["ceiling_text"]])
+    path = os.path.join(GOLD, "sampler_refmazes_refcounts.npz")
+    np.savez_compressed(path, counts=np.asarray(counts), **{k: np.asarray(v) for k, v in out.items()})
+    print("sampler_refmazes_refcounts.npz", os.path.getsize(path) // 1024, "KiB", counts)
+
+
 def gen_linds_sampled():
     """Tasks of the reference's LinearDSSampler with its seeding function pinned: the reference seeds NumPy with
     timestamp + system random + seed (utils/random_nn.py:9-16, non-reproducible), so for the fixture pseudo_random_seed
@@ -684,7 +710,7 @@ def gen_anymdp_sampled(n=32, seed0=100):
 
 FAMILIES = {"anymdp": gen_anymdp, "linds": gen_linds, "maze": gen_maze, "acrobot": gen_acrobot, "garnet": gen_garnet,
             "anymdp_vi": gen_anymdp_vi, "anymdp_sampled": gen_anymdp_sampled, "maze_sampled": gen_maze_sampled,
-            "linds_sampled": gen_linds_sampled, "maze_agent": gen_maze_agent}
+            "linds_sampled": gen_linds_sampled, "maze_agent": gen_maze_agent, "maze_refcounts": gen_maze_refcounts}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

@@ -54,8 +54,11 @@ def test_golden_trajectory(path):
     env.close()
 
 
+@pytest.mark.parametrize("search", ["fence", "bucket"])
 @pytest.mark.parametrize("mode", ["disabled", "next_step", "same_step"])
-def test_batch_vs_oracle_injected_and_free_running(mode):
+def test_batch_vs_oracle_injected_and_free_running(mode, search):
+    """reference-sampled multi-token tasks; search = bucket runs the cooperative kernel (transition and observation
+    bucket lines), fence the per-lane one"""
     tasks = [load_anymdp_tok_golden(p)[1] for p in FILES if "mtpomdp" in p]
     tab = build_tables(tasks)
     obs_cdf, n_obs, d_obs, d_act = build_obs_tables(tasks, tab["S"])
@@ -64,6 +67,7 @@ def test_batch_vs_oracle_injected_and_free_running(mode):
     seed, base = 77, 1000
     env = AnyMDPVecEnv(n, autoreset_mode=mode, seed=seed, env_id_base=base)
     env.set_task(tasks, env_task_index=env_task)
+    env.set_search(search, n_bucket=16) if search == "bucket" else env.set_search(search)
     ora = oracle.AnyMDPTokOracle(tab, env_task, obs_cdf, d_act)
     tick = env.engine.tick
     o0, _ = env.reset()
@@ -99,7 +103,8 @@ def test_batch_vs_oracle_injected_and_free_running(mode):
 
 
 @pytest.mark.parametrize("n_obs,d_obs,d_act,search", [(64, 3, 2, "fence"), (22, 2, 3, "fence"), (15, 2, 2, "fence"),
-                                                     (64, 3, 2, "binary"), (64, 3, 2, "bucket"), (22, 2, 3, "bucket")])
+                                                     (64, 3, 2, "binary"), (64, 3, 2, "bucket"), (22, 2, 3, "bucket"),
+                                                     (15, 1, 1, "bucket"), (200, 2, 2, "bucket")])
 def test_synthetic_observation_models_vs_oracle(n_obs, d_obs, d_act, search):
     """S=64, A=8 synthetic tasks with random observation models of several shapes (n_obs 64 / 22 / 15, up to 3
     tokens) against the oracle: injected draws incl. exact CDF entries, all three auto-reset modes in turn"""

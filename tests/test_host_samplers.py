@@ -1,4 +1,6 @@
 """Host task samplers (CPU): the reference's dict schemas and invariants; tasks flow through the table builders."""
+import os
+
 import numpy as np
 import pytest
 
@@ -359,3 +361,65 @@ def test_vi_summation_orders():
     assert np.allclose(ref, got, rtol=0, atol=1e-9)
     with pytest.raises(KeyError):
         set_vi_summation("other")
+
+
+def test_maze_sampler_defaults_are_the_reference_texture_counts():
+    """tests/golden/sampler_refmazes_refcounts.npz: tasks of the reference's MazeTaskSampler sampled with ITS OWN texture
+    folder behind it (37 wall / 29 ground / 21 ceiling images — only the counts enter a task).  MazeTaskSampler(seed=k)
+    with its default library sizes returns the same task, all keys."""
+    import os
+    from util import GOLD
+    from xenoverse_amd.mazeworld import REFERENCE_TEXTURE_COUNTS
+    g = np.load(os.path.join(GOLD, "sampler_refmazes_refcounts.npz"))
+    assert tuple(int(c) for c in g["counts"]) == REFERENCE_TEXTURE_COUNTS == (37, 29, 21)
+    big_ids = 0
+    for k, seed in enumerate(g["seed"]):
+        t = MazeTaskSampler(seed=int(seed), commands_sequence=32)
+        n = int(g["n"][k])
+        assert t["cell_walls"].shape == (n, n) and np.array_equal(t["cell_walls"], g["cell_walls"][k][:n, :n]), seed
+        assert np.array_equal(t["cell_texts"], g["cell_texts"][k][:n, :n]), seed
+        assert np.array_equal(t["cell_landmarks"], g["cell_landmarks"][k][:n, :n])
+        assert tuple(t["start"]) == tuple(g["start"][k]) and np.array_equal(t["commands_sequence"], g["commands"][k])
+        nl = int(g["n_landmarks"][k])
+        assert [tuple(x) for x in t["landmarks_coordinates"]] == [tuple(x) for x in g["landmarks"][k][:nl]]
+        sc = [t["cell_size"], t["wall_height"], t["agent_height"], t["fol_angle"], t["goal_reward"], t["ground_text"], t["ceiling_text"]]
+        assert np.array_equal(np.asarray(sc, np.float64), g["scalars"][k])
+        big_ids += int(t["cell_texts"].max() >= 8)
+    assert big_ids == len(g["seed"])          # texture ids beyond the old 8-texture default really occur
+    # and the default procedural library holds them: what MazeWorldVecEnv.set_task checks before uploading
+    from xenoverse_amd.mazeworld.textures import texture_counts
+    assert texture_counts(dict(walls=np.zeros((37, 1)), grounds=np.zeros((29, 1)), ceilings=np.zeros((21, 1)))) == (37, 29, 21)
+
+
+def test_load_texture_library_reads_a_folder_like_the_reference(tmp_path):
+    """load_texture_library: sorted file order, wall* / ground* / ceiling* prefixes, everything else ignored, RGB decoded
+    and handed out with pygame.surfarray.array3d's (W, H, 3) axes as float32 (task_sampler.py:60-77)"""
+    from PIL import Image
+    from xenoverse_amd.mazeworld import load_texture_library, texture_counts
+    rng = np.random.RandomState(0)
+    W, H = 24, 16
+    imgs = {}
+    for name in ("wall_b.png", "wall_a.png", "ground_1.png", "ceiling_z.png", "ceiling_y.png", "ceiling_x.png",
+                 "notes.txt", "mywall.png"):
+        if name.endswith(".txt"):
+            (tmp_path / name).write_text("not an image")
+            continue
+        a = rng.randint(0, 256, (H, W, 3)).astype(np.uint8)        # PIL's (H, W, 3)
+        Image.fromarray(a).save(tmp_path / name)
+        imgs[name] = a
+    Image.fromarray(rng.randint(0, 256, (H, W)).astype(np.uint8), mode="L").save(tmp_path / "ground_0_gray.png")
+    lib = load_texture_library(str(tmp_path))
+    assert texture_counts(lib) == (2, 2, 3)
+    assert lib["walls"].dtype == np.float32 and lib["walls"].shape == (2, W, H, 3)
+    assert np.array_equal(lib["walls"][0], imgs["wall_a.png"].transpose(1, 0, 2))         # sorted: a before b
+    assert np.array_equal(lib["walls"][1], imgs["wall_b.png"].transpose(1, 0, 2))
+    assert np.array_equal(lib["ceilings"][2], imgs["ceiling_z.png"].transpose(1, 0, 2))
+    assert np.array_equal(lib["grounds"][1], imgs["ground_1.png"].transpose(1, 0, 2))
+    gray = lib["grounds"][0]                                        # a grey-scale file is converted to RGB
+    assert np.array_equal(gray[..., 0], gray[..., 1]) and np.array_equal(gray[..., 1], gray[..., 2])
+    (tmp_path / "sub").mkdir()
+    with pytest.raises(ValueError, match="no wall"):
+        load_texture_library(str(tmp_path / "sub"))
+    ref_dir = "/root/reference/xenoverse/mazeworld/envs/img"
+    if os.path.isdir(ref_dir):                                      # build container only: the reference's own folder
+        assert texture_counts(load_texture_library(ref_dir)) == (37, 29, 21)

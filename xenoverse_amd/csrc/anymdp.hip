@@ -87,6 +87,7 @@ struct xv_anymdp {
   uint4* bucket_rw;   // owned: the bucket lines
   const double* obs_cdf;   // observation model (POMDP / MTPOMDP), nullptr for MDP
   int n_obs, d_obs, d_act;
+  uint4* obs_bucket;       // owned: observation bucket lines (built with the transition bucket lines)
   // xv_anymdp_step_many: one ring cycle (period launches + a tick update) as an instantiated hipGraph
   int graph_mode;            // 0 off, 1 on, 2 auto: on for n_env <= XV_ANYMDP_GRAPH_AUTO_MAX
   bool graph_failed;
@@ -652,6 +653,7 @@ __global__ __launch_bounds__(256) void anymdp_tgt_kernel(AnyMDPArgs P, const int
 struct AnyMDPTokArgs {
   const double* obs_cdf;   // [n_task][d_obs][S][n_obs]
   int n_obs, d_obs, d_act;
+  const uint4* obs_bucket; // [n_task][d_obs][S][NBK] observation bucket lines (engine-owned) or nullptr
 };
 
 struct AnyMDPTokIO {
@@ -797,6 +799,311 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_kernel(AnyMDPArgs P, AnyM
   io.reward[i] = rsum; io.reward_gt[i] = rgsum;
   io.terminated[i] = (uint8_t)term; io.truncated[i] = (uint8_t)trunc;
   if (err) atomicOr(P.err, err);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cooperative multi-token step (round 3): the same dependent-level economy as the MDP step kernel.  A transition token is
+// ONE bucket line read by the 8 lanes of the env's group (anymdp_coop_entry_lines); an observation token is one
+// OBSERVATION bucket line — 15 consecutive entries of obs_cdf[t][k][s][:] that start at I = #{cdf <= b / NBK} plus I
+// itself (xv_anymdp_build_buckets builds them beside the transition lines) — and the lines of two observation tokens
+// are in flight together.  A draw whose line does not contain its answer (all entries <= u) takes the per-lane binary
+// search (rare; per-lane branch).  Same draws, same results as anymdp_tok_step_kernel.
+// ------------------------------------------------------------------------------------------------
+// One 128-byte line per env, read by the 8 lanes of the env's group: iteration `it` serves envs 8 it .. 8 it + 7, lanes
+// 8 q .. 8 q + 7 read the 8 units of the line of env 8 it + q.  issue() only requests; the resolve functions wait and
+// hand each owner lane its result, so that independent work can be placed under the latency in between.
+struct AnyMDPCoopLine {
+  uint4 bv[8];
+  __device__ __forceinline__ void issue(const uint4* base, uint32_t line, int lane) {
+    const int g = lane >> 3, j = lane & 7;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const uint32_t li = (uint32_t)__shfl((int)line, it * 8 + g);
+      bv[it] = base[(size_t)li * 8 + j];
+    }
+  }
+  // the same for the envs whose owner lane sets `want` only: the others read line 0 of the table (one cached line for
+  // all of them; their results are ignored).  A step is priced in random 128-byte lines (~5e10 per second): none is
+  // requested without need.  (An address select, not a branch: hipcc drains the load queue at the end of every
+  // conditional block that holds a load, which serialised the eight requests.)
+  __device__ __forceinline__ void issue_if(const uint4* base, uint32_t line, bool want, int lane) {
+    issue(base, want ? line : 0u, lane);
+  }
+  // transition bucket line: 7 entries {cdf, reward, noise} + metadata  ->  cnt = #{cdf <= u}, the reward pair of entry
+  // min(cnt, 6), meta = observation id | terminal flag << 16 | first next-state index << 17 of that entry
+  __device__ __forceinline__ void resolve_entry(double u, int lane, int& cnt, float& rx, float& ry, uint32_t& meta) const {
+    const int g = lane >> 3, j = lane & 7;
+    cnt = 0; rx = 0.0f; ry = 0.0f; meta = 0u;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const double ue = xv_shfl_f64(u, it * 8 + g);
+      const unsigned long long m = __ballot(j < 7 && xv_u2d(bv[it].x, bv[it].y) <= ue);
+      const int cg = __popc((unsigned)(m >> (8 * g)) & 0x7Fu);   // reader side: the env this lane group serves
+      const int co = __popc((unsigned)(m >> (8 * j)) & 0x7Fu);   // owner side: the env this lane owns
+      const int sg = cg < 6 ? cg : 6;
+      const uint4 b4 = bv[it];
+      const uint32_t mw = sg < 2 ? b4.x : (sg < 4 ? b4.y : (sg < 6 ? b4.z : b4.w));
+      const uint32_t packed = ((mw >> (16 * (sg & 1))) & 0xFFFFu) | (((b4.w >> (16 + sg)) & 1u) << 16) | ((b4.w >> 23) << 17);
+      const int so = co < 6 ? co : 6;
+      const float px = __shfl(__uint_as_float(b4.z), 8 * j + so);
+      const float py = __shfl(__uint_as_float(b4.w), 8 * j + so);
+      const uint32_t pm = (uint32_t)__shfl((int)packed, 8 * j + 7);
+      if (g == it) { cnt = co; rx = px; ry = py; meta = pm; }
+    }
+  }
+  // observation bucket line: 16 doubles, the first 15 are CDF entries (2.0 past the row), the last holds {I, 0x40000000}
+  // (a double just above 2.0, never <= u)  ->  cnt = #{entries <= u}, first = I
+  __device__ __forceinline__ void resolve_cdf(double u, int lane, int& cnt, uint32_t& first) const {
+    const int g = lane >> 3, j = lane & 7;
+    cnt = 0; first = 0u;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const double ue = xv_shfl_f64(u, it * 8 + g);
+      const unsigned long long m0 = __ballot(xv_u2d(bv[it].x, bv[it].y) <= ue);
+      const unsigned long long m1 = __ballot(xv_u2d(bv[it].z, bv[it].w) <= ue);
+      const int co = __popc((unsigned)(m0 >> (8 * j)) & 0xFFu) + __popc((unsigned)(m1 >> (8 * j)) & 0xFFu);
+      const uint32_t fi = (uint32_t)__shfl((int)bv[it].z, 8 * j + 7);
+      if (g == it) { cnt = co; first = fi; }
+    }
+  }
+};
+
+// observation bucket lines: one wave per row obs_cdf[t][k][s][:], unit q of 16 bytes = entries 2 (q & 7), 2 (q & 7) + 1 of
+// bucket q >> 3
+__global__ __launch_bounds__(256) void anymdp_build_obs_buckets_kernel(const double* obs_cdf, size_t n_rows, int n_obs, int NBK,
+                                                                       uint4* out) {
+  const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (w >= n_rows) return;
+  const int lane = threadIdx.x & 63;
+  const double* row = obs_cdf + w * (size_t)n_obs;
+  for (int q = lane; q < NBK * 8; q += 64) {
+    const int kb = q >> 3, m = q & 7;
+    const double thr = (double)kb / (double)NBK;
+    int lo = 0, n = n_obs;
+    while (n > 0) {
+      const int half = n >> 1;
+      if (row[lo + half] <= thr) { lo += half + 1; n -= half + 1; } else n = half;
+    }
+    const double v0 = lo + 2 * m < n_obs ? row[lo + 2 * m] : 2.0;
+    const double v1 = lo + 2 * m + 1 < n_obs ? row[lo + 2 * m + 1] : 2.0;
+    uint4 o4 = make_uint4((uint32_t)__double2loint(v0), (uint32_t)__double2hiint(v0), (uint32_t)__double2loint(v1),
+                          (uint32_t)__double2hiint(v1));
+    if (m == 7) { o4.z = (uint32_t)lo; o4.w = 0x40000000u; }
+    out[(w * (size_t)NBK + kb) * 8 + m] = o4;
+  }
+}
+
+template <bool INJECT>
+__global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P, AnyMDPTokArgs K, AnyMDPTokIO io, int mode) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < P.n_env;
+  const int ic = valid ? i : P.n_env - 1;
+  const int lane = threadIdx.x & 63;
+  const int S = P.S, A = P.A, N = P.n_env, DO = K.d_obs, NBK = P.NBK;
+  const uint2 sr0 = P.sr[ic];
+  const uint4 rcu = P.rs_c[ic];
+  const double2 rc01 = P.rs_a[ic];
+  const uint4 rb = P.rs_b[ic];
+  int a_cur = io.action[(size_t)ic * K.d_act];
+  const int t = (int)rcu.w, max_steps = (int)(rcu.z & 0x7FFFFFFu);
+  int s = (int)(sr0.x & 0xFFFFu), steps = (int)sr0.y, nr = (sr0.x & XV_ANYMDP_SR_NR) ? 1 : 0;
+  int cterm = (sr0.x & XV_ANYMDP_SR_TERM) ? 1 : 0;
+  const uint64_t gid = P.gid_base + (uint64_t)ic;
+  uint32_t err = 0;
+  if (valid && io.final_obs) for (int k = 0; k < DO; ++k) io.final_obs[(size_t)i * DO + k] = -1;
+
+  // uniforms: transition token k -> purpose 32 + k words (0,1), its reward normal words (2,3); observation token k ->
+  // purpose 64 + k, words (0,1) after a step and (2,3) after a restart (oracle: tok_draws)
+  auto act_draw = [&](int k, double& u, xv_u32x4& w) {
+    if (INJECT) { u = io.u[(size_t)k * N + ic]; }
+    else { w = xv_env_draw(P.seed, gid, P.tick, 32u + (uint32_t)k); u = xv_u53(w.x, w.y); }
+  };
+  // both uniforms of observation token k from ONE call: after a step (us), after a restart (ur_)
+  auto obs_draw = [&](int k, double& us, double& ur_) {
+    if (INJECT) {
+      us = io.u_obs[(size_t)k * N + ic];
+      ur_ = io.u_obs_reset[(size_t)k * N + ic];
+    } else {
+      const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick, 64u + (uint32_t)k);
+      us = xv_u53(w.x, w.y);
+      ur_ = xv_u53(w.z, w.w);
+    }
+  };
+  auto pin2 = [](double& x, double& y) {   // keeps a pair of uniforms where it is computed (see the step kernel's late_draws)
+    int a0 = __double2loint(x), a1 = __double2hiint(x), b0 = __double2loint(y), b1 = __double2hiint(y);
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+    x = __hiloint2double(a1, a0);
+    y = __hiloint2double(b1, b0);
+  };
+  auto obs_line = [&](int k, int state, double u) -> uint32_t {
+    return ((((uint32_t)t * DO + k) * S + state) * (uint32_t)NBK) + (uint32_t)(int)(u * (double)NBK);
+  };
+  auto obs_pick = [&](int k, int state, double u, int cnt, uint32_t first, bool want) -> int {
+    int ob = (int)first + cnt;
+    ob = ob < K.n_obs - 1 ? ob : K.n_obs - 1;
+    if (want && cnt >= 15) {   // beyond the line: search the row
+      const double* row = K.obs_cdf + ((((size_t)t * DO + k) * S) + state) * (size_t)K.n_obs;
+      ob = xv_upper_bound_f64(row, K.n_obs, u);
+    }
+    return ob;
+  };
+
+  const bool skip = mode == XV_AUTORESET_NEXT_STEP && nr;                 // the call after a done: reset only
+  const bool stuck = !skip && mode == XV_AUTORESET_DISABLED && cterm;     // reference raises (:95-96): observe only
+  const bool active = !skip && !stuck;
+
+  // The restart state depends on the env's records and one uniform only, and no observation uniform depends on the step:
+  // the restart draw and the uniforms of the first two observation tokens are made under the latency of the FIRST transition
+  // line (early_work, called inside the token loop).  The restart state's observation lines are requested with the step's
+  // observation lines, for the envs that do restart only (requesting them for every env up front cost 2 of 6 lines per
+  // env-step; the kernel runs at the random-line rate of the HBM system).
+  const bool restarts = mode != XV_AUTORESET_DISABLED;   // wave-uniform
+  int k0r = 0, s_new = 0;
+  double uS0 = 0.0, uS1 = 0.0, uR0 = 0.0, uR1 = 0.0;
+  const int kR1 = DO > 1 ? 1 : 0;
+  auto early_work = [&]() {
+    obs_draw(0, uS0, uR0);
+    obs_draw(kR1, uS1, uR1);
+    pin2(uS0, uS1);
+    if (restarts) {
+      double ur;
+      if (INJECT) ur = io.u_reset[ic];
+      else {
+        const xv_u32x4 v = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_RESET);
+        ur = xv_u53(v.x, v.y);
+      }
+      k0r = (int)(rc01.x <= ur) + (int)(rc01.y <= ur) + (int)(xv_u2d(rb.x, rb.y) <= ur);
+      s_new = (int)(((k0r < 2 ? rb.z : rb.w) >> (16 * (k0r & 1))) & 0xFFFFu);
+      pin2(uR0, uR1);
+      asm volatile("" : "+v"(k0r), "+v"(s_new));
+    }
+  };
+
+  // ---- transition tokens (:120-126): one bucket line each; the reward normal and the next token's uniform are made
+  //      under the line's latency ----
+  float rsum = 0.0f, rgsum = 0.0f;
+  int term = 0, trunc = 0;
+  if (stuck) { err |= XV_DEVERR_STEP_TERMINAL; term = 1; trunc = steps >= max_steps; }
+  if (active) { steps += 1; trunc = steps >= max_steps; }                // :113-114, once per step
+  bool alive = active;
+  double u_cur;
+  xv_u32x4 w_cur{0u, 0u, 0u, 0u};
+  act_draw(0, u_cur, w_cur);
+  for (int k = 0; k < K.d_act; ++k) {                                      // wave-uniform trip count
+    int a = a_cur;
+    if (a < 0 || a >= A) { if (alive && valid) err |= XV_DEVERR_ACTION_RANGE; a = a < 0 ? 0 : A - 1; }
+    const uint32_t rowidx = ((uint32_t)t * S + s) * A + a;
+    AnyMDPCoopLine L;
+    L.issue_if(P.bucket, rowidx * (uint32_t)NBK + (uint32_t)(int)(u_cur * (double)NBK), alive, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    float z;
+    double u_next = 0.0;
+    xv_u32x4 w_next{0u, 0u, 0u, 0u};
+    if (INJECT) z = io.z[(size_t)k * N + ic];
+    else z = xv_normal1(w_cur.z, w_cur.w);
+    if (k + 1 < K.d_act) {
+      act_draw(k + 1, u_next, w_next);
+      a_cur = io.action[(size_t)ic * K.d_act + k + 1];
+    }
+    if (k == 0) early_work();
+    {   // pinned here (hipcc's IR-level sinking would move them behind the search)
+      int ulo = __double2loint(u_next), uhi = __double2hiint(u_next);
+      asm volatile("" : "+v"(z), "+v"(ulo), "+v"(uhi), "+v"(w_next.z), "+v"(w_next.w));
+      u_next = __hiloint2double(uhi, ulo);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    int cnt;
+    float rx, ry;
+    uint32_t meta;
+    L.resolve_entry(u_cur, lane, cnt, rx, ry, meta);
+    int s2 = (int)(meta >> 17) + cnt;
+    s2 = s2 < S - 1 ? s2 : S - 1;
+    bool term2 = (meta >> 16) & 1u;
+    float2 rsv = make_float2(rx, ry);
+    if (alive && cnt >= XV_ANYMDP_BLK) {   // s' lies beyond the line: search the row
+      int lo = 0, m = S;
+      while (m > 0) {
+        const int half = m >> 1;
+        if (anymdp_cdf(P, rowidx, lo + half) <= u_cur) { lo += half + 1; m -= half + 1; }
+        else m = half;
+      }
+      s2 = lo < S - 1 ? lo : S - 1;
+      rsv = anymdp_rs(P, rowidx, s2);
+      term2 = (P.term_mask[(size_t)t * P.words + (s2 >> 6)] >> (s2 & 63)) & 1ull;
+    }
+    if (alive) {
+      rsum = rsum + fmaf(rsv.y, z, rsv.x);
+      rgsum = rgsum + rsv.x;
+      s = s2;
+      cterm = term2 ? 1 : 0;
+      if (term2) { term = 1; alive = false; }
+    }
+    u_cur = u_next;
+    w_cur = w_next;
+  }
+  const bool done = active && (term || trunc);
+  bool do_reset = skip;
+  if (done) {
+    if (mode == XV_AUTORESET_SAME_STEP) do_reset = true;
+    else if (mode == XV_AUTORESET_NEXT_STEP) nr = 1;
+  }
+  const bool keep_final = done && mode == XV_AUTORESET_SAME_STEP && io.final_obs != nullptr;
+
+  // ---- observation tokens (:148-157) of the state the step ended in, two lines in flight; an env that restarts reports
+  //      the observation of its restart state instead (and the step's as final_obs) ----
+  for (int kp = 0; kp < DO; kp += 2) {
+    const int k1 = kp + 1 < DO ? kp + 1 : kp;
+    double u0 = uS0, u1 = uS1, v0 = uR0, v1 = uR1;
+    if (kp > 0) {
+      obs_draw(kp, u0, v0);
+      obs_draw(k1, u1, v1);
+    }
+    AnyMDPCoopLine S0, S1, Q0, Q1;   // the step's two observation lines and, for restarting envs, the restart state's
+    const bool wq = restarts && do_reset;
+    S0.issue_if(K.obs_bucket, obs_line(kp, s, u0), !skip, lane);
+    S1.issue_if(K.obs_bucket, obs_line(k1, s, u1), !skip && k1 != kp, lane);
+    if (restarts) {
+      Q0.issue_if(K.obs_bucket, obs_line(kp, s_new, v0), wq, lane);
+      Q1.issue_if(K.obs_bucket, obs_line(k1, s_new, v1), wq && k1 != kp, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    int c0, c1;
+    uint32_t f0, f1;
+    S0.resolve_cdf(u0, lane, c0, f0);
+    S1.resolve_cdf(u1, lane, c1, f1);
+    const int ob0 = obs_pick(kp, s, u0, c0, f0, !skip), ob1 = obs_pick(k1, s, u1, c1, f1, !skip && k1 != kp);
+    int rb0 = 0, rb1 = 0;
+    if (restarts) {
+      int cr0, cr1;
+      uint32_t fr0, fr1;
+      Q0.resolve_cdf(v0, lane, cr0, fr0);
+      Q1.resolve_cdf(v1, lane, cr1, fr1);
+      rb0 = obs_pick(kp, s_new, v0, cr0, fr0, wq);
+      rb1 = obs_pick(k1, s_new, v1, cr1, fr1, wq && k1 != kp);
+    }
+    if (valid) {
+      if (!skip || do_reset) {
+        io.obs[(size_t)i * DO + kp] = do_reset ? rb0 : ob0;
+        if (k1 != kp) io.obs[(size_t)i * DO + k1] = do_reset ? rb1 : ob1;
+      }
+      if (keep_final) {
+        io.final_obs[(size_t)i * DO + kp] = ob0;
+        if (k1 != kp) io.final_obs[(size_t)i * DO + k1] = ob1;
+      }
+    }
+  }
+  if (do_reset) {
+    s = s_new;
+    cterm = (int)((rcu.z >> (27 + k0r)) & 1u);
+    steps = 0;
+    nr = 0;
+  }
+  if (valid) {
+    P.sr[i] = anymdp_sr_pack(s, steps, nr, cterm);
+    io.reward[i] = rsum; io.reward_gt[i] = rgsum;
+    io.terminated[i] = (uint8_t)term; io.truncated[i] = (uint8_t)trunc;
+  }
+  if (err && valid) atomicOr(P.err, err);
 }
 
 template <bool INJECT>
@@ -962,7 +1269,7 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
   h->eng = e;
   h->search = XV_ANYMDP_SEARCH_AUTO;
   h->fast = false;
-  h->obs_cdf = nullptr; h->n_obs = 0; h->d_obs = 0; h->d_act = 0;
+  h->obs_cdf = nullptr; h->n_obs = 0; h->d_obs = 0; h->d_act = 0; h->obs_bucket = nullptr;
   h->graph_mode = 2; h->graph_failed = false; h->graph = nullptr; h->graph_exec = nullptr;
   h->d_tick = nullptr; h->d_tick_value = 0; h->d_tick_valid = false;
   memset(&h->graph_key, 0, sizeof(h->graph_key));
@@ -1051,6 +1358,7 @@ extern "C" int xv_anymdp_destroy(xv_anymdp* h) {
   if (h->graph) (void)hipGraphDestroy(h->graph);
   if (h->d_tick) (void)hipFree(h->d_tick);
   if (h->bucket_rw) (void)hipFree(h->bucket_rw);
+  if (h->obs_bucket) (void)hipFree(h->obs_bucket);
   delete h;
   return XV_OK;
 }
@@ -1326,6 +1634,28 @@ extern "C" int xv_anymdp_set_search(xv_anymdp* h, int search) {
   return XV_OK;
 }
 
+// observation bucket lines for the current observation model and NBK (no-op without either); frees stale ones
+static int anymdp_build_obs_buckets(xv_anymdp* h) {
+  if (h->obs_bucket) {
+    XV_HIP(hipStreamSynchronize(h->eng->stream));
+    (void)hipFree(h->obs_bucket);
+    h->obs_bucket = nullptr;
+  }
+  if (!h->obs_cdf || !h->a.bucket || h->a.NBK <= 0) return XV_OK;
+  const size_t n_rows = (size_t)h->a.n_task * h->d_obs * h->a.S;
+  if (n_rows * (size_t)h->a.NBK >= (1ull << 32)) return XV_OK;      // 32-bit line index: the per-lane kernel serves
+  uint4* b = nullptr;
+  if (hipMalloc(&b, n_rows * (size_t)h->a.NBK * 128) != hipSuccess) {
+    (void)hipGetLastError();
+    return XV_OK;                                                  // not fatal: the per-lane kernel serves
+  }
+  hipLaunchKernelGGL(anymdp_build_obs_buckets_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, h->eng->stream,
+                     h->obs_cdf, n_rows, h->n_obs, h->a.NBK, b);
+  XV_LAUNCH_CHECK();
+  h->obs_bucket = b;
+  return XV_OK;
+}
+
 extern "C" int xv_anymdp_build_buckets(xv_anymdp* h, int n_bucket) {
   XV_CHECK_ARG(h != nullptr && (n_bucket == 0 || n_bucket == 16 || n_bucket == 32 || n_bucket == 64));
   XV_HIP(hipSetDevice(h->eng->device));
@@ -1338,7 +1668,7 @@ extern "C" int xv_anymdp_build_buckets(xv_anymdp* h, int n_bucket) {
     h->bucket_rw = nullptr; h->a.bucket = nullptr; h->a.NBK = 0;
     if (h->search == XV_ANYMDP_SEARCH_BUCKET) h->search = XV_ANYMDP_SEARCH_AUTO;
   }
-  if (n_bucket == 0) return XV_OK;
+  if (n_bucket == 0) return anymdp_build_obs_buckets(h);   // frees the observation lines too
   if (!h->fast) {
     xv_set_error("xv_anymdp_build_buckets: needs the fence layout (s0_max <= 4, observation ids < 65536, max_steps < 2^27)");
     return XV_ERR_UNSUPPORTED;
@@ -1367,7 +1697,7 @@ extern "C" int xv_anymdp_build_buckets(xv_anymdp* h, int n_bucket) {
     return XV_ERR_HIP;
   }
   h->bucket_rw = b; h->a.bucket = b; h->a.NBK = n_bucket;
-  return XV_OK;
+  return anymdp_build_obs_buckets(h);
 }
 
 extern "C" int xv_anymdp_get_state(xv_anymdp* h, int32_t* inner_state, int32_t* steps, uint8_t* need_reset) {
@@ -1400,16 +1730,20 @@ extern "C" int xv_anymdp_transition_gt(xv_anymdp* h, const int32_t* action, doub
 extern "C" int xv_anymdp_set_observation_model(xv_anymdp* h, int n_obs, int d_obs, int d_act, const double* obs_cdf) {
   XV_CHECK_ARG(h && obs_cdf && n_obs >= 1 && d_obs >= 1 && d_obs <= 64 && d_act >= 1 && d_act <= 64);
   h->obs_cdf = obs_cdf; h->n_obs = n_obs; h->d_obs = d_obs; h->d_act = d_act;
-  return XV_OK;
+  return anymdp_build_obs_buckets(h);   // beside existing transition bucket lines
 }
 
 template <bool INJECT>
 static int anymdp_tok_launch_step(xv_anymdp* h, const AnyMDPTokIO& io, int mode) {
-  AnyMDPTokArgs K{h->obs_cdf, h->n_obs, h->d_obs, h->d_act};
+  AnyMDPTokArgs K{h->obs_cdf, h->n_obs, h->d_obs, h->d_act, h->obs_bucket};
   AnyMDPArgs a = h->a;
   if (h->search != XV_ANYMDP_SEARCH_BUCKET) a.bucket = nullptr;
-  hipLaunchKernelGGL(anymdp_tok_step_kernel<INJECT>, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
-                     a, K, io, mode);
+  if (a.bucket != nullptr && a.NBK > 0 && K.obs_bucket != nullptr && h->fast)   // bucket search: the cooperative kernel
+    hipLaunchKernelGGL(anymdp_tok_step_coop_kernel<INJECT>, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
+                       a, K, io, mode);
+  else
+    hipLaunchKernelGGL(anymdp_tok_step_kernel<INJECT>, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
+                       a, K, io, mode);
   XV_LAUNCH_CHECK();
   return XV_OK;
 }
@@ -1439,7 +1773,7 @@ extern "C" int xv_anymdp_step_tokens_injected(xv_anymdp* h, const int32_t* actio
 extern "C" int xv_anymdp_reset_tokens(xv_anymdp* h, const uint8_t* mask, int32_t* obs) {
   XV_CHECK_ARG(h && h->obs_cdf);
   anymdp_bind_rng(h, 1);
-  AnyMDPTokArgs K{h->obs_cdf, h->n_obs, h->d_obs, h->d_act};
+  AnyMDPTokArgs K{h->obs_cdf, h->n_obs, h->d_obs, h->d_act, h->obs_bucket};
   AnyMDPTokIO io{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, obs, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(anymdp_tok_reset_kernel<false>, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
                      h->a, K, io, mask);
@@ -1451,7 +1785,7 @@ extern "C" int xv_anymdp_reset_tokens_injected(xv_anymdp* h, const uint8_t* mask
                                                const double* u_obs_reset, int32_t* obs) {
   XV_CHECK_ARG(h && h->obs_cdf && u_reset && u_obs_reset);
   anymdp_bind_rng(h, 0);
-  AnyMDPTokArgs K{h->obs_cdf, h->n_obs, h->d_obs, h->d_act};
+  AnyMDPTokArgs K{h->obs_cdf, h->n_obs, h->d_obs, h->d_act, h->obs_bucket};
   AnyMDPTokIO io{nullptr, nullptr, nullptr, nullptr, u_reset, u_obs_reset, obs, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(anymdp_tok_reset_kernel<true>, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
                      h->a, K, io, mask);

@@ -146,9 +146,15 @@ def MazeTaskSampler(n_range=(9, 25), allow_loops=True, cell_size_range=(1.5, 4.5
                     agent_height_range=(1.6, 2.0), wall_density_range=(0.2, 0.4), landmarks_number_range=(5, 15),
                     fol_angle_range=(0.3 * PI, 0.8 * PI), commands_sequence=200, step_reward=0.0,
                     collision_reward=-0.20, goal_reward=None, seed=None, verbose=False,
-                    n_wall_textures=8, n_ground_textures=4, n_ceiling_textures=4):
-    """Signature of the reference sampler (task_sampler.py:92-106) plus the texture-library sizes (the reference
-    reads them from its JPG folder)."""
+                    n_wall_textures=None, n_ground_textures=None, n_ceiling_textures=None):
+    """Signature of the reference sampler (task_sampler.py:92-106) plus the texture-library sizes, which bound the
+    texture ids it draws.  The reference reads them from its image folder (37 walls / 29 grounds / 21 ceilings); those
+    are the defaults here, so `MazeTaskSampler(seed=k)` IS the reference's task for the seed; pass
+    `*textures.texture_counts(lib)` when a library of another size is used."""
+    from .textures import REFERENCE_TEXTURE_COUNTS
+    n_wall_textures = REFERENCE_TEXTURE_COUNTS[0] if n_wall_textures is None else n_wall_textures
+    n_ground_textures = REFERENCE_TEXTURE_COUNTS[1] if n_ground_textures is None else n_ground_textures
+    n_ceiling_textures = REFERENCE_TEXTURE_COUNTS[2] if n_ceiling_textures is None else n_ceiling_textures
     rng = np.random.RandomState(seed)
     cell_size = rng.uniform(*cell_size_range)
     wall_height = rng.uniform(*wall_height_range)

@@ -6,9 +6,14 @@ are neither copied nor available on the GPU box.  This module generates determin
 array contract (float32, values in [0, 255], shape [n, 256, 256, 3], wall / ground / ceiling libraries).
 Integer lattice value-noise from numpy's legacy RandomState, so the bytes are identical on every machine.
 """
+import os
+
 import numpy as np
 
 TEX_SIZE = 256
+# library sizes of the reference's own texture folder (xenoverse/mazeworld/envs/img: 37 wall*, 29 ground*, 21 ceiling*
+# files).  MazeTaskSampler draws texture ids with these bounds, so they are part of "the task for a seed".
+REFERENCE_TEXTURE_COUNTS = (37, 29, 21)
 
 
 def _value_noise(rng, size, cells):
@@ -49,9 +54,50 @@ def make_texture(seed, kind):
     return np.round(np.clip(img, 0, 255)).astype(np.float32)   # integral values, like a decoded image
 
 
-def make_texture_library(n_walls=8, n_grounds=4, n_ceilings=4, seed=0):
-    """-> dict(walls=[n_walls,256,256,3], grounds=[...], ceilings=[...]) float32 in [0,255]"""
+_LIB_CACHE = {}
+
+
+def make_texture_library(n_walls=None, n_grounds=None, n_ceilings=None, seed=0):
+    """-> dict(walls=[n_walls,256,256,3], grounds=[...], ceilings=[...]) float32 in [0,255].  Default sizes: the
+    reference's (37 / 29 / 21), so that a reference task's texture ids index it."""
+    n_walls = REFERENCE_TEXTURE_COUNTS[0] if n_walls is None else n_walls
+    n_grounds = REFERENCE_TEXTURE_COUNTS[1] if n_grounds is None else n_grounds
+    n_ceilings = REFERENCE_TEXTURE_COUNTS[2] if n_ceilings is None else n_ceilings
+    key = (n_walls, n_grounds, n_ceilings, seed)
+    if key in _LIB_CACHE:
+        return _LIB_CACHE[key]
     walls = np.stack([make_texture(seed * 1000 + k, "wall") for k in range(n_walls)])
     grounds = np.stack([make_texture(seed * 1000 + 300 + k, "ground") for k in range(n_grounds)])
     ceilings = np.stack([make_texture(seed * 1000 + 600 + k, "ceiling") for k in range(n_ceilings)])
-    return dict(walls=walls, grounds=grounds, ceilings=ceilings)
+    _LIB_CACHE[key] = dict(walls=walls, grounds=grounds, ceilings=ceilings)
+    return _LIB_CACHE[key]
+
+
+def load_texture_library(texture_dir):
+    """The reference's way of building its libraries (mazeworld/envs/task_sampler.py:60-77): every file of `texture_dir`
+    in SORTED name order whose name starts with `wall` / `ground` / `ceiling` is decoded to RGB and appended to that
+    library as pygame.surfarray.array3d returns it — axes (W, H, 3), i.e. the decoded (H, W, 3) image transposed — as
+    float32.  Other files are ignored.  -> dict(walls, grounds, ceilings) of float32 [n, W, H, 3]; pass it to
+    `MazeWorldVecEnv(textures=...)` and its sizes to the sampler (`texture_counts(lib)`).  Needs Pillow."""
+    from PIL import Image
+    libs = {"wall": [], "ground": [], "ceiling": []}
+    for name in sorted(os.listdir(texture_dir)):
+        for kind, dst in libs.items():
+            if name.find(kind) == 0:
+                with Image.open(os.path.join(texture_dir, name)) as im:
+                    rgb = np.asarray(im.convert("RGB"))            # (H, W, 3)
+                dst.append(np.ascontiguousarray(rgb.transpose(1, 0, 2)))
+    out = {}
+    for kind, key in (("wall", "walls"), ("ground", "grounds"), ("ceiling", "ceilings")):
+        if not libs[kind]:
+            raise ValueError("no %s* image in %s" % (kind, texture_dir))
+        shapes = {a.shape for a in libs[kind]}
+        if len(shapes) != 1:
+            raise ValueError("%s* images differ in size: %s" % (kind, sorted(shapes)))
+        out[key] = np.asarray(libs[kind], dtype="float32")
+    return out
+
+
+def texture_counts(lib):
+    """(n_walls, n_grounds, n_ceilings) of a library: the bounds MazeTaskSampler draws texture ids with"""
+    return int(len(lib["walls"])), int(len(lib["grounds"])), int(len(lib["ceilings"]))

@@ -34,8 +34,10 @@ class MazeWorldVecEnv(VectorEnv):
                  precision="exact", typing="numpy2"):
         """Constructor arguments as MazeWorldContinuous3D (maze_env.py:110-118); the registered id `mazeworld-v2`
         uses resolution (256, 256), max_steps 5000, visibility_3D 12.0, Discrete16 (mazeworld/__init__.py:19-33).
-        `textures`: dict(walls, grounds, ceilings) of float32 [n,256,256,3] arrays; default = the procedural
-        library (the reference's JPG assets are not redistributed)."""
+        `textures`: dict(walls, grounds, ceilings) of float32 [n,256,256,3] arrays — `load_texture_library(dir)` reads a
+        folder of wall* / ground* / ceiling* images the way the reference does (task_sampler.py:60-77); default = the
+        procedural library in the reference's sizes (37 / 29 / 21; its JPG assets are not redistributed), so reference
+        tasks and `MazeTaskSampler` defaults index it."""
         super().__init__(num_envs, device=device, seed=seed, env_id_base=env_id_base,
                          autoreset_mode=autoreset_mode, to_numpy=to_numpy, engine=engine, copy=copy)
         if enable_render:
