@@ -288,3 +288,32 @@ def test_numba_typing_variant_follows_its_oracle():
         env.close()
     frac, worst = frame_mismatch(frames["numpy2"], frames["numba"])
     assert 0 < frac < 0.005, (frac, worst)
+
+
+def test_numba_typing_kernel_against_the_mechanical_rule_fixture():
+    """the ray-cast kernel with typing="numba" on the poses of tests/golden/maze_numba_typing_frames.npz (the reference's
+    source under numba's scalar typing, applied mechanically: oracle/gen_numba_typing.py): within the frame budget of
+    the default typing against its goldens (+-1 level on <= 0.5 % of the values), and closer to that fixture than the
+    default typing is"""
+    import os
+    from util import GOLD
+    g = np.load(os.path.join(GOLD, "maze_numba_typing_frames.npz"))
+    diff = {"numba": 0, "numpy2": 0}
+    for name in sorted(set(g["fixture"])):
+        sel = g["fixture"] == name
+        gg, task = load_maze_golden(os.path.join(GOLD, str(name)))
+        steps = g["step"][sel]
+        n = len(steps)
+        for typing in ("numba", "numpy2"):
+            env = MazeWorldVecEnv(n, resolution=(64, 64), textures=tex(), autoreset_mode="disabled",
+                                  action_space_type="Discrete16", typing=typing)
+            env.set_task(task)
+            env.reset()
+            env.set_state(pos=gg["tr_pos"][steps].T.copy(), ori=gg["tr_ori"][steps].copy(), cmd_idx=gg["tr_cmd_idx"][steps].copy())
+            f = _np(env.render_frames())
+            frac, worst = frame_mismatch(f, g["frames64"][sel])
+            if typing == "numba":
+                assert frac <= 0.005 and worst <= 1, (name, frac, worst)
+            diff[typing] += int((f != g["frames64"][sel]).sum())
+            env.close()
+    assert diff["numba"] < diff["numpy2"], diff

@@ -130,3 +130,28 @@ def test_distance_between_the_two_typings_of_the_ray_caster():
         fracs.append((d > 0).mean()); big.append((d > 1).mean())
         worst = max(worst, (d > 0).reshape(n, -1).mean(1).max())
     assert 0 < np.mean(fracs) < 0.002 and np.mean(big) < 1e-4 and worst < 0.05, (fracs, big, worst)
+
+
+def test_numba_typing_variant_is_pinned_to_the_mechanical_rule():
+    """tests/golden/maze_numba_typing_frames.npz (oracle/gen_numba_typing.py): the reference's own maze_view source with
+    numba's scalar typing applied mechanically — every literal, scalar argument, int() result and range variable a strong
+    float64 / int64 — executed under NumPy on the golden poses.  The oracle's typing="numba" wall stage (float64 DDA and
+    wall-column geometry) reproduces those frames bit for bit; the default typing does not (it follows the reference as it
+    runs without numba)."""
+    import os
+    from util import GOLD
+    g = np.load(os.path.join(GOLD, "maze_numba_typing_frames.npz"))
+    differs_from_default = 0
+    for name in sorted(set(g["fixture"])):
+        sel = g["fixture"] == name
+        gg, task = load_maze_golden(os.path.join(GOLD, str(name)))
+        steps = g["step"][sel]
+        n = len(steps)
+        o = oracle.MazeOracle(build_tables([task]), textures(), np.zeros(n, np.int32), resolution=(64, 64))
+        o.reset()
+        o.pos[:] = gg["tr_pos"][steps].T; o.ori[:] = gg["tr_ori"][steps]; o.cmd_idx[:] = gg["tr_cmd_idx"][steps]
+        b, _ = o.render(n_threads=4, typing="numba")
+        assert np.array_equal(b, g["frames64"][sel]), name
+        a, _ = o.render(n_threads=4)
+        differs_from_default += int((a != g["frames64"][sel]).sum())
+    assert differs_from_default > 0
