@@ -15,7 +15,7 @@ copied): an AST pass wraps
 so that NumPy's promotion of STRONG scalars reproduces numba's unification (numba versions re-assigned variables in SSA
 form, so no other unification applies to this source: every loop-carried variable already has one type on all its
 incoming edges once the literals are strong).  The transformed functions are executed on the golden trajectories and
-the frames go to tests/golden/maze_numba_typing_frames.npz (arrays only).  The oracle's typing="numba" variant and the
+the frames go to tests/golden/raycast_numba_typing_frames.npz (arrays only).  The oracle's typing="numba" variant and the
 kernel's must reproduce those frames (tests/test_oracle_maze.py, tests/test_gpu_maze.py).
 
 What the rule cannot cover: numba compiles `numpy.tan / sin / cos / sqrt` to LLVM / libm calls, NumPy uses its own
@@ -126,7 +126,7 @@ def main():
     a, b = np.stack(out["frames64"]), np.stack(out["frames64_stub"])
     d = np.abs(a.astype(int) - b.astype(int))
     print("frames:", a.shape, "numba-typing vs NumPy-2 typing: %.4f %% of values differ, max |diff| %d" % (100 * (d > 0).mean(), d.max()))
-    path = os.path.join(GOLD, "maze_numba_typing_frames.npz")
+    path = os.path.join(GOLD, "raycast_numba_typing_frames.npz")
     np.savez_compressed(path, fixture=np.asarray(out["file"]), step=np.asarray(out["step"]), frames64=a)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 

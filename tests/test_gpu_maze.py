@@ -291,13 +291,13 @@ def test_numba_typing_variant_follows_its_oracle():
 
 
 def test_numba_typing_kernel_against_the_mechanical_rule_fixture():
-    """the ray-cast kernel with typing="numba" on the poses of tests/golden/maze_numba_typing_frames.npz (the reference's
+    """the ray-cast kernel with typing="numba" on the poses of tests/golden/raycast_numba_typing_frames.npz (the reference's
     source under numba's scalar typing, applied mechanically: oracle/gen_numba_typing.py): within the frame budget of
     the default typing against its goldens (+-1 level on <= 0.5 % of the values), and closer to that fixture than the
     default typing is"""
     import os
     from util import GOLD
-    g = np.load(os.path.join(GOLD, "maze_numba_typing_frames.npz"))
+    g = np.load(os.path.join(GOLD, "raycast_numba_typing_frames.npz"))
     diff = {"numba": 0, "numpy2": 0}
     for name in sorted(set(g["fixture"])):
         sel = g["fixture"] == name

@@ -133,14 +133,14 @@ def test_distance_between_the_two_typings_of_the_ray_caster():
 
 
 def test_numba_typing_variant_is_pinned_to_the_mechanical_rule():
-    """tests/golden/maze_numba_typing_frames.npz (oracle/gen_numba_typing.py): the reference's own maze_view source with
+    """tests/golden/raycast_numba_typing_frames.npz (oracle/gen_numba_typing.py): the reference's own maze_view source with
     numba's scalar typing applied mechanically — every literal, scalar argument, int() result and range variable a strong
     float64 / int64 — executed under NumPy on the golden poses.  The oracle's typing="numba" wall stage (float64 DDA and
     wall-column geometry) reproduces those frames bit for bit; the default typing does not (it follows the reference as it
     runs without numba)."""
     import os
     from util import GOLD
-    g = np.load(os.path.join(GOLD, "maze_numba_typing_frames.npz"))
+    g = np.load(os.path.join(GOLD, "raycast_numba_typing_frames.npz"))
     differs_from_default = 0
     for name in sorted(set(g["fixture"])):
         sel = g["fixture"] == name
