@@ -562,6 +562,27 @@ int xv_maze_agent_act(xv_maze_agent* g, const uint8_t* exposed_inject, int32_t* 
  * path int32[n_env][5] = {len(path), path[0], path[1]}, cell_exposed uint8[n_env][NG][NG] */
 int xv_maze_agent_get(xv_maze_agent* g, uint8_t* mask, double* cost, int32_t* path, uint8_t* exposed);
 
+/* ------------------------------------------------------------------------------------------------
+ * Mixed task batch (BASELINE.json config 5: anymdp + linds + metacontrol envs in one batch; the reference steps one env
+ * object per call, its users loop over heterogeneous envs in Python): ONE kernel launch advances all three families by
+ * one vector step — the families' own step bodies share a grid — where three launches cost three launch latencies.
+ * Results are bit for bit those of xv_anymdp_step + xv_linds_step + xv_cartpole_step on the same handles (each handle
+ * keeps its own engine tick; the three engines must share one device and HIP stream).  Field meanings as in the
+ * families' step calls; *_final_obs nullable.  XV_ERR_UNSUPPORTED when no fused instantiation fits the handles (AnyMDP on
+ * the per-lane binary search or S > 112, LinDS on the scalar path or pads other than (16|32, 8, 16)): step separately.
+ * xv_mixed_step_many: n_steps steps from C over ring buffers, step k on slot k % period of every array.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct xv_mixed_io {
+  const int32_t* a_action; int32_t* a_obs; float* a_reward; float* a_reward_gt; uint8_t* a_terminated; uint8_t* a_truncated;
+  int32_t* a_final_obs;
+  const float* l_action; float* l_obs; float* l_reward; uint8_t* l_terminated; uint8_t* l_truncated; float* l_cmd;
+  float* l_error; float* l_final_obs;
+  const int32_t* c_action; float* c_obs; float* c_reward; uint8_t* c_terminated; uint8_t* c_truncated; float* c_final_obs;
+} xv_mixed_io;
+int xv_mixed_step(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mixed_io* io, int autoreset_mode);
+int xv_mixed_step_many(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mixed_io* ring, int n_steps, int period,
+                       int autoreset_mode);
+
 #ifdef __cplusplus
 }
 #endif

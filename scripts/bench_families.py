@@ -223,7 +223,7 @@ def bench_anymdp_tok(args):
             "note": "per-lane searches (general path); 2 transition + 2 observation draws per env-step"}
 
 
-def bench_mixed(args, variants=("three streams", "one stream")):
+def bench_mixed(args, variants=("three streams", "one stream", "one launch")):
     """BASELINE.json config 5, the per-GPU share: 16,384 anymdp (2b: 256 tasks x 64) + 8,192 linds (128 tasks x 64)
     + 8,192 cartpole, one launch per family per vector step, families on separate HIP streams (xenoverse_amd.mixed)
     vs the same launches serialised on one stream."""
@@ -237,7 +237,7 @@ def bench_mixed(args, variants=("three streams", "one stream")):
     ltasks = linds_tasks(nl // 64)
     ctasks = [sample_cartpole(seed=k) for k in range(1024)]
     res = {}
-    for label, mixed in (("three streams", True), ("one stream", False)):
+    for label, mixed in (("three streams", True), ("one stream", False), ("one launch", False)):
         if label not in variants:
             continue
         if mixed:
@@ -284,7 +284,29 @@ def bench_mixed(args, variants=("three streams", "one stream")):
                 mb.sync()
                 for st in mb.streams.values():
                     st.wait_stream(torch.cuda.current_stream())
-        res[label] = timed(step, args.steps, args.warmup)
+        if label == "one launch":      # xv_mixed_step_many: the three families' step bodies in ONE grid, launches issued from C
+            import ctypes as C
+            from xenoverse_amd.mixed import _MixedIO
+            P = 8
+            ring = dict(aa=torch.randint(0, A, (P, na), device=d, dtype=torch.int32), ao=torch.zeros((P, na), device=d, dtype=torch.int32),
+                        ar=torch.zeros((P, na), device=d), ag=torch.zeros((P, na), device=d),
+                        at=torch.zeros((P, na), device=d, dtype=torch.uint8), au=torch.zeros((P, na), device=d, dtype=torch.uint8),
+                        af=torch.zeros((P, na), device=d, dtype=torch.int32),
+                        la=torch.rand((P, nl, 8), device=d) * 2 - 1, lo=torch.zeros((P, nl, 16), device=d), lr=torch.zeros((P, nl), device=d),
+                        lt=torch.zeros((P, nl), device=d, dtype=torch.uint8), lu=torch.zeros((P, nl), device=d, dtype=torch.uint8),
+                        lc=torch.zeros((P, nl, 16), device=d), le=torch.zeros((P, nl), device=d), lf=torch.zeros((P, nl, 16), device=d),
+                        ca=torch.randint(0, 2, (P, nc), device=d, dtype=torch.int32), co=torch.zeros((P, nc, 4), device=d),
+                        cr=torch.zeros((P, nc), device=d), ct=torch.zeros((P, nc), device=d, dtype=torch.uint8),
+                        cu=torch.zeros((P, nc), device=d, dtype=torch.uint8), cf=torch.zeros((P, nc, 4), device=d))
+            io = _MixedIO(*[_lib.ptr(ring[k]) for k in ("aa", "ao", "ar", "ag", "at", "au", "af", "la", "lo", "lr", "lt", "lu", "lc",
+                                                         "le", "lf", "ca", "co", "cr", "ct", "cu", "cf")])
+            k = max(P, args.steps // P * P)
+
+            def many():
+                _lib.check(ea.lib.xv_mixed_step_many(ea._h, el._h, ec._h, C.byref(io), k, P, mode))
+            res[label] = timed(many, 3, 1) / k
+        else:
+            res[label] = timed(step, args.steps, args.warmup)
         (mb.close() if mixed else [e.close() for e in (ea, el, ec)])
     n = na + nl + nc
     best = min(res.values())
@@ -293,7 +315,7 @@ def bench_mixed(args, variants=("three streams", "one stream")):
             "env_steps_per_s": n / (best * 1e-6), "us_per_vector_step": res, "dtype": "f64/f32",
             "roofline": {"bound": "hbm", "achieved": algo / (best * 1e-6) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
                          "frac": algo / (best * 1e-6) / 1e9 / HBM_PEAK, "algorithmic_bytes_per_vector_step": algo,
-                         "note": "three launches of 4-10 us kernels per vector step: launch-latency bound"}}
+                         "note": "a 13 MB vector step: launch-latency bound; one fused launch instead of three"}}
 
 
 def quick_families(steps=200, warmup=20):
@@ -331,14 +353,14 @@ def quick_families(steps=200, warmup=20):
                              "note": r["roofline"]["note"]}}
 
     def mixed():
-        r = bench_mixed(a, variants=("one stream",))
+        r = bench_mixed(a, variants=("one stream", "one launch"))
         us = min(r["us_per_vector_step"].values())
         return {"config": "BASELINE configs[4], one GPU's share: " + r["workload"], "ms_per_step": us * 1e-3,
                 "env_steps_per_s": r["env_steps_per_s"], "dtype": r["dtype"],
                 "roofline": {"bound": "hbm", "frac": r["roofline"]["frac"], "algorithmic_bytes": r["roofline"]["algorithmic_bytes_per_vector_step"],
                              "peak": HBM_PEAK, "unit": "GB/s", "achieved": r["roofline"]["achieved"],
-                             "kernel": "anymdp_step_kernel + linds_step_mfma_kernel + cartpole_step_kernel, one stream",
-                             "note": r["roofline"]["note"]}}
+                             "kernel": "mixed_step_kernel (anymdp + linds + cartpole step bodies in one grid, xv_mixed_step_many)",
+                             "us_per_vector_step": r["us_per_vector_step"], "note": r["roofline"]["note"]}}
     guard("linds", linds)
     guard("mazeworld_64", maze)
     guard("mixed_share", mixed)

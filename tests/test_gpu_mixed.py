@@ -169,3 +169,57 @@ def test_rollout_allgather_over_rccl_through_the_c_abi():
     o2, a2, r2, te2, tr2 = unpack_records(out[0])
     assert torch.equal(o2, obs) and torch.equal(a2, act) and torch.equal(r2, rew) and torch.equal(te2, te) and torch.equal(tr2, tr)
     rg.close()
+
+
+@pytest.mark.parametrize("search", ["fence", "bucket"])
+@pytest.mark.parametrize("mode", ["same_step", "next_step"])
+def test_fused_mixed_step_equals_separate_steps(mode, search):
+    """xv_mixed_step: ONE launch for an AnyMDP + LinDS + CartPole batch (the families' step bodies share a grid) — every
+    output, every state and every engine tick equals stepping the three families one after the other; ragged env counts
+    (partial last workgroups / tiles) included"""
+    import oracle
+    from xenoverse_amd.anymdp import AnyMDPVecEnv, to_blocked
+    from xenoverse_amd.linds import LinDSVecEnv, LinearDSSampler
+    from xenoverse_amd.metacontrol import CartPoleVecEnv, sample_cartpole
+    from xenoverse_amd.mixed import MixedBatch
+    na, nl, nc, S, A = 1000, 17 * 16 + 5, 700, 64, 8
+    tab = oracle.anymdp_synth(seed=3, task_index_base=0, n_task=10, S=S, A=A, s0_max=4)
+    dev = dict(S=S, A=A, s0_max=4)
+    tab["rows"] = to_blocked(tab["cdf"], tab["rs"])
+    for k in ("rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps"):
+        v = np.ascontiguousarray(tab[k])
+        dev[k] = torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).cuda()
+    ltasks = [LinearDSSampler(16, 8, 8, seed=k) for k in range(3)]
+    for t in ltasks:
+        t["max_steps"] = 30
+    ctasks = [sample_cartpole(seed=k) for k in range(5)]
+    a_task = (np.arange(na) % 10).astype(np.int32)
+    l_task = np.sort(np.arange(nl) % 3).astype(np.int32)
+    rng = np.random.RandomState(1)
+    T = 40
+    acts = dict(a=rng.randint(0, A, (T, na)).astype(np.int32), l=rng.uniform(-1.3, 1.3, (T, nl, 8)).astype(np.float32),
+                c=rng.randint(0, 2, (T, nc)).astype(np.int32))
+    recs = []
+    for fused in (False, True):
+        mb = MixedBatch("cuda:0", seed=11)
+        ea = mb.add("a", AnyMDPVecEnv, na, autoreset_mode=mode)
+        el = mb.add("l", LinDSVecEnv, nl, autoreset_mode=mode)
+        ec = mb.add("c", CartPoleVecEnv, nc, frameskip=1, autoreset_mode=mode)
+        mb.set_task({"a": (dev, a_task), "l": (ltasks, l_task), "c": ctasks})
+        ea.set_search(search, n_bucket=16) if search == "bucket" else ea.set_search(search)
+        mb.reset()
+        rec = []
+        for t in range(T):
+            out = (mb.step_fused if fused else mb.step)({k: v[t] for k, v in acts.items()})
+            for name in ("a", "l", "c"):
+                o, r, te, tr, info = out[name]
+                rec += [_np(o), _np(r), _np(te), _np(tr)]
+                rec += [_np(info[k]) for k in sorted(info) if torch.is_tensor(info[k])]
+        rec += [_np(x) for x in ea.get_state()] + [_np(x) for x in el.get_state()] + [_np(x) for x in ec.get_state()]
+        rec += [np.int64(ea.engine.tick), np.int64(el.engine.tick), np.int64(ec.engine.tick)]
+        assert ea.check_errors() == 0
+        recs.append(rec)
+        mb.close()
+    assert len(recs[0]) == len(recs[1])
+    for x, y in zip(*recs):
+        assert np.array_equal(x, y)

@@ -58,6 +58,8 @@ SIGNATURES = {
     "xv_anymdp_set_state": [c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_anymdp_transition_gt": [c_void_p, c_void_p, c_void_p],
     "xv_anymdp_synth_tasks": [c_void_p, c_u64, c_i64, c_int, c_int, c_int, c_int] + [c_void_p] * 6,
+    "xv_mixed_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_int],
+    "xv_mixed_step_many": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int],
     "xv_linds_create": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, C.POINTER(c_void_p)],
     "xv_linds_destroy": [c_void_p],
     "xv_linds_step_many": [c_void_p, c_int, c_int] + [c_void_p] * 8 + [c_int],

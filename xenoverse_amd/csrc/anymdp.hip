@@ -111,12 +111,12 @@ __device__ __forceinline__ uint2 anymdp_sr_pack(int s, int steps, int nr, int ct
   return make_uint2((uint32_t)s | (cterm ? XV_ANYMDP_SR_TERM : 0u) | (nr ? XV_ANYMDP_SR_NR : 0u), (uint32_t)steps);
 }
 
-__global__ void anymdp_init_sr_kernel(uint2* sr, int n) {
+static __global__ void anymdp_init_sr_kernel(uint2* sr, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) sr[i] = make_uint2(XV_ANYMDP_SR_NR, 0u);
 }
-__global__ void anymdp_set_tick_kernel(uint64_t* t, uint64_t v) { *t = v; }
-__global__ void anymdp_advance_tick_kernel(uint64_t* t, uint64_t dv) { *t += dv; }
+static __global__ void anymdp_set_tick_kernel(uint64_t* t, uint64_t v) { *t = v; }
+static __global__ void anymdp_advance_tick_kernel(uint64_t* t, uint64_t dv) { *t += dv; }
 
 __device__ __forceinline__ bool anymdp_is_term(const AnyMDPArgs& P, int t, uint64_t tm0, int s) {
   if (P.words == 1) return (tm0 >> s) & 1ull;
@@ -155,12 +155,13 @@ __device__ __forceinline__ double xv_u2d(uint32_t lo, uint32_t hi) { return __hi
 //    the last level reads G lines).
 // TICKDEV: the launch tick is *P.tick_dev + P.tick (graph replay); otherwise P.tick (a kernel argument).
 // BK: bucket mode: the step's table line is named by (row, floor(u * NBK)); G only shapes the fence fall-back.
+// `bid`: the workgroup's index within this family's part of the launch (blockIdx.x for the family's own kernels; the fused
+// mixed-batch kernel of mixed.hip hands every family a contiguous range of its workgroups)
 template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false, bool BK = false>
-__global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPStepIO io, int T_steps,
-                                                          int mode) {
+__device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyMDPStepIO& io, int T_steps, int mode, int bid) {
   constexpr bool FAST = G > 0;
   constexpr int GG = G > 0 ? G : 1;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = bid * blockDim.x + threadIdx.x;
   const bool valid = i < P.n_env;
   const int ic = valid ? i : P.n_env - 1;
   const int lane = threadIdx.x & 63;
@@ -470,10 +471,15 @@ __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPSt
   if (err) atomicOr(P.err, err);
 }
 
+template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false, bool BK = false>
+__global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPStepIO io, int T_steps, int mode) {
+  anymdp_step_body<INJECT, G, ROLLOUT, TICKDEV, BK>(P, io, T_steps, mode, (int)blockIdx.x);
+}
+
 // Completes the rows in place (create time): fence line and per-block metadata.  One thread per (row, k < 64).
 //   fence[k] (k < 16) = CDF entry of the last next-state of block group k (G blocks) for k < NB/G - 1, else 2.0
 //   meta of block k (k < NB) = {u16 obs[7]; u8 term_bits; u8 0} of next states 7k..7k+6 (clamped to S-1, as s' is)
-__global__ __launch_bounds__(256) void anymdp_finish_rows_kernel(AnyMDPArgs P, uint4* lines_rw, size_t row_base,
+static __global__ __launch_bounds__(256) void anymdp_finish_rows_kernel(AnyMDPArgs P, uint4* lines_rw, size_t row_base,
                                                                  size_t n_rows) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_rows * 64) return;
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(256) void anymdp_finish_rows_kernel(AnyMDPArgs P, u
 // Bucket lines (xv_anymdp_build_buckets): one wave per row, lane q and q + 64, ... each write one 16-byte unit.
 //   line (row, k), unit m < 7: the entry of next state I[k] + m (cdf 2.0 past the row), I[k] = #{cdf <= k / NBK}
 //   unit 7: the block metadata of those seven states (clamped to S - 1, as s' is) with I[k] in bits 23..31 of .w
-__global__ __launch_bounds__(256) void anymdp_build_buckets_kernel(AnyMDPArgs P, uint4* bucket, size_t row_base,
+static __global__ __launch_bounds__(256) void anymdp_build_buckets_kernel(AnyMDPArgs P, uint4* bucket, size_t row_base,
                                                                    size_t n_rows, int NBK) {
   const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (w >= n_rows) return;
@@ -560,7 +566,7 @@ __global__ __launch_bounds__(256) void anymdp_build_buckets_kernel(AnyMDPArgs P,
 }
 
 // per-env reset records (create time): the s_0 distribution of the env's task, ready for coalesced 16-byte reads
-__global__ __launch_bounds__(256) void anymdp_env_records_kernel(AnyMDPArgs P, double2* ra, uint4* rb, uint4* rc) {
+static __global__ __launch_bounds__(256) void anymdp_env_records_kernel(AnyMDPArgs P, double2* ra, uint4* rb, uint4* rc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
   const int t = P.env_task[i];
@@ -583,7 +589,7 @@ __global__ __launch_bounds__(256) void anymdp_env_records_kernel(AnyMDPArgs P, d
 
 // xv_anymdp_get_state / _set_state: the 8-byte env records <-> the caller's arrays (nullable each); the terminal flag of
 // a state set from outside is recomputed from term_mask
-__global__ __launch_bounds__(256) void anymdp_get_state_kernel(AnyMDPArgs P, int32_t* state, int32_t* steps, uint8_t* need_reset) {
+static __global__ __launch_bounds__(256) void anymdp_get_state_kernel(AnyMDPArgs P, int32_t* state, int32_t* steps, uint8_t* need_reset) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
   const uint2 r = P.sr[i];
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(256) void anymdp_get_state_kernel(AnyMDPArgs P, int
   if (steps) steps[i] = (int32_t)r.y;
   if (need_reset) need_reset[i] = (r.x & XV_ANYMDP_SR_NR) ? 1 : 0;
 }
-__global__ __launch_bounds__(256) void anymdp_set_state_kernel(AnyMDPArgs P, const int32_t* state, const int32_t* steps,
+static __global__ __launch_bounds__(256) void anymdp_set_state_kernel(AnyMDPArgs P, const int32_t* state, const int32_t* steps,
                                                                const uint8_t* need_reset) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
@@ -605,7 +611,7 @@ __global__ __launch_bounds__(256) void anymdp_set_state_kernel(AnyMDPArgs P, con
 }
 
 // largest observation id (decides whether ids fit the 16-bit block metadata)
-__global__ __launch_bounds__(256) void anymdp_max_obs_kernel(const int32_t* state_map, size_t n, int* out) {
+static __global__ __launch_bounds__(256) void anymdp_max_obs_kernel(const int32_t* state_map, size_t n, int* out) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < n) atomicMax(out, state_map[idx]);
 }
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(256) void anymdp_reset_kernel(AnyMDPArgs P, const u
 }
 
 // info["transition_gt"] = transition_obs[self.state, action]   (anymdp_env.py:130, :12-20)
-__global__ __launch_bounds__(256) void anymdp_tgt_kernel(AnyMDPArgs P, const int32_t* action, double* out) {
+static __global__ __launch_bounds__(256) void anymdp_tgt_kernel(AnyMDPArgs P, const int32_t* action, double* out) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)P.n_env * P.S;
   if (idx >= total) return;
@@ -870,7 +876,7 @@ struct AnyMDPCoopLine {
 
 // observation bucket lines: one wave per row obs_cdf[t][k][s][:], unit q of 16 bytes = entries 2 (q & 7), 2 (q & 7) + 1 of
 // bucket q >> 3
-__global__ __launch_bounds__(256) void anymdp_build_obs_buckets_kernel(const double* obs_cdf, size_t n_rows, int n_obs, int NBK,
+static __global__ __launch_bounds__(256) void anymdp_build_obs_buckets_kernel(const double* obs_cdf, size_t n_rows, int n_obs, int NBK,
                                                                        uint4* out) {
   const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (w >= n_rows) return;
@@ -1242,6 +1248,14 @@ __global__ __launch_bounds__(512) void anymdp_solve_kernel(AnyMDPArgs P, double 
   if (iters_out && tid == 0) iters_out[t] = it;
 }
 
+static inline void anymdp_bind_rng(xv_anymdp* h, uint64_t ticks) {
+  h->a.seed = h->eng->seed;
+  h->a.gid_base = h->eng->env_id_base;
+  h->a.tick = h->eng->tick;
+  h->eng->tick += ticks;
+}
+
+#ifndef XV_KERNELS_ONLY   // mixed.hip includes this file for its kernels and handle types only
 // ------------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------------
@@ -1361,13 +1375,6 @@ extern "C" int xv_anymdp_destroy(xv_anymdp* h) {
   if (h->obs_bucket) (void)hipFree(h->obs_bucket);
   delete h;
   return XV_OK;
-}
-
-static inline void anymdp_bind_rng(xv_anymdp* h, uint64_t ticks) {
-  h->a.seed = h->eng->seed;
-  h->a.gid_base = h->eng->env_id_base;
-  h->a.tick = h->eng->tick;
-  h->eng->tick += ticks;
 }
 
 extern "C" int xv_anymdp_reset(xv_anymdp* h, const uint8_t* mask, int32_t* obs) {
@@ -1792,3 +1799,4 @@ extern "C" int xv_anymdp_reset_tokens_injected(xv_anymdp* h, const uint8_t* mask
   XV_LAUNCH_CHECK();
   return XV_OK;
 }
+#endif   // XV_KERNELS_ONLY

@@ -56,10 +56,11 @@ __device__ __forceinline__ CpState cartpole_reset_state(const CartPoleArgs& P, c
 }
 
 template <bool INJECT>
-__global__ __launch_bounds__(256) void cartpole_step_kernel(CartPoleArgs P, CartPoleIO io, int mode, int T) {
+__device__ __forceinline__ void cartpole_step_body(const CartPoleArgs& P, const CartPoleIO& io, int mode, int T, int bid) {
   // T steps per launch (xv_cartpole_rollout; T = 1 for xv_cartpole_step): the state stays in registers, step ts reads
   // action[ts][i], writes row ts of the outputs and draws with tick + ts — the same values as T launches of one step
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // (`bid`: the workgroup's index within this family's part of the launch, see mixed.hip)
+  const int i = bid * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
   const size_t N = (size_t)P.n_env;
   double x = P.state[i], xd = P.state[N + i], th = P.state[2 * N + i], thd = P.state[3 * N + i];
@@ -131,6 +132,11 @@ __global__ __launch_bounds__(256) void cartpole_step_kernel(CartPoleArgs P, Cart
 }
 
 template <bool INJECT>
+__global__ __launch_bounds__(256) void cartpole_step_kernel(CartPoleArgs P, CartPoleIO io, int mode, int T) {
+  cartpole_step_body<INJECT>(P, io, mode, T, (int)blockIdx.x);
+}
+
+template <bool INJECT>
 __global__ __launch_bounds__(256) void cartpole_reset_kernel(CartPoleArgs P, const uint8_t* mask, const double* u,
                                                              float* obs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -144,6 +150,14 @@ __global__ __launch_bounds__(256) void cartpole_reset_kernel(CartPoleArgs P, con
   if (obs) reinterpret_cast<float4*>(obs)[i] = make_float4((float)s0.x, (float)s0.xd, (float)s0.th, (float)s0.thd);
 }
 
+static inline void cartpole_bind_rng(xv_cartpole* h, uint64_t ticks) {
+  h->a.seed = h->eng->seed;
+  h->a.gid_base = h->eng->env_id_base;
+  h->a.tick = h->eng->tick;
+  h->eng->tick += ticks;
+}
+
+#ifndef XV_KERNELS_ONLY   // mixed.hip includes this file for its kernels and handle types only
 extern "C" int xv_cartpole_create(xv_engine* e, int n_env, int n_task, int frameskip, int max_steps,
                                   const double* params, const double* reset_scale, const int32_t* env_task,
                                   xv_cartpole** out) {
@@ -201,12 +215,6 @@ extern "C" int xv_cartpole_destroy(xv_cartpole* h) {
   return XV_OK;
 }
 
-static inline void cartpole_bind_rng(xv_cartpole* h, uint64_t ticks) {
-  h->a.seed = h->eng->seed;
-  h->a.gid_base = h->eng->env_id_base;
-  h->a.tick = h->eng->tick;
-  h->eng->tick += ticks;
-}
 
 extern "C" int xv_cartpole_reset(xv_cartpole* h, const uint8_t* mask, float* obs) {
   XV_CHECK_ARG(h != nullptr);
@@ -281,3 +289,4 @@ extern "C" int xv_cartpole_set_state(xv_cartpole* h, const double* state, const 
   if (need_reset) XV_HIP(hipMemcpyAsync(h->a.need_reset, need_reset, n, hipMemcpyDeviceToDevice, h->eng->stream));
   return XV_OK;
 }
+#endif   // XV_KERNELS_ONLY

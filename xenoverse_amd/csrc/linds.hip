@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void linds_build_cmd_tab_kernel(LinDSArgs P, f
 
 // max over tasks of max_steps and of the command delay (sizes the command table), and the number of live command
 // columns: 1 + the last column whose target_valid is non-zero in some task (commands are multiplied by target_valid)
-__global__ __launch_bounds__(256) void linds_max_ints_kernel(const int32_t* ints, const float* valid, int NO, int n_task, int* out3) {
+static __global__ __launch_bounds__(256) void linds_max_ints_kernel(const int32_t* ints, const float* valid, int NO, int n_task, int* out3) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_task) return;
   atomicMax(out3, ints[(size_t)t * 4]);
@@ -695,7 +695,7 @@ struct LinDSFrag {
 };
 
 // builds frag (one thread per (task, q, lane)) and tvec from the caller's tables
-__global__ __launch_bounds__(256) void linds_build_frag_kernel(LinDSArgs P, float4* frag, float* tvec) {
+static __global__ __launch_bounds__(256) void linds_build_frag_kernel(LinDSArgs P, float4* frag, float* tvec) {
   const int NS = P.NS, NA = P.NA, NO = P.NO;
   const int MT = NS / 16, MO = NO / 16, KS = NS / 4, KA = NA / 4;
   const int NF = MT * KS + MT * KA + MO * KS, NQ = (NF + 3) / 4;
@@ -1005,9 +1005,9 @@ struct LinDSTileId {
   bool valid;
   uint64_t gid;
 };
-__device__ __forceinline__ bool linds_tile_id(const LinDSArgs& P, LinDSTileId& id) {
+__device__ __forceinline__ bool linds_tile_id(const LinDSArgs& P, LinDSTileId& id, int bid) {
   id.lane = threadIdx.x & 63;
-  id.wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  id.wave = (int)((bid * blockDim.x + threadIdx.x) >> 6);
   const int tile0 = id.wave * 16;
   if (tile0 >= P.n_slot) return false;   // wave-uniform
   id.n = id.lane & 15; id.g = id.lane >> 4;
@@ -1023,10 +1023,10 @@ __device__ __forceinline__ bool linds_tile_id(const LinDSArgs& P, LinDSTileId& i
 }
 
 template <int NS, int NA, int NO, bool INJECT>
-__device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const LinDSStepIO& io, int mode) {
+__device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const LinDSStepIO& io, int mode, int bid) {
   using F = LinDSFrag<NS, NA, NO>;
   LinDSTileId id;
-  if (!linds_tile_id(P, id)) return;
+  if (!linds_tile_id(P, id, bid)) return;
   // ---- every load of the step is in flight before the first MFMA; the step counter first (the command rows wait for it) ----
   const uint32_t sn0 = (uint32_t)P.sn[id.es];
   float4* xq = reinterpret_cast<float4*>(P.x) + (size_t)id.wave * F::MT * 64 + id.lane;
@@ -1079,7 +1079,7 @@ template <int NS, int NA, int NO>
 __global__ __launch_bounds__(256) void linds_rollout_mfma_kernel(LinDSArgs P, LinDSRolloutIO io, int T) {
   using F = LinDSFrag<NS, NA, NO>;
   LinDSTileId id;
-  if (!linds_tile_id(P, id)) return;
+  if (!linds_tile_id(P, id, (int)blockIdx.x)) return;
   F fr;
   fr.load(P, id.t, id.lane);
   float4* xq = reinterpret_cast<float4*>(P.x) + (size_t)id.wave * F::MT * 64 + id.lane;
@@ -1114,21 +1114,29 @@ void linds_step_mfma_kernel(LinDSArgs P, LinDSStepIO io, int mode) {
   __shared__ float occ_pad[(XV_LINDS_OCC == 2 ? 60 : XV_LINDS_OCC == 3 ? 45 : 150) * 256];
   if (P.n_env < 0) occ_pad[threadIdx.x] = 0.0f;
 #endif
-  linds_step_mfma_body<NS, NA, NO, INJECT>(P, io, mode);
+  linds_step_mfma_body<NS, NA, NO, INJECT>(P, io, mode, (int)blockIdx.x);
 }
 template <int NS, int NA, int NO, bool INJECT>
 __global__ __launch_bounds__(256) void linds_step_mfma_wide_kernel(LinDSArgs P, LinDSStepIO io, int mode) {
-  linds_step_mfma_body<NS, NA, NO, INJECT>(P, io, mode);
+  linds_step_mfma_body<NS, NA, NO, INJECT>(P, io, mode, (int)blockIdx.x);
 }
 
 // every aligned group of 16 envs shares one task?  (else the engine builds its slot layout)   bit 1: env_task[i] != i >> shift
-__global__ __launch_bounds__(256) void linds_check_tiles_kernel(const int32_t* env_task, int n_env, int shift, int* not_uniform) {
+static __global__ __launch_bounds__(256) void linds_check_tiles_kernel(const int32_t* env_task, int n_env, int shift, int* not_uniform) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_env) return;
   if (env_task[i] != env_task[i & ~15]) atomicOr(not_uniform, 1);
   if (shift < 4 || env_task[i] != (i >> shift)) atomicOr(not_uniform, 2);
 }
 
+static inline void linds_bind_rng(xv_linds* h, uint64_t ticks) {
+  h->a.seed = h->eng->seed;
+  h->a.gid_base = h->eng->env_id_base;
+  h->a.tick = h->eng->tick;
+  h->eng->tick += ticks;
+}
+
+#ifndef XV_KERNELS_ONLY   // mixed.hip includes this file for its kernels and handle types only
 // ------------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------------
@@ -1344,13 +1352,6 @@ extern "C" int xv_linds_destroy(xv_linds* h) {
   return XV_OK;
 }
 
-static inline void linds_bind_rng(xv_linds* h, uint64_t ticks) {
-  h->a.seed = h->eng->seed;
-  h->a.gid_base = h->eng->env_id_base;
-  h->a.tick = h->eng->tick;
-  h->eng->tick += ticks;
-}
-
 #define LINDS_DISPATCH(FN, ...)                                                                      \
   do {                                                                                               \
     const int key = (h->a.NS == 32 ? 4 : 0) | (h->a.NA == 16 ? 2 : 0) | (h->a.NO == 32 ? 1 : 0);    \
@@ -1511,3 +1512,4 @@ extern "C" int xv_linds_set_state(xv_linds* h, const float* x, const int32_t* st
   XV_LAUNCH_CHECK();
   return XV_OK;
 }
+#endif   // XV_KERNELS_ONLY

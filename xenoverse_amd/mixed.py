@@ -10,10 +10,23 @@ Each family keeps its own engine.  `streams="shared"` (default) launches all fam
 step is long (MazeWorld frames) or the consumer does not need all families at every step.  A family's trajectory
 is identical either way and identical to what it would be stepped alone: engines share nothing (no global RNG).
 Across GPUs each rank owns a contiguous slice of every family (`distributed.shard_range`).
+
+Round 3: `step_fused` advances one AnyMDP, one LinDS and one CartPole family with ONE kernel launch (`xv_mixed_step`:
+the families' own step bodies share a grid) — same results as `step`, one launch latency instead of three.
 """
+import ctypes as C
+
 import torch
 
-from .engine import Engine
+from . import _lib
+from .engine import AUTORESET, Engine
+
+
+class _MixedIO(C.Structure):   # xv_mixed_io (include/xeno.h)
+    _fields_ = [(k, C.c_void_p) for k in (
+        "a_action", "a_obs", "a_reward", "a_reward_gt", "a_terminated", "a_truncated", "a_final_obs",
+        "l_action", "l_obs", "l_reward", "l_terminated", "l_truncated", "l_cmd", "l_error", "l_final_obs",
+        "c_action", "c_obs", "c_reward", "c_terminated", "c_truncated", "c_final_obs")]
 
 
 class MixedBatch(object):
@@ -66,6 +79,52 @@ class MixedBatch(object):
                 out[name] = env.step(actions[name])
         self.sync()
         return out
+
+    def _fused_trio(self):
+        from .anymdp import AnyMDPVecEnv
+        from .linds import LinDSVecEnv
+        from .metacontrol import CartPoleVecEnv
+        pick = {}
+        for name, env in self.envs.items():
+            for key, cls in (("a", AnyMDPVecEnv), ("l", LinDSVecEnv), ("c", CartPoleVecEnv)):
+                if isinstance(env, cls):
+                    if key in pick:
+                        raise ValueError("step_fused takes one env of each family (anymdp, linds, cartpole)")
+                    pick[key] = (name, env)
+        if len(pick) != 3 or len(self.envs) != 3:
+            raise ValueError("step_fused needs exactly one AnyMDPVecEnv, one LinDSVecEnv and one CartPoleVecEnv")
+        if self.separate:
+            raise ValueError("step_fused launches one kernel: build the batch with streams='shared'")
+        modes = {e.autoreset_mode for _, e in pick.values()}
+        if len(modes) != 1:
+            raise ValueError("the three families must use one autoreset_mode")
+        return pick, modes.pop()
+
+    def step_fused(self, actions):
+        """One launch for the whole mixed batch (xv_mixed_step).  actions: dict name -> batched action, as for step().
+        -> dict name -> (obs, reward, terminated, truncated, infos), bit for bit what step() returns."""
+        pick, mode = self._fused_trio()
+        (na, ea), (nl, el), (nc, ec) = pick["a"], pick["l"], pick["c"]
+        if ea._tok is not None or ea._ring is not None:
+            raise ValueError("step_fused serves MDP tasks with copy=True outputs")
+        ea._check_step(); el._check_step()
+        if (not ec.task_set) or ec.need_reset:
+            raise Exception("Must \"set_task\" and \"reset\" before doing any actions")
+        aa = ea._dev(actions[na], torch.int32)
+        al = el._action(actions[nl])
+        ac = ec._dev(actions[nc], torch.int32)
+        if aa.shape != (ea.num_envs,) or ac.shape != (ec.num_envs,):
+            raise AssertionError("action batch shapes do not match the env counts")
+        ea._renew("_obs", "_reward", "_reward_gt", "_term", "_trunc", "_final_obs")
+        el._renew(*el._STEP_OUTPUTS); el._fresh_final_obs()
+        ec._renew("_obs", "_reward", "_term", "_trunc", "_fobs")
+        io = _MixedIO(*[_lib.ptr(t) for t in (
+            aa, ea._obs, ea._reward, ea._reward_gt, ea._term, ea._trunc, ea._final_obs,
+            al, el._obs, el._reward, el._term, el._trunc, el._cmd, el._error, el._fobs,
+            ac, ec._obs, ec._reward, ec._term, ec._trunc, ec._fobs)])
+        _lib.check(ea.lib.xv_mixed_step(ea._h, el._h, ec._h, C.byref(io), AUTORESET[mode]))
+        return {na: (ea._of(ea._obs), ea._of(ea._reward), ea._obf(ea._term), ea._obf(ea._trunc), ea._infos(aa)),
+                nl: el._ret(), nc: ec._ret()}
 
     def sync(self):
         if not self.separate:
