@@ -562,6 +562,16 @@ int xv_maze_agent_act(xv_maze_agent* g, const uint8_t* exposed_inject, int32_t* 
  * path int32[n_env][5] = {len(path), path[0], path[1]}, cell_exposed uint8[n_env][NG][NG] */
 int xv_maze_agent_get(xv_maze_agent* g, uint8_t* mask, double* cost, int32_t* path, uint8_t* exposed);
 
+/* Observation models of AnyPOMDPTaskSampler / MultiTokensAnyPOMDPTaskSampler (task_sampler.py:78-87, :103-117) for the
+ * tasks task_base .. task_base + n_task - 1 on the device: per (task, observation token) scipy.sparse.random(S, n_obs,
+ * min(density, maximum_distribution / n_obs)) — exactly round(density * S * n_obs) cells without replacement, U[0,1) values
+ * — with a 1 in a random column of every empty row, rows normalised, written as the inclusive row CDFs
+ * obs_cdf double[n_task][d_obs][S][n_obs] that xv_anymdp_set_observation_model takes.  Counter-based draws (its own stream,
+ * reproducible per (seed, task, token), independent of the batch split); the reference's distribution, not NumPy's
+ * stream — the seeded host samplers give that. */
+int xv_anymdp_sample_observation_model(xv_engine* e, uint64_t seed, int64_t task_base, int n_task, int S, int n_obs,
+                                       int d_obs, double density, double maximum_distribution, double* obs_cdf);
+
 /* ------------------------------------------------------------------------------------------------
  * Mixed task batch (BASELINE.json config 5: anymdp + linds + metacontrol envs in one batch; the reference steps one env
  * object per call, its users loop over heterogeneous envs in Python): ONE kernel launch advances all three families by

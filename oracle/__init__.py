@@ -195,6 +195,14 @@ class AnyMDPOracle(object):
         return out
 
 
+def anymdp_sample_observation_model(seed, task_base, n_task, S, n_obs, d_obs, density=0.20, maximum_distribution=4):
+    """xv_anymdp_sample_observation_model restated (same draws): obs_cdf float64[n_task, d_obs, S, n_obs]"""
+    out = np.empty((n_task, d_obs, S, n_obs), np.float64)
+    lib().xo_anymdp_sample_observation_model(C.c_uint64(seed), C.c_int64(task_base), C.c_int(n_task), C.c_int(S), C.c_int(n_obs),
+                                             C.c_int(d_obs), C.c_double(density), C.c_double(maximum_distribution), _p(out))
+    return out
+
+
 def anymdp_synth(seed, task_index_base, n_task, S, A, s0_max, task_stride=1):
     """Synthetic task tables (same bits as the device generator xv_anymdp_synth_tasks) of the tasks
     task_index_base + k * task_stride."""

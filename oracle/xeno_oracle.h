@@ -108,6 +108,8 @@ typedef struct {
   double max_steps, gini, ent, gap_min;
   double s0_prob[4];
 } xo_cand_info;
+void xo_anymdp_sample_observation_model(uint64_t seed, int64_t task_base, int n_task, int S, int n_obs, int d_obs, double density,
+                                        double maximum_distribution, double* obs_cdf);
 int xo_anymdp_sample_candidate(uint64_t seed, uint64_t cand, int ns, int na, double* T, double* R, double* noise,
                                xo_cand_info* info);
 

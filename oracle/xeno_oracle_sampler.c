@@ -554,3 +554,62 @@ void xo_anymdp_solve(const xo_anymdp* h, double gamma, double tol, int max_iter,
   }
   free(T); free(er); free(q); free(qn); free(v);
 }
+
+/* =====================================================================================================================
+ * Observation models (csrc/anymdp_sampler.hip: anymdp_obs_model_kernel; reference task_sampler.py:78-87, :103-117):
+ * scipy.sparse.random(S, n_obs, density) = exactly k = round(density * S * n_obs) cells chosen uniformly without
+ * replacement, U[0,1) values; an empty row gets a 1 in a random column; rows normalised; emitted as inclusive row CDFs.
+ * Same draws as the device: cell c of matrix m -> Philox(counter = {c, m, 0x40}, key = seed), key = {high random bits |
+ * cell index}, the k smallest keys are chosen.
+ * ===================================================================================================================*/
+static uint64_t xs_obs_key(uint64_t seed, uint64_t mat, uint32_t cell, uint64_t idx_mask, double* val) {
+  uint32_t ctr[4] = {cell, (uint32_t)mat, (uint32_t)(mat >> 32), 0x40u};
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, w[4];
+  xo_philox4x32_10(ctr, key, w);
+  if (val) *val = xo_u53(w[2], w[3]);
+  return ((((uint64_t)w[0] << 32) | (uint64_t)w[1]) & ~idx_mask) | (uint64_t)cell;
+}
+static int xs_cmp_u64(const void* a, const void* b) {
+  const uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+void xo_anymdp_sample_observation_model(uint64_t seed, int64_t task_base, int n_task, int S, int n_obs, int d_obs, double density,
+                                        double maximum_distribution, double* obs_cdf) {
+  const double d = density < maximum_distribution / (double)n_obs ? density : maximum_distribution / (double)n_obs;
+  const long long k = (long long)rint(d * (double)S * (double)n_obs);
+  const int M = S * n_obs;
+  uint64_t idx_mask = 1;
+  while (idx_mask < (uint64_t)M) idx_mask <<= 1;
+  idx_mask -= 1;
+  uint64_t* keys = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)M);
+  for (size_t q = 0; q < (size_t)n_task * d_obs; ++q) {
+    const uint64_t mat = (uint64_t)task_base * (uint64_t)d_obs + q;
+    uint64_t thr = 0;
+    if (k > 0) {   /* the k-th smallest key (a sort here, a bisection on the device: the same threshold) */
+      for (int c = 0; c < M; ++c) keys[c] = xs_obs_key(seed, mat, (uint32_t)c, idx_mask, 0);
+      qsort(keys, (size_t)M, sizeof(uint64_t), xs_cmp_u64);
+      thr = keys[(k < M ? k : M) - 1];
+    }
+    double* out = obs_cdf + q * (size_t)M;
+    for (int row = 0; row < S; ++row) {
+      double* o = out + (size_t)row * n_obs;
+      double acc = 0.0;
+      for (int j = 0; j < n_obs; ++j) {
+        double v;
+        const uint64_t key = xs_obs_key(seed, mat, (uint32_t)(row * n_obs + j), idx_mask, &v);
+        acc += (k > 0 && key <= thr) ? v : 0.0;
+        o[j] = acc;
+      }
+      if (acc == 0.0) {
+        uint32_t ctr[4] = {(uint32_t)row, (uint32_t)mat, (uint32_t)(mat >> 32), 0x41u};
+        uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, w[4];
+        xo_philox4x32_10(ctr, key, w);
+        const int col = (int)(((uint64_t)w[0] * (uint64_t)(uint32_t)n_obs) >> 32);
+        for (int j = 0; j < n_obs; ++j) o[j] = j >= col ? 1.0 : 0.0;
+        acc = 1.0;
+      }
+      for (int j = 0; j < n_obs; ++j) o[j] = o[j] / acc;
+    }
+  }
+  free(keys);
+}

@@ -170,3 +170,59 @@ def test_throughput_is_reported():
     s = out["stats"]
     assert s["accepted"] == 64 and s["candidates"] >= 64 and out["rows"].shape[0] == 64
     assert sum(s["status"].values()) == s["candidates"]
+
+
+@pytest.mark.parametrize("S,n_obs,d_obs,density", [(64, 64, 2, 0.20), (16, 22, 1, 0.20), (64, 200, 4, 0.05), (300, 64, 1, 0.20), (8, 5, 3, 0.0)])
+def test_device_observation_model_sampler_equals_its_oracle(S, n_obs, d_obs, density):
+    """xv_anymdp_sample_observation_model (AnyPOMDPTaskSampler / MultiTokensAnyPOMDPTaskSampler's observation matrices,
+    task_sampler.py:78-87, :103-117, on the device) against xo_anymdp_sample_observation_model: the same tables bit for
+    bit (the k chosen cells — a key-threshold bisection on the device, a sort in the oracle — values, fixed rows, CDFs),
+    and independent of how the task range is split over launches"""
+    import oracle
+    from xenoverse_amd import Engine
+    from xenoverse_amd.anymdp.device_sampler import sample_observation_model_device
+    eng = Engine("cuda:0")
+    n_task = 9
+    dev = sample_observation_model_device(eng, 21, n_task, S, n_obs, d_obs, density=density)
+    eng.sync()
+    ref = oracle.anymdp_sample_observation_model(21, 0, n_task, S, n_obs, d_obs, density=density)
+    assert np.array_equal(dev.cpu().numpy(), ref)
+    part = sample_observation_model_device(eng, 21, 4, S, n_obs, d_obs, density=density, task_base=3)
+    eng.sync()
+    assert np.array_equal(part.cpu().numpy(), ref[3:7])
+    eng.close()
+
+
+def test_sample_tasks_device_emits_multi_token_pomdp_tables_that_step():
+    """sample_tasks_device(task_type="MTPOMDP"): MDP tables from the device task sampler + observation models from the
+    device observation sampler go into AnyMDPVecEnv.set_task as they are and step on the cooperative kernel; the first
+    steps are checked against the oracle built from the same tables"""
+    import oracle
+    from xenoverse_amd.anymdp import AnyMDPVecEnv, from_blocked
+    from xenoverse_amd.anymdp.device_sampler import sample_tasks_device
+    tab = sample_tasks_device(6, state_space=16, action_space=4, seed=5, task_type="MTPOMDP", observation_space=12,
+                              observation_tokens=3, action_tokens=2)
+    assert tab["task_type"] == "MTPOMDP" and tuple(tab["obs_cdf"].shape) == (6, 3, 16, 12)
+    n = 6 * 20
+    env = AnyMDPVecEnv(n, seed=3, autoreset_mode="same_step")
+    env.set_task(tab)
+    assert env.task_type == "MTPOMDP" and (env.no, env.do, env.da) == (12, 3, 2)
+    env.set_search("bucket", n_bucket=16)
+    cdf, rs = from_blocked(tab["rows"].cpu().numpy(), 16)
+    host = dict(S=16, A=4, s0_max=tab["s0_max"], cdf=cdf, rs=rs, **{k: tab[k].cpu().numpy() for k in
+                ("state_map", "s0_cdf", "s0_ids", "max_steps")}, term_mask=tab["term_mask"].cpu().numpy().view(np.uint64))
+    env_task = np.repeat(np.arange(6, dtype=np.int32), 20)
+    ora = oracle.AnyMDPTokOracle(host, env_task, tab["obs_cdf"].cpu().numpy(), 2)
+    tick = env.engine.tick
+    o0, _ = env.reset()
+    assert np.array_equal(o0.cpu().numpy(), ora.tok_reset(3, 0, tick))
+    rng = np.random.RandomState(0)
+    for t in range(30):
+        a = rng.randint(0, 4, (n, 2)).astype(np.int32)
+        tick = env.engine.tick
+        obs, r, term, trunc, info = env.step(a)
+        o = ora.tok_step(3, 0, tick, a, 2)
+        assert np.array_equal(obs.cpu().numpy(), o[0]) and np.array_equal(term.cpu().numpy().astype(np.uint8), o[3])
+        assert np.array_equal(trunc.cpu().numpy().astype(np.uint8), o[4])
+    assert env.check_errors() == 0
+    env.close()

@@ -115,3 +115,46 @@ def test_device_algorithm_population_matches_the_reference_stream_population():
         b = np.array([r[k] for r in dev if k in r])
         se = np.sqrt(a.var() / len(a) + b.var() / len(b))
         assert abs(a.mean() - b.mean()) <= 4 * se + 1e-12, (k, a.mean(), b.mean(), se)
+
+
+def test_observation_model_sampler_follows_the_reference_rules():
+    """xo_anymdp_sample_observation_model (the restatement of the device's observation-model sampler) against the
+    reference's construction (task_sampler.py:78-87: scipy.sparse.random + empty-row fix + normalisation) run on NumPy's
+    stream: exactly round(density * S * n_obs) non-zeros per matrix before the fix, rows that sum to 1, the same share of
+    fixed rows and the same row-occupancy distribution within 4 sigma"""
+    import scipy.sparse as sp
+    S, n_obs, d_obs, n_task = 64, 64, 2, 40
+    cdf = oracle.anymdp_sample_observation_model(7, 0, n_task, S, n_obs, d_obs)
+    pmf = np.diff(np.concatenate([np.zeros(cdf.shape[:-1] + (1,)), cdf], -1), axis=-1)
+    assert np.all(pmf >= 0) and np.array_equal(cdf[..., -1], np.ones(cdf.shape[:-1]))
+    dens = min(0.20, 4 / n_obs)
+    k = int(round(dens * S * n_obs))
+    nnz = (pmf > 0).sum(-1)                                    # [n_task, d_obs, S]
+    fixed = nnz.sum(-1) - k                                     # cells added by the empty-row fix, per matrix
+    assert np.all(fixed >= 0)
+    single_one = (nnz == 1) & (pmf.max(-1) == 1.0)
+    assert np.all(fixed <= single_one.sum(-1))
+    # the reference's construction on its own stream
+    rng = np.random.RandomState(3)
+    ref_nnz = []
+    for _ in range(n_task * d_obs):
+        m = sp.random(S, n_obs, density=dens, format="csr", random_state=rng).toarray()
+        ref_nnz.append((m > 0).sum(-1))
+    ref_nnz = np.asarray(ref_nnz)
+    p_empty_ref = (ref_nnz == 0).mean()
+    p_empty = fixed.sum() / (n_task * d_obs * S)
+    n = n_task * d_obs * S
+    assert abs(p_empty - p_empty_ref) < 4 * np.sqrt(2 * p_empty_ref * (1 - p_empty_ref) / n) + 1e-3
+    for c in range(1, 8):                                        # occupancy histogram of the rows that were not fixed
+        a = ((nnz == c) & ~single_one).mean() + (single_one.mean() - p_empty if c == 1 else 0.0)
+        b = (ref_nnz == c).mean()
+        assert abs(a - b) < 4 * np.sqrt(2 * max(b, 1e-3) / n) + 2e-3, (c, a, b)
+    # values: uniform on [0, 1) before normalisation -> within a row of c >= 2 entries the largest share averages c / (c + 1)
+    # only in expectation of order statistics; cheaper invariant: a different seed gives different matrices, the same seed
+    # and task index the same ones whatever the batch split
+    again = oracle.anymdp_sample_observation_model(7, 10, 5, S, n_obs, d_obs)
+    assert np.array_equal(again, cdf[10:15])
+    other = oracle.anymdp_sample_observation_model(8, 0, 2, S, n_obs, d_obs)
+    assert not np.array_equal(other, cdf[:2])
+    tiny = oracle.anymdp_sample_observation_model(1, 0, 3, 5, 7, 1, density=0.0)      # k = 0: every row is a fixed row
+    assert np.all(np.isin(tiny, (0.0, 1.0))) and np.all(tiny[..., -1] == 1.0)

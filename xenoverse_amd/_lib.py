@@ -44,6 +44,7 @@ SIGNATURES = {
     "xv_anymdp_step_many_graph_state": [c_void_p],
     "xv_anymdp_sample_tasks": [c_void_p, c_u64, c_i64, c_int, c_int, c_int, c_int] + [c_void_p] * 11,
     "xv_anymdp_value_iteration_set_summation": [c_int],
+    "xv_anymdp_sample_observation_model": [c_void_p, c_u64, c_i64, c_int, c_int, c_int, c_int, C.c_double, C.c_double, c_void_p],
     "xv_anymdp_value_iteration_gs": [c_void_p, c_void_p, c_int, c_int, C.c_double, c_int, c_void_p, c_void_p],
     "xv_anymdp_rollout": [c_void_p, c_int] + [c_void_p] * 7,
     "xv_anymdp_set_search": [c_void_p, c_int],

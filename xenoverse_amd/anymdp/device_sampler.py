@@ -54,11 +54,30 @@ def sample_candidates(engine, seed, cand_base, n_cand, S, A, s0_max=4, tables=Tr
     return out
 
 
+def sample_observation_model_device(engine, seed, n_tasks, state_space, observation_space=64, observation_tokens=1,
+                                    density=0.20, maximum_distribution=4, task_base=0):
+    """Observation models of AnyPOMDPTaskSampler / MultiTokensAnyPOMDPTaskSampler (task_sampler.py:78-87, :103-117) for
+    n_tasks tasks on the device -> obs_cdf float64[n_tasks, observation_tokens, state_space, observation_space] (device):
+    sparse random rows (exactly round(density * S * n_obs) cells per matrix), empty rows fixed, normalised, as CDFs."""
+    out = torch.empty((n_tasks, observation_tokens, state_space, observation_space), dtype=torch.float64, device=engine.device)
+    _lib.check(engine.lib.xv_anymdp_sample_observation_model(
+        engine.handle, int(seed) & (2**64 - 1), int(task_base), int(n_tasks), int(state_space), int(observation_space),
+        int(observation_tokens), float(density), float(maximum_distribution), _lib.ptr(out)))
+    return out
+
+
 def sample_tasks_device(n_tasks, state_space=64, action_space=5, seed=0, device="cuda:0", engine=None, batch=None,
-                        s0_max=4, dense=False, max_candidates=None):
+                        s0_max=4, dense=False, max_candidates=None, task_type="MDP", observation_space=64,
+                        observation_tokens=4, action_tokens=2, density=0.20, maximum_distribution=4):
     """n_tasks accepted tasks -> dict of device tensors (keys as anymdp.tables.build_tables: S, A, s0_max, rows,
     state_map, term_mask, s0_cdf, s0_ids, max_steps; with dense=True also transition / reward / reward_noise fp64 and
-    max_steps_real) + "stats" (candidates tried, status histogram, seconds)."""
+    max_steps_real) + "stats" (candidates tried, status histogram, seconds).
+    task_type "POMDP" / "MTPOMDP" (the reference's AnyPOMDPTaskSampler / MultiTokensAnyPOMDPTaskSampler, whose arguments
+    observation_space, observation_tokens, action_tokens, density, maximum_distribution are taken as they are) adds the
+    observation model of every task, sampled on the device too: obs_cdf, n_obs, d_obs, d_act, task_type — the dict
+    `AnyMDPVecEnv.set_task` takes as it is."""
+    if task_type not in ("MDP", "POMDP", "MTPOMDP"):
+        raise NotImplementedError(f"Unknown task type: {task_type}")
     S, A = int(state_space), int(action_space)
     own = engine is None
     eng = Engine(device) if own else engine
@@ -83,8 +102,13 @@ def sample_tasks_device(n_tasks, state_space=64, action_space=5, seed=0, device=
                 got[k].append(r[k].index_select(0, acc))
             n_acc += int(len(acc))
             base += batch
-        eng.sync()
         out = dict(S=S, A=A, s0_max=s0_max, **{k: torch.cat(v) for k, v in got.items()})
+        if task_type != "MDP":
+            d_obs, d_act = (int(observation_tokens), int(action_tokens)) if task_type == "MTPOMDP" else (1, 1)
+            out.update(task_type=task_type, n_obs=int(observation_space), d_obs=d_obs, d_act=d_act,
+                       obs_cdf=sample_observation_model_device(eng, seed, n_tasks, S, observation_space, d_obs, density,
+                                                               maximum_distribution))
+        eng.sync()
         out["stats"] = dict(candidates=int(hist.sum()), accepted=int(hist[0]), seconds=time.perf_counter() - t0,
                             status={STATUS[i]: int(hist[i]) for i in range(len(STATUS))}, batch=batch)
         return out

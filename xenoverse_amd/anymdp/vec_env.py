@@ -46,8 +46,12 @@ class AnyMDPVecEnv(VectorEnv):
         device tensors, keys as xenoverse_amd.anymdp.tables.build_tables returns).  env_task_index[i] is
         the task of env i (default: envs split evenly and contiguously over tasks)."""
         obs_model = None
+        table_type = None
         if isinstance(tasks, dict) and "rows" in tasks:
             tab = tasks
+            if tab.get("obs_cdf") is not None:      # prebuilt POMDP / MTPOMDP tables (device_sampler.sample_tasks_device)
+                obs_model = (tab["obs_cdf"], int(tab["n_obs"]), int(tab["d_obs"]), int(tab["d_act"]))
+                table_type = tab.get("task_type", "MTPOMDP" if (obs_model[2] > 1 or obs_model[3] > 1) else "POMDP")
         else:
             if isinstance(tasks, dict):
                 tasks = [tasks]
@@ -57,7 +61,7 @@ class AnyMDPVecEnv(VectorEnv):
             tab = build_tables(tasks)
             if ttype != "MDP":
                 obs_model = build_obs_tables(tasks, tab["S"])
-        self.task_type = "MDP" if obs_model is None else tasks[0]["task_type"]
+        self.task_type = "MDP" if obs_model is None else (table_type or tasks[0]["task_type"])
         dev = {}
         for k in _TABLE_KEYS:
             v = tab[k]
@@ -112,7 +116,10 @@ class AnyMDPVecEnv(VectorEnv):
         self._tok = None
         if obs_model is not None:      # POMDP / MTPOMDP (anymdp_env.py:39-44)
             obs_cdf, n_obs, d_obs, d_act = obs_model
-            self._tab["obs_cdf"] = torch.from_numpy(np.ascontiguousarray(obs_cdf)).to(d)
+            self._tab["obs_cdf"] = obs_cdf.to(d, torch.float64).contiguous() if torch.is_tensor(obs_cdf) else \
+                torch.from_numpy(np.ascontiguousarray(obs_cdf, np.float64)).to(d)
+            if tuple(self._tab["obs_cdf"].shape) != (n_task, d_obs, S, n_obs):
+                raise ValueError("obs_cdf has shape %s, expected %s" % (tuple(self._tab["obs_cdf"].shape), (n_task, d_obs, S, n_obs)))
             _lib.check(self.lib.xv_anymdp_set_observation_model(self._h, n_obs, d_obs, d_act,
                                                                 _lib.ptr(self._tab["obs_cdf"])))
             self._tok = (d_obs, d_act)

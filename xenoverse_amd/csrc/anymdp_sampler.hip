@@ -637,3 +637,93 @@ extern "C" int xv_anymdp_sample_tasks(xv_engine* e, uint64_t seed, int64_t cand_
   XV_LAUNCH_CHECK();
   return XV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Observation models of AnyPOMDPTaskSampler / MultiTokensAnyPOMDPTaskSampler (task_sampler.py:78-87, :103-117) for whole
+// task batches: per (task, observation token) a matrix obs[S][n_obs] = scipy.sparse.random(S, n_obs, density) — exactly
+// k = round(density * S * n_obs) cells, uniformly chosen without replacement over the WHOLE matrix, values U[0, 1) —
+// where a row left empty gets a 1 in a random column, every row normalised; density = min(density,
+// maximum_distribution / n_obs).  Emitted as the step engine's table: the inclusive row CDF cumsum(row) / cumsum(row)[-1]
+// (what numpy.random.choice forms, anymdp_env.py:150-157), obs_cdf[task][token][s][:].
+// Same distribution and rules as the reference, its own stream: every cell c of matrix m draws Philox(counter = {c, m,
+// purpose}, key = seed); the k chosen cells are the k smallest 64-bit keys {random high bits | cell index}, found by a
+// 64-step bisection of the key threshold (no sort, no storage: keys are recomputed).  One workgroup per matrix.
+// Oracle: xo_anymdp_sample_observation_model (same draws, bit-identical tables).
+// ------------------------------------------------------------------------------------------------
+#define XS_OBS_KEY 0x40u
+#define XS_OBS_FIX 0x41u
+__device__ __forceinline__ uint64_t xs_obs_key(uint64_t seed, uint64_t mat, uint32_t cell, uint64_t idx_mask, double* val) {
+  const xv_u32x4 w = xv_philox4x32_10(cell, (uint32_t)mat, (uint32_t)(mat >> 32), XS_OBS_KEY, (uint32_t)seed, (uint32_t)(seed >> 32));
+  if (val) *val = xv_u53(w.z, w.w);
+  return ((((uint64_t)w.x << 32) | (uint64_t)w.y) & ~idx_mask) | (uint64_t)cell;
+}
+
+__global__ __launch_bounds__(256) void anymdp_obs_model_kernel(uint64_t seed, uint64_t mat_base, int S, int n_obs, long long k_cells,
+                                                               double* obs_cdf) {
+  __shared__ unsigned long long s_cnt;
+  __shared__ unsigned long long s_thr;
+  const uint64_t mat = mat_base + blockIdx.x;
+  const int M = S * n_obs, tid = threadIdx.x;
+  uint64_t idx_mask = 1;
+  while (idx_mask < (uint64_t)M) idx_mask <<= 1;
+  idx_mask -= 1;
+  // smallest threshold T with #{key <= T} >= k  (keys are distinct: their low bits are the cell index)
+  uint64_t lo = 0, hi = ~0ull;
+  if (k_cells > 0) {
+    for (int it = 0; it < 64; ++it) {
+      const uint64_t mid = lo + ((hi - lo) >> 1);
+      if (tid == 0) s_cnt = 0ull;
+      __syncthreads();
+      unsigned long long c = 0;
+      for (int cell = tid; cell < M; cell += blockDim.x) c += xs_obs_key(seed, mat, (uint32_t)cell, idx_mask, nullptr) <= mid ? 1ull : 0ull;
+      atomicAdd(&s_cnt, c);
+      __syncthreads();
+      const bool enough = s_cnt >= (unsigned long long)k_cells;
+      __syncthreads();
+      if (enough) hi = mid; else lo = mid + 1;
+      if (lo >= hi) break;
+    }
+  }
+  if (tid == 0) s_thr = hi;
+  __syncthreads();
+  const uint64_t thr = s_thr;
+  double* out = obs_cdf + (size_t)blockIdx.x * (size_t)M;
+  for (int row = tid; row < S; row += blockDim.x) {   // one thread per row: values, empty-row fix, cumsum, normalisation
+    double* o = out + (size_t)row * n_obs;
+    double acc = 0.0;
+    for (int j = 0; j < n_obs; ++j) {
+      double v;
+      const uint64_t key = xs_obs_key(seed, mat, (uint32_t)(row * n_obs + j), idx_mask, &v);
+      acc += (k_cells > 0 && key <= thr) ? v : 0.0;
+      o[j] = acc;
+    }
+    if (acc == 0.0) {   // obs_mat[i][random.randint(observation_space)] = 1
+      const xv_u32x4 w = xv_philox4x32_10((uint32_t)row, (uint32_t)mat, (uint32_t)(mat >> 32), XS_OBS_FIX, (uint32_t)seed,
+                                          (uint32_t)(seed >> 32));
+      const int col = (int)(((uint64_t)w.x * (uint64_t)(uint32_t)n_obs) >> 32);
+      for (int j = 0; j < n_obs; ++j) o[j] = j >= col ? 1.0 : 0.0;
+      acc = 1.0;
+    }
+    for (int j = 0; j < n_obs; ++j) o[j] = o[j] / acc;
+  }
+}
+
+extern "C" int xv_anymdp_sample_observation_model(xv_engine* e, uint64_t seed, int64_t task_base, int n_task, int S, int n_obs,
+                                                  int d_obs, double density, double maximum_distribution, double* obs_cdf) {
+  XV_CHECK_ARG(e != nullptr && obs_cdf != nullptr);
+  XV_CHECK_ARG(n_task > 0 && task_base >= 0 && S >= 1 && S <= 512 && n_obs >= 1 && n_obs <= 65536 && d_obs >= 1 && d_obs <= 64);
+  XV_CHECK_ARG(density >= 0.0 && density <= 1.0 && maximum_distribution > 0.0);
+  XV_CHECK_ARG((long long)S * n_obs < (1ll << 31));
+  XV_HIP(hipSetDevice(e->device));
+  const double d = density < maximum_distribution / (double)n_obs ? density : maximum_distribution / (double)n_obs;
+  const long long k = (long long)rint(d * (double)S * (double)n_obs);     // scipy.sparse.random: int(round(density * m * n))
+  const size_t n_mat = (size_t)n_task * d_obs;
+  const size_t chunk = 1u << 20;
+  for (size_t m0 = 0; m0 < n_mat; m0 += chunk) {
+    const size_t nm = n_mat - m0 < chunk ? n_mat - m0 : chunk;
+    hipLaunchKernelGGL(anymdp_obs_model_kernel, dim3((unsigned)nm), dim3(256), 0, e->stream, seed,
+                       (uint64_t)task_base * (uint64_t)d_obs + m0, S, n_obs, k, obs_cdf + m0 * (size_t)S * n_obs);
+  }
+  XV_LAUNCH_CHECK();
+  return XV_OK;
+}
