@@ -386,8 +386,10 @@ def main():
         env.set_task(tab, env_task_index=env_task)
         search, bucket_gib = choose_search(env, torch, args, n_task, S, A)
         # a short timed batch is one submission when its ring cycle replays from a hipGraph (20 steps: 154 instead of
-        # 173 us); thousands of steps of a large batch are not launch-bound and plain launches are 2-3 % faster there
-        graph_mode = args.graph if args.graph != "auto" else ("on" if (args.steps <= 128 or n_env <= 8192) else "off")
+        # 173 us)
+        # round 3: with the 5.3-us step kernel the graph also wins on long runs (2,000 steps: 5.59 vs 5.83 us per step), so
+        # auto = on; `--graph off` issues plain launches
+        graph_mode = args.graph if args.graph != "auto" else "on"
         env.set_step_many_graph(graph_mode)
         device = env.device
         g = torch.Generator(device=device)
