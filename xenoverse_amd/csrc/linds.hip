@@ -68,8 +68,10 @@ struct LinDSArgs {
 #endif                         //    they must not displace the state, sn, the fragments and the command rows in the L2
                                //    (measured at config 3: 10.25 -> 9.41 us per step, fused roll-out 7.3 -> 5.7 us per step)
 #ifndef XV_LINDS_NT_MORE
-#define XV_LINDS_NT_MORE 4     // bit 0: action reads non-temporal (measured: no gain, slower beyond 131k envs); bit 1: scalar
-#endif                         // outputs (no gain); bit 2: the state stores too (9.57 -> 9.29 us: kept)
+#define XV_LINDS_NT_MORE 12    // bit 0: action reads non-temporal (measured: no gain, slower beyond 131k envs); bit 1: scalar
+#endif                         // outputs (no gain); bit 2: the state stores too (9.57 -> 9.29 us: kept); bit 3: the state
+                               // loads too (8.73 -> 8.34 us issued from C: kept) — the state is read once and written once per
+                               // step, the L2 is better spent on the fragments and the command rows
 #ifndef XV_LINDS_WARM
 #define XV_LINDS_WARM 0        // 1: touch the rows a restarting env will read (initial state, its tabulated observation, cmd(0))
 #endif                         //    while the first loads are in flight, so that the restart reads hit the cache
@@ -1033,8 +1035,13 @@ __device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const L
   xv_f32x4 xs[F::MT];
 #pragma unroll
   for (int m = 0; m < F::MT; ++m) {
+#if XV_LINDS_NT_MORE & 8
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    xs[m] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(xq + m * 64));
+#else
     const float4 v = xq[m * 64];
     xs[m] = xv_f32x4{v.x, v.y, v.z, v.w};
+#endif
   }
   F fr;
   fr.load(P, id.t, id.lane);
