@@ -36,6 +36,9 @@
 #include <cstring>
 
 #define XV_ANYMDP_BLK 7   // next states per block
+#ifndef XV_ANYMDP_NT_OUT
+#define XV_ANYMDP_NT_OUT 1   // the step's outputs leave with non-temporal stores (written once, read by somebody else): 5.41-5.73
+#endif                       // -> 5.27-5.32 us per 65,536-env step on the same box, two A/B rounds (scripts/runs_r03/gpu_n.sh)
 
 struct AnyMDPArgs {
   // borrowed task tables
@@ -459,12 +462,21 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
       nr = 0;
     }
     if (valid) {
+#if XV_ANYMDP_NT_OUT
+      __builtin_nontemporal_store(o_obs, io.obs + o);
+      __builtin_nontemporal_store(o_r, io.reward + o);
+      __builtin_nontemporal_store(o_rgt, io.reward_gt + o);
+      __builtin_nontemporal_store((uint8_t)(o_term ? 1 : 0), io.terminated + o);
+      __builtin_nontemporal_store((uint8_t)(o_trunc ? 1 : 0), io.truncated + o);
+      if (io.final_obs) __builtin_nontemporal_store(o_fobs, io.final_obs + o);
+#else
       io.obs[o] = o_obs;
       io.reward[o] = o_r;
       io.reward_gt[o] = o_rgt;
       io.terminated[o] = o_term ? 1 : 0;
       io.truncated[o] = o_trunc ? 1 : 0;
       if (io.final_obs) io.final_obs[o] = o_fobs;
+#endif
     }
   }
   if (valid) P.sr[i] = anymdp_sr_pack(s, steps, nr, cterm);
