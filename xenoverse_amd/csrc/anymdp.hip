@@ -36,6 +36,9 @@
 #include <cstring>
 
 #define XV_ANYMDP_BLK 7   // next states per block
+#ifndef XV_ANYMDP_SELECT
+#define XV_ANYMDP_SELECT 1   // the owner lane keeps its result by SELECTS: written as `if (g == it) {...}` hipcc emits an exec-masked
+#endif                       // branch per env group (45 -> 14 branches in the step kernel; 5.31-5.34 -> 5.05-5.13 us per step)
 #ifndef XV_ANYMDP_NT_OUT
 #define XV_ANYMDP_NT_OUT 1   // the step's outputs leave with non-temporal stores (written once, read by somebody else): 5.41-5.73
 #endif                       // -> 5.27-5.32 us per 65,536-env step on the same box, two A/B rounds (scripts/runs_r03/gpu_n.sh)
@@ -292,7 +295,11 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
         const float px = __shfl(__uint_as_float(b4.z), 8 * j + so);
         const float py = __shfl(__uint_as_float(b4.w), 8 * j + so);
         const uint32_t pm = (uint32_t)__shfl((int)packed, 8 * j + 7);
+#if XV_ANYMDP_SELECT
+        { const bool own = g == it; cnt_own = own ? co : cnt_own; rx = own ? px : rx; ry = own ? py : ry; meta_own = own ? pm : meta_own; }
+#else
         if (g == it) { cnt_own = co; rx = px; ry = py; meta_own = pm; }
+#endif
       }
       s2 = (int)(meta_own >> 17) + cnt_own;
       s2 = s2 < S - 1 ? s2 : S - 1;
@@ -327,7 +334,7 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
         const unsigned long long m0 = __ballot(xv_u2d(fv[it].x, fv[it].y) <= ue[it]);
         const unsigned long long m1 = __ballot(xv_u2d(fv[it].z, fv[it].w) <= ue[it]);
         const int cnt = __popc((unsigned)(m0 >> (8 * j)) & 0xFFu) + __popc((unsigned)(m1 >> (8 * j)) & 0xFFu);
-        if (g == it) k_own = cnt;
+        k_own = g == it ? cnt : k_own;
       }
       const int NF = P.NB / GG;
       k_own = k_own < NF - 1 ? k_own : NF - 1;       // fences of absent groups hold 2.0: cannot exceed
@@ -387,7 +394,7 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
             if (q == lo_) { px = x; py = y; }
           }
           const uint32_t pm = (uint32_t)__shfl((int)packed, 8 * j + 7);
-          if (g == b0 + it) { cnt_own = co; rx = px; ry = py; meta_own = pm; }
+          { const bool own = g == b0 + it; cnt_own = own ? co : cnt_own; rx = own ? px : rx; ry = own ? py : ry; meta_own = own ? pm : meta_own; }
         }
       }
       k_own *= GG;
@@ -866,7 +873,7 @@ struct AnyMDPCoopLine {
       const float px = __shfl(__uint_as_float(b4.z), 8 * j + so);
       const float py = __shfl(__uint_as_float(b4.w), 8 * j + so);
       const uint32_t pm = (uint32_t)__shfl((int)packed, 8 * j + 7);
-      if (g == it) { cnt = co; rx = px; ry = py; meta = pm; }
+      { const bool own = g == it; cnt = own ? co : cnt; rx = own ? px : rx; ry = own ? py : ry; meta = own ? pm : meta; }
     }
   }
   // observation bucket line: 16 doubles, the first 15 are CDF entries (2.0 past the row), the last holds {I, 0x40000000}
@@ -881,7 +888,7 @@ struct AnyMDPCoopLine {
       const unsigned long long m1 = __ballot(xv_u2d(bv[it].z, bv[it].w) <= ue);
       const int co = __popc((unsigned)(m0 >> (8 * j)) & 0xFFu) + __popc((unsigned)(m1 >> (8 * j)) & 0xFFu);
       const uint32_t fi = (uint32_t)__shfl((int)bv[it].z, 8 * j + 7);
-      if (g == it) { cnt = co; first = fi; }
+      { const bool own = g == it; cnt = own ? co : cnt; first = own ? fi : first; }
     }
   }
 };
