@@ -48,6 +48,10 @@ out = mb.step({"anymdp": torch.zeros(1024, dtype=torch.int32, device="cuda"),
                "linds": torch.zeros((512, 8), device="cuda"),
                "cartpole": torch.ones(512, dtype=torch.int32, device="cuda")})
 print({k: tuple(v[0].shape) for k, v in out.items()})
+out = mb.step_fused({"anymdp": torch.zeros(1024, dtype=torch.int32, device="cuda"),      # the same step as ONE kernel launch
+                     "linds": torch.zeros((512, 8), device="cuda"),
+                     "cartpole": torch.ones(512, dtype=torch.int32, device="cuda")})
+print("fused:", {k: tuple(v[0].shape) for k, v in out.items()})
 mb.close()
 
 # 5. mazes with the rule-based teacher on the device: SmartSLAMAgent explores, then walks to the commanded landmarks
