@@ -346,13 +346,20 @@ def test_step_many_equals_single_steps():
         env = LinDSVecEnv(n, autoreset_mode="same_step", seed=5, env_id_base=64)
         env.set_task(tasks, env_task_index=env_task)
         env.reset()
-        if many:
-            ring = env.step_many(K, acts)
+        extra = np.random.RandomState(12).uniform(-1, 1, (n, 8)).astype(np.float32)
+        if many:      # whole ring cycles replay from a hipGraph (tick read from device memory), the remainder is plain launches;
+            ring = env.step_many(K, acts)                 # 2 cycles + 5 steps
+            env.step(extra)                               # an ordinary step in between moves the engine tick
+            ring = env.step_many(2 * P, acts, out=ring)   # cached graph, tick re-synchronised
             rec = {k: _np(v) for k, v in ring.items()}
         else:
             rows = [None] * P
-            for k in range(K):
-                o, r, te, tr, info = env.step(acts[k % P])
+            seq = [acts[k % P] for k in range(K)] + [extra] + [acts[k % P] for k in range(2 * P)]
+            for q, a in enumerate(seq):
+                o, r, te, tr, info = env.step(a)
+                if q == K:
+                    continue
+                k = q if q < K else q - K - 1
                 rows[k % P] = dict(obs=_np(o), reward=_np(r), terminated=_np(te).astype(np.uint8),
                                    truncated=_np(tr).astype(np.uint8), command=_np(info["command"]), error=_np(info["error"]),
                                    final_obs=_np(info["final_obs"]))
