@@ -385,11 +385,11 @@ def main():
         env_task = (torch.arange(n_env, device=env.device, dtype=torch.int32) // per).contiguous()
         env.set_task(tab, env_task_index=env_task)
         search, bucket_gib = choose_search(env, torch, args, n_task, S, A)
-        # a short timed batch is one submission when its ring cycle replays from a hipGraph (20 steps: 154 instead of
-        # 173 us)
-        # round 3: with the 5.3-us step kernel the graph also wins on long runs (2,000 steps: 5.59 vs 5.83 us per step), so
-        # auto = on; `--graph off` issues plain launches
-        graph_mode = args.graph if args.graph != "auto" else "on"
+        # a short timed batch is one submission when its ring cycle replays from a hipGraph (20 steps of the 5.0-us kernel:
+        # 126 vs 129 us of wall clock); on long runs plain launches from C keep ahead of the kernel and the graph's
+        # per-cycle cost shows (2,000 steps: 4.98 vs 5.19 us per step).  auto = the library's own rule (graph for calls of
+        # at most 128 steps, or up to 8,192 envs); `--graph on|off` forces one
+        graph_mode = args.graph
         env.set_step_many_graph(graph_mode)
         device = env.device
         g = torch.Generator(device=device)
@@ -477,24 +477,28 @@ def main():
         if gpu:
             torch.cuda.synchronize()
 
+    class _StopEvent:        # the engine's stop event behind the interface spin_sync polls
+        def query(self):
+            return env.engine.event_done(1)
+
     def timed_pass(with_gather, repeats):
-        """-> (median wall seconds of a K-step batch, median event ms) after MAX over ranks per repetition"""
+        """-> (median wall seconds of a K-step batch, median event ms) after MAX over ranks per repetition.
+        The HIP events are the engine's own (xv_engine_event_*: hipEventRecord on the stream the step kernels are
+        launched on, ~2 us of host time each instead of ~5 for a torch Event)."""
         run(args.warmup, with_gather)
         walls, evs = [], []
+        stop = _StopEvent() if gpu else None
         for _ in range(repeats):
             barrier()
-            e0 = e1 = None
-            if gpu:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
             if gpu:
-                e0.record()
+                env.engine.event_record(0)
             run(args.steps, with_gather)
             if gpu:
-                e1.record()
-            barrier(e1)
+                env.engine.event_record(1)
+            barrier(stop)
             walls.append(time.perf_counter() - t0)
-            evs.append(e0.elapsed_time(e1) if gpu else walls[-1] * 1e3)   # HIP events on the launch stream
+            evs.append(env.engine.event_elapsed_ms() if gpu else walls[-1] * 1e3)   # HIP events on the launch stream
         tt = torch.tensor([walls, evs], dtype=torch.float64)
         if dist is not None:              # MAX over ranks, per repetition
             if dist.get_backend() == "nccl":
@@ -511,7 +515,7 @@ def main():
     wall, ev_ms, walls = timed_pass(False, R)
     state["errs"] = env.check_errors() if env is not None else 0
     state["graph"] = 0
-    if env is not None and graph_mode == "on" and args.steps >= P and int(env.lib.xv_anymdp_step_many_graph_state(env._h)) >= 0:
+    if env is not None and int(env.lib.xv_anymdp_step_many_graph_state(env._h)) == 1:
         state["graph"] = 1
 
     def report(timeout_note=None):

@@ -37,7 +37,7 @@ extern "C" {
  *    graph-replay switches
  * 4: xv_linds_rollout, xv_cartpole_rollout, xv_acrobot_rollout; the maze teachers (xv_maze_agent_*);
  *    xv_maze_set_typing; AnyMDP bucket search (xv_anymdp_build_buckets) */
-#define XV_ABI_VERSION 5
+#define XV_ABI_VERSION 6
 
 /* return codes */
 #define XV_OK 0
@@ -87,6 +87,12 @@ int xv_engine_error_flags(xv_engine* e, int clear, uint32_t* out_flags);
 /* the launch counter that forms the Philox counter's tick word; get/set makes runs resumable */
 int xv_engine_get_tick(xv_engine* e, uint64_t* out_tick);
 int xv_engine_set_tick(xv_engine* e, uint64_t tick);
+/* Two timing events on the engine's own stream (slot 0 = start, 1 = stop), for callers that time a burst of launches
+   without a second event API: record is stream-ordered and asynchronous; done polls without blocking (*done = 1 once
+   everything ahead of the record has finished); elapsed needs both slots finished (XV_ERR_HIP otherwise). */
+int xv_engine_event_record(xv_engine* e, int slot);
+int xv_engine_event_done(xv_engine* e, int slot, int* done);
+int xv_engine_event_elapsed_ms(xv_engine* e, float* ms);
 
 /* Philox4x32-10 known-answer hook: fills out[4*n] on the device from ctr[4*n], key[2] (device ptrs). */
 int xv_philox4x32_10(xv_engine* e, const uint32_t* ctr, const uint32_t* key, uint32_t* out, int n);

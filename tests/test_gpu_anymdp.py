@@ -633,7 +633,7 @@ def test_step_many_graph_replay_equals_plain_launches(search):
     tab = oracle.anymdp_synth(seed=12, task_index_base=0, n_task=8, S=64, A=8, s0_max=4)
     n, P = 512, 8
     rng = np.random.RandomState(5)
-    acts = rng.randint(0, 8, (P, n)).astype(np.int32)
+    acts_np = rng.randint(0, 8, (P, n)).astype(np.int32)
     acts2 = rng.randint(0, 8, (P, n)).astype(np.int32)
     single = rng.randint(0, 8, n).astype(np.int32)
     res = []
@@ -644,6 +644,7 @@ def test_step_many_graph_replay_equals_plain_launches(search):
         env.set_step_many_graph(graph)
         env.reset()
         rec = []
+        acts = torch.as_tensor(acts_np, device=env.device)        # device tensors: the marshalled argument list is cached
         ring = env.step_many(3 * P + 5, acts)                    # 3 cycles + remainder
         rec.append({k: _np(v).copy() for k, v in ring.items()})
         o = env.step(single)                                      # an ordinary step moves the engine tick
@@ -652,6 +653,9 @@ def test_step_many_graph_replay_equals_plain_launches(search):
         rec.append({k: _np(v).copy() for k, v in ring.items()})
         ring2 = env.step_many(P, acts2)                           # other arrays: graph rebuilt
         rec.append({k: _np(v).copy() for k, v in ring2.items()})
+        for _ in range(3):                                        # single cycles: the two tick words alternate
+            ring2 = env.step_many(P, acts2, out=ring2)
+            rec.append({k: _np(v).copy() for k, v in ring2.items()})
         s, st, _ = env.get_state()
         rec.append({"state": _np(s), "steps": _np(st)})
         assert env.check_errors() == 0
@@ -661,6 +665,30 @@ def test_step_many_graph_replay_equals_plain_launches(search):
         for k in a:
             assert np.array_equal(a[k], b[k]), k
     assert res[0][0]["terminated"].sum() > 50
+
+
+def test_engine_timing_events_bracket_a_burst_of_steps():
+    """xv_engine_event_*: two events on the engine's stream; elapsed time of a 64-step burst is positive and below the
+    host's wall clock around the same region"""
+    import time
+    tab = oracle.anymdp_synth(seed=3, task_index_base=0, n_task=4, S=64, A=8, s0_max=4)
+    env = AnyMDPVecEnv(1024, seed=1, autoreset_mode="same_step")
+    env.set_task(_dev_tables(tab))
+    env.reset()
+    acts = torch.randint(0, 8, (8, 1024), device=env.device, dtype=torch.int32)
+    ring = env.step_many(8, acts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    env.engine.event_record(0)
+    env.step_many(64, acts, out=ring)
+    env.engine.event_record(1)
+    while not env.engine.event_done(1):
+        pass
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    assert env.engine.event_done(0)
+    ms = env.engine.event_elapsed_ms()
+    assert 0.0 < ms <= wall_ms
+    env.close()
 
 
 @pytest.mark.parametrize("case", ["golden16", "synth64", "synth100", "sampled64"])

@@ -31,6 +31,9 @@ SIGNATURES = {
     "xv_engine_error_flags": [c_void_p, c_int, C.POINTER(c_u32)],
     "xv_engine_get_tick": [c_void_p, C.POINTER(c_u64)],
     "xv_engine_set_tick": [c_void_p, c_u64],
+    "xv_engine_event_record": [c_void_p, c_int],
+    "xv_engine_event_done": [c_void_p, c_int, C.POINTER(c_int)],
+    "xv_engine_event_elapsed_ms": [c_void_p, C.POINTER(C.c_float)],
     "xv_philox4x32_10": [c_void_p, c_void_p, c_void_p, c_void_p, c_int],
     "xv_anymdp_create": [c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 7 + [C.POINTER(c_void_p)],
     "xv_anymdp_destroy": [c_void_p],
@@ -116,7 +119,7 @@ class XenoError(RuntimeError):
     pass
 
 
-ABI_VERSION = 5      # include/xeno.h XV_ABI_VERSION
+ABI_VERSION = 6      # include/xeno.h XV_ABI_VERSION
 
 
 def load():

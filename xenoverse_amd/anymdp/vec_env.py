@@ -38,6 +38,7 @@ class AnyMDPVecEnv(VectorEnv):
         self._ring = None
         self._set_spaces(Discrete(1), Discrete(1))   # placeholders until set_task, as in the reference
         self._h = None
+        self._many_cache = None
         self._tab = None
 
     # ---- set_task ---------------------------------------------------------------------------------
@@ -105,6 +106,7 @@ class AnyMDPVecEnv(VectorEnv):
             _lib.ptr(dev["term_mask"]), _lib.ptr(dev["s0_cdf"]), _lib.ptr(dev["s0_ids"]),
             _lib.ptr(dev["max_steps"]), _lib.ptr(dev["env_task"]), C.byref(h)))
         self._h = h
+        self._many_cache = None
         self._n_bucket = 0
         self._tab = dev       # keeps the borrowed device tables alive
         self.S, self.A, self.s0_max, self.n_task = S, A, s0_max, n_task
@@ -361,25 +363,34 @@ class AnyMDPVecEnv(VectorEnv):
         self.engine.sync()
         return out
 
+    _MANY_KEYS = ("obs", "reward", "reward_gt", "terminated", "truncated", "final_obs")
+
     def step_many(self, n_steps, actions, out=None):
         """n_steps back-to-back step launches issued from C.  actions int32[P, N] is cycled with period P;
         `out` holds [P, N] ring buffers (allocated when None) — slot k % P receives step k."""
         self._check_step()
-        a = self._dev(actions, torch.int32)
-        P = int(a.shape[0])
-        assert a.shape == (P, self.num_envs)
-        d = self.device
-        if out is None:
-            out = dict(obs=torch.empty((P, self.num_envs), dtype=torch.int32, device=d),
-                       reward=torch.empty((P, self.num_envs), dtype=torch.float32, device=d),
-                       reward_gt=torch.empty((P, self.num_envs), dtype=torch.float32, device=d),
-                       terminated=torch.empty((P, self.num_envs), dtype=torch.uint8, device=d),
-                       truncated=torch.empty((P, self.num_envs), dtype=torch.uint8, device=d),
-                       final_obs=torch.empty((P, self.num_envs), dtype=torch.int32, device=d))
-        _lib.check(self.lib.xv_anymdp_step_many(
-            self._h, int(n_steps), P, _lib.ptr(a), _lib.ptr(out["obs"]), _lib.ptr(out["reward"]),
-            _lib.ptr(out["reward_gt"]), _lib.ptr(out["terminated"]), _lib.ptr(out["truncated"]),
-            _lib.ptr(out.get("final_obs")), AUTORESET[self.autoreset_mode]))
+        c = self._many_cache
+        if c is not None and out is not None and actions is c[0] and all(out.get(k) is t for k, t in zip(self._MANY_KEYS, c[1])):
+            args = c[2]     # the same tensors as in the last call: the marshalled argument list is reused
+        else:
+            a = self._dev(actions, torch.int32)
+            P = int(a.shape[0])
+            assert a.shape == (P, self.num_envs)
+            d = self.device
+            if out is None:
+                out = dict(obs=torch.empty((P, self.num_envs), dtype=torch.int32, device=d),
+                           reward=torch.empty((P, self.num_envs), dtype=torch.float32, device=d),
+                           reward_gt=torch.empty((P, self.num_envs), dtype=torch.float32, device=d),
+                           terminated=torch.empty((P, self.num_envs), dtype=torch.uint8, device=d),
+                           truncated=torch.empty((P, self.num_envs), dtype=torch.uint8, device=d),
+                           final_obs=torch.empty((P, self.num_envs), dtype=torch.int32, device=d))
+            for k in self._MANY_KEYS[:5]:
+                assert tuple(out[k].shape) == (P, self.num_envs) and out[k].device == d, k
+            args = (P, _lib.ptr(a), _lib.ptr(out["obs"]), _lib.ptr(out["reward"]), _lib.ptr(out["reward_gt"]),
+                    _lib.ptr(out["terminated"]), _lib.ptr(out["truncated"]), _lib.ptr(out.get("final_obs")))
+            # `a` is kept alive with the cache entry when _dev had to convert `actions`
+            self._many_cache = (actions, tuple(out.get(k) for k in self._MANY_KEYS), args, a) if a is actions else None
+        _lib.check(self.lib.xv_anymdp_step_many(self._h, int(n_steps), *args, AUTORESET[self.autoreset_mode]))
         return out
 
     def set_step_many_graph(self, mode):

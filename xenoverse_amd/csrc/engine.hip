@@ -34,6 +34,8 @@ extern "C" int xv_engine_create(int device, uint64_t seed, uint64_t env_id_base,
   e->own_stream = (hip_stream == XV_STREAM_OWN);
   e->stream = e->own_stream ? nullptr : (hipStream_t)hip_stream;
   e->d_err = nullptr;
+  e->ev[0] = e->ev[1] = nullptr;
+  e->ev_made = false;
   if (e->own_stream) {
     hipError_t s = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (s != hipSuccess) {
@@ -59,6 +61,7 @@ extern "C" int xv_engine_destroy(xv_engine* e) {
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
   if (e->d_err) hipFree(e->d_err);
+  if (e->ev_made) { hipEventDestroy(e->ev[0]); hipEventDestroy(e->ev[1]); }
   if (e->own_stream) hipStreamDestroy(e->stream);
   delete e;
   return XV_OK;
@@ -90,6 +93,32 @@ extern "C" int xv_engine_get_tick(xv_engine* e, uint64_t* out_tick) {
 extern "C" int xv_engine_set_tick(xv_engine* e, uint64_t tick) {
   XV_CHECK_ARG(e != nullptr);
   e->tick = tick;
+  return XV_OK;
+}
+
+extern "C" int xv_engine_event_record(xv_engine* e, int slot) {
+  XV_CHECK_ARG(e != nullptr && (slot == 0 || slot == 1));
+  if (!e->ev_made) {
+    XV_HIP(hipSetDevice(e->device));
+    XV_HIP(hipEventCreate(&e->ev[0]));
+    XV_HIP(hipEventCreate(&e->ev[1]));
+    e->ev_made = true;
+  }
+  XV_HIP(hipEventRecord(e->ev[slot], e->stream));
+  return XV_OK;
+}
+
+extern "C" int xv_engine_event_done(xv_engine* e, int slot, int* done) {
+  XV_CHECK_ARG(e != nullptr && (slot == 0 || slot == 1) && done != nullptr && e->ev_made);
+  const hipError_t q = hipEventQuery(e->ev[slot]);
+  *done = q == hipSuccess;
+  if (q != hipSuccess && q != hipErrorNotReady) XV_HIP(q);
+  return XV_OK;
+}
+
+extern "C" int xv_engine_event_elapsed_ms(xv_engine* e, float* ms) {
+  XV_CHECK_ARG(e != nullptr && ms != nullptr && e->ev_made);
+  XV_HIP(hipEventElapsedTime(ms, e->ev[0], e->ev[1]));
   return XV_OK;
 }
 

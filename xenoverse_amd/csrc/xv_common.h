@@ -16,6 +16,8 @@ struct xv_engine {
   uint64_t env_id_base;
   uint64_t tick;        // launch counter: Philox counter word, advanced by every stochastic launch
   uint32_t* d_err;      // sticky device error word
+  hipEvent_t ev[2];     // xv_engine_event_*: created on first use
+  bool ev_made;
 };
 
 // thread-local error text (xv_last_error)

@@ -48,6 +48,20 @@ class Engine(object):
     def tick(self, value):
         _lib.check(self.lib.xv_engine_set_tick(self.handle, int(value)))
 
+    # ---- timing events on the engine's own stream (xv_engine_event_*) ----------------------------------------
+    def event_record(self, slot):
+        _lib.check(self.lib.xv_engine_event_record(self.handle, int(slot)))
+
+    def event_done(self, slot):
+        v = C.c_int(0)
+        _lib.check(self.lib.xv_engine_event_done(self.handle, int(slot), C.byref(v)))
+        return bool(v.value)
+
+    def event_elapsed_ms(self):
+        v = C.c_float(0.0)
+        _lib.check(self.lib.xv_engine_event_elapsed_ms(self.handle, C.byref(v)))
+        return float(v.value)
+
     def philox(self, ctr, key):
         """Philox4x32-10 known-answer hook: ctr uint32[n,4], key uint32[2] -> uint32[n,4] (device)."""
         ctr = torch.as_tensor(ctr, dtype=torch.int64).to(torch.int32).to(self.device).contiguous() \
