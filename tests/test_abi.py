@@ -88,3 +88,14 @@ def test_header_is_plain_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
                            str(src), "-o", exe])
     assert subprocess.call([exe]) == 0
+
+
+def test_build_tracks_sources_included_by_sources():
+    """mixed.hip is compiled from the three family sources it #includes: a change to any of them must rebuild mixed.o
+    (a stale object there reads the family handles with an old layout)"""
+    import os
+    from xenoverse_amd import build as xb
+    deps = {os.path.basename(p) for p in xb._includes(os.path.join(xb.CSRC, "mixed.hip"), set())}
+    assert {"anymdp.hip", "linds.hip", "cartpole.hip", "xv_common.h", "philox.h", "xeno.h"} <= deps
+    newest = max(os.path.getmtime(os.path.join(xb.CSRC, f)) for f in ("anymdp.hip", "linds.hip", "cartpole.hip"))
+    assert xb._deps_mtime(os.path.join(xb.CSRC, "mixed.hip")) >= newest

@@ -39,17 +39,40 @@ def source_hash(names):
     return h.hexdigest()[:16]
 
 
-def _deps_mtime():
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hs.append(os.path.join(os.path.dirname(HERE), "include", "xeno.h"))
-    return max(os.path.getmtime(h) for h in hs)
+_INC = None
+
+
+def _includes(path, seen):
+    """the csrc / include files `path` pulls in through #include "..." (recursively; .hip files include .hip files:
+    mixed.hip is built from the three family sources)"""
+    import re
+    global _INC
+    if _INC is None:
+        _INC = re.compile(r'^\s*#\s*include\s*"([^"]+)"', re.M)
+    with open(path) as f:
+        text = f.read()
+    for name in _INC.findall(text):
+        for d in (os.path.dirname(path), CSRC, os.path.join(os.path.dirname(HERE), "include")):
+            q = os.path.join(d, name)
+            if os.path.exists(q):
+                if q not in seen:
+                    seen.add(q)
+                    _includes(q, seen)
+                break
+    return seen
+
+
+def _deps_mtime(src_path):
+    deps = _includes(src_path, set())
+    deps.add(os.path.join(os.path.dirname(HERE), "include", "xeno.h"))
+    return max(os.path.getmtime(d) for d in deps)
 
 
 def _compile(src, force, extra):
     obj = os.path.join(OBJ, src[:-4] + ".o")
     s = os.path.join(CSRC, src)
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(s)
-            and os.path.getmtime(obj) > _deps_mtime()):
+            and os.path.getmtime(obj) > _deps_mtime(s)):
         return obj, False
     cmd = [_hipcc()] + FLAGS + extra + ["-c", s, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)

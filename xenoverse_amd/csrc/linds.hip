@@ -625,7 +625,14 @@ typedef float xv_f32x4 __attribute__((ext_vector_type(4)));
 // read before the matrix unit has written it — observed as wrong observation rows 3, 7, 11, 15 while the state stayed
 // right.  The chains whose results are consumed after a branch are therefore followed by the wait states themselves.
 // (the asm names the accumulator tuple as an in/out AGPR operand, which orders it after the MFMA and before the reads)
+#ifndef XV_LINDS_ACC_AGPR
+#define XV_LINDS_ACC_AGPR 1
+#endif
+#if XV_LINDS_ACC_AGPR
 __device__ __forceinline__ void xv_mfma_settle(xv_f32x4& acc) { asm volatile("s_nop 7\n\ts_nop 3" : "+a"(acc)); }
+#else
+__device__ __forceinline__ void xv_mfma_settle(xv_f32x4& acc) { asm volatile("s_nop 7\n\ts_nop 3" : "+v"(acc)); }
+#endif
 
 __device__ __forceinline__ float xv_sel4(int g, float a, float b, float c, float d) {
   asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
