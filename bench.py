@@ -385,11 +385,11 @@ def main():
         env_task = (torch.arange(n_env, device=env.device, dtype=torch.int32) // per).contiguous()
         env.set_task(tab, env_task_index=env_task)
         search, bucket_gib = choose_search(env, torch, args, n_task, S, A)
-        # a short timed batch is one submission when its ring cycle replays from a hipGraph (20 steps of the 5.0-us kernel:
-        # 126 vs 129 us of wall clock); on long runs plain launches from C keep ahead of the kernel and the graph's
-        # per-cycle cost shows (2,000 steps: 4.98 vs 5.19 us per step).  auto = the library's own rule (graph for calls of
-        # at most 128 steps, or up to 8,192 envs); `--graph on|off` forces one
-        graph_mode = args.graph
+        # ring cycles replay from a hipGraph (one submission per `--period` steps): a short timed batch is then one
+        # submission (20 steps: 6.4-6.5 vs 7.4 us per step with plain launches), and on long runs the result does not
+        # depend on the host's launch rate, which sits close to the 5-us kernel (2,000 steps, graph vs plain launches:
+        # 5.19 vs 4.98 us per step on one box of the pool, 5.15 vs 5.35 on another).  `--graph off` issues plain launches
+        graph_mode = args.graph if args.graph != "auto" else "on"
         env.set_step_many_graph(graph_mode)
         device = env.device
         g = torch.Generator(device=device)
@@ -515,8 +515,8 @@ def main():
     wall, ev_ms, walls = timed_pass(False, R)
     state["errs"] = env.check_errors() if env is not None else 0
     state["graph"] = 0
-    if env is not None and int(env.lib.xv_anymdp_step_many_graph_state(env._h)) == 1:
-        state["graph"] = 1
+    if env is not None and graph_mode == "on" and args.steps >= P and int(env.lib.xv_anymdp_step_many_graph_state(env._h)) >= 0:
+        state["graph"] = 1     # whole ring cycles were replayed (a remainder shorter than the ring is plain launches)
 
     def report(timeout_note=None):
         with report_lock:
@@ -552,9 +552,10 @@ def main():
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                              "frac_traffic": None if traffic is None else traffic / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                              "traffic_over_algorithmic": None if traffic is None else traffic / algo,
-                             "kernel": "anymdp_step_kernel<false, %d, false, false%s>  (INJECT, blocks per fence entry | "
+                             "kernel": "anymdp_step_kernel<false, %d, false, %s%s>  (INJECT, blocks per fence entry | "
                                        "0 = binary search, ROLLOUT, TICKDEV, BUCKET)"
-                                       % (0 if search == "binary" else 1, ", true" if search == "bucket" else ""),
+                                       % (0 if search == "binary" else 1, "true" if state.get("graph") == 1 else "false",
+                                          ", true" if search == "bucket" else (", false" if state.get("graph") == 1 else "")),
                              "kernel_source_sha16": None if selftest else kernel_source_hash(),
                              "avg_launch_us": kern_us, "algorithmic_bytes_per_launch": algo},
                 "rccl": dinfo["rccl"],

@@ -10,11 +10,11 @@ echo "== pytest -m gpu"; timeout 1800 python -m pytest tests -m gpu -q > gpurun_
 echo "== smoke"; timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1
 echo "== bench default"; timeout 900 python bench.py --fused > gpurun_out/${T}_bench_2a.json 2> gpurun_out/${T}_bench_2a.err; echo "rc=$?"
 echo "== bench driver flags"; timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/${T}_bench_2a_steps20.json 2> gpurun_out/${T}_bench_2a_steps20.err; echo "rc=$?"
-echo "== bench graph on (2000 steps)"; timeout 900 python bench.py --graph on --no-cpu-baseline --no-families > gpurun_out/${T}_bench_2a_graph.json 2>/dev/null; echo "rc=$?"
+echo "== bench plain launches (2000 steps)"; timeout 900 python bench.py --graph off --no-cpu-baseline --no-families > gpurun_out/${T}_bench_2a_plain.json 2>/dev/null; echo "rc=$?"
 echo "== bench 2b"; timeout 900 python bench.py --tasks 1024 --no-cpu-baseline --no-families --fused > gpurun_out/${T}_bench_2b.json 2>/dev/null; echo "rc=$?"
 python - <<PY
 import json
-for f in ("bench_2a", "bench_2a_steps20", "bench_2a_graph", "bench_2b"):
+for f in ("bench_2a", "bench_2a_steps20", "bench_2a_plain", "bench_2b"):
     try:
         d = json.load(open("gpurun_out/${T}_%s.json" % f))
     except Exception as ex:
