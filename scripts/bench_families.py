@@ -189,7 +189,10 @@ def bench_anymdp_tok(args):
     from xenoverse_amd.anymdp import AnyMDPVecEnv, row_lines
     from xenoverse_amd.engine import AUTORESET
     n, n_task, S, A, n_obs, d_obs, d_act = 65536, 1024, 64, 8, 64, 2, 2
-    env = AnyMDPVecEnv(n, seed=1, autoreset_mode="same_step")
+    d_obs = int(os.environ.get("XV_TOK_DOBS", d_obs))      # decomposition runs (scripts/runs_r03): other token counts
+    d_act = int(os.environ.get("XV_TOK_DACT", d_act))
+    mode = os.environ.get("XV_TOK_MODE", "same_step")
+    env = AnyMDPVecEnv(n, seed=1, autoreset_mode=mode)
     d = env.device
     tab = dict(S=S, A=A, s0_max=4, rows=torch.empty((n_task, S, A, row_lines(S), 16), dtype=torch.float64, device=d),
                state_map=torch.empty((n_task, S), dtype=torch.int32, device=d),
@@ -213,12 +216,12 @@ def bench_anymdp_tok(args):
     def step():
         _lib.check(env.lib.xv_anymdp_step_tokens(env._h, _lib.ptr(a), _lib.ptr(tobs), _lib.ptr(env._reward),
                                                  _lib.ptr(env._reward_gt), _lib.ptr(env._term), _lib.ptr(env._trunc),
-                                                 _lib.ptr(tfobs), AUTORESET["same_step"]))
+                                                 _lib.ptr(tfobs), AUTORESET[mode]))
     us = timed(step, args.steps, args.warmup)
     env.set_search("bucket", n_bucket=16)      # transitions through the bucket lines (one dependent level each)
     us_b = timed(step, args.steps, args.warmup)
     env.close()
-    return {"family": "anymdp multi-token POMDP", "workload": "65,536 envs, 1,024 tasks, S=64 A=8 n_obs=64 d_obs=2 d_act=2",
+    return {"family": "anymdp multi-token POMDP", "workload": "65,536 envs, 1,024 tasks, S=64 A=8 n_obs=64 d_obs=%d d_act=%d%s" % (d_obs, d_act, "" if mode == "same_step" else ", " + mode),
             "dtype": "f64", "env_steps_per_s": n / (min(us, us_b) * 1e-6), "us_per_step": {"binary search": us, "bucket lines": us_b},
             "note": "per-lane searches (general path); 2 transition + 2 observation draws per env-step"}
 
