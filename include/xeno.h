@@ -523,11 +523,16 @@ int xv_maze_render(xv_maze* h, uint8_t* frames, float* command_rgb);
  * of an env in one lane; NINE_LANES / THREE_LANES give an env the lanes of its 3x3 wall neighbourhood (one cell or one
  * row of cells each), evaluate the position-independent part of all sub-steps (heading, sin / cos, displacement) in
  * parallel first and keep only the position chain sequential (dynamics.py:98-123,158-187); AUTO picks nine or three
- * lanes by the batch size. */
+ * lanes by the batch size.  NINE_LANES_COMPACT (what AUTO uses from 10,240 envs up): an env whose action has no walk
+ * speed and whose 3x3 neighbourhood holds no wall within collision distance keeps its position through all sub-steps
+ * (every displacement is +-0 and every push-out force exactly 0) — a first kernel finishes those envs (heading
+ * recurrence + rules) and lists the others, and the nine-lane kernel walks the listed envs only (10 of the 16
+ * Discrete16 actions only turn). */
 #define XV_MAZE_MOVE_LANE_PER_ENV 0
 #define XV_MAZE_MOVE_NINE_LANES 1
 #define XV_MAZE_MOVE_THREE_LANES 2
 #define XV_MAZE_MOVE_AUTO 3
+#define XV_MAZE_MOVE_NINE_LANES_COMPACT 4
 int xv_maze_set_move_kernel(xv_maze* h, int kernel);
 #define XV_MAZE_FILTER_EXACT 0
 #define XV_MAZE_FILTER_F32 1

@@ -239,7 +239,9 @@ def test_nine_lane_move_kernel_equals_the_lane_per_env_kernel(mode, space):
     acts = rng.uniform(-1.2, 1.2, (T, n, 2)) if space == "Continuous" else \
         rng.randint(0, 16 if space == "Discrete16" else 32, (T, n)).astype(np.int32)
     recs = []
-    for kern in ("lane_per_env", "nine_lanes", "three_lanes"):
+    # nine_lanes_compact: envs that only turn away from every wall are finished by the sorting kernel, the nine-lane
+    # kernel walks the listed rest (Discrete16 / 32: both kinds present; Continuous: every env walks)
+    for kern in ("lane_per_env", "nine_lanes", "three_lanes", "nine_lanes_compact"):
         env = MazeWorldVecEnv(n, resolution=(32, 32), textures=tex(), autoreset_mode=mode, max_steps=17,
                               action_space_type=space, seed=2)
         env.set_task(tasks, env_task_index=env_task)
@@ -256,8 +258,8 @@ def test_nine_lane_move_kernel_equals_the_lane_per_env_kernel(mode, space):
         recs.append(rec)
         assert any(float(x.max()) > 0 for x in rec[10::11])        # walls were touched (collision > 0 somewhere)
         env.close()
-    for a, b, c in zip(*recs):
-        assert np.array_equal(a, b) and np.array_equal(a, c)
+    for a, b, c, d in zip(*recs):
+        assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d)
 
 
 def test_numba_typing_variant_follows_its_oracle():

@@ -41,6 +41,10 @@ struct xv_maze {
   bool typing_numba = false; // xv_maze_set_typing
   bool move_lanes9 = true;   // xv_maze_set_move_kernel
   int move_lanes = 0;        // 0: by batch size; 3 or 9: forced (xv_maze_set_move_kernel)
+  int move_compact = -1;     // -1: by batch size; 0 / 1: forced (xv_maze_set_move_kernel)
+  int32_t* move_list = nullptr;   // [n_env] envs the nine-lane kernel has to walk this step (maze_move_sort_kernel)
+  int32_t* move_count = nullptr;  // [2] their number; the two words alternate between steps
+  int move_word = 0;
 };
 
 static __device__ const double MZ_ACT16[16][2] = {{0.0, 0.5}, {0.05, 0.0}, {-0.05, 0.0}, {0.1, 0.0}, {-0.1, 0.0}, {0.2, 0.0},

@@ -166,10 +166,11 @@ class MazeWorldVecEnv(VectorEnv):
                 self._obf(self._trunc), infos)
 
     def set_move_kernel(self, kernel):
-        """"auto" (default: nine or three lanes per env by batch size), "nine_lanes", "three_lanes" or "lane_per_env":
+        """"auto" (default: nine or three lanes per env by batch size; from 10,240 envs up the nine-lane kernel walks only the
+        envs that can move or touch a wall), "nine_lanes", "nine_lanes_compact", "three_lanes" or "lane_per_env":
         arrangements of the same move / collision arithmetic, identical results"""
         _lib.check(self.lib.xv_maze_set_move_kernel(self._h, {"lane_per_env": 0, "nine_lanes": 1, "three_lanes": 2,
-                                                              "auto": 3}[kernel]))
+                                                              "auto": 3, "nine_lanes_compact": 4}[kernel]))
 
     def render_frames(self):
         """frames of the current state, without stepping"""
