@@ -525,8 +525,9 @@ int xv_maze_render(xv_maze* h, uint8_t* frames, float* command_rgb);
  * parallel first and keep only the position chain sequential (dynamics.py:98-123,158-187); AUTO picks nine or three
  * lanes by the batch size.  NINE_LANES_COMPACT (what AUTO uses from 10,240 envs up): an env whose action has no walk
  * speed and whose 3x3 neighbourhood holds no wall within collision distance keeps its position through all sub-steps
- * (every displacement is +-0 and every push-out force exactly 0) — a first kernel finishes those envs (heading
- * recurrence + rules) and lists the others, and the nine-lane kernel walks the listed envs only (10 of the 16
+ * (every displacement is +-0 and every push-out force exactly 0) — a first kernel sorts the batch into envs to walk
+ * and envs that stand still, the nine-lane kernel walks the first kind and its spare workgroups finish the second
+ * (heading recurrence + rules) beside them (10 of the 16
  * Discrete16 actions only turn). */
 #define XV_MAZE_MOVE_LANE_PER_ENV 0
 #define XV_MAZE_MOVE_NINE_LANES 1

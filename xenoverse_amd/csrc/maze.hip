@@ -315,8 +315,8 @@ constexpr int MZ_NSUB = 100;     // sub-steps of a move that are not skipped (se
 // L lanes per env (9: one neighbour cell each; 3: one row of three cells each), 64 / L envs per wave.  Which one is
 // faster is a matter of filling the chip: every lane of an env repeats the position arithmetic, so more lanes per env
 // mean more waves issuing the same instructions (xv_maze_step picks L from the batch size).
-// `list` / `count` (nullable): walk only the envs list[0 .. *count) (maze_move_sort_kernel); the grid then covers
-// n_env and the workgroups past the list return at once.
+// `list` / `count` (nullable; maze_move_sort_kernel): walk only the envs list[0 .. count[0]); the grid is sized for
+// every env, and the workgroups past the walked ones finish the count[1] envs that stand still (list[n_env - 1 - k]).
 template <int L>
 __global__ __launch_bounds__(64) void maze_step9_kernel(MazeArgs P, const void* action, int action_mode, float* reward,
                                                         uint8_t* terminated, uint8_t* truncated, int mode,
@@ -325,8 +325,25 @@ __global__ __launch_bounds__(64) void maze_step9_kernel(MazeArgs P, const void* 
   __shared__ double2 s_d[MZ_EPW + 1][MZ_SUBMAX];
   __shared__ double2 s_g[(MZ_EPW + 1) * 9];
   const int lane = threadIdx.x, q = lane / L, cell = lane - L * q;   // `cell`: this lane's index within its env
-  const int n_walk = list ? *count : P.n_env;
-  if ((int)blockIdx.x * MZ_EPW >= n_walk) return;   // uniform
+  const int n_walk = list ? count[0] : P.n_env;
+  if ((int)blockIdx.x * MZ_EPW >= n_walk) {   // uniform: a workgroup past the walked envs
+    // finishes 64 of the envs that stand still (listed from the end of `list`): heading recurrence, rules, stores —
+    // a few microseconds beside the walking workgroups' ~85
+    if (list == nullptr) return;
+    const int k = ((int)blockIdx.x - (n_walk + MZ_EPW - 1) / MZ_EPW) * 64 + lane;
+    if (k >= count[1]) return;
+    const int e = list[P.n_env - 1 - k];
+    double turn_rate, walk_speed;
+    uint32_t err = 0;
+    mz_decode_action(action, action_mode, e, turn_rate, walk_speed, err);
+    const double d_theta = turn_rate * 0.01;
+    double ori = P.ori[e];
+    for (int c = 0; c < MZ_NSUB; ++c) ori = mz_angle_norm(ori + d_theta);
+    P.fin_flag[e] = 0;
+    mz_finish_move(P, e, P.env_task[e], P.pos[e], P.pos[(size_t)P.n_env + e], ori, 0.0, err, mode, reward, terminated,
+                   truncated);
+    return;
+  }
   const int slot = blockIdx.x * MZ_EPW + q;
   const bool active = q < MZ_EPW && slot < n_walk;
   // idle lanes shadow a real env (the workgroup's first when a list is walked) and store nothing
@@ -467,15 +484,14 @@ __global__ __launch_bounds__(64) void maze_step9_kernel(MazeArgs P, const void* 
 // if at p none of the nine cells pushes (each is either no wall or farther than the collision distance: the zero
 // filter of maze_step9_kernel, evaluated here on the same operands) the force sum is exactly 0 and p = 0 + e = p: the
 // env stands still through all 100 sub-steps, collision 0, and only its heading turns.  10 of the 16 Discrete16 actions
-// are turns.  One thread per env: such envs are finished here (heading recurrence, rules, stores — mz_finish_move, as
-// the walking kernels do), the others are appended to `list` (order does not matter: envs are independent).  count[w]
-// is this step's counter, count[w ^ 1] is zeroed for the next step.
+// are turns.  One thread per env sorts the batch: envs to walk are listed from the front of `list`, envs that stand still
+// from its end (one atomic per wave and kind; order does not matter, envs are independent).  count[2 w], count[2 w + 1]
+// are this step's counters, the other pair is zeroed for the next step.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void maze_move_sort_kernel(MazeArgs P, const void* action, int action_mode, float* reward,
-                                                             uint8_t* terminated, uint8_t* truncated, int mode,
+__global__ __launch_bounds__(256) void maze_move_sort_kernel(MazeArgs P, const void* action, int action_mode, int mode,
                                                              int32_t* list, int32_t* count, int w) {
   const int e_raw = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e_raw == 0) count[w ^ 1] = 0;
+  if (e_raw == 0) { count[2 * (w ^ 1)] = 0; count[2 * (w ^ 1) + 1] = 0; }
   const bool valid = e_raw < P.n_env;
   const int e = valid ? e_raw : P.n_env - 1;
   const size_t N = (size_t)P.n_env;
@@ -490,42 +506,42 @@ __global__ __launch_bounds__(256) void maze_move_sort_kernel(MazeArgs P, const v
   const double cell_size = db[0];
   const double p0 = P.pos[e], p1 = P.pos[N + e];
   bool still = valid && !resetting && walk_speed == 0.0 && p0 > 0.0 && p1 > 0.0;   // (p > 0: p + -0 and 0 + p keep p's bits)
-  if (still) {
+  {
     const int8_t* walls = P.T.walls + (size_t)t * NG * NG;
     const MzDivisor R_cs = mz_divisor(cell_size);
     const double eff_cd = P.collision_dist / cell_size;
     const double c0 = mz_div(p0, R_cs), c1 = mz_div(p1, R_cs);
     const int b0 = (int)c0, b1 = (int)c1;
     const double fr0 = c0 - floor(c0), fr1 = c1 - floor(c1);
+    int8_t wv[9];
+#pragma unroll
+    for (int idx = 0; idx < 9; ++idx) {   // all nine bytes requested at once
+      const int wi = b0 + idx / 3 - 1, wj = b1 + idx % 3 - 1;
+      const int ri = wi < 0 ? 0 : (wi >= NG ? NG - 1 : wi), rj = wj < 0 ? 0 : (wj >= NG ? NG - 1 : wj);
+      wv[idx] = walls[ri * NG + rj];
+    }
 #pragma unroll
     for (int idx = 0; idx < 9; ++idx) {
-      const int ni = idx / 3 - 1, nj = idx - 3 * (idx / 3) - 1;
+      const int ni = idx / 3 - 1, nj = idx % 3 - 1;
       const int wi = b0 + ni, wj = b1 + nj;
-      const int ri = wi < 0 ? 0 : (wi >= NG ? NG - 1 : wi), rj = wj < 0 ? 0 : (wj >= NG ? NG - 1 : wj);
-      const bool wall = wi > -1 && wi < n && wj > -1 && wj < n && walls[ri * NG + rj] > 0;
+      const bool wall = wi > -1 && wi < n && wj > -1 && wj < n && wv[idx] > 0;
       const double v0 = fr0 - (double)(float)(ni + 0.5), v1 = fr1 - (double)(float)(nj + 0.5);
       const double cheb = __builtin_fmax(fabs(v0), fabs(v1)) - 0.5;
       if (wall && !(cheb > eff_cd + 1.0e-9)) still = false;
     }
   }
-  if (still) {
-    const double d_theta = turn_rate * 0.01;
-    double ori = P.ori[e];
-    for (int k = 0; k < MZ_NSUB; ++k) ori = mz_angle_norm(ori + d_theta);
-    P.fin_flag[e] = 0;
-    mz_finish_move(P, e, t, p0, p1, ori, 0.0, err, mode, reward, terminated, truncated);
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const unsigned long long mw = __ballot(valid && !still), ms = __ballot(valid && still);
+  int base_w = 0, base_s = 0;
+  if (lane == 0) {
+    if (mw) base_w = atomicAdd(count + 2 * w, __popcll(mw));
+    if (ms) base_s = atomicAdd(count + 2 * w + 1, __popcll(ms));
   }
-  // the others: one atomic per wave, slots handed out in lane order
-  const bool walk = valid && !still;
-  const unsigned long long m = __ballot(walk);
-  if (m != 0ull) {
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(count + w, __popcll(m));
-    base = __shfl(base, leader);
-    if (walk) list[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
-  }
+  base_w = __shfl(base_w, 0);
+  base_s = __shfl(base_s, 0);
+  if (valid && !still) list[base_w + __popcll(mw & below)] = e;
+  if (valid && still) list[P.n_env - 1 - (base_s + __popcll(ms & below))] = e;
 }
 
 // interpolate, ray_caster_utils.py:123-140 (see oracle mz_interpolate for the typing).
@@ -969,8 +985,8 @@ extern "C" int xv_maze_create(xv_engine* e, int n_env, int n_task, int NG, int n
   if (m == hipSuccess) m = hipMalloc(&a.fin_cmd, 4 * n);
   if (m == hipSuccess) m = hipMalloc(&a.fin_flag, n);
   if (m == hipSuccess) m = hipMalloc(&h->move_list, 4 * n);
-  if (m == hipSuccess) m = hipMalloc(&h->move_count, 2 * sizeof(int32_t));
-  if (m == hipSuccess) m = hipMemsetAsync(h->move_count, 0, 2 * sizeof(int32_t), e->stream);
+  if (m == hipSuccess) m = hipMalloc(&h->move_count, 4 * sizeof(int32_t));
+  if (m == hipSuccess) m = hipMemsetAsync(h->move_count, 0, 4 * sizeof(int32_t), e->stream);
   if (m == hipSuccess) m = hipMemsetAsync(a.need_reset, 1, n, e->stream);
   if (m == hipSuccess) m = hipMemsetAsync(a.fin_flag, 0, n, e->stream);
   if (m != hipSuccess) {
@@ -1107,8 +1123,8 @@ extern "C" int xv_maze_step(xv_maze* h, const void* action, int action_mode, uin
   // lanes per env: enough waves to give every SIMD work, no more (the lanes of an env repeat the position arithmetic)
   // (measured at 16,384 envs: 169 us with nine lanes, 225 us with three, 269 us with the lane-per-env kernel)
   const int lanes = h->move_lanes > 0 ? h->move_lanes : (h->a.n_env <= 32768 ? 9 : 3);
-  // envs that cannot leave their position are finished by a one-thread-per-env kernel and the nine-lane kernel walks the
-  // rest.  Measured (uniform Discrete16 actions): 16,384 envs 138 -> 99 us, a batch of turning envs 50 -> 11 us; but
+  // a one-thread-per-env kernel sorts the batch into envs to walk and envs that cannot leave their position; the
+  // nine-lane kernel walks the first kind and its spare workgroups finish the second.  Measured (uniform Discrete16 actions): 16,384 envs 138 -> 99 us, a batch of turning envs 50 -> 11 us; but
   // 6,144 envs 84 -> 96 us and 16,384 envs that all walk 140 -> 148 us: the sorting launch costs ~10 us and only pays
   // when the unsorted walk has more than one wave per SIMD (7 envs per wave, 1,024 SIMDs), hence AUTO's threshold
   const bool compact = h->move_lanes9 && lanes == 9 && h->move_list != nullptr &&
@@ -1117,10 +1133,10 @@ extern "C" int xv_maze_step(xv_maze* h, const void* action, int action_mode, uin
     const int w = h->move_word;
     h->move_word ^= 1;
     hipLaunchKernelGGL(maze_move_sort_kernel, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream, h->a, action,
-                       action_mode, reward, terminated, truncated, autoreset_mode, h->move_list, h->move_count, w);
-    hipLaunchKernelGGL(maze_step9_kernel<9>, dim3(xv_div_up(h->a.n_env, 7)), dim3(64), 0, h->eng->stream, h->a, action,
+                       action_mode, autoreset_mode, h->move_list, h->move_count, w);
+    hipLaunchKernelGGL(maze_step9_kernel<9>, dim3(xv_div_up(h->a.n_env, 7) + 1), dim3(64), 0, h->eng->stream, h->a, action,
                        action_mode, reward, terminated, truncated, autoreset_mode, (const int32_t*)h->move_list,
-                       (const int32_t*)(h->move_count + w));
+                       (const int32_t*)(h->move_count + 2 * w));
   } else if (h->move_lanes9 && lanes == 9)
     hipLaunchKernelGGL(maze_step9_kernel<9>, dim3(xv_div_up(h->a.n_env, 7)), dim3(64), 0, h->eng->stream, h->a, action,
                        action_mode, reward, terminated, truncated, autoreset_mode, (const int32_t*)nullptr,

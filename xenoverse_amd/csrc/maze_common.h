@@ -43,7 +43,7 @@ struct xv_maze {
   int move_lanes = 0;        // 0: by batch size; 3 or 9: forced (xv_maze_set_move_kernel)
   int move_compact = -1;     // -1: by batch size; 0 / 1: forced (xv_maze_set_move_kernel)
   int32_t* move_list = nullptr;   // [n_env] envs the nine-lane kernel has to walk this step (maze_move_sort_kernel)
-  int32_t* move_count = nullptr;  // [2] their number; the two words alternate between steps
+  int32_t* move_count = nullptr;  // [2][2] {envs to walk, envs standing still}; the two pairs alternate between steps
   int move_word = 0;
 };
 
