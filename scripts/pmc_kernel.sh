@@ -11,6 +11,8 @@ PMCG=("FETCH_SIZE" "WRITE_SIZE"
         "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES"
         "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_MFMA"
         "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE")
+# PMC_EXTRA="group one|group two": further passes (e.g. the texture path: TA_* / TCP_* counters)
+if [ -n "${PMC_EXTRA:-}" ]; then IFS='|' read -r -a EXTRA <<< "$PMC_EXTRA"; PMCG+=("${EXTRA[@]}"); fi
 i=0
 for g in "${PMCG[@]}"; do
   d=gpurun_out/pmc_${TAG}_g$i
