@@ -1126,9 +1126,11 @@ extern "C" int xv_maze_step(xv_maze* h, const void* action, int action_mode, uin
   // a one-thread-per-env kernel sorts the batch into envs to walk and envs that cannot leave their position; the
   // nine-lane kernel walks the first kind and its spare workgroups finish the second.  Measured (uniform Discrete16 actions): 16,384 envs 138 -> 99 us, a batch of turning envs 50 -> 11 us; but
   // 6,144 envs 84 -> 96 us and 16,384 envs that all walk 140 -> 148 us: the sorting launch costs ~10 us and only pays
-  // when the unsorted walk has more than one wave per SIMD (7 envs per wave, 1,024 SIMDs), hence AUTO's threshold
+  // when the unsorted walk has more than one wave per SIMD (7 envs per wave, 1,024 SIMDs), hence AUTO's threshold;
+  // continuous actions have a walk speed of exactly 0 by accident only: AUTO does not sort them
   const bool compact = h->move_lanes9 && lanes == 9 && h->move_list != nullptr &&
-                       (h->move_compact >= 0 ? h->move_compact == 1 : h->a.n_env >= 10240);
+                       (h->move_compact >= 0 ? h->move_compact == 1
+                                              : (h->a.n_env >= 10240 && action_mode != XV_MAZE_ACTION_CONTINUOUS));
   if (compact) {
     const int w = h->move_word;
     h->move_word ^= 1;
