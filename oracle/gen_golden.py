@@ -660,7 +660,7 @@ def gen_anymdp_vi():
     print("sampler_vi_ref.npz", os.path.getsize(os.path.join(GOLD, "sampler_vi_ref.npz")) // 1024, "KiB")
 
 
-def gen_anymdp_sampled(n=32, seed0=100):
+def gen_anymdp_sampled(n=int(os.environ.get("XV_REFPOP_N", "128")), seed0=100):
     """n tasks of the reference's AnyMDPTaskSampler(16, 4, seed = seed0 + k) with the sampler's own bookkeeping: how
     many candidates sample_mdp produced, how many of them could not be repaired (None) and how many
     check_valuefunction rejected.  Used (a) for the seed-compatibility test of the build's sampler and (b) as the

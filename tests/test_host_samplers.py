@@ -423,3 +423,15 @@ def test_load_texture_library_reads_a_folder_like_the_reference(tmp_path):
     ref_dir = "/root/reference/xenoverse/mazeworld/envs/img"
     if os.path.isdir(ref_dir):                                      # build container only: the reference's own folder
         assert texture_counts(load_texture_library(ref_dir)) == (37, 29, 21)
+
+
+def test_acrobot_kernel_sincos_construction_is_within_one_ulp_of_libm():
+    """csrc/acrobot.hip: ac_sincos (Cody-Waite reduction + minimax kernels) with the constants read from the source,
+    restated in NumPy: at most 1 ulp from glibc's sin / cos over +-1000 (the oracle calls glibc; states are compared at 1e-9)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_ac_sincos", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "scripts", "devtools", "check_ac_sincos.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    worst, same = m.check(100000)
+    assert worst <= 1.0 and same > 0.95, (worst, same)

@@ -47,16 +47,45 @@ struct AcrobotTask {
   double l1, m1, m2, lc1, lc2, g, I1, I2;
 };
 
+// sin and cos of an angle of this system in ~45 fp64 instructions (ocml's sincos is ~200 with its large-argument path,
+// and a step evaluates 16 of them: they were four fifths of the kernel).  The classic two-step Cody-Waite reduction by
+// pi/2 (x - n pio2_1 is exact: 33-bit constant, |n| < 2^20) followed by the degree-13 / degree-14 minimax kernels with the
+// reduction's tail — the construction of fdlibm / msun (k_sin.c, k_cos.c, e_rem_pio2.c: public constants), restated.
+// Within 1 ulp of glibc's sin / cos (96.8 % of 8e6 arguments in +-1000 identical, the rest 1 ulp off; the oracle calls
+// glibc).  Domain: |x| < ~1e6 — the state is wrapped to [-pi, pi] and the velocities are bounded by 9 pi.
+__device__ __forceinline__ void ac_sincos(double x, double* sn, double* cs) {
+  const double fn = rint(x * 6.36619772367581382433e-01);
+  double r = x - fn * 1.57079632673412561417e+00;
+  const double t = r;
+  double w = fn * 6.07710050630396597660e-11;
+  r = t - w;
+  w = fn * 2.02226624879595063154e-21 - ((t - r) - w);
+  const double y0 = r - w, y1 = (r - y0) - w;
+  const double z = y0 * y0, v = z * y0;
+  const double rs = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                    z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double s = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * -1.66666666666666324348e-01);
+  const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double hz = 0.5 * z, wv = 1.0 - hz;
+  const double c = wv + (((1.0 - wv) - hz) + (z * rc - y0 * y1));
+  const int n = (int)fn & 3;
+  const double a = (n & 1) ? c : s, b = (n & 1) ? s : c;
+  *sn = (n & 2) ? -a : a;
+  *cs = ((n + 1) & 2) ? -b : b;
+}
+__device__ __forceinline__ double ac_cos(double x) { double sn, cs; ac_sincos(x, &sn, &cs); return cs; }
+
 // random_acrobot.py:58-96; y = (theta1, theta2, dtheta1, dtheta2), a = torque
 __device__ __forceinline__ void acrobot_dsdt(const AcrobotTask& K, const double (&y)[4], double a, double (&out)[4]) {
   const double theta1 = y[0], theta2 = y[1], dtheta1 = y[2], dtheta2 = y[3];
   double s2, c2;
-  sincos(theta2, &s2, &c2);
+  ac_sincos(theta2, &s2, &c2);
   const double d1 = K.m1 * (K.lc1 * K.lc1) + K.m2 * (K.l1 * K.l1 + K.lc2 * K.lc2 + 2 * K.l1 * K.lc2 * c2) + K.I1 + K.I2;
   const double d2 = K.m2 * (K.lc2 * K.lc2 + K.l1 * K.lc2 * c2) + K.I2;
-  const double phi2 = K.m2 * K.lc2 * K.g * cos(theta1 + theta2 - AC_PI / 2.0);
+  const double phi2 = K.m2 * K.lc2 * K.g * ac_cos(theta1 + theta2 - AC_PI / 2.0);
   const double phi1 = -K.m2 * K.l1 * K.lc2 * (dtheta2 * dtheta2) * s2 - 2 * K.m2 * K.l1 * K.lc2 * dtheta2 * dtheta1 * s2 +
-                      (K.m1 * K.lc1 + K.m2 * K.l1) * K.g * cos(theta1 - AC_PI / 2) + phi2;
+                      (K.m1 * K.lc1 + K.m2 * K.l1) * K.g * ac_cos(theta1 - AC_PI / 2) + phi2;
   const double ddtheta2 = (a + d2 / d1 * phi1 - K.m2 * K.l1 * K.lc2 * (dtheta1 * dtheta1) * s2 - phi2) /
                           (K.m2 * (K.lc2 * K.lc2) + K.I2 - d2 * d2 / d1);
   const double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
@@ -76,8 +105,8 @@ __device__ __forceinline__ void acrobot_obs(const double (&s)[4], bool f32, floa
     sincosf((float)s[1], &sn, &cs); o[2] = cs; o[3] = sn;
   } else {
     double sn, cs;
-    sincos(s[0], &sn, &cs); o[0] = (float)cs; o[1] = (float)sn;
-    sincos(s[1], &sn, &cs); o[2] = (float)cs; o[3] = (float)sn;
+    ac_sincos(s[0], &sn, &cs); o[0] = (float)cs; o[1] = (float)sn;
+    ac_sincos(s[1], &sn, &cs); o[2] = (float)cs; o[3] = (float)sn;
   }
   o[4] = (float)s[2]; o[5] = (float)s[3];
 }
@@ -160,7 +189,7 @@ __global__ __launch_bounds__(64) void acrobot_step_kernel(AcrobotArgs P, Acrobot
       if (stuck) err |= XV_DEVERR_NONFINITE;      // the reference would loop forever here
       s[2] = acrobot_bound(y[2], -4 * AC_PI, 4 * AC_PI);
       s[3] = acrobot_bound(y[3], -9 * AC_PI, 9 * AC_PI);
-      term = (-cos(s[0]) - cos(s[1] + s[0]) > K.l1) ? 1 : 0;   // _terminal :98-101
+      term = (-ac_cos(s[0]) - ac_cos(s[1] + s[0]) > K.l1) ? 1 : 0;   // _terminal :98-101
       total += term ? 0.0 : -1.0;
       if (term) break;
     }
