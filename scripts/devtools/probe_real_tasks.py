@@ -27,3 +27,21 @@ for search in ("fence", "bucket", "bucket32", "bucket64"):
         env.set_search(search)
     us = [timed(lambda: env.step_many(P, acts, out=ring), 30, 5) / P for _ in range(3)]
     print("%-9s %s us per step" % (search, ["%.2f" % u for u in us]), flush=True)
+env.close()
+
+# the multi-token / POMDP step on reference-distribution tasks (transition rows as above, sparse observation rows)
+for tt, do, da in (("POMDP", 1, 1), ("MTPOMDP", 2, 2)):
+    t = ds.sample_tasks_device(n_task, S, A, seed=3, batch=4096, task_type=tt, observation_space=64, observation_tokens=do,
+                               action_tokens=da)
+    env = AnyMDPVecEnv(n, seed=1, autoreset_mode="same_step")
+    env.set_task(t, env_task_index=(torch.arange(n, device=env.device, dtype=torch.int32) // per).contiguous())
+    env.reset()
+    a = torch.randint(0, A, (n, da) if tt == "MTPOMDP" else (n,), device=env.device, dtype=torch.int32)
+    for search in ("fence", "bucket"):
+        if search == "bucket":
+            env.set_search("bucket", n_bucket=16)
+        else:
+            env.set_search(search)
+        us = [timed(lambda: env.step(a), 60, 10) for _ in range(3)]
+        print("%-8s d_obs %d d_act %d %-7s %s us per step (python step() loop)" % (tt, do, da, search, ["%.2f" % u for u in us]), flush=True)
+    env.close()

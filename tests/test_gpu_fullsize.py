@@ -373,6 +373,23 @@ def test_step_then_masked_reset_keeps_returned_tensors():
     assert torch.equal(obs, keep) and torch.equal(o2[~mt], keep[~mt])
     assert bool((env.inner_state[mt] <= 2).all())            # the masked envs restarted in s_0 = {0, 1, 2}
     env.close()
+    # anymdp, multi-token POMDP: step() hands its fresh output set out without copies
+    d_obs, d_act, n_obs = 2, 2, 16
+    w = np.random.RandomState(1).rand(4, d_obs, 64, n_obs) + 0.05
+    oc = np.cumsum(w, -1); oc /= oc[..., -1:]; oc[..., -1] = 1.0
+    tab2 = dict(tab, obs_cdf=np.ascontiguousarray(oc), n_obs=n_obs, d_obs=d_obs, d_act=d_act, task_type="MTPOMDP")
+    env = AnyMDPVecEnv(n, autoreset_mode="disabled", seed=1)
+    env.set_task(tab2)
+    env.reset()
+    a = np.random.RandomState(2).randint(0, 8, (n, d_act)).astype(np.int32)
+    o1, r1, te1, tr1, i1 = env.step(a)
+    keep = [x.clone() for x in (o1, r1, te1, tr1, i1["reward_gt"])]
+    o2, r2, te2, tr2, i2 = env.step(a)                         # the next step writes another set
+    o3, _ = env.reset(options={"reset_mask": mask})            # and a masked reset a private clone
+    for x, k in zip((o1, r1, te1, tr1, i1["reward_gt"]), keep):
+        assert torch.equal(x, k)
+    assert o1.data_ptr() != o2.data_ptr() and torch.equal(o3[~mt], o2[~mt])
+    env.close()
     # linds
     env = LinDSVecEnv(n, autoreset_mode="disabled", seed=1)
     env.set_task([LinearDSSampler(16, 8, 8, seed=k) for k in range(4)])

@@ -180,6 +180,7 @@ class AnyMDPVecEnv(VectorEnv):
             mask = self._dev(options["reset_mask"], torch.uint8)
         self._detach("_obs")
         if self._tok is not None:
+            self._detach("_tobs")      # a masked reset writes part of it: never into the tensor the last step handed out
             _lib.check(self.lib.xv_anymdp_reset_tokens(self._h, _lib.ptr(mask), _lib.ptr(self._tobs)))
             self.need_reset = False
             return self._tok_obs(self._tobs), {"steps": self._out(self._get_steps())}
@@ -201,19 +202,26 @@ class AnyMDPVecEnv(VectorEnv):
             raise AssertionError(f"Action {tuple(a.shape)} is out of range")   # anymdp_env.py:117
         return a.contiguous()
 
+    def _tok_fresh(self):
+        """before a token step: the step kernels write observation, rewards and flags of EVERY env, so fresh buffers are
+        swapped in and handed out without copies (the previous call's tensors are never written again); final_obs is
+        written for finished envs only and stays a persistent buffer that is copied out"""
+        self._renew("_tobs", "_reward", "_reward_gt", "_term", "_trunc")
+
     def _tok_ret(self):
-        infos = {"steps": self._out(self._get_steps()), "reward_gt": self._out(self._reward_gt.clone())}
+        infos = {"steps": self._out(self._get_steps()), "reward_gt": self._of(self._reward_gt)}
         if self.autoreset_mode == "same_step":
             infos["final_obs"] = self._tok_obs(self._tfobs)
-            infos["_final_obs"] = self._out((self._term | self._trunc).bool())
-        return (self._tok_obs(self._tobs), self._out(self._reward.clone()), self._out(self._term.bool()),
-                self._out(self._trunc.bool()), infos)
+            infos["_final_obs"] = self._out((self._term | self._trunc).view(torch.bool))
+        obs = self._tobs[:, 0] if self.task_type == "POMDP" else self._tobs
+        return (self._of(obs), self._of(self._reward), self._obf(self._term), self._obf(self._trunc), infos)
 
     def reset_tokens_injected(self, u_reset, u_obs_reset, mask=None):
         self._require_task()
         ur = self._dev(u_reset, torch.float64)
         uo = self._dev(u_obs_reset, torch.float64)
         m = None if mask is None else self._dev(mask, torch.uint8)
+        self._detach("_tobs")
         _lib.check(self.lib.xv_anymdp_reset_tokens_injected(self._h, _lib.ptr(m), _lib.ptr(ur), _lib.ptr(uo),
                                                             _lib.ptr(self._tobs)))
         self.need_reset = False
@@ -225,6 +233,7 @@ class AnyMDPVecEnv(VectorEnv):
         a = self._tok_action(actions)
         args = [self._dev(u, torch.float64), self._dev(z, torch.float32), self._dev(u_obs, torch.float64),
                 self._dev(u_reset, torch.float64), self._dev(u_obs_reset, torch.float64)]
+        self._tok_fresh()
         _lib.check(self.lib.xv_anymdp_step_tokens_injected(
             self._h, _lib.ptr(a), *[_lib.ptr(x) for x in args], _lib.ptr(self._tobs), _lib.ptr(self._reward),
             _lib.ptr(self._reward_gt), _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._tfobs),
@@ -261,6 +270,7 @@ class AnyMDPVecEnv(VectorEnv):
         self._check_step()
         if self._tok is not None:
             a = self._tok_action(actions)
+            self._tok_fresh()
             _lib.check(self.lib.xv_anymdp_step_tokens(
                 self._h, _lib.ptr(a), _lib.ptr(self._tobs), _lib.ptr(self._reward), _lib.ptr(self._reward_gt),
                 _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._tfobs), AUTORESET[self.autoreset_mode]))
