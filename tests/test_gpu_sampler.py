@@ -1,6 +1,6 @@
 """The device task sampler (xv_anymdp_sample_tasks, csrc/anymdp_sampler.hip) against its CPU restatement
 (oracle/xeno_oracle_sampler.c part 2: same counter-based draws, same formulas), against the reference's population
-(tests/golden/sampler_refpop_16x4.npz: 32 tasks of the reference's own sampler with its candidate counts) and end
+(tests/golden/sampler_refpop_16x4.npz: 128 tasks of the reference's own sampler with its candidate counts) and end
 to end: accepted tasks go straight into the step engine and step like the same tasks uploaded from the host."""
 import os
 
@@ -93,7 +93,7 @@ def _pop_stats(T, s_e_mask, goal):
 
 
 def test_population_matches_the_reference_sampler():
-    """distribution test against 32 tasks of the reference's own sampler (and the 142 candidates it needed): acceptance
+    """distribution test against 128 tasks of the reference's own sampler (and the 452 candidates it needed): acceptance
     rate, pitfall density, goal share, band width and non-zeros per row of the device sampler's accepted tasks lie
     within sampling error of the reference population"""
     from xenoverse_amd.anymdp import device_sampler as ds

@@ -214,7 +214,7 @@ def test_seeded_pomdp_samplers_reproduce_the_reference_tasks(name, kind, seed):
 
 
 def test_seeded_sampler_reproduces_32_reference_sampled_tasks():
-    """tests/golden/sampler_refpop_16x4.npz: 32 tasks of the reference's sampler (seeds 100..131) with its own
+    """tests/golden/sampler_refpop_16x4.npz: 128 tasks of the reference's sampler (seeds 100..227) with its own
     candidate / unrepairable / rejected counts — the build's sampler walks the same candidates"""
     import os
     from util import GOLD
