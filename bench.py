@@ -25,6 +25,7 @@ One JSON line on rank 0: metric/value/unit/... as the driver's contract says, pl
   rccl / rccl_ranks   N > 1: whether the RCCL process group came up and what all_reduce(ones) returned
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -488,6 +489,8 @@ def main():
         run(args.warmup, with_gather)
         walls, evs = [], []
         stop = _StopEvent() if gpu else None
+        gc.collect()       # a full collection of this heap takes tens of milliseconds: not inside a 0.1-ms timed region
+        gc.disable()
         for _ in range(repeats):
             barrier()
             t0 = time.perf_counter()
@@ -499,6 +502,7 @@ def main():
             barrier(stop)
             walls.append(time.perf_counter() - t0)
             evs.append(env.engine.event_elapsed_ms() if gpu else walls[-1] * 1e3)   # HIP events on the launch stream
+        gc.enable()
         tt = torch.tensor([walls, evs], dtype=torch.float64)
         if dist is not None:              # MAX over ranks, per repetition
             if dist.get_backend() == "nccl":

@@ -19,15 +19,26 @@ HBM_PEAK = 8000.0
 
 
 def timed(fn, steps, warmup):
+    """us per call from HIP events around `steps` launches issued by a Python loop.  The collector is held off meanwhile:
+    a full collection of this process's heap takes ~75 ms (scripts/devtools/probe_slow_window.py), during which the GPU
+    starves and a 9-us step reads as 265 us — the 'erratic' family lines of earlier rounds."""
+    import gc
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(steps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+    finally:
+        if was:
+            gc.enable()
     return e0.elapsed_time(e1) * 1e3 / steps      # us per call
 
 

@@ -1,0 +1,53 @@
+"""Wall time of one Python-level VectorEnv.step() call (what a policy-in-the-loop user pays per vector step), per family,
+copy=True (default) and copy=False, 65,536 envs (maze 16,384): the kernels take 5-9 us (maze 1.4 ms)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+import oracle  # noqa: F401  (synthetic tables only; this is a devtool)
+from xenoverse_amd.anymdp import AnyMDPVecEnv, to_blocked
+from xenoverse_amd.linds import LinDSVecEnv
+from xenoverse_amd.metacontrol import CartPoleVecEnv, sample_cartpole, AcrobotVecEnv, sample_acrobot
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench_families import linds_tasks
+
+
+def wall(fn, n=300, warm=30):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+n = 65536
+tab = oracle.anymdp_synth(seed=3, task_index_base=0, n_task=64, S=64, A=8, s0_max=4)
+tab["rows"] = to_blocked(tab["cdf"], tab["rs"])
+for copy in (True, False):
+    env = AnyMDPVecEnv(n, seed=1, autoreset_mode="same_step", copy=copy)
+    env.set_task(tab)
+    env.reset()
+    a = torch.randint(0, 8, (n,), device=env.device, dtype=torch.int32)
+    print("anymdp   copy=%-5s %.1f us per step() call" % (copy, wall(lambda: env.step(a))), flush=True)
+    env.close()
+    env = LinDSVecEnv(n, seed=1, autoreset_mode="same_step", copy=copy)
+    env.set_task(linds_tasks(1024))
+    env.reset()
+    a = torch.rand((n, 8), device=env.device) * 2 - 1
+    print("linds    copy=%-5s %.1f us per step() call" % (copy, wall(lambda: env.step(a))), flush=True)
+    env.close()
+    env = CartPoleVecEnv(n, seed=1, autoreset_mode="same_step", frameskip=1, copy=copy)
+    env.set_task([sample_cartpole(seed=k) for k in range(64)])
+    env.reset()
+    a = torch.randint(0, 2, (n,), device=env.device, dtype=torch.int32)
+    print("cartpole copy=%-5s %.1f us per step() call" % (copy, wall(lambda: env.step(a))), flush=True)
+    env.close()
+    env = AcrobotVecEnv(n, seed=1, autoreset_mode="same_step", frameskip=1, copy=copy)
+    env.set_task([sample_acrobot(seed=k) for k in range(64)])
+    env.reset()
+    a = torch.randint(0, 3, (n,), device=env.device, dtype=torch.int32)
+    print("acrobot  copy=%-5s %.1f us per step() call" % (copy, wall(lambda: env.step(a))), flush=True)
+    env.close()
