@@ -223,3 +223,40 @@ def test_fused_mixed_step_equals_separate_steps(mode, search):
     assert len(recs[0]) == len(recs[1])
     for x, y in zip(*recs):
         assert np.array_equal(x, y)
+
+
+def test_create_and_close_return_device_memory():
+    """every family handle frees what it allocated (tables' engine-side copies, bucket lines, compaction lists, ...): after
+    a warm-up round, 12 rounds of create -> set_task -> reset -> step -> close leave the free device memory where it was"""
+    from xenoverse_amd.anymdp import AnyMDPVecEnv, to_blocked
+    from xenoverse_amd.linds import LinDSVecEnv, LinearDSSampler
+    from xenoverse_amd.mazeworld import MazeTaskSampler, MazeWorldVecEnv, make_texture_library
+    from xenoverse_amd.metacontrol import AcrobotVecEnv, CartPoleVecEnv, sample_acrobot, sample_cartpole
+    tab = oracle.anymdp_synth(seed=3, task_index_base=0, n_task=16, S=64, A=8, s0_max=4)
+    tab["rows"] = to_blocked(tab["cdf"], tab["rs"])
+    lt = [LinearDSSampler(16, 8, 8, seed=k) for k in range(4)]
+    mz = [MazeTaskSampler(n_range=(9, 10), seed=k, n_wall_textures=8, n_ground_textures=4, n_ceiling_textures=4) for k in range(2)]
+    tex = make_texture_library(8, 4, 4, seed=0)
+
+    def round_():
+        e = AnyMDPVecEnv(12288, seed=1, autoreset_mode="same_step")
+        e.set_task(tab); e.set_search("bucket", n_bucket=16); e.reset()
+        e.step(np.zeros(12288, np.int32)); e.step_many(8, torch.zeros((8, 12288), dtype=torch.int32, device=e.device)); e.close()
+        e = LinDSVecEnv(4096, seed=1, autoreset_mode="same_step")
+        e.set_task(lt); e.reset(); e.step(np.zeros((4096, 8), np.float32)); e.close()
+        e = MazeWorldVecEnv(12288, resolution=(16, 16), textures=tex, autoreset_mode="same_step", seed=1)
+        e.set_task(mz); e.reset(); e.step(np.zeros(12288, np.int32)); e.close()      # 12,288 envs: the sorted move kernel
+        e = CartPoleVecEnv(4096, seed=1, autoreset_mode="same_step")
+        e.set_task([sample_cartpole(seed=k) for k in range(4)]); e.reset(); e.step(np.zeros(4096, np.int32)); e.close()
+        e = AcrobotVecEnv(4096, seed=1, autoreset_mode="same_step")
+        e.set_task([sample_acrobot(seed=k) for k in range(4)]); e.reset(); e.step(np.zeros(4096, np.int32)); e.close()
+
+    import gc
+    round_()
+    gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(12):
+        round_()
+    gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, (free0 - free1) / 2**20      # a leak of one handle's tables per round would be >> 64 MiB
