@@ -44,4 +44,14 @@ for tt, do, da in (("POMDP", 1, 1), ("MTPOMDP", 2, 2)):
             env.set_search(search)
         us = [timed(lambda: env.step(a), 60, 10) for _ in range(3)]
         print("%-8s d_obs %d d_act %d %-7s %s us per step (python step() loop)" % (tt, do, da, search, ["%.2f" % u for u in us]), flush=True)
+        from xenoverse_amd import _lib
+        from xenoverse_amd.engine import AUTORESET
+        aa = env._tok_action(a)
+
+        def raw():
+            _lib.check(env.lib.xv_anymdp_step_tokens(env._h, _lib.ptr(aa), _lib.ptr(env._tobs), _lib.ptr(env._reward),
+                                                     _lib.ptr(env._reward_gt), _lib.ptr(env._term), _lib.ptr(env._trunc),
+                                                     _lib.ptr(env._tfobs), AUTORESET["same_step"]))
+        us = [timed(raw, 200, 20) for _ in range(3)]
+        print("%-8s d_obs %d d_act %d %-7s %s us per step (xv_anymdp_step_tokens from a Python loop)" % (tt, do, da, search, ["%.2f" % u for u in us]), flush=True)
     env.close()
