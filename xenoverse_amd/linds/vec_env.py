@@ -154,8 +154,9 @@ class LinDSVecEnv(VectorEnv):
         return a.contiguous()
 
     def _steps_now(self):
+        self._renew("_steps")      # the launch writes every entry: a fresh buffer, handed out as it is (no copy)
         _lib.check(self.lib.xv_linds_get_state(self._h, None, _lib.ptr(self._steps), None))
-        return self._steps.clone()
+        return self._steps if (self.copy and not self.to_numpy) else self._steps.clone()
 
     def _infos(self, with_final, fresh=False):
         o = self._of if fresh else self._o      # fresh: the buffers were renewed before the launch (step paths)

@@ -127,8 +127,9 @@ class MazeWorldVecEnv(VectorEnv):
         self.need_reset = True
 
     def _steps_now(self):
+        self._renew("_steps")      # the launch writes every entry: a fresh buffer, handed out as it is (no copy)
         _lib.check(self.lib.xv_maze_get_state(self._h, None, None, None, _lib.ptr(self._steps), None, None, None, None))
-        return self._steps.clone()
+        return self._steps if (self.copy and not self.to_numpy) else self._steps.clone()
 
     def reset(self, *, seed=None, options=None):
         if not self.task_set:
