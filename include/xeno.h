@@ -37,7 +37,7 @@ extern "C" {
  *    graph-replay switches
  * 4: xv_linds_rollout, xv_cartpole_rollout, xv_acrobot_rollout; the maze teachers (xv_maze_agent_*);
  *    xv_maze_set_typing; AnyMDP bucket search (xv_anymdp_build_buckets) */
-#define XV_ABI_VERSION 6
+#define XV_ABI_VERSION 7
 
 /* return codes */
 #define XV_OK 0
@@ -221,6 +221,11 @@ int xv_anymdp_reset_tokens_injected(xv_anymdp* h, const uint8_t* mask, const dou
                                     const double* u_obs_reset, int32_t* obs);
 int xv_anymdp_step_tokens(xv_anymdp* h, const int32_t* action, int32_t* obs, float* reward, float* reward_gt,
                           uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int autoreset_mode);
+/* n_steps token steps issued from C over [period][...] ring buffers (step k on slot k % period), as xv_anymdp_step_many
+ * does for the scalar step; equals n_steps calls of xv_anymdp_step_tokens. */
+int xv_anymdp_step_tokens_many(xv_anymdp* h, int n_steps, int period, const int32_t* action, int32_t* obs, float* reward,
+                               float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs,
+                               int autoreset_mode);
 int xv_anymdp_step_tokens_injected(xv_anymdp* h, const int32_t* action, const double* u, const float* z,
                                    const double* u_obs, const double* u_reset, const double* u_obs_reset,
                                    int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated,

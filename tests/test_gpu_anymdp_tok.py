@@ -153,3 +153,49 @@ def test_synthetic_observation_models_vs_oracle(n_obs, d_obs, d_act, search):
                 env.reset_tokens_injected(ur2, uor2, mask=o[3]); ora.tok_reset_injected(ur2, uor2, mask=o[3])
         assert ended > 30
         env.close()
+
+
+@pytest.mark.parametrize("search,task_type", [("fence", "MTPOMDP"), ("bucket", "MTPOMDP"), ("fence", "POMDP")])
+def test_step_tokens_many_equals_single_steps(search, task_type):
+    """xv_anymdp_step_tokens_many (token steps issued from C over ring buffers) == the same number of step() calls: every
+    output of the last ring cycle and the engine state, free-running draws (same seed, same ticks)"""
+    S, A, n_task, n_obs = 64, 8, 6, 22
+    d_obs, d_act = (2, 2) if task_type == "MTPOMDP" else (1, 1)
+    tab = oracle.anymdp_synth(seed=17, task_index_base=0, n_task=n_task, S=S, A=A, s0_max=3)
+    rng = np.random.RandomState(4)
+    w = rng.random_sample((n_task, d_obs, S, n_obs)) + 1e-3
+    oc = np.cumsum(w, -1); oc /= oc[..., -1:]; oc[..., -1] = 1.0
+    n, P, K = 500, 6, 3 * 6 + 4
+    env_task = (np.arange(n) * 5 % n_task).astype(np.int32)
+    acts = rng.randint(0, A, (P, n, d_act)).astype(np.int32)
+    res = []
+    for many in (True, False):
+        env = AnyMDPVecEnv(n, autoreset_mode="same_step", seed=9)
+        env.set_task(dict(_dev_tables(tab), obs_cdf=np.ascontiguousarray(oc), n_obs=n_obs, d_obs=d_obs, d_act=d_act, task_type=task_type),
+                     env_task_index=env_task)
+        env.set_search(search)
+        env.reset()
+        if many:
+            ring = env.step_tokens_many(K, acts if d_act > 1 else acts[:, :, 0])
+            rec = {k: _np(v).copy() for k, v in ring.items()}
+        else:
+            rows = [None] * P
+            for k in range(K):
+                a = acts[k % P] if d_act > 1 else acts[k % P][:, 0]
+                o, r, te, tr, info = env.step(a)
+                rows[k % P] = dict(obs=_np(o).reshape(n, d_obs), reward=_np(r), reward_gt=_np(info["reward_gt"]),
+                                   terminated=_np(te).astype(np.uint8), truncated=_np(tr).astype(np.uint8),
+                                   final_obs=_np(info["final_obs"]).reshape(n, d_obs))
+            rec = {k: np.stack([row[k] for row in rows]) for k in rows[0]}
+        s, st, nr = env.get_state()
+        rec["state"], rec["steps"], rec["tick"] = _np(s), _np(st), np.array([env.engine.tick])
+        assert env.check_errors() == 0
+        res.append(rec)
+        env.close()
+    done = (res[1]["terminated"] | res[1]["truncated"]).astype(bool)
+    for k in res[0]:
+        if k == "final_obs":      # written for finished envs (the per-lane kernel leaves the other rows alone)
+            assert np.array_equal(res[0][k][done], res[1][k][done]), k
+        else:
+            assert np.array_equal(res[0][k], res[1][k]), k
+    assert done.sum() > 20

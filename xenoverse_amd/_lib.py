@@ -57,6 +57,7 @@ SIGNATURES = {
     "xv_anymdp_reset_tokens_injected": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_anymdp_step_tokens": [c_void_p] + [c_void_p] * 7 + [c_int],
     "xv_anymdp_step_tokens_injected": [c_void_p] + [c_void_p] * 12 + [c_int],
+    "xv_anymdp_step_tokens_many": [c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int],
     "xv_anymdp_rollout_teacher": [c_void_p, c_int, c_void_p, C.c_float] + [c_void_p] * 7,
     "xv_anymdp_get_state": [c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_anymdp_set_state": [c_void_p, c_void_p, c_void_p, c_void_p],
@@ -119,7 +120,7 @@ class XenoError(RuntimeError):
     pass
 
 
-ABI_VERSION = 6      # include/xeno.h XV_ABI_VERSION
+ABI_VERSION = 7      # include/xeno.h XV_ABI_VERSION
 
 
 def load():

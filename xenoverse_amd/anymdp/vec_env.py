@@ -403,6 +403,33 @@ class AnyMDPVecEnv(VectorEnv):
         _lib.check(self.lib.xv_anymdp_step_many(self._h, int(n_steps), *args, AUTORESET[self.autoreset_mode]))
         return out
 
+    def step_tokens_many(self, n_steps, actions, out=None):
+        """POMDP / multi-token tasks: n_steps token steps issued from C (xv_anymdp_step_tokens_many).  actions int32[P, N,
+        d_act] is cycled with period P; `out` holds ring buffers (allocated when None): obs / final_obs [P, N, d_obs],
+        reward, reward_gt, terminated, truncated [P, N] — slot k % P receives step k.  Equals n_steps calls of step()."""
+        self._check_step()
+        assert self._tok is not None, "step_tokens_many needs a POMDP / MTPOMDP task"
+        d_obs, d_act = self._tok
+        a = self._dev(actions, torch.int32)
+        if a.dim() == 2 and d_act == 1:
+            a = a[:, :, None]
+        P = int(a.shape[0])
+        assert a.shape == (P, self.num_envs, d_act)
+        a = a.contiguous()
+        d, n = self.device, self.num_envs
+        if out is None:
+            out = dict(obs=torch.empty((P, n, d_obs), dtype=torch.int32, device=d),
+                       reward=torch.empty((P, n), dtype=torch.float32, device=d),
+                       reward_gt=torch.empty((P, n), dtype=torch.float32, device=d),
+                       terminated=torch.empty((P, n), dtype=torch.uint8, device=d),
+                       truncated=torch.empty((P, n), dtype=torch.uint8, device=d),
+                       final_obs=torch.full((P, n, d_obs), -1, dtype=torch.int32, device=d))
+        _lib.check(self.lib.xv_anymdp_step_tokens_many(
+            self._h, int(n_steps), P, _lib.ptr(a), _lib.ptr(out["obs"]), _lib.ptr(out["reward"]), _lib.ptr(out["reward_gt"]),
+            _lib.ptr(out["terminated"]), _lib.ptr(out["truncated"]), _lib.ptr(out.get("final_obs")),
+            AUTORESET[self.autoreset_mode]))
+        return out
+
     def set_step_many_graph(self, mode):
         """step_many replays whole ring cycles from a hipGraph (True / "on"), issues plain launches (False / "off")
         or decides ("auto", the default: graph up to 8,192 envs and for calls of at most 128 steps); same results

@@ -1784,6 +1784,27 @@ extern "C" int xv_anymdp_step_tokens(xv_anymdp* h, const int32_t* action, int32_
   return anymdp_tok_launch_step<false>(h, io, autoreset_mode);
 }
 
+// n_steps token steps issued from C over ring buffers: step k reads actions slot k % period ([period][n_env][d_act]) and
+// writes slot k % period of the outputs (obs / final_obs [period][n_env][d_obs], the others [period][n_env]); equals
+// n_steps calls of xv_anymdp_step_tokens (a Python / ctypes loop costs more per call than the 10-20 us kernel)
+extern "C" int xv_anymdp_step_tokens_many(xv_anymdp* h, int n_steps, int period, const int32_t* action, int32_t* obs,
+                                          float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated,
+                                          int32_t* final_obs, int autoreset_mode) {
+  XV_CHECK_ARG(h && h->obs_cdf && n_steps > 0 && period > 0);
+  XV_CHECK_ARG(action && obs && reward && reward_gt && terminated && truncated);
+  XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
+  const size_t n = (size_t)h->a.n_env, da = (size_t)h->d_act, dob = (size_t)h->d_obs;
+  for (int k = 0; k < n_steps; ++k) {
+    const size_t o = (size_t)(k % period) * n;
+    anymdp_bind_rng(h, 1);
+    AnyMDPTokIO io{action + o * da, nullptr, nullptr, nullptr, nullptr, nullptr, obs + o * dob, reward + o, reward_gt + o,
+                   terminated + o, truncated + o, final_obs ? final_obs + o * dob : nullptr};
+    const int rc = anymdp_tok_launch_step<false>(h, io, autoreset_mode);
+    if (rc != XV_OK) return rc;
+  }
+  return XV_OK;
+}
+
 extern "C" int xv_anymdp_step_tokens_injected(xv_anymdp* h, const int32_t* action, const double* u, const float* z,
                                               const double* u_obs, const double* u_reset, const double* u_obs_reset,
                                               int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated,
