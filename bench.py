@@ -486,11 +486,11 @@ def main():
         """-> (median wall seconds of a K-step batch, median event ms) after MAX over ranks per repetition.
         The HIP events are the engine's own (xv_engine_event_*: hipEventRecord on the stream the step kernels are
         launched on, ~2 us of host time each instead of ~5 for a torch Event)."""
+        gc.collect()       # a full collection of this heap takes tens of milliseconds: not inside a 0.1-ms timed region,
+        gc.disable()       # and not right in front of it either (the idle GPU clocks down) — before the warm-up
         run(args.warmup, with_gather)
         walls, evs = [], []
         stop = _StopEvent() if gpu else None
-        gc.collect()       # a full collection of this heap takes tens of milliseconds: not inside a 0.1-ms timed region
-        gc.disable()
         for _ in range(repeats):
             barrier()
             t0 = time.perf_counter()

@@ -23,14 +23,15 @@ def timed(fn, steps, warmup):
     a full collection of this process's heap takes ~75 ms (scripts/devtools/probe_slow_window.py), during which the GPU
     starves and a 9-us step reads as 265 us — the 'erratic' family lines of earlier rounds."""
     import gc
-    for _ in range(warmup):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    was = gc.isenabled()
-    gc.collect()
-    gc.disable()
+    was = gc.isenabled() and not os.environ.get("XV_BENCH_KEEP_GC")
+    if was:
+        gc.collect()      # before the warm-up: tens of idle milliseconds right in front of the timed launches would let
+        gc.disable()      # the GPU clock down
     try:
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(steps):
             fn()
@@ -397,23 +398,35 @@ def bench_maze(args, res, precision="exact", move_kernel="auto"):
     env.set_task(tasks)
     env.set_move_kernel(move_kernel)
     env.reset()
-    a = torch.randint(0, 16, (n,), device=env.device, dtype=torch.int32)
-    steps = max(3, args.steps // (40 if res <= 64 else 400))
+    # BASELINE config 4: actions uniform over Discrete16, drawn anew for every step (a ring of 64 pre-generated action sets);
+    # 32 untimed steps first, so that the batch is past the reset transient (every agent at its start cell's centre) —
+    # what a frame costs depends on what the agents see.  Enough timed launches for the GPU's clock to settle: 5 steps
+    # (7 ms) read 1.38 or 1.54 ms per step depending on what ran (or idled) just before.
+    ring = torch.randint(0, 16, (64, n), device=env.device, dtype=torch.int32)
+    clock = [0]
+
+    def action_ptr():
+        clock[0] += 1
+        return _lib.ptr(ring[clock[0] % 64])
+    steps = max(24 if res <= 64 else 4, args.steps // (40 if res <= 64 else 400))
+    steps = int(os.environ.get("XV_MAZE_STEPS", steps))
 
     def move():
-        _lib.check(env.lib.xv_maze_step(env._h, _lib.ptr(a), 1, None, _lib.ptr(env._reward), _lib.ptr(env._term),
+        _lib.check(env.lib.xv_maze_step(env._h, action_ptr(), 1, None, _lib.ptr(env._reward), _lib.ptr(env._term),
                                         _lib.ptr(env._trunc), None, None, AUTORESET["same_step"]))
 
     def render():
         _lib.check(env.lib.xv_maze_render(env._h, _lib.ptr(env._frames), _lib.ptr(env._cmd_rgb)))
 
     def full():
-        _lib.check(env.lib.xv_maze_step(env._h, _lib.ptr(a), 1, _lib.ptr(env._frames), _lib.ptr(env._reward),
+        _lib.check(env.lib.xv_maze_step(env._h, action_ptr(), 1, _lib.ptr(env._frames), _lib.ptr(env._reward),
                                         _lib.ptr(env._term), _lib.ptr(env._trunc), _lib.ptr(env._cmd_rgb), None,
                                         AUTORESET["same_step"]))
-    us_move = timed(move, steps, 2)
-    us_render = timed(render, steps, 2)
-    us_full = timed(full, steps, 2)
+    for _ in range(32 if res <= 64 else 8):
+        move()
+    us_move = timed(move, steps, 4)
+    us_render = timed(render, steps, 4)
+    us_full = timed(full, steps, 4)
     env.close()
     algo = (3 * res * res + 64) * n
     # the ray-caster is bound by fp64 VALU issue, not HBM: a painted pixel needs >= 16 taps x (8 weight + 3 x 5 colour)

@@ -481,8 +481,9 @@ __global__ __launch_bounds__(64) void maze_step9_kernel(MazeArgs P, const void* 
 // ------------------------------------------------------------------------------------------------
 // Which envs have to be walked at all.  An env whose action has no walk speed gets a displacement of +-0 in every
 // sub-step (dynamics.py:98-123: arc = walk_speed * dt = 0, or offset = 2 s_dt * walk_speed / turn_rate = 0), so e = p + d = p;
-// if at p none of the nine cells pushes (each is either no wall or farther than the collision distance: the zero
-// filter of maze_step9_kernel, evaluated here on the same operands) the force sum is exactly 0 and p = 0 + e = p: the
+// if at p none of the nine cells pushes (each is no wall, or farther than the collision distance by the zero filter of
+// maze_step9_kernel, or inside the band with a force of exactly 0 from the same mz_collision_force_near on the same
+// operands) the force sum is exactly 0 and p = 0 + e = p: the
 // env stands still through all 100 sub-steps, collision 0, and only its heading turns.  10 of the 16 Discrete16 actions
 // are turns.  One thread per env sorts the batch: envs to walk are listed from the front of `list`, envs that stand still
 // from its end (one atomic per wave and kind; order does not matter, envs are independent).  count[2 w], count[2 w + 1]
@@ -527,7 +528,13 @@ __global__ __launch_bounds__(256) void maze_move_sort_kernel(MazeArgs P, const v
       const bool wall = wi > -1 && wi < n && wj > -1 && wj < n && wv[idx] > 0;
       const double v0 = fr0 - (double)(float)(ni + 0.5), v1 = fr1 - (double)(float)(nj + 0.5);
       const double cheb = __builtin_fmax(fabs(v0), fabs(v1)) - 0.5;
-      if (wall && !(cheb > eff_cd + 1.0e-9)) still = false;
+      if (still && wall && !(cheb > eff_cd + 1.0e-9)) {
+        // inside the band the reference's own arithmetic decides (an agent a wall has pushed out rests exactly at the
+        // collision distance, where the force is 0 again): the same function on the same operands as the walking kernel
+        double g0, g1;
+        mz_collision_force_near(v0, v1, cell_size, eff_cd, g0, g1);
+        if (g0 != 0.0 || g1 != 0.0) still = false;
+      }
     }
   }
   const int lane = threadIdx.x & 63;
