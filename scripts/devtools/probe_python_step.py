@@ -4,8 +4,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
-import oracle  # noqa: F401  (synthetic tables only; this is a devtool)
-from xenoverse_amd.anymdp import AnyMDPVecEnv, to_blocked
+from xenoverse_amd import _lib
+from xenoverse_amd.anymdp import AnyMDPVecEnv, row_lines
 from xenoverse_amd.linds import LinDSVecEnv
 from xenoverse_amd.metacontrol import CartPoleVecEnv, sample_cartpole, AcrobotVecEnv, sample_acrobot
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,11 +24,25 @@ def wall(fn, n=300, warm=30):
 
 
 n = 65536
-tab = oracle.anymdp_synth(seed=3, task_index_base=0, n_task=64, S=64, A=8, s0_max=4)
-tab["rows"] = to_blocked(tab["cdf"], tab["rs"])
+
+
+def synth_tables(env, n_task=64, S=64, A=8):
+    """synthetic tasks made on the device (xv_anymdp_synth_tasks, as bench.py does)"""
+    d = env.device
+    tab = dict(S=S, A=A, s0_max=4, rows=torch.empty((n_task, S, A, row_lines(S), 16), dtype=torch.float64, device=d),
+               state_map=torch.empty((n_task, S), dtype=torch.int32, device=d),
+               term_mask=torch.empty((n_task, 1), dtype=torch.int64, device=d),
+               s0_cdf=torch.empty((n_task, 4), dtype=torch.float64, device=d),
+               s0_ids=torch.empty((n_task, 4), dtype=torch.int32, device=d),
+               max_steps=torch.empty(n_task, dtype=torch.int32, device=d))
+    _lib.check(env.lib.xv_anymdp_synth_tasks(env.engine.handle, 7, 0, n_task, S, A, 4, *[_lib.ptr(tab[k]) for k in
+               ("rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")]))
+    return tab
+
+
 for copy in (True, False):
     env = AnyMDPVecEnv(n, seed=1, autoreset_mode="same_step", copy=copy)
-    env.set_task(tab)
+    env.set_task(synth_tables(env))
     env.reset()
     a = torch.randint(0, 8, (n,), device=env.device, dtype=torch.int32)
     print("anymdp   copy=%-5s %.1f us per step() call" % (copy, wall(lambda: env.step(a))), flush=True)
