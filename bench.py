@@ -2,7 +2,8 @@
 """bench.py — env-steps/sec of the AnyMDP hot path (BASELINE.json metric) on N MI355X GPUs of one node.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...; started WITHOUT a launcher,
+   `python bench.py --gpus N` launches exactly that as a fresh child process before anything touches the GPU: self_launch)
 
 Workload = BASELINE.json configs[1]: anymdp |S|=64, |A|=8, 65,536 envs per GPU, synthetic tasks generated on
 the device.  Default task sharing is "distinct" (2a: one task per env, 44 GiB of
@@ -342,14 +343,45 @@ def median(xs):
     return s[n // 2] if n % 2 else 0.5 * (s[n // 2 - 1] + s[n // 2])
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: this process — which has imported neither torch nor anything else
+    that initialises the GPU — starts ONE fresh child `python -m torch.distributed.run --nproc-per-node N bench.py <same
+    arguments>` (never an exec: a child process, whose output streams through the inherited stdout / stderr) and leaves
+    with the child's return code.  The ranks then find WORLD_SIZE in their environment and take the normal path."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+        s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    for k in ("RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK"):    # a stale single-rank environment must not leak in
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %s\n" % (args.gpus, " ".join(cmd[1:9])))
+    sys.stderr.flush()
+    sys.stdout.flush()
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT)
+    try:
+        rc = proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()          # the exact child this process started
+        rc = proc.wait()
+    sys.exit(rc)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                 % (args.gpus, args.gpus))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)
     selftest = args.exchange_selftest
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline and not selftest and not args.sweep_envs \

@@ -142,6 +142,29 @@ def test_bench_py_two_ranks_end_to_end_on_gloo():
 
 
 @pytest.mark.timeout(300)
+def test_bench_py_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` the way the driver runs N = 1 (no torch.distributed.run in front): the parent starts the
+    ranks as one fresh child process and leaves with its code; two ranks are seen, one JSON line comes out"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "64", "--warmup", "32", "--repeats", "3",
+           "--envs", "512", "--exchange-selftest"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(out) == 1
+    assert out[0]["n_gpus"] == 2 and out[0]["ranks_seen"] == 2 and out[0]["selftest"] == "ok"
+    assert "without a launcher" in r.stderr
+    # the child's failure is the parent's: a stalled rank makes the whole command leave non-zero
+    r = subprocess.run(cmd + ["--gather-timeout", "6", "--transport", "torch"], capture_output=True, text=True, timeout=240,
+                       env=dict(env, XV_BENCH_TEST_STALL="1"), cwd=root)
+    assert r.returncode != 0
+
+
+@pytest.mark.timeout(300)
 def test_bench_py_watchdog_exits_nonzero_and_keeps_the_pass1_line():
     """a rank that never joins the all-gather pass: every rank leaves with a non-zero code, rank 0 still prints the
     pass-1 line, flagged machine-readably"""
