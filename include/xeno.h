@@ -37,7 +37,7 @@ extern "C" {
  *    graph-replay switches
  * 4: xv_linds_rollout, xv_cartpole_rollout, xv_acrobot_rollout; the maze teachers (xv_maze_agent_*);
  *    xv_maze_set_typing; AnyMDP bucket search (xv_anymdp_build_buckets) */
-#define XV_ABI_VERSION 7
+#define XV_ABI_VERSION 8
 
 /* return codes */
 #define XV_OK 0
@@ -242,15 +242,38 @@ int xv_anymdp_step_tokens_injected(xv_anymdp* h, const int32_t* action, const do
 #define XV_ANYMDP_SEARCH_BINARY 1
 #define XV_ANYMDP_SEARCH_FENCE 3
 /*   BUCKET  (after xv_anymdp_build_buckets) one line in one dependent level: the row's probability axis is cut into
- *           n_bucket equal buckets and bucket line (row, k) holds the 7 entries starting at #{cdf <= k / n_bucket}, so the
- *           line that contains s' is named by the row and the env's own uniform, floor(u * n_bucket), with no fence read;
- *           a wave in which some env's s' lies beyond its line (more than 7 next states inside one bucket) takes the
- *           FENCE path for that step.  Identical results; costs n_task * S * A * n_bucket * 128 bytes of HBM. */
+ *           n_bucket equal buckets and bucket line (row, k) answers every u of bucket k by itself, so the line that
+ *           contains s' is named by the row and the env's own uniform, floor(u * n_bucket), with no fence read.  A line
+ *           lists up to 7 CUTS of the row's CDF chosen for its bucket (6 when S > 256 or an observation id > 255): the
+ *           next states a draw of the bucket can return are grouped in order, a group of one state answers exactly, a
+ *           group that lumps a run of states (chosen so that the lumped probability is least: they are the ones that
+ *           are practically never drawn) sends the draw's wave through the FENCE path for that step.  Identical
+ *           results; costs n_task * S * A * n_bucket * 128 bytes of HBM.
+ *   AUTO    (round 4) BUCKET when the lines are built and their census (below) expects fewer than 0.05 draws per launch
+ *           that a line cannot answer, else FENCE when available, else BINARY: xv_anymdp_effective_search tells. */
 #define XV_ANYMDP_SEARCH_BUCKET 4
 int xv_anymdp_set_search(xv_anymdp* h, int search);
+int xv_anymdp_effective_search(xv_anymdp* h);   /* XV_ANYMDP_SEARCH_BINARY | _FENCE | _BUCKET: what a step launches now */
 /* builds (n_bucket = 16 | 32 | 64) or frees (0) the engine-owned bucket lines of this handle's rows (FENCE layout, any
- * S <= 512).  XV_ERR_NOMEM when they do not fit. */
+ * S <= 512).  XV_ERR_NOMEM when they do not fit.  Synchronises the stream (the census is read back). */
 int xv_anymdp_build_buckets(xv_anymdp* h, int n_bucket);
+/* What the bucket lines of these rows can and cannot answer.  p_fallback: the share of draws (uniform over the rows of
+ * non-terminal states and over u) that land in a lumped group or beyond a line's last cut; one such draw costs its
+ * wave — and, with one wave per SIMD, the launch — two more dependent lines.  AUTO uses the lines iff
+ * fallbacks_per_launch = p_fallback * n_env <= 0.05.  Synthetic dense bands: 0.  Rows of the reference's sampler
+ * (task_sampler_utils.py:65-175), 16 buckets: ~5e-8 (the consecutive-entry lines of rounds 2-3: 2.7e-2). */
+typedef struct {
+  int32_t n_bucket, format;          /* format 1: 7 cuts per line (S <= 256, observation ids <= 255); 2: 6 cuts */
+  int32_t cuts_per_line, built;      /* built 0: xv_anymdp_probe_buckets (nothing allocated) */
+  int32_t auto_uses_bucket, reserved;
+  uint64_t lines, lines_dirty, live_rows;
+  double p_fallback, fallbacks_per_launch, bytes;
+} xv_anymdp_bucket_census;
+int xv_anymdp_probe_buckets(xv_anymdp* h, int n_bucket, xv_anymdp_bucket_census* out);   /* census without the memory */
+int xv_anymdp_bucket_census_get(xv_anymdp* h, xv_anymdp_bucket_census* out);             /* of the lines that are built */
+/* 1: xv_anymdp_step_tokens launches the cooperative kernel (bucket search in effect, observation bucket lines built:
+ * they are built beside the transition lines when they fit the free memory minus 2 GiB), 0: the per-lane kernel */
+int xv_anymdp_token_kernel(xv_anymdp* h);
 
 /* fused teacher rollout: like xv_anymdp_rollout, but the action of every step comes from a per-task greedy table
  * greedy uint8[n_task][S] (argmax_a Q[inner_state], the policy of AnyMDPSolverOpt, anymdp_solver_opt.py:38-51) and is

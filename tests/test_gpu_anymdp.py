@@ -882,3 +882,150 @@ def test_rebuilding_the_bucket_lines_drops_the_cached_step_many_graph():
     for a, b in zip(*res):
         for k in a:
             assert np.array_equal(a[k], b[k]), k
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 4: bucket lines as chosen cuts (csrc/anymdp_cutline.h), their census, and what AUTO makes of it
+# ---------------------------------------------------------------------------------------------------
+def _host_cut_census(cdf_rows, nbk, K):
+    """p_fallback of the same rows from the host build of anymdp_cutline.h (tests/native/cutline_host.cpp)"""
+    import ctypes as C
+    import os
+    import subprocess
+    import tempfile
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(tempfile.mkdtemp(), "libcut.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so,
+                           os.path.join(here, "native", "cutline_host.cpp")])
+    lib = C.CDLL(so)
+    rows = np.ascontiguousarray(cdf_rows, np.float64)
+    out, mass = np.zeros(5, np.int64), np.zeros(1, np.float64)
+    lib.cutline_check(rows.ctypes.data_as(C.c_void_p), C.c_int(rows.shape[0]), C.c_int(rows.shape[1]), C.c_int(nbk), C.c_int(K),
+                      C.c_int(0), out.ctypes.data_as(C.c_void_p), mass.ctypes.data_as(C.c_void_p))
+    assert out[0] == 0 and out[4] == 0
+    return float(mass[0]) / rows.shape[0], int(out[3])
+
+
+def test_bucket_census_of_reference_rows_and_auto_takes_the_bucket_search():
+    """the golden 64x8 task of the reference's sampler: its skewed rows left 2.7e-2 of the draws to the fence search with
+    consecutive-entry lines; the cut lines leave < 5e-7, the device census equals the host build of the same function,
+    AUTO therefore runs the bucket search, and the golden tuples come out of it"""
+    path = [p for p in FILES if "64x8" in p][0]
+    g, task = load_anymdp_golden(path)
+    n = len(g["ss_s"])
+    env = AnyMDPVecEnv(n, autoreset_mode="disabled")
+    env.set_task(task)
+    assert env.effective_search == "fence" and env.bucket_census()["built"] == 0
+    cen = env.probe_buckets(16)
+    assert cen["built"] == 0 and cen["format"] == 1 and cen["cuts_per_line"] == 7 and cen["n_bucket"] == 16
+    assert cen["lines"] == 64 * 8 * 16 and 0 < cen["p_fallback"] < 5e-7 and cen["auto_uses_bucket"] == 1
+    assert abs(cen["fallbacks_per_launch"] - cen["p_fallback"] * n) < 1e-12
+    assert env.effective_search == "fence"               # a probe allocates nothing and changes nothing
+    T = g["transition"]
+    live = np.setdiff1d(np.arange(64), g["s_e"])
+    c = np.cumsum(T[live].reshape(-1, 64), -1)
+    p_host, dirty_host = _host_cut_census(c / c[:, -1:], 16, 7)
+    assert cen["lines_dirty"] == dirty_host and cen["live_rows"] == len(live) * 8
+    assert abs(cen["p_fallback"] - p_host) <= 1e-9 + 1e-6 * p_host      # the device sums in fixed point, rounded up per wave
+    env.set_search("auto", n_bucket=16)
+    assert env.effective_search == "bucket" and env.bucket_census()["built"] == 1
+    assert env.bucket_census()["p_fallback"] == cen["p_fallback"]
+    env.set_state(inner_state=g["ss_s"], steps=np.zeros(n), need_reset=np.zeros(n))
+    obs, r, term, trunc, info = env.step_injected(g["ss_a"], g["ss_u"], g["ss_z"], np.zeros(n))
+    assert np.array_equal(_np(env.inner_state), g["ss_next"])
+    assert np.array_equal(_np(obs), g["state_mapping"][g["ss_next"]])
+    assert np.array_equal(_np(term).astype(np.uint8), g["ss_term"])
+    assert np.array_equal(_np(info["reward_gt"]), g["ss_rgt"].astype(np.float32))
+    assert close_f32(_np(r), g["ss_r"])
+    env.set_search("fence")
+    assert env.effective_search == "fence"
+    env.set_search("binary")
+    assert env.effective_search == "binary"
+    assert env.check_errors() == 0
+    env.close()
+
+
+def test_auto_keeps_the_fence_search_when_the_census_says_lines_overflow():
+    """uniform rows over 200 next states: 12.5 states per bucket of 1 / 16, far more than a line lists — the census says
+    so, AUTO stays on the fence search although the lines are built, and an explicit "bucket" still gives equal results"""
+    S, A, n_task, n_env = 200, 2, 3, 768
+    rng = np.random.RandomState(4)
+    T = np.ones((n_task, S, A, S)) * rng.uniform(0.9, 1.1, (n_task, S, A, S))
+    cdf = np.cumsum(T, -1)
+    cdf /= cdf[..., -1:]
+    rs = rng.standard_normal((n_task, S, A, S, 2)).astype(np.float32)
+    tab = dict(S=S, A=A, s0_max=2, cdf=cdf, rs=rs, state_map=np.tile(np.arange(S, dtype=np.int32), (n_task, 1)),
+               term_mask=np.zeros((n_task, 4), np.uint64), s0_cdf=np.tile(np.array([0.5, 1.0]), (n_task, 1)),
+               s0_ids=np.tile(np.array([0, 1], np.int32), (n_task, 1)), max_steps=np.full(n_task, 1000, np.int32))
+    env_task = rng.randint(0, n_task, n_env).astype(np.int32)
+    env = AnyMDPVecEnv(n_env, autoreset_mode="same_step", seed=1)
+    env.set_task(_dev_tables(tab), env_task_index=env_task)
+    cen = env.probe_buckets(16)
+    assert cen["p_fallback"] > 0.2 and cen["auto_uses_bucket"] == 0 and cen["lines_dirty"] == cen["lines"]
+    env.set_search("auto", n_bucket=16)                 # the census says no: nothing is built
+    assert env.effective_search == "fence" and env.bucket_census()["built"] == 0
+    env.set_search("bucket", n_bucket=16)
+    assert env.effective_search == "bucket"
+    env.set_search("auto")                              # lines exist now, AUTO still declines them
+    assert env.effective_search == "fence" and env.bucket_census()["built"] == 1
+    env.set_search("bucket", n_bucket=16)
+    ora = oracle.AnyMDPOracle(tab, env_task)
+    ur0 = rng.random_sample(n_env)
+    env.reset_injected(ur0); ora.reset_injected(ur0)
+    for t in range(10):
+        a = rng.randint(0, A, n_env).astype(np.int32)
+        u, z, ur = rng.random_sample(n_env), rng.standard_normal(n_env).astype(np.float32), rng.random_sample(n_env)
+        _compare_step(env.step_injected(a, u, z, ur), ora.step_injected(a, u, z, ur, 2))
+    assert env.check_errors() == 0
+    env.close()
+
+
+@pytest.mark.parametrize("S,big_obs", [(64, True), (300, False), (256, False), (257, True)])
+def test_bucket_lines_in_the_six_cut_packing(S, big_obs):
+    """observation ids above 255 or S > 256 take the wide metadata packing (6 cuts per line, format 2); S = 256 with small
+    ids is the largest task of the 7-cut packing.  Skewed rows (a few heavy states among runs of tiny ones), injected draws
+    on exact CDF entries and bucket edges, against the oracle."""
+    A, n_task, n_env = 3, 4, 1024
+    rng = np.random.RandomState(S + int(big_obs))
+    T = np.exp(-rng.uniform(0, 60, (n_task, S, A, S))) * (rng.random_sample((n_task, S, A, S)) < 0.4)
+    T[..., 0] += 1e-30
+    cdf = np.cumsum(T, -1)
+    cdf /= cdf[..., -1:]
+    rs = rng.standard_normal((n_task, S, A, S, 2)).astype(np.float32)
+    sm = np.stack([rng.permutation(S) for _ in range(n_task)]).astype(np.int32)
+    if big_obs:
+        sm = sm * 97 + 300                                # ids up to ~25,000
+    tm = np.zeros((n_task, (S + 63) // 64), np.uint64)
+    for t in range(n_task):
+        for s_ in rng.choice(np.arange(2, S), 5, replace=False):
+            tm[t, s_ // 64] |= np.uint64(1) << np.uint64(s_ % 64)
+    tab = dict(S=S, A=A, s0_max=2, cdf=cdf, rs=rs, state_map=sm, term_mask=tm, s0_cdf=np.tile(np.array([0.5, 1.0]), (n_task, 1)),
+               s0_ids=np.tile(np.array([0, 1], np.int32), (n_task, 1)), max_steps=np.full(n_task, 1000, np.int32),
+               obs_space=np.full(n_task, int(sm.max()) + 1))
+    env_task = rng.randint(0, n_task, n_env).astype(np.int32)
+    env = AnyMDPVecEnv(n_env, autoreset_mode="same_step", seed=1)
+    env.set_task(_dev_tables(tab), env_task_index=env_task)
+    env.set_search("bucket", n_bucket=16)
+    cen = env.bucket_census()
+    assert cen["format"] == (2 if (big_obs or S > 256) else 1) and cen["cuts_per_line"] == (6 if cen["format"] == 2 else 7)
+    assert cen["p_fallback"] < 1e-3
+    ora = oracle.AnyMDPOracle(tab, env_task)
+    ur0 = rng.random_sample(n_env)
+    env.reset_injected(ur0); ora.reset_injected(ur0)
+    for t in range(24):
+        a = rng.randint(0, A, n_env).astype(np.int32)
+        u, z, ur = rng.random_sample(n_env), rng.standard_normal(n_env).astype(np.float32), rng.random_sample(n_env)
+        k = rng.randint(0, n_env, 64)
+        rows = cdf[env_task[k], ora.state[k], a[k]]
+        u[k[:32]] = np.minimum(rows[np.arange(32), rng.randint(0, S, 32)], np.nextafter(1.0, 0.0))
+        u[k[32:]] = rng.randint(0, 16, 32) / 16
+        _compare_step(env.step_injected(a, u, z, ur), ora.step_injected(a, u, z, ur, 2))
+        s_, _, _ = env.get_state()
+        assert np.array_equal(_np(s_), ora.state)
+    tick = env.engine.tick
+    for t in range(8):                                    # free-running draws as well (Philox on the device)
+        a = rng.randint(0, A, n_env).astype(np.int32)
+        d = env.step(a)
+        _compare_step(d, ora.step(1, 0, tick + t, a, 2), exact_reward=False)   # the normal is device log / cos vs libm
+    assert env.check_errors() == 0
+    env.close()

@@ -52,6 +52,10 @@ SIGNATURES = {
     "xv_anymdp_rollout": [c_void_p, c_int] + [c_void_p] * 7,
     "xv_anymdp_set_search": [c_void_p, c_int],
     "xv_anymdp_build_buckets": [c_void_p, c_int],
+    "xv_anymdp_probe_buckets": [c_void_p, c_int, c_void_p],
+    "xv_anymdp_bucket_census_get": [c_void_p, c_void_p],
+    "xv_anymdp_effective_search": [c_void_p],
+    "xv_anymdp_token_kernel": [c_void_p],
     "xv_anymdp_set_observation_model": [c_void_p, c_int, c_int, c_int, c_void_p],
     "xv_anymdp_reset_tokens": [c_void_p, c_void_p, c_void_p],
     "xv_anymdp_reset_tokens_injected": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -116,11 +120,22 @@ _RESTYPE = {"xv_last_error": C.c_char_p, "xv_engine_stream": c_void_p}
 _lib = None
 
 
+class BucketCensus(C.Structure):
+    """xv_anymdp_bucket_census (include/xeno.h)"""
+    _fields_ = [("n_bucket", C.c_int32), ("format", C.c_int32), ("cuts_per_line", C.c_int32), ("built", C.c_int32),
+                ("auto_uses_bucket", C.c_int32), ("reserved", C.c_int32), ("lines", C.c_uint64), ("lines_dirty", C.c_uint64),
+                ("live_rows", C.c_uint64), ("p_fallback", C.c_double), ("fallbacks_per_launch", C.c_double),
+                ("bytes", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
 class XenoError(RuntimeError):
     pass
 
 
-ABI_VERSION = 7      # include/xeno.h XV_ABI_VERSION
+ABI_VERSION = 8      # include/xeno.h XV_ABI_VERSION
 
 
 def load():

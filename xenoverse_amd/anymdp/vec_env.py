@@ -158,15 +158,52 @@ class AnyMDPVecEnv(VectorEnv):
         self.need_reset = True
 
     SEARCH = {"auto": 0, "binary": 1, "fence": 3, "bucket": 4}
+    _SEARCH_NAME = {1: "binary", 3: "fence", 4: "bucket"}
 
-    def set_search(self, mode, n_bucket=32):
-        """Select how the categorical draw searches the CDF row (results are identical; see xeno.h).  "bucket" builds
-        n_task * S * A * n_bucket * 128 bytes of bucket lines (once) and makes a step one table line in one dependent
-        level; raises if they do not fit."""
-        if mode == "bucket" and getattr(self, "_n_bucket", 0) != n_bucket:
-            _lib.check(self.lib.xv_anymdp_build_buckets(self._h, int(n_bucket)))
-            self._n_bucket = n_bucket
+    def set_search(self, mode, n_bucket=None):
+        """Select how the categorical draw searches the CDF row (results are identical; see xeno.h).
+        "bucket": builds n_task * S * A * n_bucket * 128 bytes of bucket lines (once; default 32 buckets) and makes a step
+                  one table line in one dependent level; raises if they do not fit.
+        "auto":   the engine decides per launch: the bucket search when its lines are built AND their census expects fewer
+                  than 0.05 draws per launch that a line cannot answer, else the fence search (two dependent lines), else
+                  the per-lane binary search.  With n_bucket given, the lines are built first when — and only when —
+                  the census (taken without allocating anything) says AUTO would use them and they fit the free memory.
+        `effective_search` names what runs; `bucket_census()` has the numbers."""
+        if mode == "bucket":
+            n_bucket = 32 if n_bucket is None else n_bucket
+            if getattr(self, "_n_bucket", 0) != n_bucket:
+                _lib.check(self.lib.xv_anymdp_build_buckets(self._h, int(n_bucket)))
+                self._n_bucket = n_bucket
+        elif mode == "auto" and n_bucket is not None and getattr(self, "_n_bucket", 0) != n_bucket:
+            cen = self.probe_buckets(n_bucket)
+            free, _ = torch.cuda.mem_get_info(self.device)
+            if cen["auto_uses_bucket"] and cen["bytes"] + (4 << 30) <= free:
+                _lib.check(self.lib.xv_anymdp_build_buckets(self._h, int(n_bucket)))
+                self._n_bucket = n_bucket
         _lib.check(self.lib.xv_anymdp_set_search(self._h, self.SEARCH[mode]))
+        self._many_cache = None
+
+    def probe_buckets(self, n_bucket=16):
+        """census of the bucket lines these rows WOULD get (nothing allocated): xv_anymdp_probe_buckets -> dict"""
+        cen = _lib.BucketCensus()
+        _lib.check(self.lib.xv_anymdp_probe_buckets(self._h, int(n_bucket), C.byref(cen)))
+        return cen.as_dict()
+
+    def bucket_census(self):
+        """census of the bucket lines that are built (all zero when none are)"""
+        cen = _lib.BucketCensus()
+        _lib.check(self.lib.xv_anymdp_bucket_census_get(self._h, C.byref(cen)))
+        return cen.as_dict()
+
+    @property
+    def effective_search(self):
+        """"binary" | "fence" | "bucket": what a step launches now (how AUTO resolves)"""
+        return self._SEARCH_NAME[int(self.lib.xv_anymdp_effective_search(self._h))]
+
+    @property
+    def token_kernel(self):
+        """POMDP / multi-token tasks: "cooperative" (bucket lines) or "per-lane": the kernel step() launches now"""
+        return "cooperative" if int(self.lib.xv_anymdp_token_kernel(self._h)) == 1 else "per-lane"
 
     # ---- reset ------------------------------------------------------------------------------------
     def reset(self, *, seed=None, options=None):

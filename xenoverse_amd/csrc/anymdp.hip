@@ -23,12 +23,16 @@
 // (the first layout read a 32-B fence record, a 256-B block and a 128-B task header: 4 lines).
 // BINARY mode (any S <= 256, any s0 table) is the general per-lane fallback.
 //
-// BUCKET mode (xv_anymdp_build_buckets, opt-in: it spends memory) removes level 2.  The row's probability axis is cut
-// into NBK equal buckets; bucket line (row, k) holds the 7 entries that start at I[k] = #{cdf <= k / NBK} — the first
-// candidates for any u in [k / NBK, (k + 1) / NBK) — in the block format, with I[k] in the spare metadata byte.  The
-// line's address follows from the row index and the env's own uniform (k = floor(u * NBK), no memory), so a step is ONE
-// table line in ONE dependent level: s' = I[k] + #{cdf <= u}.  If all 7 entries are <= u (more than 7 next states
-// inside one bucket of probability 1 / NBK: rare for NBK = 32) the wave takes the fence path instead — same result.
+// BUCKET mode (xv_anymdp_build_buckets: it spends memory) removes level 2.  The row's probability axis is cut into NBK
+// equal buckets; bucket line (row, k) answers every u in [k / NBK, (k + 1) / NBK) by itself.  The line's address follows
+// from the row index and the env's own uniform (k = floor(u * NBK), no memory), so a step is ONE table line in ONE
+// dependent level.  Round 4: a line lists K CUTS of the row's CDF chosen for this bucket (anymdp_cutline.h) instead of
+// the 7 consecutive entries that start at #{cdf <= k / NBK}: unit c = {cut_c, reward pair of group c's next state}, the
+// metadata names each group's next state, its observation id and terminal flag, and flags the groups that lump a run of
+// (practically never drawn) states together.  c = #{cut <= u}; a draw that lands in a flagged group or beyond the last
+// cut sends its wave through the fence path — same result.  On the reference sampler's rows that is 5e-8 of the draws
+// (2.7e-2 with consecutive entries, which made the search slower than the fence search there).
+#include "anymdp_cutline.h"
 #include "philox.h"
 #include "xv_common.h"
 
@@ -64,6 +68,7 @@ struct AnyMDPArgs {
   int n_env, n_task, S, A, s0_max, words, NB, RL, G;   // RL = 1 + NB lines per row; G blocks per fence entry
   const uint4* bucket;   // [row][NBK] bucket lines (engine-owned, xv_anymdp_build_buckets); nullptr if not built
   int NBK;
+  int bfmt;              // metadata packing of the bucket lines: 1 = 7 cuts (S <= 256, observation ids <= 255), 2 = 6 cuts
   uint64_t seed, gid_base, tick;
   const uint64_t* tick_dev;   // graph replay: the launch tick is *tick_dev + tick (tick = node index); else nullptr
 };
@@ -91,6 +96,8 @@ struct xv_anymdp {
   int search;  // XV_ANYMDP_SEARCH_*
   bool fast;   // fence lines, block metadata and reset records are built
   uint4* bucket_rw;   // owned: the bucket lines
+  int max_obs;        // largest observation id of the tables (-1: not probed)
+  xv_anymdp_bucket_census census;   // of the lines that are built (xv_anymdp_build_buckets)
   const double* obs_cdf;   // observation model (POMDP / MTPOMDP), nullptr for MDP
   int n_obs, d_obs, d_act;
   uint4* obs_bucket;       // owned: observation bucket lines (built with the transition bucket lines)
@@ -154,16 +161,35 @@ __device__ __forceinline__ double xv_shfl_f64(double v, int src) {
 }
 __device__ __forceinline__ double xv_u2d(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 
+// Bucket ("cut") line metadata -> one word about group `sg` of the line: observation id (bits 0..15) | next state (16..24) |
+// terminal flag (25) | the group lumps several states, or is unused (26).  Meaningful on the metadata lane (unit 7) only.
+//   FMT 1: unit 7 = bytes 0..6 observation ids, byte 7 terminal bits, bytes 8..14 next states, byte 15 lumped bits (7 groups)
+//   FMT 2: unit 6 = 6 x u16 next states; unit 7 = 6 x u16 observation ids, .w = terminal bits | lumped bits << 8 (6 groups)
+template <int FMT>
+__device__ __forceinline__ uint32_t anymdp_cut_meta(const uint4& b4, int sg) {
+  if (FMT == 1) {
+    const uint32_t ow = sg < 4 ? b4.x : b4.y, sw = sg < 4 ? b4.z : b4.w;
+    const int sh = 8 * (sg & 3);
+    return ((ow >> sh) & 0xFFu) | (((sw >> sh) & 0xFFu) << 16) | (((b4.y >> (24 + sg)) & 1u) << 25) |
+           (((b4.w >> (24 + sg)) & 1u) << 26);
+  }
+  const uint32_t hw = sg < 2 ? b4.x : (sg < 4 ? b4.y : b4.z);
+  const uint32_t h16 = (hw >> (16 * (sg & 1))) & 0xFFFFu;   // lane of unit 6: the group's next state; of unit 7: its observation id
+  const uint32_t st = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h16, 0x111 /* row_shr:1: lane 7 <- lane 6 */, 0xF, 0xF, false);
+  return h16 | ((st & 0x1FFu) << 16) | (((b4.w >> sg) & 1u) << 25) | (((b4.w >> (8 + sg)) & 1u) << 26);
+}
+
 // T_steps == 1: one vector step.  T_steps > 1: fused rollout, io arrays are [T][n_env], mode SAME_STEP.
 // FAST: fence line + block line, per-env reset record; otherwise per-lane binary search and per-task tables.
 // G: 0 = per-lane binary search and per-task tables; 1..5 = fence path, a fence entry names G consecutive blocks
 //    (G = 1 for S <= 112, 2 for S <= 224, 3 for S <= 336, 4 for S <= 448, 5 up to 512: the fence always fits one line,
 //    the last level reads G lines).
 // TICKDEV: the launch tick is *P.tick_dev + P.tick (graph replay); otherwise P.tick (a kernel argument).
-// BK: bucket mode: the step's table line is named by (row, floor(u * NBK)); G only shapes the fence fall-back.
+// BK: bucket mode (0 off, 1 / 2 = the lines' metadata packing, AnyMDPArgs::bfmt): the step's table line is named by
+//     (row, floor(u * NBK)); G only shapes the fence fall-back.
 // `bid`: the workgroup's index within this family's part of the launch (blockIdx.x for the family's own kernels; the fused
 // mixed-batch kernel of mixed.hip hands every family a contiguous range of its workgroups)
-template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false, bool BK = false>
+template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false, int BK = 0>
 __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyMDPStepIO& io, int T_steps, int mode, int bid) {
   constexpr bool FAST = G > 0;
   constexpr int GG = G > 0 ? G : 1;
@@ -278,22 +304,19 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
 #pragma unroll
       for (int it = 0; it < 8; ++it) ue[it] = xv_shfl_f64(u, it * 8 + g);
       __builtin_amdgcn_sched_barrier(0);
+      constexpr int KC = BK == 2 ? 6 : 7;   // cuts per line
       int cnt_own = 0;
       float rx = 0.0f, ry = 0.0f;
       uint32_t meta_own = 0;
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const unsigned long long m = __ballot(j < 7 && xv_u2d(bv[it].x, bv[it].y) <= ue[it]);
-        const int cg = __popc((unsigned)(m >> (8 * g)) & 0x7Fu);   // reader side: the env this lane group serves
-        const int co = __popc((unsigned)(m >> (8 * j)) & 0x7Fu);   // owner side: the env this lane owns
-        const int sg = cg < 6 ? cg : 6;
-        const uint4 b4 = bv[it];
-        const uint32_t mw = sg < 2 ? b4.x : (sg < 4 ? b4.y : (sg < 6 ? b4.z : b4.w));
-        // observation id, terminal flag of the chosen entry and the line's first next-state index, one word
-        const uint32_t packed = ((mw >> (16 * (sg & 1))) & 0xFFFFu) | (((b4.w >> (16 + sg)) & 1u) << 16) | ((b4.w >> 23) << 17);
-        const int so = co < 6 ? co : 6;
-        const float px = __shfl(__uint_as_float(b4.z), 8 * j + so);
-        const float py = __shfl(__uint_as_float(b4.w), 8 * j + so);
+        const unsigned long long m = __ballot(j < KC && xv_u2d(bv[it].x, bv[it].y) <= ue[it]);
+        const int cg = __popc((unsigned)(m >> (8 * g)) & 0xFFu);   // reader side: the env this lane group serves
+        const int co = __popc((unsigned)(m >> (8 * j)) & 0xFFu);   // owner side: the env this lane owns
+        const uint32_t packed = anymdp_cut_meta<BK>(bv[it], cg < KC - 1 ? cg : KC - 1);
+        const int so = co < KC - 1 ? co : KC - 1;
+        const float px = __shfl(__uint_as_float(bv[it].z), 8 * j + so);
+        const float py = __shfl(__uint_as_float(bv[it].w), 8 * j + so);
         const uint32_t pm = (uint32_t)__shfl((int)packed, 8 * j + 7);
 #if XV_ANYMDP_SELECT
         { const bool own = g == it; cnt_own = own ? co : cnt_own; rx = own ? px : rx; ry = own ? py : ry; meta_own = own ? pm : meta_own; }
@@ -301,12 +324,12 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
         if (g == it) { cnt_own = co; rx = px; ry = py; meta_own = pm; }
 #endif
       }
-      s2 = (int)(meta_own >> 17) + cnt_own;
-      s2 = s2 < S - 1 ? s2 : S - 1;
+      s2 = (int)((meta_own >> 16) & 0x1FFu);
       rsv = make_float2(rx, ry);
       obs2 = (int)(meta_own & 0xFFFFu);
-      term2 = (meta_own >> 16) & 1u;
-      need_fence = __ballot(cnt_own >= XV_ANYMDP_BLK) != 0ull;   // wave-uniform: some env's s' lies beyond its line
+      term2 = (meta_own >> 25) & 1u;
+      // wave-uniform: some env's draw lies beyond the last cut of its line or in a group that lumps several states
+      need_fence = __ballot(cnt_own >= KC || ((meta_own >> 26) & 1u)) != 0ull;
     }
     if (FAST && need_fence) {
       const uint32_t fl = rowidx * (uint32_t)P.RL;   // fence line of the row
@@ -490,7 +513,7 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
   if (err) atomicOr(P.err, err);
 }
 
-template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false, bool BK = false>
+template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false, int BK = 0>
 __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPStepIO io, int T_steps, int mode) {
   anymdp_step_body<INJECT, G, ROLLOUT, TICKDEV, BK>(P, io, T_steps, mode, (int)blockIdx.x);
 }
@@ -536,51 +559,66 @@ static __global__ __launch_bounds__(256) void anymdp_finish_rows_kernel(AnyMDPAr
   }
 }
 
-// Bucket lines (xv_anymdp_build_buckets): one wave per row, lane q and q + 64, ... each write one 16-byte unit.
-//   line (row, k), unit m < 7: the entry of next state I[k] + m (cdf 2.0 past the row), I[k] = #{cdf <= k / NBK}
-//   unit 7: the block metadata of those seven states (clamped to S - 1, as s' is) with I[k] in bits 23..31 of .w
-static __global__ __launch_bounds__(256) void anymdp_build_buckets_kernel(AnyMDPArgs P, uint4* bucket, size_t row_base,
-                                                                   size_t n_rows, int NBK) {
-  const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (w >= n_rows) return;
-  const int lane = threadIdx.x & 63;
-  const size_t r = row_base + w;
-  const int t = (int)(r / ((size_t)P.S * P.A));
-  const uint4* row = P.lines + r * (size_t)P.RL * 8;
-  for (int q = lane; q < NBK * 8; q += 64) {
-    const int k = q >> 3, m = q & 7;
-    const double thr = (double)k / (double)NBK;
-    int lo = 0, n = P.S;                       // I = #{cdf <= thr} (upper bound; the CDF is non-decreasing)
-    while (n > 0) {
-      const int half = n >> 1;
-      const int jj = lo + half;
-      const double c = reinterpret_cast<const double*>(row + (size_t)(1 + jj / XV_ANYMDP_BLK) * 8 + (jj % XV_ANYMDP_BLK))[0];
-      if (c <= thr) { lo += half + 1; n -= half + 1; } else n = half;
-    }
-    const int I = lo < 511 ? lo : 511;
-    uint4 out;
-    if (m < 7) {
-      const int jn = I + m;
-      if (jn < P.S) {
-        out = row[(size_t)(1 + jn / XV_ANYMDP_BLK) * 8 + (jn % XV_ANYMDP_BLK)];
-      } else {   // cdf 2.0 and the reward pair of next state S-1 (what a clamped s' gets, see anymdp_finish_rows_kernel)
-        const uint4 last = row[(size_t)(1 + (P.S - 1) / XV_ANYMDP_BLK) * 8 + ((P.S - 1) % XV_ANYMDP_BLK)];
-        out = make_uint4(0u, 0x40000000u, last.z, last.w);
+// Bucket lines (xv_anymdp_build_buckets): one thread per (row, bucket) chooses the line's cuts (anymdp_cutline.h) and writes
+// its 8 units; `bucket` == nullptr: census only (xv_anymdp_probe_buckets).  census[0] += lines with draws they cannot
+// answer, census[1] += their probability mass (fixed point, 2^-36, rounded up per wave), census[2] += live rows (rows of
+// terminal states are never drawn from and count nowhere).
+template <int FMT>
+static __global__ __launch_bounds__(256) void anymdp_build_cutlines_kernel(AnyMDPArgs P, uint4* bucket, size_t row_base,
+                                                                          size_t n_rows, int NBK, unsigned long long* census) {
+  constexpr int KC = FMT == 2 ? 6 : 7;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double mass = 0.0;
+  bool live_row = false;
+  if (idx < n_rows * (size_t)NBK) {
+    const size_t r = row_base + idx / (size_t)NBK;
+    const int k = (int)(idx % (size_t)NBK);
+    const int t = (int)(r / ((size_t)P.S * P.A)), s_cur = (int)((r / (size_t)P.A) % (size_t)P.S);
+    const uint4* row = P.lines + r * (size_t)P.RL * 8;
+    auto unit = [row](int jn) { return row + (size_t)(1 + jn / XV_ANYMDP_BLK) * 8 + (jn % XV_ANYMDP_BLK); };
+    auto cdf = [&unit](int jn) { return reinterpret_cast<const double*>(unit(jn))[0]; };
+    XvCutLine L;
+    xv_cutline_build(cdf, P.S, (double)k / (double)NBK, (double)(k + 1) / (double)NBK, KC, L);
+    const bool term_row = (P.term_mask[(size_t)t * P.words + (s_cur >> 6)] >> (s_cur & 63)) & 1ull;
+    if (!term_row) mass = L.dirty_mass;
+    live_row = !term_row && k == 0;
+    if (bucket) {
+      uint4* out = bucket + (r * (size_t)NBK + k) * 8;
+      uint32_t ob[7], st[7], tb = 0;
+#pragma unroll
+      for (int c = 0; c < 7; ++c) {
+        ob[c] = 0; st[c] = 0;
+        if (c < KC) {
+          const int sn = L.state[c];
+          const uint4 e = *unit(L.entry[c]);
+          out[c] = make_uint4((uint32_t)__double2loint(L.cut[c]), (uint32_t)__double2hiint(L.cut[c]), e.z, e.w);
+          ob[c] = (uint32_t)P.state_map[(size_t)t * P.S + sn];
+          st[c] = (uint32_t)sn;
+          if ((P.term_mask[(size_t)t * P.words + (sn >> 6)] >> (sn & 63)) & 1ull) tb |= 1u << c;
+        }
       }
-    } else {
-      uint32_t wd[4] = {0, 0, 0, 0};
-      uint32_t tb = 0;
-      for (int e = 0; e < XV_ANYMDP_BLK; ++e) {
-        int sn = I + e;
-        sn = sn < P.S - 1 ? sn : P.S - 1;
-        const uint32_t ob = (uint32_t)P.state_map[(size_t)t * P.S + sn] & 0xFFFFu;
-        wd[e >> 1] |= ob << (16 * (e & 1));
-        if ((P.term_mask[(size_t)t * P.words + (sn >> 6)] >> (sn & 63)) & 1ull) tb |= 1u << e;
+      if (FMT == 1) {
+        out[7] = make_uint4((ob[0] & 0xFFu) | ((ob[1] & 0xFFu) << 8) | ((ob[2] & 0xFFu) << 16) | ((ob[3] & 0xFFu) << 24),
+                            (ob[4] & 0xFFu) | ((ob[5] & 0xFFu) << 8) | ((ob[6] & 0xFFu) << 16) | (tb << 24),
+                            (st[0] & 0xFFu) | ((st[1] & 0xFFu) << 8) | ((st[2] & 0xFFu) << 16) | ((st[3] & 0xFFu) << 24),
+                            (st[4] & 0xFFu) | ((st[5] & 0xFFu) << 8) | ((st[6] & 0xFFu) << 16) | ((L.dirty & 0x7Fu) << 24));
+      } else {
+        out[6] = make_uint4((st[0] & 0xFFFFu) | (st[1] << 16), (st[2] & 0xFFFFu) | (st[3] << 16), (st[4] & 0xFFFFu) | (st[5] << 16), 0u);
+        out[7] = make_uint4((ob[0] & 0xFFFFu) | (ob[1] << 16), (ob[2] & 0xFFFFu) | (ob[3] << 16), (ob[4] & 0xFFFFu) | (ob[5] << 16),
+                            (tb & 0x3Fu) | ((L.dirty & 0x3Fu) << 8));
       }
-      wd[3] |= (tb << 16) | ((uint32_t)I << 23);   // 7 terminal bits at 16..22, the line's first next-state index at 23..31
-      out = make_uint4(wd[0], wd[1], wd[2], wd[3]);
     }
-    bucket[(r * (size_t)NBK + k) * 8 + m] = out;
+  }
+  const unsigned long long dm = __ballot(mass > 0.0), lm = __ballot(live_row);
+  double sum = mass;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+  if ((threadIdx.x & 63) == 0) {
+    if (dm) {
+      atomicAdd(census + 0, (unsigned long long)__popcll(dm));
+      atomicAdd(census + 1, (unsigned long long)ceil(sum * 68719476736.0));
+    }
+    if (lm) atomicAdd(census + 2, (unsigned long long)__popcll(lm));
   }
 }
 
@@ -725,7 +763,6 @@ __device__ __forceinline__ void anymdp_tok_observe(const AnyMDPArgs& P, const An
 
 template <bool INJECT>
 __global__ __launch_bounds__(256) void anymdp_tok_step_kernel(AnyMDPArgs P, AnyMDPTokArgs K, AnyMDPTokIO io, int mode) {
-  const bool BK = P.bucket != nullptr && P.NBK > 0;   // bucket search selected (the launcher hands the lines over only then)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
   const int S = P.S, A = P.A, N = P.n_env;
@@ -765,22 +802,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_kernel(AnyMDPArgs P, AnyM
       const uint32_t rowidx = ((uint32_t)t * S + s) * A + a;
       int lo = -1;
       float2 rsv = make_float2(0.0f, 0.0f);
-      if (BK) {   // bucket line of (row, floor(u * NBK)), read per lane: the 7 candidate entries in one dependent level
-        const uint4* bl = P.bucket + ((size_t)rowidx * P.NBK + (size_t)(int)(u * (double)P.NBK)) * 8;
-        uint4 en[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) en[q] = bl[q];
-        int cnt = 0;
-#pragma unroll
-        for (int q = 0; q < 7; ++q) cnt += xv_u2d(en[q].x, en[q].y) <= u ? 1 : 0;
-        if (cnt < 7) {
-          lo = (int)(en[7].w >> 23) + cnt;
-#pragma unroll
-          for (int q = 0; q < 7; ++q)
-            if (q == cnt) rsv = make_float2(__uint_as_float(en[q].z), __uint_as_float(en[q].w));
-        }
-      }
-      if (lo < 0) {   // no bucket lines, or s' lies beyond the line: search the row
+      {   // per-lane search of the row
         lo = 0;
         int m = S;
         while (m > 0) {
@@ -854,27 +876,29 @@ struct AnyMDPCoopLine {
   __device__ __forceinline__ void issue_if(const uint4* base, uint32_t line, bool want, int lane) {
     issue(base, want ? line : 0u, lane);
   }
-  // transition bucket line: 7 entries {cdf, reward, noise} + metadata  ->  cnt = #{cdf <= u}, the reward pair of entry
-  // min(cnt, 6), meta = observation id | terminal flag << 16 | first next-state index << 17 of that entry
-  __device__ __forceinline__ void resolve_entry(double u, int lane, int& cnt, float& rx, float& ry, uint32_t& meta) const {
+  // transition bucket line (anymdp_cutline.h): K cuts {cut, reward, noise} + metadata  ->  the reward pair of the group
+  // c = #{cut <= u} and meta = its observation id | next state << 16 | terminal flag << 25 (anymdp_cut_meta);
+  // beyond = the line cannot answer this draw (c == K, or the group lumps several states): search the row
+  template <int FMT>
+  __device__ __forceinline__ void resolve_entry(double u, int lane, bool& beyond, float& rx, float& ry, uint32_t& meta) const {
+    constexpr int KC = FMT == 2 ? 6 : 7;
     const int g = lane >> 3, j = lane & 7;
-    cnt = 0; rx = 0.0f; ry = 0.0f; meta = 0u;
+    int cnt = 0;
+    rx = 0.0f; ry = 0.0f; meta = 0u;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const double ue = xv_shfl_f64(u, it * 8 + g);
-      const unsigned long long m = __ballot(j < 7 && xv_u2d(bv[it].x, bv[it].y) <= ue);
-      const int cg = __popc((unsigned)(m >> (8 * g)) & 0x7Fu);   // reader side: the env this lane group serves
-      const int co = __popc((unsigned)(m >> (8 * j)) & 0x7Fu);   // owner side: the env this lane owns
-      const int sg = cg < 6 ? cg : 6;
-      const uint4 b4 = bv[it];
-      const uint32_t mw = sg < 2 ? b4.x : (sg < 4 ? b4.y : (sg < 6 ? b4.z : b4.w));
-      const uint32_t packed = ((mw >> (16 * (sg & 1))) & 0xFFFFu) | (((b4.w >> (16 + sg)) & 1u) << 16) | ((b4.w >> 23) << 17);
-      const int so = co < 6 ? co : 6;
-      const float px = __shfl(__uint_as_float(b4.z), 8 * j + so);
-      const float py = __shfl(__uint_as_float(b4.w), 8 * j + so);
+      const unsigned long long m = __ballot(j < KC && xv_u2d(bv[it].x, bv[it].y) <= ue);
+      const int cg = __popc((unsigned)(m >> (8 * g)) & 0xFFu);   // reader side: the env this lane group serves
+      const int co = __popc((unsigned)(m >> (8 * j)) & 0xFFu);   // owner side: the env this lane owns
+      const uint32_t packed = anymdp_cut_meta<FMT>(bv[it], cg < KC - 1 ? cg : KC - 1);
+      const int so = co < KC - 1 ? co : KC - 1;
+      const float px = __shfl(__uint_as_float(bv[it].z), 8 * j + so);
+      const float py = __shfl(__uint_as_float(bv[it].w), 8 * j + so);
       const uint32_t pm = (uint32_t)__shfl((int)packed, 8 * j + 7);
       { const bool own = g == it; cnt = own ? co : cnt; rx = own ? px : rx; ry = own ? py : ry; meta = own ? pm : meta; }
     }
+    beyond = cnt >= KC || ((meta >> 26) & 1u);
   }
   // observation bucket line: 16 doubles, the first 15 are CDF entries (2.0 past the row), the last holds {I, 0x40000000}
   // (a double just above 2.0, never <= u)  ->  cnt = #{entries <= u}, first = I
@@ -918,7 +942,7 @@ static __global__ __launch_bounds__(256) void anymdp_build_obs_buckets_kernel(co
   }
 }
 
-template <bool INJECT>
+template <bool INJECT, int FMT>
 __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P, AnyMDPTokArgs K, AnyMDPTokIO io, int mode) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < P.n_env;
@@ -1037,15 +1061,14 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
       u_next = __hiloint2double(uhi, ulo);
     }
     __builtin_amdgcn_sched_barrier(0);
-    int cnt;
+    bool beyond;
     float rx, ry;
     uint32_t meta;
-    L.resolve_entry(u_cur, lane, cnt, rx, ry, meta);
-    int s2 = (int)(meta >> 17) + cnt;
-    s2 = s2 < S - 1 ? s2 : S - 1;
-    bool term2 = (meta >> 16) & 1u;
+    L.template resolve_entry<FMT>(u_cur, lane, beyond, rx, ry, meta);
+    int s2 = (int)((meta >> 16) & 0x1FFu);
+    bool term2 = (meta >> 25) & 1u;
     float2 rsv = make_float2(rx, ry);
-    if (alive && cnt >= XV_ANYMDP_BLK) {   // s' lies beyond the line: search the row
+    if (alive && beyond) {   // the line cannot answer this draw: search the row
       int lo = 0, m = S;
       while (m > 0) {
         const int half = m >> 1;
@@ -1274,6 +1297,18 @@ static inline void anymdp_bind_rng(xv_anymdp* h, uint64_t ticks) {
   h->eng->tick += ticks;
 }
 
+// What the handle's search setting means right now.  AUTO takes the bucket search only when its lines are built AND their
+// census says a launch of this batch size meets a draw they cannot answer less often than XV_ANYMDP_AUTO_FALLBACKS (one
+// such draw sends its wave, and with it the launch, through three dependent lines instead of one); else FENCE; else BINARY.
+#define XV_ANYMDP_AUTO_FALLBACKS 0.05
+static inline int anymdp_effective_search(const xv_anymdp* h) {
+  if (h->search == XV_ANYMDP_SEARCH_BINARY || !h->fast) return XV_ANYMDP_SEARCH_BINARY;
+  if (h->a.bucket != nullptr &&
+      (h->search == XV_ANYMDP_SEARCH_BUCKET || (h->search == XV_ANYMDP_SEARCH_AUTO && h->census.auto_uses_bucket)))
+    return XV_ANYMDP_SEARCH_BUCKET;
+  return XV_ANYMDP_SEARCH_FENCE;
+}
+
 #ifndef XV_KERNELS_ONLY   // mixed.hip includes this file for its kernels and handle types only
 // ------------------------------------------------------------------------------------------------
 // C-ABI
@@ -1303,6 +1338,8 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
   h->search = XV_ANYMDP_SEARCH_AUTO;
   h->fast = false;
   h->obs_cdf = nullptr; h->n_obs = 0; h->d_obs = 0; h->d_act = 0; h->obs_bucket = nullptr;
+  h->max_obs = -1;
+  memset(&h->census, 0, sizeof(h->census));
   h->graph_mode = 2; h->graph_failed = false; h->graph = nullptr; h->graph_exec = nullptr;
   h->d_tick = nullptr; h->d_tick_value = 0; h->d_tick_valid = false;
   memset(&h->graph_key, 0, sizeof(h->graph_key));
@@ -1337,6 +1374,7 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
     if (fast) {
       r = device_max(state_map, (size_t)n_task * S, &h_max);
       fast = r == hipSuccess && h_max < 65536;
+      if (r == hipSuccess) h->max_obs = h_max;
     }
     if (fast) {   // max_steps shares its per-env word with four flags: it must fit 27 bits
       r = device_max(max_steps, (size_t)n_task, &h_max);
@@ -1421,19 +1459,26 @@ static int anymdp_launch_step(xv_anymdp* h, const AnyMDPStepIO& io, int T, int m
   hipLaunchKernelGGL((anymdp_step_kernel<INJECT, GV, ROLL>), grid, block, 0, h->eng->stream, h->a, io, T, mode)
 #define XV_LAUNCH_STEP_G(GV) do { if (roll) XV_LAUNCH_STEP(GV, true); else XV_LAUNCH_STEP(GV, false); } while (0)
   const bool roll = T > 1 || io.greedy != nullptr;
-  if (h->search == XV_ANYMDP_SEARCH_BUCKET && h->a.bucket != nullptr) {
-#define XV_LAUNCH_BK(GV)                                                                                                  \
+  const int eff = anymdp_effective_search(h);
+  if (eff == XV_ANYMDP_SEARCH_BUCKET) {
+#define XV_LAUNCH_BK(GV, FV)                                                                                              \
   do {                                                                                                                     \
-    if (roll) hipLaunchKernelGGL((anymdp_step_kernel<INJECT, GV, true, false, true>), grid, block, 0, h->eng->stream, h->a, io, T, mode);  \
-    else hipLaunchKernelGGL((anymdp_step_kernel<INJECT, GV, false, false, true>), grid, block, 0, h->eng->stream, h->a, io, T, mode);      \
+    if (roll) hipLaunchKernelGGL((anymdp_step_kernel<INJECT, GV, true, false, FV>), grid, block, 0, h->eng->stream, h->a, io, T, mode);  \
+    else hipLaunchKernelGGL((anymdp_step_kernel<INJECT, GV, false, false, FV>), grid, block, 0, h->eng->stream, h->a, io, T, mode);      \
   } while (0)
-    if (h->a.G == 1) XV_LAUNCH_BK(1);
-    else if (h->a.G == 2) XV_LAUNCH_BK(2);
-    else if (h->a.G == 3) XV_LAUNCH_BK(3);
-    else if (h->a.G == 4) XV_LAUNCH_BK(4);
-    else XV_LAUNCH_BK(5);
+    if (h->a.bfmt == 1) {        // 7 cuts per line: S <= 256, i.e. G <= 3
+      if (h->a.G == 1) XV_LAUNCH_BK(1, 1);
+      else if (h->a.G == 2) XV_LAUNCH_BK(2, 1);
+      else XV_LAUNCH_BK(3, 1);
+    } else {
+      if (h->a.G == 1) XV_LAUNCH_BK(1, 2);
+      else if (h->a.G == 2) XV_LAUNCH_BK(2, 2);
+      else if (h->a.G == 3) XV_LAUNCH_BK(3, 2);
+      else if (h->a.G == 4) XV_LAUNCH_BK(4, 2);
+      else XV_LAUNCH_BK(5, 2);
+    }
 #undef XV_LAUNCH_BK
-  } else if (h->fast && h->search != XV_ANYMDP_SEARCH_BINARY) {
+  } else if (eff == XV_ANYMDP_SEARCH_FENCE) {
     if (h->a.G == 1) XV_LAUNCH_STEP_G(1);
     else if (h->a.G == 2) XV_LAUNCH_STEP_G(2);
     else if (h->a.G == 3) XV_LAUNCH_STEP_G(3);
@@ -1474,10 +1519,11 @@ extern "C" int xv_anymdp_step_injected(xv_anymdp* h, const int32_t* action, cons
 // dependent launches cost ~3.3 us each on a stream and ~1.6 us as graph nodes (scripts/devtools/graph_floor.hip).
 static bool anymdp_ensure_graph(xv_anymdp* h, int period, const int32_t* actions, int32_t* obs, float* reward,
                                 float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
-  const bool fast = h->fast && h->search != XV_ANYMDP_SEARCH_BINARY;
+  const int eff = anymdp_effective_search(h);
+  const bool fast = eff != XV_ANYMDP_SEARCH_BINARY;
   const void* ptrs[7] = {actions, obs, reward, reward_gt, terminated, truncated, final_obs};
   auto& K = h->graph_key;
-  if (h->graph_exec && K.period == period && K.mode == mode && K.search == h->search && K.fast == (int)fast &&
+  if (h->graph_exec && K.period == period && K.mode == mode && K.search == eff && K.fast == (int)fast &&
       K.bucket == (const void*)h->a.bucket && K.nbk == h->a.NBK &&
       K.seed == h->eng->seed && K.gid_base == h->eng->env_id_base && memcmp(K.ptrs, ptrs, sizeof(ptrs)) == 0)
     return true;
@@ -1487,14 +1533,15 @@ static bool anymdp_ensure_graph(xv_anymdp* h, int period, const int32_t* actions
   if (hipGraphCreate(&h->graph, 0) != hipSuccess) return false;
   const size_t n = (size_t)h->a.n_env;
   const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
-  const bool bk = h->search == XV_ANYMDP_SEARCH_BUCKET && h->a.bucket != nullptr;
+  const int bk = eff == XV_ANYMDP_SEARCH_BUCKET ? h->a.bfmt : 0;
 #define XV_STEP_FN(GV, BKV) reinterpret_cast<void*>(&anymdp_step_kernel<false, GV, false, true, BKV>)
   const int Gv = h->a.G;
-  void* fn = bk ? (Gv == 1 ? XV_STEP_FN(1, true) : Gv == 2 ? XV_STEP_FN(2, true) : Gv == 3 ? XV_STEP_FN(3, true)
-                   : Gv == 4 ? XV_STEP_FN(4, true) : XV_STEP_FN(5, true))
-             : !fast ? XV_STEP_FN(0, false)
-             : (Gv == 1 ? XV_STEP_FN(1, false) : Gv == 2 ? XV_STEP_FN(2, false) : Gv == 3 ? XV_STEP_FN(3, false)
-                : Gv == 4 ? XV_STEP_FN(4, false) : XV_STEP_FN(5, false));
+  void* fn = bk == 1 ? (Gv == 1 ? XV_STEP_FN(1, 1) : Gv == 2 ? XV_STEP_FN(2, 1) : XV_STEP_FN(3, 1))
+             : bk == 2 ? (Gv == 1 ? XV_STEP_FN(1, 2) : Gv == 2 ? XV_STEP_FN(2, 2) : Gv == 3 ? XV_STEP_FN(3, 2)
+                          : Gv == 4 ? XV_STEP_FN(4, 2) : XV_STEP_FN(5, 2))
+             : !fast ? XV_STEP_FN(0, 0)
+             : (Gv == 1 ? XV_STEP_FN(1, 0) : Gv == 2 ? XV_STEP_FN(2, 0) : Gv == 3 ? XV_STEP_FN(3, 0)
+                : Gv == 4 ? XV_STEP_FN(4, 0) : XV_STEP_FN(5, 0));
 #undef XV_STEP_FN
   hipGraphNode_t prev = nullptr;
   for (int j = 0; j <= period; ++j) {
@@ -1521,7 +1568,7 @@ static bool anymdp_ensure_graph(xv_anymdp* h, int period, const int32_t* actions
     prev = node;
   }
   if (hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0) != hipSuccess) { h->graph_exec = nullptr; return false; }
-  K.period = period; K.mode = mode; K.search = h->search; K.fast = (int)fast;
+  K.period = period; K.mode = mode; K.search = eff; K.fast = (int)fast;
   K.bucket = (const void*)h->a.bucket; K.nbk = h->a.NBK;
   K.seed = h->eng->seed; K.gid_base = h->eng->env_id_base;
   memcpy(K.ptrs, ptrs, sizeof(ptrs));
@@ -1670,8 +1717,13 @@ static int anymdp_build_obs_buckets(xv_anymdp* h) {
   if (!h->obs_cdf || !h->a.bucket || h->a.NBK <= 0) return XV_OK;
   const size_t n_rows = (size_t)h->a.n_task * h->d_obs * h->a.S;
   if (n_rows * (size_t)h->a.NBK >= (1ull << 32)) return XV_OK;      // 32-bit line index: the per-lane kernel serves
+  // budget: the lines may take what is free minus 2 GiB of headroom for the caller (1,024 tasks x 4 tokens x S = 256 x 16
+  // buckets are 2 GiB); beyond that the per-lane kernel serves (xv_anymdp_token_kernel reports which one runs)
+  size_t free_b = 0, total_b = 0;
+  const size_t need = n_rows * (size_t)h->a.NBK * 128;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need + ((size_t)2 << 30) > free_b) return XV_OK;
   uint4* b = nullptr;
-  if (hipMalloc(&b, n_rows * (size_t)h->a.NBK * 128) != hipSuccess) {
+  if (hipMalloc(&b, need) != hipSuccess) {
     (void)hipGetLastError();
     return XV_OK;                                                  // not fatal: the per-lane kernel serves
   }
@@ -1680,6 +1732,75 @@ static int anymdp_build_obs_buckets(xv_anymdp* h) {
   XV_LAUNCH_CHECK();
   h->obs_bucket = b;
   return XV_OK;
+}
+
+// runs the cut-line builder over every row: writes the lines into `b` (nullptr: census only) and fills `out`
+static int anymdp_run_cutlines(xv_anymdp* h, int n_bucket, uint4* b, xv_anymdp_bucket_census* out) {
+  const size_t n_rows = (size_t)h->a.n_task * h->a.S * h->a.A;
+  const int fmt = (h->a.S <= 256 && h->max_obs >= 0 && h->max_obs <= 255) ? 1 : 2;
+  unsigned long long* d_cen = nullptr;
+  XV_HIP(hipMalloc(&d_cen, 3 * sizeof(unsigned long long)));
+  hipError_t r = hipMemsetAsync(d_cen, 0, 3 * sizeof(unsigned long long), h->eng->stream);
+  const size_t chunk = (size_t)1 << 22;      // rows per launch: a launch holds fewer than 2^32 threads
+  for (size_t r0 = 0; r == hipSuccess && r0 < n_rows; r0 += chunk) {
+    const size_t nr = n_rows - r0 < chunk ? n_rows - r0 : chunk;
+    const dim3 grid((unsigned)((nr * (size_t)n_bucket + 255) / 256)), block(256);
+    if (fmt == 1) hipLaunchKernelGGL(anymdp_build_cutlines_kernel<1>, grid, block, 0, h->eng->stream, h->a, b, r0, nr, n_bucket, d_cen);
+    else hipLaunchKernelGGL(anymdp_build_cutlines_kernel<2>, grid, block, 0, h->eng->stream, h->a, b, r0, nr, n_bucket, d_cen);
+    r = hipGetLastError();
+  }
+  unsigned long long cen[3] = {0, 0, 0};
+  if (r == hipSuccess) r = hipMemcpyAsync(cen, d_cen, sizeof(cen), hipMemcpyDeviceToHost, h->eng->stream);
+  if (r == hipSuccess) r = hipStreamSynchronize(h->eng->stream);
+  (void)hipFree(d_cen);
+  if (r != hipSuccess) {
+    xv_set_error("xv_anymdp_build_buckets: building the lines failed: %s", hipGetErrorString(r));
+    return XV_ERR_HIP;
+  }
+  memset(out, 0, sizeof(*out));
+  out->n_bucket = n_bucket;
+  out->format = fmt;
+  out->cuts_per_line = fmt == 1 ? 7 : 6;
+  out->built = b != nullptr;
+  out->lines = (uint64_t)(n_rows * (size_t)n_bucket);
+  out->lines_dirty = (uint64_t)cen[0];
+  out->live_rows = (uint64_t)cen[2];
+  out->p_fallback = cen[2] ? (double)cen[1] / 68719476736.0 / (double)cen[2] : 0.0;
+  out->fallbacks_per_launch = out->p_fallback * (double)h->a.n_env;
+  out->auto_uses_bucket = out->fallbacks_per_launch <= XV_ANYMDP_AUTO_FALLBACKS;
+  out->bytes = (double)n_rows * (double)n_bucket * 128.0;
+  return XV_OK;
+}
+
+static int anymdp_buckets_supported(const xv_anymdp* h, int n_bucket) {
+  if (!h->fast) {
+    xv_set_error("xv_anymdp_build_buckets: needs the fence layout (s0_max <= 4, observation ids < 65536, max_steps < 2^27)");
+    return XV_ERR_UNSUPPORTED;
+  }
+  const size_t n_rows = (size_t)h->a.n_task * h->a.S * h->a.A;
+  if (n_rows * (size_t)n_bucket >= (1ull << 32)) {
+    xv_set_error("xv_anymdp_build_buckets: %zu bucket lines exceed the 32-bit line index", n_rows * (size_t)n_bucket);
+    return XV_ERR_UNSUPPORTED;
+  }
+  return XV_OK;
+}
+
+extern "C" int xv_anymdp_probe_buckets(xv_anymdp* h, int n_bucket, xv_anymdp_bucket_census* out) {
+  XV_CHECK_ARG(h != nullptr && out != nullptr && (n_bucket == 16 || n_bucket == 32 || n_bucket == 64));
+  XV_HIP(hipSetDevice(h->eng->device));
+  const int rc = anymdp_buckets_supported(h, n_bucket);
+  if (rc != XV_OK) return rc;
+  return anymdp_run_cutlines(h, n_bucket, nullptr, out);
+}
+
+extern "C" int xv_anymdp_bucket_census_get(xv_anymdp* h, xv_anymdp_bucket_census* out) {
+  XV_CHECK_ARG(h != nullptr && out != nullptr);
+  *out = h->census;
+  return XV_OK;
+}
+
+extern "C" int xv_anymdp_effective_search(xv_anymdp* h) {
+  return h ? anymdp_effective_search(h) : XV_ERR_INVALID;
 }
 
 extern "C" int xv_anymdp_build_buckets(xv_anymdp* h, int n_bucket) {
@@ -1691,38 +1812,28 @@ extern "C" int xv_anymdp_build_buckets(xv_anymdp* h, int n_bucket) {
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
     (void)hipFree(h->bucket_rw);
-    h->bucket_rw = nullptr; h->a.bucket = nullptr; h->a.NBK = 0;
+    h->bucket_rw = nullptr; h->a.bucket = nullptr; h->a.NBK = 0; h->a.bfmt = 0;
+    memset(&h->census, 0, sizeof(h->census));
     if (h->search == XV_ANYMDP_SEARCH_BUCKET) h->search = XV_ANYMDP_SEARCH_AUTO;
   }
   if (n_bucket == 0) return anymdp_build_obs_buckets(h);   // frees the observation lines too
-  if (!h->fast) {
-    xv_set_error("xv_anymdp_build_buckets: needs the fence layout (s0_max <= 4, observation ids < 65536, max_steps < 2^27)");
-    return XV_ERR_UNSUPPORTED;
-  }
-  const size_t n_rows = (size_t)h->a.n_task * h->a.S * h->a.A;
-  const size_t bytes = n_rows * (size_t)n_bucket * 128;
-  if (n_rows * (size_t)n_bucket >= (1ull << 32)) {
-    xv_set_error("xv_anymdp_build_buckets: %zu bucket lines exceed the 32-bit line index", n_rows * (size_t)n_bucket);
-    return XV_ERR_UNSUPPORTED;
-  }
+  int rc = anymdp_buckets_supported(h, n_bucket);
+  if (rc != XV_OK) return rc;
+  const size_t bytes = (size_t)h->a.n_task * h->a.S * h->a.A * (size_t)n_bucket * 128;
   uint4* b = nullptr;
   if (hipMalloc(&b, bytes) != hipSuccess) {
     (void)hipGetLastError();
     xv_set_error("xv_anymdp_build_buckets: cannot allocate %.1f GiB of bucket lines", (double)bytes / (double)(1ull << 30));
     return XV_ERR_NOMEM;
   }
-  const size_t chunk = (size_t)1 << 22;      // rows per launch: 4 rows per 256-thread block
-  for (size_t r0 = 0; r0 < n_rows; r0 += chunk) {
-    const size_t nr = n_rows - r0 < chunk ? n_rows - r0 : chunk;
-    hipLaunchKernelGGL(anymdp_build_buckets_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, h->eng->stream, h->a, b,
-                       r0, nr, n_bucket);
-  }
-  if (hipGetLastError() != hipSuccess) {
+  xv_anymdp_bucket_census cen;
+  rc = anymdp_run_cutlines(h, n_bucket, b, &cen);
+  if (rc != XV_OK) {
     (void)hipFree(b);
-    xv_set_error("xv_anymdp_build_buckets: launch failed");
-    return XV_ERR_HIP;
+    return rc;
   }
-  h->bucket_rw = b; h->a.bucket = b; h->a.NBK = n_bucket;
+  h->bucket_rw = b; h->a.bucket = b; h->a.NBK = n_bucket; h->a.bfmt = cen.format;
+  h->census = cen;
   return anymdp_build_obs_buckets(h);
 }
 
@@ -1755,21 +1866,28 @@ extern "C" int xv_anymdp_transition_gt(xv_anymdp* h, const int32_t* action, doub
 // ---- POMDP / MTPOMDP entry points ----
 extern "C" int xv_anymdp_set_observation_model(xv_anymdp* h, int n_obs, int d_obs, int d_act, const double* obs_cdf) {
   XV_CHECK_ARG(h && obs_cdf && n_obs >= 1 && d_obs >= 1 && d_obs <= 64 && d_act >= 1 && d_act <= 64);
+  XV_HIP(hipSetDevice(h->eng->device));   // the observation bucket lines are allocated and built on the engine's device
   h->obs_cdf = obs_cdf; h->n_obs = n_obs; h->d_obs = d_obs; h->d_act = d_act;
   return anymdp_build_obs_buckets(h);   // beside existing transition bucket lines
 }
 
+// which kernel xv_anymdp_step_tokens launches now: 1 = the cooperative kernel on transition + observation bucket lines
+// (bucket search in effect and both line sets built), 0 = the per-lane kernel
+static inline bool anymdp_tok_coop(const xv_anymdp* h) {
+  return anymdp_effective_search(h) == XV_ANYMDP_SEARCH_BUCKET && h->a.NBK > 0 && h->obs_bucket != nullptr;
+}
+extern "C" int xv_anymdp_token_kernel(xv_anymdp* h) { return h ? (anymdp_tok_coop(h) ? 1 : 0) : XV_ERR_INVALID; }
+
 template <bool INJECT>
 static int anymdp_tok_launch_step(xv_anymdp* h, const AnyMDPTokIO& io, int mode) {
   AnyMDPTokArgs K{h->obs_cdf, h->n_obs, h->d_obs, h->d_act, h->obs_bucket};
-  AnyMDPArgs a = h->a;
-  if (h->search != XV_ANYMDP_SEARCH_BUCKET) a.bucket = nullptr;
-  if (a.bucket != nullptr && a.NBK > 0 && K.obs_bucket != nullptr && h->fast)   // bucket search: the cooperative kernel
-    hipLaunchKernelGGL(anymdp_tok_step_coop_kernel<INJECT>, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
-                       a, K, io, mode);
-  else
-    hipLaunchKernelGGL(anymdp_tok_step_kernel<INJECT>, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
-                       a, K, io, mode);
+  const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
+  if (anymdp_tok_coop(h)) {   // bucket search: the cooperative kernel
+    if (h->a.bfmt == 1) hipLaunchKernelGGL((anymdp_tok_step_coop_kernel<INJECT, 1>), grid, block, 0, h->eng->stream, h->a, K, io, mode);
+    else hipLaunchKernelGGL((anymdp_tok_step_coop_kernel<INJECT, 2>), grid, block, 0, h->eng->stream, h->a, K, io, mode);
+  } else {
+    hipLaunchKernelGGL(anymdp_tok_step_kernel<INJECT>, grid, block, 0, h->eng->stream, h->a, K, io, mode);
+  }
   XV_LAUNCH_CHECK();
   return XV_OK;
 }

@@ -14,7 +14,7 @@
 #include "cartpole.hip"
 #include "linds.hip"
 
-template <int AG, bool ABK, int LNS, int LNO>
+template <int AG, int ABK, int LNS, int LNO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void mixed_step_kernel(AnyMDPArgs A, AnyMDPStepIO aio, int nbA, LinDSArgs L, LinDSStepIO lio, int nbL, CartPoleArgs C, CartPoleIO cio,
                        int mode) {
@@ -30,9 +30,11 @@ void mixed_step_kernel(AnyMDPArgs A, AnyMDPStepIO aio, int nbA, LinDSArgs L, Lin
 
 // which instantiation serves these handles (-1: none — the caller falls back to three launches)
 static int mixed_variant(const xv_anymdp* a, const xv_linds* l) {
-  if (!a->fast || a->a.G != 1 || a->search == XV_ANYMDP_SEARCH_BINARY) return -1;
+  const int eff = anymdp_effective_search(a);
+  if (a->a.G != 1 || eff == XV_ANYMDP_SEARCH_BINARY) return -1;
   if (l->path == XV_LINDS_PATH_SCALAR || l->a.NA != 8 || l->a.NO != 16) return -1;
-  const int bk = (a->search == XV_ANYMDP_SEARCH_BUCKET && a->a.bucket != nullptr) ? 1 : 0;
+  // bucket lines in the 7-cut packing only (S <= 112 here, observation ids <= 255); the 6-cut packing takes the fence form
+  const int bk = (eff == XV_ANYMDP_SEARCH_BUCKET && a->a.bfmt == 1) ? 1 : 0;
   return bk * 2 + (l->a.NS == 32 ? 1 : 0);
 }
 
@@ -69,10 +71,10 @@ extern "C" int xv_mixed_step(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv
 #define XV_MIXED_LAUNCH(AG, ABK, LNS) \
   hipLaunchKernelGGL((mixed_step_kernel<AG, ABK, LNS, 16>), grid, block, 0, st, a->a, aio, nbA, l->a, lio, nbL, c->a, cio, autoreset_mode)
   switch (v) {
-    case 0: XV_MIXED_LAUNCH(1, false, 16); break;
-    case 1: XV_MIXED_LAUNCH(1, false, 32); break;
-    case 2: XV_MIXED_LAUNCH(1, true, 16); break;
-    default: XV_MIXED_LAUNCH(1, true, 32); break;
+    case 0: XV_MIXED_LAUNCH(1, 0, 16); break;
+    case 1: XV_MIXED_LAUNCH(1, 0, 32); break;
+    case 2: XV_MIXED_LAUNCH(1, 1, 16); break;
+    default: XV_MIXED_LAUNCH(1, 1, 32); break;
   }
 #undef XV_MIXED_LAUNCH
   XV_LAUNCH_CHECK();
