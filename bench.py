@@ -59,8 +59,9 @@ def parse():
     ap.add_argument("--no-allgather", action="store_true",
                     help="N>1: skip the RCCL all-gather of rollout chunks (pure replicas)")
     ap.add_argument("--search", default="auto", choices=["auto", "binary", "fence", "bucket"],
-                    help="auto: bucket search (one table line per env-step, --buckets bucket lines per row) when its lines fit the "
-                         "free HBM, else fence search (two dependent lines)")
+                    help="auto (what the library's own AUTO does, xv_anymdp_set_search): the bucket search (one table line per "
+                         "env-step, --buckets lines per row) when the census of its lines expects few enough unanswerable draws per "
+                         "launch and they fit the free HBM, else the fence search (two dependent lines)")
     ap.add_argument("--buckets", type=int, default=16, choices=[16, 32, 64])
     ap.add_argument("--fused", action="store_true", help="also time the fused T-step rollout kernel")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
@@ -69,6 +70,11 @@ def parse():
                     help="comma list of envs/GPU (e.g. 16384,32768,65536,131072,262144): time the 2a step at each size "
                          "and write --sweep-out instead of the bench line")
     ap.add_argument("--sweep-out", default=os.path.join(ROOT, "gpurun_out", "anymdp_envs_sweep.json"))
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the `search_variants` object (the fence and the bucket search each timed on the same workload)")
+    ap.add_argument("--sustain-seconds", type=float, default=6.0,
+                    help="after the timed passes: an UNTIMED leg of back-to-back stepping of this length (excluded from `value`; "
+                         "`sustain_s` in the line) so that a monitor sampling every few seconds sees the GPU busy; 0 = off")
     ap.add_argument("--no-families", action="store_true",
                     help="N = 1: skip the `families` object (configs 3, 4 and the per-GPU share of 5, a few seconds)")
     ap.add_argument("--transport", default="auto", choices=["auto", "torch", "rccl"],
@@ -212,7 +218,7 @@ def pmc_traffic(n_env, n_task, search):
             d = json.load(open(f))
             k = d.get("bench_key", {})
             want = "2a" if n_task == n_env else "2b"
-            if k.get("workload") == want and k.get("search") in (search, "auto") and k.get("envs_per_gpu") == n_env \
+            if k.get("workload") == want and k.get("search") == search and k.get("envs_per_gpu") == n_env \
                     and k.get("kernel_source_sha16") == want_src:
                 for name, v in d["kernels"].items():
                     if "step_kernel" in name:
@@ -223,23 +229,33 @@ def pmc_traffic(n_env, n_task, search):
 
 
 def choose_search(env, torch, args, n_task, S, A):
-    """-> (search actually used, GiB of bucket lines).  auto: bucket search if its lines fit beside the rows."""
+    """-> (search actually used, GiB of bucket lines, census or None).  auto = the library's AUTO: its census decides
+    (AnyMDPVecEnv.set_search("auto", n_bucket=...): probe without allocating, build when AUTO would use the lines and they fit)"""
     want = args.search
-    if want in ("auto", "bucket"):
-        need = n_task * S * A * args.buckets * 128
-        free, _ = torch.cuda.mem_get_info()
-        if want == "bucket" or need + (8 << 30) <= free:
-            try:
-                env.set_search("bucket", n_bucket=args.buckets)
-                return "bucket", need / 2**30
-            except Exception as ex:
-                if want == "bucket":
-                    raise
-                print("bench: bucket lines not built (%s): fence search" % (ex,), file=sys.stderr)
-        env.set_search("fence")
-        return "fence", 0.0
-    env.set_search(want)
-    return want, 0.0
+    if want == "auto":
+        env.set_search("auto", n_bucket=args.buckets)
+    elif want == "bucket":
+        env.set_search("bucket", n_bucket=args.buckets)
+    else:
+        env.set_search(want)
+    cen = env.bucket_census()
+    built = bool(cen["built"])
+    return env.effective_search, (cen["bytes"] / 2**30 if built else 0.0), (cen if built else None)
+
+
+def floor_probe():
+    """latency and line-rate floors of a 65,536-lane step measured on this box class (scripts/devtools/floor_probe.py, the
+    latest committed profiles/*floor_probe*.json); without one, the round-1 measurements recorded in DESIGN.md 4.1"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*floor_probe*.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            return {"empty_launch_us": d["empty_launch_us"], "coop_lines_us": {int(k): v for k, v in d["coop_lines_us"].items()},
+                    "random_lines_per_s": d["random_lines_per_s"], "source": os.path.basename(f)}
+        except Exception:
+            pass
+    return {"empty_launch_us": 2.9, "coop_lines_us": {1: 4.3, 2: 6.75, 3: 9.1}, "random_lines_per_s": 5.0e10,
+            "source": "DESIGN.md 4.1 (round-1 box)"}
 
 
 def make_tables(eng, torch, _lib, n_task, task_base, seed, S=64, A=8, s0_max=4):
@@ -406,7 +422,7 @@ def main():
     n_task = args.tasks if args.tasks > 0 else n_env
     S, A, P = 64, 8, min(args.period, max(args.steps, 1))   # a ring no longer than the timed batch: whole cycles can replay
     search = {"auto": "fence"}.get(args.search, args.search)
-    bucket_gib = 0.0
+    bucket_gib, census = 0.0, None
     env = None
     if not selftest:
         from xenoverse_amd import _lib
@@ -417,7 +433,7 @@ def main():
         per = n_env // n_task
         env_task = (torch.arange(n_env, device=env.device, dtype=torch.int32) // per).contiguous()
         env.set_task(tab, env_task_index=env_task)
-        search, bucket_gib = choose_search(env, torch, args, n_task, S, A)
+        search, bucket_gib, census = choose_search(env, torch, args, n_task, S, A)
         # ring cycles replay from a hipGraph (one submission per `--period` steps): a short timed batch is then one
         # submission (20 steps: 6.4-6.5 vs 7.4 us per step with plain launches), and on long runs the result does not
         # depend on the host's launch rate, which sits close to the 5-us kernel (2,000 steps, graph vs plain launches:
@@ -520,21 +536,23 @@ def main():
         launched on, ~2 us of host time each instead of ~5 for a torch Event)."""
         gc.collect()       # a full collection of this heap takes tens of milliseconds: not inside a 0.1-ms timed region,
         gc.disable()       # and not right in front of it either (the idle GPU clocks down) — before the warm-up
-        run(args.warmup, with_gather)
-        walls, evs = [], []
-        stop = _StopEvent() if gpu else None
-        for _ in range(repeats):
-            barrier()
-            t0 = time.perf_counter()
-            if gpu:
-                env.engine.event_record(0)
-            run(args.steps, with_gather)
-            if gpu:
-                env.engine.event_record(1)
-            barrier(stop)
-            walls.append(time.perf_counter() - t0)
-            evs.append(env.engine.event_elapsed_ms() if gpu else walls[-1] * 1e3)   # HIP events on the launch stream
-        gc.enable()
+        try:
+            run(args.warmup, with_gather)
+            walls, evs = [], []
+            stop = _StopEvent() if gpu else None
+            for _ in range(repeats):
+                barrier()
+                t0 = time.perf_counter()
+                if gpu:
+                    env.engine.event_record(0)
+                run(args.steps, with_gather)
+                if gpu:
+                    env.engine.event_record(1)
+                barrier(stop)
+                walls.append(time.perf_counter() - t0)
+                evs.append(env.engine.event_elapsed_ms() if gpu else walls[-1] * 1e3)   # HIP events on the launch stream
+        finally:
+            gc.enable()    # also when a launch or a collective raised: the rest of the process keeps its collector
         tt = torch.tensor([walls, evs], dtype=torch.float64)
         if dist is not None:              # MAX over ranks, per repetition
             if dist.get_backend() == "nccl":
@@ -554,6 +572,50 @@ def main():
     if env is not None and graph_mode == "on" and args.steps >= P and int(env.lib.xv_anymdp_step_many_graph_state(env._h)) >= 0:
         state["graph"] = 1     # whole ring cycles were replayed (a remainder shorter than the ring is plain launches)
 
+    # the other searches on the same workload (`value` above is the AUTO choice): each timed with min(R, 5) repetitions
+    variants = None
+    if env is not None and world == 1 and not args.no_variants and not under_profiler():   # (N = 1: no collective in here)
+        variants = {"auto_choice": search, search: {"us_per_step": ev_ms * 1e3 / args.steps, "env_steps_per_s": n_env * args.steps / wall,
+                                                    "is_value": True}}
+        for name in ("fence", "bucket"):
+            if name == search:
+                continue
+            try:
+                if name == "bucket":
+                    need = n_task * S * A * args.buckets * 128
+                    free, _ = torch.cuda.mem_get_info()
+                    if not env.bucket_census()["built"] and need + (8 << 30) > free:
+                        variants[name] = {"skipped": "the bucket lines (%.0f GiB) do not fit the free HBM" % (need / 2**30)}
+                        continue
+                    env.set_search("bucket", n_bucket=args.buckets)
+                else:
+                    env.set_search("fence")
+                w, e, _ = timed_pass(False, max(1, min(R, 5)))
+                variants[name] = {"us_per_step": e * 1e3 / args.steps, "env_steps_per_s": n_env * args.steps / w, "is_value": False}
+            except Exception as ex:
+                variants[name] = {"error": repr(ex)}
+        env.set_search("auto") if args.search == "auto" else env.set_search(args.search, n_bucket=args.buckets) \
+            if args.search == "bucket" else env.set_search(args.search)
+        if census is None and env.bucket_census()["built"]:
+            census = env.bucket_census()
+        state["errs"] |= env.check_errors()
+
+    # untimed sustained stepping: a monitor that samples the GPU every few seconds sees it busy (the timed passes are
+    # milliseconds).  Excluded from `value`; `sustain_s` says how long it ran.
+    sustain = None
+    if env is not None and args.sustain_seconds > 0 and not under_profiler():
+        t0 = time.perf_counter()
+        done = 0
+        while time.perf_counter() - t0 < args.sustain_seconds:
+            run(8 * P)
+            done += 8 * P
+            if done % (256 * P) == 0:
+                torch.cuda.synchronize()       # bounds the launch queue
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        sustain = {"sustain_s": dt, "steps": done, "env_steps_per_s_rank0": n_env * done / dt}
+        state["errs"] |= env.check_errors()
+
     def report(timeout_note=None):
         with report_lock:
             if rank != 0 or state["done"]:
@@ -564,6 +626,9 @@ def main():
             algo = ALGO_BYTES_PER_ENV_STEP[8] * n_env
             achieved = algo / (kern_us * 1e-6) / 1e9
             traffic, traffic_src = (None, None) if selftest else pmc_traffic(n_env, n_task, search)
+            floor = floor_probe()
+            lines = {"bucket": 1, "fence": 2}.get(search)
+            floor_us = floor["coop_lines_us"].get(lines) if lines else None
             exchange = gather_note if timeout_note is None else gather_note + "; " + timeout_note
             out = {
                 "metric": "env-steps/sec (whole node), anymdp |S|=64 |A|=8, 65k envs/GPU",
@@ -583,15 +648,30 @@ def main():
                            "launch": "one step kernel per vector step (xv_anymdp_step_many%s)"
                                      % (", ring cycles of %d steps replayed from a hipGraph" % P if state.get("graph") == 1 else
                                         ", plain launches"),
-                           "search": search, "exchange": exchange, "device_error_flags": state["errs"]},
+                           "search": search, "search_requested": args.search,
+                           "bucket_census": None if census is None else {k: census[k] for k in (
+                               "n_bucket", "cuts_per_line", "lines_dirty", "p_fallback", "fallbacks_per_launch", "auto_limit", "auto_uses_bucket")},
+                           "exchange": exchange, "device_error_flags": state["errs"]},
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                              "frac_traffic": None if traffic is None else traffic / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                              "traffic_over_algorithmic": None if traffic is None else traffic / algo,
-                             "kernel": "anymdp_step_kernel<false, %d, false, %s%s>  (INJECT, blocks per fence entry | "
-                                       "0 = binary search, ROLLOUT, TICKDEV, BUCKET)"
+                             # which of the fractions to read: SURVEY 8(d)'s `frac` prices the 512-byte row; a search that
+                             # reads one or two 128-byte lines of it moves fewer bytes (traffic / algorithmic < 1), and `frac`
+                             # then says "faster than reading the rows would allow", not "HBM is busy".  The step is a latency
+                             # chain of `dependent_lines` random lines: `floor_us` is that chain measured bare on this box class
+                             # (scripts/devtools/floor_probe.py), `lines_per_s` against the measured random-line rate
+                             "primary": ("frac_traffic" if traffic is not None and traffic < algo else
+                                         ("frac" if traffic is not None else "frac_of_floor")),
+                             "dependent_lines": lines, "floor_us": floor_us, "frac_of_floor": None if floor_us is None else floor_us / kern_us,
+                             "empty_launch_us": floor["empty_launch_us"], "floor_source": floor["source"],
+                             "lines_per_s": None if lines is None else lines * n_env / (kern_us * 1e-6),
+                             "random_line_rate": floor["random_lines_per_s"],
+                             "frac_of_line_rate": None if lines is None else lines * n_env / (kern_us * 1e-6) / floor["random_lines_per_s"],
+                             "kernel": "anymdp_step_kernel<false, %d, false, %s, %d>  (INJECT, blocks per fence entry | "
+                                       "0 = binary search, ROLLOUT, TICKDEV, BK = 0 | bucket-line packing 1, 2)"
                                        % (0 if search == "binary" else 1, "true" if state.get("graph") == 1 else "false",
-                                          ", true" if search == "bucket" else (", false" if state.get("graph") == 1 else "")),
+                                          (census or {}).get("format", 1) if search == "bucket" else 0),
                              "kernel_source_sha16": None if selftest else kernel_source_hash(),
                              "avg_launch_us": kern_us, "algorithmic_bytes_per_launch": algo},
                 "rccl": dinfo["rccl"],
@@ -613,6 +693,10 @@ def main():
                 out["with_allgather"] = {"value": total_steps / state["wall_g"], "unit": "env-steps/s",
                                          "gathered_GB_per_s_per_rank":
                                              chunks * P * n_env * REC_BYTES * (world - 1) / state["wall_g"] / 1e9}
+            if variants is not None:
+                out["search_variants"] = variants
+            if sustain is not None:
+                out.update(sustain_s=sustain["sustain_s"], sustain=sustain)
             out["cpu_baseline"] = cpu if world == 1 else None      # the CPU lines are measured at N = 1 only
             if state.get("families") is not None:
                 out["families"] = state["families"]
@@ -692,7 +776,7 @@ def sweep(args, torch, local):
         env = AnyMDPVecEnv(n_env, device="cuda:%d" % local, seed=args.seed, autoreset_mode="same_step")
         tab = make_tables(env.engine, torch, _lib, n_env, 0, args.seed + 1, S, A)
         env.set_task(tab, env_task_index=torch.arange(n_env, device=env.device, dtype=torch.int32))
-        used, _ = choose_search(env, torch, args, n_env, S, A)
+        used, _, _ = choose_search(env, torch, args, n_env, S, A)
         env.set_step_many_graph("off")
         g = torch.Generator(device=env.device)
         g.manual_seed(args.seed)

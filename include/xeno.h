@@ -87,6 +87,24 @@ int xv_engine_error_flags(xv_engine* e, int clear, uint32_t* out_flags);
 /* the launch counter that forms the Philox counter's tick word; get/set makes runs resumable */
 int xv_engine_get_tick(xv_engine* e, uint64_t* out_tick);
 int xv_engine_set_tick(xv_engine* e, uint64_t tick);
+/* Device tick mode (ABI 8; what makes a step CAPTURABLE in a hipGraph / torch.cuda.graph).  By default the launch tick is a
+ * host counter handed to every stochastic kernel as an argument: a captured launch would replay the same draws for ever.
+ * With the device tick on, the counter lives in device memory: every stochastic entry point first launches a one-thread
+ * kernel that advances it and then its own kernel, which reads it — nothing host-side remains in the arguments, no
+ * allocation and no synchronisation happen in a step call, and a replayed capture draws fresh numbers exactly as the same
+ * calls issued eagerly would (same Philox counters: bit-identical trajectories, tested).  xv_engine_get_tick reads the
+ * device word back (synchronises) in this mode; xv_anymdp_step_many issues plain launches.  The policy -> step loop the
+ * reference runs per env object (anymdp/test_utils.py:45-57) becomes one graph replay per vector step (or per `unroll`
+ * steps): xenoverse_amd/capture.py. */
+int xv_engine_set_device_tick(xv_engine* e, int on);
+int xv_engine_device_tick(xv_engine* e);          /* 1 on, 0 off */
+/* device tick mode, for a capture that unrolls several steps: between (e, 1) and (e, 0) stochastic launches read
+ * *tick + 0, + 1, + 2, ... and advance nothing; (e, 0) advances the word once by what the batch consumed — one tick
+ * node per unrolled capture instead of one per step.  Same draws as without the batch. */
+int xv_engine_tick_batch(xv_engine* e, int on);
+/* re-points an engine created on a caller's stream at another stream of the same device (stream capture runs on a side
+ * stream: the launches of a captured step must go there).  XV_ERR_UNSUPPORTED for an engine that owns its stream. */
+int xv_engine_set_stream(xv_engine* e, void* hip_stream);
 /* Two timing events on the engine's own stream (slot 0 = start, 1 = stop), for callers that time a burst of launches
    without a second event API: record is stream-ordered and asynchronous; done polls without blocking (*done = 1 once
    everything ahead of the record has finished); elapsed needs both slots finished (XV_ERR_HIP otherwise). */
@@ -249,8 +267,10 @@ int xv_anymdp_step_tokens_injected(xv_anymdp* h, const int32_t* action, const do
  *           group that lumps a run of states (chosen so that the lumped probability is least: they are the ones that
  *           are practically never drawn) sends the draw's wave through the FENCE path for that step.  Identical
  *           results; costs n_task * S * A * n_bucket * 128 bytes of HBM.
- *   AUTO    (round 4) BUCKET when the lines are built and their census (below) expects fewer than 0.05 draws per launch
- *           that a line cannot answer, else FENCE when available, else BINARY: xv_anymdp_effective_search tells. */
+ *   AUTO    (round 4) BUCKET when the lines are built and their census (below) expects no more draws per launch that a
+ *           line cannot answer than `auto_limit` (0.5 when the rows miss every cache, 0.1 when the fence lines of all
+ *           tasks stay cache resident: there the fence search is nearly as fast and a fall-back costs relatively more),
+ *           else FENCE when available, else BINARY: xv_anymdp_effective_search tells. */
 #define XV_ANYMDP_SEARCH_BUCKET 4
 int xv_anymdp_set_search(xv_anymdp* h, int search);
 int xv_anymdp_effective_search(xv_anymdp* h);   /* XV_ANYMDP_SEARCH_BINARY | _FENCE | _BUCKET: what a step launches now */
@@ -260,7 +280,7 @@ int xv_anymdp_build_buckets(xv_anymdp* h, int n_bucket);
 /* What the bucket lines of these rows can and cannot answer.  p_fallback: the share of draws (uniform over the rows of
  * non-terminal states and over u) that land in a lumped group or beyond a line's last cut; one such draw costs its
  * wave — and, with one wave per SIMD, the launch — two more dependent lines.  AUTO uses the lines iff
- * fallbacks_per_launch = p_fallback * n_env <= 0.05.  Synthetic dense bands: 0.  Rows of the reference's sampler
+ * fallbacks_per_launch = p_fallback * n_env <= auto_limit.  Synthetic dense bands: 0.  Rows of the reference's sampler
  * (task_sampler_utils.py:65-175), 16 buckets: ~5e-8 (the consecutive-entry lines of rounds 2-3: 2.7e-2). */
 typedef struct {
   int32_t n_bucket, format;          /* format 1: 7 cuts per line (S <= 256, observation ids <= 255); 2: 6 cuts */
@@ -268,6 +288,7 @@ typedef struct {
   int32_t auto_uses_bucket, reserved;
   uint64_t lines, lines_dirty, live_rows;
   double p_fallback, fallbacks_per_launch, bytes;
+  double auto_limit;                 /* AUTO uses the lines iff fallbacks_per_launch <= auto_limit */
 } xv_anymdp_bucket_census;
 int xv_anymdp_probe_buckets(xv_anymdp* h, int n_bucket, xv_anymdp_bucket_census* out);   /* census without the memory */
 int xv_anymdp_bucket_census_get(xv_anymdp* h, xv_anymdp_bucket_census* out);             /* of the lines that are built */
@@ -630,6 +651,8 @@ typedef struct xv_mixed_io {
   const int32_t* c_action; float* c_obs; float* c_reward; uint8_t* c_terminated; uint8_t* c_truncated; float* c_final_obs;
 } xv_mixed_io;
 int xv_mixed_step(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mixed_io* io, int autoreset_mode);
+/* 1: xv_mixed_step has a fused instantiation for these three handles as they are configured now, 0: step them separately */
+int xv_mixed_supported(xv_anymdp* a, xv_linds* l, xv_cartpole* c);
 int xv_mixed_step_many(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mixed_io* ring, int n_steps, int period,
                        int autoreset_mode);
 

@@ -335,6 +335,99 @@ def bench_mixed(args, variants=("three streams", "one stream", "one launch")):
                          "note": "a 13 MB vector step: launch-latency bound; one fused launch instead of three"}}
 
 
+def _synth_anymdp_env(n, n_task, copy=True, seed=1234):
+    """65,536-env style AnyMDP batch on synthetic tasks generated on the device (as bench.py's headline, shared tasks)"""
+    from xenoverse_amd import _lib
+    from xenoverse_amd.anymdp import AnyMDPVecEnv, row_lines
+    S, A, s0_max = 64, 8, 4
+    env = AnyMDPVecEnv(n, seed=seed, autoreset_mode="same_step", copy=copy)
+    d = env.device
+    t = dict(S=S, A=A, s0_max=s0_max,
+             rows=torch.empty((n_task, S, A, row_lines(S), 16), dtype=torch.float64, device=d),
+             state_map=torch.empty((n_task, S), dtype=torch.int32, device=d),
+             term_mask=torch.empty((n_task, 1), dtype=torch.int64, device=d),
+             s0_cdf=torch.empty((n_task, s0_max), dtype=torch.float64, device=d),
+             s0_ids=torch.empty((n_task, s0_max), dtype=torch.int32, device=d),
+             max_steps=torch.empty(n_task, dtype=torch.int32, device=d))
+    _lib.check(env.lib.xv_anymdp_synth_tasks(env.engine.handle, seed + 1, 0, n_task, S, A, s0_max,
+                                             *[_lib.ptr(t[k]) for k in ("rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")]))
+    env.set_task(t, env_task_index=(torch.arange(n, device=d, dtype=torch.int32) // (n // n_task)).contiguous())
+    return env
+
+
+def bench_anymdp_refdist(args, n_task=1024, per=64):
+    """the AnyMDP step on tasks of the REFERENCE's distribution (task_sampler_utils.py:65-175: banded rows with a few large
+    probabilities among many tiny ones, sampled on the device by xv_anymdp_sample_tasks) instead of the survey's synthetic
+    dense bands: 65,536 envs = 1,024 tasks x 64; what AUTO picks, and each search timed"""
+    from xenoverse_amd.anymdp import AnyMDPVecEnv
+    from xenoverse_amd.anymdp import device_sampler as ds
+    S, A = 64, 8
+    n = n_task * per
+    t0 = time.time()
+    t = ds.sample_tasks_device(n_task, S, A, seed=3, batch=4096)
+    env = AnyMDPVecEnv(n, seed=1, autoreset_mode="same_step")
+    env.set_task({k: t[k] for k in ("S", "A", "s0_max", "rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")},
+                 env_task_index=(torch.arange(n, device=env.device, dtype=torch.int32) // per).contiguous())
+    env.reset()
+    P = 32
+    acts = torch.randint(0, A, (P, n), device=env.device, dtype=torch.int32)
+    ring = env.step_many(P, acts)
+    env.set_search("auto", n_bucket=16)
+    auto = env.effective_search
+    cen = env.bucket_census() if auto == "bucket" else env.probe_buckets(16)
+    k = max(P, args.steps // P * P)
+    out = {}
+    for name in ("auto", "fence", "bucket"):
+        env.set_search(name, n_bucket=16) if name != "fence" else env.set_search("fence")
+        out[name] = min(timed(lambda: env.step_many(k, acts, out=ring), 3, 1) / k for _ in range(2))
+    errs = env.check_errors()
+    env.close()
+    us = out["auto"]
+    algo = (8 * S + 50) * n
+    return {"family": "anymdp_refdist", "workload": "anymdp S=64 A=8, 65,536 envs = 1,024 device-sampled reference-distribution "
+            "tasks x 64 (xv_anymdp_sample_tasks), launches from C", "dtype": "f64", "auto_search": auto,
+            "us_per_step": out, "env_steps_per_s": n / (us * 1e-6),
+            "bucket_census": {k2: cen[k2] for k2 in ("n_bucket", "format", "cuts_per_line", "lines", "lines_dirty", "p_fallback",
+                                                    "fallbacks_per_launch", "auto_limit", "auto_uses_bucket")},
+            "roofline": {"bound": "hbm", "achieved": algo / (us * 1e-6) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
+                         "frac": algo / (us * 1e-6) / 1e9 / HBM_PEAK, "algorithmic_bytes_per_env_step": 8 * S + 50,
+                         "note": "1,024 shared tasks: the rows are Infinity-Cache resident, the 562-byte count prices them as HBM reads"},
+            "device_error_flags": errs, "setup_s": round(time.time() - t0, 1)}
+
+
+def bench_python_loop(args, n=65536, n_task=1024):
+    """the loop a training script runs — actions = policy(obs) on the device, env.step(actions) — per vector step of 65,536
+    AnyMDP envs: issued from Python call by call (copy=True and copy=False), and replayed from a captured graph
+    (xenoverse_amd/capture.py: device tick, one hipGraphLaunch per `unroll` iterations)"""
+    def policy(obs):
+        return torch.bitwise_and(obs, 7)      # ONE elementwise op: a graph node of its own, like any policy kernel
+
+    out = {}
+    steps = max(200, args.steps)
+    for copy in (True, False):
+        env = _synth_anymdp_env(n, n_task, copy=copy)
+        obs, _ = env.reset()
+        st = {"obs": obs}
+
+        def it():
+            st["obs"] = env.step(policy(st["obs"]))[0]
+        out["eager copy=%s" % copy] = timed(it, steps, 20)
+        env.close()
+    for unroll in (1, 8):
+        env = _synth_anymdp_env(n, n_task, copy=False)
+        obs, _ = env.reset()
+        loop = env.capture(policy, obs, unroll=unroll, warmup=2)
+        k = max(1, steps // unroll)
+        out["captured unroll=%d" % unroll] = min(timed(lambda: loop.replay(k), 3, 1) / (k * unroll) for _ in range(2))
+        errs = env.check_errors()
+        loop.close()
+        env.close()
+    best = min(v for k2, v in out.items() if k2.startswith("captured"))
+    return {"family": "python_loop", "workload": "anymdp S=64 A=8, 65,536 envs over 1,024 synthetic tasks; policy = one "
+            "elementwise torch op on the device; closed loop policy -> step", "dtype": "f64", "us_per_vector_step": out,
+            "env_steps_per_s": n / (best * 1e-6), "device_error_flags": errs}
+
+
 def quick_families(steps=200, warmup=20):
     """the `families` object of bench.py's JSON line: BASELINE.json configs 3 (linds), 4 (mazeworld, 64x64 frames) and the
     per-GPU share of config 5 (mixed), each timed with HIP events over back-to-back launches; a few seconds in all"""
@@ -378,9 +471,22 @@ def quick_families(steps=200, warmup=20):
                              "peak": HBM_PEAK, "unit": "GB/s", "achieved": r["roofline"]["achieved"],
                              "kernel": "mixed_step_kernel (anymdp + linds + cartpole step bodies in one grid, xv_mixed_step_many)",
                              "us_per_vector_step": r["us_per_vector_step"], "note": r["roofline"]["note"]}}
+    def refdist():
+        r = bench_anymdp_refdist(a)
+        return {"config": r["workload"], "ms_per_step": r["us_per_step"]["auto"] * 1e-3, "env_steps_per_s": r["env_steps_per_s"],
+                "auto_search": r["auto_search"], "us_per_step": r["us_per_step"], "bucket_census": r["bucket_census"],
+                "dtype": "f64", "roofline": r["roofline"], "device_error_flags": r["device_error_flags"]}
+
+    def pyloop():
+        r = bench_python_loop(a)
+        us = min(v for k2, v in r["us_per_vector_step"].items() if k2.startswith("captured"))
+        return {"config": r["workload"], "ms_per_step": us * 1e-3, "env_steps_per_s": r["env_steps_per_s"],
+                "us_per_vector_step": r["us_per_vector_step"], "dtype": "f64", "device_error_flags": r["device_error_flags"]}
     guard("linds", linds)
     guard("mazeworld_64", maze)
     guard("mixed_share", mixed)
+    guard("anymdp_refdist", refdist)
+    guard("python_loop", pyloop)
     return out
 
 
@@ -504,6 +610,10 @@ if __name__ == "__main__":
             r = bench_mixed(args)
         elif f == "anymdp_tok":
             r = bench_anymdp_tok(args)
+        elif f == "anymdp_refdist":
+            r = bench_anymdp_refdist(args)
+        elif f == "python_loop":
+            r = bench_python_loop(args)
         elif f == "teacher":
             r = bench_teacher(args)
         elif f.startswith("maze"):

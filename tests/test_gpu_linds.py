@@ -347,10 +347,10 @@ def test_step_many_equals_single_steps():
         env.set_task(tasks, env_task_index=env_task)
         env.reset()
         extra = np.random.RandomState(12).uniform(-1, 1, (n, 8)).astype(np.float32)
-        if many:      # whole ring cycles replay from a hipGraph (tick read from device memory), the remainder is plain launches;
-            ring = env.step_many(K, acts)                 # 2 cycles + 5 steps
+        if many:      # xv_linds_step_many is a plain launch loop in C over the ring slots (no graph: DESIGN 5.1)
+            ring = env.step_many(K, acts)                 # 2 ring cycles + 5 steps
             env.step(extra)                               # an ordinary step in between moves the engine tick
-            ring = env.step_many(2 * P, acts, out=ring)   # cached graph, tick re-synchronised
+            ring = env.step_many(2 * P, acts, out=ring)   # the same ring buffers again
             rec = {k: _np(v) for k, v in ring.items()}
         else:
             rows = [None] * P
@@ -377,3 +377,48 @@ def test_step_many_equals_single_steps():
         if k == "final_obs":            # the ring's rows are written by finished envs only (earlier cycles may linger)
             a, b = a[done], b[done]
         assert np.array_equal(a, b), k
+
+
+def test_process_noise_generator_is_standard_normal_on_the_device():
+    """the device's 16 + 16-bit Box-Muller (csrc/philox.h: xv_box_muller16), sampled through the C-ABI and independent of
+    the oracle's restatement: from x = 0 with a zero action and X = 0 one step leaves x' = noise_drift * dt * z, so the state
+    IS the noise.  16.8 million draws: mean, variance, kurtosis and tail mass against N(0, 1) and against the exact moments of
+    the generator's 65,536 x 65,536 grid (tests/test_host_normals.py): variance 0.99990, |z| <= 4.71."""
+    from math import erfc, sqrt
+    from xenoverse_amd.linds import LinearDSSampler
+    n, nd = 65536, 0.02
+    tasks = []
+    for k in range(4):
+        t = LinearDSSampler(16, 8, 8, seed=k)
+        t["ld_X"] = np.zeros_like(np.asarray(t["ld_X"]))
+        t["initial_states"] = [np.zeros(16)]
+        t["noise_drift"] = nd
+        t["max_steps"] = 10000
+        tasks.append(t)
+    env = LinDSVecEnv(n, autoreset_mode="disabled", seed=77)
+    env.set_task(tasks)
+    env.reset()
+    a = torch.zeros((n, 8), device=env.device)
+    zero = torch.zeros((16, n), device=env.device)
+    scale = np.float32(nd) * np.float32(0.1)
+    acc = []
+    for it in range(16):
+        env.set_state(x=zero, steps=torch.zeros(n, dtype=torch.int32, device=env.device))
+        env.step(a)
+        x, _, _ = env.get_state()
+        acc.append((x.double() / float(scale)).cpu().numpy().ravel())
+    z = np.concatenate(acc)
+    N = z.size
+    assert N == 16 * 16 * n
+    assert abs(z.mean()) < 5.0 / np.sqrt(N)
+    var = z.var()
+    assert abs(var - 0.99990) < 5.0 * np.sqrt(2.0 / N) + 2e-5, var
+    kurt = np.mean((z - z.mean()) ** 4) / var ** 2
+    assert abs(kurt - 2.9987) < 5.0 * np.sqrt(24.0 / N) + 1e-3, kurt
+    assert np.abs(z).max() <= 4.7097 * (1 + 1e-5)
+    for t_, tol in ((1.0, 0.005), (2.0, 0.01), (3.0, 0.03)):
+        p = float(np.mean(np.abs(z) > t_))
+        assert abs(p - erfc(t_ / sqrt(2.0))) <= tol * erfc(t_ / sqrt(2.0)), (t_, p)
+    # the draws of different envs, components and steps are not the same numbers
+    assert len(np.unique(z[:1 << 20])) > 0.98 * (1 << 20)
+    env.close()

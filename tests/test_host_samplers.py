@@ -397,7 +397,7 @@ def test_load_texture_library_reads_a_folder_like_the_reference(tmp_path):
     from PIL import Image
     from xenoverse_amd.mazeworld import load_texture_library, texture_counts
     rng = np.random.RandomState(0)
-    W, H = 24, 16
+    W, H = 256, 256                 # the engine's texture size (and that of every image of the reference's folder)
     imgs = {}
     for name in ("wall_b.png", "wall_a.png", "ground_1.png", "ceiling_z.png", "ceiling_y.png", "ceiling_x.png",
                  "notes.txt", "mywall.png"):
@@ -423,6 +423,29 @@ def test_load_texture_library_reads_a_folder_like_the_reference(tmp_path):
     ref_dir = "/root/reference/xenoverse/mazeworld/envs/img"
     if os.path.isdir(ref_dir):                                      # build container only: the reference's own folder
         assert texture_counts(load_texture_library(ref_dir)) == (37, 29, 21)
+
+
+def test_texture_libraries_of_another_size_are_refused_or_resampled(tmp_path):
+    """the ray caster addresses textures as 256 x 256 x 3: an image of another size must never reach it as it is"""
+    from PIL import Image
+    from xenoverse_amd.mazeworld import load_texture_library
+    from xenoverse_amd.mazeworld.textures import check_texture_library, make_texture_library
+    rng = np.random.RandomState(1)
+    for name, (w, h) in (("wall_0.png", (256, 256)), ("wall_1.png", (64, 48)), ("ground_0.png", (256, 256)),
+                         ("ceiling_0.png", (300, 256))):
+        Image.fromarray(rng.randint(0, 256, (h, w, 3)).astype(np.uint8)).save(tmp_path / name)
+    with pytest.raises(ValueError, match="ceiling_0.png is 300 x 256"):
+        load_texture_library(str(tmp_path))
+    lib = load_texture_library(str(tmp_path), resize=True)
+    assert lib["walls"].shape == (2, 256, 256, 3) and lib["ceilings"].shape == (1, 256, 256, 3)
+    assert lib["walls"].min() >= 0 and lib["walls"].max() <= 255
+    check_texture_library(lib)
+    check_texture_library(make_texture_library(2, 1, 1, seed=0))
+    bad = dict(lib, grounds=np.zeros((1, 128, 128, 3), np.float32))
+    with pytest.raises(ValueError, match=r"'grounds' has shape \(1, 128, 128, 3\)"):
+        check_texture_library(bad)
+    with pytest.raises(ValueError, match="lacks 'ceilings'"):
+        check_texture_library({"walls": lib["walls"], "grounds": lib["grounds"]})
 
 
 def test_acrobot_kernel_sincos_construction_is_within_one_ulp_of_libm():

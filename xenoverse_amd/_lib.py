@@ -31,6 +31,10 @@ SIGNATURES = {
     "xv_engine_error_flags": [c_void_p, c_int, C.POINTER(c_u32)],
     "xv_engine_get_tick": [c_void_p, C.POINTER(c_u64)],
     "xv_engine_set_tick": [c_void_p, c_u64],
+    "xv_engine_set_device_tick": [c_void_p, c_int],
+    "xv_engine_device_tick": [c_void_p],
+    "xv_engine_tick_batch": [c_void_p, c_int],
+    "xv_engine_set_stream": [c_void_p, c_void_p],
     "xv_engine_event_record": [c_void_p, c_int],
     "xv_engine_event_done": [c_void_p, c_int, C.POINTER(c_int)],
     "xv_engine_event_elapsed_ms": [c_void_p, C.POINTER(C.c_float)],
@@ -68,6 +72,7 @@ SIGNATURES = {
     "xv_anymdp_transition_gt": [c_void_p, c_void_p, c_void_p],
     "xv_anymdp_synth_tasks": [c_void_p, c_u64, c_i64, c_int, c_int, c_int, c_int] + [c_void_p] * 6,
     "xv_mixed_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_int],
+    "xv_mixed_supported": [c_void_p, c_void_p, c_void_p],
     "xv_mixed_step_many": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int],
     "xv_linds_create": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, C.POINTER(c_void_p)],
     "xv_linds_destroy": [c_void_p],
@@ -125,7 +130,7 @@ class BucketCensus(C.Structure):
     _fields_ = [("n_bucket", C.c_int32), ("format", C.c_int32), ("cuts_per_line", C.c_int32), ("built", C.c_int32),
                 ("auto_uses_bucket", C.c_int32), ("reserved", C.c_int32), ("lines", C.c_uint64), ("lines_dirty", C.c_uint64),
                 ("live_rows", C.c_uint64), ("p_fallback", C.c_double), ("fallbacks_per_launch", C.c_double),
-                ("bytes", C.c_double)]
+                ("bytes", C.c_double), ("auto_limit", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -164,8 +164,8 @@ class AnyMDPVecEnv(VectorEnv):
         """Select how the categorical draw searches the CDF row (results are identical; see xeno.h).
         "bucket": builds n_task * S * A * n_bucket * 128 bytes of bucket lines (once; default 32 buckets) and makes a step
                   one table line in one dependent level; raises if they do not fit.
-        "auto":   the engine decides per launch: the bucket search when its lines are built AND their census expects fewer
-                  than 0.05 draws per launch that a line cannot answer, else the fence search (two dependent lines), else
+        "auto":   the engine decides per launch: the bucket search when its lines are built AND their census expects no more
+                  draws per launch that a line cannot answer than `auto_limit` (0.5; 0.1 for cache-resident tables), else the fence search (two dependent lines), else
                   the per-lane binary search.  With n_bucket given, the lines are built first when — and only when —
                   the census (taken without allocating anything) says AUTO would use them and they fit the free memory.
         `effective_search` names what runs; `bucket_census()` has the numbers."""
@@ -317,9 +317,15 @@ class AnyMDPVecEnv(VectorEnv):
             raise AssertionError(f"Action {tuple(a.shape)} is out of range")
         if self._ring is not None:      # copy=False: outputs are views of the output set this step writes
             b = self._ring[self._ring_pos]
-            self._ring_pos ^= 1
+            if not self._holding:           # a captured loop (capture.py) writes one output set: its policy reads it back
+                self._ring_pos ^= 1
             lib, mode = self.lib, AUTORESET[self.autoreset_mode]
             _lib.check(lib.xv_anymdp_step(self._h, C.c_void_p(a.data_ptr()), *b["args"], mode))
+            if self.lean_infos:             # nothing that needs a launch of its own; final_obs >= 0 marks a finished env
+                infos = {"reward_gt": b["reward_gt"]}
+                if mode == 2:
+                    infos["final_obs"] = b["final_obs"]
+                return b["obs"], b["reward"], b["term_b"], b["trunc_b"], infos
             _lib.check(lib.xv_anymdp_get_state(self._h, None, b["steps_p"], None))
             infos = {"steps": b["steps"], "reward_gt": b["reward_gt"]}
             if mode == 2:

@@ -26,6 +26,7 @@ struct AcrobotArgs {
   uint32_t* err;
   int n_env, n_task, frameskip, max_steps;
   uint64_t seed, gid_base, tick;
+  const uint64_t* tick_dev;   // device tick mode of the engine: the launch tick is *tick_dev + tick (xv_launch_tick)
 };
 
 struct AcrobotIO {
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(64) void acrobot_step_kernel(AcrobotArgs P, Acrobot
     }
   }
   if (do_reset) {
-    acrobot_reset_state<INJECT>(P, io.u_reset, i, P.tick + (uint64_t)ts, s);
+    acrobot_reset_state<INJECT>(P, io.u_reset, i, xv_launch_tick(P.tick, P.tick_dev) + (uint64_t)ts, s);
     fresh = 1;
     steps = 0;
     nr = 0;
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(64) void acrobot_reset_kernel(AcrobotArgs P, const 
   if (mask && !mask[i]) return;
   const size_t N = (size_t)P.n_env;
   double s[4];
-  acrobot_reset_state<INJECT>(P, u, i, P.tick, s);
+  acrobot_reset_state<INJECT>(P, u, i, xv_launch_tick(P.tick, P.tick_dev), s);
   P.state[i] = s[0]; P.state[N + i] = s[1]; P.state[2 * N + i] = s[2]; P.state[3 * N + i] = s[3];
   P.steps[i] = 0;
   P.need_reset[i] = 0;
@@ -265,7 +266,7 @@ extern "C" int xv_acrobot_create(xv_engine* e, int n_env, int n_task, int frames
   a.n_env = n_env; a.n_task = n_task; a.frameskip = frameskip; a.max_steps = max_steps;
   a.scale_is_vector = scale_is_vector ? 1 : 0;
   a.err = e->d_err;
-  a.seed = e->seed; a.gid_base = e->env_id_base; a.tick = 0;
+  a.seed = e->seed; a.gid_base = e->env_id_base; a.tick = 0; a.tick_dev = nullptr;
   XV_HIP(hipMemcpyAsync(a.reset_scale, reset_scale, sizeof(a.reset_scale), hipMemcpyDeviceToHost, e->stream));
   XV_HIP(hipStreamSynchronize(e->stream));
   a.state = nullptr; a.steps = nullptr; a.need_reset = nullptr; a.fresh = nullptr;
@@ -302,8 +303,9 @@ extern "C" int xv_acrobot_destroy(xv_acrobot* h) {
 static inline void acrobot_bind_rng(xv_acrobot* h, uint64_t ticks) {
   h->a.seed = h->eng->seed;
   h->a.gid_base = h->eng->env_id_base;
-  h->a.tick = h->eng->tick;
-  h->eng->tick += ticks;
+  const XvTickBind b = xv_engine_bind_tick(h->eng, ticks);
+  h->a.tick = b.tick;
+  h->a.tick_dev = b.tick_dev;
 }
 
 extern "C" int xv_acrobot_reset(xv_acrobot* h, const uint8_t* mask, float* obs) {

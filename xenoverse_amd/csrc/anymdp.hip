@@ -232,7 +232,9 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
     tm0 = P.term_mask[(size_t)t * P.words];
   }
 
-  const uint64_t tick0 = TICKDEV ? *P.tick_dev + P.tick : P.tick;
+  // the launch tick: a kernel argument, or — device tick mode of the engine (xv_engine_set_device_tick) and graph replays
+  // of step_many — relative to the engine's / the graph's tick word in device memory
+  const uint64_t tick0 = TICKDEV ? *P.tick_dev + P.tick : xv_launch_tick(P.tick, P.tick_dev);
   const int T = ROLLOUT ? T_steps : 1;   // single step: straight-line code, counted vmcnt waits
   for (int ts = 0; ts < T; ++ts) {
     const size_t o = (size_t)ts * P.n_env + ic;
@@ -684,7 +686,7 @@ __global__ __launch_bounds__(256) void anymdp_reset_kernel(AnyMDPArgs P, const u
   if (INJECT) {
     u = u_in[i];
   } else {
-    const xv_u32x4 v = xv_env_draw(P.seed, P.gid_base + (uint64_t)i, P.tick, XV_DRAW_RESET);
+    const xv_u32x4 v = xv_env_draw(P.seed, P.gid_base + (uint64_t)i, xv_launch_tick(P.tick, P.tick_dev), XV_DRAW_RESET);
     u = xv_u53(v.x, v.y);
   }
   const int s = anymdp_draw_s0(P, t, u);
@@ -748,12 +750,13 @@ __device__ __forceinline__ int xv_upper_bound_f64(const double* row, int n, doub
 template <bool INJECT, bool RESET>
 __device__ __forceinline__ void anymdp_tok_observe(const AnyMDPArgs& P, const AnyMDPTokArgs& K, const AnyMDPTokIO& io,
                                                    int i, int t, int s, uint64_t gid, int32_t* out) {
+  const uint64_t tick_now = xv_launch_tick(P.tick, P.tick_dev);
   for (int k = 0; k < K.d_obs; ++k) {
     double u;
     if (INJECT) {
       u = (RESET ? io.u_obs_reset : io.u_obs)[(size_t)k * P.n_env + i];
     } else {
-      const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick, 64u + (uint32_t)k);
+      const xv_u32x4 w = xv_env_draw(P.seed, gid, tick_now, 64u + (uint32_t)k);
       u = RESET ? xv_u53(w.z, w.w) : xv_u53(w.x, w.y);
     }
     const double* row = K.obs_cdf + ((((size_t)t * K.d_obs + k) * P.S) + s) * (size_t)K.n_obs;
@@ -763,6 +766,7 @@ __device__ __forceinline__ void anymdp_tok_observe(const AnyMDPArgs& P, const An
 
 template <bool INJECT>
 __global__ __launch_bounds__(256) void anymdp_tok_step_kernel(AnyMDPArgs P, AnyMDPTokArgs K, AnyMDPTokIO io, int mode) {
+  const uint64_t tick_now = xv_launch_tick(P.tick, P.tick_dev);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
   const int S = P.S, A = P.A, N = P.n_env;
@@ -795,7 +799,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_kernel(AnyMDPArgs P, AnyM
         u = io.u[(size_t)k * N + i];
         z = io.z[(size_t)k * N + i];
       } else {
-        const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick, 32u + (uint32_t)k);
+        const xv_u32x4 w = xv_env_draw(P.seed, gid, tick_now, 32u + (uint32_t)k);
         u = xv_u53(w.x, w.y);
         z = xv_normal1(w.z, w.w);
       }
@@ -834,7 +838,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_kernel(AnyMDPArgs P, AnyM
     double ur;
     if (INJECT) ur = io.u_reset[i];
     else {
-      const xv_u32x4 v = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_RESET);
+      const xv_u32x4 v = xv_env_draw(P.seed, gid, tick_now, XV_DRAW_RESET);
       ur = xv_u53(v.x, v.y);
     }
     s = anymdp_draw_s0(P, t, ur);
@@ -944,6 +948,7 @@ static __global__ __launch_bounds__(256) void anymdp_build_obs_buckets_kernel(co
 
 template <bool INJECT, int FMT>
 __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P, AnyMDPTokArgs K, AnyMDPTokIO io, int mode) {
+  const uint64_t tick_now = xv_launch_tick(P.tick, P.tick_dev);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < P.n_env;
   const int ic = valid ? i : P.n_env - 1;
@@ -965,7 +970,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
   // purpose 64 + k, words (0,1) after a step and (2,3) after a restart (oracle: tok_draws)
   auto act_draw = [&](int k, double& u, xv_u32x4& w) {
     if (INJECT) { u = io.u[(size_t)k * N + ic]; }
-    else { w = xv_env_draw(P.seed, gid, P.tick, 32u + (uint32_t)k); u = xv_u53(w.x, w.y); }
+    else { w = xv_env_draw(P.seed, gid, tick_now, 32u + (uint32_t)k); u = xv_u53(w.x, w.y); }
   };
   // both uniforms of observation token k from ONE call: after a step (us), after a restart (ur_)
   auto obs_draw = [&](int k, double& us, double& ur_) {
@@ -973,7 +978,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
       us = io.u_obs[(size_t)k * N + ic];
       ur_ = io.u_obs_reset[(size_t)k * N + ic];
     } else {
-      const xv_u32x4 w = xv_env_draw(P.seed, gid, P.tick, 64u + (uint32_t)k);
+      const xv_u32x4 w = xv_env_draw(P.seed, gid, tick_now, 64u + (uint32_t)k);
       us = xv_u53(w.x, w.y);
       ur_ = xv_u53(w.z, w.w);
     }
@@ -1018,7 +1023,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
       double ur;
       if (INJECT) ur = io.u_reset[ic];
       else {
-        const xv_u32x4 v = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_RESET);
+        const xv_u32x4 v = xv_env_draw(P.seed, gid, tick_now, XV_DRAW_RESET);
         ur = xv_u53(v.x, v.y);
       }
       k0r = (int)(rc01.x <= ur) + (int)(rc01.y <= ur) + (int)(xv_u2d(rb.x, rb.y) <= ur);
@@ -1157,6 +1162,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
 template <bool INJECT>
 __global__ __launch_bounds__(256) void anymdp_tok_reset_kernel(AnyMDPArgs P, AnyMDPTokArgs K, AnyMDPTokIO io,
                                                                const uint8_t* mask) {
+  const uint64_t tick_now = xv_launch_tick(P.tick, P.tick_dev);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
   if (mask && !mask[i]) return;
@@ -1165,7 +1171,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_reset_kernel(AnyMDPArgs P, Any
   double ur;
   if (INJECT) ur = io.u_reset[i];
   else {
-    const xv_u32x4 v = xv_env_draw(P.seed, gid, P.tick, XV_DRAW_RESET);
+    const xv_u32x4 v = xv_env_draw(P.seed, gid, tick_now, XV_DRAW_RESET);
     ur = xv_u53(v.x, v.y);
   }
   const int s = anymdp_draw_s0(P, t, ur);
@@ -1290,17 +1296,28 @@ __global__ __launch_bounds__(512) void anymdp_solve_kernel(AnyMDPArgs P, double 
   if (iters_out && tid == 0) iters_out[t] = it;
 }
 
-static inline void anymdp_bind_rng(xv_anymdp* h, uint64_t ticks) {
+static inline void anymdp_bind_rng(xv_anymdp* h, uint64_t ticks, bool advance = true) {
   h->a.seed = h->eng->seed;
   h->a.gid_base = h->eng->env_id_base;
-  h->a.tick = h->eng->tick;
-  h->eng->tick += ticks;
+  const XvTickBind b = xv_engine_bind_tick(h->eng, ticks, advance);
+  h->a.tick = b.tick;
+  h->a.tick_dev = b.tick_dev;
 }
 
 // What the handle's search setting means right now.  AUTO takes the bucket search only when its lines are built AND their
-// census says a launch of this batch size meets a draw they cannot answer less often than XV_ANYMDP_AUTO_FALLBACKS (one
-// such draw sends its wave, and with it the launch, through three dependent lines instead of one); else FENCE; else BINARY.
-#define XV_ANYMDP_AUTO_FALLBACKS 0.05
+// census says a launch of this batch size rarely meets a draw they cannot answer: one such draw sends its wave, and with
+// it the launch, through three dependent lines instead of one.  With lam = expected such draws per launch a launch costs
+// t_bucket + (1 - exp(-lam)) * penalty against t_fence; measured on config 2 (65,536 envs, S = 64): rows that miss every
+// cache (one task per env: 4 GiB of fence lines) 5.4 us vs 7.2 us with a penalty of ~4 us -> the bucket search wins up to
+// lam ~ 0.7; rows whose fence lines stay cache resident (1,024 shared tasks: 64 MiB) 4.6 vs 4.9 us, penalty ~2.5 us ->
+// up to lam ~ 0.13.  Thresholds with a margin (XV_ANYMDP_AUTO_FALLBACKS_*); the fence lines count as cache resident up to
+// half of the 256 MB Infinity Cache.
+#define XV_ANYMDP_AUTO_FALLBACKS_CACHED 0.1
+#define XV_ANYMDP_AUTO_FALLBACKS_HBM 0.5
+static inline double anymdp_auto_fallback_limit(const xv_anymdp* h) {
+  const double fence_bytes = (double)h->a.n_task * h->a.S * h->a.A * 128.0;
+  return fence_bytes <= 128.0 * 1048576.0 ? XV_ANYMDP_AUTO_FALLBACKS_CACHED : XV_ANYMDP_AUTO_FALLBACKS_HBM;
+}
 static inline int anymdp_effective_search(const xv_anymdp* h) {
   if (h->search == XV_ANYMDP_SEARCH_BINARY || !h->fast) return XV_ANYMDP_SEARCH_BINARY;
   if (h->a.bucket != nullptr &&
@@ -1582,6 +1599,7 @@ static bool anymdp_ensure_graph(xv_anymdp* h, int period, const int32_t* actions
 #define XV_ANYMDP_GRAPH_AUTO_MAX 8192
 #define XV_ANYMDP_GRAPH_AUTO_STEPS 128
 static inline bool anymdp_graph_wanted(const xv_anymdp* h, int n_steps) {
+  if (h->eng->dev_tick) return false;   // the graph keeps its own tick word, fed from the host tick: plain launches here
   return h->graph_mode == 1 ||
          (h->graph_mode == 2 && (h->a.n_env <= XV_ANYMDP_GRAPH_AUTO_MAX || n_steps <= XV_ANYMDP_GRAPH_AUTO_STEPS));
 }
@@ -1767,7 +1785,8 @@ static int anymdp_run_cutlines(xv_anymdp* h, int n_bucket, uint4* b, xv_anymdp_b
   out->live_rows = (uint64_t)cen[2];
   out->p_fallback = cen[2] ? (double)cen[1] / 68719476736.0 / (double)cen[2] : 0.0;
   out->fallbacks_per_launch = out->p_fallback * (double)h->a.n_env;
-  out->auto_uses_bucket = out->fallbacks_per_launch <= XV_ANYMDP_AUTO_FALLBACKS;
+  out->auto_limit = anymdp_auto_fallback_limit(h);
+  out->auto_uses_bucket = out->fallbacks_per_launch <= out->auto_limit;
   out->bytes = (double)n_rows * (double)n_bucket * 128.0;
   return XV_OK;
 }

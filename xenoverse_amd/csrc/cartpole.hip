@@ -21,6 +21,7 @@ struct CartPoleArgs {
   uint32_t* err;
   int n_env, n_task, frameskip, max_steps;
   uint64_t seed, gid_base, tick;
+  const uint64_t* tick_dev;   // device tick mode of the engine: the launch tick is *tick_dev + tick (xv_launch_tick)
 };
 
 struct CartPoleIO {
@@ -114,7 +115,7 @@ __device__ __forceinline__ void cartpole_step_body(const CartPoleArgs& P, const 
     }
   }
   if (do_reset) {
-    const CpState s0 = cartpole_reset_state<INJECT>(P, io.u_reset, i, P.tick + (uint64_t)ts);
+    const CpState s0 = cartpole_reset_state<INJECT>(P, io.u_reset, i, xv_launch_tick(P.tick, P.tick_dev) + (uint64_t)ts);
     x = s0.x; xd = s0.xd; th = s0.th; thd = s0.thd;
     steps = 0;
     nr = 0;
@@ -143,18 +144,19 @@ __global__ __launch_bounds__(256) void cartpole_reset_kernel(CartPoleArgs P, con
   if (i >= P.n_env) return;
   if (mask && !mask[i]) return;
   const size_t N = (size_t)P.n_env;
-  const CpState s0 = cartpole_reset_state<INJECT>(P, u, i, P.tick);
+  const CpState s0 = cartpole_reset_state<INJECT>(P, u, i, xv_launch_tick(P.tick, P.tick_dev));
   P.state[i] = s0.x; P.state[N + i] = s0.xd; P.state[2 * N + i] = s0.th; P.state[3 * N + i] = s0.thd;
   P.steps[i] = 0;
   P.need_reset[i] = 0;
   if (obs) reinterpret_cast<float4*>(obs)[i] = make_float4((float)s0.x, (float)s0.xd, (float)s0.th, (float)s0.thd);
 }
 
-static inline void cartpole_bind_rng(xv_cartpole* h, uint64_t ticks) {
+static inline void cartpole_bind_rng(xv_cartpole* h, uint64_t ticks, bool advance = true) {
   h->a.seed = h->eng->seed;
   h->a.gid_base = h->eng->env_id_base;
-  h->a.tick = h->eng->tick;
-  h->eng->tick += ticks;
+  const XvTickBind b = xv_engine_bind_tick(h->eng, ticks, advance);
+  h->a.tick = b.tick;
+  h->a.tick_dev = b.tick_dev;
 }
 
 #ifndef XV_KERNELS_ONLY   // mixed.hip includes this file for its kernels and handle types only
@@ -175,7 +177,7 @@ extern "C" int xv_cartpole_create(xv_engine* e, int n_env, int n_task, int frame
   a.params = params; a.env_task = env_task;
   a.n_env = n_env; a.n_task = n_task; a.frameskip = frameskip; a.max_steps = max_steps;
   a.err = e->d_err;
-  a.seed = e->seed; a.gid_base = e->env_id_base; a.tick = 0;
+  a.seed = e->seed; a.gid_base = e->env_id_base; a.tick = 0; a.tick_dev = nullptr;
   {
     hipError_t r = hipMemcpyAsync(a.reset_scale, reset_scale, sizeof(a.reset_scale), hipMemcpyDeviceToHost, e->stream);
     if (r == hipSuccess) r = hipStreamSynchronize(e->stream);

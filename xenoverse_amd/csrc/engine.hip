@@ -34,6 +34,10 @@ extern "C" int xv_engine_create(int device, uint64_t seed, uint64_t env_id_base,
   e->own_stream = (hip_stream == XV_STREAM_OWN);
   e->stream = e->own_stream ? nullptr : (hipStream_t)hip_stream;
   e->d_err = nullptr;
+  e->d_tick = nullptr;
+  e->dev_tick = false;
+  e->tick_batch = false;
+  e->tick_pending = 0;
   e->ev[0] = e->ev[1] = nullptr;
   e->ev_made = false;
   if (e->own_stream) {
@@ -61,6 +65,7 @@ extern "C" int xv_engine_destroy(xv_engine* e) {
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
   if (e->d_err) hipFree(e->d_err);
+  if (e->d_tick) hipFree(e->d_tick);
   if (e->ev_made) { hipEventDestroy(e->ev[0]); hipEventDestroy(e->ev[1]); }
   if (e->own_stream) hipStreamDestroy(e->stream);
   delete e;
@@ -85,14 +90,90 @@ extern "C" int xv_engine_error_flags(xv_engine* e, int clear, uint32_t* out_flag
   return XV_OK;
 }
 
+static __global__ void xv_tick_set_kernel(uint64_t* t, uint64_t v) { *t = v; }
+static __global__ void xv_tick_add_kernel(uint64_t* t, uint64_t dv) { *t += dv; }
+
+void xv_engine_advance_device_tick(xv_engine* e, uint64_t ticks) {
+  hipLaunchKernelGGL(xv_tick_add_kernel, dim3(1), dim3(1), 0, e->stream, e->d_tick, ticks);
+}
+
+static __global__ void xv_tick_add3_kernel(uint64_t* t0, uint64_t* t1, uint64_t* t2, uint64_t dv) {
+  *t0 += dv;
+  if (t1 != t0) *t1 += dv;
+  if (t2 != t0 && t2 != t1) *t2 += dv;
+}
+void xv_engine_advance_device_tick3(xv_engine* e0, xv_engine* e1, xv_engine* e2, uint64_t ticks) {
+  hipLaunchKernelGGL(xv_tick_add3_kernel, dim3(1), dim3(1), 0, e0->stream, e0->d_tick, e1->d_tick, e2->d_tick, ticks);
+}
+
 extern "C" int xv_engine_get_tick(xv_engine* e, uint64_t* out_tick) {
   XV_CHECK_ARG(e != nullptr && out_tick != nullptr);
+  if (e->dev_tick) {   // the device word is the truth (graph replays advance it without the host); synchronises
+    XV_HIP(hipMemcpyAsync(&e->tick, e->d_tick, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+    XV_HIP(hipStreamSynchronize(e->stream));
+  }
   *out_tick = e->tick;
   return XV_OK;
 }
 extern "C" int xv_engine_set_tick(xv_engine* e, uint64_t tick) {
   XV_CHECK_ARG(e != nullptr);
   e->tick = tick;
+  if (e->dev_tick) {
+    hipLaunchKernelGGL(xv_tick_set_kernel, dim3(1), dim3(1), 0, e->stream, e->d_tick, tick);
+    XV_LAUNCH_CHECK();
+  }
+  return XV_OK;
+}
+
+extern "C" int xv_engine_set_device_tick(xv_engine* e, int on) {
+  XV_CHECK_ARG(e != nullptr && (on == 0 || on == 1));
+  if ((on != 0) == e->dev_tick) return XV_OK;
+  XV_HIP(hipSetDevice(e->device));
+  if (on) {
+    if (!e->d_tick) XV_HIP(hipMalloc(&e->d_tick, sizeof(uint64_t)));
+    hipLaunchKernelGGL(xv_tick_set_kernel, dim3(1), dim3(1), 0, e->stream, e->d_tick, e->tick);
+    XV_LAUNCH_CHECK();
+    e->dev_tick = true;
+  } else {
+    if (e->tick_batch && e->tick_pending) xv_engine_advance_device_tick(e, e->tick_pending);
+    e->tick_batch = false;
+    e->tick_pending = 0;
+    XV_HIP(hipMemcpyAsync(&e->tick, e->d_tick, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+    XV_HIP(hipStreamSynchronize(e->stream));
+    e->dev_tick = false;
+  }
+  return XV_OK;
+}
+extern "C" int xv_engine_device_tick(xv_engine* e) { return e ? (e->dev_tick ? 1 : 0) : XV_ERR_INVALID; }
+
+extern "C" int xv_engine_tick_batch(xv_engine* e, int on) {
+  XV_CHECK_ARG(e != nullptr && (on == 0 || on == 1));
+  if (!e->dev_tick) {
+    xv_set_error("xv_engine_tick_batch: needs the device tick (xv_engine_set_device_tick)");
+    return XV_ERR_UNSUPPORTED;
+  }
+  if (on) {
+    XV_CHECK_ARG(!e->tick_batch);
+    e->tick_batch = true;
+    e->tick_pending = 0;
+  } else if (e->tick_batch) {
+    e->tick_batch = false;
+    if (e->tick_pending) {
+      xv_engine_advance_device_tick(e, e->tick_pending);
+      XV_LAUNCH_CHECK();
+    }
+    e->tick_pending = 0;
+  }
+  return XV_OK;
+}
+
+extern "C" int xv_engine_set_stream(xv_engine* e, void* hip_stream) {
+  XV_CHECK_ARG(e != nullptr);
+  if (e->own_stream) {
+    xv_set_error("xv_engine_set_stream: this engine owns its stream");
+    return XV_ERR_UNSUPPORTED;
+  }
+  e->stream = (hipStream_t)hip_stream;
   return XV_OK;
 }
 

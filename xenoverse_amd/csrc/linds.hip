@@ -36,6 +36,7 @@ struct LinDSArgs {
   uint32_t* err;
   int n_env, n_task, NS, NA, NO, NI;
   uint64_t seed, gid_base, tick;
+  const uint64_t* tick_dev;   // device tick mode of the engine: the launch tick is *tick_dev + tick (xv_launch_tick)
   // engine-built command table (nullptr if it would not fit the budget): cmd_tab[task][tt - ct_tmin][NO] holds
   // get_inner_cmd at integer time tt, already multiplied by target_valid, for tt in [ct_tmin, ct_tmin + ct_len)
   // Rows hold the first ct_w columns only (a multiple of 4): every column past the last one whose target_valid is
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
       const XV_CONST_AS float* sc = xv_cptr(P.T.scal) + (size_t)tu * 8;
       const XV_CONST_AS int32_t* in = xv_cptr(P.T.ints) + (size_t)tu * 4;
       const int max_steps = in[0], delay = in[1], n_init = in[2], nf = in[3];
-      if (!INJECT) init_idx = linds_init_from_word(linds_restart_word(P, gid, P.tick), n_init);
+      if (!INJECT) init_idx = linds_init_from_word(linds_restart_word(P, gid, xv_launch_tick(P.tick, P.tick_dev)), n_init);
       if (mode == XV_AUTORESET_NEXT_STEP && nr) {
         // the call after a done ignores the action and returns the reset observation
         linds_reset_env<NS, NO>(P, tu, nf, n_init, init_idx, xs, y, crep, o_err);
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(256) void linds_step_kernel(LinDSArgs P, LinDSStepI
 #pragma unroll
               for (int r = 0; r < 4; ++r) z[m][r] = io.z[(size_t)(16 * m + 4 * gq + r) * N + i];
           } else {
-            (void)linds_noise_group<MT>(P, gid, P.tick, gq, z);
+            (void)linds_noise_group<MT>(P, gid, xv_launch_tick(P.tick, P.tick_dev), gq, z);
           }
 #pragma unroll
           for (int m = 0; m < MT; ++m)
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(256) void linds_reset_kernel(LinDSArgs P, const uin
     if (t == tu_cmp) {
       const XV_CONST_AS int32_t* in = xv_cptr(P.T.ints) + (size_t)tu * 4;
       const int n_init = in[2], nf = in[3];
-      const int idx = INJECT ? init_index[i] : linds_draw_init(P, P.gid_base + (uint64_t)i, P.tick, n_init);
+      const int idx = INJECT ? init_index[i] : linds_draw_init(P, P.gid_base + (uint64_t)i, xv_launch_tick(P.tick, P.tick_dev), n_init);
       linds_reset_env<NS, NO>(P, tu, nf, n_init, idx, xs, y, c, e);
       break;
     }
@@ -1054,7 +1055,7 @@ __device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const L
   fr.load(P, id.t, id.lane);
   int steps = (int)(sn0 & ~XV_LINDS_NR_BIT), nr = (int)(sn0 >> 31), bad = 0;
   const int init_inj = INJECT ? io.init_index[id.e] : 0;
-  LinDSTileStep<NS, NA, NO, INJECT>::run(P, fr, id.t, id.lane, id.e, id.valid, id.gid, P.tick, mode,
+  LinDSTileStep<NS, NA, NO, INJECT>::run(P, fr, id.t, id.lane, id.e, id.valid, id.gid, xv_launch_tick(P.tick, P.tick_dev), mode,
                                          io.action + (size_t)id.e * NA, io.z, P.n_env, init_inj, (size_t)id.e, io.obs, io.cmd,
                                          io.final_obs, io.reward, io.error, io.terminated, io.truncated, xs, steps, nr, bad);
   if (id.valid) {
@@ -1107,7 +1108,7 @@ __global__ __launch_bounds__(256) void linds_rollout_mfma_kernel(LinDSArgs P, Li
   const size_t N = (size_t)P.n_env;
   for (int ts = 0; ts < T; ++ts) {
     const size_t ob = (size_t)ts * N + id.e;          // this step's row of the [T][n_env] outputs
-    LinDSTileStep<NS, NA, NO, false>::run(P, fr, id.t, id.lane, id.e, id.valid, id.gid, P.tick + (uint64_t)ts,
+    LinDSTileStep<NS, NA, NO, false>::run(P, fr, id.t, id.lane, id.e, id.valid, id.gid, xv_launch_tick(P.tick, P.tick_dev) + (uint64_t)ts,
                                           XV_AUTORESET_SAME_STEP, io.action + ob * NA, nullptr, P.n_env, 0, ob, io.obs, io.cmd,
                                           io.final_obs, io.reward, io.error, io.terminated, io.truncated, xs, steps, nr, bad);
   }
@@ -1143,11 +1144,12 @@ static __global__ __launch_bounds__(256) void linds_check_tiles_kernel(const int
   if (shift < 4 || env_task[i] != (i >> shift)) atomicOr(not_uniform, 2);
 }
 
-static inline void linds_bind_rng(xv_linds* h, uint64_t ticks) {
+static inline void linds_bind_rng(xv_linds* h, uint64_t ticks, bool advance = true) {
   h->a.seed = h->eng->seed;
   h->a.gid_base = h->eng->env_id_base;
-  h->a.tick = h->eng->tick;
-  h->eng->tick += ticks;
+  const XvTickBind b = xv_engine_bind_tick(h->eng, ticks, advance);
+  h->a.tick = b.tick;
+  h->a.tick_dev = b.tick_dev;
 }
 
 #ifndef XV_KERNELS_ONLY   // mixed.hip includes this file for its kernels and handle types only
@@ -1176,7 +1178,7 @@ extern "C" int xv_linds_create(xv_engine* e, int n_env, int n_task, int NS, int 
   a.env_task = env_task;
   a.n_env = n_env; a.n_task = n_task; a.NS = NS; a.NA = NA; a.NO = NO; a.NI = NI;
   a.err = e->d_err;
-  a.seed = e->seed; a.gid_base = e->env_id_base; a.tick = 0;
+  a.seed = e->seed; a.gid_base = e->env_id_base; a.tick = 0; a.tick_dev = nullptr;
   a.x = nullptr; a.sn = nullptr; a.frag = nullptr; a.tvec = nullptr;
   h->frag = nullptr; h->tvec = nullptr;
   a.slot_env = nullptr; a.env_slot = nullptr; a.tile_task = nullptr; a.n_slot = n_env; a.task_shift = -1;

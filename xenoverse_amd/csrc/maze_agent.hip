@@ -38,6 +38,7 @@ struct AgentArgs {
   double keep_ratio;
   double act_cost[32];  // 1e-4 * (a0 ** 2 + a1 ** 2), host pow() as CPython's float ** 2
   uint64_t seed, gid_base, tick;
+  const uint64_t* tick_dev;   // device tick mode of the engine (xv_launch_tick)
 };
 
 struct xv_maze_agent {
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void maze_agent_kernel(MazeArgs P, AgentArgs A
       float hit_dist = 0.0f;
       xv_u32x4 w4 = xv_u32x4{0, 0, 0, 0};
       auto expose = [&](int ci, int cj) {
-        if ((k & 3) == 0) w4 = xv_env_draw_sub(A.seed, gid, A.tick, XV_DRAW_EXPOSE, 64u * (uint32_t)d_h + (uint32_t)(k >> 2));
+        if ((k & 3) == 0) w4 = xv_env_draw_sub(A.seed, gid, xv_launch_tick(A.tick, A.tick_dev), XV_DRAW_EXPOSE, 64u * (uint32_t)d_h + (uint32_t)(k >> 2));
         const uint32_t w = (k & 3) == 0 ? w4.x : ((k & 3) == 1 ? w4.y : ((k & 3) == 2 ? w4.z : w4.w));
         const bool hit = (double)w * (1.0 / 4294967296.0) < 0.05;                      // random.random() < 0.05 (:254)
         if (hit && ci >= 0 && ci < n && cj >= 0 && cj < n) atomicOr(&ex[(ci * NG + cj) >> 5], 1u << ((ci * NG + cj) & 31));
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void maze_agent_kernel(MazeArgs P, AgentArgs A
       if (A.keep_ratio < 1.0 && old != 0u) {           // rand(nx, ny) < memory_keep_ratio, one draw per cell (:80)
         uint32_t keep = 0u;
         for (int b = 0; b < 32; b += 4) {
-          const xv_u32x4 d = xv_env_draw_sub(A.seed, gid, A.tick, XV_DRAW_KEEP, (uint32_t)((w * 32 + b) >> 2));
+          const xv_u32x4 d = xv_env_draw_sub(A.seed, gid, xv_launch_tick(A.tick, A.tick_dev), XV_DRAW_KEEP, (uint32_t)((w * 32 + b) >> 2));
           keep |= ((double)d.x * (1.0 / 4294967296.0) < A.keep_ratio ? 1u : 0u) << b;
           keep |= ((double)d.y * (1.0 / 4294967296.0) < A.keep_ratio ? 1u : 0u) << (b + 1);
           keep |= ((double)d.z * (1.0 / 4294967296.0) < A.keep_ratio ? 1u : 0u) << (b + 2);
@@ -480,8 +481,9 @@ extern "C" int xv_maze_agent_act(xv_maze_agent* g, const uint8_t* exposed_inject
   XV_CHECK_ARG(g != nullptr && action != nullptr);
   xv_engine* eng = g->env->eng;
   AgentArgs& a = g->a;
-  a.seed = eng->seed; a.gid_base = eng->env_id_base; a.tick = eng->tick;
-  eng->tick += 1;
+  a.seed = eng->seed; a.gid_base = eng->env_id_base;
+  const XvTickBind tb = xv_engine_bind_tick(eng, 1);
+  a.tick = tb.tick; a.tick_dev = tb.tick_dev;
   const MazeArgs& m = g->env->a;
   const size_t G2 = (size_t)m.NG * m.NG;
   const size_t lds = G2 * 8 + (size_t)a.words * 8 + 2 * G2 + 2 + 2 * G2 + 16;

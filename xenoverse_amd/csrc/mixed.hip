@@ -38,6 +38,14 @@ static int mixed_variant(const xv_anymdp* a, const xv_linds* l) {
   return bk * 2 + (l->a.NS == 32 ? 1 : 0);
 }
 
+extern "C" int xv_mixed_supported(xv_anymdp* a, xv_linds* l, xv_cartpole* c) {
+  if (!a || !l || !c) return 0;
+  if (a->eng->stream != l->eng->stream || a->eng->stream != c->eng->stream || a->eng->device != l->eng->device ||
+      a->eng->device != c->eng->device)
+    return 0;
+  return mixed_variant(a, l) >= 0 ? 1 : 0;
+}
+
 extern "C" int xv_mixed_step(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mixed_io* io, int autoreset_mode) {
   XV_CHECK_ARG(a && l && c && io);
   XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
@@ -57,9 +65,20 @@ extern "C" int xv_mixed_step(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv
   }
   XV_HIP(hipSetDevice(a->eng->device));
   // the same tick bookkeeping as three separate step calls, in the order anymdp, linds, cartpole
-  anymdp_bind_rng(a, 1);
-  linds_bind_rng(l, 1);
-  cartpole_bind_rng(c, 1);
+  // (device tick mode: the three engines' tick words are advanced by ONE one-thread launch in front of the step)
+  const bool dev3 = a->eng->dev_tick && l->eng->dev_tick && c->eng->dev_tick;
+  if (a->eng->dev_tick != l->eng->dev_tick || a->eng->dev_tick != c->eng->dev_tick) {
+    xv_set_error("xv_mixed_step: the three engines must agree on the device tick mode (xv_engine_set_device_tick)");
+    return XV_ERR_INVALID;
+  }
+  if (a->eng->tick_batch != l->eng->tick_batch || a->eng->tick_batch != c->eng->tick_batch) {
+    xv_set_error("xv_mixed_step: the three engines must open and close their tick batches together (xv_engine_tick_batch)");
+    return XV_ERR_INVALID;
+  }
+  if (dev3 && !a->eng->tick_batch) xv_engine_advance_device_tick3(a->eng, l->eng, c->eng, 1);
+  anymdp_bind_rng(a, 1, !dev3);
+  linds_bind_rng(l, 1, !dev3);
+  cartpole_bind_rng(c, 1, !dev3);
   AnyMDPStepIO aio{io->a_action, nullptr, nullptr, nullptr, io->a_obs, io->a_reward, io->a_reward_gt, io->a_terminated,
                    io->a_truncated, io->a_final_obs, nullptr, nullptr, 0.0f};
   LinDSStepIO lio{io->l_action, nullptr, nullptr, io->l_obs, io->l_reward, io->l_terminated, io->l_truncated, io->l_cmd,

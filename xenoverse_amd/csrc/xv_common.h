@@ -15,6 +15,10 @@ struct xv_engine {
   uint64_t seed;
   uint64_t env_id_base;
   uint64_t tick;        // launch counter: Philox counter word, advanced by every stochastic launch
+  uint64_t* d_tick;     // the same counter in device memory (xv_engine_set_device_tick), nullptr until first used
+  bool dev_tick;        // kernels read the launch tick from *d_tick: a step leaves nothing host-side in its arguments
+  bool tick_batch;      // device tick mode, xv_engine_tick_batch: launches read *d_tick + tick_pending and advance nothing;
+  uint64_t tick_pending;   // closing the batch advances the word once by the ticks it consumed
   uint32_t* d_err;      // sticky device error word
   hipEvent_t ev[2];     // xv_engine_event_*: created on first use
   bool ev_made;
@@ -50,3 +54,38 @@ void xv_set_error(const char* fmt, ...);
   } while (0)
 
 static inline int xv_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// ---- launch tick of a stochastic launch (engine.hip) ----
+// Host tick (default): the launch gets tick = e->tick as a kernel argument.  Device tick (xv_engine_set_device_tick: what
+// makes a step capturable in a hipGraph / torch.cuda.graph): a one-thread kernel advances *d_tick by `ticks` FIRST, and
+// the launch reads *d_tick + (0 - ticks) — so that every entry point stays "bind, then launch" and a replayed graph
+// draws fresh numbers at every replay.  Kernels evaluate xv_launch_tick(P.tick, P.tick_dev).
+void xv_engine_advance_device_tick(xv_engine* e, uint64_t ticks);
+void xv_engine_advance_device_tick3(xv_engine* e0, xv_engine* e1, xv_engine* e2, uint64_t ticks);   // one launch (mixed batch)
+struct XvTickBind {
+  uint64_t tick;
+  const uint64_t* tick_dev;
+};
+static inline XvTickBind xv_engine_bind_tick(xv_engine* e, uint64_t ticks, bool advance = true) {
+  XvTickBind b;
+  if (e->dev_tick) {
+    b.tick_dev = e->d_tick;
+    if (e->tick_batch) {      // an unrolled capture: step j of the batch reads *d_tick + j, ONE advance closes the batch
+      b.tick = e->tick_pending;
+      e->tick_pending += ticks;
+    } else {
+      if (ticks && advance) xv_engine_advance_device_tick(e, ticks);
+      b.tick = (uint64_t)0 - ticks;
+    }
+  } else {
+    b.tick = e->tick;
+    b.tick_dev = nullptr;
+  }
+  e->tick += ticks;      // host mirror (exact while every launch is issued through the C-ABI; a replayed graph is not)
+  return b;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ uint64_t xv_launch_tick(uint64_t tick, const uint64_t* tick_dev) {
+  return tick_dev ? tick + *tick_dev : tick;
+}
+#endif

@@ -48,6 +48,27 @@ class Engine(object):
     def tick(self, value):
         _lib.check(self.lib.xv_engine_set_tick(self.handle, int(value)))
 
+    # ---- device tick (xv_engine_set_device_tick): what makes a step capturable in a torch.cuda.graph ------------
+    @property
+    def device_tick(self):
+        return bool(self.lib.xv_engine_device_tick(self.handle))
+
+    def set_device_tick(self, on=True):
+        """on: the launch tick lives in device memory and every stochastic launch advances it there — a captured step
+        draws fresh numbers at every replay, exactly those the same calls issued eagerly would draw.  `tick` then reads
+        the device word back (synchronises)."""
+        _lib.check(self.lib.xv_engine_set_device_tick(self.handle, 1 if on else 0))
+
+    def tick_batch(self, on):
+        """device tick mode: between tick_batch(True) and tick_batch(False) launches read tick + 0, + 1, ... and the word is
+        advanced once at the end (an unrolled capture carries one tick node instead of one per step)"""
+        _lib.check(self.lib.xv_engine_tick_batch(self.handle, 1 if on else 0))
+
+    def set_stream(self, stream):
+        """launch on another torch stream of the same device from now on (stream capture runs on a side stream)"""
+        _lib.check(self.lib.xv_engine_set_stream(self.handle, C.c_void_p(stream.cuda_stream)))
+        self.torch_stream = stream
+
     # ---- timing events on the engine's own stream (xv_engine_event_*) ----------------------------------------
     def event_record(self, slot):
         _lib.check(self.lib.xv_engine_event_record(self.handle, int(slot)))

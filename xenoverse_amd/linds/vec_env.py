@@ -210,8 +210,14 @@ class LinDSVecEnv(VectorEnv):
             self._fobs.zero_()
 
     def _ret(self):
+        if self.lean_infos:      # captured loops: nothing that needs a launch of its own (no `steps`, no `_final_obs` mask)
+            infos = {"command": self._of(self._user_obs(self._cmd)), "error": self._of(self._error)}
+            if self.autoreset_mode == "same_step":
+                infos["final_obs"] = self._of(self._user_obs(self._fobs))
+        else:
+            infos = self._infos(True, fresh=True)
         return (self._of(self._user_obs(self._obs)), self._of(self._reward),
-                self._obf(self._term), self._obf(self._trunc), self._infos(True, fresh=True))
+                self._obf(self._term), self._obf(self._trunc), infos)
 
     def step(self, actions):
         self._check_step()

@@ -73,19 +73,42 @@ def make_texture_library(n_walls=None, n_grounds=None, n_ceilings=None, seed=0):
     return _LIB_CACHE[key]
 
 
-def load_texture_library(texture_dir):
+def check_texture_library(lib):
+    """The ray caster and the texture-packing kernel address a texture as 256 x 256 x 3 (csrc/maze.hip: text_id * 256 * 256 *
+    3, taps masked with & 255): a library of any other size would be read past its allocation.  Raises ValueError unless
+    every library is [n, 256, 256, 3] with n >= 1.  (The reference takes any size through texture.shape,
+    ray_caster_utils.py:124-140; its own folder is 256 x 256 throughout.)"""
+    for key in ("walls", "grounds", "ceilings"):
+        if key not in lib:
+            raise ValueError("texture library lacks %r" % key)
+        shp = tuple(lib[key].shape)
+        if len(shp) != 4 or shp[0] < 1 or shp[1:] != (TEX_SIZE, TEX_SIZE, 3):
+            raise ValueError("texture library %r has shape %s; the engine needs [n, %d, %d, 3] (load_texture_library(dir, "
+                             "resize=True) resamples other image sizes)" % (key, shp, TEX_SIZE, TEX_SIZE))
+
+
+def load_texture_library(texture_dir, resize=False):
     """The reference's way of building its libraries (mazeworld/envs/task_sampler.py:60-77): every file of `texture_dir`
     in SORTED name order whose name starts with `wall` / `ground` / `ceiling` is decoded to RGB and appended to that
     library as pygame.surfarray.array3d returns it — axes (W, H, 3), i.e. the decoded (H, W, 3) image transposed — as
     float32.  Other files are ignored.  -> dict(walls, grounds, ceilings) of float32 [n, W, H, 3]; pass it to
-    `MazeWorldVecEnv(textures=...)` and its sizes to the sampler (`texture_counts(lib)`).  Needs Pillow."""
+    `MazeWorldVecEnv(textures=...)` and its sizes to the sampler (`texture_counts(lib)`).  Needs Pillow.
+    The engine's textures are 256 x 256 (as every image of the reference's own folder): an image of another size raises
+    ValueError, or — resize=True — is resampled to 256 x 256 (bilinear; a deviation from the reference, which would sample
+    the image at its own size)."""
     from PIL import Image
     libs = {"wall": [], "ground": [], "ceiling": []}
     for name in sorted(os.listdir(texture_dir)):
         for kind, dst in libs.items():
             if name.find(kind) == 0:
                 with Image.open(os.path.join(texture_dir, name)) as im:
-                    rgb = np.asarray(im.convert("RGB"))            # (H, W, 3)
+                    im = im.convert("RGB")
+                    if im.size != (TEX_SIZE, TEX_SIZE):
+                        if not resize:
+                            raise ValueError("%s is %d x %d; the engine's textures are %d x %d (pass resize=True to resample)"
+                                             % (name, im.size[0], im.size[1], TEX_SIZE, TEX_SIZE))
+                        im = im.resize((TEX_SIZE, TEX_SIZE), Image.BILINEAR)
+                    rgb = np.asarray(im)            # (H, W, 3)
                 dst.append(np.ascontiguousarray(rgb.transpose(1, 0, 2)))
     out = {}
     for kind, key in (("wall", "walls"), ("ground", "grounds"), ("ceiling", "ceilings")):
@@ -95,6 +118,7 @@ def load_texture_library(texture_dir):
         if len(shapes) != 1:
             raise ValueError("%s* images differ in size: %s" % (kind, sorted(shapes)))
         out[key] = np.asarray(libs[kind], dtype="float32")
+    check_texture_library(out)
     return out
 
 

@@ -15,7 +15,7 @@ from ..engine import AUTORESET
 from ..spaces import Box, Discrete
 from ..vector import VectorEnv
 from .tables import DEFAULT_ACTION_SPACE_16, DEFAULT_ACTION_SPACE_32, build_tables
-from .textures import make_texture_library
+from .textures import check_texture_library, make_texture_library
 
 
 class _Tables(C.Structure):   # xv_maze_tables (include/xeno.h)
@@ -74,6 +74,7 @@ class MazeWorldVecEnv(VectorEnv):
     def set_task(self, tasks, env_task_index=None):
         tab = tasks if (isinstance(tasks, dict) and "walls" in tasks) else build_tables(tasks)
         tex = self._textures if self._textures is not None else make_texture_library()
+        check_texture_library(tex)      # the kernels address 256 x 256 x 3 texels: any other size is an out-of-bounds read
         d = self.device
         dev = {k: torch.from_numpy(np.ascontiguousarray(tab[k])).to(d) for k in
                ("walls", "texts", "landmarks", "ints", "dbl", "commands", "lm_coord")}

@@ -109,7 +109,8 @@ class CartPoleVecEnv(VectorEnv):
         infos = {}
         if self.autoreset_mode == "same_step":
             infos["final_obs"] = self._of(self._fobs)
-            infos["_final_obs"] = self._out((self._term | self._trunc).bool())
+            if not self.lean_infos:
+                infos["_final_obs"] = self._out((self._term | self._trunc).bool())
         return (self._of(self._obs), self._of(self._reward), self._obf(self._term),
                 self._obf(self._trunc), infos)
 

@@ -102,29 +102,75 @@ class MixedBatch(object):
 
     def step_fused(self, actions):
         """One launch for the whole mixed batch (xv_mixed_step).  actions: dict name -> batched action, as for step().
-        -> dict name -> (obs, reward, terminated, truncated, infos), bit for bit what step() returns."""
+        -> dict name -> (obs, reward, terminated, truncated, infos), bit for bit what step() returns.  Handles without a
+        fused instantiation (AnyMDP on the per-lane search or S > 112, LinDS on the scalar path or other pads) are stepped
+        by step() — three launches, same results."""
         pick, mode = self._fused_trio()
         (na, ea), (nl, el), (nc, ec) = pick["a"], pick["l"], pick["c"]
-        if ea._tok is not None or ea._ring is not None:
-            raise ValueError("step_fused serves MDP tasks with copy=True outputs")
+        if ea._tok is not None:
+            raise ValueError("step_fused serves MDP tasks")
         ea._check_step(); el._check_step()
         if (not ec.task_set) or ec.need_reset:
             raise Exception("Must \"set_task\" and \"reset\" before doing any actions")
+        if not ea.lib.xv_mixed_supported(ea._h, el._h, ec._h):      # asked BEFORE any output buffer is renewed
+            return self.step(actions)
         aa = ea._dev(actions[na], torch.int32)
         al = el._action(actions[nl])
         ac = ec._dev(actions[nc], torch.int32)
         if aa.shape != (ea.num_envs,) or ac.shape != (ec.num_envs,):
             raise AssertionError("action batch shapes do not match the env counts")
-        ea._renew("_obs", "_reward", "_reward_gt", "_term", "_trunc", "_final_obs")
+        ring = None
+        if ea._ring is not None:      # copy=False: the AnyMDP family writes one of its two engine-owned output sets
+            ring = ea._ring[ea._ring_pos]
+            if not ea._holding:
+                ea._ring_pos ^= 1
+            a_out = [ring[k] for k in ("obs", "reward", "reward_gt", "term", "trunc", "final_obs")]
+        else:
+            ea._renew("_obs", "_reward", "_reward_gt", "_term", "_trunc", "_final_obs")
+            a_out = [ea._obs, ea._reward, ea._reward_gt, ea._term, ea._trunc, ea._final_obs]
         el._renew(*el._STEP_OUTPUTS); el._fresh_final_obs()
         ec._renew("_obs", "_reward", "_term", "_trunc", "_fobs")
         io = _MixedIO(*[_lib.ptr(t) for t in (
-            aa, ea._obs, ea._reward, ea._reward_gt, ea._term, ea._trunc, ea._final_obs,
-            al, el._obs, el._reward, el._term, el._trunc, el._cmd, el._error, el._fobs,
-            ac, ec._obs, ec._reward, ec._term, ec._trunc, ec._fobs)])
+            [aa] + a_out + [al, el._obs, el._reward, el._term, el._trunc, el._cmd, el._error, el._fobs,
+                            ac, ec._obs, ec._reward, ec._term, ec._trunc, ec._fobs])])
         _lib.check(ea.lib.xv_mixed_step(ea._h, el._h, ec._h, C.byref(io), AUTORESET[mode]))
-        return {na: (ea._of(ea._obs), ea._of(ea._reward), ea._obf(ea._term), ea._obf(ea._trunc), ea._infos(aa)),
-                nl: el._ret(), nc: ec._ret()}
+        if ring is not None:
+            infos = {"reward_gt": ring["reward_gt"]}
+            if mode == "same_step":
+                infos["final_obs"] = ring["final_obs"]
+            if not ea.lean_infos:
+                _lib.check(ea.lib.xv_anymdp_get_state(ea._h, None, ring["steps_p"], None))
+                infos["steps"] = ring["steps"]
+                if mode == "same_step":
+                    torch.bitwise_or(ring["term"], ring["trunc"], out=ring["done"])
+                    infos["_final_obs"] = ring["done_b"]
+            ra = (ring["obs"], ring["reward"], ring["term_b"], ring["trunc_b"], infos)
+        else:
+            ra = (ea._of(ea._obs), ea._of(ea._reward), ea._obf(ea._term), ea._obf(ea._trunc), ea._infos(aa))
+        return {na: ra, nl: el._ret(), nc: ec._ret()}
+
+    def capture(self, policy_fn, obs, unroll=1, warmup=1, lean=True):
+        """[policy_fn(obs dict) -> actions dict; step_fused(actions)] captured in a torch.cuda.graph (capture.py):
+        one graph launch per `unroll` vector steps of the whole mixed batch.  obs: dict name -> the observation the family
+        returned last.  The envs must be built with copy=False."""
+        from .capture import CapturedLoop
+        pick, _ = self._fused_trio()
+        envs = [e for _, e in pick.values()]
+        if any(e.copy or e.to_numpy for e in envs):
+            raise ValueError("capture() needs the three envs built with copy=False and to_numpy=False")
+        for e in envs:
+            e._lean_saved, e._lean_wanted = e.lean_infos, bool(lean) or e.lean_infos
+
+        def hold(on):
+            for e in envs:
+                e._capture_hold(on)
+
+        def step(actions):
+            out = self.step_fused(actions)
+            return ({k: v[0] for k, v in out.items()}, out)
+
+        return CapturedLoop(step, [e.engine for e in envs], policy_fn, obs, unroll=unroll, warmup=warmup, device=self.device,
+                            hold=hold)
 
     def sync(self):
         if not self.separate:

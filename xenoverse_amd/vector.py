@@ -34,6 +34,9 @@ class VectorEnv(_GymVectorEnv):
         # copy (as gymnasium's SyncVectorEnv(copy=...)): True returns fresh tensors from every call; False returns
         # views of engine-owned output buffers, valid until the next step()/reset() (no per-step device copies)
         self.copy = bool(copy)
+        # lean_infos: step() returns only the infos that cost no extra launch (captured loops: xenoverse_amd/capture.py)
+        self.lean_infos = False
+        self._holding = False
         self.closed = False
         self.task_set = False
         self.single_observation_space = None
@@ -98,6 +101,24 @@ class VectorEnv(_GymVectorEnv):
         if not self.task_set:
             # reference: raise Exception("Must call \"set_task\" first") (anymdp_env.py:83, linds_env.py:110)
             raise Exception("Must call \"set_task\" first")
+
+    def _capture_hold(self, on):
+        """while a captured loop exists: pins whatever the family alternates between step() calls (output sets) and,
+        when asked, leaves out the infos that need a launch of their own"""
+        self._holding = bool(on)
+        self.lean_infos = self._lean_wanted if on else self._lean_saved
+
+    def capture(self, policy_fn, obs, unroll=1, warmup=1, lean=True):
+        """[policy_fn(obs) -> actions; step(actions)] captured in a torch.cuda.graph -> CapturedLoop (capture.py): one
+        graph launch per `unroll` vector steps, same trajectory as the eager calls.  Needs copy=False, to_numpy=False.
+        `warmup` eager iterations run first and are real steps.  lean: step() skips the infos that need a launch of
+        their own (AnyMDP / LinDS `steps`, the `_final_obs` mask) while the loop exists."""
+        from .capture import CapturedLoop
+        if self.copy or self.to_numpy:
+            raise ValueError("capture() needs an env built with copy=False and to_numpy=False (fixed output buffers)")
+        self._lean_saved, self._lean_wanted = self.lean_infos, bool(lean) or self.lean_infos
+        return CapturedLoop(self.step, [self.engine], policy_fn, obs, unroll=unroll, warmup=warmup, device=self.device,
+                            hold=self._capture_hold)
 
     def check_errors(self, clear=True):
         """Device-side range errors are sticky bits, read on demand (one stream sync)."""
