@@ -289,6 +289,11 @@ typedef struct {
   uint64_t lines, lines_dirty, live_rows;
   double p_fallback, fallbacks_per_launch, bytes;
   double auto_limit;                 /* AUTO uses the lines iff fallbacks_per_launch <= auto_limit */
+  /* POMDP / multi-token tasks: the observation bucket lines built beside them (14 cuts of obs_cdf[t][k][s][:] per line,
+   * n_obs <= 256; 0 lines: not built, the per-lane token kernel serves) and the share of observation draws they cannot
+   * answer (those take a per-lane search of the row) */
+  uint64_t obs_lines, obs_lines_dirty;
+  double obs_p_fallback;
 } xv_anymdp_bucket_census;
 int xv_anymdp_probe_buckets(xv_anymdp* h, int n_bucket, xv_anymdp_bucket_census* out);   /* census without the memory */
 int xv_anymdp_bucket_census_get(xv_anymdp* h, xv_anymdp_bucket_census* out);             /* of the lines that are built */

@@ -238,6 +238,40 @@ def bench_anymdp_tok(args):
             "note": "per-lane searches (general path); 2 transition + 2 observation draws per env-step"}
 
 
+def bench_anymdp_tok_refdist(args, n_task=1024, per=64):
+    """the POMDP / multi-token step on tasks of the REFERENCE's distribution (device sampler: skewed transition rows, sparse
+    observation rows), 65,536 envs, token steps issued from C: the per-lane kernel (search = fence) against what AUTO picks
+    once the bucket lines are offered (the cooperative kernel on transition + observation cut lines)"""
+    from xenoverse_amd.anymdp import AnyMDPVecEnv
+    from xenoverse_amd.anymdp import device_sampler as ds
+    S, A = 64, 8
+    n = n_task * per
+    out = {}
+    for tt, do, da in (("POMDP", 1, 1), ("MTPOMDP", 2, 2)):
+        t = ds.sample_tasks_device(n_task, S, A, seed=3, batch=4096, task_type=tt, observation_space=64, observation_tokens=do,
+                                   action_tokens=da)
+        env = AnyMDPVecEnv(n, seed=1, autoreset_mode="same_step")
+        env.set_task(t, env_task_index=(torch.arange(n, device=env.device, dtype=torch.int32) // per).contiguous())
+        env.reset()
+        P = 8
+        a = torch.randint(0, A, (P, n, da), device=env.device, dtype=torch.int32)
+        ring = env.step_tokens_many(P, a)
+        k = max(P, args.steps // P * P)
+        row = {}
+        for name in ("fence", "auto"):
+            env.set_search(name, n_bucket=16) if name == "auto" else env.set_search(name)
+            us = min(timed(lambda: env.step_tokens_many(k, a, out=ring), 3, 1) / k for _ in range(2))
+            row[name] = {"us_per_step": us, "kernel": env.token_kernel, "search": env.effective_search}
+        cen = env.bucket_census()
+        row["census"] = {k2: cen[k2] for k2 in ("p_fallback", "fallbacks_per_launch", "auto_uses_bucket", "obs_lines", "obs_lines_dirty",
+                                               "obs_p_fallback")}
+        row["device_error_flags"] = env.check_errors()
+        out["%s d_obs=%d d_act=%d" % (tt, do, da)] = row
+        env.close()
+    return {"family": "anymdp_tok_refdist", "workload": "65,536 envs = 1,024 device-sampled reference-distribution tasks x 64, S=64 A=8 "
+            "n_obs=64, token steps from C (xv_anymdp_step_tokens_many)", "dtype": "f64", "variants": out}
+
+
 def bench_mixed(args, variants=("three streams", "one stream", "one launch")):
     """BASELINE.json config 5, the per-GPU share: 16,384 anymdp (2b: 256 tasks x 64) + 8,192 linds (128 tasks x 64)
     + 8,192 cartpole, one launch per family per vector step, families on separate HIP streams (xenoverse_amd.mixed)
@@ -413,7 +447,7 @@ def bench_python_loop(args, n=65536, n_task=1024):
             st["obs"] = env.step(policy(st["obs"]))[0]
         out["eager copy=%s" % copy] = timed(it, steps, 20)
         env.close()
-    for unroll in (1, 8):
+    for unroll in (1, 8, 32):
         env = _synth_anymdp_env(n, n_task, copy=False)
         obs, _ = env.reset()
         loop = env.capture(policy, obs, unroll=unroll, warmup=2)
@@ -612,6 +646,8 @@ if __name__ == "__main__":
             r = bench_anymdp_tok(args)
         elif f == "anymdp_refdist":
             r = bench_anymdp_refdist(args)
+        elif f == "anymdp_tok_refdist":
+            r = bench_anymdp_tok_refdist(args)
         elif f == "python_loop":
             r = bench_python_loop(args)
         elif f == "teacher":

@@ -104,14 +104,21 @@ def test_batch_vs_oracle_injected_and_free_running(mode, search):
 
 @pytest.mark.parametrize("n_obs,d_obs,d_act,search", [(64, 3, 2, "fence"), (22, 2, 3, "fence"), (15, 2, 2, "fence"),
                                                      (64, 3, 2, "binary"), (64, 3, 2, "bucket"), (22, 2, 3, "bucket"),
-                                                     (15, 1, 1, "bucket"), (200, 2, 2, "bucket")])
+                                                     (15, 1, 1, "bucket"), (200, 2, 2, "bucket"), (256, 2, 1, "bucket"),
+                                                     (300, 2, 2, "bucket"), (64, 2, 2, "sparse-bucket")])
 def test_synthetic_observation_models_vs_oracle(n_obs, d_obs, d_act, search):
     """S=64, A=8 synthetic tasks with random observation models of several shapes (n_obs 64 / 22 / 15, up to 3
     tokens) against the oracle: injected draws incl. exact CDF entries, all three auto-reset modes in turn"""
     S, A, n_task = 64, 8, 6
     tab = oracle.anymdp_synth(seed=17, task_index_base=0, n_task=n_task, S=S, A=A, s0_max=3)
     rng = np.random.RandomState(n_obs)
-    w = rng.random_sample((n_task, d_obs, S, n_obs)) * (rng.random_sample((n_task, d_obs, S, n_obs)) < 0.5) + 1e-3
+    sparse = search == "sparse-bucket"      # the reference's observation rows: a few live symbols, exact zeros between them
+    search = "bucket" if sparse else search
+    w = rng.random_sample((n_task, d_obs, S, n_obs)) * (rng.random_sample((n_task, d_obs, S, n_obs)) < (0.08 if sparse else 0.5))
+    if sparse:
+        w[..., 0] += (w.sum(-1) == 0)
+    else:
+        w += 1e-3
     obs_cdf = np.cumsum(w, -1)
     obs_cdf = obs_cdf / obs_cdf[..., -1:]
     n = 333
@@ -127,6 +134,14 @@ def test_synthetic_observation_models_vs_oracle(n_obs, d_obs, d_act, search):
         env._tobs = torch.zeros((n, d_obs), dtype=torch.int32, device="cuda")
         env._tfobs = torch.full((n, d_obs), -1, dtype=torch.int32, device="cuda")
         env.set_search(search)
+        if search == "bucket":      # the cooperative kernel serves when the symbol ids fit the lines' bytes (n_obs <= 256)
+            assert env.token_kernel == ("cooperative" if n_obs <= 256 else "per-lane")
+            cen = env.bucket_census()
+            assert (cen["obs_lines"] > 0) == (n_obs <= 256)
+            if sparse:
+                assert cen["obs_lines_dirty"] == 0 and cen["obs_p_fallback"] == 0.0
+        else:
+            assert env.token_kernel == "per-lane"
         ora = oracle.AnyMDPTokOracle(tab, env_task, obs_cdf, d_act)
         ur0, uo0 = rng.random_sample(n), rng.random_sample((d_obs, n))
         assert np.array_equal(_np(env.reset_tokens_injected(ur0, uo0)), ora.tok_reset_injected(ur0, uo0))

@@ -106,3 +106,22 @@ def test_host_sampled_tasks(lib):
         assert r["wrong"] == 0 and r["faults"] == 0
         tot.append(r["p_fallback"])
     assert max(tot) < 1e-6, tot
+
+
+@pytest.mark.parametrize("n_obs,density", [(64, 0.08), (200, 0.03), (256, 0.5), (15, 1.0)])
+def test_observation_rows_with_fourteen_cuts(lib, n_obs, density):
+    """observation bucket lines list 14 cuts (csrc/anymdp.hip: anymdp_build_obs_cutlines_kernel): the reference's observation
+    rows are sparse (scipy.sparse.random rows + a 1 in empty rows, task_sampler.py:78-87) — the zero-probability symbols between
+    the few live ones no longer use up a line: nothing is left to the per-lane search"""
+    rng = np.random.RandomState(n_obs)
+    rows = []
+    for _ in range(256):
+        p = rng.rand(n_obs) * (rng.rand(n_obs) < density)
+        if p.sum() == 0:
+            p[rng.randint(n_obs)] = 1.0
+        rows.append(_cdf(p))
+    r = _check(lib, np.stack(rows), 16, 14)
+    assert r["wrong"] == 0 and r["faults"] == 0
+    if density <= 0.1:
+        assert r["dirty_lines"] == 0 and r["fenced"] == 0, r       # <= 14 live symbols meet any bucket
+    assert r["p_fallback"] < (0.02 if density > 0.3 else 1e-12), r

@@ -130,7 +130,8 @@ class BucketCensus(C.Structure):
     _fields_ = [("n_bucket", C.c_int32), ("format", C.c_int32), ("cuts_per_line", C.c_int32), ("built", C.c_int32),
                 ("auto_uses_bucket", C.c_int32), ("reserved", C.c_int32), ("lines", C.c_uint64), ("lines_dirty", C.c_uint64),
                 ("live_rows", C.c_uint64), ("p_fallback", C.c_double), ("fallbacks_per_launch", C.c_double),
-                ("bytes", C.c_double), ("auto_limit", C.c_double)]
+                ("bytes", C.c_double), ("auto_limit", C.c_double), ("obs_lines", C.c_uint64), ("obs_lines_dirty", C.c_uint64),
+                ("obs_p_fallback", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -904,45 +904,69 @@ struct AnyMDPCoopLine {
     }
     beyond = cnt >= KC || ((meta >> 26) & 1u);
   }
-  // observation bucket line: 16 doubles, the first 15 are CDF entries (2.0 past the row), the last holds {I, 0x40000000}
-  // (a double just above 2.0, never <= u)  ->  cnt = #{entries <= u}, first = I
-  __device__ __forceinline__ void resolve_cdf(double u, int lane, int& cnt, uint32_t& first) const {
+  // observation bucket line (anymdp_cutline.h, 14 cuts): units 0..6 = the cuts as doubles (2.0 when unused), unit 7 = the
+  // groups' symbol ids (bytes 0..13) and their lumped / unused bits (bits 16..29 of .w)  ->  id of the group c = #{cut <= u};
+  // beyond = the line cannot answer this draw (c == 14, or the group lumps several symbols): search the row
+  __device__ __forceinline__ void resolve_obs(double u, int lane, bool& beyond, int& id) const {
     const int g = lane >> 3, j = lane & 7;
-    cnt = 0; first = 0u;
+    int cnt = 0;
+    uint32_t meta = 0u;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const double ue = xv_shfl_f64(u, it * 8 + g);
-      const unsigned long long m0 = __ballot(xv_u2d(bv[it].x, bv[it].y) <= ue);
-      const unsigned long long m1 = __ballot(xv_u2d(bv[it].z, bv[it].w) <= ue);
-      const int co = __popc((unsigned)(m0 >> (8 * j)) & 0xFFu) + __popc((unsigned)(m1 >> (8 * j)) & 0xFFu);
-      const uint32_t fi = (uint32_t)__shfl((int)bv[it].z, 8 * j + 7);
-      { const bool own = g == it; cnt = own ? co : cnt; first = own ? fi : first; }
+      const unsigned long long m0 = __ballot(j < 7 && xv_u2d(bv[it].x, bv[it].y) <= ue);
+      const unsigned long long m1 = __ballot(j < 7 && xv_u2d(bv[it].z, bv[it].w) <= ue);
+      const int cg = __popc((unsigned)(m0 >> (8 * g)) & 0xFFu) + __popc((unsigned)(m1 >> (8 * g)) & 0xFFu);   // reader side
+      const int co = __popc((unsigned)(m0 >> (8 * j)) & 0xFFu) + __popc((unsigned)(m1 >> (8 * j)) & 0xFFu);   // owner side
+      const int sg = cg < 13 ? cg : 13;
+      const uint4 b4 = bv[it];
+      const uint32_t word = sg < 4 ? b4.x : (sg < 8 ? b4.y : (sg < 12 ? b4.z : b4.w));
+      const uint32_t packed = ((word >> (8 * (sg & 3))) & 0xFFu) | (((b4.w >> (16 + sg)) & 1u) << 8);
+      const uint32_t pm = (uint32_t)__shfl((int)packed, 8 * j + 7);
+      { const bool own = g == it; cnt = own ? co : cnt; meta = own ? pm : meta; }
     }
+    beyond = cnt >= 14 || ((meta >> 8) & 1u);
+    id = (int)(meta & 0xFFu);
   }
 };
 
-// observation bucket lines: one wave per row obs_cdf[t][k][s][:], unit q of 16 bytes = entries 2 (q & 7), 2 (q & 7) + 1 of
-// bucket q >> 3
-static __global__ __launch_bounds__(256) void anymdp_build_obs_buckets_kernel(const double* obs_cdf, size_t n_rows, int n_obs, int NBK,
-                                                                       uint4* out) {
-  const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (w >= n_rows) return;
-  const int lane = threadIdx.x & 63;
-  const double* row = obs_cdf + w * (size_t)n_obs;
-  for (int q = lane; q < NBK * 8; q += 64) {
-    const int kb = q >> 3, m = q & 7;
-    const double thr = (double)kb / (double)NBK;
-    int lo = 0, n = n_obs;
-    while (n > 0) {
-      const int half = n >> 1;
-      if (row[lo + half] <= thr) { lo += half + 1; n -= half + 1; } else n = half;
+// observation bucket lines: one thread per (row obs_cdf[t][k][s][:], bucket) chooses 14 cuts (anymdp_cutline.h) and writes
+// the line; n_obs <= 256 (symbol ids are bytes).  census as in anymdp_build_cutlines_kernel (every row counts as live).
+static __global__ __launch_bounds__(256) void anymdp_build_obs_cutlines_kernel(const double* obs_cdf, size_t n_rows, int n_obs, int NBK,
+                                                                        uint4* out, unsigned long long* census) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double mass = 0.0;
+  bool first = false;
+  if (idx < n_rows * (size_t)NBK) {
+    const size_t w = idx / (size_t)NBK;
+    const int kb = (int)(idx % (size_t)NBK);
+    const double* row = obs_cdf + w * (size_t)n_obs;
+    auto cdf = [row](int jn) { return row[jn]; };
+    XvCutLine L;
+    xv_cutline_build(cdf, n_obs, (double)kb / (double)NBK, (double)(kb + 1) / (double)NBK, 14, L);
+    mass = L.dirty_mass;
+    first = kb == 0;
+    uint4* o = out + idx * 8;
+    uint32_t idw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int c = 0; c < 14; ++c) idw[c >> 2] |= ((uint32_t)L.state[c] & 0xFFu) << (8 * (c & 3));
+    idw[3] |= (L.dirty & 0x3FFFu) << 16;
+#pragma unroll
+    for (int q = 0; q < 7; ++q)
+      o[q] = make_uint4((uint32_t)__double2loint(L.cut[2 * q]), (uint32_t)__double2hiint(L.cut[2 * q]),
+                        (uint32_t)__double2loint(L.cut[2 * q + 1]), (uint32_t)__double2hiint(L.cut[2 * q + 1]));
+    o[7] = make_uint4(idw[0], idw[1], idw[2], idw[3]);
+  }
+  const unsigned long long dm = __ballot(mass > 0.0), lm = __ballot(first);
+  double sum = mass;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+  if ((threadIdx.x & 63) == 0) {
+    if (dm) {
+      atomicAdd(census + 0, (unsigned long long)__popcll(dm));
+      atomicAdd(census + 1, (unsigned long long)ceil(sum * 68719476736.0));
     }
-    const double v0 = lo + 2 * m < n_obs ? row[lo + 2 * m] : 2.0;
-    const double v1 = lo + 2 * m + 1 < n_obs ? row[lo + 2 * m + 1] : 2.0;
-    uint4 o4 = make_uint4((uint32_t)__double2loint(v0), (uint32_t)__double2hiint(v0), (uint32_t)__double2loint(v1),
-                          (uint32_t)__double2hiint(v1));
-    if (m == 7) { o4.z = (uint32_t)lo; o4.w = 0x40000000u; }
-    out[(w * (size_t)NBK + kb) * 8 + m] = o4;
+    if (lm) atomicAdd(census + 2, (unsigned long long)__popcll(lm));
   }
 }
 
@@ -992,10 +1016,9 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
   auto obs_line = [&](int k, int state, double u) -> uint32_t {
     return ((((uint32_t)t * DO + k) * S + state) * (uint32_t)NBK) + (uint32_t)(int)(u * (double)NBK);
   };
-  auto obs_pick = [&](int k, int state, double u, int cnt, uint32_t first, bool want) -> int {
-    int ob = (int)first + cnt;
-    ob = ob < K.n_obs - 1 ? ob : K.n_obs - 1;
-    if (want && cnt >= 15) {   // beyond the line: search the row
+  auto obs_pick = [&](int k, int state, double u, int id, bool beyond, bool want) -> int {
+    int ob = id;
+    if (want && beyond) {   // the line cannot answer this draw: search the row
       const double* row = K.obs_cdf + ((((size_t)t * DO + k) * S) + state) * (size_t)K.n_obs;
       ob = xv_upper_bound_f64(row, K.n_obs, u);
     }
@@ -1121,16 +1144,16 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
     }
     __builtin_amdgcn_sched_barrier(0);
     int c0, c1;
-    uint32_t f0, f1;
-    S0.resolve_cdf(u0, lane, c0, f0);
-    S1.resolve_cdf(u1, lane, c1, f1);
+    bool f0, f1;
+    S0.resolve_obs(u0, lane, f0, c0);
+    S1.resolve_obs(u1, lane, f1, c1);
     const int ob0 = obs_pick(kp, s, u0, c0, f0, !skip), ob1 = obs_pick(k1, s, u1, c1, f1, !skip && k1 != kp);
     int rb0 = 0, rb1 = 0;
     if (restarts) {
       int cr0, cr1;
-      uint32_t fr0, fr1;
-      Q0.resolve_cdf(v0, lane, cr0, fr0);
-      Q1.resolve_cdf(v1, lane, cr1, fr1);
+      bool fr0, fr1;
+      Q0.resolve_obs(v0, lane, fr0, cr0);
+      Q1.resolve_obs(v1, lane, fr1, cr1);
       rb0 = obs_pick(kp, s_new, v0, cr0, fr0, wq);
       rb1 = obs_pick(k1, s_new, v1, cr1, fr1, wq && k1 != kp);
     }
@@ -1732,7 +1755,9 @@ static int anymdp_build_obs_buckets(xv_anymdp* h) {
     (void)hipFree(h->obs_bucket);
     h->obs_bucket = nullptr;
   }
+  h->census.obs_lines = 0; h->census.obs_lines_dirty = 0; h->census.obs_p_fallback = 0.0;
   if (!h->obs_cdf || !h->a.bucket || h->a.NBK <= 0) return XV_OK;
+  if (h->n_obs > 256) return XV_OK;                                    // symbol ids are bytes in the lines: the per-lane kernel serves
   const size_t n_rows = (size_t)h->a.n_task * h->d_obs * h->a.S;
   if (n_rows * (size_t)h->a.NBK >= (1ull << 32)) return XV_OK;      // 32-bit line index: the per-lane kernel serves
   // budget: the lines may take what is free minus 2 GiB of headroom for the caller (1,024 tasks x 4 tokens x S = 256 x 16
@@ -1741,14 +1766,33 @@ static int anymdp_build_obs_buckets(xv_anymdp* h) {
   const size_t need = n_rows * (size_t)h->a.NBK * 128;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need + ((size_t)2 << 30) > free_b) return XV_OK;
   uint4* b = nullptr;
-  if (hipMalloc(&b, need) != hipSuccess) {
+  unsigned long long* d_cen = nullptr;
+  if (hipMalloc(&b, need) != hipSuccess || hipMalloc(&d_cen, 3 * sizeof(unsigned long long)) != hipSuccess) {
     (void)hipGetLastError();
+    if (b) (void)hipFree(b);
     return XV_OK;                                                  // not fatal: the per-lane kernel serves
   }
-  hipLaunchKernelGGL(anymdp_build_obs_buckets_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, h->eng->stream,
-                     h->obs_cdf, n_rows, h->n_obs, h->a.NBK, b);
-  XV_LAUNCH_CHECK();
+  hipError_t r = hipMemsetAsync(d_cen, 0, 3 * sizeof(unsigned long long), h->eng->stream);
+  const size_t chunk = (size_t)1 << 22;
+  for (size_t r0 = 0; r == hipSuccess && r0 < n_rows; r0 += chunk) {
+    const size_t nr = n_rows - r0 < chunk ? n_rows - r0 : chunk;
+    hipLaunchKernelGGL(anymdp_build_obs_cutlines_kernel, dim3((unsigned)((nr * (size_t)h->a.NBK + 255) / 256)), dim3(256), 0,
+                       h->eng->stream, h->obs_cdf + r0 * (size_t)h->n_obs, nr, h->n_obs, h->a.NBK, b + r0 * (size_t)h->a.NBK * 8, d_cen);
+    r = hipGetLastError();
+  }
+  unsigned long long cen[3] = {0, 0, 0};
+  if (r == hipSuccess) r = hipMemcpyAsync(cen, d_cen, sizeof(cen), hipMemcpyDeviceToHost, h->eng->stream);
+  if (r == hipSuccess) r = hipStreamSynchronize(h->eng->stream);
+  (void)hipFree(d_cen);
+  if (r != hipSuccess) {
+    (void)hipFree(b);
+    xv_set_error("xv_anymdp: building the observation bucket lines failed: %s", hipGetErrorString(r));
+    return XV_ERR_HIP;
+  }
   h->obs_bucket = b;
+  h->census.obs_lines = (uint64_t)(n_rows * (size_t)h->a.NBK);
+  h->census.obs_lines_dirty = (uint64_t)cen[0];
+  h->census.obs_p_fallback = cen[2] ? (double)cen[1] / 68719476736.0 / (double)cen[2] : 0.0;
   return XV_OK;
 }
 

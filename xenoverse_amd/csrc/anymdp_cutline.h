@@ -23,7 +23,8 @@
 #define XV_HD __host__ __device__
 #endif
 
-#define XV_CUT_MAXK 7     // cuts per line: 7 (narrow metadata: S <= 256 and observation ids <= 255) or 6 (wide)
+#define XV_CUT_MAXK 14    // cuts per line: transition lines 7 (narrow metadata: S <= 256 and observation ids <= 255) or 6
+                          // (wide); observation lines 14 (8-byte cuts only, one-byte symbol ids)
 #define XV_CUT_MAXL 64    // live states considered per bucket; a longer run ends in the unlisted tail
 
 struct XvCutLine {
@@ -77,7 +78,7 @@ XV_HD inline void xv_cutline_build(const CDF& cdf, int S, double lo, double hi, 
   // run (a further state may join it at no extra group).  dec[i]: how the best f after state i was reached.
   const double INF = 1.0e300, total = hi - lo;
   double f[XV_CUT_MAXK + 1][2];
-  unsigned short dec[XV_CUT_MAXL];
+  unsigned dec[XV_CUT_MAXL];            // bit g: the pure group g - 1 follows a dirty run; bit 16 + g: a dirty run opens group g - 1
   for (int g = 0; g <= K; ++g) f[g][0] = f[g][1] = INF;
   f[0][0] = 0.0;
   double best = total;          // nothing listed: every draw of the bucket is beyond the line
@@ -92,9 +93,9 @@ XV_HD inline void xv_cutline_build(const CDF& cdf, int S, double lo, double hi, 
       if (f[g - 1][1] < f[g - 1][0]) { nf[g][0] = f[g - 1][1]; d |= 1u << g; } else nf[g][0] = f[g - 1][0];
       // state i in a dirty run: joins the open run (same g) or opens group g - 1 after a pure group
       const double ext = f[g][1], neu = f[g - 1][0];
-      if (neu < ext) { nf[g][1] = neu + w; d |= 1u << (8 + g); } else if (ext < INF) nf[g][1] = ext + w;
+      if (neu < ext) { nf[g][1] = neu + w; d |= 1u << (16 + g); } else if (ext < INF) nf[g][1] = ext + w;
     }
-    dec[i] = (unsigned short)d;
+    dec[i] = d;
     for (int g = 0; g <= K; ++g) { f[g][0] = nf[g][0]; f[g][1] = nf[g][1]; }
     const double tail = total - pre[i];      // the states after i (and any beyond the cap) stay unlisted
     for (int g = 1; g <= K; ++g)
@@ -115,7 +116,7 @@ XV_HD inline void xv_cutline_build(const CDF& cdf, int S, double lo, double hi, 
       open = -1;
     } else {
       if (open != q) { emit(q, jj[i], true); open = q; }
-      if ((d >> (8 + g)) & 1u) { b = 0; g -= 1; open = -1; }
+      if ((d >> (16 + g)) & 1u) { b = 0; g -= 1; open = -1; }
     }
   }
 }
