@@ -340,7 +340,9 @@ int xv_anymdp_value_iteration_set_summation(int mode);
  * optimal and uniform policy < 2 | 3 long-run occupancy too concentrated (gini <= 0.70 or entropy <= 0.35) | 4 no
  * convergence.  Accepted candidates write slot i of the step engine's tables (rows / state_map / term_mask / s0_cdf /
  * s0_ids / max_steps, exactly what xv_anymdp_create takes; pass env_task entries that point at accepted slots); the
- * dense fp64 tensors and `info` (nullable) are written for every candidate.  Supported: 8 <= S <= 64, S * A <= 512. */
+ * dense fp64 tensors and `info` (nullable) are written for every candidate.  Supported: 8 <= S <= 64 with S * A <= 512
+ * (the candidate's transition tensor in registers) and S <= 256 with S * A <= 4096 (round 4: rows in a transposed global
+ * scratch, allocated stream-ordered per call; term_mask then has ceil(S / 64) words per candidate). */
 typedef struct {
   int32_t status, goal, n_s0, repair_rounds;
   int32_t s0[4];

@@ -491,9 +491,14 @@ def quick_families(steps=200, warmup=20):
         us = r["us_per_step"]["step (both)"]
         return {"config": "BASELINE configs[3]: " + r["workload"], "ms_per_step": us * 1e-3, "env_steps_per_s": r["env_steps_per_s"],
                 "us_per_step": r["us_per_step"], "dtype": r["dtype"],
-                "roofline": {"bound": "hbm", "frac": r["roofline"]["frac"], "algorithmic_bytes": (3 * 64 * 64 + 64) * 16384,
-                             "peak": HBM_PEAK, "unit": "GB/s", "achieved": r["roofline"]["achieved"],
-                             "kernel": "maze_step9_kernel + maze_raycast_kernel", "valu_f64_frac": r["valu_f64"]["frac"],
+                # the ray caster (92 % of the step) is bound by fp64 VALU issue — the 16-tap filter in the reference's typing —
+                # not by HBM: `bound` / `frac` are that kernel's; the HBM view of the same step is kept beside it
+                "roofline": {"bound": "valu_f64", "frac": r["valu_f64"]["frac"], "achieved": r["valu_f64"]["achieved"],
+                             "peak": r["valu_f64"]["peak"], "unit": r["valu_f64"]["unit"], "model": r["valu_f64"]["model"],
+                             "kernel": "maze_raycast_kernel (exact filter; + maze_step9_kernel for the move)",
+                             "valu_f64_frac": r["valu_f64"]["frac"],
+                             "hbm": {"frac": r["roofline"]["frac"], "algorithmic_bytes": (3 * 64 * 64 + 64) * 16384, "peak": HBM_PEAK,
+                                     "unit": "GB/s", "achieved": r["roofline"]["achieved"]},
                              "note": r["roofline"]["note"]}}
 
     def mixed():

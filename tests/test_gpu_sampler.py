@@ -23,7 +23,8 @@ def _engine():
     return Engine("cuda:0")
 
 
-@pytest.mark.parametrize("S,A,n", [(16, 4, 192), (8, 2, 64), (24, 5, 48), (32, 8, 40), (64, 8, 24), (64, 5, 16), (40, 12, 12)])
+@pytest.mark.parametrize("S,A,n", [(16, 4, 192), (8, 2, 64), (24, 5, 48), (32, 8, 40), (64, 8, 24), (64, 5, 16), (40, 12, 12),
+                                   (96, 4, 10), (128, 5, 8), (256, 5, 4), (64, 12, 8), (200, 20, 3)])
 def test_candidates_equal_the_oracle(S, A, n):
     """every candidate, accepted or not: status, start / terminal states, bands, sweep counts exact; tensors to 1e-9"""
     from xenoverse_amd.anymdp import device_sampler as ds
@@ -54,7 +55,8 @@ def test_candidates_equal_the_oracle(S, A, n):
         if o["status"] in (0, 2, 3):
             assert abs(inf["gap_min"] - o["gap_min"]) < 1e-6 * max(1.0, abs(o["gap_min"]))
         n_acc += st[i] == 0
-    assert n_acc >= 1 and (st != 0).sum() >= 1            # both outcomes occurred
+    if n >= 12:
+        assert n_acc >= 1 and (st != 0).sum() >= 1        # both outcomes occurred
     eng.close()
 
 
@@ -124,6 +126,42 @@ def test_population_matches_the_reference_sampler():
     assert abs(dev["pit_frac"] - ref["pit_frac"]) < 4 * pf.std() / np.sqrt(n_ref), (dev["pit_frac"], ref["pit_frac"])
     assert abs(dev["goal"] - ref["goal"]) < 4 * np.sqrt(0.25 / n_ref)
     eng.close()
+
+
+def test_population_at_128_states_matches_the_seed_compatible_host_sampler():
+    """128 x 5 (the size of the reference's Garnet default; its multi-token default is 256): the interpreted reference cannot
+    produce tasks of this size here, so the population is the seed-compatible host sampler's (oracle/gen_hostpop.py: bit-equal
+    to the reference wherever the reference could be run).  Band width, non-zeros per row, pitfall density, goal share and
+    start-state count of the device sampler's accepted tasks within 4 standard errors of that population; and the tables go
+    into the step engine and step."""
+    from xenoverse_amd.anymdp import AnyMDPVecEnv
+    from xenoverse_amd.anymdp import device_sampler as ds
+    g = np.load(os.path.join(GOLD, "sampler_hostpop_128x5.npz"))
+    n_task = 48
+    out = ds.sample_tasks_device(n_task, 128, 5, seed=11, batch=96, dense=True)
+    assert out["stats"]["accepted"] == n_task and tuple(out["term_mask"].shape) == (n_task, 2)
+    T = _np(out["transition"])
+    tm = _np(out["term_mask"]).view(np.uint64)
+    se = np.array([[(int(tm[k, j >> 6]) >> (j & 63)) & 1 for j in range(128)] for k in range(n_task)], bool)
+    dev = dict(band=[], nnz=[], pit_frac=se.mean(1), goal=se[:, 127].astype(float))
+    for k in range(n_task):
+        nz = T[k][~se[k]] > 0
+        dev["band"].append(np.mean([np.ptp(np.nonzero(x.any(0))[0]) + 1 for x in nz]))
+        dev["nnz"].append(nz.sum(-1).mean())
+        assert np.allclose(T[k][~se[k]].sum(-1), 1.0, atol=1e-12) and not T[k][se[k]].any()
+    for key in ("band", "nnz", "pit_frac", "goal"):
+        a, b = np.asarray(dev[key], float), g[key]
+        se_ = np.sqrt(a.var() / len(a) + b.var() / len(b)) + 1e-12
+        assert abs(a.mean() - b.mean()) < 4 * se_, (key, a.mean(), b.mean(), se_)
+    env = AnyMDPVecEnv(n_task * 16, seed=2, autoreset_mode="same_step")
+    env.set_task({k: out[k] for k in ("S", "A", "s0_max", "rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")})
+    obs, _ = env.reset()
+    done = 0
+    for t in range(64):
+        o = env.step(torch.randint(0, 5, (n_task * 16,), device=env.device, dtype=torch.int32))
+        done += int((o[2] | o[3]).sum())
+    assert env.check_errors() == 0 and int(o[0].max()) < 128
+    env.close()
 
 
 def test_sampled_tasks_step_in_the_engine_like_uploaded_ones():

@@ -6,7 +6,9 @@ Same generative model and acceptance test as the reference's AnyMDPTaskSampler (
 task_sampler_utils.py:65-256, solver.py:84-148) with counter-based randomness: task k of (seed, state_space,
 action_space) is the k-th ACCEPTED candidate in candidate order — a pure function of those arguments, independent of
 the batch size used to find it — but not the task NumPy's stream would give for that seed (for that, the host sampler
-`AnyMDPTaskSampler(seed=...)`).  Supported sizes: 8 <= state_space <= 64, state_space * action_space <= 512.
+`AnyMDPTaskSampler(seed=...)`).  Supported sizes: 8 <= state_space <= 64 with state_space * action_space <= 512 (a
+candidate's transition tensor lives in registers) and, round 4, state_space <= 256 with state_space * action_space <= 4096
+(rows in a transposed global scratch: the defaults of the reference's Garnet (128) and multi-token (256) samplers).
 """
 import ctypes as C
 import time
@@ -34,7 +36,7 @@ def sample_candidates(engine, seed, cand_base, n_cand, S, A, s0_max=4, tables=Tr
     if tables:
         out.update(rows=torch.empty((n_cand, S, A, row_lines(S), 16), dtype=torch.float64, device=d),
                    state_map=torch.empty((n_cand, S), dtype=torch.int32, device=d),
-                   term_mask=torch.empty((n_cand, 1), dtype=torch.int64, device=d),
+                   term_mask=torch.empty((n_cand, (S + 63) // 64), dtype=torch.int64, device=d),
                    s0_cdf=torch.empty((n_cand, s0_max), dtype=torch.float64, device=d),
                    s0_ids=torch.empty((n_cand, s0_max), dtype=torch.int32, device=d),
                    max_steps=torch.empty(n_cand, dtype=torch.int32, device=d))
@@ -84,6 +86,8 @@ def sample_tasks_device(n_tasks, state_space=64, action_space=5, seed=0, device=
     try:
         if batch is None:
             per = S * A * row_lines(S) * 128 + (3 * S * A * S * 8 if dense else 0)
+            if S > 64 or S * A > 512:      # the candidate's scratch: transposed transition rows + two S x S matrices
+                per += ((S * A + 63) // 64 * 64 * S + 2 * S * S) * 8
             batch = int(max(64, min(8192, (6 << 30) // per, 4 * n_tasks + 64)))
         keys = ["rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps"] + \
             (["transition", "reward", "reward_noise"] if dense else [])

@@ -598,6 +598,595 @@ __global__ __launch_bounds__(512) void anymdp_sampler_kernel(SamplerArgs P) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same sampler for 64 < S <= 256 (round 4; the reference's GarnetTaskSampler defaults to 128 states and its
+// MultiTokensAnyPOMDPTaskSampler to 256, task_sampler.py:90-126).  A candidate's transition tensor is S * A rows of S
+// doubles (2.6 MB at 256 x 5): it no longer lives in registers but in a per-candidate global scratch, TRANSPOSED in blocks
+// of 64 rows — Tt[(row >> 6) * S + j][row & 63] — so that the 64 lanes of a wave, which own 64 consecutive rows, read
+// element j of their rows as one coalesced 512-byte access.  Thread tid owns rows tid, tid + blockDim, ... (R <= 4 of them);
+// every chain keeps the order of the register kernel (fma over j ascending: a zero outside a row's band adds nothing), so
+// both kernels and the oracle restatement (oracle/xeno_oracle_sampler.c) agree to rounding, candidates draw for draw.
+// Same Philox coordinates as the register kernel: the index strides (64 words per 256 states) were laid out for 256 states.
+// ------------------------------------------------------------------------------------------------
+struct BigScratch {
+  double* Tt;        // [n_cand][n_rb * S * 64]
+  double* Pm;        // [n_cand][2 * S * S]   band weights during generation, occupancy matrices at acceptance
+  int n_rb;
+};
+
+__device__ __forceinline__ double xsb_t(const double* Tt, int S, int r, int j) { return Tt[((size_t)(r >> 6) * S + j) * 64 + (r & 63)]; }
+
+// reward of (row with potential pot_s and state-action piece rsa) -> next state j, without the terminal bonus
+__device__ __forceinline__ void xsb_sa_pieces(const SamplerArgs& P, uint64_t cand, double sbase, int r, double& rsa, double& nsa) {
+  double zr, zn;
+  const xv_u32x4 q4 = xs_draw(P, cand, XS_SAM, (uint32_t)r);
+  const double on = xs_u32(q4.x) > 0.7 ? 1.0 : 0.0;
+  xs_normal2(q4.y, q4.z, zr, zn);
+  rsa = sbase * zr * on;
+  nsa = 0.30 * sbase * (zn > 0.0 ? zn : 0.0) * on;
+}
+
+template <int R>
+__device__ __forceinline__ int xsb_value_iteration(const double* Tt, int S, int A, int SA, double gamma, bool greedy,
+                                                   const double (&er)[R], double (&q)[R], const int (&wf)[R], const int (&wl)[R],
+                                                   double* Qs, double* Vs, double* part, int n_waves) {
+  const int tid = threadIdx.x, BD = blockDim.x;
+  double d2 = 0.0;
+  int it = 0;
+  for (;;) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int r = k * BD + tid;
+      if (r < SA) Qs[r] = q[k];
+    }
+    {
+      double x = d2;
+      for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+      if ((tid & 63) == 0) part[tid >> 6] = x;
+    }
+    __syncthreads();
+    if (it > 0) {
+      double tot = 0.0;
+      for (int w = 0; w < n_waves; ++w) tot += part[w];
+      if (sqrt(tot / (double)SA) <= 1.0e-4 || it >= XS_MAX_SWEEPS) break;
+    }
+    if (tid < S) {
+      const double* row = Qs + tid * A;
+      double v;
+      if (greedy) {
+        v = row[0];
+        for (int a = 1; a < A; ++a) v = row[a] > v ? row[a] : v;
+      } else {
+        v = 0.0;
+        for (int a = 0; a < A; ++a) v += row[a];
+        v /= (double)A;
+      }
+      Vs[tid] = v;
+    }
+    __syncthreads();
+    d2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int r = k * BD + tid;
+      const double* col = Tt + ((size_t)(r >> 6) * S) * 64 + (r & 63);
+      double acc = 0.0;
+      for (int j = wf[k]; j < wl[k]; ++j) acc = fma(col[(size_t)j * 64], Vs[j], acc);
+      const double qn = fma(gamma, acc, er[k]);
+      if (r < SA) d2 += (qn - q[k]) * (qn - q[k]);
+      q[k] = qn;
+    }
+    ++it;
+  }
+  __syncthreads();
+  return it;
+}
+
+template <int R>
+__global__ __launch_bounds__(1024) void anymdp_sampler_big_kernel(SamplerArgs P, BigScratch X) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int S = P.S, A = P.A, SA = S * A, tid = threadIdx.x, BD = blockDim.x;
+  const int n_waves = BD >> 6;
+  const int ci = blockIdx.x;
+  const uint64_t cand = (uint64_t)(P.cand_base + ci);
+  const int SAp = X.n_rb * 64;
+  double* Tt = X.Tt + (size_t)ci * SAp * S;
+  double* Pm = X.Pm + (size_t)ci * 2 * S * S;
+  double* Qs = lds;                    // [SAp]
+  double* Vs = Qs + SAp;               // [S]
+  double* part = Vs + S;               // [16]
+  double* pot = part + 16;             // [S]
+  double* rpos = pot + S;
+  double* npos = rpos + S;
+  double* bonus = npos + S;
+  double* vstate = bonus + S;
+  int* pitm = reinterpret_cast<int*>(vstate + S);
+  int* bandlo = pitm + S;
+  int* bandhi = bandlo + S;
+
+  // ---- uniform scalars (as the register kernel) ----
+  xv_u32x4 w = xs_draw(P, cand, XS_HEAD, 0);
+  const double lower = 4.0 * S > 100 ? 4.0 * S : 100;
+  double upper = 8.0 * S < 500 ? 8.0 * S : 500;
+  if (upper < lower + 1) upper = lower + 1;
+  const double max_steps = lower + xv_u53(w.x, w.y) * (upper - lower);
+  double w0[3] = {1.0, 0.0, 0.0};
+  for (uint32_t r = 0; r < 16; ++r) {
+    const xv_u32x4 q4 = xs_draw(P, cand, XS_S0, r);
+    double z0, z1, z2, z3;
+    xs_normal2(q4.x, q4.y, z0, z1);
+    xs_normal2(q4.z, q4.w, z2, z3);
+    const double c0 = z0 > 0.0 ? z0 : 0.0, c1 = z1 > 0.0 ? z1 : 0.0, c2 = z2 > 0.0 ? z2 : 0.0;
+    if ((c0 + c1) + c2 >= XS_EPS) { w0[0] = c0; w0[1] = c1; w0[2] = c2; break; }
+  }
+  int s0_id[3], n_s0 = 0;
+  double s0_p[3], s0sum = 0.0;
+  for (int k = 0; k < 3; ++k)
+    if (w0[k] > XS_EPS) { s0_id[n_s0] = k; s0_p[n_s0] = w0[k]; s0sum += w0[k]; ++n_s0; }
+  for (int k = n_s0; k < 3; ++k) { s0_id[k] = 0; s0_p[k] = 0.0; }
+  for (int k = 0; k < n_s0; ++k) s0_p[k] /= s0sum;
+  w = xs_draw(P, cand, XS_PIT, 0);
+  double p_pit = -0.20 + 0.60 * xv_u53(w.x, w.y);
+  if (p_pit < 0.0) p_pit = 0.0;
+  const int goal = xs_u32(w.z) < 0.3 ? 1 : 0;
+  {
+    int mine = 0;
+    for (uint32_t r = 0; r < 64; ++r) {
+      mine = 0;
+      if (tid < S) {
+        const xv_u32x4 q4 = xs_draw(P, cand, XS_PITS, r * 64u + (uint32_t)(tid >> 2));
+        mine = xs_u32(xs_word(q4, tid & 3)) < p_pit ? 1 : 0;
+      }
+      const int cnt = __syncthreads_count(mine);
+      if ((double)cnt < (double)S * p_pit + 1.0) break;
+    }
+    if (tid < S) {
+      for (int k = 0; k < n_s0; ++k) if (tid == s0_id[k]) mine = 0;
+      if (tid == S - 1) mine = goal;
+      pitm[tid] = mine;
+    }
+  }
+  __syncthreads();
+  int n_se = 0;
+  for (int j = 0; j < S; ++j) n_se += pitm[j];
+
+  // ---- bands ----
+  if (tid < S) {
+    int first = 0, last = 0;
+    if (!pitm[tid]) {
+      const int st = tid;
+      const int fwd_max = S / 4 + 1 > 2 ? S / 4 + 1 : 2, back_max = S / 2 + 1 > 2 ? S / 2 + 1 : 2;
+      const int a_lo = st - back_max > 0 ? st - back_max : 0;
+      int a_hi = st - 1 > 0 ? st - 1 : 0;
+      if (a_hi < a_lo + 1) a_hi = a_lo + 1;
+      const int b_hi = S < st + fwd_max ? S : st + fwd_max;
+      int b_lo = S - 1 < st + 1 ? S - 1 : st + 1;
+      if (b_lo > b_hi - 1) b_lo = b_hi - 1;
+      w = xs_draw(P, cand, XS_BAND, (uint32_t)st);
+      first = a_lo + (int)(w.x % (uint32_t)(a_hi - a_lo));
+      last = b_lo + (int)(w.y % (uint32_t)(b_hi - b_lo));
+      while (last < S) {
+        int ahead = 0;
+        for (int j = st + 1; j < last; ++j) ahead += !pitm[j];
+        if (ahead > 1) break;
+        ++last;
+      }
+    }
+    bandlo[tid] = first; bandhi[tid] = last;
+  }
+  __syncthreads();
+  for (int el = tid; el < S * S; el += BD) {
+    const int st = el / S, j = el - st * S;
+    double v = 0.0;
+    if (j >= bandlo[st] && j < bandhi[st]) {
+      const xv_u32x4 q4 = xs_draw(P, cand, XS_BANDW, ((uint32_t)st * 8u) * 64u + (uint32_t)(j >> 2));
+      v = xs_clip(xs_normal_of(q4, j & 3), 0.10, 1.0);
+    }
+    Pm[el] = v;
+  }
+  __syncthreads();
+  if (tid < S && !pitm[tid]) {
+    Pm[tid * S + tid] = (tid == S - 1) ? 0.0 : Pm[tid * S + tid] / 2.0;
+    double tot = 0.0;
+    for (int j = bandlo[tid]; j < bandhi[tid]; ++j) tot += Pm[tid * S + j];
+    Vs[tid] = tot;
+  }
+  __syncthreads();
+
+  // ---- the rows of the transition tensor, into the transposed scratch; wave-uniform column ranges of each row group ----
+  int wf[R], wl[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int r = k * BD + tid;
+    const bool in = r < SA;
+    const int s = in ? r / A : 0, a = in ? r - s * A : 0;
+    const bool live = in && !pitm[s];
+    const int first = live ? bandlo[s] : 0, last = live ? bandhi[s] : 0;
+    int lo = live ? first : S, hi = live ? last : 0;
+    for (int o = 32; o > 0; o >>= 1) {
+      const int l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+      lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+    }
+    wf[k] = lo < hi ? lo : 0; wl[k] = lo < hi ? hi : 0;
+    if (r >= SAp) continue;
+    double* col = Tt + ((size_t)(r >> 6) * S) * 64 + (r & 63);
+    if (!live) {
+      for (int j = 0; j < S; ++j) col[(size_t)j * 64] = 0.0;
+      continue;
+    }
+    const double tot = Vs[s];
+    double cen[64];
+    for (int b = 0; b < A; ++b) {
+      const xv_u32x4 q4 = xs_draw(P, cand, XS_ACT, (uint32_t)s * 16u + (uint32_t)(b >> 2));
+      cen[b] = (double)(first - 1) + xs_u32(xs_word(q4, b & 3)) * (double)(last - (first - 1));
+    }
+    w = xs_draw(P, cand, XS_ACTW, (uint32_t)s);
+    const double width = xs_clip(xs_expo(xv_u53(w.x, w.y)), 0.20, 1.6);
+    const double inv_w2 = 1.0 / (width * width);
+    double rs = 0.0;
+    for (int j = 0; j < S; ++j) {
+      double v = 0.0;
+      if (j >= first && j < last) {
+        double colsum = 0.0, dmin = 0.0, e_me = 0.0;
+        int amin = 0;
+        for (int b = 0; b < A; ++b) {
+          const double d = cen[b] - (double)j, d2 = d * d;
+          const double e = exp(-d2 * inv_w2);
+          colsum += e;
+          if (b == a) e_me = e;
+          if (b == 0 || d2 < dmin) { dmin = d2; amin = b; }
+        }
+        if (colsum < XS_EPS) {
+          colsum = 0.0;
+          for (int b = 0; b < A; ++b) {
+            const double d = cen[b] - (double)j;
+            colsum += (b == amin) ? 1.0 : exp(-(d * d) * inv_w2);
+          }
+          if (a == amin) e_me = 1.0;
+        }
+        v = (e_me / colsum) * (Pm[s * S + j] / tot);
+        rs += v;
+      }
+      col[(size_t)j * 64] = v;
+    }
+    for (int j = first; j < last; ++j) col[(size_t)j * 64] /= rs;
+  }
+  __syncthreads();
+
+  // ---- rewards: per-state pieces in LDS (as the register kernel) ----
+  double pbase, ub;
+  {
+    w = xs_draw(P, cand, XS_POS, 0);
+    pbase = 0.2 * xs_expo(xv_u53(w.x, w.y));
+    ub = xv_u53(w.z, w.w);
+  }
+  if (tid < S) {
+    const int j = tid;
+    xv_u32x4 q4 = xs_draw(P, cand, XS_POT, 0);
+    const double base = xv_u53(q4.x, q4.y) < 0.5 ? 0.0 : xs_clip(xs_expo(xv_u53(q4.z, q4.w)), 0.20, 5.0);
+    q4 = xs_draw(P, cand, XS_POT, 1);
+    double box = -base + 2.0 * base * xv_u53(q4.x, q4.y);
+    if (box < 0.0) box = 0.0;
+    const int n_items = 1 + (int)(q4.z % 3u);
+    const double scale = box / sqrt((double)n_items);
+    const double x = (double)j / (double)(2 * S);
+    double pj = 0.0;
+    for (int k = 0; k <= n_items; ++k) {
+      double za, zb, order = 0.0;
+      q4 = xs_draw(P, cand, XS_POT, 2u + (uint32_t)k);
+      xs_normal2(q4.x, q4.y, za, zb);
+      const double ca = za * (xs_expo(xs_u32(q4.z)) * scale), cb = zb * (xs_expo(xs_u32(q4.w)) * scale);
+      if (k > 0) {
+        double zo, zd;
+        q4 = xs_draw(P, cand, XS_POT, 8u + (uint32_t)k);
+        xs_normal2(q4.y, q4.z, zo, zd);
+        order = (double)(1 + (int)(q4.x % 5u)) + zo;
+      }
+      pj += ca * sin(order * x) + cb * cos(order * x);
+    }
+    pot[j] = pj;
+    q4 = xs_draw(P, cand, XS_POSN, (uint32_t)(j >> 2));
+    double pdf = xs_normal_of(q4, j & 3);
+    pdf = pdf > 0.0 ? pdf : 0.0;
+    if (j == S - 1) pdf += 0.20;
+    rpos[j] = pdf * pbase;
+    q4 = xs_draw(P, cand, XS_POSU, (uint32_t)(j >> 2));
+    const double u = -0.30 + 0.60 * xs_u32(xs_word(q4, j & 3));
+    npos[j] = pitm[j] ? 0.0 : (u > 0.0 ? u : 0.0) * pbase;
+    bonus[j] = (j == S - 1) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  double cdf_j = 0.0, c_all = 0.0;
+  for (int i = 0; i < S; ++i) {
+    c_all += rpos[i];
+    if (i == tid) cdf_j = c_all;
+  }
+  __syncthreads();
+  if (tid < S) {
+    const double baseline = 0.1 * c_all + ub * (0.9 * c_all - 0.1 * c_all);
+    rpos[tid] = pitm[tid] ? 0.0 : cdf_j - baseline;
+  }
+  double r_step = 0.0, sbase;
+  {
+    w = xs_draw(P, cand, XS_SA, 0);
+    sbase = xs_clip(0.05 * xs_expo(xv_u53(w.x, w.y)), 0.0, 0.10);
+    double zs, zd;
+    w = xs_draw(P, cand, XS_STEP, 0);
+    xs_normal2(w.x, w.y, zs, zd);
+    if (goal) r_step = (zs < 0.0 ? zs : 0.0) * 0.01;
+    else if (n_se > 0) r_step = (zs > 0.0 ? zs : 0.0) * 0.01;
+  }
+  double rsa[R], nsa[R], pot_s[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int r = k * BD + tid;
+    rsa[k] = 0.0; nsa[k] = 0.0; pot_s[k] = 0.0;
+    if (r < SA) {
+      xsb_sa_pieces(P, cand, sbase, r, rsa[k], nsa[k]);
+      pot_s[k] = pot[r / A];
+    }
+  }
+  __syncthreads();
+
+  // expected reward of this thread's rows under the current bonus: the chain of the register kernel over the row's band
+  auto expected = [&](double (&er)[R]) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int r = k * BD + tid;
+      double e = 0.0;
+      if (r < SA) {
+        const double* col = Tt + ((size_t)(r >> 6) * S) * 64 + (r & 63);
+        for (int j = wf[k]; j < wl[k]; ++j) {
+          double rr = (((pot_s[k] - pot[j]) + rpos[j]) + rsa[k]) + r_step;
+          rr += bonus[j];
+          e = fma(col[(size_t)j * 64], rr, e);
+        }
+      }
+      er[k] = e;
+    }
+  };
+
+  // ---- terminal rewards repaired against the value function ----
+  const int last_live = goal ? S - 2 : S - 1;
+  int status = 1, repair_rounds = 0;
+  int sweeps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double q[R], er[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) q[k] = 0.0;
+  for (int tries = 0; tries < 5; ++tries) {
+    expected(er);
+    const int sw = xsb_value_iteration<R>(Tt, S, A, SA, 0.99, true, er, q, wf, wl, Qs, Vs, part, n_waves);
+    sweeps[tries] = sw;
+    repair_rounds = tries + 1;
+    if (sw >= XS_MAX_SWEEPS) { status = 4; break; }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int r = k * BD + tid;
+      if (r < SA) Qs[r] = q[k];
+    }
+    __syncthreads();
+    if (tid < S) {
+      double v = Qs[tid * A];
+      for (int b = 1; b < A; ++b) v = Qs[tid * A + b] > v ? Qs[tid * A + b] : v;
+      vstate[tid] = v;
+    }
+    __syncthreads();
+    double vmin_live = 0.0, vmax_s0 = 0.0, bmin = bonus[0];
+    bool first_live = true;
+    for (int j = 0; j < S; ++j) {
+      const double v = vstate[j];
+      if (!pitm[j] && (first_live || v < vmin_live)) { vmin_live = v; first_live = false; }
+      if (bonus[j] < bmin) bmin = bonus[j];
+    }
+    for (int k = 0; k < n_s0; ++k) {
+      const double v = vstate[s0_id[k]];
+      if (k == 0 || v > vmax_s0) vmax_s0 = v;
+    }
+    w = xs_draw(P, cand, XS_REPAIR, (uint32_t)tries);
+    const double pit_gap = bmin - vmin_live + 1.0;
+    const double goal_gap = vmax_s0 - vstate[last_live] + (2.0 + 3.0 * xv_u53(w.x, w.y));
+    if (pit_gap <= 0.0 && goal_gap <= 0.0) { status = 0; break; }
+    __syncthreads();
+    if (tid < S) {
+      double bj = bonus[tid];
+      if (pit_gap > 0.0 && pitm[tid] && !(goal && tid == S - 1)) bj -= pit_gap + (1.0 + 9.0 * xs_u32(w.z));
+      if (goal_gap > 0.0 && tid == S - 1) {
+        const double extra = 1.0 + 9.0 * xs_u32(w.w);
+        const double lift = 2.0 * goal_gap > extra ? 2.0 * goal_gap : extra;
+        bj += goal ? lift : (1.0 - 0.99) * lift;
+      }
+      bonus[tid] = bj;
+    }
+    __syncthreads();
+  }
+
+  // ---- acceptance ----
+  double gini = 0.0, ent = 0.0, gap_min = 0.0;
+  if (status == 0) {
+    const double g2 = exp2(-1.0 / (double)S);
+    expected(er);
+    double qo[R], qr[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) { qo[k] = 0.0; qr[k] = 0.0; }
+    sweeps[5] = xsb_value_iteration<R>(Tt, S, A, SA, g2, true, er, qo, wf, wl, Qs, Vs, part, n_waves);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int r = k * BD + tid;
+      if (r < SA) Qs[r] = qo[k];
+    }
+    __syncthreads();
+    if (tid < S) {
+      double v = Qs[tid * A];
+      for (int b = 1; b < A; ++b) if (Qs[tid * A + b] > v) v = Qs[tid * A + b];
+      vstate[tid] = v;
+    }
+    __syncthreads();
+    // occupancy matrix: row s = the greedy action's row of T (first maximum), or the start distribution for terminal states
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int r = k * BD + tid;
+      if (r < SA) {
+        const int s = r / A, a = r - s * A;
+        int g_s = 0;
+        double v = Qs[s * A];
+        for (int b = 1; b < A; ++b) if (Qs[s * A + b] > v) { v = Qs[s * A + b]; g_s = b; }
+        if (a == g_s) {
+          const double* col = Tt + ((size_t)(r >> 6) * S) * 64 + (r & 63);
+          for (int j = 0; j < S; ++j) {
+            double pj = col[(size_t)j * 64];
+            if (pitm[s]) {
+              pj = 0.0;
+              for (int kk = 0; kk < n_s0; ++kk) if (j == s0_id[kk]) pj = s0_p[kk];
+            }
+            Pm[s * S + j] = pj;
+          }
+        }
+      }
+    }
+    double vo_s0[3];
+    for (int k = 0; k < 3; ++k) vo_s0[k] = k < n_s0 ? vstate[s0_id[k]] : 0.0;
+    __syncthreads();
+    sweeps[6] = xsb_value_iteration<R>(Tt, S, A, SA, g2, false, er, qr, wf, wl, Qs, Vs, part, n_waves);
+    if (sweeps[5] >= XS_MAX_SWEEPS || sweeps[6] >= XS_MAX_SWEEPS) status = 4;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int r = k * BD + tid;
+      if (r < SA) Qs[r] = qr[k];
+    }
+    __syncthreads();
+    const double scale = (1.0 - g2) * max_steps;
+    for (int k = 0; k < n_s0; ++k) {
+      const int s0 = s0_id[k];
+      double vr = Qs[s0 * A];
+      for (int b = 1; b < A; ++b) vr = Qs[s0 * A + b] > vr ? Qs[s0 * A + b] : vr;
+      const double gap = vo_s0[k] * scale - vr * scale;
+      if (k == 0 || gap < gap_min) gap_min = gap;
+    }
+    if (status == 0 && gap_min < 2.0) status = 2;
+    if (status == 0) {
+      const int K = (int)log2(max_steps) + 1;
+      double* Pa = Pm;
+      double* Pb = Pm + (size_t)S * S;
+      for (int rep = 0; rep < K; ++rep) {
+        __syncthreads();
+        for (int e = tid; e < S * S; e += BD) {
+          const int i = e / S, j = e - i * S;
+          double acc = 0.0;
+          for (int k = 0; k < S; ++k) acc = fma(Pa[i * S + k], Pa[k * S + j], acc);
+          Pb[e] = acc;
+        }
+        double* t = Pa; Pa = Pb; Pb = t;
+      }
+      __syncthreads();
+      for (int k = 0; k < n_s0; ++k) {
+        const double* row = Pa + s0_id[k] * S;
+        double s2 = 0.0, h = 0.0;
+        for (int j = 0; j < S; ++j) {
+          const double p = row[j] + 1.0e-12;
+          s2 += p * p;
+          h += p * log(p);
+        }
+        const double gk = 1.0 - s2, ek = -h / log((double)S);
+        if (k == 0 || gk < gini) gini = gk;
+        if (k == 0 || ek < ent) ent = ek;
+      }
+      if (!(gini > 0.70 && ent > 0.35)) status = 3;
+    }
+  }
+
+  // ---- outputs ----
+  if (tid == 0) {
+    P.status[ci] = status;
+    if (P.info) {
+      xv_anymdp_cand_info& o = P.info[ci];
+      o.status = status; o.goal = goal; o.n_s0 = n_s0; o.repair_rounds = repair_rounds;
+      for (int k = 0; k < 4; ++k) { o.s0[k] = k < n_s0 ? s0_id[k] : 0; o.s0_prob[k] = k < n_s0 ? s0_p[k] : 0.0; }
+      for (int k = 0; k < 8; ++k) o.sweeps[k] = sweeps[k];
+      o.max_steps = max_steps; o.gini = gini; o.ent = ent; o.gap_min = gap_min;
+    }
+  }
+  if (P.info && tid < S) {
+    P.info[ci].band_lo[tid] = bandlo[tid];
+    P.info[ci].band_hi[tid] = bandhi[tid];
+    P.info[ci].s_e[tid] = (uint8_t)pitm[tid];
+  }
+  if (P.transition || P.reward || P.noise) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int r = k * BD + tid;
+      if (r < SA) {
+        const size_t o = ((size_t)ci * SA + r) * S;
+        const double* col = Tt + ((size_t)(r >> 6) * S) * 64 + (r & 63);
+        for (int j = 0; j < S; ++j) {
+          if (P.transition) P.transition[o + j] = col[(size_t)j * 64];
+          if (P.reward) {
+            const double rr = (((pot_s[k] - pot[j]) + rpos[j]) + rsa[k]) + r_step;
+            P.reward[o + j] = rr + bonus[j];
+          }
+          if (P.noise) P.noise[o + j] = npos[j] + nsa[k];
+        }
+      }
+    }
+  }
+  if (tid == 0 && (P.state_map || P.info)) {
+    int* sm = reinterpret_cast<int*>(Qs);
+    for (int i = 0; i < S; ++i) sm[i] = i;
+    for (int i = S - 1; i >= 1; --i) {
+      const xv_u32x4 q4 = xs_draw(P, cand, XS_PERM, (uint32_t)(i >> 2));
+      const int j = (int)(xs_word(q4, i & 3) % (uint32_t)(i + 1));
+      const int t = sm[i]; sm[i] = sm[j]; sm[j] = t;
+    }
+    for (int i = 0; i < S; ++i) {
+      if (P.info) P.info[ci].state_map[i] = sm[i];
+      if (P.state_map && status == 0) P.state_map[(size_t)ci * S + i] = sm[i];
+    }
+  }
+  if (status != 0 || P.rows == nullptr) return;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int r = k * BD + tid;
+    if (r >= SA) continue;
+    const double* col = Tt + ((size_t)(r >> 6) * S) * 64 + (r & 63);
+    double* rec = P.rows + ((size_t)ci * SA + r) * (size_t)P.row_lines * 16;
+    for (int e = 0; e < P.row_lines * 16; ++e) rec[e] = 0.0;
+    double tot = 0.0;
+    for (int j = 0; j < S; ++j) tot += col[(size_t)j * 64];
+    const bool zero_row = tot == 0.0;
+    double c = 0.0;
+    const int n_ent = (P.row_lines - 1) * 7;
+    for (int jj = 0; jj < S; ++jj) {
+      c += col[(size_t)jj * 64];
+      const double cdf = zero_row ? 1.0 : c / tot;
+      const double rr = ((((pot_s[k] - pot[jj]) + rpos[jj]) + rsa[k]) + r_step) + bonus[jj];
+      const float rf = (float)rr, nf = (float)(npos[jj] + nsa[k]);
+      double* ent2 = rec + 16 * (1 + jj / 7) + 2 * (jj % 7);
+      ent2[0] = cdf;
+      ent2[1] = __hiloint2double((int)__float_as_uint(nf), (int)__float_as_uint(rf));
+    }
+    for (int j = S; j < n_ent; ++j) rec[16 * (1 + j / 7) + 2 * (j % 7)] = 2.0;
+  }
+  if (tid < (S + 63) / 64) {
+    uint64_t m = 0;
+    for (int j = 0; j < 64 && 64 * tid + j < S; ++j) if (pitm[64 * tid + j]) m |= 1ull << j;
+    P.term_mask[(size_t)ci * ((S + 63) / 64) + tid] = m;
+  }
+  if (tid == 0) {
+    double c = 0.0, ctot = 0.0;
+    for (int k = 0; k < n_s0; ++k) ctot += s0_p[k];
+    for (int k = 0; k < P.s0_max; ++k) {
+      if (k < n_s0) {
+        c += s0_p[k];
+        P.s0_cdf[(size_t)ci * P.s0_max + k] = c / ctot;
+        P.s0_ids[(size_t)ci * P.s0_max + k] = s0_id[k];
+      } else {
+        P.s0_cdf[(size_t)ci * P.s0_max + k] = 1.0;
+        P.s0_ids[(size_t)ci * P.s0_max + k] = s0_id[n_s0 - 1];
+      }
+    }
+    P.max_steps[ci] = (int32_t)ceil(max_steps);
+  }
+}
+
 }  // namespace
 
 extern "C" int xv_anymdp_sample_tasks(xv_engine* e, uint64_t seed, int64_t cand_base, int n_cand, int S, int A, int s0_max,
@@ -606,9 +1195,11 @@ extern "C" int xv_anymdp_sample_tasks(xv_engine* e, uint64_t seed, int64_t cand_
                                       double* reward_noise, xv_anymdp_cand_info* info, int32_t* status) {
   XV_CHECK_ARG(e != nullptr && status != nullptr);
   XV_CHECK_ARG(n_cand > 0 && cand_base >= 0);
-  if (!(S >= 8 && S <= 64 && A >= 2 && A <= 64 && S * A <= 512)) {
-    xv_set_error("xv_anymdp_sample_tasks: the device sampler covers 8 <= S <= 64 with S * A <= 512 (got S = %d, A = %d); "
-                 "larger tasks: the seeded host sampler", S, A);
+  const bool small = S >= 8 && S <= 64 && A >= 2 && A <= 64 && S * A <= 512;
+  const bool big = !small && S > 16 && S <= 256 && A >= 2 && A <= 64 && S * A <= 4096;
+  if (!small && !big) {
+    xv_set_error("xv_anymdp_sample_tasks: the device sampler covers 8 <= S <= 64 with S * A <= 512 and S <= 256 with S * A <= 4096 "
+                 "(got S = %d, A = %d); larger tasks: the seeded host sampler", S, A);
     return XV_ERR_UNSUPPORTED;
   }
   XV_CHECK_ARG(s0_max >= 3 && s0_max <= 256);
@@ -620,6 +1211,44 @@ extern "C" int xv_anymdp_sample_tasks(xv_engine* e, uint64_t seed, int64_t cand_
   P.rows = static_cast<double*>(rows); P.state_map = state_map; P.term_mask = term_mask; P.s0_cdf = s0_cdf;
   P.s0_ids = s0_ids; P.max_steps = max_steps; P.transition = transition; P.reward = reward; P.noise = reward_noise;
   P.info = info; P.status = status;
+  if (big) {
+    // rows in a transposed global scratch (stream-ordered allocation: no synchronisation), R rows per thread
+    const int SA = S * A, n_rb = (SA + 63) / 64, R = (SA + 1023) / 1024;
+    const int threads = 64 * ((n_rb + R - 1) / R);
+    BigScratch X;
+    X.n_rb = n_rb; X.Tt = nullptr; X.Pm = nullptr;
+    const size_t tt_bytes = sizeof(double) * (size_t)n_cand * n_rb * 64 * S, pm_bytes = sizeof(double) * (size_t)n_cand * 2 * S * S;
+    hipError_t r = hipMallocAsync((void**)&X.Tt, tt_bytes, e->stream);
+    if (r == hipSuccess) r = hipMallocAsync((void**)&X.Pm, pm_bytes, e->stream);
+    if (r != hipSuccess) {
+      (void)hipGetLastError();
+      if (X.Tt) (void)hipFreeAsync(X.Tt, e->stream);
+      xv_set_error("xv_anymdp_sample_tasks: cannot allocate %.1f GiB of candidate scratch (lower n_cand)",
+                   (double)(tt_bytes + pm_bytes) / (double)(1ull << 30));
+      return XV_ERR_NOMEM;
+    }
+    const size_t lds = sizeof(double) * ((size_t)n_rb * 64 + 6 * (size_t)S + 16) + sizeof(int) * 3 * (size_t)S;
+#define XSB_LAUNCH(R_)                                                                                              \
+  do {                                                                                                              \
+    if (lds > 48 * 1024)                                                                                            \
+      XV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&anymdp_sampler_big_kernel<R_>),                    \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+    hipLaunchKernelGGL(anymdp_sampler_big_kernel<R_>, dim3(n_cand), dim3(threads), lds, e->stream, P, X);           \
+  } while (0)
+    if (R == 1) XSB_LAUNCH(1);
+    else if (R == 2) XSB_LAUNCH(2);
+    else if (R == 3) XSB_LAUNCH(3);
+    else XSB_LAUNCH(4);
+#undef XSB_LAUNCH
+    const hipError_t le = hipGetLastError();
+    (void)hipFreeAsync(X.Tt, e->stream);
+    (void)hipFreeAsync(X.Pm, e->stream);
+    if (le != hipSuccess) {
+      xv_set_error("xv_anymdp_sample_tasks: kernel launch failed: %s", hipGetErrorString(le));
+      return XV_ERR_HIP;
+    }
+    return XV_OK;
+  }
   const int threads = (S * A + 63) / 64 * 64;
   const int SP = S <= 16 ? 16 : (S <= 32 ? 32 : 64);
   const size_t lds = sizeof(double) * ((size_t)S * A + 6 * SP + 8 + 2 * (size_t)SP * SP) + sizeof(int) * 3 * SP;
