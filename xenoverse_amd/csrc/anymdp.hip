@@ -292,6 +292,10 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
     if (BK) {
       // the ONE line: bucket floor(u * NBK) of the row.  Iteration `it` serves envs 8*it .. 8*it+7 as below.
       const uint32_t bk = rowidx * (uint32_t)P.NBK + (uint32_t)(int)(u * (double)P.NBK);
+      constexpr int KC = BK == 2 ? 6 : 7;   // cuts per line
+      int cnt_own = 0;
+      float rx = 0.0f, ry = 0.0f;
+      uint32_t meta_own = 0;
       uint32_t li[8];
 #pragma unroll
       for (int it = 0; it < 8; ++it) li[it] = (uint32_t)__shfl((int)bk, it * 8 + g);
@@ -306,10 +310,6 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
 #pragma unroll
       for (int it = 0; it < 8; ++it) ue[it] = xv_shfl_f64(u, it * 8 + g);
       __builtin_amdgcn_sched_barrier(0);
-      constexpr int KC = BK == 2 ? 6 : 7;   // cuts per line
-      int cnt_own = 0;
-      float rx = 0.0f, ry = 0.0f;
-      uint32_t meta_own = 0;
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const unsigned long long m = __ballot(j < KC && xv_u2d(bv[it].x, bv[it].y) <= ue[it]);
