@@ -22,6 +22,11 @@
 static const size_t MAZE_LDS_CHUNK_MAX = 50176;   // 256 columns x (64 rows x 3 + 4) bytes: three workgroups per 160-KiB CU
 static inline int maze_rc_threads(int W) { return W <= 64 ? 64 : (W <= 128 ? 128 : 256); }
 #define MZ_TEX_PITCH 260   // 256 texels + 3 wrapped ones (+1 pad): the 4 y-taps of a filter row never wrap
+// Round 4: a second packed copy with PAIRS of filter rows interleaved — texel (x, y) at word ((x >> 1) * PITCH + y) * 2 +
+// (x & 1) — so that the four y-taps of rows 2m and 2m + 1 are 32 contiguous bytes and a 4 x 4 window lies in 2 (x even) or 3
+// such spans instead of 4 rows 1 KB apart.  The fp32 filter, which waits on its texture fetches, reads this copy (64 x 64:
+// 1.09 -> 0.98 ms, 256 x 256: 11.95 -> 11.24 ms); the exact filter, which is bound by fp64 issue and pays for the extra
+// selects (17.1 -> 18.0 ms at 256 x 256), keeps the row-major copy (profiles/r04_j_ab_tex_pairs.txt).
 
 // ray_caster_utils.py:11-25
 __device__ const float MZ_LANDMARK_RGB[XV_MAZE_LMAX][3] = {
@@ -551,6 +556,41 @@ __global__ __launch_bounds__(256) void maze_move_sort_kernel(MazeArgs P, const v
   if (valid && still) list[P.n_env - 1 - (base_s + __popcll(ms & below))] = e;
 }
 
+// The 16 packed texels of the 4 x 4 filter window, q[row xx + 1][tap yy + 1], rows ib - 1 .. ib + 2 (mod 256), taps
+// (jb - 1) & 255 ... + 3 (rows are padded: no wrap in y).
+template <bool PAIRS>
+__device__ __forceinline__ void mz_fetch_window(const void* __restrict__ texv, int ib, int jb, uint32_t (&q)[4][4]) {
+  const uint32_t* tb = static_cast<const uint32_t*>(texv);
+  const int ys = (jb - 1) & 255;
+  if (PAIRS) {
+  // spans of 8 words = {row 2m tap t, row 2m + 1 tap t : t = 0..3}.  x0 even: rows x0, x0 + 1 in span 0, x0 + 2, x0 + 3 in span
+  // 1; x0 odd: x0 is the odd row of span 0, x0 + 1, x0 + 2 fill span 1, x0 + 3 is the even row of span 2.  The third span
+  // of an even x0 is span 1 again (same address: no further request).
+  const int x0 = (ib - 1) & 255;
+  const int odd = x0 & 1;
+  const int p0 = x0 >> 1, p1 = ((x0 + 2) & 255) >> 1, p2 = ((x0 + 3) & 255) >> 1;
+  const uint4* s0 = reinterpret_cast<const uint4*>(tb + ((size_t)p0 * MZ_TEX_PITCH + ys) * 2);
+  const uint4* s1 = reinterpret_cast<const uint4*>(tb + ((size_t)p1 * MZ_TEX_PITCH + ys) * 2);
+  const uint4* s2 = reinterpret_cast<const uint4*>(tb + ((size_t)p2 * MZ_TEX_PITCH + ys) * 2);
+  const uint4 a0 = s0[0], b0 = s0[1], a1 = s1[0], b1 = s1[1], a2 = s2[0], b2 = s2[1];   // dword-aligned 16-byte loads
+  // row 0: span 0, member `odd`
+  q[0][0] = odd ? a0.y : a0.x; q[0][1] = odd ? a0.w : a0.z; q[0][2] = odd ? b0.y : b0.x; q[0][3] = odd ? b0.w : b0.z;
+  // row 1: even -> span 0 member 1; odd -> span 1 member 0
+  q[1][0] = odd ? a1.x : a0.y; q[1][1] = odd ? a1.z : a0.w; q[1][2] = odd ? b1.x : b0.y; q[1][3] = odd ? b1.z : b0.w;
+  // row 2: span 1, member `odd`
+  q[2][0] = odd ? a1.y : a1.x; q[2][1] = odd ? a1.w : a1.z; q[2][2] = odd ? b1.y : b1.x; q[2][3] = odd ? b1.w : b1.z;
+  // row 3: even -> span 1 member 1; odd -> span 2 member 0
+  q[3][0] = odd ? a2.x : a1.y; q[3][1] = odd ? a2.z : a1.w; q[3][2] = odd ? b2.x : b1.y; q[3][3] = odd ? b2.z : b1.w;
+  } else {
+#pragma unroll
+    for (int xx = 0; xx < 4; ++xx) {
+      const int xv = (ib - 1 + xx) & 255;
+      const uint4 v = *reinterpret_cast<const uint4*>(tb + (size_t)xv * MZ_TEX_PITCH + ys);   // dword-aligned 16-byte load
+      q[xx][0] = v.x; q[xx][1] = v.y; q[xx][2] = v.z; q[xx][3] = v.w;
+    }
+  }
+}
+
 // interpolate, ray_caster_utils.py:123-140 (see oracle mz_interpolate for the typing).
 // PACKED: the texture is the engine's RGBX-byte copy with padded rows: the four y-taps of filter row x are the
 // 16 contiguous bytes at [x & 255][(jb - 1) & 255 ...], one global_load_dwordx4 instead of 12 dword loads.  Texel
@@ -574,18 +614,14 @@ __device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, do
     const double b = ((double)(jb + yy) - j) * py;
     bb[yy + 1] = b * b;
   }
+  uint32_t qw[4][4];
+  if (PACKED) mz_fetch_window<false>(texv, ib, jb, qw);
 #pragma unroll
   for (int xx = -1; xx < 3; ++xx) {
     const int x = ib + xx;
     const double a = ((double)x - i) * px;
     const double aa = a * a;
     const int xv = x & 255;   // python's non-negative x % 256
-    uint32_t q[4];
-    if (PACKED) {
-      const uint32_t* row = static_cast<const uint32_t*>(texv) + (size_t)xv * MZ_TEX_PITCH + ((jb - 1) & 255);
-      const uint4 v = *reinterpret_cast<const uint4*>(row);   // dword-aligned 16-byte load
-      q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
-    }
 #pragma unroll
     for (int yy = -1; yy < 3; ++yy) {
       const double dist = aa + bb[yy + 1];
@@ -593,7 +629,7 @@ __device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, do
       sum_wht += wht;
       float t0, t1, t2;
       if (PACKED) {
-        const uint32_t p = q[yy + 1];
+        const uint32_t p = qw[xx + 1][yy + 1];
         t0 = (float)(p & 0xFFu); t1 = (float)((p >> 8) & 0xFFu); t2 = (float)((p >> 16) & 0xFFu);
       } else {
         const float* tp = static_cast<const float*>(texv) + ((size_t)xv * 256 + ((jb + yy) & 255)) * 3;
@@ -626,23 +662,19 @@ __device__ __forceinline__ void mz_interpolate_f32(const void* __restrict__ texv
     const float b = (fj + (float)yy) * p;
     bb[yy + 1] = b * b;
   }
+  uint32_t qw[4][4];
+  if (PACKED) mz_fetch_window<true>(texv, ib, jb, qw);   // the pair-interleaved copy
 #pragma unroll
   for (int xx = -1; xx < 3; ++xx) {
     const float a = (fi + (float)xx) * p, aa = a * a;
     const int xv = (ib + xx) & 255;
-    uint32_t q[4];
-    if (PACKED) {
-      const uint32_t* row = static_cast<const uint32_t*>(texv) + (size_t)xv * MZ_TEX_PITCH + ((jb - 1) & 255);
-      const uint4 v = *reinterpret_cast<const uint4*>(row);
-      q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
-    }
 #pragma unroll
     for (int yy = -1; yy < 3; ++yy) {
       const float wht = fmaxf(fmaf(-(aa + bb[yy + 1]), k10, 1.0f), 0.01f);
       sw += wht;
       float t0, t1, t2;
       if (PACKED) {
-        const uint32_t px = q[yy + 1];
+        const uint32_t px = qw[xx + 1][yy + 1];
         t0 = (float)(px & 0xFFu); t1 = (float)((px >> 8) & 0xFFu); t2 = (float)((px >> 16) & 0xFFu);
       } else {
         const float* tp = static_cast<const float*>(texv) + ((size_t)xv * 256 + ((jb + yy) & 255)) * 3;
@@ -655,13 +687,24 @@ __device__ __forceinline__ void mz_interpolate_f32(const void* __restrict__ texv
   out[0] = (double)(s0 * inv); out[1] = (double)(s1 * inv); out[2] = (double)(s2 * inv);
 }
 
-// texel (x, y) of library entry k -> packed RGBX word at [k][x][y], rows padded with 3 wrapped texels
+// texel (x, y) of library entry k -> packed RGBX word, rows padded with 3 wrapped texels: at [k][x][y], or — PAIRS — at
+// [k][x >> 1][y][x & 1]
+template <bool PAIRS>
 __global__ __launch_bounds__(256) void maze_pack_tex_kernel(const float* tex, uint32_t* pk, int n_tex) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)n_tex * 256 * MZ_TEX_PITCH;
   if (idx >= total) return;
-  const int y = (int)(idx % MZ_TEX_PITCH);
-  const size_t kx = idx / MZ_TEX_PITCH;
+  int y;
+  size_t kx;
+  if (PAIRS) {
+    const size_t per = (size_t)256 * MZ_TEX_PITCH, k = idx / per, w = idx % per;
+    const int b = (int)(w & 1), m = (int)((w >> 1) / MZ_TEX_PITCH);
+    y = (int)((w >> 1) % MZ_TEX_PITCH);
+    kx = k * 256 + (size_t)(2 * m + b);
+  } else {
+    y = (int)(idx % MZ_TEX_PITCH);
+    kx = idx / MZ_TEX_PITCH;
+  }
   const float* tp = tex + (kx * 256 + (size_t)(y & 255)) * 3;
   pk[idx] = (uint32_t)tp[0] | ((uint32_t)tp[1] << 8) | ((uint32_t)tp[2] << 16);
 }
@@ -702,9 +745,9 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
   const int8_t* walls = P.T.walls + (size_t)t * NG * NG;
   const int8_t* transp = P.T.landmarks + (size_t)t * NG * NG;
   const int32_t* texts = P.T.texts + (size_t)t * NG * NG;
-  const void* ground = PACKED ? (const void*)(P.pk_grounds + (size_t)in[3] * 256 * MZ_TEX_PITCH)
+  const void* ground = PACKED ? (const void*)((F32 ? P.pp_grounds : P.pk_grounds) + (size_t)in[3] * 256 * MZ_TEX_PITCH)
                               : (const void*)(P.T.tex_grounds + (size_t)in[3] * 256 * 256 * 3);
-  const void* ceil_t = PACKED ? (const void*)(P.pk_ceilings + (size_t)in[4] * 256 * MZ_TEX_PITCH)
+  const void* ceil_t = PACKED ? (const void*)((F32 ? P.pp_ceilings : P.pk_ceilings) + (size_t)in[4] * 256 * MZ_TEX_PITCH)
                               : (const void*)(P.T.tex_ceilings + (size_t)in[4] * 256 * 256 * 3);
   const double pe0 = FINAL ? P.fin_pose[e] : P.pos[e];
   const double pe1 = FINAL ? P.fin_pose[N + e] : P.pos[N + e];
@@ -828,7 +871,7 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
     int v_s = (int)((half_v - (double)top_v) / pixel_size), v_e = (int)((half_v + (double)bot_v) / pixel_size);
     v_s = v_s < 0 ? 0 : v_s;
     v_e = v_e > H ? H : v_e;
-    const void* wt = PACKED ? (const void*)(P.pk_walls + (size_t)text_id * 256 * MZ_TEX_PITCH)
+    const void* wt = PACKED ? (const void*)((F32 ? P.pp_walls : P.pk_walls) + (size_t)text_id * 256 * MZ_TEX_PITCH)
                             : (const void*)(P.T.tex_walls + (size_t)text_id * 256 * 256 * 3);
     const double eff_ps_w = eff_stale * pixel_size / l_focal;
     float wall_ti;
@@ -1024,17 +1067,24 @@ extern "C" int xv_maze_create(xv_engine* e, int n_env, int n_task, int NG, int n
     XV_HIP(hipStreamSynchronize(e->stream));
     XV_HIP(hipFree(d_flag));
     if (h_flag == 0) {
-      uint32_t* pk[3] = {nullptr, nullptr, nullptr};
+      uint32_t* pk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // row-major copies, then pair-interleaved
       bool ok = true;
-      for (int k = 0; k < 3 && ok; ++k) {
-        const size_t words = (size_t)cnt[k] * 256 * MZ_TEX_PITCH + 4;
+      for (int k = 0; k < 6 && ok; ++k) {
+        const size_t words = (size_t)cnt[k % 3] * 256 * MZ_TEX_PITCH + 4;
         ok = hipMalloc(&pk[k], words * sizeof(uint32_t)) == hipSuccess;
-        if (ok)
-          hipLaunchKernelGGL(maze_pack_tex_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, e->stream,
-                             libs[k], pk[k], cnt[k]);
+        if (ok) {
+          const dim3 grid((unsigned)((words + 255) / 256)), block(256);
+          if (k < 3) hipLaunchKernelGGL(maze_pack_tex_kernel<false>, grid, block, 0, e->stream, libs[k], pk[k], cnt[k]);
+          else hipLaunchKernelGGL(maze_pack_tex_kernel<true>, grid, block, 0, e->stream, libs[k - 3], pk[k], cnt[k - 3]);
+        }
       }
-      if (ok) { a.pk_walls = pk[0]; a.pk_grounds = pk[1]; a.pk_ceilings = pk[2]; }
-      else { for (int k = 0; k < 3; ++k) if (pk[k]) (void)hipFree(pk[k]); (void)hipGetLastError(); }
+      if (ok) {
+        a.pk_walls = pk[0]; a.pk_grounds = pk[1]; a.pk_ceilings = pk[2];
+        a.pp_walls = pk[3]; a.pp_grounds = pk[4]; a.pp_ceilings = pk[5];
+      } else {
+        for (int k = 0; k < 6; ++k) if (pk[k]) (void)hipFree(pk[k]);
+        (void)hipGetLastError();
+      }
     }
   }
   // ray-caster LDS chunk: the whole column if it fits in MAZE_LDS_CHUNK_MAX, else a multiple of 16 rows
@@ -1058,8 +1108,8 @@ extern "C" int xv_maze_destroy(xv_maze* h) {
   (void)hipStreamSynchronize(h->eng->stream);
   MazeArgs& a = h->a;
   void* ps[] = {a.pos, a.ori, a.grid, a.steps, a.cmd_idx, a.cmd_age, a.need_reset, a.collision, a.fin_pose,
-                a.fin_cmd, a.fin_flag, (void*)a.pk_walls, (void*)a.pk_grounds, (void*)a.pk_ceilings, h->move_list,
-                h->move_count};
+                a.fin_cmd, a.fin_flag, (void*)a.pk_walls, (void*)a.pk_grounds, (void*)a.pk_ceilings, (void*)a.pp_walls,
+                (void*)a.pp_grounds, (void*)a.pp_ceilings, h->move_list, h->move_count};
   for (void* p : ps) if (p) (void)hipFree(p);
   delete h;
   return XV_OK;

@@ -25,6 +25,10 @@ struct MazeArgs {
   const uint32_t* pk_walls;
   const uint32_t* pk_grounds;
   const uint32_t* pk_ceilings;
+  // the same texels with PAIRS of filter rows interleaved ([n][128][MZ_TEX_PITCH][2]): what the fp32 filter fetches (round 4)
+  const uint32_t* pp_walls;
+  const uint32_t* pp_grounds;
+  const uint32_t* pp_ceilings;
   // pose of envs that ended this step, kept for the optional final frame
   double* fin_pose;  // [3][n_env]
   int32_t* fin_cmd;  // [n_env]
