@@ -628,7 +628,9 @@ def main():
             traffic, traffic_src = (None, None) if selftest else pmc_traffic(n_env, n_task, search)
             floor = floor_probe()
             lines = {"bucket": 1, "fence": 2}.get(search)
-            floor_us = floor["coop_lines_us"].get(lines) if lines else None
+            # the bare chain was measured on tables that miss every cache: it is the floor of config 2a (one task per env),
+            # not of shared tasks whose lines are cache hits (2b runs under it)
+            floor_us = floor["coop_lines_us"].get(lines) if (lines and n_task == n_env) else None
             exchange = gather_note if timeout_note is None else gather_note + "; " + timeout_note
             out = {
                 "metric": "env-steps/sec (whole node), anymdp |S|=64 |A|=8, 65k envs/GPU",
@@ -662,7 +664,7 @@ def main():
                              # chain of `dependent_lines` random lines: `floor_us` is that chain measured bare on this box class
                              # (scripts/devtools/floor_probe.py), `lines_per_s` against the measured random-line rate
                              "primary": ("frac_traffic" if traffic is not None and traffic < algo else
-                                         ("frac" if traffic is not None else "frac_of_floor")),
+                                         ("frac" if (traffic is not None or floor_us is None) else "frac_of_floor")),
                              "dependent_lines": lines, "floor_us": floor_us, "frac_of_floor": None if floor_us is None else floor_us / kern_us,
                              "empty_launch_us": floor["empty_launch_us"], "floor_source": floor["source"],
                              "lines_per_s": None if lines is None else lines * n_env / (kern_us * 1e-6),

@@ -64,10 +64,22 @@ data = teacher_rollout(menv, agent, T=300)
 print("maze teacher: goals reached per env in 300 steps: %.2f" % ((data["reward"] > 0.1).sum().item() / 256))
 menv.close()
 
-# 6. memory for speed: one table line per AnyMDP step (identical results)
-env = AnyMDPVecEnv(num_envs=4096, seed=0)
+# 6. memory for speed: one table line per AnyMDP step (identical results).  "auto" asks the engine's census first and builds
+#    the bucket lines only when its AUTO rule would use them
+env = AnyMDPVecEnv(num_envs=4096, seed=0, copy=False)
 env.set_task(tasks)
-env.set_search("bucket")
-env.reset()
+env.set_search("auto", n_bucket=16)
+print("search in effect:", env.effective_search, "| share of draws the lines cannot answer: %.1e" % env.bucket_census()["p_fallback"])
+obs, _ = env.reset()
 print("bucket search:", tuple(env.rollout(torch.zeros((16, 4096), dtype=torch.int32, device=env.device))["obs"].shape))
+
+# 7. the closed loop policy -> step at kernel rate: captured once in a torch.cuda.graph, replayed with one launch per 8 steps
+#    (same trajectory as the eager calls, bit for bit)
+loop = env.capture(lambda o: (o + 1) % 4, obs, unroll=8)
+ret = 0.0
+for _ in range(25):
+    obs, reward, terminated, truncated, info = loop.replay()       # the 5-tuple of the last of the 8 steps (static buffers)
+    ret += reward.mean().item()
+print("captured loop: %d steps replayed, mean reward of the sampled steps %.4f" % (loop.steps_replayed, ret / 25))
+loop.close()
 env.close()

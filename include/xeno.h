@@ -268,7 +268,7 @@ int xv_anymdp_step_tokens_injected(xv_anymdp* h, const int32_t* action, const do
  *           are practically never drawn) sends the draw's wave through the FENCE path for that step.  Identical
  *           results; costs n_task * S * A * n_bucket * 128 bytes of HBM.
  *   AUTO    (round 4) BUCKET when the lines are built and their census (below) expects no more draws per launch that a
- *           line cannot answer than `auto_limit` (0.5 when the rows miss every cache, 0.1 when the fence lines of all
+ *           line cannot answer than `auto_limit` (0.5 when the rows miss every cache, 0.2 when the fence lines of all
  *           tasks stay cache resident: there the fence search is nearly as fast and a fall-back costs relatively more),
  *           else FENCE when available, else BINARY: xv_anymdp_effective_search tells. */
 #define XV_ANYMDP_SEARCH_BUCKET 4

@@ -446,6 +446,9 @@ def bench_python_loop(args, n=65536, n_task=1024):
         def it():
             st["obs"] = env.step(policy(st["obs"]))[0]
         out["eager copy=%s" % copy] = timed(it, steps, 20)
+        if not copy:      # without the infos that need a launch of their own (`steps`, the `_final_obs` mask)
+            env.lean_infos = True
+            out["eager copy=False lean_infos"] = timed(it, steps, 20)
         env.close()
     for unroll in (1, 8, 32):
         env = _synth_anymdp_env(n, n_task, copy=False)

@@ -165,7 +165,7 @@ class AnyMDPVecEnv(VectorEnv):
         "bucket": builds n_task * S * A * n_bucket * 128 bytes of bucket lines (once; default 32 buckets) and makes a step
                   one table line in one dependent level; raises if they do not fit.
         "auto":   the engine decides per launch: the bucket search when its lines are built AND their census expects no more
-                  draws per launch that a line cannot answer than `auto_limit` (0.5; 0.1 for cache-resident tables), else the fence search (two dependent lines), else
+                  draws per launch that a line cannot answer than `auto_limit` (0.5; 0.2 for cache-resident tables), else the fence search (two dependent lines), else
                   the per-lane binary search.  With n_bucket given, the lines are built first when — and only when —
                   the census (taken without allocating anything) says AUTO would use them and they fit the free memory.
         `effective_search` names what runs; `bucket_census()` has the numbers."""

@@ -1331,11 +1331,11 @@ static inline void anymdp_bind_rng(xv_anymdp* h, uint64_t ticks, bool advance = 
 // census says a launch of this batch size rarely meets a draw they cannot answer: one such draw sends its wave, and with
 // it the launch, through three dependent lines instead of one.  With lam = expected such draws per launch a launch costs
 // t_bucket + (1 - exp(-lam)) * penalty against t_fence; measured on config 2 (65,536 envs, S = 64): rows that miss every
-// cache (one task per env: 4 GiB of fence lines) 5.4 us vs 7.2 us with a penalty of ~4 us -> the bucket search wins up to
-// lam ~ 0.7; rows whose fence lines stay cache resident (1,024 shared tasks: 64 MiB) 4.6 vs 4.9 us, penalty ~2.5 us ->
-// up to lam ~ 0.13.  Thresholds with a margin (XV_ANYMDP_AUTO_FALLBACKS_*); the fence lines count as cache resident up to
-// half of the 256 MB Infinity Cache.
-#define XV_ANYMDP_AUTO_FALLBACKS_CACHED 0.1
+// cache (one task per env: 4 GiB of fence lines) 5.0-5.4 us vs 7.0-7.2 us with a penalty of ~4 us -> the bucket search wins up
+// to lam ~ 0.7; rows whose fence lines stay cache resident (1,024 shared tasks: 64 MiB) 4.6 vs 4.8-5.1 us with a penalty of
+// ~2 us (the synthetic 2b tasks, lam = 0.135, run 4.63 vs 5.12 us fallbacks included) -> up to lam ~ 0.2-0.3.  Thresholds with
+// a margin (XV_ANYMDP_AUTO_FALLBACKS_*); the fence lines count as cache resident up to half of the 256 MB Infinity Cache.
+#define XV_ANYMDP_AUTO_FALLBACKS_CACHED 0.2
 #define XV_ANYMDP_AUTO_FALLBACKS_HBM 0.5
 static inline double anymdp_auto_fallback_limit(const xv_anymdp* h) {
   const double fence_bytes = (double)h->a.n_task * h->a.S * h->a.A * 128.0;
