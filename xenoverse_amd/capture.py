@@ -60,6 +60,10 @@ class CapturedLoop(object):
                     e.tick_batch(False)
         finally:
             for e, st in zip(self.engines, orig):
+                try:
+                    e.tick_batch(False)      # a capture that failed half way must not leave the batch open (no-op when closed)
+                except Exception:
+                    pass
                 e.set_stream(st)
         cur.wait_stream(side)
         if not self._same_memory(out[0], obs):
