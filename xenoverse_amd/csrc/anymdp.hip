@@ -863,8 +863,14 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_kernel(AnyMDPArgs P, AnyM
 // One 128-byte line per env, read by the 8 lanes of the env's group: iteration `it` serves envs 8 it .. 8 it + 7, lanes
 // 8 q .. 8 q + 7 read the 8 units of the line of env 8 it + q.  issue() only requests; the resolve functions wait and
 // hand each owner lane its result, so that independent work can be placed under the latency in between.
+#ifndef XV_ANYMDP_COOP_PRE
+#define XV_ANYMDP_COOP_PRE 1   // the uniforms travel to the reader lanes right behind the line requests (under their latency), not
+#endif                         // inside the resolve loops (A/B: profiles/r04_k_*)
 struct AnyMDPCoopLine {
   uint4 bv[8];
+#if XV_ANYMDP_COOP_PRE
+  double ue[8];
+#endif
   __device__ __forceinline__ void issue(const uint4* base, uint32_t line, int lane) {
     const int g = lane >> 3, j = lane & 7;
 #pragma unroll
@@ -872,6 +878,21 @@ struct AnyMDPCoopLine {
       const uint32_t li = (uint32_t)__shfl((int)line, it * 8 + g);
       bv[it] = base[(size_t)li * 8 + j];
     }
+  }
+  // the env's uniform to the 8 lanes that hold its line: call right after issue*()
+  __device__ __forceinline__ void send(double u, int lane) {
+#if XV_ANYMDP_COOP_PRE
+    const int g = lane >> 3;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) ue[it] = xv_shfl_f64(u, it * 8 + g);
+#endif
+  }
+  __device__ __forceinline__ double uni(double u, int it, int g) const {
+#if XV_ANYMDP_COOP_PRE
+    return ue[it];
+#else
+    return xv_shfl_f64(u, it * 8 + g);
+#endif
   }
   // the same for the envs whose owner lane sets `want` only: the others read line 0 of the table (one cached line for
   // all of them; their results are ignored).  A step is priced in random 128-byte lines (~5e10 per second): none is
@@ -891,7 +912,7 @@ struct AnyMDPCoopLine {
     rx = 0.0f; ry = 0.0f; meta = 0u;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const double ue = xv_shfl_f64(u, it * 8 + g);
+      const double ue = uni(u, it, g);
       const unsigned long long m = __ballot(j < KC && xv_u2d(bv[it].x, bv[it].y) <= ue);
       const int cg = __popc((unsigned)(m >> (8 * g)) & 0xFFu);   // reader side: the env this lane group serves
       const int co = __popc((unsigned)(m >> (8 * j)) & 0xFFu);   // owner side: the env this lane owns
@@ -913,7 +934,7 @@ struct AnyMDPCoopLine {
     uint32_t meta = 0u;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const double ue = xv_shfl_f64(u, it * 8 + g);
+      const double ue = uni(u, it, g);
       const unsigned long long m0 = __ballot(j < 7 && xv_u2d(bv[it].x, bv[it].y) <= ue);
       const unsigned long long m1 = __ballot(j < 7 && xv_u2d(bv[it].z, bv[it].w) <= ue);
       const int cg = __popc((unsigned)(m0 >> (8 * g)) & 0xFFu) + __popc((unsigned)(m1 >> (8 * g)) & 0xFFu);   // reader side
@@ -1072,6 +1093,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
     const uint32_t rowidx = ((uint32_t)t * S + s) * A + a;
     AnyMDPCoopLine L;
     L.issue_if(P.bucket, rowidx * (uint32_t)NBK + (uint32_t)(int)(u_cur * (double)NBK), alive, lane);
+    L.send(u_cur, lane);
     __builtin_amdgcn_sched_barrier(0);
     float z;
     double u_next = 0.0;
@@ -1142,6 +1164,8 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
       Q0.issue_if(K.obs_bucket, obs_line(kp, s_new, v0), wq, lane);
       Q1.issue_if(K.obs_bucket, obs_line(k1, s_new, v1), wq && k1 != kp, lane);
     }
+    S0.send(u0, lane); S1.send(u1, lane);
+    if (restarts) { Q0.send(v0, lane); Q1.send(v1, lane); }
     __builtin_amdgcn_sched_barrier(0);
     int c0, c1;
     bool f0, f1;
