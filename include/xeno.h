@@ -194,6 +194,12 @@ int xv_anymdp_reset_injected(xv_anymdp* h, const uint8_t* mask, const double* u,
  * MT19937 words; z is a Box-Muller normal from the other two words. */
 int xv_anymdp_step(xv_anymdp* h, const int32_t* action, int32_t* obs, float* reward, float* reward_gt,
                    uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int autoreset_mode);
+/* xv_anymdp_step that also writes, from the same launch, info["steps"] (the env's step counter after the step: 0 for an env the
+ * call restarted) and the terminated | truncated mask — steps int32[n_env], done uint8[n_env], each nullable.  A Python-level
+ * step() otherwise pays a second launch (xv_anymdp_get_state) and an elementwise op for them: ~8 us of host time per call. */
+int xv_anymdp_step_info(xv_anymdp* h, const int32_t* action, int32_t* obs, float* reward, float* reward_gt,
+                        uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int32_t* steps, uint8_t* done,
+                        int autoreset_mode);
 /* parity hook: the three random inputs are supplied per env: u[n_env] fp64 (transition draw),
  * z[n_env] fp32 (standard normal), u_reset[n_env] fp64 (initial-state draw used if the env resets) */
 int xv_anymdp_step_injected(xv_anymdp* h, const int32_t* action, const double* u, const float* z,

@@ -1029,3 +1029,39 @@ def test_bucket_lines_in_the_six_cut_packing(S, big_obs):
         _compare_step(d, ora.step(1, 0, tick + t, a, 2), exact_reward=False)   # the normal is device log / cos vs libm
     assert env.check_errors() == 0
     env.close()
+
+
+@pytest.mark.parametrize("copy", [True, False])
+@pytest.mark.parametrize("mode", ["same_step", "next_step", "disabled"])
+def test_step_writes_steps_and_done_mask_from_the_same_launch(copy, mode):
+    """xv_anymdp_step_info: info["steps"] and the `_final_obs` mask come out of the step kernel itself — equal to the env's
+    counters (xv_anymdp_get_state) and to terminated | truncated, in every auto-reset mode, copy=True and copy=False"""
+    tasks, tab, env_task = _config1()
+    n = len(env_task)
+    env = AnyMDPVecEnv(n, autoreset_mode=mode, seed=4, copy=copy)
+    env.set_task(tasks, env_task_index=env_task)
+    ora = oracle.AnyMDPOracle(tab, env_task)
+    tick = env.engine.tick
+    obs, _ = env.reset()
+    assert np.array_equal(_np(obs), ora.reset(4, 0, tick))
+    rng = np.random.RandomState(1)
+    ended = 0
+    for t in range(120):
+        a = rng.randint(0, 4, n).astype(np.int32)
+        tick = env.engine.tick
+        o, r, te, tr, info = env.step(a)
+        eo = ora.step(4, 0, tick, a, MODES[mode])
+        assert np.array_equal(_np(o), eo[0]) and np.array_equal(_np(te).astype(np.uint8), eo[3])
+        _, st, _ = env.get_state()
+        assert np.array_equal(_np(info["steps"]), _np(st)) and np.array_equal(_np(st), ora.steps)
+        if mode == "same_step":
+            assert np.array_equal(_np(info["_final_obs"]), _np(te) | _np(tr))
+            assert np.array_equal(_np(info["final_obs"]), eo[5])
+        ended += int((eo[3] | eo[4]).sum())
+        if mode == "disabled" and (eo[3] | eo[4]).any():
+            m = (eo[3] | eo[4]).astype(bool)
+            tick = env.engine.tick
+            env.reset(options={"reset_mask": m})
+            ora.reset(4, 0, tick, mask=m)
+    assert ended > 20 and env.check_errors() == 0
+    env.close()

@@ -44,6 +44,7 @@ SIGNATURES = {
     "xv_anymdp_reset": [c_void_p, c_void_p, c_void_p],
     "xv_anymdp_reset_injected": [c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_anymdp_step": [c_void_p] + [c_void_p] * 7 + [c_int],
+    "xv_anymdp_step_info": [c_void_p] + [c_void_p] * 9 + [c_int],
     "xv_anymdp_step_injected": [c_void_p] + [c_void_p] * 10 + [c_int],
     "xv_anymdp_step_many": [c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int],
     "xv_anymdp_set_step_many_graph": [c_void_p, c_int],

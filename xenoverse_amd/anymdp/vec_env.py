@@ -139,6 +139,7 @@ class AnyMDPVecEnv(VectorEnv):
         self._trunc = torch.zeros(n, dtype=torch.uint8, device=d)
         self._final_obs = torch.full((n,), -1, dtype=torch.int32, device=d)
         self._steps = torch.zeros(n, dtype=torch.int32, device=d)
+        self._done = torch.zeros(n, dtype=torch.uint8, device=d)
         self._tgt = torch.zeros((n, S), dtype=torch.float64, device=d) if self.with_transition_gt else None
         self._ring = None
         if (not self.copy) and (not self.to_numpy) and self._tok is None and not self.with_transition_gt:
@@ -153,6 +154,7 @@ class AnyMDPVecEnv(VectorEnv):
                 b["args"] = tuple(C.c_void_p(b[k].data_ptr()) for k in
                                   ("obs", "reward", "reward_gt", "term", "trunc", "final_obs"))
                 b["steps_p"] = C.c_void_p(b["steps"].data_ptr())
+                b["done_p"] = C.c_void_p(b["done"].data_ptr())
                 self._ring.append(b)
         self.task_set = True
         self.need_reset = True
@@ -320,27 +322,27 @@ class AnyMDPVecEnv(VectorEnv):
             if not self._holding:           # a captured loop (capture.py) writes one output set: its policy reads it back
                 self._ring_pos ^= 1
             lib, mode = self.lib, AUTORESET[self.autoreset_mode]
-            _lib.check(lib.xv_anymdp_step(self._h, C.c_void_p(a.data_ptr()), *b["args"], mode))
-            if self.lean_infos:             # nothing that needs a launch of its own; final_obs >= 0 marks a finished env
-                infos = {"reward_gt": b["reward_gt"]}
-                if mode == 2:
-                    infos["final_obs"] = b["final_obs"]
-                return b["obs"], b["reward"], b["term_b"], b["trunc_b"], infos
-            _lib.check(lib.xv_anymdp_get_state(self._h, None, b["steps_p"], None))
+            # ONE launch: the step kernel writes info["steps"] and the terminated | truncated mask itself (xv_anymdp_step_info)
+            _lib.check(lib.xv_anymdp_step_info(self._h, C.c_void_p(a.data_ptr()), *b["args"], b["steps_p"], b["done_p"], mode))
             infos = {"steps": b["steps"], "reward_gt": b["reward_gt"]}
             if mode == 2:
-                torch.bitwise_or(b["term"], b["trunc"], out=b["done"])
                 infos["final_obs"] = b["final_obs"]
                 infos["_final_obs"] = b["done_b"]
             return b["obs"], b["reward"], b["term_b"], b["trunc_b"], infos
         # copy=True without copies: the step writes every output for every env, so fresh buffers are swapped in
-        self._renew("_obs", "_reward", "_reward_gt", "_term", "_trunc", "_final_obs")
-        _lib.check(self.lib.xv_anymdp_step(
+        self._renew("_obs", "_reward", "_reward_gt", "_term", "_trunc", "_final_obs", "_steps", "_done")
+        _lib.check(self.lib.xv_anymdp_step_info(
             self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward), _lib.ptr(self._reward_gt),
-            _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._final_obs),
+            _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._final_obs), _lib.ptr(self._steps), _lib.ptr(self._done),
             AUTORESET[self.autoreset_mode]))
-        return (self._of(self._obs), self._of(self._reward), self._obf(self._term), self._obf(self._trunc),
-                self._infos(a))
+        infos = {"steps": self._of(self._steps), "reward_gt": self._of(self._reward_gt)}
+        if self.autoreset_mode == "same_step":
+            infos["final_obs"] = self._of(self._final_obs)
+            infos["_final_obs"] = self._obf(self._done)
+        if self.with_transition_gt:
+            _lib.check(self.lib.xv_anymdp_transition_gt(self._h, _lib.ptr(a), _lib.ptr(self._tgt)))
+            infos["transition_gt"] = self._out(self._tgt.clone())
+        return (self._of(self._obs), self._of(self._reward), self._obf(self._term), self._obf(self._trunc), infos)
 
     def step_injected(self, actions, u, z, u_reset):
         """Parity hook (C-ABI xv_anymdp_step_injected): random inputs supplied per env."""

@@ -88,6 +88,10 @@ struct AnyMDPStepIO {
   const uint8_t* greedy;
   int32_t* action_out;
   float epsilon;
+  // info["steps"] and the terminated | truncated mask of the same step (xv_anymdp_step_info; nullable): a host that wants them
+  // needs no second launch and no elementwise op of its own
+  int32_t* steps_out;
+  uint8_t* done_out;
 };
 
 struct xv_anymdp {
@@ -501,6 +505,8 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
       __builtin_nontemporal_store((uint8_t)(o_term ? 1 : 0), io.terminated + o);
       __builtin_nontemporal_store((uint8_t)(o_trunc ? 1 : 0), io.truncated + o);
       if (io.final_obs) __builtin_nontemporal_store(o_fobs, io.final_obs + o);
+      if (io.steps_out) __builtin_nontemporal_store((int32_t)steps, io.steps_out + o);
+      if (io.done_out) __builtin_nontemporal_store((uint8_t)((o_term || o_trunc) ? 1 : 0), io.done_out + o);
 #else
       io.obs[o] = o_obs;
       io.reward[o] = o_r;
@@ -508,6 +514,8 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
       io.terminated[o] = o_term ? 1 : 0;
       io.truncated[o] = o_trunc ? 1 : 0;
       if (io.final_obs) io.final_obs[o] = o_fobs;
+      if (io.steps_out) io.steps_out[o] = (int32_t)steps;
+      if (io.done_out) io.done_out[o] = (uint8_t)((o_term || o_trunc) ? 1 : 0);
 #endif
     }
   }
@@ -1564,6 +1572,17 @@ extern "C" int xv_anymdp_step(xv_anymdp* h, const int32_t* action, int32_t* obs,
   XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
   anymdp_bind_rng(h, 1);
   AnyMDPStepIO io{action, nullptr, nullptr, nullptr, obs, reward, reward_gt, terminated, truncated, final_obs, nullptr, nullptr, 0.0f};
+  return anymdp_launch_step<false>(h, io, 1, autoreset_mode);
+}
+
+extern "C" int xv_anymdp_step_info(xv_anymdp* h, const int32_t* action, int32_t* obs, float* reward, float* reward_gt,
+                                   uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int32_t* steps, uint8_t* done,
+                                   int autoreset_mode) {
+  XV_CHECK_ARG(h && action && obs && reward && reward_gt && terminated && truncated);
+  XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
+  anymdp_bind_rng(h, 1);
+  AnyMDPStepIO io{action, nullptr, nullptr, nullptr, obs, reward, reward_gt, terminated, truncated, final_obs, nullptr, nullptr, 0.0f,
+                  steps, done};
   return anymdp_launch_step<false>(h, io, 1, autoreset_mode);
 }
 
