@@ -779,7 +779,9 @@ def sweep(args, torch, local):
         tab = make_tables(env.engine, torch, _lib, n_env, 0, args.seed + 1, S, A)
         env.set_task(tab, env_task_index=torch.arange(n_env, device=env.device, dtype=torch.int32))
         used, _, _ = choose_search(env, torch, args, n_env, S, A)
-        env.set_step_many_graph("off")
+        # ring cycles replayed from a hipGraph, as the headline run: plain launches follow the HOST's launch rate (3-5 us per
+        # launch depending on the box), which is all a sweep below 65,536 envs would then show
+        env.set_step_many_graph(args.graph if args.graph != "auto" else "on")
         g = torch.Generator(device=env.device)
         g.manual_seed(args.seed)
         actions = torch.randint(0, A, (P, n_env), generator=g, device=env.device, dtype=torch.int32)
@@ -809,15 +811,28 @@ def sweep(args, torch, local):
         except Exception:
             pass
         algo = ALGO_BYTES_PER_ENV_STEP[8] * n_env
+        floor = floor_probe()
+        lines = 1 if used == "bucket" else 2
+        # bytes the search really moves per env-step (PMC, profiles/r04_z_pmc_traffic_*): one 128-byte line + 88 B of streams
+        # (bucket) or two lines (fence).  SURVEY 8(d)'s `frac` prices the 512-byte row: beyond ~100k envs a search that reads
+        # one line of it runs "faster than reading the rows would allow" (frac > 1) — the fractions to read are the line rate's
+        # and, up to 65,536 envs, the latency floor's
+        moved = (216.0 if used == "bucket" else 344.5) * n_env
+        frac = algo / (t * 1e-6) / 1e9 / HBM_PEAK_GBS
         rows.append({"envs": n_env, "table_gib": round(need / 2**30, 1), "search": used, "us_per_step": t,
                      "env_steps_per_s": n_env / (t * 1e-6),
-                     "random_128B_lines_per_s": (1 if used == "bucket" else 2) * n_env / (t * 1e-6),
-                     "algorithmic_GBs": algo / (t * 1e-6) / 1e9, "frac": algo / (t * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "random_128B_lines_per_s": lines * n_env / (t * 1e-6),
+                     "frac_of_line_rate": lines * n_env / (t * 1e-6) / floor["random_lines_per_s"],
+                     "floor_us_at_65536": floor["coop_lines_us"].get(lines), "frac_of_floor": (floor["coop_lines_us"].get(lines) / t) if n_env == 65536 else None,   # the chain was measured at 65,536 lanes
+                     "algorithmic_GBs": algo / (t * 1e-6) / 1e9, "frac": frac,
+                     "frac_traffic": moved / (t * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "primary": "frac_traffic",
+                     "frac_note": ("frac > 1: the search reads %d line(s) of the row, not the 512 bytes SURVEY 8(d) prices" % lines) if frac > 1 else None,
                      "fused_rollout_us_per_step": fus, "device_error_flags": env.check_errors()})
         env.close()
         del tab, env, ring, actions
         torch.cuda.empty_cache()
-    out = {"what": "anymdp 2a (one task per env, S=64, A=8, bucket search where its lines fit else fence, plain launches): step time against envs/GPU",
+    out = {"what": "anymdp 2a (one task per env, S=64, A=8, the search AUTO picks, ring cycles replayed from a hipGraph unless --graph off): step time against envs/GPU",
            "steps": args.steps, "warmup": args.warmup, "kernel_source_sha16": kernel_source_hash(), "rows": rows}
     os.makedirs(os.path.dirname(args.sweep_out), exist_ok=True)
     json.dump(out, open(args.sweep_out, "w"), indent=1)

@@ -452,6 +452,11 @@ int xv_linds_step(xv_linds* h, const float* action, float* obs, float* reward, u
 int xv_linds_step_many(xv_linds* h, int n_steps, int period, const float* action, float* obs, float* reward,
                        uint8_t* terminated, uint8_t* truncated, float* cmd, float* error, float* final_obs,
                        int autoreset_mode);
+/* xv_linds_step that also writes, from the same launch, info["steps"] (the counter after the step: 0 for an env the call
+ * restarted) and the terminated | truncated mask — steps int32[n_env], done uint8[n_env], each nullable.  Matrix kernel only
+ * (XV_ERR_UNSUPPORTED on XV_LINDS_PATH_SCALAR). */
+int xv_linds_step_info(xv_linds* h, const float* action, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated,
+                       float* cmd, float* error, float* final_obs, int32_t* steps, uint8_t* done, int autoreset_mode);
 /* parity hook: z float[NS][n_env] standard normals, init_index int32[n_env] (initial state used on reset) */
 int xv_linds_step_injected(xv_linds* h, const float* action, const float* z, const int32_t* init_index,
                            float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, float* cmd,

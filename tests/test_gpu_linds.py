@@ -422,3 +422,31 @@ def test_process_noise_generator_is_standard_normal_on_the_device():
     # the draws of different envs, components and steps are not the same numbers
     assert len(np.unique(z[:1 << 20])) > 0.98 * (1 << 20)
     env.close()
+
+
+@pytest.mark.parametrize("copy", [True, False])
+def test_step_writes_steps_and_done_mask_from_the_same_launch(copy):
+    """xv_linds_step_info: info["steps"] and the `_final_obs` mask come out of the step kernel — equal to the env's counters
+    (xv_linds_get_state) and to terminated | truncated; the scalar test kernel (two more launches) gives the same infos"""
+    tasks, tab, env_task = _batch(64, FILES[:3])
+    n = len(env_task)
+    acts = np.random.RandomState(3).uniform(-1.3, 1.3, (80, n, 8)).astype(np.float32)
+    recs = []
+    for path in ("mfma", "scalar"):
+        env = LinDSVecEnv(n, autoreset_mode="same_step", seed=5, copy=copy)
+        env.set_task(tasks, env_task_index=env_task)
+        env.set_path(path)
+        env.reset()
+        rec, ended = [], 0
+        for t in range(80):
+            o, r, te, tr, info = env.step(acts[t])
+            _, st, _ = env.get_state()
+            assert np.array_equal(_np(info["steps"]), _np(st))
+            assert np.array_equal(_np(info["_final_obs"]), _np(te) | _np(tr))
+            rec.append((_np(info["steps"]).copy(), _np(info["_final_obs"]).copy(), _np(o).copy()))
+            ended += int((_np(te) | _np(tr)).sum())
+        assert ended > 5 and env.check_errors() == 0
+        recs.append(rec)
+        env.close()
+    for a, b in zip(*recs):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])

@@ -83,6 +83,7 @@ SIGNATURES = {
     "xv_linds_reset": [c_void_p] + [c_void_p] * 4,
     "xv_linds_reset_injected": [c_void_p] + [c_void_p] * 5,
     "xv_linds_step": [c_void_p] + [c_void_p] * 8 + [c_int],
+    "xv_linds_step_info": [c_void_p] + [c_void_p] * 10 + [c_int],
     "xv_linds_step_injected": [c_void_p] + [c_void_p] * 10 + [c_int],
     "xv_linds_rollout": [c_void_p, c_int] + [c_void_p] * 8,
     "xv_linds_get_state": [c_void_p, c_void_p, c_void_p, c_void_p],

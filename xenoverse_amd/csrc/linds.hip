@@ -96,6 +96,9 @@ struct LinDSStepIO {
   float* cmd;               // [n_env][NO]
   float* error;
   float* final_obs;         // nullable
+  // info["steps"] and the terminated | truncated mask of the same step (xv_linds_step_info, matrix kernel; nullable)
+  int32_t* steps_out;
+  uint8_t* done_out;
 };
 
 struct xv_linds {
@@ -750,7 +753,7 @@ struct LinDSTileStep {
                                              int init_inj, size_t orow /* row of this env in the [.][n_env] outputs */,
                                              float* o_obs, float* o_cmd, float* o_fobs, float* o_reward, float* o_error,
                                              uint8_t* o_term_p, uint8_t* o_trunc_p, xv_f32x4 (&xs)[MT], int& steps, int& nr,
-                                             int& bad_out) {
+                                             int& bad_out, int32_t* o_steps_p = nullptr, uint8_t* o_done_p = nullptr) {
     const int g = lane >> 4;
     const XV_CONST_AS float* sc = xv_cptr(P.T.scal) + (size_t)t * 8;
     const XV_CONST_AS int32_t* in = xv_cptr(P.T.ints) + (size_t)t * 4;
@@ -998,6 +1001,8 @@ struct LinDSTileStep {
         o_term_p[orow] = (uint8_t)o_term;
         o_trunc_p[orow] = (uint8_t)o_trunc;
 #endif
+        if (o_steps_p) o_steps_p[orow] = steps;                               // the counter after the step (0 after a restart)
+        if (o_done_p) o_done_p[orow] = (uint8_t)((o_term | o_trunc) ? 1 : 0);
       }
     }
 #pragma unroll
@@ -1057,7 +1062,8 @@ __device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const L
   const int init_inj = INJECT ? io.init_index[id.e] : 0;
   LinDSTileStep<NS, NA, NO, INJECT>::run(P, fr, id.t, id.lane, id.e, id.valid, id.gid, xv_launch_tick(P.tick, P.tick_dev), mode,
                                          io.action + (size_t)id.e * NA, io.z, P.n_env, init_inj, (size_t)id.e, io.obs, io.cmd,
-                                         io.final_obs, io.reward, io.error, io.terminated, io.truncated, xs, steps, nr, bad);
+                                         io.final_obs, io.reward, io.error, io.terminated, io.truncated, xs, steps, nr, bad,
+                                         io.steps_out, io.done_out);
   if (id.valid) {
 #pragma unroll
     for (int m = 0; m < F::MT; ++m) {
@@ -1442,6 +1448,20 @@ extern "C" int xv_linds_step(xv_linds* h, const float* action, float* obs, float
   XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
   linds_bind_rng(h, 1);
   LinDSStepIO io{action, nullptr, nullptr, obs, reward, terminated, truncated, cmd, error, final_obs};
+  return linds_launch_step<false>(h, io, autoreset_mode);
+}
+
+extern "C" int xv_linds_step_info(xv_linds* h, const float* action, float* obs, float* reward, uint8_t* terminated,
+                                  uint8_t* truncated, float* cmd, float* error, float* final_obs, int32_t* steps, uint8_t* done,
+                                  int autoreset_mode) {
+  XV_CHECK_ARG(h && action && obs && reward && terminated && truncated && cmd && error);
+  XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
+  if (h->path == XV_LINDS_PATH_SCALAR) {
+    xv_set_error("xv_linds_step_info: served by the matrix kernel (the scalar test kernel: xv_linds_step + xv_linds_get_state)");
+    return XV_ERR_UNSUPPORTED;
+  }
+  linds_bind_rng(h, 1);
+  LinDSStepIO io{action, nullptr, nullptr, obs, reward, terminated, truncated, cmd, error, final_obs, steps, done};
   return linds_launch_step<false>(h, io, autoreset_mode);
 }
 

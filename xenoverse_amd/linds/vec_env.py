@@ -121,6 +121,8 @@ class LinDSVecEnv(VectorEnv):
         self._term = torch.zeros(n, dtype=torch.uint8, device=d)
         self._trunc = torch.zeros(n, dtype=torch.uint8, device=d)
         self._steps = torch.zeros(n, dtype=torch.int32, device=d)
+        self._done = torch.zeros(n, dtype=torch.uint8, device=d)
+        self._path_name = "auto"
         self._command_type = np.where(tab["ints"][:, 3] > 0, "dynamic_target", "static_target") \
             if not torch.is_tensor(tab["ints"]) else None
         self.task_set = True
@@ -131,6 +133,7 @@ class LinDSVecEnv(VectorEnv):
     def set_path(self, path):
         """Select the step kernel ("auto", "mfma", "scalar"); results are identical (include/xeno.h)."""
         _lib.check(self.lib.xv_linds_set_path(self._h, self.PATH[path]))
+        self._path_name = path
 
     def set_command_table(self, enable):
         """Use the per-task table of get_inner_cmd values built at set_task (default) or evaluate the Fourier
@@ -224,11 +227,23 @@ class LinDSVecEnv(VectorEnv):
         a = self._action(actions)
         self._renew(*self._STEP_OUTPUTS)
         self._fresh_final_obs()
-        _lib.check(self.lib.xv_linds_step(self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward),
-                                          _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._cmd),
-                                          _lib.ptr(self._error), _lib.ptr(self._fobs),
-                                          AUTORESET[self.autoreset_mode]))
-        return self._ret()
+        if self._path_name == "scalar":      # the test kernel: steps and the done mask by a launch / an op of their own
+            _lib.check(self.lib.xv_linds_step(self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward),
+                                              _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._cmd),
+                                              _lib.ptr(self._error), _lib.ptr(self._fobs),
+                                              AUTORESET[self.autoreset_mode]))
+            return self._ret()
+        # ONE launch: the step kernel writes info["steps"] and the terminated | truncated mask itself (xv_linds_step_info)
+        self._renew("_steps", "_done")
+        _lib.check(self.lib.xv_linds_step_info(self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward),
+                                               _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._cmd),
+                                               _lib.ptr(self._error), _lib.ptr(self._fobs), _lib.ptr(self._steps),
+                                               _lib.ptr(self._done), AUTORESET[self.autoreset_mode]))
+        infos = {"steps": self._of(self._steps), "command": self._of(self._user_obs(self._cmd)), "error": self._of(self._error)}
+        if self.autoreset_mode == "same_step":
+            infos["final_obs"] = self._of(self._user_obs(self._fobs))
+            infos["_final_obs"] = self._obf(self._done)
+        return (self._of(self._user_obs(self._obs)), self._of(self._reward), self._obf(self._term), self._obf(self._trunc), infos)
 
     def step_injected(self, actions, z, init_index):
         """Parity hook: z float[NS, N] standard normals (process noise), init_index int[N] (used on reset)."""
