@@ -424,3 +424,87 @@ def test_step_then_masked_reset_keeps_returned_tensors():
     f3 = env.render_frames()
     assert torch.equal(f2[1::2], keep[1::2]) and torch.equal(frames, keep) and torch.equal(f3, f2)
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# AnyMDP on tasks of the REFERENCE's distribution at full size (round 4): 65,536 envs = 1,024 device-sampled tasks x 64, the
+# search AUTO picks after the census of the bucket lines — every env against the oracle, free-running draws
+# ---------------------------------------------------------------------------------------------------
+def _refdist_tables(task_type="MDP", **kw):
+    from xenoverse_amd.anymdp import from_blocked
+    from xenoverse_amd.anymdp.device_sampler import sample_tasks_device
+    tab = sample_tasks_device(1024, 64, 8, seed=3, batch=4096, task_type=task_type, **kw)
+    cdf, rs = from_blocked(_np(tab["rows"]), 64)
+    host = dict(S=64, A=8, s0_max=tab["s0_max"], cdf=cdf, rs=rs, state_map=_np(tab["state_map"]), s0_cdf=_np(tab["s0_cdf"]),
+                s0_ids=_np(tab["s0_ids"]), max_steps=_np(tab["max_steps"]), term_mask=_np(tab["term_mask"]).view(np.uint64))
+    return tab, host
+
+
+def test_reference_distribution_tasks_65536_envs_auto_search_vs_oracle():
+    from xenoverse_amd.anymdp import AnyMDPVecEnv
+    tab, host = _refdist_tables()
+    n, seed = 65536, 11
+    env_task = np.repeat(np.arange(1024, dtype=np.int32), 64)
+    env = AnyMDPVecEnv(n, seed=seed, autoreset_mode="same_step")
+    env.set_task({k: tab[k] for k in ("S", "A", "s0_max", "rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")},
+                 env_task_index=env_task)
+    env.set_search("auto", n_bucket=16)
+    cen = env.bucket_census()
+    assert env.effective_search == "bucket" and cen["built"] == 1 and cen["lines_dirty"] > 0      # skewed rows: some lines lump runs
+    assert cen["p_fallback"] < 5e-6 and cen["fallbacks_per_launch"] <= cen["auto_limit"]
+    ora = oracle.AnyMDPOracle(host, env_task)
+    tick = env.engine.tick
+    obs, _ = env.reset()
+    assert np.array_equal(_np(obs), ora.reset(seed, 0, tick))
+    rng = np.random.RandomState(0)
+    done = 0
+    for t in range(48):
+        a = rng.randint(0, 8, n).astype(np.int32)
+        tick = env.engine.tick
+        o, r, te, tr, info = env.step(a)
+        eo, er, ergt, ete, etr, efo = ora.step(seed, 0, tick, a, 2, n_threads=NT)
+        assert np.array_equal(_np(o), eo) and np.array_equal(_np(te).astype(np.uint8), ete)
+        assert np.array_equal(_np(tr).astype(np.uint8), etr) and np.array_equal(_np(info["reward_gt"]), ergt)
+        assert np.array_equal(_np(info["final_obs"]), efo) and np.array_equal(_np(info["steps"]), ora.steps)
+        assert np.allclose(_np(r), er, rtol=1e-5, atol=2e-6)
+        s_, _, _ = env.get_state()
+        assert np.array_equal(_np(s_), ora.state)
+        done += int((ete | etr).sum())
+    assert done > 10000 and env.check_errors() == 0
+    # the same steps on the fence search give the same trajectory (states were compared above): one more step on each
+    env.set_search("fence")
+    a = rng.randint(0, 8, n).astype(np.int32)
+    tick = env.engine.tick
+    o = env.step(a)
+    eo = ora.step(seed, 0, tick, a, 2, n_threads=NT)
+    assert np.array_equal(_np(o[0]), eo[0])
+    env.close()
+
+
+def test_reference_distribution_multi_token_tasks_65536_envs_cooperative_kernel_vs_oracle():
+    from xenoverse_amd.anymdp import AnyMDPVecEnv
+    tab, host = _refdist_tables("MTPOMDP", observation_space=64, observation_tokens=2, action_tokens=2)
+    n, seed = 65536, 12
+    env_task = np.repeat(np.arange(1024, dtype=np.int32), 64)
+    env = AnyMDPVecEnv(n, seed=seed, autoreset_mode="same_step")
+    env.set_task(tab, env_task_index=env_task)
+    env.set_search("auto", n_bucket=16)
+    assert env.effective_search == "bucket" and env.token_kernel == "cooperative"
+    assert env.bucket_census()["obs_lines"] == 1024 * 2 * 64 * 16
+    ora = oracle.AnyMDPTokOracle(host, env_task, _np(tab["obs_cdf"]), 2)
+    tick = env.engine.tick
+    o0, _ = env.reset()
+    assert np.array_equal(_np(o0), ora.tok_reset(seed, 0, tick))
+    rng = np.random.RandomState(1)
+    done = 0
+    for t in range(24):
+        a = rng.randint(0, 8, (n, 2)).astype(np.int32)
+        tick = env.engine.tick
+        obs, r, term, trunc, info = env.step(a)
+        o = ora.tok_step(seed, 0, tick, a, 2)
+        assert np.array_equal(_np(obs), o[0]) and np.array_equal(_np(term).astype(np.uint8), o[3])
+        assert np.array_equal(_np(trunc).astype(np.uint8), o[4]) and np.array_equal(_np(info["reward_gt"]), o[2])
+        assert np.allclose(_np(r), o[1], rtol=1e-5, atol=4e-6)
+        done += int((o[3] | o[4]).sum())
+    assert done > 5000 and env.check_errors() == 0
+    env.close()
