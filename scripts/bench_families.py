@@ -229,8 +229,9 @@ def bench_anymdp_tok(args):
         _lib.check(env.lib.xv_anymdp_step_tokens(env._h, _lib.ptr(a), _lib.ptr(tobs), _lib.ptr(env._reward),
                                                  _lib.ptr(env._reward_gt), _lib.ptr(env._term), _lib.ptr(env._trunc),
                                                  _lib.ptr(tfobs), AUTORESET[mode]))
+    env.set_search("fence")                    # the per-lane kernel (binary searches of the rows)
     us = timed(step, args.steps, args.warmup)
-    env.set_search("bucket", n_bucket=16)      # transitions through the bucket lines (one dependent level each)
+    env.set_search("bucket", n_bucket=16)      # the cooperative kernel on transition + observation bucket lines
     us_b = timed(step, args.steps, args.warmup)
     env.close()
     return {"family": "anymdp multi-token POMDP", "workload": "65,536 envs, 1,024 tasks, S=64 A=8 n_obs=64 d_obs=%d d_act=%d%s" % (d_obs, d_act, "" if mode == "same_step" else ", " + mode),

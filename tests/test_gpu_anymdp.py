@@ -913,7 +913,11 @@ def test_bucket_census_of_reference_rows_and_auto_takes_the_bucket_search():
     path = [p for p in FILES if "64x8" in p][0]
     g, task = load_anymdp_golden(path)
     n = len(g["ss_s"])
-    env = AnyMDPVecEnv(n, autoreset_mode="disabled")
+    dflt = AnyMDPVecEnv(n, autoreset_mode="disabled")      # the default: 1 MB of lines is within the 1-GiB budget of "auto"
+    dflt.set_task(task)
+    assert dflt.effective_search == "bucket" and dflt.bucket_census()["built"] == 1
+    dflt.close()
+    env = AnyMDPVecEnv(n, autoreset_mode="disabled", bucket_lines="off")
     env.set_task(task)
     assert env.effective_search == "fence" and env.bucket_census()["built"] == 0
     cen = env.probe_buckets(16)
@@ -958,8 +962,9 @@ def test_auto_keeps_the_fence_search_when_the_census_says_lines_overflow():
                term_mask=np.zeros((n_task, 4), np.uint64), s0_cdf=np.tile(np.array([0.5, 1.0]), (n_task, 1)),
                s0_ids=np.tile(np.array([0, 1], np.int32), (n_task, 1)), max_steps=np.full(n_task, 1000, np.int32))
     env_task = rng.randint(0, n_task, n_env).astype(np.int32)
-    env = AnyMDPVecEnv(n_env, autoreset_mode="same_step", seed=1)
+    env = AnyMDPVecEnv(n_env, autoreset_mode="same_step", seed=1)      # (bucket_lines="auto": the census declines, nothing built)
     env.set_task(_dev_tables(tab), env_task_index=env_task)
+    assert env.effective_search == "fence" and env.bucket_census()["built"] == 0
     cen = env.probe_buckets(16)
     assert cen["p_fallback"] > 0.2 and cen["auto_uses_bucket"] == 0 and cen["lines_dirty"] == cen["lines"]
     env.set_search("auto", n_bucket=16)                 # the census says no: nothing is built

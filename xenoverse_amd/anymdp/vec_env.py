@@ -21,20 +21,29 @@ _TABLE_DTYPES = dict(rows=torch.float64, state_map=torch.int32, term_mask=torch.
 
 
 class AnyMDPVecEnv(VectorEnv):
+    AUTO_BUCKET_BYTES = 1 << 30      # bucket_lines="auto": lines are built at set_task when they take no more than this
+
     def __init__(self, num_envs, max_steps=5000, device="cuda:0", seed=0, env_id_base=0,
-                 autoreset_mode="same_step", to_numpy=False, engine=None, with_transition_gt=False, copy=True):
+                 autoreset_mode="same_step", to_numpy=False, engine=None, with_transition_gt=False, copy=True,
+                 bucket_lines="auto"):
         """`max_steps` is kept for signature parity with AnyMDPEnv(max_steps); as in the reference it is
         overridden by each task's own `max_steps` at set_task (anymdp_env.py:23-34).
 
         copy (as gymnasium's SyncVectorEnv(copy=...)): True returns fresh tensors from every step().  False returns
         views of two engine-owned output sets used alternately — what step() returned stays valid until the step
         after the next one — and takes the per-step host cost from ~50 us (clones, bool conversions) to a launch, a
-        16-KB copy and one fused op (`scripts/bench_python_step.py`)."""
+        16-KB copy and one fused op (`scripts/bench_python_step.py`).
+
+        bucket_lines: "auto" (default) — at set_task the engine takes the census of 16 bucket lines per row and builds them
+        when its AUTO rule would use them AND they take at most 1 GiB (n_task * S * A * 2 KiB: up to 1,024 tasks of 64 x 8):
+        a step then reads one table line instead of two, same results; "off" — never without set_search(..., n_bucket=);
+        an int — that many buckets per row whatever the size (as set_search("auto", n_bucket=int))."""
         super().__init__(num_envs, device=device, seed=seed, env_id_base=env_id_base,
                          autoreset_mode=autoreset_mode, to_numpy=to_numpy, engine=engine, copy=copy)
         self.max_steps = max_steps
         self.with_transition_gt = bool(with_transition_gt)
         self.copy = bool(copy)
+        self.bucket_lines = bucket_lines
         self._ring = None
         self._set_spaces(Discrete(1), Discrete(1))   # placeholders until set_task, as in the reference
         self._h = None
@@ -158,6 +167,13 @@ class AnyMDPVecEnv(VectorEnv):
                 self._ring.append(b)
         self.task_set = True
         self.need_reset = True
+        if self.bucket_lines != "off":      # memory for speed, within a small budget unless the caller named a bucket count
+            nb = 16 if self.bucket_lines == "auto" else int(self.bucket_lines)
+            if self.bucket_lines != "auto" or n_task * S * A * nb * 128 <= self.AUTO_BUCKET_BYTES:
+                try:
+                    self.set_search("auto", n_bucket=nb)
+                except _lib.XenoError:      # tables the fence layout does not serve (s0_max > 4, ...): the per-lane search
+                    pass
 
     SEARCH = {"auto": 0, "binary": 1, "fence": 3, "bucket": 4}
     _SEARCH_NAME = {1: "binary", 3: "fence", 4: "bucket"}
