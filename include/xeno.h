@@ -36,7 +36,13 @@ extern "C" {
  *    xv_anymdp_create; xv_maze_tables carries the texture-library sizes; Acrobot family; command-table and
  *    graph-replay switches
  * 4: xv_linds_rollout, xv_cartpole_rollout, xv_acrobot_rollout; the maze teachers (xv_maze_agent_*);
- *    xv_maze_set_typing; AnyMDP bucket search (xv_anymdp_build_buckets) */
+ *    xv_maze_set_typing; AnyMDP bucket search (xv_anymdp_build_buckets)
+ * 5-7: xv_linds_step_many, xv_mixed_step[_many], device observation-model sampler, xv_rccl_comm_count, engine timing events,
+ *    xv_anymdp_step_tokens_many
+ * 8: device tick (xv_engine_set_device_tick / _tick_batch / _set_stream: a step is capturable in a hipGraph); AnyMDP bucket
+ *    lines list chosen cuts of the row's CDF, with a census (xv_anymdp_probe_buckets, xv_anymdp_bucket_census_get,
+ *    xv_anymdp_effective_search, xv_anymdp_token_kernel); xv_anymdp_step_info / xv_linds_step_info (steps and the done mask
+ *    from the step launch); xv_mixed_supported; xv_anymdp_sample_tasks up to 256 states */
 #define XV_ABI_VERSION 8
 
 /* return codes */
