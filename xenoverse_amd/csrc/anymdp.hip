@@ -40,9 +40,8 @@
 #include <cstring>
 
 #define XV_ANYMDP_BLK 7   // next states per block
-#ifndef XV_ANYMDP_SELECT
-#define XV_ANYMDP_SELECT 1   // the owner lane keeps its result by SELECTS: written as `if (g == it) {...}` hipcc emits an exec-masked
-#endif                       // branch per env group (45 -> 14 branches in the step kernel; 5.31-5.34 -> 5.05-5.13 us per step)
+// (the owner lane keeps its result by SELECTS throughout: written as `if (g == it) {...}` hipcc emits an exec-masked branch per
+//  env group — 45 -> 14 branches in the round-3 step kernel, 5.31-5.34 -> 5.05-5.13 us per step)
 #ifndef XV_ANYMDP_NT_OUT
 #define XV_ANYMDP_NT_OUT 1   // the step's outputs leave with non-temporal stores (written once, read by somebody else): 5.41-5.73
 #endif                       // -> 5.27-5.32 us per 65,536-env step on the same box, two A/B rounds (scripts/runs_r03/gpu_n.sh)
@@ -165,23 +164,150 @@ __device__ __forceinline__ double xv_shfl_f64(double v, int src) {
 }
 __device__ __forceinline__ double xv_u2d(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 
-// Bucket ("cut") line metadata -> one word about group `sg` of the line: observation id (bits 0..15) | next state (16..24) |
-// terminal flag (25) | the group lumps several states, or is unused (26).  Meaningful on the metadata lane (unit 7) only.
+// Bucket ("cut") line metadata, unit 7 of the line (and unit 6 in the wide packing), per group `sg` of the line: observation id,
+// next state, terminal flag, and whether the group lumps several states or is unused:
 //   FMT 1: unit 7 = bytes 0..6 observation ids, byte 7 terminal bits, bytes 8..14 next states, byte 15 lumped bits (7 groups)
 //   FMT 2: unit 6 = 6 x u16 next states; unit 7 = 6 x u16 observation ids, .w = terminal bits | lumped bits << 8 (6 groups)
-template <int FMT>
-__device__ __forceinline__ uint32_t anymdp_cut_meta(const uint4& b4, int sg) {
-  if (FMT == 1) {
-    const uint32_t ow = sg < 4 ? b4.x : b4.y, sw = sg < 4 ? b4.z : b4.w;
-    const int sh = 8 * (sg & 3);
-    return ((ow >> sh) & 0xFFu) | (((sw >> sh) & 0xFFu) << 16) | (((b4.y >> (24 + sg)) & 1u) << 25) |
-           (((b4.w >> (24 + sg)) & 1u) << 26);
+// resolve_entry() hands the owner lane one word: observation id (bits 0..15) | next state (16..24) | terminal (25) | lumped (26).
+//
+// One 128-byte line per env, read by LPE lanes x UPL = 8 / LPE units of 16 bytes: round `it` (of LPE) serves the 64 / LPE envs
+// it * 64 / LPE + g, lane LPE g + jl reads UPL units of the line of env g's round.  CONTIG: lane jl reads units UPL jl ..
+// UPL jl + UPL - 1; otherwise units jl, jl + LPE, ... (one load instruction then covers LPE * 16 contiguous bytes of every
+// line).  issue() only requests; the resolve functions wait and hand each owner lane (lane l owns env l) its result, so that
+// independent work can be placed under the latency in between.  The uniforms travel to the reader lanes right behind the
+// line requests (send(), under their latency), not inside the resolve loops (A/B: profiles/r04_k_*).
+// One wave per SIMD runs the token step at 65,536 envs, so the resolve code IS on the critical path: per round it costs a
+// ballot per unit slot, the metadata extraction and the trips back to the owner lanes; fewer lanes per env = fewer rounds
+// (table below).
+// Lanes per env, measured (65,536 envs, scripts/runs_r04/gpu_q.sh and gpu_r.sh):
+//   token step (2 + 2 tokens, ~1.3 GiB of lines)   LPE 8: 13.2 us   4: 11.0   2: 10.6   1: 11.5      (interleaved units: +0.1)
+//   MDP step (config 2a, 8 GiB of lines)           LPE 8: 5.23 us   4: 5.12   2: 5.37   1: 5.81      (interleaved units: same)
+// fewer lanes per env = fewer resolve rounds but more distinct lines per load instruction; the token step has four resolves
+// per step on its critical path, the MDP step one.
+#ifndef XV_ANYMDP_STEP_LPE
+#define XV_ANYMDP_STEP_LPE 4
+#endif
+#ifndef XV_ANYMDP_TOK_LPE
+#define XV_ANYMDP_TOK_LPE 2
+#endif
+#ifndef XV_ANYMDP_COOP_CONTIG
+#define XV_ANYMDP_COOP_CONTIG 1
+#endif
+template <int LPE, bool CONTIG>
+struct AnyMDPCoopLineN {
+  static constexpr int UPL = 8 / LPE, EPR = 64 / LPE;          // units per lane, envs per round
+  static constexpr unsigned GM = (1u << LPE) - 1u;
+  uint4 v[LPE][UPL];
+  double ue[LPE];
+  static __device__ __forceinline__ constexpr int unit_of(int jl, int k) { return CONTIG ? jl * UPL + k : jl + k * LPE; }
+  static __device__ __forceinline__ int lane_of(int unit) { return CONTIG ? unit / UPL : unit % LPE; }   // within the group
+  static __device__ __forceinline__ int slot_of(int unit) { return CONTIG ? unit % UPL : unit / LPE; }
+  __device__ __forceinline__ void issue(const uint4* base, uint32_t line, int lane) {
+    const int g = lane / LPE, jl = lane % LPE;
+#pragma unroll
+    for (int it = 0; it < LPE; ++it) {
+      const uint32_t li = (uint32_t)__shfl((int)line, it * EPR + g);
+      const uint4* lp = base + (size_t)li * 8;
+#pragma unroll
+      for (int k = 0; k < UPL; ++k) v[it][k] = lp[unit_of(jl, k)];
+    }
   }
-  const uint32_t hw = sg < 2 ? b4.x : (sg < 4 ? b4.y : b4.z);
-  const uint32_t h16 = (hw >> (16 * (sg & 1))) & 0xFFFFu;   // lane of unit 6: the group's next state; of unit 7: its observation id
-  const uint32_t st = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h16, 0x111 /* row_shr:1: lane 7 <- lane 6 */, 0xF, 0xF, false);
-  return h16 | ((st & 0x1FFu) << 16) | (((b4.w >> sg) & 1u) << 25) | (((b4.w >> (8 + sg)) & 1u) << 26);
-}
+  // the same for the envs whose owner lane sets `want` only: the others read line 0 of the table (one cached line for
+  // all of them; their results are ignored).  A step is priced in random 128-byte lines (~5e10 per second): none is
+  // requested without need.  (An address select, not a branch: hipcc drains the load queue at the end of every
+  // conditional block that holds a load, which serialised the requests.)
+  __device__ __forceinline__ void issue_if(const uint4* base, uint32_t line, bool want, int lane) {
+    issue(base, want ? line : 0u, lane);
+  }
+  // the env's uniform to the lanes that hold its line: call right after issue*()
+  __device__ __forceinline__ void send(double u, int lane) {
+    const int g = lane / LPE;
+#pragma unroll
+    for (int it = 0; it < LPE; ++it) ue[it] = xv_shfl_f64(u, it * EPR + g);
+  }
+  // slot `ks` (a run-time value) of round `it`
+  __device__ __forceinline__ uint4 slot(int it, int ks) const {
+    uint4 r = v[it][0];
+#pragma unroll
+    for (int k = 1; k < UPL; ++k) {
+      const bool p = ks == k;
+      r.x = p ? v[it][k].x : r.x; r.y = p ? v[it][k].y : r.y; r.z = p ? v[it][k].z : r.z; r.w = p ? v[it][k].w : r.w;
+    }
+    return r;
+  }
+  // transition bucket line (anymdp_cutline.h): K cuts {cut, reward, noise} + metadata  ->  the reward pair of the group
+  // c = #{cut <= u} and meta = its observation id | next state << 16 | terminal flag << 25 | lumped << 26 (as
+  // anymdp_cut_meta); beyond = the line cannot answer this draw (c == K, or the group lumps several states): search the row
+  template <int FMT>
+  __device__ __forceinline__ void resolve_entry(double u, int lane, bool& beyond, float& rx, float& ry, uint32_t& meta) const {
+    constexpr int KC = FMT == 2 ? 6 : 7;
+    const int g = lane / LPE, jl = lane % LPE, qo = lane % EPR, ro = lane / EPR;
+    int cnt = 0;
+    rx = 0.0f; ry = 0.0f; meta = 0u;
+#pragma unroll
+    for (int it = 0; it < LPE; ++it) {
+      int cg = 0, co = 0;   // reader side: the env this lane group serves; owner side: the env this lane owns
+#pragma unroll
+      for (int k = 0; k < UPL; ++k) {
+        const unsigned long long m = __ballot(unit_of(jl, k) < KC && xv_u2d(v[it][k].x, v[it][k].y) <= ue[it]);
+        cg += __popc((unsigned)(m >> (LPE * g)) & GM);
+        co += __popc((unsigned)(m >> (LPE * qo)) & GM);
+      }
+      const int sg = cg < KC - 1 ? cg : KC - 1, so = co < KC - 1 ? co : KC - 1;
+      const uint4 b7 = v[it][UPL - 1];                // unit 7 on the last lane of the group
+      uint32_t packed, st16 = 0u;
+      if (FMT == 1) {
+        const uint32_t ow = sg < 4 ? b7.x : b7.y, sw = sg < 4 ? b7.z : b7.w;
+        const int sh = 8 * (sg & 3);
+        packed = ((ow >> sh) & 0xFFu) | (((sw >> sh) & 0xFFu) << 16) | (((b7.y >> (24 + sg)) & 1u) << 25) |
+                 (((b7.w >> (24 + sg)) & 1u) << 26);
+      } else {
+        const uint32_t ow = sg < 2 ? b7.x : (sg < 4 ? b7.y : b7.z);
+        packed = ((ow >> (16 * (sg & 1))) & 0xFFFFu) | (((b7.w >> sg) & 1u) << 25) | (((b7.w >> (8 + sg)) & 1u) << 26);
+        const uint4 b6 = v[it][slot_of(6)];           // unit 6 (the next states) on lane lane_of(6) of the group
+        const uint32_t sw = sg < 2 ? b6.x : (sg < 4 ? b6.y : b6.z);
+        st16 = (sw >> (16 * (sg & 1))) & 0x1FFu;
+      }
+      const uint4 e = slot(it, slot_of(sg));          // group sg's entry, meaningful on lane lane_of(sg) of the group
+      const float px = __shfl(__uint_as_float(e.z), LPE * qo + lane_of(so));
+      const float py = __shfl(__uint_as_float(e.w), LPE * qo + lane_of(so));
+      uint32_t pm = (uint32_t)__shfl((int)packed, LPE * qo + LPE - 1);
+      if (FMT == 2) pm |= (uint32_t)__shfl((int)st16, LPE * qo + lane_of(6)) << 16;
+      { const bool own = ro == it; cnt = own ? co : cnt; rx = own ? px : rx; ry = own ? py : ry; meta = own ? pm : meta; }
+    }
+    beyond = cnt >= KC || ((meta >> 26) & 1u);
+  }
+  // observation bucket line (anymdp_cutline.h, 14 cuts): units 0..6 = the cuts as doubles (2.0 when unused), unit 7 = the
+  // groups' symbol ids (bytes 0..13) and their lumped / unused bits (bits 16..29 of .w)  ->  id of the group c = #{cut <= u};
+  // beyond = the line cannot answer this draw (c == 14, or the group lumps several symbols): search the row
+  __device__ __forceinline__ void resolve_obs(double u, int lane, bool& beyond, int& id) const {
+    const int g = lane / LPE, jl = lane % LPE, qo = lane % EPR, ro = lane / EPR;
+    int cnt = 0;
+    uint32_t meta = 0u;
+#pragma unroll
+    for (int it = 0; it < LPE; ++it) {
+      int cg = 0, co = 0;
+#pragma unroll
+      for (int k = 0; k < UPL; ++k) {
+        const bool cutu = unit_of(jl, k) < 7;
+        const unsigned long long m0 = __ballot(cutu && xv_u2d(v[it][k].x, v[it][k].y) <= ue[it]);
+        const unsigned long long m1 = __ballot(cutu && xv_u2d(v[it][k].z, v[it][k].w) <= ue[it]);
+        cg += __popc((unsigned)(m0 >> (LPE * g)) & GM) + __popc((unsigned)(m1 >> (LPE * g)) & GM);
+        co += __popc((unsigned)(m0 >> (LPE * qo)) & GM) + __popc((unsigned)(m1 >> (LPE * qo)) & GM);
+      }
+      const int sg = cg < 13 ? cg : 13;
+      const uint4 b4 = v[it][UPL - 1];
+      const uint32_t word = sg < 4 ? b4.x : (sg < 8 ? b4.y : (sg < 12 ? b4.z : b4.w));
+      const uint32_t packed = ((word >> (8 * (sg & 3))) & 0xFFu) | (((b4.w >> (16 + sg)) & 1u) << 8);
+      const uint32_t pm = (uint32_t)__shfl((int)packed, LPE * qo + LPE - 1);
+      { const bool own = ro == it; cnt = own ? co : cnt; meta = own ? pm : meta; }
+    }
+    beyond = cnt >= 14 || ((meta >> 8) & 1u);
+    id = (int)(meta & 0xFFu);
+  }
+};
+typedef AnyMDPCoopLineN<XV_ANYMDP_STEP_LPE, XV_ANYMDP_COOP_CONTIG != 0> AnyMDPStepLine;
+typedef AnyMDPCoopLineN<XV_ANYMDP_TOK_LPE, XV_ANYMDP_COOP_CONTIG != 0> AnyMDPTokLine;
 
 // T_steps == 1: one vector step.  T_steps > 1: fused rollout, io arrays are [T][n_env], mode SAME_STEP.
 // FAST: fence line + block line, per-env reset record; otherwise per-lane binary search and per-task tables.
@@ -294,48 +420,26 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
     float2 rsv;
     bool need_fence = true;
     if (BK) {
-      // the ONE line: bucket floor(u * NBK) of the row.  Iteration `it` serves envs 8*it .. 8*it+7 as below.
+      // the ONE line: bucket floor(u * NBK) of the row, read by the lanes of the env's group (AnyMDPCoopLineN)
       const uint32_t bk = rowidx * (uint32_t)P.NBK + (uint32_t)(int)(u * (double)P.NBK);
-      constexpr int KC = BK == 2 ? 6 : 7;   // cuts per line
-      int cnt_own = 0;
-      float rx = 0.0f, ry = 0.0f;
-      uint32_t meta_own = 0;
-      uint32_t li[8];
-#pragma unroll
-      for (int it = 0; it < 8; ++it) li[it] = (uint32_t)__shfl((int)bk, it * 8 + g);
-      uint4 bv[8];
-#pragma unroll
-      for (int it = 0; it < 8; ++it) bv[it] = P.bucket[(size_t)li[it] * 8 + j];
+      AnyMDPStepLine L;
+      L.issue(P.bucket, bk, lane);
       if (ROLLOUT && io.action && ts + 1 < T) a_next = io.action[o + P.n_env];   // prefetch behind the line
       __builtin_amdgcn_sched_barrier(0);
       late_draws();
       __builtin_amdgcn_sched_barrier(0);
-      double ue[8];
-#pragma unroll
-      for (int it = 0; it < 8; ++it) ue[it] = xv_shfl_f64(u, it * 8 + g);
+      L.send(u, lane);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const unsigned long long m = __ballot(j < KC && xv_u2d(bv[it].x, bv[it].y) <= ue[it]);
-        const int cg = __popc((unsigned)(m >> (8 * g)) & 0xFFu);   // reader side: the env this lane group serves
-        const int co = __popc((unsigned)(m >> (8 * j)) & 0xFFu);   // owner side: the env this lane owns
-        const uint32_t packed = anymdp_cut_meta<BK>(bv[it], cg < KC - 1 ? cg : KC - 1);
-        const int so = co < KC - 1 ? co : KC - 1;
-        const float px = __shfl(__uint_as_float(bv[it].z), 8 * j + so);
-        const float py = __shfl(__uint_as_float(bv[it].w), 8 * j + so);
-        const uint32_t pm = (uint32_t)__shfl((int)packed, 8 * j + 7);
-#if XV_ANYMDP_SELECT
-        { const bool own = g == it; cnt_own = own ? co : cnt_own; rx = own ? px : rx; ry = own ? py : ry; meta_own = own ? pm : meta_own; }
-#else
-        if (g == it) { cnt_own = co; rx = px; ry = py; meta_own = pm; }
-#endif
-      }
+      bool beyond_own;
+      float rx, ry;
+      uint32_t meta_own;
+      L.template resolve_entry<BK>(u, lane, beyond_own, rx, ry, meta_own);
       s2 = (int)((meta_own >> 16) & 0x1FFu);
       rsv = make_float2(rx, ry);
       obs2 = (int)(meta_own & 0xFFFFu);
       term2 = (meta_own >> 25) & 1u;
       // wave-uniform: some env's draw lies beyond the last cut of its line or in a group that lumps several states
-      need_fence = __ballot(cnt_own >= KC || ((meta_own >> 26) & 1u)) != 0ull;
+      need_fence = __ballot(beyond_own) != 0ull;
     }
     if (FAST && need_fence) {
       const uint32_t fl = rowidx * (uint32_t)P.RL;   // fence line of the row
@@ -862,102 +966,13 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_kernel(AnyMDPArgs P, AnyM
 
 // ------------------------------------------------------------------------------------------------
 // Cooperative multi-token step (round 3): the same dependent-level economy as the MDP step kernel.  A transition token is
-// ONE bucket line read by the 8 lanes of the env's group (anymdp_coop_entry_lines); an observation token is one
+// ONE bucket line read by the lanes of the env's group (AnyMDPCoopLineN); an observation token is one
 // OBSERVATION bucket line — 15 consecutive entries of obs_cdf[t][k][s][:] that start at I = #{cdf <= b / NBK} plus I
 // itself (xv_anymdp_build_buckets builds them beside the transition lines) — and the lines of two observation tokens
 // are in flight together.  A draw whose line does not contain its answer (all entries <= u) takes the per-lane binary
 // search (rare; per-lane branch).  Same draws, same results as anymdp_tok_step_kernel.
 // ------------------------------------------------------------------------------------------------
-// One 128-byte line per env, read by the 8 lanes of the env's group: iteration `it` serves envs 8 it .. 8 it + 7, lanes
-// 8 q .. 8 q + 7 read the 8 units of the line of env 8 it + q.  issue() only requests; the resolve functions wait and
-// hand each owner lane its result, so that independent work can be placed under the latency in between.
-#ifndef XV_ANYMDP_COOP_PRE
-#define XV_ANYMDP_COOP_PRE 1   // the uniforms travel to the reader lanes right behind the line requests (under their latency), not
-#endif                         // inside the resolve loops (A/B: profiles/r04_k_*)
-struct AnyMDPCoopLine {
-  uint4 bv[8];
-#if XV_ANYMDP_COOP_PRE
-  double ue[8];
-#endif
-  __device__ __forceinline__ void issue(const uint4* base, uint32_t line, int lane) {
-    const int g = lane >> 3, j = lane & 7;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const uint32_t li = (uint32_t)__shfl((int)line, it * 8 + g);
-      bv[it] = base[(size_t)li * 8 + j];
-    }
-  }
-  // the env's uniform to the 8 lanes that hold its line: call right after issue*()
-  __device__ __forceinline__ void send(double u, int lane) {
-#if XV_ANYMDP_COOP_PRE
-    const int g = lane >> 3;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) ue[it] = xv_shfl_f64(u, it * 8 + g);
-#endif
-  }
-  __device__ __forceinline__ double uni(double u, int it, int g) const {
-#if XV_ANYMDP_COOP_PRE
-    return ue[it];
-#else
-    return xv_shfl_f64(u, it * 8 + g);
-#endif
-  }
-  // the same for the envs whose owner lane sets `want` only: the others read line 0 of the table (one cached line for
-  // all of them; their results are ignored).  A step is priced in random 128-byte lines (~5e10 per second): none is
-  // requested without need.  (An address select, not a branch: hipcc drains the load queue at the end of every
-  // conditional block that holds a load, which serialised the eight requests.)
-  __device__ __forceinline__ void issue_if(const uint4* base, uint32_t line, bool want, int lane) {
-    issue(base, want ? line : 0u, lane);
-  }
-  // transition bucket line (anymdp_cutline.h): K cuts {cut, reward, noise} + metadata  ->  the reward pair of the group
-  // c = #{cut <= u} and meta = its observation id | next state << 16 | terminal flag << 25 (anymdp_cut_meta);
-  // beyond = the line cannot answer this draw (c == K, or the group lumps several states): search the row
-  template <int FMT>
-  __device__ __forceinline__ void resolve_entry(double u, int lane, bool& beyond, float& rx, float& ry, uint32_t& meta) const {
-    constexpr int KC = FMT == 2 ? 6 : 7;
-    const int g = lane >> 3, j = lane & 7;
-    int cnt = 0;
-    rx = 0.0f; ry = 0.0f; meta = 0u;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const double ue = uni(u, it, g);
-      const unsigned long long m = __ballot(j < KC && xv_u2d(bv[it].x, bv[it].y) <= ue);
-      const int cg = __popc((unsigned)(m >> (8 * g)) & 0xFFu);   // reader side: the env this lane group serves
-      const int co = __popc((unsigned)(m >> (8 * j)) & 0xFFu);   // owner side: the env this lane owns
-      const uint32_t packed = anymdp_cut_meta<FMT>(bv[it], cg < KC - 1 ? cg : KC - 1);
-      const int so = co < KC - 1 ? co : KC - 1;
-      const float px = __shfl(__uint_as_float(bv[it].z), 8 * j + so);
-      const float py = __shfl(__uint_as_float(bv[it].w), 8 * j + so);
-      const uint32_t pm = (uint32_t)__shfl((int)packed, 8 * j + 7);
-      { const bool own = g == it; cnt = own ? co : cnt; rx = own ? px : rx; ry = own ? py : ry; meta = own ? pm : meta; }
-    }
-    beyond = cnt >= KC || ((meta >> 26) & 1u);
-  }
-  // observation bucket line (anymdp_cutline.h, 14 cuts): units 0..6 = the cuts as doubles (2.0 when unused), unit 7 = the
-  // groups' symbol ids (bytes 0..13) and their lumped / unused bits (bits 16..29 of .w)  ->  id of the group c = #{cut <= u};
-  // beyond = the line cannot answer this draw (c == 14, or the group lumps several symbols): search the row
-  __device__ __forceinline__ void resolve_obs(double u, int lane, bool& beyond, int& id) const {
-    const int g = lane >> 3, j = lane & 7;
-    int cnt = 0;
-    uint32_t meta = 0u;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const double ue = uni(u, it, g);
-      const unsigned long long m0 = __ballot(j < 7 && xv_u2d(bv[it].x, bv[it].y) <= ue);
-      const unsigned long long m1 = __ballot(j < 7 && xv_u2d(bv[it].z, bv[it].w) <= ue);
-      const int cg = __popc((unsigned)(m0 >> (8 * g)) & 0xFFu) + __popc((unsigned)(m1 >> (8 * g)) & 0xFFu);   // reader side
-      const int co = __popc((unsigned)(m0 >> (8 * j)) & 0xFFu) + __popc((unsigned)(m1 >> (8 * j)) & 0xFFu);   // owner side
-      const int sg = cg < 13 ? cg : 13;
-      const uint4 b4 = bv[it];
-      const uint32_t word = sg < 4 ? b4.x : (sg < 8 ? b4.y : (sg < 12 ? b4.z : b4.w));
-      const uint32_t packed = ((word >> (8 * (sg & 3))) & 0xFFu) | (((b4.w >> (16 + sg)) & 1u) << 8);
-      const uint32_t pm = (uint32_t)__shfl((int)packed, 8 * j + 7);
-      { const bool own = g == it; cnt = own ? co : cnt; meta = own ? pm : meta; }
-    }
-    beyond = cnt >= 14 || ((meta >> 8) & 1u);
-    id = (int)(meta & 0xFFu);
-  }
-};
+// (the line reader itself, AnyMDPCoopLineN, sits above anymdp_step_body: the MDP step reads its bucket line the same way)
 
 // observation bucket lines: one thread per (row obs_cdf[t][k][s][:], bucket) chooses 14 cuts (anymdp_cutline.h) and writes
 // the line; n_obs <= 256 (symbol ids are bytes).  census as in anymdp_build_cutlines_kernel (every row counts as live).
@@ -999,7 +1014,8 @@ static __global__ __launch_bounds__(256) void anymdp_build_obs_cutlines_kernel(c
   }
 }
 
-template <bool INJECT, int FMT>
+// PAIR: d_obs > 1 (two observation lines in flight per round of the observation loop; a single-token POMDP has no second line)
+template <bool INJECT, int FMT, bool PAIR>
 __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P, AnyMDPTokArgs K, AnyMDPTokIO io, int mode) {
   const uint64_t tick_now = xv_launch_tick(P.tick, P.tick_dev);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1066,10 +1082,10 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
   const bool restarts = mode != XV_AUTORESET_DISABLED;   // wave-uniform
   int k0r = 0, s_new = 0;
   double uS0 = 0.0, uS1 = 0.0, uR0 = 0.0, uR1 = 0.0;
-  const int kR1 = DO > 1 ? 1 : 0;
+  const int kR1 = PAIR && DO > 1 ? 1 : 0;
   auto early_work = [&]() {
     obs_draw(0, uS0, uR0);
-    obs_draw(kR1, uS1, uR1);
+    if (PAIR) obs_draw(kR1, uS1, uR1);
     pin2(uS0, uS1);
     if (restarts) {
       double ur;
@@ -1099,7 +1115,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
     int a = a_cur;
     if (a < 0 || a >= A) { if (alive && valid) err |= XV_DEVERR_ACTION_RANGE; a = a < 0 ? 0 : A - 1; }
     const uint32_t rowidx = ((uint32_t)t * S + s) * A + a;
-    AnyMDPCoopLine L;
+    AnyMDPTokLine L;
     L.issue_if(P.bucket, rowidx * (uint32_t)NBK + (uint32_t)(int)(u_cur * (double)NBK), alive, lane);
     L.send(u_cur, lane);
     __builtin_amdgcn_sched_barrier(0);
@@ -1158,36 +1174,43 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
   // ---- observation tokens (:148-157) of the state the step ended in, two lines in flight; an env that restarts reports
   //      the observation of its restart state instead (and the step's as final_obs) ----
   for (int kp = 0; kp < DO; kp += 2) {
-    const int k1 = kp + 1 < DO ? kp + 1 : kp;
+    const int k1 = PAIR && kp + 1 < DO ? kp + 1 : kp;
     double u0 = uS0, u1 = uS1, v0 = uR0, v1 = uR1;
     if (kp > 0) {
       obs_draw(kp, u0, v0);
       obs_draw(k1, u1, v1);
     }
-    AnyMDPCoopLine S0, S1, Q0, Q1;   // the step's two observation lines and, for restarting envs, the restart state's
+    AnyMDPTokLine S0, S1, Q0, Q1;   // the step's two observation lines and, for restarting envs, the restart state's
     const bool wq = restarts && do_reset;
     S0.issue_if(K.obs_bucket, obs_line(kp, s, u0), !skip, lane);
-    S1.issue_if(K.obs_bucket, obs_line(k1, s, u1), !skip && k1 != kp, lane);
+    if (PAIR) S1.issue_if(K.obs_bucket, obs_line(k1, s, u1), !skip && k1 != kp, lane);
     if (restarts) {
       Q0.issue_if(K.obs_bucket, obs_line(kp, s_new, v0), wq, lane);
-      Q1.issue_if(K.obs_bucket, obs_line(k1, s_new, v1), wq && k1 != kp, lane);
+      if (PAIR) Q1.issue_if(K.obs_bucket, obs_line(k1, s_new, v1), wq && k1 != kp, lane);
     }
-    S0.send(u0, lane); S1.send(u1, lane);
-    if (restarts) { Q0.send(v0, lane); Q1.send(v1, lane); }
+    S0.send(u0, lane);
+    if (PAIR) S1.send(u1, lane);
+    if (restarts) {
+      Q0.send(v0, lane);
+      if (PAIR) Q1.send(v1, lane);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    int c0, c1;
-    bool f0, f1;
+    // (every line requested is resolved by every wave: skipping the resolves nobody needs — the restart state's when no env
+    //  of the wave restarts — behind wave-uniform branches cost 0.7 us at 2 + 2 tokens, scripts/runs_r04/gpu_s.sh: the
+    //  branches split the schedule the resolves otherwise share)
+    int c0, c1 = 0;
+    bool f0, f1 = false;
     S0.resolve_obs(u0, lane, f0, c0);
-    S1.resolve_obs(u1, lane, f1, c1);
-    const int ob0 = obs_pick(kp, s, u0, c0, f0, !skip), ob1 = obs_pick(k1, s, u1, c1, f1, !skip && k1 != kp);
+    if (PAIR) S1.resolve_obs(u1, lane, f1, c1);
+    const int ob0 = obs_pick(kp, s, u0, c0, f0, !skip), ob1 = PAIR ? obs_pick(k1, s, u1, c1, f1, !skip && k1 != kp) : 0;
     int rb0 = 0, rb1 = 0;
     if (restarts) {
-      int cr0, cr1;
-      bool fr0, fr1;
+      int cr0, cr1 = 0;
+      bool fr0, fr1 = false;
       Q0.resolve_obs(v0, lane, fr0, cr0);
-      Q1.resolve_obs(v1, lane, fr1, cr1);
+      if (PAIR) Q1.resolve_obs(v1, lane, fr1, cr1);
       rb0 = obs_pick(kp, s_new, v0, cr0, fr0, wq);
-      rb1 = obs_pick(k1, s_new, v1, cr1, fr1, wq && k1 != kp);
+      if (PAIR) rb1 = obs_pick(k1, s_new, v1, cr1, fr1, wq && k1 != kp);
     }
     if (valid) {
       if (!skip || do_reset) {
@@ -1989,8 +2012,14 @@ static int anymdp_tok_launch_step(xv_anymdp* h, const AnyMDPTokIO& io, int mode)
   AnyMDPTokArgs K{h->obs_cdf, h->n_obs, h->d_obs, h->d_act, h->obs_bucket};
   const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
   if (anymdp_tok_coop(h)) {   // bucket search: the cooperative kernel
-    if (h->a.bfmt == 1) hipLaunchKernelGGL((anymdp_tok_step_coop_kernel<INJECT, 1>), grid, block, 0, h->eng->stream, h->a, K, io, mode);
-    else hipLaunchKernelGGL((anymdp_tok_step_coop_kernel<INJECT, 2>), grid, block, 0, h->eng->stream, h->a, K, io, mode);
+    const bool pair = K.d_obs > 1;
+    if (h->a.bfmt == 1) {
+      if (pair) hipLaunchKernelGGL((anymdp_tok_step_coop_kernel<INJECT, 1, true>), grid, block, 0, h->eng->stream, h->a, K, io, mode);
+      else hipLaunchKernelGGL((anymdp_tok_step_coop_kernel<INJECT, 1, false>), grid, block, 0, h->eng->stream, h->a, K, io, mode);
+    } else {
+      if (pair) hipLaunchKernelGGL((anymdp_tok_step_coop_kernel<INJECT, 2, true>), grid, block, 0, h->eng->stream, h->a, K, io, mode);
+      else hipLaunchKernelGGL((anymdp_tok_step_coop_kernel<INJECT, 2, false>), grid, block, 0, h->eng->stream, h->a, K, io, mode);
+    }
   } else {
     hipLaunchKernelGGL(anymdp_tok_step_kernel<INJECT>, grid, block, 0, h->eng->stream, h->a, K, io, mode);
   }
