@@ -610,6 +610,8 @@ int xv_maze_render(xv_maze* h, uint8_t* frames, float* command_rgb);
 int xv_maze_set_move_kernel(xv_maze* h, int kernel);
 #define XV_MAZE_FILTER_EXACT 0
 #define XV_MAZE_FILTER_F32 1
+#define XV_MAZE_FILTER_EXACT_DIRECT 2   /* EXACT's bytes with every pixel filtered in the reference's typing directly (EXACT
+                                          speculates in float64 sums and re-runs a pixel whose byte is not certain) */
 int xv_maze_set_precision(xv_maze* h, int filter);
 /* Which typing of the reference's ray-caster source the frames follow.  NUMPY2 (default): its @njit functions run as plain
  * Python under NumPy >= 2 (Python floats are weak, so DDA_2D and the wall-column geometry stay in the float32 of the

@@ -495,11 +495,11 @@ def quick_families(steps=200, warmup=20):
         us = r["us_per_step"]["step (both)"]
         return {"config": "BASELINE configs[3]: " + r["workload"], "ms_per_step": us * 1e-3, "env_steps_per_s": r["env_steps_per_s"],
                 "us_per_step": r["us_per_step"], "dtype": r["dtype"],
-                # the ray caster (92 % of the step) is bound by fp64 VALU issue — the 16-tap filter in the reference's typing —
-                # not by HBM: `bound` / `frac` are that kernel's; the HBM view of the same step is kept beside it
+                # the ray caster (90 % of the step) is bound by fp64 VALU issue and texture requests — the 16-tap filter with the
+                # reference's bytes — not by HBM: `bound` / `frac` are that kernel's; the HBM view of the same step is kept beside it
                 "roofline": {"bound": "valu_f64", "frac": r["valu_f64"]["frac"], "achieved": r["valu_f64"]["achieved"],
                              "peak": r["valu_f64"]["peak"], "unit": r["valu_f64"]["unit"], "model": r["valu_f64"]["model"],
-                             "kernel": "maze_raycast_kernel (exact filter; + maze_step9_kernel for the move)",
+                             "kernel": "maze_raycast_kernel (exact filter, speculated; + maze_step9_kernel for the move)",
                              "valu_f64_frac": r["valu_f64"]["frac"],
                              "hbm": {"frac": r["roofline"]["frac"], "algorithmic_bytes": (3 * 64 * 64 + 64) * 16384, "peak": HBM_PEAK,
                                      "unit": "GB/s", "achieved": r["roofline"]["achieved"]},
@@ -578,9 +578,12 @@ def bench_maze(args, res, precision="exact", move_kernel="auto"):
     us_full = timed(full, steps, 4)
     env.close()
     algo = (3 * res * res + 64) * n
-    # the ray-caster is bound by fp64 VALU issue, not HBM: a painted pixel needs >= 16 taps x (8 weight + 3 x 5 colour)
-    # = 368 fp64-pipe instructions + ~40 of geometry; peak = 1024 SIMDs x 64 lanes x 2.4 GHz / 4 cycles per wave-instr
-    valu_ops = 408.0 * res * res * n
+    # the ray-caster is bound by fp64 VALU issue, not HBM: in the reference's typing a painted pixel needs >= 16 taps x
+    # (8 weight + 3 x 5 colour) = 368 fp64-pipe instructions + ~40 of geometry (the direct filter); the default filter
+    # speculates with float64 sums, 16 x (4 + 3 x 3) + 40 = 248, and re-runs the ~1 pixel in 3,000 whose byte is not certain;
+    # peak = 1024 SIMDs x 64 lanes x 2.4 GHz / 4 cycles per wave-instr
+    per_pixel = 248.0 if precision == "exact" else 408.0
+    valu_ops = per_pixel * res * res * n
     valu_peak = 1024 * 64 * 2.4e9 / 4
     return {"family": "mazeworld", "filter": precision, "move_kernel": move_kernel,
             "workload": "15x15 mazes, 16,384 envs = 256 tasks x 64, %dx%d frames" % (res, res),
@@ -592,7 +595,7 @@ def bench_maze(args, res, precision="exact", move_kernel="auto"):
                          "note": "the 16-tap fp64 texture filter (VALU issue), not HBM, bounds the ray-caster"},
             "valu_f64": {"achieved": valu_ops / (us_render * 1e-6) / 1e12, "peak": valu_peak / 1e12,
                          "unit": "T lane-instr/s", "frac": valu_ops / (us_render * 1e-6) / valu_peak,
-                         "model": "408 fp64-pipe instructions per pixel (all pixels counted as painted)"}}
+                         "model": "%d fp64-pipe instructions per pixel (all pixels counted as painted)" % per_pixel}}
 
 
 def bench_teacher(args, res=64):
@@ -664,7 +667,7 @@ if __name__ == "__main__":
         elif f.startswith("maze"):
             tok = f[4:].split("_")
             mv = {"m1": "lane_per_env", "m3": "three_lanes", "m9": "nine_lanes"}
-            r = bench_maze(args, int(tok[0]), "f32" if "f32" in tok else "exact",
+            r = bench_maze(args, int(tok[0]), "f32" if "f32" in tok else ("exact_direct" if "direct" in tok else "exact"),
                            next((mv[t] for t in tok if t in mv), "auto"))
         else:
             continue

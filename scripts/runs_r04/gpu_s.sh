@@ -1,4 +1,4 @@
-# A/B: token step with the unneeded observation resolves skipped (in-tree) vs all four resolved (tbase)
+# A/B: restart-state observation lines read by the owner lane alone (in-tree) vs by lane pairs (tbase)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_anymdp_tok.py tests/test_gpu_mixed.py tests/test_gpu_fullsize.py -m gpu -q -x > gpurun_out/r04_s_pytest.log 2>&1; echo "pytest rc=$? $(grep -h 'passed\|failed' gpurun_out/r04_s_pytest.log | tail -1)"

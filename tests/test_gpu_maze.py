@@ -227,6 +227,33 @@ def test_f32_filter_vs_exact_and_oracle_on_a_batch(res):
     assert frac <= 0.005 and worst <= 1, (frac, worst)
 
 
+@pytest.mark.parametrize("res,per,typing", [((64, 64), 700, "numpy2"), ((256, 256), 20, "numpy2"), ((96, 48), 150, "numba")])
+def test_speculated_exact_filter_paints_the_bytes_of_the_direct_one(res, per, typing):
+    """precision="exact" (default) runs the 16 taps with float64 sums and re-runs a pixel in the reference's typing when its
+    byte is not certain (csrc/maze.hip: mz_interpolate_spec); "exact_direct" evaluates the reference's typing for every
+    pixel.  The frames must be the same bytes — here on 8.6M / 3.9M / 2.1M pixels of batches walked 10 and 25 steps (walls
+    at every distance, floors, ceilings, landmark overlays)."""
+    tasks = [load_maze_golden(p)[1] for p in FILES]
+    env_task = np.repeat(np.arange(len(tasks), dtype=np.int32), per)
+    n = len(env_task)
+    a = np.random.RandomState(11).randint(0, 16, (25, n)).astype(np.int32)
+    frames = {}
+    for prec in ("exact", "exact_direct"):
+        env = MazeWorldVecEnv(n, resolution=res, textures=tex(), autoreset_mode="same_step", precision=prec, typing=typing,
+                              seed=3)
+        env.set_task(tasks, env_task_index=env_task)
+        env.reset()
+        got = []
+        for t in range(25):
+            out = env.step(a[t])
+            if t in (9, 24):
+                got.append(_np(out[0]).copy())
+        frames[prec] = got
+        env.close()
+    for f0, f1 in zip(frames["exact"], frames["exact_direct"]):
+        assert f0.shape == f1.shape and np.array_equal(f0, f1), int((f0 != f1).sum())
+
+
 @pytest.mark.parametrize("mode,space", [("same_step", "Discrete16"), ("next_step", "Discrete32"), ("disabled", "Continuous"),
                                         ("same_step", "turns")])
 def test_nine_lane_move_kernel_equals_the_lane_per_env_kernel(mode, space):

@@ -206,7 +206,7 @@ struct AnyMDPCoopLineN {
     const int g = lane / LPE, jl = lane % LPE;
 #pragma unroll
     for (int it = 0; it < LPE; ++it) {
-      const uint32_t li = (uint32_t)__shfl((int)line, it * EPR + g);
+      const uint32_t li = LPE == 1 ? line : (uint32_t)__shfl((int)line, it * EPR + g);
       const uint4* lp = base + (size_t)li * 8;
 #pragma unroll
       for (int k = 0; k < UPL; ++k) v[it][k] = lp[unit_of(jl, k)];
@@ -223,7 +223,7 @@ struct AnyMDPCoopLineN {
   __device__ __forceinline__ void send(double u, int lane) {
     const int g = lane / LPE;
 #pragma unroll
-    for (int it = 0; it < LPE; ++it) ue[it] = xv_shfl_f64(u, it * EPR + g);
+    for (int it = 0; it < LPE; ++it) ue[it] = LPE == 1 ? u : xv_shfl_f64(u, it * EPR + g);
   }
   // slot `ks` (a run-time value) of round `it`
   __device__ __forceinline__ uint4 slot(int it, int ks) const {
@@ -281,6 +281,17 @@ struct AnyMDPCoopLineN {
   // groups' symbol ids (bytes 0..13) and their lumped / unused bits (bits 16..29 of .w)  ->  id of the group c = #{cut <= u};
   // beyond = the line cannot answer this draw (c == 14, or the group lumps several symbols): search the row
   __device__ __forceinline__ void resolve_obs(double u, int lane, bool& beyond, int& id) const {
+    if constexpr (LPE == 1) {   // the owner lane holds its whole line: no ballots, no trips
+      int c = 0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) c += (int)(xv_u2d(v[0][k].x, v[0][k].y) <= u) + (int)(xv_u2d(v[0][k].z, v[0][k].w) <= u);
+      const int sg = c < 13 ? c : 13;
+      const uint4 b4 = v[0][7];
+      const uint32_t word = sg < 4 ? b4.x : (sg < 8 ? b4.y : (sg < 12 ? b4.z : b4.w));
+      beyond = c >= 14 || ((b4.w >> (16 + sg)) & 1u);
+      id = (int)((word >> (8 * (sg & 3))) & 0xFFu);
+      return;
+    }
     const int g = lane / LPE, jl = lane % LPE, qo = lane % EPR, ro = lane / EPR;
     int cnt = 0;
     uint32_t meta = 0u;
@@ -1181,6 +1192,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
       obs_draw(k1, u1, v1);
     }
     AnyMDPTokLine S0, S1, Q0, Q1;   // the step's two observation lines and, for restarting envs, the restart state's
+    // (Q0, Q1 read by the owner lane alone, LPE 1 — most lanes then read line 0: no difference, scripts/runs_r04/gpu_s.sh)
     const bool wq = restarts && do_reset;
     S0.issue_if(K.obs_bucket, obs_line(kp, s, u0), !skip, lane);
     if (PAIR) S1.issue_if(K.obs_bucket, obs_line(k1, s, u1), !skip && k1 != kp, lane);

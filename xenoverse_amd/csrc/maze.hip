@@ -556,6 +556,10 @@ __global__ __launch_bounds__(256) void maze_move_sort_kernel(MazeArgs P, const v
   if (valid && still) list[P.n_env - 1 - (base_s + __popcll(ms & below))] = e;
 }
 
+__device__ __forceinline__ uint8_t mz_clip_u8(double v) {   // numpy.clip(v, 0, 255) -> int32 -> uint8
+  return (uint8_t)(int)__builtin_fmin(__builtin_fmax(v, 0.0), 255.0);   // v_max/v_min_f64: no NaNs reach here
+}
+
 // The 16 packed texels of the 4 x 4 filter window, q[row xx + 1][tap yy + 1], rows ib - 1 .. ib + 2 (mod 256), taps
 // (jb - 1) & 255 ... + 3 (rows are padded: no wrap in y).
 template <bool PAIRS>
@@ -599,9 +603,10 @@ __device__ __forceinline__ void mz_fetch_window(const void* __restrict__ texv, i
 // The weight 1 - 10*dist/d2 divides by the same d2 for all 16 taps (d2 in [1e-8, ~1e3], 10*dist 0 or in
 // [~1e-40, 1e4]): mz_div, 3 instructions per tap instead of 14.
 // dist >= 0 and d2 > 0 make the reference's upper clamp (wht > 1 -> 1) unreachable; the lower one is a v_max_f64.
-template <bool PACKED>
+// W: the 4 x 4 window is already in registers (`win`, mz_fetch_window); otherwise PACKED says which copy `texv` is.
+template <bool PACKED, bool W = false>
 __device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, double i, double j, double d,
-                                               double px, double py, double (&out)[3]) {
+                                               double px, double py, double (&out)[3], const uint32_t (*win)[4] = nullptr) {
   double d2 = d * d;
   if (d2 < 1.0e-8) d2 = 1.0e-8;
   const MzDivisor D2 = mz_divisor(d2);
@@ -615,7 +620,7 @@ __device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, do
     bb[yy + 1] = b * b;
   }
   uint32_t qw[4][4];
-  if (PACKED) mz_fetch_window<false>(texv, ib, jb, qw);
+  if (PACKED && !W) mz_fetch_window<false>(texv, ib, jb, qw);
 #pragma unroll
   for (int xx = -1; xx < 3; ++xx) {
     const int x = ib + xx;
@@ -628,8 +633,8 @@ __device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, do
       const double wht = __builtin_fmax(1.0 - mz_div(10 * dist, D2), 0.01);
       sum_wht += wht;
       float t0, t1, t2;
-      if (PACKED) {
-        const uint32_t p = qw[xx + 1][yy + 1];
+      if (PACKED || W) {
+        const uint32_t p = W ? win[xx + 1][yy + 1] : qw[xx + 1][yy + 1];
         t0 = (float)(p & 0xFFu); t1 = (float)((p >> 8) & 0xFFu); t2 = (float)((p >> 16) & 0xFFu);
       } else {
         const float* tp = static_cast<const float*>(texv) + ((size_t)xv * 256 + ((jb + yy) & 255)) * 3;
@@ -642,6 +647,60 @@ __device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, do
   }
   const MzDivisor SW = mz_divisor(sum_wht);   // in [0.16, 16]
   out[0] = mz_div((double)s0, SW); out[1] = mz_div((double)s1, SW); out[2] = mz_div((double)s2, SW);
+}
+
+// The exact filter, speculated (the default on packed textures, XV_MAZE_FILTER_EXACT).  What the reference's typing costs
+// is the float32 accumulator: every tap rounds three running sums to float32 and widens them again (3 x 6 of the tap's 26
+// fp64-rate instructions), and the weight is a true division.  mz_interpolate_spec runs the same taps on the same window
+// with float64 sums (fma), the weight as fma(-dist, 10 / d2, 1): 13 instructions per tap.  Its colour c' differs from the
+// reference's c by a PROVEN bound, and the pixel byte is floor(clip(L (A + B c))), monotone in c — so the byte is certain
+// unless an integer lies within the bound of L (A + B c'); only then the lane re-runs mz_interpolate on the window it
+// already holds (a per-lane branch; about one pixel in 3,000).  Same bytes as the plain exact filter, always.
+//   weights: w_ref = max(fl(1 - fl(fl(10 dist) / d2)), .01), w' = max(fl(1 - dist fl(10 / d2)), .01): both within 2^-52 of the
+//     real max(1 - 10 dist / d2, .01) where that is not clamped on both sides, so |w' - w_ref| <= 2^-51 <= 4.5e-14 w_ref
+//     (w >= .01); sums of positive terms keep relative errors: S' = sum w' t and sw' = sum w' are within 5e-14 (incl. their
+//     own 16 roundings of 2^-53) of sum w_ref t and sum w_ref, and the reference's float64 sum_wht within 16 * 2^-53 of it.
+//   float32 chain of the reference: s <- fl32(fl64(s + fl64(w t))), |fl32(x) - x| <= 2^-24 |x| (normal range: a nonzero
+//     term is >= .01), partial sums <= the final one: |s_ref - sum w_ref t| <= 16 * 2^-24 (1 + 1e-6) sum w_ref t.
+//   so |c' - c| <= (9.5368e-7 * 1.000001 + 2e-13) c < 9.6e-7 c'(1 + 1e-6); v = fl(L fl(A + fl(B c))) with L, B >= 0 moves by
+//     at most L B |c' - c| + 3 roundings of values < 2^9 (< 1e-12): KAPPA = 9.7e-7 and an absolute 1e-9 cover both.
+#define MZ_SPEC_KAPPA 9.7e-7
+__device__ __forceinline__ void mz_interpolate_spec(const uint32_t (&qw)[4][4], double i, double j, double d, double ps,
+                                                    double (&out)[3]) {
+  double d2 = d * d;
+  if (d2 < 1.0e-8) d2 = 1.0e-8;
+  const double k10 = mz_div(10.0, mz_divisor(d2));   // == 10 / d2, correctly rounded
+  const int ib = (int)i, jb = (int)j;
+  double sw = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0, bb[4];
+#pragma unroll
+  for (int yy = -1; yy < 3; ++yy) {
+    const double b = ((double)(jb + yy) - j) * ps;
+    bb[yy + 1] = b * b;
+  }
+#pragma unroll
+  for (int xx = -1; xx < 3; ++xx) {
+    const double a = ((double)(ib + xx) - i) * ps;
+    const double aa = a * a;
+#pragma unroll
+    for (int yy = -1; yy < 3; ++yy) {
+      const double wht = __builtin_fmax(__builtin_fma(-(aa + bb[yy + 1]), k10, 1.0), 0.01);
+      sw += wht;
+      const uint32_t p = qw[xx + 1][yy + 1];
+      s0 = __builtin_fma(wht, (double)(p & 0xFFu), s0);
+      s1 = __builtin_fma(wht, (double)((p >> 8) & 0xFFu), s1);
+      s2 = __builtin_fma(wht, (double)((p >> 16) & 0xFFu), s2);
+    }
+  }
+  const MzDivisor SW = mz_divisor(sw);
+  out[0] = mz_div(s0, SW); out[1] = mz_div(s1, SW); out[2] = mz_div(s2, SW);
+}
+// byte of v' = L (A + B c') and whether the reference's byte could differ (an integer within the bound of v', or no number)
+__device__ __forceinline__ uint8_t mz_spec_byte(double L, double A, double B, double c, bool& doubt) {
+  const double t = B * c, v = L * (A + t);
+  const double e = __builtin_fma(L * t, MZ_SPEC_KAPPA, 1.0e-9);
+  const double fr = v - __builtin_floor(v);
+  doubt = doubt || !(fr > e && fr < 1.0 - e);
+  return mz_clip_u8(v);
 }
 
 // Opt-in fp32 variant of the filter above (xv_maze_set_precision(XV_MAZE_FILTER_F32)): same 4x4 taps, same weights
@@ -717,10 +776,6 @@ __global__ __launch_bounds__(256) void maze_tex_integral_kernel(const float* tex
   if (!(v >= 0.0f && v <= 255.0f && v == floorf(v))) atomicOr(not_integral, 1);
 }
 
-__device__ __forceinline__ uint8_t mz_clip_u8(double v) {   // numpy.clip(v, 0, 255) -> int32 -> uint8
-  return (uint8_t)(int)__builtin_fmin(__builtin_fmax(v, 0.0), 255.0);   // v_max/v_min_f64: no NaNs reach here
-}
-
 // One workgroup per frame, one lane per column.  FINAL: render the stored pre-reset pose of flagged envs.
 // The frame is built in LDS in chunks of P.HC rows ([column][HC*3 + 4] bytes: the pad makes the per-lane byte
 // writes bank-conflict free) and each chunk leaves with 16-byte stores; a 64x64 frame is one chunk, the registered
@@ -728,9 +783,19 @@ __device__ __forceinline__ uint8_t mz_clip_u8(double v) {   // numpy.clip(v, 0, 
 // NB (xv_maze_set_typing(XV_MAZE_TYPING_NUMBA)): DDA_2D and the wall-column geometry in float64, the types numba infers
 // for the reference's source (float32 table entry op float64 -> float64); default float32 = the same source run as plain
 // Python under NumPy 2, which the golden frames were made with (oracle/mz_wall_stage.inc holds both, REAL = float / double).
-template <bool FINAL, bool PACKED, bool F32, bool NB>
-__global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* frames, float* command_rgb) {
+// FILT: 0 / 3 = the exact filter, speculated when PACKED (mz_interpolate_spec), reading the pair-interleaved (0) or the
+// row-major (3) texture copy; 1 = the opt-in fp32 filter; 2 = the exact filter evaluated directly for every pixel
+// (XV_MAZE_FILTER_EXACT_DIRECT: what the speculated one is tested against).  The launcher picks 0 for frames up to 128 x 128
+// and 3 beyond (16,384 envs, scripts/runs_r04/gpu_t.sh: 64 x 64 1.09 ms pairs / 1.16 ms rows, 256 x 256 14.6 / 14.1 ms;
+// direct 1.29 / 17.4 ms).
+#ifndef XV_MAZE_RC_WAVES
+#define XV_MAZE_RC_WAVES 3   // waves per SIMD the register allocation aims at (2: 1.12 ms at 64 x 64, same at 256 x 256)
+#endif
+template <bool FINAL, bool PACKED, int FILT, bool NB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_WAVES, XV_MAZE_RC_WAVES))) void maze_raycast_kernel(MazeArgs P, uint8_t* frames, float* command_rgb) {
   using RT = typename std::conditional<NB, double, float>::type;
+  constexpr bool F32 = FILT == 1, SPEC = (FILT == 0 || FILT == 3) && PACKED;
+  constexpr bool PP = F32 || (SPEC && FILT == 0);   // which packed copy the pixels read
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int e = blockIdx.x;
   if (FINAL && !P.fin_flag[e]) return;   // block-uniform
@@ -745,9 +810,9 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
   const int8_t* walls = P.T.walls + (size_t)t * NG * NG;
   const int8_t* transp = P.T.landmarks + (size_t)t * NG * NG;
   const int32_t* texts = P.T.texts + (size_t)t * NG * NG;
-  const void* ground = PACKED ? (const void*)((F32 ? P.pp_grounds : P.pk_grounds) + (size_t)in[3] * 256 * MZ_TEX_PITCH)
+  const void* ground = PACKED ? (const void*)((PP ? P.pp_grounds : P.pk_grounds) + (size_t)in[3] * 256 * MZ_TEX_PITCH)
                               : (const void*)(P.T.tex_grounds + (size_t)in[3] * 256 * 256 * 3);
-  const void* ceil_t = PACKED ? (const void*)((F32 ? P.pp_ceilings : P.pk_ceilings) + (size_t)in[4] * 256 * MZ_TEX_PITCH)
+  const void* ceil_t = PACKED ? (const void*)((PP ? P.pp_ceilings : P.pk_ceilings) + (size_t)in[4] * 256 * MZ_TEX_PITCH)
                               : (const void*)(P.T.tex_ceilings + (size_t)in[4] * 256 * 256 * 3);
   const double pe0 = FINAL ? P.fin_pose[e] : P.pos[e];
   const double pe1 = FINAL ? P.fin_pose[N + e] : P.pos[N + e];
@@ -871,7 +936,7 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
     int v_s = (int)((half_v - (double)top_v) / pixel_size), v_e = (int)((half_v + (double)bot_v) / pixel_size);
     v_s = v_s < 0 ? 0 : v_s;
     v_e = v_e > H ? H : v_e;
-    const void* wt = PACKED ? (const void*)((F32 ? P.pp_walls : P.pk_walls) + (size_t)text_id * 256 * MZ_TEX_PITCH)
+    const void* wt = PACKED ? (const void*)((PP ? P.pp_walls : P.pk_walls) + (size_t)text_id * 256 * MZ_TEX_PITCH)
                             : (const void*)(P.T.tex_walls + (size_t)text_id * 256 * 256 * 3);
     const double eff_ps_w = eff_stale * pixel_size / l_focal;
     float wall_ti;
@@ -887,53 +952,94 @@ __global__ __launch_bounds__(256) void maze_raycast_kernel(MazeArgs P, uint8_t* 
     // segment [v_s, v_e) over them (:258-298); a floor/ceiling pixel under the wall is a dead store, so each pixel
     // is filtered once with the parameters of the stage that owns it.  Every lane runs exactly H iterations and
     // there is a single copy of the 16-tap filter.  Unpainted pixels keep FAR_RGB = 1 (:165-166).
-    for (int c0 = 0; c0 < H; c0 += HC) {
-      const int c1 = min(c0 + HC, H);
-      for (int d_v = c0; d_v < c1; ++d_v) {
-        bool paint = false;
-        const void* tx = wt;
-        double f_i = 0.0, f_j = 0.0, f_d = eff_ps_w, L = (double)light_w, A = a_far_w, B = a_near_w;
-        if (d_v >= v_s && d_v < v_e) {
-          const double local_v = (half_v - (d_v + 0.5) * pixel_size) * (double)ratio + vision_height;
-          double d_j = local_v / text_size;
-          d_j -= floor(d_j);
-          f_i = (double)wall_ti;
-          f_j = (double)(int)(256 * d_j);
-          paint = true;
-        } else {
-          const bool is_floor = d_v > H / 2;   // wave-uniform
-          const double2 dl = rowtab[d_v];
-          const double distance = dl.x, light = dl.y;
-          if (!(distance > visibility)) {
-            const double eff = mz_div(distance, R_cos);
-            double alpha = mz_div(2.0 * eff, R_vis) - 1.0;
-            alpha = __builtin_fmin(__builtin_fmax(alpha, 0.0), 1.0);
-            if (is_floor) alpha *= light;   // :189, the floor only
-            const double hit_x = eff * (double)co + (double)pos0, hit_y = eff * (double)so + (double)pos1;
-            const double fi = mz_div(hit_x, R_cs), fj = mz_div(hit_y, R_cs);
-            double d_i = fi - floor(fi), d_j = fj - floor(fj);
-            const int i = (int)fi, j = (int)fj;
-            if (i < n && i >= 0 && j < n && j >= 0) {
-              d_i *= percell; d_j *= percell;
-              d_i -= floor(d_i); d_j -= floor(d_j);
-              f_i = d_i * 256; f_j = d_j * 256;
-              f_d = mz_div(eff * pixel_size, R_lf);
-              tx = is_floor ? ground : ceil_t;
-              L = light; A = alpha * 1.0; B = 1.0 - alpha;
-              paint = true;
-            }
+    // what pixel d_v of the column shows: the texture, the filter position (f_i, f_j), the footprint f_d and the shading
+    // v = L (A + B c) of its colour c
+    auto pixel = [&](int d_v, const void*& tx, double& f_i, double& f_j, double& f_d, double& L, double& A, double& B) -> bool {
+      bool paint = false;
+      tx = wt;
+      f_i = 0.0; f_j = 0.0; f_d = eff_ps_w; L = (double)light_w; A = a_far_w; B = a_near_w;
+      if (d_v >= v_s && d_v < v_e) {
+        const double local_v = (half_v - (d_v + 0.5) * pixel_size) * (double)ratio + vision_height;
+        double d_j = local_v / text_size;
+        d_j -= floor(d_j);
+        f_i = (double)wall_ti;
+        f_j = (double)(int)(256 * d_j);
+        paint = true;
+      } else {
+        const bool is_floor = d_v > H / 2;   // wave-uniform
+        const double2 dl = rowtab[d_v];
+        const double distance = dl.x, light = dl.y;
+        if (!(distance > visibility)) {
+          const double eff = mz_div(distance, R_cos);
+          double alpha = mz_div(2.0 * eff, R_vis) - 1.0;
+          alpha = __builtin_fmin(__builtin_fmax(alpha, 0.0), 1.0);
+          if (is_floor) alpha *= light;   // :189, the floor only
+          const double hit_x = eff * (double)co + (double)pos0, hit_y = eff * (double)so + (double)pos1;
+          const double fi = mz_div(hit_x, R_cs), fj = mz_div(hit_y, R_cs);
+          double d_i = fi - floor(fi), d_j = fj - floor(fj);
+          const int i = (int)fi, j = (int)fj;
+          if (i < n && i >= 0 && j < n && j >= 0) {
+            d_i *= percell; d_j *= percell;
+            d_i -= floor(d_i); d_j -= floor(d_j);
+            f_i = d_i * 256; f_j = d_j * 256;
+            f_d = mz_div(eff * pixel_size, R_lf);
+            tx = is_floor ? ground : ceil_t;
+            L = light; A = alpha * 1.0; B = 1.0 - alpha;
+            paint = true;
           }
         }
-        uint8_t* px = col + (d_v - c0) * 3;
-        if (paint) {
-          double c[3];
-          if (F32) mz_interpolate_f32<PACKED>(tx, f_i, f_j, f_d, tps, c);
-          else mz_interpolate<PACKED>(tx, f_i, f_j, f_d, tps, tps, c);
-          px[0] = mz_clip_u8(L * (A + B * c[0]));
-          px[1] = mz_clip_u8(L * (A + B * c[1]));
-          px[2] = mz_clip_u8(L * (A + B * c[2]));
-        } else {
-          px[0] = 1; px[1] = 1; px[2] = 1;
+      }
+      return paint;
+    };
+    for (int c0 = 0; c0 < H; c0 += HC) {
+      const int c1 = min(c0 + HC, H);
+      // SPEC: blocks of 64 rows; the pixels whose byte the speculated filter could not settle are noted in `redo` and
+      // filtered in the reference's typing by a second loop (rare: the two filters never share a register allocation)
+      for (int r0 = c0; r0 < c1; r0 += SPEC ? 64 : HC) {
+        const int r1 = SPEC ? min(r0 + 64, c1) : c1;
+        unsigned long long redo = 0ull;
+        for (int d_v = r0; d_v < r1; ++d_v) {
+          const void* tx;
+          double f_i, f_j, f_d, L, A, B;
+          const bool paint = pixel(d_v, tx, f_i, f_j, f_d, L, A, B);
+          uint8_t* px = col + (d_v - c0) * 3;
+          if (paint) {
+            double c[3];
+            if (SPEC) {
+              uint32_t qw[4][4];
+              mz_fetch_window<PP>(tx, (int)f_i, (int)f_j, qw);
+              mz_interpolate_spec(qw, f_i, f_j, f_d, tps, c);
+              bool doubt = false;
+              px[0] = mz_spec_byte(L, A, B, c[0], doubt);
+              px[1] = mz_spec_byte(L, A, B, c[1], doubt);
+              px[2] = mz_spec_byte(L, A, B, c[2], doubt);
+              redo |= (unsigned long long)doubt << (d_v - r0);
+            } else {
+              if (F32) mz_interpolate_f32<PACKED>(tx, f_i, f_j, f_d, tps, c);
+              else mz_interpolate<PACKED>(tx, f_i, f_j, f_d, tps, tps, c);
+              px[0] = mz_clip_u8(L * (A + B * c[0]));
+              px[1] = mz_clip_u8(L * (A + B * c[1]));
+              px[2] = mz_clip_u8(L * (A + B * c[2]));
+            }
+          } else {
+            px[0] = 1; px[1] = 1; px[2] = 1;
+          }
+        }
+        if (SPEC) {
+          while (redo) {
+            const int d_v = r0 + __builtin_ctzll(redo);
+            redo &= redo - 1ull;
+            const void* tx;
+            double f_i, f_j, f_d, L, A, B, c[3];
+            (void)pixel(d_v, tx, f_i, f_j, f_d, L, A, B);
+            uint32_t qw[4][4];
+            mz_fetch_window<PP>(tx, (int)f_i, (int)f_j, qw);
+            mz_interpolate<true, true>(nullptr, f_i, f_j, f_d, tps, tps, c, qw);
+            uint8_t* px = col + (d_v - c0) * 3;
+            px[0] = mz_clip_u8(L * (A + B * c[0]));
+            px[1] = mz_clip_u8(L * (A + B * c[1]));
+            px[2] = mz_clip_u8(L * (A + B * c[2]));
+          }
         }
       }
       // ---- transparent landmark overlays, far to near :301-318 ----
@@ -1125,8 +1231,11 @@ static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, b
   hipLaunchKernelGGL((maze_raycast_kernel<F, K, Q, B>), dim3(a.n_env), dim3(threads), lds_bytes, h->eng->stream, a, frames, crgb)
 #define MAZE_RC2(F, K)                                                                  \
   do {                                                                                  \
-    if (h->typing_numba) { if (h->filter_f32) MAZE_RC(F, K, true, true); else MAZE_RC(F, K, false, true); }   \
-    else { if (h->filter_f32) MAZE_RC(F, K, true, false); else MAZE_RC(F, K, false, false); }                 \
+    const int filt = h->filter != XV_MAZE_FILTER_EXACT ? h->filter : ((K) && (size_t)a.W * a.H > 128 * 128 ? 3 : 0);                  \
+    if (h->typing_numba) { if (filt == 1) MAZE_RC(F, K, 1, true); else if (filt == 2) MAZE_RC(F, K, 2, true);                          \
+                           else if (filt == 3) MAZE_RC(F, K, 3, true); else MAZE_RC(F, K, 0, true); }                                  \
+    else { if (filt == 1) MAZE_RC(F, K, 1, false); else if (filt == 2) MAZE_RC(F, K, 2, false);                                        \
+           else if (filt == 3) MAZE_RC(F, K, 3, false); else MAZE_RC(F, K, 0, false); }                                                \
   } while (0)
   if (final) { if (packed) MAZE_RC2(true, true); else MAZE_RC2(true, false); }
   else { if (packed) MAZE_RC2(false, true); else MAZE_RC2(false, false); }
@@ -1137,8 +1246,8 @@ static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, b
 }
 
 extern "C" int xv_maze_set_precision(xv_maze* h, int filter) {
-  XV_CHECK_ARG(h != nullptr && (filter == XV_MAZE_FILTER_EXACT || filter == XV_MAZE_FILTER_F32));
-  h->filter_f32 = filter == XV_MAZE_FILTER_F32;
+  XV_CHECK_ARG(h != nullptr && (filter == XV_MAZE_FILTER_EXACT || filter == XV_MAZE_FILTER_F32 || filter == XV_MAZE_FILTER_EXACT_DIRECT));
+  h->filter = filter;
   return XV_OK;
 }
 

@@ -41,7 +41,7 @@ struct MazeArgs {
 struct xv_maze {
   xv_engine* eng;
   MazeArgs a;
-  bool filter_f32 = false;   // xv_maze_set_precision
+  int filter = 0;            // xv_maze_set_precision (XV_MAZE_FILTER_*)
   bool typing_numba = false; // xv_maze_set_typing
   bool move_lanes9 = true;   // xv_maze_set_move_kernel
   int move_lanes = 0;        // 0: by batch size; 3 or 9: forced (xv_maze_set_move_kernel)

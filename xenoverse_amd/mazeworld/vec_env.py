@@ -52,8 +52,9 @@ class MazeWorldVecEnv(VectorEnv):
         self.action_space_type = action_space_type
         self.collision_dist = float(collision_dist)
         self.with_final_obs = bool(with_final_obs)
-        if precision not in ("exact", "f32"):
-            raise ValueError("precision must be 'exact' (the reference's typing, default) or 'f32'")
+        if precision not in ("exact", "f32", "exact_direct"):
+            raise ValueError("precision must be 'exact' (the reference's typing, default), 'exact_direct' (the same bytes, "
+                             "every pixel filtered directly: what 'exact' is tested against) or 'f32'")
         if typing not in ("numpy2", "numba"):
             raise ValueError("typing must be 'numpy2' (the reference's source as plain Python under NumPy 2, default) or "
                              "'numba' (the types numba infers: DDA and wall-column geometry in float64)")
@@ -112,8 +113,8 @@ class MazeWorldVecEnv(VectorEnv):
                                            self.visibility_3D, C.byref(ct), _lib.ptr(dev["env_task"]), C.byref(h)))
         self._h = h
         self._tab = dev
-        if self.precision == "f32":
-            _lib.check(self.lib.xv_maze_set_precision(h, 1))
+        if self.precision != "exact":
+            _lib.check(self.lib.xv_maze_set_precision(h, 1 if self.precision == "f32" else 2))
         if self.typing == "numba":
             _lib.check(self.lib.xv_maze_set_typing(h, 1))
         n = self.num_envs
