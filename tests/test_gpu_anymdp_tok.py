@@ -105,15 +105,17 @@ def test_batch_vs_oracle_injected_and_free_running(mode, search):
 @pytest.mark.parametrize("n_obs,d_obs,d_act,search", [(64, 3, 2, "fence"), (22, 2, 3, "fence"), (15, 2, 2, "fence"),
                                                      (64, 3, 2, "binary"), (64, 3, 2, "bucket"), (22, 2, 3, "bucket"),
                                                      (15, 1, 1, "bucket"), (200, 2, 2, "bucket"), (256, 2, 1, "bucket"),
-                                                     (300, 2, 2, "bucket"), (64, 2, 2, "sparse-bucket")])
+                                                     (300, 2, 2, "bucket"), (64, 2, 2, "sparse-bucket"),
+                                                     (40, 2, 2, "bucket-S300"), (40, 1, 1, "bucket-S300")])
 def test_synthetic_observation_models_vs_oracle(n_obs, d_obs, d_act, search):
     """S=64, A=8 synthetic tasks with random observation models of several shapes (n_obs 64 / 22 / 15, up to 3
     tokens) against the oracle: injected draws incl. exact CDF entries, all three auto-reset modes in turn"""
-    S, A, n_task = 64, 8, 6
+    wide = search == "bucket-S300"          # S > 256: the transition lines' six-cut packing (16-bit ids) in the cooperative kernel
+    S, A, n_task = (300, 4, 3) if wide else (64, 8, 6)
     tab = oracle.anymdp_synth(seed=17, task_index_base=0, n_task=n_task, S=S, A=A, s0_max=3)
     rng = np.random.RandomState(n_obs)
     sparse = search == "sparse-bucket"      # the reference's observation rows: a few live symbols, exact zeros between them
-    search = "bucket" if sparse else search
+    search = "bucket" if sparse or wide else search
     w = rng.random_sample((n_task, d_obs, S, n_obs)) * (rng.random_sample((n_task, d_obs, S, n_obs)) < (0.08 if sparse else 0.5))
     if sparse:
         w[..., 0] += (w.sum(-1) == 0)
@@ -137,6 +139,7 @@ def test_synthetic_observation_models_vs_oracle(n_obs, d_obs, d_act, search):
         if search == "bucket":      # the cooperative kernel serves when the symbol ids fit the lines' bytes (n_obs <= 256)
             assert env.token_kernel == ("cooperative" if n_obs <= 256 else "per-lane")
             cen = env.bucket_census()
+            assert cen["format"] == (2 if wide else 1)
             assert (cen["obs_lines"] > 0) == (n_obs <= 256)
             if sparse:
                 assert cen["obs_lines_dirty"] == 0 and cen["obs_p_fallback"] == 0.0
