@@ -42,7 +42,8 @@ extern "C" {
  * 8: device tick (xv_engine_set_device_tick / _tick_batch / _set_stream: a step is capturable in a hipGraph); AnyMDP bucket
  *    lines list chosen cuts of the row's CDF, with a census (xv_anymdp_probe_buckets, xv_anymdp_bucket_census_get,
  *    xv_anymdp_effective_search, xv_anymdp_token_kernel); xv_anymdp_step_info / xv_linds_step_info (steps and the done mask
- *    from the step launch); xv_mixed_supported; xv_anymdp_sample_tasks up to 256 states */
+ *    from the step launch); xv_mixed_supported; xv_anymdp_sample_tasks up to 256 states; xv_maze_set_precision accepts
+ *    XV_MAZE_FILTER_EXACT_DIRECT (a new value of an existing argument: no bump) */
 #define XV_ABI_VERSION 8
 
 /* return codes */
