@@ -29,9 +29,13 @@ def _dev_tables(tab, dev="cuda:0"):
     return out
 
 
+class Mismatch(Exception):
+    pass
+
+
 def _check(ok, what):
     if not ok:
-        raise AssertionError(what)
+        raise Mismatch(what)
 
 
 def _compare(dev_out, ora_out, exact_reward, same_step):
@@ -169,7 +173,7 @@ if __name__ == "__main__":
         fn = soak_tok if n % 3 == 2 else soak_mdp
         try:
             line = fn(rng, seed)
-        except AssertionError as ex:
+        except Mismatch as ex:
             print("MISMATCH in %s with seed %d: %s" % (fn.__name__, seed, ex), flush=True)
             sys.exit(1)
         n += 1

@@ -19,9 +19,13 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+class Mismatch(Exception):
+    pass
+
+
 def _check(ok, what):
     if not ok:
-        raise AssertionError(what)
+        raise Mismatch(what)
 
 
 def soak(rng, seed):
@@ -91,7 +95,7 @@ if __name__ == "__main__":
         seed = int(master.randint(1, 1 << 30))
         try:
             line = soak(np.random.RandomState(seed), seed)
-        except AssertionError as ex:
+        except Mismatch as ex:
             print("MISMATCH with seed %d: %s" % (seed, ex), flush=True)
             sys.exit(1)
         n += 1
