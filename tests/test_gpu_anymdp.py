@@ -1036,6 +1036,42 @@ def test_bucket_lines_in_the_six_cut_packing(S, big_obs):
     env.close()
 
 
+def test_default_path_builds_bucket_lines_within_an_eighth_of_the_free_memory():
+    """AnyMDPVecEnv(bucket_lines="auto"), the default: 2,048 tasks of 64 x 8 need 2 GiB of lines — more than the 1 GiB that is
+    always allowed, within an eighth of the free memory of an otherwise empty GPU: set_task builds them and AUTO runs the
+    one-line search; with the cap taken away (or little memory free) the same call stays on the fence search"""
+    from xenoverse_amd import _lib
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2**30:
+        pytest.skip("needs an (almost) empty GPU")
+    n_task, S, A, n_env = 2048, 64, 8, 4096
+    got = {}
+    for cap in (16 << 30, 1 << 30):
+        env = AnyMDPVecEnv(n_env, seed=3, autoreset_mode="same_step")
+        env.AUTO_BUCKET_CAP = cap
+        d = env.device
+        t = dict(S=S, A=A, s0_max=4,
+                 rows=torch.empty((n_task, S, A, row_lines(S), 16), dtype=torch.float64, device=d),
+                 state_map=torch.empty((n_task, S), dtype=torch.int32, device=d),
+                 term_mask=torch.empty((n_task, 1), dtype=torch.int64, device=d),
+                 s0_cdf=torch.empty((n_task, 4), dtype=torch.float64, device=d),
+                 s0_ids=torch.empty((n_task, 4), dtype=torch.int32, device=d),
+                 max_steps=torch.empty(n_task, dtype=torch.int32, device=d))
+        _lib.check(env.lib.xv_anymdp_synth_tasks(env.engine.handle, 77, 0, n_task, S, A, 4, *[_lib.ptr(t[k]) for k in
+                   ("rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")]))
+        env.set_task(t, env_task_index=(torch.arange(n_env, dtype=torch.int32, device=d) // 2))
+        got[cap] = (env.effective_search, env.bucket_census()["built"])
+        obs, _ = env.reset()
+        out = env.step(torch.zeros(n_env, dtype=torch.int32, device=d))
+        got[(cap, "obs")] = _np(out[0]).copy()
+        assert env.check_errors() == 0
+        env.close()
+        del t
+        torch.cuda.empty_cache()
+    assert got[16 << 30] == ("bucket", 1) and got[1 << 30][0] == "fence"
+    assert np.array_equal(got[(16 << 30, "obs")], got[(1 << 30, "obs")])      # same seed, same draws: the searches agree
+
+
 @pytest.mark.parametrize("copy", [True, False])
 @pytest.mark.parametrize("mode", ["same_step", "next_step", "disabled"])
 def test_step_writes_steps_and_done_mask_from_the_same_launch(copy, mode):

@@ -21,7 +21,11 @@ _TABLE_DTYPES = dict(rows=torch.float64, state_map=torch.int32, term_mask=torch.
 
 
 class AnyMDPVecEnv(VectorEnv):
-    AUTO_BUCKET_BYTES = 1 << 30      # bucket_lines="auto": lines are built at set_task when they take no more than this
+    # bucket_lines="auto": the lines are built at set_task when they take no more than 1 GiB, or no more than an eighth of the
+    # device memory that is free at that moment, up to 16 GiB (an MI355X has 288 GB: 16,384 tasks of 64 x 8 on an empty one)
+    AUTO_BUCKET_BYTES = 1 << 30
+    AUTO_BUCKET_SHARE = 0.125
+    AUTO_BUCKET_CAP = 16 << 30
 
     def __init__(self, num_envs, max_steps=5000, device="cuda:0", seed=0, env_id_base=0,
                  autoreset_mode="same_step", to_numpy=False, engine=None, with_transition_gt=False, copy=True,
@@ -35,8 +39,8 @@ class AnyMDPVecEnv(VectorEnv):
         16-KB copy and one fused op (`scripts/bench_python_step.py`).
 
         bucket_lines: "auto" (default) — at set_task the engine takes the census of 16 bucket lines per row and builds them
-        when its AUTO rule would use them AND they take at most 1 GiB (n_task * S * A * 2 KiB: up to 1,024 tasks of 64 x 8):
-        a step then reads one table line instead of two, same results; "off" — never without set_search(..., n_bucket=);
+        when its AUTO rule would use them AND they take at most 1 GiB or an eighth of the free device memory up to 16 GiB
+        (n_task * S * A * 2 KiB: 1,024 ... 16,384 tasks of 64 x 8): a step then reads one table line instead of two, same results; "off" — never without set_search(..., n_bucket=);
         an int — that many buckets per row whatever the size (as set_search("auto", n_bucket=int))."""
         super().__init__(num_envs, device=device, seed=seed, env_id_base=env_id_base,
                          autoreset_mode=autoreset_mode, to_numpy=to_numpy, engine=engine, copy=copy)
@@ -169,7 +173,11 @@ class AnyMDPVecEnv(VectorEnv):
         self.need_reset = True
         if self.bucket_lines != "off":      # memory for speed, within a small budget unless the caller named a bucket count
             nb = 16 if self.bucket_lines == "auto" else int(self.bucket_lines)
-            if self.bucket_lines != "auto" or n_task * S * A * nb * 128 <= self.AUTO_BUCKET_BYTES:
+            budget = self.AUTO_BUCKET_BYTES
+            if self.bucket_lines == "auto" and n_task * S * A * nb * 128 > budget:
+                free, _ = torch.cuda.mem_get_info(self.device)
+                budget = max(budget, min(self.AUTO_BUCKET_CAP, int(free * self.AUTO_BUCKET_SHARE)))
+            if self.bucket_lines != "auto" or n_task * S * A * nb * 128 <= budget:
                 try:
                     self.set_search("auto", n_bucket=nb)
                 except _lib.XenoError:      # tables the fence layout does not serve (s0_max > 4, ...): the per-lane search
