@@ -580,7 +580,7 @@ def bench_maze(args, res, precision="exact", move_kernel="auto"):
     algo = (3 * res * res + 64) * n
     # the ray-caster is bound by fp64 VALU issue, not HBM: in the reference's typing a painted pixel needs >= 16 taps x
     # (8 weight + 3 x 5 colour) = 368 fp64-pipe instructions + ~40 of geometry (the direct filter); the default filter
-    # speculates with float64 sums, 16 x (4 + 3 x 3) + 40 = 248, and re-runs the ~1 pixel in 3,000 whose byte is not certain;
+    # speculates with float64 sums, 16 x (4 + 3 x 3) + 40 = 248, and re-runs the ~1 pixel in 300 whose byte is not certain;
     # peak = 1024 SIMDs x 64 lanes x 2.4 GHz / 4 cycles per wave-instr
     per_pixel = 248.0 if precision == "exact" else 408.0
     valu_ops = per_pixel * res * res * n

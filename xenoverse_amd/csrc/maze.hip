@@ -655,7 +655,8 @@ __device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, do
 // with float64 sums (fma), the weight as fma(-dist, 10 / d2, 1): 13 instructions per tap.  Its colour c' differs from the
 // reference's c by a PROVEN bound, and the pixel byte is floor(clip(L (A + B c))), monotone in c — so the byte is certain
 // unless an integer lies within the bound of L (A + B c'); only then the lane re-runs mz_interpolate on the window it
-// already holds (a per-lane branch; about one pixel in 3,000).  Same bytes as the plain exact filter, always.
+// already holds (a second loop per 64 rows; one pixel in ~300 on the bench's synthetic textures, whose flat areas put many
+// colours within the bound of an integer — scripts/devtools/probe_spec_redo.py).  Same bytes as the plain exact filter, always.
 //   weights: w_ref = max(fl(1 - fl(fl(10 dist) / d2)), .01), w' = max(fl(1 - dist fl(10 / d2)), .01): both within 2^-52 of the
 //     real max(1 - 10 dist / d2, .01) where that is not clamped on both sides, so |w' - w_ref| <= 2^-51 <= 4.5e-14 w_ref
 //     (w >= .01); sums of positive terms keep relative errors: S' = sum w' t and sw' = sum w' are within 5e-14 (incl. their
