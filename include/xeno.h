@@ -43,8 +43,9 @@ extern "C" {
  *    lines list chosen cuts of the row's CDF, with a census (xv_anymdp_probe_buckets, xv_anymdp_bucket_census_get,
  *    xv_anymdp_effective_search, xv_anymdp_token_kernel); xv_anymdp_step_info / xv_linds_step_info (steps and the done mask
  *    from the step launch); xv_mixed_supported; xv_anymdp_sample_tasks up to 256 states; xv_maze_set_precision accepts
- *    XV_MAZE_FILTER_EXACT_DIRECT (a new value of an existing argument: no bump) */
-#define XV_ABI_VERSION 8
+ *    XV_MAZE_FILTER_EXACT_DIRECT (a new value of an existing argument: no bump)
+ * 9: xv_anymdp_step_tokens_info (the POMDP / multi-token step writes steps and the done mask itself) */
+#define XV_ABI_VERSION 9
 
 /* return codes */
 #define XV_OK 0
@@ -252,6 +253,11 @@ int xv_anymdp_reset_tokens_injected(xv_anymdp* h, const uint8_t* mask, const dou
                                     const double* u_obs_reset, int32_t* obs);
 int xv_anymdp_step_tokens(xv_anymdp* h, const int32_t* action, int32_t* obs, float* reward, float* reward_gt,
                           uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int autoreset_mode);
+/* xv_anymdp_step_tokens that also writes info["steps"] (int32[n_env], the counter after the step) and the terminated | truncated
+ * mask (uint8[n_env]) from the same launch, each nullable — as xv_anymdp_step_info for the MDP step (ABI 9) */
+int xv_anymdp_step_tokens_info(xv_anymdp* h, const int32_t* action, int32_t* obs, float* reward, float* reward_gt,
+                               uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int32_t* steps, uint8_t* done,
+                               int autoreset_mode);
 /* n_steps token steps issued from C over [period][...] ring buffers (step k on slot k % period), as xv_anymdp_step_many
  * does for the scalar step; equals n_steps calls of xv_anymdp_step_tokens. */
 int xv_anymdp_step_tokens_many(xv_anymdp* h, int n_steps, int period, const int32_t* action, int32_t* obs, float* reward,

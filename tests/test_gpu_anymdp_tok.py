@@ -94,6 +94,10 @@ def test_batch_vs_oracle_injected_and_free_running(mode, search):
         s, st, nr = env.get_state()
         assert np.array_equal(_np(s), ora.state) and np.array_equal(_np(st), ora.steps) and np.array_equal(_np(nr), ora.need_reset)
         done = (o[3] | o[4]).astype(bool)
+        # info["steps"] and the done mask: written by the step launch itself on the free-running path (xv_anymdp_step_tokens_info)
+        assert np.array_equal(_np(info["steps"]), ora.steps)
+        if mode == "same_step":
+            assert np.array_equal(_np(info["_final_obs"]), done)
         ended += int(done.sum())
         if mode == "disabled" and o[3].any():
             ur2, uor2 = rng.random_sample(n), rng.random_sample((d_obs, n))
@@ -217,3 +221,41 @@ def test_step_tokens_many_equals_single_steps(search, task_type):
         else:
             assert np.array_equal(res[0][k], res[1][k]), k
     assert done.sum() > 20
+
+
+@pytest.mark.parametrize("mode", ["same_step", "next_step", "disabled"])
+@pytest.mark.parametrize("kind", ["pomdp", "mtpomdp"])
+def test_copy_false_token_steps_equal_fresh_tensor_steps(kind, mode):
+    """copy=False (persistent outputs, cached pointers and views, one launch per step) returns what copy=True returns — same
+    seed, same actions — and info["steps"] / the done mask come from the step launch in both"""
+    tasks = [load_anymdp_tok_golden(p)[1] for p in FILES if ("mtpomdp" in p) == (kind == "mtpomdp")]
+    n = 150
+    env_task = (np.arange(n) % len(tasks)).astype(np.int32)
+    envs = []
+    for copy in (True, False):
+        env = AnyMDPVecEnv(n, autoreset_mode=mode, seed=21, copy=copy)
+        env.set_task(tasks, env_task_index=env_task)
+        env.set_search("bucket", n_bucket=16)
+        envs.append(env)
+    o0 = [_np(e.reset()[0]).copy() for e in envs]
+    assert np.array_equal(o0[0], o0[1])
+    A = int(envs[0].na)
+    rng = np.random.RandomState(2)
+    d_act = envs[0]._tok[1]
+    for t in range(60):
+        a = rng.randint(0, A, (n, d_act)).astype(np.int32)
+        outs = [e.step(a if d_act > 1 else a[:, 0]) for e in envs]
+        got = [[_np(x).copy() for x in o[:4]] + [_np(o[4]["steps"]).copy(), _np(o[4]["reward_gt"]).copy()] for o in outs]
+        for x, y in zip(*got):
+            assert np.array_equal(x, y)
+        if mode == "same_step":
+            assert np.array_equal(_np(outs[0][4]["final_obs"]), _np(outs[1][4]["final_obs"]))
+            assert np.array_equal(_np(outs[0][4]["_final_obs"]), _np(outs[1][4]["_final_obs"]))
+            assert np.array_equal(_np(outs[1][4]["_final_obs"]), got[1][2] | got[1][3])
+        if mode == "disabled":
+            term = got[0][2].astype(bool)
+            if term.any():
+                for e in envs:
+                    e.reset_tokens_injected(np.full(n, 0.25), np.full((e._tok[0], n), 0.5), mask=term.astype(np.uint8))
+    for e in envs:
+        e.close()

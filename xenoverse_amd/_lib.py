@@ -65,6 +65,7 @@ SIGNATURES = {
     "xv_anymdp_reset_tokens": [c_void_p, c_void_p, c_void_p],
     "xv_anymdp_reset_tokens_injected": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_anymdp_step_tokens": [c_void_p] + [c_void_p] * 7 + [c_int],
+    "xv_anymdp_step_tokens_info": [c_void_p] + [c_void_p] * 9 + [c_int],
     "xv_anymdp_step_tokens_injected": [c_void_p] + [c_void_p] * 12 + [c_int],
     "xv_anymdp_step_tokens_many": [c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int],
     "xv_anymdp_rollout_teacher": [c_void_p, c_int, c_void_p, C.c_float] + [c_void_p] * 7,
@@ -143,7 +144,7 @@ class XenoError(RuntimeError):
     pass
 
 
-ABI_VERSION = 8      # include/xeno.h XV_ABI_VERSION
+ABI_VERSION = 9      # include/xeno.h XV_ABI_VERSION
 
 
 def load():

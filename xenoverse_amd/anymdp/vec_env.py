@@ -49,6 +49,7 @@ class AnyMDPVecEnv(VectorEnv):
         self.copy = bool(copy)
         self.bucket_lines = bucket_lines
         self._ring = None
+        self._tok_cache = None
         self._set_spaces(Discrete(1), Discrete(1))   # placeholders until set_task, as in the reference
         self._h = None
         self._many_cache = None
@@ -145,6 +146,7 @@ class AnyMDPVecEnv(VectorEnv):
                 self._set_spaces(Discrete(n_obs), Discrete(A))
             self._tobs = torch.zeros((n, d_obs), dtype=torch.int32, device=d)
             self._tfobs = torch.full((n, d_obs), -1, dtype=torch.int32, device=d)
+        self._tok_cache = None          # (copy=False token steps cache pointers and views of the buffers made here)
         self._obs = torch.zeros(n, dtype=torch.int32, device=d)
         self._reward = torch.zeros(n, dtype=torch.float32, device=d)
         self._reward_gt = torch.zeros(n, dtype=torch.float32, device=d)
@@ -265,17 +267,29 @@ class AnyMDPVecEnv(VectorEnv):
             raise AssertionError(f"Action {tuple(a.shape)} is out of range")   # anymdp_env.py:117
         return a.contiguous()
 
-    def _tok_fresh(self):
-        """before a token step: the step kernels write observation, rewards and flags of EVERY env, so fresh buffers are
-        swapped in and handed out without copies (the previous call's tensors are never written again); final_obs is
-        written for finished envs only and stays a persistent buffer that is copied out"""
-        self._renew("_tobs", "_reward", "_reward_gt", "_term", "_trunc")
+    def _tok_make_cache(self):
+        pomdp = self.task_type == "POMDP"
+        return dict(key=(self._tobs.data_ptr(), self._tfobs.data_ptr()),
+                    args=tuple(C.c_void_p(t.data_ptr()) for t in (self._tobs, self._reward, self._reward_gt, self._term,
+                                                                  self._trunc, self._tfobs, self._steps, self._done)),
+                    obs=self._tobs[:, 0] if pomdp else self._tobs, fobs=self._tfobs[:, 0] if pomdp else self._tfobs,
+                    term_b=self._term.view(torch.bool), trunc_b=self._trunc.view(torch.bool),
+                    done_b=self._done.view(torch.bool))
 
-    def _tok_ret(self):
-        infos = {"steps": self._out(self._get_steps()), "reward_gt": self._of(self._reward_gt)}
+    def _tok_fresh(self):
+        """before a token step: the step kernels write observation, rewards, flags and final_obs (-1 where the env goes on) of
+        EVERY env, so fresh buffers are swapped in and handed out without copies (the previous call's tensors are never
+        written again)"""
+        self._renew("_tobs", "_reward", "_reward_gt", "_term", "_trunc", "_tfobs")
+
+    def _tok_ret(self, from_launch=False):
+        """from_launch: the step wrote `_steps` and `_done` itself (xv_anymdp_step_tokens_info)"""
+        infos = {"steps": self._of(self._steps) if from_launch else self._out(self._get_steps()),
+                 "reward_gt": self._of(self._reward_gt)}
         if self.autoreset_mode == "same_step":
-            infos["final_obs"] = self._tok_obs(self._tfobs)
-            infos["_final_obs"] = self._out((self._term | self._trunc).view(torch.bool))
+            infos["final_obs"] = self._of(self._tfobs[:, 0] if self.task_type == "POMDP" else self._tfobs)
+            infos["_final_obs"] = self._obf(self._done) if from_launch else \
+                self._out((self._term | self._trunc).view(torch.bool))
         obs = self._tobs[:, 0] if self.task_type == "POMDP" else self._tobs
         return (self._of(obs), self._of(self._reward), self._obf(self._term), self._obf(self._trunc), infos)
 
@@ -333,11 +347,25 @@ class AnyMDPVecEnv(VectorEnv):
         self._check_step()
         if self._tok is not None:
             a = self._tok_action(actions)
+            if not self.copy and not self.to_numpy:     # persistent outputs: pointers and views are made once
+                c = self._tok_cache
+                if c is None or c["key"] != (self._tobs.data_ptr(), self._tfobs.data_ptr()):
+                    c = self._tok_cache = self._tok_make_cache()
+                _lib.check(self.lib.xv_anymdp_step_tokens_info(self._h, C.c_void_p(a.data_ptr()), *c["args"],
+                                                               AUTORESET[self.autoreset_mode]))
+                infos = {"steps": self._steps, "reward_gt": self._reward_gt}
+                if self.autoreset_mode == "same_step":
+                    infos["final_obs"] = c["fobs"]
+                    infos["_final_obs"] = c["done_b"]
+                return c["obs"], self._reward, c["term_b"], c["trunc_b"], infos
             self._tok_fresh()
-            _lib.check(self.lib.xv_anymdp_step_tokens(
+            self._renew("_steps", "_done")
+            # ONE launch: the token step writes info["steps"] and the terminated | truncated mask itself
+            _lib.check(self.lib.xv_anymdp_step_tokens_info(
                 self._h, _lib.ptr(a), _lib.ptr(self._tobs), _lib.ptr(self._reward), _lib.ptr(self._reward_gt),
-                _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._tfobs), AUTORESET[self.autoreset_mode]))
-            return self._tok_ret()
+                _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._tfobs), _lib.ptr(self._steps), _lib.ptr(self._done),
+                AUTORESET[self.autoreset_mode]))
+            return self._tok_ret(from_launch=True)
         a = self._dev(actions, torch.int32)
         if a.shape != (self.num_envs,):
             raise AssertionError(f"Action {tuple(a.shape)} is out of range")

@@ -236,8 +236,8 @@ struct AnyMDPCoopLineN {
     return r;
   }
   // transition bucket line (anymdp_cutline.h): K cuts {cut, reward, noise} + metadata  ->  the reward pair of the group
-  // c = #{cut <= u} and meta = its observation id | next state << 16 | terminal flag << 25 | lumped << 26 (as
-  // anymdp_cut_meta); beyond = the line cannot answer this draw (c == K, or the group lumps several states): search the row
+  // c = #{cut <= u} and meta = its observation id | next state << 16 | terminal flag << 25 | lumped << 26 (the packings
+  // are described above the struct); beyond = the line cannot answer this draw (c == K, or the group lumps several states): search the row
   template <int FMT>
   __device__ __forceinline__ void resolve_entry(double u, int lane, bool& beyond, float& rx, float& ry, uint32_t& meta) const {
     constexpr int KC = FMT == 2 ? 6 : 7;
@@ -857,6 +857,8 @@ struct AnyMDPTokIO {
   uint8_t* terminated;
   uint8_t* truncated;
   int32_t* final_obs;          // [n_env][d_obs], nullable
+  int32_t* steps_out;          // [n_env] info["steps"] after the step and the terminated | truncated mask of the same step
+  uint8_t* done_out;           //         (xv_anymdp_step_tokens_info; each nullable)
 };
 
 __device__ __forceinline__ int xv_upper_bound_f64(const double* row, int n, double u) {
@@ -972,6 +974,8 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_kernel(AnyMDPArgs P, AnyM
   P.sr[i] = anymdp_sr_pack(s, steps, nr, anymdp_is_term(P, t, tm0, s) ? 1 : 0);
   io.reward[i] = rsum; io.reward_gt[i] = rgsum;
   io.terminated[i] = (uint8_t)term; io.truncated[i] = (uint8_t)trunc;
+  if (io.steps_out) io.steps_out[i] = (int32_t)steps;
+  if (io.done_out) io.done_out[i] = (uint8_t)((term || trunc) ? 1 : 0);
   if (err) atomicOr(P.err, err);
 }
 
@@ -1245,6 +1249,8 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
     P.sr[i] = anymdp_sr_pack(s, steps, nr, cterm);
     io.reward[i] = rsum; io.reward_gt[i] = rgsum;
     io.terminated[i] = (uint8_t)term; io.truncated[i] = (uint8_t)trunc;
+    if (io.steps_out) io.steps_out[i] = (int32_t)steps;
+    if (io.done_out) io.done_out[i] = (uint8_t)((term || trunc) ? 1 : 0);
   }
   if (err && valid) atomicOr(P.err, err);
 }
@@ -2046,6 +2052,19 @@ extern "C" int xv_anymdp_step_tokens(xv_anymdp* h, const int32_t* action, int32_
   XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
   anymdp_bind_rng(h, 1);
   AnyMDPTokIO io{action, nullptr, nullptr, nullptr, nullptr, nullptr, obs, reward, reward_gt, terminated, truncated, final_obs};
+  return anymdp_tok_launch_step<false>(h, io, autoreset_mode);
+}
+
+// xv_anymdp_step_tokens that also writes info["steps"] and the terminated | truncated mask from the same launch (as
+// xv_anymdp_step_info does for the MDP step): a Python-level step() of a POMDP is then ONE launch
+extern "C" int xv_anymdp_step_tokens_info(xv_anymdp* h, const int32_t* action, int32_t* obs, float* reward, float* reward_gt,
+                                          uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int32_t* steps,
+                                          uint8_t* done, int autoreset_mode) {
+  XV_CHECK_ARG(h && h->obs_cdf && action && obs && reward && reward_gt && terminated && truncated);
+  XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
+  anymdp_bind_rng(h, 1);
+  AnyMDPTokIO io{action, nullptr, nullptr, nullptr, nullptr, nullptr, obs, reward, reward_gt, terminated, truncated, final_obs,
+                 steps, done};
   return anymdp_tok_launch_step<false>(h, io, autoreset_mode);
 }
 
