@@ -164,7 +164,7 @@ class MazeWorldVecEnv(VectorEnv):
         infos = {"steps": self._out(steps_before), "command": self._of(self._cmd_rgb)}
         if self.with_final_obs and self.autoreset_mode == "same_step":
             infos["final_obs"] = self._o(self._final)
-            infos["_final_obs"] = self._out((self._term | self._trunc).bool())
+            infos["_final_obs"] = self._out((self._term | self._trunc).view(torch.bool))   # flags are 0 / 1 bytes: one op, no conversion
         return (self._of(self._frames), self._of(self._reward), self._obf(self._term),
                 self._obf(self._trunc), infos)
 

@@ -110,7 +110,7 @@ class CartPoleVecEnv(VectorEnv):
         if self.autoreset_mode == "same_step":
             infos["final_obs"] = self._of(self._fobs)
             if not self.lean_infos:
-                infos["_final_obs"] = self._out((self._term | self._trunc).bool())
+                infos["_final_obs"] = self._out((self._term | self._trunc).view(torch.bool))   # flags are 0 / 1 bytes: one op, no conversion
         return (self._of(self._obs), self._of(self._reward), self._obf(self._term),
                 self._obf(self._trunc), infos)
 
