@@ -51,6 +51,14 @@ def _make(family, copy, n=1024):
         env = LinDSVecEnv(n, seed=9, copy=copy)
         env.set_task([LinearDSSampler(16, 8, 8, seed=k) for k in range(n // 64)])
         return env, _pol_l, ("command", "error", "final_obs")
+    if family == "pomdp":      # token steps (xv_anymdp_step_tokens_info) on reference-sampled POMDP tasks, cooperative kernel
+        from util import golden_files, load_anymdp_tok_golden
+        tasks = [load_anymdp_tok_golden(p)[1] for p in golden_files("anymdptok_") if "mtpomdp" not in p]
+        env = AnyMDPVecEnv(n, seed=9, copy=copy)
+        env.set_task(tasks, env_task_index=(np.arange(n) % len(tasks)).astype(np.int32))
+        env.set_search("bucket", n_bucket=16)
+        na = int(env.na)
+        return env, (lambda obs: (obs * 5 + 1) % na), ("reward_gt", "final_obs", "steps")
     env = CartPoleVecEnv(n, seed=9, frameskip=1, copy=copy)
     env.set_task([sample_cartpole(seed=k) for k in range(16)])
     return env, _pol_c, ("final_obs",)
@@ -69,7 +77,7 @@ def _record(out, keys, finished_only=("final_obs",)):
 
 
 @pytest.mark.parametrize("unroll", [1, 4])
-@pytest.mark.parametrize("family", ["anymdp", "linds", "cartpole"])
+@pytest.mark.parametrize("family", ["anymdp", "linds", "cartpole", "pomdp"])
 def test_captured_loop_equals_eager_calls(family, unroll):
     # eager, host tick, fresh tensors from every call
     env, pol, keys = _make(family, copy=True)
