@@ -525,10 +525,21 @@ def quick_families(steps=200, warmup=20):
         us = min(v for k2, v in r["us_per_vector_step"].items() if k2.startswith("captured"))
         return {"config": r["workload"], "ms_per_step": us * 1e-3, "env_steps_per_s": r["env_steps_per_s"],
                 "us_per_vector_step": r["us_per_vector_step"], "dtype": "f64", "device_error_flags": r["device_error_flags"]}
+    def tok():      # the POMDP / multi-token step on reference-distribution tasks (cooperative kernel on AUTO)
+        r = bench_anymdp_tok_refdist(a)
+        v = r["variants"]
+        us = {k: {"auto": v[k]["auto"]["us_per_step"], "per-lane (fence search)": v[k]["fence"]["us_per_step"],
+                  "kernel": v[k]["auto"]["kernel"]} for k in v}
+        one = v["POMDP d_obs=1 d_act=1"]["auto"]["us_per_step"]
+        # priced in random 128-byte lines: (1, 1) reads 2 dependent lines per env-step, (2, 2) three stages of 4.4 lines
+        return {"config": r["workload"], "ms_per_step": one * 1e-3, "env_steps_per_s": 65536 / (one * 1e-6), "us_per_step": us,
+                "dtype": "f64", "note": "ms_per_step / env_steps_per_s: the single-token POMDP; (2, 2) beside it in us_per_step",
+                "device_error_flags": max(v[k]["device_error_flags"] for k in v)}
     guard("linds", linds)
     guard("mazeworld_64", maze)
     guard("mixed_share", mixed)
     guard("anymdp_refdist", refdist)
+    guard("anymdp_tok_refdist", tok)
     guard("python_loop", pyloop)
     return out
 
