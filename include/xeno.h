@@ -44,7 +44,8 @@ extern "C" {
  *    xv_anymdp_effective_search, xv_anymdp_token_kernel); xv_anymdp_step_info / xv_linds_step_info (steps and the done mask
  *    from the step launch); xv_mixed_supported; xv_anymdp_sample_tasks up to 256 states; xv_maze_set_precision accepts
  *    XV_MAZE_FILTER_EXACT_DIRECT (a new value of an existing argument: no bump)
- * 9: xv_anymdp_step_tokens_info (the POMDP / multi-token step writes steps and the done mask itself) */
+ * 9: xv_anymdp_step_tokens_info (the POMDP / multi-token step writes steps and the done mask itself); xv_cartpole_step_info,
+ *    xv_acrobot_step_info (the done mask from the step launch) */
 #define XV_ABI_VERSION 9
 
 /* return codes */
@@ -504,6 +505,9 @@ int xv_cartpole_reset_injected(xv_cartpole* h, const uint8_t* mask, const double
                                float* obs);
 int xv_cartpole_step(xv_cartpole* h, const int32_t* action, float* obs, float* reward, uint8_t* terminated,
                      uint8_t* truncated, float* final_obs, int autoreset_mode);
+/* the same, and the terminated | truncated mask from the same launch (done uint8[n_env], nullable; ABI 9) */
+int xv_cartpole_step_info(xv_cartpole* h, const int32_t* action, float* obs, float* reward, uint8_t* terminated,
+                          uint8_t* truncated, float* final_obs, uint8_t* done, int autoreset_mode);
 /* T steps in one launch, the state in registers between them: action int32[T][n_env], outputs with a leading T
  * (obs float[T][n_env][4] ...); equals T calls of xv_cartpole_step (step t draws with the tick the t-th call would) */
 int xv_cartpole_rollout(xv_cartpole* h, int T, const int32_t* action, float* obs, float* reward, uint8_t* terminated,
@@ -535,6 +539,8 @@ int xv_acrobot_reset(xv_acrobot* h, const uint8_t* mask, float* obs /*[n_env][6]
 int xv_acrobot_reset_injected(xv_acrobot* h, const uint8_t* mask, const double* u /*[4][n_env] in [0,1)*/, float* obs);
 int xv_acrobot_step(xv_acrobot* h, const int32_t* action, float* obs, float* reward, uint8_t* terminated,
                     uint8_t* truncated, float* final_obs, int autoreset_mode);
+int xv_acrobot_step_info(xv_acrobot* h, const int32_t* action, float* obs, float* reward, uint8_t* terminated,
+                         uint8_t* truncated, float* final_obs, uint8_t* done, int autoreset_mode);   /* as xv_cartpole_step_info */
 /* T steps in one launch, as xv_cartpole_rollout: action int32[T][n_env], obs float[T][n_env][6] ... */
 int xv_acrobot_rollout(xv_acrobot* h, int T, const int32_t* action, float* obs, float* reward, uint8_t* terminated,
                        uint8_t* truncated, float* final_obs, int autoreset_mode);

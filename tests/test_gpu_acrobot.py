@@ -95,6 +95,8 @@ def test_free_running_philox_and_misuse():
         a = rng.randint(0, 3, n).astype(np.int32)
         tick = env.engine.tick
         obs, r, term, trunc, info = env.step(a)
+        if "_final_obs" in info:      # the done mask comes from the step launch (xv_*_step_info)
+            assert np.array_equal(_np(info["_final_obs"]), _np(term) | _np(trunc))
         o = ora.step(seed, base, tick, a, 2)
         assert np.array_equal(_np(trunc).astype(np.uint8), o["truncated"])
         agree = _np(term).astype(np.uint8) == o["terminated"]      # marginal terminal tests may differ in the last bit

@@ -69,6 +69,8 @@ def test_free_running_and_fp64_equations():
         before = _np(env.get_state()[0]).astype(np.float64)
         tick = env.engine.tick
         obs, r, term, trunc, info = env.step(a)
+        if "_final_obs" in info:      # the done mask comes from the step launch (xv_*_step_info)
+            assert np.array_equal(_np(info["_final_obs"]), _np(term) | _np(trunc))
         o = ora.step(seed, base, tick, a, 2)
         assert np.allclose(_np(obs), o["obs"], rtol=1e-6, atol=1e-7)
         fo = _np(info["final_obs"])

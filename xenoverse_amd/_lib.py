@@ -94,6 +94,7 @@ SIGNATURES = {
     "xv_cartpole_reset": [c_void_p, c_void_p, c_void_p],
     "xv_cartpole_reset_injected": [c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_cartpole_step": [c_void_p] + [c_void_p] * 6 + [c_int],
+    "xv_cartpole_step_info": [c_void_p] + [c_void_p] * 7 + [c_int],
     "xv_cartpole_rollout": [c_void_p, c_int] + [c_void_p] * 6 + [c_int],
     "xv_cartpole_step_injected": [c_void_p] + [c_void_p] * 7 + [c_int],
     "xv_cartpole_get_state": [c_void_p, c_void_p, c_void_p, c_void_p],
@@ -103,6 +104,7 @@ SIGNATURES = {
     "xv_acrobot_reset": [c_void_p, c_void_p, c_void_p],
     "xv_acrobot_reset_injected": [c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_acrobot_step": [c_void_p] + [c_void_p] * 6 + [c_int],
+    "xv_acrobot_step_info": [c_void_p] + [c_void_p] * 7 + [c_int],
     "xv_acrobot_rollout": [c_void_p, c_int] + [c_void_p] * 6 + [c_int],
     "xv_acrobot_step_injected": [c_void_p] + [c_void_p] * 7 + [c_int],
     "xv_acrobot_get_state": [c_void_p, c_void_p, c_void_p, c_void_p],

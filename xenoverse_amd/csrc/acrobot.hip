@@ -37,6 +37,7 @@ struct AcrobotIO {
   uint8_t* terminated;
   uint8_t* truncated;
   float* final_obs;          // nullable
+  uint8_t* done_out;         // nullable: terminated | truncated of the same step (xv_acrobot_step_info)
 };
 
 struct xv_acrobot {
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(64) void acrobot_step_kernel(AcrobotArgs P, Acrobot
   io.reward[ob] = reward;
   io.terminated[ob] = (uint8_t)term;
   io.truncated[ob] = (uint8_t)trunc;
+  if (io.done_out) io.done_out[ob] = (uint8_t)((term || trunc) ? 1 : 0);
   if (io.final_obs) acrobot_store_obs(io.final_obs + ob * 6, fobs);
   }
   P.state[i] = s[0]; P.state[N + i] = s[1]; P.state[2 * N + i] = s[2]; P.state[3 * N + i] = s[3];
@@ -332,6 +334,19 @@ extern "C" int xv_acrobot_step(xv_acrobot* h, const int32_t* action, float* obs,
   XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
   acrobot_bind_rng(h, 1);
   AcrobotIO io{action, nullptr, obs, reward, terminated, truncated, final_obs};
+  hipLaunchKernelGGL(acrobot_step_kernel<false>, dim3(xv_div_up(h->a.n_env, 64)), dim3(64), 0, h->eng->stream, h->a, io,
+                     autoreset_mode, 1);
+  XV_LAUNCH_CHECK();
+  return XV_OK;
+}
+
+// xv_acrobot_step that also writes the terminated | truncated mask from the same launch (done uint8[n_env], nullable)
+extern "C" int xv_acrobot_step_info(xv_acrobot* h, const int32_t* action, float* obs, float* reward, uint8_t* terminated,
+                                    uint8_t* truncated, float* final_obs, uint8_t* done, int autoreset_mode) {
+  XV_CHECK_ARG(h && action && obs && reward && terminated && truncated);
+  XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
+  acrobot_bind_rng(h, 1);
+  AcrobotIO io{action, nullptr, obs, reward, terminated, truncated, final_obs, done};
   hipLaunchKernelGGL(acrobot_step_kernel<false>, dim3(xv_div_up(h->a.n_env, 64)), dim3(64), 0, h->eng->stream, h->a, io,
                      autoreset_mode, 1);
   XV_LAUNCH_CHECK();

@@ -32,6 +32,7 @@ struct CartPoleIO {
   uint8_t* terminated;
   uint8_t* truncated;
   float* final_obs;          // nullable
+  uint8_t* done_out;         // nullable: terminated | truncated of the same step (xv_cartpole_step_info)
 };
 
 struct xv_cartpole {
@@ -124,6 +125,7 @@ __device__ __forceinline__ void cartpole_step_body(const CartPoleArgs& P, const 
   io.reward[o] = reward;
   io.terminated[o] = (uint8_t)term;
   io.truncated[o] = (uint8_t)trunc;
+  if (io.done_out) io.done_out[o] = (uint8_t)((term || trunc) ? 1 : 0);
   if (io.final_obs) reinterpret_cast<float4*>(io.final_obs)[o] = fobs;
   }
   P.state[i] = x; P.state[N + i] = xd; P.state[2 * N + i] = th; P.state[3 * N + i] = thd;
@@ -242,6 +244,19 @@ extern "C" int xv_cartpole_step(xv_cartpole* h, const int32_t* action, float* ob
   XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
   cartpole_bind_rng(h, 1);
   CartPoleIO io{action, nullptr, obs, reward, terminated, truncated, final_obs};
+  hipLaunchKernelGGL(cartpole_step_kernel<false>, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
+                     h->a, io, autoreset_mode, 1);
+  XV_LAUNCH_CHECK();
+  return XV_OK;
+}
+
+// xv_cartpole_step that also writes the terminated | truncated mask from the same launch (done uint8[n_env], nullable)
+extern "C" int xv_cartpole_step_info(xv_cartpole* h, const int32_t* action, float* obs, float* reward, uint8_t* terminated,
+                                     uint8_t* truncated, float* final_obs, uint8_t* done, int autoreset_mode) {
+  XV_CHECK_ARG(h && action && obs && reward && terminated && truncated);
+  XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
+  cartpole_bind_rng(h, 1);
+  CartPoleIO io{action, nullptr, obs, reward, terminated, truncated, final_obs, done};
   hipLaunchKernelGGL(cartpole_step_kernel<false>, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, h->eng->stream,
                      h->a, io, autoreset_mode, 1);
   XV_LAUNCH_CHECK();

@@ -84,6 +84,7 @@ class AcrobotVecEnv(VectorEnv):
         self._reward = torch.zeros(n, dtype=torch.float32, device=d)
         self._term = torch.zeros(n, dtype=torch.uint8, device=d)
         self._trunc = torch.zeros(n, dtype=torch.uint8, device=d)
+        self._done = torch.zeros(n, dtype=torch.uint8, device=d)       # terminated | truncated, written by the step launch
         self.task_set = True
         self.need_reset = True
 
@@ -108,11 +109,13 @@ class AcrobotVecEnv(VectorEnv):
         self.need_reset = False
         return self._o(self._obs)
 
-    def _ret(self):
+    def _ret(self, from_launch=False):
+        """from_launch: the step wrote `_done` itself (xv_acrobot_step_info)"""
         infos = {}
         if self.autoreset_mode == "same_step":
             infos["final_obs"] = self._of(self._fobs)
-            infos["_final_obs"] = self._out((self._term | self._trunc).view(torch.bool))   # flags are 0 / 1 bytes: one op, no conversion
+            infos["_final_obs"] = self._obf(self._done) if from_launch else \
+                self._out((self._term | self._trunc).view(torch.bool))      # flags are 0 / 1 bytes: a view, no conversion
         return (self._of(self._obs), self._of(self._reward), self._obf(self._term),
                 self._obf(self._trunc), infos)
 
@@ -121,11 +124,11 @@ class AcrobotVecEnv(VectorEnv):
             raise Exception("Must \"set_task\" and \"reset\" before doing any actions")
         a = self._dev(actions, torch.int32)
         assert a.shape == (self.num_envs,)
-        self._renew("_obs", "_reward", "_term", "_trunc", "_fobs")      # all fully written by the step
-        _lib.check(self.lib.xv_acrobot_step(self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward),
-                                            _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._fobs),
-                                            AUTORESET[self.autoreset_mode]))
-        return self._ret()
+        self._renew("_obs", "_reward", "_term", "_trunc", "_fobs", "_done")      # all fully written by the step
+        _lib.check(self.lib.xv_acrobot_step_info(self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward),
+                   _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._fobs), _lib.ptr(self._done),
+                   AUTORESET[self.autoreset_mode]))      # one launch: the done mask comes from the step kernel
+        return self._ret(from_launch=True)
 
     def rollout(self, actions, out=None):
         """Fused open-loop roll-out: actions int32[T, N] -> dict of [T, N(, 6)] device tensors from one launch with the
