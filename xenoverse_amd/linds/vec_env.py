@@ -113,6 +113,7 @@ class LinDSVecEnv(VectorEnv):
         self._tab = dev
         self.n_task = n_task
         n = self.num_envs
+        self._step_cache = None      # (copy=False steps cache pointers and views of the buffers made here)
         self._obs = torch.zeros((n, self.NO), dtype=torch.float32, device=d)
         self._cmd = torch.zeros((n, self.NO), dtype=torch.float32, device=d)
         self._fobs = torch.zeros((n, self.NO), dtype=torch.float32, device=d)
@@ -203,6 +204,14 @@ class LinDSVecEnv(VectorEnv):
 
     _STEP_OUTPUTS = ("_obs", "_reward", "_term", "_trunc", "_cmd", "_error")   # all fully written by a step
 
+    def _make_step_cache(self):
+        return dict(key=(self._obs.data_ptr(), self._fobs.data_ptr(), self._done.data_ptr()),
+                    args=tuple(C.c_void_p(t.data_ptr()) for t in (self._obs, self._reward, self._term, self._trunc, self._cmd,
+                                                                  self._error, self._fobs, self._steps, self._done)),
+                    obs=self._user_obs(self._obs), cmd=self._user_obs(self._cmd), fobs=self._user_obs(self._fobs),
+                    term_b=self._term.view(torch.bool), trunc_b=self._trunc.view(torch.bool),
+                    done_b=self._done.view(torch.bool))
+
     def _fresh_final_obs(self):
         """the step writes final_obs rows of FINISHED envs only (64 B per env-step that ~93 % of the envs do not need):
         copy=True / to_numpy hand out zero rows elsewhere, as before; with copy=False the rows of unfinished envs keep
@@ -233,6 +242,16 @@ class LinDSVecEnv(VectorEnv):
                                               _lib.ptr(self._error), _lib.ptr(self._fobs),
                                               AUTORESET[self.autoreset_mode]))
             return self._ret()
+        if not self.copy and not self.to_numpy:      # persistent outputs: pointers and views are made once
+            c = self._step_cache
+            if c is None or c["key"] != (self._obs.data_ptr(), self._fobs.data_ptr(), self._done.data_ptr()):
+                c = self._step_cache = self._make_step_cache()
+            _lib.check(self.lib.xv_linds_step_info(self._h, C.c_void_p(a.data_ptr()), *c["args"], AUTORESET[self.autoreset_mode]))
+            infos = {"steps": self._steps, "command": c["cmd"], "error": self._error}
+            if self.autoreset_mode == "same_step":
+                infos["final_obs"] = c["fobs"]
+                infos["_final_obs"] = c["done_b"]
+            return c["obs"], self._reward, c["term_b"], c["trunc_b"], infos
         # ONE launch: the step kernel writes info["steps"] and the terminated | truncated mask itself (xv_linds_step_info)
         self._renew("_steps", "_done")
         _lib.check(self.lib.xv_linds_step_info(self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward),
