@@ -113,3 +113,38 @@ def test_fused_rollout_equals_single_steps(mode):
     assert recs[0]["terminated"].sum() > 0 and recs[0]["truncated"].sum() > 0
     for k in recs[0]:
         assert np.array_equal(recs[0][k], recs[1][k]), k
+
+
+@pytest.mark.parametrize("family", ["cartpole", "acrobot"])
+@pytest.mark.parametrize("mode", ["same_step", "next_step"])
+def test_copy_false_steps_equal_fresh_tensor_steps(family, mode):
+    """copy=False (persistent outputs, cached pointers and views) returns what copy=True returns: same seed, same actions"""
+    from xenoverse_amd.metacontrol import AcrobotVecEnv, sample_acrobot
+    n = 300
+    envs = []
+    for copy in (True, False):
+        if family == "cartpole":
+            env = CartPoleVecEnv(n, frameskip=1, autoreset_mode=mode, max_steps=40, seed=5, copy=copy)
+            env.set_task([sample_cartpole(seed=k) for k in range(10)], env_task_index=(np.arange(n) % 10).astype(np.int32))
+        else:
+            env = AcrobotVecEnv(n, frameskip=1, autoreset_mode=mode, max_steps=40, seed=5, copy=copy)
+            env.set_task([sample_acrobot(seed=k) for k in range(10)], env_task_index=(np.arange(n) % 10).astype(np.int32))
+        envs.append(env)
+    o = [_np(e.reset()[0]).copy() for e in envs]
+    assert np.array_equal(o[0], o[1])
+    rng = np.random.RandomState(3)
+    ended = 0
+    for t in range(120):
+        a = rng.randint(0, 2, n).astype(np.int32)
+        outs = [e.step(a) for e in envs]
+        got = [[_np(x).copy() for x in out[:4]] for out in outs]
+        for x, y in zip(*got):
+            assert np.array_equal(x, y)
+        if mode == "same_step":
+            done = got[1][2] | got[1][3]
+            assert np.array_equal(_np(outs[1][4]["_final_obs"]), done) and np.array_equal(_np(outs[0][4]["_final_obs"]), done)
+            assert np.array_equal(_np(outs[0][4]["final_obs"])[done], _np(outs[1][4]["final_obs"])[done])
+            ended += int(done.sum())
+    assert mode != "same_step" or ended > 100
+    for e in envs:
+        e.close()

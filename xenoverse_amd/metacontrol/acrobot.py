@@ -85,6 +85,7 @@ class AcrobotVecEnv(VectorEnv):
         self._term = torch.zeros(n, dtype=torch.uint8, device=d)
         self._trunc = torch.zeros(n, dtype=torch.uint8, device=d)
         self._done = torch.zeros(n, dtype=torch.uint8, device=d)       # terminated | truncated, written by the step launch
+        self._step_cache = None      # (copy=False steps cache pointers and views of these buffers)
         self.task_set = True
         self.need_reset = True
 
@@ -124,6 +125,21 @@ class AcrobotVecEnv(VectorEnv):
             raise Exception("Must \"set_task\" and \"reset\" before doing any actions")
         a = self._dev(actions, torch.int32)
         assert a.shape == (self.num_envs,)
+        if not self.copy and not self.to_numpy:      # persistent outputs: pointers and views are made once
+            c = self._step_cache
+            if c is None or c["key"] != (self._obs.data_ptr(), self._fobs.data_ptr(), self._done.data_ptr()):
+                c = self._step_cache = dict(
+                    key=(self._obs.data_ptr(), self._fobs.data_ptr(), self._done.data_ptr()),
+                    args=tuple(C.c_void_p(t.data_ptr()) for t in (self._obs, self._reward, self._term, self._trunc, self._fobs,
+                                                                  self._done)),
+                    term_b=self._term.view(torch.bool), trunc_b=self._trunc.view(torch.bool), done_b=self._done.view(torch.bool))
+            _lib.check(self.lib.xv_acrobot_step_info(self._h, C.c_void_p(a.data_ptr()), *c["args"], AUTORESET[self.autoreset_mode]))
+            infos = {}
+            if self.autoreset_mode == "same_step":
+                infos["final_obs"] = self._fobs
+                if not getattr(self, "lean_infos", False):
+                    infos["_final_obs"] = c["done_b"]
+            return self._obs, self._reward, c["term_b"], c["trunc_b"], infos
         self._renew("_obs", "_reward", "_term", "_trunc", "_fobs", "_done")      # all fully written by the step
         _lib.check(self.lib.xv_acrobot_step_info(self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward),
                    _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._fobs), _lib.ptr(self._done),
