@@ -45,7 +45,7 @@ extern "C" {
  *    from the step launch); xv_mixed_supported; xv_anymdp_sample_tasks up to 256 states; xv_maze_set_precision accepts
  *    XV_MAZE_FILTER_EXACT_DIRECT (a new value of an existing argument: no bump)
  * 9: xv_anymdp_step_tokens_info (the POMDP / multi-token step writes steps and the done mask itself); xv_cartpole_step_info,
- *    xv_acrobot_step_info (the done mask from the step launch) */
+ *    xv_acrobot_step_info (the done mask from the step launch); xv_maze_set_raycast_mapping */
 #define XV_ABI_VERSION 9
 
 /* return codes */
@@ -626,6 +626,15 @@ int xv_maze_set_move_kernel(xv_maze* h, int kernel);
 #define XV_MAZE_FILTER_EXACT_DIRECT 2   /* EXACT's bytes with every pixel filtered in the reference's typing directly (EXACT
                                           speculates in float64 sums and re-runs a pixel whose byte is not certain) */
 int xv_maze_set_precision(xv_maze* h, int filter);
+/* Which lanes paint which pixels in the ray caster (same bytes either way).  COLUMNS: a lane paints its column top to bottom.
+ * ROWS: per batch of columns the lanes first work out what each column hands its pixels (wall hit, ray direction; 96 bytes per
+ * column in LDS), then every wave paints 64 rows of one column at a time — wall pixels of a column share their four texture
+ * rows, so the texture path sees fewer distinct lines per load.  AUTO (default): ROWS for the fp32 filter and for the exact
+ * filter on frames beyond 128 x 128, COLUMNS otherwise.  Packed (integer-valued) texture libraries only. */
+#define XV_MAZE_MAP_AUTO 0
+#define XV_MAZE_MAP_COLUMNS 1
+#define XV_MAZE_MAP_ROWS 2
+int xv_maze_set_raycast_mapping(xv_maze* h, int mapping);
 /* Which typing of the reference's ray-caster source the frames follow.  NUMPY2 (default): its @njit functions run as plain
  * Python under NumPy >= 2 (Python floats are weak, so DDA_2D and the wall-column geometry stay in the float32 of the
  * per-column tables) — the typing the golden frames were generated with.  NUMBA: the types numba infers for the same

@@ -35,7 +35,7 @@ def soak(rng, seed):
                              n_ceiling_textures=int(rng.randint(1, 4))) for k in range(n_task)]
     tex = make_texture_library(5, 3, 3, seed=seed % 997)
     tab = build_tables(tasks)
-    res = [(32, 32), (64, 64), (48, 40), (40, 72), (128, 128), (24, 96)][int(rng.randint(0, 6))]
+    res = [(32, 32), (64, 64), (48, 40), (40, 72), (128, 128), (24, 96), (160, 120)][int(rng.randint(0, 7))]   # the last: rows mapping
     per = int(rng.randint(1, max(2, 60000 // (res[0] * res[1] * n_task) + 1)))
     env_task = np.repeat(np.arange(n_task, dtype=np.int32), per)
     rng.shuffle(env_task)

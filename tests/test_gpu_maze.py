@@ -254,6 +254,36 @@ def test_speculated_exact_filter_paints_the_bytes_of_the_direct_one(res, per, ty
         assert f0.shape == f1.shape and np.array_equal(f0, f1), int((f0 != f1).sum())
 
 
+@pytest.mark.parametrize("res,per,prec,typing", [((64, 64), 300, "exact", "numpy2"), ((256, 256), 12, "exact", "numpy2"),
+                                                 ((64, 64), 300, "f32", "numpy2"), ((256, 256), 12, "f32", "numba"),
+                                                 ((136, 200), 20, "exact", "numba"), ((40, 24), 200, "f32", "numpy2")])
+def test_rows_mapping_of_the_ray_caster_paints_the_bytes_of_the_columns_mapping(res, per, prec, typing):
+    """set_raycast_mapping("rows"): every wave paints 64 rows of one column at a time from what the column left in LDS;
+    "columns": a lane paints its column.  Same arithmetic per pixel, so the same bytes — exact (speculated) and fp32 filter,
+    frames of one and of several column batches / row chunks (W up to 200 > 128 threads... and H = 200 > one chunk)"""
+    tasks = [load_maze_golden(p)[1] for p in FILES]
+    env_task = np.repeat(np.arange(len(tasks), dtype=np.int32), per)
+    n = len(env_task)
+    a = np.random.RandomState(13).randint(0, 16, (20, n)).astype(np.int32)
+    frames = {}
+    for mapping in ("columns", "rows", "auto"):
+        env = MazeWorldVecEnv(n, resolution=res, textures=tex(), autoreset_mode="same_step", precision=prec, typing=typing,
+                              seed=3, command_in_observation=True)
+        env.set_task(tasks, env_task_index=env_task)
+        env.set_raycast_mapping(mapping)
+        env.reset()
+        got = []
+        for t in range(20):
+            out = env.step(a[t])
+            if t in (7, 19):
+                got.append(_np(out[0]).copy())
+        frames[mapping] = got
+        env.close()
+    for k in range(2):
+        assert np.array_equal(frames["columns"][k], frames["rows"][k]), int((frames["columns"][k] != frames["rows"][k]).sum())
+        assert np.array_equal(frames["columns"][k], frames["auto"][k])
+
+
 @pytest.mark.parametrize("mode,space", [("same_step", "Discrete16"), ("next_step", "Discrete32"), ("disabled", "Continuous"),
                                         ("same_step", "turns")])
 def test_nine_lane_move_kernel_equals_the_lane_per_env_kernel(mode, space):

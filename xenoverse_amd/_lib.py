@@ -118,6 +118,7 @@ SIGNATURES = {
     "xv_maze_set_state": [c_void_p] + [c_void_p] * 6,
     "xv_maze_render": [c_void_p, c_void_p, c_void_p],
     "xv_maze_set_precision": [c_void_p, c_int],
+    "xv_maze_set_raycast_mapping": [c_void_p, c_int],
     "xv_maze_set_typing": [c_void_p, c_int],
     "xv_maze_set_move_kernel": [c_void_p, c_int],
     "xv_maze_agent_create": [c_void_p, c_int, C.c_double, c_int, c_int, c_int, c_void_p],

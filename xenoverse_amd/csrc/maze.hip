@@ -786,17 +786,25 @@ __global__ __launch_bounds__(256) void maze_tex_integral_kernel(const float* tex
 // Python under NumPy 2, which the golden frames were made with (oracle/mz_wall_stage.inc holds both, REAL = float / double).
 // FILT: 0 / 3 = the exact filter, speculated when PACKED (mz_interpolate_spec), reading the pair-interleaved (0) or the
 // row-major (3) texture copy; 1 = the opt-in fp32 filter; 2 = the exact filter evaluated directly for every pixel
-// (XV_MAZE_FILTER_EXACT_DIRECT: what the speculated one is tested against).  The launcher picks 0 for frames up to 128 x 128
+// (XV_MAZE_FILTER_EXACT_DIRECT: what the speculated one is tested against); 5 / 6 = 3 / 1 with the pixel loop on the ROWS of
+// one column per wave (xv_maze_set_raycast_mapping; maze_launch_render picks).  The launcher picks 0 for frames up to 128 x 128
 // and 3 beyond (16,384 envs, scripts/runs_r04/gpu_t.sh: 64 x 64 1.09 ms pairs / 1.16 ms rows, 256 x 256 14.6 / 14.1 ms;
 // direct 1.29 / 17.4 ms).
+// What a column of the frame hands to its pixels (the wall the column's ray hit and the ray's direction): in registers when a
+// lane paints its own column, in LDS when the lanes of a wave paint the ROWS of one column (FILT 5 / 6)
+struct MzColumn {
+  int v_s, v_e, text_id, pad;                                       // wall rows [v_s, v_e), wall texture
+  double f_i, L, a_far, a_near, ratio, co, so, rcos_b, rcos_y, pad2;   // 96 bytes
+};
 #ifndef XV_MAZE_RC_WAVES
 #define XV_MAZE_RC_WAVES 3   // waves per SIMD the register allocation aims at (2: 1.12 ms at 64 x 64, same at 256 x 256)
 #endif
 template <bool FINAL, bool PACKED, int FILT, bool NB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_WAVES, XV_MAZE_RC_WAVES))) void maze_raycast_kernel(MazeArgs P, uint8_t* frames, float* command_rgb) {
   using RT = typename std::conditional<NB, double, float>::type;
-  constexpr bool F32 = FILT == 1, SPEC = (FILT == 0 || FILT == 3) && PACKED;
+  constexpr bool F32 = FILT == 1 || FILT == 6, SPEC = (FILT == 0 || FILT == 3 || FILT == 5) && PACKED;
   constexpr bool PP = F32 || (SPEC && FILT == 0);   // which packed copy the pixels read
+  constexpr bool ROWS = (FILT == 5 || FILT == 6) && PACKED;        // lanes = rows of one column in the pixel loop
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int e = blockIdx.x;
   if (FINAL && !P.fin_flag[e]) return;   // block-uniform
@@ -955,27 +963,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
     // there is a single copy of the 16-tap filter.  Unpainted pixels keep FAR_RGB = 1 (:165-166).
     // what pixel d_v of the column shows: the texture, the filter position (f_i, f_j), the footprint f_d and the shading
     // v = L (A + B c) of its colour c
-    auto pixel = [&](int d_v, const void*& tx, double& f_i, double& f_j, double& f_d, double& L, double& A, double& B) -> bool {
+    const MzColumn me = {v_s, v_e, text_id, 0, (double)wall_ti, (double)light_w, a_far_w, a_near_w, (double)ratio,
+                         (double)co, (double)so, R_cos.b, R_cos.y, 0.0};
+    auto pixel = [&](const MzColumn& C, int d_v, const void*& tx, double& f_i, double& f_j, double& f_d, double& L, double& A,
+                     double& B) -> bool {
       bool paint = false;
-      tx = wt;
-      f_i = 0.0; f_j = 0.0; f_d = eff_ps_w; L = (double)light_w; A = a_far_w; B = a_near_w;
-      if (d_v >= v_s && d_v < v_e) {
-        const double local_v = (half_v - (d_v + 0.5) * pixel_size) * (double)ratio + vision_height;
+      tx = PACKED ? (const void*)((PP ? P.pp_walls : P.pk_walls) + (size_t)C.text_id * 256 * MZ_TEX_PITCH)
+                  : (const void*)(P.T.tex_walls + (size_t)C.text_id * 256 * 256 * 3);
+      f_i = 0.0; f_j = 0.0; f_d = eff_ps_w; L = C.L; A = C.a_far; B = C.a_near;
+      if (d_v >= C.v_s && d_v < C.v_e) {
+        const double local_v = (half_v - (d_v + 0.5) * pixel_size) * C.ratio + vision_height;
         double d_j = local_v / text_size;
         d_j -= floor(d_j);
-        f_i = (double)wall_ti;
+        f_i = C.f_i;
         f_j = (double)(int)(256 * d_j);
         paint = true;
       } else {
-        const bool is_floor = d_v > H / 2;   // wave-uniform
+        const bool is_floor = d_v > H / 2;
         const double2 dl = rowtab[d_v];
         const double distance = dl.x, light = dl.y;
         if (!(distance > visibility)) {
-          const double eff = mz_div(distance, R_cos);
+          const MzDivisor R_c = {C.rcos_b, C.rcos_y};
+          const double eff = mz_div(distance, R_c);
           double alpha = mz_div(2.0 * eff, R_vis) - 1.0;
           alpha = __builtin_fmin(__builtin_fmax(alpha, 0.0), 1.0);
           if (is_floor) alpha *= light;   // :189, the floor only
-          const double hit_x = eff * (double)co + (double)pos0, hit_y = eff * (double)so + (double)pos1;
+          const double hit_x = eff * C.co + (double)pos0, hit_y = eff * C.so + (double)pos1;
           const double fi = mz_div(hit_x, R_cs), fj = mz_div(hit_y, R_cs);
           double d_i = fi - floor(fi), d_j = fj - floor(fj);
           const int i = (int)fi, j = (int)fj;
@@ -992,17 +1005,78 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
       }
       return paint;
     };
+    MzColumn* colp = reinterpret_cast<MzColumn*>(rowtab + H);   // ROWS: the columns of this batch, behind the row table
+    if (ROWS) colp[threadIdx.x] = me;
     for (int c0 = 0; c0 < H; c0 += HC) {
       const int c1 = min(c0 + HC, H);
       // SPEC: blocks of 64 rows; the pixels whose byte the speculated filter could not settle are noted in `redo` and
       // filtered in the reference's typing by a second loop (rare: the two filters never share a register allocation)
+      if (ROWS) {
+        // the lanes of a wave paint 64 ROWS of one column at a time (wave w takes columns w, w + nw, ...): wall pixels of a
+        // column read the same four texture rows, the rows of a ray's floor / ceiling pixels neighbouring texels
+        __syncthreads();
+        const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6, ln = threadIdx.x & 63;
+        const int ncols = min((int)blockDim.x, W - g0);
+        for (int r0 = c0; r0 < c1; r0 += 64) {
+          const bool act = r0 + ln < c1;
+          const int d_v = act ? r0 + ln : c1 - 1;
+          unsigned long long redo = 0ull;
+          int k = 0;
+          for (int cc = wv; cc < ncols; cc += nw, ++k) {
+            const MzColumn C = colp[cc];
+            const void* tx;
+            double f_i, f_j, f_d, L, A, B;
+            const bool paint = pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B);
+            uint8_t* px = lds + (size_t)cc * cstride + (d_v - c0) * 3;
+            uint8_t b0 = 1, b1 = 1, b2 = 1;
+            if (paint) {
+              double c[3];
+              if (SPEC) {
+                uint32_t qw[4][4];
+                mz_fetch_window<PP>(tx, (int)f_i, (int)f_j, qw);
+                mz_interpolate_spec(qw, f_i, f_j, f_d, tps, c);
+                bool doubt = false;
+                b0 = mz_spec_byte(L, A, B, c[0], doubt);
+                b1 = mz_spec_byte(L, A, B, c[1], doubt);
+                b2 = mz_spec_byte(L, A, B, c[2], doubt);
+                redo |= (unsigned long long)(doubt && act) << k;
+              } else {
+                mz_interpolate_f32<PACKED>(tx, f_i, f_j, f_d, tps, c);
+                b0 = mz_clip_u8(L * (A + B * c[0]));
+                b1 = mz_clip_u8(L * (A + B * c[1]));
+                b2 = mz_clip_u8(L * (A + B * c[2]));
+              }
+            }
+            if (act) { px[0] = b0; px[1] = b1; px[2] = b2; }
+          }
+          if (SPEC) {
+            while (redo) {   // per lane: the pixels whose byte the speculation could not settle, in the reference's typing
+              const int kk = __builtin_ctzll(redo);
+              redo &= redo - 1ull;
+              const int cc = wv + kk * nw;
+              const MzColumn C = colp[cc];
+              const void* tx;
+              double f_i, f_j, f_d, L, A, B, c[3];
+              (void)pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B);
+              uint32_t qw[4][4];
+              mz_fetch_window<PP>(tx, (int)f_i, (int)f_j, qw);
+              mz_interpolate<true, true>(nullptr, f_i, f_j, f_d, tps, tps, c, qw);
+              uint8_t* px = lds + (size_t)cc * cstride + (d_v - c0) * 3;
+              px[0] = mz_clip_u8(L * (A + B * c[0]));
+              px[1] = mz_clip_u8(L * (A + B * c[1]));
+              px[2] = mz_clip_u8(L * (A + B * c[2]));
+            }
+          }
+        }
+        __syncthreads();
+      } else
       for (int r0 = c0; r0 < c1; r0 += SPEC ? 64 : HC) {
         const int r1 = SPEC ? min(r0 + 64, c1) : c1;
         unsigned long long redo = 0ull;
         for (int d_v = r0; d_v < r1; ++d_v) {
           const void* tx;
           double f_i, f_j, f_d, L, A, B;
-          const bool paint = pixel(d_v, tx, f_i, f_j, f_d, L, A, B);
+          const bool paint = pixel(me, d_v, tx, f_i, f_j, f_d, L, A, B);
           uint8_t* px = col + (d_v - c0) * 3;
           if (paint) {
             double c[3];
@@ -1032,7 +1106,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
             redo &= redo - 1ull;
             const void* tx;
             double f_i, f_j, f_d, L, A, B, c[3];
-            (void)pixel(d_v, tx, f_i, f_j, f_d, L, A, B);
+            (void)pixel(me, d_v, tx, f_i, f_j, f_d, L, A, B);
             uint32_t qw[4][4];
             mz_fetch_window<PP>(tx, (int)f_i, (int)f_j, qw);
             mz_interpolate<true, true>(nullptr, f_i, f_j, f_d, tps, tps, c, qw);
@@ -1225,18 +1299,27 @@ extern "C" int xv_maze_destroy(xv_maze* h) {
 static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, bool final) {
   const MazeArgs& a = h->a;
   const int threads = maze_rc_threads(a.W);
-  const size_t lds_bytes = (((size_t)threads * (a.HC * 3 + 4) + 15) & ~(size_t)15) + (size_t)a.H * 16;
+  // which lanes paint what (xv_maze_set_raycast_mapping): AUTO = rows of a column for the fp32 filter and for the exact filter on
+  // frames beyond 128 x 128 (scripts/runs_r04/gpu_rows.sh: fp32 1.05 -> 0.90 ms at 64 x 64, 11.6 -> 10.8 ms at 256 x 256; exact
+  // 14.1 -> 13.4 ms at 256 x 256, but 1.08 -> 1.19 ms at 64 x 64, where it stays on columns)
+  const int rows_map = h->raycast_mapping == XV_MAZE_MAP_COLUMNS ? 0 : (h->raycast_mapping == XV_MAZE_MAP_ROWS ? 3 : 2);
   float* crgb = final ? nullptr : command_rgb;
   const bool packed = a.pk_walls != nullptr;
+  // FILT of the kernel: 0 / 3 the speculated exact filter on the pair / row-major texture copy, 1 fp32, 2 direct, 5 / 6 = 3 / 1 on rows
+  const int filt0 = h->filter != XV_MAZE_FILTER_EXACT ? h->filter : (packed && (size_t)a.W * a.H > 128 * 128 ? 3 : 0);
+  const int filt = !packed || !rows_map ? filt0 : (filt0 == 1 ? 6 : ((filt0 == 3 || (filt0 == 0 && rows_map == 3)) ? 5 : filt0));
+  const size_t lds_bytes = (((size_t)threads * (a.HC * 3 + 4) + 15) & ~(size_t)15) + (size_t)a.H * 16 +
+                           (filt >= 5 ? (size_t)threads * sizeof(MzColumn) : 0);
 #define MAZE_RC(F, K, Q, B) \
   hipLaunchKernelGGL((maze_raycast_kernel<F, K, Q, B>), dim3(a.n_env), dim3(threads), lds_bytes, h->eng->stream, a, frames, crgb)
 #define MAZE_RC2(F, K)                                                                  \
   do {                                                                                  \
-    const int filt = h->filter != XV_MAZE_FILTER_EXACT ? h->filter : ((K) && (size_t)a.W * a.H > 128 * 128 ? 3 : 0);                  \
     if (h->typing_numba) { if (filt == 1) MAZE_RC(F, K, 1, true); else if (filt == 2) MAZE_RC(F, K, 2, true);                          \
-                           else if (filt == 3) MAZE_RC(F, K, 3, true); else MAZE_RC(F, K, 0, true); }                                  \
+                           else if (filt == 3) MAZE_RC(F, K, 3, true); else if (filt == 5) MAZE_RC(F, K, 5, true);                     \
+                           else if (filt == 6) MAZE_RC(F, K, 6, true); else MAZE_RC(F, K, 0, true); }                                  \
     else { if (filt == 1) MAZE_RC(F, K, 1, false); else if (filt == 2) MAZE_RC(F, K, 2, false);                                        \
-           else if (filt == 3) MAZE_RC(F, K, 3, false); else MAZE_RC(F, K, 0, false); }                                                \
+           else if (filt == 3) MAZE_RC(F, K, 3, false); else if (filt == 5) MAZE_RC(F, K, 5, false);                                   \
+           else if (filt == 6) MAZE_RC(F, K, 6, false); else MAZE_RC(F, K, 0, false); }                                               \
   } while (0)
   if (final) { if (packed) MAZE_RC2(true, true); else MAZE_RC2(true, false); }
   else { if (packed) MAZE_RC2(false, true); else MAZE_RC2(false, false); }
@@ -1249,6 +1332,12 @@ static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, b
 extern "C" int xv_maze_set_precision(xv_maze* h, int filter) {
   XV_CHECK_ARG(h != nullptr && (filter == XV_MAZE_FILTER_EXACT || filter == XV_MAZE_FILTER_F32 || filter == XV_MAZE_FILTER_EXACT_DIRECT));
   h->filter = filter;
+  return XV_OK;
+}
+
+extern "C" int xv_maze_set_raycast_mapping(xv_maze* h, int mapping) {
+  XV_CHECK_ARG(h != nullptr && (mapping == XV_MAZE_MAP_AUTO || mapping == XV_MAZE_MAP_COLUMNS || mapping == XV_MAZE_MAP_ROWS));
+  h->raycast_mapping = mapping;
   return XV_OK;
 }
 

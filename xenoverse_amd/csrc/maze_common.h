@@ -42,6 +42,7 @@ struct xv_maze {
   xv_engine* eng;
   MazeArgs a;
   int filter = 0;            // xv_maze_set_precision (XV_MAZE_FILTER_*)
+  int raycast_mapping = 0;   // xv_maze_set_raycast_mapping (XV_MAZE_MAP_*)
   bool typing_numba = false; // xv_maze_set_typing
   bool move_lanes9 = true;   // xv_maze_set_move_kernel
   int move_lanes = 0;        // 0: by batch size; 3 or 9: forced (xv_maze_set_move_kernel)

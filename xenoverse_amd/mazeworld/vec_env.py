@@ -175,6 +175,11 @@ class MazeWorldVecEnv(VectorEnv):
         _lib.check(self.lib.xv_maze_set_move_kernel(self._h, {"lane_per_env": 0, "nine_lanes": 1, "three_lanes": 2,
                                                               "auto": 3, "nine_lanes_compact": 4}[kernel]))
 
+    def set_raycast_mapping(self, mapping):
+        """"auto" (default), "columns" or "rows": which lanes of the ray caster paint which pixels (xv_maze_set_raycast_mapping);
+        the frames are the same bytes either way"""
+        _lib.check(self.lib.xv_maze_set_raycast_mapping(self._h, {"auto": 0, "columns": 1, "rows": 2}[mapping]))
+
     def render_frames(self):
         """frames of the current state, without stepping"""
         self._detach("_frames", "_cmd_rgb")
