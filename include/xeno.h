@@ -46,7 +46,7 @@ extern "C" {
  *    XV_MAZE_FILTER_EXACT_DIRECT (a new value of an existing argument: no bump)
  * 9: xv_anymdp_step_tokens_info (the POMDP / multi-token step writes steps and the done mask itself); xv_cartpole_step_info,
  *    xv_acrobot_step_info (the done mask from the step launch); xv_maze_set_raycast_mapping */
-#define XV_ABI_VERSION 9
+#define XV_ABI_VERSION 10
 
 /* return codes */
 #define XV_OK 0
@@ -233,6 +233,29 @@ int xv_anymdp_set_step_many_graph(xv_anymdp* h, int mode);
 /* 1: the last xv_anymdp_step_many replayed the graph, 0: plain launches, -1: graph construction or launch failed (plain
  * launches used) */
 int xv_anymdp_step_many_graph_state(xv_anymdp* h);
+
+/* A VIEW of envs [env_lo, env_lo + n_env) of `parent` as a handle of its own (ABI 10).  The reference steps one env object
+ * at a time and its batched loop iterates independent envs (anymdp/anymdp_env.py:92-132, anymdp/test_utils.py:42-60): any
+ * subset of a vector step can run on its own.  The view borrows the parent's tables, env records and bucket / observation
+ * lines and launches on the stream of `e`, whose seed must equal the parent engine's and whose env_id_base must be the
+ * parent's + env_lo — an env then has the same Philox counters through either handle, so a view stepped with launch tick t
+ * writes exactly what the parent stepped with tick t writes for those envs.  Every entry point that takes an xv_anymdp
+ * takes a view (step, step_info, step_many, rollout, reset, get/set_state, token steps ...).  While views exist the parent
+ * refuses xv_anymdp_build_buckets, xv_anymdp_set_observation_model and xv_anymdp_destroy (XV_ERR_UNSUPPORTED /
+ * XV_ERR_INVALID); destroy the views first.  Device errors of a view's launches land in ITS engine's error word. */
+int xv_anymdp_view(xv_anymdp* parent, xv_engine* e, int env_lo, int n_env, xv_anymdp** out);
+/* xv_anymdp_step_many with the envs stepped as n_views INDEPENDENT chains (n_views <= 16).  views[c] are views of `parent`
+ * that tile its envs in order.  Step k of chain c waits for step k - 1 of chain c only, so the launch-to-launch gap of one
+ * chain (an empty launch of a 65,536-env grid is 2.7 of the step's 5.0 us) is covered by the table lines other chains
+ * have in flight.  how = 0: every chain on its view's stream (its own cycle graph, or plain launches when the parent's
+ * step_many graph mode is 0); how = 1: ONE graph on the parent's stream whose branches are the chains.  Arrays are the
+ * parent's [period][parent n_env] rings.  Same launch ticks, same per-env Philox counters: outputs, env records and the
+ * parent's tick afterwards equal xv_anymdp_step_many's bit for bit (tests/test_gpu_chains.py).  Stream order as for one
+ * call on the parent's stream: the chains start behind what that stream holds and it waits for all of them.  Needs the
+ * host tick (XV_ERR_UNSUPPORTED on device-tick engines). */
+int xv_anymdp_step_many_chains(xv_anymdp* parent, xv_anymdp* const* views, int n_views, int how, int n_steps, int period,
+                               const int32_t* actions, int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated,
+                               uint8_t* truncated, int32_t* final_obs, int autoreset_mode);
 
 /* fused rollout: T vector steps in one launch with pre-generated actions[T][n_env] (open-loop / random
  * policy data collection); outputs are [T][n_env].  Bit-identical to T calls of xv_anymdp_step with

@@ -1,0 +1,186 @@
+"""Sub-batch views (xv_anymdp_view) and K interleaved chains (xv_anymdp_step_many_chains) — GPU tests.
+
+The reference steps one env object per call and its batched loop iterates independent envs
+(anymdp/anymdp_env.py:92-132, anymdp/test_utils.py:42-60): the envs of a vector step may be stepped as K sub-batches
+in any interleaving.  The contract checked here is bit-equality with the one-chain path (outputs of every ring slot,
+the env records, the launch tick) — the oracle parity of the one-chain path is tests/test_gpu_anymdp.py's business.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from xenoverse_amd import _lib
+from xenoverse_amd.anymdp import AnyMDPVecEnv
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+
+
+def _dev_tables(tab, dev="cuda:0"):
+    out = {}
+    for k, v in tab.items():
+        if isinstance(v, np.ndarray):
+            if v.dtype == np.uint64:
+                v = v.view(np.int64)
+            out[k] = torch.from_numpy(np.ascontiguousarray(v)).to(dev)
+        else:
+            out[k] = v
+    return out
+
+
+def _run_many(tab, n, P, acts_np, plan, search, chains, how, graph, seed=77):
+    """-> list of snapshots: the ring after every step_many of `plan`, then (state, steps, need_reset, tick)"""
+    env = AnyMDPVecEnv(n, seed=seed, autoreset_mode="same_step", bucket_lines="off")
+    env.set_task(_dev_tables(tab))
+    if search == "bucket":
+        env.set_search("bucket", n_bucket=16)
+    else:
+        env.set_search(search)
+    env.set_step_many_graph(graph)
+    env.reset()
+    acts = torch.as_tensor(acts_np, device=env.device)
+    rec, ring = [], None
+    for n_steps in plan:
+        ring = env.step_many(n_steps, acts, out=ring, chains=chains, how=how)
+        torch.cuda.synchronize()
+        rec.append({k: _np(v).copy() for k, v in ring.items()})
+    s, st, nr = env.get_state()
+    rec.append({"state": _np(s), "steps": _np(st), "need_reset": _np(nr), "tick": np.asarray(env.engine.tick)})
+    assert env.check_errors() == 0
+    env.close()
+    return rec
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        for k in x:
+            assert np.array_equal(x[k], y[k]), k
+
+
+@pytest.mark.parametrize("search", ["fence", "bucket", "binary"])
+@pytest.mark.parametrize("how", ["streams", "graph"])
+@pytest.mark.parametrize("chains", [2, 4, 8])
+def test_k_chains_equal_one_chain_small(search, how, chains):
+    """whole cycles, a remainder, a second call on the same rings (cached graphs, ticks re-synchronised)"""
+    tab = oracle.anymdp_synth(seed=12, task_index_base=0, n_task=16, S=64, A=8, s0_max=4)
+    n, P = 2048, 8
+    acts = np.random.RandomState(5).randint(0, 8, (P, n)).astype(np.int32)
+    plan = [3 * P + 5, 2 * P, 3, P]
+    ref = _run_many(tab, n, P, acts, plan, search, 1, "streams", True)
+    got = _run_many(tab, n, P, acts, plan, search, chains, how, True)
+    _same(ref, got)
+    assert ref[0]["terminated"].sum() > 50
+
+
+@pytest.mark.parametrize("how", ["streams", "graph"])
+def test_k_chains_with_plain_launches(how):
+    """step_many graph mode off: the chains issue plain launches on their streams (how = streams) / the parent's own
+    launches (how = graph falls back)"""
+    tab = oracle.anymdp_synth(seed=13, task_index_base=0, n_task=8, S=64, A=8, s0_max=4)
+    n, P = 1024, 4
+    acts = np.random.RandomState(6).randint(0, 8, (P, n)).astype(np.int32)
+    plan = [2 * P + 1, P]
+    ref = _run_many(tab, n, P, acts, plan, "fence", 1, "streams", False)
+    got = _run_many(tab, n, P, acts, plan, "fence", 4, how, False)
+    _same(ref, got)
+
+
+@pytest.mark.parametrize("search", ["bucket", "fence"])
+@pytest.mark.parametrize("how,chains", [("streams", 2), ("streams", 4), ("streams", 8), ("graph", 4)])
+def test_k_chains_equal_one_chain_at_65536_envs(search, how, chains):
+    """the headline batch size (65,536 envs; 1,024 shared tasks so that the tables fit any box): every output of a
+    32-slot ring over 3 cycles + 7 steps, the env records and the tick, bit for bit"""
+    tab = oracle.anymdp_synth(seed=21, task_index_base=0, n_task=1024, S=64, A=8, s0_max=4)
+    n, P = 65536, 32
+    acts = np.random.RandomState(7).randint(0, 8, (P, n)).astype(np.int32)
+    plan = [3 * P + 7]
+    ref = _run_many(tab, n, P, acts, plan, search, 1, "streams", True)
+    got = _run_many(tab, n, P, acts, plan, search, chains, how, True)
+    _same(ref, got)
+    assert ref[0]["terminated"].sum() > 1000 and ref[0]["truncated"].sum() >= 0
+
+
+def test_view_steps_equal_the_parents_slice():
+    """sub-batches made by split(): step(), reset(), get_state() of view k == the parent's slice (same seed, same tick),
+    in either order of the sub-batches; the views share the env records with the parent"""
+    tab = oracle.anymdp_synth(seed=31, task_index_base=0, n_task=8, S=64, A=8, s0_max=4)
+    n, K, T = 1024, 4, 24
+    acts = np.random.RandomState(8).randint(0, 8, (T, n)).astype(np.int32)
+
+    whole = AnyMDPVecEnv(n, seed=5, autoreset_mode="same_step")
+    whole.set_task(_dev_tables(tab))
+    obs0, _ = whole.reset()
+    ref = [whole.step(acts[t]) for t in range(T)]
+    ref = [tuple(_np(x) for x in r[:4]) + (_np(r[4]["reward_gt"]), _np(r[4]["final_obs"]), _np(r[4]["steps"])) for r in ref]
+    s_ref = [_np(x) for x in whole.get_state()]
+    whole.close()
+
+    env = AnyMDPVecEnv(n, seed=5, autoreset_mode="same_step")
+    env.set_task(_dev_tables(tab))
+    env.reset()
+    subs = env.split(K)
+    assert env.split(K) is subs and len(subs) == K and all(s.num_envs == n // K for s in subs)
+    per = n // K
+    for t in range(T):
+        order = range(K) if t % 2 == 0 else reversed(range(K))      # sub-batches are independent: any order
+        for c in order:
+            sub = subs[c]
+            with torch.cuda.stream(sub.stream):      # actions are produced and results read on the sub-batch's stream
+                o = sub.step(torch.as_tensor(acts[t, c * per:(c + 1) * per], device=env.device))
+                got = tuple(_np(x) for x in o[:4]) + (_np(o[4]["reward_gt"]), _np(o[4]["final_obs"]), _np(o[4]["steps"]))
+            for x, y in zip(got, ref[t]):
+                assert np.array_equal(x, y[c * per:(c + 1) * per])
+    torch.cuda.synchronize()
+    s_got = [_np(x) for x in env.get_state()]           # the PARENT's records: the views wrote them
+    for x, y in zip(s_got, s_ref):
+        assert np.array_equal(x, y)
+    assert np.array_equal(_np(subs[1].state), _np(env.state)[per:2 * per])
+    assert env.check_errors() == 0
+    # the parent's tables are pinned while views exist
+    with pytest.raises(_lib.XenoError):
+        _lib.check(env.lib.xv_anymdp_build_buckets(env._h, 16))
+    assert env.lib.xv_anymdp_destroy(env._h) != 0
+    env.set_search("bucket", n_bucket=32)                # other lines: the wrapper drops the views first
+    assert env._views == []
+    subs = env.split(2)
+    assert subs[0].effective_search == "bucket"
+    env.close()
+
+
+def test_view_argument_checks():
+    tab = oracle.anymdp_synth(seed=31, task_index_base=0, n_task=4, S=16, A=4, s0_max=3)
+    env = AnyMDPVecEnv(256, seed=9, env_id_base=1000)
+    env.set_task(_dev_tables(tab))
+    from xenoverse_amd.engine import Engine
+    lib = env.lib
+    h = C.c_void_p()
+    bad_base = Engine(env.device, seed=9, env_id_base=1000)          # must be 1000 + env_lo
+    assert lib.xv_anymdp_view(env._h, bad_base.handle, 64, 64, C.byref(h)) != 0
+    bad_seed = Engine(env.device, seed=10, env_id_base=1064)
+    assert lib.xv_anymdp_view(env._h, bad_seed.handle, 64, 64, C.byref(h)) != 0
+    ok = Engine(env.device, seed=9, env_id_base=1064)
+    assert lib.xv_anymdp_view(env._h, ok.handle, 64, 256, C.byref(h)) != 0      # beyond the parent's envs
+    assert lib.xv_anymdp_view(env._h, ok.handle, 64, 64, C.byref(h)) == 0
+    v = C.c_void_p(h.value)
+    h2 = C.c_void_p()
+    assert lib.xv_anymdp_view(v, ok.handle, 0, 8, C.byref(h2)) != 0             # no views of views
+    # chains must tile the parent
+    arr = (C.c_void_p * 1)(v)
+    z = torch.zeros((2, 256), dtype=torch.int32, device=env.device)
+    f = torch.zeros((2, 256), dtype=torch.float32, device=env.device)
+    b = torch.zeros((2, 256), dtype=torch.uint8, device=env.device)
+    env.reset()
+    rc = lib.xv_anymdp_step_many_chains(env._h, arr, 1, 0, 2, 2, z.data_ptr(), z.data_ptr(), f.data_ptr(), f.data_ptr(),
+                                        b.data_ptr(), b.data_ptr(), None, 2)
+    assert rc != 0
+    assert lib.xv_anymdp_destroy(v) == 0
+    env.close()
+    for e in (bad_base, bad_seed, ok):
+        e.close()

@@ -48,6 +48,8 @@ SIGNATURES = {
     "xv_anymdp_step_injected": [c_void_p] + [c_void_p] * 10 + [c_int],
     "xv_anymdp_step_many": [c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int],
     "xv_anymdp_set_step_many_graph": [c_void_p, c_int],
+    "xv_anymdp_view": [c_void_p, c_void_p, c_int, c_int, C.POINTER(c_void_p)],
+    "xv_anymdp_step_many_chains": [c_void_p, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 7 + [c_int],
     "xv_anymdp_solve": [c_void_p, C.c_double, C.c_double, c_int, c_void_p, c_void_p, c_void_p],
     "xv_anymdp_step_many_graph_state": [c_void_p],
     "xv_anymdp_sample_tasks": [c_void_p, c_u64, c_i64, c_int, c_int, c_int, c_int] + [c_void_p] * 11,
@@ -147,7 +149,7 @@ class XenoError(RuntimeError):
     pass
 
 
-ABI_VERSION = 9      # include/xeno.h XV_ABI_VERSION
+ABI_VERSION = 10     # include/xeno.h XV_ABI_VERSION
 
 
 def load():

@@ -54,6 +54,8 @@ class AnyMDPVecEnv(VectorEnv):
         self._h = None
         self._many_cache = None
         self._tab = None
+        self._views = []            # sub-batch envs made by split(): they borrow this env's tables
+        self._parent = None
 
     # ---- set_task ---------------------------------------------------------------------------------
     def set_task(self, tasks, env_task_index=None):
@@ -110,6 +112,9 @@ class AnyMDPVecEnv(VectorEnv):
             if lo < 0 or hi >= n_task:
                 raise ValueError("env_task_index out of range")
         dev["env_task"] = env_task.contiguous()
+        if self._parent is not None:
+            raise ValueError("set_task on a sub-batch made by split(): set the task on the env it was split from")
+        self._drop_views()
         if self._h is not None:
             self.lib.xv_anymdp_destroy(self._h)
             self._h = None
@@ -127,23 +132,41 @@ class AnyMDPVecEnv(VectorEnv):
         ns = int(np.max(tab["obs_space"])) if "obs_space" in tab else S
         self.ns, self.na = ns, A
         self._set_spaces(Discrete(ns), Discrete(A))
-        n = self.num_envs
-        d = self.device
         self._tok = None
         if obs_model is not None:      # POMDP / MTPOMDP (anymdp_env.py:39-44)
             obs_cdf, n_obs, d_obs, d_act = obs_model
-            self._tab["obs_cdf"] = obs_cdf.to(d, torch.float64).contiguous() if torch.is_tensor(obs_cdf) else \
-                torch.from_numpy(np.ascontiguousarray(obs_cdf, np.float64)).to(d)
+            self._tab["obs_cdf"] = obs_cdf.to(self.device, torch.float64).contiguous() if torch.is_tensor(obs_cdf) else \
+                torch.from_numpy(np.ascontiguousarray(obs_cdf, np.float64)).to(self.device)
             if tuple(self._tab["obs_cdf"].shape) != (n_task, d_obs, S, n_obs):
                 raise ValueError("obs_cdf has shape %s, expected %s" % (tuple(self._tab["obs_cdf"].shape), (n_task, d_obs, S, n_obs)))
             _lib.check(self.lib.xv_anymdp_set_observation_model(self._h, n_obs, d_obs, d_act,
                                                                 _lib.ptr(self._tab["obs_cdf"])))
             self._tok = (d_obs, d_act)
             self.no, self.do, self.da = n_obs, d_obs, d_act
+        self._make_buffers()
+        self.task_set = True
+        self.need_reset = True
+        if self.bucket_lines != "off":      # memory for speed, within a small budget unless the caller named a bucket count
+            nb = 16 if self.bucket_lines == "auto" else int(self.bucket_lines)
+            budget = self.AUTO_BUCKET_BYTES
+            if self.bucket_lines == "auto" and n_task * S * A * nb * 128 > budget:
+                free, _ = torch.cuda.mem_get_info(self.device)
+                budget = max(budget, min(self.AUTO_BUCKET_CAP, int(free * self.AUTO_BUCKET_SHARE)))
+            if self.bucket_lines != "auto" or n_task * S * A * nb * 128 <= budget:
+                try:
+                    self.set_search("auto", n_bucket=nb)
+                except _lib.XenoError:      # tables the fence layout does not serve (s0_max > 4, ...): the per-lane search
+                    pass
+
+    def _make_buffers(self):
+        """spaces for the task type and the output buffers step() / reset() write (set_task, and a view made by split())"""
+        n, d, S, A = self.num_envs, self.device, self.S, self.A
+        if self._tok is not None:
+            d_obs, d_act = self._tok
             if self.task_type == "MTPOMDP":
-                self._set_spaces(MultiDiscrete([n_obs] * d_obs), MultiDiscrete([A] * d_act))
+                self._set_spaces(MultiDiscrete([self.no] * d_obs), MultiDiscrete([A] * d_act))
             else:
-                self._set_spaces(Discrete(n_obs), Discrete(A))
+                self._set_spaces(Discrete(self.no), Discrete(A))
             self._tobs = torch.zeros((n, d_obs), dtype=torch.int32, device=d)
             self._tfobs = torch.full((n, d_obs), -1, dtype=torch.int32, device=d)
         self._tok_cache = None          # (copy=False token steps cache pointers and views of the buffers made here)
@@ -171,19 +194,6 @@ class AnyMDPVecEnv(VectorEnv):
                 b["steps_p"] = C.c_void_p(b["steps"].data_ptr())
                 b["done_p"] = C.c_void_p(b["done"].data_ptr())
                 self._ring.append(b)
-        self.task_set = True
-        self.need_reset = True
-        if self.bucket_lines != "off":      # memory for speed, within a small budget unless the caller named a bucket count
-            nb = 16 if self.bucket_lines == "auto" else int(self.bucket_lines)
-            budget = self.AUTO_BUCKET_BYTES
-            if self.bucket_lines == "auto" and n_task * S * A * nb * 128 > budget:
-                free, _ = torch.cuda.mem_get_info(self.device)
-                budget = max(budget, min(self.AUTO_BUCKET_CAP, int(free * self.AUTO_BUCKET_SHARE)))
-            if self.bucket_lines != "auto" or n_task * S * A * nb * 128 <= budget:
-                try:
-                    self.set_search("auto", n_bucket=nb)
-                except _lib.XenoError:      # tables the fence layout does not serve (s0_max > 4, ...): the per-lane search
-                    pass
 
     SEARCH = {"auto": 0, "binary": 1, "fence": 3, "bucket": 4}
     _SEARCH_NAME = {1: "binary", 3: "fence", 4: "bucket"}
@@ -197,6 +207,10 @@ class AnyMDPVecEnv(VectorEnv):
                   the per-lane binary search.  With n_bucket given, the lines are built first when — and only when —
                   the census (taken without allocating anything) says AUTO would use them and they fit the free memory.
         `effective_search` names what runs; `bucket_census()` has the numbers."""
+        if self._parent is not None:
+            raise ValueError("set_search on a sub-batch made by split(): it follows the env it was split from")
+        if n_bucket is not None and getattr(self, "_n_bucket", 0) != n_bucket:
+            self._drop_views()          # they borrow the lines this call may rebuild
         if mode == "bucket":
             n_bucket = 32 if n_bucket is None else n_bucket
             if getattr(self, "_n_bucket", 0) != n_bucket:
@@ -209,6 +223,8 @@ class AnyMDPVecEnv(VectorEnv):
                 _lib.check(self.lib.xv_anymdp_build_buckets(self._h, int(n_bucket)))
                 self._n_bucket = n_bucket
         _lib.check(self.lib.xv_anymdp_set_search(self._h, self.SEARCH[mode]))
+        for v in self._views:
+            _lib.check(self.lib.xv_anymdp_set_search(v._h, self.SEARCH[mode]))
         self._many_cache = None
 
     def probe_buckets(self, n_bucket=16):
@@ -248,10 +264,20 @@ class AnyMDPVecEnv(VectorEnv):
             self._detach("_tobs")      # a masked reset writes part of it: never into the tensor the last step handed out
             _lib.check(self.lib.xv_anymdp_reset_tokens(self._h, _lib.ptr(mask), _lib.ptr(self._tobs)))
             self.need_reset = False
+            self._sync_views()
             return self._tok_obs(self._tobs), {"steps": self._out(self._get_steps())}
         _lib.check(self.lib.xv_anymdp_reset(self._h, _lib.ptr(mask), _lib.ptr(self._obs)))
         self.need_reset = False
+        self._sync_views()
         return self._out(self._obs.clone()), {"steps": self._out(self._get_steps())}
+
+    def _sync_views(self):
+        """after a reset of this env: its sub-batches (split) continue from this env's tick"""
+        if self._views:
+            t = self.engine.tick
+            for v in self._views:
+                v.engine.tick = t
+                v.need_reset = False
 
     # ---- POMDP / MTPOMDP helpers ---------------------------------------------------------------------
     def _tok_obs(self, t):
@@ -472,9 +498,14 @@ class AnyMDPVecEnv(VectorEnv):
 
     _MANY_KEYS = ("obs", "reward", "reward_gt", "terminated", "truncated", "final_obs")
 
-    def step_many(self, n_steps, actions, out=None):
+    def step_many(self, n_steps, actions, out=None, chains=1, how="streams"):
         """n_steps back-to-back step launches issued from C.  actions int32[P, N] is cycled with period P;
-        `out` holds [P, N] ring buffers (allocated when None) — slot k % P receives step k."""
+        `out` holds [P, N] ring buffers (allocated when None) — slot k % P receives step k.
+
+        chains = K > 1: the envs are stepped as K independent chains of N / K envs (split(K); xv_anymdp_step_many_chains) —
+        step k of a chain waits for step k - 1 of that chain only, so one chain's launch gap is covered by the others'
+        table lines in flight.  how: "streams" (each chain on its own stream, its own cycle graph) or "graph" (one graph
+        with K branches).  Outputs, env states and the tick afterwards equal chains=1 bit for bit."""
         self._check_step()
         c = self._many_cache
         if c is not None and out is not None and actions is c[0] and all(out.get(k) is t for k, t in zip(self._MANY_KEYS, c[1])):
@@ -497,8 +528,82 @@ class AnyMDPVecEnv(VectorEnv):
                     _lib.ptr(out["terminated"]), _lib.ptr(out["truncated"]), _lib.ptr(out.get("final_obs")))
             # `a` is kept alive with the cache entry when _dev had to convert `actions`
             self._many_cache = (actions, tuple(out.get(k) for k in self._MANY_KEYS), args, a) if a is actions else None
+        if chains > 1:
+            views = self.split(chains)
+            arr = self._chain_handles
+            _lib.check(self.lib.xv_anymdp_step_many_chains(self._h, arr, len(views), {"streams": 0, "graph": 1}[how],
+                                                           int(n_steps), *args, AUTORESET[self.autoreset_mode]))
+            return out
         _lib.check(self.lib.xv_anymdp_step_many(self._h, int(n_steps), *args, AUTORESET[self.autoreset_mode]))
         return out
+
+    # ---- sub-batches (xv_anymdp_view) ------------------------------------------------------------------------
+    def split(self, K):
+        """-> K AnyMDPVecEnv over contiguous sub-batches of this env's envs (K | num_envs), each with a HIP stream of its
+        own (`sub.stream`).  The reference steps env objects one at a time (anymdp/test_utils.py:42-60): sub-batches of a
+        vector step are independent, so [policy(sub k) -> step(sub k)] of one sub-batch can overlap another's.  A sub-batch
+        is a full VectorEnv (step, reset, step_many, rollout, get_state ...); it shares tables and env states with this env:
+        stepping sub k IS stepping envs [k N / K, (k + 1) N / K) of this env, with the draws this env would make at the same
+        tick (every sub-batch starts at this env's tick of the moment).  The views are cached per K and dropped by set_task /
+        set_search(n_bucket=...)."""
+        self._require_task()
+        K = int(K)
+        if self._parent is not None:
+            raise ValueError("split() of a sub-batch")
+        if self._views and len(self._views) == K:
+            return self._views
+        if K < 1 or K > 16 or self.num_envs % K != 0:
+            raise ValueError("split(K): K must divide num_envs and be at most 16")
+        self._drop_views()
+        n = self.num_envs // K
+        tick = self.engine.tick
+        views = []
+        for c in range(K):
+            views.append(AnyMDPSubBatch._make_view(self, c * n, n, tick))
+        self._views = views
+        self._chain_handles = (C.c_void_p * K)(*[v._h for v in views])
+        return views
+
+    @classmethod
+    def _make_view(cls, parent, lo, n, tick):
+        from ..engine import Engine
+        stream = torch.cuda.Stream(device=parent.device)
+        eng = Engine(parent.device, seed=parent.engine.seed, env_id_base=parent.engine.env_id_base + lo, stream=stream)
+        eng.tick = tick
+        v = cls(n, max_steps=parent.max_steps, autoreset_mode=parent.autoreset_mode, to_numpy=parent.to_numpy, engine=eng,
+                with_transition_gt=parent.with_transition_gt, copy=parent.copy, bucket_lines="off")
+        v._own_engine = True
+        v._parent, v.view_lo, v.stream = parent, lo, stream
+        h = C.c_void_p()
+        _lib.check(parent.lib.xv_anymdp_view(parent._h, eng.handle, int(lo), int(n), C.byref(h)))
+        v._h = h
+        v._tab = dict(parent._tab)               # keeps the borrowed tables alive
+        v._tab["env_task"] = parent._tab["env_task"][lo:lo + n]
+        for k in ("S", "A", "s0_max", "n_task", "ns", "na", "task_type", "_tok", "_n_bucket"):
+            setattr(v, k, getattr(parent, k, None))
+        for k in ("no", "do", "da"):
+            if hasattr(parent, k):
+                setattr(v, k, getattr(parent, k))
+        v._set_spaces(Discrete(parent.ns), Discrete(parent.A))
+        with torch.cuda.stream(stream):
+            v._make_buffers()
+        stream.wait_stream(torch.cuda.current_stream(parent.device))      # behind whatever built / reset the parent
+        v.task_set = True
+        v.need_reset = parent.need_reset
+        return v
+
+    def _drop_views(self):
+        for v in self._views:
+            v.close()
+        self._views = []
+        self._chain_handles = None
+
+    def check_errors(self, clear=True):
+        """device error bits of this env and of its sub-batches (a view's launches report to its own engine)"""
+        f = self.engine.error_flags(clear)
+        for v in self._views:
+            f |= v.engine.error_flags(clear)
+        return f
 
     def step_tokens_many(self, n_steps, actions, out=None):
         """POMDP / multi-token tasks: n_steps token steps issued from C (xv_anymdp_step_tokens_many).  actions int32[P, N,
@@ -596,7 +701,43 @@ class AnyMDPVecEnv(VectorEnv):
         self.need_reset = False
 
     def close_extras(self, **kwargs):
+        self._drop_views()
         if self._h is not None:
             self.lib.xv_anymdp_destroy(self._h)
             self._h = None
         self._tab = None
+        self._parent = None
+
+
+class AnyMDPSubBatch(AnyMDPVecEnv):
+    """A sub-batch of an AnyMDPVecEnv (AnyMDPVecEnv.split): the same surface, launched on `self.stream`.  Calls that
+    launch run under `torch.cuda.stream(self.stream)`, so the tensors they allocate belong to that stream and torch ops
+    the caller issues on the results inside the same `with` are ordered behind the step; to read a result from another
+    stream, `other.wait_stream(sub.stream)` first (or `sub.stream.synchronize()`)."""
+
+    def _on_stream(name):      # noqa: N805 (a decorator factory evaluated in the class body)
+        def call(self, *a, **kw):
+            with torch.cuda.stream(self.stream):
+                return getattr(AnyMDPVecEnv, name)(self, *a, **kw)
+        call.__name__ = name
+        call.__doc__ = getattr(AnyMDPVecEnv, name).__doc__
+        return call
+
+    for _n in ("reset", "step", "step_injected", "reset_injected", "rollout", "rollout_teacher", "step_many",
+               "step_tokens_many", "step_tokens_injected", "reset_tokens_injected", "get_state", "set_state", "solve"):
+        locals()[_n] = _on_stream(_n)
+    del _n, _on_stream
+
+    @property
+    def inner_state(self):
+        with torch.cuda.stream(self.stream):
+            r = AnyMDPVecEnv.inner_state.fget(self)
+        self.stream.synchronize()
+        return r
+
+    @property
+    def state(self):
+        with torch.cuda.stream(self.stream):
+            r = AnyMDPVecEnv.state.fget(self)
+        self.stream.synchronize()
+        return r

@@ -40,6 +40,7 @@
 #include <cstring>
 
 #define XV_ANYMDP_BLK 7   // next states per block
+#define XV_ANYMDP_MAX_CHAINS 16
 // (the owner lane keeps its result by SELECTS throughout: written as `if (g == it) {...}` hipcc emits an exec-masked branch per
 //  env group — 45 -> 14 branches in the round-3 step kernel, 5.31-5.34 -> 5.05-5.13 us per step)
 #ifndef XV_ANYMDP_NT_OUT
@@ -116,9 +117,25 @@ struct xv_anymdp {
   struct {
     int period, mode, search, fast, nbk;
     uint64_t seed, gid_base;
+    size_t stride;
     const void* ptrs[7];
     const void* bucket;   // the bucket lines and their count are baked into the kernel nodes' arguments
   } graph_key;
+  // views (xv_anymdp_view): a handle over envs [view_lo, view_lo + a.n_env) of `parent` with an engine (stream, tick,
+  // error word) of its own; tables, env records, bucket and observation lines are the parent's (borrowed, never freed here)
+  xv_anymdp* parent;
+  int view_lo;
+  int n_views;               // parent: live views (the parent's tables may not change or go while > 0)
+  hipEvent_t chain_ev;       // xv_anymdp_step_many_chains: fork (parent) / join (view) event, made on first use
+  // xv_anymdp_step_many_chains, how = 1: ONE graph whose K branches are the views' chains (kept on the parent)
+  hipGraph_t cgraph;
+  hipGraphExec_t cgraph_exec;
+  struct {
+    int period, mode, search, n_views;
+    const void* ptrs[7];
+    const void* bucket;
+    const void* views[XV_ANYMDP_MAX_CHAINS];
+  } cgraph_key;
 };
 
 #define XV_ANYMDP_SR_TERM 0x10000u
@@ -1456,6 +1473,9 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
   h->graph_mode = 2; h->graph_failed = false; h->graph = nullptr; h->graph_exec = nullptr;
   h->d_tick = nullptr; h->d_tick_value = 0; h->d_tick_valid = false;
   memset(&h->graph_key, 0, sizeof(h->graph_key));
+  h->parent = nullptr; h->view_lo = 0; h->n_views = 0; h->chain_ev = nullptr;
+  h->cgraph = nullptr; h->cgraph_exec = nullptr;
+  memset(&h->cgraph_key, 0, sizeof(h->cgraph_key));
   AnyMDPArgs& a = h->a;
   memset(&a, 0, sizeof(a));
   a.lines = (const uint4*)rows; a.state_map = state_map; a.term_mask = term_mask;
@@ -1531,19 +1551,77 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
   return XV_OK;
 }
 
+static void anymdp_drop_chain_graph(xv_anymdp* h) {
+  if (h->cgraph_exec) { (void)hipGraphExecDestroy(h->cgraph_exec); h->cgraph_exec = nullptr; }
+  if (h->cgraph) { (void)hipGraphDestroy(h->cgraph); h->cgraph = nullptr; }
+  memset(&h->cgraph_key, 0, sizeof(h->cgraph_key));
+}
+
 extern "C" int xv_anymdp_destroy(xv_anymdp* h) {
   if (!h) return XV_OK;
+  if (h->n_views > 0) {   // its views read this handle's tables and env records
+    xv_set_error("xv_anymdp_destroy: %d view(s) of this handle are alive: destroy them first", h->n_views);
+    return XV_ERR_INVALID;
+  }
   (void)hipSetDevice(h->eng->device);
   (void)hipStreamSynchronize(h->eng->stream);
   AnyMDPArgs& a = h->a;
-  void* ps[] = {a.sr, (void*)a.rs_a, (void*)a.rs_b, (void*)a.rs_c};
-  for (void* q : ps) if (q) (void)hipFree(q);
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   if (h->graph) (void)hipGraphDestroy(h->graph);
+  anymdp_drop_chain_graph(h);
   if (h->d_tick) (void)hipFree(h->d_tick);
+  if (h->chain_ev) (void)hipEventDestroy(h->chain_ev);
+  if (h->parent) {        // a view owns its graph, tick word and event only
+    anymdp_drop_chain_graph(h->parent);   // the parent's K-branch graph names this view's arguments
+    h->parent->n_views -= 1;
+    delete h;
+    return XV_OK;
+  }
+  void* ps[] = {a.sr, (void*)a.rs_a, (void*)a.rs_b, (void*)a.rs_c};
+  for (void* q : ps) if (q) (void)hipFree(q);
   if (h->bucket_rw) (void)hipFree(h->bucket_rw);
   if (h->obs_bucket) (void)hipFree(h->obs_bucket);
   delete h;
+  return XV_OK;
+}
+
+// A view: envs [env_lo, env_lo + n_env) of `parent` behind a handle of their own.  It borrows the parent's tables, env
+// records, bucket and observation lines and its search setting (as they are NOW: while views exist the parent refuses
+// xv_anymdp_build_buckets / xv_anymdp_set_observation_model / xv_anymdp_destroy), and launches on the stream of `e`, whose
+// seed must be the parent's and whose env_id_base must be the parent's + env_lo: the Philox counters of an env are then
+// the same through either handle, so a view stepped with launch tick t writes what the parent stepped with tick t writes
+// for those envs.  Every entry point that takes an xv_anymdp takes a view.  Sub-batches of one vector step are independent
+// (anymdp_env.py:92-132 is per env; the batched loop of anymdp/test_utils.py:42-60 iterates envs), which is what
+// xv_anymdp_step_many_chains uses.
+extern "C" int xv_anymdp_view(xv_anymdp* parent, xv_engine* e, int env_lo, int n_env, xv_anymdp** out) {
+  XV_CHECK_ARG(out != nullptr);
+  *out = nullptr;
+  XV_CHECK_ARG(parent != nullptr && e != nullptr && parent->parent == nullptr);
+  XV_CHECK_ARG(env_lo >= 0 && n_env > 0 && (int64_t)env_lo + n_env <= (int64_t)parent->a.n_env);
+  XV_CHECK_ARG(e->device == parent->eng->device && e->seed == parent->eng->seed);
+  XV_CHECK_ARG(e->env_id_base == parent->eng->env_id_base + (uint64_t)env_lo);
+  xv_anymdp* h = new (std::nothrow) xv_anymdp(*parent);
+  if (!h) {
+    xv_set_error("xv_anymdp_view: out of host memory");
+    return XV_ERR_NOMEM;
+  }
+  h->eng = e;
+  h->parent = parent; h->view_lo = env_lo; h->n_views = 0;
+  h->bucket_rw = nullptr;                       // borrowed through a.bucket
+  h->graph = nullptr; h->graph_exec = nullptr; h->graph_failed = false; h->graph_used_last = false;
+  h->d_tick = nullptr; h->d_tick_value = 0; h->d_tick_valid = false;
+  memset(&h->graph_key, 0, sizeof(h->graph_key));
+  h->chain_ev = nullptr; h->cgraph = nullptr; h->cgraph_exec = nullptr;
+  memset(&h->cgraph_key, 0, sizeof(h->cgraph_key));
+  AnyMDPArgs& a = h->a;
+  a.sr += env_lo;
+  if (a.rs_a) { a.rs_a += env_lo; a.rs_b += env_lo; a.rs_c += env_lo; }
+  a.env_task += env_lo;
+  a.n_env = n_env;
+  a.err = e->d_err;
+  a.seed = e->seed; a.gid_base = e->env_id_base; a.tick = 0; a.tick_dev = nullptr;
+  parent->n_views += 1;
+  *out = h;
   return XV_OK;
 }
 
@@ -1641,22 +1719,10 @@ extern "C" int xv_anymdp_step_injected(xv_anymdp* h, const int32_t* action, cons
 // One ring cycle of xv_anymdp_step_many as a graph: `period` step-kernel nodes in a chain (node j reads actions slot j,
 // writes output slot j, draws with tick *d_tick + j) and a node that advances *d_tick by `period`.  Back-to-back
 // dependent launches cost ~3.3 us each on a stream and ~1.6 us as graph nodes (scripts/devtools/graph_floor.hip).
-static bool anymdp_ensure_graph(xv_anymdp* h, int period, const int32_t* actions, int32_t* obs, float* reward,
-                                float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
-  const int eff = anymdp_effective_search(h);
+// `stride`: elements between two ring slots (n_env for the handle's own rings; the parent's n_env when a view steps its
+// columns of the parent's rings, xv_anymdp_step_many_chains).
+static void* anymdp_graph_step_fn(const xv_anymdp* h, int eff) {
   const bool fast = eff != XV_ANYMDP_SEARCH_BINARY;
-  const void* ptrs[7] = {actions, obs, reward, reward_gt, terminated, truncated, final_obs};
-  auto& K = h->graph_key;
-  if (h->graph_exec && K.period == period && K.mode == mode && K.search == eff && K.fast == (int)fast &&
-      K.bucket == (const void*)h->a.bucket && K.nbk == h->a.NBK &&
-      K.seed == h->eng->seed && K.gid_base == h->eng->env_id_base && memcmp(K.ptrs, ptrs, sizeof(ptrs)) == 0)
-    return true;
-  if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
-  if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
-  if (!h->d_tick && hipMalloc(&h->d_tick, sizeof(uint64_t)) != hipSuccess) return false;
-  if (hipGraphCreate(&h->graph, 0) != hipSuccess) return false;
-  const size_t n = (size_t)h->a.n_env;
-  const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
   const int bk = eff == XV_ANYMDP_SEARCH_BUCKET ? h->a.bfmt : 0;
 #define XV_STEP_FN(GV, BKV) reinterpret_cast<void*>(&anymdp_step_kernel<false, GV, false, true, BKV>)
   const int Gv = h->a.G;
@@ -1667,32 +1733,66 @@ static bool anymdp_ensure_graph(xv_anymdp* h, int period, const int32_t* actions
              : (Gv == 1 ? XV_STEP_FN(1, 0) : Gv == 2 ? XV_STEP_FN(2, 0) : Gv == 3 ? XV_STEP_FN(3, 0)
                 : Gv == 4 ? XV_STEP_FN(4, 0) : XV_STEP_FN(5, 0));
 #undef XV_STEP_FN
-  hipGraphNode_t prev = nullptr;
-  for (int j = 0; j <= period; ++j) {
+  return fn;
+}
+
+// the chain of `period` step nodes of handle `h` appended to `graph` behind `prev` (nullptr: a root); -> its last node
+static bool anymdp_add_chain(xv_anymdp* h, hipGraph_t graph, hipGraphNode_t* prev, uint64_t* d_tick, int eff, int period,
+                             size_t stride, const int32_t* actions, int32_t* obs, float* reward, float* reward_gt,
+                             uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
+  const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
+  void* fn = anymdp_graph_step_fn(h, eff);
+  for (int j = 0; j < period; ++j) {
     hipKernelNodeParams np;
     memset(&np, 0, sizeof(np));
     AnyMDPArgs a = h->a;
     a.seed = h->eng->seed; a.gid_base = h->eng->env_id_base;
-    a.tick = (uint64_t)j; a.tick_dev = h->d_tick;
-    const size_t off = (size_t)j * n;
+    a.tick = (uint64_t)j; a.tick_dev = d_tick;
+    const size_t off = (size_t)j * stride;
     AnyMDPStepIO io{actions + off, nullptr, nullptr, nullptr, obs + off, reward + off, reward_gt + off, terminated + off,
                     truncated + off, final_obs ? final_obs + off : nullptr, nullptr, nullptr, 0.0f};
     int T = 1, md = mode;
-    uint64_t dv = (uint64_t)period;
     void* step_params[] = {&a, &io, &T, &md};
-    void* tick_params[] = {&h->d_tick, &dv};
-    if (j < period) {
-      np.func = fn; np.gridDim = grid; np.blockDim = block; np.kernelParams = step_params;
-    } else {
-      np.func = reinterpret_cast<void*>(&anymdp_advance_tick_kernel); np.gridDim = dim3(1); np.blockDim = dim3(1);
-      np.kernelParams = tick_params;
-    }
+    np.func = fn; np.gridDim = grid; np.blockDim = block; np.kernelParams = step_params;
     hipGraphNode_t node;
-    if (hipGraphAddKernelNode(&node, h->graph, prev ? &prev : nullptr, prev ? 1 : 0, &np) != hipSuccess) return false;
-    prev = node;
+    if (hipGraphAddKernelNode(&node, graph, *prev ? prev : nullptr, *prev ? 1 : 0, &np) != hipSuccess) return false;
+    *prev = node;
   }
+  return true;
+}
+
+static bool anymdp_add_tick_node(hipGraph_t graph, const hipGraphNode_t* deps, int n_deps, uint64_t* d_tick, int period) {
+  hipKernelNodeParams np;
+  memset(&np, 0, sizeof(np));
+  uint64_t dv = (uint64_t)period;
+  void* tick_params[] = {&d_tick, &dv};
+  np.func = reinterpret_cast<void*>(&anymdp_advance_tick_kernel); np.gridDim = dim3(1); np.blockDim = dim3(1);
+  np.kernelParams = tick_params;
+  hipGraphNode_t node;
+  return hipGraphAddKernelNode(&node, graph, deps, (size_t)n_deps, &np) == hipSuccess;
+}
+
+static bool anymdp_ensure_graph(xv_anymdp* h, int period, size_t stride, const int32_t* actions, int32_t* obs, float* reward,
+                                float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
+  const int eff = anymdp_effective_search(h);
+  const bool fast = eff != XV_ANYMDP_SEARCH_BINARY;
+  const void* ptrs[7] = {actions, obs, reward, reward_gt, terminated, truncated, final_obs};
+  auto& K = h->graph_key;
+  if (h->graph_exec && K.period == period && K.mode == mode && K.search == eff && K.fast == (int)fast && K.stride == stride &&
+      K.bucket == (const void*)h->a.bucket && K.nbk == h->a.NBK &&
+      K.seed == h->eng->seed && K.gid_base == h->eng->env_id_base && memcmp(K.ptrs, ptrs, sizeof(ptrs)) == 0)
+    return true;
+  if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+  if (!h->d_tick && hipMalloc(&h->d_tick, sizeof(uint64_t)) != hipSuccess) return false;
+  if (hipGraphCreate(&h->graph, 0) != hipSuccess) return false;
+  hipGraphNode_t prev = nullptr;
+  if (!anymdp_add_chain(h, h->graph, &prev, h->d_tick, eff, period, stride, actions, obs, reward, reward_gt, terminated,
+                        truncated, final_obs, mode))
+    return false;
+  if (!anymdp_add_tick_node(h->graph, &prev, 1, h->d_tick, period)) return false;
   if (hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0) != hipSuccess) { h->graph_exec = nullptr; return false; }
-  K.period = period; K.mode = mode; K.search = eff; K.fast = (int)fast;
+  K.period = period; K.mode = mode; K.search = eff; K.fast = (int)fast; K.stride = stride;
   K.bucket = (const void*)h->a.bucket; K.nbk = h->a.NBK;
   K.seed = h->eng->seed; K.gid_base = h->eng->env_id_base;
   memcpy(K.ptrs, ptrs, sizeof(ptrs));
@@ -1720,7 +1820,53 @@ extern "C" int xv_anymdp_set_step_many_graph(xv_anymdp* h, int mode) {
 extern "C" int xv_anymdp_step_many_graph_state(xv_anymdp* h) {   // 0 plain launches, 1 graph built and in use, -1 failed
   if (!h) return 0;
   if (h->graph_failed) return -1;
-  return (h->graph_mode != 0 && h->graph_exec && h->graph_used_last) ? 1 : 0;
+  return (h->graph_mode != 0 && (h->graph_exec || h->cgraph_exec) && h->graph_used_last) ? 1 : 0;
+}
+
+// the stepping of xv_anymdp_step_many in three pieces, so that xv_anymdp_step_many_chains can interleave the cycles of
+// several handles: prepare (graph + its tick word), one ring cycle, one plain step
+static bool anymdp_many_prepare(xv_anymdp* h, int n_steps, int period, size_t stride, const int32_t* actions, int32_t* obs,
+                                float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs,
+                                int mode, bool force_graph) {
+  h->graph_used_last = false;
+  if (n_steps / period <= 0 || period <= 1 || h->graph_failed) return false;
+  if (!(force_graph ? (!h->eng->dev_tick && h->graph_mode != 0) : anymdp_graph_wanted(h, n_steps))) return false;
+  bool ok = anymdp_ensure_graph(h, period, stride, actions, obs, reward, reward_gt, terminated, truncated, final_obs, mode);
+  if (ok && !(h->d_tick_valid && h->d_tick_value == h->eng->tick)) {
+    hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, h->eng->stream, h->d_tick, h->eng->tick);
+    ok = hipGetLastError() == hipSuccess;
+    if (ok) { h->d_tick_value = h->eng->tick; h->d_tick_valid = true; }
+  }
+  if (!ok) {   // same kernels, plain launches; never retried on this handle
+    (void)hipGetLastError();
+    h->graph_failed = true;
+    h->d_tick_valid = false;
+  }
+  return ok;
+}
+
+static bool anymdp_many_cycle(xv_anymdp* h, int period) {
+  if (hipGraphLaunch(h->graph_exec, h->eng->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    h->graph_failed = true;
+    h->d_tick_valid = false;
+    return false;
+  }
+  h->eng->tick += (uint64_t)period;
+  h->d_tick_value = h->eng->tick;
+  h->d_tick_valid = true;
+  h->graph_used_last = true;
+  return true;
+}
+
+static int anymdp_many_plain(xv_anymdp* h, int k, int period, size_t stride, const int32_t* actions, int32_t* obs,
+                             float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs,
+                             int mode) {
+  const size_t off = (size_t)(k % period) * stride;
+  anymdp_bind_rng(h, 1);
+  AnyMDPStepIO io{actions + off, nullptr, nullptr, nullptr, obs + off, reward + off, reward_gt + off,
+                  terminated + off, truncated + off, final_obs ? final_obs + off : nullptr, nullptr, nullptr, 0.0f};
+  return anymdp_launch_step<false>(h, io, 1, mode);
 }
 
 extern "C" int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const int32_t* actions,
@@ -1733,39 +1879,165 @@ extern "C" int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const 
   int k = 0;
   // whole ring cycles: replay the graph
   const int cycles = n_steps / period;
-  h->graph_used_last = false;
-  if (cycles > 0 && period > 1 && anymdp_graph_wanted(h, n_steps) && !h->graph_failed) {
-    bool ok = anymdp_ensure_graph(h, period, actions, obs, reward, reward_gt, terminated, truncated, final_obs,
-                                  autoreset_mode);
-    if (ok && !(h->d_tick_valid && h->d_tick_value == h->eng->tick)) {
-      hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, h->eng->stream, h->d_tick, h->eng->tick);
-      ok = hipGetLastError() == hipSuccess;
-    }
-    for (int c = 0; ok && c < cycles; ++c) {
-      ok = hipGraphLaunch(h->graph_exec, h->eng->stream) == hipSuccess;
-      if (ok) {
-        h->eng->tick += (uint64_t)period;
-        h->d_tick_value = h->eng->tick;
-        h->d_tick_valid = true;
-        h->graph_used_last = true;
-        k += period;
-      }
-    }
-    if (!ok) {   // same kernels, plain launches; never retried on this handle
-      (void)hipGetLastError();
-      h->graph_failed = true;
-      h->d_tick_valid = false;
-    }
-  }
+  if (anymdp_many_prepare(h, n_steps, period, n, actions, obs, reward, reward_gt, terminated, truncated, final_obs,
+                          autoreset_mode, false))
+    for (int c = 0; c < cycles && anymdp_many_cycle(h, period); ++c) k += period;
   for (; k < n_steps; ++k) {
-    const size_t off = (size_t)(k % period) * n;
-    anymdp_bind_rng(h, 1);
-    AnyMDPStepIO io{actions + off, nullptr, nullptr, nullptr, obs + off, reward + off, reward_gt + off,
-                    terminated + off, truncated + off, final_obs ? final_obs + off : nullptr, nullptr, nullptr, 0.0f};
-    const int rc = anymdp_launch_step<false>(h, io, 1, autoreset_mode);
+    const int rc = anymdp_many_plain(h, k, period, n, actions, obs, reward, reward_gt, terminated, truncated, final_obs,
+                                     autoreset_mode);
     if (rc != XV_OK) return rc;
   }
   return XV_OK;
+}
+
+// ONE graph for a ring cycle of all chains: K branches (the views' chains of `period` step nodes, all reading the parent's
+// tick word) joined by the node that advances the word.  Kept on the parent.
+static bool anymdp_ensure_chain_graph(xv_anymdp* p, xv_anymdp* const* views, int n_views, int period, const int32_t* actions,
+                                      int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated,
+                                      int32_t* final_obs, int mode) {
+  const int eff = anymdp_effective_search(p);
+  const void* ptrs[7] = {actions, obs, reward, reward_gt, terminated, truncated, final_obs};
+  auto& K = p->cgraph_key;
+  bool same = p->cgraph_exec && K.period == period && K.mode == mode && K.search == eff && K.n_views == n_views &&
+              K.bucket == (const void*)p->a.bucket && memcmp(K.ptrs, ptrs, sizeof(ptrs)) == 0;
+  for (int v = 0; same && v < n_views; ++v) same = K.views[v] == (const void*)views[v];
+  if (same) return true;
+  anymdp_drop_chain_graph(p);
+  if (!p->d_tick && hipMalloc(&p->d_tick, sizeof(uint64_t)) != hipSuccess) return false;
+  if (hipGraphCreate(&p->cgraph, 0) != hipSuccess) return false;
+  hipGraphNode_t tails[XV_ANYMDP_MAX_CHAINS];
+  for (int v = 0; v < n_views; ++v) {
+    xv_anymdp* h = views[v];
+    const size_t lo = (size_t)h->view_lo;
+    tails[v] = nullptr;
+    if (!anymdp_add_chain(h, p->cgraph, &tails[v], p->d_tick, eff, period, (size_t)p->a.n_env, actions + lo, obs + lo,
+                          reward + lo, reward_gt + lo, terminated + lo, truncated + lo, final_obs ? final_obs + lo : nullptr,
+                          mode))
+      return false;
+  }
+  if (!anymdp_add_tick_node(p->cgraph, tails, n_views, p->d_tick, period)) return false;
+  if (hipGraphInstantiate(&p->cgraph_exec, p->cgraph, nullptr, nullptr, 0) != hipSuccess) { p->cgraph_exec = nullptr; return false; }
+  K.period = period; K.mode = mode; K.search = eff; K.n_views = n_views; K.bucket = (const void*)p->a.bucket;
+  memcpy(K.ptrs, ptrs, sizeof(ptrs));
+  for (int v = 0; v < n_views; ++v) K.views[v] = (const void*)views[v];
+  return true;
+}
+
+// xv_anymdp_step_many with the envs stepped as K independent chains: views[c] (xv_anymdp_view) covers a contiguous range
+// of the parent's envs, the K ranges tile it in order.  Step k of chain c depends on step k - 1 of chain c only — so the
+// chains run on their own streams (how = 0: each replays its own cycle graph, or plain launches when graphs are off) or as
+// the K branches of one graph on the parent's stream (how = 1), and the launch-to-launch gap of one chain (an empty launch
+// of this grid is 2.7 of the step's 5.0 us) is covered by the other chains' table lines in flight.  Same launch ticks and
+// the same per-env Philox counters as one chain: every output, the env records and the parent's tick afterwards equal
+// xv_anymdp_step_many's bit for bit.  Arrays are the parent's [period][parent n_env] rings.  Stream order: the chains start
+// behind what the parent's stream holds at the call and the parent's stream waits for all of them before it goes on.
+// Host tick only (device-tick engines: XV_ERR_UNSUPPORTED).
+extern "C" int xv_anymdp_step_many_chains(xv_anymdp* p, xv_anymdp* const* views, int n_views, int how, int n_steps, int period,
+                                          const int32_t* actions, int32_t* obs, float* reward, float* reward_gt,
+                                          uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int autoreset_mode) {
+  XV_CHECK_ARG(p && views && n_views >= 1 && n_views <= XV_ANYMDP_MAX_CHAINS && (how == 0 || how == 1));
+  XV_CHECK_ARG(n_steps > 0 && period > 0);
+  XV_CHECK_ARG(actions && obs && reward && reward_gt && terminated && truncated);
+  XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
+  int covered = 0;
+  bool dev_tick = p->eng->dev_tick;
+  for (int v = 0; v < n_views; ++v) {
+    XV_CHECK_ARG(views[v] != nullptr && views[v]->parent == p && views[v]->view_lo == covered);
+    covered += views[v]->a.n_env;
+    dev_tick = dev_tick || views[v]->eng->dev_tick;
+  }
+  XV_CHECK_ARG(covered == p->a.n_env);
+  if (dev_tick) {
+    xv_set_error("xv_anymdp_step_many_chains: needs the host tick on the parent's and the views' engines");
+    return XV_ERR_UNSUPPORTED;
+  }
+  XV_HIP(hipSetDevice(p->eng->device));
+  const uint64_t t0 = p->eng->tick;
+  const size_t N = (size_t)p->a.n_env;
+  const int cycles = n_steps / period;
+  p->graph_used_last = false;
+  for (int v = 0; v < n_views; ++v) {      // the views follow the parent: search setting and launch tick
+    views[v]->search = p->search;
+    views[v]->graph_mode = p->graph_mode;
+    views[v]->eng->tick = t0;
+  }
+  int k = 0;
+  if (how == 1) {
+    bool ok = cycles > 0 && period > 1 && p->graph_mode != 0 && !p->graph_failed &&
+              anymdp_ensure_chain_graph(p, views, n_views, period, actions, obs, reward, reward_gt, terminated, truncated,
+                                        final_obs, autoreset_mode);
+    if (ok && !(p->d_tick_valid && p->d_tick_value == t0)) {
+      hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, p->eng->stream, p->d_tick, t0);
+      ok = hipGetLastError() == hipSuccess;
+    }
+    for (int c = 0; ok && c < cycles; ++c) {
+      ok = hipGraphLaunch(p->cgraph_exec, p->eng->stream) == hipSuccess;
+      if (ok) {
+        k += period;
+        p->eng->tick = t0 + (uint64_t)k;
+        p->d_tick_value = p->eng->tick;
+        p->d_tick_valid = true;
+        p->graph_used_last = true;
+      }
+    }
+    if (!ok && cycles > 0 && period > 1 && p->graph_mode != 0) { (void)hipGetLastError(); p->d_tick_valid = false; }
+    for (; k < n_steps; ++k) {           // what is left of the call: the parent's own launches
+      const int rc = anymdp_many_plain(p, k, period, N, actions, obs, reward, reward_gt, terminated, truncated, final_obs,
+                                       autoreset_mode);
+      if (rc != XV_OK) return rc;
+    }
+    for (int v = 0; v < n_views; ++v) views[v]->eng->tick = t0 + (uint64_t)n_steps;
+    return XV_OK;
+  }
+  // how = 0: fork
+  if (!p->chain_ev) XV_HIP(hipEventCreateWithFlags(&p->chain_ev, hipEventDisableTiming));
+  XV_HIP(hipEventRecord(p->chain_ev, p->eng->stream));
+  bool graph[XV_ANYMDP_MAX_CHAINS];
+  bool all_graph = true;
+  for (int v = 0; v < n_views; ++v) {
+    xv_anymdp* h = views[v];
+    if (h->eng->stream != p->eng->stream) XV_HIP(hipStreamWaitEvent(h->eng->stream, p->chain_ev, 0));
+    const size_t lo = (size_t)h->view_lo;
+    graph[v] = anymdp_many_prepare(h, n_steps, period, N, actions + lo, obs + lo, reward + lo, reward_gt + lo, terminated + lo,
+                                   truncated + lo, final_obs ? final_obs + lo : nullptr, autoreset_mode, true);
+    all_graph = all_graph && graph[v];
+  }
+  int rc = XV_OK;
+  if (all_graph) {
+    for (int c = 0; c < cycles && all_graph; ++c) {
+      for (int v = 0; v < n_views; ++v) all_graph = anymdp_many_cycle(views[v], period) && all_graph;
+      if (all_graph) k += period;
+    }
+    p->graph_used_last = k > 0;
+  }
+  // a graph launch that failed mid-cycle leaves the chains at different steps: bring every chain to the furthest one
+  for (int v = 0; v < n_views; ++v) k = (int)(views[v]->eng->tick - t0) > k ? (int)(views[v]->eng->tick - t0) : k;
+  for (int v = 0; v < n_views && rc == XV_OK; ++v) {
+    xv_anymdp* h = views[v];
+    const size_t lo = (size_t)h->view_lo;
+    for (int kk = (int)(h->eng->tick - t0); kk < k && rc == XV_OK; ++kk)
+      rc = anymdp_many_plain(h, kk, period, N, actions + lo, obs + lo, reward + lo, reward_gt + lo, terminated + lo,
+                             truncated + lo, final_obs ? final_obs + lo : nullptr, autoreset_mode);
+  }
+  for (; k < n_steps && rc == XV_OK; ++k)
+    for (int v = 0; v < n_views && rc == XV_OK; ++v) {
+      xv_anymdp* h = views[v];
+      const size_t lo = (size_t)h->view_lo;
+      rc = anymdp_many_plain(h, k, period, N, actions + lo, obs + lo, reward + lo, reward_gt + lo, terminated + lo,
+                             truncated + lo, final_obs ? final_obs + lo : nullptr, autoreset_mode);
+    }
+  // join (also after an error: the parent's stream must not run ahead of launches already issued)
+  for (int v = 0; v < n_views; ++v) {
+    xv_anymdp* h = views[v];
+    if (h->eng->stream == p->eng->stream) continue;
+    if (!h->chain_ev && hipEventCreateWithFlags(&h->chain_ev, hipEventDisableTiming) != hipSuccess) { rc = rc == XV_OK ? XV_ERR_HIP : rc; continue; }
+    if (hipEventRecord(h->chain_ev, h->eng->stream) != hipSuccess ||
+        hipStreamWaitEvent(p->eng->stream, h->chain_ev, 0) != hipSuccess)
+      rc = rc == XV_OK ? XV_ERR_HIP : rc;
+  }
+  if (rc == XV_ERR_HIP) xv_set_error("xv_anymdp_step_many_chains: joining the chains failed: %s", hipGetErrorString(hipGetLastError()));
+  if (rc == XV_OK) p->eng->tick = t0 + (uint64_t)n_steps;
+  return rc;
 }
 
 extern "C" int xv_anymdp_rollout(xv_anymdp* h, int T, const int32_t* actions, int32_t* obs, float* reward,
@@ -1950,8 +2222,17 @@ extern "C" int xv_anymdp_effective_search(xv_anymdp* h) {
   return h ? anymdp_effective_search(h) : XV_ERR_INVALID;
 }
 
+#define XV_ANYMDP_NO_VIEWS(h)                                                                                   \
+  do {                                                                                                           \
+    if ((h)->parent != nullptr || (h)->n_views > 0) {                                                            \
+      xv_set_error("%s: not on a view, and not while views of the handle exist (they borrow its lines)", __func__); \
+      return XV_ERR_UNSUPPORTED;                                                                                 \
+    }                                                                                                            \
+  } while (0)
+
 extern "C" int xv_anymdp_build_buckets(xv_anymdp* h, int n_bucket) {
   XV_CHECK_ARG(h != nullptr && (n_bucket == 0 || n_bucket == 16 || n_bucket == 32 || n_bucket == 64));
+  XV_ANYMDP_NO_VIEWS(h);
   XV_HIP(hipSetDevice(h->eng->device));
   if (h->bucket_rw) {
     XV_HIP(hipStreamSynchronize(h->eng->stream));
@@ -2013,6 +2294,7 @@ extern "C" int xv_anymdp_transition_gt(xv_anymdp* h, const int32_t* action, doub
 // ---- POMDP / MTPOMDP entry points ----
 extern "C" int xv_anymdp_set_observation_model(xv_anymdp* h, int n_obs, int d_obs, int d_act, const double* obs_cdf) {
   XV_CHECK_ARG(h && obs_cdf && n_obs >= 1 && d_obs >= 1 && d_obs <= 64 && d_act >= 1 && d_act <= 64);
+  XV_ANYMDP_NO_VIEWS(h);
   XV_HIP(hipSetDevice(h->eng->device));   // the observation bucket lines are allocated and built on the engine's device
   h->obs_cdf = obs_cdf; h->n_obs = n_obs; h->d_obs = d_obs; h->d_act = d_act;
   return anymdp_build_obs_buckets(h);   // beside existing transition bucket lines
