@@ -65,6 +65,7 @@ extern "C" {
 #define XV_DEVERR_ACTION_RANGE 1u   /* reference: `assert action < self.na` (anymdp_env.py:97) */
 #define XV_DEVERR_STEP_TERMINAL 2u  /* reference: raise "given an terminated state" (anymdp_env.py:95-96) */
 #define XV_DEVERR_NONFINITE 4u      /* a float state left the finite range */
+#define XV_DEVERR_HANDOFF 8u        /* overlapped xv_anymdp_step_many: a wave's bounded wait for the step before it expired */
 
 #define XV_STREAM_OWN ((void*)(intptr_t)-1)
 
@@ -233,6 +234,19 @@ int xv_anymdp_set_step_many_graph(xv_anymdp* h, int mode);
 /* 1: the last xv_anymdp_step_many replayed the graph, 0: plain launches, -1: graph construction or launch failed (plain
  * launches used) */
 int xv_anymdp_step_many_graph_state(xv_anymdp* h);
+/* Overlapped xv_anymdp_step_many (ABI 10; off by default).  on = 1: whole ring cycles of an EVEN period are issued as two
+ * cycle graphs — ring slots 0, 2, ... on the engine's stream, 1, 3, ... on a side stream the handle owns — with no dependency
+ * between the streams: step k + 1 is dispatched while step k runs, and each of its waves takes its 64 envs over from the
+ * same wave of step k through a hand-off word in device memory (release / acquire at agent scope; an env depends on its own
+ * previous step only, anymdp_env.py:92-132).  The drain-and-dispatch gap between two dependent launches of one stream
+ * (2.7 of the 5.0 us of a 65,536-env step) is covered by the other stream.  The engine's stream waits for the side stream
+ * before the call's remainder and whatever follows.  Same launch ticks, same results as plain launches.  A wave's wait is
+ * bounded (2 ms): if the two streams do not run concurrently it expires, the wave goes on and XV_DEVERR_HANDOFF is set in
+ * the engine's error word — wrong data, flagged, never a hang.  Needs the fence or bucket search and the host tick;
+ * otherwise, and for odd periods, step_many behaves as without it.
+ * xv_anymdp_step_many_overlap_state: 1 the last call overlapped, 0 it did not, -1 the path failed and is no longer tried. */
+int xv_anymdp_set_step_many_overlap(xv_anymdp* h, int on);
+int xv_anymdp_step_many_overlap_state(xv_anymdp* h);
 
 /* A VIEW of envs [env_lo, env_lo + n_env) of `parent` as a handle of its own (ABI 10).  The reference steps one env object
  * at a time and its batched loop iterates independent envs (anymdp/anymdp_env.py:92-132, anymdp/test_utils.py:42-60): any

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=7)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--overlap", action="store_true", help="also time chains=1 with the overlapped step_many")
     args = ap.parse_args()
 
     import torch
@@ -80,9 +81,16 @@ def main():
         us.sort()
         return us[len(us) // 2], us[0], us[-1]
 
-    for K in [int(x) for x in args.ks.split(",")]:
-        for how in (args.hows.split(",") if K > 1 else ["streams"]):
+    variants = [(K, how, False) for K in [int(x) for x in args.ks.split(",")] for how in (args.hows.split(",") if K > 1 else ["streams"])]
+    if args.overlap:
+        variants.append((1, "overlap", True))
+        variants.append((1, "streams", False))      # and once more without, after it
+    for K, how, ov in variants:
+        if True:
             row = dict(meta, chains=K, how=how)
+            env.set_step_many_overlap(ov)
+            if ov:
+                how = "streams"
             try:
                 med, lo, hi = timed(args.steps, args.period, K, how, args.repeats)
                 row.update(steps=args.steps, period=args.period, us_per_step=med, us_min=lo, us_max=hi,
@@ -92,6 +100,7 @@ def main():
                     row.update(short_steps=args.short, short_us_per_step=m2, short_us_min=l2,
                                short_env_steps_per_s=n_env / (m2 * 1e-6))
                 row["device_error_flags"] = env.check_errors()
+                row["overlap_state"] = env.step_many_overlap_state
             except Exception as ex:
                 row["error"] = repr(ex)
             print(json.dumps(row), flush=True)

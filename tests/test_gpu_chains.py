@@ -13,7 +13,7 @@ import torch
 
 import oracle
 from xenoverse_amd import _lib
-from xenoverse_amd.anymdp import AnyMDPVecEnv
+from xenoverse_amd.anymdp import AnyMDPVecEnv, to_blocked
 
 pytestmark = pytest.mark.gpu
 
@@ -23,26 +23,26 @@ def _np(t):
 
 
 def _dev_tables(tab, dev="cuda:0"):
-    out = {}
-    for k, v in tab.items():
-        if isinstance(v, np.ndarray):
-            if v.dtype == np.uint64:
-                v = v.view(np.int64)
-            out[k] = torch.from_numpy(np.ascontiguousarray(v)).to(dev)
-        else:
-            out[k] = v
+    out = dict(S=tab["S"], A=tab["A"], s0_max=tab["s0_max"])
+    tab = dict(tab, rows=to_blocked(tab["cdf"], tab["rs"]))
+    for k in ("rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps"):
+        v = np.ascontiguousarray(tab[k])
+        if v.dtype == np.uint64:
+            v = v.view(np.int64)
+        out[k] = torch.from_numpy(v).to(dev)
     return out
 
 
-def _run_many(tab, n, P, acts_np, plan, search, chains, how, graph, seed=77):
+def _run_many(tab, n, P, acts_np, plan, search, chains, how, graph, seed=77, overlap=False, mode="same_step"):
     """-> list of snapshots: the ring after every step_many of `plan`, then (state, steps, need_reset, tick)"""
-    env = AnyMDPVecEnv(n, seed=seed, autoreset_mode="same_step", bucket_lines="off")
+    env = AnyMDPVecEnv(n, seed=seed, autoreset_mode=mode, bucket_lines="off")
     env.set_task(_dev_tables(tab))
     if search == "bucket":
         env.set_search("bucket", n_bucket=16)
     else:
         env.set_search(search)
     env.set_step_many_graph(graph)
+    env.set_step_many_overlap(overlap)
     env.reset()
     acts = torch.as_tensor(acts_np, device=env.device)
     rec, ring = [], None
@@ -53,6 +53,8 @@ def _run_many(tab, n, P, acts_np, plan, search, chains, how, graph, seed=77):
     s, st, nr = env.get_state()
     rec.append({"state": _np(s), "steps": _np(st), "need_reset": _np(nr), "tick": np.asarray(env.engine.tick)})
     assert env.check_errors() == 0
+    if overlap:
+        assert env.step_many_overlap_state == (1 if (search != "binary" and P % 2 == 0 and plan[-1] >= P) else 0)
     env.close()
     return rec
 
@@ -77,6 +79,60 @@ def test_k_chains_equal_one_chain_small(search, how, chains):
     got = _run_many(tab, n, P, acts, plan, search, chains, how, True)
     _same(ref, got)
     assert ref[0]["terminated"].sum() > 50
+
+
+@pytest.mark.parametrize("search", ["fence", "bucket", "binary"])
+@pytest.mark.parametrize("mode", ["same_step", "next_step"])
+def test_overlapped_step_many_equals_plain_launches_small(search, mode):
+    """overlap mode (two streams, per-wave hand-off words): whole cycles, remainders, repeated calls on the same rings, a
+    call on other rings (graphs rebuilt), ordinary steps in between (hand-off words re-initialised) — against plain
+    launches; the per-lane search and odd periods take the ordinary path"""
+    tab = oracle.anymdp_synth(seed=12, task_index_base=0, n_task=16, S=64, A=8, s0_max=4)
+    n, P = 2000, 8                       # a ragged last workgroup
+    acts = np.random.RandomState(5).randint(0, 8, (P, n)).astype(np.int32)
+    plan = [3 * P + 5, 2 * P, 3, 6 * P]
+    ref = _run_many(tab, n, P, acts, plan, search, 1, "streams", False, mode=mode)
+    got = _run_many(tab, n, P, acts, plan, search, 1, "streams", True, overlap=True, mode=mode)
+    _same(ref, got)
+    assert ref[0]["terminated"].sum() > 50
+
+
+def test_overlapped_step_many_odd_period_and_other_rings():
+    tab = oracle.anymdp_synth(seed=14, task_index_base=0, n_task=8, S=64, A=8, s0_max=4)
+    n = 1024
+    for P in (7, 6):
+        acts = np.random.RandomState(P).randint(0, 8, (P, n)).astype(np.int32)
+        res = []
+        for overlap in (False, True):
+            env = AnyMDPVecEnv(n, seed=3, autoreset_mode="same_step")
+            env.set_task(_dev_tables(tab))
+            env.set_step_many_overlap(overlap)
+            env.reset()
+            a = torch.as_tensor(acts, device=env.device)
+            r1 = env.step_many(2 * P + 1, a)
+            r2 = env.step_many(3 * P, a)             # other rings: the cycle graphs are rebuilt
+            o = env.step(acts[0])                    # an ordinary step in between
+            r3 = env.step_many(2 * P, a, out=r1)
+            torch.cuda.synchronize()
+            res.append([_np(v).copy() for r in (r1, r2, r3) for v in r.values()] + [_np(o[0]), _np(env.get_state()[0])])
+            assert env.check_errors() == 0
+            if overlap:
+                assert env.step_many_overlap_state == (1 if P % 2 == 0 else 0)
+            env.close()
+        for x, y in zip(*res):
+            assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("search", ["bucket", "fence"])
+def test_overlapped_step_many_at_65536_envs(search):
+    """the headline batch size: 5 cycles of 32 + 9 steps, twice, every output, the env records and the tick"""
+    tab = oracle.anymdp_synth(seed=21, task_index_base=0, n_task=1024, S=64, A=8, s0_max=4)
+    n, P = 65536, 32
+    acts = np.random.RandomState(7).randint(0, 8, (P, n)).astype(np.int32)
+    plan = [5 * P + 9, 4 * P]
+    ref = _run_many(tab, n, P, acts, plan, search, 1, "streams", True)
+    got = _run_many(tab, n, P, acts, plan, search, 1, "streams", True, overlap=True)
+    _same(ref, got)
 
 
 @pytest.mark.parametrize("how", ["streams", "graph"])

@@ -639,6 +639,17 @@ class AnyMDPVecEnv(VectorEnv):
         m = {"off": 0, "on": 1, "auto": 2}.get(mode, 1 if mode is True else (0 if mode is False else mode))
         _lib.check(self.lib.xv_anymdp_set_step_many_graph(self._h, int(m)))
 
+    def set_step_many_overlap(self, on=True):
+        """step_many issues consecutive vector steps alternately on two HIP streams with no dependency between them; each
+        wave of step k + 1 takes its envs over from the same wave of step k through a hand-off word (xeno.h:
+        xv_anymdp_set_step_many_overlap).  Same results; whole cycles of an even ring period only."""
+        _lib.check(self.lib.xv_anymdp_set_step_many_overlap(self._h, 1 if on else 0))
+
+    @property
+    def step_many_overlap_state(self):
+        """1: the last step_many overlapped its cycles, 0: it did not, -1: the overlapped path failed on this env"""
+        return int(self.lib.xv_anymdp_step_many_overlap_state(self._h))
+
     # ---- accessors (anymdp_env.py:134-165) ----------------------------------------------------------
     def _get_steps(self):
         self._renew("_steps")

@@ -71,6 +71,8 @@ struct AnyMDPArgs {
   int bfmt;              // metadata packing of the bucket lines: 1 = 7 cuts (S <= 256, observation ids <= 255), 2 = 6 cuts
   uint64_t seed, gid_base, tick;
   const uint64_t* tick_dev;   // graph replay: the launch tick is *tick_dev + tick (tick = node index); else nullptr
+  uint32_t* hand;             // HAND kernels (overlapped step_many): per-wave hand-off word, hand[w] = low 32 bits of the launch
+                              // tick of the next step wave w's envs may take (the step before it has stored their records)
 };
 
 struct AnyMDPStepIO {
@@ -121,6 +123,27 @@ struct xv_anymdp {
     const void* ptrs[7];
     const void* bucket;   // the bucket lines and their count are baked into the kernel nodes' arguments
   } graph_key;
+  // overlapped step_many (xv_anymdp_set_step_many_overlap): even ring slots on the engine's stream, odd ones on `side`, two
+  // cycle graphs of HAND kernels, each with its own tick word; hand[] as in AnyMDPArgs
+  int overlap;               // 0 off, 1 on
+  bool pipe_failed;
+  hipStream_t side;
+  hipEvent_t side_ev[2];     // fork, join
+  hipGraph_t pgraph[2];
+  hipGraphExec_t pgraph_exec[2];
+  uint64_t* d_ptick;         // two tick words
+  uint64_t ptick_value;      // what both hold once the streams have drained (valid with pgraph_exec)
+  bool ptick_valid;
+  uint32_t* d_hand;
+  uint64_t hand_value;       // hand[w] == (uint32_t)hand_value for every wave
+  bool hand_valid;
+  struct {
+    int period, mode, search;
+    size_t stride;
+    const void* ptrs[7];
+    const void* bucket;
+    uint64_t seed, gid_base;
+  } pipe_key;
   // views (xv_anymdp_view): a handle over envs [view_lo, view_lo + a.n_env) of `parent` with an engine (stream, tick,
   // error word) of its own; tables, env records, bucket and observation lines are the parent's (borrowed, never freed here)
   xv_anymdp* parent;
@@ -347,7 +370,16 @@ typedef AnyMDPCoopLineN<XV_ANYMDP_TOK_LPE, XV_ANYMDP_COOP_CONTIG != 0> AnyMDPTok
 //     (row, floor(u * NBK)); G only shapes the fence fall-back.
 // `bid`: the workgroup's index within this family's part of the launch (blockIdx.x for the family's own kernels; the fused
 // mixed-batch kernel of mixed.hip hands every family a contiguous range of its workgroups)
-template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false, int BK = 0>
+// HAND: the launch may start while the launch of the step before it is still running (xv_anymdp_step_many, overlap mode:
+//     consecutive steps alternate between two HIP streams with no dependency between the streams).  Everything that does not
+//     depend on the env records is done first (action and reset-record loads, the transition uniform); then lane 0 of each
+//     wave waits until hand[w] names this launch's tick — the same wave of the step before has stored its records and
+//     released them — and only then are the records read.  At the end the wave releases its stores and publishes tick + 1.
+//     A wave depends on the same wave of the previous step only (one lane per env, anymdp_env.py:92-132 is per env).  The
+//     wait is bounded (XV_ANYMDP_HAND_TIMEOUT of the 100-MHz wall clock): on expiry the wave goes on and sets
+//     XV_DEVERR_HANDOFF — wrong results, flagged, never a hang.
+#define XV_ANYMDP_HAND_TIMEOUT 200000ull   // 2 ms
+template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false, int BK = 0, bool HAND = false>
 __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyMDPStepIO& io, int T_steps, int mode, int bid) {
   constexpr bool FAST = G > 0;
   constexpr int GG = G > 0 ? G : 1;
@@ -359,11 +391,8 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
   const int S = P.S, A = P.A;
 
   // ---- link 1: per-env words (coalesced): the 8-byte env record, the action and (fast path) three 16-byte reset units ----
-  const uint2 sr0 = P.sr[ic];
-  int s = (int)(sr0.x & 0xFFFFu);
-  int steps = (int)sr0.y;
-  int nr = (sr0.x & XV_ANYMDP_SR_NR) ? 1 : 0;
-  int cterm = (sr0.x & XV_ANYMDP_SR_TERM) ? 1 : 0;
+  uint2 sr0 = make_uint2(0u, 0u);
+  if (!HAND) sr0 = P.sr[ic];
   int a_next = io.action ? io.action[ic] : 0;
   const uint64_t gid = P.gid_base + (uint64_t)ic;
   uint32_t err = 0;
@@ -393,6 +422,26 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
   // the launch tick: a kernel argument, or — device tick mode of the engine (xv_engine_set_device_tick) and graph replays
   // of step_many — relative to the engine's / the graph's tick word in device memory
   const uint64_t tick0 = TICKDEV ? *P.tick_dev + P.tick : xv_launch_tick(P.tick, P.tick_dev);
+  xv_u32x4 w_pre{0u, 0u, 0u, 0u};
+  if (HAND) {
+    w_pre = xv_env_draw(P.seed, gid, tick0, XV_DRAW_STEP);      // the transition uniform does not need the env record
+    asm volatile("" : "+v"(w_pre.x), "+v"(w_pre.y), "+v"(w_pre.z), "+v"(w_pre.w));      // made here, in front of the wait
+    uint32_t* flag = P.hand + ((uint32_t)i >> 6);
+    const uint32_t want = (uint32_t)tick0;
+    if (lane == 0) {
+      const uint64_t t_begin = wall_clock64();
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t_begin > XV_ANYMDP_HAND_TIMEOUT) { err |= XV_DEVERR_HANDOFF; break; }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    sr0 = P.sr[ic];
+  }
+  int s = (int)(sr0.x & 0xFFFFu);
+  int steps = (int)sr0.y;
+  int nr = (sr0.x & XV_ANYMDP_SR_NR) ? 1 : 0;
+  int cterm = (sr0.x & XV_ANYMDP_SR_TERM) ? 1 : 0;
   const int T = ROLLOUT ? T_steps : 1;   // single step: straight-line code, counted vmcnt waits
   for (int ts = 0; ts < T; ++ts) {
     const size_t o = (size_t)ts * P.n_env + ic;
@@ -407,7 +456,7 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
     if (INJECT) {
       u = io.u[o];
     } else {
-      w = xv_env_draw(P.seed, gid, tick0 + (uint64_t)ts, XV_DRAW_STEP);
+      w = HAND ? w_pre : xv_env_draw(P.seed, gid, tick0 + (uint64_t)ts, XV_DRAW_STEP);
       u = xv_u53(w.x, w.y);
     }
     auto late_draws = [&]() {
@@ -652,12 +701,20 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
     }
   }
   if (valid) P.sr[i] = anymdp_sr_pack(s, steps, nr, cterm);
+  if (HAND) {      // the wave's records (and outputs) are out before the next step's wave is let at them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_store(P.hand + ((uint32_t)i >> 6), (uint32_t)tick0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (err) atomicOr(P.err, err);
 }
 
-template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false, int BK = 0>
+template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false, int BK = 0, bool HAND = false>
 __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPStepIO io, int T_steps, int mode) {
-  anymdp_step_body<INJECT, G, ROLLOUT, TICKDEV, BK>(P, io, T_steps, mode, (int)blockIdx.x);
+  anymdp_step_body<INJECT, G, ROLLOUT, TICKDEV, BK, HAND>(P, io, T_steps, mode, (int)blockIdx.x);
+}
+static __global__ void anymdp_fill_u32_kernel(uint32_t* p, uint32_t v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
 }
 
 // Completes the rows in place (create time): fence line and per-block metadata.  One thread per (row, k < 64).
@@ -1440,6 +1497,31 @@ static inline int anymdp_effective_search(const xv_anymdp* h) {
 }
 
 #ifndef XV_KERNELS_ONLY   // mixed.hip includes this file for its kernels and handle types only
+static void anymdp_pipe_clear(xv_anymdp* h) {      // fields of the overlapped step_many: nothing built
+  h->overlap = 0; h->pipe_failed = false; h->side = nullptr;
+  h->side_ev[0] = h->side_ev[1] = nullptr;
+  h->pgraph[0] = h->pgraph[1] = nullptr; h->pgraph_exec[0] = h->pgraph_exec[1] = nullptr;
+  h->d_ptick = nullptr; h->ptick_value = 0; h->ptick_valid = false;
+  h->d_hand = nullptr; h->hand_value = 0; h->hand_valid = false;
+  memset(&h->pipe_key, 0, sizeof(h->pipe_key));
+}
+static void anymdp_pipe_drop_graphs(xv_anymdp* h) {
+  for (int q = 0; q < 2; ++q) {
+    if (h->pgraph_exec[q]) { (void)hipGraphExecDestroy(h->pgraph_exec[q]); h->pgraph_exec[q] = nullptr; }
+    if (h->pgraph[q]) { (void)hipGraphDestroy(h->pgraph[q]); h->pgraph[q] = nullptr; }
+  }
+  memset(&h->pipe_key, 0, sizeof(h->pipe_key));
+  h->ptick_valid = false;
+}
+static void anymdp_pipe_release(xv_anymdp* h) {
+  anymdp_pipe_drop_graphs(h);
+  if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+  for (int q = 0; q < 2; ++q) if (h->side_ev[q]) (void)hipEventDestroy(h->side_ev[q]);
+  if (h->d_ptick) (void)hipFree(h->d_ptick);
+  if (h->d_hand) (void)hipFree(h->d_hand);
+  anymdp_pipe_clear(h);
+}
+
 // ------------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------------
@@ -1476,6 +1558,7 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
   h->parent = nullptr; h->view_lo = 0; h->n_views = 0; h->chain_ev = nullptr;
   h->cgraph = nullptr; h->cgraph_exec = nullptr;
   memset(&h->cgraph_key, 0, sizeof(h->cgraph_key));
+  anymdp_pipe_clear(h);
   AnyMDPArgs& a = h->a;
   memset(&a, 0, sizeof(a));
   a.lines = (const uint4*)rows; a.state_map = state_map; a.term_mask = term_mask;
@@ -1569,6 +1652,7 @@ extern "C" int xv_anymdp_destroy(xv_anymdp* h) {
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   if (h->graph) (void)hipGraphDestroy(h->graph);
   anymdp_drop_chain_graph(h);
+  anymdp_pipe_release(h);
   if (h->d_tick) (void)hipFree(h->d_tick);
   if (h->chain_ev) (void)hipEventDestroy(h->chain_ev);
   if (h->parent) {        // a view owns its graph, tick word and event only
@@ -1613,7 +1697,9 @@ extern "C" int xv_anymdp_view(xv_anymdp* parent, xv_engine* e, int env_lo, int n
   memset(&h->graph_key, 0, sizeof(h->graph_key));
   h->chain_ev = nullptr; h->cgraph = nullptr; h->cgraph_exec = nullptr;
   memset(&h->cgraph_key, 0, sizeof(h->cgraph_key));
+  anymdp_pipe_clear(h);
   AnyMDPArgs& a = h->a;
+  a.hand = nullptr;
   a.sr += env_lo;
   if (a.rs_a) { a.rs_a += env_lo; a.rs_b += env_lo; a.rs_c += env_lo; }
   a.env_task += env_lo;
@@ -1721,11 +1807,21 @@ extern "C" int xv_anymdp_step_injected(xv_anymdp* h, const int32_t* action, cons
 // dependent launches cost ~3.3 us each on a stream and ~1.6 us as graph nodes (scripts/devtools/graph_floor.hip).
 // `stride`: elements between two ring slots (n_env for the handle's own rings; the parent's n_env when a view steps its
 // columns of the parent's rings, xv_anymdp_step_many_chains).
-static void* anymdp_graph_step_fn(const xv_anymdp* h, int eff) {
+static void* anymdp_graph_step_fn(const xv_anymdp* h, int eff, bool hand = false) {
   const bool fast = eff != XV_ANYMDP_SEARCH_BINARY;
   const int bk = eff == XV_ANYMDP_SEARCH_BUCKET ? h->a.bfmt : 0;
-#define XV_STEP_FN(GV, BKV) reinterpret_cast<void*>(&anymdp_step_kernel<false, GV, false, true, BKV>)
   const int Gv = h->a.G;
+  if (hand) {      // the hand-off kernels: fence and bucket searches
+#define XV_STEP_FN(GV, BKV) reinterpret_cast<void*>(&anymdp_step_kernel<false, GV, false, true, BKV, true>)
+    if (!fast) return nullptr;
+    return bk == 1 ? (Gv == 1 ? XV_STEP_FN(1, 1) : Gv == 2 ? XV_STEP_FN(2, 1) : XV_STEP_FN(3, 1))
+           : bk == 2 ? (Gv == 1 ? XV_STEP_FN(1, 2) : Gv == 2 ? XV_STEP_FN(2, 2) : Gv == 3 ? XV_STEP_FN(3, 2)
+                        : Gv == 4 ? XV_STEP_FN(4, 2) : XV_STEP_FN(5, 2))
+           : (Gv == 1 ? XV_STEP_FN(1, 0) : Gv == 2 ? XV_STEP_FN(2, 0) : Gv == 3 ? XV_STEP_FN(3, 0)
+              : Gv == 4 ? XV_STEP_FN(4, 0) : XV_STEP_FN(5, 0));
+#undef XV_STEP_FN
+  }
+#define XV_STEP_FN(GV, BKV) reinterpret_cast<void*>(&anymdp_step_kernel<false, GV, false, true, BKV>)
   void* fn = bk == 1 ? (Gv == 1 ? XV_STEP_FN(1, 1) : Gv == 2 ? XV_STEP_FN(2, 1) : XV_STEP_FN(3, 1))
              : bk == 2 ? (Gv == 1 ? XV_STEP_FN(1, 2) : Gv == 2 ? XV_STEP_FN(2, 2) : Gv == 3 ? XV_STEP_FN(3, 2)
                           : Gv == 4 ? XV_STEP_FN(4, 2) : XV_STEP_FN(5, 2))
@@ -1739,15 +1835,17 @@ static void* anymdp_graph_step_fn(const xv_anymdp* h, int eff) {
 // the chain of `period` step nodes of handle `h` appended to `graph` behind `prev` (nullptr: a root); -> its last node
 static bool anymdp_add_chain(xv_anymdp* h, hipGraph_t graph, hipGraphNode_t* prev, uint64_t* d_tick, int eff, int period,
                              size_t stride, const int32_t* actions, int32_t* obs, float* reward, float* reward_gt,
-                             uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
+                             uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode, int j0 = 0, int dj = 1,
+                             uint32_t* hand = nullptr) {
   const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
-  void* fn = anymdp_graph_step_fn(h, eff);
-  for (int j = 0; j < period; ++j) {
+  void* fn = anymdp_graph_step_fn(h, eff, hand != nullptr);
+  if (!fn) return false;
+  for (int j = j0; j < period; j += dj) {
     hipKernelNodeParams np;
     memset(&np, 0, sizeof(np));
     AnyMDPArgs a = h->a;
     a.seed = h->eng->seed; a.gid_base = h->eng->env_id_base;
-    a.tick = (uint64_t)j; a.tick_dev = d_tick;
+    a.tick = (uint64_t)j; a.tick_dev = d_tick; a.hand = hand;
     const size_t off = (size_t)j * stride;
     AnyMDPStepIO io{actions + off, nullptr, nullptr, nullptr, obs + off, reward + off, reward_gt + off, terminated + off,
                     truncated + off, final_obs ? final_obs + off : nullptr, nullptr, nullptr, 0.0f};
@@ -1869,6 +1967,123 @@ static int anymdp_many_plain(xv_anymdp* h, int k, int period, size_t stride, con
   return anymdp_launch_step<false>(h, io, 1, mode);
 }
 
+// Overlapped step_many: consecutive vector steps alternate between the engine's stream (even ring slots) and a side stream
+// (odd slots) with NO dependency between the streams — step k + 1 is dispatched while step k runs, and each of its waves
+// takes its envs over from the same wave of step k through the hand-off word (HAND kernels above).  What a stream's barrier
+// between two launches costs — the drain of one launch and the dispatch of the next, 2.7 of the step's 5.0 us at 65,536
+// envs — is then covered by the other stream's launch.  Two cycle graphs (slots 0, 2, ... / 1, 3, ...), each with its own
+// tick word advanced by its own last node.  Same launch ticks, same results as plain launches (tests/test_gpu_chains.py).
+static bool anymdp_pipe_prepare(xv_anymdp* h, int period, size_t stride, const int32_t* actions, int32_t* obs, float* reward,
+                                float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
+  const int eff = anymdp_effective_search(h);
+  if (eff == XV_ANYMDP_SEARCH_BINARY || h->pipe_failed) return false;
+  if (!h->side) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    // a stream of another priority class: its launches go to a hardware queue of their own
+    if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, greatest) != hipSuccess) { h->side = nullptr; return false; }
+    if (hipEventCreateWithFlags(&h->side_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->side_ev[1], hipEventDisableTiming) != hipSuccess)
+      return false;
+  }
+  const int n_wave = xv_div_up(h->a.n_env, 256) * 4;
+  if (!h->d_hand && hipMalloc(&h->d_hand, sizeof(uint32_t) * (size_t)n_wave) != hipSuccess) return false;
+  if (!h->d_ptick && hipMalloc(&h->d_ptick, 2 * sizeof(uint64_t)) != hipSuccess) return false;
+  const void* ptrs[7] = {actions, obs, reward, reward_gt, terminated, truncated, final_obs};
+  auto& K = h->pipe_key;
+  if (h->pgraph_exec[0] && h->pgraph_exec[1] && K.period == period && K.mode == mode && K.search == eff && K.stride == stride &&
+      K.bucket == (const void*)h->a.bucket && K.seed == h->eng->seed && K.gid_base == h->eng->env_id_base &&
+      memcmp(K.ptrs, ptrs, sizeof(ptrs)) == 0)
+    return true;
+  (void)hipStreamSynchronize(h->side);
+  (void)hipStreamSynchronize(h->eng->stream);
+  anymdp_pipe_drop_graphs(h);
+  for (int q = 0; q < 2; ++q) {
+    if (hipGraphCreate(&h->pgraph[q], 0) != hipSuccess) return false;
+    hipGraphNode_t prev = nullptr;
+    if (!anymdp_add_chain(h, h->pgraph[q], &prev, h->d_ptick + q, eff, period, stride, actions, obs, reward, reward_gt,
+                          terminated, truncated, final_obs, mode, q, 2, h->d_hand))
+      return false;
+    if (!anymdp_add_tick_node(h->pgraph[q], &prev, 1, h->d_ptick + q, period)) return false;
+    if (hipGraphInstantiate(&h->pgraph_exec[q], h->pgraph[q], nullptr, nullptr, 0) != hipSuccess) {
+      h->pgraph_exec[q] = nullptr;
+      return false;
+    }
+  }
+  K.period = period; K.mode = mode; K.search = eff; K.stride = stride; K.bucket = (const void*)h->a.bucket;
+  K.seed = h->eng->seed; K.gid_base = h->eng->env_id_base;
+  memcpy(K.ptrs, ptrs, sizeof(ptrs));
+  return true;
+}
+
+// `cycles` whole ring cycles, overlapped; -> steps issued (0: not available, nothing issued)
+static int anymdp_pipe_run(xv_anymdp* h, int cycles, int period, size_t stride, const int32_t* actions, int32_t* obs,
+                           float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs,
+                           int mode) {
+  if (!anymdp_pipe_prepare(h, period, stride, actions, obs, reward, reward_gt, terminated, truncated, final_obs, mode)) {
+    (void)hipGetLastError();
+    h->pipe_failed = true;
+    return 0;
+  }
+  hipStream_t st = h->eng->stream;
+  const uint64_t t0 = h->eng->tick;
+  const int n_wave = xv_div_up(h->a.n_env, 256) * 4;
+  bool ok = true;
+  if (!(h->hand_valid && h->hand_value == t0)) {
+    hipLaunchKernelGGL(anymdp_fill_u32_kernel, dim3(xv_div_up(n_wave, 256)), dim3(256), 0, st, h->d_hand, (uint32_t)t0, n_wave);
+    ok = hipGetLastError() == hipSuccess;
+  }
+  if (ok && !(h->ptick_valid && h->ptick_value == t0)) {
+    hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick, t0);
+    hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick + 1, t0);
+    ok = hipGetLastError() == hipSuccess;
+  }
+  ok = ok && hipEventRecord(h->side_ev[0], st) == hipSuccess && hipStreamWaitEvent(h->side, h->side_ev[0], 0) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    h->pipe_failed = true; h->hand_valid = false; h->ptick_valid = false;
+    return 0;
+  }
+  int done = 0;
+  for (int c = 0; c < cycles; ++c) {
+    // both or neither: a cycle whose odd half is missing would leave the even half of the next one waiting
+    if (hipGraphLaunch(h->pgraph_exec[0], st) != hipSuccess) break;
+    if (hipGraphLaunch(h->pgraph_exec[1], h->side) != hipSuccess) {
+      // the even half is out: its waves time out on the hand-off words (flagged) — report failure to the caller
+      done = -1;
+      break;
+    }
+    done += period;
+  }
+  const bool joined = hipEventRecord(h->side_ev[1], h->side) == hipSuccess && hipStreamWaitEvent(st, h->side_ev[1], 0) == hipSuccess;
+  if (done < 0 || !joined) {
+    (void)hipGetLastError();
+    h->pipe_failed = true; h->hand_valid = false; h->ptick_valid = false;
+    return -1;
+  }
+  if (done < cycles * period) { (void)hipGetLastError(); h->pipe_failed = true; }
+  h->eng->tick = t0 + (uint64_t)done;
+  h->hand_value = h->eng->tick; h->hand_valid = true;
+  h->ptick_value = h->eng->tick; h->ptick_valid = true;
+  h->graph_used_last = done > 0;
+  return done;
+}
+
+extern "C" int xv_anymdp_set_step_many_overlap(xv_anymdp* h, int on) {
+  XV_CHECK_ARG(h != nullptr && (on == 0 || on == 1));
+  h->overlap = on;
+  if (on) h->pipe_failed = false;
+  return XV_OK;
+}
+
+// 1: the last xv_anymdp_step_many overlapped its ring cycles, 0: it did not (off, odd period, per-lane search, device tick,
+// graph mode 0), -1: the overlapped path failed on this handle and is no longer tried
+extern "C" int xv_anymdp_step_many_overlap_state(xv_anymdp* h) {
+  if (!h) return 0;
+  if (h->pipe_failed) return -1;
+  return (h->overlap && h->pgraph_exec[0] && h->graph_used_last) ? 1 : 0;
+}
+
 extern "C" int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const int32_t* actions,
                                    int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated,
                                    uint8_t* truncated, int32_t* final_obs, int autoreset_mode) {
@@ -1879,7 +2094,18 @@ extern "C" int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const 
   int k = 0;
   // whole ring cycles: replay the graph
   const int cycles = n_steps / period;
-  if (anymdp_many_prepare(h, n_steps, period, n, actions, obs, reward, reward_gt, terminated, truncated, final_obs,
+  if (h->overlap && cycles > 0 && period % 2 == 0 && h->graph_mode != 0 && !h->eng->dev_tick && !h->pipe_failed) {
+    XV_HIP(hipSetDevice(h->eng->device));
+    h->graph_used_last = false;
+    const int done = anymdp_pipe_run(h, cycles, period, n, actions, obs, reward, reward_gt, terminated, truncated, final_obs,
+                                     autoreset_mode);
+    if (done < 0) {
+      xv_set_error("xv_anymdp_step_many: an overlapped ring cycle could be issued only in part; the envs' states are undefined");
+      return XV_ERR_HIP;
+    }
+    k = done;
+  }
+  if (k == 0 && anymdp_many_prepare(h, n_steps, period, n, actions, obs, reward, reward_gt, terminated, truncated, final_obs,
                           autoreset_mode, false))
     for (int c = 0; c < cycles && anymdp_many_cycle(h, period); ++c) k += period;
   for (; k < n_steps; ++k) {
@@ -2239,6 +2465,8 @@ extern "C" int xv_anymdp_build_buckets(xv_anymdp* h, int n_bucket) {
     // an instantiated step_many graph holds the old lines' address and count in its kernel arguments: drop it with them
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    if (h->side) XV_HIP(hipStreamSynchronize(h->side));
+    anymdp_pipe_drop_graphs(h);
     (void)hipFree(h->bucket_rw);
     h->bucket_rw = nullptr; h->a.bucket = nullptr; h->a.NBK = 0; h->a.bfmt = 0;
     memset(&h->census, 0, sizeof(h->census));
