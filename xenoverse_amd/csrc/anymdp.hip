@@ -435,8 +435,12 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
         if (wall_clock64() - t_begin > XV_ANYMDP_HAND_TIMEOUT) { err |= XV_DEVERR_HANDOFF; break; }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    sr0 = P.sr[ic];
+    // the records cross between the two launches as agent-scope atomics (sc1: coherent over the whole device without a
+    // cache write-back or invalidate — a release / acquire FENCE at agent scope costs `buffer_wbl2` per wave: 39 us per
+    // step instead of 5, profiles/r05_b_*); this load is issued after the hand-off word has been seen
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint64_t r64 = __hip_atomic_load(reinterpret_cast<const uint64_t*>(P.sr) + ic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sr0 = make_uint2((uint32_t)r64, (uint32_t)(r64 >> 32));
   }
   int s = (int)(sr0.x & 0xFFFFu);
   int steps = (int)sr0.y;
@@ -700,10 +704,16 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
 #endif
     }
   }
-  if (valid) P.sr[i] = anymdp_sr_pack(s, steps, nr, cterm);
-  if (HAND) {      // the wave's records (and outputs) are out before the next step's wave is let at them
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (HAND) {      // the wave's records are out (agent-scope stores, waited for) before the next step's wave is let at them
+    const uint2 q = anymdp_sr_pack(s, steps, nr, cterm);
+    if (valid) __hip_atomic_store(reinterpret_cast<uint64_t*>(P.sr) + i, (uint64_t)q.x | ((uint64_t)q.y << 32), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // compiler ordering; no cache maintenance at this scope
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the record stores have been performed (stores may complete
+                                                                // out of order): only then the hand-off word
     if (lane == 0) __hip_atomic_store(P.hand + ((uint32_t)i >> 6), (uint32_t)tick0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (valid) {
+    P.sr[i] = anymdp_sr_pack(s, steps, nr, cterm);
   }
   if (err) atomicOr(P.err, err);
 }
@@ -2094,7 +2104,8 @@ extern "C" int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const 
   int k = 0;
   // whole ring cycles: replay the graph
   const int cycles = n_steps / period;
-  if (h->overlap && cycles > 0 && period % 2 == 0 && h->graph_mode != 0 && !h->eng->dev_tick && !h->pipe_failed) {
+  if (h->overlap && cycles > 0 && period % 2 == 0 && h->graph_mode != 0 && !h->eng->dev_tick && !h->pipe_failed &&
+      anymdp_effective_search(h) != XV_ANYMDP_SEARCH_BINARY) {
     XV_HIP(hipSetDevice(h->eng->device));
     h->graph_used_last = false;
     const int done = anymdp_pipe_run(h, cycles, period, n, actions, obs, reward, reward_gt, terminated, truncated, final_obs,
