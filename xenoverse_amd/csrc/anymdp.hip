@@ -37,6 +37,7 @@
 #include "xv_common.h"
 
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
 
 #define XV_ANYMDP_BLK 7   // next states per block
@@ -393,7 +394,8 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
   // ---- link 1: per-env words (coalesced): the 8-byte env record, the action and (fast path) three 16-byte reset units ----
   uint2 sr0 = make_uint2(0u, 0u);
   if (!HAND) sr0 = P.sr[ic];
-  int a_next = io.action ? io.action[ic] : 0;
+  // (HAND: nothing a caller may have written just before the call is read in front of the wait — the action follows it)
+  int a_next = (!HAND && io.action) ? io.action[ic] : 0;
   const uint64_t gid = P.gid_base + (uint64_t)ic;
   uint32_t err = 0;
 
@@ -440,6 +442,7 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
     // step instead of 5, profiles/r05_b_*); this load is issued after the hand-off word has been seen
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const uint64_t r64 = __hip_atomic_load(reinterpret_cast<const uint64_t*>(P.sr) + ic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (io.action) a_next = io.action[ic];
     sr0 = make_uint2((uint32_t)r64, (uint32_t)(r64 >> 32));
   }
   int s = (int)(sr0.x & 0xFFFFu);
@@ -2043,12 +2046,14 @@ static int anymdp_pipe_run(xv_anymdp* h, int cycles, int period, size_t stride, 
     hipLaunchKernelGGL(anymdp_fill_u32_kernel, dim3(xv_div_up(n_wave, 256)), dim3(256), 0, st, h->d_hand, (uint32_t)t0, n_wave);
     ok = hipGetLastError() == hipSuccess;
   }
+  static const bool nofork = getenv("XV_PIPE_NOFORK") != nullptr, side_first = getenv("XV_PIPE_SIDE_FIRST") != nullptr;
   if (ok && !(h->ptick_valid && h->ptick_value == t0)) {
     hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick, t0);
-    hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick + 1, t0);
+    hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, nofork ? h->side : st, h->d_ptick + 1, t0);
     ok = hipGetLastError() == hipSuccess;
   }
-  ok = ok && hipEventRecord(h->side_ev[0], st) == hipSuccess && hipStreamWaitEvent(h->side, h->side_ev[0], 0) == hipSuccess;
+  if (!nofork)
+    ok = ok && hipEventRecord(h->side_ev[0], st) == hipSuccess && hipStreamWaitEvent(h->side, h->side_ev[0], 0) == hipSuccess;
   if (!ok) {
     (void)hipGetLastError();
     h->pipe_failed = true; h->hand_valid = false; h->ptick_valid = false;
@@ -2057,6 +2062,12 @@ static int anymdp_pipe_run(xv_anymdp* h, int cycles, int period, size_t stride, 
   int done = 0;
   for (int c = 0; c < cycles; ++c) {
     // both or neither: a cycle whose odd half is missing would leave the even half of the next one waiting
+    if (side_first) {
+      if (hipGraphLaunch(h->pgraph_exec[1], h->side) != hipSuccess) break;
+      if (hipGraphLaunch(h->pgraph_exec[0], st) != hipSuccess) { done = -1; break; }
+      done += period;
+      continue;
+    }
     if (hipGraphLaunch(h->pgraph_exec[0], st) != hipSuccess) break;
     if (hipGraphLaunch(h->pgraph_exec[1], h->side) != hipSuccess) {
       // the even half is out: its waves time out on the hand-off words (flagged) — report failure to the caller
