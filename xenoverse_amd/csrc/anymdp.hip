@@ -128,6 +128,7 @@ struct xv_anymdp {
   // cycle graphs of HAND kernels, each with its own tick word; hand[] as in AnyMDPArgs
   int overlap;               // 0 off, 1 on
   bool pipe_failed;
+  bool pipe_used_last;       // the last xv_anymdp_step_many issued overlapped steps
   hipStream_t side;
   hipEvent_t side_ev[2];     // fork, join
   hipGraph_t pgraph[2];
@@ -685,6 +686,16 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
       steps = 0;
       nr = 0;
     }
+    if (HAND) {
+      // hand the envs on BEFORE the outputs leave: the record store (agent scope) is the only store in flight when it is
+      // waited for, and the next step's wave does not wait for this wave's seven output streams
+      const uint2 q = anymdp_sr_pack(s, steps, nr, cterm);
+      if (valid) __hip_atomic_store(reinterpret_cast<uint64_t*>(P.sr) + i, (uint64_t)q.x | ((uint64_t)q.y << 32), __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // compiler ordering; no cache maintenance at this scope
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the record store has been performed: only then the word
+      if (lane == 0) __hip_atomic_store(P.hand + ((uint32_t)i >> 6), (uint32_t)tick0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (valid) {
 #if XV_ANYMDP_NT_OUT
       __builtin_nontemporal_store(o_obs, io.obs + o);
@@ -707,17 +718,7 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
 #endif
     }
   }
-  if (HAND) {      // the wave's records are out (agent-scope stores, waited for) before the next step's wave is let at them
-    const uint2 q = anymdp_sr_pack(s, steps, nr, cterm);
-    if (valid) __hip_atomic_store(reinterpret_cast<uint64_t*>(P.sr) + i, (uint64_t)q.x | ((uint64_t)q.y << 32), __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // compiler ordering; no cache maintenance at this scope
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the record stores have been performed (stores may complete
-                                                                // out of order): only then the hand-off word
-    if (lane == 0) __hip_atomic_store(P.hand + ((uint32_t)i >> 6), (uint32_t)tick0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else if (valid) {
-    P.sr[i] = anymdp_sr_pack(s, steps, nr, cterm);
-  }
+  if (!HAND && valid) P.sr[i] = anymdp_sr_pack(s, steps, nr, cterm);
   if (err) atomicOr(P.err, err);
 }
 
@@ -1511,7 +1512,7 @@ static inline int anymdp_effective_search(const xv_anymdp* h) {
 
 #ifndef XV_KERNELS_ONLY   // mixed.hip includes this file for its kernels and handle types only
 static void anymdp_pipe_clear(xv_anymdp* h) {      // fields of the overlapped step_many: nothing built
-  h->overlap = 0; h->pipe_failed = false; h->side = nullptr;
+  h->overlap = 0; h->pipe_failed = false; h->pipe_used_last = false; h->side = nullptr;
   h->side_ev[0] = h->side_ev[1] = nullptr;
   h->pgraph[0] = h->pgraph[1] = nullptr; h->pgraph_exec[0] = h->pgraph_exec[1] = nullptr;
   h->d_ptick = nullptr; h->ptick_value = 0; h->ptick_valid = false;
@@ -1980,16 +1981,17 @@ static int anymdp_many_plain(xv_anymdp* h, int k, int period, size_t stride, con
   return anymdp_launch_step<false>(h, io, 1, mode);
 }
 
-// Overlapped step_many: consecutive vector steps alternate between the engine's stream (even ring slots) and a side stream
-// (odd slots) with NO dependency between the streams — step k + 1 is dispatched while step k runs, and each of its waves
-// takes its envs over from the same wave of step k through the hand-off word (HAND kernels above).  What a stream's barrier
+// Overlapped step_many: consecutive vector steps alternate between the engine's stream (even steps) and a side stream (odd
+// steps) with NO dependency between the streams — step k + 1 is dispatched while step k runs, and each of its waves takes
+// its envs over from the same wave of step k through the hand-off word (HAND kernels above).  What a stream's barrier
 // between two launches costs — the drain of one launch and the dispatch of the next, 2.7 of the step's 5.0 us at 65,536
-// envs — is then covered by the other stream's launch.  Two cycle graphs (slots 0, 2, ... / 1, 3, ...), each with its own
-// tick word advanced by its own last node.  Same launch ticks, same results as plain launches (tests/test_gpu_chains.py).
-static bool anymdp_pipe_prepare(xv_anymdp* h, int period, size_t stride, const int32_t* actions, int32_t* obs, float* reward,
-                                float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
-  const int eff = anymdp_effective_search(h);
-  if (eff == XV_ANYMDP_SEARCH_BINARY || h->pipe_failed) return false;
+// envs — is then covered by the other stream's launch.  Long calls replay two cycle graphs (ring slots 0, 2, ... / 1, 3, ...,
+// each with its own tick word advanced by its own last node); short calls and what is left over after the whole cycles are
+// plain launches issued alternately (a second hipGraphLaunch reaches the device ~25 us after the first: a 20-step burst
+// would spend a quarter of its time waiting for its odd half, profiles/r05_d_burst_timeline.txt).  Same launch ticks, same
+// results as the ordinary path (tests/test_gpu_chains.py).
+#define XV_ANYMDP_PIPE_GRAPH_MIN 64      // calls of at least this many steps replay the cycle graphs
+static bool anymdp_pipe_setup(xv_anymdp* h) {
   if (!h->side) {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
@@ -2001,7 +2003,16 @@ static bool anymdp_pipe_prepare(xv_anymdp* h, int period, size_t stride, const i
   }
   const int n_wave = xv_div_up(h->a.n_env, 256) * 4;
   if (!h->d_hand && hipMalloc(&h->d_hand, sizeof(uint32_t) * (size_t)n_wave) != hipSuccess) return false;
-  if (!h->d_ptick && hipMalloc(&h->d_ptick, 2 * sizeof(uint64_t)) != hipSuccess) return false;
+  if (!h->d_ptick) {      // [0], [1]: the two graphs' tick words; [2] stays 0: plain HAND launches carry the tick as an argument
+    if (hipMalloc(&h->d_ptick, 3 * sizeof(uint64_t)) != hipSuccess) return false;
+    if (hipMemsetAsync(h->d_ptick, 0, 3 * sizeof(uint64_t), h->eng->stream) != hipSuccess) return false;
+  }
+  return true;
+}
+
+static bool anymdp_pipe_graphs(xv_anymdp* h, int period, size_t stride, const int32_t* actions, int32_t* obs, float* reward,
+                               float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
+  const int eff = anymdp_effective_search(h);
   const void* ptrs[7] = {actions, obs, reward, reward_gt, terminated, truncated, final_obs};
   auto& K = h->pipe_key;
   if (h->pgraph_exec[0] && h->pgraph_exec[1] && K.period == period && K.mode == mode && K.search == eff && K.stride == stride &&
@@ -2029,65 +2040,92 @@ static bool anymdp_pipe_prepare(xv_anymdp* h, int period, size_t stride, const i
   return true;
 }
 
-// `cycles` whole ring cycles, overlapped; -> steps issued (0: not available, nothing issued)
-static int anymdp_pipe_run(xv_anymdp* h, int cycles, int period, size_t stride, const int32_t* actions, int32_t* obs,
+// one HAND step launched on `st` with the engine's tick as an argument (the kernels are the graphs': they add *tick_dev,
+// which is the zero word here)
+static bool anymdp_pipe_plain_step(xv_anymdp* h, hipStream_t st, int k, int period, size_t stride, const int32_t* actions,
+                                   int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated,
+                                   int32_t* final_obs, int mode) {
+  void* fn = anymdp_graph_step_fn(h, anymdp_effective_search(h), true);
+  if (!fn) return false;
+  AnyMDPArgs a = h->a;
+  a.seed = h->eng->seed; a.gid_base = h->eng->env_id_base;
+  a.tick = h->eng->tick; a.tick_dev = h->d_ptick + 2; a.hand = h->d_hand;
+  const size_t off = (size_t)(k % period) * stride;
+  AnyMDPStepIO io{actions + off, nullptr, nullptr, nullptr, obs + off, reward + off, reward_gt + off, terminated + off,
+                  truncated + off, final_obs ? final_obs + off : nullptr, nullptr, nullptr, 0.0f};
+  int T = 1, md = mode;
+  void* params[] = {&a, &io, &T, &md};
+  if (hipLaunchKernel(fn, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), params, 0, st) != hipSuccess) return false;
+  h->eng->tick += 1;
+  return true;
+}
+
+// all n_steps of a call, overlapped; -> XV_OK, or an error when a step could not be issued (the envs are then at the step
+// the engine's tick names; the streams are joined either way)
+static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride, const int32_t* actions, int32_t* obs,
                            float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs,
-                           int mode) {
-  if (!anymdp_pipe_prepare(h, period, stride, actions, obs, reward, reward_gt, terminated, truncated, final_obs, mode)) {
+                           int mode, int* issued) {
+  *issued = 0;
+  if (!anymdp_pipe_setup(h)) {
     (void)hipGetLastError();
     h->pipe_failed = true;
-    return 0;
+    return XV_OK;      // nothing issued: the caller takes the ordinary path
   }
   hipStream_t st = h->eng->stream;
   const uint64_t t0 = h->eng->tick;
   const int n_wave = xv_div_up(h->a.n_env, 256) * 4;
+  const int cycles = n_steps / period;
+  const bool graphs = cycles > 0 && period % 2 == 0 && n_steps >= XV_ANYMDP_PIPE_GRAPH_MIN &&
+                      anymdp_pipe_graphs(h, period, stride, actions, obs, reward, reward_gt, terminated, truncated, final_obs, mode);
   bool ok = true;
   if (!(h->hand_valid && h->hand_value == t0)) {
     hipLaunchKernelGGL(anymdp_fill_u32_kernel, dim3(xv_div_up(n_wave, 256)), dim3(256), 0, st, h->d_hand, (uint32_t)t0, n_wave);
     ok = hipGetLastError() == hipSuccess;
   }
-  static const bool nofork = getenv("XV_PIPE_NOFORK") != nullptr, side_first = getenv("XV_PIPE_SIDE_FIRST") != nullptr;
-  if (ok && !(h->ptick_valid && h->ptick_value == t0)) {
+  if (ok && graphs && !(h->ptick_valid && h->ptick_value == t0)) {
     hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick, t0);
-    hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, nofork ? h->side : st, h->d_ptick + 1, t0);
+    hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick + 1, t0);
     ok = hipGetLastError() == hipSuccess;
   }
-  if (!nofork)
-    ok = ok && hipEventRecord(h->side_ev[0], st) == hipSuccess && hipStreamWaitEvent(h->side, h->side_ev[0], 0) == hipSuccess;
+  // fork: the side stream starts behind what the engine's stream holds now (the caller's actions, a reset, the words above)
+  ok = ok && hipEventRecord(h->side_ev[0], st) == hipSuccess && hipStreamWaitEvent(h->side, h->side_ev[0], 0) == hipSuccess;
   if (!ok) {
     (void)hipGetLastError();
     h->pipe_failed = true; h->hand_valid = false; h->ptick_valid = false;
-    return 0;
+    return XV_OK;
   }
-  int done = 0;
-  for (int c = 0; c < cycles; ++c) {
-    // both or neither: a cycle whose odd half is missing would leave the even half of the next one waiting
-    if (side_first) {
-      if (hipGraphLaunch(h->pgraph_exec[1], h->side) != hipSuccess) break;
-      if (hipGraphLaunch(h->pgraph_exec[0], st) != hipSuccess) { done = -1; break; }
-      done += period;
-      continue;
+  h->hand_valid = false; h->ptick_valid = false;      // until the call has gone through
+  int k = 0;
+  bool broken = false;
+  if (graphs) {
+    for (int c = 0; c < cycles && !broken; ++c) {
+      // both halves or neither: an even half without its odd half leaves the next even launch waiting (bounded, flagged)
+      if (hipGraphLaunch(h->pgraph_exec[0], st) != hipSuccess) break;
+      if (hipGraphLaunch(h->pgraph_exec[1], h->side) != hipSuccess) { broken = true; break; }
+      k += period;
+      h->eng->tick = t0 + (uint64_t)k;
     }
-    if (hipGraphLaunch(h->pgraph_exec[0], st) != hipSuccess) break;
-    if (hipGraphLaunch(h->pgraph_exec[1], h->side) != hipSuccess) {
-      // the even half is out: its waves time out on the hand-off words (flagged) — report failure to the caller
-      done = -1;
+    if (k > 0) { h->ptick_value = h->eng->tick; h->ptick_valid = !broken; h->graph_used_last = true; }
+    if (k < cycles * period) { (void)hipGetLastError(); h->pipe_failed = true; }
+  }
+  for (; k < n_steps && !broken; ++k)
+    if (!anymdp_pipe_plain_step(h, (k & 1) ? h->side : st, k, period, stride, actions, obs, reward, reward_gt, terminated,
+                                truncated, final_obs, mode)) {
+      (void)hipGetLastError();
+      h->pipe_failed = true;
       break;
     }
-    done += period;
-  }
   const bool joined = hipEventRecord(h->side_ev[1], h->side) == hipSuccess && hipStreamWaitEvent(st, h->side_ev[1], 0) == hipSuccess;
-  if (done < 0 || !joined) {
+  *issued = k;
+  if (broken || !joined) {
     (void)hipGetLastError();
-    h->pipe_failed = true; h->hand_valid = false; h->ptick_valid = false;
-    return -1;
+    h->pipe_failed = true;
+    xv_set_error("xv_anymdp_step_many: an overlapped step could be issued only in part; the envs' states are undefined");
+    return XV_ERR_HIP;
   }
-  if (done < cycles * period) { (void)hipGetLastError(); h->pipe_failed = true; }
-  h->eng->tick = t0 + (uint64_t)done;
   h->hand_value = h->eng->tick; h->hand_valid = true;
-  h->ptick_value = h->eng->tick; h->ptick_valid = true;
-  h->graph_used_last = done > 0;
-  return done;
+  h->pipe_used_last = k > 0;
+  return XV_OK;
 }
 
 extern "C" int xv_anymdp_set_step_many_overlap(xv_anymdp* h, int on) {
@@ -2102,7 +2140,7 @@ extern "C" int xv_anymdp_set_step_many_overlap(xv_anymdp* h, int on) {
 extern "C" int xv_anymdp_step_many_overlap_state(xv_anymdp* h) {
   if (!h) return 0;
   if (h->pipe_failed) return -1;
-  return (h->overlap && h->pgraph_exec[0] && h->graph_used_last) ? 1 : 0;
+  return (h->overlap && h->pipe_used_last) ? 1 : 0;
 }
 
 extern "C" int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const int32_t* actions,
@@ -2115,17 +2153,14 @@ extern "C" int xv_anymdp_step_many(xv_anymdp* h, int n_steps, int period, const 
   int k = 0;
   // whole ring cycles: replay the graph
   const int cycles = n_steps / period;
-  if (h->overlap && cycles > 0 && period % 2 == 0 && h->graph_mode != 0 && !h->eng->dev_tick && !h->pipe_failed &&
+  h->pipe_used_last = false;
+  if (h->overlap && h->graph_mode != 0 && !h->eng->dev_tick && !h->pipe_failed &&
       anymdp_effective_search(h) != XV_ANYMDP_SEARCH_BINARY) {
     XV_HIP(hipSetDevice(h->eng->device));
     h->graph_used_last = false;
-    const int done = anymdp_pipe_run(h, cycles, period, n, actions, obs, reward, reward_gt, terminated, truncated, final_obs,
-                                     autoreset_mode);
-    if (done < 0) {
-      xv_set_error("xv_anymdp_step_many: an overlapped ring cycle could be issued only in part; the envs' states are undefined");
-      return XV_ERR_HIP;
-    }
-    k = done;
+    const int rc = anymdp_pipe_run(h, n_steps, period, n, actions, obs, reward, reward_gt, terminated, truncated, final_obs,
+                                   autoreset_mode, &k);
+    if (rc != XV_OK) return rc;
   }
   if (k == 0 && anymdp_many_prepare(h, n_steps, period, n, actions, obs, reward, reward_gt, terminated, truncated, final_obs,
                           autoreset_mode, false))
