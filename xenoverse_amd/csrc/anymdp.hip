@@ -72,8 +72,6 @@ struct AnyMDPArgs {
   int bfmt;              // metadata packing of the bucket lines: 1 = 7 cuts (S <= 256, observation ids <= 255), 2 = 6 cuts
   uint64_t seed, gid_base, tick;
   const uint64_t* tick_dev;   // graph replay: the launch tick is *tick_dev + tick (tick = node index); else nullptr
-  uint32_t* hand;             // HAND kernels (overlapped step_many): per-wave hand-off word, hand[w] = low 32 bits of the launch
-                              // tick of the next step wave w's envs may take (the step before it has stored their records)
 };
 
 struct AnyMDPStepIO {
@@ -136,9 +134,6 @@ struct xv_anymdp {
   uint64_t* d_ptick;         // two tick words
   uint64_t ptick_value;      // what both hold once the streams have drained (valid with pgraph_exec)
   bool ptick_valid;
-  uint32_t* d_hand;
-  uint64_t hand_value;       // hand[w] == (uint32_t)hand_value for every wave
-  bool hand_valid;
   struct {
     int period, mode, search;
     size_t stride;
@@ -165,6 +160,10 @@ struct xv_anymdp {
 
 #define XV_ANYMDP_SR_TERM 0x10000u
 #define XV_ANYMDP_SR_NR 0x20000u
+// bits 18..31 of .x: hand-off tag of the overlapped step_many (HAND kernels) — the low 14 bits of the launch tick of the step
+// that may take the env next; every other kernel ignores the bits and writes them as 0
+#define XV_ANYMDP_SR_TAG_SHIFT 18
+#define XV_ANYMDP_SR_TAG(tick) ((uint32_t)(tick) & 0x3FFFu)
 __device__ __forceinline__ uint2 anymdp_sr_pack(int s, int steps, int nr, int cterm) {
   return make_uint2((uint32_t)s | (cterm ? XV_ANYMDP_SR_TERM : 0u) | (nr ? XV_ANYMDP_SR_NR : 0u), (uint32_t)steps);
 }
@@ -374,13 +373,15 @@ typedef AnyMDPCoopLineN<XV_ANYMDP_TOK_LPE, XV_ANYMDP_COOP_CONTIG != 0> AnyMDPTok
 // mixed-batch kernel of mixed.hip hands every family a contiguous range of its workgroups)
 // HAND: the launch may start while the launch of the step before it is still running (xv_anymdp_step_many, overlap mode:
 //     consecutive steps alternate between two HIP streams with no dependency between the streams).  Everything that does not
-//     depend on the env records is done first (action and reset-record loads, the transition uniform); then lane 0 of each
-//     wave waits until hand[w] names this launch's tick — the same wave of the step before has stored its records and
-//     released them — and only then are the records read.  At the end the wave releases its stores and publishes tick + 1.
-//     A wave depends on the same wave of the previous step only (one lane per env, anymdp_env.py:92-132 is per env).  The
-//     wait is bounded (XV_ANYMDP_HAND_TIMEOUT of the 100-MHz wall clock): on expiry the wave goes on and sets
-//     XV_DEVERR_HANDOFF — wrong results, flagged, never a hang.
-#define XV_ANYMDP_HAND_TIMEOUT 200000ull   // 2 ms
+//     depend on the env records is done first (action and reset-record loads, the transition uniform); then the wave waits
+//     until its envs' records carry this launch's tag — bits 18..31 of the record's first word = the low 14 bits of the tick
+//     of the step that may take the env next: the step before stores record and tag with ONE 8-byte agent-scope store, so
+//     the record IS the hand-off (a separate word costs a second round trip: 4.45 vs 3.x us per step).  Lane 0 polls its own
+//     record; when it is there the wave reads all 64 and checks every tag (the store of a wave is four cache lines that
+//     may land apart).  A wave depends on the same wave of the previous step only (one lane per env, anymdp_env.py:92-132 is
+//     per env).  The wait is bounded (XV_ANYMDP_HAND_TIMEOUT of the 100-MHz wall clock): on expiry the wave goes on and
+//     sets XV_DEVERR_HANDOFF — wrong results, flagged, never a hang.
+#define XV_ANYMDP_HAND_TIMEOUT 5000000ull   // 50 ms
 template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false, int BK = 0, bool HAND = false>
 __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyMDPStepIO& io, int T_steps, int mode, int bid) {
   constexpr bool FAST = G > 0;
@@ -395,8 +396,7 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
   // ---- link 1: per-env words (coalesced): the 8-byte env record, the action and (fast path) three 16-byte reset units ----
   uint2 sr0 = make_uint2(0u, 0u);
   if (!HAND) sr0 = P.sr[ic];
-  // (HAND: nothing a caller may have written just before the call is read in front of the wait — the action follows it)
-  int a_next = (!HAND && io.action) ? io.action[ic] : 0;
+  int a_next = io.action ? io.action[ic] : 0;
   const uint64_t gid = P.gid_base + (uint64_t)ic;
   uint32_t err = 0;
 
@@ -429,21 +429,27 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
   if (HAND) {
     w_pre = xv_env_draw(P.seed, gid, tick0, XV_DRAW_STEP);      // the transition uniform does not need the env record
     asm volatile("" : "+v"(w_pre.x), "+v"(w_pre.y), "+v"(w_pre.z), "+v"(w_pre.w));      // made here, in front of the wait
-    uint32_t* flag = P.hand + ((uint32_t)i >> 6);
-    const uint32_t want = (uint32_t)tick0;
-    if (lane == 0) {
-      const uint64_t t_begin = wall_clock64();
-      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-        __builtin_amdgcn_s_sleep(1);
-        if (wall_clock64() - t_begin > XV_ANYMDP_HAND_TIMEOUT) { err |= XV_DEVERR_HANDOFF; break; }
+    const uint32_t want = XV_ANYMDP_SR_TAG(tick0);
+    const uint64_t* rp = reinterpret_cast<const uint64_t*>(P.sr) + ic;
+    const uint64_t t_begin = wall_clock64();
+    uint64_t r64 = 0;
+    for (;;) {
+      // records cross between the launches as agent-scope atomics (sc1: coherent over the device without cache maintenance;
+      // an agent-scope release / acquire FENCE is a `buffer_wbl2` per wave: 39 us per step, profiles/r05_b_*)
+      uint32_t head = 0;
+      if (lane == 0) head = (uint32_t)__hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      head = (uint32_t)__builtin_amdgcn_readfirstlane((int)head);
+      if ((head >> XV_ANYMDP_SR_TAG_SHIFT) == want) {
+        r64 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__ballot(((uint32_t)r64 >> XV_ANYMDP_SR_TAG_SHIFT) != want) == 0ull) break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t_begin > XV_ANYMDP_HAND_TIMEOUT) {
+        err |= XV_DEVERR_HANDOFF;
+        r64 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
       }
     }
-    // the records cross between the two launches as agent-scope atomics (sc1: coherent over the whole device without a
-    // cache write-back or invalidate — a release / acquire FENCE at agent scope costs `buffer_wbl2` per wave: 39 us per
-    // step instead of 5, profiles/r05_b_*); this load is issued after the hand-off word has been seen
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const uint64_t r64 = __hip_atomic_load(reinterpret_cast<const uint64_t*>(P.sr) + ic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (io.action) a_next = io.action[ic];
     sr0 = make_uint2((uint32_t)r64, (uint32_t)(r64 >> 32));
   }
   int s = (int)(sr0.x & 0xFFFFu);
@@ -687,14 +693,11 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
       nr = 0;
     }
     if (HAND) {
-      // hand the envs on BEFORE the outputs leave: the record store (agent scope) is the only store in flight when it is
-      // waited for, and the next step's wave does not wait for this wave's seven output streams
+      // hand the envs on BEFORE the outputs leave: record and tag of the next step in one 8-byte agent-scope store
       const uint2 q = anymdp_sr_pack(s, steps, nr, cterm);
-      if (valid) __hip_atomic_store(reinterpret_cast<uint64_t*>(P.sr) + i, (uint64_t)q.x | ((uint64_t)q.y << 32), __ATOMIC_RELAXED,
+      const uint32_t x = q.x | (XV_ANYMDP_SR_TAG(tick0 + 1u) << XV_ANYMDP_SR_TAG_SHIFT);
+      if (valid) __hip_atomic_store(reinterpret_cast<uint64_t*>(P.sr) + i, (uint64_t)x | ((uint64_t)q.y << 32), __ATOMIC_RELAXED,
                                     __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // compiler ordering; no cache maintenance at this scope
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the record store has been performed: only then the word
-      if (lane == 0) __hip_atomic_store(P.hand + ((uint32_t)i >> 6), (uint32_t)tick0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (valid) {
 #if XV_ANYMDP_NT_OUT
@@ -726,9 +729,10 @@ template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false, int BK = 0, bo
 __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPStepIO io, int T_steps, int mode) {
   anymdp_step_body<INJECT, G, ROLLOUT, TICKDEV, BK, HAND>(P, io, T_steps, mode, (int)blockIdx.x);
 }
-static __global__ void anymdp_fill_u32_kernel(uint32_t* p, uint32_t v, int n) {
+// before an overlapped call: every record gets the tag of the call's first step (ordinary kernels write the tag bits as 0)
+static __global__ __launch_bounds__(256) void anymdp_retag_kernel(uint2* sr, int n, uint32_t tag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
+  if (i < n) sr[i].x = (sr[i].x & ((1u << XV_ANYMDP_SR_TAG_SHIFT) - 1u)) | (tag << XV_ANYMDP_SR_TAG_SHIFT);
 }
 
 // Completes the rows in place (create time): fence line and per-block metadata.  One thread per (row, k < 64).
@@ -1516,7 +1520,6 @@ static void anymdp_pipe_clear(xv_anymdp* h) {      // fields of the overlapped s
   h->side_ev[0] = h->side_ev[1] = nullptr;
   h->pgraph[0] = h->pgraph[1] = nullptr; h->pgraph_exec[0] = h->pgraph_exec[1] = nullptr;
   h->d_ptick = nullptr; h->ptick_value = 0; h->ptick_valid = false;
-  h->d_hand = nullptr; h->hand_value = 0; h->hand_valid = false;
   memset(&h->pipe_key, 0, sizeof(h->pipe_key));
 }
 static void anymdp_pipe_drop_graphs(xv_anymdp* h) {
@@ -1532,7 +1535,6 @@ static void anymdp_pipe_release(xv_anymdp* h) {
   if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
   for (int q = 0; q < 2; ++q) if (h->side_ev[q]) (void)hipEventDestroy(h->side_ev[q]);
   if (h->d_ptick) (void)hipFree(h->d_ptick);
-  if (h->d_hand) (void)hipFree(h->d_hand);
   anymdp_pipe_clear(h);
 }
 
@@ -1713,7 +1715,6 @@ extern "C" int xv_anymdp_view(xv_anymdp* parent, xv_engine* e, int env_lo, int n
   memset(&h->cgraph_key, 0, sizeof(h->cgraph_key));
   anymdp_pipe_clear(h);
   AnyMDPArgs& a = h->a;
-  a.hand = nullptr;
   a.sr += env_lo;
   if (a.rs_a) { a.rs_a += env_lo; a.rs_b += env_lo; a.rs_c += env_lo; }
   a.env_task += env_lo;
@@ -1850,16 +1851,16 @@ static void* anymdp_graph_step_fn(const xv_anymdp* h, int eff, bool hand = false
 static bool anymdp_add_chain(xv_anymdp* h, hipGraph_t graph, hipGraphNode_t* prev, uint64_t* d_tick, int eff, int period,
                              size_t stride, const int32_t* actions, int32_t* obs, float* reward, float* reward_gt,
                              uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode, int j0 = 0, int dj = 1,
-                             uint32_t* hand = nullptr) {
+                             bool hand = false) {
   const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
-  void* fn = anymdp_graph_step_fn(h, eff, hand != nullptr);
+  void* fn = anymdp_graph_step_fn(h, eff, hand);
   if (!fn) return false;
   for (int j = j0; j < period; j += dj) {
     hipKernelNodeParams np;
     memset(&np, 0, sizeof(np));
     AnyMDPArgs a = h->a;
     a.seed = h->eng->seed; a.gid_base = h->eng->env_id_base;
-    a.tick = (uint64_t)j; a.tick_dev = d_tick; a.hand = hand;
+    a.tick = (uint64_t)j; a.tick_dev = d_tick;
     const size_t off = (size_t)j * stride;
     AnyMDPStepIO io{actions + off, nullptr, nullptr, nullptr, obs + off, reward + off, reward_gt + off, terminated + off,
                     truncated + off, final_obs ? final_obs + off : nullptr, nullptr, nullptr, 0.0f};
@@ -1985,12 +1986,15 @@ static int anymdp_many_plain(xv_anymdp* h, int k, int period, size_t stride, con
 // steps) with NO dependency between the streams — step k + 1 is dispatched while step k runs, and each of its waves takes
 // its envs over from the same wave of step k through the hand-off word (HAND kernels above).  What a stream's barrier
 // between two launches costs — the drain of one launch and the dispatch of the next, 2.7 of the step's 5.0 us at 65,536
-// envs — is then covered by the other stream's launch.  Long calls replay two cycle graphs (ring slots 0, 2, ... / 1, 3, ...,
-// each with its own tick word advanced by its own last node); short calls and what is left over after the whole cycles are
-// plain launches issued alternately (a second hipGraphLaunch reaches the device ~25 us after the first: a 20-step burst
-// would spend a quarter of its time waiting for its odd half, profiles/r05_d_burst_timeline.txt).  Same launch ticks, same
+// envs — is then covered by the other stream's launch.  Whole ring cycles of an even period replay two cycle graphs (ring
+// slots 0, 2, ... / 1, 3, ..., each with its own tick word advanced by its own last node); what is left over runs the ordinary
+// way behind the join.  Calls shorter than XV_ANYMDP_PIPE_GRAPH_MIN steps take the ordinary path altogether: the second
+// hipGraphLaunch reaches the device ~12-25 us after the first and the join costs a cross-queue wait, so a 20-step burst
+// (~110 us) loses what the overlap gains (measured 5.9-6.4 vs 5.55 us per step; issuing the steps as plain launches
+// alternately on the two streams is host-bound: 5.7; profiles/r05_c_*, r05_d_burst_timeline.txt).  Same launch ticks, same
 // results as the ordinary path (tests/test_gpu_chains.py).
-#define XV_ANYMDP_PIPE_GRAPH_MIN 64      // calls of at least this many steps replay the cycle graphs
+#define XV_ANYMDP_PIPE_GRAPH_MIN 64      // calls of at least this many steps are overlapped
+static bool anymdp_pipe_selftest(xv_anymdp* h);
 static bool anymdp_pipe_setup(xv_anymdp* h) {
   if (!h->side) {
     int least = 0, greatest = 0;
@@ -2001,11 +2005,9 @@ static bool anymdp_pipe_setup(xv_anymdp* h) {
         hipEventCreateWithFlags(&h->side_ev[1], hipEventDisableTiming) != hipSuccess)
       return false;
   }
-  const int n_wave = xv_div_up(h->a.n_env, 256) * 4;
-  if (!h->d_hand && hipMalloc(&h->d_hand, sizeof(uint32_t) * (size_t)n_wave) != hipSuccess) return false;
-  if (!h->d_ptick) {      // [0], [1]: the two graphs' tick words; [2] stays 0: plain HAND launches carry the tick as an argument
-    if (hipMalloc(&h->d_ptick, 3 * sizeof(uint64_t)) != hipSuccess) return false;
-    if (hipMemsetAsync(h->d_ptick, 0, 3 * sizeof(uint64_t), h->eng->stream) != hipSuccess) return false;
+  if (!h->d_ptick) {      // the two graphs' tick words
+    if (hipMalloc(&h->d_ptick, 2 * sizeof(uint64_t)) != hipSuccess) return false;
+    if (!anymdp_pipe_selftest(h)) return false;      // once per handle
   }
   return true;
 }
@@ -2026,7 +2028,7 @@ static bool anymdp_pipe_graphs(xv_anymdp* h, int period, size_t stride, const in
     if (hipGraphCreate(&h->pgraph[q], 0) != hipSuccess) return false;
     hipGraphNode_t prev = nullptr;
     if (!anymdp_add_chain(h, h->pgraph[q], &prev, h->d_ptick + q, eff, period, stride, actions, obs, reward, reward_gt,
-                          terminated, truncated, final_obs, mode, q, 2, h->d_hand))
+                          terminated, truncated, final_obs, mode, q, 2, true))
       return false;
     if (!anymdp_add_tick_node(h->pgraph[q], &prev, 1, h->d_ptick + q, period)) return false;
     if (hipGraphInstantiate(&h->pgraph_exec[q], h->pgraph[q], nullptr, nullptr, 0) != hipSuccess) {
@@ -2040,91 +2042,90 @@ static bool anymdp_pipe_graphs(xv_anymdp* h, int period, size_t stride, const in
   return true;
 }
 
-// one HAND step launched on `st` with the engine's tick as an argument (the kernels are the graphs': they add *tick_dev,
-// which is the zero word here)
-static bool anymdp_pipe_plain_step(xv_anymdp* h, hipStream_t st, int k, int period, size_t stride, const int32_t* actions,
-                                   int32_t* obs, float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated,
-                                   int32_t* final_obs, int mode) {
-  void* fn = anymdp_graph_step_fn(h, anymdp_effective_search(h), true);
-  if (!fn) return false;
-  AnyMDPArgs a = h->a;
-  a.seed = h->eng->seed; a.gid_base = h->eng->env_id_base;
-  a.tick = h->eng->tick; a.tick_dev = h->d_ptick + 2; a.hand = h->d_hand;
-  const size_t off = (size_t)(k % period) * stride;
-  AnyMDPStepIO io{actions + off, nullptr, nullptr, nullptr, obs + off, reward + off, reward_gt + off, terminated + off,
-                  truncated + off, final_obs ? final_obs + off : nullptr, nullptr, nullptr, 0.0f};
-  int T = 1, md = mode;
-  void* params[] = {&a, &io, &T, &md};
-  if (hipLaunchKernel(fn, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), params, 0, st) != hipSuccess) return false;
-  h->eng->tick += 1;
-  return true;
+// Do launches on the two streams really run at the same time?  A probe on the side stream waits (bounded, 20 ms) for a word
+// that a launch issued AFTERWARDS on the engine's stream sets.  If the streams share a hardware queue, or the device takes
+// one launch at a time, the wait expires and the overlapped path is never used on this handle.
+static __global__ void anymdp_probe_wait_kernel(uint32_t* flag, uint32_t* seen) {
+  const uint64_t t_begin = wall_clock64();
+  uint32_t ok = 0;
+  while (wall_clock64() - t_begin < 2000000ull) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) { ok = 1; break; }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  *seen = ok;
+}
+static __global__ void anymdp_probe_set_kernel(uint32_t* flag) {
+  __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static bool anymdp_pipe_selftest(xv_anymdp* h) {
+  uint32_t* d = nullptr;
+  if (hipMalloc(&d, 2 * sizeof(uint32_t)) != hipSuccess) return false;
+  uint32_t seen = 0;
+  bool ok = hipMemsetAsync(d, 0, 2 * sizeof(uint32_t), h->eng->stream) == hipSuccess &&
+            hipStreamSynchronize(h->eng->stream) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(anymdp_probe_wait_kernel, dim3(1), dim3(1), 0, h->side, d, d + 1);
+    hipLaunchKernelGGL(anymdp_probe_set_kernel, dim3(1), dim3(1), 0, h->eng->stream, d);
+    ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(h->side) == hipSuccess &&
+         hipStreamSynchronize(h->eng->stream) == hipSuccess &&
+         hipMemcpy(&seen, d + 1, sizeof(seen), hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  (void)hipFree(d);
+  return ok && seen == 1u;
 }
 
-// all n_steps of a call, overlapped; -> XV_OK, or an error when a step could not be issued (the envs are then at the step
-// the engine's tick names; the streams are joined either way)
+// the whole ring cycles of a call, overlapped; *issued = steps issued (0: the caller takes the ordinary path for all of it).
+// -> XV_OK, or an error when a cycle went out in part (the streams are joined either way)
 static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride, const int32_t* actions, int32_t* obs,
                            float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs,
                            int mode, int* issued) {
   *issued = 0;
-  if (!anymdp_pipe_setup(h)) {
+  const int cycles = n_steps / period;
+  if (cycles <= 0 || period % 2 != 0 || n_steps < XV_ANYMDP_PIPE_GRAPH_MIN) return XV_OK;
+  if (!anymdp_pipe_setup(h) ||
+      !anymdp_pipe_graphs(h, period, stride, actions, obs, reward, reward_gt, terminated, truncated, final_obs, mode)) {
     (void)hipGetLastError();
     h->pipe_failed = true;
-    return XV_OK;      // nothing issued: the caller takes the ordinary path
+    return XV_OK;
   }
   hipStream_t st = h->eng->stream;
   const uint64_t t0 = h->eng->tick;
-  const int n_wave = xv_div_up(h->a.n_env, 256) * 4;
-  const int cycles = n_steps / period;
-  const bool graphs = cycles > 0 && period % 2 == 0 && n_steps >= XV_ANYMDP_PIPE_GRAPH_MIN &&
-                      anymdp_pipe_graphs(h, period, stride, actions, obs, reward, reward_gt, terminated, truncated, final_obs, mode);
-  bool ok = true;
-  if (!(h->hand_valid && h->hand_value == t0)) {
-    hipLaunchKernelGGL(anymdp_fill_u32_kernel, dim3(xv_div_up(n_wave, 256)), dim3(256), 0, st, h->d_hand, (uint32_t)t0, n_wave);
-    ok = hipGetLastError() == hipSuccess;
-  }
-  if (ok && graphs && !(h->ptick_valid && h->ptick_value == t0)) {
+  // every record gets the tag of the first step (whatever ran since the last overlapped call wrote the tag bits as 0)
+  hipLaunchKernelGGL(anymdp_retag_kernel, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, st, h->a.sr, h->a.n_env,
+                     XV_ANYMDP_SR_TAG(t0));
+  bool ok = hipGetLastError() == hipSuccess;
+  if (ok && !(h->ptick_valid && h->ptick_value == t0)) {
     hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick, t0);
     hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick + 1, t0);
     ok = hipGetLastError() == hipSuccess;
   }
-  // fork: the side stream starts behind what the engine's stream holds now (the caller's actions, a reset, the words above)
+  // fork: the side stream starts behind what the engine's stream holds now (the caller's actions, a reset, the tags above)
   ok = ok && hipEventRecord(h->side_ev[0], st) == hipSuccess && hipStreamWaitEvent(h->side, h->side_ev[0], 0) == hipSuccess;
   if (!ok) {
     (void)hipGetLastError();
-    h->pipe_failed = true; h->hand_valid = false; h->ptick_valid = false;
+    h->pipe_failed = true; h->ptick_valid = false;
     return XV_OK;
   }
-  h->hand_valid = false; h->ptick_valid = false;      // until the call has gone through
+  h->ptick_valid = false;      // until the cycles have gone out
   int k = 0;
   bool broken = false;
-  if (graphs) {
-    for (int c = 0; c < cycles && !broken; ++c) {
-      // both halves or neither: an even half without its odd half leaves the next even launch waiting (bounded, flagged)
-      if (hipGraphLaunch(h->pgraph_exec[0], st) != hipSuccess) break;
-      if (hipGraphLaunch(h->pgraph_exec[1], h->side) != hipSuccess) { broken = true; break; }
-      k += period;
-      h->eng->tick = t0 + (uint64_t)k;
-    }
-    if (k > 0) { h->ptick_value = h->eng->tick; h->ptick_valid = !broken; h->graph_used_last = true; }
-    if (k < cycles * period) { (void)hipGetLastError(); h->pipe_failed = true; }
+  for (int c = 0; c < cycles; ++c) {
+    // both halves or neither: an even half without its odd half leaves the next even launch waiting (bounded, flagged)
+    if (hipGraphLaunch(h->pgraph_exec[0], st) != hipSuccess) break;
+    if (hipGraphLaunch(h->pgraph_exec[1], h->side) != hipSuccess) { broken = true; break; }
+    k += period;
+    h->eng->tick = t0 + (uint64_t)k;
   }
-  for (; k < n_steps && !broken; ++k)
-    if (!anymdp_pipe_plain_step(h, (k & 1) ? h->side : st, k, period, stride, actions, obs, reward, reward_gt, terminated,
-                                truncated, final_obs, mode)) {
-      (void)hipGetLastError();
-      h->pipe_failed = true;
-      break;
-    }
+  if (k < cycles * period) { (void)hipGetLastError(); h->pipe_failed = true; }
   const bool joined = hipEventRecord(h->side_ev[1], h->side) == hipSuccess && hipStreamWaitEvent(st, h->side_ev[1], 0) == hipSuccess;
   *issued = k;
   if (broken || !joined) {
     (void)hipGetLastError();
     h->pipe_failed = true;
-    xv_set_error("xv_anymdp_step_many: an overlapped step could be issued only in part; the envs' states are undefined");
+    xv_set_error("xv_anymdp_step_many: an overlapped ring cycle could be issued only in part; the envs' states are undefined");
     return XV_ERR_HIP;
   }
-  h->hand_value = h->eng->tick; h->hand_valid = true;
-  h->pipe_used_last = k > 0;
+  if (k > 0) { h->ptick_value = h->eng->tick; h->ptick_valid = true; h->graph_used_last = true; h->pipe_used_last = true; }
   return XV_OK;
 }
 
