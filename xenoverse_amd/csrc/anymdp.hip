@@ -376,9 +376,9 @@ typedef AnyMDPCoopLineN<XV_ANYMDP_TOK_LPE, XV_ANYMDP_COOP_CONTIG != 0> AnyMDPTok
 //     depend on the env records is done first (action and reset-record loads, the transition uniform); then the wave waits
 //     until its envs' records carry this launch's tag — bits 18..31 of the record's first word = the low 14 bits of the tick
 //     of the step that may take the env next: the step before stores record and tag with ONE 8-byte agent-scope store, so
-//     the record IS the hand-off (a separate word costs a second round trip: 4.45 vs 3.x us per step).  Lane 0 polls its own
-//     record; when it is there the wave reads all 64 and checks every tag (the store of a wave is four cache lines that
-//     may land apart).  A wave depends on the same wave of the previous step only (one lane per env, anymdp_env.py:92-132 is
+//     the record IS the hand-off (a separate word costs a second round trip: 4.45 vs 3.95 us per step).  Every lane polls
+//     its own record and the wave goes on when all 64 tags are there (the store of a wave is four cache lines that may
+//     land apart).  A wave depends on the same wave of the previous step only (one lane per env, anymdp_env.py:92-132 is
 //     per env).  The wait is bounded (XV_ANYMDP_HAND_TIMEOUT of the 100-MHz wall clock): on expiry the wave goes on and
 //     sets XV_DEVERR_HANDOFF — wrong results, flagged, never a hang.
 #define XV_ANYMDP_HAND_TIMEOUT 5000000ull   // 50 ms
@@ -436,17 +436,13 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
     for (;;) {
       // records cross between the launches as agent-scope atomics (sc1: coherent over the device without cache maintenance;
       // an agent-scope release / acquire FENCE is a `buffer_wbl2` per wave: 39 us per step, profiles/r05_b_*)
-      uint32_t head = 0;
-      if (lane == 0) head = (uint32_t)__hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      head = (uint32_t)__builtin_amdgcn_readfirstlane((int)head);
-      if ((head >> XV_ANYMDP_SR_TAG_SHIFT) == want) {
-        r64 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__ballot(((uint32_t)r64 >> XV_ANYMDP_SR_TAG_SHIFT) != want) == 0ull) break;
-      }
+      // every lane polls its own record: one round trip per try (lane 0 first and then the wave costs a second one: 3.95 vs
+      // 3.x us per step); a wave has one poll in flight, 1,024 waves x 512 B per ~0.7 us is a tenth of the L2's bandwidth
+      r64 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__ballot(((uint32_t)r64 >> XV_ANYMDP_SR_TAG_SHIFT) != want) == 0ull) break;
       __builtin_amdgcn_s_sleep(1);
       if (wall_clock64() - t_begin > XV_ANYMDP_HAND_TIMEOUT) {
         err |= XV_DEVERR_HANDOFF;
-        r64 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
     }
