@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--fused", action="store_true", help="also time the fused T-step rollout kernel")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="xv_anymdp_step_many: replay ring cycles from a hipGraph (auto: only for small batches)")
+    ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
+                    help="xv_anymdp_step_many overlap mode (xv_anymdp_set_step_many_overlap): consecutive vector steps on two HIP "
+                         "streams, each wave taking its envs over from the same wave of the step before through the env records; "
+                         "auto = on (the library uses it for calls of >= 64 steps; same results)")
     ap.add_argument("--sweep-envs", default=None,
                     help="comma list of envs/GPU (e.g. 16384,32768,65536,131072,262144): time the 2a step at each size "
                          "and write --sweep-out instead of the bench line")
@@ -440,6 +444,7 @@ def main():
         # 5.19 vs 4.98 us per step on one box of the pool, 5.15 vs 5.35 on another).  `--graph off` issues plain launches
         graph_mode = args.graph if args.graph != "auto" else "on"
         env.set_step_many_graph(graph_mode)
+        env.set_step_many_overlap(args.overlap != "off" and graph_mode == "on")
         device = env.device
         g = torch.Generator(device=device)
         g.manual_seed(args.seed + 17 * rank)
@@ -503,6 +508,10 @@ def main():
                 gather_note = "all_gather unavailable: %r" % (ex,)
 
     def run(k_steps, with_gather=False):
+        if not with_gather:      # ONE call: the library replays whole ring cycles (and overlaps them when the call is long enough)
+            if k_steps > 0:
+                step_many(k_steps)
+            return
         done = 0
         while done < k_steps:
             n = min(P, k_steps - done)
@@ -569,14 +578,19 @@ def main():
     wall, ev_ms, walls = timed_pass(False, R)
     state["errs"] = env.check_errors() if env is not None else 0
     state["graph"] = 0
+    state["overlap"] = 0
     if env is not None and graph_mode == "on" and args.steps >= P and int(env.lib.xv_anymdp_step_many_graph_state(env._h)) >= 0:
         state["graph"] = 1     # whole ring cycles were replayed (a remainder shorter than the ring is plain launches)
+        state["overlap"] = 1 if env.step_many_overlap_state == 1 else 0
 
     # the other searches on the same workload (`value` above is the AUTO choice): each timed with min(R, 5) repetitions
     variants = None
     if env is not None and world == 1 and not args.no_variants and not under_profiler():   # (N = 1: no collective in here)
-        variants = {"auto_choice": search, search: {"us_per_step": ev_ms * 1e3 / args.steps, "env_steps_per_s": n_env * args.steps / wall,
-                                                    "is_value": True}}
+        def vrow(w, e, is_value):      # both clocks side by side: events (us_per_step, env_steps_per_s) and host wall (wall_*)
+            return {"us_per_step": e * 1e3 / args.steps, "env_steps_per_s": n_env * args.steps / (e * 1e-3),
+                    "wall_us_per_step": w * 1e6 / args.steps, "wall_env_steps_per_s": n_env * args.steps / w, "is_value": is_value}
+        variants = {"auto_choice": search, "clock": "us_per_step / env_steps_per_s: HIP events; wall_*: host wall (what `value` uses)",
+                    search: vrow(wall, ev_ms, True)}
         for name in ("fence", "bucket"):
             if name == search:
                 continue
@@ -591,7 +605,7 @@ def main():
                 else:
                     env.set_search("fence")
                 w, e, _ = timed_pass(False, max(1, min(R, 5)))
-                variants[name] = {"us_per_step": e * 1e3 / args.steps, "env_steps_per_s": n_env * args.steps / w, "is_value": False}
+                variants[name] = vrow(w, e, False)
             except Exception as ex:
                 variants[name] = {"error": repr(ex)}
         env.set_search("auto") if args.search == "auto" else env.set_search(args.search, n_bucket=args.buckets) \
@@ -599,6 +613,20 @@ def main():
         if census is None and env.bucket_census()["built"]:
             census = env.bucket_census()
         state["errs"] |= env.check_errors()
+        # the same search issued the other way: one stream (each launch waits for the one before) vs overlapped
+        if state.get("overlap") == 1 or args.overlap != "off":
+            try:
+                lv = {"overlapped" if state.get("overlap") == 1 else "one stream": vrow(wall, ev_ms, True)}
+                other = state.get("overlap") != 1
+                env.set_step_many_overlap(other)
+                w, e, _ = timed_pass(False, max(1, min(R, 5)))
+                took = env.step_many_overlap_state == 1
+                lv["overlapped" if took else ("one stream" if not other else "one stream (overlap not taken: short call)")] = vrow(w, e, False)
+                env.set_step_many_overlap(not other)
+                variants["launch"] = lv
+            except Exception as ex:
+                variants["launch"] = {"error": repr(ex)}
+            state["errs"] |= env.check_errors()
 
     # untimed sustained stepping: a monitor that samples the GPU every few seconds sees it busy (the timed passes are
     # milliseconds).  Excluded from `value`; `sustain_s` says how long it ran.
@@ -648,14 +676,24 @@ def main():
                            "table_gib_per_gpu": round(n_task * S * A * (1 + (S + 6) // 7) * 128 / 2**30, 2),
                            "bucket_lines_gib_per_gpu": round(bucket_gib, 2),
                            "launch": "one step kernel per vector step (xv_anymdp_step_many%s)"
-                                     % (", ring cycles of %d steps replayed from a hipGraph" % P if state.get("graph") == 1 else
-                                        ", plain launches"),
+                                     % ((", ring cycles of %d steps replayed from two hipGraphs on two HIP streams: consecutive "
+                                         "steps overlap, every wave takes its 64 envs over from the same wave of the step before "
+                                         "through the env records (xv_anymdp_set_step_many_overlap)" % P)
+                                        if state.get("overlap") == 1 else
+                                        (", ring cycles of %d steps replayed from a hipGraph" % P if state.get("graph") == 1 else
+                                         ", plain launches")),
+                           "overlap": bool(state.get("overlap")), "overlap_requested": args.overlap,
                            "search": search, "search_requested": args.search,
                            "bucket_census": None if census is None else {k: census[k] for k in (
                                "n_bucket", "cuts_per_line", "lines_dirty", "p_fallback", "fallbacks_per_launch", "auto_limit", "auto_uses_bucket")},
                            "exchange": exchange, "device_error_flags": state["errs"]},
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                             "frac": achieved / HBM_PEAK_GBS,
+                             # the same fraction on the line's own wall clock: algorithmic bytes / ms_per_step / peak (host wall
+                             # around barrier + sync; `frac` and the fields below use the HIP-event time `avg_launch_us`)
+                             "frac_wall": algo / (wall / args.steps) / 1e9 / HBM_PEAK_GBS,
+                             "clock": "HIP events on the launch stream (avg_launch_us); frac_wall: host wall (ms_per_step)",
+                             "traffic": traffic, "traffic_source": traffic_src,
                              "frac_traffic": None if traffic is None else traffic / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                              "traffic_over_algorithmic": None if traffic is None else traffic / algo,
                              # which of the fractions to read: SURVEY 8(d)'s `frac` prices the 512-byte row; a search that
@@ -670,10 +708,14 @@ def main():
                              "lines_per_s": None if lines is None else lines * n_env / (kern_us * 1e-6),
                              "random_line_rate": floor["random_lines_per_s"],
                              "frac_of_line_rate": None if lines is None else lines * n_env / (kern_us * 1e-6) / floor["random_lines_per_s"],
-                             "kernel": "anymdp_step_kernel<false, %d, false, %s, %d>  (INJECT, blocks per fence entry | "
-                                       "0 = binary search, ROLLOUT, TICKDEV, BK = 0 | bucket-line packing 1, 2)"
+                             "kernel": "anymdp_step_kernel<false, %d, false, %s, %d%s>  (INJECT, blocks per fence entry | "
+                                       "0 = binary search, ROLLOUT, TICKDEV, BK = 0 | bucket-line packing 1, 2, HAND = overlapped launches)"
                                        % (0 if search == "binary" else 1, "true" if state.get("graph") == 1 else "false",
-                                          (census or {}).get("format", 1) if search == "bucket" else 0),
+                                          (census or {}).get("format", 1) if search == "bucket" else 0,
+                                          ", true" if state.get("overlap") == 1 else ""),
+                             "avg_launch_us_note": ("overlapped launches: time per launch in steady state = timed region / launches; two "
+                                                    "launches are in flight, so a profiler's per-kernel duration (start of dispatch to end, "
+                                                    "the wait for the step before included) is ~1.7x this") if state.get("overlap") == 1 else None,
                              "kernel_source_sha16": None if selftest else kernel_source_hash(),
                              "avg_launch_us": kern_us, "algorithmic_bytes_per_launch": algo},
                 "rccl": dinfo["rccl"],
@@ -782,6 +824,7 @@ def sweep(args, torch, local):
         # ring cycles replayed from a hipGraph, as the headline run: plain launches follow the HOST's launch rate (3-5 us per
         # launch depending on the box), which is all a sweep below 65,536 envs would then show
         env.set_step_many_graph(args.graph if args.graph != "auto" else "on")
+        env.set_step_many_overlap(args.overlap != "off")
         g = torch.Generator(device=env.device)
         g.manual_seed(args.seed)
         actions = torch.randint(0, A, (P, n_env), generator=g, device=env.device, dtype=torch.int32)
@@ -828,7 +871,8 @@ def sweep(args, torch, local):
                      "frac_traffic": moved / (t * 1e-6) / 1e9 / HBM_PEAK_GBS,
                      "primary": "frac_traffic",
                      "frac_note": ("frac > 1: the search reads %d line(s) of the row, not the 512 bytes SURVEY 8(d) prices" % lines) if frac > 1 else None,
-                     "fused_rollout_us_per_step": fus, "device_error_flags": env.check_errors()})
+                     "fused_rollout_us_per_step": fus, "overlapped": env.step_many_overlap_state == 1,
+                     "device_error_flags": env.check_errors()})
         env.close()
         del tab, env, ring, actions
         torch.cuda.empty_cache()

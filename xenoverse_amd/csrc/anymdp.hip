@@ -2077,7 +2077,8 @@ static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride,
                            int mode, int* issued) {
   *issued = 0;
   const int cycles = n_steps / period;
-  if (cycles <= 0 || period % 2 != 0 || n_steps < XV_ANYMDP_PIPE_GRAPH_MIN) return XV_OK;
+  static const int min_steps = getenv("XV_ANYMDP_PIPE_MIN_STEPS") ? atoi(getenv("XV_ANYMDP_PIPE_MIN_STEPS")) : XV_ANYMDP_PIPE_GRAPH_MIN;
+  if (cycles <= 0 || period % 2 != 0 || n_steps < min_steps) return XV_OK;
   if (!anymdp_pipe_setup(h) ||
       !anymdp_pipe_graphs(h, period, stride, actions, obs, reward, reward_gt, terminated, truncated, final_obs, mode)) {
     (void)hipGetLastError();
