@@ -44,6 +44,9 @@ EXIT_WATCHDOG = 3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--workload", default="anymdp", choices=["anymdp", "mixed"],
+                    help="anymdp: BASELINE.json's metric (configs[1]); mixed: configs[4], the mixed task batch (anymdp + linds + "
+                         "metacontrol) sharded over the GPUs with the all-gather of its rollout chunks (scripts/bench_mixed.py)")
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--repeats", type=int, default=25, help="the K-step batch is timed this many times; median reported")
@@ -406,7 +409,15 @@ def main():
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline and not selftest and not args.sweep_envs \
             and not under_profiler():
-        cpu = cpu_baseline(args.cpu_seconds, args.seed, args.cpu_table_gib)      # before the GPU is touched
+        if args.workload == "mixed":
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import bench_mixed
+            try:
+                cpu = bench_mixed.cpu_baseline_mixed(args.cpu_seconds, args.seed, usable_cpus())
+            except Exception as ex:
+                cpu = {"value": None, "unit": "env-steps/s", "cores": usable_cpus(), "kind": "port", "sample": "failed: %r" % (ex,)}
+        else:
+            cpu = cpu_baseline(args.cpu_seconds, args.seed, args.cpu_table_gib)      # before the GPU is touched
 
     import torch
     if os.environ.get("XV_BENCH_SHARE_GPU"):   # functional test of the N>1 path on a 1-GPU box (not a measurement)
@@ -420,6 +431,24 @@ def main():
 
     if args.sweep_envs:
         return sweep(args, torch, local)
+
+    if args.workload == "mixed":      # BASELINE configs[4] end to end on `world` ranks: its own line
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import bench_mixed
+        out = bench_mixed.run_mixed(args, torch, dist, dinfo, rank, world, local, wd, selftest=selftest)
+        out["cpu_baseline"] = cpu if world == 1 else None
+        if selftest:
+            out["ranks_seen"] = dinfo.get("ranks_seen")
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            wd.arm("final barrier")
+            dist.barrier()
+            dist.destroy_process_group()
+            wd.cancel()
+        if selftest and rank == 0 and out.get("selftest") != "ok":
+            sys.exit(1)
+        return
 
     from xenoverse_amd.distributed import REC_BYTES, RolloutGather, pack_records, unpack_records
     n_env = args.envs
@@ -771,6 +800,16 @@ def main():
             state["families"] = bench_families.quick_families()
         except Exception as ex:
             state["families"] = {"error": repr(ex)}
+
+    if world > 1 and env is not None and not args.no_families and not selftest:
+        # N > 1: BASELINE configs[4] on the same ranks (the N = 1 line carries one GPU's share as `families.mixed_share`)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import bench_mixed
+            margs = argparse.Namespace(**dict(vars(args), steps=max(args.steps, 64), repeats=max(1, min(R, 5))))
+            state["families"] = {"mixed": bench_mixed.run_mixed(margs, torch, dist, dinfo, rank, world, local, wd)}
+        except Exception as ex:
+            state["families"] = {"mixed": {"error": repr(ex)}}
 
     if gather is not None:      # pass 2 (N > 1): every finished rollout chunk all-gathered to all ranks, overlapped
         wd.emit = report

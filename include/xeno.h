@@ -133,6 +133,14 @@ int xv_pack_rollout(void* hip_stream, size_t n, const int32_t* obs, const int32_
                     const uint8_t* terminated, const uint8_t* truncated, uint64_t* out);
 int xv_unpack_rollout(void* hip_stream, size_t n, const uint64_t* rec, int32_t* obs, int32_t* action, float* reward,
                       uint8_t* terminated, uint8_t* truncated);
+/* The same for the families whose observation is a float vector (ABI 10; the mixed batch of BASELINE config 5 gathers all
+ * three families): one env-step = obs_dim + 2 32-bit words — obs_dim fp32 observation values (LinDS: the 16 padded outputs
+ * linds_env.py:83-91 returns; CartPole: the 4 state values of random_cartpole.py:52-61), the reward (fp32 bits), and a flag
+ * word: bit 0 terminated, bit 1 truncated, bits 8-31 the discrete action (`action` nullable: 0).  n records. */
+int xv_pack_rollout_f32(void* hip_stream, size_t n, int obs_dim, const float* obs, const float* reward,
+                        const uint8_t* terminated, const uint8_t* truncated, const int32_t* action, uint32_t* out);
+int xv_unpack_rollout_f32(void* hip_stream, size_t n, int obs_dim, const uint32_t* rec, float* obs, float* reward,
+                          uint8_t* terminated, uint8_t* truncated, int32_t* action);
 
 /* The all-gather of finished rollout chunks over RCCL directly (no torch.distributed needed):
  * every rank contributes `bytes_per_rank` bytes at `local` and receives all ranks' chunks, rank-major, at `global`

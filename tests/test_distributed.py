@@ -8,8 +8,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from xenoverse_amd.distributed import (REC_BYTES, RolloutGather, pack_records, shard_env_task, shard_range,
-                                       unpack_records)
+from xenoverse_amd.distributed import (REC_BYTES, MixedChunk, RolloutGather, pack_records, pack_records_f32, shard_env_task,
+                                       shard_range, unpack_records, unpack_records_f32)
 
 
 def test_shard_range_partitions_exactly():
@@ -49,6 +49,55 @@ def test_record_packing_roundtrip():
     assert torch.equal(te2, te) and torch.equal(tr2, tr)
 
 
+def test_float_record_packing_roundtrip():
+    """LinDS / CartPole records: D fp32 observation words + reward + flag word (terminated, truncated, action)"""
+    g = torch.Generator().manual_seed(3)
+    for D, with_action in ((16, False), (4, True)):
+        T, N = 5, 37
+        obs = torch.randn((T, N, D), generator=g)
+        obs[0, 0, 0] = float("inf"); obs[1, 2, 1] = -0.0
+        rew = torch.randn((T, N), generator=g)
+        te = (torch.rand((T, N), generator=g) < 0.3).to(torch.uint8)
+        tr = (torch.rand((T, N), generator=g) < 0.3).to(torch.uint8)
+        act = torch.randint(0, 1 << 24, (T, N), generator=g, dtype=torch.int32) if with_action else None
+        rec = pack_records_f32(obs, rew, te, tr, act)
+        assert rec.shape == (T, N, 4 * (D + 2)) and rec.dtype == torch.uint8
+        out = unpack_records_f32(rec, D, with_action=with_action)
+        assert torch.equal(out[0].view(torch.int32), obs.view(torch.int32)) and torch.equal(out[1], rew)
+        assert torch.equal(out[2], te) and torch.equal(out[3], tr)
+        if with_action:
+            assert torch.equal(out[4], act)
+
+
+@pytest.mark.parametrize("world,tot", [(8, (131072, 65536, 65536)), (2, (1024, 512, 520)), (3, (200, 100, 50))])
+def test_mixed_chunk_layout_and_pack_unpack(world, tot):
+    """config 5's chunk: three record blocks per rank, padded to the largest share; packing every rank's share and
+    unpacking the concatenation gives back the unsharded families in global env order"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import bench_mixed
+    T = 3
+    if tot[0] > 4096:       # the real sizes: layout arithmetic only
+        ch = MixedChunk(32, *tot, world)
+        assert ch.bytes_per_rank == 32 * (16384 * 8 + 8192 * 72 + 8192 * 24) == 29360128
+        assert all(ch.n_local("anymdp", r) == 16384 and ch.share["linds"][r] == (8192 * r, 8192 * (r + 1)) for r in range(world))
+        return
+    ch = MixedChunk(T, *tot, world)
+    assert ch.bytes_per_rank % 16 == 0
+    gathered = torch.zeros((world, ch.bytes_per_rank), dtype=torch.uint8)
+    for r in range(world):
+        fab = bench_mixed.fabricate(torch, ch, T, {f: ch.share[f][r] for f in ch.rec})
+        ch.pack(r, fab, gathered[r])
+    got = ch.unpack(gathered)
+    ref = bench_mixed.fabricate(torch, ch, T, {"anymdp": (0, tot[0]), "linds": (0, tot[1]), "cartpole": (0, tot[2])})
+    for j, k in enumerate(("obs", "action", "reward", "terminated", "truncated")):
+        assert torch.equal(got["anymdp"][j], ref["anymdp"][k]), k
+    for j, k in enumerate(("obs", "reward", "terminated", "truncated")):
+        assert torch.equal(got["linds"][j], ref["linds"][k]), k
+    for j, k in enumerate(("obs", "reward", "terminated", "truncated", "action")):
+        assert torch.equal(got["cartpole"][j], ref["cartpole"][k]), k
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -84,6 +133,12 @@ def _worker(rank, world, port, n_total, T, q):
                   and torch.equal(a2, (gid_all[None, :] + torch.arange(T, dtype=torch.int32)[:, None]) % 8)
                   and torch.equal(r2, gid_all[None, :].float() * 0.5 + torch.arange(T)[:, None].float())
                   and torch.equal(te2, ((gid_all[None, :] + torch.arange(T, dtype=torch.int32)[:, None]) % 5 == 0).to(torch.uint8)))
+        # the store that carries a RCCL unique id: the process group's own (no second port is opened)
+        from xenoverse_amd.distributed import _rendezvous_store
+        st = _rendezvous_store(rank, world, None, None, None, 30)
+        if rank == 0:
+            st.set("id_test", b"\x07" * 128)
+        ok = ok and bytes(st.get("id_test")) == b"\x07" * 128
         # max-over-ranks timing reduction used by bench.py
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -139,6 +194,20 @@ def test_bench_py_two_ranks_end_to_end_on_gloo():
     assert "families" not in d
     assert d["allgather_timeout"] is False and d["rccl"] is False and d["with_allgather"]["value"] > 0
     assert d["value"] is None and "NOT a measurement" in d["mode"] and d["cpu_baseline"] is None
+
+
+@pytest.mark.timeout(300)
+def test_bench_py_mixed_workload_two_ranks_on_gloo():
+    """bench.py --workload mixed --gpus 2 (BASELINE configs[4]): sharding of the three families, chunk layout, pack ->
+    all-gather -> unpack of all three record formats, checked against the fabricated global batch on every rank"""
+    r, out = _run_bench_selftest({}, ["--workload", "mixed"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(out) == 1
+    d = out[0]
+    assert d["n_gpus"] == 2 and d["selftest"] == "ok" and d["ranks_seen"] == 2
+    assert d["config"]["envs_total"] == {"anymdp": 32768, "linds": 16384, "cartpole": 16384}
+    assert d["config"]["chunk_bytes_per_rank"] == 29360128 and d["transport"] == "torch"
+    assert d["with_allgather"]["gathered_slice_equals_local_rings"] == "ok" and d["value"] is None
 
 
 @pytest.mark.timeout(300)

@@ -198,3 +198,42 @@ def test_step_fused_falls_back_to_three_launches_without_touching_the_buffers():
     for a, b in zip(*res):
         for k in "alc":
             assert np.array_equal(a[k][0], b[k][0]) and np.array_equal(a[k][1], b[k][1])
+
+
+@pytest.mark.parametrize("dev_tick", [False, True])
+def test_fused_mixed_step_with_one_shared_engine_equals_three_separate_steps(dev_tick):
+    """handles that SHARE an engine (one tick word): xv_mixed_step must hand the families the ticks T, T + 1, T + 2 that
+    three separate step calls take — also with the tick in device memory, where one advance per call used to give all three
+    the same tick"""
+    from xenoverse_amd.engine import Engine
+    res = []
+    for fused in (False, True):
+        eng = Engine("cuda:0", seed=5)
+        mb = MixedBatch("cuda:0", seed=5)
+        mb.envs = {"a": AnyMDPVecEnv(512, engine=eng), "l": LinDSVecEnv(256, engine=eng),
+                   "c": CartPoleVecEnv(256, frameskip=1, engine=eng)}
+        mb.streams = {k: eng.torch_stream for k in mb.envs}
+        mb.envs["a"].set_task(_anymdp_tables(8))
+        mb.envs["l"].set_task([LinearDSSampler(16, 8, 8, seed=k) for k in range(4)])
+        mb.envs["c"].set_task([sample_cartpole(seed=k) for k in range(256)])
+        if dev_tick:
+            eng.set_device_tick(True)
+        obs = {k: e.reset()[0] for k, e in mb.envs.items()}
+        rec = []
+        for t in range(12):
+            acts = {"a": _pol_a(obs["a"]), "l": _pol_l(obs["l"]), "c": _pol_c(obs["c"])}
+            if fused:
+                out = mb.step_fused(acts)
+            else:
+                out = {k: mb.envs[k].step(acts[k]) for k in "alc"}      # anymdp, linds, cartpole: the order of the fused call
+            obs = {k: v[0] for k, v in out.items()}
+            rec.append({k: (_np(out[k][0]), _np(out[k][1]), _np(out[k][2])) for k in "alc"})
+        assert eng.tick == 3 + 3 * 12
+        res.append(rec)
+        for e in mb.envs.values():
+            e.close()
+        eng.close()
+    for a, b in zip(*res):
+        for k in "alc":
+            for x, y in zip(a[k], b[k]):
+                assert np.array_equal(x, y), k

@@ -1,0 +1,93 @@
+"""BASELINE configs[4] across ranks (scaled down, one GPU): every rank's share of the mixed batch, stepped on its own and
+exchanged through the chunk format, reproduces its slice of the UNSHARDED batch bit for bit — the property that lets the
+8-GPU run be correct by construction (env_id_base = the share's start, tasks named by global index)."""
+import numpy as np
+import pytest
+import torch
+
+from xenoverse_amd.distributed import MixedChunk, RolloutGather, pack_records_f32, unpack_records_f32
+from xenoverse_amd.mixed_shard import MixedShare
+
+pytestmark = pytest.mark.gpu
+
+A_KEYS = ("obs", "action", "reward", "terminated", "truncated")
+L_KEYS = ("obs", "reward", "terminated", "truncated")
+C_KEYS = ("obs", "reward", "terminated", "truncated", "action")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _run_share(rank, world, tot, T, n_steps, acts, seed=11):
+    sh = MixedShare(rank, world, *tot, T=T, seed=seed, linds_ns=16)
+    lo = sh.lo
+    sh.set_actions(acts["a"][:, lo["anymdp"]:lo["anymdp"] + sh.n["anymdp"]],
+                   acts["l"][:, lo["linds"]:lo["linds"] + sh.n["linds"]],
+                   acts["c"][:, lo["cartpole"]:lo["cartpole"] + sh.n["cartpole"]])
+    sh.reset()
+    sh.step_many(n_steps)
+    torch.cuda.synchronize()
+    assert sh.check_errors() == 0
+    return sh
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_rank_shares_exchange_to_the_unsharded_batch(world):
+    tot, T, n_steps = (2048, 1024, 1024), 8, 19            # 19 steps: the ring holds steps 11 .. 18 (slots of k % 8)
+    rng = np.random.RandomState(3)
+    acts = dict(a=rng.randint(0, 8, (T, tot[0])).astype(np.int32), l=rng.uniform(-1.2, 1.2, (T, tot[1], 8)).astype(np.float32),
+                c=rng.randint(0, 2, (T, tot[2])).astype(np.int32))
+    whole = _run_share(0, 1, tot, T, n_steps, acts)
+    assert whole.fused
+    ref = {f: {k: v.clone() for k, v in d.items()} for f, d in whole.rings_for_pack().items()}
+    whole.close()
+    chunk = MixedChunk(T, *tot, world)
+    gathered = torch.zeros((world, chunk.bytes_per_rank), dtype=torch.uint8, device="cuda")
+    for r in range(world):
+        sh = _run_share(r, world, tot, T, n_steps, acts)
+        assert sh.chunk.bytes_per_rank == chunk.bytes_per_rank
+        # the rank's own rings are its slice of the unsharded ones
+        mine = sh.rings_for_pack()
+        for f in ("anymdp", "linds", "cartpole"):
+            lo, hi = chunk.share[f][r]
+            for k, v in mine[f].items():
+                assert torch.equal(v, ref[f][k][:, lo:hi]), (f, k, r)
+        # pack (HIP kernels) and send through the C-ABI's collective on a one-rank communicator (what one GPU can host)
+        g = RolloutGather((chunk.bytes_per_rank,), device="cuda", transport="rccl", rank=0, world=1)
+        sh.pack(g.local)
+        g.launch()
+        gathered[r].copy_(g.wait()[0])
+        torch.cuda.synchronize()
+        g.close()
+        sh.close()
+    got = chunk.unpack(gathered)
+    for f, keys in (("anymdp", A_KEYS), ("linds", L_KEYS), ("cartpole", C_KEYS)):
+        for j, k in enumerate(keys):
+            assert torch.equal(got[f][j], ref[f][k]), (f, k)
+    assert int(ref["anymdp"]["terminated"].sum()) > 100 and int(ref["cartpole"]["terminated"].sum()) > 50
+
+
+def test_device_float_records_match_the_host_format():
+    """xv_pack_rollout_f32 / xv_unpack_rollout_f32: the same bits as the torch (CPU) packer, both record widths"""
+    g = torch.Generator().manual_seed(2)
+    for D, with_action in ((16, False), (4, True)):
+        T, N = 7, 1001
+        obs = torch.randn((T, N, D), generator=g)
+        rew = torch.randn((T, N), generator=g)
+        te = (torch.rand((T, N), generator=g) < 0.3).to(torch.uint8)
+        tr = (torch.rand((T, N), generator=g) < 0.3).to(torch.uint8)
+        act = torch.randint(0, 1 << 24, (T, N), generator=g, dtype=torch.int32) if with_action else None
+        host = pack_records_f32(obs, rew, te, tr, act)
+        dev = pack_records_f32(obs.cuda(), rew.cuda(), te.cuda(), tr.cuda(), None if act is None else act.cuda())
+        assert torch.equal(dev.cpu(), host)
+        out = unpack_records_f32(dev, D, with_action=with_action)
+        assert torch.equal(out[0].cpu(), obs) and torch.equal(out[1].cpu(), rew)
+        assert torch.equal(out[2].cpu(), te) and torch.equal(out[3].cpu(), tr)
+        if with_action:
+            assert torch.equal(out[4].cpu(), act)
+
+
+def test_shares_must_be_whole_tasks():
+    with pytest.raises(ValueError):
+        MixedShare(0, 3, 2048, 1024, 1024, T=4)          # 2048 / 3 is not a multiple of 64

@@ -18,6 +18,8 @@ SIGNATURES = {
     "xv_abi_version": [],
     "xv_pack_rollout": [c_void_p, C.c_size_t] + [c_void_p] * 6,
     "xv_unpack_rollout": [c_void_p, C.c_size_t] + [c_void_p] * 6,
+    "xv_pack_rollout_f32": [c_void_p, C.c_size_t, c_int] + [c_void_p] * 6,
+    "xv_unpack_rollout_f32": [c_void_p, C.c_size_t, c_int] + [c_void_p] * 6,
     "xv_last_error": [],
     "xv_rccl_unique_id": [c_void_p],
     "xv_rccl_comm_create": [c_void_p, c_int, c_int, c_void_p, C.POINTER(c_void_p)],
@@ -148,7 +150,10 @@ class BucketCensus(C.Structure):
 
 
 class XenoError(RuntimeError):
-    pass
+    code = 0      # the XV_ERR_* value check() saw (include/xeno.h)
+
+
+XV_ERR_INVALID, XV_ERR_HIP, XV_ERR_UNSUPPORTED, XV_ERR_NOMEM = -1, -2, -3, -4
 
 
 ABI_VERSION = 10     # include/xeno.h XV_ABI_VERSION
@@ -178,7 +183,9 @@ def load():
 def check(rc):
     if rc != 0:
         msg = load().xv_last_error()
-        raise XenoError("libxeno_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+        err = XenoError("libxeno_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+        err.code = int(rc)
+        raise err
 
 
 def ptr(t):

@@ -149,14 +149,20 @@ class AnyMDPVecEnv(VectorEnv):
         if self.bucket_lines != "off":      # memory for speed, within a small budget unless the caller named a bucket count
             nb = 16 if self.bucket_lines == "auto" else int(self.bucket_lines)
             budget = self.AUTO_BUCKET_BYTES
-            if self.bucket_lines == "auto" and n_task * S * A * nb * 128 > budget:
+            # transition lines + the observation lines a POMDP / multi-token task adds beside them (same 128-byte lines)
+            need = n_task * S * A * nb * 128 + (n_task * self._tok[0] * S * nb * 128 if self._tok is not None else 0)
+            if self.bucket_lines == "auto" and need > budget:
                 free, _ = torch.cuda.mem_get_info(self.device)
                 budget = max(budget, min(self.AUTO_BUCKET_CAP, int(free * self.AUTO_BUCKET_SHARE)))
-            if self.bucket_lines != "auto" or n_task * S * A * nb * 128 <= budget:
+            self.bucket_budget = {"bytes_needed": need, "budget": budget, "within": self.bucket_lines != "auto" or need <= budget}
+            if self.bucket_budget["within"]:
                 try:
                     self.set_search("auto", n_bucket=nb)
-                except _lib.XenoError:      # tables the fence layout does not serve (s0_max > 4, ...): the per-lane search
-                    pass
+                except _lib.XenoError as ex:
+                    # tables the fence layout does not serve (s0_max > 4, ...): the per-lane search.  Anything else — a HIP
+                    # error, no memory — is the caller's to see
+                    if ex.code != _lib.XV_ERR_UNSUPPORTED:
+                        raise
 
     def _make_buffers(self):
         """spaces for the task type and the output buffers step() / reset() write (set_task, and a view made by split())"""

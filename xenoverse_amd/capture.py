@@ -32,8 +32,17 @@ class CapturedLoop(object):
         self.device = torch.device(device if device is not None else self.engines[0].device)
         self.unroll = int(unroll)
         self._hold = hold
-        if hold is not None:
-            hold(True)
+        self.graph = None
+        self._tick_was = [e.device_tick for e in self.engines]      # restored by close()
+        try:
+            self._build(step_fn, policy_fn, obs, warmup)
+        except Exception:
+            self.close()      # a failed construction leaves the env as it found it: output sets alternate, infos complete, host tick
+            raise
+
+    def _build(self, step_fn, policy_fn, obs, warmup):
+        if self._hold is not None:
+            self._hold(True)
         for e in self.engines:
             e.set_device_tick(True)
         out = None
@@ -87,7 +96,16 @@ class CapturedLoop(object):
         return self.out
 
     def close(self):
+        """drops the graph, releases the env's hold and puts every engine's tick back where the loop found it (host tick:
+        eager launches then pay no tick kernel and step_many may replay its graphs again)"""
         self.graph = None
         if self._hold is not None:
             self._hold(False)
             self._hold = None
+        for e, was in zip(self.engines, getattr(self, "_tick_was", [])):
+            try:
+                if not was and e.handle is not None and e.device_tick:
+                    e.set_device_tick(False)
+            except Exception:
+                pass
+        self._tick_was = []

@@ -1228,19 +1228,21 @@ extern "C" int xv_anymdp_sample_tasks(xv_engine* e, uint64_t seed, int64_t cand_
       return XV_ERR_NOMEM;
     }
     const size_t lds = sizeof(double) * ((size_t)n_rb * 64 + 6 * (size_t)S + 16) + sizeof(int) * 3 * (size_t)S;
+    hipError_t attr = hipSuccess;      // a failed attribute call must not leave with the scratch allocated
 #define XSB_LAUNCH(R_)                                                                                              \
   do {                                                                                                              \
     if (lds > 48 * 1024)                                                                                            \
-      XV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&anymdp_sampler_big_kernel<R_>),                    \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
-    hipLaunchKernelGGL(anymdp_sampler_big_kernel<R_>, dim3(n_cand), dim3(threads), lds, e->stream, P, X);           \
+      attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&anymdp_sampler_big_kernel<R_>),                     \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+    if (attr == hipSuccess)                                                                                         \
+      hipLaunchKernelGGL(anymdp_sampler_big_kernel<R_>, dim3(n_cand), dim3(threads), lds, e->stream, P, X);         \
   } while (0)
     if (R == 1) XSB_LAUNCH(1);
     else if (R == 2) XSB_LAUNCH(2);
     else if (R == 3) XSB_LAUNCH(3);
     else XSB_LAUNCH(4);
 #undef XSB_LAUNCH
-    const hipError_t le = hipGetLastError();
+    const hipError_t le = attr != hipSuccess ? attr : hipGetLastError();
     (void)hipFreeAsync(X.Tt, e->stream);
     (void)hipFreeAsync(X.Pm, e->stream);
     if (le != hipSuccess) {

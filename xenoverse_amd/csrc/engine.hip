@@ -93,22 +93,40 @@ extern "C" int xv_engine_error_flags(xv_engine* e, int clear, uint32_t* out_flag
 static __global__ void xv_tick_set_kernel(uint64_t* t, uint64_t v) { *t = v; }
 static __global__ void xv_tick_add_kernel(uint64_t* t, uint64_t dv) { *t += dv; }
 
+// (no launch check of its own: the family's launch follows at once and its XV_LAUNCH_CHECK reads the same sticky error)
 void xv_engine_advance_device_tick(xv_engine* e, uint64_t ticks) {
   hipLaunchKernelGGL(xv_tick_add_kernel, dim3(1), dim3(1), 0, e->stream, e->d_tick, ticks);
 }
 
-static __global__ void xv_tick_add3_kernel(uint64_t* t0, uint64_t* t1, uint64_t* t2, uint64_t dv) {
-  *t0 += dv;
-  if (t1 != t0) *t1 += dv;
-  if (t2 != t0 && t2 != t1) *t2 += dv;
+// d0, d1, d2: what each word advances by (a word shared by several handles is advanced once, by the ticks all of them consume)
+static __global__ void xv_tick_add3_kernel(uint64_t* t0, uint64_t* t1, uint64_t* t2, uint64_t d0, uint64_t d1, uint64_t d2) {
+  *t0 += d0;
+  if (t1 != t0) *t1 += d1;
+  if (t2 != t0 && t2 != t1) *t2 += d2;
 }
-void xv_engine_advance_device_tick3(xv_engine* e0, xv_engine* e1, xv_engine* e2, uint64_t ticks) {
-  hipLaunchKernelGGL(xv_tick_add3_kernel, dim3(1), dim3(1), 0, e0->stream, e0->d_tick, e1->d_tick, e2->d_tick, ticks);
+void xv_engine_advance_device_tick3(xv_engine* e0, xv_engine* e1, xv_engine* e2, uint64_t d0, uint64_t d1, uint64_t d2) {
+  hipLaunchKernelGGL(xv_tick_add3_kernel, dim3(1), dim3(1), 0, e0->stream, e0->d_tick, e1->d_tick, e2->d_tick, d0, d1, d2);
+}
+
+// a tick batch is open between (e, 1) and (e, 0): launches inside it read word + pending, so reading or overwriting the
+// word there would be off by the pending ticks
+static int xv_engine_no_open_batch(const xv_engine* e, const char* fn) {
+  if (e->dev_tick && e->tick_batch) {
+    xv_set_error("%s: not while a tick batch is open (xv_engine_tick_batch(e, 0) first)", fn);
+    return XV_ERR_UNSUPPORTED;
+  }
+  return XV_OK;
 }
 
 extern "C" int xv_engine_get_tick(xv_engine* e, uint64_t* out_tick) {
   XV_CHECK_ARG(e != nullptr && out_tick != nullptr);
+  if (const int rc = xv_engine_no_open_batch(e, __func__)) return rc;
   if (e->dev_tick) {   // the device word is the truth (graph replays advance it without the host); synchronises
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(e->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+      xv_set_error("xv_engine_get_tick: the engine's stream is capturing; the device tick cannot be read back now");
+      return XV_ERR_UNSUPPORTED;
+    }
     XV_HIP(hipMemcpyAsync(&e->tick, e->d_tick, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
     XV_HIP(hipStreamSynchronize(e->stream));
   }
@@ -117,6 +135,7 @@ extern "C" int xv_engine_get_tick(xv_engine* e, uint64_t* out_tick) {
 }
 extern "C" int xv_engine_set_tick(xv_engine* e, uint64_t tick) {
   XV_CHECK_ARG(e != nullptr);
+  if (const int rc = xv_engine_no_open_batch(e, __func__)) return rc;
   e->tick = tick;
   if (e->dev_tick) {
     hipLaunchKernelGGL(xv_tick_set_kernel, dim3(1), dim3(1), 0, e->stream, e->d_tick, tick);
@@ -172,6 +191,14 @@ extern "C" int xv_engine_set_stream(xv_engine* e, void* hip_stream) {
   if (e->own_stream) {
     xv_set_error("xv_engine_set_stream: this engine owns its stream");
     return XV_ERR_UNSUPPORTED;
+  }
+  if (hip_stream != nullptr) {      // (the null stream belongs to whatever device is current: nothing to check)
+    hipDevice_t dev = -1;
+    if (hipStreamGetDevice((hipStream_t)hip_stream, &dev) == hipSuccess && (int)dev != e->device) {
+      xv_set_error("xv_engine_set_stream: the stream belongs to device %d, the engine to device %d", (int)dev, e->device);
+      return XV_ERR_INVALID;
+    }
+    (void)hipGetLastError();
   }
   e->stream = (hipStream_t)hip_stream;
   return XV_OK;
@@ -264,6 +291,68 @@ extern "C" int xv_unpack_rollout(void* hip_stream, size_t n, const uint64_t* rec
   XV_CHECK_ARG((n + 255) / 256 < 0x7FFFFFFFull);
   hipLaunchKernelGGL(xv_unpack_rollout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, n,
                      rec, obs, action, reward, terminated, truncated);
+  XV_LAUNCH_CHECK();
+  return XV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rollout records of the float-observation families (config 5: LinDS, CartPole): one env-step = D + 2 32-bit words
+//   words 0..D-1 observation (fp32; LinDS D = 16 padded, linds_env.py:83-91; CartPole D = 4, random_cartpole.py:52-61)
+//   word D       reward (fp32 bits)
+//   word D + 1   bit 0 terminated | bit 1 truncated | bits 8..31 the discrete action (CartPole; 0 when `action` is null)
+// One thread per word: the record stream is written / read fully coalesced, the per-field arrays nearly so.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xv_pack_rollout_f32_kernel(size_t n_words, int D, const float* obs, const float* reward,
+                                                                  const uint8_t* terminated, const uint8_t* truncated,
+                                                                  const int32_t* action, uint32_t* out) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_words) return;
+  const size_t r = idx / (size_t)(D + 2);
+  const int w = (int)(idx - r * (size_t)(D + 2));
+  uint32_t v;
+  if (w < D) v = __float_as_uint(obs[r * (size_t)D + w]);
+  else if (w == D) v = __float_as_uint(reward[r]);
+  else v = (terminated[r] ? 1u : 0u) | (truncated[r] ? 2u : 0u) | (action ? ((uint32_t)action[r] << 8) : 0u);
+  out[idx] = v;
+}
+
+__global__ __launch_bounds__(256) void xv_unpack_rollout_f32_kernel(size_t n_words, int D, const uint32_t* rec, float* obs,
+                                                                    float* reward, uint8_t* terminated, uint8_t* truncated,
+                                                                    int32_t* action) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_words) return;
+  const size_t r = idx / (size_t)(D + 2);
+  const int w = (int)(idx - r * (size_t)(D + 2));
+  const uint32_t v = rec[idx];
+  if (w < D) obs[r * (size_t)D + w] = __uint_as_float(v);
+  else if (w == D) reward[r] = __uint_as_float(v);
+  else {
+    terminated[r] = (uint8_t)(v & 1u);
+    truncated[r] = (uint8_t)((v >> 1) & 1u);
+    if (action) action[r] = (int32_t)(v >> 8);
+  }
+}
+
+extern "C" int xv_pack_rollout_f32(void* hip_stream, size_t n, int obs_dim, const float* obs, const float* reward,
+                                   const uint8_t* terminated, const uint8_t* truncated, const int32_t* action, uint32_t* out) {
+  XV_CHECK_ARG(obs && reward && terminated && truncated && out && obs_dim >= 1 && obs_dim <= 4096);
+  if (n == 0) return XV_OK;
+  const size_t nw = n * (size_t)(obs_dim + 2);
+  XV_CHECK_ARG((nw + 255) / 256 < 0x7FFFFFFFull);
+  hipLaunchKernelGGL(xv_pack_rollout_f32_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, nw,
+                     obs_dim, obs, reward, terminated, truncated, action, out);
+  XV_LAUNCH_CHECK();
+  return XV_OK;
+}
+
+extern "C" int xv_unpack_rollout_f32(void* hip_stream, size_t n, int obs_dim, const uint32_t* rec, float* obs, float* reward,
+                                     uint8_t* terminated, uint8_t* truncated, int32_t* action) {
+  XV_CHECK_ARG(rec && obs && reward && terminated && truncated && obs_dim >= 1 && obs_dim <= 4096);
+  if (n == 0) return XV_OK;
+  const size_t nw = n * (size_t)(obs_dim + 2);
+  XV_CHECK_ARG((nw + 255) / 256 < 0x7FFFFFFFull);
+  hipLaunchKernelGGL(xv_unpack_rollout_f32_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, nw,
+                     obs_dim, rec, obs, reward, terminated, truncated, action);
   XV_LAUNCH_CHECK();
   return XV_OK;
 }

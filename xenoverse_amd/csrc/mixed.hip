@@ -75,10 +75,26 @@ extern "C" int xv_mixed_step(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv
     xv_set_error("xv_mixed_step: the three engines must open and close their tick batches together (xv_engine_tick_batch)");
     return XV_ERR_INVALID;
   }
-  if (dev3 && !a->eng->tick_batch) xv_engine_advance_device_tick3(a->eng, l->eng, c->eng, 1);
+  // handles may SHARE an engine: the shared tick word then advances once per handle that uses it, and the handles read
+  // consecutive ticks off it (T, T + 1, T + 2 in the order anymdp, linds, cartpole) — what three separate step calls, the
+  // host tick and a tick batch all give.  (One advance for a shared word handed the three families the same tick.)
+  xv_engine* const E[3] = {a->eng, l->eng, c->eng};
+  uint64_t n_tot[3], n_before[3];
+  for (int i = 0; i < 3; ++i) {
+    n_tot[i] = n_before[i] = 0;
+    for (int j = 0; j < 3; ++j) {
+      if (E[j] == E[i]) { n_tot[i] += 1; if (j < i) n_before[i] += 1; }
+    }
+  }
+  if (dev3 && !a->eng->tick_batch) xv_engine_advance_device_tick3(a->eng, l->eng, c->eng, n_tot[0], n_tot[1], n_tot[2]);
   anymdp_bind_rng(a, 1, !dev3);
   linds_bind_rng(l, 1, !dev3);
   cartpole_bind_rng(c, 1, !dev3);
+  if (dev3 && !a->eng->tick_batch) {      // relative to the advanced word: -n, -n + 1, ... for the handles that share it
+    a->a.tick = (uint64_t)0 - n_tot[0] + n_before[0];
+    l->a.tick = (uint64_t)0 - n_tot[1] + n_before[1];
+    c->a.tick = (uint64_t)0 - n_tot[2] + n_before[2];
+  }
   AnyMDPStepIO aio{io->a_action, nullptr, nullptr, nullptr, io->a_obs, io->a_reward, io->a_reward_gt, io->a_terminated,
                    io->a_truncated, io->a_final_obs, nullptr, nullptr, 0.0f};
   LinDSStepIO lio{io->l_action, nullptr, nullptr, io->l_obs, io->l_reward, io->l_terminated, io->l_truncated, io->l_cmd,

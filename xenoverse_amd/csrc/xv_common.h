@@ -61,7 +61,8 @@ static inline int xv_div_up(int a, int b) { return (a + b - 1) / b; }
 // the launch reads *d_tick + (0 - ticks) — so that every entry point stays "bind, then launch" and a replayed graph
 // draws fresh numbers at every replay.  Kernels evaluate xv_launch_tick(P.tick, P.tick_dev).
 void xv_engine_advance_device_tick(xv_engine* e, uint64_t ticks);
-void xv_engine_advance_device_tick3(xv_engine* e0, xv_engine* e1, xv_engine* e2, uint64_t ticks);   // one launch (mixed batch)
+void xv_engine_advance_device_tick3(xv_engine* e0, xv_engine* e1, xv_engine* e2, uint64_t d0, uint64_t d1,
+                                    uint64_t d2);   // one launch (mixed batch): per-word increments
 struct XvTickBind {
   uint64_t tick;
   const uint64_t* tick_dev;

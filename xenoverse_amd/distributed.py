@@ -77,14 +77,171 @@ def unpack_records(rec):
     return obs, act, rew, te, tr
 
 
-class RcclComm(object):
-    """A RCCL communicator made through the C-ABI (xv_rccl_*), without torch.distributed: rank 0 creates the 128-byte
-    unique id, a `torch.distributed.TCPStore` (plain key-value rendezvous, no process group) carries it to the others.
-    rank / world / address default to the launcher's environment (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT + 1)."""
+def pack_records_f32(obs, reward, terminated, truncated, action=None, out=None):
+    """Float-observation families (LinDS, CartPole): obs float32 [T, N, D], reward float32 [T, N], terminated / truncated uint8
+    [T, N], action int32 [T, N] or None -> uint8 [T, N, 4 (D + 2)]: D fp32 observation words, the reward, a flag word (bit 0
+    terminated, bit 1 truncated, bits 8-31 the discrete action).  Device tensors: one HIP kernel (xv_pack_rollout_f32, a
+    thread per 32-bit word); CPU tensors (the gloo tests of the N > 1 path): torch integer ops."""
+    T, N, D = obs.shape
+    if out is None:
+        out = torch.empty((T, N, 4 * (D + 2)), dtype=torch.uint8, device=obs.device)
+    assert out.is_contiguous() and out.numel() == T * N * 4 * (D + 2)
+    if obs.is_cuda:
+        from . import _lib
+        lib = _lib.load()
+        args = [obs.contiguous(), reward.contiguous(), terminated.contiguous(), truncated.contiguous(),
+                None if action is None else action.contiguous()]
+        st = torch.cuda.current_stream(obs.device).cuda_stream
+        _lib.check(lib.xv_pack_rollout_f32(st, T * N, D, *[_lib.ptr(a) for a in args], _lib.ptr(out)))
+        return out
+    w = torch.empty((T, N, D + 2), dtype=torch.int32)
+    w[..., :D] = obs.contiguous().view(torch.int32)
+    w[..., D] = reward.contiguous().view(torch.int32)
+    flags = (terminated != 0).to(torch.int64) | ((truncated != 0).to(torch.int64) << 1)
+    if action is not None:
+        flags = flags | ((action.to(torch.int64) & 0xFFFFFF) << 8)
+    w[..., D + 1] = torch.where(flags >= 2**31, flags - 2**32, flags).to(torch.int32)      # the 32 bits, as a signed word
+    out.view(-1).copy_(w.view(torch.uint8).view(-1))
+    return out
 
-    def __init__(self, engine, rank=None, world=None, host=None, port=None, timeout_s=120):
+
+def unpack_records_f32(rec, obs_dim, with_action=False):
+    """inverse of pack_records_f32 (rec uint8 [..., 4 (obs_dim + 2)]) -> obs float32 [..., obs_dim], reward float32,
+    terminated, truncated uint8 (and action int32 when with_action)"""
+    r = rec.contiguous()
+    lead = tuple(r.shape[:-1])
+    D = int(obs_dim)
+    assert r.shape[-1] == 4 * (D + 2)
+    if r.is_cuda:
+        from . import _lib
+        lib = _lib.load()
+        d = r.device
+        obs = torch.empty(lead + (D,), dtype=torch.float32, device=d)
+        rew = torch.empty(lead, dtype=torch.float32, device=d)
+        te = torch.empty(lead, dtype=torch.uint8, device=d)
+        tr = torch.empty(lead, dtype=torch.uint8, device=d)
+        act = torch.empty(lead, dtype=torch.int32, device=d) if with_action else None
+        st = torch.cuda.current_stream(d).cuda_stream
+        _lib.check(lib.xv_unpack_rollout_f32(st, rew.numel(), D, _lib.ptr(r), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(te),
+                                             _lib.ptr(tr), _lib.ptr(act)))
+        return (obs, rew, te, tr, act) if with_action else (obs, rew, te, tr)
+    w = r.view(torch.int32).view(lead + (D + 2,))
+    obs = w[..., :D].contiguous().view(torch.float32)
+    rew = w[..., D].contiguous().view(torch.float32)
+    f = w[..., D + 1].to(torch.int64) & 0xFFFFFFFF
+    te = (f & 1).to(torch.uint8)
+    tr = ((f >> 1) & 1).to(torch.uint8)
+    if with_action:
+        return obs, rew, te, tr, (f >> 8).to(torch.int32)
+    return obs, rew, te, tr
+
+
+class MixedChunk(object):
+    """Byte layout of one rank's T-step rollout chunk of a mixed batch (BASELINE config 5: anymdp + linds + cartpole) and of
+    the all-gathered buffer.  A rank's chunk is three record blocks back to back,
+
+        [T, n_a, 8]  AnyMDP 8-byte records | [T, n_l, 4 (16 + 2)]  LinDS records | [T, n_c, 4 (4 + 2)]  CartPole records
+
+    each padded to the largest share of any rank (an all-gather moves equal byte counts; with the env counts of config 5 no
+    share needs padding).  Shares follow `shard_range` per family, so rank r's block of family f holds the global envs
+    shard_range(N_f, r, world) of that family, and concatenating the ranks' blocks in rank order is the unsharded batch."""
+    LINDS_DIM, CART_DIM = 16, 4
+
+    def __init__(self, T, n_anymdp, n_linds, n_cartpole, world):
+        self.T, self.world = int(T), int(world)
+        self.n_total = {"anymdp": int(n_anymdp), "linds": int(n_linds), "cartpole": int(n_cartpole)}
+        self.rec = {"anymdp": REC_BYTES, "linds": 4 * (self.LINDS_DIM + 2), "cartpole": 4 * (self.CART_DIM + 2)}
+        self.share = {f: [shard_range(n, r, self.world) for r in range(self.world)] for f, n in self.n_total.items()}
+        self.n_max = {f: max(hi - lo for lo, hi in sh) for f, sh in self.share.items()}
+        self.offset, off = {}, 0
+        for f in ("anymdp", "linds", "cartpole"):
+            self.offset[f] = off
+            off += self.T * self.n_max[f] * self.rec[f]
+        self.bytes_per_rank = (off + 15) // 16 * 16
+
+    def n_local(self, family, rank):
+        lo, hi = self.share[family][rank]
+        return hi - lo
+
+    def block(self, buf, family, rank=None):
+        """view [T, n_local, rec] of family's block inside a rank's chunk `buf` (uint8 [bytes_per_rank]); rank: whose chunk it
+        is (its share may be smaller than the padded block)"""
+        n = self.n_max[family] if rank is None else self.n_local(family, rank)
+        o = self.offset[family]
+        return buf[o:o + self.T * self.n_max[family] * self.rec[family]].view(self.T, self.n_max[family], self.rec[family])[:, :n]
+
+    def pack(self, rank, rings, out):
+        """rings: {"anymdp": dict(obs, action, reward, terminated, truncated), "linds": dict(obs, reward, terminated,
+        truncated), "cartpole": dict(obs, action, reward, terminated, truncated)}, each [T, n_local(...)] -> fills `out`
+        (uint8 [bytes_per_rank]) on the current stream"""
+        a, l, c = rings["anymdp"], rings["linds"], rings["cartpole"]
+        full = all(self.n_local(f, rank) == self.n_max[f] for f in self.rec)
+        tgt = {f: (self.block(out, f) if full else torch.empty((self.T, self.n_local(f, rank), self.rec[f]), dtype=torch.uint8,
+                                                                device=out.device)) for f in self.rec}
+        pack_records(a["obs"], a["action"], a["reward"], a["terminated"], a["truncated"], out=tgt["anymdp"])
+        pack_records_f32(l["obs"], l["reward"], l["terminated"], l["truncated"], None, out=tgt["linds"])
+        pack_records_f32(c["obs"], c["reward"], c["terminated"], c["truncated"], c["action"], out=tgt["cartpole"])
+        if not full:
+            for f in self.rec:
+                self.block(out, f, rank).copy_(tgt[f])
+        return out
+
+    def unpack(self, gathered):
+        """gathered: uint8 [world, bytes_per_rank] -> {"anymdp": (obs, action, reward, terminated, truncated), "linds": (obs,
+        reward, terminated, truncated), "cartpole": (obs, reward, terminated, truncated, action)}, each [T, N_family] in
+        global env order (rank blocks concatenated)"""
+        out = {}
+        for f in ("anymdp", "linds", "cartpole"):
+            parts = []
+            for r in range(self.world):
+                b = self.block(gathered[r], f, r).contiguous()
+                if f == "anymdp":
+                    parts.append(unpack_records(b))
+                elif f == "linds":
+                    parts.append(unpack_records_f32(b, self.LINDS_DIM))
+                else:
+                    parts.append(unpack_records_f32(b, self.CART_DIM, with_action=True))
+            out[f] = tuple(torch.cat([p[k] for p in parts], dim=1) for k in range(len(parts[0])))
+        return out
+
+
+_RCCL_COMM_SEQ = [0]      # communicators are created in the same order on every rank: the key of an id carries the count
+
+
+def _rendezvous_store(rank, world, store, host, port, timeout_s):
+    """The key-value store that carries the RCCL unique id from rank 0 to the others — an EXISTING one whenever there is one:
+    1. `store` handed in by the caller (anything with set / get);
+    2. the default process group's store (torch.distributed is initialised: bench.py, trainers);
+    3. the launcher's own store (torchrun / torch.distributed.run hosts a TCPStore at MASTER_ADDR:MASTER_PORT for its
+       workers, TORCHELASTIC_USE_AGENT_STORE=True): joined as a client;
+    4. none of these: rank 0 hosts a TCPStore at `port` (default MASTER_PORT — nobody else is serving it in that case).
+    No second port is taken (earlier rounds opened MASTER_PORT + 1, which another job on the node may own)."""
+    import datetime
+    import os
+    if store is not None:
+        return store
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        from torch.distributed.distributed_c10d import _get_default_store
+        return dist.PrefixStore("xv_rccl", _get_default_store())
+    from torch.distributed import TCPStore
+    host = host or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(port or os.environ.get("MASTER_PORT", "29500"))
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true"
+    tmo = datetime.timedelta(seconds=timeout_s)
+    if agent:
+        return dist.PrefixStore("xv_rccl", TCPStore(host, port, None, False, timeout=tmo))
+    return dist.PrefixStore("xv_rccl", TCPStore(host, port, world, rank == 0, timeout=tmo))
+
+
+class RcclComm(object):
+    """A RCCL communicator made through the C-ABI (xv_rccl_*), without a process group of its own: rank 0 creates the 128-byte
+    unique id and an existing key-value store carries it to the others (`_rendezvous_store`: the caller's, the default
+    process group's, the launcher's — a fresh TCPStore on MASTER_PORT only when there is none).  rank / world default to the
+    launcher's environment (RANK, WORLD_SIZE)."""
+
+    def __init__(self, engine, rank=None, world=None, host=None, port=None, timeout_s=120, store=None):
         import ctypes as C
-        import datetime
         import os
         from . import _lib
         self.lib = engine.lib
@@ -93,16 +250,15 @@ class RcclComm(object):
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         ident = C.create_string_buffer(128)
         if self.world > 1:
-            from torch.distributed import TCPStore
-            host = host or os.environ.get("MASTER_ADDR", "127.0.0.1")
-            port = int(port or int(os.environ.get("MASTER_PORT", "29500")) + 1)
-            store = TCPStore(host, port, self.world, self.rank == 0, timeout=datetime.timedelta(seconds=timeout_s))
+            st = _rendezvous_store(self.rank, self.world, store, host, port, timeout_s)
+            key = "id_%d" % _RCCL_COMM_SEQ[0]
+            _RCCL_COMM_SEQ[0] += 1
             if self.rank == 0:
                 _lib.check(self.lib.xv_rccl_unique_id(ident))
-                store.set("xv_rccl_id", ident.raw)
+                st.set(key, ident.raw)
             else:
-                ident.raw = store.get("xv_rccl_id")
-            self._store = store
+                ident.raw = bytes(st.get(key))[:128]
+            self._store = st
         else:
             _lib.check(self.lib.xv_rccl_unique_id(ident))
         h = C.c_void_p()
