@@ -695,6 +695,61 @@ __device__ __forceinline__ void mz_interpolate_spec(const uint32_t (&qw)[4][4], 
   const MzDivisor SW = mz_divisor(sw);
   out[0] = mz_div(s0, SW); out[1] = mz_div(s1, SW); out[2] = mz_div(s2, SW);
 }
+// The speculated filter of a WALL pixel.  Quirk (ii) truncates a wall pixel's texel coordinates to integers before the
+// filter (ray_caster_utils.py:289-290) and quirk (i) gives every wall pixel of a frame the same stale footprint (:294), so the
+// tap offsets are the integers {-1, 0, 1, 2}^2 and the 16 weights 1 - 10 (xx^2 + yy^2) ps^2 / d^2 (:124-140) take SIX values
+// that are constants of the frame — one per squared offset 0, 1, 2, 4, 5, 8 — and so is their sum.  The texels are bytes, so
+// the sum of a class's texels is exact integer arithmetic (two channels at a time in 16-bit fields of one word): a wall
+// pixel costs 16 byte-adds and 6 FMAs per channel instead of 16 weights and 48 FMAs.  Same bound as mz_interpolate_spec:
+// the weights are computed by the same expression, the class sums are exact, the 18 products / 15 additions round less often
+// than the 16-term chains did (KAPPA's 5e-14 share for this side of the comparison has room to spare), and the reference's
+// float32 chain — what KAPPA is made of — is untouched.
+__device__ __forceinline__ double mz_uniform(double v) {      // a value every lane holds alike -> scalar registers
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+struct MzWallFilter {
+  double w[6];        // weight of squared offset 0, 1, 2, 4, 5, 8
+  MzDivisor SW;       // sum of the 16 weights
+};
+__device__ __forceinline__ MzWallFilter mz_wall_filter(double d, double ps) {
+  double d2 = d * d;
+  if (d2 < 1.0e-8) d2 = 1.0e-8;
+  const double k10 = mz_div(10.0, mz_divisor(d2));
+  const double p1 = (1.0 * ps) * (1.0 * ps), p2 = (2.0 * ps) * (2.0 * ps);      // (xx ps)^2 as the filters form it
+  const double dist[6] = {0.0 + 0.0, p1 + 0.0, p1 + p1, p2 + 0.0, p2 + p1, p2 + p2};
+  MzWallFilter F;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) F.w[k] = __builtin_fmax(__builtin_fma(-dist[k], k10, 1.0), 0.01);
+  F.SW = mz_divisor(F.w[0] + 4.0 * F.w[1] + 4.0 * F.w[2] + 2.0 * F.w[3] + 4.0 * F.w[4] + F.w[5]);
+  return F;
+}
+__device__ __forceinline__ void mz_interpolate_wall_spec(const uint32_t (&q)[4][4], const MzWallFilter& F, double (&out)[3]) {
+  // q[xx + 1][yy + 1]; fields of a word: R | G << 8 | B << 16.  rb: R and B in 16-bit fields (4 x 255 fits), g: G alone
+#define MZ_RB(p) ((p) & 0x00FF00FFu)
+#define MZ_G(p) (((p) >> 8) & 0xFFu)
+  const uint32_t rb[6] = {MZ_RB(q[1][1]),
+                          MZ_RB(q[0][1]) + MZ_RB(q[2][1]) + MZ_RB(q[1][0]) + MZ_RB(q[1][2]),
+                          MZ_RB(q[0][0]) + MZ_RB(q[0][2]) + MZ_RB(q[2][0]) + MZ_RB(q[2][2]),
+                          MZ_RB(q[3][1]) + MZ_RB(q[1][3]),
+                          MZ_RB(q[3][0]) + MZ_RB(q[3][2]) + MZ_RB(q[0][3]) + MZ_RB(q[2][3]),
+                          MZ_RB(q[3][3])};
+  const uint32_t g[6] = {MZ_G(q[1][1]),
+                         MZ_G(q[0][1]) + MZ_G(q[2][1]) + MZ_G(q[1][0]) + MZ_G(q[1][2]),
+                         MZ_G(q[0][0]) + MZ_G(q[0][2]) + MZ_G(q[2][0]) + MZ_G(q[2][2]),
+                         MZ_G(q[3][1]) + MZ_G(q[1][3]),
+                         MZ_G(q[3][0]) + MZ_G(q[3][2]) + MZ_G(q[0][3]) + MZ_G(q[2][3]),
+                         MZ_G(q[3][3])};
+#undef MZ_RB
+#undef MZ_G
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    s0 = __builtin_fma(F.w[k], (double)(rb[k] & 0xFFFFu), s0);
+    s1 = __builtin_fma(F.w[k], (double)g[k], s1);
+    s2 = __builtin_fma(F.w[k], (double)(rb[k] >> 16), s2);
+  }
+  out[0] = mz_div(s0, F.SW); out[1] = mz_div(s1, F.SW); out[2] = mz_div(s2, F.SW);
+}
 // byte of v' = L (A + B c') and whether the reference's byte could differ (an integer within the bound of v', or no number)
 __device__ __forceinline__ uint8_t mz_spec_byte(double L, double A, double B, double c, bool& doubt) {
   const double t = B * c, v = L * (A + t);
@@ -948,6 +1003,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
     const void* wt = PACKED ? (const void*)((PP ? P.pp_walls : P.pk_walls) + (size_t)text_id * 256 * MZ_TEX_PITCH)
                             : (const void*)(P.T.tex_walls + (size_t)text_id * 256 * 256 * 3);
     const double eff_ps_w = eff_stale * pixel_size / l_focal;
+    // the wall stage's filter: constants of the frame (mz_wall_filter); the same in every lane, kept in scalar registers
+    MzWallFilter WF = mz_wall_filter(eff_ps_w, tps);
+    if (SPEC) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) WF.w[k] = mz_uniform(WF.w[k]);
+      WF.SW.b = mz_uniform(WF.SW.b); WF.SW.y = mz_uniform(WF.SW.y);
+    }
     float wall_ti;
     {
       RT d_i = local_h * (RT)percell;
@@ -966,12 +1028,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
     const MzColumn me = {v_s, v_e, text_id, 0, (double)wall_ti, (double)light_w, a_far_w, a_near_w, (double)ratio,
                          (double)co, (double)so, R_cos.b, R_cos.y, 0.0};
     auto pixel = [&](const MzColumn& C, int d_v, const void*& tx, double& f_i, double& f_j, double& f_d, double& L, double& A,
-                     double& B) -> bool {
+                     double& B, bool& wall) -> bool {
       bool paint = false;
+      wall = d_v >= C.v_s && d_v < C.v_e;
       tx = PACKED ? (const void*)((PP ? P.pp_walls : P.pk_walls) + (size_t)C.text_id * 256 * MZ_TEX_PITCH)
                   : (const void*)(P.T.tex_walls + (size_t)C.text_id * 256 * 256 * 3);
       f_i = 0.0; f_j = 0.0; f_d = eff_ps_w; L = C.L; A = C.a_far; B = C.a_near;
-      if (d_v >= C.v_s && d_v < C.v_e) {
+      if (wall) {
         const double local_v = (half_v - (d_v + 0.5) * pixel_size) * C.ratio + vision_height;
         double d_j = local_v / text_size;
         d_j -= floor(d_j);
@@ -1026,7 +1089,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
             const MzColumn C = colp[cc];
             const void* tx;
             double f_i, f_j, f_d, L, A, B;
-            const bool paint = pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B);
+            bool wall;
+            const bool paint = pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B, wall);
             uint8_t* px = lds + (size_t)cc * cstride + (d_v - c0) * 3;
             uint8_t b0 = 1, b1 = 1, b2 = 1;
             if (paint) {
@@ -1034,7 +1098,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
               if (SPEC) {
                 uint32_t qw[4][4];
                 mz_fetch_window<PP>(tx, (int)f_i, (int)f_j, qw);
-                mz_interpolate_spec(qw, f_i, f_j, f_d, tps, c);
+                if (wall) mz_interpolate_wall_spec(qw, WF, c);
+                else mz_interpolate_spec(qw, f_i, f_j, f_d, tps, c);
                 bool doubt = false;
                 b0 = mz_spec_byte(L, A, B, c[0], doubt);
                 b1 = mz_spec_byte(L, A, B, c[1], doubt);
@@ -1057,7 +1122,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
               const MzColumn C = colp[cc];
               const void* tx;
               double f_i, f_j, f_d, L, A, B, c[3];
-              (void)pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B);
+              bool wall;
+              (void)pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B, wall);
               uint32_t qw[4][4];
               mz_fetch_window<PP>(tx, (int)f_i, (int)f_j, qw);
               mz_interpolate<true, true>(nullptr, f_i, f_j, f_d, tps, tps, c, qw);
@@ -1076,14 +1142,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
         for (int d_v = r0; d_v < r1; ++d_v) {
           const void* tx;
           double f_i, f_j, f_d, L, A, B;
-          const bool paint = pixel(me, d_v, tx, f_i, f_j, f_d, L, A, B);
+          bool wall;
+          const bool paint = pixel(me, d_v, tx, f_i, f_j, f_d, L, A, B, wall);
           uint8_t* px = col + (d_v - c0) * 3;
           if (paint) {
             double c[3];
             if (SPEC) {
               uint32_t qw[4][4];
               mz_fetch_window<PP>(tx, (int)f_i, (int)f_j, qw);
-              mz_interpolate_spec(qw, f_i, f_j, f_d, tps, c);
+              if (wall) mz_interpolate_wall_spec(qw, WF, c);
+              else mz_interpolate_spec(qw, f_i, f_j, f_d, tps, c);
               bool doubt = false;
               px[0] = mz_spec_byte(L, A, B, c[0], doubt);
               px[1] = mz_spec_byte(L, A, B, c[1], doubt);
@@ -1106,7 +1174,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
             redo &= redo - 1ull;
             const void* tx;
             double f_i, f_j, f_d, L, A, B, c[3];
-            (void)pixel(me, d_v, tx, f_i, f_j, f_d, L, A, B);
+            bool wall;
+            (void)pixel(me, d_v, tx, f_i, f_j, f_d, L, A, B, wall);
             uint32_t qw[4][4];
             mz_fetch_window<PP>(tx, (int)f_i, (int)f_j, qw);
             mz_interpolate<true, true>(nullptr, f_i, f_j, f_d, tps, tps, c, qw);
