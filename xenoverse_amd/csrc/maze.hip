@@ -1091,6 +1091,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
             double f_i, f_j, f_d, L, A, B;
             bool wall;
             const bool paint = pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B, wall);
+            const bool all_wall = SPEC && __ballot(paint && !wall) == 0ull;
             uint8_t* px = lds + (size_t)cc * cstride + (d_v - c0) * 3;
             uint8_t b0 = 1, b1 = 1, b2 = 1;
             if (paint) {
@@ -1098,7 +1099,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
               if (SPEC) {
                 uint32_t qw[4][4];
                 mz_fetch_window<PP>(tx, (int)f_i, (int)f_j, qw);
-                if (wall) mz_interpolate_wall_spec(qw, WF, c);
+                if (all_wall) mz_interpolate_wall_spec(qw, WF, c);      // wave-uniform, as in the column loop below
                 else mz_interpolate_spec(qw, f_i, f_j, f_d, tps, c);
                 bool doubt = false;
                 b0 = mz_spec_byte(L, A, B, c[0], doubt);
@@ -1144,13 +1145,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
           double f_i, f_j, f_d, L, A, B;
           bool wall;
           const bool paint = pixel(me, d_v, tx, f_i, f_j, f_d, L, A, B, wall);
+          const bool all_wall = SPEC && __ballot(paint && !wall) == 0ull;
           uint8_t* px = col + (d_v - c0) * 3;
           if (paint) {
             double c[3];
             if (SPEC) {
               uint32_t qw[4][4];
               mz_fetch_window<PP>(tx, (int)f_i, (int)f_j, qw);
-              if (wall) mz_interpolate_wall_spec(qw, WF, c);
+              // wave-uniform choice: the constant-weight wall filter when every painting lane of the wave is on a wall at this
+              // row, else the general filter for all of them (it serves wall pixels too) — a mixed row never pays for both
+              if (all_wall) mz_interpolate_wall_spec(qw, WF, c);
               else mz_interpolate_spec(qw, f_i, f_j, f_d, tps, c);
               bool doubt = false;
               px[0] = mz_spec_byte(L, A, B, c[0], doubt);
