@@ -256,6 +256,19 @@ int xv_anymdp_step_many_graph_state(xv_anymdp* h);
 int xv_anymdp_set_step_many_overlap(xv_anymdp* h, int on);
 int xv_anymdp_step_many_overlap_state(xv_anymdp* h);
 
+/* The device half of set_task for RAW task tensors (ABI 10): transition / reward / reward_noise, fp64 [n_task][S][A][S] as the
+ * reference's task dicts hold them (anymdp/task_sampler.py:46-50, set by AnyMDPEnv.set_task, anymdp_env.py:32-79), device
+ * pointers -> rows_out, the [n_task][S][A][XV_ANYMDP_ROW_LINES(S)] row records xv_anymdp_create takes (fence line and block
+ * metadata zero: create completes them).  The CDF of a row is formed as numpy.random.choice forms it every step
+ * (anymdp_env.py:99-100: sequential fp64 accumulate, divided by its last entry; all-zero rows -> 1.0), bit for bit what the
+ * host builder (xenoverse_amd/anymdp/tables.py) produces; rewards and noise are rounded to fp32.  term_mask: [n_task][ceil(S/64)]
+ * (states in s_e).  The reference's row check, (sum(row) - 1)^2 < 1e-6 unless the state is in s_e (anymdp_env.py:66-71), is
+ * made on the way: *bad_row (device word, set it to ~0 first) receives the smallest failing row index row_index_base +
+ * t * S * A + s * A + a (row_index_base: the first row of this call when the tasks arrive in chunks). */
+int xv_anymdp_build_rows(xv_engine* e, int n_task, int S, int A, const double* transition, const double* reward,
+                         const double* reward_noise, const uint64_t* term_mask, void* rows_out, unsigned long long* bad_row,
+                         unsigned long long row_index_base);
+
 /* A VIEW of envs [env_lo, env_lo + n_env) of `parent` as a handle of its own (ABI 10).  The reference steps one env object
  * at a time and its batched loop iterates independent envs (anymdp/anymdp_env.py:92-132, anymdp/test_utils.py:42-60): any
  * subset of a vector step can run on its own.  The view borrows the parent's tables, env records and bucket / observation

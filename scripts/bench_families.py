@@ -505,6 +505,18 @@ def quick_families(steps=200, warmup=20):
                                      "unit": "GB/s", "achieved": r["roofline"]["achieved"]},
                              "note": r["roofline"]["note"]}}
 
+    def maze256():      # the registered default resolution (mazeworld/__init__.py:27): 196,672 B per env-step
+        r = bench_maze(a, 256)
+        us = r["us_per_step"]["step (both)"]
+        return {"config": "BASELINE configs[3] at the registered 256 x 256: " + r["workload"], "ms_per_step": us * 1e-3,
+                "env_steps_per_s": r["env_steps_per_s"], "us_per_step": r["us_per_step"], "dtype": r["dtype"],
+                "roofline": {"bound": "valu_f64", "frac": r["valu_f64"]["frac"], "achieved": r["valu_f64"]["achieved"],
+                             "peak": r["valu_f64"]["peak"], "unit": r["valu_f64"]["unit"], "model": r["valu_f64"]["model"],
+                             "kernel": "maze_raycast_kernel (exact filter, speculated, rows of a column per wave; + maze_step9_kernel)",
+                             "hbm": {"frac": r["roofline"]["frac"], "algorithmic_bytes": (3 * 256 * 256 + 64) * 16384,
+                                     "peak": HBM_PEAK, "unit": "GB/s", "achieved": r["roofline"]["achieved"]},
+                             "note": r["roofline"]["note"]}}
+
     def mixed():
         r = bench_mixed(a, variants=("one stream", "one launch"))
         us = min(r["us_per_vector_step"].values())
@@ -537,6 +549,7 @@ def quick_families(steps=200, warmup=20):
                 "device_error_flags": max(v[k]["device_error_flags"] for k in v)}
     guard("linds", linds)
     guard("mazeworld_64", maze)
+    guard("mazeworld_256", maze256)
     guard("mixed_share", mixed)
     guard("anymdp_refdist", refdist)
     guard("anymdp_tok_refdist", tok)
@@ -545,14 +558,25 @@ def quick_families(steps=200, warmup=20):
 
 
 
+_MAZE_TASKS = {}
+
+
+def maze_tasks(n_task):
+    """BASELINE config 4's mazes (15 x 15, seeds 0 .. n_task - 1), sampled once per process (11 ms each)"""
+    from xenoverse_amd.mazeworld import MazeTaskSampler
+    if n_task not in _MAZE_TASKS:
+        _MAZE_TASKS[n_task] = [MazeTaskSampler(n_range=(15, 16), seed=k, n_wall_textures=8, n_ground_textures=4,
+                                               n_ceiling_textures=4) for k in range(n_task)]
+    return _MAZE_TASKS[n_task]
+
+
 def bench_maze(args, res, precision="exact", move_kernel="auto"):
-    from xenoverse_amd.mazeworld import MazeTaskSampler, MazeWorldVecEnv, make_texture_library
+    from xenoverse_amd.mazeworld import MazeWorldVecEnv, make_texture_library
     from xenoverse_amd import _lib
     from xenoverse_amd.engine import AUTORESET
     n_task, per = 256, 64
     n = n_task * per
-    tasks = [MazeTaskSampler(n_range=(15, 16), seed=k, n_wall_textures=8, n_ground_textures=4, n_ceiling_textures=4)
-             for k in range(n_task)]
+    tasks = maze_tasks(n_task)
     env = MazeWorldVecEnv(n, resolution=(res, res), textures=make_texture_library(8, 4, 4, seed=0),
                           autoreset_mode="same_step", action_space_type="Discrete16", precision=precision)
     env.set_task(tasks)
@@ -568,7 +592,7 @@ def bench_maze(args, res, precision="exact", move_kernel="auto"):
     def action_ptr():
         clock[0] += 1
         return _lib.ptr(ring[clock[0] % 64])
-    steps = max(24 if res <= 64 else 4, args.steps // (40 if res <= 64 else 400))
+    steps = max(24 if res <= 64 else 10, args.steps // (40 if res <= 64 else 400))
     steps = int(os.environ.get("XV_MAZE_STEPS", steps))
 
     def move():

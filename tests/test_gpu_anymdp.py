@@ -1106,3 +1106,35 @@ def test_step_writes_steps_and_done_mask_from_the_same_launch(copy, mode):
             ora.reset(4, 0, tick, mask=m)
     assert ended > 20 and env.check_errors() == 0
     env.close()
+
+
+def test_copy_true_hands_out_tensors_that_are_never_written_again():
+    """copy=True (the default): outputs come from slabs made for 32 steps at once (vector.OutputSlabs) — every step's tensors
+    are fresh memory, stay what they were over the following 100 steps (three slabs later) and equal the copy=False values"""
+    tab = oracle.anymdp_synth(seed=9, task_index_base=0, n_task=8, S=64, A=8, s0_max=4)
+    n, T = 1024, 100
+    acts = np.random.RandomState(4).randint(0, 8, (T, n)).astype(np.int32)
+    ref = []
+    env = AnyMDPVecEnv(n, seed=3, copy=False)
+    env.set_task(_dev_tables(tab))
+    env.reset()
+    for t in range(T):
+        o = env.step(acts[t])
+        ref.append([_np(x).copy() for x in o[:4]] + [_np(o[4][k]).copy() for k in ("steps", "reward_gt", "final_obs", "_final_obs")])
+    env.close()
+    env = AnyMDPVecEnv(n, seed=3)
+    env.set_task(_dev_tables(tab))
+    obs0, _ = env.reset()
+    kept, ptrs = [], set()
+    for t in range(T):
+        o = env.step(acts[t])
+        assert o[2].dtype == torch.bool and o[3].dtype == torch.bool and o[4]["_final_obs"].dtype == torch.bool
+        kept.append(list(o[:4]) + [o[4][k] for k in ("steps", "reward_gt", "final_obs", "_final_obs")])
+        ptrs.add(o[0].data_ptr())
+    assert len(ptrs) == T                                   # a new tensor every step
+    obs_m, _ = env.reset(options={"reset_mask": np.arange(n) % 2 == 0})      # a masked reset keeps the other envs' last observation
+    assert np.array_equal(_np(obs_m)[1::2], ref[-1][0][1::2])
+    for t in range(T):
+        for x, y in zip(kept[t], ref[t]):
+            assert np.array_equal(_np(x), y), t
+    env.close()

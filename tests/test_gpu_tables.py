@@ -1,0 +1,108 @@
+"""Device-side set_task for raw task tensors (xv_anymdp_build_rows, tables.build_tables_device): the row records equal the
+host builder's bit for bit — the CDF numpy.random.choice forms every step (anymdp_env.py:99-100), fp32 reward pairs, block
+layout — on the reference's own golden tasks, on sampled tasks and on awkward rows; the reference's checks raise as before."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from util import golden_files, load_anymdp_golden
+from xenoverse_amd.anymdp import AnyMDPTaskSampler, AnyMDPVecEnv, build_tables
+from xenoverse_amd.anymdp.tables import build_tables_device, device_buildable
+from xenoverse_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_tables(tasks, eng, **kw):
+    host = build_tables(tasks)
+    dev = build_tables_device(tasks, eng, **kw)
+    assert torch.equal(dev["rows"].cpu(), torch.from_numpy(host["rows"])), "row records differ"
+    for k in ("state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps", "obs_space"):
+        assert np.array_equal(dev[k], host[k]), k
+    assert (dev["S"], dev["A"], dev["s0_max"]) == (host["S"], host["A"], host["s0_max"])
+
+
+def test_golden_tasks_rows_equal_the_host_builder():
+    eng = Engine("cuda:0")
+    by_shape = {}
+    for p in golden_files("anymdp_"):
+        t = load_anymdp_golden(p)[1]
+        by_shape.setdefault(np.shape(t["transition"]), []).append(t)
+    assert len(by_shape) >= 2
+    for tasks in by_shape.values():
+        assert device_buildable(tasks)
+        _same_tables(tasks, eng)
+    eng.close()
+
+
+def test_sampled_tasks_in_chunks_equal_the_host_builder():
+    """128 tasks of the reference sampler's distribution (a few large probabilities among many of 1e-8 ... 1e-300), uploaded
+    in chunks of 24 tasks through the two pinned staging buffers"""
+    eng = Engine("cuda:0")
+    tasks = [AnyMDPTaskSampler(64, 8, seed=k) for k in range(8)]
+    big = tasks * 16                                    # 128 tasks, 8 distinct: chunking and offsets, not sampling time
+    for k, t in enumerate(big):
+        big[k] = dict(t, max_steps=float(t["max_steps"]) + k)
+    _same_tables(big, eng, chunk_bytes=24 * 3 * 64 * 8 * 64 * 8)
+    small = [AnyMDPTaskSampler(16, 4, seed=k) for k in range(128)]
+    _same_tables(small, eng, chunk_bytes=1 << 20)
+    eng.close()
+
+
+def test_awkward_rows_and_the_references_checks():
+    rng = np.random.RandomState(0)
+    S, A = 20, 3
+
+    def task(T, s_e=(), s_0=(0,)):
+        return dict(ns=S, na=A, max_steps=77.5, state_mapping=np.arange(S), task_type="MDP", s_0=np.array(s_0),
+                    s_0_prob=np.ones(len(s_0)) / len(s_0), s_e=np.array(s_e, dtype=np.int64), transition=T,
+                    reward=rng.randn(S, A, S), reward_noise=np.abs(rng.randn(S, A, S)))
+    T = rng.rand(S, A, S) ** 8
+    T[3] = 0.0                                           # a terminal state: all-zero rows -> CDF 1.0
+    T[5, 1] = 0.0; T[5, 1, 7] = 1.0                      # a deterministic row
+    T[6, 2] = 1e-300; T[6, 2, 11] = 1.0                  # sub-ulp entries beside one heavy state
+    T[7, 0] = 1.0                                        # uniform (sums to S before normalising below)
+    T /= np.where(T.sum(-1, keepdims=True) == 0, 1.0, T.sum(-1, keepdims=True))
+    T[8, 0] *= (1.0 - 3e-4)                              # sums to 0.9997: (sum - 1)^2 = 9e-8 < 1e-6 passes, CDF still ends at 1
+    eng = Engine("cuda:0")
+    _same_tables([task(T, s_e=(3,)), task(T[::-1].copy(), s_e=(S - 1 - 3,))], eng)
+    bad = T.copy(); bad[9, 2] *= 0.99                    # (sum - 1)^2 = 1e-4: the reference raises (anymdp_env.py:66-71)
+    with pytest.raises(Exception, match="Transition Matrix Sum != 1"):
+        build_tables_device([task(T, s_e=(3,)), task(bad, s_e=(3,))], eng)
+    with pytest.raises(Exception, match="Transition Matrix Sum != 1"):
+        build_tables_device([task(T, s_e=())], eng)      # the all-zero rows of state 3 without s_e naming it
+    with pytest.raises(Exception, match="State"):
+        build_tables_device([task(T, s_e=(3,), s_0=(3,)), task(T, s_e=(3,))], eng)      # s_0 and s_e intersect (:74-76)
+    assert not device_buildable([task(T), dict(task(T), na=4)]) and not device_buildable(task(T))
+    eng.close()
+
+
+def test_set_task_uses_the_device_builder_and_steps_alike():
+    """AnyMDPVecEnv.set_task on a list of raw task dicts: device-built and host-built tables give the same trajectories;
+    the device build of 256 tasks of 64 x 8 is at least 20 times faster than the host build"""
+    tasks = [AnyMDPTaskSampler(64, 8, seed=k) for k in range(4)] * 64
+    n = 1024
+    acts = np.random.RandomState(1).randint(0, 8, (40, n)).astype(np.int32)
+    res = []
+    for dev_tab in (True, False):
+        env = AnyMDPVecEnv(n, seed=2, device_tables=dev_tab)
+        env.set_task(tasks)
+        obs, _ = env.reset()
+        rec = [obs.cpu().numpy()]
+        for t in range(40):
+            o = env.step(acts[t])
+            rec += [o[0].cpu().numpy(), o[1].cpu().numpy(), o[2].cpu().numpy()]
+        assert env.check_errors() == 0
+        res.append(rec)
+        env.close()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+    eng = Engine("cuda:0")
+    build_tables_device(tasks[:8], eng)                  # warm up (pinned allocation, first launch)
+    t0 = time.perf_counter(); build_tables_device(tasks, eng); t_dev = time.perf_counter() - t0
+    t0 = time.perf_counter(); build_tables(tasks); t_host = time.perf_counter() - t0
+    print("build of 256 tasks: device %.3f s, host %.3f s" % (t_dev, t_host))
+    assert t_host > 20 * t_dev
+    eng.close()

@@ -52,6 +52,7 @@ SIGNATURES = {
     "xv_anymdp_set_step_many_graph": [c_void_p, c_int],
     "xv_anymdp_set_step_many_overlap": [c_void_p, c_int],
     "xv_anymdp_step_many_overlap_state": [c_void_p],
+    "xv_anymdp_build_rows": [c_void_p, c_int, c_int, c_int] + [c_void_p] * 6 + [c_u64],
     "xv_anymdp_view": [c_void_p, c_void_p, c_int, c_int, C.POINTER(c_void_p)],
     "xv_anymdp_step_many_chains": [c_void_p, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 7 + [c_int],
     "xv_anymdp_solve": [c_void_p, C.c_double, C.c_double, c_int, c_void_p, c_void_p, c_void_p],

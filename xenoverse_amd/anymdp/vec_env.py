@@ -12,8 +12,8 @@ import torch
 from .. import _lib
 from ..engine import AUTORESET
 from ..spaces import Discrete, MultiDiscrete
-from ..vector import VectorEnv
-from .tables import build_obs_tables, build_tables
+from ..vector import OutputSlabs, VectorEnv
+from .tables import build_obs_tables, build_tables, build_tables_device, device_buildable
 
 _TABLE_KEYS = ("rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")
 _TABLE_DTYPES = dict(rows=torch.float64, state_map=torch.int32, term_mask=torch.int64,
@@ -29,7 +29,7 @@ class AnyMDPVecEnv(VectorEnv):
 
     def __init__(self, num_envs, max_steps=5000, device="cuda:0", seed=0, env_id_base=0,
                  autoreset_mode="same_step", to_numpy=False, engine=None, with_transition_gt=False, copy=True,
-                 bucket_lines="auto"):
+                 bucket_lines="auto", device_tables=True):
         """`max_steps` is kept for signature parity with AnyMDPEnv(max_steps); as in the reference it is
         overridden by each task's own `max_steps` at set_task (anymdp_env.py:23-34).
 
@@ -48,6 +48,7 @@ class AnyMDPVecEnv(VectorEnv):
         self.with_transition_gt = bool(with_transition_gt)
         self.copy = bool(copy)
         self.bucket_lines = bucket_lines
+        self.device_tables = bool(device_tables)      # set_task forms the row records of raw task dicts on the device
         self._ring = None
         self._tok_cache = None
         self._set_spaces(Discrete(1), Discrete(1))   # placeholders until set_task, as in the reference
@@ -75,7 +76,9 @@ class AnyMDPVecEnv(VectorEnv):
             ttype = tasks[0].get("task_type", "MDP")
             if ttype not in ("MDP", "POMDP", "MTPOMDP"):
                 raise NotImplementedError(f"Unknown task type: {ttype}")   # anymdp_env.py:45-46
-            tab = build_tables(tasks)
+            # raw task tensors of one shape: the row records are formed on the device (xv_anymdp_build_rows), bit for bit
+            # what the host builder forms and ~50x faster; anything else (ragged shapes, bandits) on the host
+            tab = build_tables_device(tasks, self.engine) if (self.device_tables and device_buildable(tasks)) else build_tables(tasks)
             if ttype != "MDP":
                 obs_model = build_obs_tables(tasks, tab["S"])
         self.task_type = "MDP" if obs_model is None else (table_type or tasks[0]["task_type"])
@@ -176,6 +179,7 @@ class AnyMDPVecEnv(VectorEnv):
             self._tobs = torch.zeros((n, d_obs), dtype=torch.int32, device=d)
             self._tfobs = torch.full((n, d_obs), -1, dtype=torch.int32, device=d)
         self._tok_cache = None          # (copy=False token steps cache pointers and views of the buffers made here)
+        self._slabs = None              # copy=True: output sets of 32 steps per allocation (made at the first step)
         self._obs = torch.zeros(n, dtype=torch.int32, device=d)
         self._reward = torch.zeros(n, dtype=torch.float32, device=d)
         self._reward_gt = torch.zeros(n, dtype=torch.float32, device=d)
@@ -413,6 +417,24 @@ class AnyMDPVecEnv(VectorEnv):
                 infos["final_obs"] = b["final_obs"]
                 infos["_final_obs"] = b["done_b"]
             return b["obs"], b["reward"], b["term_b"], b["trunc_b"], infos
+        if self.copy and not self.to_numpy and not self.with_transition_gt:
+            # copy=True without copies and without allocations: the step writes every output for every env into the next set of
+            # a slab made for 32 steps at once (vector.OutputSlabs); what earlier steps handed out is never written again
+            if self._slabs is None:
+                i32, f32, u8 = torch.int32, torch.float32, torch.uint8
+                self._slabs = OutputSlabs([("obs", i32, ()), ("final_obs", i32, ()), ("steps", i32, ()), ("reward", f32, ()),
+                                           ("reward_gt", f32, ()), ("term", u8, ()), ("trunc", u8, ()), ("done", u8, ())],
+                                          self.num_envs, self.device, K=32, as_bool=("term", "trunc", "done"))
+            t, p = self._slabs.next()
+            mode = AUTORESET[self.autoreset_mode]
+            _lib.check(self.lib.xv_anymdp_step_info(self._h, C.c_void_p(a.data_ptr()), p["obs"], p["reward"], p["reward_gt"], p["term"],
+                                                    p["trunc"], p["final_obs"], p["steps"], p["done"], mode))
+            self._obs = t["obs"]      # (reset() and the accessors read the latest observation from here)
+            infos = {"steps": t["steps"], "reward_gt": t["reward_gt"]}
+            if mode == 2:
+                infos["final_obs"] = t["final_obs"]
+                infos["_final_obs"] = t["done"]
+            return t["obs"], t["reward"], t["term"], t["trunc"], infos
         # copy=True without copies: the step writes every output for every env, so fresh buffers are swapped in
         self._renew("_obs", "_reward", "_reward_gt", "_term", "_trunc", "_final_obs", "_steps", "_done")
         _lib.check(self.lib.xv_anymdp_step_info(
