@@ -210,7 +210,10 @@ def device_buildable(tasks):
                int(t["na"]) == sh[1] for t in tasks)
 
 
-def build_tables_device(tasks, engine, chunk_bytes=256 << 20, s0_max=None, validate=True):
+_STAGING = {}      # (device, bytes) -> two pinned staging buffers, kept: pinning 2 x 32 MB costs more than building 100 tasks
+
+
+def build_tables_device(tasks, engine, chunk_bytes=32 << 20, s0_max=None, validate=True):
     """build_tables with the heavy half on the device (xv_anymdp_build_rows): the transition / reward / reward_noise tensors
     go up in chunks through pinned memory and the row records — CDF as numpy.random.choice forms it, fp32 reward pairs,
     block layout — are written where they will be read; host memory stays O(chunk) beside the caller's task dicts and a
@@ -270,7 +273,11 @@ def build_tables_device(tasks, engine, chunk_bytes=256 << 20, s0_max=None, valid
     per_task = 3 * S * A * S * 8
     chunk = max(1, min(n_task, int(chunk_bytes) // per_task))
     # two pinned staging buffers: the host fills one while the other's copy and kernel run
-    pins = [torch.empty((3, chunk, S, A, S), dtype=torch.float64).pin_memory() for _ in range(2)]
+    key = (str(dev), 3 * chunk * S * A * S)
+    if key not in _STAGING:
+        _STAGING.clear()
+        _STAGING[key] = [torch.empty(key[1], dtype=torch.float64).pin_memory() for _ in range(2)]
+    pins = [p.view(3, chunk, S, A, S) for p in _STAGING[key]]
     devs = [torch.empty((3, chunk, S, A, S), dtype=torch.float64, device=dev) for _ in range(2)]
     evs = [None, None]
     st = engine.torch_stream
@@ -292,7 +299,7 @@ def build_tables_device(tasks, engine, chunk_bytes=256 << 20, s0_max=None, valid
             _lib.check(lib.xv_anymdp_build_rows(engine.handle, t1 - t0, S, A, C.c_void_p(d[0].data_ptr()), C.c_void_p(d[1].data_ptr()),
                                                 C.c_void_p(d[2].data_ptr()), C.c_void_p(tm_dev[t0:].data_ptr()),
                                                 C.c_void_p(rows[t0:].data_ptr()), C.c_void_p(bad.data_ptr()), t0 * S * A))
-    engine.sync()
+    engine.sync()          # (the staging buffers are free again: the next call may fill them)
     if validate:      # the kernel made the row-sum check on the way (anymdp_env.py:66-71)
         w = int(bad.item())
         if w != -1:

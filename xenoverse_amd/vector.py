@@ -39,20 +39,24 @@ class OutputSlabs(object):
         per_step = [dict() for _ in range(self.K)]
         ptrs = [dict() for _ in range(self.K)]
         for dt, fl in by.items():
-            sizes = [self.n * math.prod(t) for _, t in fl]
-            tot = sum(sizes)
-            slab = torch.empty((self.K, tot), dtype=dt, device=self.device)
+            # [field][step][n * tail]: two unbind() calls hand out every per-step tensor (slicing K x fields views one by one
+            # in Python cost more than the allocations it was meant to save)
+            width = max(self.n * math.prod(t) for _, t in fl)
+            slab = torch.empty((len(fl), self.K, width), dtype=dt, device=self.device)
             base, esz = slab.data_ptr(), slab.element_size()
-            rows = slab.unbind(0)
-            brows = slab.view(torch.bool).unbind(0) if dt == torch.uint8 else None
-            off = 0
-            for (name, tail), sz in zip(fl, sizes):
+            fields = (slab.view(torch.bool) if dt == torch.uint8 else slab).unbind(0)
+            plain = slab.unbind(0)
+            for f, (name, tail) in enumerate(fl):
+                src = fields[f] if name in self.as_bool else plain[f]
+                sz = self.n * math.prod(tail)
+                if sz != width:
+                    src = src[:, :sz]
+                if tail:
+                    src = src.view((self.K, self.n) + tail)
+                rows = src.unbind(0)
                 for k in range(self.K):
-                    src = brows[k] if (brows is not None and name in self.as_bool) else rows[k]
-                    v = src[off:off + sz]
-                    per_step[k][name] = v.view((self.n,) + tail) if tail else v
-                    ptrs[k][name] = C.c_void_p(base + (k * tot + off) * esz)
-                off += sz
+                    per_step[k][name] = rows[k]
+                    ptrs[k][name] = C.c_void_p(base + ((f * self.K + k) * width) * esz)
         self._sets = list(zip(per_step, ptrs))
         self._pos = 0
 
