@@ -581,6 +581,8 @@ def bench_maze(args, res, precision="exact", move_kernel="auto"):
                           autoreset_mode="same_step", action_space_type="Discrete16", precision=precision)
     env.set_task(tasks)
     env.set_move_kernel(move_kernel)
+    if os.environ.get("XV_MAZE_MAPPING"):      # A/B of the ray caster's lane -> pixel mappings (scripts/runs_r05/gpu_m.sh)
+        env.set_raycast_mapping(os.environ["XV_MAZE_MAPPING"])
     env.reset()
     # BASELINE config 4: actions uniform over Discrete16, drawn anew for every step (a ring of 64 pre-generated action sets);
     # 32 untimed steps first, so that the batch is past the reset transient (every agent at its start cell's centre) —

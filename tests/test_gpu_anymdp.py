@@ -1109,10 +1109,10 @@ def test_step_writes_steps_and_done_mask_from_the_same_launch(copy, mode):
 
 
 def test_copy_true_hands_out_tensors_that_are_never_written_again():
-    """copy=True (the default): outputs come from slabs made for 32 steps at once (vector.OutputSlabs) — every step's tensors
-    are fresh memory, stay what they were over the following 100 steps (three slabs later) and equal the copy=False values"""
+    """copy=True (the default): outputs come from slabs made for 64 steps at once (vector.OutputSlabs) — every step's tensors
+    are fresh memory, stay what they were over the following steps (three slabs later) and equal the copy=False values"""
     tab = oracle.anymdp_synth(seed=9, task_index_base=0, n_task=8, S=64, A=8, s0_max=4)
-    n, T = 1024, 100
+    n, T = 1024, 150
     acts = np.random.RandomState(4).randint(0, 8, (T, n)).astype(np.int32)
     ref = []
     env = AnyMDPVecEnv(n, seed=3, copy=False)

@@ -179,7 +179,7 @@ class AnyMDPVecEnv(VectorEnv):
             self._tobs = torch.zeros((n, d_obs), dtype=torch.int32, device=d)
             self._tfobs = torch.full((n, d_obs), -1, dtype=torch.int32, device=d)
         self._tok_cache = None          # (copy=False token steps cache pointers and views of the buffers made here)
-        self._slabs = None              # copy=True: output sets of 32 steps per allocation (made at the first step)
+        self._slabs = None              # copy=True: output sets of 64 steps per allocation (made at the first step)
         self._obs = torch.zeros(n, dtype=torch.int32, device=d)
         self._reward = torch.zeros(n, dtype=torch.float32, device=d)
         self._reward_gt = torch.zeros(n, dtype=torch.float32, device=d)
@@ -419,16 +419,16 @@ class AnyMDPVecEnv(VectorEnv):
             return b["obs"], b["reward"], b["term_b"], b["trunc_b"], infos
         if self.copy and not self.to_numpy and not self.with_transition_gt:
             # copy=True without copies and without allocations: the step writes every output for every env into the next set of
-            # a slab made for 32 steps at once (vector.OutputSlabs); what earlier steps handed out is never written again
+            # a slab made for 64 steps at once (vector.OutputSlabs); what earlier steps handed out is never written again
             if self._slabs is None:
                 i32, f32, u8 = torch.int32, torch.float32, torch.uint8
                 self._slabs = OutputSlabs([("obs", i32, ()), ("final_obs", i32, ()), ("steps", i32, ()), ("reward", f32, ()),
                                            ("reward_gt", f32, ()), ("term", u8, ()), ("trunc", u8, ()), ("done", u8, ())],
-                                          self.num_envs, self.device, K=32, as_bool=("term", "trunc", "done"))
+                                          self.num_envs, self.device, K=64, as_bool=("term", "trunc", "done"),
+                                          order=("obs", "reward", "reward_gt", "term", "trunc", "final_obs", "steps", "done"))
             t, p = self._slabs.next()
             mode = AUTORESET[self.autoreset_mode]
-            _lib.check(self.lib.xv_anymdp_step_info(self._h, C.c_void_p(a.data_ptr()), p["obs"], p["reward"], p["reward_gt"], p["term"],
-                                                    p["trunc"], p["final_obs"], p["steps"], p["done"], mode))
+            _lib.check(self.lib.xv_anymdp_step_info(self._h, C.c_void_p(a.data_ptr()), *p, mode))
             self._obs = t["obs"]      # (reset() and the accessors read the latest observation from here)
             infos = {"steps": t["steps"], "reward_gt": t["reward_gt"]}
             if mode == 2:

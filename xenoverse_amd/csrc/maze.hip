@@ -857,9 +857,14 @@ struct MzColumn {
 template <bool FINAL, bool PACKED, int FILT, bool NB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_WAVES, XV_MAZE_RC_WAVES))) void maze_raycast_kernel(MazeArgs P, uint8_t* frames, float* command_rgb) {
   using RT = typename std::conditional<NB, double, float>::type;
-  constexpr bool F32 = FILT == 1 || FILT == 6, SPEC = (FILT == 0 || FILT == 3 || FILT == 5) && PACKED;
-  constexpr bool PP = F32 || (SPEC && FILT == 0);   // which packed copy the pixels read
+  constexpr bool F32 = FILT == 1 || FILT == 6, SPEC = (FILT == 0 || FILT == 3 || FILT == 5 || FILT == 7) && PACKED;
+  constexpr bool PP = F32 || (SPEC && (FILT == 0 || FILT == 7));   // which packed copy the pixels read
   constexpr bool ROWS = (FILT == 5 || FILT == 6) && PACKED;        // lanes = rows of one column in the pixel loop
+  // LIST (FILT 7, xv_maze_set_raycast_mapping(XV_MAZE_MAP_LIST)): the chunk's pixels are painted in two passes over two
+  // index spaces — all WALL pixels of all columns (dense waves of wall pixels: the six-weight filter, no divergence against
+  // floor pixels), then all the others.  A lane finds the (column, row) of entry k by a binary search in the prefix sums of
+  // the columns' wall-row counts (LDS).
+  constexpr bool LIST = FILT == 7 && PACKED;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int e = blockIdx.x;
   if (FINAL && !P.fin_flag[e]) return;   // block-uniform
@@ -1069,12 +1074,131 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
       return paint;
     };
     MzColumn* colp = reinterpret_cast<MzColumn*>(rowtab + H);   // ROWS: the columns of this batch, behind the row table
-    if (ROWS) colp[threadIdx.x] = me;
+    if (ROWS || LIST) colp[threadIdx.x] = me;
     for (int c0 = 0; c0 < H; c0 += HC) {
       const int c1 = min(c0 + HC, H);
       // SPEC: blocks of 64 rows; the pixels whose byte the speculated filter could not settle are noted in `redo` and
       // filtered in the reference's typing by a second loop (rare: the two filters never share a register allocation)
-      if (ROWS) {
+      if (LIST) {
+        const int ncols = min((int)blockDim.x, W - g0), rows = c1 - c0, tid = threadIdx.x;
+        int* prefW = reinterpret_cast<int*>(colp + blockDim.x);      // [blockDim.x + 1] behind the columns
+        // wall rows of this lane's column inside the chunk: [ws, ws + wc)
+        int ws = min(max(me.v_s, c0), c1), we = min(max(me.v_e, c0), c1);
+        const int wc = (tid < ncols && we > ws) ? we - ws : 0;
+        __syncthreads();                                              // colp written; prefW free (last chunk's passes done)
+        {      // exclusive prefix sums of wc over the columns: wave scan, then the waves' offsets through LDS
+          int incl = wc;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if ((tid & 63) >= d) incl += up;
+          }
+          int* wtot = prefW + blockDim.x + 1;                         // [4]
+          if ((tid & 63) == 63) wtot[tid >> 6] = incl;
+          __syncthreads();
+          int base = 0;
+          for (int w = 0; w < (tid >> 6); ++w) base += wtot[w];
+          prefW[tid + 1] = base + incl;
+          if (tid == 0) prefW[0] = 0;
+          __syncthreads();
+        }
+        const int Wtot = prefW[ncols], Ftot = ncols * rows - Wtot;
+        auto wall_of = [&](int k, int& c, int& d_v) {                 // entry k of the wall list
+          int lo = 0, hi = ncols;
+          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefW[mid] <= k) lo = mid; else hi = mid; }
+          c = lo;
+          d_v = min(max(colp[lo].v_s, c0), c1) + (k - prefW[lo]);
+        };
+        auto flat_of = [&](int k, int& c, int& d_v) {                 // entry k of the list of the other pixels
+          int lo = 0, hi = ncols;                                     // prefF(c) = c rows - prefW[c]
+          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (mid * rows - prefW[mid] <= k) lo = mid; else hi = mid; }
+          c = lo;
+          const int idx = k - (lo * rows - prefW[lo]);
+          const int s0 = min(max(colp[lo].v_s, c0), c1), wcc = prefW[lo + 1] - prefW[lo];
+          d_v = idx < s0 - c0 ? c0 + idx : c0 + idx + wcc;
+        };
+        // ---- pass 1: wall pixels.  Quirk (ii) / (i): integer texel coordinates, the frame's stale footprint ----
+        unsigned long long redo = 0ull;
+        for (int k0 = 0, it = 0; k0 < Wtot; k0 += blockDim.x, ++it) {
+          const bool act = k0 + tid < Wtot;
+          int cc, d_v;
+          wall_of(act ? k0 + tid : Wtot - 1, cc, d_v);
+          const MzColumn C = colp[cc];
+          const double local_v = (half_v - (d_v + 0.5) * pixel_size) * C.ratio + vision_height;
+          double d_j = local_v / text_size;
+          d_j -= floor(d_j);
+          const int fi = (int)C.f_i, fj = (int)(256 * d_j);
+          const void* tx = (const void*)(P.pp_walls + (size_t)C.text_id * 256 * MZ_TEX_PITCH);
+          uint32_t qw[4][4];
+          mz_fetch_window<true>(tx, fi, fj, qw);
+          double c[3];
+          mz_interpolate_wall_spec(qw, WF, c);
+          bool doubt = false;
+          const uint8_t b0 = mz_spec_byte(C.L, C.a_far, C.a_near, c[0], doubt);
+          const uint8_t b1 = mz_spec_byte(C.L, C.a_far, C.a_near, c[1], doubt);
+          const uint8_t b2 = mz_spec_byte(C.L, C.a_far, C.a_near, c[2], doubt);
+          redo |= (unsigned long long)(doubt && act) << it;
+          if (act) { uint8_t* px = lds + (size_t)cc * cstride + (d_v - c0) * 3; px[0] = b0; px[1] = b1; px[2] = b2; }
+        }
+        while (redo) {      // the wall pixels whose byte the speculation could not settle, in the reference's typing
+          const int it = __builtin_ctzll(redo);
+          redo &= redo - 1ull;
+          int cc, d_v;
+          wall_of(it * (int)blockDim.x + tid, cc, d_v);
+          const MzColumn C = colp[cc];
+          const void* tx;
+          double f_i, f_j, f_d, L, A, B, c[3];
+          bool wall;
+          (void)pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B, wall);
+          uint32_t qw[4][4];
+          mz_fetch_window<true>(tx, (int)f_i, (int)f_j, qw);
+          mz_interpolate<true, true>(nullptr, f_i, f_j, f_d, tps, tps, c, qw);
+          uint8_t* px = lds + (size_t)cc * cstride + (d_v - c0) * 3;
+          px[0] = mz_clip_u8(L * (A + B * c[0])); px[1] = mz_clip_u8(L * (A + B * c[1])); px[2] = mz_clip_u8(L * (A + B * c[2]));
+        }
+        // ---- pass 2: floor, ceiling and unpainted pixels ----
+        redo = 0ull;
+        for (int k0 = 0, it = 0; k0 < Ftot; k0 += blockDim.x, ++it) {
+          const bool act = k0 + tid < Ftot;
+          int cc, d_v;
+          flat_of(act ? k0 + tid : Ftot - 1, cc, d_v);
+          const MzColumn C = colp[cc];
+          const void* tx;
+          double f_i, f_j, f_d, L, A, B;
+          bool wall;
+          const bool paint = pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B, wall);
+          uint8_t b0 = 1, b1 = 1, b2 = 1;
+          if (paint) {
+            double c[3];
+            uint32_t qw[4][4];
+            mz_fetch_window<true>(tx, (int)f_i, (int)f_j, qw);
+            mz_interpolate_spec(qw, f_i, f_j, f_d, tps, c);
+            bool doubt = false;
+            b0 = mz_spec_byte(L, A, B, c[0], doubt);
+            b1 = mz_spec_byte(L, A, B, c[1], doubt);
+            b2 = mz_spec_byte(L, A, B, c[2], doubt);
+            redo |= (unsigned long long)(doubt && act) << it;
+          }
+          if (act) { uint8_t* px = lds + (size_t)cc * cstride + (d_v - c0) * 3; px[0] = b0; px[1] = b1; px[2] = b2; }
+        }
+        while (redo) {
+          const int it = __builtin_ctzll(redo);
+          redo &= redo - 1ull;
+          int cc, d_v;
+          flat_of(it * (int)blockDim.x + tid, cc, d_v);
+          const MzColumn C = colp[cc];
+          const void* tx;
+          double f_i, f_j, f_d, L, A, B, c[3];
+          bool wall;
+          (void)pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B, wall);
+          uint32_t qw[4][4];
+          mz_fetch_window<true>(tx, (int)f_i, (int)f_j, qw);
+          mz_interpolate<true, true>(nullptr, f_i, f_j, f_d, tps, tps, c, qw);
+          uint8_t* px = lds + (size_t)cc * cstride + (d_v - c0) * 3;
+          px[0] = mz_clip_u8(L * (A + B * c[0])); px[1] = mz_clip_u8(L * (A + B * c[1])); px[2] = mz_clip_u8(L * (A + B * c[2]));
+        }
+        __syncthreads();
+      } else if (ROWS) {
         // the lanes of a wave paint 64 ROWS of one column at a time (wave w takes columns w, w + nw, ...): wall pixels of a
         // column read the same four texture rows, the rows of a ray's floor / ceiling pixels neighbouring texels
         __syncthreads();
@@ -1380,19 +1504,22 @@ static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, b
   const bool packed = a.pk_walls != nullptr;
   // FILT of the kernel: 0 / 3 the speculated exact filter on the pair / row-major texture copy, 1 fp32, 2 direct, 5 / 6 = 3 / 1 on rows
   const int filt0 = h->filter != XV_MAZE_FILTER_EXACT ? h->filter : (packed && (size_t)a.W * a.H > 128 * 128 ? 3 : 0);
-  const int filt = !packed || !rows_map ? filt0 : (filt0 == 1 ? 6 : ((filt0 == 3 || (filt0 == 0 && rows_map == 3)) ? 5 : filt0));
+  int filt = !packed || !rows_map ? filt0 : (filt0 == 1 ? 6 : ((filt0 == 3 || (filt0 == 0 && rows_map == 3)) ? 5 : filt0));
+  if (packed && h->raycast_mapping == XV_MAZE_MAP_LIST && (filt0 == 0 || filt0 == 3)) filt = 7;      // the speculated exact filter only
   const size_t lds_bytes = (((size_t)threads * (a.HC * 3 + 4) + 15) & ~(size_t)15) + (size_t)a.H * 16 +
-                           (filt >= 5 ? (size_t)threads * sizeof(MzColumn) : 0);
+                           (filt >= 5 ? (size_t)threads * sizeof(MzColumn) : 0) + (filt == 7 ? ((size_t)threads + 8) * sizeof(int) : 0);
 #define MAZE_RC(F, K, Q, B) \
   hipLaunchKernelGGL((maze_raycast_kernel<F, K, Q, B>), dim3(a.n_env), dim3(threads), lds_bytes, h->eng->stream, a, frames, crgb)
 #define MAZE_RC2(F, K)                                                                  \
   do {                                                                                  \
     if (h->typing_numba) { if (filt == 1) MAZE_RC(F, K, 1, true); else if (filt == 2) MAZE_RC(F, K, 2, true);                          \
                            else if (filt == 3) MAZE_RC(F, K, 3, true); else if (filt == 5) MAZE_RC(F, K, 5, true);                     \
-                           else if (filt == 6) MAZE_RC(F, K, 6, true); else MAZE_RC(F, K, 0, true); }                                  \
+                           else if (filt == 6) MAZE_RC(F, K, 6, true); else if (filt == 7) MAZE_RC(F, K, 7, true);                    \
+                           else MAZE_RC(F, K, 0, true); }                                                                             \
     else { if (filt == 1) MAZE_RC(F, K, 1, false); else if (filt == 2) MAZE_RC(F, K, 2, false);                                        \
            else if (filt == 3) MAZE_RC(F, K, 3, false); else if (filt == 5) MAZE_RC(F, K, 5, false);                                   \
-           else if (filt == 6) MAZE_RC(F, K, 6, false); else MAZE_RC(F, K, 0, false); }                                               \
+           else if (filt == 6) MAZE_RC(F, K, 6, false); else if (filt == 7) MAZE_RC(F, K, 7, false);                                  \
+           else MAZE_RC(F, K, 0, false); }                                                                                           \
   } while (0)
   if (final) { if (packed) MAZE_RC2(true, true); else MAZE_RC2(true, false); }
   else { if (packed) MAZE_RC2(false, true); else MAZE_RC2(false, false); }
@@ -1409,7 +1536,8 @@ extern "C" int xv_maze_set_precision(xv_maze* h, int filter) {
 }
 
 extern "C" int xv_maze_set_raycast_mapping(xv_maze* h, int mapping) {
-  XV_CHECK_ARG(h != nullptr && (mapping == XV_MAZE_MAP_AUTO || mapping == XV_MAZE_MAP_COLUMNS || mapping == XV_MAZE_MAP_ROWS));
+  XV_CHECK_ARG(h != nullptr && (mapping == XV_MAZE_MAP_AUTO || mapping == XV_MAZE_MAP_COLUMNS || mapping == XV_MAZE_MAP_ROWS ||
+                                mapping == XV_MAZE_MAP_LIST));
   h->raycast_mapping = mapping;
   return XV_OK;
 }

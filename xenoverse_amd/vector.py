@@ -26,9 +26,11 @@ class OutputSlabs(object):
 
     fields: [(name, torch dtype, trailing shape)], uint8 fields named in `as_bool` are handed out as bool views."""
 
-    def __init__(self, fields, n, device, K=32, as_bool=()):
+    def __init__(self, fields, n, device, K=64, as_bool=(), order=None):
+        """order: field names in the order the C call takes its pointers — next() then returns them as a ready tuple"""
         self.fields, self.n, self.device, self.K = list(fields), int(n), device, int(K)
         self.as_bool = set(as_bool)
+        self.order = list(order) if order is not None else [f[0] for f in self.fields]
         self._sets, self._pos = [], 0
 
     def _refill(self):
@@ -57,11 +59,11 @@ class OutputSlabs(object):
                 for k in range(self.K):
                     per_step[k][name] = rows[k]
                     ptrs[k][name] = C.c_void_p(base + ((f * self.K + k) * width) * esz)
-        self._sets = list(zip(per_step, ptrs))
+        self._sets = [(per_step[k], tuple(ptrs[k][name] for name in self.order)) for k in range(self.K)]
         self._pos = 0
 
     def next(self):
-        """-> (dict name -> tensor, dict name -> ctypes pointer) of a set no earlier step has written"""
+        """-> (dict name -> tensor, tuple of ctypes pointers in `order`) of a set no earlier step has written"""
         if self._pos >= len(self._sets):
             self._refill()
         s = self._sets[self._pos]
