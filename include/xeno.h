@@ -692,7 +692,6 @@ int xv_maze_set_precision(xv_maze* h, int filter);
 #define XV_MAZE_MAP_AUTO 0
 #define XV_MAZE_MAP_COLUMNS 1
 #define XV_MAZE_MAP_ROWS 2
-#define XV_MAZE_MAP_LIST 3      /* the chunk's wall pixels first (six-weight filter, dense waves), then the others */
 int xv_maze_set_raycast_mapping(xv_maze* h, int mapping);
 /* Which typing of the reference's ray-caster source the frames follow.  NUMPY2 (default): its @njit functions run as plain
  * Python under NumPy >= 2 (Python floats are weak, so DDA_2D and the wall-column geometry stay in the float32 of the

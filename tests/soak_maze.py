@@ -49,7 +49,7 @@ def soak(rng, seed):
     env = MazeWorldVecEnv(n, resolution=res, textures=tex, autoreset_mode=mode, max_steps=max_steps, action_space_type=space,
                           typing=typing, command_in_observation=cio, seed=seed)
     env.set_task(tasks, env_task_index=env_task)
-    mapping = str(rng.choice(["auto", "auto", "list", "rows", "columns"]))
+    mapping = str(rng.choice(["auto", "auto", "rows", "columns"]))
     env.set_raycast_mapping(mapping)
     ora = oracle.MazeOracle(tab, tex, env_task, resolution=res, max_steps=max_steps, command_in_observation=cio)
     f0, _ = env.reset()

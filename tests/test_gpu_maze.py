@@ -266,7 +266,7 @@ def test_rows_mapping_of_the_ray_caster_paints_the_bytes_of_the_columns_mapping(
     n = len(env_task)
     a = np.random.RandomState(13).randint(0, 16, (20, n)).astype(np.int32)
     frames = {}
-    for mapping in ("columns", "rows", "auto", "list"):
+    for mapping in ("columns", "rows", "auto"):
         env = MazeWorldVecEnv(n, resolution=res, textures=tex(), autoreset_mode="same_step", precision=prec, typing=typing,
                               seed=3, command_in_observation=True)
         env.set_task(tasks, env_task_index=env_task)
@@ -282,7 +282,6 @@ def test_rows_mapping_of_the_ray_caster_paints_the_bytes_of_the_columns_mapping(
     for k in range(2):
         assert np.array_equal(frames["columns"][k], frames["rows"][k]), int((frames["columns"][k] != frames["rows"][k]).sum())
         assert np.array_equal(frames["columns"][k], frames["auto"][k])
-        assert np.array_equal(frames["columns"][k], frames["list"][k]), int((frames["columns"][k] != frames["list"][k]).sum())
 
 
 @pytest.mark.parametrize("mode,space", [("same_step", "Discrete16"), ("next_step", "Discrete32"), ("disabled", "Continuous"),

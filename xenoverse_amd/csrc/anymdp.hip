@@ -1519,6 +1519,7 @@ static void anymdp_pipe_clear(xv_anymdp* h) {      // fields of the overlapped s
   memset(&h->pipe_key, 0, sizeof(h->pipe_key));
 }
 static void anymdp_pipe_drop_graphs(xv_anymdp* h) {
+  if (h->pgraph_exec[1] == h->pgraph_exec[0]) h->pgraph_exec[1] = nullptr;
   for (int q = 0; q < 2; ++q) {
     if (h->pgraph_exec[q]) { (void)hipGraphExecDestroy(h->pgraph_exec[q]); h->pgraph_exec[q] = nullptr; }
     if (h->pgraph[q]) { (void)hipGraphDestroy(h->pgraph[q]); h->pgraph[q] = nullptr; }
@@ -2020,6 +2021,18 @@ static bool anymdp_pipe_graphs(xv_anymdp* h, int period, size_t stride, const in
   (void)hipStreamSynchronize(h->side);
   (void)hipStreamSynchronize(h->eng->stream);
   anymdp_pipe_drop_graphs(h);
+  static const bool one_graph = getenv("XV_ANYMDP_PIPE_ONE_GRAPH") != nullptr;      // experiment: both chains as branches of ONE graph
+  if (one_graph) {
+    if (hipGraphCreate(&h->pgraph[0], 0) != hipSuccess) return false;
+    hipGraphNode_t tails[2] = {nullptr, nullptr};
+    for (int q = 0; q < 2; ++q)
+      if (!anymdp_add_chain(h, h->pgraph[0], &tails[q], h->d_ptick, eff, period, stride, actions, obs, reward, reward_gt,
+                            terminated, truncated, final_obs, mode, q, 2, true))
+        return false;
+    if (!anymdp_add_tick_node(h->pgraph[0], tails, 2, h->d_ptick, period)) return false;
+    if (hipGraphInstantiate(&h->pgraph_exec[0], h->pgraph[0], nullptr, nullptr, 0) != hipSuccess) { h->pgraph_exec[0] = nullptr; return false; }
+    h->pgraph_exec[1] = h->pgraph_exec[0];      // (marks "built"; never launched or destroyed separately)
+  } else
   for (int q = 0; q < 2; ++q) {
     if (hipGraphCreate(&h->pgraph[q], 0) != hipSuccess) return false;
     hipGraphNode_t prev = nullptr;
@@ -2109,7 +2122,7 @@ static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride,
   for (int c = 0; c < cycles; ++c) {
     // both halves or neither: an even half without its odd half leaves the next even launch waiting (bounded, flagged)
     if (hipGraphLaunch(h->pgraph_exec[0], st) != hipSuccess) break;
-    if (hipGraphLaunch(h->pgraph_exec[1], h->side) != hipSuccess) { broken = true; break; }
+    if (h->pgraph_exec[1] != h->pgraph_exec[0] && hipGraphLaunch(h->pgraph_exec[1], h->side) != hipSuccess) { broken = true; break; }
     k += period;
     h->eng->tick = t0 + (uint64_t)k;
   }

@@ -695,61 +695,6 @@ __device__ __forceinline__ void mz_interpolate_spec(const uint32_t (&qw)[4][4], 
   const MzDivisor SW = mz_divisor(sw);
   out[0] = mz_div(s0, SW); out[1] = mz_div(s1, SW); out[2] = mz_div(s2, SW);
 }
-// The speculated filter of a WALL pixel.  Quirk (ii) truncates a wall pixel's texel coordinates to integers before the
-// filter (ray_caster_utils.py:289-290) and quirk (i) gives every wall pixel of a frame the same stale footprint (:294), so the
-// tap offsets are the integers {-1, 0, 1, 2}^2 and the 16 weights 1 - 10 (xx^2 + yy^2) ps^2 / d^2 (:124-140) take SIX values
-// that are constants of the frame — one per squared offset 0, 1, 2, 4, 5, 8 — and so is their sum.  The texels are bytes, so
-// the sum of a class's texels is exact integer arithmetic (two channels at a time in 16-bit fields of one word): a wall
-// pixel costs 16 byte-adds and 6 FMAs per channel instead of 16 weights and 48 FMAs.  Same bound as mz_interpolate_spec:
-// the weights are computed by the same expression, the class sums are exact, the 18 products / 15 additions round less often
-// than the 16-term chains did (KAPPA's 5e-14 share for this side of the comparison has room to spare), and the reference's
-// float32 chain — what KAPPA is made of — is untouched.
-__device__ __forceinline__ double mz_uniform(double v) {      // a value every lane holds alike -> scalar registers
-  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-}
-struct MzWallFilter {
-  double w[6];        // weight of squared offset 0, 1, 2, 4, 5, 8
-  MzDivisor SW;       // sum of the 16 weights
-};
-__device__ __forceinline__ MzWallFilter mz_wall_filter(double d, double ps) {
-  double d2 = d * d;
-  if (d2 < 1.0e-8) d2 = 1.0e-8;
-  const double k10 = mz_div(10.0, mz_divisor(d2));
-  const double p1 = (1.0 * ps) * (1.0 * ps), p2 = (2.0 * ps) * (2.0 * ps);      // (xx ps)^2 as the filters form it
-  const double dist[6] = {0.0 + 0.0, p1 + 0.0, p1 + p1, p2 + 0.0, p2 + p1, p2 + p2};
-  MzWallFilter F;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) F.w[k] = __builtin_fmax(__builtin_fma(-dist[k], k10, 1.0), 0.01);
-  F.SW = mz_divisor(F.w[0] + 4.0 * F.w[1] + 4.0 * F.w[2] + 2.0 * F.w[3] + 4.0 * F.w[4] + F.w[5]);
-  return F;
-}
-__device__ __forceinline__ void mz_interpolate_wall_spec(const uint32_t (&q)[4][4], const MzWallFilter& F, double (&out)[3]) {
-  // q[xx + 1][yy + 1]; fields of a word: R | G << 8 | B << 16.  rb: R and B in 16-bit fields (4 x 255 fits), g: G alone
-#define MZ_RB(p) ((p) & 0x00FF00FFu)
-#define MZ_G(p) (((p) >> 8) & 0xFFu)
-  const uint32_t rb[6] = {MZ_RB(q[1][1]),
-                          MZ_RB(q[0][1]) + MZ_RB(q[2][1]) + MZ_RB(q[1][0]) + MZ_RB(q[1][2]),
-                          MZ_RB(q[0][0]) + MZ_RB(q[0][2]) + MZ_RB(q[2][0]) + MZ_RB(q[2][2]),
-                          MZ_RB(q[3][1]) + MZ_RB(q[1][3]),
-                          MZ_RB(q[3][0]) + MZ_RB(q[3][2]) + MZ_RB(q[0][3]) + MZ_RB(q[2][3]),
-                          MZ_RB(q[3][3])};
-  const uint32_t g[6] = {MZ_G(q[1][1]),
-                         MZ_G(q[0][1]) + MZ_G(q[2][1]) + MZ_G(q[1][0]) + MZ_G(q[1][2]),
-                         MZ_G(q[0][0]) + MZ_G(q[0][2]) + MZ_G(q[2][0]) + MZ_G(q[2][2]),
-                         MZ_G(q[3][1]) + MZ_G(q[1][3]),
-                         MZ_G(q[3][0]) + MZ_G(q[3][2]) + MZ_G(q[0][3]) + MZ_G(q[2][3]),
-                         MZ_G(q[3][3])};
-#undef MZ_RB
-#undef MZ_G
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    s0 = __builtin_fma(F.w[k], (double)(rb[k] & 0xFFFFu), s0);
-    s1 = __builtin_fma(F.w[k], (double)g[k], s1);
-    s2 = __builtin_fma(F.w[k], (double)(rb[k] >> 16), s2);
-  }
-  out[0] = mz_div(s0, F.SW); out[1] = mz_div(s1, F.SW); out[2] = mz_div(s2, F.SW);
-}
 // byte of v' = L (A + B c') and whether the reference's byte could differ (an integer within the bound of v', or no number)
 __device__ __forceinline__ uint8_t mz_spec_byte(double L, double A, double B, double c, bool& doubt) {
   const double t = B * c, v = L * (A + t);
@@ -857,14 +802,9 @@ struct MzColumn {
 template <bool FINAL, bool PACKED, int FILT, bool NB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_WAVES, XV_MAZE_RC_WAVES))) void maze_raycast_kernel(MazeArgs P, uint8_t* frames, float* command_rgb) {
   using RT = typename std::conditional<NB, double, float>::type;
-  constexpr bool F32 = FILT == 1 || FILT == 6, SPEC = (FILT == 0 || FILT == 3 || FILT == 5 || FILT == 7) && PACKED;
-  constexpr bool PP = F32 || (SPEC && (FILT == 0 || FILT == 7));   // which packed copy the pixels read
+  constexpr bool F32 = FILT == 1 || FILT == 6, SPEC = (FILT == 0 || FILT == 3 || FILT == 5) && PACKED;
+  constexpr bool PP = F32 || (SPEC && FILT == 0);   // which packed copy the pixels read
   constexpr bool ROWS = (FILT == 5 || FILT == 6) && PACKED;        // lanes = rows of one column in the pixel loop
-  // LIST (FILT 7, xv_maze_set_raycast_mapping(XV_MAZE_MAP_LIST)): the chunk's pixels are painted in two passes over two
-  // index spaces — all WALL pixels of all columns (dense waves of wall pixels: the six-weight filter, no divergence against
-  // floor pixels), then all the others.  A lane finds the (column, row) of entry k by a binary search in the prefix sums of
-  // the columns' wall-row counts (LDS).
-  constexpr bool LIST = FILT == 7 && PACKED;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int e = blockIdx.x;
   if (FINAL && !P.fin_flag[e]) return;   // block-uniform
@@ -1008,13 +948,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
     const void* wt = PACKED ? (const void*)((PP ? P.pp_walls : P.pk_walls) + (size_t)text_id * 256 * MZ_TEX_PITCH)
                             : (const void*)(P.T.tex_walls + (size_t)text_id * 256 * 256 * 3);
     const double eff_ps_w = eff_stale * pixel_size / l_focal;
-    // the wall stage's filter: constants of the frame (mz_wall_filter); the same in every lane, kept in scalar registers
-    MzWallFilter WF = mz_wall_filter(eff_ps_w, tps);
-    if (SPEC) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) WF.w[k] = mz_uniform(WF.w[k]);
-      WF.SW.b = mz_uniform(WF.SW.b); WF.SW.y = mz_uniform(WF.SW.y);
-    }
     float wall_ti;
     {
       RT d_i = local_h * (RT)percell;
@@ -1033,13 +966,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
     const MzColumn me = {v_s, v_e, text_id, 0, (double)wall_ti, (double)light_w, a_far_w, a_near_w, (double)ratio,
                          (double)co, (double)so, R_cos.b, R_cos.y, 0.0};
     auto pixel = [&](const MzColumn& C, int d_v, const void*& tx, double& f_i, double& f_j, double& f_d, double& L, double& A,
-                     double& B, bool& wall) -> bool {
+                     double& B) -> bool {
       bool paint = false;
-      wall = d_v >= C.v_s && d_v < C.v_e;
       tx = PACKED ? (const void*)((PP ? P.pp_walls : P.pk_walls) + (size_t)C.text_id * 256 * MZ_TEX_PITCH)
                   : (const void*)(P.T.tex_walls + (size_t)C.text_id * 256 * 256 * 3);
       f_i = 0.0; f_j = 0.0; f_d = eff_ps_w; L = C.L; A = C.a_far; B = C.a_near;
-      if (wall) {
+      if (d_v >= C.v_s && d_v < C.v_e) {
         const double local_v = (half_v - (d_v + 0.5) * pixel_size) * C.ratio + vision_height;
         double d_j = local_v / text_size;
         d_j -= floor(d_j);
@@ -1074,131 +1006,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
       return paint;
     };
     MzColumn* colp = reinterpret_cast<MzColumn*>(rowtab + H);   // ROWS: the columns of this batch, behind the row table
-    if (ROWS || LIST) colp[threadIdx.x] = me;
+    if (ROWS) colp[threadIdx.x] = me;
     for (int c0 = 0; c0 < H; c0 += HC) {
       const int c1 = min(c0 + HC, H);
       // SPEC: blocks of 64 rows; the pixels whose byte the speculated filter could not settle are noted in `redo` and
       // filtered in the reference's typing by a second loop (rare: the two filters never share a register allocation)
-      if (LIST) {
-        const int ncols = min((int)blockDim.x, W - g0), rows = c1 - c0, tid = threadIdx.x;
-        int* prefW = reinterpret_cast<int*>(colp + blockDim.x);      // [blockDim.x + 1] behind the columns
-        // wall rows of this lane's column inside the chunk: [ws, ws + wc)
-        int ws = min(max(me.v_s, c0), c1), we = min(max(me.v_e, c0), c1);
-        const int wc = (tid < ncols && we > ws) ? we - ws : 0;
-        __syncthreads();                                              // colp written; prefW free (last chunk's passes done)
-        {      // exclusive prefix sums of wc over the columns: wave scan, then the waves' offsets through LDS
-          int incl = wc;
-#pragma unroll
-          for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(incl, d);
-            if ((tid & 63) >= d) incl += up;
-          }
-          int* wtot = prefW + blockDim.x + 1;                         // [4]
-          if ((tid & 63) == 63) wtot[tid >> 6] = incl;
-          __syncthreads();
-          int base = 0;
-          for (int w = 0; w < (tid >> 6); ++w) base += wtot[w];
-          prefW[tid + 1] = base + incl;
-          if (tid == 0) prefW[0] = 0;
-          __syncthreads();
-        }
-        const int Wtot = prefW[ncols], Ftot = ncols * rows - Wtot;
-        auto wall_of = [&](int k, int& c, int& d_v) {                 // entry k of the wall list
-          int lo = 0, hi = ncols;
-          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefW[mid] <= k) lo = mid; else hi = mid; }
-          c = lo;
-          d_v = min(max(colp[lo].v_s, c0), c1) + (k - prefW[lo]);
-        };
-        auto flat_of = [&](int k, int& c, int& d_v) {                 // entry k of the list of the other pixels
-          int lo = 0, hi = ncols;                                     // prefF(c) = c rows - prefW[c]
-          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (mid * rows - prefW[mid] <= k) lo = mid; else hi = mid; }
-          c = lo;
-          const int idx = k - (lo * rows - prefW[lo]);
-          const int s0 = min(max(colp[lo].v_s, c0), c1), wcc = prefW[lo + 1] - prefW[lo];
-          d_v = idx < s0 - c0 ? c0 + idx : c0 + idx + wcc;
-        };
-        // ---- pass 1: wall pixels.  Quirk (ii) / (i): integer texel coordinates, the frame's stale footprint ----
-        unsigned long long redo = 0ull;
-        for (int k0 = 0, it = 0; k0 < Wtot; k0 += blockDim.x, ++it) {
-          const bool act = k0 + tid < Wtot;
-          int cc, d_v;
-          wall_of(act ? k0 + tid : Wtot - 1, cc, d_v);
-          const MzColumn C = colp[cc];
-          const double local_v = (half_v - (d_v + 0.5) * pixel_size) * C.ratio + vision_height;
-          double d_j = local_v / text_size;
-          d_j -= floor(d_j);
-          const int fi = (int)C.f_i, fj = (int)(256 * d_j);
-          const void* tx = (const void*)(P.pp_walls + (size_t)C.text_id * 256 * MZ_TEX_PITCH);
-          uint32_t qw[4][4];
-          mz_fetch_window<true>(tx, fi, fj, qw);
-          double c[3];
-          mz_interpolate_wall_spec(qw, WF, c);
-          bool doubt = false;
-          const uint8_t b0 = mz_spec_byte(C.L, C.a_far, C.a_near, c[0], doubt);
-          const uint8_t b1 = mz_spec_byte(C.L, C.a_far, C.a_near, c[1], doubt);
-          const uint8_t b2 = mz_spec_byte(C.L, C.a_far, C.a_near, c[2], doubt);
-          redo |= (unsigned long long)(doubt && act) << it;
-          if (act) { uint8_t* px = lds + (size_t)cc * cstride + (d_v - c0) * 3; px[0] = b0; px[1] = b1; px[2] = b2; }
-        }
-        while (redo) {      // the wall pixels whose byte the speculation could not settle, in the reference's typing
-          const int it = __builtin_ctzll(redo);
-          redo &= redo - 1ull;
-          int cc, d_v;
-          wall_of(it * (int)blockDim.x + tid, cc, d_v);
-          const MzColumn C = colp[cc];
-          const void* tx;
-          double f_i, f_j, f_d, L, A, B, c[3];
-          bool wall;
-          (void)pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B, wall);
-          uint32_t qw[4][4];
-          mz_fetch_window<true>(tx, (int)f_i, (int)f_j, qw);
-          mz_interpolate<true, true>(nullptr, f_i, f_j, f_d, tps, tps, c, qw);
-          uint8_t* px = lds + (size_t)cc * cstride + (d_v - c0) * 3;
-          px[0] = mz_clip_u8(L * (A + B * c[0])); px[1] = mz_clip_u8(L * (A + B * c[1])); px[2] = mz_clip_u8(L * (A + B * c[2]));
-        }
-        // ---- pass 2: floor, ceiling and unpainted pixels ----
-        redo = 0ull;
-        for (int k0 = 0, it = 0; k0 < Ftot; k0 += blockDim.x, ++it) {
-          const bool act = k0 + tid < Ftot;
-          int cc, d_v;
-          flat_of(act ? k0 + tid : Ftot - 1, cc, d_v);
-          const MzColumn C = colp[cc];
-          const void* tx;
-          double f_i, f_j, f_d, L, A, B;
-          bool wall;
-          const bool paint = pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B, wall);
-          uint8_t b0 = 1, b1 = 1, b2 = 1;
-          if (paint) {
-            double c[3];
-            uint32_t qw[4][4];
-            mz_fetch_window<true>(tx, (int)f_i, (int)f_j, qw);
-            mz_interpolate_spec(qw, f_i, f_j, f_d, tps, c);
-            bool doubt = false;
-            b0 = mz_spec_byte(L, A, B, c[0], doubt);
-            b1 = mz_spec_byte(L, A, B, c[1], doubt);
-            b2 = mz_spec_byte(L, A, B, c[2], doubt);
-            redo |= (unsigned long long)(doubt && act) << it;
-          }
-          if (act) { uint8_t* px = lds + (size_t)cc * cstride + (d_v - c0) * 3; px[0] = b0; px[1] = b1; px[2] = b2; }
-        }
-        while (redo) {
-          const int it = __builtin_ctzll(redo);
-          redo &= redo - 1ull;
-          int cc, d_v;
-          flat_of(it * (int)blockDim.x + tid, cc, d_v);
-          const MzColumn C = colp[cc];
-          const void* tx;
-          double f_i, f_j, f_d, L, A, B, c[3];
-          bool wall;
-          (void)pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B, wall);
-          uint32_t qw[4][4];
-          mz_fetch_window<true>(tx, (int)f_i, (int)f_j, qw);
-          mz_interpolate<true, true>(nullptr, f_i, f_j, f_d, tps, tps, c, qw);
-          uint8_t* px = lds + (size_t)cc * cstride + (d_v - c0) * 3;
-          px[0] = mz_clip_u8(L * (A + B * c[0])); px[1] = mz_clip_u8(L * (A + B * c[1])); px[2] = mz_clip_u8(L * (A + B * c[2]));
-        }
-        __syncthreads();
-      } else if (ROWS) {
+      if (ROWS) {
         // the lanes of a wave paint 64 ROWS of one column at a time (wave w takes columns w, w + nw, ...): wall pixels of a
         // column read the same four texture rows, the rows of a ray's floor / ceiling pixels neighbouring texels
         __syncthreads();
@@ -1213,9 +1026,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
             const MzColumn C = colp[cc];
             const void* tx;
             double f_i, f_j, f_d, L, A, B;
-            bool wall;
-            const bool paint = pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B, wall);
-            const bool all_wall = SPEC && __ballot(paint && !wall) == 0ull;
+            const bool paint = pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B);
             uint8_t* px = lds + (size_t)cc * cstride + (d_v - c0) * 3;
             uint8_t b0 = 1, b1 = 1, b2 = 1;
             if (paint) {
@@ -1223,8 +1034,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
               if (SPEC) {
                 uint32_t qw[4][4];
                 mz_fetch_window<PP>(tx, (int)f_i, (int)f_j, qw);
-                if (all_wall) mz_interpolate_wall_spec(qw, WF, c);      // wave-uniform, as in the column loop below
-                else mz_interpolate_spec(qw, f_i, f_j, f_d, tps, c);
+                mz_interpolate_spec(qw, f_i, f_j, f_d, tps, c);
                 bool doubt = false;
                 b0 = mz_spec_byte(L, A, B, c[0], doubt);
                 b1 = mz_spec_byte(L, A, B, c[1], doubt);
@@ -1247,8 +1057,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
               const MzColumn C = colp[cc];
               const void* tx;
               double f_i, f_j, f_d, L, A, B, c[3];
-              bool wall;
-              (void)pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B, wall);
+              (void)pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B);
               uint32_t qw[4][4];
               mz_fetch_window<PP>(tx, (int)f_i, (int)f_j, qw);
               mz_interpolate<true, true>(nullptr, f_i, f_j, f_d, tps, tps, c, qw);
@@ -1267,19 +1076,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
         for (int d_v = r0; d_v < r1; ++d_v) {
           const void* tx;
           double f_i, f_j, f_d, L, A, B;
-          bool wall;
-          const bool paint = pixel(me, d_v, tx, f_i, f_j, f_d, L, A, B, wall);
-          const bool all_wall = SPEC && __ballot(paint && !wall) == 0ull;
+          const bool paint = pixel(me, d_v, tx, f_i, f_j, f_d, L, A, B);
           uint8_t* px = col + (d_v - c0) * 3;
           if (paint) {
             double c[3];
             if (SPEC) {
               uint32_t qw[4][4];
               mz_fetch_window<PP>(tx, (int)f_i, (int)f_j, qw);
-              // wave-uniform choice: the constant-weight wall filter when every painting lane of the wave is on a wall at this
-              // row, else the general filter for all of them (it serves wall pixels too) — a mixed row never pays for both
-              if (all_wall) mz_interpolate_wall_spec(qw, WF, c);
-              else mz_interpolate_spec(qw, f_i, f_j, f_d, tps, c);
+              mz_interpolate_spec(qw, f_i, f_j, f_d, tps, c);
               bool doubt = false;
               px[0] = mz_spec_byte(L, A, B, c[0], doubt);
               px[1] = mz_spec_byte(L, A, B, c[1], doubt);
@@ -1302,8 +1106,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
             redo &= redo - 1ull;
             const void* tx;
             double f_i, f_j, f_d, L, A, B, c[3];
-            bool wall;
-            (void)pixel(me, d_v, tx, f_i, f_j, f_d, L, A, B, wall);
+            (void)pixel(me, d_v, tx, f_i, f_j, f_d, L, A, B);
             uint32_t qw[4][4];
             mz_fetch_window<PP>(tx, (int)f_i, (int)f_j, qw);
             mz_interpolate<true, true>(nullptr, f_i, f_j, f_d, tps, tps, c, qw);
@@ -1504,22 +1307,19 @@ static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, b
   const bool packed = a.pk_walls != nullptr;
   // FILT of the kernel: 0 / 3 the speculated exact filter on the pair / row-major texture copy, 1 fp32, 2 direct, 5 / 6 = 3 / 1 on rows
   const int filt0 = h->filter != XV_MAZE_FILTER_EXACT ? h->filter : (packed && (size_t)a.W * a.H > 128 * 128 ? 3 : 0);
-  int filt = !packed || !rows_map ? filt0 : (filt0 == 1 ? 6 : ((filt0 == 3 || (filt0 == 0 && rows_map == 3)) ? 5 : filt0));
-  if (packed && h->raycast_mapping == XV_MAZE_MAP_LIST && (filt0 == 0 || filt0 == 3)) filt = 7;      // the speculated exact filter only
+  const int filt = !packed || !rows_map ? filt0 : (filt0 == 1 ? 6 : ((filt0 == 3 || (filt0 == 0 && rows_map == 3)) ? 5 : filt0));
   const size_t lds_bytes = (((size_t)threads * (a.HC * 3 + 4) + 15) & ~(size_t)15) + (size_t)a.H * 16 +
-                           (filt >= 5 ? (size_t)threads * sizeof(MzColumn) : 0) + (filt == 7 ? ((size_t)threads + 8) * sizeof(int) : 0);
+                           (filt >= 5 ? (size_t)threads * sizeof(MzColumn) : 0);
 #define MAZE_RC(F, K, Q, B) \
   hipLaunchKernelGGL((maze_raycast_kernel<F, K, Q, B>), dim3(a.n_env), dim3(threads), lds_bytes, h->eng->stream, a, frames, crgb)
 #define MAZE_RC2(F, K)                                                                  \
   do {                                                                                  \
     if (h->typing_numba) { if (filt == 1) MAZE_RC(F, K, 1, true); else if (filt == 2) MAZE_RC(F, K, 2, true);                          \
                            else if (filt == 3) MAZE_RC(F, K, 3, true); else if (filt == 5) MAZE_RC(F, K, 5, true);                     \
-                           else if (filt == 6) MAZE_RC(F, K, 6, true); else if (filt == 7) MAZE_RC(F, K, 7, true);                    \
-                           else MAZE_RC(F, K, 0, true); }                                                                             \
+                           else if (filt == 6) MAZE_RC(F, K, 6, true); else MAZE_RC(F, K, 0, true); }                                  \
     else { if (filt == 1) MAZE_RC(F, K, 1, false); else if (filt == 2) MAZE_RC(F, K, 2, false);                                        \
            else if (filt == 3) MAZE_RC(F, K, 3, false); else if (filt == 5) MAZE_RC(F, K, 5, false);                                   \
-           else if (filt == 6) MAZE_RC(F, K, 6, false); else if (filt == 7) MAZE_RC(F, K, 7, false);                                  \
-           else MAZE_RC(F, K, 0, false); }                                                                                           \
+           else if (filt == 6) MAZE_RC(F, K, 6, false); else MAZE_RC(F, K, 0, false); }                                               \
   } while (0)
   if (final) { if (packed) MAZE_RC2(true, true); else MAZE_RC2(true, false); }
   else { if (packed) MAZE_RC2(false, true); else MAZE_RC2(false, false); }
@@ -1536,8 +1336,7 @@ extern "C" int xv_maze_set_precision(xv_maze* h, int filter) {
 }
 
 extern "C" int xv_maze_set_raycast_mapping(xv_maze* h, int mapping) {
-  XV_CHECK_ARG(h != nullptr && (mapping == XV_MAZE_MAP_AUTO || mapping == XV_MAZE_MAP_COLUMNS || mapping == XV_MAZE_MAP_ROWS ||
-                                mapping == XV_MAZE_MAP_LIST));
+  XV_CHECK_ARG(h != nullptr && (mapping == XV_MAZE_MAP_AUTO || mapping == XV_MAZE_MAP_COLUMNS || mapping == XV_MAZE_MAP_ROWS));
   h->raycast_mapping = mapping;
   return XV_OK;
 }

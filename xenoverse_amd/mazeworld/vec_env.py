@@ -176,10 +176,9 @@ class MazeWorldVecEnv(VectorEnv):
                                                               "auto": 3, "nine_lanes_compact": 4}[kernel]))
 
     def set_raycast_mapping(self, mapping):
-        """"auto" (default), "columns", "rows" or "list": which lanes of the ray caster paint which pixels
-        (xv_maze_set_raycast_mapping; "list": all wall pixels of a chunk first, then the others — the exact filter only);
+        """"auto" (default), "columns" or "rows": which lanes of the ray caster paint which pixels (xv_maze_set_raycast_mapping);
         the frames are the same bytes either way"""
-        _lib.check(self.lib.xv_maze_set_raycast_mapping(self._h, {"auto": 0, "columns": 1, "rows": 2, "list": 3}[mapping]))
+        _lib.check(self.lib.xv_maze_set_raycast_mapping(self._h, {"auto": 0, "columns": 1, "rows": 2}[mapping]))
 
     def render_frames(self):
         """frames of the current state, without stepping"""
