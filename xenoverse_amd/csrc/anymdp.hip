@@ -433,11 +433,12 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
     const uint64_t* rp = reinterpret_cast<const uint64_t*>(P.sr) + ic;
     const uint64_t t_begin = wall_clock64();
     uint64_t r64 = 0;
+    // records cross between the launches as agent-scope atomics (sc1: coherent over the device without cache maintenance;
+    // an agent-scope release / acquire FENCE is a `buffer_wbl2` per wave: 39 us per step, profiles/r05_b_*).
+    // Every lane polls its own record: one round trip per try (lane 0 first and then the wave costs a second one: 3.95 vs
+    // 3.76 us per step; a second poll in flight half a period behind the first: 3.87 vs 3.83, profiles/r05_o_*); 1,024 waves x
+    // 512 B per ~0.7 us is a tenth of the L2's bandwidth.
     for (;;) {
-      // records cross between the launches as agent-scope atomics (sc1: coherent over the device without cache maintenance;
-      // an agent-scope release / acquire FENCE is a `buffer_wbl2` per wave: 39 us per step, profiles/r05_b_*)
-      // every lane polls its own record: one round trip per try (lane 0 first and then the wave costs a second one: 3.95 vs
-      // 3.x us per step); a wave has one poll in flight, 1,024 waves x 512 B per ~0.7 us is a tenth of the L2's bandwidth
       r64 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (__ballot(((uint32_t)r64 >> XV_ANYMDP_SR_TAG_SHIFT) != want) == 0ull) break;
       __builtin_amdgcn_s_sleep(1);
@@ -1519,7 +1520,6 @@ static void anymdp_pipe_clear(xv_anymdp* h) {      // fields of the overlapped s
   memset(&h->pipe_key, 0, sizeof(h->pipe_key));
 }
 static void anymdp_pipe_drop_graphs(xv_anymdp* h) {
-  if (h->pgraph_exec[1] == h->pgraph_exec[0]) h->pgraph_exec[1] = nullptr;
   for (int q = 0; q < 2; ++q) {
     if (h->pgraph_exec[q]) { (void)hipGraphExecDestroy(h->pgraph_exec[q]); h->pgraph_exec[q] = nullptr; }
     if (h->pgraph[q]) { (void)hipGraphDestroy(h->pgraph[q]); h->pgraph[q] = nullptr; }
@@ -1988,7 +1988,8 @@ static int anymdp_many_plain(xv_anymdp* h, int k, int period, size_t stride, con
 // way behind the join.  Calls shorter than XV_ANYMDP_PIPE_GRAPH_MIN steps take the ordinary path altogether: the second
 // hipGraphLaunch reaches the device ~12-25 us after the first and the join costs a cross-queue wait, so a 20-step burst
 // (~110 us) loses what the overlap gains (measured 5.9-6.4 vs 5.55 us per step; issuing the steps as plain launches
-// alternately on the two streams is host-bound: 5.7; profiles/r05_c_*, r05_d_burst_timeline.txt).  Same launch ticks, same
+// alternately on the two streams is host-bound: 5.7; both chains as the branches of ONE graph: 6.8, and 4.3 instead of 3.7
+// on long calls; profiles/r05_c_*, r05_d_burst_timeline.txt, r05_n_*).  Same launch ticks, same
 // results as the ordinary path (tests/test_gpu_chains.py).
 #define XV_ANYMDP_PIPE_GRAPH_MIN 64      // calls of at least this many steps are overlapped
 static bool anymdp_pipe_selftest(xv_anymdp* h);
@@ -2021,18 +2022,6 @@ static bool anymdp_pipe_graphs(xv_anymdp* h, int period, size_t stride, const in
   (void)hipStreamSynchronize(h->side);
   (void)hipStreamSynchronize(h->eng->stream);
   anymdp_pipe_drop_graphs(h);
-  static const bool one_graph = getenv("XV_ANYMDP_PIPE_ONE_GRAPH") != nullptr;      // experiment: both chains as branches of ONE graph
-  if (one_graph) {
-    if (hipGraphCreate(&h->pgraph[0], 0) != hipSuccess) return false;
-    hipGraphNode_t tails[2] = {nullptr, nullptr};
-    for (int q = 0; q < 2; ++q)
-      if (!anymdp_add_chain(h, h->pgraph[0], &tails[q], h->d_ptick, eff, period, stride, actions, obs, reward, reward_gt,
-                            terminated, truncated, final_obs, mode, q, 2, true))
-        return false;
-    if (!anymdp_add_tick_node(h->pgraph[0], tails, 2, h->d_ptick, period)) return false;
-    if (hipGraphInstantiate(&h->pgraph_exec[0], h->pgraph[0], nullptr, nullptr, 0) != hipSuccess) { h->pgraph_exec[0] = nullptr; return false; }
-    h->pgraph_exec[1] = h->pgraph_exec[0];      // (marks "built"; never launched or destroyed separately)
-  } else
   for (int q = 0; q < 2; ++q) {
     if (hipGraphCreate(&h->pgraph[q], 0) != hipSuccess) return false;
     hipGraphNode_t prev = nullptr;
@@ -2122,7 +2111,7 @@ static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride,
   for (int c = 0; c < cycles; ++c) {
     // both halves or neither: an even half without its odd half leaves the next even launch waiting (bounded, flagged)
     if (hipGraphLaunch(h->pgraph_exec[0], st) != hipSuccess) break;
-    if (h->pgraph_exec[1] != h->pgraph_exec[0] && hipGraphLaunch(h->pgraph_exec[1], h->side) != hipSuccess) { broken = true; break; }
+    if (hipGraphLaunch(h->pgraph_exec[1], h->side) != hipSuccess) { broken = true; break; }
     k += period;
     h->eng->tick = t0 + (uint64_t)k;
   }
