@@ -258,7 +258,7 @@ def choose_search(env, torch, args, n_task, S, A):
 
 def floor_probe():
     """latency and line-rate floors of a 65,536-lane step measured on this box class (scripts/devtools/floor_probe.py, the
-    latest committed profiles/*floor_probe*.json); without one, the round-1 measurements recorded in DESIGN.md 4.1"""
+    latest committed profiles/*floor_probe*.json); without one, the round-1 measurements recorded in HISTORY.md 4.1"""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*floor_probe*.json")), reverse=True):
         try:
@@ -268,7 +268,7 @@ def floor_probe():
         except Exception:
             pass
     return {"empty_launch_us": 2.9, "coop_lines_us": {1: 4.3, 2: 6.75, 3: 9.1}, "random_lines_per_s": 5.0e10,
-            "source": "DESIGN.md 4.1 (round-1 box)"}
+            "source": "HISTORY.md 4.1 (round-1 box)"}
 
 
 def make_tables(eng, torch, _lib, n_task, task_base, seed, S=64, A=8, s0_max=4):

@@ -347,7 +347,7 @@ def test_step_many_equals_single_steps():
         env.set_task(tasks, env_task_index=env_task)
         env.reset()
         extra = np.random.RandomState(12).uniform(-1, 1, (n, 8)).astype(np.float32)
-        if many:      # xv_linds_step_many is a plain launch loop in C over the ring slots (no graph: DESIGN 5.1)
+        if many:      # xv_linds_step_many is a plain launch loop in C over the ring slots (no graph: HISTORY.md 5.1)
             ring = env.step_many(K, acts)                 # 2 ring cycles + 5 steps
             env.step(extra)                               # an ordinary step in between moves the engine tick
             ring = env.step_many(2 * P, acts, out=ring)   # the same ring buffers again

@@ -3,7 +3,7 @@
 //
 // The families' step kernels are 4-6 us each at those sizes — about the cost of launching anything — so stepping them
 // one after the other costs three launch latencies per vector step (14-17 us measured), and separate streams cost more
-// in cross-stream waits than the overlap returns.  Here the three families share ONE grid: workgroups
+// in cross-stream waits than the overlap returns (HISTORY.md 5.1).  Here the three families share ONE grid: workgroups
 // [0, nbA) run the AnyMDP step body, [nbA, nbA + nbL) the LinDS matrix body, the rest the CartPole body — the very
 // functions the families' own kernels wrap (anymdp_step_body / linds_step_mfma_body / cartpole_step_body, called with the
 // workgroup's index inside its family), so every env gets bit for bit what xv_anymdp_step / xv_linds_step /
