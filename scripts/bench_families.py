@@ -263,6 +263,12 @@ def bench_anymdp_tok_refdist(args, n_task=1024, per=64):
             env.set_search(name, n_bucket=16) if name == "auto" else env.set_search(name)
             us = min(timed(lambda: env.step_tokens_many(k, a, out=ring), 3, 1) / k for _ in range(2))
             row[name] = {"us_per_step": us, "kernel": env.token_kernel, "search": env.effective_search}
+        # the same steps with consecutive launches overlapped (two streams, hand-off through the env records: the record
+        # leaves before the observation stage) — xv_anymdp_set_step_many_overlap
+        env.set_step_many_overlap(True)
+        us = min(timed(lambda: env.step_tokens_many(k, a, out=ring), 3, 1) / k for _ in range(2))
+        row["auto, overlapped"] = {"us_per_step": us, "kernel": env.token_kernel, "taken": env.step_many_overlap_state == 1}
+        env.set_step_many_overlap(False)
         cen = env.bucket_census()
         row["census"] = {k2: cen[k2] for k2 in ("p_fallback", "fallbacks_per_launch", "auto_uses_bucket", "obs_lines", "obs_lines_dirty",
                                                "obs_p_fallback")}
@@ -540,9 +546,9 @@ def quick_families(steps=200, warmup=20):
     def tok():      # the POMDP / multi-token step on reference-distribution tasks (cooperative kernel on AUTO)
         r = bench_anymdp_tok_refdist(a)
         v = r["variants"]
-        us = {k: {"auto": v[k]["auto"]["us_per_step"], "per-lane (fence search)": v[k]["fence"]["us_per_step"],
-                  "kernel": v[k]["auto"]["kernel"]} for k in v}
-        one = v["POMDP d_obs=1 d_act=1"]["auto"]["us_per_step"]
+        us = {k: {"auto": v[k]["auto"]["us_per_step"], "auto, overlapped": v[k]["auto, overlapped"]["us_per_step"],
+                  "per-lane (fence search)": v[k]["fence"]["us_per_step"], "kernel": v[k]["auto"]["kernel"]} for k in v}
+        one = min(v["POMDP d_obs=1 d_act=1"]["auto"]["us_per_step"], v["POMDP d_obs=1 d_act=1"]["auto, overlapped"]["us_per_step"])
         # priced in random 128-byte lines: (1, 1) reads 2 dependent lines per env-step, (2, 2) three stages of 4.4 lines
         return {"config": r["workload"], "ms_per_step": one * 1e-3, "env_steps_per_s": 65536 / (one * 1e-6), "us_per_step": us,
                 "dtype": "f64", "note": "ms_per_step / env_steps_per_s: the single-token POMDP; (2, 2) beside it in us_per_step",

@@ -240,3 +240,39 @@ def test_view_argument_checks():
     env.close()
     for e in (bad_base, bad_seed, ok):
         e.close()
+
+
+@pytest.mark.parametrize("kind", ["pomdp", "mtpomdp"])
+def test_overlapped_token_steps_equal_plain_launches(kind):
+    """xv_anymdp_step_tokens_many with the overlap on (cooperative token kernel, HAND): the env record is handed on before the
+    observation stage — every output of the rings, the env records and the tick equal the plain launches', on the
+    reference's own golden POMDP / multi-token tasks; short calls, an odd period and the per-lane kernel take the plain path"""
+    from util import golden_files, load_anymdp_tok_golden
+    tasks = [load_anymdp_tok_golden(p)[1] for p in golden_files("anymdptok_") if ("mtpomdp" in p) == (kind == "mtpomdp")]
+    n = 1536
+    env_task = (np.arange(n) % len(tasks)).astype(np.int32)
+    res = []
+    for overlap in (False, True):
+        env = AnyMDPVecEnv(n, seed=13, autoreset_mode="same_step")
+        env.set_task(tasks, env_task_index=env_task)
+        env.set_search("bucket", n_bucket=16)
+        assert env.token_kernel == "cooperative"
+        env.set_step_many_overlap(overlap)
+        env.reset()
+        d_act = env._tok[1]
+        rng = np.random.RandomState(3)
+        rec = []
+        for P, n_steps in ((8, 75), (8, 64), (7, 70), (8, 20)):
+            acts = torch.as_tensor(rng.randint(0, int(env.na), (P, n, d_act)).astype(np.int32), device=env.device)
+            out = env.step_tokens_many(n_steps, acts)
+            torch.cuda.synchronize()
+            rec.append({k: _np(v).copy() for k, v in out.items()})
+            if overlap:
+                assert env.step_many_overlap_state == (1 if (P % 2 == 0 and n_steps >= 64) else 0)
+        s, st, nr = env.get_state()
+        rec.append({"state": _np(s), "steps": _np(st), "nr": _np(nr), "tick": np.asarray(env.engine.tick)})
+        assert env.check_errors() == 0
+        res.append(rec)
+        env.close()
+    _same(res[0], res[1])
+    assert res[0][0]["terminated"].sum() > 0

@@ -141,6 +141,15 @@ struct xv_anymdp {
     const void* bucket;
     uint64_t seed, gid_base;
   } pipe_key;
+  hipGraph_t tgraph[2];      // the same for xv_anymdp_step_tokens_many (cooperative token kernel, HAND)
+  hipGraphExec_t tgraph_exec[2];
+  struct {
+    int period, mode, fmt, d_obs, d_act;
+    const void* ptrs[7];
+    const void* bucket;
+    const void* obs_bucket;
+    uint64_t seed, gid_base;
+  } tpipe_key;
   // views (xv_anymdp_view): a handle over envs [view_lo, view_lo + a.n_env) of `parent` with an engine (stream, tick,
   // error word) of its own; tables, env records, bucket and observation lines are the parent's (borrowed, never freed here)
   xv_anymdp* parent;
@@ -1119,7 +1128,10 @@ static __global__ __launch_bounds__(256) void anymdp_build_obs_cutlines_kernel(c
 }
 
 // PAIR: d_obs > 1 (two observation lines in flight per round of the observation loop; a single-token POMDP has no second line)
-template <bool INJECT, int FMT, bool PAIR>
+// HAND: overlapped xv_anymdp_step_tokens_many — as the MDP step's HAND (see anymdp_step_body): the wave waits for its envs'
+// records to carry this launch's tag, and stores record + next tag in one agent-scope store as soon as the transition tokens
+// are through — BEFORE the observation stage, so the next step's transition lines fly under this step's observation lines.
+template <bool INJECT, int FMT, bool PAIR, bool HAND = false>
 __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P, AnyMDPTokArgs K, AnyMDPTokIO io, int mode) {
   const uint64_t tick_now = xv_launch_tick(P.tick, P.tick_dev);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1127,23 +1139,40 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
   const int ic = valid ? i : P.n_env - 1;
   const int lane = threadIdx.x & 63;
   const int S = P.S, A = P.A, N = P.n_env, DO = K.d_obs, NBK = P.NBK;
-  const uint2 sr0 = P.sr[ic];
+  uint2 sr0 = make_uint2(0u, 0u);
+  if (!HAND) sr0 = P.sr[ic];
   const uint4 rcu = P.rs_c[ic];
   const double2 rc01 = P.rs_a[ic];
   const uint4 rb = P.rs_b[ic];
   int a_cur = io.action[(size_t)ic * K.d_act];
   const int t = (int)rcu.w, max_steps = (int)(rcu.z & 0x7FFFFFFu);
-  int s = (int)(sr0.x & 0xFFFFu), steps = (int)sr0.y, nr = (sr0.x & XV_ANYMDP_SR_NR) ? 1 : 0;
-  int cterm = (sr0.x & XV_ANYMDP_SR_TERM) ? 1 : 0;
   const uint64_t gid = P.gid_base + (uint64_t)ic;
   uint32_t err = 0;
+  xv_u32x4 w_first{0u, 0u, 0u, 0u};
+  if (HAND) {
+    w_first = xv_env_draw(P.seed, gid, tick_now, 32u);      // the first transition uniform needs no record
+    asm volatile("" : "+v"(w_first.x), "+v"(w_first.y), "+v"(w_first.z), "+v"(w_first.w));
+    const uint32_t want = XV_ANYMDP_SR_TAG(tick_now);
+    const uint64_t* rp = reinterpret_cast<const uint64_t*>(P.sr) + ic;
+    const uint64_t t_begin = wall_clock64();
+    uint64_t r64 = 0;
+    for (;;) {
+      r64 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__ballot(((uint32_t)r64 >> XV_ANYMDP_SR_TAG_SHIFT) != want) == 0ull) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t_begin > XV_ANYMDP_HAND_TIMEOUT) { err |= XV_DEVERR_HANDOFF; break; }
+    }
+    sr0 = make_uint2((uint32_t)r64, (uint32_t)(r64 >> 32));
+  }
+  int s = (int)(sr0.x & 0xFFFFu), steps = (int)sr0.y, nr = (sr0.x & XV_ANYMDP_SR_NR) ? 1 : 0;
+  int cterm = (sr0.x & XV_ANYMDP_SR_TERM) ? 1 : 0;
   if (valid && io.final_obs) for (int k = 0; k < DO; ++k) io.final_obs[(size_t)i * DO + k] = -1;
 
   // uniforms: transition token k -> purpose 32 + k words (0,1), its reward normal words (2,3); observation token k ->
   // purpose 64 + k, words (0,1) after a step and (2,3) after a restart (oracle: tok_draws)
   auto act_draw = [&](int k, double& u, xv_u32x4& w) {
     if (INJECT) { u = io.u[(size_t)k * N + ic]; }
-    else { w = xv_env_draw(P.seed, gid, tick_now, 32u + (uint32_t)k); u = xv_u53(w.x, w.y); }
+    else { w = (HAND && k == 0) ? w_first : xv_env_draw(P.seed, gid, tick_now, 32u + (uint32_t)k); u = xv_u53(w.x, w.y); }
   };
   // both uniforms of observation token k from ONE call: after a step (us), after a restart (ur_)
   auto obs_draw = [&](int k, double& us, double& ur_) {
@@ -1274,6 +1303,12 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
     else if (mode == XV_AUTORESET_NEXT_STEP) nr = 1;
   }
   const bool keep_final = done && mode == XV_AUTORESET_SAME_STEP && io.final_obs != nullptr;
+  if (HAND) {      // the env's record is final here (a restart state was drawn under the first line): hand the env on
+    const uint2 q = do_reset ? anymdp_sr_pack(s_new, 0, 0, (int)((rcu.z >> (27 + k0r)) & 1u)) : anymdp_sr_pack(s, steps, nr, cterm);
+    const uint32_t x = q.x | (XV_ANYMDP_SR_TAG(tick_now + 1u) << XV_ANYMDP_SR_TAG_SHIFT);
+    if (valid) __hip_atomic_store(reinterpret_cast<uint64_t*>(P.sr) + i, (uint64_t)x | ((uint64_t)q.y << 32), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+  }
 
   // ---- observation tokens (:148-157) of the state the step ended in, two lines in flight; an env that restarts reports
   //      the observation of its restart state instead (and the step's as final_obs) ----
@@ -1335,7 +1370,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
     nr = 0;
   }
   if (valid) {
-    P.sr[i] = anymdp_sr_pack(s, steps, nr, cterm);
+    if (!HAND) P.sr[i] = anymdp_sr_pack(s, steps, nr, cterm);
     io.reward[i] = rsum; io.reward_gt[i] = rgsum;
     io.terminated[i] = (uint8_t)term; io.truncated[i] = (uint8_t)trunc;
     if (io.steps_out) io.steps_out[i] = (int32_t)steps;
@@ -1516,6 +1551,8 @@ static void anymdp_pipe_clear(xv_anymdp* h) {      // fields of the overlapped s
   h->overlap = 0; h->pipe_failed = false; h->pipe_used_last = false; h->side = nullptr;
   h->side_ev[0] = h->side_ev[1] = nullptr;
   h->pgraph[0] = h->pgraph[1] = nullptr; h->pgraph_exec[0] = h->pgraph_exec[1] = nullptr;
+  h->tgraph[0] = h->tgraph[1] = nullptr; h->tgraph_exec[0] = h->tgraph_exec[1] = nullptr;
+  memset(&h->tpipe_key, 0, sizeof(h->tpipe_key));
   h->d_ptick = nullptr; h->ptick_value = 0; h->ptick_valid = false;
   memset(&h->pipe_key, 0, sizeof(h->pipe_key));
 }
@@ -1523,8 +1560,11 @@ static void anymdp_pipe_drop_graphs(xv_anymdp* h) {
   for (int q = 0; q < 2; ++q) {
     if (h->pgraph_exec[q]) { (void)hipGraphExecDestroy(h->pgraph_exec[q]); h->pgraph_exec[q] = nullptr; }
     if (h->pgraph[q]) { (void)hipGraphDestroy(h->pgraph[q]); h->pgraph[q] = nullptr; }
+    if (h->tgraph_exec[q]) { (void)hipGraphExecDestroy(h->tgraph_exec[q]); h->tgraph_exec[q] = nullptr; }
+    if (h->tgraph[q]) { (void)hipGraphDestroy(h->tgraph[q]); h->tgraph[q] = nullptr; }
   }
   memset(&h->pipe_key, 0, sizeof(h->pipe_key));
+  memset(&h->tpipe_key, 0, sizeof(h->tpipe_key));
   h->ptick_valid = false;
 }
 static void anymdp_pipe_release(xv_anymdp* h) {
@@ -2074,6 +2114,8 @@ static bool anymdp_pipe_selftest(xv_anymdp* h) {
 
 // the whole ring cycles of a call, overlapped; *issued = steps issued (0: the caller takes the ordinary path for all of it).
 // -> XV_OK, or an error when a cycle went out in part (the streams are joined either way)
+static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int period, int* issued);
+
 static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride, const int32_t* actions, int32_t* obs,
                            float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs,
                            int mode, int* issued) {
@@ -2081,12 +2123,19 @@ static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride,
   const int cycles = n_steps / period;
   static const int min_steps = getenv("XV_ANYMDP_PIPE_MIN_STEPS") ? atoi(getenv("XV_ANYMDP_PIPE_MIN_STEPS")) : XV_ANYMDP_PIPE_GRAPH_MIN;
   if (cycles <= 0 || period % 2 != 0 || n_steps < min_steps) return XV_OK;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;      // not inside a stream capture: the set-up synchronises
+  if (hipStreamIsCapturing(h->eng->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return XV_OK; }
   if (!anymdp_pipe_setup(h) ||
       !anymdp_pipe_graphs(h, period, stride, actions, obs, reward, reward_gt, terminated, truncated, final_obs, mode)) {
     (void)hipGetLastError();
     h->pipe_failed = true;
     return XV_OK;
   }
+  return anymdp_pipe_launch(h, h->pgraph_exec, cycles, period, issued);
+}
+
+// `cycles` replays of the two cycle graphs ex[0] (engine's stream) / ex[1] (side stream): tags, tick words, fork, launches, join
+static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int period, int* issued) {
   hipStream_t st = h->eng->stream;
   const uint64_t t0 = h->eng->tick;
   // every record gets the tag of the first step (whatever ran since the last overlapped call wrote the tag bits as 0)
@@ -2110,8 +2159,8 @@ static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride,
   bool broken = false;
   for (int c = 0; c < cycles; ++c) {
     // both halves or neither: an even half without its odd half leaves the next even launch waiting (bounded, flagged)
-    if (hipGraphLaunch(h->pgraph_exec[0], st) != hipSuccess) break;
-    if (hipGraphLaunch(h->pgraph_exec[1], h->side) != hipSuccess) { broken = true; break; }
+    if (hipGraphLaunch(ex[0], st) != hipSuccess) break;
+    if (hipGraphLaunch(ex[1], h->side) != hipSuccess) { broken = true; break; }
     k += period;
     h->eng->tick = t0 + (uint64_t)k;
   }
@@ -2638,6 +2687,60 @@ extern "C" int xv_anymdp_step_tokens_info(xv_anymdp* h, const int32_t* action, i
 // n_steps token steps issued from C over ring buffers: step k reads actions slot k % period ([period][n_env][d_act]) and
 // writes slot k % period of the outputs (obs / final_obs [period][n_env][d_obs], the others [period][n_env]); equals
 // n_steps calls of xv_anymdp_step_tokens (a Python / ctypes loop costs more per call than the 10-20 us kernel)
+// the two cycle graphs of the overlapped token step: HAND instantiations of the cooperative kernel, ring slots q, q + 2, ...
+static bool anymdp_tok_pipe_graphs(xv_anymdp* h, int period, const int32_t* action, int32_t* obs, float* reward, float* reward_gt,
+                                   uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
+  const void* ptrs[7] = {action, obs, reward, reward_gt, terminated, truncated, final_obs};
+  auto& K = h->tpipe_key;
+  if (h->tgraph_exec[0] && h->tgraph_exec[1] && K.period == period && K.mode == mode && K.fmt == h->a.bfmt && K.d_obs == h->d_obs &&
+      K.d_act == h->d_act && K.bucket == (const void*)h->a.bucket && K.obs_bucket == (const void*)h->obs_bucket &&
+      K.seed == h->eng->seed && K.gid_base == h->eng->env_id_base && memcmp(K.ptrs, ptrs, sizeof(ptrs)) == 0)
+    return true;
+  (void)hipStreamSynchronize(h->side);
+  (void)hipStreamSynchronize(h->eng->stream);
+  anymdp_pipe_drop_graphs(h);
+  const bool pair = h->d_obs > 1;
+  void* fn = h->a.bfmt == 1 ? (pair ? reinterpret_cast<void*>(&anymdp_tok_step_coop_kernel<false, 1, true, true>)
+                                    : reinterpret_cast<void*>(&anymdp_tok_step_coop_kernel<false, 1, false, true>))
+                            : (pair ? reinterpret_cast<void*>(&anymdp_tok_step_coop_kernel<false, 2, true, true>)
+                                    : reinterpret_cast<void*>(&anymdp_tok_step_coop_kernel<false, 2, false, true>));
+  const size_t n = (size_t)h->a.n_env, da = (size_t)h->d_act, dob = (size_t)h->d_obs;
+  const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
+  for (int q = 0; q < 2; ++q) {
+    if (hipGraphCreate(&h->tgraph[q], 0) != hipSuccess) return false;
+    hipGraphNode_t prev = nullptr;
+    for (int j = q; j < period; j += 2) {
+      AnyMDPArgs a = h->a;
+      a.seed = h->eng->seed; a.gid_base = h->eng->env_id_base;
+      a.tick = (uint64_t)j; a.tick_dev = h->d_ptick + q;
+      AnyMDPTokArgs KA{h->obs_cdf, h->n_obs, h->d_obs, h->d_act, h->obs_bucket};
+      const size_t o = (size_t)j * n;
+      AnyMDPTokIO io{action + o * da, nullptr, nullptr, nullptr, nullptr, nullptr, obs + o * dob, reward + o, reward_gt + o,
+                     terminated + o, truncated + o, final_obs ? final_obs + o * dob : nullptr};
+      int md = mode;
+      void* params[] = {&a, &KA, &io, &md};
+      hipKernelNodeParams np;
+      memset(&np, 0, sizeof(np));
+      np.func = fn; np.gridDim = grid; np.blockDim = block; np.kernelParams = params;
+      hipGraphNode_t node;
+      if (hipGraphAddKernelNode(&node, h->tgraph[q], prev ? &prev : nullptr, prev ? 1 : 0, &np) != hipSuccess) return false;
+      prev = node;
+    }
+    if (!anymdp_add_tick_node(h->tgraph[q], &prev, 1, h->d_ptick + q, period)) return false;
+    if (hipGraphInstantiate(&h->tgraph_exec[q], h->tgraph[q], nullptr, nullptr, 0) != hipSuccess) { h->tgraph_exec[q] = nullptr; return false; }
+  }
+  K.period = period; K.mode = mode; K.fmt = h->a.bfmt; K.d_obs = h->d_obs; K.d_act = h->d_act;
+  K.bucket = (const void*)h->a.bucket; K.obs_bucket = (const void*)h->obs_bucket;
+  K.seed = h->eng->seed; K.gid_base = h->eng->env_id_base;
+  memcpy(K.ptrs, ptrs, sizeof(ptrs));
+  return true;
+}
+
+// n_steps token steps issued from C over ring buffers: step k reads actions slot k % period ([period][n_env][d_act]) and
+// writes slot k % period of the outputs (obs / final_obs [period][n_env][d_obs], the others [period][n_env]); equals
+// n_steps calls of xv_anymdp_step_tokens (a Python / ctypes loop costs more per call than the 10-20 us kernel).
+// With xv_anymdp_set_step_many_overlap on, whole cycles of an even period (calls of >= 64 steps, cooperative kernel, host
+// tick) are issued on two streams with the hand-off through the env records, as xv_anymdp_step_many's.
 extern "C" int xv_anymdp_step_tokens_many(xv_anymdp* h, int n_steps, int period, const int32_t* action, int32_t* obs,
                                           float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated,
                                           int32_t* final_obs, int autoreset_mode) {
@@ -2645,7 +2748,28 @@ extern "C" int xv_anymdp_step_tokens_many(xv_anymdp* h, int n_steps, int period,
   XV_CHECK_ARG(action && obs && reward && reward_gt && terminated && truncated);
   XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
   const size_t n = (size_t)h->a.n_env, da = (size_t)h->d_act, dob = (size_t)h->d_obs;
-  for (int k = 0; k < n_steps; ++k) {
+  int k = 0;
+  h->pipe_used_last = false;
+  const int cycles = n_steps / period;
+  if (h->overlap && !h->eng->dev_tick && !h->pipe_failed && anymdp_tok_coop(h) && cycles > 0 && period % 2 == 0 &&
+      n_steps >= XV_ANYMDP_PIPE_GRAPH_MIN) {
+    XV_HIP(hipSetDevice(h->eng->device));
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(h->eng->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    if (!capturing) {
+      if (anymdp_pipe_setup(h) && anymdp_tok_pipe_graphs(h, period, action, obs, reward, reward_gt, terminated, truncated,
+                                                          final_obs, autoreset_mode)) {
+        const int rc = anymdp_pipe_launch(h, h->tgraph_exec, cycles, period, &k);
+        if (rc != XV_OK) return rc;
+      } else {
+        (void)hipGetLastError();
+        h->pipe_failed = true;
+      }
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  for (; k < n_steps; ++k) {
     const size_t o = (size_t)(k % period) * n;
     anymdp_bind_rng(h, 1);
     AnyMDPTokIO io{action + o * da, nullptr, nullptr, nullptr, nullptr, nullptr, obs + o * dob, reward + o, reward_gt + o,
