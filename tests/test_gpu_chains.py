@@ -275,4 +275,4 @@ def test_overlapped_token_steps_equal_plain_launches(kind):
         res.append(rec)
         env.close()
     _same(res[0], res[1])
-    assert res[0][0]["terminated"].sum() > 0
+    assert res[0][0]["obs"].std() > 0 and (res[0][0]["terminated"].sum() + res[0][0]["truncated"].sum() + res[0][1]["reward"].std()) > 0
