@@ -421,13 +421,19 @@ def bench_anymdp_refdist(args, n_task=1024, per=64):
     for name in ("auto", "fence", "bucket"):
         env.set_search(name, n_bucket=16) if name != "fence" else env.set_search("fence")
         out[name] = min(timed(lambda: env.step_many(k, acts, out=ring), 3, 1) / k for _ in range(2))
+    # the AUTO search with consecutive launches overlapped (xv_anymdp_set_step_many_overlap; calls of >= 64 steps)
+    env.set_search("auto", n_bucket=16)
+    env.set_step_many_graph("on")
+    env.set_step_many_overlap(True)
+    out["auto, overlapped"] = min(timed(lambda: env.step_many(k, acts, out=ring), 3, 1) / k for _ in range(2))
+    overlapped = env.step_many_overlap_state == 1
     errs = env.check_errors()
     env.close()
-    us = out["auto"]
+    us = min(out["auto"], out["auto, overlapped"])
     algo = (8 * S + 50) * n
     return {"family": "anymdp_refdist", "workload": "anymdp S=64 A=8, 65,536 envs = 1,024 device-sampled reference-distribution "
             "tasks x 64 (xv_anymdp_sample_tasks), launches from C", "dtype": "f64", "auto_search": auto,
-            "us_per_step": out, "env_steps_per_s": n / (us * 1e-6),
+            "us_per_step": out, "overlap_taken": overlapped, "env_steps_per_s": n / (us * 1e-6),
             "bucket_census": {k2: cen[k2] for k2 in ("n_bucket", "format", "cuts_per_line", "lines", "lines_dirty", "p_fallback",
                                                     "fallbacks_per_launch", "auto_limit", "auto_uses_bucket")},
             "roofline": {"bound": "hbm", "achieved": algo / (us * 1e-6) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
@@ -534,7 +540,8 @@ def quick_families(steps=200, warmup=20):
                              "us_per_vector_step": r["us_per_vector_step"], "note": r["roofline"]["note"]}}
     def refdist():
         r = bench_anymdp_refdist(a)
-        return {"config": r["workload"], "ms_per_step": r["us_per_step"]["auto"] * 1e-3, "env_steps_per_s": r["env_steps_per_s"],
+        return {"config": r["workload"], "ms_per_step": min(r["us_per_step"]["auto"], r["us_per_step"]["auto, overlapped"]) * 1e-3,
+                "env_steps_per_s": r["env_steps_per_s"],
                 "auto_search": r["auto_search"], "us_per_step": r["us_per_step"], "bucket_census": r["bucket_census"],
                 "dtype": "f64", "roofline": r["roofline"], "device_error_flags": r["device_error_flags"]}
 
