@@ -82,4 +82,25 @@ for _ in range(25):
     ret += reward.mean().item()
 print("captured loop: %d steps replayed, mean reward of the sampled steps %.4f" % (loop.steps_replayed, ret / 25))
 loop.close()
+
+# 8. long open-loop bursts: step_many with consecutive launches overlapped on two streams (each wave takes its envs over from
+#    the same wave of the step before through a tag in the env record) — same results, ~1.3x the steps per second
+actions = torch.randint(0, 4, (32, 4096), device=env.device, dtype=torch.int32)
+env.reset(seed=123)
+ring_a = {k: v.clone() for k, v in env.step_many(256, actions).items()}
+env.reset(seed=123)
+env.set_step_many_graph("on")
+env.set_step_many_overlap(True)
+ring_b = env.step_many(256, actions)
+torch.cuda.synchronize()
+print("overlapped step_many: taken =", env.step_many_overlap_state == 1, "| equal to the one-stream result:",
+      all(torch.equal(ring_a[k], ring_b[k]) for k in ring_a), "| device error flags:", env.check_errors())
+
+# 9. sub-batches: K envs over contiguous ranges of this env's envs, each on a stream of its own (same states, same draws)
+subs = env.split(4)
+for sub in subs:
+    with torch.cuda.stream(sub.stream):
+        o = sub.step(torch.zeros(sub.num_envs, dtype=torch.int32, device=env.device))
+torch.cuda.synchronize()
+print("sub-batches:", len(subs), "x", subs[0].num_envs, "envs; observation of sub 2:", tuple(o[0].shape))
 env.close()
