@@ -96,11 +96,36 @@ def soak_mdp(rng, seed):
         if mode == "disabled" and o[3].any():
             ur2 = rng.random_sample(n_env)
             env.reset_injected(ur2, mask=o[3]); ora.reset_injected(ur2, mask=o[3])
+    many = ""
+    if mode != "disabled":      # a burst issued from C (step_many): plain, graph replay, overlapped launches, K chains
+        P = int(rng.choice([2, 4, 6, 7, 8]))
+        n_steps = int(rng.choice([rng.randint(1, 3 * P + 1), rng.randint(64, 100)]))
+        how = str(rng.choice(["plain", "graph", "overlap", "chains"]))
+        acts = rng.randint(0, A, (P, n_env)).astype(np.int32)
+        env.set_step_many_graph(how != "plain")
+        env.set_step_many_overlap(how == "overlap")
+        chains = 1
+        if how == "chains":
+            chains = int(rng.choice([k for k in (2, 4, 8) if n_env % k == 0] or [1]))
+        tick0 = env.engine.tick
+        ring = env.step_many(n_steps, torch.as_tensor(acts, device=env.device), chains=chains,
+                             how=str(rng.choice(["streams", "graph"])))
+        torch.cuda.synchronize()
+        last = {}
+        for k in range(n_steps):
+            last[k % P] = ora.step(seed, env.engine.env_id_base, tick0 + k, acts[k % P], MODES[mode])
+        for slot, o in last.items():
+            _check(np.array_equal(_np(ring["obs"][slot]), o[0]) and np.array_equal(_np(ring["terminated"][slot]), o[3]) and
+                   np.array_equal(_np(ring["truncated"][slot]), o[4]), "step_many ring (%s)" % how)
+        s, st, nr = env.get_state()
+        _check(np.array_equal(_np(s), ora.state) and np.array_equal(_np(st), ora.steps), "state / steps after step_many (%s)" % how)
+        _check(env.engine.tick == tick0 + n_steps, "tick after step_many")
+        many = " many=%s/P%d/n%d/K%d/ov%d" % (how, P, n_steps, chains, env.step_many_overlap_state)
     flags = env.check_errors() if mode != "disabled" else 0
     eff = env.effective_search
     env.close()
-    return "mdp S=%d A=%d tasks=%d envs=%d search=%s->%s nb=%d mode=%s big_obs=%d steps=%d flags=%d" % (
-        S, A, n_task, n_env, search, eff, nb, mode, big_obs, T, flags)
+    return "mdp S=%d A=%d tasks=%d envs=%d search=%s->%s nb=%d mode=%s big_obs=%d steps=%d flags=%d%s" % (
+        S, A, n_task, n_env, search, eff, nb, mode, big_obs, T, flags, many)
 
 
 def soak_tok(rng, seed):
