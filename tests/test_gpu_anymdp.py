@@ -462,6 +462,30 @@ def test_full_size_config_2a_properties_and_subset_vs_oracle(search):
         assert np.array_equal(ora.state, _np(s_after[sub_t])) and np.array_equal(ora.steps, _np(st_after[sub_t]))
         n_sub_done += int((eterm | etrunc).sum())
     assert n_done > 65536 and n_sub_done > 8192 and env.check_errors() == 0
+    # -- the same envs stepped from C: overlapped launches (two streams, hand-off through the env records) against the
+    #    one-stream path, every ring slot of 4 cycles + 9 steps, the env records and the tick, bit for bit; the scattered
+    #    subset of the last ring against the oracle --
+    P = 32
+    acts = torch.randint(0, A, (P, n_env), generator=g, device=d, dtype=torch.int32)
+    env.set_step_many_graph("on")
+    snap = []
+    for overlap in (False, True):
+        env.reset(seed=77)
+        env.set_step_many_overlap(overlap)
+        tick0 = env.engine.tick
+        ring = env.step_many(4 * P + 9, acts)
+        torch.cuda.synchronize()
+        assert env.step_many_overlap_state == (1 if overlap else 0)
+        snap.append(([v.clone() for v in ring.values()], [x.clone() for x in env.get_state()], env.engine.tick))
+    for x, y in zip(snap[0][0] + snap[0][1], snap[1][0] + snap[1][1]):
+        assert torch.equal(x, y)
+    assert snap[0][2] == snap[1][2] == tick0 + 4 * P + 9
+    ora.reset(seed, first, (77 & 0xFFFFFFFF) << 24)
+    for k in range(4 * P + 9):
+        o = ora.step(seed, first, tick0 + k, _np(acts[k % P][sub_t]), 2)
+    last = (4 * P + 8) % P
+    assert np.array_equal(o[0], _np(snap[1][0][0][last][sub_t])) and np.array_equal(ora.state, _np(snap[1][1][0][sub_t]))
+    assert env.check_errors() == 0
     env.close()
 
 
