@@ -252,6 +252,8 @@ int xv_anymdp_step_many_graph_state(xv_anymdp* h);
  * bounded (2 ms): if the two streams do not run concurrently it expires, the wave goes on and XV_DEVERR_HANDOFF is set in
  * the engine's error word — wrong data, flagged, never a hang.  Needs the fence or bucket search and the host tick;
  * otherwise, and for odd periods, step_many behaves as without it.
+ * One handle per device at a time, never a view (XV_ERR_UNSUPPORTED): two overlapped calls in flight can block each other
+ * on the hardware queues their streams share.  Not inside a stream capture (the call takes the one-stream path).
  * xv_anymdp_step_many_overlap_state: 1 the last call overlapped, 0 it did not, -1 the path failed and is no longer tried. */
 int xv_anymdp_set_step_many_overlap(xv_anymdp* h, int on);
 int xv_anymdp_step_many_overlap_state(xv_anymdp* h);

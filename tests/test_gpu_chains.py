@@ -276,3 +276,24 @@ def test_overlapped_token_steps_equal_plain_launches(kind):
         env.close()
     _same(res[0], res[1])
     assert res[0][0]["obs"].std() > 0 and (res[0][0]["terminated"].sum() + res[0][0]["truncated"].sum() + res[0][1]["reward"].std()) > 0
+
+
+def test_one_overlapped_handle_per_device_and_never_a_view():
+    """two overlapped calls in flight can block each other on the hardware queues their streams share: the second handle and
+    any view are refused; closing (or switching off) the first frees the slot"""
+    tab = oracle.anymdp_synth(seed=5, task_index_base=0, n_task=4, S=64, A=8, s0_max=4)
+    a = AnyMDPVecEnv(512, seed=1)
+    a.set_task(_dev_tables(tab))
+    b = AnyMDPVecEnv(512, seed=2)
+    b.set_task(_dev_tables(tab))
+    a.set_step_many_overlap(True)
+    with pytest.raises(_lib.XenoError):
+        b.set_step_many_overlap(True)
+    a.reset()
+    with pytest.raises(_lib.XenoError):
+        a.split(2)[0].set_step_many_overlap(True)
+    a.set_step_many_overlap(False)
+    b.set_step_many_overlap(True)
+    b.close()                                    # a closed owner gives the slot back
+    a.set_step_many_overlap(True)
+    a.close()

@@ -39,6 +39,7 @@
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #define XV_ANYMDP_BLK 7   // next states per block
 #define XV_ANYMDP_MAX_CHAINS 16
@@ -1687,6 +1688,8 @@ extern "C" int xv_anymdp_create(xv_engine* e, int n_env, int n_task, int S, int 
   return XV_OK;
 }
 
+extern "C" int xv_anymdp_set_step_many_overlap(xv_anymdp* h, int on);
+
 static void anymdp_drop_chain_graph(xv_anymdp* h) {
   if (h->cgraph_exec) { (void)hipGraphExecDestroy(h->cgraph_exec); h->cgraph_exec = nullptr; }
   if (h->cgraph) { (void)hipGraphDestroy(h->cgraph); h->cgraph = nullptr; }
@@ -1701,6 +1704,7 @@ extern "C" int xv_anymdp_destroy(xv_anymdp* h) {
   }
   (void)hipSetDevice(h->eng->device);
   (void)hipStreamSynchronize(h->eng->stream);
+  if (h->overlap) (void)xv_anymdp_set_step_many_overlap(h, 0);      // gives the device's overlap slot back
   AnyMDPArgs& a = h->a;
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   if (h->graph) (void)hipGraphDestroy(h->graph);
@@ -1750,7 +1754,7 @@ extern "C" int xv_anymdp_view(xv_anymdp* parent, xv_engine* e, int env_lo, int n
   memset(&h->graph_key, 0, sizeof(h->graph_key));
   h->chain_ev = nullptr; h->cgraph = nullptr; h->cgraph_exec = nullptr;
   memset(&h->cgraph_key, 0, sizeof(h->cgraph_key));
-  anymdp_pipe_clear(h);
+  anymdp_pipe_clear(h);      // (overlap off: a view never overlaps)
   AnyMDPArgs& a = h->a;
   a.sr += env_lo;
   if (a.rs_a) { a.rs_a += env_lo; a.rs_b += env_lo; a.rs_c += env_lo; }
@@ -2177,10 +2181,33 @@ static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int 
   return XV_OK;
 }
 
+// One handle per device may have the overlap on at a time, and never a view.  Two overlapped calls in flight at once can
+// deadlock on the hardware queues: streams are mapped onto a few queues, each in order, and a launch that waits for a wave
+// of a launch queued BEHIND another handle's waiting launch never gets it (measured: two views, each overlapped, 4.5 us
+// per step instead of 3.6; four, their waits ran into the bound — scripts/devtools/probe_views_overlap.py).
+static std::mutex g_overlap_mu;
+static xv_anymdp* g_overlap_owner[64] = {nullptr};
+
 extern "C" int xv_anymdp_set_step_many_overlap(xv_anymdp* h, int on) {
   XV_CHECK_ARG(h != nullptr && (on == 0 || on == 1));
+  const int dev = h->eng->device;
+  XV_CHECK_ARG(dev >= 0 && dev < 64);
+  std::lock_guard<std::mutex> lock(g_overlap_mu);
+  if (on) {
+    if (h->parent != nullptr) {
+      xv_set_error("xv_anymdp_set_step_many_overlap: not on a view (overlap the parent's step_many instead)");
+      return XV_ERR_UNSUPPORTED;
+    }
+    if (g_overlap_owner[dev] != nullptr && g_overlap_owner[dev] != h) {
+      xv_set_error("xv_anymdp_set_step_many_overlap: another handle on device %d has the overlap on; one at a time", dev);
+      return XV_ERR_UNSUPPORTED;
+    }
+    g_overlap_owner[dev] = h;
+    h->pipe_failed = false;
+  } else if (g_overlap_owner[dev] == h) {
+    g_overlap_owner[dev] = nullptr;
+  }
   h->overlap = on;
-  if (on) h->pipe_failed = false;
   return XV_OK;
 }
 
