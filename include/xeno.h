@@ -45,8 +45,11 @@ extern "C" {
  *    from the step launch); xv_mixed_supported; xv_anymdp_sample_tasks up to 256 states; xv_maze_set_precision accepts
  *    XV_MAZE_FILTER_EXACT_DIRECT (a new value of an existing argument: no bump)
  * 9: xv_anymdp_step_tokens_info (the POMDP / multi-token step writes steps and the done mask itself); xv_cartpole_step_info,
- *    xv_acrobot_step_info (the done mask from the step launch); xv_maze_set_raycast_mapping */
-#define XV_ABI_VERSION 10
+ *    xv_acrobot_step_info (the done mask from the step launch); xv_maze_set_raycast_mapping
+ * 10: overlapped step_many (xv_anymdp_set_step_many_overlap / _overlap_state), sub-batch views (xv_anymdp_view,
+ *    xv_anymdp_step_many_chains), xv_anymdp_build_rows, xv_pack_rollout_f32 / xv_unpack_rollout_f32, XV_DEVERR_HANDOFF
+ * 11: the overlap switch also covers xv_mixed_step_many; xv_mixed_step_many_overlap_state */
+#define XV_ABI_VERSION 11
 
 /* return codes */
 #define XV_OK 0
@@ -763,6 +766,15 @@ int xv_mixed_step(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mixed_io* 
 int xv_mixed_supported(xv_anymdp* a, xv_linds* l, xv_cartpole* c);
 int xv_mixed_step_many(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mixed_io* ring, int n_steps, int period,
                        int autoreset_mode);
+/* Overlapped xv_mixed_step_many: with xv_anymdp_set_step_many_overlap(a, 1) on the AnyMDP handle, calls of >= 64 steps over
+ * an even period issue the ring's even slots on the engines' stream and the odd slots on a side stream (two hipGraphs), so
+ * the launch of step k + 1 runs under step k; every wave takes its envs over from the same wave of the step before (AnyMDP:
+ * tag in the env record; LinDS and CartPole: one word per wave).  Same launch ticks, same results, bit for bit.  Needs
+ * the three handles on three engines of their own (host ticks, one stream); otherwise, and for the steps beyond the last
+ * whole ring cycle, the ordinary loop runs.  A wait that exceeds 50 ms sets XV_DEVERR_HANDOFF (never a hang).
+ * xv_mixed_step_many_overlap_state: 1 the last call with this AnyMDP handle was overlapped, 0 it was not, -1 the overlapped
+ * path failed on this device (streams do not run concurrently, graph build) and is no longer tried. */
+int xv_mixed_step_many_overlap_state(xv_anymdp* a);
 
 #ifdef __cplusplus
 }

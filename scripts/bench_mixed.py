@@ -99,6 +99,8 @@ def run_mixed(args, torch, dist, dinfo, rank, world, local, wd, selftest=False, 
         from xenoverse_amd.mixed_shard import MixedShare
         share = MixedShare(rank, world, tot["anymdp"], tot["linds"], tot["cartpole"], T=T, seed=args.seed, device=str(dev))
         chunk = share.chunk
+        if getattr(args, "overlap", "auto") != "off":
+            share.set_overlap(True)       # calls of >= 64 steps: two streams, the launch of step k + 1 under step k
         share.random_actions(args.seed + 17 * rank)
         share.reset()
         share.step_many(T)
@@ -192,6 +194,7 @@ def run_mixed(args, torch, dist, dinfo, rank, world, local, wd, selftest=False, 
     R = max(1, args.repeats)
     wall, ev_ms = timed_pass(False, R)
     errs = share.check_errors() if gpu else 0
+    overlapped = bool(gpu and share.overlap_state == 1)
     wall_g, check = None, None
     if gather is not None:
         if wd is not None:
@@ -247,8 +250,12 @@ def run_mixed(args, torch, dist, dinfo, rank, world, local, wd, selftest=False, 
                                % (world * n_rank, world, per["anymdp"], per["anymdp"] // 64, per["linds"], per["linds"] // 64,
                                   per["cartpole"], per["cartpole"] // 8),
                    "envs_per_gpu": per, "envs_total": {f: n * world for f, n in per.items()},
-                   "launch": "one fused kernel per vector step of a rank's share (xv_mixed_step_many)" if (share is None or share.fused)
+                   "launch": ("one fused kernel per vector step of a rank's share (xv_mixed_step_many)" +
+                              ("; consecutive steps alternate between two HIP streams and overlap, every wave takes its envs over "
+                               "from the same wave of the step before (xv_anymdp_set_step_many_overlap)" if overlapped else ""))
+                             if (share is None or share.fused)
                              else "three launches per vector step (no fused instantiation for these handles)",
+                   "overlap": overlapped, "overlap_requested": getattr(args, "overlap", "auto"),
                    "sharding": "contiguous ranges per family (shard_range), env_id_base = the range's start, tasks named by global "
                                "index: no data-path collective",
                    "exchange": gather_note, "chunk_bytes_per_rank": chunk.bytes_per_rank, "chunk_steps": T,
@@ -258,6 +265,7 @@ def run_mixed(args, torch, dist, dinfo, rank, world, local, wd, selftest=False, 
             "frac": algo / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "frac_wall": algo / (wall / args.steps) / 1e9 / HBM_PEAK_GBS,
             "traffic": None, "kernel": "mixed_step_kernel (anymdp + linds + cartpole step bodies in one grid)",
             "avg_launch_us": us, "algorithmic_bytes_per_launch": algo,
+            "avg_launch_us_note": "overlapped launches: time per launch in steady state = timed region / launches" if overlapped else None,
             "note": "a 13 MB vector step: launch-latency bound (an empty launch is 2.7 us)"},
         "rccl": dinfo.get("rccl"), "rccl_ranks": (gather.comm.count() if transport == "rccl" else dinfo.get("rccl_ranks")),
         "transport": transport,

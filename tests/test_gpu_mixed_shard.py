@@ -91,3 +91,43 @@ def test_device_float_records_match_the_host_format():
 def test_shares_must_be_whole_tasks():
     with pytest.raises(ValueError):
         MixedShare(0, 3, 2048, 1024, 1024, T=4)          # 2048 / 3 is not a multiple of 64
+
+
+@pytest.mark.parametrize("mode,T,n_steps", [("same_step", 8, 203), ("next_step", 16, 128), ("disabled", 2, 64)])
+def test_overlapped_step_many_equals_the_ordinary_one(mode, T, n_steps):
+    """Two HIP streams, the launch of step k + 1 under step k, hand-off per wave (AnyMDP: tag in the env record; LinDS and
+    CartPole: a word per wave): rings, states, step counters and later steps equal the one-stream loop's bit for bit"""
+    tot = (4096, 2048, 1024 + 8)                              # a partial last CartPole wave
+    rng = np.random.RandomState(5)
+    acts = dict(a=rng.randint(0, 8, (T, tot[0])).astype(np.int32), l=rng.uniform(-1.2, 1.2, (T, tot[1], 8)).astype(np.float32),
+                c=rng.randint(0, 2, (T, tot[2])).astype(np.int32))
+    res = []
+    for overlap in (False, True):
+        sh = MixedShare(0, 1, *tot, T=T, seed=21, linds_ns=16, autoreset_mode=mode)
+        sh.set_actions(acts["a"], acts["l"], acts["c"])
+        if overlap:
+            sh.set_overlap(True)
+        sh.reset()
+        rec = []
+        for n in (n_steps, 3, n_steps):                      # a long call, a short one (ordinary loop), a long one again
+            sh.step_many(n)
+            torch.cuda.synchronize()
+            if overlap:
+                assert sh.overlap_state == (1 if n >= 64 else 0), (n, sh.overlap_state)
+            rec.append({k: v.clone() for k, v in sh.ring.items()})
+            st = {}
+            for f, e in (("a", sh.ea), ("l", sh.el), ("c", sh.ec)):
+                for name, v in zip(("state", "steps", "need_reset"), e.get_state()):
+                    st[f + "_" + name] = torch.as_tensor(v).clone()
+            rec.append(st)
+        assert sh.check_errors() == 0
+        if overlap:
+            sh.set_overlap(False)
+        sh.close()
+        res.append(rec)
+    for i, (p, q) in enumerate(zip(*res)):
+        for k in p:
+            assert torch.equal(torch.as_tensor(p[k]), torch.as_tensor(q[k])), (i, k)
+    last = res[0][-2]
+    if mode != "disabled":
+        assert int(last["at"].sum()) > 0 and int(last["ct"].sum()) > 0

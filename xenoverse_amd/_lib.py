@@ -83,6 +83,7 @@ SIGNATURES = {
     "xv_mixed_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_int],
     "xv_mixed_supported": [c_void_p, c_void_p, c_void_p],
     "xv_mixed_step_many": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int],
+    "xv_mixed_step_many_overlap_state": [c_void_p],
     "xv_linds_create": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, C.POINTER(c_void_p)],
     "xv_linds_destroy": [c_void_p],
     "xv_linds_step_many": [c_void_p, c_int, c_int] + [c_void_p] * 8 + [c_int],
@@ -157,7 +158,7 @@ class XenoError(RuntimeError):
 XV_ERR_INVALID, XV_ERR_HIP, XV_ERR_UNSUPPORTED, XV_ERR_NOMEM = -1, -2, -3, -4
 
 
-ABI_VERSION = 10     # include/xeno.h XV_ABI_VERSION
+ABI_VERSION = 11     # include/xeno.h XV_ABI_VERSION
 
 
 def load():

@@ -10,6 +10,7 @@
 // Same operation order as oracle/xeno_oracle.c: cartpole_step_one.
 #include "philox.h"
 #include "xv_common.h"
+#include "xv_hand.h"
 
 struct CartPoleArgs {
   const double* params;      // [n_task][4]: gravity, masscart, masspole, length
@@ -22,6 +23,7 @@ struct CartPoleArgs {
   int n_env, n_task, frameskip, max_steps;
   uint64_t seed, gid_base, tick;
   const uint64_t* tick_dev;   // device tick mode of the engine: the launch tick is *tick_dev + tick (xv_launch_tick)
+  uint32_t* hand;             // [waves] HAND kernels only (mixed.hip): hand-off words of the waves' envs, xv_hand.h
 };
 
 struct CartPoleIO {
@@ -57,7 +59,7 @@ __device__ __forceinline__ CpState cartpole_reset_state(const CartPoleArgs& P, c
                  fma(2.0, u2, -1.0) * P.reset_scale[2], fma(2.0, u3, -1.0) * P.reset_scale[3]};
 }
 
-template <bool INJECT>
+template <bool INJECT, bool HAND = false>
 __device__ __forceinline__ void cartpole_step_body(const CartPoleArgs& P, const CartPoleIO& io, int mode, int T, int bid) {
   // T steps per launch (xv_cartpole_rollout; T = 1 for xv_cartpole_step): the state stays in registers, step ts reads
   // action[ts][i], writes row ts of the outputs and draws with tick + ts — the same values as T launches of one step
@@ -65,11 +67,25 @@ __device__ __forceinline__ void cartpole_step_body(const CartPoleArgs& P, const 
   const int i = bid * blockDim.x + threadIdx.x;
   if (i >= P.n_env) return;
   const size_t N = (size_t)P.n_env;
-  double x = P.state[i], xd = P.state[N + i], th = P.state[2 * N + i], thd = P.state[3 * N + i];
-  int steps = P.steps[i];
-  int nr = P.need_reset[i];
-  const double* prm = P.params + (size_t)P.env_task[i] * 4;
+  double x, xd, th, thd;
+  int steps, nr;
   uint32_t err = 0;
+  const double* prm = P.params + (size_t)P.env_task[i] * 4;
+  // HAND (overlapped step_many of the mixed batch, mixed.hip; T = 1): the wave waits for its word P.hand[wave] to carry this
+  // step's tick — written by the same wave of the step before, after its state stores completed — and hands on likewise
+  // (xv_hand.h).  The env's word in P.steps carries need_reset in bit 31 between HAND launches (mixed.hip packs / unpacks).
+  if (HAND) {
+    if (!xv_hand_wait(P.hand + (i >> 6), (uint32_t)xv_launch_tick(P.tick, P.tick_dev))) err |= XV_DEVERR_HANDOFF;
+    asm volatile("" ::: "memory");
+    x = xv_agent_load_f64(P.state + i); xd = xv_agent_load_f64(P.state + N + i);
+    th = xv_agent_load_f64(P.state + 2 * N + i); thd = xv_agent_load_f64(P.state + 3 * N + i);
+    const uint32_t w = xv_agent_load32(P.steps + i);
+    steps = (int)(w & 0x7FFFFFFFu); nr = (int)(w >> 31);
+  } else {
+    x = P.state[i]; xd = P.state[N + i]; th = P.state[2 * N + i]; thd = P.state[3 * N + i];
+    steps = P.steps[i];
+    nr = P.need_reset[i];
+  }
   for (int ts = 0; ts < T; ++ts) {
   const size_t o = (size_t)ts * N + i;
   int action = io.action[o];
@@ -128,9 +144,16 @@ __device__ __forceinline__ void cartpole_step_body(const CartPoleArgs& P, const 
   if (io.done_out) io.done_out[o] = (uint8_t)((term || trunc) ? 1 : 0);
   if (io.final_obs) reinterpret_cast<float4*>(io.final_obs)[o] = fobs;
   }
-  P.state[i] = x; P.state[N + i] = xd; P.state[2 * N + i] = th; P.state[3 * N + i] = thd;
-  P.steps[i] = steps;
-  P.need_reset[i] = (uint8_t)nr;
+  if (HAND) {
+    xv_agent_store_f64(P.state + i, x); xv_agent_store_f64(P.state + N + i, xd);
+    xv_agent_store_f64(P.state + 2 * N + i, th); xv_agent_store_f64(P.state + 3 * N + i, thd);
+    xv_agent_store32(P.steps + i, (uint32_t)steps | ((uint32_t)nr << 31));
+    xv_hand_publish(P.hand + (i >> 6), (uint32_t)xv_launch_tick(P.tick, P.tick_dev) + 1u);
+  } else {
+    P.state[i] = x; P.state[N + i] = xd; P.state[2 * N + i] = th; P.state[3 * N + i] = thd;
+    P.steps[i] = steps;
+    P.need_reset[i] = (uint8_t)nr;
+  }
   if (err) atomicOr(P.err, err);
 }
 

@@ -27,6 +27,7 @@
 
 #include "philox.h"
 #include "xv_common.h"
+#include "xv_hand.h"
 
 struct LinDSArgs {
   xv_linds_tables T;
@@ -37,6 +38,7 @@ struct LinDSArgs {
   int n_env, n_task, NS, NA, NO, NI;
   uint64_t seed, gid_base, tick;
   const uint64_t* tick_dev;   // device tick mode of the engine: the launch tick is *tick_dev + tick (xv_launch_tick)
+  uint32_t* hand;             // [waves] HAND kernels only (mixed.hip): tile hand-off words, xv_hand.h
   // engine-built command table (nullptr if it would not fit the budget): cmd_tab[task][tt - ct_tmin][NO] holds
   // get_inner_cmd at integer time tt, already multiplied by target_valid, for tt in [ct_tmin, ct_tmin + ct_len)
   // Rows hold the first ct_w columns only (a multiple of 4): every column past the last one whose target_valid is
@@ -1037,15 +1039,35 @@ __device__ __forceinline__ bool linds_tile_id(const LinDSArgs& P, LinDSTileId& i
   return true;
 }
 
-template <int NS, int NA, int NO, bool INJECT>
+// HAND (overlapped step_many of the mixed batch, mixed.hip): the launch may start while the step before it is still running.
+// The wave asks for its task's fragments, then waits for ITS tile's word P.hand[wave] to carry this step's tick (written by
+// the same wave of the step before, after its x / sn stores completed), loads x and sn with agent-scope loads, and hands
+// the tile on the same way (xv_hand.h).
+template <int NS, int NA, int NO, bool INJECT, bool HAND = false>
 __device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const LinDSStepIO& io, int mode, int bid) {
   using F = LinDSFrag<NS, NA, NO>;
   LinDSTileId id;
   if (!linds_tile_id(P, id, bid)) return;
-  // ---- every load of the step is in flight before the first MFMA; the step counter first (the command rows wait for it) ----
-  const uint32_t sn0 = (uint32_t)P.sn[id.es];
   float4* xq = reinterpret_cast<float4*>(P.x) + (size_t)id.wave * F::MT * 64 + id.lane;
   xv_f32x4 xs[F::MT];
+  uint32_t sn0;
+  F fr;
+  bool late = false;
+  if (HAND) {
+    fr.load(P, id.t, id.lane);
+    late = !xv_hand_wait(P.hand + id.wave, (uint32_t)xv_launch_tick(P.tick, P.tick_dev));
+    asm volatile("" ::: "memory");
+    sn0 = xv_agent_load32(P.sn + id.es);
+#pragma unroll
+    for (int m = 0; m < F::MT; ++m) {
+      const uint64_t lo = xv_agent_load64(reinterpret_cast<const uint64_t*>(xq + m * 64));
+      const uint64_t hi = xv_agent_load64(reinterpret_cast<const uint64_t*>(xq + m * 64) + 1);
+      xs[m] = xv_f32x4{__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float((uint32_t)hi),
+                       __uint_as_float((uint32_t)(hi >> 32))};
+    }
+  } else {
+  // ---- every load of the step is in flight before the first MFMA; the step counter first (the command rows wait for it) ----
+  sn0 = (uint32_t)P.sn[id.es];
 #pragma unroll
   for (int m = 0; m < F::MT; ++m) {
 #if XV_LINDS_NT_MORE & 8
@@ -1056,14 +1078,29 @@ __device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const L
     xs[m] = xv_f32x4{v.x, v.y, v.z, v.w};
 #endif
   }
-  F fr;
   fr.load(P, id.t, id.lane);
+  }
   int steps = (int)(sn0 & ~XV_LINDS_NR_BIT), nr = (int)(sn0 >> 31), bad = 0;
   const int init_inj = INJECT ? io.init_index[id.e] : 0;
   LinDSTileStep<NS, NA, NO, INJECT>::run(P, fr, id.t, id.lane, id.e, id.valid, id.gid, xv_launch_tick(P.tick, P.tick_dev), mode,
                                          io.action + (size_t)id.e * NA, io.z, P.n_env, init_inj, (size_t)id.e, io.obs, io.cmd,
                                          io.final_obs, io.reward, io.error, io.terminated, io.truncated, xs, steps, nr, bad,
                                          io.steps_out, io.done_out);
+  if (HAND) {
+    if (id.valid) {
+#pragma unroll
+      for (int m = 0; m < F::MT; ++m) {
+        uint64_t* q = reinterpret_cast<uint64_t*>(xq + m * 64);
+        xv_agent_store64(q, (uint64_t)__float_as_uint(xs[m][0]) | ((uint64_t)__float_as_uint(xs[m][1]) << 32));
+        xv_agent_store64(q + 1, (uint64_t)__float_as_uint(xs[m][2]) | ((uint64_t)__float_as_uint(xs[m][3]) << 32));
+      }
+      if (id.g == 0) xv_agent_store32(P.sn + id.es, (uint32_t)steps | (nr ? XV_LINDS_NR_BIT : 0u));
+    }
+    xv_hand_publish(P.hand + id.wave, (uint32_t)xv_launch_tick(P.tick, P.tick_dev) + 1u);
+    if (id.valid && (bad || late))
+      atomicOr(P.err, (uint32_t)((bad ? XV_DEVERR_NONFINITE : 0u) | (late ? XV_DEVERR_HANDOFF : 0u)));
+    return;
+  }
   if (id.valid) {
 #pragma unroll
     for (int m = 0; m < F::MT; ++m) {

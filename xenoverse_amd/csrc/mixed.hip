@@ -14,17 +14,25 @@
 #include "cartpole.hip"
 #include "linds.hip"
 
-template <int AG, int ABK, int LNS, int LNO>
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+// HAND: the overlapped xv_mixed_step_many — the launch may start while the step before it is still running; every wave
+// waits for its own envs / tile to be handed on (AnyMDP: the tag in the env record, anymdp.hip; LinDS and CartPole: a word
+// per wave, xv_hand.h).
+template <int AG, int ABK, int LNS, int LNO, bool HAND = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void mixed_step_kernel(AnyMDPArgs A, AnyMDPStepIO aio, int nbA, LinDSArgs L, LinDSStepIO lio, int nbL, CartPoleArgs C, CartPoleIO cio,
                        int mode) {
   const int b = (int)blockIdx.x;
   if (b < nbA) {
-    anymdp_step_body<false, AG, false, false, ABK>(A, aio, 1, mode, b);
+    anymdp_step_body<false, AG, false, false, ABK, HAND>(A, aio, 1, mode, b);
   } else if (b < nbA + nbL) {
-    linds_step_mfma_body<LNS, 8, LNO, false>(L, lio, mode, b - nbA);
+    linds_step_mfma_body<LNS, 8, LNO, false, HAND>(L, lio, mode, b - nbA);
   } else {
-    cartpole_step_body<false>(C, cio, mode, 1, b - nbA - nbL);
+    cartpole_step_body<false, HAND>(C, cio, mode, 1, b - nbA - nbL);
   }
 }
 
@@ -116,23 +124,284 @@ extern "C" int xv_mixed_step(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv
   return XV_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The overlapped xv_mixed_step_many.  A fused step of config 5 is one round of 224 workgroups: 5.5 us of launch, dependent
+// loads and drain during which most of the device idles.  As for the AnyMDP step_many (anymdp.hip, "overlap"), the ring's
+// even slots go to the engines' stream and the odd slots to a side stream, as two graphs of HAND kernels, so step k + 1
+// starts while step k runs and every wave takes its envs over from the same wave of the step before.  Switched on by the
+// AnyMDP handle's xv_anymdp_set_step_many_overlap (one overlapped handle per device: two overlapped calls in flight can
+// deadlock on the hardware queues).  Needs the three handles on three engines of their own (one tick each per step), host
+// ticks, an even period and a call of >= XV_MIXED_PIPE_MIN steps; anything else takes the ordinary loop below.
+#define XV_MIXED_PIPE_MIN 64
+struct MixedPipeKey {
+  AnyMDPArgs A;
+  LinDSArgs L;
+  CartPoleArgs C;
+  xv_mixed_io ring;
+  int period, mode, variant;
+};
+struct MixedPipe {
+  hipStream_t side;
+  hipEvent_t ev[2];
+  uint64_t* d_tick;      // [family][parity]: the graphs' tick words
+  uint32_t* d_hand;      // LinDS waves, then CartPole waves
+  size_t hand_cap;
+  hipGraph_t graph[2];
+  hipGraphExec_t exec[2];
+  MixedPipeKey key;
+  bool key_valid, tested, failed, used_last;
+  const xv_anymdp* used_by;
+};
+static MixedPipe g_mixed_pipe[64];
+static std::mutex g_mixed_mu;
+
+static __global__ __launch_bounds__(256) void mixed_pipe_open_kernel(uint2* sr, int n_a, uint32_t tag_a, uint32_t* hand_l, int n_lw,
+                                                                     uint32_t tag_l, uint32_t* hand_c, int n_cw, uint32_t tag_c,
+                                                                     int32_t* c_steps, const uint8_t* c_nr, int n_c,
+                                                                     uint64_t* d_tick, uint64_t ta, uint64_t tl, uint64_t tc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_a) sr[i].x = (sr[i].x & ((1u << XV_ANYMDP_SR_TAG_SHIFT) - 1u)) | (tag_a << XV_ANYMDP_SR_TAG_SHIFT);
+  if (i < n_lw) hand_l[i] = tag_l;
+  if (i < n_cw) hand_c[i] = tag_c;
+  if (i < n_c) c_steps[i] = (int32_t)(((uint32_t)c_steps[i] & 0x7FFFFFFFu) | ((uint32_t)(c_nr[i] ? 1u : 0u) << 31));
+  if (i < 6) d_tick[i] = i < 2 ? ta : (i < 4 ? tl : tc);
+}
+// after the join: CartPole's need_reset leaves the step words again
+static __global__ __launch_bounds__(256) void mixed_pipe_close_kernel(int32_t* c_steps, uint8_t* c_nr, int n_c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_c) {
+    const uint32_t w = (uint32_t)c_steps[i];
+    c_steps[i] = (int32_t)(w & 0x7FFFFFFFu);
+    c_nr[i] = (uint8_t)(w >> 31);
+  }
+}
+static __global__ void mixed_pipe_tick_kernel(uint64_t* w, uint64_t dv) { w[0] += dv; w[2] += dv; w[4] += dv; }
+
+// do launches on the two streams run at the same time?  (as anymdp_pipe_selftest: a bounded wait on the side stream for a
+// word that a launch issued afterwards on the engines' stream sets)
+static __global__ void mixed_probe_wait_kernel(uint32_t* flag, uint32_t* seen) {
+  const uint64_t t_begin = wall_clock64();
+  uint32_t ok = 0;
+  while (wall_clock64() - t_begin < 2000000ull) {
+    if (xv_agent_load32(flag) == 1u) { ok = 1; break; }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  *seen = ok;
+}
+static __global__ void mixed_probe_set_kernel(uint32_t* flag) { xv_agent_store32(flag, 1u); }
+
+static bool mixed_pipe_setup(MixedPipe& M, hipStream_t st, size_t n_hand) {
+  if (!M.side) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (hipStreamCreateWithPriority(&M.side, hipStreamNonBlocking, greatest) != hipSuccess) { M.side = nullptr; return false; }
+    if (hipEventCreateWithFlags(&M.ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&M.ev[1], hipEventDisableTiming) != hipSuccess)
+      return false;
+  }
+  if (!M.d_tick && hipMalloc(&M.d_tick, 6 * sizeof(uint64_t)) != hipSuccess) return false;
+  if (M.hand_cap < n_hand) {
+    (void)hipStreamSynchronize(M.side);
+    (void)hipStreamSynchronize(st);
+    if (M.d_hand) (void)hipFree(M.d_hand);
+    M.d_hand = nullptr; M.hand_cap = 0; M.key_valid = false;
+    if (hipMalloc(&M.d_hand, n_hand * sizeof(uint32_t)) != hipSuccess) return false;
+    M.hand_cap = n_hand;
+  }
+  if (!M.tested) {
+    uint32_t* d = nullptr;
+    if (hipMalloc(&d, 2 * sizeof(uint32_t)) != hipSuccess) return false;
+    uint32_t seen = 0;
+    bool ok = hipMemsetAsync(d, 0, 2 * sizeof(uint32_t), st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    if (ok) {
+      hipLaunchKernelGGL(mixed_probe_wait_kernel, dim3(1), dim3(1), 0, M.side, d, d + 1);
+      hipLaunchKernelGGL(mixed_probe_set_kernel, dim3(1), dim3(1), 0, st, d);
+      ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(M.side) == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
+           hipMemcpy(&seen, d + 1, sizeof(seen), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d);
+    if (!ok || seen != 1u) return false;
+    M.tested = true;
+  }
+  return true;
+}
+
+static void mixed_pipe_drop_graphs(MixedPipe& M) {
+  for (int q = 0; q < 2; ++q) {
+    if (M.exec[q]) (void)hipGraphExecDestroy(M.exec[q]);
+    if (M.graph[q]) (void)hipGraphDestroy(M.graph[q]);
+    M.exec[q] = nullptr; M.graph[q] = nullptr;
+  }
+  M.key_valid = false;
+}
+
+static void mixed_io_slot(const xv_mixed_io* ring, size_t s, size_t na, size_t nl, size_t nc, size_t LA, size_t LO, xv_mixed_io* out) {
+  xv_mixed_io io = *ring;
+  io.a_action += s * na; io.a_obs += s * na; io.a_reward += s * na; io.a_reward_gt += s * na;
+  io.a_terminated += s * na; io.a_truncated += s * na;
+  if (io.a_final_obs) io.a_final_obs += s * na;
+  io.l_action += s * nl * LA; io.l_obs += s * nl * LO; io.l_reward += s * nl; io.l_terminated += s * nl;
+  io.l_truncated += s * nl; io.l_cmd += s * nl * LO; io.l_error += s * nl;
+  if (io.l_final_obs) io.l_final_obs += s * nl * LO;
+  io.c_action += s * nc; io.c_obs += s * nc * 4; io.c_reward += s * nc; io.c_terminated += s * nc; io.c_truncated += s * nc;
+  if (io.c_final_obs) io.c_final_obs += s * nc * 4;
+  *out = io;
+}
+
+static void* mixed_hand_fn(int v) {
+  switch (v) {
+    case 0: return reinterpret_cast<void*>(&mixed_step_kernel<1, 0, 16, 16, true>);
+    case 1: return reinterpret_cast<void*>(&mixed_step_kernel<1, 0, 32, 16, true>);
+    case 2: return reinterpret_cast<void*>(&mixed_step_kernel<1, 1, 16, 16, true>);
+    default: return reinterpret_cast<void*>(&mixed_step_kernel<1, 1, 32, 16, true>);
+  }
+}
+
+static bool mixed_pipe_graphs(MixedPipe& M, xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mixed_io* ring, int period, int mode,
+                              int v, int n_lw) {
+  MixedPipeKey K;
+  memset(&K, 0, sizeof(K));
+  memcpy(&K.A, &a->a, sizeof(K.A)); memcpy(&K.L, &l->a, sizeof(K.L)); memcpy(&K.C, &c->a, sizeof(K.C));
+  K.A.tick = 0; K.A.tick_dev = nullptr; K.L.tick = 0; K.L.tick_dev = nullptr; K.C.tick = 0; K.C.tick_dev = nullptr;
+  K.L.hand = M.d_hand; K.C.hand = M.d_hand + n_lw;
+  memcpy(&K.ring, ring, sizeof(K.ring));
+  K.period = period; K.mode = mode; K.variant = v;
+  if (M.key_valid && M.exec[0] && M.exec[1] && memcmp(&K, &M.key, sizeof(K)) == 0) return true;
+  (void)hipStreamSynchronize(M.side);
+  (void)hipStreamSynchronize(a->eng->stream);
+  mixed_pipe_drop_graphs(M);
+  const size_t na = (size_t)a->a.n_env, nl = (size_t)l->a.n_env, nc = (size_t)c->a.n_env;
+  int nbA = xv_div_up(a->a.n_env, 256), nbL = xv_div_up(xv_div_up(l->a.n_slot, 16), 4), nbC = xv_div_up(c->a.n_env, 256);
+  void* fn = mixed_hand_fn(v);
+  for (int q = 0; q < 2; ++q) {
+    if (hipGraphCreate(&M.graph[q], 0) != hipSuccess) return false;
+    hipGraphNode_t prev = nullptr;
+    for (int s = q; s < period; s += 2) {
+      AnyMDPArgs A = K.A; LinDSArgs L = K.L; CartPoleArgs C = K.C;
+      A.tick = (uint64_t)s; A.tick_dev = M.d_tick + q;
+      L.tick = (uint64_t)s; L.tick_dev = M.d_tick + 2 + q;
+      C.tick = (uint64_t)s; C.tick_dev = M.d_tick + 4 + q;
+      xv_mixed_io io;
+      mixed_io_slot(ring, (size_t)s, na, nl, nc, (size_t)l->a.NA, (size_t)l->a.NO, &io);
+      AnyMDPStepIO aio{io.a_action, nullptr, nullptr, nullptr, io.a_obs, io.a_reward, io.a_reward_gt, io.a_terminated,
+                       io.a_truncated, io.a_final_obs, nullptr, nullptr, 0.0f};
+      LinDSStepIO lio{io.l_action, nullptr, nullptr, io.l_obs, io.l_reward, io.l_terminated, io.l_truncated, io.l_cmd,
+                      io.l_error, io.l_final_obs};
+      CartPoleIO cio{io.c_action, nullptr, io.c_obs, io.c_reward, io.c_terminated, io.c_truncated, io.c_final_obs};
+      void* params[9] = {&A, &aio, &nbA, &L, &lio, &nbL, &C, &cio, &mode};
+      hipKernelNodeParams np;
+      memset(&np, 0, sizeof(np));
+      np.func = fn; np.gridDim = dim3(nbA + nbL + nbC); np.blockDim = dim3(256); np.kernelParams = params;
+      hipGraphNode_t node = nullptr;
+      if (hipGraphAddKernelNode(&node, M.graph[q], prev ? &prev : nullptr, prev ? 1 : 0, &np) != hipSuccess) return false;
+      prev = node;
+    }
+    uint64_t* w = M.d_tick + q;
+    uint64_t dv = (uint64_t)period;
+    void* tparams[2] = {&w, &dv};
+    hipKernelNodeParams np;
+    memset(&np, 0, sizeof(np));
+    np.func = reinterpret_cast<void*>(&mixed_pipe_tick_kernel); np.gridDim = dim3(1); np.blockDim = dim3(1); np.kernelParams = tparams;
+    hipGraphNode_t node = nullptr;
+    if (hipGraphAddKernelNode(&node, M.graph[q], &prev, 1, &np) != hipSuccess) return false;
+    if (hipGraphInstantiate(&M.exec[q], M.graph[q], nullptr, nullptr, 0) != hipSuccess) { M.exec[q] = nullptr; return false; }
+  }
+  M.key = K; M.key_valid = true;
+  return true;
+}
+
+// whole ring cycles of a call, overlapped; *issued = steps issued (0: the caller's loop takes all of them)
+static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mixed_io* ring, int n_steps, int period, int mode,
+                          int* issued) {
+  *issued = 0;
+  const int dev = a->eng->device;
+  if (dev < 0 || dev >= 64) return XV_OK;
+  std::lock_guard<std::mutex> lock(g_mixed_mu);
+  MixedPipe& M = g_mixed_pipe[dev];
+  M.used_last = false; M.used_by = a;
+  const int cycles = n_steps / period;
+  static const int min_steps = getenv("XV_MIXED_PIPE_MIN_STEPS") ? atoi(getenv("XV_MIXED_PIPE_MIN_STEPS")) : XV_MIXED_PIPE_MIN;
+  if (M.failed || cycles <= 0 || period % 2 != 0 || n_steps < min_steps) return XV_OK;
+  if (a->eng == l->eng || a->eng == c->eng || l->eng == c->eng) return XV_OK;      // one tick per family and step
+  if (a->eng->dev_tick || l->eng->dev_tick || c->eng->dev_tick) return XV_OK;
+  if (a->eng->stream != l->eng->stream || a->eng->stream != c->eng->stream || l->eng->device != dev || c->eng->device != dev) return XV_OK;
+  const int v = mixed_variant(a, l);
+  if (v < 0) return XV_OK;
+  hipStream_t st = a->eng->stream;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return XV_OK; }
+  XV_HIP(hipSetDevice(dev));
+  const int n_lw = xv_div_up(l->a.n_slot, 16), n_cw = xv_div_up(c->a.n_env, 64);
+  anymdp_bind_rng(a, 0, false);
+  linds_bind_rng(l, 0, false);
+  cartpole_bind_rng(c, 0, false);
+  if (!mixed_pipe_setup(M, st, (size_t)(n_lw + n_cw)) || !mixed_pipe_graphs(M, a, l, c, ring, period, mode, v, n_lw)) {
+    (void)hipGetLastError();
+    M.failed = true;
+    return XV_OK;
+  }
+  const uint64_t ta = a->eng->tick, tl = l->eng->tick, tc = c->eng->tick;
+  const int n_open = std::max(std::max(a->a.n_env, c->a.n_env), std::max(n_lw, 6));
+  hipLaunchKernelGGL(mixed_pipe_open_kernel, dim3(xv_div_up(n_open, 256)), dim3(256), 0, st, a->a.sr, a->a.n_env, XV_ANYMDP_SR_TAG(ta),
+                     M.d_hand, n_lw, (uint32_t)tl, M.d_hand + n_lw, n_cw, (uint32_t)tc, c->a.steps, c->a.need_reset, c->a.n_env,
+                     M.d_tick, ta, tl, tc);
+  bool ok = hipGetLastError() == hipSuccess && hipEventRecord(M.ev[0], st) == hipSuccess &&
+            hipStreamWaitEvent(M.side, M.ev[0], 0) == hipSuccess;
+  int k = 0;
+  bool broken = false;
+  if (ok) {
+    for (int cy = 0; cy < cycles; ++cy) {
+      // both halves or neither: an even half without its odd half leaves the next even launch waiting (bounded, flagged)
+      if (hipGraphLaunch(M.exec[0], st) != hipSuccess) break;
+      if (hipGraphLaunch(M.exec[1], M.side) != hipSuccess) { broken = true; break; }
+      k += period;
+    }
+  }
+  a->eng->tick = ta + (uint64_t)k; l->eng->tick = tl + (uint64_t)k; c->eng->tick = tc + (uint64_t)k;
+  const bool joined = hipEventRecord(M.ev[1], M.side) == hipSuccess && hipStreamWaitEvent(st, M.ev[1], 0) == hipSuccess;
+  hipLaunchKernelGGL(mixed_pipe_close_kernel, dim3(xv_div_up(c->a.n_env, 256)), dim3(256), 0, st, c->a.steps, c->a.need_reset, c->a.n_env);
+  const bool closed = hipGetLastError() == hipSuccess;
+  *issued = k;
+  if (!ok || k < cycles * period) { (void)hipGetLastError(); M.failed = true; }
+  if (broken || !joined || !closed) {
+    (void)hipGetLastError();
+    M.failed = true;
+    xv_set_error("xv_mixed_step_many: an overlapped ring cycle could be issued only in part; the envs' states are undefined");
+    return XV_ERR_HIP;
+  }
+  M.used_last = k > 0;
+  return XV_OK;
+}
+
+// 1: the last xv_mixed_step_many with this AnyMDP handle overlapped its ring cycles, 0: it did not, -1: the overlapped path
+// failed on this device (no concurrent streams, graph build) and is no longer tried
+extern "C" int xv_mixed_step_many_overlap_state(xv_anymdp* a) {
+  if (!a) return 0;
+  const int dev = a->eng->device;
+  if (dev < 0 || dev >= 64) return 0;
+  std::lock_guard<std::mutex> lock(g_mixed_mu);
+  const MixedPipe& M = g_mixed_pipe[dev];
+  if (M.failed) return -1;
+  return (M.used_by == a && M.used_last) ? 1 : 0;
+}
+
 // n_steps fused vector steps issued from C over ring buffers: step k uses slot k % period of every [period][...] array
 extern "C" int xv_mixed_step_many(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mixed_io* ring, int n_steps, int period,
                                   int autoreset_mode) {
   XV_CHECK_ARG(a && l && c && ring && n_steps > 0 && period > 0);
+  XV_CHECK_ARG(autoreset_mode >= 0 && autoreset_mode <= 2);
   const size_t na = (size_t)a->a.n_env, nl = (size_t)l->a.n_env, nc = (size_t)c->a.n_env;
-  const size_t LA = (size_t)l->a.NA, LO = (size_t)l->a.NO;
-  for (int k = 0; k < n_steps; ++k) {
-    const size_t s = (size_t)(k % period);
-    xv_mixed_io io = *ring;
-    io.a_action += s * na; io.a_obs += s * na; io.a_reward += s * na; io.a_reward_gt += s * na;
-    io.a_terminated += s * na; io.a_truncated += s * na;
-    if (io.a_final_obs) io.a_final_obs += s * na;
-    io.l_action += s * nl * LA; io.l_obs += s * nl * LO; io.l_reward += s * nl; io.l_terminated += s * nl;
-    io.l_truncated += s * nl; io.l_cmd += s * nl * LO; io.l_error += s * nl;
-    if (io.l_final_obs) io.l_final_obs += s * nl * LO;
-    io.c_action += s * nc; io.c_obs += s * nc * 4; io.c_reward += s * nc; io.c_terminated += s * nc; io.c_truncated += s * nc;
-    if (io.c_final_obs) io.c_final_obs += s * nc * 4;
+  int k = 0;
+  if (a->overlap) {
+    XV_CHECK_ARG(ring->a_action && ring->a_obs && ring->a_reward && ring->a_reward_gt && ring->a_terminated && ring->a_truncated);
+    XV_CHECK_ARG(ring->l_action && ring->l_obs && ring->l_reward && ring->l_terminated && ring->l_truncated && ring->l_cmd && ring->l_error);
+    XV_CHECK_ARG(ring->c_action && ring->c_obs && ring->c_reward && ring->c_terminated && ring->c_truncated);
+    const int rc = mixed_pipe_run(a, l, c, ring, n_steps, period, autoreset_mode, &k);
+    if (rc != XV_OK) return rc;
+  }
+  for (; k < n_steps; ++k) {
+    xv_mixed_io io;
+    mixed_io_slot(ring, (size_t)(k % period), na, nl, nc, (size_t)l->a.NA, (size_t)l->a.NO, &io);
     const int rc = xv_mixed_step(a, l, c, &io, autoreset_mode);
     if (rc != XV_OK) return rc;
   }

@@ -134,6 +134,17 @@ class MixedShare(object):
             _lib.check(lib.xv_cartpole_step(self.ec._h, _lib.ptr(r["ca"][s]), _lib.ptr(r["co"][s]), _lib.ptr(r["cr"][s]),
                                             _lib.ptr(r["ct"][s]), _lib.ptr(r["cu"][s]), _lib.ptr(r["cf"][s]), mode))
 
+    def set_overlap(self, on=True):
+        """step_many issues consecutive fused steps alternately on two HIP streams; each wave of step k + 1 takes its envs
+        over from the same wave of step k (xeno.h: overlapped xv_mixed_step_many).  Same results; calls of >= 64 steps over
+        an even T only.  One overlapped share (or AnyMDP env) per device."""
+        self.ea.set_step_many_overlap(on)
+
+    @property
+    def overlap_state(self):
+        """1: the last step_many overlapped its ring cycles, 0: it did not, -1: the overlapped path failed on this device"""
+        return int(self.ea.lib.xv_mixed_step_many_overlap_state(self.ea._h))
+
     def rings_for_pack(self):
         r = self.ring
         return {"anymdp": dict(obs=r["ao"], action=r["aa"], reward=r["ar"], terminated=r["at"], truncated=r["au"]),
