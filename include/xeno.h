@@ -48,7 +48,7 @@ extern "C" {
  *    xv_acrobot_step_info (the done mask from the step launch); xv_maze_set_raycast_mapping
  * 10: overlapped step_many (xv_anymdp_set_step_many_overlap / _overlap_state), sub-batch views (xv_anymdp_view,
  *    xv_anymdp_step_many_chains), xv_anymdp_build_rows, xv_pack_rollout_f32 / xv_unpack_rollout_f32, XV_DEVERR_HANDOFF
- * 11: the overlap switch also covers xv_mixed_step_many; xv_mixed_step_many_overlap_state */
+ * 11: the overlap switch also covers xv_mixed_step_many; xv_mixed_step_many_overlap_state; xv_engine_probe_side_streams */
 #define XV_ABI_VERSION 11
 
 /* return codes */
@@ -124,6 +124,12 @@ int xv_engine_set_stream(xv_engine* e, void* hip_stream);
 int xv_engine_event_record(xv_engine* e, int slot);
 int xv_engine_event_done(xv_engine* e, int slot, int* done);
 int xv_engine_event_elapsed_ms(xv_engine* e, float* ms);
+/* Diagnostic for the overlapped step_many paths: the side-stream candidates tried beside this engine's stream, in order (a
+   ping-pong of chained one-thread launches over the two streams against the same chain on one stream, us per launch; a
+   negative two_stream_us: a bounded wait expired, the streams did not run side by side).  accepted[i] = 1 for the
+   candidate the overlapped paths would keep (the trial stops there).  Rows up to max_rows (6 are tried at most). */
+int xv_engine_probe_side_streams(xv_engine* e, int max_rows, int* priority, float* two_stream_us, float* one_stream_us,
+                                 int* accepted, int* n_rows);
 
 /* Philox4x32-10 known-answer hook: fills out[4*n] on the device from ctr[4*n], key[2] (device ptrs). */
 int xv_philox4x32_10(xv_engine* e, const uint32_t* ctr, const uint32_t* key, uint32_t* out, int n);

@@ -183,6 +183,8 @@ def run_mixed(args, torch, dist, dinfo, rank, world, local, wd, selftest=False, 
                 evs.append(share.ea.engine.event_elapsed_ms() if gpu else walls[-1] * 1e3)
         finally:
             gc.enable()
+        if os.environ.get("XV_BENCH_DEBUG_WALLS"):
+            sys.stderr.write("walls us/step %s\n" % ([round(w / args.steps * 1e6, 2) for w in walls],))
         tt = torch.tensor([walls, evs], dtype=torch.float64)
         if dist is not None:
             if dist.get_backend() == "nccl":

@@ -84,6 +84,7 @@ SIGNATURES = {
     "xv_mixed_supported": [c_void_p, c_void_p, c_void_p],
     "xv_mixed_step_many": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int],
     "xv_mixed_step_many_overlap_state": [c_void_p],
+    "xv_engine_probe_side_streams": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "xv_linds_create": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, C.POINTER(c_void_p)],
     "xv_linds_destroy": [c_void_p],
     "xv_linds_step_many": [c_void_p, c_int, c_int] + [c_void_p] * 8 + [c_int],

@@ -35,6 +35,7 @@
 #include "anymdp_cutline.h"
 #include "philox.h"
 #include "xv_common.h"
+#include "xv_pipe.h"
 
 #include <cstddef>
 #include <cstdlib>
@@ -129,6 +130,8 @@ struct xv_anymdp {
   bool pipe_failed;
   bool pipe_used_last;       // the last xv_anymdp_step_many issued overlapped steps
   hipStream_t side;
+  hipStream_t side_for;      // the engine's stream `side` was chosen against (xv_pipe.h)
+  XvPipeGate gate;           // the even half of a cycle starts once the host has enqueued both halves (xv_pipe.h)
   hipEvent_t side_ev[2];     // fork, join
   hipGraph_t pgraph[2];
   hipGraphExec_t pgraph_exec[2];
@@ -184,6 +187,11 @@ static __global__ void anymdp_init_sr_kernel(uint2* sr, int n) {
 }
 static __global__ void anymdp_set_tick_kernel(uint64_t* t, uint64_t v) { *t = v; }
 static __global__ void anymdp_advance_tick_kernel(uint64_t* t, uint64_t dv) { *t += dv; }
+// first node of an overlapped cycle graph: this cycle's tick base; the even half also passes the cycle gate (xv_pipe.h)
+static __global__ void anymdp_pipe_head_kernel(uint64_t* t, uint64_t dv, uint32_t* seen, const uint32_t* issued, uint32_t* err) {
+  *t += dv;
+  if (seen) xv_pipe_gate_pass(seen, issued, err);
+}
 
 __device__ __forceinline__ bool anymdp_is_term(const AnyMDPArgs& P, int t, uint64_t tm0, int s) {
   if (P.words == 1) return (tm0 >> s) & 1ull;
@@ -1549,7 +1557,8 @@ static inline int anymdp_effective_search(const xv_anymdp* h) {
 
 #ifndef XV_KERNELS_ONLY   // mixed.hip includes this file for its kernels and handle types only
 static void anymdp_pipe_clear(xv_anymdp* h) {      // fields of the overlapped step_many: nothing built
-  h->overlap = 0; h->pipe_failed = false; h->pipe_used_last = false; h->side = nullptr;
+  h->overlap = 0; h->pipe_failed = false; h->pipe_used_last = false; h->side = nullptr; h->side_for = nullptr;
+  h->gate.h_issued = nullptr; h->gate.d_issued = nullptr; h->gate.d_seen = nullptr; h->gate.issued = 0;
   h->side_ev[0] = h->side_ev[1] = nullptr;
   h->pgraph[0] = h->pgraph[1] = nullptr; h->pgraph_exec[0] = h->pgraph_exec[1] = nullptr;
   h->tgraph[0] = h->tgraph[1] = nullptr; h->tgraph_exec[0] = h->tgraph_exec[1] = nullptr;
@@ -1573,6 +1582,7 @@ static void anymdp_pipe_release(xv_anymdp* h) {
   if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
   for (int q = 0; q < 2; ++q) if (h->side_ev[q]) (void)hipEventDestroy(h->side_ev[q]);
   if (h->d_ptick) (void)hipFree(h->d_ptick);
+  xv_pipe_gate_destroy(&h->gate);
   anymdp_pipe_clear(h);
 }
 
@@ -1926,6 +1936,24 @@ static bool anymdp_add_tick_node(hipGraph_t graph, const hipGraphNode_t* deps, i
   return hipGraphAddKernelNode(&node, graph, deps, (size_t)n_deps, &np) == hipSuccess;
 }
 
+// head of cycle graph q of the overlapped paths: tick word q += period; q == 0 passes the cycle gate
+static bool anymdp_add_head_node(xv_anymdp* h, hipGraph_t graph, hipGraphNode_t* prev, int q, int period) {
+  hipKernelNodeParams np;
+  memset(&np, 0, sizeof(np));
+  uint64_t* t = h->d_ptick + q;
+  uint64_t dv = (uint64_t)period;
+  uint32_t* seen = q == 0 ? h->gate.d_seen : nullptr;
+  const uint32_t* issued = h->gate.d_issued;
+  uint32_t* err = h->a.err;
+  void* params[] = {&t, &dv, &seen, &issued, &err};
+  np.func = reinterpret_cast<void*>(&anymdp_pipe_head_kernel); np.gridDim = dim3(1); np.blockDim = dim3(1);
+  np.kernelParams = params;
+  hipGraphNode_t node;
+  if (hipGraphAddKernelNode(&node, graph, nullptr, 0, &np) != hipSuccess) return false;
+  *prev = node;
+  return true;
+}
+
 static bool anymdp_ensure_graph(xv_anymdp* h, int period, size_t stride, const int32_t* actions, int32_t* obs, float* reward,
                                 float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
   const int eff = anymdp_effective_search(h);
@@ -2036,21 +2064,24 @@ static int anymdp_many_plain(xv_anymdp* h, int k, int period, size_t stride, con
 // on long calls; profiles/r05_c_*, r05_d_burst_timeline.txt, r05_n_*).  Same launch ticks, same
 // results as the ordinary path (tests/test_gpu_chains.py).
 #define XV_ANYMDP_PIPE_GRAPH_MIN 64      // calls of at least this many steps are overlapped
-static bool anymdp_pipe_selftest(xv_anymdp* h);
 static bool anymdp_pipe_setup(xv_anymdp* h) {
+  if (h->side && h->side_for != h->eng->stream) {      // the engine moved to another stream: choose again
+    (void)hipStreamSynchronize(h->side);
+    anymdp_pipe_drop_graphs(h);
+    (void)hipStreamDestroy(h->side);
+    h->side = nullptr;
+  }
   if (!h->side) {
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    // a stream of another priority class: its launches go to a hardware queue of their own
-    if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, greatest) != hipSuccess) { h->side = nullptr; return false; }
-    if (hipEventCreateWithFlags(&h->side_ev[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->side_ev[1], hipEventDisableTiming) != hipSuccess)
+    // the side stream is chosen by measurement (xv_pipe.h): a ping-pong of chained launches over the two streams must cost
+    // about what the same chain costs on one stream — concurrent hardware queues, not two that take turns
+    h->side_for = h->eng->stream;
+    if (!xv_pipe_pick_side_stream(h->eng->stream, &h->side, nullptr, nullptr)) { h->side = nullptr; return false; }
+    if (!h->side_ev[0] && (hipEventCreateWithFlags(&h->side_ev[0], hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&h->side_ev[1], hipEventDisableTiming) != hipSuccess))
       return false;
   }
-  if (!h->d_ptick) {      // the two graphs' tick words
-    if (hipMalloc(&h->d_ptick, 2 * sizeof(uint64_t)) != hipSuccess) return false;
-    if (!anymdp_pipe_selftest(h)) return false;      // once per handle
-  }
+  if (!h->d_ptick && hipMalloc(&h->d_ptick, 2 * sizeof(uint64_t)) != hipSuccess) return false;      // the two graphs' tick words
+  if (!h->gate.d_seen && !xv_pipe_gate_create(&h->gate)) return false;
   return true;
 }
 
@@ -2069,10 +2100,10 @@ static bool anymdp_pipe_graphs(xv_anymdp* h, int period, size_t stride, const in
   for (int q = 0; q < 2; ++q) {
     if (hipGraphCreate(&h->pgraph[q], 0) != hipSuccess) return false;
     hipGraphNode_t prev = nullptr;
+    if (!anymdp_add_head_node(h, h->pgraph[q], &prev, q, period)) return false;
     if (!anymdp_add_chain(h, h->pgraph[q], &prev, h->d_ptick + q, eff, period, stride, actions, obs, reward, reward_gt,
                           terminated, truncated, final_obs, mode, q, 2, true))
       return false;
-    if (!anymdp_add_tick_node(h->pgraph[q], &prev, 1, h->d_ptick + q, period)) return false;
     if (hipGraphInstantiate(&h->pgraph_exec[q], h->pgraph[q], nullptr, nullptr, 0) != hipSuccess) {
       h->pgraph_exec[q] = nullptr;
       return false;
@@ -2082,38 +2113,6 @@ static bool anymdp_pipe_graphs(xv_anymdp* h, int period, size_t stride, const in
   K.seed = h->eng->seed; K.gid_base = h->eng->env_id_base;
   memcpy(K.ptrs, ptrs, sizeof(ptrs));
   return true;
-}
-
-// Do launches on the two streams really run at the same time?  A probe on the side stream waits (bounded, 20 ms) for a word
-// that a launch issued AFTERWARDS on the engine's stream sets.  If the streams share a hardware queue, or the device takes
-// one launch at a time, the wait expires and the overlapped path is never used on this handle.
-static __global__ void anymdp_probe_wait_kernel(uint32_t* flag, uint32_t* seen) {
-  const uint64_t t_begin = wall_clock64();
-  uint32_t ok = 0;
-  while (wall_clock64() - t_begin < 2000000ull) {
-    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) { ok = 1; break; }
-    __builtin_amdgcn_s_sleep(8);
-  }
-  *seen = ok;
-}
-static __global__ void anymdp_probe_set_kernel(uint32_t* flag) {
-  __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-static bool anymdp_pipe_selftest(xv_anymdp* h) {
-  uint32_t* d = nullptr;
-  if (hipMalloc(&d, 2 * sizeof(uint32_t)) != hipSuccess) return false;
-  uint32_t seen = 0;
-  bool ok = hipMemsetAsync(d, 0, 2 * sizeof(uint32_t), h->eng->stream) == hipSuccess &&
-            hipStreamSynchronize(h->eng->stream) == hipSuccess;
-  if (ok) {
-    hipLaunchKernelGGL(anymdp_probe_wait_kernel, dim3(1), dim3(1), 0, h->side, d, d + 1);
-    hipLaunchKernelGGL(anymdp_probe_set_kernel, dim3(1), dim3(1), 0, h->eng->stream, d);
-    ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(h->side) == hipSuccess &&
-         hipStreamSynchronize(h->eng->stream) == hipSuccess &&
-         hipMemcpy(&seen, d + 1, sizeof(seen), hipMemcpyDeviceToHost) == hipSuccess;
-  }
-  (void)hipFree(d);
-  return ok && seen == 1u;
 }
 
 // the whole ring cycles of a call, overlapped; *issued = steps issued (0: the caller takes the ordinary path for all of it).
@@ -2147,8 +2146,9 @@ static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int 
                      XV_ANYMDP_SR_TAG(t0));
   bool ok = hipGetLastError() == hipSuccess;
   if (ok && !(h->ptick_valid && h->ptick_value == t0)) {
-    hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick, t0);
-    hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick + 1, t0);
+    // the graphs' head nodes advance the words by `period` first
+    hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick, t0 - (uint64_t)period);
+    hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick + 1, t0 - (uint64_t)period);
     ok = hipGetLastError() == hipSuccess;
   }
   // fork: the side stream starts behind what the engine's stream holds now (the caller's actions, a reset, the tags above)
@@ -2163,8 +2163,11 @@ static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int 
   bool broken = false;
   for (int c = 0; c < cycles; ++c) {
     // both halves or neither: an even half without its odd half leaves the next even launch waiting (bounded, flagged)
+    // (the even half starts with the cycle gate: it runs once both halves are enqueued, however long the host takes)
     if (hipGraphLaunch(ex[0], st) != hipSuccess) break;
-    if (hipGraphLaunch(ex[1], h->side) != hipSuccess) { broken = true; break; }
+    xv_pipe_test_stall(c);
+    if (hipGraphLaunch(ex[1], h->side) != hipSuccess) { broken = true; xv_pipe_gate_release(&h->gate); break; }
+    xv_pipe_gate_release(&h->gate);
     k += period;
     h->eng->tick = t0 + (uint64_t)k;
   }
@@ -2736,6 +2739,7 @@ static bool anymdp_tok_pipe_graphs(xv_anymdp* h, int period, const int32_t* acti
   for (int q = 0; q < 2; ++q) {
     if (hipGraphCreate(&h->tgraph[q], 0) != hipSuccess) return false;
     hipGraphNode_t prev = nullptr;
+    if (!anymdp_add_head_node(h, h->tgraph[q], &prev, q, period)) return false;
     for (int j = q; j < period; j += 2) {
       AnyMDPArgs a = h->a;
       a.seed = h->eng->seed; a.gid_base = h->eng->env_id_base;
@@ -2753,7 +2757,6 @@ static bool anymdp_tok_pipe_graphs(xv_anymdp* h, int period, const int32_t* acti
       if (hipGraphAddKernelNode(&node, h->tgraph[q], prev ? &prev : nullptr, prev ? 1 : 0, &np) != hipSuccess) return false;
       prev = node;
     }
-    if (!anymdp_add_tick_node(h->tgraph[q], &prev, 1, h->d_ptick + q, period)) return false;
     if (hipGraphInstantiate(&h->tgraph_exec[q], h->tgraph[q], nullptr, nullptr, 0) != hipSuccess) { h->tgraph_exec[q] = nullptr; return false; }
   }
   K.period = period; K.mode = mode; K.fmt = h->a.bfmt; K.d_obs = h->d_obs; K.d_act = h->d_act;

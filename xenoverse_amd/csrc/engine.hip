@@ -1,6 +1,7 @@
 // engine.hip — engine handle (device + stream + Philox key + sticky device error word).
 #include "philox.h"
 #include "xv_common.h"
+#include "xv_pipe.h"
 
 static thread_local char g_err[512] = "";
 
@@ -227,6 +228,24 @@ extern "C" int xv_engine_event_done(xv_engine* e, int slot, int* done) {
 extern "C" int xv_engine_event_elapsed_ms(xv_engine* e, float* ms) {
   XV_CHECK_ARG(e != nullptr && ms != nullptr && e->ev_made);
   XV_HIP(hipEventElapsedTime(ms, e->ev[0], e->ev[1]));
+  return XV_OK;
+}
+
+// diagnostic: which side streams would the overlapped step_many paths accept beside this engine's stream right now
+// (xv_pipe.h)?  One row per candidate tried, in order; nothing is kept.
+extern "C" int xv_engine_probe_side_streams(xv_engine* e, int max_rows, int* priority, float* two_stream_us, float* one_stream_us,
+                                            int* accepted, int* n_rows) {
+  XV_CHECK_ARG(e != nullptr && max_rows > 0 && priority && two_stream_us && one_stream_us && accepted && n_rows);
+  XV_HIP(hipSetDevice(e->device));
+  XvPipeCandidate rep[XV_PIPE_MAX_CANDIDATES];
+  int n = 0;
+  hipStream_t s = nullptr;
+  (void)xv_pipe_pick_side_stream(e->stream, &s, rep, &n);
+  if (s) (void)hipStreamDestroy(s);
+  *n_rows = n < max_rows ? n : max_rows;
+  for (int i = 0; i < *n_rows; ++i) {
+    priority[i] = rep[i].priority; two_stream_us[i] = rep[i].two_us; one_stream_us[i] = rep[i].one_us; accepted[i] = rep[i].accepted;
+  }
   return XV_OK;
 }
 

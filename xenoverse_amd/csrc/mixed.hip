@@ -13,6 +13,7 @@
 #include "anymdp.hip"
 #include "cartpole.hip"
 #include "linds.hip"
+#include "xv_pipe.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -149,7 +150,9 @@ struct MixedPipe {
   hipGraph_t graph[2];
   hipGraphExec_t exec[2];
   MixedPipeKey key;
-  bool key_valid, tested, failed, used_last;
+  bool key_valid, failed, used_last;
+  hipStream_t side_for;  // the engines' stream the side stream was chosen against
+  XvPipeGate gate;       // the even half of a cycle starts once the host has enqueued both halves (xv_pipe.h)
   const xv_anymdp* used_by;
 };
 static MixedPipe g_mixed_pipe[64];
@@ -175,55 +178,10 @@ static __global__ __launch_bounds__(256) void mixed_pipe_close_kernel(int32_t* c
     c_nr[i] = (uint8_t)(w >> 31);
   }
 }
-static __global__ void mixed_pipe_tick_kernel(uint64_t* w, uint64_t dv) { w[0] += dv; w[2] += dv; w[4] += dv; }
-
-// do launches on the two streams run at the same time?  (as anymdp_pipe_selftest: a bounded wait on the side stream for a
-// word that a launch issued afterwards on the engines' stream sets)
-static __global__ void mixed_probe_wait_kernel(uint32_t* flag, uint32_t* seen) {
-  const uint64_t t_begin = wall_clock64();
-  uint32_t ok = 0;
-  while (wall_clock64() - t_begin < 2000000ull) {
-    if (xv_agent_load32(flag) == 1u) { ok = 1; break; }
-    __builtin_amdgcn_s_sleep(8);
-  }
-  *seen = ok;
-}
-static __global__ void mixed_probe_set_kernel(uint32_t* flag) { xv_agent_store32(flag, 1u); }
-
-static bool mixed_pipe_setup(MixedPipe& M, hipStream_t st, size_t n_hand) {
-  if (!M.side) {
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (hipStreamCreateWithPriority(&M.side, hipStreamNonBlocking, greatest) != hipSuccess) { M.side = nullptr; return false; }
-    if (hipEventCreateWithFlags(&M.ev[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&M.ev[1], hipEventDisableTiming) != hipSuccess)
-      return false;
-  }
-  if (!M.d_tick && hipMalloc(&M.d_tick, 6 * sizeof(uint64_t)) != hipSuccess) return false;
-  if (M.hand_cap < n_hand) {
-    (void)hipStreamSynchronize(M.side);
-    (void)hipStreamSynchronize(st);
-    if (M.d_hand) (void)hipFree(M.d_hand);
-    M.d_hand = nullptr; M.hand_cap = 0; M.key_valid = false;
-    if (hipMalloc(&M.d_hand, n_hand * sizeof(uint32_t)) != hipSuccess) return false;
-    M.hand_cap = n_hand;
-  }
-  if (!M.tested) {
-    uint32_t* d = nullptr;
-    if (hipMalloc(&d, 2 * sizeof(uint32_t)) != hipSuccess) return false;
-    uint32_t seen = 0;
-    bool ok = hipMemsetAsync(d, 0, 2 * sizeof(uint32_t), st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
-    if (ok) {
-      hipLaunchKernelGGL(mixed_probe_wait_kernel, dim3(1), dim3(1), 0, M.side, d, d + 1);
-      hipLaunchKernelGGL(mixed_probe_set_kernel, dim3(1), dim3(1), 0, st, d);
-      ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(M.side) == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
-           hipMemcpy(&seen, d + 1, sizeof(seen), hipMemcpyDeviceToHost) == hipSuccess;
-    }
-    (void)hipFree(d);
-    if (!ok || seen != 1u) return false;
-    M.tested = true;
-  }
-  return true;
+// first node of a cycle graph: this cycle's tick bases (one word per family); the even half also passes the cycle gate
+static __global__ void mixed_pipe_head_kernel(uint64_t* w, uint64_t dv, uint32_t* seen, const uint32_t* issued, uint32_t* err) {
+  w[0] += dv; w[2] += dv; w[4] += dv;
+  if (seen) xv_pipe_gate_pass(seen, issued, err);
 }
 
 static void mixed_pipe_drop_graphs(MixedPipe& M) {
@@ -233,6 +191,33 @@ static void mixed_pipe_drop_graphs(MixedPipe& M) {
     M.exec[q] = nullptr; M.graph[q] = nullptr;
   }
   M.key_valid = false;
+}
+
+static bool mixed_pipe_setup(MixedPipe& M, hipStream_t st, size_t n_hand) {
+  if (M.side && M.side_for != st) {      // measured against another engines' stream: choose again
+    (void)hipStreamSynchronize(M.side);
+    mixed_pipe_drop_graphs(M);
+    (void)hipStreamDestroy(M.side);
+    M.side = nullptr;
+  }
+  if (!M.side) {      // chosen by measurement (xv_pipe.h)
+    M.side_for = st;
+    if (!xv_pipe_pick_side_stream(st, &M.side, nullptr, nullptr)) { M.side = nullptr; return false; }
+    if (!M.ev[0] && (hipEventCreateWithFlags(&M.ev[0], hipEventDisableTiming) != hipSuccess ||
+                     hipEventCreateWithFlags(&M.ev[1], hipEventDisableTiming) != hipSuccess))
+      return false;
+  }
+  if (!M.d_tick && hipMalloc(&M.d_tick, 6 * sizeof(uint64_t)) != hipSuccess) return false;
+  if (!M.gate.d_seen && !xv_pipe_gate_create(&M.gate)) return false;
+  if (M.hand_cap < n_hand) {
+    (void)hipStreamSynchronize(M.side);
+    (void)hipStreamSynchronize(st);
+    if (M.d_hand) (void)hipFree(M.d_hand);
+    M.d_hand = nullptr; M.hand_cap = 0; M.key_valid = false;
+    if (hipMalloc(&M.d_hand, n_hand * sizeof(uint32_t)) != hipSuccess) return false;
+    M.hand_cap = n_hand;
+  }
+  return true;
 }
 
 static void mixed_io_slot(const xv_mixed_io* ring, size_t s, size_t na, size_t nl, size_t nc, size_t LA, size_t LO, xv_mixed_io* out) {
@@ -276,6 +261,18 @@ static bool mixed_pipe_graphs(MixedPipe& M, xv_anymdp* a, xv_linds* l, xv_cartpo
   for (int q = 0; q < 2; ++q) {
     if (hipGraphCreate(&M.graph[q], 0) != hipSuccess) return false;
     hipGraphNode_t prev = nullptr;
+    {
+      uint64_t* w = M.d_tick + q;
+      uint64_t dv = (uint64_t)period;
+      uint32_t* seen = q == 0 ? M.gate.d_seen : nullptr;
+      const uint32_t* issued = M.gate.d_issued;
+      uint32_t* err = a->a.err;
+      void* hparams[5] = {&w, &dv, &seen, &issued, &err};
+      hipKernelNodeParams np;
+      memset(&np, 0, sizeof(np));
+      np.func = reinterpret_cast<void*>(&mixed_pipe_head_kernel); np.gridDim = dim3(1); np.blockDim = dim3(1); np.kernelParams = hparams;
+      if (hipGraphAddKernelNode(&prev, M.graph[q], nullptr, 0, &np) != hipSuccess) return false;
+    }
     for (int s = q; s < period; s += 2) {
       AnyMDPArgs A = K.A; LinDSArgs L = K.L; CartPoleArgs C = K.C;
       A.tick = (uint64_t)s; A.tick_dev = M.d_tick + q;
@@ -296,14 +293,6 @@ static bool mixed_pipe_graphs(MixedPipe& M, xv_anymdp* a, xv_linds* l, xv_cartpo
       if (hipGraphAddKernelNode(&node, M.graph[q], prev ? &prev : nullptr, prev ? 1 : 0, &np) != hipSuccess) return false;
       prev = node;
     }
-    uint64_t* w = M.d_tick + q;
-    uint64_t dv = (uint64_t)period;
-    void* tparams[2] = {&w, &dv};
-    hipKernelNodeParams np;
-    memset(&np, 0, sizeof(np));
-    np.func = reinterpret_cast<void*>(&mixed_pipe_tick_kernel); np.gridDim = dim3(1); np.blockDim = dim3(1); np.kernelParams = tparams;
-    hipGraphNode_t node = nullptr;
-    if (hipGraphAddKernelNode(&node, M.graph[q], &prev, 1, &np) != hipSuccess) return false;
     if (hipGraphInstantiate(&M.exec[q], M.graph[q], nullptr, nullptr, 0) != hipSuccess) { M.exec[q] = nullptr; return false; }
   }
   M.key = K; M.key_valid = true;
@@ -321,7 +310,9 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
   M.used_last = false; M.used_by = a;
   const int cycles = n_steps / period;
   static const int min_steps = getenv("XV_MIXED_PIPE_MIN_STEPS") ? atoi(getenv("XV_MIXED_PIPE_MIN_STEPS")) : XV_MIXED_PIPE_MIN;
-  if (M.failed || cycles <= 0 || period % 2 != 0 || n_steps < min_steps) return XV_OK;
+  if (cycles <= 0 || period % 2 != 0 || n_steps < min_steps) return XV_OK;
+  if (M.failed && M.side_for == a->eng->stream) return XV_OK;      // tried beside this stream already
+  M.failed = false;
   if (a->eng == l->eng || a->eng == c->eng || l->eng == c->eng) return XV_OK;      // one tick per family and step
   if (a->eng->dev_tick || l->eng->dev_tick || c->eng->dev_tick) return XV_OK;
   if (a->eng->stream != l->eng->stream || a->eng->stream != c->eng->stream || l->eng->device != dev || c->eng->device != dev) return XV_OK;
@@ -344,7 +335,7 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
   const int n_open = std::max(std::max(a->a.n_env, c->a.n_env), std::max(n_lw, 6));
   hipLaunchKernelGGL(mixed_pipe_open_kernel, dim3(xv_div_up(n_open, 256)), dim3(256), 0, st, a->a.sr, a->a.n_env, XV_ANYMDP_SR_TAG(ta),
                      M.d_hand, n_lw, (uint32_t)tl, M.d_hand + n_lw, n_cw, (uint32_t)tc, c->a.steps, c->a.need_reset, c->a.n_env,
-                     M.d_tick, ta, tl, tc);
+                     M.d_tick, ta - (uint64_t)period, tl - (uint64_t)period, tc - (uint64_t)period);   // the head nodes add `period`
   bool ok = hipGetLastError() == hipSuccess && hipEventRecord(M.ev[0], st) == hipSuccess &&
             hipStreamWaitEvent(M.side, M.ev[0], 0) == hipSuccess;
   int k = 0;
@@ -352,8 +343,11 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
   if (ok) {
     for (int cy = 0; cy < cycles; ++cy) {
       // both halves or neither: an even half without its odd half leaves the next even launch waiting (bounded, flagged)
+      // (the even half starts with the cycle gate: it runs once both halves are enqueued, however long the host takes)
       if (hipGraphLaunch(M.exec[0], st) != hipSuccess) break;
-      if (hipGraphLaunch(M.exec[1], M.side) != hipSuccess) { broken = true; break; }
+      xv_pipe_test_stall(cy);
+      if (hipGraphLaunch(M.exec[1], M.side) != hipSuccess) { broken = true; xv_pipe_gate_release(&M.gate); break; }
+      xv_pipe_gate_release(&M.gate);
       k += period;
     }
   }

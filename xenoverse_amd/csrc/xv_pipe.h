@@ -1,0 +1,176 @@
+// xv_pipe.h — picking the SIDE STREAM of the overlapped step_many paths (anymdp.hip, mixed.hip).
+//
+// The overlapped paths issue consecutive vector steps alternately on the engine's stream and on a side stream; a wave of
+// step k + 1 waits for the same wave of step k.  That pays only if the device really processes the two streams' launches
+// side by side.  Whether it does depends on where the runtime puts the side stream: streams are mapped onto a few hardware
+// queues, and two queues served by the same command-processor pipe take turns instead — measured on MI355X with an RCCL
+// communicator created BEFORE the side stream: the same two-graph schedule ran at 23 us per step instead of 4.5
+// (profiles/r05_t_*), while a plain "did the other stream start within 20 ms" probe still passed.
+//
+// So the side stream is chosen by MEASUREMENT: a ping-pong of n one-thread launches, launch k waiting (bounded) for the
+// word launch k - 1 leaves, alternating between the two streams, timed with events against the same n launches on the
+// engine's stream alone.  Candidates of several priorities are tried; the first whose ping-pong costs no more than
+// XV_PIPE_ACCEPT_RATIO x the one-stream chain (+ XV_PIPE_ACCEPT_SLACK_US) is kept.  If none qualifies the overlapped path
+// is not used on that handle (the ordinary one-stream path runs instead: same results).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <thread>
+
+#include "xv_hand.h"
+
+#define XV_PIPE_PING_STEPS 128
+#define XV_PIPE_ACCEPT_RATIO 1.5f
+#define XV_PIPE_ACCEPT_SLACK_US 1.0f
+#define XV_PIPE_MAX_CANDIDATES 6
+
+static __global__ void xv_pipe_ping_kernel(uint32_t* word, uint32_t want, uint32_t* late) {
+  const uint64_t t_begin = wall_clock64();
+  while (xv_agent_load32(word) != want) {
+    if (wall_clock64() - t_begin > 200000ull) {      // 2 ms: the launch before this one has not run
+      atomicOr(late, 1u);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  xv_agent_store32(word, want + 1u);
+}
+
+// n chained one-thread launches, alternating main / side (side == nullptr: all on main) -> us per launch, < 0 on failure
+// or when a wait expired.  d_words: two uint32 of device memory.
+static float xv_pipe_pingpong(hipStream_t main, hipStream_t side, uint32_t* d_words, hipEvent_t* ev /*[4]*/, int n) {
+  if (hipMemsetAsync(d_words, 0, 2 * sizeof(uint32_t), main) != hipSuccess) return -1.0f;
+  bool ok = hipEventRecord(ev[0], main) == hipSuccess;
+  if (side) ok = ok && hipEventRecord(ev[2], main) == hipSuccess && hipStreamWaitEvent(side, ev[2], 0) == hipSuccess;
+  // two streams: the odd launch of a pair is issued FIRST, on the side stream — if the streams share a hardware queue it
+  // sits in front of the launch it waits for, its wait expires and the candidate is out (never a hang)
+  for (int k = 0; ok && k < n; ++k) {
+    const int kk = side ? (k ^ 1) : k;
+    hipLaunchKernelGGL(xv_pipe_ping_kernel, dim3(1), dim3(1), 0, (side && (kk & 1)) ? side : main, d_words, (uint32_t)kk, d_words + 1);
+    ok = hipGetLastError() == hipSuccess;
+  }
+  if (side) ok = hipEventRecord(ev[3], side) == hipSuccess && hipStreamWaitEvent(main, ev[3], 0) == hipSuccess && ok;
+  ok = hipEventRecord(ev[1], main) == hipSuccess && ok;
+  ok = hipStreamSynchronize(main) == hipSuccess && ok;
+  if (side) ok = hipStreamSynchronize(side) == hipSuccess && ok;
+  uint32_t w[2] = {0u, 1u};
+  float ms = 0.0f;
+  ok = ok && hipMemcpy(w, d_words, sizeof(w), hipMemcpyDeviceToHost) == hipSuccess && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess;
+  if (!ok) { (void)hipGetLastError(); return -1.0f; }
+  if (w[0] != (uint32_t)n || w[1] != 0u) return -1.0f;
+  return ms * 1000.0f / (float)n;
+}
+
+struct XvPipeCandidate {
+  int priority;        // what the stream was created with
+  float two_us;        // ping-pong over main + this stream, us per launch (< 0: a wait expired / failure)
+  float one_us;        // the same chain on main alone
+  int accepted;
+};
+
+// Tries up to XV_PIPE_MAX_CANDIDATES side streams; *out = the first accepted one (the others are destroyed), nullptr when
+// none qualifies.  report (nullable): one row per candidate tried; *n_report rows filled.
+static bool xv_pipe_pick_side_stream(hipStream_t main, hipStream_t* out, XvPipeCandidate* report, int* n_report) {
+  *out = nullptr;
+  if (n_report) *n_report = 0;
+  uint32_t* d = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (hipMalloc(&d, 2 * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return false; }
+  bool ok = true;
+  for (int i = 0; i < 4; ++i) ok = ok && hipEventCreate(&ev[i]) == hipSuccess;
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  // a stream of another priority class gets a hardware queue of its own: the highest first, then ordinary streams (each
+  // new one moves on to the runtime's next queue), the lowest last
+  const int prio[XV_PIPE_MAX_CANDIDATES] = {greatest, 0, 0, least, 0, 0};
+  float one = -1.0f;
+  if (ok) {
+    (void)xv_pipe_pingpong(main, nullptr, d, ev, 16);      // warm-up: code object load, first launch
+    one = xv_pipe_pingpong(main, nullptr, d, ev, XV_PIPE_PING_STEPS);
+    ok = one > 0.0f;
+  }
+  hipStream_t rejected[XV_PIPE_MAX_CANDIDATES];
+  int n_rej = 0;
+  for (int c = 0; ok && c < XV_PIPE_MAX_CANDIDATES && !*out; ++c) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio[c]) != hipSuccess) { (void)hipGetLastError(); continue; }
+    (void)xv_pipe_pingpong(main, s, d, ev, 16);
+    float two = xv_pipe_pingpong(main, s, d, ev, XV_PIPE_PING_STEPS);
+    if (two > 0.0f) {      // the better of two rounds: a first use of a new queue can be slow once
+      const float again = xv_pipe_pingpong(main, s, d, ev, XV_PIPE_PING_STEPS);
+      if (again > 0.0f && again < two) two = again;
+    }
+    const bool take = two > 0.0f && two <= XV_PIPE_ACCEPT_RATIO * one + XV_PIPE_ACCEPT_SLACK_US;
+    if (report && n_report) {
+      report[*n_report] = XvPipeCandidate{prio[c], two, one, take ? 1 : 0};
+      *n_report += 1;
+    }
+    if (take) *out = s;
+    else rejected[n_rej++] = s;      // kept alive until the choice is made: destroying one would hand its queue to the next
+  }
+  for (int i = 0; i < n_rej; ++i) (void)hipStreamDestroy(rejected[i]);
+  for (int i = 0; i < 4; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]);
+  (void)hipFree(d);
+  (void)hipGetLastError();
+  return *out != nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The cycle gate.  The host issues a ring cycle as two graph launches, the even half on the engine's stream and then the odd
+// half on the side stream.  The even half's second step waits (bounded, 50 ms) for the odd half's first step: were the
+// host held up between the two launches for longer than that — a page fault, a descheduled thread, the runtime blocking on
+// a full queue — the wait would expire and the results be wrong (flagged, XV_DEVERR_HANDOFF).  So the even half starts
+// with a one-thread GATE node: gate number g (counted in device memory) passes once the host has published
+// `issued >= g`, which it does, in pinned host memory, after BOTH launches of that cycle have been enqueued.  A held-up
+// host then just delays the device.  The gate's own wait is bounded too (2 s; then flagged).
+#define XV_PIPE_GATE_TIMEOUT 200000000ull   // 2 s of the 100-MHz wall clock
+
+struct XvPipeGate {
+  uint32_t* h_issued;   // pinned, mapped host word
+  uint32_t* d_issued;   // the device's view of it
+  uint32_t* d_seen;     // gates passed so far (device memory)
+  uint32_t issued;      // host mirror
+};
+
+__device__ __forceinline__ void xv_pipe_gate_pass(uint32_t* seen, const uint32_t* issued, uint32_t* err) {
+  const uint32_t g = *seen + 1u;
+  *seen = g;
+  const uint64_t t_begin = wall_clock64();
+  while ((int32_t)(__hip_atomic_load(issued, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - g) < 0) {
+    if (wall_clock64() - t_begin > XV_PIPE_GATE_TIMEOUT) {
+      atomicOr(err, 8u /* XV_DEVERR_HANDOFF */);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(16);
+  }
+}
+
+static bool xv_pipe_gate_create(XvPipeGate* g) {
+  g->h_issued = nullptr; g->d_issued = nullptr; g->d_seen = nullptr; g->issued = 0;
+  if (hipHostMalloc(reinterpret_cast<void**>(&g->h_issued), 64, hipHostMallocMapped) != hipSuccess) { g->h_issued = nullptr; return false; }
+  *g->h_issued = 0u;
+  if (hipHostGetDevicePointer(reinterpret_cast<void**>(&g->d_issued), g->h_issued, 0) != hipSuccess) return false;
+  if (hipMalloc(&g->d_seen, sizeof(uint32_t)) != hipSuccess) { g->d_seen = nullptr; return false; }
+  return hipMemset(g->d_seen, 0, sizeof(uint32_t)) == hipSuccess;
+}
+static void xv_pipe_gate_destroy(XvPipeGate* g) {
+  if (g->d_seen) (void)hipFree(g->d_seen);
+  if (g->h_issued) (void)hipHostFree(g->h_issued);
+  g->h_issued = nullptr; g->d_issued = nullptr; g->d_seen = nullptr; g->issued = 0;
+}
+// after both launches of a cycle are enqueued (or to let a half-issued cycle's gate go on the error path)
+static inline void xv_pipe_gate_release(XvPipeGate* g) {
+  g->issued += 1u;
+  __atomic_store_n(g->h_issued, g->issued, __ATOMIC_RELEASE);
+}
+
+// test hook (tests/test_gpu_chains.py): XV_PIPE_TEST_STALL_MS=<ms> holds the host up between the two launches of the
+// second cycle of every overlapped call — longer than the hand-off bound, the cycle gate must make that harmless
+static inline void xv_pipe_test_stall(int cycle) {
+  if (cycle != 1) return;
+  const char* v = getenv("XV_PIPE_TEST_STALL_MS");
+  if (v && atoi(v) > 0) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(v)));
+}

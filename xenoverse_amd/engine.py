@@ -83,6 +83,16 @@ class Engine(object):
         _lib.check(self.lib.xv_engine_event_elapsed_ms(self.handle, C.byref(v)))
         return float(v.value)
 
+    def probe_side_streams(self):
+        """diagnostic (xv_engine_probe_side_streams): the side-stream candidates the overlapped step_many paths would try
+        beside this engine's stream -> list of dicts(priority, two_stream_us, one_stream_us, accepted)"""
+        n = 8
+        pr, ac, k = (C.c_int * n)(), (C.c_int * n)(), C.c_int(0)
+        two, one = (C.c_float * n)(), (C.c_float * n)()
+        _lib.check(self.lib.xv_engine_probe_side_streams(self.handle, n, pr, two, one, ac, C.byref(k)))
+        return [dict(priority=int(pr[i]), two_stream_us=float(two[i]), one_stream_us=float(one[i]), accepted=bool(ac[i]))
+                for i in range(k.value)]
+
     def philox(self, ctr, key):
         """Philox4x32-10 known-answer hook: ctr uint32[n,4], key uint32[2] -> uint32[n,4] (device)."""
         ctr = torch.as_tensor(ctr, dtype=torch.int64).to(torch.int32).to(self.device).contiguous() \
