@@ -311,5 +311,8 @@ def test_a_held_up_host_between_the_two_launches_of_a_cycle_is_harmless(monkeypa
     monkeypatch.setenv("XV_PIPE_TEST_STALL_MS", "120")
     got = _run_many(tab, n, P, acts, plan, "fence", 1, "streams", True, overlap=True)      # asserts check_errors() == 0
     _same(ref, got)
-    probe = AnyMDPVecEnv(64, seed=1).engine.probe_side_streams()
+    from xenoverse_amd.engine import Engine
+    eng = Engine("cuda:0")
+    probe = eng.probe_side_streams()
+    eng.close()
     assert probe and probe[-1]["accepted"] and probe[-1]["two_stream_us"] > 0, probe
