@@ -428,6 +428,7 @@ def main():
     import torch
     if os.environ.get("XV_BENCH_SHARE_GPU"):   # functional test of the N>1 path on a 1-GPU box (not a measurement)
         local = 0
+        args.overlap = "off"      # one overlapped handle per DEVICE: two processes on one GPU must not both overlap
     if not selftest:
         torch.cuda.set_device(local)
     wd = Watchdog(args.gather_timeout, rank)

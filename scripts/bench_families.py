@@ -345,7 +345,7 @@ def bench_mixed(args, variants=("three streams", "one stream", "one launch")):
         if label == "one launch":      # xv_mixed_step_many: the three families' step bodies in ONE grid, launches issued from C
             import ctypes as C
             from xenoverse_amd.mixed import _MixedIO
-            P = 8
+            P = 32
             ring = dict(aa=torch.randint(0, A, (P, na), device=d, dtype=torch.int32), ao=torch.zeros((P, na), device=d, dtype=torch.int32),
                         ar=torch.zeros((P, na), device=d), ag=torch.zeros((P, na), device=d),
                         at=torch.zeros((P, na), device=d, dtype=torch.uint8), au=torch.zeros((P, na), device=d, dtype=torch.uint8),
@@ -363,6 +363,12 @@ def bench_mixed(args, variants=("three streams", "one stream", "one launch")):
             def many():
                 _lib.check(ea.lib.xv_mixed_step_many(ea._h, el._h, ec._h, C.byref(io), k, P, mode))
             res[label] = timed(many, 3, 1) / k
+            # the same calls with consecutive steps alternating between two streams (overlapped xv_mixed_step_many)
+            ea.set_step_many_overlap(True)
+            t_ov = timed(many, 3, 1) / k
+            if int(ea.lib.xv_mixed_step_many_overlap_state(ea._h)) == 1:
+                res[label + ", overlapped"] = t_ov
+            ea.set_step_many_overlap(False)
         else:
             res[label] = timed(step, args.steps, args.warmup)
         (mb.close() if mixed else [e.close() for e in (ea, el, ec)])
@@ -373,7 +379,8 @@ def bench_mixed(args, variants=("three streams", "one stream", "one launch")):
             "env_steps_per_s": n / (best * 1e-6), "us_per_vector_step": res, "dtype": "f64/f32",
             "roofline": {"bound": "hbm", "achieved": algo / (best * 1e-6) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
                          "frac": algo / (best * 1e-6) / 1e9 / HBM_PEAK, "algorithmic_bytes_per_vector_step": algo,
-                         "note": "a 13 MB vector step: launch-latency bound; one fused launch instead of three"}}
+                         "note": "a 13 MB vector step: launch-latency bound; one fused launch instead of three; overlapped: "
+                                 "consecutive launches on two streams, per-wave hand-off (xv_mixed_step_many with the overlap on)"}}
 
 
 def _synth_anymdp_env(n, n_task, copy=True, seed=1234):
