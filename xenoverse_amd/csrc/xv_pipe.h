@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <thread>
 
@@ -104,6 +105,9 @@ static bool xv_pipe_pick_side_stream(hipStream_t main, hipStream_t* out, XvPipeC
       if (again > 0.0f && again < two) two = again;
     }
     const bool take = two > 0.0f && two <= XV_PIPE_ACCEPT_RATIO * one + XV_PIPE_ACCEPT_SLACK_US;
+    if (getenv("XV_PIPE_DEBUG"))
+      fprintf(stderr, "xv_pipe: candidate %d priority %d: two streams %.2f us, one stream %.2f us per launch -> %s\n", c, prio[c],
+              (double)two, (double)one, take ? "taken" : "rejected");
     if (report && n_report) {
       report[*n_report] = XvPipeCandidate{prio[c], two, one, take ? 1 : 0};
       *n_report += 1;
