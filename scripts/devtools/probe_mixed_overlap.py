@@ -26,6 +26,8 @@ def timed(sh, n, all_times=None):
 
 if __name__ == "__main__":
     combos = [(16384, 8192, 8192), (16384, 64, 8), (64, 8192, 8), (64, 64, 8192), (64, 64, 8)]
+    if "--linds" in sys.argv:       # what would an overlapped xv_linds_step_many give at config 3's size?
+        combos = [(64, 65536, 8), (64, 16384, 8), (64, 32768, 8), (64, 131072, 8)]
     gather = None
     if "--gather" in sys.argv:      # does a live RCCL communicator (its streams and queues) change the picture?
         from xenoverse_amd.distributed import RolloutGather

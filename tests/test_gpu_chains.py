@@ -316,3 +316,20 @@ def test_a_held_up_host_between_the_two_launches_of_a_cycle_is_harmless(monkeypa
     probe = eng.probe_side_streams()
     eng.close()
     assert probe and probe[-1]["accepted"] and probe[-1]["two_stream_us"] > 0, probe
+
+
+def test_overlap_is_not_taken_when_two_launches_cannot_be_resident_together():
+    """A workgroup of step k + 1 spins in its slot until the same workgroup of step k has run; with grids beyond half of what
+    the device holds, step k's workgroups could be left without slots.  Such calls take the one-stream path (xv_pipe.h)."""
+    tab = oracle.anymdp_synth(seed=3, task_index_base=0, n_task=16, S=64, A=8, s0_max=4)
+    n, P = 1 << 21, 2                                   # 8,192 workgroups per launch
+    env = AnyMDPVecEnv(n, seed=5, bucket_lines="off")
+    env.set_task(_dev_tables(tab), env_task_index=(torch.arange(n, device="cuda", dtype=torch.int32) % 16).contiguous())
+    env.set_search("fence")
+    env.set_step_many_overlap(True)
+    env.reset()
+    acts = torch.randint(0, 8, (P, n), device=env.device, dtype=torch.int32)
+    env.step_many(64, acts)
+    torch.cuda.synchronize()
+    assert env.step_many_overlap_state == 0 and env.check_errors() == 0
+    env.close()

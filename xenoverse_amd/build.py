@@ -29,13 +29,20 @@ def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+KERNELS_END = b"#ifndef XV_KERNELS_ONLY"
+
+
 def source_hash(names):
-    """sha256[:16] of the named csrc files, in order: ties a committed profile to the kernel source it measured"""
+    """sha256[:16] of the named csrc files, in order: ties a committed profile to the KERNEL source it measured.  A .hip file
+    counts up to its `#ifndef XV_KERNELS_ONLY` line — structs, device functions and kernels (what mixed.hip includes of it);
+    the host code behind it (handles, graphs, the C-ABI) does not change what a launch moves."""
     import hashlib
     h = hashlib.sha256()
     for n in names:
         with open(os.path.join(CSRC, n), "rb") as f:
-            h.update(f.read())
+            text = f.read()
+        cut = text.find(KERNELS_END) if n.endswith(".hip") else -1
+        h.update(text if cut < 0 else text[:cut])
     return h.hexdigest()[:16]
 
 

@@ -2127,6 +2127,10 @@ static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride,
   const int cycles = n_steps / period;
   static const int min_steps = getenv("XV_ANYMDP_PIPE_MIN_STEPS") ? atoi(getenv("XV_ANYMDP_PIPE_MIN_STEPS")) : XV_ANYMDP_PIPE_GRAPH_MIN;
   if (cycles <= 0 || period % 2 != 0 || n_steps < min_steps) return XV_OK;
+  // both launches resident at once, or the one-stream path (xv_pipe.h)
+  if (!xv_pipe_two_launches_fit(anymdp_graph_step_fn(h, anymdp_effective_search(h), true), 256, (size_t)xv_div_up(h->a.n_env, 256),
+                                h->eng->device))
+    return XV_OK;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;      // not inside a stream capture: the set-up synchronises
   if (hipStreamIsCapturing(h->eng->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return XV_OK; }
   if (!anymdp_pipe_setup(h) ||
@@ -2718,6 +2722,14 @@ extern "C" int xv_anymdp_step_tokens_info(xv_anymdp* h, const int32_t* action, i
 // n_steps token steps issued from C over ring buffers: step k reads actions slot k % period ([period][n_env][d_act]) and
 // writes slot k % period of the outputs (obs / final_obs [period][n_env][d_obs], the others [period][n_env]); equals
 // n_steps calls of xv_anymdp_step_tokens (a Python / ctypes loop costs more per call than the 10-20 us kernel)
+static void* anymdp_tok_hand_fn(const xv_anymdp* h) {      // the HAND instantiation of the cooperative token kernel for this handle
+  const bool pair = h->d_obs > 1;
+  return h->a.bfmt == 1 ? (pair ? reinterpret_cast<void*>(&anymdp_tok_step_coop_kernel<false, 1, true, true>)
+                                : reinterpret_cast<void*>(&anymdp_tok_step_coop_kernel<false, 1, false, true>))
+                        : (pair ? reinterpret_cast<void*>(&anymdp_tok_step_coop_kernel<false, 2, true, true>)
+                                : reinterpret_cast<void*>(&anymdp_tok_step_coop_kernel<false, 2, false, true>));
+}
+
 // the two cycle graphs of the overlapped token step: HAND instantiations of the cooperative kernel, ring slots q, q + 2, ...
 static bool anymdp_tok_pipe_graphs(xv_anymdp* h, int period, const int32_t* action, int32_t* obs, float* reward, float* reward_gt,
                                    uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
@@ -2730,11 +2742,7 @@ static bool anymdp_tok_pipe_graphs(xv_anymdp* h, int period, const int32_t* acti
   (void)hipStreamSynchronize(h->side);
   (void)hipStreamSynchronize(h->eng->stream);
   anymdp_pipe_drop_graphs(h);
-  const bool pair = h->d_obs > 1;
-  void* fn = h->a.bfmt == 1 ? (pair ? reinterpret_cast<void*>(&anymdp_tok_step_coop_kernel<false, 1, true, true>)
-                                    : reinterpret_cast<void*>(&anymdp_tok_step_coop_kernel<false, 1, false, true>))
-                            : (pair ? reinterpret_cast<void*>(&anymdp_tok_step_coop_kernel<false, 2, true, true>)
-                                    : reinterpret_cast<void*>(&anymdp_tok_step_coop_kernel<false, 2, false, true>));
+  void* fn = anymdp_tok_hand_fn(h);
   const size_t n = (size_t)h->a.n_env, da = (size_t)h->d_act, dob = (size_t)h->d_obs;
   const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
   for (int q = 0; q < 2; ++q) {
@@ -2783,8 +2791,8 @@ extern "C" int xv_anymdp_step_tokens_many(xv_anymdp* h, int n_steps, int period,
   h->pipe_used_last = false;
   const int cycles = n_steps / period;
   if (h->overlap && !h->eng->dev_tick && !h->pipe_failed && anymdp_tok_coop(h) && cycles > 0 && period % 2 == 0 &&
-      n_steps >= XV_ANYMDP_PIPE_GRAPH_MIN) {
-    XV_HIP(hipSetDevice(h->eng->device));
+      n_steps >= XV_ANYMDP_PIPE_GRAPH_MIN && hipSetDevice(h->eng->device) == hipSuccess &&
+      xv_pipe_two_launches_fit(anymdp_tok_hand_fn(h), 256, (size_t)xv_div_up(h->a.n_env, 256), h->eng->device)) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(h->eng->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
     if (!capturing) {

@@ -318,10 +318,14 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
   if (a->eng->stream != l->eng->stream || a->eng->stream != c->eng->stream || l->eng->device != dev || c->eng->device != dev) return XV_OK;
   const int v = mixed_variant(a, l);
   if (v < 0) return XV_OK;
+  XV_HIP(hipSetDevice(dev));
+  // both launches resident at once, or the ordinary loop (xv_pipe.h)
+  if (!xv_pipe_two_launches_fit(mixed_hand_fn(v), 256,
+                                (size_t)(xv_div_up(a->a.n_env, 256) + xv_div_up(xv_div_up(l->a.n_slot, 16), 4) + xv_div_up(c->a.n_env, 256)), dev))
+    return XV_OK;
   hipStream_t st = a->eng->stream;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return XV_OK; }
-  XV_HIP(hipSetDevice(dev));
   const int n_lw = xv_div_up(l->a.n_slot, 16), n_cw = xv_div_up(c->a.n_env, 64);
   anymdp_bind_rng(a, 0, false);
   linds_bind_rng(l, 0, false);

@@ -178,3 +178,17 @@ static inline void xv_pipe_test_stall(int cycle) {
   const char* v = getenv("XV_PIPE_TEST_STALL_MS");
   if (v && atoi(v) > 0) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(v)));
 }
+
+// Two launches of `fn` must be able to be RESIDENT at once.  A workgroup of step k + 1 that holds a slot spins until the
+// same workgroup of step k has run; if step k still has workgroups waiting for a slot while step k + 1's spinners hold them
+// all (the side stream may be served first), nobody moves until the bounded waits expire.  With 2 x grid <= what the device
+// holds of this kernel that cannot happen: every workgroup of step k gets its slot without waiting for one of step k + 1.
+static bool xv_pipe_two_launches_fit(const void* fn, int block_threads, size_t grid_blocks, int device) {
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block_threads, 0) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return 2 * grid_blocks <= (size_t)per_cu * (size_t)cus;
+}
