@@ -254,12 +254,15 @@ int xv_anymdp_step_many_graph_state(xv_anymdp* h);
 /* Overlapped xv_anymdp_step_many (ABI 10; off by default).  on = 1: whole ring cycles of an EVEN period are issued as two
  * cycle graphs — ring slots 0, 2, ... on the engine's stream, 1, 3, ... on a side stream the handle owns — with no dependency
  * between the streams: step k + 1 is dispatched while step k runs, and each of its waves takes its 64 envs over from the
- * same wave of step k through a hand-off word in device memory (release / acquire at agent scope; an env depends on its own
- * previous step only, anymdp_env.py:92-132).  The drain-and-dispatch gap between two dependent launches of one stream
+ * same wave of step k through a tag in the envs' 8-byte records (one agent-scope store hands an env on; an env depends on
+ * its own previous step only, anymdp_env.py:92-132).  The drain-and-dispatch gap between two dependent launches of one stream
  * (2.7 of the 5.0 us of a 65,536-env step) is covered by the other stream.  The engine's stream waits for the side stream
- * before the call's remainder and whatever follows.  Same launch ticks, same results as plain launches.  A wave's wait is
- * bounded (2 ms): if the two streams do not run concurrently it expires, the wave goes on and XV_DEVERR_HANDOFF is set in
- * the engine's error word — wrong data, flagged, never a hang.  Needs the fence or bucket search and the host tick;
+ * before the call's remainder and whatever follows.  Same launch ticks, same results as plain launches.  The side stream is
+ * chosen by measurement at the first overlapped call (xv_engine_probe_side_streams); each cycle's even half starts behind a
+ * gate the host opens once both halves are enqueued; calls whose two launches could not be resident together take the
+ * one-stream path.  A wave's wait is bounded — 2^20 polls AND 2 s of wall clock (a suspended wave does not poll: time the
+ * device spends on another process does not count) — then the wave goes on and XV_DEVERR_HANDOFF is set in the engine's
+ * error word: wrong data, flagged, never a hang.  Needs the fence or bucket search and the host tick;
  * otherwise, and for odd periods, step_many behaves as without it.
  * One handle per device at a time, never a view (XV_ERR_UNSUPPORTED): two overlapped calls in flight can block each other
  * on the hardware queues their streams share.  Not inside a stream capture (the call takes the one-stream path).
@@ -777,7 +780,7 @@ int xv_mixed_step_many(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mixed
  * the launch of step k + 1 runs under step k; every wave takes its envs over from the same wave of the step before (AnyMDP:
  * tag in the env record; LinDS and CartPole: one word per wave).  Same launch ticks, same results, bit for bit.  Needs
  * the three handles on three engines of their own (host ticks, one stream); otherwise, and for the steps beyond the last
- * whole ring cycle, the ordinary loop runs.  A wait that exceeds 50 ms sets XV_DEVERR_HANDOFF (never a hang).
+ * whole ring cycle, the ordinary loop runs.  Waits are bounded as for xv_anymdp_step_many (XV_DEVERR_HANDOFF, never a hang).
  * xv_mixed_step_many_overlap_state: 1 the last call with this AnyMDP handle was overlapped, 0 it was not, -1 the overlapped
  * path failed on this device (streams do not run concurrently, graph build) and is no longer tried. */
 int xv_mixed_step_many_overlap_state(xv_anymdp* a);

@@ -300,15 +300,15 @@ def test_one_overlapped_handle_per_device_and_never_a_view():
 
 
 def test_a_held_up_host_between_the_two_launches_of_a_cycle_is_harmless(monkeypatch):
-    """The even half of a cycle waits for the odd half's steps for at most 50 ms.  With the host held up for 120 ms between
-    the two graph launches (test hook XV_PIPE_TEST_STALL_MS) that wait would expire — unless the even half starts behind the
+    """The even half of a cycle waits for the odd half's steps for a bounded time (2^20 polls and 2 s).  With the host held up
+    for 3.5 s between the two graph launches (test hook XV_PIPE_TEST_STALL_MS) that wait would expire — unless the even half starts behind the
     cycle gate, which passes only once both halves are enqueued (xv_pipe.h): no flag, same results"""
     tab = oracle.anymdp_synth(seed=12, task_index_base=0, n_task=16, S=64, A=8, s0_max=4)
     n, P = 4096, 8
     acts = np.random.RandomState(6).randint(0, 8, (P, n)).astype(np.int32)
-    plan = [10 * P, 12 * P + 1]
+    plan = [12 * P + 1]
     ref = _run_many(tab, n, P, acts, plan, "fence", 1, "streams", False)
-    monkeypatch.setenv("XV_PIPE_TEST_STALL_MS", "120")
+    monkeypatch.setenv("XV_PIPE_TEST_STALL_MS", "3500")
     got = _run_many(tab, n, P, acts, plan, "fence", 1, "streams", True, overlap=True)      # asserts check_errors() == 0
     _same(ref, got)
     from xenoverse_amd.engine import Engine

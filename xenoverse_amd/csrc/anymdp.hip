@@ -397,9 +397,10 @@ typedef AnyMDPCoopLineN<XV_ANYMDP_TOK_LPE, XV_ANYMDP_COOP_CONTIG != 0> AnyMDPTok
 //     the record IS the hand-off (a separate word costs a second round trip: 4.45 vs 3.95 us per step).  Every lane polls
 //     its own record and the wave goes on when all 64 tags are there (the store of a wave is four cache lines that may
 //     land apart).  A wave depends on the same wave of the previous step only (one lane per env, anymdp_env.py:92-132 is
-//     per env).  The wait is bounded (XV_ANYMDP_HAND_TIMEOUT of the 100-MHz wall clock): on expiry the wave goes on and
-//     sets XV_DEVERR_HANDOFF — wrong results, flagged, never a hang.
-#define XV_ANYMDP_HAND_TIMEOUT 5000000ull   // 50 ms
+//     per env).  Only valid lanes count: a wave without any (n_env not a multiple of 256) would poll the last env's record,
+//     which its owner re-tags for the NEXT step — a late look would never see this step's tag.  The wait is bounded
+//     (xv_hand.h: polls AND wall clock): on expiry the wave goes on and sets XV_DEVERR_HANDOFF — wrong results, flagged,
+//     never a hang.
 template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false, int BK = 0, bool HAND = false>
 __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyMDPStepIO& io, int T_steps, int mode, int bid) {
   constexpr bool FAST = G > 0;
@@ -456,11 +457,11 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
     // Every lane polls its own record: one round trip per try (lane 0 first and then the wave costs a second one: 3.95 vs
     // 3.76 us per step; a second poll in flight half a period behind the first: 3.87 vs 3.83, profiles/r05_o_*); 1,024 waves x
     // 512 B per ~0.7 us is a tenth of the L2's bandwidth.
-    for (;;) {
+    for (uint32_t polls = 0;; ++polls) {
       r64 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__ballot(((uint32_t)r64 >> XV_ANYMDP_SR_TAG_SHIFT) != want) == 0ull) break;
+      if (__ballot(valid && ((uint32_t)r64 >> XV_ANYMDP_SR_TAG_SHIFT) != want) == 0ull) break;
       __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t_begin > XV_ANYMDP_HAND_TIMEOUT) {
+      if (xv_hand_expired(polls, t_begin)) {
         err |= XV_DEVERR_HANDOFF;
         break;
       }
@@ -1165,11 +1166,11 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
     const uint64_t* rp = reinterpret_cast<const uint64_t*>(P.sr) + ic;
     const uint64_t t_begin = wall_clock64();
     uint64_t r64 = 0;
-    for (;;) {
+    for (uint32_t polls = 0;; ++polls) {
       r64 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__ballot(((uint32_t)r64 >> XV_ANYMDP_SR_TAG_SHIFT) != want) == 0ull) break;
+      if (__ballot(valid && ((uint32_t)r64 >> XV_ANYMDP_SR_TAG_SHIFT) != want) == 0ull) break;
       __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t_begin > XV_ANYMDP_HAND_TIMEOUT) { err |= XV_DEVERR_HANDOFF; break; }
+      if (xv_hand_expired(polls, t_begin)) { err |= XV_DEVERR_HANDOFF; break; }
     }
     sr0 = make_uint2((uint32_t)r64, (uint32_t)(r64 >> 32));
   }

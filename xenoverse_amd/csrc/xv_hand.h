@@ -8,13 +8,24 @@
 // Agent-scope relaxed atomics compile to sc1 loads / stores: coherent across the XCDs' L2s without cache maintenance (an
 // agent-scope FENCE is a `buffer_wbl2` per wave, 39 us per step: profiles/r05_b_*).  Ordering comes from the wave itself:
 // the stores have completed (vmcnt 0) before the word is written, and the state loads are issued after the poll returned.
-// The wait is bounded by the 100-MHz wall clock; on expiry the wave goes on and the caller sets XV_DEVERR_HANDOFF —
-// wrong results, flagged, never a hang.
+// The wait is bounded: it gives up — the caller sets XV_DEVERR_HANDOFF: wrong results, flagged, never a hang — once it has
+// polled XV_HAND_MIN_POLLS times AND 2 s of the 100-MHz wall clock have passed.  Both, because the clock alone is not the
+// wave's own time: the device's scheduler can take a process's queues off the hardware for tens of milliseconds when
+// another process touches the GPU; a waiter that comes back finds "its" 50 ms gone although the step before it was simply
+// suspended too (measured with a 50-ms clock bound: 11-15 spurious expiries per 2,700 overlapped soak calls, every family
+// of a step at the same microsecond, 10-25 s apart — profiles/r05_v_*).  A suspended wave does not poll, so polls count
+// the wave's own waiting.  A wait that is late but not lost must never be cut short: waiting longer is always correct.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define XV_HAND_TIMEOUT 5000000ull   // 50 ms of the 100-MHz wall clock
+#define XV_HAND_TIMEOUT 200000000ull   // 2 s of the 100-MHz wall clock ...
+#define XV_HAND_MIN_POLLS (1u << 20)   // ... and this many polls (~0.7 s of polling)
+
+// has a wait that began at t_begin and has polled `polls` times run out?  (the clock is read only beyond the poll count)
+__device__ __forceinline__ bool xv_hand_expired(uint32_t polls, uint64_t t_begin) {
+  return polls > XV_HAND_MIN_POLLS && wall_clock64() - t_begin > XV_HAND_TIMEOUT;
+}
 
 __device__ __forceinline__ uint64_t xv_agent_load64(const void* p) {
   return __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -34,11 +45,11 @@ __device__ __forceinline__ void xv_agent_store_f64(double* p, double v) { xv_age
 // all lanes of the wave wait until *word == want; false: the bound expired
 __device__ __forceinline__ bool xv_hand_wait(const uint32_t* word, uint32_t want) {
   const uint64_t t_begin = wall_clock64();
-  for (;;) {
+  for (uint32_t polls = 0;; ++polls) {
     const uint32_t v = __builtin_amdgcn_readfirstlane(xv_agent_load32(word));
     if (v == want) return true;
     __builtin_amdgcn_s_sleep(1);
-    if (wall_clock64() - t_begin > XV_HAND_TIMEOUT) return false;
+    if (xv_hand_expired(polls, t_begin)) return false;
   }
 }
 

@@ -124,13 +124,14 @@ static bool xv_pipe_pick_side_stream(hipStream_t main, hipStream_t* out, XvPipeC
 
 // ------------------------------------------------------------------------------------------------------------------
 // The cycle gate.  The host issues a ring cycle as two graph launches, the even half on the engine's stream and then the odd
-// half on the side stream.  The even half's second step waits (bounded, 50 ms) for the odd half's first step: were the
+// half on the side stream.  The even half's second step waits (bounded, xv_hand.h) for the odd half's first step: were the
 // host held up between the two launches for longer than that — a page fault, a descheduled thread, the runtime blocking on
 // a full queue — the wait would expire and the results be wrong (flagged, XV_DEVERR_HANDOFF).  So the even half starts
 // with a one-thread GATE node: gate number g (counted in device memory) passes once the host has published
 // `issued >= g`, which it does, in pinned host memory, after BOTH launches of that cycle have been enqueued.  A held-up
-// host then just delays the device.  The gate's own wait is bounded too (2 s; then flagged).
-#define XV_PIPE_GATE_TIMEOUT 200000000ull   // 2 s of the 100-MHz wall clock
+// host then just delays the device.  The gate's own wait is bounded too (polls and 10 s, as xv_hand.h; then flagged).
+#define XV_PIPE_GATE_TIMEOUT 1000000000ull   // 10 s of the 100-MHz wall clock ...
+#define XV_PIPE_GATE_MIN_POLLS (1u << 20)     // ... and this many reads of the host's word (~2 us each): the wave's own waiting
 
 struct XvPipeGate {
   uint32_t* h_issued;   // pinned, mapped host word
@@ -143,8 +144,9 @@ __device__ __forceinline__ void xv_pipe_gate_pass(uint32_t* seen, const uint32_t
   const uint32_t g = *seen + 1u;
   *seen = g;
   const uint64_t t_begin = wall_clock64();
+  uint32_t polls = 0;
   while ((int32_t)(__hip_atomic_load(issued, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - g) < 0) {
-    if (wall_clock64() - t_begin > XV_PIPE_GATE_TIMEOUT) {
+    if (++polls > XV_PIPE_GATE_MIN_POLLS && wall_clock64() - t_begin > XV_PIPE_GATE_TIMEOUT) {
       atomicOr(err, 8u /* XV_DEVERR_HANDOFF */);
       break;
     }
