@@ -21,10 +21,18 @@
 
 #define XV_HAND_TIMEOUT 200000000ull   // 2 s of the 100-MHz wall clock ...
 #define XV_HAND_MIN_POLLS (1u << 20)   // ... and this many polls (~0.7 s of polling)
+#ifndef XV_HAND_POLL_SLEEP
+#define XV_HAND_POLL_SLEEP 1           // s_sleep units (64 clocks) between two polls of a waiting wave
+#endif
 
 // has a wait that began at t_begin and has polled `polls` times run out?  (the clock is read only beyond the poll count)
 __device__ __forceinline__ bool xv_hand_expired(uint32_t polls, uint64_t t_begin) {
+#ifdef XV_HAND_CLOCK_EVERY_POLL      // devtools A/B: the instruction sequence of the clock-only bound (s_memrealtime per poll)
+  const bool late = wall_clock64() - t_begin > XV_HAND_TIMEOUT;
+  return late && polls > XV_HAND_MIN_POLLS;
+#else
   return polls > XV_HAND_MIN_POLLS && wall_clock64() - t_begin > XV_HAND_TIMEOUT;
+#endif
 }
 
 __device__ __forceinline__ uint64_t xv_agent_load64(const void* p) {
@@ -48,7 +56,7 @@ __device__ __forceinline__ bool xv_hand_wait(const uint32_t* word, uint32_t want
   for (uint32_t polls = 0;; ++polls) {
     const uint32_t v = __builtin_amdgcn_readfirstlane(xv_agent_load32(word));
     if (v == want) return true;
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(XV_HAND_POLL_SLEEP);
     if (xv_hand_expired(polls, t_begin)) return false;
   }
 }
