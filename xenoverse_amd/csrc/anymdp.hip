@@ -1943,8 +1943,7 @@ static bool anymdp_add_head_node(xv_anymdp* h, hipGraph_t graph, hipGraphNode_t*
   memset(&np, 0, sizeof(np));
   uint64_t* t = h->d_ptick + q;
   uint64_t dv = (uint64_t)period;
-  static const bool no_gate = getenv("XV_PIPE_NO_GATE") != nullptr;      // devtools: the cost of the gate (profiles/r05_t_*)
-  uint32_t* seen = (q == 0 && !no_gate) ? h->gate.d_seen : nullptr;
+  uint32_t* seen = q == 0 ? h->gate.d_seen : nullptr;
   const uint32_t* issued = h->gate.d_issued;
   uint32_t* err = h->a.err;
   void* params[] = {&t, &dv, &seen, &issued, &err};
