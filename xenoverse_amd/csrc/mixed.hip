@@ -3,9 +3,9 @@
 //
 // The families' step kernels are 4-6 us each at those sizes — about the cost of launching anything — so stepping them
 // one after the other costs three launch latencies per vector step (14-17 us measured), and separate streams cost more
-// in cross-stream waits than the overlap returns (HISTORY.md 5.1).  Here the three families share ONE grid: workgroups
-// [0, nbA) run the AnyMDP step body, [nbA, nbA + nbL) the LinDS matrix body, the rest the CartPole body — the very
-// functions the families' own kernels wrap (anymdp_step_body / linds_step_mfma_body / cartpole_step_body, called with the
+// in cross-stream waits than the overlap returns (HISTORY.md 5.1).  Here the three families share ONE grid: a range of
+// workgroups runs the AnyMDP step body, a range the LinDS matrix body, the rest the CartPole body (the order of the ranges:
+// see the kernel) — the very functions the families' own kernels wrap (anymdp_step_body / linds_step_mfma_body / cartpole_step_body, called with the
 // workgroup's index inside its family), so every env gets bit for bit what xv_anymdp_step / xv_linds_step /
 // xv_cartpole_step would give it.  Each family keeps its handle, its engine tick and its Philox stream; the handles must
 // share one HIP stream.  The reference has no counterpart: it steps one env object per Python call.
@@ -27,13 +27,26 @@ template <int AG, int ABK, int LNS, int LNO, bool HAND = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void mixed_step_kernel(AnyMDPArgs A, AnyMDPStepIO aio, int nbA, LinDSArgs L, LinDSStepIO lio, int nbL, CartPoleArgs C, CartPoleIO cio,
                        int mode) {
+  // Which family gets the first workgroups?  On one stream the step lasts as long as its longest dependent chain, LinDS's
+  // (state -> command rows -> MFMAs -> stores): started first it ends 0.3 us sooner (5.42-5.54 -> 5.04-5.26 us,
+  // profiles/r05_x_*).  Overlapped (HAND), AnyMDP first is the better order (4.57-4.66 against 4.73-4.77).
   const int b = (int)blockIdx.x;
-  if (b < nbA) {
-    anymdp_step_body<false, AG, false, false, ABK, HAND>(A, aio, 1, mode, b);
-  } else if (b < nbA + nbL) {
-    linds_step_mfma_body<LNS, 8, LNO, false, HAND>(L, lio, mode, b - nbA);
+  if (HAND) {
+    if (b < nbA) {
+      anymdp_step_body<false, AG, false, false, ABK, HAND>(A, aio, 1, mode, b);
+    } else if (b < nbA + nbL) {
+      linds_step_mfma_body<LNS, 8, LNO, false, HAND>(L, lio, mode, b - nbA);
+    } else {
+      cartpole_step_body<false, HAND>(C, cio, mode, 1, b - nbA - nbL);
+    }
   } else {
-    cartpole_step_body<false, HAND>(C, cio, mode, 1, b - nbA - nbL);
+    if (b < nbL) {
+      linds_step_mfma_body<LNS, 8, LNO, false, HAND>(L, lio, mode, b);
+    } else if (b < nbL + nbA) {
+      anymdp_step_body<false, AG, false, false, ABK, HAND>(A, aio, 1, mode, b - nbL);
+    } else {
+      cartpole_step_body<false, HAND>(C, cio, mode, 1, b - nbA - nbL);
+    }
   }
 }
 
