@@ -246,6 +246,9 @@ static void mixed_io_slot(const xv_mixed_io* ring, size_t s, size_t na, size_t n
   *out = io;
 }
 
+// ring cycles per cycle graph: short rings are unrolled until a graph holds >= 16 steps behind its head node (as anymdp.hip)
+static inline int mixed_pipe_unroll(int period) { return period >= 32 ? 1 : 32 / period; }
+
 static void* mixed_hand_fn(int v) {
   switch (v) {
     case 0: return reinterpret_cast<void*>(&mixed_step_kernel<1, 0, 16, 16, true>);
@@ -276,7 +279,7 @@ static bool mixed_pipe_graphs(MixedPipe& M, xv_anymdp* a, xv_linds* l, xv_cartpo
     hipGraphNode_t prev = nullptr;
     {
       uint64_t* w = M.d_tick + q;
-      uint64_t dv = (uint64_t)period;
+      uint64_t dv = (uint64_t)period * (uint64_t)mixed_pipe_unroll(period);
       uint32_t* seen = q == 0 ? M.gate.d_seen : nullptr;
       const uint32_t* issued = M.gate.d_issued;
       uint32_t* err = a->a.err;
@@ -286,11 +289,13 @@ static bool mixed_pipe_graphs(MixedPipe& M, xv_anymdp* a, xv_linds* l, xv_cartpo
       np.func = reinterpret_cast<void*>(&mixed_pipe_head_kernel); np.gridDim = dim3(1); np.blockDim = dim3(1); np.kernelParams = hparams;
       if (hipGraphAddKernelNode(&prev, M.graph[q], nullptr, 0, &np) != hipSuccess) return false;
     }
+    for (int rep = 0; rep < mixed_pipe_unroll(period); ++rep)
     for (int s = q; s < period; s += 2) {
       AnyMDPArgs A = K.A; LinDSArgs L = K.L; CartPoleArgs C = K.C;
-      A.tick = (uint64_t)s; A.tick_dev = M.d_tick + q;
-      L.tick = (uint64_t)s; L.tick_dev = M.d_tick + 2 + q;
-      C.tick = (uint64_t)s; C.tick_dev = M.d_tick + 4 + q;
+      const uint64_t tk = (uint64_t)rep * (uint64_t)period + (uint64_t)s;
+      A.tick = tk; A.tick_dev = M.d_tick + q;
+      L.tick = tk; L.tick_dev = M.d_tick + 2 + q;
+      C.tick = tk; C.tick_dev = M.d_tick + 4 + q;
       xv_mixed_io io;
       mixed_io_slot(ring, (size_t)s, na, nl, nc, (size_t)l->a.NA, (size_t)l->a.NO, &io);
       AnyMDPStepIO aio{io.a_action, nullptr, nullptr, nullptr, io.a_obs, io.a_reward, io.a_reward_gt, io.a_terminated,
@@ -321,7 +326,8 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
   std::lock_guard<std::mutex> lock(g_mixed_mu);
   MixedPipe& M = g_mixed_pipe[dev];
   M.used_last = false; M.used_by = a;
-  const int cycles = n_steps / period;
+  const int U = mixed_pipe_unroll(period), per_launch = U * period;
+  const int cycles = n_steps / per_launch;      // launches of the two cycle graphs (U ring cycles each)
   static const int min_steps = getenv("XV_MIXED_PIPE_MIN_STEPS") ? atoi(getenv("XV_MIXED_PIPE_MIN_STEPS")) : XV_MIXED_PIPE_MIN;
   if (cycles <= 0 || period % 2 != 0 || n_steps < min_steps) return XV_OK;
   if (M.failed && M.side_for == a->eng->stream) return XV_OK;      // tried beside this stream already
@@ -352,7 +358,7 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
   const int n_open = std::max(std::max(a->a.n_env, c->a.n_env), std::max(n_lw, 6));
   hipLaunchKernelGGL(mixed_pipe_open_kernel, dim3(xv_div_up(n_open, 256)), dim3(256), 0, st, a->a.sr, a->a.n_env, XV_ANYMDP_SR_TAG(ta),
                      M.d_hand, n_lw, (uint32_t)tl, M.d_hand + n_lw, n_cw, (uint32_t)tc, c->a.steps, c->a.need_reset, c->a.n_env,
-                     M.d_tick, ta - (uint64_t)period, tl - (uint64_t)period, tc - (uint64_t)period);   // the head nodes add `period`
+                     M.d_tick, ta - (uint64_t)per_launch, tl - (uint64_t)per_launch, tc - (uint64_t)per_launch);   // the head nodes add it
   bool ok = hipGetLastError() == hipSuccess && hipEventRecord(M.ev[0], st) == hipSuccess &&
             hipStreamWaitEvent(M.side, M.ev[0], 0) == hipSuccess;
   int k = 0;
@@ -365,7 +371,7 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
       xv_pipe_test_stall(cy);
       if (hipGraphLaunch(M.exec[1], M.side) != hipSuccess) { broken = true; xv_pipe_gate_release(&M.gate); break; }
       xv_pipe_gate_release(&M.gate);
-      k += period;
+      k += per_launch;
     }
   }
   a->eng->tick = ta + (uint64_t)k; l->eng->tick = tl + (uint64_t)k; c->eng->tick = tc + (uint64_t)k;
@@ -373,7 +379,7 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
   hipLaunchKernelGGL(mixed_pipe_close_kernel, dim3(xv_div_up(c->a.n_env, 256)), dim3(256), 0, st, c->a.steps, c->a.need_reset, c->a.n_env);
   const bool closed = hipGetLastError() == hipSuccess;
   *issued = k;
-  if (!ok || k < cycles * period) { (void)hipGetLastError(); M.failed = true; }
+  if (!ok || k < cycles * per_launch) { (void)hipGetLastError(); M.failed = true; }
   if (broken || !joined || !closed) {
     (void)hipGetLastError();
     M.failed = true;
