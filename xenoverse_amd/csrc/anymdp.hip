@@ -1576,6 +1576,7 @@ static void anymdp_pipe_drop_graphs(xv_anymdp* h) {
   }
   memset(&h->pipe_key, 0, sizeof(h->pipe_key));
   memset(&h->tpipe_key, 0, sizeof(h->tpipe_key));
+  h->gate.unroll[0] = h->gate.unroll[1] = 0;
   h->ptick_valid = false;
 }
 static void anymdp_pipe_release(xv_anymdp* h) {
@@ -1938,17 +1939,12 @@ static bool anymdp_add_tick_node(hipGraph_t graph, const hipGraphNode_t* deps, i
   return hipGraphAddKernelNode(&node, graph, deps, (size_t)n_deps, &np) == hipSuccess;
 }
 
-// Ring cycles per cycle graph of the overlapped paths.  Every graph starts with a head node (tick word, cycle gate: a
-// dispatch and a read of host memory on the even stream's chain); with a short ring that is paid every few steps — period 8:
-// 6.15 instead of 5.6 us per token step.  So short rings are unrolled until a graph holds >= 16 steps.
-static inline int anymdp_pipe_unroll(int period) { return period >= 32 ? 1 : 32 / period; }
-
 // head of cycle graph q of the overlapped paths: tick word q += period; q == 0 passes the cycle gate
-static bool anymdp_add_head_node(xv_anymdp* h, hipGraph_t graph, hipGraphNode_t* prev, int q, int period) {
+static bool anymdp_add_head_node(xv_anymdp* h, hipGraph_t graph, hipGraphNode_t* prev, int q, int period, int unroll) {
   hipKernelNodeParams np;
   memset(&np, 0, sizeof(np));
   uint64_t* t = h->d_ptick + q;
-  uint64_t dv = (uint64_t)period * (uint64_t)anymdp_pipe_unroll(period);
+  uint64_t dv = (uint64_t)period * (uint64_t)unroll;
   uint32_t* seen = q == 0 ? h->gate.d_seen : nullptr;
   const uint32_t* issued = h->gate.d_issued;
   uint32_t* err = h->a.err;
@@ -2092,34 +2088,38 @@ static bool anymdp_pipe_setup(xv_anymdp* h) {
   return true;
 }
 
-static bool anymdp_pipe_graphs(xv_anymdp* h, int period, size_t stride, const int32_t* actions, int32_t* obs, float* reward,
-                               float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
+// -> cycles per graph the call uses (graphs built / reused), 0: this call is not overlapped, -1: failure
+static int anymdp_pipe_graphs(xv_anymdp* h, int period, int cycles, size_t stride, const int32_t* actions, int32_t* obs, float* reward,
+                              float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
   const int eff = anymdp_effective_search(h);
   const void* ptrs[7] = {actions, obs, reward, reward_gt, terminated, truncated, final_obs};
   auto& K = h->pipe_key;
-  if (h->pgraph_exec[0] && h->pgraph_exec[1] && K.period == period && K.mode == mode && K.search == eff && K.stride == stride &&
-      K.bucket == (const void*)h->a.bucket && K.seed == h->eng->seed && K.gid_base == h->eng->env_id_base &&
-      memcmp(K.ptrs, ptrs, sizeof(ptrs)) == 0)
-    return true;
+  const bool same = h->pgraph_exec[0] && h->pgraph_exec[1] && K.period == period && K.mode == mode && K.search == eff &&
+                    K.stride == stride && K.bucket == (const void*)h->a.bucket && K.seed == h->eng->seed &&
+                    K.gid_base == h->eng->env_id_base && memcmp(K.ptrs, ptrs, sizeof(ptrs)) == 0;
+  const int U = xv_pipe_pick_unroll(period, cycles, same ? h->gate.unroll[0] : 0);
+  if (U == 0) return 0;
+  if (same && U == h->gate.unroll[0]) return U;
   (void)hipStreamSynchronize(h->side);
   (void)hipStreamSynchronize(h->eng->stream);
   anymdp_pipe_drop_graphs(h);
   for (int q = 0; q < 2; ++q) {
-    if (hipGraphCreate(&h->pgraph[q], 0) != hipSuccess) return false;
+    if (hipGraphCreate(&h->pgraph[q], 0) != hipSuccess) return -1;
     hipGraphNode_t prev = nullptr;
-    if (!anymdp_add_head_node(h, h->pgraph[q], &prev, q, period)) return false;
+    if (!anymdp_add_head_node(h, h->pgraph[q], &prev, q, period, U)) return -1;
     if (!anymdp_add_chain(h, h->pgraph[q], &prev, h->d_ptick + q, eff, period, stride, actions, obs, reward, reward_gt,
-                          terminated, truncated, final_obs, mode, q, 2, true, anymdp_pipe_unroll(period)))
-      return false;
+                          terminated, truncated, final_obs, mode, q, 2, true, U))
+      return -1;
     if (hipGraphInstantiate(&h->pgraph_exec[q], h->pgraph[q], nullptr, nullptr, 0) != hipSuccess) {
       h->pgraph_exec[q] = nullptr;
-      return false;
+      return -1;
     }
   }
   K.period = period; K.mode = mode; K.search = eff; K.stride = stride; K.bucket = (const void*)h->a.bucket;
   K.seed = h->eng->seed; K.gid_base = h->eng->env_id_base;
   memcpy(K.ptrs, ptrs, sizeof(ptrs));
-  return true;
+  h->gate.unroll[0] = U;
+  return U;
 }
 
 // the whole ring cycles of a call, overlapped; *issued = steps issued (0: the caller takes the ordinary path for all of it).
@@ -2132,20 +2132,22 @@ static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride,
   *issued = 0;
   const int cycles = n_steps / period;
   static const int min_steps = getenv("XV_ANYMDP_PIPE_MIN_STEPS") ? atoi(getenv("XV_ANYMDP_PIPE_MIN_STEPS")) : XV_ANYMDP_PIPE_GRAPH_MIN;
-  if (cycles <= 0 || period % 2 != 0 || n_steps < min_steps || cycles / anymdp_pipe_unroll(period) <= 0) return XV_OK;
+  if (cycles <= 0 || period % 2 != 0 || n_steps < min_steps) return XV_OK;
   // both launches resident at once, or the one-stream path (xv_pipe.h)
   if (!xv_pipe_two_launches_fit(anymdp_graph_step_fn(h, anymdp_effective_search(h), true), 256, (size_t)xv_div_up(h->a.n_env, 256),
                                 h->eng->device))
     return XV_OK;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;      // not inside a stream capture: the set-up synchronises
   if (hipStreamIsCapturing(h->eng->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return XV_OK; }
-  if (!anymdp_pipe_setup(h) ||
-      !anymdp_pipe_graphs(h, period, stride, actions, obs, reward, reward_gt, terminated, truncated, final_obs, mode)) {
+  const int U = anymdp_pipe_setup(h) ? anymdp_pipe_graphs(h, period, cycles, stride, actions, obs, reward, reward_gt, terminated,
+                                                          truncated, final_obs, mode) : -1;
+  if (U < 0) {
     (void)hipGetLastError();
     h->pipe_failed = true;
     return XV_OK;
   }
-  return anymdp_pipe_launch(h, h->pgraph_exec, cycles / anymdp_pipe_unroll(period), period * anymdp_pipe_unroll(period), issued);
+  if (U == 0) return XV_OK;      // too short for the graphs this handle holds: one stream
+  return anymdp_pipe_launch(h, h->pgraph_exec, cycles / U, period * U, issued);
 }
 
 // `cycles` replays of the two cycle graphs ex[0] (engine's stream) / ex[1] (side stream): tags, tick words, fork, launches, join
@@ -2737,14 +2739,18 @@ static void* anymdp_tok_hand_fn(const xv_anymdp* h) {      // the HAND instantia
 }
 
 // the two cycle graphs of the overlapped token step: HAND instantiations of the cooperative kernel, ring slots q, q + 2, ...
-static bool anymdp_tok_pipe_graphs(xv_anymdp* h, int period, const int32_t* action, int32_t* obs, float* reward, float* reward_gt,
-                                   uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
+// -> cycles per graph (built / reused), 0: this call is not overlapped, -1: failure
+static int anymdp_tok_pipe_graphs(xv_anymdp* h, int period, int cycles, const int32_t* action, int32_t* obs, float* reward,
+                                  float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
   const void* ptrs[7] = {action, obs, reward, reward_gt, terminated, truncated, final_obs};
   auto& K = h->tpipe_key;
-  if (h->tgraph_exec[0] && h->tgraph_exec[1] && K.period == period && K.mode == mode && K.fmt == h->a.bfmt && K.d_obs == h->d_obs &&
-      K.d_act == h->d_act && K.bucket == (const void*)h->a.bucket && K.obs_bucket == (const void*)h->obs_bucket &&
-      K.seed == h->eng->seed && K.gid_base == h->eng->env_id_base && memcmp(K.ptrs, ptrs, sizeof(ptrs)) == 0)
-    return true;
+  const bool same = h->tgraph_exec[0] && h->tgraph_exec[1] && K.period == period && K.mode == mode && K.fmt == h->a.bfmt &&
+                    K.d_obs == h->d_obs && K.d_act == h->d_act && K.bucket == (const void*)h->a.bucket &&
+                    K.obs_bucket == (const void*)h->obs_bucket && K.seed == h->eng->seed && K.gid_base == h->eng->env_id_base &&
+                    memcmp(K.ptrs, ptrs, sizeof(ptrs)) == 0;
+  const int U = xv_pipe_pick_unroll(period, cycles, same ? h->gate.unroll[1] : 0);
+  if (U == 0) return 0;
+  if (same && U == h->gate.unroll[1]) return U;
   (void)hipStreamSynchronize(h->side);
   (void)hipStreamSynchronize(h->eng->stream);
   anymdp_pipe_drop_graphs(h);
@@ -2752,10 +2758,10 @@ static bool anymdp_tok_pipe_graphs(xv_anymdp* h, int period, const int32_t* acti
   const size_t n = (size_t)h->a.n_env, da = (size_t)h->d_act, dob = (size_t)h->d_obs;
   const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
   for (int q = 0; q < 2; ++q) {
-    if (hipGraphCreate(&h->tgraph[q], 0) != hipSuccess) return false;
+    if (hipGraphCreate(&h->tgraph[q], 0) != hipSuccess) return -1;
     hipGraphNode_t prev = nullptr;
-    if (!anymdp_add_head_node(h, h->tgraph[q], &prev, q, period)) return false;
-    for (int rep = 0; rep < anymdp_pipe_unroll(period); ++rep)
+    if (!anymdp_add_head_node(h, h->tgraph[q], &prev, q, period, U)) return -1;
+    for (int rep = 0; rep < U; ++rep)
     for (int j = q; j < period; j += 2) {
       AnyMDPArgs a = h->a;
       a.seed = h->eng->seed; a.gid_base = h->eng->env_id_base;
@@ -2770,16 +2776,17 @@ static bool anymdp_tok_pipe_graphs(xv_anymdp* h, int period, const int32_t* acti
       memset(&np, 0, sizeof(np));
       np.func = fn; np.gridDim = grid; np.blockDim = block; np.kernelParams = params;
       hipGraphNode_t node;
-      if (hipGraphAddKernelNode(&node, h->tgraph[q], prev ? &prev : nullptr, prev ? 1 : 0, &np) != hipSuccess) return false;
+      if (hipGraphAddKernelNode(&node, h->tgraph[q], prev ? &prev : nullptr, prev ? 1 : 0, &np) != hipSuccess) return -1;
       prev = node;
     }
-    if (hipGraphInstantiate(&h->tgraph_exec[q], h->tgraph[q], nullptr, nullptr, 0) != hipSuccess) { h->tgraph_exec[q] = nullptr; return false; }
+    if (hipGraphInstantiate(&h->tgraph_exec[q], h->tgraph[q], nullptr, nullptr, 0) != hipSuccess) { h->tgraph_exec[q] = nullptr; return -1; }
   }
   K.period = period; K.mode = mode; K.fmt = h->a.bfmt; K.d_obs = h->d_obs; K.d_act = h->d_act;
   K.bucket = (const void*)h->a.bucket; K.obs_bucket = (const void*)h->obs_bucket;
   K.seed = h->eng->seed; K.gid_base = h->eng->env_id_base;
   memcpy(K.ptrs, ptrs, sizeof(ptrs));
-  return true;
+  h->gate.unroll[1] = U;
+  return U;
 }
 
 // n_steps token steps issued from C over ring buffers: step k reads actions slot k % period ([period][n_env][d_act]) and
@@ -2798,16 +2805,17 @@ extern "C" int xv_anymdp_step_tokens_many(xv_anymdp* h, int n_steps, int period,
   h->pipe_used_last = false;
   const int cycles = n_steps / period;
   if (h->overlap && !h->eng->dev_tick && !h->pipe_failed && anymdp_tok_coop(h) && cycles > 0 && period % 2 == 0 &&
-      n_steps >= XV_ANYMDP_PIPE_GRAPH_MIN && cycles / anymdp_pipe_unroll(period) > 0 && hipSetDevice(h->eng->device) == hipSuccess &&
+      n_steps >= XV_ANYMDP_PIPE_GRAPH_MIN && hipSetDevice(h->eng->device) == hipSuccess &&
       xv_pipe_two_launches_fit(anymdp_tok_hand_fn(h), 256, (size_t)xv_div_up(h->a.n_env, 256), h->eng->device)) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(h->eng->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
     if (!capturing) {
-      if (anymdp_pipe_setup(h) && anymdp_tok_pipe_graphs(h, period, action, obs, reward, reward_gt, terminated, truncated,
-                                                          final_obs, autoreset_mode)) {
-        const int rc = anymdp_pipe_launch(h, h->tgraph_exec, cycles / anymdp_pipe_unroll(period), period * anymdp_pipe_unroll(period), &k);
+      const int U = anymdp_pipe_setup(h) ? anymdp_tok_pipe_graphs(h, period, cycles, action, obs, reward, reward_gt, terminated,
+                                                                  truncated, final_obs, autoreset_mode) : -1;
+      if (U > 0) {
+        const int rc = anymdp_pipe_launch(h, h->tgraph_exec, cycles / U, period * U, &k);
         if (rc != XV_OK) return rc;
-      } else {
+      } else if (U < 0) {
         (void)hipGetLastError();
         h->pipe_failed = true;
       }

@@ -198,6 +198,7 @@ static __global__ void mixed_pipe_head_kernel(uint64_t* w, uint64_t dv, uint32_t
 }
 
 static void mixed_pipe_drop_graphs(MixedPipe& M) {
+  M.gate.unroll[0] = 0;
   for (int q = 0; q < 2; ++q) {
     if (M.exec[q]) (void)hipGraphExecDestroy(M.exec[q]);
     if (M.graph[q]) (void)hipGraphDestroy(M.graph[q]);
@@ -246,9 +247,6 @@ static void mixed_io_slot(const xv_mixed_io* ring, size_t s, size_t na, size_t n
   *out = io;
 }
 
-// ring cycles per cycle graph: short rings are unrolled until a graph holds >= 16 steps behind its head node (as anymdp.hip)
-static inline int mixed_pipe_unroll(int period) { return period >= 32 ? 1 : 32 / period; }
-
 static void* mixed_hand_fn(int v) {
   switch (v) {
     case 0: return reinterpret_cast<void*>(&mixed_step_kernel<1, 0, 16, 16, true>);
@@ -258,8 +256,9 @@ static void* mixed_hand_fn(int v) {
   }
 }
 
-static bool mixed_pipe_graphs(MixedPipe& M, xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mixed_io* ring, int period, int mode,
-                              int v, int n_lw) {
+// -> ring cycles per graph (built / reused), 0: this call is not overlapped, -1: failure
+static int mixed_pipe_graphs(MixedPipe& M, xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mixed_io* ring, int period, int ring_cycles,
+                             int mode, int v, int n_lw) {
   MixedPipeKey K;
   memset(&K, 0, sizeof(K));
   memcpy(&K.A, &a->a, sizeof(K.A)); memcpy(&K.L, &l->a, sizeof(K.L)); memcpy(&K.C, &c->a, sizeof(K.C));
@@ -267,7 +266,10 @@ static bool mixed_pipe_graphs(MixedPipe& M, xv_anymdp* a, xv_linds* l, xv_cartpo
   K.L.hand = M.d_hand; K.C.hand = M.d_hand + n_lw;
   memcpy(&K.ring, ring, sizeof(K.ring));
   K.period = period; K.mode = mode; K.variant = v;
-  if (M.key_valid && M.exec[0] && M.exec[1] && memcmp(&K, &M.key, sizeof(K)) == 0) return true;
+  const bool same = M.key_valid && M.exec[0] && M.exec[1] && memcmp(&K, &M.key, sizeof(K)) == 0;
+  const int U = xv_pipe_pick_unroll(period, ring_cycles, same ? M.gate.unroll[0] : 0);
+  if (U == 0) return 0;
+  if (same && U == M.gate.unroll[0]) return U;
   (void)hipStreamSynchronize(M.side);
   (void)hipStreamSynchronize(a->eng->stream);
   mixed_pipe_drop_graphs(M);
@@ -275,11 +277,11 @@ static bool mixed_pipe_graphs(MixedPipe& M, xv_anymdp* a, xv_linds* l, xv_cartpo
   int nbA = xv_div_up(a->a.n_env, 256), nbL = xv_div_up(xv_div_up(l->a.n_slot, 16), 4), nbC = xv_div_up(c->a.n_env, 256);
   void* fn = mixed_hand_fn(v);
   for (int q = 0; q < 2; ++q) {
-    if (hipGraphCreate(&M.graph[q], 0) != hipSuccess) return false;
+    if (hipGraphCreate(&M.graph[q], 0) != hipSuccess) return -1;
     hipGraphNode_t prev = nullptr;
     {
       uint64_t* w = M.d_tick + q;
-      uint64_t dv = (uint64_t)period * (uint64_t)mixed_pipe_unroll(period);
+      uint64_t dv = (uint64_t)period * (uint64_t)U;
       uint32_t* seen = q == 0 ? M.gate.d_seen : nullptr;
       const uint32_t* issued = M.gate.d_issued;
       uint32_t* err = a->a.err;
@@ -287,9 +289,9 @@ static bool mixed_pipe_graphs(MixedPipe& M, xv_anymdp* a, xv_linds* l, xv_cartpo
       hipKernelNodeParams np;
       memset(&np, 0, sizeof(np));
       np.func = reinterpret_cast<void*>(&mixed_pipe_head_kernel); np.gridDim = dim3(1); np.blockDim = dim3(1); np.kernelParams = hparams;
-      if (hipGraphAddKernelNode(&prev, M.graph[q], nullptr, 0, &np) != hipSuccess) return false;
+      if (hipGraphAddKernelNode(&prev, M.graph[q], nullptr, 0, &np) != hipSuccess) return -1;
     }
-    for (int rep = 0; rep < mixed_pipe_unroll(period); ++rep)
+    for (int rep = 0; rep < U; ++rep)
     for (int s = q; s < period; s += 2) {
       AnyMDPArgs A = K.A; LinDSArgs L = K.L; CartPoleArgs C = K.C;
       const uint64_t tk = (uint64_t)rep * (uint64_t)period + (uint64_t)s;
@@ -308,13 +310,14 @@ static bool mixed_pipe_graphs(MixedPipe& M, xv_anymdp* a, xv_linds* l, xv_cartpo
       memset(&np, 0, sizeof(np));
       np.func = fn; np.gridDim = dim3(nbA + nbL + nbC); np.blockDim = dim3(256); np.kernelParams = params;
       hipGraphNode_t node = nullptr;
-      if (hipGraphAddKernelNode(&node, M.graph[q], prev ? &prev : nullptr, prev ? 1 : 0, &np) != hipSuccess) return false;
+      if (hipGraphAddKernelNode(&node, M.graph[q], prev ? &prev : nullptr, prev ? 1 : 0, &np) != hipSuccess) return -1;
       prev = node;
     }
-    if (hipGraphInstantiate(&M.exec[q], M.graph[q], nullptr, nullptr, 0) != hipSuccess) { M.exec[q] = nullptr; return false; }
+    if (hipGraphInstantiate(&M.exec[q], M.graph[q], nullptr, nullptr, 0) != hipSuccess) { M.exec[q] = nullptr; return -1; }
   }
   M.key = K; M.key_valid = true;
-  return true;
+  M.gate.unroll[0] = U;
+  return U;
 }
 
 // whole ring cycles of a call, overlapped; *issued = steps issued (0: the caller's loop takes all of them)
@@ -326,10 +329,9 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
   std::lock_guard<std::mutex> lock(g_mixed_mu);
   MixedPipe& M = g_mixed_pipe[dev];
   M.used_last = false; M.used_by = a;
-  const int U = mixed_pipe_unroll(period), per_launch = U * period;
-  const int cycles = n_steps / per_launch;      // launches of the two cycle graphs (U ring cycles each)
+  const int ring_cycles = n_steps / period;
   static const int min_steps = getenv("XV_MIXED_PIPE_MIN_STEPS") ? atoi(getenv("XV_MIXED_PIPE_MIN_STEPS")) : XV_MIXED_PIPE_MIN;
-  if (cycles <= 0 || period % 2 != 0 || n_steps < min_steps) return XV_OK;
+  if (ring_cycles <= 0 || period % 2 != 0 || n_steps < min_steps) return XV_OK;
   if (M.failed && M.side_for == a->eng->stream) return XV_OK;      // tried beside this stream already
   M.failed = false;
   if (a->eng == l->eng || a->eng == c->eng || l->eng == c->eng) return XV_OK;      // one tick per family and step
@@ -349,11 +351,14 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
   anymdp_bind_rng(a, 0, false);
   linds_bind_rng(l, 0, false);
   cartpole_bind_rng(c, 0, false);
-  if (!mixed_pipe_setup(M, st, (size_t)(n_lw + n_cw)) || !mixed_pipe_graphs(M, a, l, c, ring, period, mode, v, n_lw)) {
+  const int U = mixed_pipe_setup(M, st, (size_t)(n_lw + n_cw)) ? mixed_pipe_graphs(M, a, l, c, ring, period, ring_cycles, mode, v, n_lw) : -1;
+  if (U < 0) {
     (void)hipGetLastError();
     M.failed = true;
     return XV_OK;
   }
+  if (U == 0) return XV_OK;      // too short for the graphs held: the ordinary loop
+  const int per_launch = U * period, cycles = ring_cycles / U;      // launches of the two cycle graphs (U ring cycles each)
   const uint64_t ta = a->eng->tick, tl = l->eng->tick, tc = c->eng->tick;
   const int n_open = std::max(std::max(a->a.n_env, c->a.n_env), std::max(n_lw, 6));
   hipLaunchKernelGGL(mixed_pipe_open_kernel, dim3(xv_div_up(n_open, 256)), dim3(256), 0, st, a->a.sr, a->a.n_env, XV_ANYMDP_SR_TAG(ta),

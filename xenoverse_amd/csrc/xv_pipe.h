@@ -142,6 +142,7 @@ struct XvPipeGate {
   uint32_t* d_issued;   // the device's view of it
   uint32_t* d_seen;     // gates passed so far (device memory)
   uint32_t issued;      // host mirror
+  int unroll[2];        // ring cycles per cycle graph of the graph pairs built on this gate (0: none built); see below
 };
 
 __device__ __forceinline__ void xv_pipe_gate_pass(uint32_t* seen, const uint32_t* issued, uint32_t* err) {
@@ -159,7 +160,7 @@ __device__ __forceinline__ void xv_pipe_gate_pass(uint32_t* seen, const uint32_t
 }
 
 static bool xv_pipe_gate_create(XvPipeGate* g) {
-  g->h_issued = nullptr; g->d_issued = nullptr; g->d_seen = nullptr; g->issued = 0;
+  g->h_issued = nullptr; g->d_issued = nullptr; g->d_seen = nullptr; g->issued = 0; g->unroll[0] = g->unroll[1] = 0;
   if (hipHostMalloc(reinterpret_cast<void**>(&g->h_issued), 64, hipHostMallocMapped) != hipSuccess) { g->h_issued = nullptr; return false; }
   *g->h_issued = 0u;
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&g->d_issued), g->h_issued, 0) != hipSuccess) return false;
@@ -197,4 +198,23 @@ static bool xv_pipe_two_launches_fit(const void* fn, int block_threads, size_t g
     return false;
   }
   return 2 * grid_blocks <= (size_t)per_cu * (size_t)cus;
+}
+
+// Ring cycles per cycle graph.  Every cycle graph starts with a head node (tick word; on the even stream the cycle gate: a
+// dispatch and a read of host memory on that stream's chain), so the more steps a graph holds the less the head costs per
+// step — measured at 65,536 envs, period 32: 16 steps per graph 3.94 us, 32: 3.79, 64: 3.65-3.77, 128: 3.70-3.72 (2b: 3.51 /
+// 3.30 / 3.23 / 3.20; a token step on a ring of 8: 6.15 us with 4 steps per graph, 4.95 with 16) — profiles/r05_x_*.
+// A call must hold at least one whole graph, so the unroll is chosen per call, sticky: long calls (>= XV_PIPE_GRAPH_STEPS_BIG
+// steps) build the big graphs; a handle that has them serves shorter calls on one stream rather than rebuilding; a handle
+// without them serves calls of >= XV_PIPE_GRAPH_STEPS_SMALL steps with small graphs.  -> cycles per graph, 0: do not overlap
+// this call.  have: what the handle's graphs for these rings hold now (0: none).
+#define XV_PIPE_GRAPH_STEPS_BIG 128
+#define XV_PIPE_GRAPH_STEPS_SMALL 32
+static inline int xv_pipe_pick_unroll(int period, int cycles, int have) {
+  static const int big_steps = getenv("XV_PIPE_GRAPH_STEPS") ? atoi(getenv("XV_PIPE_GRAPH_STEPS")) : XV_PIPE_GRAPH_STEPS_BIG;   // devtools A/B
+  const int big = period >= big_steps ? 1 : big_steps / period;
+  const int small = period >= XV_PIPE_GRAPH_STEPS_SMALL ? 1 : XV_PIPE_GRAPH_STEPS_SMALL / period;
+  if (cycles >= big) return big;
+  if (have == big && big != small) return 0;
+  return cycles >= small ? small : 0;
 }
