@@ -179,9 +179,9 @@ static inline void xv_pipe_gate_release(XvPipeGate* g) {
 }
 
 // test hook (tests/test_gpu_chains.py): XV_PIPE_TEST_STALL_MS=<ms> holds the host up between the two launches of the
-// second cycle of every overlapped call — longer than the hand-off bound, the cycle gate must make that harmless
+// first graph pair of every overlapped call — longer than the hand-off bound, the cycle gate must make that harmless
 static inline void xv_pipe_test_stall(int cycle) {
-  if (cycle != 1) return;
+  if (cycle != 0) return;
   const char* v = getenv("XV_PIPE_TEST_STALL_MS");
   if (v && atoi(v) > 0) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(v)));
 }
@@ -204,17 +204,28 @@ static bool xv_pipe_two_launches_fit(const void* fn, int block_threads, size_t g
 // dispatch and a read of host memory on that stream's chain), so the more steps a graph holds the less the head costs per
 // step — measured at 65,536 envs, period 32: 16 steps per graph 3.94 us, 32: 3.79, 64: 3.65-3.77, 128: 3.70-3.72 (2b: 3.51 /
 // 3.30 / 3.23 / 3.20; a token step on a ring of 8: 6.15 us with 4 steps per graph, 4.95 with 16) — profiles/r05_x_*.
-// A call must hold at least one whole graph, so the unroll is chosen per call, sticky: long calls (>= XV_PIPE_GRAPH_STEPS_BIG
-// steps) build the big graphs; a handle that has them serves shorter calls on one stream rather than rebuilding; a handle
-// without them serves calls of >= XV_PIPE_GRAPH_STEPS_SMALL steps with small graphs.  -> cycles per graph, 0: do not overlap
-// this call.  have: what the handle's graphs for these rings hold now (0: none).
+// A call is served by whole graphs; the ring cycles that do not fill one go out on one stream.  So the unroll U is chosen
+// per call by a small cost model — steps in graphs cost 1 + 1.15 / (steps per graph and stream), left-over steps 1.3 (the
+// one-stream step against the overlapped one) — over U = 1 .. XV_PIPE_GRAPH_STEPS_BIG / period, and it is sticky: the graphs
+// a handle holds are kept while they are within 3 % of the best choice for the call at hand (a rebuild costs milliseconds;
+// callers repeat one call length).  -> ring cycles per graph, 0: do not overlap this call.  have: what the handle's graphs
+// for these rings hold now (0: none).
 #define XV_PIPE_GRAPH_STEPS_BIG 128
-#define XV_PIPE_GRAPH_STEPS_SMALL 32
+static inline double xv_pipe_unroll_cost(int period, int cycles, int U) {
+  const int covered = U * (cycles / U) * period, left = cycles * period - covered;
+  if (covered <= 0) return 1.0e30;
+  return (double)covered * (1.0 + 1.15 / (0.5 * (double)U * (double)period)) + 1.3 * (double)left;
+}
 static inline int xv_pipe_pick_unroll(int period, int cycles, int have) {
   static const int big_steps = getenv("XV_PIPE_GRAPH_STEPS") ? atoi(getenv("XV_PIPE_GRAPH_STEPS")) : XV_PIPE_GRAPH_STEPS_BIG;   // devtools A/B
   const int big = period >= big_steps ? 1 : big_steps / period;
-  const int small = period >= XV_PIPE_GRAPH_STEPS_SMALL ? 1 : XV_PIPE_GRAPH_STEPS_SMALL / period;
-  if (cycles >= big) return big;
-  if (have == big && big != small) return 0;
-  return cycles >= small ? small : 0;
+  int best = 0;
+  double best_cost = 1.0e30;
+  for (int U = 1; U <= big && U <= cycles; ++U) {
+    const double c = xv_pipe_unroll_cost(period, cycles, U);
+    if (c <= best_cost) { best = U; best_cost = c; }      // ties: the larger graph
+  }
+  if (best == 0) return 0;
+  if (have > 0 && have <= cycles && xv_pipe_unroll_cost(period, cycles, have) <= 1.03 * best_cost) return have;
+  return best;
 }
