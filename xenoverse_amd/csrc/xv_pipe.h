@@ -86,6 +86,7 @@ static bool xv_pipe_pick_side_stream(hipStream_t main, hipStream_t* out, XvPipeC
   (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
   // a stream of another priority class gets a hardware queue of its own: the highest first, then ordinary streams (each
   // new one moves on to the runtime's next queue), the lowest last
+  // (which class comes first makes no difference where both qualify: 3.75-3.78 against 3.73-3.76 us, profiles/r05_x_*)
   const int prio[XV_PIPE_MAX_CANDIDATES] = {greatest, 0, 0, least, 0, 0};
   float one = -1.0f;
   if (ok) {
