@@ -375,3 +375,16 @@ def test_side_stream_is_chosen_by_measurement_with_a_communicator_created_first(
     g.close()
     print("us per step: one stream %.2f, overlapped %.2f" % (us[False], us[True]))
     assert us[True] < 1.3 * us[False], us
+
+
+@pytest.mark.parametrize("P", [2, 4, 6])
+def test_overlapped_step_many_on_short_rings(P):
+    """Up to three steps are in flight: they must write distinct ring slots, so a ring of two keeps two streams; rings of
+    four and six take three (graphs of several ring cycles, steps per stream not a multiple of the period)"""
+    tab = oracle.anymdp_synth(seed=12, task_index_base=0, n_task=16, S=64, A=8, s0_max=4)
+    n = 8192
+    acts = np.random.RandomState(8).randint(0, 8, (P, n)).astype(np.int32)
+    plan = [200, 66, 7, 131]
+    ref = _run_many(tab, n, P, acts, plan, "fence", 1, "streams", False)
+    got = _run_many(tab, n, P, acts, plan, "fence", 1, "streams", True, overlap=True)
+    _same(ref, got)

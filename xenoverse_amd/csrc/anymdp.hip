@@ -1577,6 +1577,11 @@ static void anymdp_pipe_drop_graphs(xv_anymdp* h) {
   memset(&h->pipe_key, 0, sizeof(h->pipe_key));
   memset(&h->tpipe_key, 0, sizeof(h->tpipe_key));
   h->gate.unroll[0] = h->gate.unroll[1] = 0;
+  for (int i = 0; i < 2; ++i) {
+    if (h->gate.exec_n[i]) { (void)hipGraphExecDestroy(h->gate.exec_n[i]); h->gate.exec_n[i] = nullptr; }
+    if (h->gate.graph_n[i]) { (void)hipGraphDestroy(h->gate.graph_n[i]); h->gate.graph_n[i] = nullptr; }
+  }
+  h->gate.depth = 0;
   h->ptick_valid = false;
 }
 static void anymdp_pipe_release(xv_anymdp* h) {
@@ -1584,6 +1589,10 @@ static void anymdp_pipe_release(xv_anymdp* h) {
   if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
   for (int q = 0; q < 2; ++q) if (h->side_ev[q]) (void)hipEventDestroy(h->side_ev[q]);
   if (h->d_ptick) (void)hipFree(h->d_ptick);
+  for (int i = 0; i < 2; ++i) {
+    if (h->gate.side_n[i]) { (void)hipStreamSynchronize(h->gate.side_n[i]); (void)hipStreamDestroy(h->gate.side_n[i]); h->gate.side_n[i] = nullptr; }
+    if (h->gate.ev_n[i]) { (void)hipEventDestroy(h->gate.ev_n[i]); h->gate.ev_n[i] = nullptr; }
+  }
   xv_pipe_gate_destroy(&h->gate);
   anymdp_pipe_clear(h);
 }
@@ -1908,13 +1917,15 @@ static bool anymdp_add_chain(xv_anymdp* h, hipGraph_t graph, hipGraphNode_t* pre
   const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
   void* fn = anymdp_graph_step_fn(h, eff, hand);
   if (!fn) return false;
-  for (int rep = 0; rep < reps; ++rep)      // `reps` ring cycles in one graph (overlapped path, short rings): ticks run on
-  for (int j = j0; j < period; j += dj) {
+  // `reps` ring cycles in one graph (overlapped paths): step g of the graph set goes to stream g % dj, uses ring slot
+  // g % period and tick base + g
+  for (int g = j0; g < reps * period; g += dj) {
+    const int j = g % period;
     hipKernelNodeParams np;
     memset(&np, 0, sizeof(np));
     AnyMDPArgs a = h->a;
     a.seed = h->eng->seed; a.gid_base = h->eng->env_id_base;
-    a.tick = (uint64_t)rep * (uint64_t)period + (uint64_t)j; a.tick_dev = d_tick;
+    a.tick = (uint64_t)g; a.tick_dev = d_tick;
     const size_t off = (size_t)j * stride;
     AnyMDPStepIO io{actions + off, nullptr, nullptr, nullptr, obs + off, reward + off, reward_gt + off, terminated + off,
                     truncated + off, final_obs ? final_obs + off : nullptr, nullptr, nullptr, 0.0f};
@@ -2083,38 +2094,59 @@ static bool anymdp_pipe_setup(xv_anymdp* h) {
                            hipEventCreateWithFlags(&h->side_ev[1], hipEventDisableTiming) != hipSuccess))
       return false;
   }
-  if (!h->d_ptick && hipMalloc(&h->d_ptick, 2 * sizeof(uint64_t)) != hipSuccess) return false;      // the two graphs' tick words
+  if (!h->d_ptick && hipMalloc(&h->d_ptick, XV_PIPE_DEPTH_MAX * sizeof(uint64_t)) != hipSuccess) return false;   // the graphs' tick words
   if (!h->gate.d_seen && !xv_pipe_gate_create(&h->gate)) return false;
+  return true;
+}
+// streams 2 .. depth - 1 (xv_pipe_depth() > 2): each accepted beside the engine's stream by the same timed trial
+static bool anymdp_pipe_setup_deep(xv_anymdp* h, int depth) {
+  XvPipeGate& G = h->gate;
+  if (G.side_n_for != h->eng->stream) {
+    for (int i = 0; i < 2; ++i)
+      if (G.side_n[i]) { (void)hipStreamSynchronize(G.side_n[i]); (void)hipStreamDestroy(G.side_n[i]); G.side_n[i] = nullptr; }
+    G.side_n_for = h->eng->stream;
+  }
+  for (int i = 0; i < depth - 2; ++i) {
+    // (beside the engine's stream AND beside the first side stream; a fourth stream is tried against those two only)
+    if (!G.side_n[i] && !xv_pipe_pick_side_stream(h->eng->stream, &G.side_n[i], nullptr, nullptr, h->side)) { G.side_n[i] = nullptr; return false; }
+    if (!G.ev_n[i] && hipEventCreateWithFlags(&G.ev_n[i], hipEventDisableTiming) != hipSuccess) return false;
+  }
   return true;
 }
 
 // -> cycles per graph the call uses (graphs built / reused), 0: this call is not overlapped, -1: failure
-static int anymdp_pipe_graphs(xv_anymdp* h, int period, int cycles, size_t stride, const int32_t* actions, int32_t* obs, float* reward,
-                              float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
+static int anymdp_pipe_graphs(xv_anymdp* h, int D, int period, int cycles, size_t stride, const int32_t* actions, int32_t* obs,
+                              float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
   const int eff = anymdp_effective_search(h);
   const void* ptrs[7] = {actions, obs, reward, reward_gt, terminated, truncated, final_obs};
   auto& K = h->pipe_key;
   const bool same = h->pgraph_exec[0] && h->pgraph_exec[1] && K.period == period && K.mode == mode && K.search == eff &&
                     K.stride == stride && K.bucket == (const void*)h->a.bucket && K.seed == h->eng->seed &&
                     K.gid_base == h->eng->env_id_base && memcmp(K.ptrs, ptrs, sizeof(ptrs)) == 0;
-  const int U = xv_pipe_pick_unroll(period, cycles, same ? h->gate.unroll[0] : 0);
+  const bool same_d = same && h->gate.depth == D;
+  const int U = xv_pipe_pick_unroll(period, cycles, same_d ? h->gate.unroll[0] : 0, D);
   if (U == 0) return 0;
-  if (same && U == h->gate.unroll[0]) return U;
+  if (same_d && U == h->gate.unroll[0]) return U;
   (void)hipStreamSynchronize(h->side);
+  for (int i = 0; i < 2; ++i) if (h->gate.side_n[i]) (void)hipStreamSynchronize(h->gate.side_n[i]);
   (void)hipStreamSynchronize(h->eng->stream);
   anymdp_pipe_drop_graphs(h);
-  for (int q = 0; q < 2; ++q) {
-    if (hipGraphCreate(&h->pgraph[q], 0) != hipSuccess) return -1;
+  if (D > 2 && !anymdp_pipe_setup_deep(h, D)) return -1;
+  for (int q = 0; q < D; ++q) {
+    hipGraph_t* gr = q < 2 ? &h->pgraph[q] : &h->gate.graph_n[q - 2];
+    hipGraphExec_t* ge = q < 2 ? &h->pgraph_exec[q] : &h->gate.exec_n[q - 2];
+    if (hipGraphCreate(gr, 0) != hipSuccess) return -1;
     hipGraphNode_t prev = nullptr;
-    if (!anymdp_add_head_node(h, h->pgraph[q], &prev, q, period, U)) return -1;
-    if (!anymdp_add_chain(h, h->pgraph[q], &prev, h->d_ptick + q, eff, period, stride, actions, obs, reward, reward_gt,
-                          terminated, truncated, final_obs, mode, q, 2, true, U))
+    if (!anymdp_add_head_node(h, *gr, &prev, q, period, U)) return -1;
+    if (!anymdp_add_chain(h, *gr, &prev, h->d_ptick + q, eff, period, stride, actions, obs, reward, reward_gt,
+                          terminated, truncated, final_obs, mode, q, D, true, U))
       return -1;
-    if (hipGraphInstantiate(&h->pgraph_exec[q], h->pgraph[q], nullptr, nullptr, 0) != hipSuccess) {
-      h->pgraph_exec[q] = nullptr;
+    if (hipGraphInstantiate(ge, *gr, nullptr, nullptr, 0) != hipSuccess) {
+      *ge = nullptr;
       return -1;
     }
   }
+  h->gate.depth = D;
   K.period = period; K.mode = mode; K.search = eff; K.stride = stride; K.bucket = (const void*)h->a.bucket;
   K.seed = h->eng->seed; K.gid_base = h->eng->env_id_base;
   memcpy(K.ptrs, ptrs, sizeof(ptrs));
@@ -2124,7 +2156,7 @@ static int anymdp_pipe_graphs(xv_anymdp* h, int period, int cycles, size_t strid
 
 // the whole ring cycles of a call, overlapped; *issued = steps issued (0: the caller takes the ordinary path for all of it).
 // -> XV_OK, or an error when a cycle went out in part (the streams are joined either way)
-static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int period, int* issued);
+static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int period, int* issued, int depth = 2);
 
 static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride, const int32_t* actions, int32_t* obs,
                            float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs,
@@ -2133,26 +2165,30 @@ static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride,
   const int cycles = n_steps / period;
   static const int min_steps = getenv("XV_ANYMDP_PIPE_MIN_STEPS") ? atoi(getenv("XV_ANYMDP_PIPE_MIN_STEPS")) : XV_ANYMDP_PIPE_GRAPH_MIN;
   if (cycles <= 0 || period % 2 != 0 || n_steps < min_steps) return XV_OK;
-  // both launches resident at once, or the one-stream path (xv_pipe.h)
-  if (!xv_pipe_two_launches_fit(anymdp_graph_step_fn(h, anymdp_effective_search(h), true), 256, (size_t)xv_div_up(h->a.n_env, 256),
-                                h->eng->device))
-    return XV_OK;
+  // two or three launches resident at once, or the one-stream path (xv_pipe.h)
+  int D = xv_pipe_choose_depth(anymdp_graph_step_fn(h, anymdp_effective_search(h), true), 256,
+                               (size_t)xv_div_up(h->a.n_env, 256), h->eng->device);
+  if (D > period) D = period;      // the steps in flight write distinct ring slots
+  if (D < 2) return XV_OK;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;      // not inside a stream capture: the set-up synchronises
   if (hipStreamIsCapturing(h->eng->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return XV_OK; }
-  const int U = anymdp_pipe_setup(h) ? anymdp_pipe_graphs(h, period, cycles, stride, actions, obs, reward, reward_gt, terminated,
-                                                          truncated, final_obs, mode) : -1;
+  const bool set_up = anymdp_pipe_setup(h);
+  if (set_up && D > 2 && !anymdp_pipe_setup_deep(h, D)) { (void)hipGetLastError(); D = 2; }      // no third stream qualifies: two
+  const int U = set_up ? anymdp_pipe_graphs(h, D, period, cycles, stride, actions, obs, reward, reward_gt, terminated,
+                                            truncated, final_obs, mode) : -1;
   if (U < 0) {
     (void)hipGetLastError();
     h->pipe_failed = true;
     return XV_OK;
   }
   if (U == 0) return XV_OK;      // too short for the graphs this handle holds: one stream
-  return anymdp_pipe_launch(h, h->pgraph_exec, cycles / U, period * U, issued);
+  return anymdp_pipe_launch(h, h->pgraph_exec, cycles / U, period * U, issued, h->gate.depth);
 }
 
 // `cycles` replays of the two cycle graphs ex[0] (engine's stream) / ex[1] (side stream): tags, tick words, fork, launches, join
-static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int period, int* issued) {
+static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int period, int* issued, int depth) {
   hipStream_t st = h->eng->stream;
+  const int deep = depth > 2 ? depth - 2 : 0;      // streams beyond the engine's and `side`
   const uint64_t t0 = h->eng->tick;
   // every record gets the tag of the first step (whatever ran since the last overlapped call wrote the tag bits as 0)
   hipLaunchKernelGGL(anymdp_retag_kernel, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, st, h->a.sr, h->a.n_env,
@@ -2162,10 +2198,12 @@ static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int 
     // the graphs' head nodes advance the words by `period` first
     hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick, t0 - (uint64_t)period);
     hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick + 1, t0 - (uint64_t)period);
+    for (int i = 0; i < deep; ++i) hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick + 2 + i, t0 - (uint64_t)period);
     ok = hipGetLastError() == hipSuccess;
   }
   // fork: the side stream starts behind what the engine's stream holds now (the caller's actions, a reset, the tags above)
   ok = ok && hipEventRecord(h->side_ev[0], st) == hipSuccess && hipStreamWaitEvent(h->side, h->side_ev[0], 0) == hipSuccess;
+  for (int i = 0; i < deep; ++i) ok = ok && hipStreamWaitEvent(h->gate.side_n[i], h->side_ev[0], 0) == hipSuccess;
   if (!ok) {
     (void)hipGetLastError();
     h->pipe_failed = true; h->ptick_valid = false;
@@ -2180,12 +2218,17 @@ static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int 
     if (hipGraphLaunch(ex[0], st) != hipSuccess) break;
     xv_pipe_test_stall(c);
     if (hipGraphLaunch(ex[1], h->side) != hipSuccess) { broken = true; xv_pipe_gate_release(&h->gate); break; }
+    for (int i = 0; i < deep && !broken; ++i)
+      if (hipGraphLaunch(h->gate.exec_n[i], h->gate.side_n[i]) != hipSuccess) broken = true;
+    if (broken) { xv_pipe_gate_release(&h->gate); break; }
     xv_pipe_gate_release(&h->gate);
     k += period;
     h->eng->tick = t0 + (uint64_t)k;
   }
   if (k < cycles * period) { (void)hipGetLastError(); h->pipe_failed = true; }
-  const bool joined = hipEventRecord(h->side_ev[1], h->side) == hipSuccess && hipStreamWaitEvent(st, h->side_ev[1], 0) == hipSuccess;
+  bool joined = hipEventRecord(h->side_ev[1], h->side) == hipSuccess && hipStreamWaitEvent(st, h->side_ev[1], 0) == hipSuccess;
+  for (int i = 0; i < deep; ++i)
+    joined = hipEventRecord(h->gate.ev_n[i], h->gate.side_n[i]) == hipSuccess && hipStreamWaitEvent(st, h->gate.ev_n[i], 0) == hipSuccess && joined;
   *issued = k;
   if (broken || !joined) {
     (void)hipGetLastError();
@@ -2615,6 +2658,7 @@ extern "C" int xv_anymdp_build_buckets(xv_anymdp* h, int n_bucket) {
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
     if (h->side) XV_HIP(hipStreamSynchronize(h->side));
+    for (int i = 0; i < 2; ++i) if (h->gate.side_n[i]) XV_HIP(hipStreamSynchronize(h->gate.side_n[i]));
     anymdp_pipe_drop_graphs(h);
     (void)hipFree(h->bucket_rw);
     h->bucket_rw = nullptr; h->a.bucket = nullptr; h->a.NBK = 0; h->a.bfmt = 0;
@@ -2740,7 +2784,7 @@ static void* anymdp_tok_hand_fn(const xv_anymdp* h) {      // the HAND instantia
 
 // the two cycle graphs of the overlapped token step: HAND instantiations of the cooperative kernel, ring slots q, q + 2, ...
 // -> cycles per graph (built / reused), 0: this call is not overlapped, -1: failure
-static int anymdp_tok_pipe_graphs(xv_anymdp* h, int period, int cycles, const int32_t* action, int32_t* obs, float* reward,
+static int anymdp_tok_pipe_graphs(xv_anymdp* h, int D, int period, int cycles, const int32_t* action, int32_t* obs, float* reward,
                                   float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs, int mode) {
   const void* ptrs[7] = {action, obs, reward, reward_gt, terminated, truncated, final_obs};
   auto& K = h->tpipe_key;
@@ -2748,24 +2792,29 @@ static int anymdp_tok_pipe_graphs(xv_anymdp* h, int period, int cycles, const in
                     K.d_obs == h->d_obs && K.d_act == h->d_act && K.bucket == (const void*)h->a.bucket &&
                     K.obs_bucket == (const void*)h->obs_bucket && K.seed == h->eng->seed && K.gid_base == h->eng->env_id_base &&
                     memcmp(K.ptrs, ptrs, sizeof(ptrs)) == 0;
-  const int U = xv_pipe_pick_unroll(period, cycles, same ? h->gate.unroll[1] : 0);
+  const bool same_d = same && h->gate.depth == D;
+  const int U = xv_pipe_pick_unroll(period, cycles, same_d ? h->gate.unroll[1] : 0, D);
   if (U == 0) return 0;
-  if (same && U == h->gate.unroll[1]) return U;
+  if (same_d && U == h->gate.unroll[1]) return U;
   (void)hipStreamSynchronize(h->side);
+  for (int i = 0; i < 2; ++i) if (h->gate.side_n[i]) (void)hipStreamSynchronize(h->gate.side_n[i]);
   (void)hipStreamSynchronize(h->eng->stream);
   anymdp_pipe_drop_graphs(h);
+  if (D > 2 && !anymdp_pipe_setup_deep(h, D)) return -1;
   void* fn = anymdp_tok_hand_fn(h);
   const size_t n = (size_t)h->a.n_env, da = (size_t)h->d_act, dob = (size_t)h->d_obs;
   const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
-  for (int q = 0; q < 2; ++q) {
-    if (hipGraphCreate(&h->tgraph[q], 0) != hipSuccess) return -1;
+  for (int q = 0; q < D; ++q) {
+    hipGraph_t* gr = q < 2 ? &h->tgraph[q] : &h->gate.graph_n[q - 2];
+    hipGraphExec_t* ge = q < 2 ? &h->tgraph_exec[q] : &h->gate.exec_n[q - 2];
+    if (hipGraphCreate(gr, 0) != hipSuccess) return -1;
     hipGraphNode_t prev = nullptr;
-    if (!anymdp_add_head_node(h, h->tgraph[q], &prev, q, period, U)) return -1;
-    for (int rep = 0; rep < U; ++rep)
-    for (int j = q; j < period; j += 2) {
+    if (!anymdp_add_head_node(h, *gr, &prev, q, period, U)) return -1;
+    for (int g = q; g < U * period; g += D) {      // step g of the graph set: stream g % D, ring slot g % period, tick base + g
+      const int j = g % period;
       AnyMDPArgs a = h->a;
       a.seed = h->eng->seed; a.gid_base = h->eng->env_id_base;
-      a.tick = (uint64_t)rep * (uint64_t)period + (uint64_t)j; a.tick_dev = h->d_ptick + q;
+      a.tick = (uint64_t)g; a.tick_dev = h->d_ptick + q;
       AnyMDPTokArgs KA{h->obs_cdf, h->n_obs, h->d_obs, h->d_act, h->obs_bucket};
       const size_t o = (size_t)j * n;
       AnyMDPTokIO io{action + o * da, nullptr, nullptr, nullptr, nullptr, nullptr, obs + o * dob, reward + o, reward_gt + o,
@@ -2776,11 +2825,12 @@ static int anymdp_tok_pipe_graphs(xv_anymdp* h, int period, int cycles, const in
       memset(&np, 0, sizeof(np));
       np.func = fn; np.gridDim = grid; np.blockDim = block; np.kernelParams = params;
       hipGraphNode_t node;
-      if (hipGraphAddKernelNode(&node, h->tgraph[q], prev ? &prev : nullptr, prev ? 1 : 0, &np) != hipSuccess) return -1;
+      if (hipGraphAddKernelNode(&node, *gr, prev ? &prev : nullptr, prev ? 1 : 0, &np) != hipSuccess) return -1;
       prev = node;
     }
-    if (hipGraphInstantiate(&h->tgraph_exec[q], h->tgraph[q], nullptr, nullptr, 0) != hipSuccess) { h->tgraph_exec[q] = nullptr; return -1; }
+    if (hipGraphInstantiate(ge, *gr, nullptr, nullptr, 0) != hipSuccess) { *ge = nullptr; return -1; }
   }
+  h->gate.depth = D;
   K.period = period; K.mode = mode; K.fmt = h->a.bfmt; K.d_obs = h->d_obs; K.d_act = h->d_act;
   K.bucket = (const void*)h->a.bucket; K.obs_bucket = (const void*)h->obs_bucket;
   K.seed = h->eng->seed; K.gid_base = h->eng->env_id_base;
@@ -2806,14 +2856,18 @@ extern "C" int xv_anymdp_step_tokens_many(xv_anymdp* h, int n_steps, int period,
   const int cycles = n_steps / period;
   if (h->overlap && !h->eng->dev_tick && !h->pipe_failed && anymdp_tok_coop(h) && cycles > 0 && period % 2 == 0 &&
       n_steps >= XV_ANYMDP_PIPE_GRAPH_MIN && hipSetDevice(h->eng->device) == hipSuccess &&
-      xv_pipe_two_launches_fit(anymdp_tok_hand_fn(h), 256, (size_t)xv_div_up(h->a.n_env, 256), h->eng->device)) {
+      xv_pipe_choose_depth(anymdp_tok_hand_fn(h), 256, (size_t)xv_div_up(h->a.n_env, 256), h->eng->device) >= 2) {
+    int D = xv_pipe_choose_depth(anymdp_tok_hand_fn(h), 256, (size_t)xv_div_up(h->a.n_env, 256), h->eng->device);
+    if (D > period) D = period;      // the steps in flight write distinct ring slots
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(h->eng->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
     if (!capturing) {
-      const int U = anymdp_pipe_setup(h) ? anymdp_tok_pipe_graphs(h, period, cycles, action, obs, reward, reward_gt, terminated,
-                                                                  truncated, final_obs, autoreset_mode) : -1;
+      const bool set_up = anymdp_pipe_setup(h);
+      if (set_up && D > 2 && !anymdp_pipe_setup_deep(h, D)) { (void)hipGetLastError(); D = 2; }
+      const int U = set_up ? anymdp_tok_pipe_graphs(h, D, period, cycles, action, obs, reward, reward_gt, terminated,
+                                                    truncated, final_obs, autoreset_mode) : -1;
       if (U > 0) {
-        const int rc = anymdp_pipe_launch(h, h->tgraph_exec, cycles / U, period * U, &k);
+        const int rc = anymdp_pipe_launch(h, h->tgraph_exec, cycles / U, period * U, &k, h->gate.depth);
         if (rc != XV_OK) return rc;
       } else if (U < 0) {
         (void)hipGetLastError();

@@ -152,16 +152,18 @@ struct MixedPipeKey {
   LinDSArgs L;
   CartPoleArgs C;
   xv_mixed_io ring;
-  int period, mode, variant;
+  int period, mode, variant, depth;
 };
 struct MixedPipe {
   hipStream_t side;
+  hipStream_t side2;     // third stream (depth 3: steps k, k + 1, k + 2 in flight, xv_pipe.h)
   hipEvent_t ev[2];
-  uint64_t* d_tick;      // [family][parity]: the graphs' tick words
+  hipEvent_t ev2;
+  uint64_t* d_tick;      // [family][stream], 4 words per family: the graphs' tick words
   uint32_t* d_hand;      // LinDS waves, then CartPole waves
   size_t hand_cap;
-  hipGraph_t graph[2];
-  hipGraphExec_t exec[2];
+  hipGraph_t graph[3];
+  hipGraphExec_t exec[3];
   MixedPipeKey key;
   bool key_valid, failed, used_last;
   hipStream_t side_for;  // the engines' stream the side stream was chosen against
@@ -180,7 +182,7 @@ static __global__ __launch_bounds__(256) void mixed_pipe_open_kernel(uint2* sr, 
   if (i < n_lw) hand_l[i] = tag_l;
   if (i < n_cw) hand_c[i] = tag_c;
   if (i < n_c) c_steps[i] = (int32_t)(((uint32_t)c_steps[i] & 0x7FFFFFFFu) | ((uint32_t)(c_nr[i] ? 1u : 0u) << 31));
-  if (i < 6) d_tick[i] = i < 2 ? ta : (i < 4 ? tl : tc);
+  if (i < 12) d_tick[i] = i < 4 ? ta : (i < 8 ? tl : tc);
 }
 // after the join: CartPole's need_reset leaves the step words again
 static __global__ __launch_bounds__(256) void mixed_pipe_close_kernel(int32_t* c_steps, uint8_t* c_nr, int n_c) {
@@ -193,13 +195,13 @@ static __global__ __launch_bounds__(256) void mixed_pipe_close_kernel(int32_t* c
 }
 // first node of a cycle graph: this cycle's tick bases (one word per family); the even half also passes the cycle gate
 static __global__ void mixed_pipe_head_kernel(uint64_t* w, uint64_t dv, uint32_t* seen, const uint32_t* issued, uint32_t* err) {
-  w[0] += dv; w[2] += dv; w[4] += dv;
+  w[0] += dv; w[4] += dv; w[8] += dv;
   if (seen) xv_pipe_gate_pass(seen, issued, err);
 }
 
 static void mixed_pipe_drop_graphs(MixedPipe& M) {
   M.gate.unroll[0] = 0;
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < 3; ++q) {
     if (M.exec[q]) (void)hipGraphExecDestroy(M.exec[q]);
     if (M.graph[q]) (void)hipGraphDestroy(M.graph[q]);
     M.exec[q] = nullptr; M.graph[q] = nullptr;
@@ -207,12 +209,14 @@ static void mixed_pipe_drop_graphs(MixedPipe& M) {
   M.key_valid = false;
 }
 
-static bool mixed_pipe_setup(MixedPipe& M, hipStream_t st, size_t n_hand) {
+static bool mixed_pipe_setup(MixedPipe& M, hipStream_t st, size_t n_hand, int depth) {
   if (M.side && M.side_for != st) {      // measured against another engines' stream: choose again
     (void)hipStreamSynchronize(M.side);
+    if (M.side2) (void)hipStreamSynchronize(M.side2);
     mixed_pipe_drop_graphs(M);
     (void)hipStreamDestroy(M.side);
-    M.side = nullptr;
+    if (M.side2) (void)hipStreamDestroy(M.side2);
+    M.side = nullptr; M.side2 = nullptr;
   }
   if (!M.side) {      // chosen by measurement (xv_pipe.h)
     M.side_for = st;
@@ -221,10 +225,15 @@ static bool mixed_pipe_setup(MixedPipe& M, hipStream_t st, size_t n_hand) {
                      hipEventCreateWithFlags(&M.ev[1], hipEventDisableTiming) != hipSuccess))
       return false;
   }
-  if (!M.d_tick && hipMalloc(&M.d_tick, 6 * sizeof(uint64_t)) != hipSuccess) return false;
+  if (depth > 2 && !M.side2) {
+    if (!xv_pipe_pick_side_stream(st, &M.side2, nullptr, nullptr, M.side)) { M.side2 = nullptr; return false; }
+    if (!M.ev2 && hipEventCreateWithFlags(&M.ev2, hipEventDisableTiming) != hipSuccess) return false;
+  }
+  if (!M.d_tick && hipMalloc(&M.d_tick, 12 * sizeof(uint64_t)) != hipSuccess) return false;
   if (!M.gate.d_seen && !xv_pipe_gate_create(&M.gate)) return false;
   if (M.hand_cap < n_hand) {
     (void)hipStreamSynchronize(M.side);
+    if (M.side2) (void)hipStreamSynchronize(M.side2);
     (void)hipStreamSynchronize(st);
     if (M.d_hand) (void)hipFree(M.d_hand);
     M.d_hand = nullptr; M.hand_cap = 0; M.key_valid = false;
@@ -258,25 +267,26 @@ static void* mixed_hand_fn(int v) {
 
 // -> ring cycles per graph (built / reused), 0: this call is not overlapped, -1: failure
 static int mixed_pipe_graphs(MixedPipe& M, xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mixed_io* ring, int period, int ring_cycles,
-                             int mode, int v, int n_lw) {
+                             int mode, int v, int n_lw, int D) {
   MixedPipeKey K;
   memset(&K, 0, sizeof(K));
   memcpy(&K.A, &a->a, sizeof(K.A)); memcpy(&K.L, &l->a, sizeof(K.L)); memcpy(&K.C, &c->a, sizeof(K.C));
   K.A.tick = 0; K.A.tick_dev = nullptr; K.L.tick = 0; K.L.tick_dev = nullptr; K.C.tick = 0; K.C.tick_dev = nullptr;
   K.L.hand = M.d_hand; K.C.hand = M.d_hand + n_lw;
   memcpy(&K.ring, ring, sizeof(K.ring));
-  K.period = period; K.mode = mode; K.variant = v;
+  K.period = period; K.mode = mode; K.variant = v; K.depth = D;
   const bool same = M.key_valid && M.exec[0] && M.exec[1] && memcmp(&K, &M.key, sizeof(K)) == 0;
-  const int U = xv_pipe_pick_unroll(period, ring_cycles, same ? M.gate.unroll[0] : 0);
+  const int U = xv_pipe_pick_unroll(period, ring_cycles, same ? M.gate.unroll[0] : 0, D);
   if (U == 0) return 0;
   if (same && U == M.gate.unroll[0]) return U;
   (void)hipStreamSynchronize(M.side);
+  if (M.side2) (void)hipStreamSynchronize(M.side2);
   (void)hipStreamSynchronize(a->eng->stream);
   mixed_pipe_drop_graphs(M);
   const size_t na = (size_t)a->a.n_env, nl = (size_t)l->a.n_env, nc = (size_t)c->a.n_env;
   int nbA = xv_div_up(a->a.n_env, 256), nbL = xv_div_up(xv_div_up(l->a.n_slot, 16), 4), nbC = xv_div_up(c->a.n_env, 256);
   void* fn = mixed_hand_fn(v);
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < D; ++q) {
     if (hipGraphCreate(&M.graph[q], 0) != hipSuccess) return -1;
     hipGraphNode_t prev = nullptr;
     {
@@ -291,13 +301,13 @@ static int mixed_pipe_graphs(MixedPipe& M, xv_anymdp* a, xv_linds* l, xv_cartpol
       np.func = reinterpret_cast<void*>(&mixed_pipe_head_kernel); np.gridDim = dim3(1); np.blockDim = dim3(1); np.kernelParams = hparams;
       if (hipGraphAddKernelNode(&prev, M.graph[q], nullptr, 0, &np) != hipSuccess) return -1;
     }
-    for (int rep = 0; rep < U; ++rep)
-    for (int s = q; s < period; s += 2) {
+    for (int g = q; g < U * period; g += D) {      // step g of the graph set: stream g % D, ring slot g % period, tick base + g
+      const int s = g % period;
       AnyMDPArgs A = K.A; LinDSArgs L = K.L; CartPoleArgs C = K.C;
-      const uint64_t tk = (uint64_t)rep * (uint64_t)period + (uint64_t)s;
+      const uint64_t tk = (uint64_t)g;
       A.tick = tk; A.tick_dev = M.d_tick + q;
-      L.tick = tk; L.tick_dev = M.d_tick + 2 + q;
-      C.tick = tk; C.tick_dev = M.d_tick + 4 + q;
+      L.tick = tk; L.tick_dev = M.d_tick + 4 + q;
+      C.tick = tk; C.tick_dev = M.d_tick + 8 + q;
       xv_mixed_io io;
       mixed_io_slot(ring, (size_t)s, na, nl, nc, (size_t)l->a.NA, (size_t)l->a.NO, &io);
       AnyMDPStepIO aio{io.a_action, nullptr, nullptr, nullptr, io.a_obs, io.a_reward, io.a_reward_gt, io.a_terminated,
@@ -340,10 +350,14 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
   const int v = mixed_variant(a, l);
   if (v < 0) return XV_OK;
   XV_HIP(hipSetDevice(dev));
-  // both launches resident at once, or the ordinary loop (xv_pipe.h)
-  if (!xv_pipe_two_launches_fit(mixed_hand_fn(v), 256,
-                                (size_t)(xv_div_up(a->a.n_env, 256) + xv_div_up(xv_div_up(l->a.n_slot, 16), 4) + xv_div_up(c->a.n_env, 256)), dev))
-    return XV_OK;
+  // two or three launches resident at once, or the ordinary loop (xv_pipe.h)
+  int D = xv_pipe_choose_depth(mixed_hand_fn(v), 256,
+                               (size_t)(xv_div_up(a->a.n_env, 256) + xv_div_up(xv_div_up(l->a.n_slot, 16), 4) + xv_div_up(c->a.n_env, 256)), dev);
+  if (D < 2) return XV_OK;
+  // three launches in flight pay for the AnyMDP step (anymdp.hip) but not here: 4.26-4.36 us with two, 4.41 with three
+  // (profiles/r05_y_*) — the LinDS chain, not the dispatch gap, bounds the fused step.  (The machinery takes D = 3: a ring
+  // must then hold at least three slots, steps k and k + 2 would otherwise write one output slot at the same time.)
+  if (D > 2) D = 2;
   hipStream_t st = a->eng->stream;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return XV_OK; }
@@ -351,7 +365,7 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
   anymdp_bind_rng(a, 0, false);
   linds_bind_rng(l, 0, false);
   cartpole_bind_rng(c, 0, false);
-  const int U = mixed_pipe_setup(M, st, (size_t)(n_lw + n_cw)) ? mixed_pipe_graphs(M, a, l, c, ring, period, ring_cycles, mode, v, n_lw) : -1;
+  const int U = mixed_pipe_setup(M, st, (size_t)(n_lw + n_cw), D) ? mixed_pipe_graphs(M, a, l, c, ring, period, ring_cycles, mode, v, n_lw, D) : -1;
   if (U < 0) {
     (void)hipGetLastError();
     M.failed = true;
@@ -360,12 +374,12 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
   if (U == 0) return XV_OK;      // too short for the graphs held: the ordinary loop
   const int per_launch = U * period, cycles = ring_cycles / U;      // launches of the two cycle graphs (U ring cycles each)
   const uint64_t ta = a->eng->tick, tl = l->eng->tick, tc = c->eng->tick;
-  const int n_open = std::max(std::max(a->a.n_env, c->a.n_env), std::max(n_lw, 6));
+  const int n_open = std::max(std::max(a->a.n_env, c->a.n_env), std::max(n_lw, 12));
   hipLaunchKernelGGL(mixed_pipe_open_kernel, dim3(xv_div_up(n_open, 256)), dim3(256), 0, st, a->a.sr, a->a.n_env, XV_ANYMDP_SR_TAG(ta),
                      M.d_hand, n_lw, (uint32_t)tl, M.d_hand + n_lw, n_cw, (uint32_t)tc, c->a.steps, c->a.need_reset, c->a.n_env,
                      M.d_tick, ta - (uint64_t)per_launch, tl - (uint64_t)per_launch, tc - (uint64_t)per_launch);   // the head nodes add it
   bool ok = hipGetLastError() == hipSuccess && hipEventRecord(M.ev[0], st) == hipSuccess &&
-            hipStreamWaitEvent(M.side, M.ev[0], 0) == hipSuccess;
+            hipStreamWaitEvent(M.side, M.ev[0], 0) == hipSuccess && (D < 3 || hipStreamWaitEvent(M.side2, M.ev[0], 0) == hipSuccess);
   int k = 0;
   bool broken = false;
   if (ok) {
@@ -375,12 +389,14 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
       if (hipGraphLaunch(M.exec[0], st) != hipSuccess) break;
       xv_pipe_test_stall(cy);
       if (hipGraphLaunch(M.exec[1], M.side) != hipSuccess) { broken = true; xv_pipe_gate_release(&M.gate); break; }
+      if (D == 3 && hipGraphLaunch(M.exec[2], M.side2) != hipSuccess) { broken = true; xv_pipe_gate_release(&M.gate); break; }
       xv_pipe_gate_release(&M.gate);
       k += per_launch;
     }
   }
   a->eng->tick = ta + (uint64_t)k; l->eng->tick = tl + (uint64_t)k; c->eng->tick = tc + (uint64_t)k;
-  const bool joined = hipEventRecord(M.ev[1], M.side) == hipSuccess && hipStreamWaitEvent(st, M.ev[1], 0) == hipSuccess;
+  const bool joined = hipEventRecord(M.ev[1], M.side) == hipSuccess && hipStreamWaitEvent(st, M.ev[1], 0) == hipSuccess &&
+                      (D < 3 || (hipEventRecord(M.ev2, M.side2) == hipSuccess && hipStreamWaitEvent(st, M.ev2, 0) == hipSuccess));
   hipLaunchKernelGGL(mixed_pipe_close_kernel, dim3(xv_div_up(c->a.n_env, 256)), dim3(256), 0, st, c->a.steps, c->a.need_reset, c->a.n_env);
   const bool closed = hipGetLastError() == hipSuccess;
   *issued = k;

@@ -74,7 +74,8 @@ struct XvPipeCandidate {
 
 // Tries up to XV_PIPE_MAX_CANDIDATES side streams; *out = the first accepted one (the others are destroyed), nullptr when
 // none qualifies.  report (nullable): one row per candidate tried; *n_report rows filled.
-static bool xv_pipe_pick_side_stream(hipStream_t main, hipStream_t* out, XvPipeCandidate* report, int* n_report) {
+static bool xv_pipe_pick_side_stream(hipStream_t main, hipStream_t* out, XvPipeCandidate* report, int* n_report,
+                                     hipStream_t other = nullptr /* a side stream already chosen: the new one must run beside it too */) {
   *out = nullptr;
   if (n_report) *n_report = 0;
   uint32_t* d = nullptr;
@@ -109,7 +110,14 @@ static bool xv_pipe_pick_side_stream(hipStream_t main, hipStream_t* out, XvPipeC
       const float again = xv_pipe_pingpong(main, s, d, ev, XV_PIPE_PING_STEPS);
       if (again > 0.0f && (two <= 0.0f || again < two)) two = again;
     }
-    const bool take = two > 0.0f && two <= XV_PIPE_ACCEPT_RATIO * one + XV_PIPE_ACCEPT_SLACK_US;
+    bool take = two > 0.0f && two <= XV_PIPE_ACCEPT_RATIO * one + XV_PIPE_ACCEPT_SLACK_US;
+    if (take && other) {      // three streams: the two side streams must not share a hardware queue with each other either
+      float pair = xv_pipe_pingpong(other, s, d, ev, XV_PIPE_PING_STEPS);
+      const float again = xv_pipe_pingpong(other, s, d, ev, XV_PIPE_PING_STEPS);
+      if (again > 0.0f && (pair <= 0.0f || again < pair)) pair = again;
+      take = pair > 0.0f && pair <= XV_PIPE_ACCEPT_RATIO * one + XV_PIPE_ACCEPT_SLACK_US;
+      if (pair > two || pair <= 0.0f) two = pair;      // report the worse pairing
+    }
     if (getenv("XV_PIPE_DEBUG"))
       fprintf(stderr, "xv_pipe: candidate %d priority %d: two streams %.2f us, one stream %.2f us per launch -> %s\n", c, prio[c],
               (double)two, (double)one, take ? "taken" : "rejected");
@@ -144,6 +152,13 @@ struct XvPipeGate {
   uint32_t* d_seen;     // gates passed so far (device memory)
   uint32_t issued;      // host mirror
   int unroll[2];        // ring cycles per cycle graph of the graph pairs built on this gate (0: none built); see below
+  // streams 2 and 3 of the overlapped MDP step_many (depth 3 / 4: steps k .. k + 3 in flight), see xv_pipe_depth()
+  hipStream_t side_n[2];
+  hipStream_t side_n_for;   // the engine's stream they were chosen against
+  hipEvent_t ev_n[2];
+  hipGraph_t graph_n[2];
+  hipGraphExec_t exec_n[2];
+  int depth;            // streams the graphs of unroll[0] were built for (2 .. 4)
 };
 
 __device__ __forceinline__ void xv_pipe_gate_pass(uint32_t* seen, const uint32_t* issued, uint32_t* err) {
@@ -162,6 +177,8 @@ __device__ __forceinline__ void xv_pipe_gate_pass(uint32_t* seen, const uint32_t
 
 static bool xv_pipe_gate_create(XvPipeGate* g) {
   g->h_issued = nullptr; g->d_issued = nullptr; g->d_seen = nullptr; g->issued = 0; g->unroll[0] = g->unroll[1] = 0;
+  for (int i = 0; i < 2; ++i) { g->side_n[i] = nullptr; g->ev_n[i] = nullptr; g->graph_n[i] = nullptr; g->exec_n[i] = nullptr; }
+  g->side_n_for = nullptr; g->depth = 0;
   if (hipHostMalloc(reinterpret_cast<void**>(&g->h_issued), 64, hipHostMallocMapped) != hipSuccess) { g->h_issued = nullptr; return false; }
   *g->h_issued = 0u;
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&g->d_issued), g->h_issued, 0) != hipSuccess) return false;
@@ -191,14 +208,14 @@ static inline void xv_pipe_test_stall(int cycle) {
 // same workgroup of step k has run; if step k still has workgroups waiting for a slot while step k + 1's spinners hold them
 // all (the side stream may be served first), nobody moves until the bounded waits expire.  With 2 x grid <= what the device
 // holds of this kernel that cannot happen: every workgroup of step k gets its slot without waiting for one of step k + 1.
-static bool xv_pipe_two_launches_fit(const void* fn, int block_threads, size_t grid_blocks, int device) {
+static bool xv_pipe_two_launches_fit(const void* fn, int block_threads, size_t grid_blocks, int device, int n_launches = 2) {
   int per_cu = 0, cus = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block_threads, 0) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) {
     (void)hipGetLastError();
     return false;
   }
-  return 2 * grid_blocks <= (size_t)per_cu * (size_t)cus;
+  return (size_t)n_launches * grid_blocks <= (size_t)per_cu * (size_t)cus;
 }
 
 // Ring cycles per cycle graph.  Every cycle graph starts with a head node (tick word; on the even stream the cycle gate: a
@@ -212,21 +229,40 @@ static bool xv_pipe_two_launches_fit(const void* fn, int block_threads, size_t g
 // callers repeat one call length).  -> ring cycles per graph, 0: do not overlap this call.  have: what the handle's graphs
 // for these rings hold now (0: none).
 #define XV_PIPE_GRAPH_STEPS_BIG 128
-static inline double xv_pipe_unroll_cost(int period, int cycles, int U) {
+static inline double xv_pipe_unroll_cost(int period, int cycles, int U, int depth) {
   const int covered = U * (cycles / U) * period, left = cycles * period - covered;
-  if (covered <= 0) return 1.0e30;
-  return (double)covered * (1.0 + 1.15 / (0.5 * (double)U * (double)period)) + 1.3 * (double)left;
+  if (covered <= 0 || (U * period) % depth != 0) return 1.0e30;      // a graph set takes whole steps-per-stream
+  return (double)covered * (1.0 + 1.15 / ((double)U * (double)period / (double)depth)) + 1.3 * (double)left;
 }
-static inline int xv_pipe_pick_unroll(int period, int cycles, int have) {
+static inline int xv_pipe_pick_unroll(int period, int cycles, int have, int depth = 2) {
   static const int big_steps = getenv("XV_PIPE_GRAPH_STEPS") ? atoi(getenv("XV_PIPE_GRAPH_STEPS")) : XV_PIPE_GRAPH_STEPS_BIG;   // devtools A/B
-  const int big = period >= big_steps ? 1 : big_steps / period;
+  const int big = (period >= big_steps ? 1 : big_steps / period) * (depth == 2 ? 1 : depth);
   int best = 0;
   double best_cost = 1.0e30;
   for (int U = 1; U <= big && U <= cycles; ++U) {
-    const double c = xv_pipe_unroll_cost(period, cycles, U);
-    if (c <= best_cost) { best = U; best_cost = c; }      // ties: the larger graph
+    const double c = xv_pipe_unroll_cost(period, cycles, U, depth);
+    if (c < 1.0e29 && c <= best_cost) { best = U; best_cost = c; }      // ties: the larger graph
   }
   if (best == 0) return 0;
-  if (have > 0 && have <= cycles && xv_pipe_unroll_cost(period, cycles, have) <= 1.03 * best_cost) return have;
+  if (have > 0 && have <= cycles && xv_pipe_unroll_cost(period, cycles, have, depth) <= 1.03 * best_cost) return have;
   return best;
+}
+// Steps in flight (= streams).  With two streams, launch k + 2 waits behind launch k on its stream: every wave of k must have
+// drained before k + 2 is dispatched, and the 2.7 us a dispatch costs are covered by one other launch only.  Three streams —
+// steps k, k + 1, k + 2 resident together, every wave still depending on the same wave of the step before only — measured
+// at 65,536 envs: 2a 3.64-3.85 -> **3.22-3.36 us**, 2b 3.21-3.25 -> **2.95-3.07**; four: 3.10-3.25 / 2.95-3.08, no better, and
+// four launches of 256 workgroups are all the device holds of this kernel (profiles/r05_y_*).  So: three where three
+// launches fit on the device together, else two, else none.  XV_PIPE_DEPTH = 2 .. 4 caps it (devtools A/B).
+#define XV_PIPE_DEPTH_MAX 4
+#define XV_PIPE_DEPTH_DEFAULT 3
+static inline int xv_pipe_depth() {
+  static const int d = getenv("XV_PIPE_DEPTH") ? atoi(getenv("XV_PIPE_DEPTH")) : XV_PIPE_DEPTH_DEFAULT;
+  return d < 2 ? 2 : (d > XV_PIPE_DEPTH_MAX ? XV_PIPE_DEPTH_MAX : d);
+}
+// -> streams to use for launches of `fn` over grid_blocks workgroups: the wanted depth if that many launches can be resident
+// together (see xv_pipe_two_launches_fit), else fewer, 0: not even two
+static int xv_pipe_choose_depth(const void* fn, int block_threads, size_t grid_blocks, int device) {
+  for (int d = xv_pipe_depth(); d >= 2; --d)
+    if (xv_pipe_two_launches_fit(fn, block_threads, grid_blocks, device, d)) return d;
+  return 0;
 }
