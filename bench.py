@@ -712,7 +712,8 @@ def main():
                            "table_gib_per_gpu": round(n_task * S * A * (1 + (S + 6) // 7) * 128 / 2**30, 2),
                            "bucket_lines_gib_per_gpu": round(bucket_gib, 2),
                            "launch": "one step kernel per vector step (xv_anymdp_step_many%s)"
-                                     % ((", ring cycles of %d steps replayed from two hipGraphs on two HIP streams: consecutive "
+                                     % ((", ring cycles of %d steps replayed from cycle graphs on up to three HIP streams (three where "
+                                         "three launches fit on the device together: steps k, k + 1, k + 2 in flight): consecutive "
                                          "steps overlap, every wave takes its 64 envs over from the same wave of the step before "
                                          "through the env records (xv_anymdp_set_step_many_overlap)" % P)
                                         if state.get("overlap") == 1 else
@@ -749,9 +750,9 @@ def main():
                                        % (0 if search == "binary" else 1, "true" if state.get("graph") == 1 else "false",
                                           (census or {}).get("format", 1) if search == "bucket" else 0,
                                           ", true" if state.get("overlap") == 1 else ""),
-                             "avg_launch_us_note": ("overlapped launches: time per launch in steady state = timed region / launches; two "
-                                                    "launches are in flight, so a profiler's per-kernel duration (start of dispatch to end, "
-                                                    "the wait for the step before included) is ~1.7x this") if state.get("overlap") == 1 else None,
+                             "avg_launch_us_note": ("overlapped launches: time per launch in steady state = timed region / launches; two or "
+                                                    "three launches are in flight, so a profiler's per-kernel duration (start of dispatch to "
+                                                    "end, the wait for the step before included) is a multiple of this") if state.get("overlap") == 1 else None,
                              "kernel_source_sha16": None if selftest else kernel_source_hash(),
                              "avg_launch_us": kern_us, "algorithmic_bytes_per_launch": algo},
                 "rccl": dinfo["rccl"],

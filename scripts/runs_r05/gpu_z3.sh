@@ -3,7 +3,7 @@
 set -u
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r05_z8
+O=gpurun_out/r05_z9
 mkdir -p $O
 timeout 900 python bench.py > $O/bench_2a.json 2> $O/bench_2a.err; echo "bench 2a rc=$?"
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_2a_steps20.json 2> $O/bench_2a_steps20.err; echo "bench steps20 rc=$?"
