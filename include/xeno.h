@@ -252,8 +252,9 @@ int xv_anymdp_set_step_many_graph(xv_anymdp* h, int mode);
  * launches used) */
 int xv_anymdp_step_many_graph_state(xv_anymdp* h);
 /* Overlapped xv_anymdp_step_many (ABI 10; off by default).  on = 1: whole ring cycles of an EVEN period are issued as two
- * cycle graphs — ring slots 0, 2, ... on the engine's stream, 1, 3, ... on a side stream the handle owns — with no dependency
- * between the streams: step k + 1 is dispatched while step k runs, and each of its waves takes its 64 envs over from the
+ * cycle graphs — ring slots 0, 2, ... on the engine's stream, 1, 3, ... on a side stream the handle owns — or as three
+ * (slots 0, 3, ... / 1, 4, ... / 2, 5, ... on three streams: three steps in flight) where three launches fit on the device
+ * together and the ring holds at least three slots, with no dependency between the streams: step k + 1 is dispatched while step k runs, and each of its waves takes its 64 envs over from the
  * same wave of step k through a tag in the envs' 8-byte records (one agent-scope store hands an env on; an env depends on
  * its own previous step only, anymdp_env.py:92-132).  The drain-and-dispatch gap between two dependent launches of one stream
  * (2.7 of the 5.0 us of a 65,536-env step) is covered by the other stream.  The engine's stream waits for the side stream
