@@ -1559,7 +1559,7 @@ static inline int anymdp_effective_search(const xv_anymdp* h) {
 #ifndef XV_KERNELS_ONLY   // mixed.hip includes this file for its kernels and handle types only
 static void anymdp_pipe_clear(xv_anymdp* h) {      // fields of the overlapped step_many: nothing built
   h->overlap = 0; h->pipe_failed = false; h->pipe_used_last = false; h->side = nullptr; h->side_for = nullptr;
-  h->gate.h_issued = nullptr; h->gate.d_issued = nullptr; h->gate.d_seen = nullptr; h->gate.issued = 0;
+  memset(&h->gate, 0, sizeof(h->gate));      // gate, deep streams, graph bookkeeping (xv_pipe.h): nothing built
   h->side_ev[0] = h->side_ev[1] = nullptr;
   h->pgraph[0] = h->pgraph[1] = nullptr; h->pgraph_exec[0] = h->pgraph_exec[1] = nullptr;
   h->tgraph[0] = h->tgraph[1] = nullptr; h->tgraph_exec[0] = h->tgraph_exec[1] = nullptr;
