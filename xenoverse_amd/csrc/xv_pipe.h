@@ -1,4 +1,5 @@
-// xv_pipe.h — picking the SIDE STREAM of the overlapped step_many paths (anymdp.hip, mixed.hip).
+// xv_pipe.h — the host side of the overlapped step_many paths (anymdp.hip, mixed.hip): picking the SIDE STREAMS, the cycle
+// gate, how many ring cycles a cycle graph holds, how many steps are in flight, what must fit on the device.
 //
 // The overlapped paths issue consecutive vector steps alternately on the engine's stream and on a side stream; a wave of
 // step k + 1 waits for the same wave of step k.  That pays only if the device really processes the two streams' launches
