@@ -2169,6 +2169,7 @@ static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride,
   int D = xv_pipe_choose_depth(anymdp_graph_step_fn(h, anymdp_effective_search(h), true), 256,
                                (size_t)xv_div_up(h->a.n_env, 256), h->eng->device);
   if (D > period) D = period;      // the steps in flight write distinct ring slots
+  if (D > 2 && xv_pipe_pick_unroll(period, cycles, 0, D) == 0) D = 2;      // too few ring cycles for a three-stream graph set
   if (D < 2) return XV_OK;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;      // not inside a stream capture: the set-up synchronises
   if (hipStreamIsCapturing(h->eng->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return XV_OK; }
@@ -2859,6 +2860,7 @@ extern "C" int xv_anymdp_step_tokens_many(xv_anymdp* h, int n_steps, int period,
       xv_pipe_choose_depth(anymdp_tok_hand_fn(h), 256, (size_t)xv_div_up(h->a.n_env, 256), h->eng->device) >= 2) {
     int D = xv_pipe_choose_depth(anymdp_tok_hand_fn(h), 256, (size_t)xv_div_up(h->a.n_env, 256), h->eng->device);
     if (D > period) D = period;      // the steps in flight write distinct ring slots
+    if (D > 2 && xv_pipe_pick_unroll(period, cycles, 0, D) == 0) D = 2;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(h->eng->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
     if (!capturing) {
