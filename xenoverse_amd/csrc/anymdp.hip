@@ -2186,22 +2186,24 @@ static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride,
   return anymdp_pipe_launch(h, h->pgraph_exec, cycles / U, period * U, issued, h->gate.depth);
 }
 
-// `cycles` replays of the two cycle graphs ex[0] (engine's stream) / ex[1] (side stream): tags, tick words, fork, launches, join
+static __global__ __launch_bounds__(256) void anymdp_pipe_open_kernel(uint2* sr, int n, uint32_t tag, uint64_t* tick_words, int n_words,
+                                                                      uint64_t tick_base) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sr[i].x = (sr[i].x & ((1u << XV_ANYMDP_SR_TAG_SHIFT) - 1u)) | (tag << XV_ANYMDP_SR_TAG_SHIFT);
+  if (i < n_words) tick_words[i] = tick_base;
+}
+
+// `cycles` replays of the cycle graphs ex[0] (engine's stream) / ex[1] (side stream) / the deep ones: tags and tick words, fork,
+// launches, join
 static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int period, int* issued, int depth) {
   hipStream_t st = h->eng->stream;
   const int deep = depth > 2 ? depth - 2 : 0;      // streams beyond the engine's and `side`
   const uint64_t t0 = h->eng->tick;
-  // every record gets the tag of the first step (whatever ran since the last overlapped call wrote the tag bits as 0)
-  hipLaunchKernelGGL(anymdp_retag_kernel, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, st, h->a.sr, h->a.n_env,
-                     XV_ANYMDP_SR_TAG(t0));
+  // one launch opens the call: every record gets the tag of the first step (whatever ran since the last overlapped call
+  // wrote the tag bits as 0), the graphs' tick words the base their head nodes advance by `period` first
+  hipLaunchKernelGGL(anymdp_pipe_open_kernel, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, st, h->a.sr, h->a.n_env,
+                     XV_ANYMDP_SR_TAG(t0), h->d_ptick, XV_PIPE_DEPTH_MAX, t0 - (uint64_t)period);
   bool ok = hipGetLastError() == hipSuccess;
-  if (ok && !(h->ptick_valid && h->ptick_value == t0)) {
-    // the graphs' head nodes advance the words by `period` first
-    hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick, t0 - (uint64_t)period);
-    hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick + 1, t0 - (uint64_t)period);
-    for (int i = 0; i < deep; ++i) hipLaunchKernelGGL(anymdp_set_tick_kernel, dim3(1), dim3(1), 0, st, h->d_ptick + 2 + i, t0 - (uint64_t)period);
-    ok = hipGetLastError() == hipSuccess;
-  }
   // fork: the side stream starts behind what the engine's stream holds now (the caller's actions, a reset, the tags above)
   ok = ok && hipEventRecord(h->side_ev[0], st) == hipSuccess && hipStreamWaitEvent(h->side, h->side_ev[0], 0) == hipSuccess;
   for (int i = 0; i < deep; ++i) ok = ok && hipStreamWaitEvent(h->gate.side_n[i], h->side_ev[0], 0) == hipSuccess;
