@@ -83,7 +83,7 @@ for _ in range(25):
 print("captured loop: %d steps replayed, mean reward of the sampled steps %.4f" % (loop.steps_replayed, ret / 25))
 loop.close()
 
-# 8. long open-loop bursts: step_many with consecutive launches overlapped on two streams (each wave takes its envs over from
+# 8. long open-loop bursts: step_many with consecutive launches overlapped on two or three streams (each wave takes its envs over from
 #    the same wave of the step before through a tag in the env record) — same results, ~1.3x the steps per second
 actions = torch.randint(0, 4, (32, 4096), device=env.device, dtype=torch.int32)
 env.reset(seed=123)

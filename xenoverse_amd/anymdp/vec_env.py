@@ -668,7 +668,7 @@ class AnyMDPVecEnv(VectorEnv):
         _lib.check(self.lib.xv_anymdp_set_step_many_graph(self._h, int(m)))
 
     def set_step_many_overlap(self, on=True):
-        """step_many issues consecutive vector steps alternately on two HIP streams with no dependency between them; each
+        """step_many issues consecutive vector steps in turn on two or three HIP streams with no dependency between them; each
         wave of step k + 1 takes its envs over from the same wave of step k through a hand-off word (xeno.h:
         xv_anymdp_set_step_many_overlap).  Same results; whole cycles of an even ring period only."""
         _lib.check(self.lib.xv_anymdp_set_step_many_overlap(self._h, 1 if on else 0))
