@@ -70,3 +70,28 @@ def test_mixed_workload_fabricated_records_are_functions_of_global_ids():
             for k in part[f]:
                 assert torch.equal(part[f][k], whole[f][k][:, lo:hi]), (f, k)
     assert ch.bytes_per_rank == 4 * (128 * 8 + 64 * 72 + 32 * 24)
+
+
+def test_profile_hash_covers_the_kernel_section_only(tmp_path, monkeypatch):
+    """xenoverse_amd.build.source_hash ties a committed counter profile to the KERNEL source it measured: a .hip file counts
+    up to its `#ifndef XV_KERNELS_ONLY` line, headers whole — host-side edits behind the marker leave the hash alone"""
+    from xenoverse_amd import build as xb
+    d = tmp_path / "csrc"
+    d.mkdir()
+    (d / "k.hip").write_text("__global__ void k() {}\n#ifndef XV_KERNELS_ONLY\nint host_a;\n#endif\n")
+    (d / "h.h").write_text("#define X 1\n")
+    monkeypatch.setattr(xb, "CSRC", str(d))
+    h0 = xb.source_hash(("k.hip", "h.h"))
+    (d / "k.hip").write_text("__global__ void k() {}\n#ifndef XV_KERNELS_ONLY\nint host_b; int more;\n#endif\n")
+    assert xb.source_hash(("k.hip", "h.h")) == h0                      # host part changed: same hash
+    (d / "k.hip").write_text("__global__ void k() { }\n#ifndef XV_KERNELS_ONLY\nint host_b;\n#endif\n")
+    assert xb.source_hash(("k.hip", "h.h")) != h0                      # kernel part changed
+    (d / "k.hip").write_text("__global__ void k() {}\n#ifndef XV_KERNELS_ONLY\nint host_a;\n#endif\n")
+    (d / "h.h").write_text("#define X 2\n")
+    assert xb.source_hash(("k.hip", "h.h")) != h0                      # a header counts whole
+    # the committed profile of the step kernel is keyed to the source in the tree
+    monkeypatch.undo()
+    import json, glob, os
+    import bench
+    prof = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_z_pmc_traffic*.json")))
+    assert prof and json.load(open(prof[-1]))["bench_key"]["kernel_source_sha16"] == bench.kernel_source_hash()
