@@ -170,6 +170,8 @@ struct MixedPipe {
   XvPipeGate gate;       // the even half of a cycle starts once the host has enqueued both halves (xv_pipe.h)
   const xv_anymdp* used_by;
 };
+// one per device, for the life of the process (side stream, events, tick and hand-off words, the cached graph set: a few
+// kilobytes; not released at exit — the HIP runtime may be gone by the time static destructors run)
 static MixedPipe g_mixed_pipe[64];
 static std::mutex g_mixed_mu;
 
