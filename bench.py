@@ -17,9 +17,12 @@ ranks is taken per repetition and the MEDIAN repetition is reported (`steps` sta
 driver's K = 20 one repetition is a 0.15 ms region, which a single sample cannot resolve.
 
 One JSON line on rank 0: metric/value/unit/... as the driver's contract says, plus
-  roofline      HBM bound for the step kernel: `achieved`/`frac` from the algorithmic 562 B per env-step (SURVEY.md
-                §8(d)); `traffic` = bytes the kernel really moved (PMC counters of the committed profile of THIS
-                kernel source, else null), `frac_traffic` = traffic / launch time / peak
+  roofline      HBM bound for the step kernel.  `traffic` = bytes the kernel really moved per launch (PMC counters of the
+                committed profile of THIS kernel source, else null).  `achieved` / `frac` price those bytes when they are below
+                SURVEY.md §8(d)'s algorithmic 562 B per env-step (the search reads one 128-byte line of the 512-byte row) — a
+                fraction above 1 is never printed; the survey's figure stays as `achieved_survey_bytes` / `frac_survey_bytes`
+  long_call     SURVEY.md §8(d)'s own definition (>= 2,000 back-to-back steps after >= 100 warm-up, median of 5, both clocks)
+                for the three issue modes on the same tables: one stream, overlapped, fused roll-out
   cpu_baseline  SURVEY.md §8(d): the reference's execution style (one env per Python object, one step() per call,
                 NumPy global RNG; oracle/py_ref_style.py) in P = usable CPUs processes; `c_oracle` = the
                 vectorised C oracle (OpenMP) on a working set that does not fit the last-level cache
@@ -82,6 +85,10 @@ def parse():
     ap.add_argument("--sustain-seconds", type=float, default=6.0,
                     help="after the timed passes: an UNTIMED leg of back-to-back stepping of this length (excluded from `value`; "
                          "`sustain_s` in the line) so that a monitor sampling every few seconds sees the GPU busy; 0 = off")
+    ap.add_argument("--long-steps", type=int, default=2016,
+                    help="the `long_call` block (SURVEY.md 8(d): >= 1,000 back-to-back step launches after >= 100 warm-up steps): "
+                         "steps per call, rounded to whole ring cycles of --period; 0 = no block")
+    ap.add_argument("--long-repeats", type=int, default=5)
     ap.add_argument("--no-families", action="store_true",
                     help="N = 1: skip the `families` object (configs 3, 4 and the per-GPU share of 5, a few seconds)")
     ap.add_argument("--transport", default="auto", choices=["auto", "torch", "rccl"],
@@ -239,6 +246,25 @@ def pmc_traffic(n_env, n_task, search, overlap=False):
         except Exception:
             pass
     return None, None
+
+
+def roofline_basis(algo, traffic, kern_us, distinct_tasks):
+    """-> {bound, achieved, frac, basis}: which bytes `achieved` / `frac` price (never a fraction above 1).
+    algo: SURVEY 8(d)'s algorithmic bytes per launch; traffic: PMC bytes per launch or None; kern_us: time per launch."""
+    t = kern_us * 1e-6
+    survey = algo / t / 1e9
+    if not distinct_tasks:
+        return {"bound": "cache", "achieved": survey, "frac": None,
+                "basis": "shared tasks: the rows are Infinity-Cache / L2 resident; `achieved` prices SURVEY 8(d)'s algorithmic bytes "
+                         "as if they were HBM reads, so no fraction of the HBM peak is claimed"}
+    if traffic is not None and traffic < algo:
+        return {"bound": "hbm", "achieved": traffic / t / 1e9, "frac": traffic / t / 1e9 / HBM_PEAK_GBS,
+                "basis": "traffic: HBM bytes the kernel moves per launch (PMC), below SURVEY 8(d)'s algorithmic bytes because the "
+                         "search reads one or two 128-byte lines of the 512-byte row; the survey's figure: *_survey_bytes"}
+    f = survey / HBM_PEAK_GBS
+    return {"bound": "hbm", "achieved": survey, "frac": f if f <= 1.0 else None,
+            "basis": "SURVEY 8(d) algorithmic bytes" + ("" if f <= 1.0 else " (above the peak: the search moves fewer bytes than "
+                                                        "the survey prices and no PMC profile of this kernel source is committed; frac null)")}
 
 
 def choose_search(env, torch, args, n_task, S, A):
@@ -480,7 +506,8 @@ def main():
         # 5.19 vs 4.98 us per step on one box of the pool, 5.15 vs 5.35 on another).  `--graph off` issues plain launches
         graph_mode = args.graph if args.graph != "auto" else "on"
         env.set_step_many_graph(graph_mode)
-        env.set_step_many_overlap(args.overlap != "off" and graph_mode == "on")
+        overlap_requested = args.overlap != "off" and graph_mode == "on"
+        env.set_step_many_overlap(overlap_requested)
         device = env.device
         g = torch.Generator(device=device)
         g.manual_seed(args.seed + 17 * rank)
@@ -575,14 +602,15 @@ def main():
         def query(self):
             return env.engine.event_done(1)
 
-    def timed_pass(with_gather, repeats):
+    def timed_pass(with_gather, repeats, fn=None, warm=None):
         """-> (median wall seconds of a K-step batch, median event ms) after MAX over ranks per repetition.
         The HIP events are the engine's own (xv_engine_event_*: hipEventRecord on the stream the step kernels are
-        launched on, ~2 us of host time each instead of ~5 for a torch Event)."""
+        launched on, ~2 us of host time each instead of ~5 for a torch Event).
+        fn / warm: another batch to time / its warm-up (the `long_call` block), bracketed the same way."""
         gc.collect()       # a full collection of this heap takes tens of milliseconds: not inside a 0.1-ms timed region,
         gc.disable()       # and not right in front of it either (the idle GPU clocks down) — before the warm-up
         try:
-            run(args.warmup, with_gather)
+            run(args.warmup, with_gather) if warm is None else warm()
             walls, evs = [], []
             stop = _StopEvent() if gpu else None
             for _ in range(repeats):
@@ -590,7 +618,7 @@ def main():
                 t0 = time.perf_counter()
                 if gpu:
                     env.engine.event_record(0)
-                run(args.steps, with_gather)
+                run(args.steps, with_gather) if fn is None else fn()
                 if gpu:
                     env.engine.event_record(1)
                 barrier(stop)
@@ -658,26 +686,88 @@ def main():
                 w, e, _ = timed_pass(False, max(1, min(R, 5)))
                 took = env.step_many_overlap_state == 1
                 lv["overlapped" if took else ("one stream" if not other else "one stream (overlap not taken: short call)")] = vrow(w, e, False)
-                env.set_step_many_overlap(not other)
+                env.set_step_many_overlap(overlap_requested)      # what was REQUESTED (round 5 restored `not other`: off)
                 variants["launch"] = lv
             except Exception as ex:
                 variants["launch"] = {"error": repr(ex)}
             state["errs"] |= env.check_errors()
 
+    # `long_call`: SURVEY.md 8(d)'s own definition of the metric inside this line — >= 1,000 (here >= 2,000) back-to-back step
+    # launches after >= 100 warm-up steps — for the three ways the library issues open-loop steps of the SAME envs and tables:
+    # one stream (every launch behind the one before), overlapped (consecutive launches on up to three streams, per-wave
+    # hand-off) and the fused roll-out (one launch per ring cycle).  All three take their actions from a pre-filled ring and are
+    # bit-equal (tests/test_gpu_chains.py, test_fused_rollout_equals_stepwise); both clocks, the library's own state words and
+    # the device error flags read back after each.  `value` / `ms_per_step` stay the `--steps` burst.
+    long_call = None
+    PL = max(2, args.period - args.period % 2)
+    KL = (max(args.long_steps, PL) + PL - 1) // PL * PL if args.long_steps > 0 else 0
+    ring_l = actions_l = None
+    if env is not None and KL > 0 and not under_profiler():
+        try:
+            g2 = torch.Generator(device=device)
+            g2.manual_seed(args.seed + 17 * rank + 5)
+            actions_l = actions if P == PL else torch.randint(0, A, (PL, n_env), generator=g2, device=device, dtype=torch.int32)
+            ring_l = ring if P == PL else env.step_many(1, actions_l)
+            WL = (max(100, args.warmup) + PL - 1) // PL * PL
+            RL = max(1, args.long_repeats)
+
+            def lrow(w, e, launches, note):
+                return {"steps": KL, "warmup": WL, "repeats": RL, "launches_per_call": launches,
+                        "us_per_step": e * 1e3 / KL, "env_steps_per_s_events": world * n_env * KL / (e * 1e-3),
+                        "wall_us_per_step": w * 1e6 / KL, "env_steps_per_s": world * n_env * KL / w,
+                        "overlap_state": env.step_many_overlap_state,
+                        "graph_state": int(env.lib.xv_anymdp_step_many_graph_state(env._h)),
+                        "device_error_flags": env.check_errors(), "issue": note}
+            long_call = {"definition": "SURVEY.md 8(d): hipEvent / host wall around ONE call of `steps` back-to-back vector steps "
+                                       "after `warmup` warm-up steps, median of `repeats`, MAX over ranks; ring period %d; same envs, "
+                                       "tables, search (%s) and actions ring for the three issue modes" % (PL, search),
+                         "clock": "us_per_step / env_steps_per_s_events: HIP events on the launch stream; wall_us_per_step / "
+                                  "env_steps_per_s: host wall incl. the closing synchronise"}
+            for name, ov in (("one_stream", False), ("overlapped", True)):
+                if ov and args.overlap == "off":
+                    long_call[name] = {"skipped": "--overlap off"}
+                    continue
+                env.set_step_many_overlap(ov)
+                w, e, _ = timed_pass(False, RL, fn=lambda: env.step_many(KL, actions_l, out=ring_l),
+                                     warm=lambda: env.step_many(WL, actions_l, out=ring_l))
+                long_call[name] = lrow(w, e, KL, "xv_anymdp_step_many, one step kernel per vector step, ring cycles replayed from "
+                                       + ("cycle graphs on up to three HIP streams" if ov else "a hipGraph on the engine's stream"))
+            env.set_step_many_overlap(False)
+
+            def fused():
+                for _ in range(KL // PL):
+                    env.rollout(actions_l, out=ring_l)
+            w, e, _ = timed_pass(False, RL, fn=fused, warm=lambda: [env.rollout(actions_l, out=ring_l) for _ in range(WL // PL)])
+            long_call["fused_rollout"] = lrow(w, e, KL // PL, "xv_anymdp_rollout: ONE launch per ring cycle of %d steps (open loop, "
+                                              "the same input contract as step_many)" % PL)
+            env.set_step_many_overlap(overlap_requested)
+        except Exception as ex:
+            long_call = dict(long_call or {}, error=repr(ex))
+            try:
+                env.set_step_many_overlap(overlap_requested)
+            except Exception:
+                pass
+        state["errs"] |= env.check_errors()
+
     # untimed sustained stepping: a monitor that samples the GPU every few seconds sees it busy (the timed passes are
-    # milliseconds).  Excluded from `value`; `sustain_s` says how long it ran.
+    # milliseconds).  Excluded from `value`; `sustain_s` says how long it ran.  Issued the way `long_call.overlapped` (or, with
+    # --overlap off, `.one_stream`) is: calls of `long_call` length on the long ring, so that the two figures can be compared.
     sustain = None
     if env is not None and args.sustain_seconds > 0 and not under_profiler():
+        ks, al, rl = (KL, actions_l, ring_l) if (KL > 0 and ring_l is not None) else (8 * P, actions, ring)
         t0 = time.perf_counter()
-        done = 0
+        done = calls = 0
         while time.perf_counter() - t0 < args.sustain_seconds:
-            run(8 * P)
-            done += 8 * P
-            if done % (256 * P) == 0:
+            env.step_many(ks, al, out=rl)
+            done += ks
+            calls += 1
+            if calls % 8 == 0:
                 torch.cuda.synchronize()       # bounds the launch queue
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        sustain = {"sustain_s": dt, "steps": done, "env_steps_per_s_rank0": n_env * done / dt}
+        sustain = {"sustain_s": dt, "steps": done, "steps_per_call": ks, "env_steps_per_s_rank0": n_env * done / dt,
+                   "us_per_step": dt * 1e6 / done, "overlap_state": env.step_many_overlap_state,
+                   "overlap_requested": bool(overlap_requested)}
         state["errs"] |= env.check_errors()
 
     def report(timeout_note=None):
@@ -696,6 +786,7 @@ def main():
             # not of shared tasks whose lines are cache hits (2b runs under it)
             floor_us = floor["coop_lines_us"].get(lines) if (lines and n_task == n_env) else None
             exchange = gather_note if timeout_note is None else gather_note + "; " + timeout_note
+            roof = roofline_basis(algo, traffic, kern_us, n_task == n_env)
             out = {
                 "metric": "env-steps/sec (whole node), anymdp |S|=64 |A|=8, 65k envs/GPU",
                 "value": total_steps / wall, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
@@ -724,22 +815,25 @@ def main():
                            "bucket_census": None if census is None else {k: census[k] for k in (
                                "n_bucket", "cuts_per_line", "lines_dirty", "p_fallback", "fallbacks_per_launch", "auto_limit", "auto_uses_bucket")},
                            "exchange": exchange, "device_error_flags": state["errs"]},
-                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": achieved / HBM_PEAK_GBS,
-                             # the same fraction on the line's own wall clock: algorithmic bytes / ms_per_step / peak (host wall
-                             # around barrier + sync; `frac` and the fields below use the HIP-event time `avg_launch_us`)
-                             "frac_wall": algo / (wall / args.steps) / 1e9 / HBM_PEAK_GBS,
-                             "clock": "HIP events on the launch stream (avg_launch_us); frac_wall: host wall (ms_per_step)",
+                # `frac` is never printed above 1 (a fraction above 1 is a wrong bound, not a fast kernel): SURVEY 8(d) prices a
+                # step at the 512-byte CDF row + 50 B; the bucket / fence search reads one or two 128-byte lines of it, so when the
+                # PMC traffic of this kernel source is below the algorithmic bytes, `achieved` / `frac` are the bytes really moved
+                # (HBM busy) and the survey's figure stays beside them as `achieved_survey_bytes` / `frac_survey_bytes`; shared
+                # tasks (2b) are served by the Infinity Cache: no HBM fraction is claimed for them (`frac` null)
+                "roofline": dict(roof, **{"peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "achieved_survey_bytes": achieved, "frac_survey_bytes": achieved / HBM_PEAK_GBS,
+                             # the survey fraction on the line's own wall clock: algorithmic bytes / ms_per_step / peak (host wall
+                             # around barrier + sync; the other fields use the HIP-event time `avg_launch_us`)
+                             "frac_wall_survey_bytes": algo / (wall / args.steps) / 1e9 / HBM_PEAK_GBS,
+                             "frac_wall": None if roof["frac"] is None else roof["frac"] * kern_us / (wall * 1e6 / args.steps),
+                             "clock": "HIP events on the launch stream (avg_launch_us); frac_wall*: host wall (ms_per_step)",
                              "traffic": traffic, "traffic_source": traffic_src,
                              "frac_traffic": None if traffic is None else traffic / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                              "traffic_over_algorithmic": None if traffic is None else traffic / algo,
-                             # which of the fractions to read: SURVEY 8(d)'s `frac` prices the 512-byte row; a search that
-                             # reads one or two 128-byte lines of it moves fewer bytes (traffic / algorithmic < 1), and `frac`
-                             # then says "faster than reading the rows would allow", not "HBM is busy".  The step is a latency
-                             # chain of `dependent_lines` random lines: `floor_us` is that chain measured bare on this box class
-                             # (scripts/devtools/floor_probe.py), `lines_per_s` against the measured random-line rate
-                             "primary": ("frac_traffic" if traffic is not None and traffic < algo else
-                                         ("frac" if (traffic is not None or floor_us is None) else "frac_of_floor")),
+                             # the step is a latency chain of `dependent_lines` random lines: `floor_us` is that chain measured
+                             # bare on this box class (scripts/devtools/floor_probe.py), `lines_per_s` against the measured
+                             # random-line rate
+                             "primary": "frac" if roof["frac"] is not None else ("frac_of_floor" if floor_us is not None else None),
                              "dependent_lines": lines, "floor_us": floor_us, "frac_of_floor": None if floor_us is None else floor_us / kern_us,
                              "empty_launch_us": floor["empty_launch_us"], "floor_source": floor["source"],
                              "lines_per_s": None if lines is None else lines * n_env / (kern_us * 1e-6),
@@ -754,7 +848,7 @@ def main():
                                                     "three launches are in flight, so a profiler's per-kernel duration (start of dispatch to "
                                                     "end, the wait for the step before included) is a multiple of this") if state.get("overlap") == 1 else None,
                              "kernel_source_sha16": None if selftest else kernel_source_hash(),
-                             "avg_launch_us": kern_us, "algorithmic_bytes_per_launch": algo},
+                             "avg_launch_us": kern_us, "algorithmic_bytes_per_launch": algo}),
                 "rccl": dinfo["rccl"],
                 "rccl_ranks": transport["rccl_comm_count"] if transport["rccl_comm_count"] is not None else dinfo["rccl_ranks"],
                 "transport": transport["used"], "transport_requested": transport["requested"],
@@ -776,6 +870,19 @@ def main():
                                              chunks * P * n_env * REC_BYTES * (world - 1) / state["wall_g"] / 1e9}
             if variants is not None:
                 out["search_variants"] = variants
+            if long_call is not None:
+                for name, ov in (("one_stream", False), ("overlapped", True), ("fused_rollout", None)):
+                    row = long_call.get(name)
+                    if isinstance(row, dict) and "us_per_step" in row:
+                        tr, src = (None, None) if ov is None else pmc_traffic(n_env, n_task, search, ov)
+                        rb = roofline_basis(algo, tr, row["us_per_step"], n_task == n_env)
+                        row["roofline"] = dict(rb, peak=HBM_PEAK_GBS, unit="GB/s", traffic=tr, traffic_source=src,
+                                               frac_survey_bytes=algo / (row["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS)
+                if sustain is not None:
+                    ref = long_call.get("overlapped" if sustain.get("overlap_state") == 1 else "one_stream")
+                    if isinstance(ref, dict) and ref.get("env_steps_per_s"):
+                        long_call["sustain_over_long_call"] = sustain["env_steps_per_s_rank0"] * world / ref["env_steps_per_s"]
+                out["long_call"] = long_call
             if sustain is not None:
                 out.update(sustain_s=sustain["sustain_s"], sustain=sustain)
             out["cpu_baseline"] = cpu if world == 1 else None      # the CPU lines are measured at N = 1 only
@@ -815,9 +922,15 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
             import bench_mixed
             margs = argparse.Namespace(**dict(vars(args), steps=max(args.steps, 64), repeats=max(1, min(R, 5))))
+            # one handle per device may hold the overlap switch: `env` hands it to the mixed share for the time of its line
+            env.set_step_many_overlap(False)
             state["families"] = {"mixed": bench_mixed.run_mixed(margs, torch, dist, dinfo, rank, world, local, wd)}
         except Exception as ex:
             state["families"] = {"mixed": {"error": repr(ex)}}
+        try:
+            env.set_step_many_overlap(overlap_requested)
+        except Exception:
+            pass
 
     if gather is not None:      # pass 2 (N > 1): every finished rollout chunk all-gathered to all ranks, overlapped
         wd.emit = report

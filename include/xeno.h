@@ -48,8 +48,11 @@ extern "C" {
  *    xv_acrobot_step_info (the done mask from the step launch); xv_maze_set_raycast_mapping
  * 10: overlapped step_many (xv_anymdp_set_step_many_overlap / _overlap_state), sub-batch views (xv_anymdp_view,
  *    xv_anymdp_step_many_chains), xv_anymdp_build_rows, xv_pack_rollout_f32 / xv_unpack_rollout_f32, XV_DEVERR_HANDOFF
- * 11: the overlap switch also covers xv_mixed_step_many; xv_mixed_step_many_overlap_state; xv_engine_probe_side_streams */
-#define XV_ABI_VERSION 11
+ * 11: the overlap switch also covers xv_mixed_step_many; xv_mixed_step_many_overlap_state; xv_engine_probe_side_streams
+ * 12: an expired hand-off of an overlapped xv_anymdp_step_many / xv_mixed_step_many is repaired (the call is replayed from its
+ *    entry state on one stream; the *_overlap_state functions return -2 for such a call); every cycle graph starts with the
+ *    cycle gate; launches in flight are sized against 3/4 of the device, two at most beside an RCCL communicator */
+#define XV_ABI_VERSION 12
 
 /* return codes */
 #define XV_OK 0
@@ -263,11 +266,19 @@ int xv_anymdp_step_many_graph_state(xv_anymdp* h);
  * gate the host opens once both halves are enqueued; calls whose two launches could not be resident together take the
  * one-stream path.  A wave's wait is bounded — 2^20 polls AND 2 s of wall clock (a suspended wave does not poll: time the
  * device spends on another process does not count) — then the wave goes on and XV_DEVERR_HANDOFF is set in the engine's
- * error word: wrong data, flagged, never a hang.  Needs the fence or bucket search and the host tick;
- * otherwise, and for odd periods, step_many behaves as without it.
+ * error word.  Such a call is REPAIRED (ABI 12): its opening kernel keeps every env record and the error word as they were at
+ * entry, and behind the join a replay kernel — a nearly empty launch when no hand-off expired — restores them and re-runs the
+ * whole call on the engine's stream as the fused roll-out does (same ticks, every ring slot rewritten), clears the bit and
+ * drops the error bits the failed attempt raised from wrong states: an expiry costs time (seconds), never results, and
+ * never a hang.  (xv_anymdp_step_tokens_many's overlapped path still only flags.)  Needs the fence or bucket search and the
+ * host tick; otherwise, and for odd periods, step_many behaves as without it.
  * One handle per device at a time, never a view (XV_ERR_UNSUPPORTED): two overlapped calls in flight can block each other
  * on the hardware queues their streams share.  Not inside a stream capture (the call takes the one-stream path).
- * xv_anymdp_step_many_overlap_state: 1 the last call overlapped, 0 it did not, -1 the path failed and is no longer tried. */
+ * The launches in flight are sized against 3/4 of what the empty device holds of the kernel (a neighbour kernel of the same
+ * process takes slots), and while the process holds an RCCL communicator on the device at most two are in flight.
+ * xv_anymdp_step_many_overlap_state: 1 the last call overlapped, 0 it did not, -1 the path failed and is no longer tried,
+ * -2 the last call overlapped, a hand-off expired and the call was replayed (results are right; read it once the stream has
+ * drained). */
 int xv_anymdp_set_step_many_overlap(xv_anymdp* h, int on);
 int xv_anymdp_step_many_overlap_state(xv_anymdp* h);
 
@@ -781,9 +792,12 @@ int xv_mixed_step_many(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mixed
  * the launch of step k + 1 runs under step k; every wave takes its envs over from the same wave of the step before (AnyMDP:
  * tag in the env record; LinDS and CartPole: one word per wave).  Same launch ticks, same results, bit for bit.  Needs
  * the three handles on three engines of their own (host ticks, one stream); otherwise, and for the steps beyond the last
- * whole ring cycle, the ordinary loop runs.  Waits are bounded as for xv_anymdp_step_many (XV_DEVERR_HANDOFF, never a hang).
+ * whole ring cycle, the ordinary loop runs.  Waits are bounded as for xv_anymdp_step_many, and an expired one is repaired the
+ * same way (ABI 12): the three families' states and error words are kept at the call's entry and the call is replayed in one
+ * launch behind the join.
  * xv_mixed_step_many_overlap_state: 1 the last call with this AnyMDP handle was overlapped, 0 it was not, -1 the overlapped
- * path failed on this device (streams do not run concurrently, graph build) and is no longer tried. */
+ * path failed on this device (streams do not run concurrently, graph build) and is no longer tried, -2 the last call
+ * overlapped, a hand-off expired and the call was replayed (results are right). */
 int xv_mixed_step_many_overlap_state(xv_anymdp* a);
 
 #ifdef __cplusplus

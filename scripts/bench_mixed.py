@@ -87,9 +87,25 @@ def cpu_baseline_mixed(seconds, seed, cores):
 
 
 def run_mixed(args, torch, dist, dinfo, rank, world, local, wd, selftest=False, scale=1):
-    """-> the JSON line (dict) on every rank (rank 0 prints it).  scale: divides the per-GPU share (tests)."""
+    """-> the JSON line (dict) on every rank (rank 0 prints it).  scale: divides the per-GPU share (tests).
+    The share and the gather are closed on every way out (an exception included)."""
+    held = {}
+    try:
+        return _run_mixed(args, torch, dist, dinfo, rank, world, local, wd, selftest, scale, held)
+    finally:
+        for k in ("gather", "share"):
+            obj = held.pop(k, None)
+            if obj is not None:
+                try:
+                    obj.close()
+                except Exception:
+                    pass
+
+
+def _run_mixed(args, torch, dist, dinfo, rank, world, local, wd, selftest, scale, held):
     from xenoverse_amd.distributed import MixedChunk, RolloutGather
     T = int(args.period)
+    overlap_note = None
     per = {f: max(64, n // scale) for f, n in PER_GPU.items()}
     tot = {f: n * world for f, n in per.items()}
     gpu = not selftest
@@ -98,9 +114,13 @@ def run_mixed(args, torch, dist, dinfo, rank, world, local, wd, selftest=False, 
     if gpu:
         from xenoverse_amd.mixed_shard import MixedShare
         share = MixedShare(rank, world, tot["anymdp"], tot["linds"], tot["cartpole"], T=T, seed=args.seed, device=str(dev))
+        held["share"] = share
         chunk = share.chunk
         if getattr(args, "overlap", "auto") != "off":
-            share.set_overlap(True)       # calls of >= 64 steps: two streams, the launch of step k + 1 under step k
+            try:
+                share.set_overlap(True)       # calls of >= 64 steps: two streams, the launch of step k + 1 under step k
+            except Exception as ex:           # e.g. another handle on this device holds the overlap switch: one stream, same results
+                overlap_note = "overlap not taken: %r" % (ex,)
         share.random_actions(args.seed + 17 * rank)
         share.reset()
         share.step_many(T)
@@ -132,6 +152,7 @@ def run_mixed(args, torch, dist, dinfo, rank, world, local, wd, selftest=False, 
                 except Exception as ex2:
                     gather_note += " / %r" % (ex2,)
         if gather is not None:
+            held["gather"] = gather
             gather_note = "all_gather of %d-step chunks of the three families, %d B per rank (%s, side stream)" % (
                 T, chunk.bytes_per_rank, "xv_rollout_allgather: ncclAllGather over librccl" if transport == "rccl"
                 else "torch.distributed " + str(dinfo.get("backend")))
@@ -257,7 +278,7 @@ def run_mixed(args, torch, dist, dinfo, rank, world, local, wd, selftest=False, 
                                "from the same wave of the step before (xv_anymdp_set_step_many_overlap)" if overlapped else ""))
                              if (share is None or share.fused)
                              else "three launches per vector step (no fused instantiation for these handles)",
-                   "overlap": overlapped, "overlap_requested": getattr(args, "overlap", "auto"),
+                   "overlap": overlapped, "overlap_requested": getattr(args, "overlap", "auto"), "overlap_note": overlap_note,
                    "sharding": "contiguous ranges per family (shard_range), env_id_base = the range's start, tasks named by global "
                                "index: no data-path collective",
                    "exchange": gather_note, "chunk_bytes_per_rank": chunk.bytes_per_rank, "chunk_steps": T,
@@ -282,8 +303,4 @@ def run_mixed(args, torch, dist, dinfo, rank, world, local, wd, selftest=False, 
     if selftest:
         out["mode"] = "exchange-selftest: fabricated CPU records, no stepping — NOT a measurement"
         out["selftest"] = check
-    if gather is not None:
-        gather.close()
-    if share is not None:
-        share.close()
     return out

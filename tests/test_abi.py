@@ -39,7 +39,7 @@ def test_every_declared_symbol_is_bound_in_python():
 
 def test_abi_version_and_loader():
     lib = _lib.load()
-    assert lib.xv_abi_version() == _lib.ABI_VERSION == 11
+    assert lib.xv_abi_version() == _lib.ABI_VERSION == 12
 
 
 def test_missing_library_is_loud(monkeypatch):

@@ -33,7 +33,8 @@ def _dev_tables(tab, dev="cuda:0"):
     return out
 
 
-def _run_many(tab, n, P, acts_np, plan, search, chains, how, graph, seed=77, overlap=False, mode="same_step"):
+def _run_many(tab, n, P, acts_np, plan, search, chains, how, graph, seed=77, overlap=False, mode="same_step", expect_state=None,
+              states=None):
     """-> list of snapshots: the ring after every step_many of `plan`, then (state, steps, need_reset, tick)"""
     env = AnyMDPVecEnv(n, seed=seed, autoreset_mode=mode, bucket_lines="off")
     env.set_task(_dev_tables(tab))
@@ -53,8 +54,11 @@ def _run_many(tab, n, P, acts_np, plan, search, chains, how, graph, seed=77, ove
     s, st, nr = env.get_state()
     rec.append({"state": _np(s), "steps": _np(st), "need_reset": _np(nr), "tick": np.asarray(env.engine.tick)})
     assert env.check_errors() == 0
+    if states is not None:
+        states.append(env.step_many_overlap_state)
     if overlap:
-        assert env.step_many_overlap_state == (1 if (search != "binary" and P % 2 == 0 and plan[-1] >= 64) else 0)
+        want = expect_state if expect_state is not None else (1 if (search != "binary" and P % 2 == 0 and plan[-1] >= 64) else 0)
+        assert env.step_many_overlap_state == want
     env.close()
     return rec
 
@@ -388,3 +392,150 @@ def test_overlapped_step_many_on_short_rings(P):
     ref = _run_many(tab, n, P, acts, plan, "fence", 1, "streams", False)
     got = _run_many(tab, n, P, acts, plan, "fence", 1, "streams", True, overlap=True)
     _same(ref, got)
+
+
+# ---- an expired hand-off is repaired (ABI 12) ------------------------------------------------------------------------------
+@pytest.mark.parametrize("search", ["fence", "bucket"])
+@pytest.mark.parametrize("mode", ["same_step", "next_step"])
+def test_an_expired_hand_off_is_repaired_by_the_replay(monkeypatch, search, mode):
+    """XV_PIPE_TEST_FAIL=1 leaves behind what an expired hand-off does — XV_DEVERR_HANDOFF (and a spurious error bit), wrong env
+    records, wrong ring contents — between the join of an overlapped call and its replay kernel.  The replay restores the
+    records the call's opening kernel kept, re-runs the call on one stream and publishes entry | replay error bits: rings,
+    records, tick and flags equal the one-stream path's, and the state word says -2."""
+    tab = oracle.anymdp_synth(seed=12, task_index_base=0, n_task=16, S=64, A=8, s0_max=4)
+    n, P = 2000, 8
+    acts = np.random.RandomState(5).randint(0, 8, (P, n)).astype(np.int32)
+    plan = [3 * P + 5, 9 * P + 3, 3, 12 * P]
+    ref = _run_many(tab, n, P, acts, plan, search, 1, "streams", False, mode=mode)
+    monkeypatch.setenv("XV_PIPE_TEST_FAIL", "1")
+    monkeypatch.setenv("XV_PIPE_NO_BACKOFF", "1")          # every long call of the plan is overlapped, fails and is replayed
+    got = _run_many(tab, n, P, acts, plan, search, 1, "streams", True, overlap=True, mode=mode, expect_state=-2)   # asserts flags == 0
+    _same(ref, got)
+    monkeypatch.delenv("XV_PIPE_NO_BACKOFF")
+    if search == "fence" and mode == "same_step":
+        # with the back-off (the default): the call after a replayed one takes the one-stream path — state 0, same results
+        got = _run_many(tab, n, P, acts, plan, search, 1, "streams", True, overlap=True, mode=mode, expect_state=0)
+        _same(ref, got)
+    monkeypatch.delenv("XV_PIPE_TEST_FAIL")
+    again = _run_many(tab, n, P, acts, plan, search, 1, "streams", True, overlap=True, mode=mode, expect_state=1)   # and no replay without a failure
+    _same(ref, again)
+
+
+def test_a_hand_off_that_really_expires_is_repaired():
+    """XV_PIPE_TEST_BAD_TAG=1: the call's opening kernel gives env 0 a tag no step waits for, so the first step's first wave polls
+    2^19 times and 0.5 s, gives up and sets XV_DEVERR_HANDOFF — the real expiry path.  The call is replayed: same results, no flag."""
+    import os
+    tab = oracle.anymdp_synth(seed=12, task_index_base=0, n_task=16, S=64, A=8, s0_max=4)
+    n, P = 4096, 8
+    acts = np.random.RandomState(6).randint(0, 8, (P, n)).astype(np.int32)
+    plan = [10 * P]
+    ref = _run_many(tab, n, P, acts, plan, "fence", 1, "streams", False)
+    os.environ["XV_PIPE_TEST_BAD_TAG"] = "1"
+    try:
+        import time
+        t0 = time.time()
+        got = _run_many(tab, n, P, acts, plan, "fence", 1, "streams", True, overlap=True, expect_state=-2)
+        assert time.time() - t0 > 0.4          # the wave really waited for its bound (2^19 polls and 0.5 s)
+    finally:
+        del os.environ["XV_PIPE_TEST_BAD_TAG"]
+    _same(ref, got)
+
+
+def test_a_held_up_host_between_the_second_and_the_third_launch_of_a_set_is_harmless(monkeypatch):
+    """Three steps in flight: with the host held up for 3.5 s between the second and the third graph launch of a set, the second
+    graph's waves would spin (2-s bound) on a first graph that is still gated — unless every graph of a set starts behind the
+    gate (xv_pipe.h).  No flag, no replay, same results."""
+    tab = oracle.anymdp_synth(seed=12, task_index_base=0, n_task=16, S=64, A=8, s0_max=4)
+    n, P = 4096, 6
+    acts = np.random.RandomState(6).randint(0, 8, (P, n)).astype(np.int32)
+    plan = [20 * P + 1]
+    ref = _run_many(tab, n, P, acts, plan, "fence", 1, "streams", False)
+    monkeypatch.setenv("XV_PIPE_TEST_STALL_MS", "3500")
+    monkeypatch.setenv("XV_PIPE_TEST_STALL_AT", "1")
+    got = _run_many(tab, n, P, acts, plan, "fence", 1, "streams", True, overlap=True, expect_state=1)
+    _same(ref, got)
+
+
+@pytest.mark.parametrize("neighbour", ["matmul", "allgather"])
+def test_overlapped_step_many_beside_a_busy_neighbour_of_the_same_process(neighbour):
+    """65,536 envs, overlapped launches, while the SAME process keeps another stream busy — a torch matmul loop (a policy
+    network's kernels take CU slots) or xv_rollout_allgather of 29-MB chunks (RCCL's kernels).  Results must equal the
+    one-stream path bit for bit with no flag left: either the hand-offs simply took longer (state 1), or an expiry was
+    replayed (-2), or the library declined (0)."""
+    import threading
+    tab = oracle.anymdp_synth(seed=21, task_index_base=0, n_task=1024, S=64, A=8, s0_max=4)
+    n, P = 65536, 32
+    acts = np.random.RandomState(7).randint(0, 8, (P, n)).astype(np.int32)
+    plan = [20 * P, 20 * P + 3, 40 * P]
+    ref = _run_many(tab, n, P, acts, plan, "bucket", 1, "streams", True)
+    stop = threading.Event()
+    side = torch.cuda.Stream()
+    gather = None
+    if neighbour == "allgather":
+        from xenoverse_amd.distributed import RolloutGather
+        try:
+            gather = RolloutGather((32, 65536, 14), device="cuda", transport="rccl", rank=0, world=1)     # 29 MB per rank
+        except Exception as ex:
+            pytest.skip("RCCL transport unavailable: %r" % (ex,))
+    count = [0]
+
+    def busy():
+        torch.cuda.set_device(0)
+        if neighbour == "matmul":
+            with torch.cuda.stream(side):
+                a = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
+                b = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
+                while not stop.is_set():
+                    for _ in range(8):
+                        a = torch.tanh(a @ b) * 0.5
+                    side.synchronize()
+                    count[0] += 8
+        else:
+            with torch.cuda.stream(side):      # (this thread's current stream: not the stepping's)
+                while not stop.is_set():
+                    gather.launch()
+                    gather.wait()
+                    side.synchronize()
+                    count[0] += 1
+    th = threading.Thread(target=busy, daemon=True)
+    th.start()
+    states = []
+    try:
+        import time
+        while count[0] == 0 and th.is_alive():
+            time.sleep(0.01)
+        for _ in range(3):
+            env_states = []
+            got = _run_many_any_state(tab, n, P, acts, plan, "bucket", env_states)      # asserts flags == 0
+            _same(ref, got)
+            assert all(v in (1, -2, 0) for v in env_states), env_states
+            states.append(env_states)
+    finally:
+        stop.set()
+        th.join(timeout=30)
+        if gather is not None:
+            gather.close()
+    assert count[0] > 0
+    print("neighbour %s: overlap states %s, neighbour iterations %d" % (neighbour, states, count[0]))
+
+
+def _run_many_any_state(tab, n, P, acts_np, plan, search, states):
+    env = AnyMDPVecEnv(n, seed=77, autoreset_mode="same_step", bucket_lines="off")
+    env.set_task(_dev_tables(tab))
+    env.set_search("bucket", n_bucket=16) if search == "bucket" else env.set_search(search)
+    env.set_step_many_graph(True)
+    env.set_step_many_overlap(True)
+    env.reset()
+    acts = torch.as_tensor(acts_np, device=env.device)
+    rec, ring = [], None
+    for n_steps in plan:
+        ring = env.step_many(n_steps, acts, out=ring)
+        torch.cuda.synchronize()
+        states.append(env.step_many_overlap_state)
+        rec.append({k: _np(v).copy() for k, v in ring.items()})
+    s, st, nr = env.get_state()
+    rec.append({"state": _np(s), "steps": _np(st), "need_reset": _np(nr), "tick": np.asarray(env.engine.tick)})
+    assert env.check_errors() == 0
+    env.set_step_many_overlap(False)
+    env.close()
+    return rec

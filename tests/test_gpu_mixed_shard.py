@@ -148,3 +148,45 @@ def test_overlapped_mixed_steps_with_a_held_up_host(monkeypatch):
     assert sh.overlap_state == 1 and sh.check_errors() == 0
     sh.set_overlap(False)
     sh.close()
+
+
+@pytest.mark.parametrize("mode,T,n_steps", [("same_step", 8, 203), ("next_step", 16, 128)])
+def test_an_expired_hand_off_of_the_mixed_step_is_repaired_by_the_replay(monkeypatch, mode, T, n_steps):
+    """XV_PIPE_TEST_FAIL=1 leaves behind what an expired hand-off does (the flag plus a spurious error bit, wrong AnyMDP records,
+    LinDS tiles and CartPole states, wrong ring contents) between the join of an overlapped xv_mixed_step_many and its replay
+    kernel: the three families are restored from the call's snapshot and the call is re-run in one launch — rings, states,
+    counters and flags equal the one-stream loop's; the state word says -2"""
+    tot = (4096, 2048, 1024 + 8)
+    rng = np.random.RandomState(5)
+    acts = dict(a=rng.randint(0, 8, (T, tot[0])).astype(np.int32), l=rng.uniform(-1.2, 1.2, (T, tot[1], 8)).astype(np.float32),
+                c=rng.randint(0, 2, (T, tot[2])).astype(np.int32))
+    res = []
+    for overlap in (False, True):
+        if overlap:
+            monkeypatch.setenv("XV_PIPE_TEST_FAIL", "1")
+            monkeypatch.setenv("XV_PIPE_NO_BACKOFF", "1")      # every long call is overlapped, fails and is replayed
+        sh = MixedShare(0, 1, *tot, T=T, seed=21, linds_ns=16, autoreset_mode=mode)
+        sh.set_actions(acts["a"], acts["l"], acts["c"])
+        if overlap:
+            sh.set_overlap(True)
+        sh.reset()
+        rec = []
+        for n in (n_steps, 3, n_steps):
+            sh.step_many(n)
+            torch.cuda.synchronize()
+            if overlap:
+                assert sh.overlap_state == (-2 if n >= 64 else 0), (n, sh.overlap_state)
+            rec.append({k: v.clone() for k, v in sh.ring.items()})
+            st = {}
+            for f, e in (("a", sh.ea), ("l", sh.el), ("c", sh.ec)):
+                for name, v in zip(("state", "steps", "need_reset"), e.get_state()):
+                    st[f + "_" + name] = torch.as_tensor(v).clone()
+            rec.append(st)
+        assert sh.check_errors() == 0
+        if overlap:
+            sh.set_overlap(False)
+        sh.close()
+        res.append(rec)
+    for i, (p, q) in enumerate(zip(*res)):
+        for k in p:
+            assert torch.equal(torch.as_tensor(p[k]), torch.as_tensor(q[k])), (i, k)

@@ -159,7 +159,7 @@ class XenoError(RuntimeError):
 XV_ERR_INVALID, XV_ERR_HIP, XV_ERR_UNSUPPORTED, XV_ERR_NOMEM = -1, -2, -3, -4
 
 
-ABI_VERSION = 11     # include/xeno.h XV_ABI_VERSION
+ABI_VERSION = 12     # include/xeno.h XV_ABI_VERSION
 
 
 def load():

@@ -675,7 +675,8 @@ class AnyMDPVecEnv(VectorEnv):
 
     @property
     def step_many_overlap_state(self):
-        """1: the last step_many overlapped its cycles, 0: it did not, -1: the overlapped path failed on this env"""
+        """1: the last step_many overlapped its cycles, 0: it did not, -1: the overlapped path failed on this env, -2: it
+        overlapped, a hand-off expired and the call was replayed on one stream (results are right; read after a sync)"""
         return int(self.lib.xv_anymdp_step_many_overlap_state(self._h))
 
     # ---- accessors (anymdp_env.py:134-165) ----------------------------------------------------------

@@ -138,6 +138,12 @@ struct xv_anymdp {
   uint64_t* d_ptick;         // two tick words
   uint64_t ptick_value;      // what both hold once the streams have drained (valid with pgraph_exec)
   bool ptick_valid;
+  // an expired hand-off is repaired, not just flagged: the call's entry state is kept and the call replayed on one stream
+  // (anymdp_replay_kernel below)
+  uint2* d_snap;             // the env records at the entry of the last overlapped call
+  uint32_t* d_snap_w;        // [0] the error word at entry, [1] the replay's own error bits, [2] workgroups finished
+  uint32_t fell_seen;        // gate.h_issued[1] (calls replayed so far) when the last overlapped call was issued
+  XvPipeBackoff backoff;     // one-stream calls after a replayed one (xv_pipe.h)
   struct {
     int period, mode, search;
     size_t stride;
@@ -461,7 +467,7 @@ __device__ __forceinline__ void anymdp_step_body(const AnyMDPArgs& P, const AnyM
       r64 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (__ballot(valid && ((uint32_t)r64 >> XV_ANYMDP_SR_TAG_SHIFT) != want) == 0ull) break;
       __builtin_amdgcn_s_sleep(1);
-      if (xv_hand_expired(polls, t_begin)) {
+      if (xv_hand_expired(polls, t_begin) || xv_hand_aborted(polls, P.err)) {      // (the call is then replayed: anymdp_replay_kernel)
         err |= XV_DEVERR_HANDOFF;
         break;
       }
@@ -745,10 +751,52 @@ template <bool INJECT, int G, bool ROLLOUT, bool TICKDEV = false, int BK = 0, bo
 __global__ __launch_bounds__(256) void anymdp_step_kernel(AnyMDPArgs P, AnyMDPStepIO io, int T_steps, int mode) {
   anymdp_step_body<INJECT, G, ROLLOUT, TICKDEV, BK, HAND>(P, io, T_steps, mode, (int)blockIdx.x);
 }
-// before an overlapped call: every record gets the tag of the call's first step (ordinary kernels write the tag bits as 0)
-static __global__ __launch_bounds__(256) void anymdp_retag_kernel(uint2* sr, int n, uint32_t tag) {
+// An expired hand-off (XV_DEVERR_HANDOFF set during an overlapped call: a wave went on with a record nobody had handed it)
+// is REPAIRED: the call's opening kernel kept every env record and the error word as they were at entry (snap, w[0]); this
+// kernel runs on the engine's stream behind the join of every overlapped call.  All of its workgroups read the same two
+// words; in the usual case (no new HANDOFF bit) they return at once — one nearly empty launch per CALL.  Otherwise every
+// lane restores its env's record and replays the whole call — `cycles` ring cycles of `period` steps — as the fused roll-out
+// does: same ticks, same draws, every ring slot rewritten, bit-equal to the one-stream path (tests/test_gpu_chains.py).
+// Error bits the failed attempt raised from wrong states are dropped: the word becomes entry | what the replay raised.
+// The last workgroup to finish publishes that and counts the replay in pinned host memory (h_fell:
+// xv_anymdp_step_many_overlap_state -> -2).
+template <int G, int BK>
+__global__ __launch_bounds__(256) void anymdp_replay_kernel(AnyMDPArgs P, AnyMDPStepIO io, int period, int cycles, int mode,
+                                                            const uint2* snap, uint32_t* w, uint32_t* real_err, uint32_t* h_fell) {
+  const uint32_t e_now = __hip_atomic_load(real_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t e_in = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((e_now & XV_DEVERR_HANDOFF) == 0u) {      // (the opening kernel took the bit out of the word: set = raised by this call)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (e_in & XV_DEVERR_HANDOFF)) atomicOr(real_err, (uint32_t)XV_DEVERR_HANDOFF);
+    return;
+  }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) sr[i].x = (sr[i].x & ((1u << XV_ANYMDP_SR_TAG_SHIFT) - 1u)) | (tag << XV_ANYMDP_SR_TAG_SHIFT);
+  if (i < P.n_env) P.sr[i] = snap[i];
+  __syncthreads();      // (an invalid lane looks at the last env's record: restored by a lane of this workgroup)
+  AnyMDPArgs Q = P;
+  Q.err = w + 1;
+  Q.tick_dev = nullptr;
+  for (int c = 0; c < cycles; ++c) {
+    Q.tick = P.tick + (uint64_t)c * (uint64_t)period;
+    anymdp_step_body<false, G, true, false, BK, false>(Q, io, period, mode, (int)blockIdx.x);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(w + 2, 1u) == gridDim.x - 1u) {
+      const uint32_t re = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(real_err, e_in | re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      w[1] = 0u; w[2] = 0u;
+      __hip_atomic_fetch_add(h_fell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+// test hook (XV_PIPE_TEST_FAIL=1, tests/test_gpu_chains.py): what an expired hand-off leaves behind — the flag, records and
+// ring contents that are wrong — placed between the join and the replay kernel
+static __global__ __launch_bounds__(256) void anymdp_test_fail_kernel(uint2* sr, int n, uint32_t* err, int32_t* obs, size_t n_obs) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)n) sr[i] = make_uint2((uint32_t)(i % 3u), 5u);
+  for (size_t k = i; k < n_obs; k += (size_t)gridDim.x * blockDim.x) obs[k] = -7;
+  if (i == 0) atomicOr(err, (uint32_t)(XV_DEVERR_HANDOFF | XV_DEVERR_STEP_TERMINAL));
 }
 
 // Completes the rows in place (create time): fence line and per-block metadata.  One thread per (row, k < 64).
@@ -1565,6 +1613,8 @@ static void anymdp_pipe_clear(xv_anymdp* h) {      // fields of the overlapped s
   h->tgraph[0] = h->tgraph[1] = nullptr; h->tgraph_exec[0] = h->tgraph_exec[1] = nullptr;
   memset(&h->tpipe_key, 0, sizeof(h->tpipe_key));
   h->d_ptick = nullptr; h->ptick_value = 0; h->ptick_valid = false;
+  h->d_snap = nullptr; h->d_snap_w = nullptr; h->fell_seen = 0;
+  h->backoff.fell_known = 0; h->backoff.left = 0; h->backoff.len = 32;
   memset(&h->pipe_key, 0, sizeof(h->pipe_key));
 }
 static void anymdp_pipe_drop_graphs(xv_anymdp* h) {
@@ -1589,6 +1639,8 @@ static void anymdp_pipe_release(xv_anymdp* h) {
   if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
   for (int q = 0; q < 2; ++q) if (h->side_ev[q]) (void)hipEventDestroy(h->side_ev[q]);
   if (h->d_ptick) (void)hipFree(h->d_ptick);
+  if (h->d_snap) (void)hipFree(h->d_snap);
+  if (h->d_snap_w) (void)hipFree(h->d_snap_w);
   for (int i = 0; i < 2; ++i) {
     if (h->gate.side_n[i]) { (void)hipStreamSynchronize(h->gate.side_n[i]); (void)hipStreamDestroy(h->gate.side_n[i]); h->gate.side_n[i] = nullptr; }
     if (h->gate.ev_n[i]) { (void)hipEventDestroy(h->gate.ev_n[i]); h->gate.ev_n[i] = nullptr; }
@@ -1950,13 +2002,13 @@ static bool anymdp_add_tick_node(hipGraph_t graph, const hipGraphNode_t* deps, i
   return hipGraphAddKernelNode(&node, graph, deps, (size_t)n_deps, &np) == hipSuccess;
 }
 
-// head of cycle graph q of the overlapped paths: tick word q += period; q == 0 passes the cycle gate
+// head of cycle graph q of the overlapped paths: tick word q += period, then the cycle gate (every stream's graph: xv_pipe.h)
 static bool anymdp_add_head_node(xv_anymdp* h, hipGraph_t graph, hipGraphNode_t* prev, int q, int period, int unroll) {
   hipKernelNodeParams np;
   memset(&np, 0, sizeof(np));
   uint64_t* t = h->d_ptick + q;
   uint64_t dv = (uint64_t)period * (uint64_t)unroll;
-  uint32_t* seen = q == 0 ? h->gate.d_seen : nullptr;
+  uint32_t* seen = h->gate.d_seen + q;
   const uint32_t* issued = h->gate.d_issued;
   uint32_t* err = h->a.err;
   void* params[] = {&t, &dv, &seen, &issued, &err};
@@ -2096,7 +2148,39 @@ static bool anymdp_pipe_setup(xv_anymdp* h) {
   }
   if (!h->d_ptick && hipMalloc(&h->d_ptick, XV_PIPE_DEPTH_MAX * sizeof(uint64_t)) != hipSuccess) return false;   // the graphs' tick words
   if (!h->gate.d_seen && !xv_pipe_gate_create(&h->gate)) return false;
+  if (!h->d_snap && hipMalloc(&h->d_snap, (size_t)h->a.n_env * sizeof(uint2)) != hipSuccess) { h->d_snap = nullptr; return false; }
+  if (!h->d_snap_w) {
+    if (hipMalloc(&h->d_snap_w, 4 * sizeof(uint32_t)) != hipSuccess) { h->d_snap_w = nullptr; return false; }
+    if (hipMemsetAsync(h->d_snap_w, 0, 4 * sizeof(uint32_t), h->eng->stream) != hipSuccess) return false;
+  }
   return true;
+}
+// the replay kernel for this handle's layout and search (HAND kernels exist for the fence and bucket searches only)
+static bool anymdp_launch_replay(xv_anymdp* h, int eff, const AnyMDPStepIO& io, int period, int cycles, int mode, uint64_t t0) {
+  const int bk = eff == XV_ANYMDP_SEARCH_BUCKET ? h->a.bfmt : 0;
+  AnyMDPArgs a = h->a;
+  a.seed = h->eng->seed; a.gid_base = h->eng->env_id_base; a.tick = t0; a.tick_dev = nullptr;
+  const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
+  uint32_t* h_fell = h->gate.d_issued + 1;
+#define XV_REPLAY(GV, BKV) \
+  hipLaunchKernelGGL((anymdp_replay_kernel<GV, BKV>), grid, block, 0, h->eng->stream, a, io, period, cycles, mode, \
+                     (const uint2*)h->d_snap, h->d_snap_w, h->a.err, h_fell)
+#define XV_REPLAY_G(BKV)                                                                 \
+  do {                                                                                   \
+    if (h->a.G == 1) XV_REPLAY(1, BKV); else if (h->a.G == 2) XV_REPLAY(2, BKV);          \
+    else if (h->a.G == 3) XV_REPLAY(3, BKV); else if (h->a.G == 4) XV_REPLAY(4, BKV);     \
+    else XV_REPLAY(5, BKV);                                                               \
+  } while (0)
+  if (bk == 1) {      // 7 cuts per line: G <= 3
+    if (h->a.G == 1) XV_REPLAY(1, 1); else if (h->a.G == 2) XV_REPLAY(2, 1); else XV_REPLAY(3, 1);
+  } else if (bk == 2) {
+    XV_REPLAY_G(2);
+  } else {
+    XV_REPLAY_G(0);
+  }
+#undef XV_REPLAY_G
+#undef XV_REPLAY
+  return hipGetLastError() == hipSuccess;
 }
 // streams 2 .. depth - 1 (xv_pipe_depth() > 2): each accepted beside the engine's stream by the same timed trial
 static bool anymdp_pipe_setup_deep(xv_anymdp* h, int depth) {
@@ -2132,6 +2216,7 @@ static int anymdp_pipe_graphs(xv_anymdp* h, int D, int period, int cycles, size_
   (void)hipStreamSynchronize(h->eng->stream);
   anymdp_pipe_drop_graphs(h);
   if (D > 2 && !anymdp_pipe_setup_deep(h, D)) return -1;
+  if (!xv_pipe_gate_sync(&h->gate)) return -1;      // (every stream of the handle has drained)
   for (int q = 0; q < D; ++q) {
     hipGraph_t* gr = q < 2 ? &h->pgraph[q] : &h->gate.graph_n[q - 2];
     hipGraphExec_t* ge = q < 2 ? &h->pgraph_exec[q] : &h->gate.exec_n[q - 2];
@@ -2156,7 +2241,13 @@ static int anymdp_pipe_graphs(xv_anymdp* h, int D, int period, int cycles, size_
 
 // the whole ring cycles of a call, overlapped; *issued = steps issued (0: the caller takes the ordinary path for all of it).
 // -> XV_OK, or an error when a cycle went out in part (the streams are joined either way)
-static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int period, int* issued, int depth = 2);
+// what the replay of an overlapped call needs (nullptr: the token path, whose expired hand-offs are flagged only)
+struct AnyMDPReplay {
+  AnyMDPStepIO io;      // ring slot 0
+  int ring_period, mode, eff;
+};
+static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int period, int* issued, int depth = 2,
+                              const AnyMDPReplay* rp = nullptr);
 
 static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride, const int32_t* actions, int32_t* obs,
                            float* reward, float* reward_gt, uint8_t* terminated, uint8_t* truncated, int32_t* final_obs,
@@ -2165,6 +2256,7 @@ static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride,
   const int cycles = n_steps / period;
   static const int min_steps = getenv("XV_ANYMDP_PIPE_MIN_STEPS") ? atoi(getenv("XV_ANYMDP_PIPE_MIN_STEPS")) : XV_ANYMDP_PIPE_GRAPH_MIN;
   if (cycles <= 0 || period % 2 != 0 || n_steps < min_steps) return XV_OK;
+  if (xv_pipe_backoff_step(&h->backoff, &h->gate)) return XV_OK;      // a recent call was replayed: one stream for a while
   // two or three launches resident at once, or the one-stream path (xv_pipe.h)
   int D = xv_pipe_choose_depth(anymdp_graph_step_fn(h, anymdp_effective_search(h), true), 256,
                                (size_t)xv_div_up(h->a.n_env, 256), h->eng->device);
@@ -2183,26 +2275,44 @@ static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride,
     return XV_OK;
   }
   if (U == 0) return XV_OK;      // too short for the graphs this handle holds: one stream
-  return anymdp_pipe_launch(h, h->pgraph_exec, cycles / U, period * U, issued, h->gate.depth);
+  const AnyMDPReplay rp{AnyMDPStepIO{actions, nullptr, nullptr, nullptr, obs, reward, reward_gt, terminated, truncated, final_obs, nullptr,
+                                     nullptr, 0.0f},
+                        period, mode, anymdp_effective_search(h)};
+  return anymdp_pipe_launch(h, h->pgraph_exec, cycles / U, period * U, issued, h->gate.depth, &rp);
 }
 
 static __global__ __launch_bounds__(256) void anymdp_pipe_open_kernel(uint2* sr, int n, uint32_t tag, uint64_t* tick_words, int n_words,
-                                                                      uint64_t tick_base) {
+                                                                      uint64_t tick_base, uint2* snap, uint32_t* snap_w, uint32_t* err,
+                                                                      int bad_tag_env, int repairable) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) sr[i].x = (sr[i].x & ((1u << XV_ANYMDP_SR_TAG_SHIFT) - 1u)) | (tag << XV_ANYMDP_SR_TAG_SHIFT);
+  if (i < n) {
+    uint2 r = sr[i];
+    r.x &= (1u << XV_ANYMDP_SR_TAG_SHIFT) - 1u;
+    snap[i] = r;      // what the replay restores should a hand-off of this call expire (anymdp_replay_kernel)
+    r.x |= (i == bad_tag_env ? ((tag + 77u) & 0x3FFFu) : tag) << XV_ANYMDP_SR_TAG_SHIFT;      // bad_tag_env: test hook, -1 otherwise
+    sr[i] = r;
+  }
   if (i < n_words) tick_words[i] = tick_base;
+  // the error word as it is at entry; the HANDOFF bit leaves the word for the time of the call (a wave that finds it set takes
+  // it for "this call has failed": xv_hand_aborted) and returns with the replay kernel
+  // (repairable = 0: the token path, which has no replay kernel — the word stays as it is and no wait looks at it)
+  if (i == 0 && repairable) { const uint32_t e = *err; snap_w[0] = e; snap_w[1] = 0u; snap_w[2] = 0u; *err = e & ~(uint32_t)XV_DEVERR_HANDOFF; }
 }
 
 // `cycles` replays of the cycle graphs ex[0] (engine's stream) / ex[1] (side stream) / the deep ones: tags and tick words, fork,
 // launches, join
-static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int period, int* issued, int depth) {
+static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int period, int* issued, int depth, const AnyMDPReplay* rp) {
   hipStream_t st = h->eng->stream;
+  const int test_bad_tag = getenv("XV_PIPE_TEST_BAD_TAG") ? atoi(getenv("XV_PIPE_TEST_BAD_TAG")) : 0;   // tests: env 0's tag is wrong
+  const int test_fail = getenv("XV_PIPE_TEST_FAIL") ? atoi(getenv("XV_PIPE_TEST_FAIL")) : 0;            // tests: see anymdp_test_fail_kernel
+  h->fell_seen = __atomic_load_n(h->gate.h_issued + 1, __ATOMIC_ACQUIRE);
   const int deep = depth > 2 ? depth - 2 : 0;      // streams beyond the engine's and `side`
   const uint64_t t0 = h->eng->tick;
   // one launch opens the call: every record gets the tag of the first step (whatever ran since the last overlapped call
   // wrote the tag bits as 0), the graphs' tick words the base their head nodes advance by `period` first
   hipLaunchKernelGGL(anymdp_pipe_open_kernel, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, st, h->a.sr, h->a.n_env,
-                     XV_ANYMDP_SR_TAG(t0), h->d_ptick, XV_PIPE_DEPTH_MAX, t0 - (uint64_t)period);
+                     XV_ANYMDP_SR_TAG(t0), h->d_ptick, XV_PIPE_DEPTH_MAX, t0 - (uint64_t)period, h->d_snap, h->d_snap_w,
+                     h->a.err, (rp && test_bad_tag) ? 0 : -1, rp ? 1 : 0);
   bool ok = hipGetLastError() == hipSuccess;
   // fork: the side stream starts behind what the engine's stream holds now (the caller's actions, a reset, the tags above)
   ok = ok && hipEventRecord(h->side_ev[0], st) == hipSuccess && hipStreamWaitEvent(h->side, h->side_ev[0], 0) == hipSuccess;
@@ -2221,8 +2331,10 @@ static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int 
     if (hipGraphLaunch(ex[0], st) != hipSuccess) break;
     xv_pipe_test_stall(c);
     if (hipGraphLaunch(ex[1], h->side) != hipSuccess) { broken = true; xv_pipe_gate_release(&h->gate); break; }
-    for (int i = 0; i < deep && !broken; ++i)
+    for (int i = 0; i < deep && !broken; ++i) {
+      if (i == 0) xv_pipe_test_stall(c, 1);
       if (hipGraphLaunch(h->gate.exec_n[i], h->gate.side_n[i]) != hipSuccess) broken = true;
+    }
     if (broken) { xv_pipe_gate_release(&h->gate); break; }
     xv_pipe_gate_release(&h->gate);
     k += period;
@@ -2238,6 +2350,19 @@ static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int 
     h->pipe_failed = true;
     xv_set_error("xv_anymdp_step_many: an overlapped ring cycle could be issued only in part; the envs' states are undefined");
     return XV_ERR_HIP;
+  }
+  if (rp && k > 0) {
+    // behind the join: should a hand-off of this call have expired, the call is replayed from its entry state on this
+    // stream (anymdp_replay_kernel: a nearly empty launch otherwise) — an expiry costs time, never results
+    if (test_fail) {
+      const size_t n_obs = (size_t)rp->ring_period * (size_t)h->a.n_env;
+      hipLaunchKernelGGL(anymdp_test_fail_kernel, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, st, h->a.sr, h->a.n_env, h->a.err,
+                         rp->io.obs, n_obs);
+    }
+    if (!anymdp_launch_replay(h, rp->eff, rp->io, rp->ring_period, k / rp->ring_period, rp->mode, t0)) {
+      (void)hipGetLastError();
+      h->pipe_failed = true;      // (this call's hand-offs are flagged as before; the next calls take the one-stream path)
+    }
   }
   if (k > 0) { h->ptick_value = h->eng->tick; h->ptick_valid = true; h->graph_used_last = true; h->pipe_used_last = true; }
   return XV_OK;
@@ -2266,6 +2391,7 @@ extern "C" int xv_anymdp_set_step_many_overlap(xv_anymdp* h, int on) {
     }
     g_overlap_owner[dev] = h;
     h->pipe_failed = false;
+    xv_pipe_backoff_reset(&h->backoff, &h->gate);
   } else if (g_overlap_owner[dev] == h) {
     g_overlap_owner[dev] = nullptr;
   }
@@ -2274,10 +2400,14 @@ extern "C" int xv_anymdp_set_step_many_overlap(xv_anymdp* h, int on) {
 }
 
 // 1: the last xv_anymdp_step_many overlapped its ring cycles, 0: it did not (off, odd period, per-lane search, device tick,
-// graph mode 0), -1: the overlapped path failed on this handle and is no longer tried
+// graph mode 0), -1: the overlapped path failed on this handle and is no longer tried, -2: the last call overlapped, a
+// hand-off expired and the call was replayed on one stream (results are right; meaningful once the stream has drained)
 extern "C" int xv_anymdp_step_many_overlap_state(xv_anymdp* h) {
   if (!h) return 0;
   if (h->pipe_failed) return -1;
+  if (h->overlap && h->pipe_used_last && h->gate.h_issued &&
+      __atomic_load_n(h->gate.h_issued + 1, __ATOMIC_ACQUIRE) != h->fell_seen)
+    return -2;
   return (h->overlap && h->pipe_used_last) ? 1 : 0;
 }
 
@@ -2804,6 +2934,7 @@ static int anymdp_tok_pipe_graphs(xv_anymdp* h, int D, int period, int cycles, c
   (void)hipStreamSynchronize(h->eng->stream);
   anymdp_pipe_drop_graphs(h);
   if (D > 2 && !anymdp_pipe_setup_deep(h, D)) return -1;
+  if (!xv_pipe_gate_sync(&h->gate)) return -1;
   void* fn = anymdp_tok_hand_fn(h);
   const size_t n = (size_t)h->a.n_env, da = (size_t)h->d_act, dob = (size_t)h->d_obs;
   const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);

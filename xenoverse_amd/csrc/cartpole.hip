@@ -75,7 +75,7 @@ __device__ __forceinline__ void cartpole_step_body(const CartPoleArgs& P, const 
   // step's tick — written by the same wave of the step before, after its state stores completed — and hands on likewise
   // (xv_hand.h).  The env's word in P.steps carries need_reset in bit 31 between HAND launches (mixed.hip packs / unpacks).
   if (HAND) {
-    if (!xv_hand_wait(P.hand + (i >> 6), (uint32_t)xv_launch_tick(P.tick, P.tick_dev))) err |= XV_DEVERR_HANDOFF;
+    if (!xv_hand_wait(P.hand + (i >> 6), (uint32_t)xv_launch_tick(P.tick, P.tick_dev), P.err)) err |= XV_DEVERR_HANDOFF;
     asm volatile("" ::: "memory");
     x = xv_agent_load_f64(P.state + i); xd = xv_agent_load_f64(P.state + N + i);
     th = xv_agent_load_f64(P.state + 2 * N + i); thd = xv_agent_load_f64(P.state + 3 * N + i);

@@ -105,6 +105,15 @@ static __global__ void xv_tick_add3_kernel(uint64_t* t0, uint64_t* t1, uint64_t*
   if (t1 != t0) *t1 += d1;
   if (t2 != t0 && t2 != t1) *t2 += d2;
 }
+// live RCCL communicators of this process per device (rccl_gather.hip counts them; xv_pipe.h reads the figure)
+static int g_device_collectives[64] = {0};
+void xv_device_note_collective(int device, int delta) {
+  if (device >= 0 && device < 64) __atomic_fetch_add(&g_device_collectives[device], delta, __ATOMIC_RELAXED);
+}
+int xv_device_collectives(int device) {
+  return (device >= 0 && device < 64) ? __atomic_load_n(&g_device_collectives[device], __ATOMIC_RELAXED) : 0;
+}
+
 void xv_engine_advance_device_tick3(xv_engine* e0, xv_engine* e1, xv_engine* e2, uint64_t d0, uint64_t d1, uint64_t d2) {
   hipLaunchKernelGGL(xv_tick_add3_kernel, dim3(1), dim3(1), 0, e0->stream, e0->d_tick, e1->d_tick, e2->d_tick, d0, d1, d2);
 }

@@ -1055,7 +1055,7 @@ __device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const L
   bool late = false;
   if (HAND) {
     fr.load(P, id.t, id.lane);
-    late = !xv_hand_wait(P.hand + id.wave, (uint32_t)xv_launch_tick(P.tick, P.tick_dev));
+    late = !xv_hand_wait(P.hand + id.wave, (uint32_t)xv_launch_tick(P.tick, P.tick_dev), P.err);
     asm volatile("" ::: "memory");
     sn0 = xv_agent_load32(P.sn + id.es);
 #pragma unroll
@@ -1111,6 +1111,44 @@ __device__ __forceinline__ void linds_step_mfma_body(const LinDSArgs& P, const L
       xq[m * 64] = make_float4(xs[m][0], xs[m][1], xs[m][2], xs[m][3]);
 #endif
     }
+    if (id.g == 0) P.sn[id.es] = (int32_t)((uint32_t)steps | (nr ? XV_LINDS_NR_BIT : 0u));
+    if (bad) atomicOr(P.err, (uint32_t)XV_DEVERR_NONFINITE);
+  }
+}
+
+// Replay of an overlapped call of the mixed batch whose hand-off expired (mixed.hip: mixed_replay_kernel): the tile starts from
+// the state the call's snapshot kept (x_snap, sn_snap), runs the call's n_steps steps with the state in registers as the fused
+// roll-out below does — step k reads ring slot k % period of the actions, writes that slot of every output and draws with tick
+// tick0 + k, in the call's auto-reset mode — and leaves the state where the one-stream loop would have left it.
+template <int NS, int NA, int NO>
+__device__ __forceinline__ void linds_replay_body(const LinDSArgs& P, const LinDSStepIO& io /* ring slot 0 */, int period, int n_steps,
+                                                  int mode, const float* x_snap, const int32_t* sn_snap, int bid) {
+  using F = LinDSFrag<NS, NA, NO>;
+  LinDSTileId id;
+  if (!linds_tile_id(P, id, bid)) return;
+  F fr;
+  fr.load(P, id.t, id.lane);
+  const float4* xs_q = reinterpret_cast<const float4*>(x_snap) + (size_t)id.wave * F::MT * 64 + id.lane;
+  float4* xq = reinterpret_cast<float4*>(P.x) + (size_t)id.wave * F::MT * 64 + id.lane;
+  xv_f32x4 xs[F::MT];
+#pragma unroll
+  for (int m = 0; m < F::MT; ++m) {
+    const float4 v = xs_q[m * 64];
+    xs[m] = xv_f32x4{v.x, v.y, v.z, v.w};
+  }
+  const uint32_t sn0 = (uint32_t)sn_snap[id.es];
+  int steps = (int)(sn0 & ~XV_LINDS_NR_BIT), nr = (int)(sn0 >> 31), bad = 0;
+  const size_t N = (size_t)P.n_env;
+  const uint64_t tick0 = xv_launch_tick(P.tick, P.tick_dev);
+  for (int k = 0; k < n_steps; ++k) {
+    const size_t ob = (size_t)(k % period) * N + id.e;
+    LinDSTileStep<NS, NA, NO, false>::run(P, fr, id.t, id.lane, id.e, id.valid, id.gid, tick0 + (uint64_t)k, mode, io.action + ob * NA,
+                                          nullptr, P.n_env, 0, ob, io.obs, io.cmd, io.final_obs, io.reward, io.error, io.terminated,
+                                          io.truncated, xs, steps, nr, bad);
+  }
+  if (id.valid) {
+#pragma unroll
+    for (int m = 0; m < F::MT; ++m) xq[m * 64] = make_float4(xs[m][0], xs[m][1], xs[m][2], xs[m][3]);
     if (id.g == 0) P.sn[id.es] = (int32_t)((uint32_t)steps | (nr ? XV_LINDS_NR_BIT : 0u));
     if (bad) atomicOr(P.err, (uint32_t)XV_DEVERR_NONFINITE);
   }

@@ -50,6 +50,116 @@ void mixed_step_kernel(AnyMDPArgs A, AnyMDPStepIO aio, int nbA, LinDSArgs L, Lin
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// An expired hand-off of an overlapped xv_mixed_step_many is REPAIRED, as for the AnyMDP step_many (anymdp.hip:
+// anymdp_replay_kernel).  mixed_pipe_snap_kernel keeps the three families' states and error words as they are at the call's
+// entry; behind the join (and the close kernel) mixed_replay_kernel runs on the engines' stream: no new HANDOFF bit in any of
+// the three words — every workgroup returns at once (one nearly empty launch per call); else every wave restores its envs /
+// its tile from the snapshot and replays the call's steps in one launch (AnyMDP and CartPole: the fused roll-out loops of
+// their step bodies, ring cycle by ring cycle; LinDS: linds_replay_body), same ticks, every ring slot rewritten, and the last
+// workgroup publishes error words = entry | what the replay raised and counts the replay in pinned host memory.
+struct MixedSnap {
+  const uint2* a_sr;
+  const float* l_x;
+  const int32_t* l_sn;
+  const double* c_state;
+  const int32_t* c_steps;
+  const uint8_t* c_nr;
+  uint32_t* w;            // [0..2] error words at entry (anymdp, linds, cartpole), [3..5] the replay's own bits, [6] workgroups finished
+  uint32_t* err[3];       // the engines' words
+  uint32_t* h_fell;       // pinned host memory: calls replayed
+};
+struct MixedSnapCopy {
+  void* dst;
+  const void* src;
+  size_t bytes;
+};
+struct MixedSnapList {
+  MixedSnapCopy e[6];
+  uint32_t* w;
+  uint32_t* err[3];
+};
+static __global__ __launch_bounds__(256) void mixed_pipe_snap_kernel(MixedSnapList L) {
+  const MixedSnapCopy c = L.e[blockIdx.y];
+  const size_t n16 = c.bytes / 16, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = i0; i < n16; i += stride) reinterpret_cast<uint4*>(c.dst)[i] = reinterpret_cast<const uint4*>(c.src)[i];
+  for (size_t b = n16 * 16 + i0; b < c.bytes; b += stride) reinterpret_cast<uint8_t*>(c.dst)[b] = reinterpret_cast<const uint8_t*>(c.src)[b];
+  // the error words as they are at entry; the HANDOFF bit leaves them for the time of the call (xv_hand_aborted) and returns
+  // with the replay kernel
+  if (blockIdx.y == 0 && i0 < 7) {
+    uint32_t e = 0u;
+    if (i0 < 3) { e = *L.err[i0]; *L.err[i0] = e & ~(uint32_t)XV_DEVERR_HANDOFF; }
+    L.w[i0] = e;
+  }
+}
+template <int AG, int ABK, int LNS, int LNO>
+__global__ __launch_bounds__(256) void mixed_replay_kernel(AnyMDPArgs A, AnyMDPStepIO aio, int nbA, LinDSArgs L, LinDSStepIO lio, int nbL,
+                                                           CartPoleArgs C, CartPoleIO cio, int period, int cycles, int mode, MixedSnap S) {
+  uint32_t fresh = 0;      // (the snapshot kernel took the bit out of the words: set = raised by this call)
+#pragma unroll
+  for (int f = 0; f < 3; ++f) fresh |= __hip_atomic_load(S.err[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((fresh & XV_DEVERR_HANDOFF) == 0u) {
+    if (blockIdx.x == 0 && threadIdx.x < 3 && (S.w[threadIdx.x] & XV_DEVERR_HANDOFF)) atomicOr(S.err[threadIdx.x], (uint32_t)XV_DEVERR_HANDOFF);
+    return;
+  }
+  const int b = (int)blockIdx.x;
+  if (b < nbL) {
+    LinDSArgs Q = L;
+    Q.err = S.w + 4; Q.tick_dev = nullptr;
+    linds_replay_body<LNS, 8, LNO>(Q, lio, period, cycles * period, mode, S.l_x, S.l_sn, b);
+  } else if (b < nbL + nbA) {
+    const int bid = b - nbL, i = bid * (int)blockDim.x + (int)threadIdx.x;
+    if (i < A.n_env) A.sr[i] = S.a_sr[i];
+    __syncthreads();      // (an invalid lane looks at the last env's record: restored by a lane of this workgroup)
+    AnyMDPArgs Q = A;
+    Q.err = S.w + 3; Q.tick_dev = nullptr;
+    for (int c = 0; c < cycles; ++c) {
+      Q.tick = A.tick + (uint64_t)c * (uint64_t)period;
+      anymdp_step_body<false, AG, true, false, ABK, false>(Q, aio, period, mode, bid);
+    }
+  } else {
+    const int bid = b - nbA - nbL, i = bid * (int)blockDim.x + (int)threadIdx.x;
+    if (i < C.n_env) {
+      const size_t N = (size_t)C.n_env;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) C.state[q * N + i] = S.c_state[q * N + i];
+      C.steps[i] = S.c_steps[i];
+      C.need_reset[i] = S.c_nr[i];
+    }
+    CartPoleArgs Q = C;
+    Q.err = S.w + 5; Q.tick_dev = nullptr;
+    for (int c = 0; c < cycles; ++c) {
+      Q.tick = C.tick + (uint64_t)c * (uint64_t)period;
+      cartpole_step_body<false, false>(Q, cio, mode, period, bid);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(S.w + 6, 1u) == gridDim.x - 1u) {
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        const uint32_t re = __hip_atomic_load(S.w + 3 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(S.err[f], S.w[f] | re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        S.w[3 + f] = 0u;
+      }
+      S.w[6] = 0u;
+      __hip_atomic_fetch_add(S.h_fell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+// test hook (XV_PIPE_TEST_FAIL=1): what an expired hand-off leaves behind — the flag, wrong states, wrong ring contents
+static __global__ __launch_bounds__(256) void mixed_test_fail_kernel(uint2* sr, int n_a, float* l_x, size_t n_x, double* c_state, int n_c,
+                                                                     uint32_t* err_l, float* l_obs, size_t n_lobs, int32_t* a_obs, size_t n_aobs) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  if (i < (size_t)n_a) sr[i] = make_uint2((uint32_t)(i % 3u), 5u);
+  for (size_t k = i; k < n_x; k += stride) l_x[k] = 0.25f;
+  if (i < (size_t)n_c) c_state[i] = 0.125;
+  for (size_t k = i; k < n_lobs; k += stride) l_obs[k] = -7.0f;
+  for (size_t k = i; k < n_aobs; k += stride) a_obs[k] = -7;
+  if (i == 0) atomicOr(err_l, (uint32_t)(XV_DEVERR_HANDOFF | XV_DEVERR_NONFINITE));
+}
+
 // which instantiation serves these handles (-1: none — the caller falls back to three launches)
 static int mixed_variant(const xv_anymdp* a, const xv_linds* l) {
   const int eff = anymdp_effective_search(a);
@@ -169,6 +279,12 @@ struct MixedPipe {
   hipStream_t side_for;  // the engines' stream the side stream was chosen against
   XvPipeGate gate;       // the even half of a cycle starts once the host has enqueued both halves (xv_pipe.h)
   const xv_anymdp* used_by;
+  // the states at the entry of the last overlapped call (restored by mixed_replay_kernel should a hand-off expire)
+  uint8_t* d_snap;
+  size_t snap_cap;
+  uint32_t* d_snap_w;    // 8 words, see MixedSnap::w
+  uint32_t fell_seen;    // gate.h_issued[1] when the last overlapped call was issued
+  XvPipeBackoff backoff; // one-stream calls after a replayed one (xv_pipe.h)
 };
 // one per device, for the life of the process (side stream, events, tick and hand-off words, the cached graph set: a few
 // kilobytes; not released at exit — the HIP runtime may be gone by the time static destructors run)
@@ -233,6 +349,10 @@ static bool mixed_pipe_setup(MixedPipe& M, hipStream_t st, size_t n_hand, int de
   }
   if (!M.d_tick && hipMalloc(&M.d_tick, 12 * sizeof(uint64_t)) != hipSuccess) return false;
   if (!M.gate.d_seen && !xv_pipe_gate_create(&M.gate)) return false;
+  if (!M.d_snap_w) {
+    if (hipMalloc(&M.d_snap_w, 8 * sizeof(uint32_t)) != hipSuccess) { M.d_snap_w = nullptr; return false; }
+    if (hipMemsetAsync(M.d_snap_w, 0, 8 * sizeof(uint32_t), st) != hipSuccess) return false;
+  }
   if (M.hand_cap < n_hand) {
     (void)hipStreamSynchronize(M.side);
     if (M.side2) (void)hipStreamSynchronize(M.side2);
@@ -256,6 +376,13 @@ static void mixed_io_slot(const xv_mixed_io* ring, size_t s, size_t na, size_t n
   io.c_action += s * nc; io.c_obs += s * nc * 4; io.c_reward += s * nc; io.c_terminated += s * nc; io.c_truncated += s * nc;
   if (io.c_final_obs) io.c_final_obs += s * nc * 4;
   *out = io;
+}
+
+template <int AG, int ABK, int LNS>
+static void mixed_launch_replay_v(dim3 grid, hipStream_t st, const AnyMDPArgs& A, const AnyMDPStepIO& aio, int nbA, const LinDSArgs& L,
+                                  const LinDSStepIO& lio, int nbL, const CartPoleArgs& C, const CartPoleIO& cio, int period, int cycles,
+                                  int mode, const MixedSnap& S) {
+  hipLaunchKernelGGL((mixed_replay_kernel<AG, ABK, LNS, 16>), grid, dim3(256), 0, st, A, aio, nbA, L, lio, nbL, C, cio, period, cycles, mode, S);
 }
 
 static void* mixed_hand_fn(int v) {
@@ -285,6 +412,7 @@ static int mixed_pipe_graphs(MixedPipe& M, xv_anymdp* a, xv_linds* l, xv_cartpol
   if (M.side2) (void)hipStreamSynchronize(M.side2);
   (void)hipStreamSynchronize(a->eng->stream);
   mixed_pipe_drop_graphs(M);
+  if (!xv_pipe_gate_sync(&M.gate)) return -1;
   const size_t na = (size_t)a->a.n_env, nl = (size_t)l->a.n_env, nc = (size_t)c->a.n_env;
   int nbA = xv_div_up(a->a.n_env, 256), nbL = xv_div_up(xv_div_up(l->a.n_slot, 16), 4), nbC = xv_div_up(c->a.n_env, 256);
   void* fn = mixed_hand_fn(v);
@@ -294,7 +422,7 @@ static int mixed_pipe_graphs(MixedPipe& M, xv_anymdp* a, xv_linds* l, xv_cartpol
     {
       uint64_t* w = M.d_tick + q;
       uint64_t dv = (uint64_t)period * (uint64_t)U;
-      uint32_t* seen = q == 0 ? M.gate.d_seen : nullptr;
+      uint32_t* seen = M.gate.d_seen + q;      // every stream's graph starts with the cycle gate (xv_pipe.h)
       const uint32_t* issued = M.gate.d_issued;
       uint32_t* err = a->a.err;
       void* hparams[5] = {&w, &dv, &seen, &issued, &err};
@@ -345,6 +473,7 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
   static const int min_steps = getenv("XV_MIXED_PIPE_MIN_STEPS") ? atoi(getenv("XV_MIXED_PIPE_MIN_STEPS")) : XV_MIXED_PIPE_MIN;
   if (ring_cycles <= 0 || period % 2 != 0 || n_steps < min_steps) return XV_OK;
   if (M.failed && M.side_for == a->eng->stream) return XV_OK;      // tried beside this stream already
+  if (xv_pipe_backoff_step(&M.backoff, &M.gate)) return XV_OK;      // a recent call was replayed: the ordinary loop for a while
   M.failed = false;
   if (a->eng == l->eng || a->eng == c->eng || l->eng == c->eng) return XV_OK;      // one tick per family and step
   if (a->eng->dev_tick || l->eng->dev_tick || c->eng->dev_tick) return XV_OK;
@@ -376,6 +505,32 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
   if (U == 0) return XV_OK;      // too short for the graphs held: the ordinary loop
   const int per_launch = U * period, cycles = ring_cycles / U;      // launches of the two cycle graphs (U ring cycles each)
   const uint64_t ta = a->eng->tick, tl = l->eng->tick, tc = c->eng->tick;
+  // the entry state of the call, kept for the replay (mixed_replay_kernel): env records, LinDS tiles, CartPole states, error words
+  const int test_fail = getenv("XV_PIPE_TEST_FAIL") ? atoi(getenv("XV_PIPE_TEST_FAIL")) : 0;
+  const size_t n_tile = ((size_t)l->a.n_slot + 15) / 16;
+  const size_t snap_bytes[6] = {(size_t)a->a.n_env * sizeof(uint2), sizeof(float) * n_tile * (size_t)(l->a.NS / 16) * 256,
+                                sizeof(int32_t) * n_tile * 16, sizeof(double) * 4 * (size_t)c->a.n_env,
+                                sizeof(int32_t) * (size_t)c->a.n_env, (size_t)c->a.n_env};
+  size_t snap_off[6], snap_total = 0;
+  for (int i = 0; i < 6; ++i) { snap_off[i] = snap_total; snap_total += (snap_bytes[i] + 255) / 256 * 256; }
+  bool snap_ok = true;
+  if (M.snap_cap < snap_total) {
+    (void)hipStreamSynchronize(st);
+    if (M.d_snap) (void)hipFree(M.d_snap);
+    M.d_snap = nullptr; M.snap_cap = 0;
+    if (hipMalloc(&M.d_snap, snap_total) == hipSuccess) M.snap_cap = snap_total;
+    else { (void)hipGetLastError(); M.d_snap = nullptr; snap_ok = false; }
+  }
+  if (snap_ok) {
+    MixedSnapList SL;
+    const void* srcs[6] = {a->a.sr, l->a.x, l->a.sn, c->a.state, c->a.steps, c->a.need_reset};
+    for (int i = 0; i < 6; ++i) SL.e[i] = MixedSnapCopy{M.d_snap + snap_off[i], srcs[i], snap_bytes[i]};
+    SL.w = M.d_snap_w; SL.err[0] = a->a.err; SL.err[1] = l->a.err; SL.err[2] = c->a.err;
+    hipLaunchKernelGGL(mixed_pipe_snap_kernel, dim3(64, 6), dim3(256), 0, st, SL);
+    snap_ok = hipGetLastError() == hipSuccess;
+  }
+  if (!snap_ok) { (void)hipGetLastError(); M.failed = true; return XV_OK; }      // no repair possible: the ordinary loop
+  M.fell_seen = __atomic_load_n(M.gate.h_issued + 1, __ATOMIC_ACQUIRE);
   const int n_open = std::max(std::max(a->a.n_env, c->a.n_env), std::max(n_lw, 12));
   hipLaunchKernelGGL(mixed_pipe_open_kernel, dim3(xv_div_up(n_open, 256)), dim3(256), 0, st, a->a.sr, a->a.n_env, XV_ANYMDP_SR_TAG(ta),
                      M.d_hand, n_lw, (uint32_t)tl, M.d_hand + n_lw, n_cw, (uint32_t)tc, c->a.steps, c->a.need_reset, c->a.n_env,
@@ -391,6 +546,7 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
       if (hipGraphLaunch(M.exec[0], st) != hipSuccess) break;
       xv_pipe_test_stall(cy);
       if (hipGraphLaunch(M.exec[1], M.side) != hipSuccess) { broken = true; xv_pipe_gate_release(&M.gate); break; }
+      if (D == 3) xv_pipe_test_stall(cy, 1);
       if (D == 3 && hipGraphLaunch(M.exec[2], M.side2) != hipSuccess) { broken = true; xv_pipe_gate_release(&M.gate); break; }
       xv_pipe_gate_release(&M.gate);
       k += per_launch;
@@ -400,7 +556,40 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
   const bool joined = hipEventRecord(M.ev[1], M.side) == hipSuccess && hipStreamWaitEvent(st, M.ev[1], 0) == hipSuccess &&
                       (D < 3 || (hipEventRecord(M.ev2, M.side2) == hipSuccess && hipStreamWaitEvent(st, M.ev2, 0) == hipSuccess));
   hipLaunchKernelGGL(mixed_pipe_close_kernel, dim3(xv_div_up(c->a.n_env, 256)), dim3(256), 0, st, c->a.steps, c->a.need_reset, c->a.n_env);
-  const bool closed = hipGetLastError() == hipSuccess;
+  bool closed = hipGetLastError() == hipSuccess;
+  if (closed && joined && !broken && k > 0) {
+    // should a hand-off of this call have expired: the call is replayed from its entry state on this stream (a nearly
+    // empty launch otherwise) — an expiry costs time, never results
+    const size_t LA = (size_t)l->a.NA, LO = (size_t)l->a.NO;
+    if (test_fail)
+      hipLaunchKernelGGL(mixed_test_fail_kernel, dim3(256), dim3(256), 0, st, a->a.sr, a->a.n_env, l->a.x, snap_bytes[1] / sizeof(float),
+                         c->a.state, c->a.n_env, l->a.err, ring->l_obs, (size_t)period * (size_t)l->a.n_env * LO, ring->a_obs,
+                         (size_t)period * (size_t)a->a.n_env);
+    AnyMDPArgs A = a->a; LinDSArgs L = l->a; CartPoleArgs C = c->a;
+    A.seed = a->eng->seed; A.gid_base = a->eng->env_id_base; A.tick = ta; A.tick_dev = nullptr;
+    L.seed = l->eng->seed; L.gid_base = l->eng->env_id_base; L.tick = tl; L.tick_dev = nullptr;
+    C.seed = c->eng->seed; C.gid_base = c->eng->env_id_base; C.tick = tc; C.tick_dev = nullptr;
+    (void)LA;
+    AnyMDPStepIO aio{ring->a_action, nullptr, nullptr, nullptr, ring->a_obs, ring->a_reward, ring->a_reward_gt, ring->a_terminated,
+                     ring->a_truncated, ring->a_final_obs, nullptr, nullptr, 0.0f};
+    LinDSStepIO lio{ring->l_action, nullptr, nullptr, ring->l_obs, ring->l_reward, ring->l_terminated, ring->l_truncated, ring->l_cmd,
+                    ring->l_error, ring->l_final_obs};
+    CartPoleIO cio{ring->c_action, nullptr, ring->c_obs, ring->c_reward, ring->c_terminated, ring->c_truncated, ring->c_final_obs};
+    MixedSnap S;
+    S.a_sr = reinterpret_cast<const uint2*>(M.d_snap + snap_off[0]); S.l_x = reinterpret_cast<const float*>(M.d_snap + snap_off[1]);
+    S.l_sn = reinterpret_cast<const int32_t*>(M.d_snap + snap_off[2]); S.c_state = reinterpret_cast<const double*>(M.d_snap + snap_off[3]);
+    S.c_steps = reinterpret_cast<const int32_t*>(M.d_snap + snap_off[4]); S.c_nr = M.d_snap + snap_off[5];
+    S.w = M.d_snap_w; S.err[0] = a->a.err; S.err[1] = l->a.err; S.err[2] = c->a.err; S.h_fell = M.gate.d_issued + 1;
+    const int nbA = xv_div_up(a->a.n_env, 256), nbL = xv_div_up(xv_div_up(l->a.n_slot, 16), 4), nbC = xv_div_up(c->a.n_env, 256);
+    const dim3 grid(nbA + nbL + nbC);
+    switch (v) {
+      case 0: mixed_launch_replay_v<1, 0, 16>(grid, st, A, aio, nbA, L, lio, nbL, C, cio, period, k / period, mode, S); break;
+      case 1: mixed_launch_replay_v<1, 0, 32>(grid, st, A, aio, nbA, L, lio, nbL, C, cio, period, k / period, mode, S); break;
+      case 2: mixed_launch_replay_v<1, 1, 16>(grid, st, A, aio, nbA, L, lio, nbL, C, cio, period, k / period, mode, S); break;
+      default: mixed_launch_replay_v<1, 1, 32>(grid, st, A, aio, nbA, L, lio, nbL, C, cio, period, k / period, mode, S); break;
+    }
+    closed = hipGetLastError() == hipSuccess;
+  }
   *issued = k;
   if (!ok || k < cycles * per_launch) { (void)hipGetLastError(); M.failed = true; }
   if (broken || !joined || !closed) {
@@ -414,7 +603,8 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
 }
 
 // 1: the last xv_mixed_step_many with this AnyMDP handle overlapped its ring cycles, 0: it did not, -1: the overlapped path
-// failed on this device (no concurrent streams, graph build) and is no longer tried
+// failed on this device (no concurrent streams, graph build) and is no longer tried, -2: the last call overlapped, a hand-off
+// expired and the call was replayed on one stream (results are right; meaningful once the stream has drained)
 extern "C" int xv_mixed_step_many_overlap_state(xv_anymdp* a) {
   if (!a) return 0;
   const int dev = a->eng->device;
@@ -422,6 +612,7 @@ extern "C" int xv_mixed_step_many_overlap_state(xv_anymdp* a) {
   std::lock_guard<std::mutex> lock(g_mixed_mu);
   const MixedPipe& M = g_mixed_pipe[dev];
   if (M.failed) return -1;
+  if (M.used_by == a && M.used_last && M.gate.h_issued && __atomic_load_n(M.gate.h_issued + 1, __ATOMIC_ACQUIRE) != M.fell_seen) return -2;
   return (M.used_by == a && M.used_last) ? 1 : 0;
 }
 

@@ -62,6 +62,11 @@ int rccl_missing(const char* fn) {
   return XV_ERR_UNSUPPORTED;
 }
 
+// communicators made here, with their device: the overlapped step_many paths keep at most two launches in flight on a device
+// that also runs RCCL's persistent kernels (xv_pipe.h: xv_device_collectives)
+std::mutex g_comm_mu;
+struct { void* comm; int device; } g_comms[64];
+
 }  // namespace
 
 #define XV_RCCL(call)                                                                        \
@@ -91,12 +96,22 @@ extern "C" int xv_rccl_comm_create(xv_engine* e, int world, int rank, const void
   ncclComm_t c = nullptr;
   XV_RCCL(rccl().CommInitRank(&c, world, id, rank));
   *comm_out = c;
+  {
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    for (auto& slot : g_comms)
+      if (slot.comm == nullptr) { slot.comm = c; slot.device = e->device; xv_device_note_collective(e->device, +1); break; }
+  }
   return XV_OK;
 }
 
 extern "C" int xv_rccl_comm_destroy(void* comm) {
   if (!comm) return XV_OK;
   if (!rccl().ok) return rccl_missing(__func__);
+  {
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    for (auto& slot : g_comms)
+      if (slot.comm == comm) { slot.comm = nullptr; xv_device_note_collective(slot.device, -1); break; }
+  }
   XV_RCCL(rccl().CommDestroy(static_cast<ncclComm_t>(comm)));
   return XV_OK;
 }

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <thread>
 
+#include "xv_common.h"
 #include "xv_hand.h"
 
 #define XV_PIPE_PING_STEPS 128
@@ -144,13 +145,17 @@ static bool xv_pipe_pick_side_stream(hipStream_t main, hipStream_t* out, XvPipeC
 // with a one-thread GATE node: gate number g (counted in device memory) passes once the host has published
 // `issued >= g`, which it does, in pinned host memory, after BOTH launches of that cycle have been enqueued.  A held-up
 // host then just delays the device.  The gate's own wait is bounded too (polls and 10 s, as xv_hand.h; then flagged).
+// EVERY graph of a set starts with such a gate (its own counter d_seen[q], the same `issued`): with three streams a host
+// held up between the second and the third launch would otherwise leave the second graph's waves resident and spinning
+// (2-s bound) on a first graph that is still gated (10-s bound).  No wave of a set becomes resident before the whole set
+// is enqueued.
 #define XV_PIPE_GATE_TIMEOUT 1000000000ull   // 10 s of the 100-MHz wall clock ...
 #define XV_PIPE_GATE_MIN_POLLS (1u << 20)     // ... and this many reads of the host's word (~2 us each): the wave's own waiting
 
 struct XvPipeGate {
-  uint32_t* h_issued;   // pinned, mapped host word
-  uint32_t* d_issued;   // the device's view of it
-  uint32_t* d_seen;     // gates passed so far (device memory)
+  uint32_t* h_issued;   // pinned, mapped host words: [0] graph sets enqueued, [1] overlapped calls replayed after an expired hand-off
+  uint32_t* d_issued;   // the device's view of them
+  uint32_t* d_seen;     // [XV_PIPE_DEPTH_MAX] gates passed so far by the graphs of each stream (device memory)
   uint32_t issued;      // host mirror
   int unroll[2];        // ring cycles per cycle graph of the graph pairs built on this gate (0: none built); see below
   // streams 2 and 3 of the overlapped MDP step_many (depth 3 / 4: steps k .. k + 3 in flight), see xv_pipe_depth()
@@ -172,6 +177,7 @@ __device__ __forceinline__ void xv_pipe_gate_pass(uint32_t* seen, const uint32_t
       atomicOr(err, 8u /* XV_DEVERR_HANDOFF */);
       break;
     }
+    if ((polls & 63u) == 63u && (xv_agent_load32(err) & 8u)) break;      // the call has failed elsewhere: it will be replayed
     __builtin_amdgcn_s_sleep(16);
   }
 }
@@ -181,10 +187,16 @@ static bool xv_pipe_gate_create(XvPipeGate* g) {
   for (int i = 0; i < 2; ++i) { g->side_n[i] = nullptr; g->ev_n[i] = nullptr; g->graph_n[i] = nullptr; g->exec_n[i] = nullptr; }
   g->side_n_for = nullptr; g->depth = 0;
   if (hipHostMalloc(reinterpret_cast<void**>(&g->h_issued), 64, hipHostMallocMapped) != hipSuccess) { g->h_issued = nullptr; return false; }
-  *g->h_issued = 0u;
+  for (int i = 0; i < 16; ++i) g->h_issued[i] = 0u;
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&g->d_issued), g->h_issued, 0) != hipSuccess) return false;
-  if (hipMalloc(&g->d_seen, sizeof(uint32_t)) != hipSuccess) { g->d_seen = nullptr; return false; }
-  return hipMemset(g->d_seen, 0, sizeof(uint32_t)) == hipSuccess;
+  if (hipMalloc(&g->d_seen, 4 /* XV_PIPE_DEPTH_MAX */ * sizeof(uint32_t)) != hipSuccess) { g->d_seen = nullptr; return false; }
+  return hipMemset(g->d_seen, 0, 4 * sizeof(uint32_t)) == hipSuccess;
+}
+// when a graph set is (re)built — every stream of the handle drained: all gate counters start from what the host has issued
+// (a stream that sat out some sets, e.g. the third one while two steps were in flight, would otherwise pass its next gates early)
+static bool xv_pipe_gate_sync(XvPipeGate* g) {
+  const uint32_t v[4] = {g->issued, g->issued, g->issued, g->issued};
+  return hipMemcpy(g->d_seen, v, sizeof(v), hipMemcpyHostToDevice) == hipSuccess;
 }
 static void xv_pipe_gate_destroy(XvPipeGate* g) {
   if (g->d_seen) (void)hipFree(g->d_seen);
@@ -197,11 +209,14 @@ static inline void xv_pipe_gate_release(XvPipeGate* g) {
   __atomic_store_n(g->h_issued, g->issued, __ATOMIC_RELEASE);
 }
 
-// test hook (tests/test_gpu_chains.py): XV_PIPE_TEST_STALL_MS=<ms> holds the host up between the two launches of the
-// first graph pair of every overlapped call — longer than the hand-off bound, the cycle gate must make that harmless
-static inline void xv_pipe_test_stall(int cycle) {
+// test hook (tests/test_gpu_chains.py): XV_PIPE_TEST_STALL_MS=<ms> holds the host up between two launches of the first
+// graph set of every overlapped call — longer than the hand-off bound, the cycle gates must make that harmless.
+// XV_PIPE_TEST_STALL_AT = 0 (default): between the first and the second graph; 1: between the second and the third.
+static inline void xv_pipe_test_stall(int cycle, int at = 0) {
   if (cycle != 0) return;
   const char* v = getenv("XV_PIPE_TEST_STALL_MS");
+  const char* w = getenv("XV_PIPE_TEST_STALL_AT");
+  if ((w ? atoi(w) : 0) != at) return;
   if (v && atoi(v) > 0) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(v)));
 }
 
@@ -209,6 +224,15 @@ static inline void xv_pipe_test_stall(int cycle) {
 // same workgroup of step k has run; if step k still has workgroups waiting for a slot while step k + 1's spinners hold them
 // all (the side stream may be served first), nobody moves until the bounded waits expire.  With 2 x grid <= what the device
 // holds of this kernel that cannot happen: every workgroup of step k gets its slot without waiting for one of step k + 1.
+// The occupancy figure is what an EMPTY device holds.  Another resident kernel of the process (a policy network on another
+// stream, RCCL's all-gather kernels) takes slots, so a quarter of the device is left out of the sum: n x grid <= 3/4 of the
+// slots (XV_PIPE_RESIDENCY_NUM / _DEN).  A neighbour that is finite only delays the hand-offs — its workgroups end and the
+// launches in flight (at most depth x grid of them are ever dispatchable: launch k + depth sits behind launch k on its stream)
+// get their slots; a wait that expires all the same is repaired by the replay (anymdp.hip, mixed.hip), never left in the
+// results.  While the process holds an RCCL communicator on the device (xv_device_note_collective: persistent kernels that spin
+// on peers) at most two launches are in flight.
+#define XV_PIPE_RESIDENCY_NUM 3
+#define XV_PIPE_RESIDENCY_DEN 4
 static bool xv_pipe_two_launches_fit(const void* fn, int block_threads, size_t grid_blocks, int device, int n_launches = 2) {
   int per_cu = 0, cus = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block_threads, 0) != hipSuccess ||
@@ -216,7 +240,38 @@ static bool xv_pipe_two_launches_fit(const void* fn, int block_threads, size_t g
     (void)hipGetLastError();
     return false;
   }
-  return (size_t)n_launches * grid_blocks <= (size_t)per_cu * (size_t)cus;
+  if (n_launches > 2 && xv_device_collectives(device) > 0) return false;
+  return (size_t)n_launches * grid_blocks * XV_PIPE_RESIDENCY_DEN <= (size_t)per_cu * (size_t)cus * XV_PIPE_RESIDENCY_NUM;
+}
+
+// Back-off after a replayed call.  An expired hand-off costs its bound plus the replay — correct, but a hundred times a call's
+// normal time — and what made it expire (a neighbour's kernels, two of the call's streams sharing a hardware queue for a
+// while) tends to last.  The host sees the replay counter (pinned memory, no synchronisation) at the entry of a later call:
+// the next `len` calls take the one-stream path, and `len` doubles with every further replay (32 .. 4,096 calls; switching
+// the overlap on again starts over).
+struct XvPipeBackoff {
+  uint32_t fell_known;   // replays the host has accounted for
+  int left;              // calls still to issue on one stream
+  int len;               // length of the next back-off
+};
+static inline void xv_pipe_backoff_reset(XvPipeBackoff* b, const XvPipeGate* g) {
+  b->fell_known = g->h_issued ? __atomic_load_n(g->h_issued + 1, __ATOMIC_ACQUIRE) : 0u;
+  b->left = 0; b->len = 32;
+}
+// -> true: this call takes the one-stream path
+static inline bool xv_pipe_backoff_step(XvPipeBackoff* b, const XvPipeGate* g) {
+  if (getenv("XV_PIPE_NO_BACKOFF")) return false;      // tests: every call of a failing series is overlapped and replayed
+  if (g->h_issued) {
+    const uint32_t fell = __atomic_load_n(g->h_issued + 1, __ATOMIC_ACQUIRE);
+    if (fell != b->fell_known) {
+      b->fell_known = fell;
+      if (b->len < 32) b->len = 32;
+      b->left = b->len;
+      b->len = b->len >= 2048 ? 4096 : 2 * b->len;
+    }
+  }
+  if (b->left > 0) { --b->left; return true; }
+  return false;
 }
 
 // Ring cycles per cycle graph.  Every cycle graph starts with a head node (tick word; on the even stream the cycle gate: a

@@ -214,7 +214,9 @@ def _rendezvous_store(rank, world, store, host, port, timeout_s):
     2. the default process group's store (torch.distributed is initialised: bench.py, trainers);
     3. the launcher's own store (torchrun / torch.distributed.run hosts a TCPStore at MASTER_ADDR:MASTER_PORT for its
        workers, TORCHELASTIC_USE_AGENT_STORE=True): joined as a client;
-    4. none of these: rank 0 hosts a TCPStore at `port` (default MASTER_PORT — nobody else is serving it in that case).
+    4. none of these: rank 0 hosts a TCPStore at `port` (default MASTER_PORT — nobody else is serving it in that case) and
+       keeps it for the life of the communicator: a process that also wants `dist.init_process_group(env://)` on the same
+       port must call it FIRST (case 2 then applies) — documented in INTEGRATION.md §4.
     No second port is taken (earlier rounds opened MASTER_PORT + 1, which another job on the node may own)."""
     import datetime
     import os
@@ -251,7 +253,9 @@ class RcclComm(object):
         ident = C.create_string_buffer(128)
         if self.world > 1:
             st = _rendezvous_store(self.rank, self.world, store, host, port, timeout_s)
-            key = "id_%d" % _RCCL_COMM_SEQ[0]
+            # the restart attempt is part of the key: after an elastic restart the agent's store still holds the previous
+            # attempt's ids, and a rank must never pick one of those up before rank 0 has written the new one
+            key = "id_%s_%d" % (os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), _RCCL_COMM_SEQ[0])
             _RCCL_COMM_SEQ[0] += 1
             if self.rank == 0:
                 _lib.check(self.lib.xv_rccl_unique_id(ident))

@@ -142,7 +142,8 @@ class MixedShare(object):
 
     @property
     def overlap_state(self):
-        """1: the last step_many overlapped its ring cycles, 0: it did not, -1: the overlapped path failed on this device"""
+        """1: the last step_many overlapped its ring cycles, 0: it did not, -1: the overlapped path failed on this device,
+        -2: it overlapped, a hand-off expired and the call was replayed on one stream (results are right)"""
         return int(self.ea.lib.xv_mixed_step_many_overlap_state(self.ea._h))
 
     def rings_for_pack(self):
