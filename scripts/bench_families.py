@@ -72,6 +72,8 @@ def bench_linds(args, paths=("mfma", "scalar"), rollout=True):
         env = LinDSVecEnv(n, autoreset_mode="same_step", seed=1)
         env.set_task(tasks)
         env.set_path(path)
+        if os.environ.get("XV_LINDS_AB_CMD_TABLE_OFF"):      # A/B (scripts/runs_r06/gpu_e.sh): commands evaluated, not looked up
+            env.set_command_table(False)
         env.reset()
         a = torch.rand((n, 8), device=env.device) * 2 - 1
         from xenoverse_amd import _lib

@@ -389,9 +389,27 @@ __device__ __forceinline__ int linds_draw_init(const LinDSArgs& P, uint64_t gid,
 // Returns the xor of the call's four words: for g = 0 this is the env's RESTART word of the step — an env that finishes
 // in this call draws its initial state with it (linds_init_from_word), so the auto-reset costs no Philox call of its own
 // (the noise it is derived from belongs to the episode that has just ended).
+// (XV_LINDS_AB_NOISE: measurement builds only, scripts/runs_r06/gpu_e.sh — 1: no Philox call and no Box-Muller, zeros; 2: the
+//  Philox call but no Box-Muller, the normals replaced by scaled integer bits.  Never defined in the product build.)
 template <int MT>
 __device__ __forceinline__ uint32_t linds_noise_group(const LinDSArgs& P, uint64_t gid, uint64_t tick, int g, float (&z)[MT][4]) {
+#if defined(XV_LINDS_AB_NOISE) && XV_LINDS_AB_NOISE == 1
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z[m][r] = 0.0f;
+  return (uint32_t)gid * 2654435761u ^ (uint32_t)tick * 40503u ^ (uint32_t)g;
+#endif
   const xv_u32x4 w = xv_env_draw(P.seed, gid, tick, XV_DRAW_NOISE + (uint32_t)g);
+#if defined(XV_LINDS_AB_NOISE) && XV_LINDS_AB_NOISE == 2
+  z[0][0] = (float)(int)(w.x & 0xFFFFu) * 1.0e-5f; z[0][1] = (float)(int)(w.x >> 16) * 1.0e-5f;
+  z[0][2] = (float)(int)(w.y & 0xFFFFu) * 1.0e-5f; z[0][3] = (float)(int)(w.y >> 16) * 1.0e-5f;
+  if (MT > 1) {
+    z[MT - 1][0] = (float)(int)(w.z & 0xFFFFu) * 1.0e-5f; z[MT - 1][1] = (float)(int)(w.z >> 16) * 1.0e-5f;
+    z[MT - 1][2] = (float)(int)(w.w & 0xFFFFu) * 1.0e-5f; z[MT - 1][3] = (float)(int)(w.w >> 16) * 1.0e-5f;
+  }
+  return (w.x ^ w.y) ^ (w.z ^ w.w);
+#endif
   xv_box_muller16(w.x, &z[0][0], &z[0][1]);
   xv_box_muller16(w.y, &z[0][2], &z[0][3]);
   if (MT > 1) {

@@ -665,13 +665,63 @@ __device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, do
 //     term is >= .01), partial sums <= the final one: |s_ref - sum w_ref t| <= 16 * 2^-24 (1 + 1e-6) sum w_ref t.
 //   so |c' - c| <= (9.5368e-7 * 1.000001 + 2e-13) c < 9.6e-7 c'(1 + 1e-6); v = fl(L fl(A + fl(B c))) with L, B >= 0 moves by
 //     at most L B |c' - c| + 3 roundings of values < 2^9 (< 1e-12): KAPPA = 9.7e-7 and an absolute 1e-9 cover both.
+// Round 6 (XV_MAZE_SPEC32, the default): the pixel loop is bound by VALU ISSUE — every class of instruction, not the fp64 pipe:
+// gfx950 issues v_fma_f64 at the rate of v_fma_f32, which is why the fp32 filter was only 17 % faster (counters and the class count
+// of the loop: profiles/r06_*raycast*).  So the speculation is cut in INSTRUCTIONS, 13 -> 9 per tap:
+//   * weight: cx = fma(-aa, k10, 1) per window row, w' = max(fma(-bb, k10, cx), .01) — one fma per tap instead of add + fma.  Two
+//     roundings of values in [-2, 1] (below -2 both this and the reference's weight are clamped): pre-clamp value within 2^-51 of
+//     the real one, the reference's within 2^-52, max() is 1-Lipschitz: |w' - w_ref| <= 3 * 2^-52 <= 7e-14 w_ref (w >= .01).
+//   * the three colour sums run in float32: t = v_cvt_f32_ubyteN (one instruction instead of bit-field extract + v_cvt_f64_u32),
+//     wf = fl32(w'), s <- fl32(fma(wf, t, s)) (two channels in one v_pk_fma_f32).  |wf - w'| <= 2^-24 w'; every term is >= 0, so
+//     each of the 16 roundings is at most 2^-24 of the final sum: |s' - sum w' t| <= 17 * 2^-24 (1 + 2e-6) sum w' t = 1.0133e-6.
+//     The weight sum sw' stays in float64 (16 roundings of 2^-53).
+//   so |c' - c| <= (1.0133e-6 + 9.5368e-7 * 1.000001 + 3e-13) c < 1.967e-6 c'(1 + 3e-6): KAPPA = 1.98e-6 (0.97e-6 for the float64
+//     sums), and about one pixel in 150 instead of one in 300 is re-run in the reference's typing.
+//   * byte: v' = fma(L B, c', L A) instead of L (A + B c') (three roundings of values < 2^9 either way: inside the absolute 1e-9),
+//     bound e = fma(v', KAPPA, 1e-9) >= L B c' KAPPA + 1e-9 (L, A, B >= 0).
+// Same bytes as the plain exact filter, always: tests/test_gpu_maze.py (golden frames, the direct filter), tests/soak_maze.py.
+#ifndef XV_MAZE_SPEC32
+#define XV_MAZE_SPEC32 1
+#endif
+#if XV_MAZE_SPEC32
+#define MZ_SPEC_KAPPA 1.98e-6
+#else
 #define MZ_SPEC_KAPPA 9.7e-7
+#endif
+typedef float mz_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void mz_interpolate_spec(const uint32_t (&qw)[4][4], double i, double j, double d, double ps,
                                                     double (&out)[3]) {
   double d2 = d * d;
   if (d2 < 1.0e-8) d2 = 1.0e-8;
   const double k10 = mz_div(10.0, mz_divisor(d2));   // == 10 / d2, correctly rounded
   const int ib = (int)i, jb = (int)j;
+#if XV_MAZE_SPEC32
+  double sw = 0.0, nbb[4];
+  mz_f2 s01 = {0.0f, 0.0f};
+  float s2 = 0.0f;
+#pragma unroll
+  for (int yy = -1; yy < 3; ++yy) {
+    const double b = ((double)(jb + yy) - j) * ps;
+    nbb[yy + 1] = -(b * b);
+  }
+#pragma unroll
+  for (int xx = -1; xx < 3; ++xx) {
+    const double a = ((double)(ib + xx) - i) * ps;
+    const double cx = __builtin_fma(-(a * a), k10, 1.0);
+#pragma unroll
+    for (int yy = -1; yy < 3; ++yy) {
+      const double wht = __builtin_fmax(__builtin_fma(nbb[yy + 1], k10, cx), 0.01);
+      sw += wht;
+      const float wf = (float)wht;
+      const uint32_t p = qw[xx + 1][yy + 1];
+      const mz_f2 t01 = {(float)(p & 0xFFu), (float)((p >> 8) & 0xFFu)};   // v_cvt_f32_ubyte0 / 1
+      s01 = __builtin_elementwise_fma(mz_f2{wf, wf}, t01, s01);           // v_pk_fma_f32
+      s2 = __builtin_fmaf(wf, (float)((p >> 16) & 0xFFu), s2);
+    }
+  }
+  const MzDivisor SW = mz_divisor(sw);
+  out[0] = mz_div((double)s01.x, SW); out[1] = mz_div((double)s01.y, SW); out[2] = mz_div((double)s2, SW);
+#else
   double sw = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0, bb[4];
 #pragma unroll
   for (int yy = -1; yy < 3; ++yy) {
@@ -694,11 +744,17 @@ __device__ __forceinline__ void mz_interpolate_spec(const uint32_t (&qw)[4][4], 
   }
   const MzDivisor SW = mz_divisor(sw);
   out[0] = mz_div(s0, SW); out[1] = mz_div(s1, SW); out[2] = mz_div(s2, SW);
+#endif
 }
 // byte of v' = L (A + B c') and whether the reference's byte could differ (an integer within the bound of v', or no number)
 __device__ __forceinline__ uint8_t mz_spec_byte(double L, double A, double B, double c, bool& doubt) {
+#if XV_MAZE_SPEC32
+  const double v = __builtin_fma(L * B, c, L * A);      // (L B and L A are per pixel: the compiler shares them between the channels)
+  const double e = __builtin_fma(v, MZ_SPEC_KAPPA, 1.0e-9);
+#else
   const double t = B * c, v = L * (A + t);
   const double e = __builtin_fma(L * t, MZ_SPEC_KAPPA, 1.0e-9);
+#endif
   const double fr = v - __builtin_floor(v);
   doubt = doubt || !(fr > e && fr < 1.0 - e);
   return mz_clip_u8(v);
@@ -1276,6 +1332,7 @@ extern "C" int xv_maze_create(xv_engine* e, int n_env, int n_task, int NG, int n
       hc = (int)((MAZE_LDS_CHUNK_MAX / threads - 4) / 3) & ~15;
       if (hc < 16) hc = 16;
     }
+    if (getenv("XV_MAZE_HC") && atoi(getenv("XV_MAZE_HC")) >= 16) hc = std::min(H, atoi(getenv("XV_MAZE_HC")) & ~15);   // devtools A/B
     a.HC = hc;
   }
   XV_LAUNCH_CHECK();
