@@ -40,6 +40,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_ENV_STEP = {8: 8 * 64 + 50}   # w*S + 50, w = 8 (fp64 CDF), S = 64  -> 562 B
+# keys of the `long_call` block and of its rows (tests/test_host_round6.py pins them on CPU, tests/test_gpu_bench_line.py on the
+# line a GPU run prints: a renamed key fails a test, not a reader)
+LONG_CALL_MODES = ("one_stream", "overlapped", "fused_rollout")
+LONG_CALL_ROW_KEYS = ("steps", "warmup", "repeats", "launches_per_call", "us_per_step", "env_steps_per_s_events", "wall_us_per_step",
+                      "env_steps_per_s", "overlap_state", "graph_state", "device_error_flags", "issue")
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "basis", "achieved_survey_bytes", "frac_survey_bytes")
 HBM_PEAK_GBS = 8000.0
 EXIT_WATCHDOG = 3
 
@@ -290,11 +296,12 @@ def floor_probe():
         try:
             d = json.load(open(f))
             return {"empty_launch_us": d["empty_launch_us"], "coop_lines_us": {int(k): v for k, v in d["coop_lines_us"].items()},
-                    "random_lines_per_s": d["random_lines_per_s"], "source": os.path.basename(f)}
+                    "random_lines_per_s": d["random_lines_per_s"], "source": os.path.basename(f),
+                    "kernel_source_sha16": d.get("kernel_source_sha16")}
         except Exception:
             pass
     return {"empty_launch_us": 2.9, "coop_lines_us": {1: 4.3, 2: 6.75, 3: 9.1}, "random_lines_per_s": 5.0e10,
-            "source": "HISTORY.md 4.1 (round-1 box)"}
+            "source": "HISTORY.md 4.1 (round-1 box)", "kernel_source_sha16": None}
 
 
 def make_tables(eng, torch, _lib, n_task, task_base, seed, S=64, A=8, s0_max=4):
@@ -711,7 +718,7 @@ def main():
             WL = (max(100, args.warmup) + PL - 1) // PL * PL
             RL = max(1, args.long_repeats)
 
-            def lrow(w, e, launches, note):
+            def lrow(w, e, launches, note):      # keys: LONG_CALL_ROW_KEYS
                 return {"steps": KL, "warmup": WL, "repeats": RL, "launches_per_call": launches,
                         "us_per_step": e * 1e3 / KL, "env_steps_per_s_events": world * n_env * KL / (e * 1e-3),
                         "wall_us_per_step": w * 1e6 / KL, "env_steps_per_s": world * n_env * KL / w,
@@ -836,6 +843,10 @@ def main():
                              "primary": "frac" if roof["frac"] is not None else ("frac_of_floor" if floor_us is not None else None),
                              "dependent_lines": lines, "floor_us": floor_us, "frac_of_floor": None if floor_us is None else floor_us / kern_us,
                              "empty_launch_us": floor["empty_launch_us"], "floor_source": floor["source"],
+                             # the floors are a microbenchmark of the box class, not of the kernel; the probe records the kernel
+                             # source it was taken beside, so a reader sees whether the two belong to one tree
+                             "floor_kernel_source_sha16": floor.get("kernel_source_sha16"),
+                             "floor_kernel_source_current": (None if selftest else floor.get("kernel_source_sha16") == kernel_source_hash()),
                              "lines_per_s": None if lines is None else lines * n_env / (kern_us * 1e-6),
                              "random_line_rate": floor["random_lines_per_s"],
                              "frac_of_line_rate": None if lines is None else lines * n_env / (kern_us * 1e-6) / floor["random_lines_per_s"],
@@ -936,7 +947,7 @@ def main():
         wd.emit = report
         wd.arm("the all-gather pass")
         try:
-            if os.environ.get("XV_BENCH_TEST_STALL") and rank == 1:     # watchdog test: one rank never joins
+            if os.environ.get("XV_BENCH_TEST_STALL") and rank == int(os.environ.get("XV_BENCH_TEST_STALL_RANK", "1")):     # watchdog test: one rank never joins
                 time.sleep(10 * args.gather_timeout)
             state["wall_g"] = timed_pass(True, max(1, min(R, 5)))[0]
             if selftest:      # every rank sees every shard, rank order == env order

@@ -487,9 +487,103 @@ def bench_python_loop(args, n=65536, n_task=1024):
         loop.close()
         env.close()
     best = min(v for k2, v in out.items() if k2.startswith("captured"))
+    more = {}
+    for name, fn in (("linds", _python_loop_linds), ("mixed", _python_loop_mixed)):
+        try:
+            more[name] = fn(steps)
+        except Exception as ex:      # never lose the AnyMDP figures to a sibling
+            more[name] = {"error": repr(ex)}
     return {"family": "python_loop", "workload": "anymdp S=64 A=8, 65,536 envs over 1,024 synthetic tasks; policy = one "
             "elementwise torch op on the device; closed loop policy -> step", "dtype": "f64", "us_per_vector_step": out,
-            "env_steps_per_s": n / (best * 1e-6), "device_error_flags": errs}
+            "env_steps_per_s": n / (best * 1e-6), "device_error_flags": errs, "other_families": more}
+
+
+def _python_loop_linds(steps, n=65536):
+    """the same closed loop for config 3 (LinDS ns = 32, 65,536 envs): policy = one elementwise op on the observation"""
+    from xenoverse_amd.linds import LinDSVecEnv
+    tasks = linds_tasks(n // 64)
+
+    def policy(obs):
+        return torch.tanh(obs[:, :8])      # action_dim 8; the observation comes padded to 16 columns (linds_env.py:83-91)
+    out = {}
+    for copy in (True, False):
+        env = LinDSVecEnv(n, autoreset_mode="same_step", seed=1, copy=copy)
+        env.set_task(tasks)
+        obs, _ = env.reset()
+        st = {"obs": obs}
+
+        def it():
+            st["obs"] = env.step(policy(st["obs"]))[0]
+        out["eager copy=%s" % copy] = timed(it, steps, 20)
+        env.close()
+    env = LinDSVecEnv(n, autoreset_mode="same_step", seed=1, copy=False)
+    env.set_task(tasks)
+    obs, _ = env.reset()
+    loop = env.capture(policy, obs, unroll=8, warmup=2)
+    k = max(1, steps // 8)
+    out["captured unroll=8"] = min(timed(lambda: loop.replay(k), 3, 1) / (k * 8) for _ in range(2))
+    errs = env.check_errors()
+    loop.close()
+    env.close()
+    return {"workload": "linds ns=32 na=8 no=8, 65,536 envs = 1,024 tasks x 64; policy = tanh(obs)", "us_per_vector_step": out,
+            "env_steps_per_s": n / (min(out.values()) * 1e-6), "device_error_flags": errs}
+
+
+def _python_loop_mixed(steps):
+    """the same closed loop for config 5's per-GPU share (16,384 anymdp + 8,192 linds + 8,192 cartpole): MixedBatch.step_fused
+    (one launch for the three families) behind three elementwise policy ops"""
+    from xenoverse_amd import _lib
+    from xenoverse_amd.anymdp import AnyMDPVecEnv, row_lines
+    from xenoverse_amd.linds import LinDSVecEnv
+    from xenoverse_amd.metacontrol import CartPoleVecEnv, sample_cartpole
+    from xenoverse_amd.mixed import MixedBatch
+    na, nl, nc, S, A = 16384, 8192, 8192, 64, 8
+
+    def build(copy):
+        mb = MixedBatch("cuda:0", seed=3, streams="shared")
+        ea = mb.add("a", AnyMDPVecEnv, na, copy=copy)
+        mb.add("l", LinDSVecEnv, nl, copy=copy)
+        mb.add("c", CartPoleVecEnv, nc, frameskip=1, copy=copy)
+        d = ea.device
+        n_task = na // 64
+        tab = dict(S=S, A=A, s0_max=4, rows=torch.empty((n_task, S, A, row_lines(S), 16), dtype=torch.float64, device=d),
+                   state_map=torch.empty((n_task, S), dtype=torch.int32, device=d),
+                   term_mask=torch.empty((n_task, 1), dtype=torch.int64, device=d),
+                   s0_cdf=torch.empty((n_task, 4), dtype=torch.float64, device=d),
+                   s0_ids=torch.empty((n_task, 4), dtype=torch.int32, device=d),
+                   max_steps=torch.empty(n_task, dtype=torch.int32, device=d))
+        _lib.check(ea.lib.xv_anymdp_synth_tasks(ea.engine.handle, 7, 0, n_task, S, A, 4, *[_lib.ptr(tab[k]) for k in
+                   ("rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps")]))
+        ea.engine.sync()
+        mb.set_task({"a": tab, "l": linds_tasks(nl // 64), "c": [sample_cartpole(seed=k) for k in range(1024)]})
+        r = mb.reset()
+        return mb, {k: v[0] for k, v in r.items()}
+
+    def policy(obs):
+        return {"a": torch.bitwise_and(obs["a"], 7), "l": torch.tanh(obs["l"][:, :8]), "c": (obs["c"][:, 2] > 0).to(torch.int32)}
+    out = {}
+    for copy in (True, False):
+        mb, obs = build(copy)
+        st = {"obs": obs}
+
+        def it():
+            r = mb.step_fused(policy(st["obs"]))
+            st["obs"] = {k: v[0] for k, v in r.items()}
+        out["eager step_fused copy=%s" % copy] = timed(it, steps, 20)
+        mb.close()
+    mb, obs = build(False)
+    loop = mb.capture(policy, obs, unroll=8, warmup=2)
+    k = max(1, steps // 8)
+    out["captured unroll=8"] = min(timed(lambda: loop.replay(k), 3, 1) / (k * 8) for _ in range(2))
+    errs = 0
+    for e in mb.envs.values():
+        errs |= e.check_errors()
+    loop.close()
+    mb.close()
+    n = na + nl + nc
+    return {"workload": "config 5's per-GPU share: 16,384 anymdp + 8,192 linds + 8,192 cartpole, MixedBatch.step_fused (one launch); "
+            "policy = three elementwise ops", "us_per_vector_step": out, "env_steps_per_s": n / (min(out.values()) * 1e-6),
+            "device_error_flags": errs}
 
 
 def quick_families(steps=200, warmup=20):
@@ -563,7 +657,8 @@ def quick_families(steps=200, warmup=20):
         r = bench_python_loop(a)
         us = min(v for k2, v in r["us_per_vector_step"].items() if k2.startswith("captured"))
         return {"config": r["workload"], "ms_per_step": us * 1e-3, "env_steps_per_s": r["env_steps_per_s"],
-                "us_per_vector_step": r["us_per_vector_step"], "dtype": "f64", "device_error_flags": r["device_error_flags"]}
+                "us_per_vector_step": r["us_per_vector_step"], "dtype": "f64", "device_error_flags": r["device_error_flags"],
+                "other_families": r.get("other_families")}
     def tok():      # the POMDP / multi-token step on reference-distribution tasks (cooperative kernel on AUTO)
         r = bench_anymdp_tok_refdist(a)
         v = r["variants"]

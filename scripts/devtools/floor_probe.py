@@ -39,6 +39,20 @@ def main():
     t0, t1 = pick(gg, "no gather", 1048576), pick(gg, "16 B", 1048576)
     d["random_lines_per_s"] = 1048576 / ((t1 - t0) * 1e-6)
     d["random_line_traffic_GBs"] = d["random_lines_per_s"] * 128 / 1e9
+    # what the figures belong to: the probe's own sources, and the step-kernel source of the tree they were taken beside
+    # (bench.py prints both and says whether the kernel has changed since: roofline.floor_kernel_source_current)
+    import hashlib
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    h = hashlib.sha256()
+    for name in ("latency_floor.hip", "gather_granularity.hip"):
+        h.update(open(os.path.join(HERE, name), "rb").read())
+    d["probe_source_sha16"] = h.hexdigest()[:16]
+    try:
+        from xenoverse_amd.build import source_hash
+        d["kernel_source_sha16"] = source_hash(("anymdp.hip", "philox.h", "xv_common.h"))
+    except Exception as ex:
+        d["kernel_source_sha16"] = None
+        d["kernel_source_note"] = repr(ex)
     d["raw"] = {"latency_floor": lf_txt.splitlines(), "gather_granularity": gg_txt.splitlines()}
     os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     json.dump(d, open(out, "w"), indent=1)

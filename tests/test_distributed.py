@@ -106,7 +106,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_total, T, q):
+def _worker(rank, world, port, n_total, T, q, uneven=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -139,6 +139,24 @@ def _worker(rank, world, port, n_total, T, q):
         if rank == 0:
             st.set("id_test", b"\x07" * 128)
         ok = ok and bytes(st.get("id_test")) == b"\x07" * 128
+        if uneven is not None:
+            # uneven shares travel as a MixedChunk (every rank's blocks padded to the largest share: an all-gather moves equal
+            # byte counts); every rank unpacks the whole batch and checks it against the fabricated global one
+            import sys
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+            import bench_mixed
+            ch = MixedChunk(T, *uneven, world)
+            g2 = RolloutGather((ch.bytes_per_rank,), device="cpu")
+            ch.pack(rank, bench_mixed.fabricate(torch, ch, T, {f: ch.share[f][rank] for f in ch.rec}), g2.local)
+            g2.launch()
+            got = ch.unpack(g2.wait())
+            ref = bench_mixed.fabricate(torch, ch, T, {"anymdp": (0, uneven[0]), "linds": (0, uneven[1]), "cartpole": (0, uneven[2])})
+            ok = ok and all(torch.equal(got["anymdp"][j], ref["anymdp"][k]) for j, k in
+                            enumerate(("obs", "action", "reward", "terminated", "truncated")))
+            ok = ok and all(torch.equal(got["linds"][j], ref["linds"][k]) for j, k in enumerate(("obs", "reward", "terminated", "truncated")))
+            ok = ok and all(torch.equal(got["cartpole"][j], ref["cartpole"][k]) for j, k in
+                            enumerate(("obs", "reward", "terminated", "truncated", "action")))
+            ok = ok and len({ch.n_local("anymdp", r) for r in range(world)}) > 1      # the shares really differ
         # max-over-ranks timing reduction used by bench.py
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -166,14 +184,14 @@ def test_world_size_2_gloo_allgather_of_rollout_chunks():
     assert all(tmax == 2.0 for _, _, tmax in res)
 
 
-def _run_bench_selftest(extra_env, extra_args, timeout=240):
+def _run_bench_selftest(extra_env, extra_args, timeout=240, world=2):
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, **extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "64",
+    env = dict(os.environ, OMP_NUM_THREADS="1", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "64",
            "--warmup", "32", "--repeats", "3", "--envs", "512", "--exchange-selftest"] + extra_args
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
@@ -242,3 +260,53 @@ def test_bench_py_watchdog_exits_nonzero_and_keeps_the_pass1_line():
     assert len(out) == 1 and out[0]["allgather_timeout"] is True
     assert out[0]["transport"] == "torch" and out[0]["transport_requested"] == "torch" and out[0]["transport_note"] is None
     assert "did not finish within 6 s" in out[0]["config"]["exchange"]
+
+
+# ---- eight ranks before there is an eight-GPU node (round-5 review, item 3) -------------------------------------------------
+@pytest.mark.timeout(200)
+def test_world_size_8_gloo_allgather_uneven_shares_and_the_id_store():
+    """eight gloo processes: every rank checks every shard of the gathered AnyMDP chunk; UNEVEN shares (1,003 / 501 / 250 envs of
+    the three families over eight ranks) travel as a MixedChunk and every rank rebuilds the whole batch; the store that would
+    carry the RCCL unique id hands rank 0's 128 bytes to all eight; MAX over ranks"""
+    world, n_total, T = 8, 1024, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, T, q, (1003, 501, 250))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert sorted(r for r, _, _ in res) == list(range(8))
+    assert all(ok for _, ok, _ in res)
+    assert all(tmax == 8.0 for _, _, tmax in res)
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("workload", ["anymdp", "mixed"])
+def test_bench_py_eight_ranks_end_to_end_on_gloo(workload):
+    """bench.py --gpus 8 through torch.distributed.run for both workloads: eight ranks rendezvous, every rank packs its share,
+    all-gathers, unpacks and checks EVERY shard against the fabricated global batch; one JSON line"""
+    r, out = _run_bench_selftest({}, ["--workload", workload], timeout=380, world=8)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(out) == 1
+    d = out[0]
+    assert d["n_gpus"] == 8 and d["selftest"] == "ok" and d["ranks_seen"] == 8
+    if workload == "mixed":
+        assert d["config"]["envs_total"] == {"anymdp": 131072, "linds": 65536, "cartpole": 65536}      # BASELINE configs[4]: 262,144 envs
+        assert d["with_allgather"]["gathered_slice_equals_local_rings"] == "ok" and d["with_allgather"]["ranks"] == 8
+    else:
+        assert d["with_allgather"]["value"] > 0 and d["allgather_timeout"] is False
+
+
+@pytest.mark.timeout(400)
+def test_bench_py_watchdog_with_rank_5_of_8_stalling():
+    """rank 5 of eight never joins the all-gather pass: every rank leaves non-zero within the deadline, rank 0 keeps the pass-1
+    line, flagged"""
+    r, out = _run_bench_selftest({"XV_BENCH_TEST_STALL": "1", "XV_BENCH_TEST_STALL_RANK": "5"},
+                                 ["--gather-timeout", "8", "--transport", "torch"], timeout=380, world=8)
+    assert r.returncode != 0
+    assert len(out) == 1 and out[0]["allgather_timeout"] is True and out[0]["n_gpus"] == 8
+    assert "did not finish within 8 s" in out[0]["config"]["exchange"]

@@ -214,6 +214,54 @@ def test_view_steps_equal_the_parents_slice():
     env.close()
 
 
+def test_alternating_an_env_and_its_sub_batches_never_reuses_a_tick():
+    """the pipelined-trainer pattern of quickstart section 9 mixed with whole-env steps: sub-batches in lockstep, then the env,
+    then the sub-batches again ... — each side starts past every tick the other has used (AnyMDPVecEnv._sync_tick), so the
+    trajectory equals ONE handle stepping the same actions, bit for bit (round 5 let the env redraw the sub-batches' ticks)"""
+    tab = oracle.anymdp_synth(seed=31, task_index_base=0, n_task=8, S=64, A=8, s0_max=4)
+    n, K = 1024, 4
+    per = n // K
+    plan = ["s", "s", "s", "p", "p", "s", "s", "p", "s", "p", "p"]
+    acts = np.random.RandomState(9).randint(0, 8, (len(plan), n)).astype(np.int32)
+
+    whole = AnyMDPVecEnv(n, seed=6, autoreset_mode="same_step")
+    whole.set_task(_dev_tables(tab))
+    whole.reset()
+    ref = []
+    for t in range(len(plan)):
+        r = whole.step(acts[t])
+        ref.append(tuple(_np(x) for x in r[:4]) + (_np(r[4]["reward_gt"]),))
+    s_ref = [_np(x) for x in whole.get_state()]
+    t_ref = whole.engine.tick
+    whole.close()
+
+    env = AnyMDPVecEnv(n, seed=6, autoreset_mode="same_step")
+    env.set_task(_dev_tables(tab))
+    env.reset()
+    for t, who in enumerate(plan):
+        if who == "p":
+            torch.cuda.synchronize()
+            r = env.step(acts[t])
+            got = tuple(_np(x) for x in r[:4]) + (_np(r[4]["reward_gt"]),)
+            for x, y in zip(got, ref[t]):
+                assert np.array_equal(x, y), (t, who)
+        else:
+            torch.cuda.synchronize()
+            for c, sub in enumerate(env.split(K)):          # (the cached views, re-synchronised)
+                with torch.cuda.stream(sub.stream):
+                    o = sub.step(torch.as_tensor(acts[t, c * per:(c + 1) * per], device=env.device))
+                    got = tuple(_np(x) for x in o[:4]) + (_np(o[4]["reward_gt"]),)
+                for x, y in zip(got, ref[t]):
+                    assert np.array_equal(x, y[c * per:(c + 1) * per]), (t, who, c)
+    torch.cuda.synchronize()
+    for x, y in zip([_np(x) for x in env.get_state()], s_ref):
+        assert np.array_equal(x, y)
+    env._sync_tick()
+    assert env.engine.tick == t_ref
+    assert env.check_errors() == 0
+    env.close()
+
+
 def test_view_argument_checks():
     tab = oracle.anymdp_synth(seed=31, task_index_base=0, n_task=4, S=16, A=4, s0_max=3)
     env = AnyMDPVecEnv(256, seed=9, env_id_base=1000)

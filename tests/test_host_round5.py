@@ -31,6 +31,53 @@ def test_output_slabs_hand_out_disjoint_tensors_with_matching_pointers():
         assert int(t["obs"][0]) == step + 1 and float(t["frame"][6, 2, 1]) == step + 1 and bool(t["done"][3])
 
 
+def test_output_slabs_are_recycled_only_when_nobody_can_reach_them():
+    """round 6: a used-up slab is handed out again — the same tensor objects — once no Python reference, no C++ holder (DLPack)
+    and no alias of its storage (view, detach, numpy) is left; anything the caller still holds keeps its values"""
+    import torch.utils.dlpack as dl
+    fields = [("obs", torch.int32, ()), ("reward", torch.float32, ()), ("term", torch.uint8, ())]
+    sl = OutputSlabs(fields, 5, "cpu", K=4, as_bool=("term",), order=("obs", "reward", "term"))
+    last = None
+    ids = set()
+    for step in range(48):                       # the usual loop: only the latest observation is kept
+        t, p = sl.next()
+        t["obs"].fill_(step)
+        last = t["obs"]
+        ids.add(id(t["obs"]))
+    assert sl.made == 2 and sl.recycled == 10 and len(ids) == 8      # two slabs alternate: no new objects after the first two
+    assert int(last[0]) == 47
+    holders = {}
+    for step in range(64):
+        t, p = sl.next()
+        for k, v in t.items():
+            v.fill_(1 if v.dtype == torch.bool else step + 100)
+        if step == 3:
+            holders["tensor"] = (t["reward"], lambda x: float(x[0]), 103.0)
+        if step == 9:
+            holders["view"] = (t["obs"][1:3], lambda x: int(x[0]), 109)
+        if step == 14:
+            holders["detach"] = (t["reward"].detach(), lambda x: float(x[4]), 114.0)
+        if step == 21:
+            holders["numpy"] = (t["obs"].numpy(), lambda x: int(x[2]), 121)
+        if step == 26:
+            holders["dlpack"] = (dl.to_dlpack(t["obs"]), None, 126)
+    for _ in range(64):                          # plenty of further steps: every free slab is recycled and overwritten
+        t, p = sl.next()
+        for v in t.values():
+            v.fill_(0)
+    for name, (h, get, want) in holders.items():
+        if name == "dlpack":
+            h = dl.from_dlpack(h)
+            get = lambda x: int(x[0])           # noqa: E731
+        assert get(h) == want, name
+    made = sl.made
+    holders.clear()
+    del h
+    for _ in range(64):
+        sl.next()
+    assert sl.made == made                       # once the holders are gone their slabs serve again: nothing new is allocated
+
+
 def test_device_buildable_rule():
     def task(n, a, extra=None):
         d = dict(transition=np.zeros((n, a, n)), reward=np.zeros((n, a, n)), reward_noise=np.zeros((n, a, n)), na=a)
@@ -93,5 +140,5 @@ def test_profile_hash_covers_the_kernel_section_only(tmp_path, monkeypatch):
     monkeypatch.undo()
     import json, glob, os
     import bench
-    prof = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_z_pmc_traffic*.json")))
+    prof = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r0*pmc_traffic_anymdp_2a*.json")))
     assert prof and json.load(open(prof[-1]))["bench_key"]["kernel_source_sha16"] == bench.kernel_source_hash()

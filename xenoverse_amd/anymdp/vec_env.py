@@ -368,6 +368,24 @@ class AnyMDPVecEnv(VectorEnv):
         if (not self.task_set) or self.need_reset:
             # reference message, anymdp_env.py:93-94
             raise Exception("Must \"set_task\" and \"reset\" before doing any actions")
+        if self._parent is not None or self._views:
+            self._sync_tick()
+
+    def _sync_tick(self):
+        """An env and its sub-batches (split) step the SAME envs through different handles, each with a launch tick of its own;
+        an env must never draw twice at one tick (Philox(seed, env id, tick): the second draw would repeat the first).  Rule:
+        a launch of the env starts at max(its tick, its sub-batches' ticks); a launch of a sub-batch at max(its tick, the
+        env's tick).  Sub-batches stepped in lockstep therefore keep one common tick (and equal the env stepped whole, bit
+        for bit), and whichever side steps next continues past everything the other side has drawn."""
+        eng = self.engine
+        if eng.device_tick:      # a captured loop owns the word (set refused): the capture keeps to one handle
+            return
+        if self._parent is not None:
+            floor = self._parent.engine.tick
+        else:
+            floor = max(v.engine.tick for v in self._views)
+        if floor > eng.tick:
+            eng.tick = floor
 
     def _infos(self, actions):
         infos = {"steps": self._out(self._get_steps()), "reward_gt": self._of(self._reward_gt)}
@@ -572,13 +590,19 @@ class AnyMDPVecEnv(VectorEnv):
         vector step are independent, so [policy(sub k) -> step(sub k)] of one sub-batch can overlap another's.  A sub-batch
         is a full VectorEnv (step, reset, step_many, rollout, get_state ...); it shares tables and env states with this env:
         stepping sub k IS stepping envs [k N / K, (k + 1) N / K) of this env, with the draws this env would make at the same
-        tick (every sub-batch starts at this env's tick of the moment).  The views are cached per K and dropped by set_task /
-        set_search(n_bucket=...)."""
+        tick (every sub-batch starts at this env's tick of the moment).  Stepping the env and its sub-batches in turn is safe:
+        each side starts a launch past every tick the other has used (_sync_tick), so no env draws twice at one tick.  The
+        views are cached per K and dropped by set_task / set_search(n_bucket=...)."""
         self._require_task()
         K = int(K)
         if self._parent is not None:
             raise ValueError("split() of a sub-batch")
         if self._views and len(self._views) == K:
+            self._sync_tick()      # (the cached views continue from wherever this env and they have got to)
+            t = self.engine.tick
+            for v in self._views:
+                if v.engine.tick < t and not v.engine.device_tick:
+                    v.engine.tick = t
             return self._views
         if K < 1 or K > 16 or self.num_envs % K != 0:
             raise ValueError("split(K): K must divide num_envs and be at most 16")
