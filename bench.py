@@ -226,15 +226,30 @@ def kernel_source_hash():
     return source_hash(("anymdp.hip", "philox.h", "xv_common.h"))
 
 
-def pmc_traffic(n_env, n_task, search, overlap=False):
+def _kernel_kind(name):
+    """'plain' | 'hand' | 'rollout' from the step kernel's template arguments <INJECT, G, ROLLOUT, TICKDEV, BK, HAND>"""
+    try:
+        args = [x.strip() for x in name[name.index("<") + 1:name.rindex(">")].split(",")]
+    except ValueError:
+        return "plain"
+    if len(args) > 2 and args[2] == "true":
+        return "rollout"
+    if len(args) > 5 and args[5] == "true":
+        return "hand"
+    return "plain"
+
+
+def pmc_traffic(n_env, n_task, search, overlap=False, kind=None):
     """HBM bytes per launch of the step kernel from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate passes, gfx950 x2 read correction; scripts/gpu_pmc.sh -> profiles/*pmc_traffic*.json).  Counters cannot
     be read from inside this process, so the figure is the profiled one for the same workload AND the same kernel
-    source (hash of csrc/anymdp.hip + headers recorded with the profile) — a stale profile yields null.  The overlapped
-    launches run the HAND instantiation of the same kernel (name ends in `, true>`): its own entry when the profile has one,
-    else the plain kernel's (the same table line and streams per env-step; the polls of the hand-off are L2 hits)."""
+    source (hash of csrc/anymdp.hip + headers recorded with the profile) — a stale profile yields null.
+    kind: 'plain' (one launch per step on one stream), 'hand' (the overlapped launches: the HAND instantiation; the plain
+    kernel's figure when the profile has none — the same table line and streams per env-step, the polls are L2 hits) or
+    'rollout' (the fused roll-out: one launch per ring cycle — bytes per LAUNCH, i.e. of `period` steps).  Default: by `overlap`."""
     import glob
     want_src = kernel_source_hash()
+    kind = kind or ("hand" if overlap else "plain")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
         try:
             d = json.load(open(f))
@@ -242,13 +257,17 @@ def pmc_traffic(n_env, n_task, search, overlap=False):
             want = "2a" if n_task == n_env else "2b"
             if k.get("workload") == want and k.get("search") == search and k.get("envs_per_gpu") == n_env \
                     and k.get("kernel_source_sha16") == want_src:
-                cand = [(name, v) for name, v in d["kernels"].items()
-                        if "step_kernel" in name and "traffic_bytes_per_launch_corrected" in v]
-                hand = [c for c in cand if c[0].rstrip().endswith(", true>")]
-                plain = [c for c in cand if not c[0].rstrip().endswith(", true>")]
-                pick = (hand or plain) if overlap else (plain or hand)
-                if pick:
-                    return pick[0][1]["traffic_bytes_per_launch_corrected"], os.path.basename(f)
+                cand = {}
+                for name, v in d["kernels"].items():
+                    if "step_kernel" in name and "traffic_bytes_per_launch_corrected" in v:
+                        cand.setdefault(_kernel_kind(name), v["traffic_bytes_per_launch_corrected"])
+                pick = cand.get(kind)
+                if pick is None and kind == "hand":
+                    pick = cand.get("plain")
+                if pick is None and kind == "plain":
+                    pick = cand.get("hand")
+                if pick is not None:
+                    return pick, os.path.basename(f)
         except Exception:
             pass
     return None, None
@@ -885,7 +904,11 @@ def main():
                 for name, ov in (("one_stream", False), ("overlapped", True), ("fused_rollout", None)):
                     row = long_call.get(name)
                     if isinstance(row, dict) and "us_per_step" in row:
-                        tr, src = (None, None) if ov is None else pmc_traffic(n_env, n_task, search, ov)
+                        if ov is None:      # the fused roll-out: the profile holds bytes per LAUNCH of `period` steps
+                            tr, src = pmc_traffic(n_env, n_task, search, kind="rollout")
+                            tr = None if tr is None else tr / PL
+                        else:
+                            tr, src = pmc_traffic(n_env, n_task, search, ov)
                         rb = roofline_basis(algo, tr, row["us_per_step"], n_task == n_env)
                         row["roofline"] = dict(rb, peak=HBM_PEAK_GBS, unit="GB/s", traffic=tr, traffic_source=src,
                                                frac_survey_bytes=algo / (row["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS)

@@ -51,7 +51,8 @@ extern "C" {
  * 11: the overlap switch also covers xv_mixed_step_many; xv_mixed_step_many_overlap_state; xv_engine_probe_side_streams
  * 12: an expired hand-off of an overlapped xv_anymdp_step_many / xv_mixed_step_many is repaired (the call is replayed from its
  *    entry state on one stream; the *_overlap_state functions return -2 for such a call); every cycle graph starts with the
- *    cycle gate; launches in flight are sized against 3/4 of the device, two at most beside an RCCL communicator */
+ *    cycle gate; launches in flight are sized against 3/4 of the device, two at most beside an RCCL communicator;
+ *    xv_mixed_io grew five nullable outputs (steps / done masks from the fused launch) */
 #define XV_ABI_VERSION 12
 
 /* return codes */
@@ -270,7 +271,7 @@ int xv_anymdp_step_many_graph_state(xv_anymdp* h);
  * entry, and behind the join a replay kernel — a nearly empty launch when no hand-off expired — restores them and re-runs the
  * whole call on the engine's stream as the fused roll-out does (same ticks, every ring slot rewritten), clears the bit and
  * drops the error bits the failed attempt raised from wrong states: an expiry costs time (seconds), never results, and
- * never a hang.  (xv_anymdp_step_tokens_many's overlapped path still only flags.)  Needs the fence or bucket search and the
+ * never a hang (xv_anymdp_step_tokens_many's overlapped path likewise).  Needs the fence or bucket search and the
  * host tick; otherwise, and for odd periods, step_many behaves as without it.
  * One handle per device at a time, never a view (XV_ERR_UNSUPPORTED): two overlapped calls in flight can block each other
  * on the hardware queues their streams share.  Not inside a stream capture (the call takes the one-stream path).
@@ -781,6 +782,10 @@ typedef struct xv_mixed_io {
   const float* l_action; float* l_obs; float* l_reward; uint8_t* l_terminated; uint8_t* l_truncated; float* l_cmd;
   float* l_error; float* l_final_obs;
   const int32_t* c_action; float* c_obs; float* c_reward; uint8_t* c_terminated; uint8_t* c_truncated; float* c_final_obs;
+  /* ABI 12, xv_mixed_step only (each nullable; xv_mixed_step_many ignores them): info["steps"] and the terminated | truncated
+   * mask of the same step, written by the step launch itself as xv_anymdp_step_info / xv_linds_step_info / xv_cartpole_step_info
+   * do — a host that wants them needs no further launch */
+  int32_t* a_steps; uint8_t* a_done; int32_t* l_steps; uint8_t* l_done; uint8_t* c_done;
 } xv_mixed_io;
 int xv_mixed_step(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mixed_io* io, int autoreset_mode);
 /* 1: xv_mixed_step has a fused instantiation for these three handles as they are configured now, 0: step them separately */

@@ -4,7 +4,7 @@
 set -u
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-ARGS="${1:---steps 200 --warmup 20 --no-cpu-baseline --no-families}"
+ARGS="${1:---steps 200 --warmup 20 --no-cpu-baseline --no-families --fused}"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -o pmc -- python3 bench.py $ARGS > gpurun_out/pmc_$c.json 2> gpurun_out/pmc_$c.err

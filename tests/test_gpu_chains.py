@@ -469,6 +469,43 @@ def test_an_expired_hand_off_is_repaired_by_the_replay(monkeypatch, search, mode
     _same(ref, again)
 
 
+@pytest.mark.parametrize("kind", ["pomdp", "mtpomdp"])
+def test_an_expired_hand_off_of_the_token_steps_is_repaired_by_the_replay(monkeypatch, kind):
+    """xv_anymdp_step_tokens_many with the overlap on and XV_PIPE_TEST_FAIL=1 (the flag, wrong records and wrong observation
+    rings behind the join): the token replay kernel restores the records and re-runs the call — rings, records, tick and flags
+    equal the plain launches' on the reference's golden POMDP / multi-token tasks; the state word says -2"""
+    from util import golden_files, load_anymdp_tok_golden
+    tasks = [load_anymdp_tok_golden(p)[1] for p in golden_files("anymdptok_") if ("mtpomdp" in p) == (kind == "mtpomdp")]
+    n = 1536
+    env_task = (np.arange(n) % len(tasks)).astype(np.int32)
+    res = []
+    for overlap in (False, True):
+        if overlap:
+            monkeypatch.setenv("XV_PIPE_TEST_FAIL", "1")
+            monkeypatch.setenv("XV_PIPE_NO_BACKOFF", "1")
+        env = AnyMDPVecEnv(n, seed=13, autoreset_mode="same_step")
+        env.set_task(tasks, env_task_index=env_task)
+        env.set_search("bucket", n_bucket=16)
+        env.set_step_many_overlap(overlap)
+        env.reset()
+        d_act = env._tok[1]
+        rng = np.random.RandomState(3)
+        rec = []
+        for P, n_steps in ((8, 75), (8, 64), (8, 20)):
+            acts = torch.as_tensor(rng.randint(0, int(env.na), (P, n, d_act)).astype(np.int32), device=env.device)
+            out = env.step_tokens_many(n_steps, acts)
+            torch.cuda.synchronize()
+            rec.append({k: _np(v).copy() for k, v in out.items()})
+            if overlap:
+                assert env.step_many_overlap_state == (-2 if n_steps >= 64 else 0), (n_steps, env.step_many_overlap_state)
+        s, st, nr = env.get_state()
+        rec.append({"state": _np(s), "steps": _np(st), "nr": _np(nr), "tick": np.asarray(env.engine.tick)})
+        assert env.check_errors() == 0
+        res.append(rec)
+        env.close()
+    _same(res[0], res[1])
+
+
 def test_a_hand_off_that_really_expires_is_repaired():
     """XV_PIPE_TEST_BAD_TAG=1: the call's opening kernel gives env 0 a tag no step waits for, so the first step's first wave polls
     2^19 times and 0.5 s, gives up and sets XV_DEVERR_HANDOFF — the real expiry path.  The call is replayed: same results, no flag."""

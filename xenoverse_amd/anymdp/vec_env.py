@@ -438,13 +438,7 @@ class AnyMDPVecEnv(VectorEnv):
         if self.copy and not self.to_numpy and not self.with_transition_gt:
             # copy=True without copies and without allocations: the step writes every output for every env into the next set of
             # a slab made for 64 steps at once (vector.OutputSlabs); what earlier steps handed out is never written again
-            if self._slabs is None:
-                i32, f32, u8 = torch.int32, torch.float32, torch.uint8
-                self._slabs = OutputSlabs([("obs", i32, ()), ("final_obs", i32, ()), ("steps", i32, ()), ("reward", f32, ()),
-                                           ("reward_gt", f32, ()), ("term", u8, ()), ("trunc", u8, ()), ("done", u8, ())],
-                                          self.num_envs, self.device, K=64, as_bool=("term", "trunc", "done"),
-                                          order=("obs", "reward", "reward_gt", "term", "trunc", "final_obs", "steps", "done"))
-            t, p = self._slabs.next()
+            t, p = self._slab_next()
             mode = AUTORESET[self.autoreset_mode]
             _lib.check(self.lib.xv_anymdp_step_info(self._h, C.c_void_p(a.data_ptr()), *p, mode))
             self._obs = t["obs"]      # (reset() and the accessors read the latest observation from here)
@@ -467,6 +461,17 @@ class AnyMDPVecEnv(VectorEnv):
             _lib.check(self.lib.xv_anymdp_transition_gt(self._h, _lib.ptr(a), _lib.ptr(self._tgt)))
             infos["transition_gt"] = self._out(self._tgt.clone())
         return (self._of(self._obs), self._of(self._reward), self._obf(self._term), self._obf(self._trunc), infos)
+
+    def _slab_next(self):
+        """copy=True: the next output set of a 64-step slab (vector.OutputSlabs) -> (dict of tensors, pointers in the order
+        obs, reward, reward_gt, term, trunc, final_obs, steps, done)"""
+        if self._slabs is None:
+            i32, f32, u8 = torch.int32, torch.float32, torch.uint8
+            self._slabs = OutputSlabs([("obs", i32, ()), ("final_obs", i32, ()), ("steps", i32, ()), ("reward", f32, ()),
+                                       ("reward_gt", f32, ()), ("term", u8, ()), ("trunc", u8, ()), ("done", u8, ())],
+                                      self.num_envs, self.device, K=64, as_bool=("term", "trunc", "done"),
+                                      order=("obs", "reward", "reward_gt", "term", "trunc", "final_obs", "steps", "done"))
+        return self._slabs.next()
 
     def step_injected(self, actions, u, z, u_reset):
         """Parity hook (C-ABI xv_anymdp_step_injected): random inputs supplied per env."""

@@ -1190,9 +1190,9 @@ static __global__ __launch_bounds__(256) void anymdp_build_obs_cutlines_kernel(c
 // records to carry this launch's tag, and stores record + next tag in one agent-scope store as soon as the transition tokens
 // are through — BEFORE the observation stage, so the next step's transition lines fly under this step's observation lines.
 template <bool INJECT, int FMT, bool PAIR, bool HAND = false>
-__global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P, AnyMDPTokArgs K, AnyMDPTokIO io, int mode) {
+__device__ __forceinline__ void anymdp_tok_step_coop_body(const AnyMDPArgs& P, const AnyMDPTokArgs& K, const AnyMDPTokIO& io, int mode, int bid) {
   const uint64_t tick_now = xv_launch_tick(P.tick, P.tick_dev);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = bid * blockDim.x + threadIdx.x;
   const bool valid = i < P.n_env;
   const int ic = valid ? i : P.n_env - 1;
   const int lane = threadIdx.x & 63;
@@ -1218,7 +1218,7 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
       r64 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (__ballot(valid && ((uint32_t)r64 >> XV_ANYMDP_SR_TAG_SHIFT) != want) == 0ull) break;
       __builtin_amdgcn_s_sleep(1);
-      if (xv_hand_expired(polls, t_begin)) { err |= XV_DEVERR_HANDOFF; break; }
+      if (xv_hand_expired(polls, t_begin) || xv_hand_aborted(polls, P.err)) { err |= XV_DEVERR_HANDOFF; break; }      // (replayed: anymdp_tok_replay_kernel)
     }
     sr0 = make_uint2((uint32_t)r64, (uint32_t)(r64 >> 32));
   }
@@ -1435,6 +1435,48 @@ __global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P,
     if (io.done_out) io.done_out[i] = (uint8_t)((term || trunc) ? 1 : 0);
   }
   if (err && valid) atomicOr(P.err, err);
+}
+template <bool INJECT, int FMT, bool PAIR, bool HAND = false>
+__global__ __launch_bounds__(256) void anymdp_tok_step_coop_kernel(AnyMDPArgs P, AnyMDPTokArgs K, AnyMDPTokIO io, int mode) {
+  anymdp_tok_step_coop_body<INJECT, FMT, PAIR, HAND>(P, K, io, mode, (int)blockIdx.x);
+}
+// The token steps' counterpart of anymdp_replay_kernel: behind the join of an overlapped xv_anymdp_step_tokens_many, a nearly
+// empty launch unless a hand-off of the call expired; then every lane restores its env's record and re-runs the call's n_steps
+// token steps (ring slot k % period, tick tick0 + k) with the one-stream body, and the last workgroup publishes the error word.
+template <int FMT, bool PAIR>
+__global__ __launch_bounds__(256) void anymdp_tok_replay_kernel(AnyMDPArgs P, AnyMDPTokArgs K, AnyMDPTokIO io /* ring slot 0 */, int period,
+                                                                int n_steps, int mode, const uint2* snap, uint32_t* w, uint32_t* real_err,
+                                                                uint32_t* h_fell) {
+  const uint32_t e_now = __hip_atomic_load(real_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t e_in = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((e_now & XV_DEVERR_HANDOFF) == 0u) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (e_in & XV_DEVERR_HANDOFF)) atomicOr(real_err, (uint32_t)XV_DEVERR_HANDOFF);
+    return;
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < P.n_env) P.sr[i] = snap[i];
+  __syncthreads();
+  AnyMDPArgs Q = P;
+  Q.err = w + 1;
+  Q.tick_dev = nullptr;
+  const size_t n = (size_t)P.n_env, da = (size_t)K.d_act, dob = (size_t)K.d_obs;
+  for (int k = 0; k < n_steps; ++k) {
+    const size_t o = (size_t)(k % period) * n;
+    Q.tick = P.tick + (uint64_t)k;
+    const AnyMDPTokIO q{io.action + o * da, nullptr, nullptr, nullptr, nullptr, nullptr, io.obs + o * dob, io.reward + o, io.reward_gt + o,
+                        io.terminated + o, io.truncated + o, io.final_obs ? io.final_obs + o * dob : nullptr};
+    anymdp_tok_step_coop_body<false, FMT, PAIR, false>(Q, K, q, mode, (int)blockIdx.x);
+    __syncthreads();      // (an invalid lane reads the last env's record, written by a lane of this workgroup)
+  }
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(w + 2, 1u) == gridDim.x - 1u) {
+      const uint32_t re = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(real_err, e_in | re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      w[1] = 0u; w[2] = 0u;
+      __hip_atomic_fetch_add(h_fell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 template <bool INJECT>
@@ -2241,10 +2283,12 @@ static int anymdp_pipe_graphs(xv_anymdp* h, int D, int period, int cycles, size_
 
 // the whole ring cycles of a call, overlapped; *issued = steps issued (0: the caller takes the ordinary path for all of it).
 // -> XV_OK, or an error when a cycle went out in part (the streams are joined either way)
-// what the replay of an overlapped call needs (nullptr: the token path, whose expired hand-offs are flagged only)
+// what the replay of an overlapped call needs (ring slot 0 of the call's buffers)
 struct AnyMDPReplay {
-  AnyMDPStepIO io;      // ring slot 0
+  AnyMDPStepIO io;      // MDP steps (xv_anymdp_step_many)
   int ring_period, mode, eff;
+  bool tokens;          // token steps (xv_anymdp_step_tokens_many): `tio` instead of `io`
+  AnyMDPTokIO tio;
 };
 static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int period, int* issued, int depth = 2,
                               const AnyMDPReplay* rp = nullptr);
@@ -2275,9 +2319,10 @@ static int anymdp_pipe_run(xv_anymdp* h, int n_steps, int period, size_t stride,
     return XV_OK;
   }
   if (U == 0) return XV_OK;      // too short for the graphs this handle holds: one stream
-  const AnyMDPReplay rp{AnyMDPStepIO{actions, nullptr, nullptr, nullptr, obs, reward, reward_gt, terminated, truncated, final_obs, nullptr,
-                                     nullptr, 0.0f},
-                        period, mode, anymdp_effective_search(h)};
+  AnyMDPReplay rp;
+  memset(&rp, 0, sizeof(rp));
+  rp.io = AnyMDPStepIO{actions, nullptr, nullptr, nullptr, obs, reward, reward_gt, terminated, truncated, final_obs, nullptr, nullptr, 0.0f};
+  rp.ring_period = period; rp.mode = mode; rp.eff = anymdp_effective_search(h); rp.tokens = false;
   return anymdp_pipe_launch(h, h->pgraph_exec, cycles / U, period * U, issued, h->gate.depth, &rp);
 }
 
@@ -2295,7 +2340,6 @@ static __global__ __launch_bounds__(256) void anymdp_pipe_open_kernel(uint2* sr,
   if (i < n_words) tick_words[i] = tick_base;
   // the error word as it is at entry; the HANDOFF bit leaves the word for the time of the call (a wave that finds it set takes
   // it for "this call has failed": xv_hand_aborted) and returns with the replay kernel
-  // (repairable = 0: the token path, which has no replay kernel — the word stays as it is and no wait looks at it)
   if (i == 0 && repairable) { const uint32_t e = *err; snap_w[0] = e; snap_w[1] = 0u; snap_w[2] = 0u; *err = e & ~(uint32_t)XV_DEVERR_HANDOFF; }
 }
 
@@ -2355,11 +2399,28 @@ static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int 
     // behind the join: should a hand-off of this call have expired, the call is replayed from its entry state on this
     // stream (anymdp_replay_kernel: a nearly empty launch otherwise) — an expiry costs time, never results
     if (test_fail) {
-      const size_t n_obs = (size_t)rp->ring_period * (size_t)h->a.n_env;
+      const size_t n_obs = (size_t)rp->ring_period * (size_t)h->a.n_env * (size_t)(rp->tokens ? h->d_obs : 1);
       hipLaunchKernelGGL(anymdp_test_fail_kernel, dim3(xv_div_up(h->a.n_env, 256)), dim3(256), 0, st, h->a.sr, h->a.n_env, h->a.err,
-                         rp->io.obs, n_obs);
+                         rp->tokens ? rp->tio.obs : rp->io.obs, n_obs);
     }
-    if (!anymdp_launch_replay(h, rp->eff, rp->io, rp->ring_period, k / rp->ring_period, rp->mode, t0)) {
+    bool replay_ok;
+    if (rp->tokens) {
+      AnyMDPArgs a = h->a;
+      a.seed = h->eng->seed; a.gid_base = h->eng->env_id_base; a.tick = t0; a.tick_dev = nullptr;
+      AnyMDPTokArgs KA{h->obs_cdf, h->n_obs, h->d_obs, h->d_act, h->obs_bucket};
+      const dim3 grid(xv_div_up(h->a.n_env, 256)), block(256);
+      uint32_t* h_fell = h->gate.d_issued + 1;
+#define XV_TOK_REPLAY(FV, PV) \
+  hipLaunchKernelGGL((anymdp_tok_replay_kernel<FV, PV>), grid, block, 0, st, a, KA, rp->tio, rp->ring_period, k, rp->mode, \
+                     (const uint2*)h->d_snap, h->d_snap_w, h->a.err, h_fell)
+      if (h->a.bfmt == 1) { if (h->d_obs > 1) XV_TOK_REPLAY(1, true); else XV_TOK_REPLAY(1, false); }
+      else { if (h->d_obs > 1) XV_TOK_REPLAY(2, true); else XV_TOK_REPLAY(2, false); }
+#undef XV_TOK_REPLAY
+      replay_ok = hipGetLastError() == hipSuccess;
+    } else {
+      replay_ok = anymdp_launch_replay(h, rp->eff, rp->io, rp->ring_period, k / rp->ring_period, rp->mode, t0);
+    }
+    if (!replay_ok) {
       (void)hipGetLastError();
       h->pipe_failed = true;      // (this call's hand-offs are flagged as before; the next calls take the one-stream path)
     }
@@ -2989,7 +3050,7 @@ extern "C" int xv_anymdp_step_tokens_many(xv_anymdp* h, int n_steps, int period,
   h->pipe_used_last = false;
   const int cycles = n_steps / period;
   if (h->overlap && !h->eng->dev_tick && !h->pipe_failed && anymdp_tok_coop(h) && cycles > 0 && period % 2 == 0 &&
-      n_steps >= XV_ANYMDP_PIPE_GRAPH_MIN && hipSetDevice(h->eng->device) == hipSuccess &&
+      n_steps >= XV_ANYMDP_PIPE_GRAPH_MIN && !xv_pipe_backoff_step(&h->backoff, &h->gate) && hipSetDevice(h->eng->device) == hipSuccess &&
       xv_pipe_choose_depth(anymdp_tok_hand_fn(h), 256, (size_t)xv_div_up(h->a.n_env, 256), h->eng->device) >= 2) {
     int D = xv_pipe_choose_depth(anymdp_tok_hand_fn(h), 256, (size_t)xv_div_up(h->a.n_env, 256), h->eng->device);
     if (D > period) D = period;      // the steps in flight write distinct ring slots
@@ -3002,7 +3063,11 @@ extern "C" int xv_anymdp_step_tokens_many(xv_anymdp* h, int n_steps, int period,
       const int U = set_up ? anymdp_tok_pipe_graphs(h, D, period, cycles, action, obs, reward, reward_gt, terminated,
                                                     truncated, final_obs, autoreset_mode) : -1;
       if (U > 0) {
-        const int rc = anymdp_pipe_launch(h, h->tgraph_exec, cycles / U, period * U, &k, h->gate.depth);
+        AnyMDPReplay rp;
+        memset(&rp, 0, sizeof(rp));
+        rp.ring_period = period; rp.mode = autoreset_mode; rp.eff = 0; rp.tokens = true;
+        rp.tio = AnyMDPTokIO{action, nullptr, nullptr, nullptr, nullptr, nullptr, obs, reward, reward_gt, terminated, truncated, final_obs};
+        const int rc = anymdp_pipe_launch(h, h->tgraph_exec, cycles / U, period * U, &k, h->gate.depth, &rp);
         if (rc != XV_OK) return rc;
       } else if (U < 0) {
         (void)hipGetLastError();

@@ -228,10 +228,10 @@ extern "C" int xv_mixed_step(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv
     c->a.tick = (uint64_t)0 - n_tot[2] + n_before[2];
   }
   AnyMDPStepIO aio{io->a_action, nullptr, nullptr, nullptr, io->a_obs, io->a_reward, io->a_reward_gt, io->a_terminated,
-                   io->a_truncated, io->a_final_obs, nullptr, nullptr, 0.0f};
+                   io->a_truncated, io->a_final_obs, nullptr, nullptr, 0.0f, io->a_steps, io->a_done};
   LinDSStepIO lio{io->l_action, nullptr, nullptr, io->l_obs, io->l_reward, io->l_terminated, io->l_truncated, io->l_cmd,
-                  io->l_error, io->l_final_obs};
-  CartPoleIO cio{io->c_action, nullptr, io->c_obs, io->c_reward, io->c_terminated, io->c_truncated, io->c_final_obs};
+                  io->l_error, io->l_final_obs, io->l_steps, io->l_done};
+  CartPoleIO cio{io->c_action, nullptr, io->c_obs, io->c_reward, io->c_terminated, io->c_truncated, io->c_final_obs, io->c_done};
   const int nbA = xv_div_up(a->a.n_env, 256), nbL = xv_div_up(xv_div_up(l->a.n_slot, 16), 4), nbC = xv_div_up(c->a.n_env, 256);
   const dim3 grid(nbA + nbL + nbC), block(256);
   hipStream_t st = a->eng->stream;
@@ -375,6 +375,7 @@ static void mixed_io_slot(const xv_mixed_io* ring, size_t s, size_t na, size_t n
   if (io.l_final_obs) io.l_final_obs += s * nl * LO;
   io.c_action += s * nc; io.c_obs += s * nc * 4; io.c_reward += s * nc; io.c_terminated += s * nc; io.c_truncated += s * nc;
   if (io.c_final_obs) io.c_final_obs += s * nc * 4;
+  io.a_steps = nullptr; io.a_done = nullptr; io.l_steps = nullptr; io.l_done = nullptr; io.c_done = nullptr;   // xv_mixed_step only
   *out = io;
 }
 

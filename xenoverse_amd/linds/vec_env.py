@@ -13,7 +13,7 @@ import torch
 from .. import _lib
 from ..engine import AUTORESET
 from ..spaces import Box
-from ..vector import VectorEnv
+from ..vector import OutputSlabs, VectorEnv
 from .tables import build_tables
 
 _F32 = ("phiT", "gamT", "cT", "xt", "y0", "valid", "cmd0", "four_coef", "scal", "init")
@@ -114,6 +114,7 @@ class LinDSVecEnv(VectorEnv):
         self.n_task = n_task
         n = self.num_envs
         self._step_cache = None      # (copy=False steps cache pointers and views of the buffers made here)
+        self._slabs = None           # copy=True: output sets of 64 steps per allocation (vector.OutputSlabs), made at the first step
         self._obs = torch.zeros((n, self.NO), dtype=torch.float32, device=d)
         self._cmd = torch.zeros((n, self.NO), dtype=torch.float32, device=d)
         self._fobs = torch.zeros((n, self.NO), dtype=torch.float32, device=d)
@@ -234,8 +235,10 @@ class LinDSVecEnv(VectorEnv):
     def step(self, actions):
         self._check_step()
         a = self._action(actions)
-        self._renew(*self._STEP_OUTPUTS)
-        self._fresh_final_obs()
+        slab = self.copy and not self.to_numpy and self._path_name != "scalar"
+        if not slab:
+            self._renew(*self._STEP_OUTPUTS)
+            self._fresh_final_obs()
         if self._path_name == "scalar":      # the test kernel: steps and the done mask by a launch / an op of their own
             _lib.check(self.lib.xv_linds_step(self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward),
                                               _lib.ptr(self._term), _lib.ptr(self._trunc), _lib.ptr(self._cmd),
@@ -252,6 +255,18 @@ class LinDSVecEnv(VectorEnv):
                 infos["final_obs"] = c["fobs"]
                 infos["_final_obs"] = c["done_b"]
             return c["obs"], self._reward, c["term_b"], c["trunc_b"], infos
+        if slab:
+            # copy=True without copies, allocations or new tensor objects: the step writes every output of every env into the next
+            # set of a slab made for 64 steps (vector.OutputSlabs; recycled once nobody can reach it); final_obs — written for
+            # finished envs only — is zero-filled once per slab, so unfinished envs read zero rows as before
+            t, p = self._slab_next()
+            _lib.check(self.lib.xv_linds_step_info(self._h, C.c_void_p(a.data_ptr()), *p, AUTORESET[self.autoreset_mode]))
+            self._obs, self._cmd, self._error = t["obs"], t["cmd"], t["error"]      # (reset() and the accessors read these)
+            infos = {"steps": t["steps"], "command": t["cmd_u"], "error": t["error"]}
+            if self.autoreset_mode == "same_step":
+                infos["final_obs"] = t["fobs_u"]
+                infos["_final_obs"] = t["done"]
+            return t["obs_u"], t["reward"], t["term"], t["trunc"], infos
         # ONE launch: the step kernel writes info["steps"] and the terminated | truncated mask itself (xv_linds_step_info)
         self._renew("_steps", "_done")
         _lib.check(self.lib.xv_linds_step_info(self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward),
@@ -263,6 +278,21 @@ class LinDSVecEnv(VectorEnv):
             infos["final_obs"] = self._of(self._user_obs(self._fobs))
             infos["_final_obs"] = self._obf(self._done)
         return (self._of(self._user_obs(self._obs)), self._of(self._reward), self._obf(self._term), self._obf(self._trunc), infos)
+
+    def _slab_next(self):
+        """copy=True: the next output set of a 64-step slab -> (dict of tensors incl. the user's columns obs_u / cmd_u / fobs_u,
+        pointers in the order obs, reward, term, trunc, cmd, error, fobs, steps, done)"""
+        if self._slabs is None:
+            f32, u8, i32, NO = torch.float32, torch.uint8, torch.int32, self.NO
+            uo = self.user_dims[1]
+            cut = (lambda t: t[:, :uo]) if uo != NO else (lambda t: t)
+            self._slabs = OutputSlabs([("obs", f32, (NO,)), ("cmd", f32, (NO,)), ("fobs", f32, (NO,)), ("reward", f32, ()),
+                                       ("error", f32, ()), ("steps", i32, ()), ("term", u8, ()), ("trunc", u8, ()), ("done", u8, ())],
+                                      self.num_envs, self.device, K=64, as_bool=("term", "trunc", "done"),
+                                      order=("obs", "reward", "term", "trunc", "cmd", "error", "fobs", "steps", "done"),
+                                      derived={"obs_u": ("obs", cut), "cmd_u": ("cmd", cut), "fobs_u": ("fobs", cut)},
+                                      zero_on_refill=("fobs",))
+        return self._slabs.next()
 
     def step_injected(self, actions, z, init_index):
         """Parity hook: z float[NS, N] standard normals (process noise), init_index int[N] (used on reset)."""

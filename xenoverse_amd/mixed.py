@@ -26,7 +26,8 @@ class _MixedIO(C.Structure):   # xv_mixed_io (include/xeno.h)
     _fields_ = [(k, C.c_void_p) for k in (
         "a_action", "a_obs", "a_reward", "a_reward_gt", "a_terminated", "a_truncated", "a_final_obs",
         "l_action", "l_obs", "l_reward", "l_terminated", "l_truncated", "l_cmd", "l_error", "l_final_obs",
-        "c_action", "c_obs", "c_reward", "c_terminated", "c_truncated", "c_final_obs")]
+        "c_action", "c_obs", "c_reward", "c_terminated", "c_truncated", "c_final_obs",
+        "a_steps", "a_done", "l_steps", "l_done", "c_done")]      # ABI 12: steps / done masks from the fused launch (nullable)
 
 
 class MixedBatch(object):
@@ -37,6 +38,8 @@ class MixedBatch(object):
         self.separate = streams == "separate"
         self.envs = {}
         self.streams = {}
+        self._trio = None          # (_fused_trio result, cached until add())
+        self._fast = None          # copy=False: the marshalled xv_mixed_io structs and the returned views of step_fused
 
     def add(self, name, env_cls, num_envs, env_id_base=0, **kwargs):
         """Create `env_cls(num_envs, engine=<engine on a private stream>, **kwargs)` under `name`."""
@@ -46,6 +49,7 @@ class MixedBatch(object):
         env._own_engine = True   # closed with the env
         self.envs[name] = env
         self.streams[name] = st
+        self._trio = self._fast = None
         return env
 
     def _on(self, name):
@@ -81,6 +85,12 @@ class MixedBatch(object):
         return out
 
     def _fused_trio(self):
+        if self._trio is not None:
+            return self._trio
+        self._trio = self._fused_trio_uncached()
+        return self._trio
+
+    def _fused_trio_uncached(self):
         from .anymdp import AnyMDPVecEnv
         from .linds import LinDSVecEnv
         from .metacontrol import CartPoleVecEnv
@@ -119,6 +129,29 @@ class MixedBatch(object):
         ac = ec._dev(actions[nc], torch.int32)
         if aa.shape != (ea.num_envs,) or ac.shape != (ec.num_envs,):
             raise AssertionError("action batch shapes do not match the env counts")
+        if ea._ring is not None and not (el.copy or el.to_numpy or ec.copy or ec.to_numpy):
+            return self._step_fused_persistent(na, ea, nl, el, nc, ec, aa, al, ac, mode)
+        if all(e.copy and not e.to_numpy for e in (ea, el, ec)) and not ea.with_transition_gt and el._path_name != "scalar":
+            # copy=True: AnyMDP and LinDS outputs come from their 64-step slabs (no allocation, no new tensor objects: vector.
+            # OutputSlabs), CartPole's five from fresh buffers; ONE launch writes everything incl. steps and the done masks
+            ta, pa = ea._slab_next()
+            tl, pl = el._slab_next()
+            ec._renew("_obs", "_reward", "_term", "_trunc", "_fobs", "_done")
+            P = _lib.ptr
+            io = _MixedIO(P(aa), pa[0], pa[1], pa[2], pa[3], pa[4], pa[5],
+                          P(al), pl[0], pl[1], pl[2], pl[3], pl[4], pl[5], pl[6],
+                          P(ac), P(ec._obs), P(ec._reward), P(ec._term), P(ec._trunc), P(ec._fobs),
+                          pa[6], pa[7], pl[7], pl[8], P(ec._done))
+            _lib.check(ea.lib.xv_mixed_step(ea._h, el._h, ec._h, C.byref(io), AUTORESET[mode]))
+            ea._obs = ta["obs"]
+            el._obs, el._cmd, el._error = tl["obs"], tl["cmd"], tl["error"]
+            ia = {"steps": ta["steps"], "reward_gt": ta["reward_gt"]}
+            il = {"steps": tl["steps"], "command": tl["cmd_u"], "error": tl["error"]}
+            if mode == "same_step":
+                ia["final_obs"], ia["_final_obs"] = ta["final_obs"], ta["done"]
+                il["final_obs"], il["_final_obs"] = tl["fobs_u"], tl["done"]
+            return {na: (ta["obs"], ta["reward"], ta["term"], ta["trunc"], ia),
+                    nl: (tl["obs_u"], tl["reward"], tl["term"], tl["trunc"], il), nc: ec._ret(from_launch=True)}
         ring = None
         if ea._ring is not None:      # copy=False: the AnyMDP family writes one of its two engine-owned output sets
             ring = ea._ring[ea._ring_pos]
@@ -148,6 +181,41 @@ class MixedBatch(object):
         else:
             ra = (ea._of(ea._obs), ea._of(ea._reward), ea._obf(ea._term), ea._obf(ea._trunc), ea._infos(aa))
         return {na: ra, nl: el._ret(), nc: ec._ret()}
+
+    def _step_fused_persistent(self, na, ea, nl, el, nc, ec, aa, al, ac, mode):
+        """copy=False on all three families: every output lives in engine-owned buffers (AnyMDP: two sets used alternately), so
+        the xv_mixed_io structs, their pointers and the views handed out are made once; a step sets three action pointers and
+        makes ONE launch — the fused kernel writes info["steps"] and the done masks itself (ABI 12)"""
+        key = (tuple(b["obs"].data_ptr() for b in ea._ring), el._obs.data_ptr(), el._fobs.data_ptr(), el._steps.data_ptr(),
+               ec._obs.data_ptr(), ec._fobs.data_ptr(), ec._done.data_ptr(), mode)
+        f = self._fast
+        if f is None or f["key"] != key:
+            P = _lib.ptr
+            sets = []
+            lc = el._make_step_cache()
+            for b in ea._ring:
+                io = _MixedIO(None, P(b["obs"]), P(b["reward"]), P(b["reward_gt"]), P(b["term"]), P(b["trunc"]), P(b["final_obs"]),
+                              None, P(el._obs), P(el._reward), P(el._term), P(el._trunc), P(el._cmd), P(el._error), P(el._fobs),
+                              None, P(ec._obs), P(ec._reward), P(ec._term), P(ec._trunc), P(ec._fobs),
+                              P(b["steps"]), P(b["done"]), P(el._steps), P(el._done), P(ec._done))
+                ia = {"reward_gt": b["reward_gt"], "steps": b["steps"]}
+                il = {"steps": el._steps, "command": lc["cmd"], "error": el._error}
+                ic = {}
+                if mode == "same_step":
+                    ia["final_obs"], ia["_final_obs"] = b["final_obs"], b["done_b"]
+                    il["final_obs"], il["_final_obs"] = lc["fobs"], lc["done_b"]
+                    ic["final_obs"], ic["_final_obs"] = ec._fobs, ec._done.view(torch.bool)
+                sets.append((io, C.byref(io), {na: (b["obs"], b["reward"], b["term_b"], b["trunc_b"], ia),
+                                               nl: (lc["obs"], el._reward, lc["term_b"], lc["trunc_b"], il),
+                                               nc: (ec._obs, ec._reward, ec._term.view(torch.bool), ec._trunc.view(torch.bool), ic)}))
+            f = self._fast = {"key": key, "sets": sets, "mode": AUTORESET[mode]}
+        pos = ea._ring_pos
+        if not ea._holding:
+            ea._ring_pos ^= 1
+        io, ref, out = f["sets"][pos]
+        io.a_action, io.l_action, io.c_action = aa.data_ptr(), al.data_ptr(), ac.data_ptr()
+        _lib.check(ea.lib.xv_mixed_step(ea._h, el._h, ec._h, ref, f["mode"]))
+        return out
 
     def capture(self, policy_fn, obs, unroll=1, warmup=1, lean=True):
         """[policy_fn(obs dict) -> actions dict; step_fused(actions)] captured in a torch.cuda.graph (capture.py):

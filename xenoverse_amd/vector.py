@@ -38,9 +38,14 @@ class OutputSlabs(object):
 
     fields: [(name, torch dtype, trailing shape)], uint8 fields named in `as_bool` are handed out as bool views."""
 
-    def __init__(self, fields, n, device, K=64, as_bool=(), order=None, keep=3):
-        """order: field names in the order the C call takes its pointers — next() then returns them as a ready tuple"""
+    def __init__(self, fields, n, device, K=64, as_bool=(), order=None, keep=3, derived=None, zero_on_refill=()):
+        """order: field names in the order the C call takes its pointers — next() then returns them as a ready tuple
+        derived: {name: (field, fn)} — further views made once per slab, e.g. the user's columns of a padded observation;
+        zero_on_refill: fields whose whole [K, ...] block is zeroed when a slab is (re)issued — for outputs a step writes only
+        in part (LinDS final_obs: rows of finished envs), ONE fill per K steps instead of one per step"""
         self.fields, self.n, self.device, self.K = list(fields), int(n), device, int(K)
+        self.derived = dict(derived or {})
+        self.zero_on_refill = tuple(zero_on_refill)
         self.as_bool = set(as_bool)
         self.order = list(order) if order is not None else [f[0] for f in self.fields]
         self.keep = max(1, int(keep))
@@ -56,7 +61,7 @@ class OutputSlabs(object):
             by.setdefault(dt, []).append((name, tuple(tail)))
         per_step = [dict() for _ in range(self.K)]
         ptrs = [dict() for _ in range(self.K)]
-        storages = []
+        storages, zero_blocks = [], []
         for dt, fl in by.items():
             # [field][step][n * tail]: two unbind() calls hand out every per-step tensor (slicing K x fields views one by one
             # in Python cost more than the allocations it was meant to save)
@@ -71,13 +76,19 @@ class OutputSlabs(object):
                 sz = self.n * math.prod(tail)
                 if sz != width:
                     src = src[:, :sz]
+                if name in self.zero_on_refill:
+                    zero_blocks.append(src)
                 if tail:
                     src = src.view((self.K, self.n) + tail)
                 rows = src.unbind(0)
                 for k in range(self.K):
                     per_step[k][name] = rows[k]
                     ptrs[k][name] = C.c_void_p(base + ((f * self.K + k) * width) * esz)
-        rec = {"sets": [(per_step[k], tuple(ptrs[k][name] for name in self.order)) for k in range(self.K)],
+        for name, (field, fn) in self.derived.items():
+            for k in range(self.K):
+                per_step[k][name] = fn(per_step[k][field])
+        rec = {"zero": zero_blocks,
+               "sets": [(per_step[k], tuple(ptrs[k][name] for name in self.order)) for k in range(self.K)],
                "flat": [t for d in per_step for t in d.values()] + per_step, "tensors": [t for d in per_step for t in d.values()],
                "storages": storages}      # (`flat` counts the per-step dicts too: next() hands them out)
         self.made += 1
@@ -102,6 +113,8 @@ class OutputSlabs(object):
             pick = self._make()
             pick["idle"] = None
         self._ring.append(pick)
+        for blk in pick["zero"]:
+            blk.zero_()
         if pick["idle"] is None:      # (taken with every temporary of _make gone: the slab is referenced exactly as when it idles)
             pick["idle"] = self._counts(pick)
         while len(self._ring) > self.keep:
