@@ -95,6 +95,10 @@ def parse():
                     help="the `long_call` block (SURVEY.md 8(d): >= 1,000 back-to-back step launches after >= 100 warm-up steps): "
                          "steps per call, rounded to whole ring cycles of --period; 0 = no block")
     ap.add_argument("--long-repeats", type=int, default=5)
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="N = 1: do not measure `roofline.traffic` live (two child runs of this script under rocprofv3 --pmc, "
+                         "FETCH_SIZE and WRITE_SIZE in separate passes, before this process touches the GPU; ~20 s); the committed "
+                         "profile of this kernel source is used instead")
     ap.add_argument("--no-families", action="store_true",
                     help="N = 1: skip the `families` object (configs 3, 4 and the per-GPU share of 5, a few seconds)")
     ap.add_argument("--transport", default="auto", choices=["auto", "torch", "rccl"],
@@ -271,6 +275,59 @@ def pmc_traffic(n_env, n_task, search, overlap=False, kind=None):
         except Exception:
             pass
     return None, None
+
+
+def live_pmc_traffic(args):
+    """HBM bytes per launch of the step kernels MEASURED BY THIS RUN: two child processes `rocprofv3 --pmc <counter>
+    --kernel-trace -- python3 bench.py <the same workload, 128 steps, --fused>` — FETCH_SIZE and WRITE_SIZE in separate passes, only
+    --kernel-trace beside the counters, the program itself behind `--` — started BEFORE this process touches the GPU (a child of
+    a process that holds the device must not exec), outputs under /tmp.  Units and the gfx950 correction as MI355X_MICROARCH.md's
+    HBM section prescribes (counter values are KB; read bytes = 2 x FETCH_SIZE; WRITE_SIZE exact), the same arithmetic as
+    scripts/pmc_to_json.py.  -> {"plain" | "hand" | "rollout": bytes per launch, "source": ...} or {"error": ...}; never raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    t0 = time.perf_counter()
+    agg = {}
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="xv_pmc_%s_" % c, dir="/tmp")
+            cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+                   os.path.abspath(__file__), "--gpus", "1", "--steps", "128", "--warmup", "32", "--repeats", "2", "--envs", str(args.envs),
+                   "--tasks", str(args.tasks), "--period", str(args.period), "--seed", str(args.seed), "--search", args.search,
+                   "--buckets", str(args.buckets), "--graph", args.graph, "--overlap", args.overlap, "--no-cpu-baseline",
+                   "--no-families", "--no-live-pmc", "--fused", "--sustain-seconds", "0", "--long-steps", "0"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=300)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                shutil.rmtree(d, ignore_errors=True)
+                return {"error": "rocprofv3 --pmc %s: rc %d, %s" % (c, r.returncode, (r.stderr or "")[-300:])}
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == c and "anymdp_step_kernel" in row["Kernel_Name"]:
+                    agg.setdefault(row["Kernel_Name"].split("(")[0], {}).setdefault(c, []).append(float(row["Counter_Value"]))
+            shutil.rmtree(d, ignore_errors=True)
+    except Exception as ex:
+        return {"error": repr(ex)}
+    out = {"source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate child runs of this command, 128 steps, before the timed "
+                     "passes; KB counters, read bytes = 2 x FETCH_SIZE on gfx950)", "kernels": {}}
+    for name, cs in agg.items():
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            f, w = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]), sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
+            b = (2.0 * f + w) * 1024.0
+            out.setdefault(_kernel_kind(name), b)
+            out["kernels"][name] = {"bytes_per_launch": b, "dispatches": len(cs["FETCH_SIZE"])}
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    if not any(k in out for k in ("plain", "hand", "rollout")):
+        return {"error": "no step kernel in the counter files"}
+    return out
 
 
 def roofline_basis(algo, traffic, kern_us, distinct_tasks):
@@ -476,6 +533,11 @@ def main():
                 cpu = {"value": None, "unit": "env-steps/s", "cores": usable_cpus(), "kind": "port", "sample": "failed: %r" % (ex,)}
         else:
             cpu = cpu_baseline(args.cpu_seconds, args.seed, args.cpu_table_gib)      # before the GPU is touched
+
+    live = None
+    if world == 1 and rank == 0 and not selftest and not args.sweep_envs and not under_profiler() and not args.no_live_pmc \
+            and args.workload == "anymdp" and not os.environ.get("XV_BENCH_SHARE_GPU"):
+        live = live_pmc_traffic(args)      # child processes; this one has not touched the GPU yet
 
     import torch
     if os.environ.get("XV_BENCH_SHARE_GPU"):   # functional test of the N>1 path on a 1-GPU box (not a measurement)
@@ -805,7 +867,19 @@ def main():
             kern_us = ev_ms * 1e3 / args.steps
             algo = ALGO_BYTES_PER_ENV_STEP[8] * n_env
             achieved = algo / (kern_us * 1e-6) / 1e9
-            traffic, traffic_src = (None, None) if selftest else pmc_traffic(n_env, n_task, search, bool(state.get("overlap")))
+            traffic_c, traffic_src_c = (None, None) if selftest else pmc_traffic(n_env, n_task, search, bool(state.get("overlap")))
+            traffic, traffic_src = traffic_c, traffic_src_c
+
+            def live_bytes(kind):      # this run's own counters, where the child runs delivered them
+                if not live or "error" in live:
+                    return None
+                v = live.get(kind)
+                if v is None and kind in ("hand", "plain"):
+                    v = live.get("plain" if kind == "hand" else "hand")
+                return v
+            lb = live_bytes("hand" if state.get("overlap") else "plain")
+            if lb is not None:
+                traffic, traffic_src = lb, live["source"]
             floor = floor_probe()
             lines = {"bucket": 1, "fence": 2}.get(search)
             # the bare chain was measured on tables that miss every cache: it is the floor of config 2a (one task per env),
@@ -854,6 +928,10 @@ def main():
                              "frac_wall": None if roof["frac"] is None else roof["frac"] * kern_us / (wall * 1e6 / args.steps),
                              "clock": "HIP events on the launch stream (avg_launch_us); frac_wall*: host wall (ms_per_step)",
                              "traffic": traffic, "traffic_source": traffic_src,
+                             # the committed profile of the same kernel source (profiles/*pmc_traffic*.json) beside this run's own
+                             "traffic_committed_profile": traffic_c, "traffic_committed_source": traffic_src_c,
+                             "traffic_live": (None if not live else ({"error": live["error"]} if "error" in live else
+                                                                     {k: live.get(k) for k in ("plain", "hand", "rollout", "seconds")})),
                              "frac_traffic": None if traffic is None else traffic / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                              "traffic_over_algorithmic": None if traffic is None else traffic / algo,
                              # the step is a latency chain of `dependent_lines` random lines: `floor_us` is that chain measured
@@ -904,11 +982,15 @@ def main():
                 for name, ov in (("one_stream", False), ("overlapped", True), ("fused_rollout", None)):
                     row = long_call.get(name)
                     if isinstance(row, dict) and "us_per_step" in row:
-                        if ov is None:      # the fused roll-out: the profile holds bytes per LAUNCH of `period` steps
+                        if ov is None:      # the fused roll-out: bytes per LAUNCH of `period` steps (the child runs use --period too)
                             tr, src = pmc_traffic(n_env, n_task, search, kind="rollout")
+                            if live_bytes("rollout") is not None:
+                                tr, src = live_bytes("rollout"), live["source"]
                             tr = None if tr is None else tr / PL
                         else:
                             tr, src = pmc_traffic(n_env, n_task, search, ov)
+                            if live_bytes("hand" if ov else "plain") is not None:
+                                tr, src = live_bytes("hand" if ov else "plain"), live["source"]
                         rb = roofline_basis(algo, tr, row["us_per_step"], n_task == n_env)
                         row["roofline"] = dict(rb, peak=HBM_PEAK_GBS, unit="GB/s", traffic=tr, traffic_source=src,
                                                frac_survey_bytes=algo / (row["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS)

@@ -586,6 +586,16 @@ def _python_loop_mixed(steps):
             "device_error_flags": errs}
 
 
+def _maze_valu_roofline(r):
+    v = r.get("valu_issue")
+    if not v:
+        return {"bound": "valu_issue", "frac": None, "achieved": None, "peak": None, "unit": "G wave-instr/s",
+                "model": "no committed counter profile of this ray caster: no fraction claimed"}
+    return {"bound": "valu_issue", "frac": v["frac"], "frac_at_measured_clock": v["frac_at_measured_clock"], "achieved": v["achieved"],
+            "peak": v["peak"], "unit": v["unit"], "model": v["model"], "valu_instructions_per_pixel": v["valu_instructions_per_pixel"],
+            "source": v["source"]}
+
+
 def quick_families(steps=200, warmup=20):
     """the `families` object of bench.py's JSON line: BASELINE.json configs 3 (linds), 4 (mazeworld, 64x64 frames) and the
     per-GPU share of config 5 (mixed), each timed with HIP events over back-to-back launches; a few seconds in all"""
@@ -617,25 +627,22 @@ def quick_families(steps=200, warmup=20):
                 "us_per_step": r["us_per_step"], "dtype": r["dtype"],
                 # the ray caster (90 % of the step) is bound by fp64 VALU issue and texture requests — the 16-tap filter with the
                 # reference's bytes — not by HBM: `bound` / `frac` are that kernel's; the HBM view of the same step is kept beside it
-                "roofline": {"bound": "valu_f64", "frac": r["valu_f64"]["frac"], "achieved": r["valu_f64"]["achieved"],
-                             "peak": r["valu_f64"]["peak"], "unit": r["valu_f64"]["unit"], "model": r["valu_f64"]["model"],
-                             "kernel": "maze_raycast_kernel (exact filter, speculated; + maze_step9_kernel for the move)",
-                             "valu_f64_frac": r["valu_f64"]["frac"],
-                             "hbm": {"frac": r["roofline"]["frac"], "algorithmic_bytes": (3 * 64 * 64 + 64) * 16384, "peak": HBM_PEAK,
-                                     "unit": "GB/s", "achieved": r["roofline"]["achieved"]},
-                             "note": r["roofline"]["note"]}}
+                "roofline": dict(_maze_valu_roofline(r),
+                                 kernel="maze_raycast_kernel (exact filter, speculated with float32 colour sums; + maze_step9_kernel for the move)",
+                                 hbm={"frac": r["roofline"]["frac"], "algorithmic_bytes": (3 * 64 * 64 + 64) * 16384, "peak": HBM_PEAK,
+                                      "unit": "GB/s", "achieved": r["roofline"]["achieved"]},
+                                 note=r["roofline"]["note"])}
 
     def maze256():      # the registered default resolution (mazeworld/__init__.py:27): 196,672 B per env-step
         r = bench_maze(a, 256)
         us = r["us_per_step"]["step (both)"]
         return {"config": "BASELINE configs[3] at the registered 256 x 256: " + r["workload"], "ms_per_step": us * 1e-3,
                 "env_steps_per_s": r["env_steps_per_s"], "us_per_step": r["us_per_step"], "dtype": r["dtype"],
-                "roofline": {"bound": "valu_f64", "frac": r["valu_f64"]["frac"], "achieved": r["valu_f64"]["achieved"],
-                             "peak": r["valu_f64"]["peak"], "unit": r["valu_f64"]["unit"], "model": r["valu_f64"]["model"],
-                             "kernel": "maze_raycast_kernel (exact filter, speculated, rows of a column per wave; + maze_step9_kernel)",
-                             "hbm": {"frac": r["roofline"]["frac"], "algorithmic_bytes": (3 * 256 * 256 + 64) * 16384,
-                                     "peak": HBM_PEAK, "unit": "GB/s", "achieved": r["roofline"]["achieved"]},
-                             "note": r["roofline"]["note"]}}
+                "roofline": dict(_maze_valu_roofline(r),
+                                 kernel="maze_raycast_kernel (exact filter, speculated with float32 colour sums, rows of a column per wave; + maze_step9_kernel)",
+                                 hbm={"frac": r["roofline"]["frac"], "algorithmic_bytes": (3 * 256 * 256 + 64) * 16384,
+                                      "peak": HBM_PEAK, "unit": "GB/s", "achieved": r["roofline"]["achieved"]},
+                                 note=r["roofline"]["note"])}
 
     def mixed():
         r = bench_mixed(a, variants=("one stream", "one launch"))
@@ -737,13 +744,21 @@ def bench_maze(args, res, precision="exact", move_kernel="auto"):
     us_full = timed(full, steps, 4)
     env.close()
     algo = (3 * res * res + 64) * n
-    # the ray-caster is bound by fp64 VALU issue, not HBM: in the reference's typing a painted pixel needs >= 16 taps x
-    # (8 weight + 3 x 5 colour) = 368 fp64-pipe instructions + ~40 of geometry (the direct filter); the default filter
-    # speculates with float64 sums, 16 x (4 + 3 x 3) + 40 = 248, and re-runs the ~1 pixel in 300 whose byte is not certain;
-    # peak = 1024 SIMDs x 64 lanes x 2.4 GHz / 4 cycles per wave-instr
-    per_pixel = 248.0 if precision == "exact" else 408.0
-    valu_ops = per_pixel * res * res * n
-    valu_peak = 1024 * 64 * 2.4e9 / 4
+    # The ray caster is bound by VALU ISSUE (every class of instruction; gfx950 issues v_fma_f64 at the rate of v_fma_f32), not by
+    # HBM and not by the fp64 pipe.  Instructions per pixel come from the committed counters of this filter at this
+    # resolution (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES: profiles/*pmc_raycast_<filter>_<res>.json, scripts/pmc_kernel.sh);
+    # peak = 1,024 SIMDs x one wave instruction per 4 cycles at the 2.4-GHz peak clock (the counters' own GRBM_GUI_ACTIVE gives
+    # 2.25 GHz during the kernel: `frac_at_measured_clock`)
+    ipp, ipp_src = maze_valu_per_pixel("spec32" if precision == "exact" else ("f32" if precision == "f32" else None), res, n)
+    valu_peak = 1024 * 2.4e9 / 4
+    valu = None
+    if ipp is not None:
+        wave_instr = ipp * res * res * n / 64.0
+        valu = {"achieved": wave_instr / (us_render * 1e-6) / 1e9, "peak": valu_peak / 1e9, "unit": "G wave-instr/s",
+                "frac": wave_instr / (us_render * 1e-6) / valu_peak, "frac_at_measured_clock": wave_instr / (us_render * 1e-6) / (1024 * 2.25e9 / 4),
+                "valu_instructions_per_pixel": ipp, "source": ipp_src,
+                "model": "SQ_INSTS_VALU per pixel (committed counters of this kernel) x pixels / 64 lanes / ray-cast time, against "
+                         "1,024 SIMDs x 1 wave instruction / 4 cycles x 2.4 GHz"}
     return {"family": "mazeworld", "filter": precision, "move_kernel": move_kernel,
             "workload": "15x15 mazes, 16,384 envs = 256 tasks x 64, %dx%d frames" % (res, res),
             "dtype": "f64 pose, f32/f64 ray-caster, u8 frames", "env_steps_per_s": n / (us_full * 1e-6),
@@ -751,10 +766,26 @@ def bench_maze(args, res, precision="exact", move_kernel="auto"):
             "roofline": {"bound": "hbm", "achieved": algo / (us_full * 1e-6) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
                          "frac": algo / (us_full * 1e-6) / 1e9 / HBM_PEAK,
                          "algorithmic_bytes_per_env_step": 3 * res * res + 64,
-                         "note": "the 16-tap fp64 texture filter (VALU issue), not HBM, bounds the ray-caster"},
-            "valu_f64": {"achieved": valu_ops / (us_render * 1e-6) / 1e12, "peak": valu_peak / 1e12,
-                         "unit": "T lane-instr/s", "frac": valu_ops / (us_render * 1e-6) / valu_peak,
-                         "model": "%d fp64-pipe instructions per pixel (all pixels counted as painted)" % per_pixel}}
+                         "note": "VALU issue (every instruction class), not HBM, bounds the ray caster: see valu_issue"},
+            "valu_issue": valu}
+
+
+def maze_valu_per_pixel(tag, res, n):
+    """-> (VALU instructions per pixel, file) from the newest committed counter profile of the ray caster with this filter at this
+    resolution (profiles/*pmc_raycast_<tag>_<res>.json), or (None, None)"""
+    import glob
+    if tag is None:
+        return None, None
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "*pmc_raycast_%s_%d.json" % (tag, res))), reverse=True):
+        try:
+            d = json.load(open(f))
+            for name, v in d["kernels"].items():
+                if "maze_raycast" in name and "SQ_INSTS_VALU" in v:
+                    return float(v["SQ_INSTS_VALU"]) * 64.0 / (float(res) * res * n), os.path.basename(f)
+        except Exception:
+            pass
+    return None, None
 
 
 def bench_teacher(args, res=64):

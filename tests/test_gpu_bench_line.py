@@ -36,6 +36,11 @@ def test_bench_line_schema_at_the_drivers_flags():
         assert k in ro, k
     assert ro["frac"] is None or 0.0 < ro["frac"] <= 1.0
     assert ro["peak"] == 8000.0 and ro["unit"] == "GB/s" and ro["bound"] in ("hbm", "cache")
+    # the traffic is this run's own: two child passes under rocprofv3 --pmc before the GPU is touched
+    tl = ro["traffic_live"]
+    assert tl is not None and "error" not in tl, tl
+    assert tl["plain"] and tl["rollout"] and ro["traffic"] in (tl["plain"], tl["hand"]) and ro["traffic_source"].startswith("live")
+    assert 100 * 4096 < tl["plain"] < 600 * 4096          # bytes per launch: one table line + the per-env streams, per env
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb
@@ -57,6 +62,7 @@ def test_bench_line_schema_at_the_drivers_flags():
 
 
 def test_bench_line_shared_tasks_claims_no_hbm_fraction():
-    d = _line(["--tasks", "64", "--no-cpu-baseline", "--long-steps", "0"])
+    d = _line(["--tasks", "64", "--no-cpu-baseline", "--long-steps", "0", "--no-live-pmc"])
+    assert d["roofline"]["traffic_live"] is None
     assert d["roofline"]["bound"] == "cache" and d["roofline"]["frac"] is None and d["roofline"]["frac_survey_bytes"] > 0
     assert "long_call" not in d
