@@ -229,7 +229,7 @@ static inline void xv_pipe_test_stall(int cycle, int at = 0) {
 // slots (XV_PIPE_RESIDENCY_NUM / _DEN).  A neighbour that is finite only delays the hand-offs — its workgroups end and the
 // launches in flight (at most depth x grid of them are ever dispatchable: launch k + depth sits behind launch k on its stream)
 // get their slots; a wait that expires all the same is repaired by the replay (anymdp.hip, mixed.hip), never left in the
-// results.  While the process holds an RCCL communicator on the device (xv_device_note_collective: persistent kernels that spin
+// results.  The margin applies to three or more launches in flight; two may fill the device.  While the process holds an RCCL communicator on the device (xv_device_note_collective: persistent kernels that spin
 // on peers) at most two launches are in flight.
 #define XV_PIPE_RESIDENCY_NUM 3
 #define XV_PIPE_RESIDENCY_DEN 4
@@ -241,6 +241,9 @@ static bool xv_pipe_two_launches_fit(const void* fn, int block_threads, size_t g
     return false;
   }
   if (n_launches > 2 && xv_device_collectives(device) > 0) return false;
+  // three (or more) in flight: within 3/4 of the slots; two: the whole device, as in round 5 (131,072 AnyMDP envs: 5.6 instead
+  // of 7.0 us per step) — a neighbour can then starve a step for a while, which costs a replay and a back-off, not results
+  if (n_launches <= 2) return (size_t)n_launches * grid_blocks <= (size_t)per_cu * (size_t)cus;
   return (size_t)n_launches * grid_blocks * XV_PIPE_RESIDENCY_DEN <= (size_t)per_cu * (size_t)cus * XV_PIPE_RESIDENCY_NUM;
 }
 
