@@ -190,3 +190,35 @@ def test_an_expired_hand_off_of_the_mixed_step_is_repaired_by_the_replay(monkeyp
     for i, (p, q) in enumerate(zip(*res)):
         for k in p:
             assert torch.equal(torch.as_tensor(p[k]), torch.as_tensor(q[k])), (i, k)
+
+
+def test_run_mixed_beside_a_handle_that_holds_the_overlap_switch():
+    """bench.py at N > 1 runs the mixed workload (`families.mixed`) while its AnyMDP env exists (round-5 advisor finding: the
+    env held the device's one overlap slot and the block was always an error).  run_mixed must cope with a taken slot — one
+    stream, said so in the line — and overlap once the slot is free; bench.py releases it around the call."""
+    import argparse
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import bench_mixed
+    import oracle
+    from xenoverse_amd.anymdp import AnyMDPVecEnv, to_blocked
+    tab = oracle.anymdp_synth(seed=12, task_index_base=0, n_task=4, S=64, A=8, s0_max=4)
+    dev = dict(S=64, A=8, s0_max=4)
+    tab["rows"] = to_blocked(tab["cdf"], tab["rs"])
+    for k in ("rows", "state_map", "term_mask", "s0_cdf", "s0_ids", "max_steps"):
+        v = np.ascontiguousarray(tab[k])
+        dev[k] = torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).cuda()
+    env = AnyMDPVecEnv(256, seed=1)
+    env.set_task(dev)
+    env.set_step_many_overlap(True)                      # holds the device's slot, as bench.py's headline env does
+    args = argparse.Namespace(period=8, seed=3, overlap="auto", no_allgather=True, transport="torch", warmup=16, steps=64, repeats=2)
+    dinfo = {"note": None, "rccl": None, "rccl_ranks": None, "backend": None}
+    out = bench_mixed.run_mixed(args, torch, None, dinfo, 0, 1, 0, None, scale=16)
+    assert out["value"] > 0 and out["config"]["overlap"] is False and "overlap not taken" in out["config"]["overlap_note"]
+    assert out["config"]["device_error_flags"] == 0
+    env.set_step_many_overlap(False)                     # what bench.py does before families.mixed
+    out = bench_mixed.run_mixed(args, torch, None, dinfo, 0, 1, 0, None, scale=16)
+    assert out["config"]["overlap"] is True and out["config"]["overlap_note"] is None and out["config"]["device_error_flags"] == 0
+    env.set_step_many_overlap(True)                      # the share released the slot when it was closed
+    env.close()

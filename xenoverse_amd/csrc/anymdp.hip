@@ -144,6 +144,7 @@ struct xv_anymdp {
   uint32_t* d_snap_w;        // [0] the error word at entry, [1] the replay's own error bits, [2] workgroups finished
   uint32_t fell_seen;        // gate.h_issued[1] (calls replayed so far) when the last overlapped call was issued
   XvPipeBackoff backoff;     // one-stream calls after a replayed one (xv_pipe.h)
+  XvPipeBackoff backoff_mixed;   // the same for xv_mixed_step_many with this handle (mixed.hip; len == 0: not started)
   struct {
     int period, mode, search;
     size_t stride;
@@ -1657,6 +1658,7 @@ static void anymdp_pipe_clear(xv_anymdp* h) {      // fields of the overlapped s
   h->d_ptick = nullptr; h->ptick_value = 0; h->ptick_valid = false;
   h->d_snap = nullptr; h->d_snap_w = nullptr; h->fell_seen = 0;
   h->backoff.fell_known = 0; h->backoff.left = 0; h->backoff.len = 32;
+  h->backoff_mixed.fell_known = 0; h->backoff_mixed.left = 0; h->backoff_mixed.len = 0;
   memset(&h->pipe_key, 0, sizeof(h->pipe_key));
 }
 static void anymdp_pipe_drop_graphs(xv_anymdp* h) {
@@ -2453,6 +2455,7 @@ extern "C" int xv_anymdp_set_step_many_overlap(xv_anymdp* h, int on) {
     g_overlap_owner[dev] = h;
     h->pipe_failed = false;
     xv_pipe_backoff_reset(&h->backoff, &h->gate);
+    h->backoff_mixed.len = 0;      // (mixed.hip starts it over against its own replay counter)
   } else if (g_overlap_owner[dev] == h) {
     g_overlap_owner[dev] = nullptr;
   }

@@ -674,17 +674,19 @@ __device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, do
 //   * the three colour sums run in float32: t = v_cvt_f32_ubyteN (one instruction instead of bit-field extract + v_cvt_f64_u32),
 //     wf = fl32(w'), s <- fl32(fma(wf, t, s)) (two channels in one v_pk_fma_f32).  |wf - w'| <= 2^-24 w'; every term is >= 0, so
 //     each of the 16 roundings is at most 2^-24 of the final sum: |s' - sum w' t| <= 17 * 2^-24 (1 + 2e-6) sum w' t = 1.0133e-6.
-//     The weight sum sw' stays in float64 (16 roundings of 2^-53).
-//   so |c' - c| <= (1.0133e-6 + 9.5368e-7 * 1.000001 + 3e-13) c < 1.967e-6 c'(1 + 3e-6): KAPPA = 1.98e-6 (0.97e-6 for the float64
-//     sums), and about one pixel in 150 instead of one in 300 is re-run in the reference's typing.
+//     The weight sum runs in the same float32 chain (sw' <- fl32(fma(wf, 1, sw')), the second lane of the v_pk_fma_f32 that sums
+//     the third channel): |sw' - sum w'| <= 17 * 2^-24 (1 + 2e-6) sum w' likewise.
+//   so c' = s' / sw' has |c' - c| <= (2 * 1.0133e-6 + 9.5368e-7 * 1.000001 + 3e-12) c < 2.981e-6 c'(1 + 4e-6): KAPPA = 3.0e-6 (0.97e-6
+//     for the float64 sums), and about one pixel in 100 instead of one in 300 is re-run in the reference's typing.
 //   * byte: v' = fma(L B, c', L A) instead of L (A + B c') (three roundings of values < 2^9 either way: inside the absolute 1e-9),
-//     bound e = fma(v', KAPPA, 1e-9) >= L B c' KAPPA + 1e-9 (L, A, B >= 0).
+//     bound e = fma(v', KAPPA, 1e-9) >= L B c' KAPPA + 1e-9 (L, A, B >= 0).  0 <= v' <= 255 (L <= 1, A + B = 1, c' <= 255 (1 + 3e-6);
+//     a v' above 255 by that much truncates to 255 as the reference's clip does): no clamp instructions.
 // Same bytes as the plain exact filter, always: tests/test_gpu_maze.py (golden frames, the direct filter), tests/soak_maze.py.
 #ifndef XV_MAZE_SPEC32
 #define XV_MAZE_SPEC32 1
 #endif
 #if XV_MAZE_SPEC32
-#define MZ_SPEC_KAPPA 1.98e-6
+#define MZ_SPEC_KAPPA 3.0e-6
 #else
 #define MZ_SPEC_KAPPA 9.7e-7
 #endif
@@ -696,9 +698,8 @@ __device__ __forceinline__ void mz_interpolate_spec(const uint32_t (&qw)[4][4], 
   const double k10 = mz_div(10.0, mz_divisor(d2));   // == 10 / d2, correctly rounded
   const int ib = (int)i, jb = (int)j;
 #if XV_MAZE_SPEC32
-  double sw = 0.0, nbb[4];
-  mz_f2 s01 = {0.0f, 0.0f};
-  float s2 = 0.0f;
+  double nbb[4];
+  mz_f2 s01 = {0.0f, 0.0f}, s2w = {0.0f, 0.0f};      // (s0, s1), (s2, sw)
 #pragma unroll
   for (int yy = -1; yy < 3; ++yy) {
     const double b = ((double)(jb + yy) - j) * ps;
@@ -711,16 +712,16 @@ __device__ __forceinline__ void mz_interpolate_spec(const uint32_t (&qw)[4][4], 
 #pragma unroll
     for (int yy = -1; yy < 3; ++yy) {
       const double wht = __builtin_fmax(__builtin_fma(nbb[yy + 1], k10, cx), 0.01);
-      sw += wht;
       const float wf = (float)wht;
       const uint32_t p = qw[xx + 1][yy + 1];
       const mz_f2 t01 = {(float)(p & 0xFFu), (float)((p >> 8) & 0xFFu)};   // v_cvt_f32_ubyte0 / 1
+      const mz_f2 t2w = {(float)((p >> 16) & 0xFFu), 1.0f};
       s01 = __builtin_elementwise_fma(mz_f2{wf, wf}, t01, s01);           // v_pk_fma_f32
-      s2 = __builtin_fmaf(wf, (float)((p >> 16) & 0xFFu), s2);
+      s2w = __builtin_elementwise_fma(mz_f2{wf, wf}, t2w, s2w);
     }
   }
-  const MzDivisor SW = mz_divisor(sw);
-  out[0] = mz_div((double)s01.x, SW); out[1] = mz_div((double)s01.y, SW); out[2] = mz_div((double)s2, SW);
+  const MzDivisor SW = mz_divisor((double)s2w.y);
+  out[0] = mz_div((double)s01.x, SW); out[1] = mz_div((double)s01.y, SW); out[2] = mz_div((double)s2w.x, SW);
 #else
   double sw = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0, bb[4];
 #pragma unroll
@@ -757,7 +758,11 @@ __device__ __forceinline__ uint8_t mz_spec_byte(double L, double A, double B, do
 #endif
   const double fr = v - __builtin_floor(v);
   doubt = doubt || !(fr > e && fr < 1.0 - e);
+#if XV_MAZE_SPEC32
+  return (uint8_t)(int)v;      // 0 <= v < 256 (see above); a doubtful or non-finite v is re-run by the caller anyway
+#else
   return mz_clip_u8(v);
+#endif
 }
 
 // Opt-in fp32 variant of the filter above (xv_maze_set_precision(XV_MAZE_FILTER_F32)): same 4x4 taps, same weights

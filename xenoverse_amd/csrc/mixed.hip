@@ -284,7 +284,6 @@ struct MixedPipe {
   size_t snap_cap;
   uint32_t* d_snap_w;    // 8 words, see MixedSnap::w
   uint32_t fell_seen;    // gate.h_issued[1] when the last overlapped call was issued
-  XvPipeBackoff backoff; // one-stream calls after a replayed one (xv_pipe.h)
 };
 // one per device, for the life of the process (side stream, events, tick and hand-off words, the cached graph set: a few
 // kilobytes; not released at exit — the HIP runtime may be gone by the time static destructors run)
@@ -474,7 +473,10 @@ static int mixed_pipe_run(xv_anymdp* a, xv_linds* l, xv_cartpole* c, const xv_mi
   static const int min_steps = getenv("XV_MIXED_PIPE_MIN_STEPS") ? atoi(getenv("XV_MIXED_PIPE_MIN_STEPS")) : XV_MIXED_PIPE_MIN;
   if (ring_cycles <= 0 || period % 2 != 0 || n_steps < min_steps) return XV_OK;
   if (M.failed && M.side_for == a->eng->stream) return XV_OK;      // tried beside this stream already
-  if (xv_pipe_backoff_step(&M.backoff, &M.gate)) return XV_OK;      // a recent call was replayed: the ordinary loop for a while
+  // a recent call with this handle was replayed: the ordinary loop for a while (the count lives in the AnyMDP handle — switching
+  // its overlap on again starts over — against this device's replay counter)
+  if (a->backoff_mixed.len == 0) xv_pipe_backoff_reset(&a->backoff_mixed, &M.gate);
+  if (xv_pipe_backoff_step(&a->backoff_mixed, &M.gate)) return XV_OK;
   M.failed = false;
   if (a->eng == l->eng || a->eng == c->eng || l->eng == c->eng) return XV_OK;      // one tick per family and step
   if (a->eng->dev_tick || l->eng->dev_tick || c->eng->dev_tick) return XV_OK;
