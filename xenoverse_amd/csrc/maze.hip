@@ -857,6 +857,27 @@ struct MzColumn {
   int v_s, v_e, text_id, pad;                                       // wall rows [v_s, v_e), wall texture
   double f_i, L, a_far, a_near, ratio, co, so, rcos_b, rcos_y, pad2;   // 96 bytes
 };
+__device__ __forceinline__ double mz_shfl_f64(double v, int src) {
+  return __hiloint2double(__shfl(__double2hiint(v), src), __shfl(__double2loint(v), src));
+}
+__device__ __forceinline__ MzColumn mz_column_of_lane(const MzColumn& m, int src) {   // all lanes of the wave call this
+  MzColumn r;
+  r.v_s = __shfl(m.v_s, src); r.v_e = __shfl(m.v_e, src); r.text_id = __shfl(m.text_id, src); r.pad = 0;
+  r.f_i = mz_shfl_f64(m.f_i, src); r.L = mz_shfl_f64(m.L, src); r.a_far = mz_shfl_f64(m.a_far, src);
+  r.a_near = mz_shfl_f64(m.a_near, src); r.ratio = mz_shfl_f64(m.ratio, src); r.co = mz_shfl_f64(m.co, src);
+  r.so = mz_shfl_f64(m.so, src); r.rcos_b = mz_shfl_f64(m.rcos_b, src); r.rcos_y = mz_shfl_f64(m.rcos_y, src); r.pad2 = 0.0;
+  return r;
+}
+// Pixels whose byte the speculated filter could not settle (about one in 100) are re-run in the reference's typing.  They sit
+// unevenly on the lanes: a wave that lets every lane re-run its own runs max-over-lanes rounds of the ~600-instruction exact
+// filter per block of 64 x 64 pixels (3 - 4 rounds for ~40 items: a tenth of the block's time).  So the items of a block are
+// SPREAD over the wave first: compacted into a per-wave list in LDS (each round the lanes that still hold an item append their
+// lowest one, ranked by a ballot), then item idx goes to lane idx % 64 — one round for up to 64 items.  What does not fit the list
+// stays on its lane (the loop behind the spread).
+#define MZ_REDO_LIST 128
+#ifndef XV_MAZE_REDO_SPREAD
+#define XV_MAZE_REDO_SPREAD 1
+#endif
 #ifndef XV_MAZE_RC_WAVES
 #define XV_MAZE_RC_WAVES 3   // waves per SIMD the register allocation aims at (2: 1.12 ms at 64 x 64, same at 256 x 256)
 #endif
@@ -867,6 +888,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
   constexpr bool PP = F32 || (SPEC && FILT == 0);   // which packed copy the pixels read
   constexpr bool ROWS = (FILT == 5 || FILT == 6) && PACKED;        // lanes = rows of one column in the pixel loop
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  __shared__ uint16_t redo_list[4][MZ_REDO_LIST];      // per wave: (lane | index << 6) of the pixels to re-run, see above
   const int e = blockIdx.x;
   if (FINAL && !P.fin_flag[e]) return;   // block-uniform
   const int W = P.W, H = P.H, NG = P.NG;
@@ -1066,6 +1088,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
       }
       return paint;
     };
+    // redo: the wave's items out of the lanes' masks, `exact(src_lane, j, have)` for each (all lanes call it; `have`: this lane
+    // holds an item)
+    auto redo_spread = [&](unsigned long long& redo, auto&& exact) {
+      const int wvi = threadIdx.x >> 6, ln = threadIdx.x & 63;
+      uint16_t* list = redo_list[wvi];
+      int total = 0;
+      for (;;) {
+        const unsigned long long holders = __ballot(redo != 0ull);
+        if (holders == 0ull) break;
+        const int nh = __popcll(holders);
+        if (total + nh > MZ_REDO_LIST) break;
+        if (redo != 0ull) {
+          const int j = __builtin_ctzll(redo);
+          redo &= redo - 1ull;
+          list[total + __popcll(holders & ((1ull << ln) - 1ull))] = (uint16_t)(ln | (j << 6));
+        }
+        total += nh;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS writes, before its lanes read each other's
+      for (int base = 0; base < total; base += 64) {
+        const int idx = base + ln;
+        const bool have = idx < total;
+        const uint32_t it = list[have ? idx : 0];
+        exact((int)(it & 63u), (int)(it >> 6), have);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the list is free again
+    };
     MzColumn* colp = reinterpret_cast<MzColumn*>(rowtab + H);   // ROWS: the columns of this batch, behind the row table
     if (ROWS) colp[threadIdx.x] = me;
     for (int c0 = 0; c0 < H; c0 += HC) {
@@ -1109,6 +1158,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
               }
             }
             if (act) { px[0] = b0; px[1] = b1; px[2] = b2; }
+          }
+          if (SPEC && XV_MAZE_REDO_SPREAD) {
+            redo_spread(redo, [&](int src_lane, int kk, bool have) {
+              if (!have) return;
+              const int dv2 = r0 + src_lane, cc = wv + kk * nw;      // (only lanes with a row of this block recorded items)
+              const MzColumn C = colp[cc];
+              const void* tx;
+              double f_i, f_j, f_d, L, A, B, c[3];
+              (void)pixel(C, dv2, tx, f_i, f_j, f_d, L, A, B);
+              uint32_t qw[4][4];
+              mz_fetch_window<PP>(tx, (int)f_i, (int)f_j, qw);
+              mz_interpolate<true, true>(nullptr, f_i, f_j, f_d, tps, tps, c, qw);
+              uint8_t* px = lds + (size_t)cc * cstride + (dv2 - c0) * 3;
+              px[0] = mz_clip_u8(L * (A + B * c[0]));
+              px[1] = mz_clip_u8(L * (A + B * c[1]));
+              px[2] = mz_clip_u8(L * (A + B * c[2]));
+            });
           }
           if (SPEC) {
             while (redo) {   // per lane: the pixels whose byte the speculation could not settle, in the reference's typing
@@ -1160,6 +1226,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
           } else {
             px[0] = 1; px[1] = 1; px[2] = 1;
           }
+        }
+        if (SPEC && XV_MAZE_REDO_SPREAD) {
+          redo_spread(redo, [&](int src_lane, int j, bool have) {
+            const MzColumn C = mz_column_of_lane(me, src_lane);      // the item's column lives in its lane's registers
+            if (!have) return;
+            const int dv2 = r0 + j;
+            const void* tx;
+            double f_i, f_j, f_d, L, A, B, c[3];
+            (void)pixel(C, dv2, tx, f_i, f_j, f_d, L, A, B);
+            uint32_t qw[4][4];
+            mz_fetch_window<PP>(tx, (int)f_i, (int)f_j, qw);
+            mz_interpolate<true, true>(nullptr, f_i, f_j, f_d, tps, tps, c, qw);
+            uint8_t* px = lds + (size_t)((threadIdx.x & ~63u) + (unsigned)src_lane) * cstride + (dv2 - c0) * 3;
+            px[0] = mz_clip_u8(L * (A + B * c[0]));
+            px[1] = mz_clip_u8(L * (A + B * c[1]));
+            px[2] = mz_clip_u8(L * (A + B * c[2]));
+          });
         }
         if (SPEC) {
           while (redo) {
