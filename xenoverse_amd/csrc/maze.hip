@@ -51,6 +51,14 @@ __device__ __forceinline__ double mz_div(double a, const MzDivisor& r) {   // ==
   return __builtin_fma(__builtin_fma(-r.b, q0, a), r.y, q0);
 }
 
+// 1 / b to ~2^-40 or better (v_rcp_f64, accurate to at least 2^-20 — the ISA guide says about 2^-24 —, and ONE Newton step, which
+// squares the error): for the SPECULATED filter only, whose bound has room for it (MZ_SPEC_KAPPA) — never for a value the
+// reference computes by a division
+__device__ __forceinline__ double mz_rcp_spec(double b) {
+  const double y = __builtin_amdgcn_rcp(b);
+  return __builtin_fma(y, __builtin_fma(-b, y, 1.0), y);
+}
+
 // dynamics.py:56-69
 __device__ __forceinline__ double mz_nearest_point(double p0, double p1, double l10, double l11, double l20,
                                                    double l21, double& n0, double& n1) {
@@ -676,7 +684,9 @@ __device__ __forceinline__ void mz_interpolate(const void* __restrict__ texv, do
 //     each of the 16 roundings is at most 2^-24 of the final sum: |s' - sum w' t| <= 17 * 2^-24 (1 + 2e-6) sum w' t = 1.0133e-6.
 //     The weight sum runs in the same float32 chain (sw' <- fl32(fma(wf, 1, sw')), the second lane of the v_pk_fma_f32 that sums
 //     the third channel): |sw' - sum w'| <= 17 * 2^-24 (1 + 2e-6) sum w' likewise.
-//   so c' = s' / sw' has |c' - c| <= (2 * 1.0133e-6 + 9.5368e-7 * 1.000001 + 3e-12) c < 2.981e-6 c'(1 + 4e-6): KAPPA = 3.0e-6 (0.97e-6
+//   * 10 / d2 and 1 / sw' come from v_rcp_f64 + one Newton step (mz_rcp_spec: within 1e-12; the weights then move by < 1e-10 of
+//     themselves, the colour by 1e-12): 12 instructions fewer than two correctly rounded divisor set-ups and three quotients.
+//   so c' = s' / sw' has |c' - c| <= (2 * 1.0133e-6 + 9.5368e-7 * 1.000001 + 3e-10) c < 2.981e-6 c'(1 + 4e-6): KAPPA = 3.0e-6 (0.97e-6
 //     for the float64 sums), and about one pixel in 100 instead of one in 300 is re-run in the reference's typing.
 //   * byte: v' = fma(L B, c', L A) instead of L (A + B c') (three roundings of values < 2^9 either way: inside the absolute 1e-9),
 //     bound e = fma(v', KAPPA, 1e-9) >= L B c' KAPPA + 1e-9 (L, A, B >= 0).  0 <= v' <= 255 (L <= 1, A + B = 1, c' <= 255 (1 + 3e-6);
@@ -695,7 +705,11 @@ __device__ __forceinline__ void mz_interpolate_spec(const uint32_t (&qw)[4][4], 
                                                     double (&out)[3]) {
   double d2 = d * d;
   if (d2 < 1.0e-8) d2 = 1.0e-8;
+#if XV_MAZE_SPEC32
+  const double k10 = 10.0 * mz_rcp_spec(d2);         // 10 / d2 within 1e-12: the weights move by < 1e-12 absolute, 1e-10 of themselves
+#else
   const double k10 = mz_div(10.0, mz_divisor(d2));   // == 10 / d2, correctly rounded
+#endif
   const int ib = (int)i, jb = (int)j;
 #if XV_MAZE_SPEC32
   double nbb[4];
@@ -720,8 +734,8 @@ __device__ __forceinline__ void mz_interpolate_spec(const uint32_t (&qw)[4][4], 
       s2w = __builtin_elementwise_fma(mz_f2{wf, wf}, t2w, s2w);
     }
   }
-  const MzDivisor SW = mz_divisor((double)s2w.y);
-  out[0] = mz_div((double)s01.x, SW); out[1] = mz_div((double)s01.y, SW); out[2] = mz_div((double)s2w.x, SW);
+  const double isw = mz_rcp_spec((double)s2w.y);      // (1e-12 of the colour: inside the bound's slack)
+  out[0] = (double)s01.x * isw; out[1] = (double)s01.y * isw; out[2] = (double)s2w.x * isw;
 #else
   double sw = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0, bb[4];
 #pragma unroll
