@@ -2435,29 +2435,25 @@ static int anymdp_pipe_launch(xv_anymdp* h, hipGraphExec_t* ex, int cycles, int 
 // deadlock on the hardware queues: streams are mapped onto a few queues, each in order, and a launch that waits for a wave
 // of a launch queued BEHIND another handle's waiting launch never gets it (measured: two views, each overlapped, 4.5 us
 // per step instead of 3.6; four, their waits ran into the bound — scripts/devtools/probe_views_overlap.py).
-static std::mutex g_overlap_mu;
-static xv_anymdp* g_overlap_owner[64] = {nullptr};
-
+// (the slot is the device's, shared with the other families' overlapped paths: engine.hip, xv_device_overlap_acquire)
 extern "C" int xv_anymdp_set_step_many_overlap(xv_anymdp* h, int on) {
   XV_CHECK_ARG(h != nullptr && (on == 0 || on == 1));
   const int dev = h->eng->device;
   XV_CHECK_ARG(dev >= 0 && dev < 64);
-  std::lock_guard<std::mutex> lock(g_overlap_mu);
   if (on) {
     if (h->parent != nullptr) {
       xv_set_error("xv_anymdp_set_step_many_overlap: not on a view (overlap the parent's step_many instead)");
       return XV_ERR_UNSUPPORTED;
     }
-    if (g_overlap_owner[dev] != nullptr && g_overlap_owner[dev] != h) {
+    if (!xv_device_overlap_acquire(dev, h)) {
       xv_set_error("xv_anymdp_set_step_many_overlap: another handle on device %d has the overlap on; one at a time", dev);
       return XV_ERR_UNSUPPORTED;
     }
-    g_overlap_owner[dev] = h;
     h->pipe_failed = false;
     xv_pipe_backoff_reset(&h->backoff, &h->gate);
     h->backoff_mixed.len = 0;      // (mixed.hip starts it over against its own replay counter)
-  } else if (g_overlap_owner[dev] == h) {
-    g_overlap_owner[dev] = nullptr;
+  } else {
+    xv_device_overlap_release(dev, h);
   }
   h->overlap = on;
   return XV_OK;

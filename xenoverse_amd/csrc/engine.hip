@@ -1,5 +1,7 @@
 // engine.hip — engine handle (device + stream + Philox key + sticky device error word).
 #include "philox.h"
+#include <mutex>
+
 #include "xv_common.h"
 #include "xv_pipe.h"
 
@@ -105,6 +107,23 @@ static __global__ void xv_tick_add3_kernel(uint64_t* t0, uint64_t* t1, uint64_t*
   if (t1 != t0) *t1 += d1;
   if (t2 != t0 && t2 != t1) *t2 += d2;
 }
+// ONE handle per device may issue overlapped step_many calls at a time (two overlapped calls in flight can block each other on the
+// hardware queues their streams share): the slot, whatever the family of the handle that holds it
+static std::mutex g_overlap_slot_mu;
+static const void* g_overlap_slot[64] = {nullptr};
+bool xv_device_overlap_acquire(int device, const void* owner) {
+  if (device < 0 || device >= 64) return false;
+  std::lock_guard<std::mutex> lock(g_overlap_slot_mu);
+  if (g_overlap_slot[device] != nullptr && g_overlap_slot[device] != owner) return false;
+  g_overlap_slot[device] = owner;
+  return true;
+}
+void xv_device_overlap_release(int device, const void* owner) {
+  if (device < 0 || device >= 64) return;
+  std::lock_guard<std::mutex> lock(g_overlap_slot_mu);
+  if (g_overlap_slot[device] == owner) g_overlap_slot[device] = nullptr;
+}
+
 // live RCCL communicators of this process per device (rccl_gather.hip counts them; xv_pipe.h reads the figure)
 static int g_device_collectives[64] = {0};
 void xv_device_note_collective(int device, int delta) {

@@ -60,6 +60,8 @@ static inline int xv_div_up(int a, int b) { return (a + b - 1) / b; }
 // makes a step capturable in a hipGraph / torch.cuda.graph): a one-thread kernel advances *d_tick by `ticks` FIRST, and
 // the launch reads *d_tick + (0 - ticks) — so that every entry point stays "bind, then launch" and a replayed graph
 // draws fresh numbers at every replay.  Kernels evaluate xv_launch_tick(P.tick, P.tick_dev).
+bool xv_device_overlap_acquire(int device, const void* owner);   // engine.hip: the device's one overlapped-step_many slot
+void xv_device_overlap_release(int device, const void* owner);
 void xv_device_note_collective(int device, int delta);   // engine.hip: live RCCL communicators of this process per device
 int xv_device_collectives(int device);
 void xv_engine_advance_device_tick(xv_engine* e, uint64_t ticks);
