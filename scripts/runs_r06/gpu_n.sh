@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, visit n: overlapped xv_linds_step_many — parity, replay, and what it buys at 16,384 ... 65,536 envs (config 3: one launch
+# round 6, visit n (the overlapped xv_linds_step_many was removed after this run: DESIGN.md 4.1; the script is kept as the record of what ran):
 # fills the device, the second cannot be resident with it: XV_LINDS_PIPE_FORCE=1 tries it all the same)
 set -u
 mkdir -p gpurun_out
