@@ -70,3 +70,40 @@ def test_floor_probe_is_keyed_by_source_hashes():
         assert d.get("probe_source_sha16") and "kernel_source_sha16" in d
     fl = bench.floor_probe()
     assert "kernel_source_sha16" in fl and fl["source"]
+
+
+def test_the_cpython_trampoline_calls_the_c_abi_like_ctypes():
+    """xenoverse_amd/_xvfast.so (csrc/xvfast.c, built by xenoverse_amd.build.build_fast with gcc): `icall(fn, *ints)` makes the
+    same C-ABI call ctypes makes — checked on entry points that need no GPU (the version, and argument validation)"""
+    import pytest
+    from xenoverse_amd import _lib
+    from xenoverse_amd import build as xb
+    try:
+        xb.build_fast()
+    except RuntimeError as ex:
+        pytest.skip("no Python.h / gcc here: %s" % (ex,))
+    _lib._fast[0], _lib._fast[1] = None, False
+    f = _lib.fast()
+    assert f is not None
+    lib = _lib.load()
+    assert f.icall(_lib.fn_address("xv_abi_version")) == lib.xv_abi_version() == _lib.ABI_VERSION
+    # null handle: XV_ERR_INVALID from the library's own argument check, through both bindings
+    assert f.icall(_lib.fn_address("xv_anymdp_step_info"), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2) == _lib.XV_ERR_INVALID
+    assert lib.xv_anymdp_step_info(None, None, None, None, None, None, None, None, None, None, 2) == _lib.XV_ERR_INVALID
+    assert f.icall(_lib.fn_address("xv_linds_step_info"), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2) == _lib.XV_ERR_INVALID
+    assert b"" != lib.xv_last_error()
+    with pytest.raises(TypeError):
+        f.icall(*([_lib.fn_address("xv_abi_version")] + [0] * 15))
+    with pytest.raises(ValueError):
+        f.icall(0)
+    with pytest.raises(TypeError):
+        f.icall(_lib.fn_address("xv_abi_version"), "not an int")
+
+
+def test_the_trampoline_is_optional(monkeypatch):
+    from xenoverse_amd import _lib
+    monkeypatch.setenv("XV_NO_FAST", "1")
+    _lib._fast[0], _lib._fast[1] = None, False
+    assert _lib.fast() is None                      # the ctypes path serves
+    monkeypatch.delenv("XV_NO_FAST")
+    _lib._fast[0], _lib._fast[1] = None, False

@@ -183,6 +183,32 @@ def load():
     return lib
 
 
+_fast = [None, False]      # (module or None, tried)
+
+
+def fast():
+    """the CPython trampoline `_xvfast` (xenoverse_amd/_xvfast.so, built by xenoverse_amd.build.build_fast) or None: a shortcut
+    for the BINDING of a few hot calls — ctypes serves the same C-ABI without it (XV_NO_FAST=1 forces that)"""
+    if not _fast[1]:
+        _fast[1] = True
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_xvfast.so")
+        if os.path.exists(path) and not os.environ.get("XV_NO_FAST"):
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("_xvfast", path)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                _fast[0] = mod
+            except Exception:
+                _fast[0] = None
+    return _fast[0]
+
+
+def fn_address(name):
+    """address of a C-ABI entry point (for _xvfast.icall)"""
+    return C.cast(getattr(load(), name), C.c_void_p).value
+
+
 def check(rc):
     if rc != 0:
         msg = load().xv_last_error()

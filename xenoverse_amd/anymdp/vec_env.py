@@ -203,6 +203,7 @@ class AnyMDPVecEnv(VectorEnv):
                                   ("obs", "reward", "reward_gt", "term", "trunc", "final_obs"))
                 b["steps_p"] = C.c_void_p(b["steps"].data_ptr())
                 b["done_p"] = C.c_void_p(b["done"].data_ptr())
+                b["ints"] = tuple(x.value for x in b["args"]) + (b["steps"].data_ptr(), b["done"].data_ptr())
                 self._ring.append(b)
 
     SEARCH = {"auto": 0, "binary": 1, "fence": 3, "bucket": 4}
@@ -429,7 +430,13 @@ class AnyMDPVecEnv(VectorEnv):
                 self._ring_pos ^= 1
             lib, mode = self.lib, AUTORESET[self.autoreset_mode]
             # ONE launch: the step kernel writes info["steps"] and the terminated | truncated mask itself (xv_anymdp_step_info)
-            _lib.check(lib.xv_anymdp_step_info(self._h, C.c_void_p(a.data_ptr()), *b["args"], b["steps_p"], b["done_p"], mode))
+            f = _lib.fast()
+            if f is not None:
+                rc = f.icall(self._fn_step_info(), self._h.value, a.data_ptr(), *b["ints"], mode)
+                if rc:
+                    _lib.check(rc)
+            else:
+                _lib.check(lib.xv_anymdp_step_info(self._h, C.c_void_p(a.data_ptr()), *b["args"], b["steps_p"], b["done_p"], mode))
             infos = {"steps": b["steps"], "reward_gt": b["reward_gt"]}
             if mode == 2:
                 infos["final_obs"] = b["final_obs"]
@@ -438,9 +445,15 @@ class AnyMDPVecEnv(VectorEnv):
         if self.copy and not self.to_numpy and not self.with_transition_gt:
             # copy=True without copies and without allocations: the step writes every output for every env into the next set of
             # a slab made for 64 steps at once (vector.OutputSlabs); what earlier steps handed out is never written again
-            t, p = self._slab_next()
+            t, p, pi = self._slab_next3()
             mode = AUTORESET[self.autoreset_mode]
-            _lib.check(self.lib.xv_anymdp_step_info(self._h, C.c_void_p(a.data_ptr()), *p, mode))
+            f = _lib.fast()
+            if f is not None:      # the CPython trampoline (csrc/xvfast.c): the same call without ctypes' marshalling
+                rc = f.icall(self._fn_step_info(), self._h.value, a.data_ptr(), *pi, mode)
+                if rc:
+                    _lib.check(rc)
+            else:
+                _lib.check(self.lib.xv_anymdp_step_info(self._h, C.c_void_p(a.data_ptr()), *p, mode))
             self._obs = t["obs"]      # (reset() and the accessors read the latest observation from here)
             infos = {"steps": t["steps"], "reward_gt": t["reward_gt"]}
             if mode == 2:
@@ -462,16 +475,26 @@ class AnyMDPVecEnv(VectorEnv):
             infos["transition_gt"] = self._out(self._tgt.clone())
         return (self._of(self._obs), self._of(self._reward), self._obf(self._term), self._obf(self._trunc), infos)
 
+    _FN_STEP_INFO = [None]
+
+    def _fn_step_info(self):
+        if self._FN_STEP_INFO[0] is None:
+            self._FN_STEP_INFO[0] = _lib.fn_address("xv_anymdp_step_info")
+        return self._FN_STEP_INFO[0]
+
     def _slab_next(self):
+        return self._slab_next3()[:2]
+
+    def _slab_next3(self):
         """copy=True: the next output set of a 64-step slab (vector.OutputSlabs) -> (dict of tensors, pointers in the order
-        obs, reward, reward_gt, term, trunc, final_obs, steps, done)"""
+        obs, reward, reward_gt, term, trunc, final_obs, steps, done — as ctypes objects and as ints)"""
         if self._slabs is None:
             i32, f32, u8 = torch.int32, torch.float32, torch.uint8
             self._slabs = OutputSlabs([("obs", i32, ()), ("final_obs", i32, ()), ("steps", i32, ()), ("reward", f32, ()),
                                        ("reward_gt", f32, ()), ("term", u8, ()), ("trunc", u8, ()), ("done", u8, ())],
                                       self.num_envs, self.device, K=64, as_bool=("term", "trunc", "done"),
                                       order=("obs", "reward", "reward_gt", "term", "trunc", "final_obs", "steps", "done"))
-        return self._slabs.next()
+        return self._slabs.next3()
 
     def step_injected(self, actions, u, z, u_reset):
         """Parity hook (C-ABI xv_anymdp_step_injected): random inputs supplied per env."""

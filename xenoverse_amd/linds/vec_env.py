@@ -209,6 +209,8 @@ class LinDSVecEnv(VectorEnv):
         return dict(key=(self._obs.data_ptr(), self._fobs.data_ptr(), self._done.data_ptr()),
                     args=tuple(C.c_void_p(t.data_ptr()) for t in (self._obs, self._reward, self._term, self._trunc, self._cmd,
                                                                   self._error, self._fobs, self._steps, self._done)),
+                    ints=tuple(t.data_ptr() for t in (self._obs, self._reward, self._term, self._trunc, self._cmd,
+                                                      self._error, self._fobs, self._steps, self._done)),
                     obs=self._user_obs(self._obs), cmd=self._user_obs(self._cmd), fobs=self._user_obs(self._fobs),
                     term_b=self._term.view(torch.bool), trunc_b=self._trunc.view(torch.bool),
                     done_b=self._done.view(torch.bool))
@@ -249,7 +251,13 @@ class LinDSVecEnv(VectorEnv):
             c = self._step_cache
             if c is None or c["key"] != (self._obs.data_ptr(), self._fobs.data_ptr(), self._done.data_ptr()):
                 c = self._step_cache = self._make_step_cache()
-            _lib.check(self.lib.xv_linds_step_info(self._h, C.c_void_p(a.data_ptr()), *c["args"], AUTORESET[self.autoreset_mode]))
+            f = _lib.fast()
+            if f is not None:
+                rc = f.icall(self._fn_step_info(), self._h.value, a.data_ptr(), *c["ints"], AUTORESET[self.autoreset_mode])
+                if rc:
+                    _lib.check(rc)
+            else:
+                _lib.check(self.lib.xv_linds_step_info(self._h, C.c_void_p(a.data_ptr()), *c["args"], AUTORESET[self.autoreset_mode]))
             infos = {"steps": self._steps, "command": c["cmd"], "error": self._error}
             if self.autoreset_mode == "same_step":
                 infos["final_obs"] = c["fobs"]
@@ -259,8 +267,14 @@ class LinDSVecEnv(VectorEnv):
             # copy=True without copies, allocations or new tensor objects: the step writes every output of every env into the next
             # set of a slab made for 64 steps (vector.OutputSlabs; recycled once nobody can reach it); final_obs — written for
             # finished envs only — is zero-filled once per slab, so unfinished envs read zero rows as before
-            t, p = self._slab_next()
-            _lib.check(self.lib.xv_linds_step_info(self._h, C.c_void_p(a.data_ptr()), *p, AUTORESET[self.autoreset_mode]))
+            t, p, pi = self._slab_next3()
+            f = _lib.fast()
+            if f is not None:      # the CPython trampoline (csrc/xvfast.c): the same call without ctypes' marshalling
+                rc = f.icall(self._fn_step_info(), self._h.value, a.data_ptr(), *pi, AUTORESET[self.autoreset_mode])
+                if rc:
+                    _lib.check(rc)
+            else:
+                _lib.check(self.lib.xv_linds_step_info(self._h, C.c_void_p(a.data_ptr()), *p, AUTORESET[self.autoreset_mode]))
             self._obs, self._cmd, self._error = t["obs"], t["cmd"], t["error"]      # (reset() and the accessors read these)
             infos = {"steps": t["steps"], "command": t["cmd_u"], "error": t["error"]}
             if self.autoreset_mode == "same_step":
@@ -279,9 +293,19 @@ class LinDSVecEnv(VectorEnv):
             infos["_final_obs"] = self._obf(self._done)
         return (self._of(self._user_obs(self._obs)), self._of(self._reward), self._obf(self._term), self._obf(self._trunc), infos)
 
+    _FN_STEP_INFO = [None]
+
+    def _fn_step_info(self):
+        if self._FN_STEP_INFO[0] is None:
+            self._FN_STEP_INFO[0] = _lib.fn_address("xv_linds_step_info")
+        return self._FN_STEP_INFO[0]
+
     def _slab_next(self):
+        return self._slab_next3()[:2]
+
+    def _slab_next3(self):
         """copy=True: the next output set of a 64-step slab -> (dict of tensors incl. the user's columns obs_u / cmd_u / fobs_u,
-        pointers in the order obs, reward, term, trunc, cmd, error, fobs, steps, done)"""
+        pointers in the order obs, reward, term, trunc, cmd, error, fobs, steps, done — as ctypes objects and as ints)"""
         if self._slabs is None:
             f32, u8, i32, NO = torch.float32, torch.uint8, torch.int32, self.NO
             uo = self.user_dims[1]
@@ -292,7 +316,7 @@ class LinDSVecEnv(VectorEnv):
                                       order=("obs", "reward", "term", "trunc", "cmd", "error", "fobs", "steps", "done"),
                                       derived={"obs_u": ("obs", cut), "cmd_u": ("cmd", cut), "fobs_u": ("fobs", cut)},
                                       zero_on_refill=("fobs",))
-        return self._slabs.next()
+        return self._slabs.next3()
 
     def step_injected(self, actions, z, init_index):
         """Parity hook: z float[NS, N] standard normals (process noise), init_index int[N] (used on reset)."""

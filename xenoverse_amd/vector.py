@@ -88,7 +88,8 @@ class OutputSlabs(object):
             for k in range(self.K):
                 per_step[k][name] = fn(per_step[k][field])
         rec = {"zero": zero_blocks,
-               "sets": [(per_step[k], tuple(ptrs[k][name] for name in self.order)) for k in range(self.K)],
+               "sets": [(per_step[k], tuple(ptrs[k][name] for name in self.order), tuple(ptrs[k][name].value for name in self.order))
+                        for k in range(self.K)],
                "flat": [t for d in per_step for t in d.values()] + per_step, "tensors": [t for d in per_step for t in d.values()],
                "storages": storages}      # (`flat` counts the per-step dicts too: next() hands them out)
         self.made += 1
@@ -125,6 +126,10 @@ class OutputSlabs(object):
     def next(self):
         """-> (dict name -> tensor, tuple of ctypes pointers in `order`) of a set no earlier step has written — or one whose
         earlier contents nobody can reach any more"""
+        return self.next3()[:2]
+
+    def next3(self):
+        """next() plus the same pointers as plain ints (for _xvfast.icall)"""
         if self._pos >= len(self._sets):
             self._refill()
         s = self._sets[self._pos]
