@@ -305,7 +305,7 @@ def live_pmc_traffic(args):
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK"):
                 env.pop(k, None)
-            r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=300)
+            r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=150)      # (a pass takes 6-10 s)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 shutil.rmtree(d, ignore_errors=True)
