@@ -584,7 +584,15 @@ __device__ __forceinline__ void mz_fetch_window(const void* __restrict__ texv, i
   const uint4* s0 = reinterpret_cast<const uint4*>(tb + ((size_t)p0 * MZ_TEX_PITCH + ys) * 2);
   const uint4* s1 = reinterpret_cast<const uint4*>(tb + ((size_t)p1 * MZ_TEX_PITCH + ys) * 2);
   const uint4* s2 = reinterpret_cast<const uint4*>(tb + ((size_t)p2 * MZ_TEX_PITCH + ys) * 2);
-  const uint4 a0 = s0[0], b0 = s0[1], a1 = s1[0], b1 = s1[1], a2 = s2[0], b2 = s2[1];   // dword-aligned 16-byte loads
+  const uint4 a0 = s0[0], b0 = s0[1], a1 = s1[0], b1 = s1[1];   // dword-aligned 16-byte loads
+  uint4 a2 = s2[0], b2 = s2[1];
+  // only words x and z of the third span are used: left alone, hipcc narrows its two 16-byte loads to FOUR dword loads, and
+  // every load instruction is one L1 access per lane (the lanes' windows share no lines) — 8.2 accesses per pixel at 0.96 per
+  // CU and cycle; with the span fetched whole 6.2 at 0.77, the 64 x 64 ray cast 0.99 -> 0.94 ms (profiles/r06_u_*, r06_v_*).
+  // What the fetch costs beyond that is LINES, not instructions: the row-major copy (four loads, four lines per window) and a
+  // pair copy held in both phases (four loads, two lines, no selects — but twice the bytes in the 4-MB L2s) both run 1.09-1.10 ms
+  // (r06_w_*)
+  asm volatile("" : "+v"(a2.x), "+v"(a2.y), "+v"(a2.z), "+v"(a2.w), "+v"(b2.x), "+v"(b2.y), "+v"(b2.z), "+v"(b2.w));
   // row 0: span 0, member `odd`
   q[0][0] = odd ? a0.y : a0.x; q[0][1] = odd ? a0.w : a0.z; q[0][2] = odd ? b0.y : b0.x; q[0][3] = odd ? b0.w : b0.z;
   // row 1: even -> span 0 member 1; odd -> span 1 member 0
@@ -1466,7 +1474,11 @@ static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, b
   const bool packed = a.pk_walls != nullptr;
   // FILT of the kernel: 0 / 3 the speculated exact filter on the pair / row-major texture copy, 1 fp32, 2 direct, 5 / 6 = 3 / 1 on rows
   const int filt0 = h->filter != XV_MAZE_FILTER_EXACT ? h->filter : (packed && (size_t)a.W * a.H > 128 * 128 ? 3 : 0);
-  const int filt = !packed || !rows_map ? filt0 : (filt0 == 1 ? 6 : ((filt0 == 3 || (filt0 == 0 && rows_map == 3)) ? 5 : filt0));
+  int filt = !packed || !rows_map ? filt0 : (filt0 == 1 ? 6 : ((filt0 == 3 || (filt0 == 0 && rows_map == 3)) ? 5 : filt0));
+  if (packed && h->filter == XV_MAZE_FILTER_EXACT && getenv("XV_MAZE_FILT")) {      // devtools A/B: 0 / 3 / 5, all the same bytes
+    const int f = atoi(getenv("XV_MAZE_FILT"));
+    if (f == 0 || f == 3 || f == 5) filt = f;
+  }
   const size_t lds_bytes = (((size_t)threads * (a.HC * 3 + 4) + 15) & ~(size_t)15) + (size_t)a.H * 16 +
                            (filt >= 5 ? (size_t)threads * sizeof(MzColumn) : 0);
 #define MAZE_RC(F, K, Q, B) \
