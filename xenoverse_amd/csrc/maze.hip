@@ -591,8 +591,12 @@ __device__ __forceinline__ void mz_fetch_window(const void* __restrict__ texv, i
   // CU and cycle; with the span fetched whole 6.2 at 0.77, the 64 x 64 ray cast 0.99 -> 0.94 ms (profiles/r06_u_*, r06_v_*).
   // What the fetch costs beyond that is LINES, not instructions: the row-major copy (four loads, four lines per window) and a
   // pair copy held in both phases (four loads, two lines, no selects — but twice the bytes in the 4-MB L2s) both run 1.09-1.10 ms
-  // (r06_w_*)
-  asm volatile("" : "+v"(a2.x), "+v"(a2.y), "+v"(a2.z), "+v"(a2.w), "+v"(b2.x), "+v"(b2.y), "+v"(b2.z), "+v"(b2.w));
+  // (r06_w_*).  Word y is made "used" through a zero the compiler cannot see (one v_and_or_b32 per load): a 12-byte load each,
+  // and no wait at this point (an empty asm taking the words as operands would force one, which the prefetching loop cannot have)
+  uint32_t z0;
+  asm("s_mov_b32 %0, 0" : "=s"(z0));
+  a2.x |= a2.y & z0;
+  b2.x |= b2.y & z0;
   // row 0: span 0, member `odd`
   q[0][0] = odd ? a0.y : a0.x; q[0][1] = odd ? a0.w : a0.z; q[0][2] = odd ? b0.y : b0.x; q[0][3] = odd ? b0.w : b0.z;
   // row 1: even -> span 0 member 1; odd -> span 1 member 0
@@ -900,11 +904,25 @@ __device__ __forceinline__ MzColumn mz_column_of_lane(const MzColumn& m, int src
 #ifndef XV_MAZE_REDO_SPREAD
 #define XV_MAZE_REDO_SPREAD 1
 #endif
+// the frame flush as nontemporal stores: a launch writes 201 MB (64 x 64) / 3.2 GB (256 x 256) of frames through the 4-MB L2s that
+// hold the texels; as streaming lines they displace fewer of them (L2 misses 5.7e6 -> 4.0e6 per 64 x 64 launch, 0.943 -> 0.927 ms,
+// 10.58 -> 10.36 ms at 256 x 256: profiles/r06_y_*)
+#ifndef XV_MAZE_NT_FLUSH
+#define XV_MAZE_NT_FLUSH 1
+#endif
+// Columns mapping, speculated filter (FILT 0 / 3 on packed textures): the window of the NEXT pixel is requested before the current
+// one is filtered.  That takes 206 registers, i.e. two waves per SIMD instead of three — and still wins: 0.925 -> 0.885 ms at
+// 64 x 64 (two pixels ahead, 241 registers: 0.90; three waves per SIMD with the 29 spills that forces: 1.04).  The rows mapping
+// does not take it: 10.40 -> 10.52 ms at 256 x 256, where issue is 86 % busy already (profiles/r06_zz*)
+#ifndef XV_MAZE_PREFETCH
+#define XV_MAZE_PREFETCH 1
+#endif
+#define MZ_RC_WAVES_OF(FILT, PACKED) ((XV_MAZE_PREFETCH && (PACKED) && ((FILT) == 0 || (FILT) == 3)) ? 2 : XV_MAZE_RC_WAVES)
 #ifndef XV_MAZE_RC_WAVES
 #define XV_MAZE_RC_WAVES 3   // waves per SIMD the register allocation aims at (2: 1.12 ms at 64 x 64, same at 256 x 256)
 #endif
 template <bool FINAL, bool PACKED, int FILT, bool NB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_WAVES, XV_MAZE_RC_WAVES))) void maze_raycast_kernel(MazeArgs P, uint8_t* frames, float* command_rgb) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MZ_RC_WAVES_OF(FILT, PACKED), MZ_RC_WAVES_OF(FILT, PACKED)))) void maze_raycast_kernel(MazeArgs P, uint8_t* frames, float* command_rgb) {
   using RT = typename std::conditional<NB, double, float>::type;
   constexpr bool F32 = FILT == 1 || FILT == 6, SPEC = (FILT == 0 || FILT == 3 || FILT == 5) && PACKED;
   constexpr bool PP = F32 || (SPEC && FILT == 0);   // which packed copy the pixels read
@@ -1222,6 +1240,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
       for (int r0 = c0; r0 < c1; r0 += SPEC ? 64 : HC) {
         const int r1 = SPEC ? min(r0 + 64, c1) : c1;
         unsigned long long redo = 0ull;
+#if XV_MAZE_PREFETCH
+        if (SPEC) {
+          // software pipeline: the window of pixel k + 1 is requested before pixel k is filtered, so a wave's texel round trip
+          // (an L2 miss for at least one of its 64 lanes in nearly every row) runs under its own arithmetic.  Unpainted pixels
+          // fetch and filter the wall texture at (0, 0) — valid addresses, bytes discarded — so no branch separates the stages.
+          struct PxGeo { double f_i, f_j, f_d, L, A, B; bool paint; };
+          auto stage1 = [&](int d_v, PxGeo& g, uint32_t (&qw)[4][4]) {
+            const void* tx;
+            g.paint = pixel(me, d_v, tx, g.f_i, g.f_j, g.f_d, g.L, g.A, g.B);
+            mz_fetch_window<PP>(tx, (int)g.f_i, (int)g.f_j, qw);
+          };
+          auto stage2 = [&](int d_v, const PxGeo& g, const uint32_t (&qw)[4][4]) {
+            double c[3];
+            mz_interpolate_spec(qw, g.f_i, g.f_j, g.f_d, tps, c);
+            bool doubt = false;
+            const uint8_t b0 = mz_spec_byte(g.L, g.A, g.B, c[0], doubt);
+            const uint8_t b1 = mz_spec_byte(g.L, g.A, g.B, c[1], doubt);
+            const uint8_t b2 = mz_spec_byte(g.L, g.A, g.B, c[2], doubt);
+            uint8_t* px = col + (d_v - c0) * 3;
+            px[0] = g.paint ? b0 : (uint8_t)1; px[1] = g.paint ? b1 : (uint8_t)1; px[2] = g.paint ? b2 : (uint8_t)1;
+            redo |= (unsigned long long)(doubt && g.paint) << (d_v - r0);
+          };
+          PxGeo gA, gB;
+          uint32_t qA[4][4], qB[4][4];
+          stage1(r0, gA, qA);
+          for (int d_v = r0; d_v < r1; d_v += 2) {
+            stage1(min(d_v + 1, r1 - 1), gB, qB);
+            stage2(d_v, gA, qA);
+            stage1(min(d_v + 2, r1 - 1), gA, qA);
+            if (d_v + 1 < r1) stage2(d_v + 1, gB, qB);
+          }
+        } else
+#endif
         for (int d_v = r0; d_v < r1; ++d_v) {
           const void* tx;
           double f_i, f_j, f_d, L, A, B;
@@ -1327,7 +1378,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XV_MAZE_RC_
             const uint32_t* sp = reinterpret_cast<const uint32_t*>(lds + (size_t)c * cstride + v * 16);
             uint4 val;
             val.x = sp[0]; val.y = sp[1]; val.z = sp[2]; val.w = sp[3];
+#if XV_MAZE_NT_FLUSH
+            typedef uint32_t mz_u4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(mz_u4{val.x, val.y, val.z, val.w}, reinterpret_cast<mz_u4*>(gdst + (size_t)c * H * 3 + v * 16));
+#else
             *reinterpret_cast<uint4*>(gdst + (size_t)c * H * 3 + v * 16) = val;
+#endif
           }
         } else {
           for (int k = threadIdx.x; k < ncols * run; k += blockDim.x) {
