@@ -20,15 +20,7 @@
 #include <cstring>
 
 static const size_t MAZE_LDS_CHUNK_MAX = 50176;   // 256 columns x (64 rows x 3 + 4) bytes: three workgroups per 160-KiB CU
-static inline int maze_rc_threads(int W) { return W <= 64 ? 64 : (W <= 128 ? 128 : 256); }   // = columns of a pass
-// Rows mapping on frames of 256 columns and more: SIX waves share the workgroup's 80 KB of LDS (frame chunk of 256 columns, row
-// table, column table) instead of four — two workgroups per CU either way, so three waves per SIMD instead of two.  The two extra
-// waves only paint (they shadow a column through the per-column set-up and own none).
-#define MZ_ROWS_COLS 256
-#ifndef MZ_ROWS_THREADS
-#define MZ_ROWS_THREADS 768
-#endif
-#define MZ_RC_MAX_WAVES (MZ_ROWS_THREADS / 64)
+static inline int maze_rc_threads(int W) { return W <= 64 ? 64 : (W <= 128 ? 128 : 256); }
 #define MZ_TEX_PITCH 260   // 256 texels + 3 wrapped ones (+1 pad): the 4 y-taps of a filter row never wrap
 // Round 4: a second packed copy with PAIRS of filter rows interleaved — texel (x, y) at word ((x >> 1) * PITCH + y) * 2 +
 // (x & 1) — so that the four y-taps of rows 2m and 2m + 1 are 32 contiguous bytes and a 4 x 4 window lies in 2 (x even) or 3
@@ -908,7 +900,7 @@ __device__ __forceinline__ MzColumn mz_column_of_lane(const MzColumn& m, int src
 // SPREAD over the wave first: compacted into a per-wave list in LDS (each round the lanes that still hold an item append their
 // lowest one, ranked by a ballot), then item idx goes to lane idx % 64 — one round for up to 64 items.  What does not fit the list
 // stays on its lane (the loop behind the spread).
-#define MZ_REDO_LIST 80
+#define MZ_REDO_LIST 128
 #ifndef XV_MAZE_REDO_SPREAD
 #define XV_MAZE_REDO_SPREAD 1
 #endif
@@ -922,9 +914,6 @@ __device__ __forceinline__ MzColumn mz_column_of_lane(const MzColumn& m, int src
 // one is filtered.  That takes 206 registers, i.e. two waves per SIMD instead of three — and still wins: 0.925 -> 0.885 ms at
 // 64 x 64 (two pixels ahead, 241 registers: 0.90; three waves per SIMD with the 29 spills that forces: 1.04).  The rows mapping
 // does not take it: 10.40 -> 10.52 ms at 256 x 256, where issue is 86 % busy already (profiles/r06_zz*)
-#ifndef XV_MAZE_ROWS_SIX_WAVES
-#define XV_MAZE_ROWS_SIX_WAVES 1
-#endif
 #ifndef XV_MAZE_PREFETCH
 #define XV_MAZE_PREFETCH 1
 #endif
@@ -933,13 +922,13 @@ __device__ __forceinline__ MzColumn mz_column_of_lane(const MzColumn& m, int src
 #define XV_MAZE_RC_WAVES 3   // waves per SIMD the register allocation aims at (2: 1.12 ms at 64 x 64, same at 256 x 256)
 #endif
 template <bool FINAL, bool PACKED, int FILT, bool NB>
-__global__ __launch_bounds__((FILT >= 5 && PACKED) ? MZ_ROWS_THREADS : 256) __attribute__((amdgpu_waves_per_eu(MZ_RC_WAVES_OF(FILT, PACKED), MZ_RC_WAVES_OF(FILT, PACKED)))) void maze_raycast_kernel(MazeArgs P, uint8_t* frames, float* command_rgb) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MZ_RC_WAVES_OF(FILT, PACKED), MZ_RC_WAVES_OF(FILT, PACKED)))) void maze_raycast_kernel(MazeArgs P, uint8_t* frames, float* command_rgb) {
   using RT = typename std::conditional<NB, double, float>::type;
   constexpr bool F32 = FILT == 1 || FILT == 6, SPEC = (FILT == 0 || FILT == 3 || FILT == 5) && PACKED;
   constexpr bool PP = F32 || (SPEC && FILT == 0);   // which packed copy the pixels read
   constexpr bool ROWS = (FILT == 5 || FILT == 6) && PACKED;        // lanes = rows of one column in the pixel loop
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  __shared__ uint16_t redo_list[MZ_RC_MAX_WAVES][MZ_REDO_LIST];      // per wave: (lane | index << 6) of the pixels to re-run, see above
+  __shared__ uint16_t redo_list[4][MZ_REDO_LIST];      // per wave: (lane | index << 6) of the pixels to re-run, see above
   const int e = blockIdx.x;
   if (FINAL && !P.fin_flag[e]) return;   // block-uniform
   const int W = P.W, H = P.H, NG = P.NG;
@@ -974,11 +963,7 @@ __global__ __launch_bounds__((FILT >= 5 && PACKED) ? MZ_ROWS_THREADS : 256) __at
   uint8_t* dst = frames + (size_t)e * fsz;
   const int HC = P.HC, cstride = HC * 3 + 4;
   // per-row table {distance to the floor/ceiling point, light} (:182-186, :216-219): rows only, shared by all columns
-  // NC columns per pass: one per thread, except that the rows mapping may run more waves than columns / 64 (MZ_ROWS_THREADS)
-  const int NC = min((int)blockDim.x, MZ_ROWS_COLS);
-  const bool extra = (int)threadIdx.x >= NC;                       // a lane of the waves that own no column
-  const int tcol = (int)threadIdx.x % NC;                          // (it shadows this one)
-  double2* rowtab = reinterpret_cast<double2*>(lds + (((size_t)NC * cstride + 15) & ~(size_t)15));
+  double2* rowtab = reinterpret_cast<double2*>(lds + (((size_t)blockDim.x * cstride + 15) & ~(size_t)15));
   for (int d_v = threadIdx.x; d_v < H; d_v += blockDim.x) {
     const bool is_floor = d_v > H / 2;
     const double v_screen = is_floor ? (d_v + 0.5) * pixel_size - half_v : half_v - (d_v + 0.5) * pixel_size;
@@ -998,9 +983,9 @@ __global__ __launch_bounds__((FILT >= 5 && PACKED) ? MZ_ROWS_THREADS : 256) __at
   // It depends on the pose-free screen geometry only, so every lane derives it (no exchange).
   const double cmh = ceil_height - vision_height;
   const float cs_f = (float)cell_size;
-  for (int g0 = 0; g0 < W; g0 += NC) {
+  for (int g0 = 0; g0 < W; g0 += blockDim.x) {
     // lanes past the last column repeat it (no divergence); the flush below copies real columns only
-    const int d_h = min(g0 + tcol, W - 1);
+    const int d_h = min(g0 + (int)threadIdx.x, W - 1);
     // ---- per-column tables :170-177 (the reference accumulates tan_hp column by column) ----
     double tan_hp = (-0.5 - W / 2.0) * pixel_factor, tan_acc = tan_hp;
     for (int q = 0; q < W; ++q) { tan_acc += pixel_factor; if (q == d_h) tan_hp = tan_acc; }
@@ -1023,7 +1008,7 @@ __global__ __launch_bounds__((FILT >= 5 && PACKED) ? MZ_ROWS_THREADS : 256) __at
         if (!(distance > visibility)) { eff_stale = distance / (double)cos_last; found = true; }
       }
     }
-    uint8_t* col = lds + (size_t)tcol * cstride;
+    uint8_t* col = lds + (size_t)threadIdx.x * cstride;
     // ---- DDA_2D :47-115, in RT ----
     const int i0 = (int)(pos0 / cs_f), j0 = (int)(pos1 / cs_f);
     const RT cs_r = (RT)cell_size, eps_r = (RT)1.0e-8, vis_r = (RT)visibility, lf_r = (RT)l_focal;
@@ -1171,7 +1156,7 @@ __global__ __launch_bounds__((FILT >= 5 && PACKED) ? MZ_ROWS_THREADS : 256) __at
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the list is free again
     };
     MzColumn* colp = reinterpret_cast<MzColumn*>(rowtab + H);   // ROWS: the columns of this batch, behind the row table
-    if (ROWS && !extra) colp[threadIdx.x] = me;
+    if (ROWS) colp[threadIdx.x] = me;
     for (int c0 = 0; c0 < H; c0 += HC) {
       const int c1 = min(c0 + HC, H);
       // SPEC: blocks of 64 rows; the pixels whose byte the speculated filter could not settle are noted in `redo` and
@@ -1181,7 +1166,7 @@ __global__ __launch_bounds__((FILT >= 5 && PACKED) ? MZ_ROWS_THREADS : 256) __at
         // column read the same four texture rows, the rows of a ray's floor / ceiling pixels neighbouring texels
         __syncthreads();
         const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6, ln = threadIdx.x & 63;
-        const int ncols = min(NC, W - g0);
+        const int ncols = min((int)blockDim.x, W - g0);
         for (int r0 = c0; r0 < c1; r0 += 64) {
           const bool act = r0 + ln < c1;
           const int d_v = act ? r0 + ln : c1 - 1;
@@ -1350,7 +1335,7 @@ __global__ __launch_bounds__((FILT >= 5 && PACKED) ? MZ_ROWS_THREADS : 256) __at
         }
       }
       // ---- transparent landmark overlays, far to near :301-318 ----
-      for (int q = extra ? -1 : n_tr - 1; q >= 0; --q) {
+      for (int q = n_tr - 1; q >= 0; --q) {
         RT hd = 0;
         int lid = 0;
 #pragma unroll
@@ -1377,14 +1362,14 @@ __global__ __launch_bounds__((FILT >= 5 && PACKED) ? MZ_ROWS_THREADS : 256) __at
       // ---- command bar, maze_continuous_3d.py:23-29,102-107 (its x range is derived from H, as there) ----
       if (P.command_in_observation) {
         const int sx = (int)(0.25 * H), sy = (int)(0.10 * H), ex = (int)(0.25 * H + 0.50 * H), ey = (int)(0.10 * H + 0.05 * W);
-        if (!extra && d_h >= sx && d_h < ex)
+        if (d_h >= sx && d_h < ex)
           for (int y = max(sy, c0); y < ey && y < c1; ++y)
             for (int c = 0; c < 3; ++c) col[(y - c0) * 3 + c] = (uint8_t)(int)MZ_LANDMARK_RGB[cmd][c];
       }
       __syncthreads();
       // ---- chunk out: column k's rows [c0, c1) are (c1 - c0) * 3 contiguous bytes of the frame ----
       {
-        const int ncols = min(NC, W - g0), run = (c1 - c0) * 3;
+        const int ncols = min((int)blockDim.x, W - g0), run = (c1 - c0) * 3;
         uint8_t* gdst = dst + ((size_t)g0 * H + c0) * 3;
         if (((H * 3) & 15) == 0 && ((c0 * 3) & 15) == 0 && (run & 15) == 0) {
           const int vpr = run >> 4;
@@ -1552,9 +1537,8 @@ static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, b
   }
   const size_t lds_bytes = (((size_t)threads * (a.HC * 3 + 4) + 15) & ~(size_t)15) + (size_t)a.H * 16 +
                            (filt >= 5 ? (size_t)threads * sizeof(MzColumn) : 0);
-  const int launch_threads = (filt >= 5 && threads == MZ_ROWS_COLS && XV_MAZE_ROWS_SIX_WAVES) ? MZ_ROWS_THREADS : threads;
 #define MAZE_RC(F, K, Q, B) \
-  hipLaunchKernelGGL((maze_raycast_kernel<F, K, Q, B>), dim3(a.n_env), dim3(launch_threads), lds_bytes, h->eng->stream, a, frames, crgb)
+  hipLaunchKernelGGL((maze_raycast_kernel<F, K, Q, B>), dim3(a.n_env), dim3(threads), lds_bytes, h->eng->stream, a, frames, crgb)
 #define MAZE_RC2(F, K)                                                                  \
   do {                                                                                  \
     if (h->typing_numba) { if (filt == 1) MAZE_RC(F, K, 1, true); else if (filt == 2) MAZE_RC(F, K, 2, true);                          \
