@@ -284,6 +284,34 @@ def test_rows_mapping_of_the_ray_caster_paints_the_bytes_of_the_columns_mapping(
         assert np.array_equal(frames["columns"][k], frames["auto"][k])
 
 
+@pytest.mark.parametrize("res,per", [((64, 64), 200), ((128, 96), 40), ((256, 256), 8)])
+def test_the_three_window_fetches_of_the_exact_filter_paint_the_same_bytes(res, per, monkeypatch):
+    """XV_MAZE_FILT (a measurement switch read at every render): 0 = the pair-interleaved texture copy on the columns
+    mapping (prefetching pixel loop), 3 = the row-major copy on the columns mapping, 5 = the row-major copy on the rows mapping.
+    Same arithmetic per pixel, three different fetch paths and register allocations: the same frames, byte for byte."""
+    tasks = [load_maze_golden(p)[1] for p in FILES]
+    env_task = np.repeat(np.arange(len(tasks), dtype=np.int32), per)
+    n = len(env_task)
+    a = np.random.RandomState(17).randint(0, 16, (12, n)).astype(np.int32)
+    frames = {}
+    for filt in ("0", "3", "5"):
+        monkeypatch.setenv("XV_MAZE_FILT", filt)
+        env = MazeWorldVecEnv(n, resolution=res, textures=tex(), autoreset_mode="same_step", seed=5, command_in_observation=True)
+        env.set_task(tasks, env_task_index=env_task)
+        env.reset()
+        got = []
+        for t in range(12):
+            out = env.step(a[t])
+            if t in (5, 11):
+                got.append(_np(out[0]).copy())
+        frames[filt] = got
+        env.close()
+    monkeypatch.delenv("XV_MAZE_FILT")
+    for k in range(2):
+        assert np.array_equal(frames["0"][k], frames["3"][k]), int((frames["0"][k] != frames["3"][k]).sum())
+        assert np.array_equal(frames["0"][k], frames["5"][k]), int((frames["0"][k] != frames["5"][k]).sum())
+
+
 @pytest.mark.parametrize("mode,space", [("same_step", "Discrete16"), ("next_step", "Discrete32"), ("disabled", "Continuous"),
                                         ("same_step", "turns")])
 def test_nine_lane_move_kernel_equals_the_lane_per_env_kernel(mode, space):
