@@ -880,18 +880,18 @@ __global__ __launch_bounds__(256) void maze_tex_integral_kernel(const float* tex
 // What a column of the frame hands to its pixels (the wall the column's ray hit and the ray's direction): in registers when a
 // lane paints its own column, in LDS when the lanes of a wave paint the ROWS of one column (FILT 5 / 6)
 struct MzColumn {
-  int v_s, v_e, text_id, pad;                                       // wall rows [v_s, v_e), wall texture
-  double f_i, L, a_far, a_near, ratio, co, so, rcos_b, rcos_y, pad2;   // 96 bytes
+  int v_s, v_e, text_id, ti;                                        // wall rows [v_s, v_e), wall texture, its texel row (0 .. 255)
+  double L, a_far, a_near, ratio, co, so, rcos_b, rcos_y;             // 80 bytes
 };
 __device__ __forceinline__ double mz_shfl_f64(double v, int src) {
   return __hiloint2double(__shfl(__double2hiint(v), src), __shfl(__double2loint(v), src));
 }
 __device__ __forceinline__ MzColumn mz_column_of_lane(const MzColumn& m, int src) {   // all lanes of the wave call this
   MzColumn r;
-  r.v_s = __shfl(m.v_s, src); r.v_e = __shfl(m.v_e, src); r.text_id = __shfl(m.text_id, src); r.pad = 0;
-  r.f_i = mz_shfl_f64(m.f_i, src); r.L = mz_shfl_f64(m.L, src); r.a_far = mz_shfl_f64(m.a_far, src);
+  r.v_s = __shfl(m.v_s, src); r.v_e = __shfl(m.v_e, src); r.text_id = __shfl(m.text_id, src); r.ti = __shfl(m.ti, src);
+  r.L = mz_shfl_f64(m.L, src); r.a_far = mz_shfl_f64(m.a_far, src);
   r.a_near = mz_shfl_f64(m.a_near, src); r.ratio = mz_shfl_f64(m.ratio, src); r.co = mz_shfl_f64(m.co, src);
-  r.so = mz_shfl_f64(m.so, src); r.rcos_b = mz_shfl_f64(m.rcos_b, src); r.rcos_y = mz_shfl_f64(m.rcos_y, src); r.pad2 = 0.0;
+  r.so = mz_shfl_f64(m.so, src); r.rcos_b = mz_shfl_f64(m.rcos_b, src); r.rcos_y = mz_shfl_f64(m.rcos_y, src);
   return r;
 }
 // Pixels whose byte the speculated filter could not settle (about one in 100) are re-run in the reference's typing.  They sit
@@ -900,7 +900,7 @@ __device__ __forceinline__ MzColumn mz_column_of_lane(const MzColumn& m, int src
 // SPREAD over the wave first: compacted into a per-wave list in LDS (each round the lanes that still hold an item append their
 // lowest one, ranked by a ballot), then item idx goes to lane idx % 64 — one round for up to 64 items.  What does not fit the list
 // stays on its lane (the loop behind the spread).
-#define MZ_REDO_LIST 128
+#define MZ_REDO_LIST 64      // (4 waves x 64 x 2 B: with it the rows mapping's workgroup is 54,272 B, three to a CU)
 #ifndef XV_MAZE_REDO_SPREAD
 #define XV_MAZE_REDO_SPREAD 1
 #endif
@@ -914,6 +914,12 @@ __device__ __forceinline__ MzColumn mz_column_of_lane(const MzColumn& m, int src
 // one is filtered.  That takes 206 registers, i.e. two waves per SIMD instead of three — and still wins: 0.925 -> 0.885 ms at
 // 64 x 64 (two pixels ahead, 241 registers: 0.90; three waves per SIMD with the 29 spills that forces: 1.04).  The rows mapping
 // does not take it: 10.40 -> 10.52 ms at 256 x 256, where issue is 86 % busy already (profiles/r06_zz*)
+#ifndef XV_MAZE_ROWS_HALF
+#define XV_MAZE_ROWS_HALF 1
+#endif
+#ifndef XV_MAZE_ROWS_NSUB
+#define XV_MAZE_ROWS_NSUB 128
+#endif
 #ifndef XV_MAZE_PREFETCH
 #define XV_MAZE_PREFETCH 1
 #endif
@@ -963,7 +969,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MZ_RC_WAVES
   uint8_t* dst = frames + (size_t)e * fsz;
   const int HC = P.HC, cstride = HC * 3 + 4;
   // per-row table {distance to the floor/ceiling point, light} (:182-186, :216-219): rows only, shared by all columns
-  double2* rowtab = reinterpret_cast<double2*>(lds + (((size_t)blockDim.x * cstride + 15) & ~(size_t)15));
+  // rows mapping: the frame chunk holds NSUB columns at a time (the per-column table all of the pass's), see maze_launch_render
+  const int NSUB = ROWS ? P.NSUB : (int)blockDim.x;
+  double2* rowtab = reinterpret_cast<double2*>(lds + (((size_t)NSUB * cstride + 15) & ~(size_t)15));
   for (int d_v = threadIdx.x; d_v < H; d_v += blockDim.x) {
     const bool is_floor = d_v > H / 2;
     const double v_screen = is_floor ? (d_v + 0.5) * pixel_size - half_v : half_v - (d_v + 0.5) * pixel_size;
@@ -1086,8 +1094,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MZ_RC_WAVES
     // there is a single copy of the 16-tap filter.  Unpainted pixels keep FAR_RGB = 1 (:165-166).
     // what pixel d_v of the column shows: the texture, the filter position (f_i, f_j), the footprint f_d and the shading
     // v = L (A + B c) of its colour c
-    const MzColumn me = {v_s, v_e, text_id, 0, (double)wall_ti, (double)light_w, a_far_w, a_near_w, (double)ratio,
-                         (double)co, (double)so, R_cos.b, R_cos.y, 0.0};
+    const MzColumn me = {v_s, v_e, text_id, (int)wall_ti, (double)light_w, a_far_w, a_near_w, (double)ratio,
+                         (double)co, (double)so, R_cos.b, R_cos.y};
     auto pixel = [&](const MzColumn& C, int d_v, const void*& tx, double& f_i, double& f_j, double& f_d, double& L, double& A,
                      double& B) -> bool {
       bool paint = false;
@@ -1098,7 +1106,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MZ_RC_WAVES
         const double local_v = (half_v - (d_v + 0.5) * pixel_size) * C.ratio + vision_height;
         double d_j = local_v / text_size;
         d_j -= floor(d_j);
-        f_i = C.f_i;
+        f_i = (double)C.ti;
         f_j = (double)(int)(256 * d_j);
         paint = true;
       } else {
@@ -1161,23 +1169,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MZ_RC_WAVES
       const int c1 = min(c0 + HC, H);
       // SPEC: blocks of 64 rows; the pixels whose byte the speculated filter could not settle are noted in `redo` and
       // filtered in the reference's typing by a second loop (rare: the two filters never share a register allocation)
+      for (int h0 = 0; h0 < min((int)blockDim.x, W - g0); h0 += NSUB) {      // (one sub-pass unless the rows mapping splits the columns)
+      const int nsub = min(NSUB, min((int)blockDim.x, W - g0) - h0);
       if (ROWS) {
-        // the lanes of a wave paint 64 ROWS of one column at a time (wave w takes columns w, w + nw, ...): wall pixels of a
+        // the lanes of a wave paint 64 ROWS of one column at a time (wave w takes columns h0 + w, h0 + w + nw, ...): wall pixels of a
         // column read the same four texture rows, the rows of a ray's floor / ceiling pixels neighbouring texels
         __syncthreads();
         const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6, ln = threadIdx.x & 63;
-        const int ncols = min((int)blockDim.x, W - g0);
         for (int r0 = c0; r0 < c1; r0 += 64) {
           const bool act = r0 + ln < c1;
           const int d_v = act ? r0 + ln : c1 - 1;
           unsigned long long redo = 0ull;
           int k = 0;
-          for (int cc = wv; cc < ncols; cc += nw, ++k) {
-            const MzColumn C = colp[cc];
+          for (int cl = wv; cl < nsub; cl += nw, ++k) {
+            const MzColumn C = colp[h0 + cl];
             const void* tx;
             double f_i, f_j, f_d, L, A, B;
             const bool paint = pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B);
-            uint8_t* px = lds + (size_t)cc * cstride + (d_v - c0) * 3;
+            uint8_t* px = lds + (size_t)cl * cstride + (d_v - c0) * 3;
             uint8_t b0 = 1, b1 = 1, b2 = 1;
             if (paint) {
               double c[3];
@@ -1203,7 +1212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MZ_RC_WAVES
             redo_spread(redo, [&](int src_lane, int kk, bool have) {
               if (!have) return;
               const int dv2 = r0 + src_lane, cc = wv + kk * nw;      // (only lanes with a row of this block recorded items)
-              const MzColumn C = colp[cc];
+              const MzColumn C = colp[h0 + cc];
               const void* tx;
               double f_i, f_j, f_d, L, A, B, c[3];
               (void)pixel(C, dv2, tx, f_i, f_j, f_d, L, A, B);
@@ -1221,7 +1230,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MZ_RC_WAVES
               const int kk = __builtin_ctzll(redo);
               redo &= redo - 1ull;
               const int cc = wv + kk * nw;
-              const MzColumn C = colp[cc];
+              const MzColumn C = colp[h0 + cc];
               const void* tx;
               double f_i, f_j, f_d, L, A, B, c[3];
               (void)pixel(C, d_v, tx, f_i, f_j, f_d, L, A, B);
@@ -1334,8 +1343,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MZ_RC_WAVES
           }
         }
       }
+      // (rows mapping: the lanes whose column is in this sub-pass; its pixels are at column (thread - h0) of the chunk)
+      const bool mine = !ROWS || ((int)threadIdx.x >= h0 && (int)threadIdx.x < h0 + nsub);
+      uint8_t* ocol = ROWS ? lds + (size_t)(mine ? (int)threadIdx.x - h0 : 0) * cstride : col;
       // ---- transparent landmark overlays, far to near :301-318 ----
-      for (int q = n_tr - 1; q >= 0; --q) {
+      for (int q = mine ? n_tr - 1 : -1; q >= 0; --q) {
         RT hd = 0;
         int lid = 0;
 #pragma unroll
@@ -1353,7 +1365,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MZ_RC_WAVES
 #pragma unroll
         for (int c = 0; c < 3; ++c) tint[c] = (RT)0.30 * (((RT)1 - a2) * (RT)MZ_LANDMARK_RGB[lid][c] + a2 * (RT)1);
         for (int d_v = s2; d_v < e2; ++d_v) {
-          uint8_t* px = col + (d_v - c0) * 3;
+          uint8_t* px = ocol + (d_v - c0) * 3;
           px[0] = mz_clip_u8((1.0 - 0.30) * (double)px[0] + (double)tint[0]);
           px[1] = mz_clip_u8((1.0 - 0.30) * (double)px[1] + (double)tint[1]);
           px[2] = mz_clip_u8((1.0 - 0.30) * (double)px[2] + (double)tint[2]);
@@ -1362,15 +1374,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MZ_RC_WAVES
       // ---- command bar, maze_continuous_3d.py:23-29,102-107 (its x range is derived from H, as there) ----
       if (P.command_in_observation) {
         const int sx = (int)(0.25 * H), sy = (int)(0.10 * H), ex = (int)(0.25 * H + 0.50 * H), ey = (int)(0.10 * H + 0.05 * W);
-        if (d_h >= sx && d_h < ex)
+        if (mine && d_h >= sx && d_h < ex)
           for (int y = max(sy, c0); y < ey && y < c1; ++y)
-            for (int c = 0; c < 3; ++c) col[(y - c0) * 3 + c] = (uint8_t)(int)MZ_LANDMARK_RGB[cmd][c];
+            for (int c = 0; c < 3; ++c) ocol[(y - c0) * 3 + c] = (uint8_t)(int)MZ_LANDMARK_RGB[cmd][c];
       }
       __syncthreads();
       // ---- chunk out: column k's rows [c0, c1) are (c1 - c0) * 3 contiguous bytes of the frame ----
       {
-        const int ncols = min((int)blockDim.x, W - g0), run = (c1 - c0) * 3;
-        uint8_t* gdst = dst + ((size_t)g0 * H + c0) * 3;
+        const int ncols = nsub, run = (c1 - c0) * 3;
+        uint8_t* gdst = dst + ((size_t)(g0 + h0) * H + c0) * 3;
         if (((H * 3) & 15) == 0 && ((c0 * 3) & 15) == 0 && (run & 15) == 0) {
           const int vpr = run >> 4;
           for (int k = threadIdx.x; k < ncols * vpr; k += blockDim.x) {
@@ -1393,6 +1405,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MZ_RC_WAVES
         }
       }
       __syncthreads();
+      }      // h0
     }
   }
   if (command_rgb && threadIdx.x < 3) command_rgb[(size_t)e * 3 + threadIdx.x] = MZ_LANDMARK_RGB[cmd][threadIdx.x];
@@ -1535,10 +1548,14 @@ static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, b
     const int f = atoi(getenv("XV_MAZE_FILT"));
     if (f == 0 || f == 3 || f == 5) filt = f;
   }
-  const size_t lds_bytes = (((size_t)threads * (a.HC * 3 + 4) + 15) & ~(size_t)15) + (size_t)a.H * 16 +
+  // Rows mapping on passes of 256 columns: the frame chunk holds HALF the columns at a time (two sub-passes per 64-row chunk, the
+  // per-column table stays whole) — 54,272 instead of 79,872 B of LDS per workgroup, i.e. three workgroups per CU instead of two
+  MazeArgs ka = a;
+  ka.NSUB = (filt >= 5 && threads == 256 && XV_MAZE_ROWS_HALF) ? XV_MAZE_ROWS_NSUB : threads;
+  const size_t lds_bytes = (((size_t)ka.NSUB * (a.HC * 3 + 4) + 15) & ~(size_t)15) + (size_t)a.H * 16 +
                            (filt >= 5 ? (size_t)threads * sizeof(MzColumn) : 0);
 #define MAZE_RC(F, K, Q, B) \
-  hipLaunchKernelGGL((maze_raycast_kernel<F, K, Q, B>), dim3(a.n_env), dim3(threads), lds_bytes, h->eng->stream, a, frames, crgb)
+  hipLaunchKernelGGL((maze_raycast_kernel<F, K, Q, B>), dim3(a.n_env), dim3(threads), lds_bytes, h->eng->stream, ka, frames, crgb)
 #define MAZE_RC2(F, K)                                                                  \
   do {                                                                                  \
     if (h->typing_numba) { if (filt == 1) MAZE_RC(F, K, 1, true); else if (filt == 2) MAZE_RC(F, K, 2, true);                          \

@@ -21,6 +21,7 @@ struct MazeArgs {
   uint8_t* need_reset;
   double* collision;
   int HC;   // rows per LDS chunk of the ray-caster
+  int NSUB; // columns of that chunk (rows mapping; set per launch by maze_launch_render)
   // packed RGBX-byte copies of the texture libraries ([n][256][MZ_TEX_PITCH] uint32), nullptr if not integral
   const uint32_t* pk_walls;
   const uint32_t* pk_grounds;
