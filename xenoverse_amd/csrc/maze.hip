@@ -900,7 +900,7 @@ __device__ __forceinline__ MzColumn mz_column_of_lane(const MzColumn& m, int src
 // SPREAD over the wave first: compacted into a per-wave list in LDS (each round the lanes that still hold an item append their
 // lowest one, ranked by a ballot), then item idx goes to lane idx % 64 — one round for up to 64 items.  What does not fit the list
 // stays on its lane (the loop behind the spread).
-#define MZ_REDO_LIST 64      // (4 waves x 64 x 2 B: with it the rows mapping's workgroup is 54,272 B, three to a CU)
+#define MZ_REDO_LIST 64      // (items of a block beyond it stay on their lanes; 4 waves x 64 x 2 B of LDS)
 #ifndef XV_MAZE_REDO_SPREAD
 #define XV_MAZE_REDO_SPREAD 1
 #endif
@@ -1549,7 +1549,10 @@ static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, b
     if (f == 0 || f == 3 || f == 5) filt = f;
   }
   // Rows mapping on passes of 256 columns: the frame chunk holds HALF the columns at a time (two sub-passes per 64-row chunk, the
-  // per-column table stays whole) — 54,272 instead of 79,872 B of LDS per workgroup, i.e. three workgroups per CU instead of two
+  // per-column table stays whole) — 50,176 instead of 79,872 B of LDS per workgroup, i.e. three workgroups per CU instead of two:
+  // 10.40 -> 9.70 ms per 16,384 frames of 256 x 256 (2.8 instead of 1.9 waves per SIMD, issue 92 % busy).  At 54,272 B (the
+  // per-column table at its former 96 bytes) the third workgroup does not become resident; 112 / 96 / 64 columns per sub-pass:
+  // 10.10 / 10.13 / 10.30 ms (profiles/r06_zz17_*)
   MazeArgs ka = a;
   ka.NSUB = (filt >= 5 && threads == 256 && XV_MAZE_ROWS_HALF) ? XV_MAZE_ROWS_NSUB : threads;
   const size_t lds_bytes = (((size_t)ka.NSUB * (a.HC * 3 + 4) + 15) & ~(size_t)15) + (size_t)a.H * 16 +
