@@ -712,10 +712,10 @@ int xv_maze_set_move_kernel(xv_maze* h, int kernel);
                                           speculates in float64 sums and re-runs a pixel whose byte is not certain) */
 int xv_maze_set_precision(xv_maze* h, int filter);
 /* Which lanes paint which pixels in the ray caster (same bytes either way).  COLUMNS: a lane paints its column top to bottom.
- * ROWS: per batch of columns the lanes first work out what each column hands its pixels (wall hit, ray direction; 96 bytes per
+ * ROWS: per batch of columns the lanes first work out what each column hands its pixels (wall hit, ray direction; 80 bytes per
  * column in LDS), then every wave paints 64 rows of one column at a time — wall pixels of a column share their four texture
- * rows, so the texture path sees fewer distinct lines per load.  AUTO (default): ROWS for the fp32 filter and for the exact
- * filter on frames beyond 128 x 128, COLUMNS otherwise.  Packed (integer-valued) texture libraries only. */
+ * rows, so the texture path sees fewer distinct lines per load.  AUTO (default): ROWS on packed (integer-valued) texture
+ * libraries, COLUMNS otherwise (float-valued textures take the general path, which has no ROWS form). */
 #define XV_MAZE_MAP_AUTO 0
 #define XV_MAZE_MAP_COLUMNS 1
 #define XV_MAZE_MAP_ROWS 2

@@ -628,7 +628,7 @@ def quick_families(steps=200, warmup=20):
                 # the ray caster (90 % of the step) is bound by fp64 VALU issue and texture requests — the 16-tap filter with the
                 # reference's bytes — not by HBM: `bound` / `frac` are that kernel's; the HBM view of the same step is kept beside it
                 "roofline": dict(_maze_valu_roofline(r),
-                                 kernel="maze_raycast_kernel (exact filter, speculated with float32 colour sums; + maze_step9_kernel for the move)",
+                                 kernel="maze_raycast_kernel (exact filter, speculated with float32 colour sums, rows of a column per wave; + maze_step9_kernel for the move)",
                                  hbm={"frac": r["roofline"]["frac"], "algorithmic_bytes": (3 * 64 * 64 + 64) * 16384, "peak": HBM_PEAK,
                                       "unit": "GB/s", "achieved": r["roofline"]["achieved"]},
                                  note=r["roofline"]["note"])}

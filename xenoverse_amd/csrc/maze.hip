@@ -917,9 +917,6 @@ __device__ __forceinline__ MzColumn mz_column_of_lane(const MzColumn& m, int src
 #ifndef XV_MAZE_ROWS_HALF
 #define XV_MAZE_ROWS_HALF 1
 #endif
-#ifndef XV_MAZE_ROWS_NSUB
-#define XV_MAZE_ROWS_NSUB 128
-#endif
 #ifndef XV_MAZE_PREFETCH
 #define XV_MAZE_PREFETCH 1
 #endif
@@ -1535,26 +1532,29 @@ extern "C" int xv_maze_destroy(xv_maze* h) {
 static int maze_launch_render(xv_maze* h, uint8_t* frames, float* command_rgb, bool final) {
   const MazeArgs& a = h->a;
   const int threads = maze_rc_threads(a.W);
-  // which lanes paint what (xv_maze_set_raycast_mapping): AUTO = rows of a column for the fp32 filter and for the exact filter on
-  // frames beyond 128 x 128 (scripts/runs_r04/gpu_rows.sh: fp32 1.05 -> 0.90 ms at 64 x 64, 11.6 -> 10.8 ms at 256 x 256; exact
-  // 14.1 -> 13.4 ms at 256 x 256, but 1.08 -> 1.19 ms at 64 x 64, where it stays on columns)
+  // which lanes paint what (xv_maze_set_raycast_mapping): AUTO = rows of a column on packed textures, fp32 and exact filter, every
+  // frame size (round 4: exact 14.1 -> 13.4 ms at 256 x 256 but 1.08 -> 1.19 ms at 64 x 64, which stayed on columns until the
+  // half-pass chunk gave the rows mapping its third wave per SIMD — round 6, 16,384 frames, columns (pair copy, prefetch) against
+  // rows: 32 x 32 0.466 / 0.409 ms, 64 x 64 0.895 / 0.81, 96 x 96 2.27 / 2.23, 128 x 128 3.48 / 3.34, 192 x 192 8.14 / 5.74:
+  // profiles/r06_zz27_*)
   const int rows_map = h->raycast_mapping == XV_MAZE_MAP_COLUMNS ? 0 : (h->raycast_mapping == XV_MAZE_MAP_ROWS ? 3 : 2);
   float* crgb = final ? nullptr : command_rgb;
   const bool packed = a.pk_walls != nullptr;
   // FILT of the kernel: 0 / 3 the speculated exact filter on the pair / row-major texture copy, 1 fp32, 2 direct, 5 / 6 = 3 / 1 on rows
   const int filt0 = h->filter != XV_MAZE_FILTER_EXACT ? h->filter : (packed && (size_t)a.W * a.H > 128 * 128 ? 3 : 0);
-  int filt = !packed || !rows_map ? filt0 : (filt0 == 1 ? 6 : ((filt0 == 3 || (filt0 == 0 && rows_map == 3)) ? 5 : filt0));
+  int filt = !packed || !rows_map ? filt0 : (filt0 == 1 ? 6 : ((filt0 == 3 || filt0 == 0) ? 5 : filt0));
   if (packed && h->filter == XV_MAZE_FILTER_EXACT && getenv("XV_MAZE_FILT")) {      // devtools A/B: 0 / 3 / 5, all the same bytes
     const int f = atoi(getenv("XV_MAZE_FILT"));
     if (f == 0 || f == 3 || f == 5) filt = f;
   }
-  // Rows mapping on passes of 256 columns: the frame chunk holds HALF the columns at a time (two sub-passes per 64-row chunk, the
-  // per-column table stays whole) — 50,176 instead of 79,872 B of LDS per workgroup, i.e. three workgroups per CU instead of two:
-  // 10.40 -> 9.70 ms per 16,384 frames of 256 x 256 (2.8 instead of 1.9 waves per SIMD, issue 92 % busy).  At 54,272 B (the
-  // per-column table at its former 96 bytes) the third workgroup does not become resident; 112 / 96 / 64 columns per sub-pass:
-  // 10.10 / 10.13 / 10.30 ms (profiles/r06_zz17_*)
+  // Rows mapping: the frame chunk holds HALF the pass's columns at a time (two sub-passes per 64-row chunk, the per-column table
+  // stays whole), which is what lets a THIRD wave per SIMD be resident: at 256 columns 50,176 instead of 79,872 B of LDS per
+  // workgroup (three workgroups per CU instead of two: 10.40 -> 9.70 ms per 16,384 frames of 256 x 256, 2.8 instead of 1.9 waves
+  // per SIMD, issue 92 % busy; at 54,272 B — the per-column table at its former 96 bytes — the third workgroup does not become
+  // resident; 112 / 96 / 64 columns per sub-pass: 10.10 / 10.13 / 10.30 ms, profiles/r06_zz17_*), at 64 columns 12.9 instead of
+  // 19 KB per one-wave workgroup (0.885 -> 0.805 ms at 64 x 64, profiles/r06_zz26_*)
   MazeArgs ka = a;
-  ka.NSUB = (filt >= 5 && threads == 256 && XV_MAZE_ROWS_HALF) ? XV_MAZE_ROWS_NSUB : threads;
+  ka.NSUB = (filt >= 5 && XV_MAZE_ROWS_HALF) ? threads / 2 : threads;
   const size_t lds_bytes = (((size_t)ka.NSUB * (a.HC * 3 + 4) + 15) & ~(size_t)15) + (size_t)a.H * 16 +
                            (filt >= 5 ? (size_t)threads * sizeof(MzColumn) : 0);
 #define MAZE_RC(F, K, Q, B) \
