@@ -777,7 +777,10 @@ def maze_valu_per_pixel(tag, res, n):
     if tag is None:
         return None, None
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for f in sorted(glob.glob(os.path.join(root, "profiles", "*pmc_raycast_%s_%d.json" % (tag, res))), reverse=True):
+    def visit_order(path):      # r06_m < r06_zz5 < r06_zz28: numbers compare as numbers (a plain sort puts zz5 behind zz28)
+        import re
+        return [int(t) if t.isdigit() else t for t in re.findall(r"\d+|\D+", os.path.basename(path))]
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "*pmc_raycast_%s_%d.json" % (tag, res))), key=visit_order, reverse=True):
         try:
             d = json.load(open(f))
             for name, v in d["kernels"].items():

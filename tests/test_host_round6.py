@@ -3,6 +3,7 @@
 import glob
 import json
 import os
+import sys
 
 import bench
 
@@ -107,3 +108,26 @@ def test_the_trampoline_is_optional(monkeypatch):
     assert _lib.fast() is None                      # the ctypes path serves
     monkeypatch.delenv("XV_NO_FAST")
     _lib._fast[0], _lib._fast[1] = None, False
+
+
+def test_the_maze_roofline_prices_the_newest_committed_counters(tmp_path, monkeypatch):
+    """bench_families.maze_valu_per_pixel: the newest counter profile of a filter and resolution by VISIT order (r06_m < r06_zz5 <
+    r06_zz28 — a plain string sort puts zz5 behind zz28 and priced the 64 x 64 line with a kernel that no longer ran), and the
+    committed ones belong to the kernel AUTO launches (the rows mapping, FILT 5)"""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import bench_families as bf
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (tmp_path / "scripts").mkdir()
+    for name, valu in (("r06_m", 100.0), ("r06_zz5", 200.0), ("r06_zz28", 300.0)):
+        (prof / ("%s_pmc_raycast_spec32_64.json" % name)).write_text(json.dumps(
+            {"kernels": {"void maze_raycast_kernel<false, true, 5, false>": {"SQ_INSTS_VALU": valu}}}))
+    monkeypatch.setattr(bf.os.path, "abspath", lambda p: str(tmp_path / "scripts" / "bench_families.py"))
+    v, src = bf.maze_valu_per_pixel("spec32", 64, 16384)
+    assert src == "r06_zz28_pmc_raycast_spec32_64.json" and abs(v - 300.0 * 64 / (64 * 64 * 16384)) < 1e-12
+    monkeypatch.undo()
+    for res in (64, 256):
+        v, src = bf.maze_valu_per_pixel("spec32", res, 16384)
+        d = json.load(open(os.path.join(ROOT, "profiles", src)))
+        assert any("maze_raycast_kernel<false, true, 5, false>" in k for k in d["kernels"]), (res, src)
+        assert 250.0 < v < 420.0
